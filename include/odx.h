@@ -1,0 +1,175 @@
+/*
+ * odx.h — C ABI of libodx.so: the MI355X (gfx950) hot path of hsp-iit/online-detection.
+ *
+ * The reference has no FFI of its own: it is pure Python and reaches this arithmetic
+ * through third-party packages (falkon, torch/cuBLAS/cuSOLVER, maskrcnn_benchmark CUDA
+ * ops).  Each entry point below names the reference call site it stands in for
+ * (paths relative to the reference root).  Conventions, all functions:
+ *   - extern "C", return int: 0 = ok, <0 = error (odx_last_error_string() has the text);
+ *   - raw DEVICE pointers, element counts, leading dimensions in ELEMENTS, row-major;
+ *   - asynchronous on `stream` (a hipStream_t passed as void*); no allocation, no sync;
+ *     workspace sizes come from the *_workspace_bytes twins;
+ *   - one host thread per device.
+ * Precision policy: the n x M Gaussian block K_nM is formed and stored in
+ * f32 (f32-input MFMA, exact fmaf chain); everything M x M and every M-vector, including
+ * the accumulations inside the K_nM passes, is f64.
+ */
+#ifndef ODX_H
+#define ODX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ODX_OK 0
+#define ODX_ERR_INVALID (-1)     /* bad argument (shape, alignment, null pointer) */
+#define ODX_ERR_HIP (-2)         /* a HIP runtime call / launch failed */
+#define ODX_ERR_UNSUPPORTED (-3) /* size outside what the kernels are built for */
+#define ODX_ERR_WORKSPACE (-4)   /* workspace too small */
+
+typedef void* odx_stream_t;
+
+const char* odx_last_error_string(void);
+int odx_version(void);
+/* number of compute units of the current device (grid sizing for persistent kernels) */
+int odx_device_cus(void);
+
+/* ---------------------------------------------------------------- A3: Gaussian kernel
+ * falkon.kernels.GaussianKernel(sigma) as built at
+ * src/modules/region-classifier/FALKONWrapper_with_centers_selection_incore.py:50 and
+ * applied inside InCoreFalkon.fit (:68):  K_ij = exp(-||x_i - z_j||^2 / (2 sigma^2)).   */
+
+/* out[i] = sum_d X[i,d]^2 (f32 fmaf chain).  ldx % 4 == 0. */
+int odx_row_sqnorm_f32(const float* X, int64_t ldx, int64_t n, int D, float* out, odx_stream_t stream);
+
+/* K (n x M, ldk % 4 == 0) = gauss(X (n x D), Z (M x D)); xsq/zsq from odx_row_sqnorm_f32.
+ * Columns [M, ldk) of K are written as 0.  ldx % 4 == 0, ldz % 4 == 0. */
+int odx_gauss_knm_f32(const float* X, int64_t ldx, const float* xsq, int64_t n,
+                      const float* Z, int64_t ldz, const float* zsq, int64_t M, int D,
+                      double sigma, float* K, int64_t ldk, odx_stream_t stream);
+
+/* ---------------------------------------------------------------- A5 / A9: scoring
+ * model.predict(X) = K(X, ny_points_) @ alpha_
+ *   (FALKONWrapper_with_centers_selection_incore.py:75-82) and the batched multi-class
+ * kernel.mmv(features, nystrom_parallel, alpha_parallel) of the test-time heads
+ *   (mrcnn_modified/modeling/roi_heads/box_head/roi_box_predictors.py:140-160,
+ *    mrcnn_modified/modeling/rpn/rpn.py:201-227,
+ *    mrcnn_modified/modeling/roi_heads/mask_head/roi_mask_predictors.py:72-99).
+ * V (Mtot x T, f64, ldv) plays alpha_ / alpha_parallel.  Its block structure is passed as
+ * per-column row ranges: ranges[2c], ranges[2c+1] (DEVICE int32) bound the rows of V that
+ * are non-zero in column c, and out[i, c] = sum_{j in range c} K_ij V[j, c]  (f64 accumulate,
+ * rounded once to f32).  A dense V is the special case range = [0, Mtot) for every column.
+ * K is never stored.                                                                      */
+int odx_gauss_mmv_f32(const float* X, int64_t ldx, const float* xsq, int64_t n,
+                      const float* Z, int64_t ldz, const float* zsq, int D, double sigma,
+                      const double* V, int64_t ldv, const int32_t* ranges, int T,
+                      float* out, int64_t ldo, odx_stream_t stream);
+
+/* ---------------------------------------------------------------- A4: CG pass on stored K
+ * falkon's incore_fdmmv on the stored K_nM (selected by store_kernel_d_threshold=250,
+ * FALKONWrapper_with_centers_selection_incore.py:56):  out = K' (K v + w)  for one shard
+ * of rows.  K (n x M) f32; v (M) f64 or NULL; w (n) f64 or NULL; out (M) f64.
+ * One read of K per call.  Deterministic (fixed-order slab reduction).                  */
+int64_t odx_knm_fwd_bwd_workspace_bytes(int64_t n, int64_t M);
+int odx_knm_fwd_bwd(const float* K, int64_t ldk, int64_t n, int64_t M,
+                    const double* v, const double* w, double* out,
+                    void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+
+/* ---------------------------------------------------------------- A4: preconditioner (f64)
+ * FalkonPreconditioner.init as run by InCoreFalkon.fit with min_cuda_pc_size_*=0
+ * (FALKONWrapper_with_centers_selection_incore.py:56):
+ *   L_T = chol_lower(K_MM + eps*M*I) (T = L_T'),  L_A = chol_lower(T T'/M + lam*I) (A = L_A'),
+ * and their explicit inverses so that the four triangular solves of a CG iteration are
+ * row-dot matrix-vector products.
+ * Outputs, all M x M f64 row-major with leading dimension ld (ld % 2 == 0, ld >= M):
+ *   LTi  = L_T^-1 (lower)   => T^-T v = LTi v
+ *   LTit = L_T^-T (upper)   => T^-1 v = LTit v
+ *   LAi, LAit likewise for A.
+ * Z (M x D) f32 centres.  info (device int32): 0 or index+1 of the first non-positive pivot. */
+int64_t odx_falkon_precond_workspace_bytes(int64_t M, int D);
+int odx_falkon_precond_f64(const float* Z, int64_t ldz, int64_t M, int D, double sigma,
+                           double lam, double eps, double* LTi, double* LTit, double* LAi,
+                           double* LAit, int64_t ld, int32_t* info,
+                           void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+
+/* y = op(Tri) x for a triangular M x M f64 matrix, rows as dot products.
+ * uplo: 0 = lower (uses columns j <= i), 1 = upper (j >= i).
+ * y = alpha * Tri x + beta * z  (z may be NULL when beta == 0; y may alias z).          */
+int odx_trmv_f64(const double* Tri, int64_t ld, int64_t M, int uplo, const double* x,
+                 double alpha, double beta, const double* z, double* y, odx_stream_t stream);
+
+/* ---------------------------------------------------------------- A4: CG vector updates
+ * falkon ConjugateGradient.solve inner step for ONE right-hand side, all f64, length M,
+ * scalars kept on device (state[0]=rs_old, state[1]=rs_new, state[2]=stop flag as double):
+ *   odx_cg_init  : R = B; P = B; X = 0; rs_old = R.R
+ *   odx_cg_step  : a = rs_old / (P.AP + cg_eps); X += a P;
+ *                  if (!full_grad) R -= a AP;            (full_grad: caller recomputes R)
+ *   odx_cg_finish: rs_new = R.R; stop |= sqrt(rs_new) < tol; P = R + (rs_new/(rs_old+cg_eps)) P;
+ *                  rs_old = rs_new
+ * Every kernel is a no-op once the stop flag is set (device-side early exit, no host sync). */
+int odx_cg_init(const double* B, double* X, double* R, double* P, double* state, int64_t M,
+                odx_stream_t stream);
+int odx_cg_step(double* X, double* R, const double* P, const double* AP, double* state,
+                double cg_eps, int full_grad, int64_t M, odx_stream_t stream);
+int odx_cg_finish(const double* R, double* P, double* state, double cg_eps, double tol,
+                  int64_t M, odx_stream_t stream);
+/* y = a*x + b*y (f64), used for R = B - mmv(X) */
+int odx_axpby_f64(double a, const double* x, double b, double* y, int64_t M, odx_stream_t stream);
+
+/* ---------------------------------------------------------------- dense f64 building blocks
+ * (exported for the parity tests and for the RLS path)                                   */
+/* C (m x n) = alpha * A (m x k) B' (n x k) + beta * C ; flags below */
+#define ODX_GEMM_LOWER_ONLY 1   /* skip output tiles strictly above the diagonal */
+#define ODX_GEMM_A_UPPER 2      /* A[i,k] == 0 for k < i  */
+#define ODX_GEMM_B_UPPER 4      /* B[j,k] == 0 for k < j  */
+#define ODX_GEMM_A_LOWER 8      /* A[i,k] == 0 for k > i  */
+#define ODX_GEMM_B_LOWER 16     /* B[j,k] == 0 for k > j  */
+#define ODX_GEMM_STORE_T 32     /* store C transposed: Ct[j,i] (ldc applies to Ct) */
+int odx_gemm_nt_f64(const double* A, int64_t lda, const double* B, int64_t ldb, double* C,
+                    int64_t ldc, int64_t m, int64_t n, int64_t k, double alpha, double beta,
+                    int flags, odx_stream_t stream);
+int odx_gemm_nt_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                    int64_t ldc, int64_t m, int64_t n, int64_t k, float alpha, float beta,
+                    int flags, odx_stream_t stream);
+/* in-place lower Cholesky of the lower triangle of A (M x M, f64); strict upper is zeroed.
+ * Also returns the inverses of the nb x nb diagonal blocks if Dinv != NULL.             */
+int64_t odx_potrf_workspace_bytes(int64_t M);
+int odx_potrf_f64(double* A, int64_t lda, int64_t M, int32_t* info, void* workspace,
+                  int64_t workspace_bytes, odx_stream_t stream);
+/* Li = L^-1 (lower), Lit = L^-T (upper) from a lower-triangular L (strict upper == 0). */
+int64_t odx_trtri_workspace_bytes(int64_t M);
+int odx_trtri_f64(const double* L, int64_t ldl, int64_t M, double* Li, double* Lit, int64_t ld,
+                  void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+int odx_convert_f32_f64(const float* src, int64_t lds, double* dst, int64_t ldd, int64_t rows,
+                        int64_t cols, odx_stream_t stream);
+int odx_convert_f64_f32(const double* src, int64_t lds, float* dst, int64_t ldd, int64_t rows,
+                        int64_t cols, odx_stream_t stream);
+
+/* ---------------------------------------------------------------- A7: RLS box regressors
+ * RegionRefinerTrainer.train / solve
+ * (src/modules/region-refiner/region_refiner_trainer/train_region_refiner.py:25-119):
+ * per class, f64:  G = [X 1]' [X 1] + lam I,  R = chol(G),  w_k = R^-T R^-1 [X 1]' y_k.
+ * Step 1 (per row shard): gather rows idx[0..nc) of X (f32, n x D), append the bias column,
+ *   cast to f64 and accumulate  G (D1 x D1, lower, D1 = D + 1)  and  XtY (4 x D1)  with
+ *   Yt (4 x nc) f64 already whitened by the caller.  G and XtY are ACCUMULATED INTO
+ *   (beta = 1) so shards / chunks can be summed (and all-reduced) before step 2.
+ * Step 2: add lam to the diagonal, Cholesky, 4 right-hand sides -> W (4 x D1).           */
+int64_t odx_rls_gram_workspace_bytes(int64_t nc, int D);
+int odx_rls_gram_f64(const float* X, int64_t ldx, int D, const int64_t* idx, int64_t nc,
+                     const double* Yt, int64_t ldy, double* G, int64_t ldg, double* XtY,
+                     int64_t ldxy, void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+int64_t odx_rls_solve_workspace_bytes(int D);
+int odx_rls_solve_f64(double* G, int64_t ldg, int D, double lam, const double* XtY, int64_t ldxy,
+                      double* W, int64_t ldw, int32_t* info, void* workspace,
+                      int64_t workspace_bytes, odx_stream_t stream);
+
+/* P (nc x 4, ldp) = [X[idx] 1] W'  (f64 accumulate; idx may be NULL = identity): the training
+ * residuals behind the per-sample 'losses' of train_region_refiner.py:116, and the f64 form
+ * of the apply  F W[:-1] + W[-1]  of predict_regions.py:45-46.                              */
+int odx_rls_predict_rows_f64(const float* X, int64_t ldx, int D, const int64_t* idx, int64_t nc,
+                             const double* W, int64_t ldw, double* P, int64_t ldp, odx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODX_H */

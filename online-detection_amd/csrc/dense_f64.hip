@@ -1,0 +1,457 @@
+// f64 dense linear algebra of the FALKON preconditioner (and the RLS solve) on gfx950:
+// blocked Cholesky, triangular inverse, transposes, triangular matrix-vector products.
+// The O(M^3) work runs as NT GEMMs on v_mfma_f64_16x16x4_f64 (gemm.hip); only the 128 x 128
+// diagonal blocks are factored / inverted by a single workgroup inside LDS.
+#include "odx_internal.h"
+
+namespace odx {
+
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------- diagonal block: chol + inverse
+// One 1024-thread workgroup.  A (jb x jb, lower part read) -> L in place (strict upper zeroed),
+// Dinv (NB x NB, ld NB) = L^-1 (lower, zero elsewhere).  Rows/cols >= jb are padded with the
+// identity so the loops are uniform.
+template <int NB>
+__global__ __launch_bounds__(1024) void potrf_diag_kernel(double* __restrict__ A, int64_t lda, int jb,
+                                                          double* __restrict__ Dinv, int32_t* __restrict__ info,
+                                                          int info_base) {
+  constexpr int LD = NB + 1;
+  __shared__ double s[NB * LD];
+  const int tid = threadIdx.x;
+  const int tx = tid & 31, ty = tid >> 5;  // 32 x 32
+  for (int e = tid; e < NB * NB; e += 1024) {
+    const int i = e / NB, j = e % NB;
+    double v = 0.0;
+    if (i < jb && j <= i) v = A[(int64_t)i * lda + j];
+    else if (i == j) v = 1.0;
+    s[i * LD + j] = v;
+  }
+  for (int j = 0; j < NB; ++j) {
+    __syncthreads();
+    double d = s[j * LD + j];
+    if (!(d > 0.0)) {
+      if (tid == 0 && j < jb && *info == 0) *info = info_base + j + 1;
+      d = 1.0;
+    }
+    const double dj = sqrt(d);
+    const double inv = 1.0 / dj;
+    __syncthreads();
+    if (tid == 0) s[j * LD + j] = dj;
+    for (int i = j + 1 + tid; i < NB; i += 1024) s[i * LD + j] *= inv;
+    __syncthreads();
+    // trailing update of the lower triangle: s[i][k] -= s[i][j] * s[k][j], j < k <= i
+    for (int i = j + 1 + ty; i < NB; i += 32) {
+      const double lij = s[i * LD + j];
+      for (int k = j + 1 + tx; k <= i; k += 32) s[i * LD + k] -= lij * s[k * LD + j];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < jb * jb; e += 1024) {
+    const int i = e / jb, j = e % jb;
+    A[(int64_t)i * lda + j] = (j <= i) ? s[i * LD + j] : 0.0;
+  }
+  // in-place inverse of the lower-triangular factor, last column first:
+  //   X[j][j] = 1 / L[j][j];  X[i][j] = -X[j][j] * sum_{k=j+1..i} X[i][k] L[k][j]   (i > j)
+  // 8 lanes share one row i and split the k range.
+  const int row = tid >> 3, part = tid & 7;
+  for (int j = NB - 1; j >= 0; --j) {
+    __syncthreads();
+    const double xjj = 1.0 / s[j * LD + j];
+    double y = 0.0;
+    if (row > j) {
+      for (int k = j + 1 + part; k <= row; k += 8) y = fma(s[row * LD + k], s[k * LD + j], y);
+    }
+    y += __shfl_xor(y, 1);
+    y += __shfl_xor(y, 2);
+    y += __shfl_xor(y, 4);
+    __syncthreads();
+    if (part == 0) {
+      if (row > j) s[row * LD + j] = -xjj * y;
+      else if (row == j) s[j * LD + j] = xjj;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < NB * NB; e += 1024) {
+    const int i = e / NB, j = e % NB;
+    Dinv[e] = (i < jb && j <= i) ? s[i * LD + j] : 0.0;
+  }
+}
+
+// ---------------------------------------------------------------- small utility kernels
+__global__ __launch_bounds__(256) void transpose_f64_kernel(const double* __restrict__ src, int64_t lds_,
+                                                            double* __restrict__ dst, int64_t ldd, int64_t rows,
+                                                            int64_t cols) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t r = r0 + ty + q * 8, c = c0 + tx;
+    tile[ty + q * 8][tx] = (r < rows && c < cols) ? src[r * lds_ + c] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t r = c0 + ty + q * 8, c = r0 + tx;  // dst is cols x rows
+    if (r < cols && c < rows) dst[r * ldd + c] = tile[tx][ty + q * 8];
+  }
+}
+
+__global__ __launch_bounds__(256) void add_diag_f64_kernel(double* A, int64_t lda, int64_t M, double value) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < M) A[i * lda + i] += value;
+}
+
+__global__ __launch_bounds__(256) void fill_f64_kernel(double* A, int64_t lda, int64_t rows, int64_t cols,
+                                                       double value) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = blockIdx.y;
+  if (c < cols && r < rows) A[r * lda + c] = value;
+}
+
+template <typename S, typename Dt>
+__global__ __launch_bounds__(256) void convert_kernel(const S* __restrict__ src, int64_t lds_, Dt* __restrict__ dst,
+                                                      int64_t ldd, int64_t rows, int64_t cols) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = blockIdx.y;
+  if (c < cols && r < rows) dst[r * ldd + c] = (Dt)src[r * lds_ + c];
+}
+
+// copies the NB x NB diagonal inverses onto the diagonals of Li (as is) and Lit (transposed)
+__global__ __launch_bounds__(256) void place_diag_inverses_kernel(const double* __restrict__ Dinv, int nb,
+                                                                  int64_t M, double* __restrict__ Li,
+                                                                  double* __restrict__ Lit, int64_t ld) {
+  const int b = blockIdx.y;
+  const int64_t r0 = (int64_t)b * nb;
+  const double* D = Dinv + (int64_t)b * nb * nb;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < nb * nb; e += gridDim.x * 256) {
+    const int i = e / nb, j = e % nb;
+    if (r0 + i < M && r0 + j < M && j <= i) {
+      const double v = D[e];
+      Li[(r0 + i) * ld + r0 + j] = v;
+      Lit[(r0 + j) * ld + r0 + i] = v;
+    }
+  }
+}
+
+// y[i] = alpha * sum_{j in tri range} Tri[i][j] x[j] + beta * z[i]; one wave per row.
+__global__ __launch_bounds__(256) void trmv_f64_kernel(const double* __restrict__ Tri, int64_t ld, int64_t M,
+                                                       int uplo, const double* __restrict__ x, double alpha,
+                                                       double beta, const double* __restrict__ z,
+                                                       double* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= M) return;
+  const int64_t jlo = uplo ? i : 0, jhi = uplo ? M : i + 1;  // [jlo, jhi)
+  const double* row = Tri + i * ld;
+  double s = 0.0;
+  const int64_t p0 = jlo >> 1, p1 = (jhi + 1) >> 1;  // pairs of columns; ld is even so pairs are 16-B aligned
+  for (int64_t p = p0 + lane; p < p1; p += 64) {
+    const int64_t j = p * 2;
+    if (j >= jlo && j + 1 < jhi) {
+      const f64x2 a = *reinterpret_cast<const f64x2*>(row + j);
+      const f64x2 b = *reinterpret_cast<const f64x2*>(x + j);
+      s = fma(a[0], b[0], s);
+      s = fma(a[1], b[1], s);
+    } else {
+      if (j >= jlo && j < jhi) s = fma(row[j], x[j], s);
+      if (j + 1 >= jlo && j + 1 < jhi) s = fma(row[j + 1], x[j + 1], s);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) {
+    double r = alpha * s;
+    if (beta != 0.0) r += beta * z[i];
+    y[i] = r;
+  }
+}
+
+// ---------------------------------------------------------------- host drivers
+int transpose_f64(const double* src, int64_t lds_, double* dst, int64_t ldd, int64_t rows, int64_t cols,
+                  hipStream_t stream) {
+  if (rows <= 0 || cols <= 0) return ODX_OK;
+  dim3 grid((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows, 32));
+  ODX_REQUIRE(grid.y < 65536, "transpose_f64: too many rows");
+  hipLaunchKernelGGL(transpose_f64_kernel, grid, dim3(256), 0, stream, src, lds_, dst, ldd, rows, cols);
+  ODX_CHECK_LAUNCH("transpose_f64");
+  return ODX_OK;
+}
+
+int add_diag_f64(double* A, int64_t lda, int64_t M, double value, hipStream_t stream) {
+  if (M <= 0) return ODX_OK;
+  hipLaunchKernelGGL(add_diag_f64_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, stream, A, lda, M, value);
+  ODX_CHECK_LAUNCH("add_diag_f64");
+  return ODX_OK;
+}
+
+int fill_f64(double* A, int64_t lda, int64_t rows, int64_t cols, double value, hipStream_t stream) {
+  if (rows <= 0 || cols <= 0) return ODX_OK;
+  ODX_REQUIRE(rows < 65536 * 32768ll, "fill_f64: too many rows");
+  // rows go on grid.y in slabs of <= 65535
+  for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+    const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+    hipLaunchKernelGGL(fill_f64_kernel, dim3((unsigned)ceil_div(cols, 256), (unsigned)nr), dim3(256), 0, stream,
+                       A + r0 * lda, lda, nr, cols, value);
+  }
+  ODX_CHECK_LAUNCH("fill_f64");
+  return ODX_OK;
+}
+
+// Right-looking blocked Cholesky (lower), NB = 128:
+//   L11 = chol(A11), D = L11^-1            (one workgroup, LDS)
+//   L21 = A21 D'                           (NT GEMM, in place: one column tile per row panel)
+//   A22 -= L21 L21'                        (NT GEMM, lower tiles only)
+int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hipStream_t stream) {
+  constexpr int NB = POTRF_NB;
+  ODX_REQUIRE(lda % 2 == 0 && aligned16(A) && aligned16(Dinv), "potrf_f64: A/Dinv must be 16-byte aligned, lda even");
+  for (int64_t k0 = 0, b = 0; k0 < M; k0 += NB, ++b) {
+    const int jb = (int)(M - k0 < NB ? M - k0 : NB);
+    double* Akk = A + k0 * lda + k0;
+    double* D = Dinv + b * NB * NB;
+    hipLaunchKernelGGL(potrf_diag_kernel<NB>, dim3(1), dim3(1024), 0, stream, Akk, lda, jb, D, info, (int)k0);
+    ODX_CHECK_LAUNCH("potrf_diag");
+    const int64_t m = M - k0 - jb;
+    if (m <= 0) break;
+    double* A21 = A + (k0 + jb) * lda + k0;
+    GemmParams<double> t;
+    t.A = A21; t.lda = lda; t.B = D; t.ldb = NB; t.C = A21; t.ldc = lda;
+    t.m = m; t.n = jb; t.k = jb; t.alpha = 1.0; t.beta = 0.0; t.flags = ODX_GEMM_B_LOWER;
+    ODX_PROPAGATE(launch_gemm_f64(t, stream));
+    GemmParams<double> u;
+    u.A = A21; u.lda = lda; u.B = A21; u.ldb = lda; u.C = A + (k0 + jb) * lda + (k0 + jb); u.ldc = lda;
+    u.m = m; u.n = m; u.k = jb; u.alpha = -1.0; u.beta = 1.0; u.flags = ODX_GEMM_LOWER_ONLY;
+    ODX_PROPAGATE(launch_gemm_f64(u, stream));
+  }
+  return ODX_OK;
+}
+
+// Li = L^-1, Lit = L^-T by pairwise merging of inverted diagonal blocks (s = NB, 2NB, ...):
+//   [X11 0; X21 X22] with X21 = -X22 (L21 X11).  All pairs of one level form one batched launch.
+//   GEMM 1:  WT = (L21 X11)'        A = L21 (m2 x s), B = X11' = Lit block (upper), stored transposed
+//   GEMM 2:  X21 = -X22 WT'         A = X22 (lower), B = WT;  X21 -> Li, X21' -> Lit
+// Li and Lit must be zero on entry outside what is written here.  WT: >= M*M doubles.
+int trtri_from_diag_f64(const double* L, int64_t ldl, int64_t M, const double* Dinv, double* Li, double* Lit,
+                        int64_t ld, double* WT, hipStream_t stream) {
+  constexpr int NB = POTRF_NB;
+  ODX_REQUIRE(ld % 2 == 0 && ldl % 2 == 0, "trtri_f64: leading dimensions must be even");
+  const int nblk = (int)ceil_div(M, NB);
+  hipLaunchKernelGGL(place_diag_inverses_kernel, dim3(16, (unsigned)nblk), dim3(256), 0, stream, Dinv, NB, M, Li,
+                     Lit, ld);
+  ODX_CHECK_LAUNCH("place_diag_inverses");
+  for (int64_t s = NB; s < M; s *= 2) {
+    const int nb = (int)ceil_div(M, 2 * s);  // pairs; the last may be ragged or empty
+    GemmParams<double> g1;
+    g1.A = L + s * ldl; g1.lda = ldl;                  // L21 of pair 0: rows s.., cols 0..
+    g1.B = Lit; g1.ldb = ld;                           // X11' of pair 0
+    g1.C = WT; g1.ldc = s;                             // WT_b (s x m2), transposed store
+    g1.m = s; g1.n = s; g1.k = s; g1.alpha = 1.0; g1.beta = 0.0;
+    g1.flags = ODX_GEMM_B_UPPER | ODX_GEMM_STORE_T;
+    g1.batches = nb;
+    g1.strideA = 2 * s * (ldl + 1); g1.strideB = 2 * s * (ld + 1); g1.strideC = s * s;
+    g1.ragged_total = M; g1.ragged_off = s; g1.ragged_step = 2 * s;
+    ODX_PROPAGATE(launch_gemm_f64(g1, stream));
+    GemmParams<double> g2;
+    g2.A = Li + s * (ld + 1); g2.lda = ld;             // X22 of pair 0
+    g2.B = WT; g2.ldb = s;                             // WT_b: rows j < s, k over m2
+    g2.C = Li + s * ld; g2.ldc = ld;                   // X21 -> Li
+    g2.C2 = Lit + s; g2.ldc2 = ld;                     // X21' -> Lit
+    g2.m = s; g2.n = s; g2.k = s; g2.alpha = -1.0; g2.beta = 0.0;
+    g2.flags = ODX_GEMM_A_LOWER;
+    g2.batches = nb;
+    g2.strideA = 2 * s * (ld + 1); g2.strideB = s * s; g2.strideC = 2 * s * (ld + 1); g2.strideC2 = 2 * s * (ld + 1);
+    g2.ragged_total = M; g2.ragged_off = s; g2.ragged_step = 2 * s; g2.ragged_k_is_m = 1;
+    ODX_PROPAGATE(launch_gemm_f64(g2, stream));
+  }
+  return ODX_OK;
+}
+
+}  // namespace odx
+
+using namespace odx;
+
+extern "C" int odx_trmv_f64(const double* Tri, int64_t ld, int64_t M, int uplo, const double* x, double alpha,
+                            double beta, const double* z, double* y, odx_stream_t stream) {
+  if (M <= 0) return ODX_OK;
+  ODX_REQUIRE(Tri && x && y && (beta == 0.0 || z), "odx_trmv_f64: null pointer");
+  ODX_REQUIRE(ld % 2 == 0 && ld >= M && aligned16(Tri) && aligned16(x), "odx_trmv_f64: Tri/x must be 16-byte aligned, ld even, ld >= M");
+  ODX_REQUIRE(x != y, "odx_trmv_f64: x and y must not alias");
+  hipLaunchKernelGGL(trmv_f64_kernel, dim3((unsigned)ceil_div(M, 4)), dim3(256), 0, as_stream(stream), Tri, ld, M,
+                     uplo, x, alpha, beta, z, y);
+  ODX_CHECK_LAUNCH("odx_trmv_f64");
+  return ODX_OK;
+}
+
+extern "C" int odx_convert_f32_f64(const float* src, int64_t lds_, double* dst, int64_t ldd, int64_t rows,
+                                   int64_t cols, odx_stream_t stream) {
+  if (rows <= 0 || cols <= 0) return ODX_OK;
+  ODX_REQUIRE(src && dst, "odx_convert_f32_f64: null pointer");
+  for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+    const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+    hipLaunchKernelGGL((convert_kernel<float, double>), dim3((unsigned)ceil_div(cols, 256), (unsigned)nr), dim3(256),
+                       0, as_stream(stream), src + r0 * lds_, lds_, dst + r0 * ldd, ldd, nr, cols);
+  }
+  ODX_CHECK_LAUNCH("odx_convert_f32_f64");
+  return ODX_OK;
+}
+
+extern "C" int odx_convert_f64_f32(const double* src, int64_t lds_, float* dst, int64_t ldd, int64_t rows,
+                                   int64_t cols, odx_stream_t stream) {
+  if (rows <= 0 || cols <= 0) return ODX_OK;
+  ODX_REQUIRE(src && dst, "odx_convert_f64_f32: null pointer");
+  for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+    const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+    hipLaunchKernelGGL((convert_kernel<double, float>), dim3((unsigned)ceil_div(cols, 256), (unsigned)nr), dim3(256),
+                       0, as_stream(stream), src + r0 * lds_, lds_, dst + r0 * ldd, ldd, nr, cols);
+  }
+  ODX_CHECK_LAUNCH("odx_convert_f64_f32");
+  return ODX_OK;
+}
+
+extern "C" int64_t odx_potrf_workspace_bytes(int64_t M) {
+  if (M <= 0) return 0;
+  return ceil_div(M, POTRF_NB) * POTRF_NB * POTRF_NB * (int64_t)sizeof(double);
+}
+
+extern "C" int odx_potrf_f64(double* A, int64_t lda, int64_t M, int32_t* info, void* workspace,
+                             int64_t workspace_bytes, odx_stream_t stream) {
+  if (M <= 0) return ODX_OK;
+  ODX_REQUIRE(A && info && workspace, "odx_potrf_f64: null pointer");
+  if (workspace_bytes < odx_potrf_workspace_bytes(M)) {
+    set_error("odx_potrf_f64: workspace too small");
+    return ODX_ERR_WORKSPACE;
+  }
+  ODX_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), as_stream(stream)));
+  return potrf_f64(A, lda, M, static_cast<double*>(workspace), info, as_stream(stream));
+}
+
+// workspace: Dinv | WT (M*M)
+extern "C" int64_t odx_trtri_workspace_bytes(int64_t M) {
+  if (M <= 0) return 0;
+  return odx_potrf_workspace_bytes(M) + M * M * (int64_t)sizeof(double);
+}
+
+// Stand-alone triangular inverse (tests, RLS): re-derives the diagonal-block inverses from L.
+__global__ __launch_bounds__(1024) void trtri_diag_kernel(const double* __restrict__ L, int64_t ldl, int64_t M,
+                                                          double* __restrict__ Dinv) {
+  constexpr int NB = POTRF_NB;
+  constexpr int LD = NB + 1;
+  __shared__ double s[NB * LD];
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * NB;
+  const int jb = (int)(M - r0 < NB ? M - r0 : NB);
+  for (int e = tid; e < NB * NB; e += 1024) {
+    const int i = e / NB, j = e % NB;
+    double v = 0.0;
+    if (i < jb && j <= i) v = L[(r0 + i) * ldl + r0 + j];
+    else if (i == j) v = 1.0;
+    s[i * LD + j] = v;
+  }
+  const int row = tid >> 3, part = tid & 7;
+  for (int j = NB - 1; j >= 0; --j) {
+    __syncthreads();
+    const double xjj = 1.0 / s[j * LD + j];
+    double y = 0.0;
+    if (row > j) {
+      for (int k = j + 1 + part; k <= row; k += 8) y = fma(s[row * LD + k], s[k * LD + j], y);
+    }
+    y += __shfl_xor(y, 1);
+    y += __shfl_xor(y, 2);
+    y += __shfl_xor(y, 4);
+    __syncthreads();
+    if (part == 0) {
+      if (row > j) s[row * LD + j] = -xjj * y;
+      else if (row == j) s[j * LD + j] = xjj;
+    }
+  }
+  __syncthreads();
+  double* D = Dinv + (int64_t)blockIdx.x * NB * NB;
+  for (int e = tid; e < NB * NB; e += 1024) {
+    const int i = e / NB, j = e % NB;
+    D[e] = (i < jb && j <= i) ? s[i * LD + j] : 0.0;
+  }
+}
+
+extern "C" int odx_trtri_f64(const double* L, int64_t ldl, int64_t M, double* Li, double* Lit, int64_t ld,
+                             void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
+  if (M <= 0) return ODX_OK;
+  ODX_REQUIRE(L && Li && Lit && workspace, "odx_trtri_f64: null pointer");
+  ODX_REQUIRE(ld >= M && ldl >= M && aligned16(L) && aligned16(Li) && aligned16(Lit), "odx_trtri_f64: bad ld / alignment");
+  if (workspace_bytes < odx_trtri_workspace_bytes(M)) {
+    set_error("odx_trtri_f64: workspace too small");
+    return ODX_ERR_WORKSPACE;
+  }
+  hipStream_t s = as_stream(stream);
+  double* Dinv = static_cast<double*>(workspace);
+  double* WT = Dinv + ceil_div(M, POTRF_NB) * POTRF_NB * POTRF_NB;
+  hipLaunchKernelGGL(trtri_diag_kernel, dim3((unsigned)ceil_div(M, POTRF_NB)), dim3(1024), 0, s, L, ldl, M, Dinv);
+  ODX_CHECK_LAUNCH("trtri_diag");
+  ODX_PROPAGATE(fill_f64(Li, ld, M, M, 0.0, s));
+  ODX_PROPAGATE(fill_f64(Lit, ld, M, M, 0.0, s));
+  return trtri_from_diag_f64(L, ldl, M, Dinv, Li, Lit, ld, WT, s);
+}
+
+// ---------------------------------------------------------------- FALKON preconditioner
+// workspace: Zd (M x ldzd) | zsq (M, padded) | W0 (M x ld) | W1 (M x ld) | W2 (M x ld) | Dinv
+static int64_t precond_ld(int64_t M) { return round_up(M, 2); }
+
+extern "C" int64_t odx_falkon_precond_workspace_bytes(int64_t M, int D) {
+  if (M <= 0 || D <= 0) return 0;
+  const int64_t ld = precond_ld(M), ldzd = round_up(D, 2);
+  int64_t dbl = M * ldzd + round_up(M, 2) + 3 * M * ld + ceil_div(M, POTRF_NB) * POTRF_NB * POTRF_NB;
+  return dbl * (int64_t)sizeof(double);
+}
+
+extern "C" int odx_falkon_precond_f64(const float* Z, int64_t ldz, int64_t M, int D, double sigma, double lam,
+                                      double eps, double* LTi, double* LTit, double* LAi, double* LAit, int64_t ld,
+                                      int32_t* info, void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
+  ODX_REQUIRE(M > 0 && D > 0 && sigma > 0, "odx_falkon_precond_f64: bad sizes");
+  ODX_REQUIRE(Z && LTi && LTit && LAi && LAit && info && workspace, "odx_falkon_precond_f64: null pointer");
+  ODX_REQUIRE(ld % 2 == 0 && ld >= M && aligned16(LTi) && aligned16(LTit) && aligned16(LAi) && aligned16(LAit),
+              "odx_falkon_precond_f64: outputs must be 16-byte aligned with even ld >= M");
+  ODX_REQUIRE(aligned16(workspace), "odx_falkon_precond_f64: workspace must be 16-byte aligned");
+  if (workspace_bytes < odx_falkon_precond_workspace_bytes(M, D)) {
+    set_error("odx_falkon_precond_f64: workspace too small");
+    return ODX_ERR_WORKSPACE;
+  }
+  hipStream_t s = as_stream(stream);
+  const int64_t wld = precond_ld(M), ldzd = round_up(D, 2);
+  double* Zd = static_cast<double*>(workspace);
+  double* zsq = Zd + M * ldzd;
+  double* W0 = zsq + round_up(M, 2);
+  double* W1 = W0 + M * wld;
+  double* W2 = W1 + M * wld;
+  double* Dinv = W2 + M * wld;
+
+  ODX_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), s));
+  ODX_CHECK_HIP(hipMemsetAsync(Zd, 0, (size_t)(M * ldzd) * sizeof(double), s));
+  ODX_PROPAGATE(odx_convert_f32_f64(Z, ldz, Zd, ldzd, M, D, stream));
+  // W0 = K_MM + eps*M*I (lower), then L_T in place
+  ODX_CHECK_HIP(hipMemsetAsync(W0, 0, (size_t)(M * wld) * sizeof(double), s));
+  ODX_PROPAGATE(gauss_kmm_f64(Zd, ldzd, M, D, sigma, eps * (double)M, W0, wld, zsq, s));
+  ODX_PROPAGATE(potrf_f64(W0, wld, M, Dinv, info, s));
+  // W1 = L_T' = T (upper)
+  ODX_CHECK_HIP(hipMemsetAsync(W1, 0, (size_t)(M * wld) * sizeof(double), s));
+  ODX_PROPAGATE(transpose_f64(W0, wld, W1, wld, M, M, s));
+  // W2 = T T' / M + lam I (lower tiles)
+  ODX_CHECK_HIP(hipMemsetAsync(W2, 0, (size_t)(M * wld) * sizeof(double), s));
+  {
+    GemmParams<double> g;
+    g.A = W1; g.lda = wld; g.B = W1; g.ldb = wld; g.C = W2; g.ldc = wld;
+    g.m = M; g.n = M; g.k = M; g.alpha = 1.0 / (double)M; g.beta = 0.0;
+    g.flags = ODX_GEMM_LOWER_ONLY | ODX_GEMM_A_UPPER | ODX_GEMM_B_UPPER;
+    ODX_PROPAGATE(launch_gemm_f64(g, s));
+  }
+  ODX_PROPAGATE(add_diag_f64(W2, wld, M, lam, s));
+  // inverses of L_T (W1 is free now: use it as the trtri scratch)
+  ODX_PROPAGATE(fill_f64(LTi, ld, M, M, 0.0, s));
+  ODX_PROPAGATE(fill_f64(LTit, ld, M, M, 0.0, s));
+  ODX_PROPAGATE(trtri_from_diag_f64(W0, wld, M, Dinv, LTi, LTit, ld, W1, s));
+  // L_A in place in W2, then its inverses (W0 is free now)
+  ODX_PROPAGATE(potrf_f64(W2, wld, M, Dinv, info, s));
+  ODX_PROPAGATE(fill_f64(LAi, ld, M, M, 0.0, s));
+  ODX_PROPAGATE(fill_f64(LAit, ld, M, M, 0.0, s));
+  ODX_PROPAGATE(trtri_from_diag_f64(W2, wld, M, Dinv, LAi, LAit, ld, W0, s));
+  return ODX_OK;
+}

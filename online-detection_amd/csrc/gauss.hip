@@ -1,0 +1,236 @@
+// Gaussian-kernel blocks on the MFMA tile core (gfx950).
+//   odx_gauss_knm_f32 : K_nM = exp(gamma * max(0, |x|^2 + |z|^2 - 2 x.z)), stored f32 (A3)
+//   odx_gauss_mmv_f32 : out[:, c] = K(X, Z[range c]) V[range c, c], K never stored, f64 sums (A5/A9)
+//   gauss_kmm_f64     : K_MM in f64 for the preconditioner (lower tiles only)
+// The -2 X Z' contraction runs on v_mfma_f32_32x32x2_f32 (bit-exact f32 fmaf chain); the
+// norm broadcast, clamp, scale and exp are fused into the accumulator epilogue, so the
+// distance matrix never touches memory.
+#include "gemm_core.h"
+#include "odx_internal.h"
+
+namespace odx {
+
+// ---------------------------------------------------------------- row squared norms
+template <typename T, typename V4>
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const T* __restrict__ X, int64_t ldx, int64_t n, int D,
+                                                         T* __restrict__ out) {
+  constexpr int EPV = 16 / sizeof(T);
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const T* x = X + row * ldx;
+  T s = T(0);
+  const int nvec = D / EPV;
+  for (int c = lane; c < nvec; c += 64) {
+    const V4 v = *reinterpret_cast<const V4*>(x + c * EPV);
+#pragma unroll
+    for (int q = 0; q < EPV; ++q) s = fma(v[q], v[q], s);
+  }
+  for (int d = nvec * EPV + lane; d < D; d += 64) s = fma(x[d], x[d], s);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) out[row] = s;
+}
+
+// ---------------------------------------------------------------- K_nM (f32)
+__global__ __launch_bounds__(GEMM_THREADS) void gauss_knm_f32_kernel(
+    const float* __restrict__ X, int64_t ldx, const float* __restrict__ xsq, int64_t n,
+    const float* __restrict__ Z, int64_t ldz, const float* __restrict__ zsq, int64_t M, int D, float gamma,
+    float* __restrict__ K, int64_t ldk) {
+  __shared__ __attribute__((aligned(16))) char lds[GEMM_LDS_BYTES];
+  const int64_t tiles_n = (M + GEMM_BN - 1) / GEMM_BN;
+  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t i0 = (wg / tiles_n) * GEMM_BM, j0 = (wg % tiles_n) * GEMM_BN;
+
+  f32x16 acc[2][2];
+  gemm_zero_acc<float>(acc);
+  gemm_mainloop<float>(acc, X, ldx, n, Z, ldz, M, i0, j0, 0, D, lds);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int64_t mpad = (M + 3) & ~int64_t(3);  // the CG pass reads whole float4 chunks
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int64_t col = j0 + wc * 64 + gemm_acc_col<float>(tn, lane);
+    const float zs = col < M ? zsq[col] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = i0 + wr * 64 + gemm_acc_row<float>(tm, r, lane);
+        if (row < n && col < mpad) {
+          float v = 0.f;
+          if (col < M) {
+            float d2 = fmaf(-2.f, acc[tm][tn][r], xsq[row]) + zs;
+            d2 = fmaxf(d2, 0.f);
+            v = expf(d2 * gamma);
+          }
+          K[row * ldk + col] = v;
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------- fused scoring (f32 K, f64 sums)
+__global__ __launch_bounds__(GEMM_THREADS) void gauss_mmv_f32_kernel(
+    const float* __restrict__ X, int64_t ldx, const float* __restrict__ xsq, int64_t n,
+    const float* __restrict__ Z, int64_t ldz, const float* __restrict__ zsq, int D, float gamma,
+    const double* __restrict__ V, int64_t ldv, const int32_t* __restrict__ ranges, float* __restrict__ out,
+    int64_t ldo) {
+  __shared__ __attribute__((aligned(16))) char lds[GEMM_LDS_BYTES];
+  __shared__ double red[2][2][64];
+  const int c = blockIdx.y;
+  const int64_t s0 = ranges[2 * c], s1 = ranges[2 * c + 1];
+  const int64_t i0 = (int64_t)blockIdx.x * GEMM_BM;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  double rowacc[2][16];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rowacc[tm][r] = 0.0;
+
+  float xs[2][16];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = i0 + wr * 64 + gemm_acc_row<float>(tm, r, lane);
+      xs[tm][r] = row < n ? xsq[row] : 0.f;
+    }
+
+  for (int64_t j0 = s0; j0 < s1; j0 += GEMM_BN) {
+    f32x16 acc[2][2];
+    gemm_zero_acc<float>(acc);
+    gemm_mainloop<float>(acc, X, ldx, n, Z + j0 * ldz, ldz, s1 - j0, i0, 0, 0, D, lds);
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int64_t col = j0 + wc * 64 + gemm_acc_col<float>(tn, lane);
+      const bool cv = col < s1;
+      const float zs = cv ? zsq[col] : 0.f;
+      const double al = cv ? V[col * ldv + c] : 0.0;
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float d2 = fmaf(-2.f, acc[tm][tn][r], xs[tm][r]) + zs;
+          d2 = fmaxf(d2, 0.f);
+          const float kv = cv ? expf(d2 * gamma) : 0.f;
+          rowacc[tm][r] = fma((double)kv, al, rowacc[tm][r]);
+        }
+    }
+  }
+  // sum over the 32 lanes that hold the columns of one row (keep the two lane halves apart)
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double v = rowacc[tm][r];
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      if ((lane & 31) == 0) red[wr][wc][gemm_acc_row<float>(tm, r, lane)] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int w = threadIdx.x >> 6, rr = threadIdx.x & 63;
+    const int64_t row = i0 + w * 64 + rr;
+    if (row < n) out[row * ldo + c] = (float)(red[w][0][rr] + red[w][1][rr]);
+  }
+}
+
+// ---------------------------------------------------------------- K_MM (f64, lower tiles)
+__global__ __launch_bounds__(GEMM_THREADS) void gauss_kmm_f64_kernel(const double* __restrict__ Zd, int64_t ldz,
+                                                                    const double* __restrict__ zsq, int64_t M, int D,
+                                                                    double gamma, double diag_add,
+                                                                    double* __restrict__ Kmm, int64_t ldk) {
+  __shared__ __attribute__((aligned(16))) char lds[GEMM_LDS_BYTES];
+  const int64_t tiles_n = (M + GEMM_BN - 1) / GEMM_BN;
+  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t i0 = (wg / tiles_n) * GEMM_BM, j0 = (wg % tiles_n) * GEMM_BN;
+  if (j0 > i0 + GEMM_BM - 1) return;  // lower triangle only
+
+  f64x4 acc[4][4];
+  gemm_zero_acc<double>(acc);
+  gemm_mainloop<double>(acc, Zd, ldz, M, Zd, ldz, M, i0, j0, 0, D, lds);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) {
+    const int64_t col = j0 + wc * 64 + gemm_acc_col<double>(tn, lane);
+    const double zs = col < M ? zsq[col] : 0.0;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = i0 + wr * 64 + gemm_acc_row<double>(tm, r, lane);
+        if (row < M && col < M) {
+          double d2 = fma(-2.0, acc[tm][tn][r], zsq[row]) + zs;
+          d2 = fmax(d2, 0.0);
+          double v = exp(d2 * gamma);
+          if (row == col) v += diag_add;
+          Kmm[row * ldk + col] = v;
+        }
+      }
+  }
+}
+
+int gauss_kmm_f64(const double* Zd, int64_t ldz, int64_t M, int D, double sigma, double diag_add, double* Kmm,
+                  int64_t ldk, double* zsq, hipStream_t stream) {
+  ODX_REQUIRE(ldz % 2 == 0 && aligned16(Zd), "gauss_kmm_f64: Zd must be 16-byte aligned with even ld");
+  hipLaunchKernelGGL((row_sqnorm_kernel<double, f64x2>), dim3((unsigned)ceil_div(M, 4)), dim3(256), 0, stream, Zd,
+                     ldz, M, D, zsq);
+  ODX_CHECK_LAUNCH("row_sqnorm_f64");
+  const int64_t t = ceil_div(M, GEMM_BM);
+  hipLaunchKernelGGL(gauss_kmm_f64_kernel, dim3((unsigned)(t * t)), dim3(GEMM_THREADS), 0, stream, Zd, ldz, zsq, M,
+                     D, -0.5 / (sigma * sigma), diag_add, Kmm, ldk);
+  ODX_CHECK_LAUNCH("gauss_kmm_f64");
+  return ODX_OK;
+}
+
+}  // namespace odx
+
+using namespace odx;
+
+extern "C" int odx_row_sqnorm_f32(const float* X, int64_t ldx, int64_t n, int D, float* out, odx_stream_t stream) {
+  if (n <= 0) return ODX_OK;
+  ODX_REQUIRE(X && out && D > 0, "odx_row_sqnorm_f32: null pointer or D <= 0");
+  ODX_REQUIRE(ldx % 4 == 0 && ldx >= D && aligned16(X), "odx_row_sqnorm_f32: X must be 16-byte aligned, ldx %% 4 == 0, ldx >= D");
+  hipLaunchKernelGGL((row_sqnorm_kernel<float, f32x4>), dim3((unsigned)ceil_div(n, 4)), dim3(256), 0,
+                     as_stream(stream), X, ldx, n, D, out);
+  ODX_CHECK_LAUNCH("odx_row_sqnorm_f32");
+  return ODX_OK;
+}
+
+extern "C" int odx_gauss_knm_f32(const float* X, int64_t ldx, const float* xsq, int64_t n, const float* Z, int64_t ldz,
+                                 const float* zsq, int64_t M, int D, double sigma, float* K, int64_t ldk,
+                                 odx_stream_t stream) {
+  if (n <= 0 || M <= 0) return ODX_OK;
+  ODX_REQUIRE(X && xsq && Z && zsq && K && D > 0 && sigma > 0, "odx_gauss_knm_f32: bad argument");
+  ODX_REQUIRE(ldx % 4 == 0 && ldz % 4 == 0 && ldx >= D && ldz >= D && aligned16(X) && aligned16(Z),
+              "odx_gauss_knm_f32: X/Z must be 16-byte aligned with ld %% 4 == 0 and ld >= D");
+  ODX_REQUIRE(ldk % 4 == 0 && ldk >= round_up(M, 4) && aligned16(K), "odx_gauss_knm_f32: K must be 16-byte aligned, ldk %% 4 == 0, ldk >= roundup(M, 4)");
+  const int64_t tiles = ceil_div(n, GEMM_BM) * ceil_div(M, GEMM_BN);
+  ODX_REQUIRE(tiles < (1ll << 31), "odx_gauss_knm_f32: grid too large");
+  hipLaunchKernelGGL(gauss_knm_f32_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, as_stream(stream), X, ldx,
+                     xsq, n, Z, ldz, zsq, M, D, (float)(-0.5 / (sigma * sigma)), K, ldk);
+  ODX_CHECK_LAUNCH("odx_gauss_knm_f32");
+  return ODX_OK;
+}
+
+extern "C" int odx_gauss_mmv_f32(const float* X, int64_t ldx, const float* xsq, int64_t n, const float* Z, int64_t ldz,
+                                 const float* zsq, int D, double sigma, const double* V, int64_t ldv,
+                                 const int32_t* ranges, int C, float* out, int64_t ldo, odx_stream_t stream) {
+  if (n <= 0 || C <= 0) return ODX_OK;
+  ODX_REQUIRE(X && xsq && Z && zsq && V && ranges && out && D > 0 && sigma > 0 && ldv >= C, "odx_gauss_mmv_f32: bad argument");
+  ODX_REQUIRE(ldx % 4 == 0 && ldz % 4 == 0 && ldx >= D && ldz >= D && aligned16(X) && aligned16(Z),
+              "odx_gauss_mmv_f32: X/Z must be 16-byte aligned with ld %% 4 == 0 and ld >= D");
+  ODX_REQUIRE(ldo >= C && C < 65536, "odx_gauss_mmv_f32: ldo < C or too many classes");
+  const int64_t rb = ceil_div(n, GEMM_BM);
+  ODX_REQUIRE(rb < (1ll << 31), "odx_gauss_mmv_f32: grid too large");
+  hipLaunchKernelGGL(gauss_mmv_f32_kernel, dim3((unsigned)rb, (unsigned)C), dim3(GEMM_THREADS), 0, as_stream(stream),
+                     X, ldx, xsq, n, Z, ldz, zsq, D, (float)(-0.5 / (sigma * sigma)), V, ldv, ranges, out, ldo);
+  ODX_CHECK_LAUNCH("odx_gauss_mmv_f32");
+  return ODX_OK;
+}

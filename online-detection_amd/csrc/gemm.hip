@@ -1,0 +1,104 @@
+// Generic NT GEMM on the tile core: C = alpha * A B' + beta * C with triangular-operand
+// k-range clipping, lower-only output, transposed / dual store and ragged batching.
+// Used by the f64 preconditioner (potrf / trtri / T T'), the RLS Gram, and exported for tests.
+#include "gemm_core.h"
+#include "odx_internal.h"
+
+namespace odx {
+
+template <typename T>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams<T> p) {
+  __shared__ __attribute__((aligned(16))) char lds[GEMM_LDS_BYTES];
+  using Tr = GemmTraits<T>;
+  const int b = blockIdx.y;
+  int64_t m = p.m, k = p.k;
+  if (p.ragged_total > 0) {
+    int64_t mb = p.ragged_total - p.ragged_off - (int64_t)b * p.ragged_step;
+    if (mb > p.m) mb = p.m;
+    if (mb <= 0) return;
+    m = mb;
+    if (p.ragged_k_is_m) k = mb;
+  }
+  const int64_t n = p.n;
+  const int64_t tiles_n = (n + GEMM_BN - 1) / GEMM_BN;
+  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t bi = wg / tiles_n, bj = wg % tiles_n;
+  const int64_t i0 = bi * GEMM_BM, j0 = bj * GEMM_BN;
+  if (i0 >= m) return;
+  if ((p.flags & ODX_GEMM_LOWER_ONLY) && j0 > i0 + GEMM_BM - 1) return;
+
+  int64_t kb = 0, ke = k;
+  if (p.flags & ODX_GEMM_A_UPPER) kb = max(kb, i0);
+  if (p.flags & ODX_GEMM_B_UPPER) kb = max(kb, j0);
+  if (p.flags & ODX_GEMM_A_LOWER) ke = min(ke, i0 + GEMM_BM);
+  if (p.flags & ODX_GEMM_B_LOWER) ke = min(ke, j0 + GEMM_BN);
+  kb = (kb / Tr::BK) * Tr::BK;
+
+  const T* A = p.A + (int64_t)b * p.strideA;
+  const T* B = p.B + (int64_t)b * p.strideB;
+  T* C = p.C + (int64_t)b * p.strideC;
+  T* C2 = p.C2 ? p.C2 + (int64_t)b * p.strideC2 : nullptr;
+
+  typename Tr::Acc acc[Tr::TM][Tr::TN];
+  gemm_zero_acc<T>(acc);
+  gemm_mainloop<T>(acc, A, p.lda, m, B, p.ldb, n, i0, j0, kb, ke, lds);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const bool st = (p.flags & ODX_GEMM_STORE_T) != 0;
+#pragma unroll
+  for (int tm = 0; tm < Tr::TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < Tr::TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < Tr::NREG; ++r) {
+        const int64_t row = i0 + wr * 64 + gemm_acc_row<T>(tm, r, lane);
+        const int64_t col = j0 + wc * 64 + gemm_acc_col<T>(tn, lane);
+        if (row < m && col < n) {
+          const int64_t idx = st ? col * p.ldc + row : row * p.ldc + col;
+          T val = p.alpha * acc[tm][tn][r];
+          if (p.beta != T(0)) val += p.beta * C[idx];
+          C[idx] = val;
+          if (C2) C2[col * p.ldc2 + row] = val;
+        }
+      }
+}
+
+template <typename T>
+static int launch_gemm(const GemmParams<T>& p, hipStream_t stream, const char* name) {
+  constexpr int EPV = GemmTraits<T>::EPV;
+  if (p.m <= 0 || p.n <= 0 || p.batches <= 0) return ODX_OK;
+  ODX_REQUIRE(p.A && p.B && p.C, "%s: null operand", name);
+  ODX_REQUIRE(p.lda % EPV == 0 && p.ldb % EPV == 0, "%s: lda/ldb must be multiples of %d elements", name, EPV);
+  ODX_REQUIRE(aligned16(p.A) && aligned16(p.B), "%s: A/B must be 16-byte aligned", name);
+  ODX_REQUIRE(p.strideA % EPV == 0 && p.strideB % EPV == 0, "%s: batch strides must keep 16-byte alignment", name);
+  const int64_t tiles = ceil_div(p.m, GEMM_BM) * ceil_div(p.n, GEMM_BN);
+  ODX_REQUIRE(tiles < (1ll << 31) && p.batches < 65536, "%s: grid too large", name);
+  dim3 grid((unsigned)tiles, (unsigned)p.batches, 1);
+  hipLaunchKernelGGL(gemm_nt_kernel<T>, grid, dim3(GEMM_THREADS), 0, stream, p);
+  ODX_CHECK_LAUNCH(name);
+  return ODX_OK;
+}
+
+int launch_gemm_f64(const GemmParams<double>& p, hipStream_t stream) { return launch_gemm<double>(p, stream, "gemm_nt_f64"); }
+int launch_gemm_f32(const GemmParams<float>& p, hipStream_t stream) { return launch_gemm<float>(p, stream, "gemm_nt_f32"); }
+
+}  // namespace odx
+
+extern "C" int odx_gemm_nt_f64(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
+                               int64_t m, int64_t n, int64_t k, double alpha, double beta, int flags,
+                               odx_stream_t stream) {
+  odx::GemmParams<double> p;
+  p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+  p.m = m; p.n = n; p.k = k; p.alpha = alpha; p.beta = beta; p.flags = flags;
+  return odx::launch_gemm_f64(p, odx::as_stream(stream));
+}
+
+extern "C" int odx_gemm_nt_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+                               int64_t m, int64_t n, int64_t k, float alpha, float beta, int flags,
+                               odx_stream_t stream) {
+  odx::GemmParams<float> p;
+  p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+  p.m = m; p.n = n; p.k = k; p.alpha = alpha; p.beta = beta; p.flags = flags;
+  return odx::launch_gemm_f32(p, odx::as_stream(stream));
+}

@@ -1,0 +1,222 @@
+// The conjugate-gradient pass over a stored K_nM shard:  out = K' (K v + w).
+// HBM-bound: every float of K is read exactly once per call.
+//
+// A persistent workgroup streams blocks of R rows.  Thread t owns the float4 column chunks
+// t, t+NT, ... (CH of them) of every row: the running column sums of K' t live in registers
+// as f64, the R x CH float4 of K of the current block too; v sits in LDS as f64.  Phase 1 forms the R row dots (f64) and reduces them over the workgroup (wave shuffles
+// + one LDS exchange, ping-pong buffers => one barrier per block).  Phase 2 adds
+// K[r, cols] * t_r into the column sums and, chunk by chunk, re-issues the loads of the NEXT
+// block into the registers it has just finished with, so the block's worth of loads is in
+// flight across the reduction.  Each workgroup writes its column sums as one slab; a second
+// kernel adds the slabs in fixed order (bitwise reproducible, no float atomics).
+//
+// Requirements: ldk % 4 == 0, K 16-byte aligned, columns [M, roundup(M,4)) of K are zero
+// (odx_gauss_knm_f32 writes them so).
+#include "odx_common.h"
+
+namespace odx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+template <int NT, int CH, int R>
+__global__ __launch_bounds__(NT) void knm_pass_kernel(const float* __restrict__ K, int64_t ldk, int64_t n, int64_t M,
+                                                      const double* __restrict__ v, const double* __restrict__ w,
+                                                      double* __restrict__ slab, int64_t slab_ld) {
+  constexpr int NW = NT / 64;
+  constexpr int VCAP = (NT * CH * 4 < 20000) ? NT * CH * 4 : 20000;  // 160,000 B of the 163,840 B LDS at most
+  __shared__ __attribute__((aligned(16))) double vs[VCAP];
+  __shared__ double red[2][NW][R];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t nchunk = (M + 3) >> 2;
+  const int64_t nblk = (n + R - 1) / R;
+
+  // v lives in LDS (f64): its read traffic per block equals M * 8 B, a few % of LDS bandwidth.
+  for (int i = tid; i < VCAP; i += NT) vs[i] = (v != nullptr && i < M) ? v[i] : 0.0;
+
+  double acc[CH][4];
+  bool cvalid[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    cvalid[c] = (tid + (int64_t)c * NT) < nchunk;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[c][e] = 0.0;
+  }
+
+  f32x4 kr[R][CH];
+  auto load_block = [&](int64_t blk, int c) {
+    const int64_t ch = tid + (int64_t)c * NT;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = blk * R + r;
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      if (cvalid[c] && row < n) x = *reinterpret_cast<const f32x4*>(K + row * ldk + ch * 4);
+      kr[r][c] = x;
+    }
+  };
+
+  int64_t blk = blockIdx.x;
+  if (blk < nblk) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) load_block(blk, c);
+  }
+  __syncthreads();  // vs is complete
+  int pp = 0;
+  for (; blk < nblk; blk += gridDim.x) {
+    double t[R];
+    if (v != nullptr) {
+      // phase 1: row dots
+#pragma unroll
+      for (int r = 0; r < R; ++r) t[r] = 0.0;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        double vv[4] = {0.0, 0.0, 0.0, 0.0};
+        if (cvalid[c]) {
+          const f64x2 a = *reinterpret_cast<const f64x2*>(&vs[(tid + c * NT) * 4]);
+          const f64x2 b = *reinterpret_cast<const f64x2*>(&vs[(tid + c * NT) * 4 + 2]);
+          vv[0] = a[0]; vv[1] = a[1]; vv[2] = b[0]; vv[3] = b[1];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[r] = fma((double)kr[r][c][e], vv[e], t[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        double s = t[r];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) red[pp][wave][r] = s;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) s += red[pp][q][r];
+        t[r] = s;
+      }
+      pp ^= 1;
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) t[r] = 0.0;
+    }
+    if (w != nullptr) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int64_t row = blk * R + r;
+        if (row < n) t[r] += w[row];
+      }
+    }
+    // phase 2: column sums, and the next block's loads re-issued chunk by chunk
+    const int64_t nxt = blk + gridDim.x;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[c][e] = fma((double)kr[r][c][e], t[r], acc[c][e]);
+      if (nxt < nblk) load_block(nxt, c);
+    }
+  }
+  double* my = slab + (int64_t)blockIdx.x * slab_ld;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int64_t ch = tid + (int64_t)c * NT;
+    if (cvalid[c]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) my[ch * 4 + e] = acc[c][e];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const double* __restrict__ slab, int64_t slab_ld, int nslab,
+                                                          int64_t M, double* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= M) return;
+  double s = 0.0;
+  for (int g = 0; g < nslab; ++g) s += slab[(int64_t)g * slab_ld + j];
+  out[j] = s;
+}
+
+struct PassCfg {
+  int nt, ch, r, wg_per_cu;
+};
+
+static bool pick_cfg(int64_t M, PassCfg* cfg) {
+  const int64_t chunks = (M + 3) / 4;
+  if (chunks <= 256) { *cfg = {256, 1, 16, 2}; return true; }
+  if (chunks <= 512) { *cfg = {256, 2, 8, 2}; return true; }
+  if (chunks <= 1024) { *cfg = {256, 4, 4, 2}; return true; }
+  if (chunks <= 2048) { *cfg = {512, 4, 4, 1}; return true; }
+  if (chunks <= 2560) { *cfg = {512, 5, 4, 1}; return true; }
+  if (chunks <= 3072) { *cfg = {512, 6, 2, 1}; return true; }
+  if (chunks <= 5000) { *cfg = {1024, 5, 1, 1}; return true; }
+  return false;
+}
+
+static int grid_for(const PassCfg& cfg, int64_t n) {
+  int cus = odx_device_cus();
+  if (cus <= 0) cus = 256;
+  const int64_t nblk = ceil_div(n, cfg.r);
+  int64_t g = (int64_t)cus * cfg.wg_per_cu;
+  if (g > nblk) g = nblk;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace odx
+
+using namespace odx;
+
+extern "C" int64_t odx_knm_fwd_bwd_workspace_bytes(int64_t n, int64_t M) {
+  PassCfg cfg;
+  if (n <= 0 || M <= 0) return 0;
+  if (!pick_cfg(M, &cfg)) return ODX_ERR_UNSUPPORTED;
+  int cus = odx_device_cus();
+  if (cus <= 0) cus = 256;
+  // sized for the largest grid any n can get, so one workspace serves every shard size
+  return (int64_t)cus * cfg.wg_per_cu * round_up(M, 4) * (int64_t)sizeof(double);
+}
+
+#define ODX_PASS_LAUNCH(NT_, CH_, R_)                                                                          \
+  hipLaunchKernelGGL((knm_pass_kernel<NT_, CH_, R_>), dim3(grid), dim3(NT_), 0, s, K, ldk, n, M, v, w, slab, \
+                     slab_ld)
+
+extern "C" int odx_knm_fwd_bwd(const float* K, int64_t ldk, int64_t n, int64_t M, const double* v, const double* w,
+                               double* out, void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
+  ODX_REQUIRE(M > 0 && out, "odx_knm_fwd_bwd: M <= 0 or null out");
+  hipStream_t s = as_stream(stream);
+  if (n <= 0) {
+    ODX_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)M * sizeof(double), s));
+    return ODX_OK;
+  }
+  ODX_REQUIRE(K && (v || w), "odx_knm_fwd_bwd: null K, or both v and w null");
+  ODX_REQUIRE(ldk % 4 == 0 && ldk >= round_up(M, 4) && aligned16(K),
+              "odx_knm_fwd_bwd: K must be 16-byte aligned, ldk %% 4 == 0, ldk >= roundup(M, 4)");
+  PassCfg cfg;
+  if (!pick_cfg(M, &cfg)) {
+    set_error("odx_knm_fwd_bwd: M = %lld exceeds the 20000 columns the pass kernels are built for", (long long)M);
+    return ODX_ERR_UNSUPPORTED;
+  }
+  const int grid = grid_for(cfg, n);
+  const int64_t slab_ld = round_up(M, 4);
+  if (workspace == nullptr || workspace_bytes < (int64_t)grid * slab_ld * (int64_t)sizeof(double)) {
+    set_error("odx_knm_fwd_bwd: workspace too small (%lld < %lld)", (long long)workspace_bytes,
+              (long long)((int64_t)grid * slab_ld * (int64_t)sizeof(double)));
+    return ODX_ERR_WORKSPACE;
+  }
+  double* slab = static_cast<double*>(workspace);
+  if (cfg.nt == 256 && cfg.ch == 1) ODX_PASS_LAUNCH(256, 1, 16);
+  else if (cfg.nt == 256 && cfg.ch == 2) ODX_PASS_LAUNCH(256, 2, 8);
+  else if (cfg.nt == 256 && cfg.ch == 4) ODX_PASS_LAUNCH(256, 4, 4);
+  else if (cfg.nt == 512 && cfg.ch == 4) ODX_PASS_LAUNCH(512, 4, 4);
+  else if (cfg.nt == 512 && cfg.ch == 5) ODX_PASS_LAUNCH(512, 5, 4);
+  else if (cfg.nt == 512 && cfg.ch == 6) ODX_PASS_LAUNCH(512, 6, 2);
+  else ODX_PASS_LAUNCH(1024, 5, 1);
+  ODX_CHECK_LAUNCH("odx_knm_fwd_bwd");
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, s, slab, slab_ld, grid, M,
+                     out);
+  ODX_CHECK_LAUNCH("odx_knm_fwd_bwd(reduce)");
+  return ODX_OK;
+}

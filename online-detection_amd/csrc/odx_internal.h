@@ -1,0 +1,42 @@
+// Internal (non-ABI) interfaces shared between the translation units of libodx.
+#pragma once
+#include "odx_common.h"
+
+namespace odx {
+
+template <typename T>
+struct GemmParams {
+  const T* A = nullptr; int64_t lda = 0;
+  const T* B = nullptr; int64_t ldb = 0;
+  T* C = nullptr; int64_t ldc = 0;
+  T* C2 = nullptr; int64_t ldc2 = 0;   // optional transposed copy of the result: C2[j, i]
+  int64_t m = 0, n = 0, k = 0;
+  T alpha = T(1), beta = T(0);
+  int flags = 0;
+  // batching over blockIdx.y
+  int batches = 1;
+  int64_t strideA = 0, strideB = 0, strideC = 0, strideC2 = 0;
+  // ragged batches (trtri levels): m_b = clamp(ragged_total - ragged_off - b * ragged_step, 0, m)
+  int64_t ragged_total = 0, ragged_off = 0, ragged_step = 0;
+  int ragged_k_is_m = 0;               // k_b = m_b (GEMM 2 of a trtri level)
+};
+
+int launch_gemm_f64(const GemmParams<double>& p, hipStream_t stream);
+int launch_gemm_f32(const GemmParams<float>& p, hipStream_t stream);
+
+// dense_f64.hip
+constexpr int POTRF_NB = 128;
+int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv /* nblk x NB x NB */, int32_t* info,
+              hipStream_t stream);
+int trtri_from_diag_f64(const double* L, int64_t ldl, int64_t M, const double* Dinv, double* Li, double* Lit,
+                        int64_t ld, double* WT, hipStream_t stream);
+int transpose_f64(const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols,
+                  hipStream_t stream);
+int add_diag_f64(double* A, int64_t lda, int64_t M, double value, hipStream_t stream);
+int fill_f64(double* A, int64_t lda, int64_t rows, int64_t cols, double value, hipStream_t stream);
+
+// gauss.hip
+int gauss_kmm_f64(const double* Zd, int64_t ldz, int64_t M, int D, double sigma, double diag_add, double* Kmm,
+                  int64_t ldk, double* zsq /* M */, hipStream_t stream);
+
+}  // namespace odx

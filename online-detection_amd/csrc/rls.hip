@@ -1,0 +1,156 @@
+// Per-class regularised least squares of the box regressors (A7), f64 throughout:
+//   G = [X 1]' [X 1] (+ lam I),  R = chol(G),  w_k = R^-T R^-1 [X 1]' y_k,  k = 0..3
+// following RegionRefinerTrainer.solve (train_region_refiner.py:100-119).  The Gram is an
+// NT GEMM on the f64 MFMA core over a gathered, transposed, bias-augmented f64 copy of the
+// class's rows, formed chunk by chunk so that row shards / chunks simply accumulate.
+#include "odx_internal.h"
+
+namespace odx {
+
+// Xt[d][r] = X[idx[c0 + r]][d] (d < D), Xt[D][r] = 1, zero for r >= cn (pad up to ldt).
+__global__ __launch_bounds__(256) void rls_gather_transpose_kernel(const float* __restrict__ X, int64_t ldx, int D,
+                                                                   const int64_t* __restrict__ idx, int64_t c0,
+                                                                   int64_t cn, double* __restrict__ Xt, int64_t ldt) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int64_t r0 = (int64_t)blockIdx.x * 32;             // sample block
+  const int64_t d0 = (int64_t)blockIdx.y * 32;             // feature block (covers D + 1)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t r = r0 + ty + q * 8, d = d0 + tx;
+    double v = 0.0;
+    if (r < cn) {
+      if (d < D) v = (double)X[idx[c0 + r] * ldx + d];
+      else if (d == D) v = 1.0;
+    }
+    tile[ty + q * 8][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t d = d0 + ty + q * 8, r = r0 + tx;
+    if (d <= D && r < ldt) Xt[d * ldt + r] = tile[tx][ty + q * 8];
+  }
+}
+
+// P[i][k] = sum_d X[idx[i]][d] W[k][d] + W[k][D]; one wave per row, f64 accumulate.
+__global__ __launch_bounds__(256) void rls_predict_rows_kernel(const float* __restrict__ X, int64_t ldx, int D,
+                                                               const int64_t* __restrict__ idx, int64_t nc,
+                                                               const double* __restrict__ W, int64_t ldw,
+                                                               double* __restrict__ P, int64_t ldp) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= nc) return;
+  const float* x = X + (idx ? idx[i] : i) * ldx;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int d = lane; d < D; d += 64) {
+    const double xv = (double)x[d];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = fma(xv, W[k * ldw + d], s[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off);
+  }
+  if (lane < 4) P[i * ldp + lane] = s[lane] + W[lane * ldw + D];
+}
+
+static int64_t rls_chunk(int64_t workspace_bytes, int D) {
+  const int64_t D1 = D + 1;
+  int64_t chunk = workspace_bytes / (D1 * (int64_t)sizeof(double));
+  chunk = (chunk / 16) * 16;
+  return chunk;
+}
+
+}  // namespace odx
+
+using namespace odx;
+
+extern "C" int64_t odx_rls_gram_workspace_bytes(int64_t nc, int D) {
+  if (nc <= 0 || D <= 0) return 0;
+  int64_t chunk = round_up(nc, 16);
+  if (chunk > 32768) chunk = 32768;
+  return chunk * (int64_t)(D + 1) * (int64_t)sizeof(double);
+}
+
+extern "C" int odx_rls_gram_f64(const float* X, int64_t ldx, int D, const int64_t* idx, int64_t nc, const double* Yt,
+                                int64_t ldy, double* G, int64_t ldg, double* XtY, int64_t ldxy, void* workspace,
+                                int64_t workspace_bytes, odx_stream_t stream) {
+  if (nc <= 0) return ODX_OK;
+  ODX_REQUIRE(X && idx && Yt && G && XtY && workspace && D > 0, "odx_rls_gram_f64: bad argument");
+  ODX_REQUIRE(ldy % 2 == 0 && aligned16(Yt) && aligned16(workspace), "odx_rls_gram_f64: Yt/workspace must be 16-byte aligned, ldy even");
+  const int64_t D1 = D + 1;
+  ODX_REQUIRE(ldg >= D1 && ldxy >= D1, "odx_rls_gram_f64: ldg/ldxy < D + 1");
+  const int64_t chunk = rls_chunk(workspace_bytes, D);
+  if (chunk < 16) {
+    set_error("odx_rls_gram_f64: workspace too small for one 16-row chunk");
+    return ODX_ERR_WORKSPACE;
+  }
+  hipStream_t s = as_stream(stream);
+  double* Xt = static_cast<double*>(workspace);
+  for (int64_t c0 = 0; c0 < nc; c0 += chunk) {
+    const int64_t cn = nc - c0 < chunk ? nc - c0 : chunk;
+    const int64_t ldt = round_up(cn, 16);
+    dim3 grid((unsigned)ceil_div(ldt, 32), (unsigned)ceil_div(D1, 32));
+    hipLaunchKernelGGL(rls_gather_transpose_kernel, grid, dim3(256), 0, s, X, ldx, D, idx, c0, cn, Xt, ldt);
+    ODX_CHECK_LAUNCH("rls_gather_transpose");
+    GemmParams<double> g;
+    g.A = Xt; g.lda = ldt; g.B = Xt; g.ldb = ldt; g.C = G; g.ldc = ldg;
+    g.m = D1; g.n = D1; g.k = cn; g.alpha = 1.0; g.beta = 1.0; g.flags = ODX_GEMM_LOWER_ONLY;
+    ODX_PROPAGATE(launch_gemm_f64(g, s));
+    GemmParams<double> h;
+    h.A = Yt + c0; h.lda = ldy; h.B = Xt; h.ldb = ldt; h.C = XtY; h.ldc = ldxy;
+    h.m = 4; h.n = D1; h.k = cn; h.alpha = 1.0; h.beta = 1.0;
+    ODX_PROPAGATE(launch_gemm_f64(h, s));
+  }
+  return ODX_OK;
+}
+
+// workspace: Dinv | WT (D1*D1) | Li (D1 x ld) | Lit (D1 x ld) | z (ld)
+extern "C" int64_t odx_rls_solve_workspace_bytes(int D) {
+  if (D <= 0) return 0;
+  const int64_t D1 = D + 1, ld = round_up(D1, 2);
+  return odx_potrf_workspace_bytes(D1) + (round_up(D1 * D1, 2) + 2 * D1 * ld + ld) * (int64_t)sizeof(double);
+}
+
+extern "C" int odx_rls_solve_f64(double* G, int64_t ldg, int D, double lam, const double* XtY, int64_t ldxy, double* W,
+                                 int64_t ldw, int32_t* info, void* workspace, int64_t workspace_bytes,
+                                 odx_stream_t stream) {
+  ODX_REQUIRE(G && XtY && W && info && workspace && D > 0, "odx_rls_solve_f64: bad argument");
+  const int64_t D1 = D + 1, ld = round_up(D1, 2);
+  ODX_REQUIRE(ldg % 2 == 0 && ldg >= D1 && aligned16(G), "odx_rls_solve_f64: G must be 16-byte aligned with even ldg >= D + 1");
+  ODX_REQUIRE(ldxy % 2 == 0 && ldxy >= D1 && aligned16(XtY), "odx_rls_solve_f64: XtY must be 16-byte aligned with even ldxy");
+  ODX_REQUIRE(ldw >= D1 && aligned16(workspace), "odx_rls_solve_f64: ldw < D + 1 or unaligned workspace");
+  if (workspace_bytes < odx_rls_solve_workspace_bytes(D)) {
+    set_error("odx_rls_solve_f64: workspace too small");
+    return ODX_ERR_WORKSPACE;
+  }
+  hipStream_t s = as_stream(stream);
+  double* Dinv = static_cast<double*>(workspace);
+  double* WT = Dinv + ceil_div(D1, POTRF_NB) * POTRF_NB * POTRF_NB;
+  double* Li = WT + round_up(D1 * D1, 2);
+  double* Lit = Li + D1 * ld;
+  double* z = Lit + D1 * ld;
+  ODX_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), s));
+  ODX_PROPAGATE(add_diag_f64(G, ldg, D1, lam, s));
+  ODX_PROPAGATE(potrf_f64(G, ldg, D1, Dinv, info, s));
+  ODX_PROPAGATE(fill_f64(Li, ld, D1, D1, 0.0, s));
+  ODX_PROPAGATE(fill_f64(Lit, ld, D1, D1, 0.0, s));
+  ODX_PROPAGATE(trtri_from_diag_f64(G, ldg, D1, Dinv, Li, Lit, ld, WT, s));
+  for (int k = 0; k < 4; ++k) {
+    ODX_PROPAGATE(odx_trmv_f64(Li, ld, D1, 0, XtY + k * ldxy, 1.0, 0.0, nullptr, z, stream));
+    ODX_PROPAGATE(odx_trmv_f64(Lit, ld, D1, 1, z, 1.0, 0.0, nullptr, W + k * ldw, stream));
+  }
+  return ODX_OK;
+}
+
+extern "C" int odx_rls_predict_rows_f64(const float* X, int64_t ldx, int D, const int64_t* idx, int64_t nc,
+                                        const double* W, int64_t ldw, double* P, int64_t ldp, odx_stream_t stream) {
+  if (nc <= 0) return ODX_OK;
+  ODX_REQUIRE(X && W && P && D > 0 && ldw >= D + 1 && ldp >= 4, "odx_rls_predict_rows_f64: bad argument");
+  hipLaunchKernelGGL(rls_predict_rows_kernel, dim3((unsigned)ceil_div(nc, 4)), dim3(256), 0, as_stream(stream), X, ldx,
+                     D, idx, nc, W, ldw, P, ldp);
+  ODX_CHECK_LAUNCH("odx_rls_predict_rows_f64");
+  return ODX_OK;
+}

@@ -1,0 +1,251 @@
+"""HIP backend: torch tensors in, raw pointers into libodx.so, torch tensors out.
+
+This is the ONLY compute backend of the product.  PyTorch-ROCm is plumbing here (device
+memory, the current HIP stream, torch.distributed); no torch arithmetic stands in for a
+kernel.  ``tests/`` drive the same host logic (solver.py, dist.py, the drop-in modules) with
+a numpy-oracle backend of the same interface to exercise it on CPU / gloo.
+
+Interface used by the host logic (any backend provides exactly this):
+    features(X) -> Features          rows(F, idx) -> Features
+    precond(Zf, sigma, lam, eps) -> Precond
+    knm(F, Zf, sigma) -> Knm         ktk(K, v=None, w=None) -> vec(M) f64
+    trmv(P, name, x, alpha=1, beta=0, z=None) -> vec(M) f64
+    cg_init / cg_step / cg_finish / axpby on f64 vectors with a device-side state
+    mmv(F, Zf, sigma, V, ranges) -> (n, T) f32
+    vec(x) / zeros(n) f64 vectors on the backend's device
+"""
+import ctypes
+
+import torch
+
+from . import hip
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class Features:
+    """Row-major f32 rows (n x D, leading dimension a multiple of 4) plus their squared norms."""
+    __slots__ = ("X", "sq", "n", "D", "ld")
+
+    def __init__(self, X, sq, D):
+        self.X, self.sq, self.n, self.D, self.ld = X, sq, X.shape[0], D, X.stride(0) if X.shape[0] else X.shape[1]
+
+
+class Precond:
+    """Inverse Cholesky factors of the FALKON preconditioner, f64, row-major (M x ld)."""
+    __slots__ = ("LTi", "LTit", "LAi", "LAit", "M", "ld", "info")
+
+
+class Knm:
+    __slots__ = ("K", "n", "M", "ld")
+
+
+class HipBackend:
+    name = "hip-gfx950"
+
+    def __init__(self, device=None):
+        self.lib = hip.require_gpu()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._ws = {}
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, key, nbytes):
+        nbytes = max(int(nbytes), 16)
+        buf = self._ws.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = None
+            self._ws.pop(key, None)
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws[key] = buf
+        return buf
+
+    def release_workspaces(self):
+        self._ws.clear()
+
+    def vec(self, x):
+        return torch.as_tensor(x, dtype=torch.float64, device=self.device).contiguous()
+
+    def zeros(self, n, dtype=torch.float64):
+        return torch.zeros(n, dtype=dtype, device=self.device)
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
+
+    # ------------------------------------------------------------------ features
+    def features(self, X):
+        """Adopt (n, D) rows as kernel operands: f32, row stride a multiple of 4 elements,
+        16-byte aligned (copied only when the caller's tensor is not already so)."""
+        if not torch.is_tensor(X):
+            X = torch.as_tensor(X)
+        X = X.to(device=self.device, dtype=torch.float32)
+        if X.dim() != 2:
+            raise ValueError("features: expected a 2-D (n, D) tensor, got shape %s" % (tuple(X.shape),))
+        n, D = X.shape
+        ok = X.stride(1) == 1 and (n == 0 or (X.stride(0) % 4 == 0 and X.stride(0) >= D)) and X.data_ptr() % 16 == 0
+        if not ok:
+            ld = (D + 3) // 4 * 4
+            buf = torch.zeros((n, ld), dtype=torch.float32, device=self.device)
+            buf[:, :D] = X
+            X = buf[:, :D]
+        sq = torch.empty(n, dtype=torch.float32, device=self.device)
+        if n:
+            hip.check(self.lib.odx_row_sqnorm_f32(_p(X), X.stride(0), n, D, _p(sq), self._stream()), "odx_row_sqnorm_f32")
+        return Features(X, sq, D)
+
+    def rows(self, F, idx):
+        """MyCenterSelector.select: gather rows (and their norms) by index."""
+        idx = torch.as_tensor(idx, dtype=torch.int64, device=self.device).reshape(-1)
+        ld = (F.D + 3) // 4 * 4
+        buf = torch.zeros((idx.numel(), ld), dtype=torch.float32, device=self.device)
+        buf[:, :F.D] = F.X.index_select(0, idx)
+        return Features(buf[:, :F.D], F.sq.index_select(0, idx), F.D)
+
+    # ------------------------------------------------------------------ FALKON pieces
+    def precond(self, Zf, sigma, lam, eps):
+        M, D = Zf.n, Zf.D
+        ld = (M + 1) // 2 * 2
+        P = Precond()
+        P.M, P.ld = M, ld
+        mats = torch.empty((4, M, ld), dtype=torch.float64, device=self.device)
+        P.LTi, P.LTit, P.LAi, P.LAit = mats[0], mats[1], mats[2], mats[3]
+        P.info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        nbytes = self.lib.odx_falkon_precond_workspace_bytes(M, D)
+        ws = self._workspace("precond", nbytes)
+        hip.check(self.lib.odx_falkon_precond_f64(_p(Zf.X), Zf.ld, M, D, float(sigma), float(lam), float(eps),
+                                                  _p(P.LTi), _p(P.LTit), _p(P.LAi), _p(P.LAit), ld, _p(P.info),
+                                                  _p(ws), ws.numel(), self._stream()), "odx_falkon_precond_f64")
+        return P
+
+    def check_precond(self, P):
+        info = int(P.info.item())
+        if info != 0:
+            raise hip.OdxError("FALKON preconditioner: non-positive pivot at index %d (Cholesky failed)" % (info - 1))
+
+    def knm(self, F, Zf, sigma, out=None):
+        n, M = F.n, Zf.n
+        ld = (M + 3) // 4 * 4
+        K = Knm()
+        K.n, K.M, K.ld = n, M, ld
+        if out is not None:
+            if out.numel() < n * ld or out.dtype != torch.float32:
+                raise ValueError("knm: out buffer too small")
+            K.K = out.view(-1)[: n * ld].view(n, ld)
+        else:
+            K.K = torch.empty((n, ld), dtype=torch.float32, device=self.device)
+        hip.check(self.lib.odx_gauss_knm_f32(_p(F.X), F.ld, _p(F.sq), n, _p(Zf.X), Zf.ld, _p(Zf.sq), M, F.D,
+                                             float(sigma), _p(K.K), ld, self._stream()), "odx_gauss_knm_f32")
+        return K
+
+    def ktk(self, K, v=None, w=None, out=None):
+        """out = K' (K v + w) over this shard (f64)."""
+        if out is None:
+            out = torch.empty(K.M, dtype=torch.float64, device=self.device)
+        nbytes = self.lib.odx_knm_fwd_bwd_workspace_bytes(max(K.n, 1), K.M)
+        if nbytes < 0:
+            raise hip.OdxError("odx_knm_fwd_bwd: M = %d is outside the supported range" % K.M)
+        ws = self._workspace("ktk", nbytes)
+        hip.check(self.lib.odx_knm_fwd_bwd(_p(K.K), K.ld, K.n, K.M, _p(v), _p(w), _p(out), _p(ws), ws.numel(),
+                                           self._stream()), "odx_knm_fwd_bwd")
+        return out
+
+    _TRI = {"LTi": 0, "LTit": 1, "LAi": 0, "LAit": 1}
+
+    def trmv(self, P, name, x, alpha=1.0, beta=0.0, z=None, out=None):
+        """out = alpha * P.<name> x + beta * z   (name in LTi / LTit / LAi / LAit)."""
+        if out is None:
+            out = torch.empty(P.M, dtype=torch.float64, device=self.device)
+        hip.check(self.lib.odx_trmv_f64(_p(getattr(P, name)), P.ld, P.M, self._TRI[name], _p(x), float(alpha),
+                                        float(beta), _p(z), _p(out), self._stream()), "odx_trmv_f64")
+        return out
+
+    def cg_init(self, B, X, R, Pv, state):
+        hip.check(self.lib.odx_cg_init(_p(B), _p(X), _p(R), _p(Pv), _p(state), B.numel(), self._stream()), "odx_cg_init")
+
+    def cg_step(self, X, R, Pv, AP, state, cg_eps, full_grad):
+        hip.check(self.lib.odx_cg_step(_p(X), _p(R), _p(Pv), _p(AP), _p(state), float(cg_eps), int(bool(full_grad)),
+                                       X.numel(), self._stream()), "odx_cg_step")
+
+    def cg_finish(self, R, Pv, state, cg_eps, tol):
+        hip.check(self.lib.odx_cg_finish(_p(R), _p(Pv), _p(state), float(cg_eps), float(tol), R.numel(),
+                                         self._stream()), "odx_cg_finish")
+
+    def axpby(self, a, x, b, y):
+        hip.check(self.lib.odx_axpby_f64(float(a), _p(x), float(b), _p(y), y.numel(), self._stream()), "odx_axpby_f64")
+
+    # ------------------------------------------------------------------ scoring
+    def mmv(self, F, Zf, sigma, V, ranges=None, out=None):
+        """(n, T) f32 = K(F, Zf) @ V with V (Mtot, T) f64; ``ranges`` (T, 2) int32 row ranges of the
+        non-zero block of each column (None = dense)."""
+        V = V.to(device=self.device, dtype=torch.float64)
+        if V.dim() == 1:
+            V = V[:, None]
+        V = V.contiguous()
+        Mtot, T = V.shape
+        if Mtot != Zf.n:
+            raise ValueError("mmv: V has %d rows but there are %d centres" % (Mtot, Zf.n))
+        if ranges is None:
+            ranges = torch.tensor([[0, Mtot]] * T, dtype=torch.int32, device=self.device)
+        ranges = ranges.to(device=self.device, dtype=torch.int32).contiguous()
+        if out is None:
+            out = torch.empty((F.n, T), dtype=torch.float32, device=self.device)
+        if F.n == 0 or T == 0:
+            return out
+        if Mtot == 0:
+            return out.zero_()
+        hip.check(self.lib.odx_gauss_mmv_f32(_p(F.X), F.ld, _p(F.sq), F.n, _p(Zf.X), Zf.ld, _p(Zf.sq), F.D,
+                                             float(sigma), _p(V), V.stride(0), _p(ranges), T, _p(out), out.stride(0),
+                                             self._stream()), "odx_gauss_mmv_f32")
+        return out
+
+    # ------------------------------------------------------------------ RLS (A7)
+    def rls_gram(self, F, idx, Yt, G, XtY):
+        """G (D1 x D1 lower) += [X 1]'[X 1],  XtY (4 x D1) += Yt [X 1]  over rows ``idx`` of F."""
+        nc = idx.numel()
+        if nc == 0:
+            return
+        nbytes = self.lib.odx_rls_gram_workspace_bytes(nc, F.D)
+        ws = self._workspace("rls_gram", nbytes)
+        hip.check(self.lib.odx_rls_gram_f64(_p(F.X), F.ld, F.D, _p(idx), nc, _p(Yt), Yt.stride(0), _p(G), G.stride(0),
+                                            _p(XtY), XtY.stride(0), _p(ws), ws.numel(), self._stream()),
+                  "odx_rls_gram_f64")
+
+    def rls_solve(self, G, D, lam, XtY):
+        D1 = D + 1
+        W = torch.empty((4, D1), dtype=torch.float64, device=self.device)
+        info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        nbytes = self.lib.odx_rls_solve_workspace_bytes(D)
+        ws = self._workspace("rls_solve", nbytes)
+        hip.check(self.lib.odx_rls_solve_f64(_p(G), G.stride(0), D, float(lam), _p(XtY), XtY.stride(0), _p(W),
+                                             W.stride(0), _p(info), _p(ws), ws.numel(), self._stream()),
+                  "odx_rls_solve_f64")
+        return W, info
+
+    def rls_predict_rows(self, F, idx, W):
+        nc = F.n if idx is None else idx.numel()
+        Pm = torch.empty((nc, 4), dtype=torch.float64, device=self.device)
+        if nc:
+            hip.check(self.lib.odx_rls_predict_rows_f64(_p(F.X), F.ld, F.D, _p(idx), nc, _p(W), W.stride(0), _p(Pm), 4,
+                                                        self._stream()), "odx_rls_predict_rows_f64")
+        return Pm
+
+
+_BACKEND = None
+
+
+def get_backend():
+    """The process-wide HIP backend (created on first use; raises loudly without GPU / library)."""
+    global _BACKEND
+    if _BACKEND is None:
+        _BACKEND = HipBackend()
+    return _BACKEND
+
+
+def set_backend(b):
+    """Tests only: install a backend object (e.g. the numpy-oracle backend of tests/)."""
+    global _BACKEND
+    _BACKEND = b

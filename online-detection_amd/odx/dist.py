@@ -1,0 +1,48 @@
+"""Row sharding over the GPUs of one node: the n rows (and their labels) are split
+contiguously over the ranks, the M centres, the preconditioner and every CG vector are
+replicated, and each CG iteration exchanges exactly one all-reduce(sum) of the (M,) f64
+partial of K_nM'(K_nM v).  One process per GPU; the collective is RCCL through
+torch.distributed (backend "nccl" on ROCm) — "gloo" in the CPU tests.
+
+The reference has no counterpart (it is single-process); this is new design.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous, balanced split of n rows: the first n % world ranks get one extra row."""
+    base, extra = divmod(int(n), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class RowShard:
+    def __init__(self, group=None):
+        self.group = group
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.enabled else 1
+        self.rank = dist.get_rank(group) if self.enabled else 0
+
+    def bounds(self, n):
+        return shard_bounds(n, self.world, self.rank)
+
+    def allreduce(self, v):
+        """In-place sum over the row shards; returns v."""
+        if self.enabled:
+            dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+        return v
+
+    def total(self, n_local):
+        if not self.enabled:
+            return int(n_local)
+        t = torch.tensor([int(n_local)], dtype=torch.int64)
+        if dist.get_backend(self.group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return int(t.item())
+
+    def broadcast(self, t, src=0):
+        if self.enabled:
+            dist.broadcast(t, src=src, group=self.group)
+        return t

@@ -1,0 +1,151 @@
+"""falkon-shaped estimator objects backed by libodx.
+
+The reference never touches FALKON's arithmetic itself; it constructs
+``kernels.GaussianKernel(sigma)``, ``FalkonOptions(...)`` and ``InCoreFalkon`` / ``Falkon`` and
+calls ``fit`` / ``predict`` / ``kernel.mmv``
+(src/modules/region-classifier/FALKONWrapper_with_centers_selection_incore.py:50-82,
+ FALKONWrapper_with_centers_selection.py:49-78,
+ mrcnn_modified/modeling/roi_heads/box_head/roi_box_predictors.py:136-158,
+ mrcnn_modified/modeling/rpn/rpn.py:197-225).  This module provides objects with that
+surface — constructor keywords, ``fit(X, Y)``, ``predict(X) -> (n, 1)``, attributes
+``ny_points_ / alpha_ / M / kernel`` (re-assignable, deep-copyable, picklable) — so that
+the drop-in wrappers in ``src/modules/region-classifier`` stay as thin as the reference's,
+and so that ``sys.modules['falkon'] = odx.falkon`` is a valid binding for the reference's
+own wrapper files.
+"""
+import types
+
+import torch
+
+from . import backend as _backend
+from .solver import SolverOptions, falkon_fit
+
+
+class FalkonOptions:
+    """Accepts falkon's option keywords.  The ones that steer arithmetic are honoured
+    (pc_epsilon_32, cg_epsilon_32, cg_tolerance, cg_full_gradient_every); the memory /
+    dispatch knobs the reference passes (min_cuda_iter_size_*, min_cuda_pc_size_*,
+    keops_active, store_kernel_d_threshold — FALKONWrapper_..._incore.py:56) have nothing to
+    select here: K_nM is always materialised on the GPU and nothing runs on the CPU."""
+
+    def __init__(self, **kw):
+        self.pc_epsilon_32 = kw.pop("pc_epsilon_32", 1e-5)
+        self.cg_epsilon_32 = kw.pop("cg_epsilon_32", 1e-7)
+        self.cg_tolerance = kw.pop("cg_tolerance", 1e-7)
+        self.cg_full_gradient_every = kw.pop("cg_full_gradient_every", 10)
+        self.extra = dict(kw)
+
+    def solver_options(self):
+        return SolverOptions(pc_epsilon=self.pc_epsilon_32, cg_epsilon=self.cg_epsilon_32,
+                             cg_tolerance=self.cg_tolerance, cg_full_gradient_every=self.cg_full_gradient_every)
+
+
+class GaussianKernel:
+    """K(x, z) = exp(-|x - z|^2 / (2 sigma^2)); ``mmv`` is the fused scoring kernel."""
+    kernel_name = "gaussian"
+
+    def __init__(self, sigma, opt=None):
+        self.sigma = float(sigma)
+
+    def mmv(self, X1, X2, v, out=None, opt=None):
+        """K(X1, X2) @ v -> (n, T) f32.  A block-structured v (the heads' alpha_parallel) is
+        detected and only its non-zero row range per column is visited."""
+        be = _backend.get_backend()
+        F = be.features(X1)
+        Zf = be.features(X2)
+        v = torch.as_tensor(v)
+        if v.dim() == 1:
+            v = v[:, None]
+        ranges = block_ranges(v)
+        res = be.mmv(F, Zf, self.sigma, v, ranges)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+
+    def __repr__(self):
+        return "GaussianKernel(sigma=%g)" % self.sigma
+
+
+def block_ranges(v):
+    """Per column: [first non-zero row, last non-zero row + 1) as an int32 (T, 2) tensor."""
+    nz = v != 0
+    Mtot, T = v.shape
+    if Mtot == 0:
+        return torch.zeros((T, 2), dtype=torch.int32, device=v.device)
+    idx = torch.arange(Mtot, device=v.device)[:, None]
+    big = torch.where(nz, idx, torch.full_like(idx, Mtot)).amin(0)
+    end = torch.where(nz, idx + 1, torch.zeros_like(idx)).amax(0)
+    lo = torch.minimum(big, end)
+    return torch.stack([lo, end], dim=1).to(torch.int32)
+
+
+class _FalkonBase:
+    """Common fit / predict.  ``center_selection.select(X, Y)`` follows MyCenterSelector
+    (src/modules/region-classifier/MyCenterSelector.py:7-15)."""
+    _cpu_model = False
+
+    def __init__(self, kernel, penalty, M, center_selection="uniform", maxiter=20, seed=None,
+                 error_fn=None, error_every=1, options=None, **_ignored):
+        self.kernel = kernel
+        self.penalty = penalty
+        self.M = M
+        self.maxiter = maxiter
+        self.center_selection = center_selection
+        self.options = options if options is not None else FalkonOptions()
+        self.seed = seed
+        self.alpha_ = None
+        self.ny_points_ = None
+
+    def fit(self, X, Y, Xts=None, Yts=None):
+        be = _backend.get_backend()
+        F = be.features(X)
+        if isinstance(self.center_selection, str):
+            idx = torch.randperm(F.n)[: self.M]
+            Zf = be.rows(F, idx)
+        else:
+            sel = self.center_selection.select(F.X, None)
+            Z = sel[0] if isinstance(sel, tuple) else sel
+            Zf = be.features(Z)
+        self.M = Zf.n
+        y = torch.as_tensor(Y).reshape(F.n, -1)
+        if y.shape[1] != 1:
+            raise ValueError("odx FALKON fits one right-hand side per model (the reference trains one "
+                             "binary classifier per fit); got Y with %d columns" % y.shape[1])
+        yv = be.vec(y[:, 0])
+        alpha = falkon_fit(be, F, yv, Zf, self.kernel.sigma, float(self.penalty), int(self.maxiter),
+                           self.options.solver_options())
+        ny = Zf.X.contiguous() if Zf.X.stride(0) != Zf.D else Zf.X
+        self.alpha_ = alpha.reshape(-1, 1)
+        self.ny_points_ = ny
+        if self._cpu_model:
+            self.alpha_ = self.alpha_.cpu()
+            self.ny_points_ = self.ny_points_.cpu()
+        return self
+
+    def predict(self, X):
+        if self.alpha_ is None:
+            raise RuntimeError("predict called before fit")
+        res = self.kernel.mmv(X, self.ny_points_, self.alpha_)
+        if self._cpu_model and not (torch.is_tensor(X) and X.is_cuda):
+            res = res.cpu()
+        return res
+
+    def __bool__(self):
+        return True
+
+
+class InCoreFalkon(_FalkonBase):
+    """GPU-resident estimator (FALKONWrapper_with_centers_selection_incore.py:58-68)."""
+
+
+class Falkon(_FalkonBase):
+    """The reference's `--CPU` estimator (FALKONWrapper_with_centers_selection.py:53-64) keeps
+    data and model on the host; here the rows are staged to the GPU for the fit and the model
+    tensors are handed back on the host, so the callers' device moves stay valid."""
+    _cpu_model = True
+
+
+# `from falkon import kernels` / `from falkon.options import *` surfaces
+kernels = types.SimpleNamespace(GaussianKernel=GaussianKernel)
+options = types.SimpleNamespace(FalkonOptions=FalkonOptions)

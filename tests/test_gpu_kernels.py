@@ -1,0 +1,236 @@
+"""Kernel-level parity on the MI355X: every libodx entry point against the numpy oracle
+(oracle/falkon_ref.py) or numpy/scipy itself, through the C ABI, including ragged shapes."""
+import ctypes
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def be():
+    import odx
+    return odx.get_backend()
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def dev(a, dtype=None):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("m,n,k", [(128, 128, 64), (200, 136, 100), (1, 5, 3), (257, 129, 36), (384, 256, 1024)])
+def test_gemm_nt(be, dtype, m, n, k):
+    from odx import hip
+    rng = np.random.default_rng(m * 7 + n * 3 + k)
+    epv = 4 if dtype == np.float32 else 2
+    lda = (k + epv - 1) // epv * epv
+    A = np.zeros((m, lda), dtype); A[:, :k] = rng.standard_normal((m, k))
+    B = np.zeros((n, lda), dtype); B[:, :k] = rng.standard_normal((n, k))
+    # asymmetric operands: a swapped row/col map in the C write cannot hide
+    C0 = rng.standard_normal((m, n)).astype(dtype)
+    dA, dB, dC = dev(A), dev(B), dev(C0)
+    fn = be.lib.odx_gemm_nt_f32 if dtype == np.float32 else be.lib.odx_gemm_nt_f64
+    hip.check(fn(_p(dA), lda, _p(dB), lda, _p(dC), n, m, n, k, 1.5, -0.5, 0, be._stream()))
+    ref = 1.5 * (A[:, :k].astype(np.float64) @ B[:, :k].astype(np.float64).T) - 0.5 * C0
+    tol = 2e-5 if dtype == np.float32 else 1e-12
+    got = dC.cpu().numpy()
+    assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max())
+
+
+def test_gemm_identity_asymmetric(be):
+    """A = I with an asymmetric B: C must equal B' exactly (guards the MFMA lane maps)."""
+    from odx import hip
+    for dtype, fn in ((np.float32, be.lib.odx_gemm_nt_f32), (np.float64, be.lib.odx_gemm_nt_f64)):
+        n = 128
+        A = np.eye(n, dtype=dtype)
+        B = (np.arange(n * n, dtype=dtype).reshape(n, n) % 251) + np.arange(n, dtype=dtype)[:, None] * 3
+        dA, dB, dC = dev(A), dev(B), dev(np.zeros((n, n), dtype))
+        hip.check(fn(_p(dA), n, _p(dB), n, _p(dC), n, n, n, n, 1.0, 0.0, 0, be._stream()))
+        assert np.array_equal(dC.cpu().numpy(), B.T)
+
+
+def test_gemm_flags(be):
+    from odx import hip
+    rng = np.random.default_rng(5)
+    n = 300
+    U = np.triu(rng.standard_normal((n, n)))
+    L = np.tril(rng.standard_normal((n, n)))
+    # upper x upper', lower tiles only
+    dU, dC = dev(U), dev(np.zeros((n, n)))
+    hip.check(be.lib.odx_gemm_nt_f64(_p(dU), n, _p(dU), n, _p(dC), n, n, n, n, 1.0, 0.0,
+                                     hip.GEMM_LOWER_ONLY | hip.GEMM_A_UPPER | hip.GEMM_B_UPPER, be._stream()))
+    ref = U @ U.T
+    got = dC.cpu().numpy()
+    assert np.abs(np.tril(got) - np.tril(ref)).max() < 1e-11
+    # lower A, transposed store
+    dL, dB, dC = dev(L), dev(rng.standard_normal((n, n))), dev(np.zeros((n, n)))
+    Bh = dB.cpu().numpy()
+    hip.check(be.lib.odx_gemm_nt_f64(_p(dL), n, _p(dB), n, _p(dC), n, n, n, n, -1.0, 0.0,
+                                     hip.GEMM_A_LOWER | hip.GEMM_STORE_T, be._stream()))
+    assert np.abs(dC.cpu().numpy() - (-(L @ Bh.T)).T).max() < 1e-11
+
+
+@pytest.mark.parametrize("n,M,D,sigma", [(1000, 500, 256, 10.0), (333, 130, 1024, 15.0), (129, 7, 36, 5.0), (64, 2000, 2048, 20.0)])
+def test_gauss_knm(be, n, M, D, sigma):
+    from oracle import falkon_ref as fr
+    from tests.synth import blob_problem
+    X, y, rng = blob_problem(n + M, D, seed=n + M + D)
+    Z = X[n:]
+    X = X[:n]
+    F, Zf = be.features(torch.from_numpy(X)), be.features(torch.from_numpy(Z))
+    assert np.allclose(F.sq.cpu().numpy(), (X.astype(np.float64) ** 2).sum(1), rtol=1e-5)
+    K = be.knm(F, Zf, sigma)
+    got = K.K.cpu().numpy()
+    ref = fr.gaussian_kernel(X.astype(np.float64), Z.astype(np.float64), sigma)
+    assert np.abs(got[:, :M] - ref).max() < 2e-5
+    assert np.all(got[:, M:] == 0)
+    # duplicate centre / identical point -> clamp at 0 -> exactly 1
+    Z2 = be.features(torch.from_numpy(X[:5].copy()))
+    K2 = be.knm(F, Z2, sigma).K.cpu().numpy()
+    assert np.all(np.abs(np.diag(K2[:5, :5]) - 1.0) < 1e-4)
+
+
+@pytest.mark.parametrize("n,M", [(1000, 500), (4097, 2000), (37, 130), (700, 3000), (520, 10000), (300, 12001), (200, 20000)])
+def test_knm_fwd_bwd(be, n, M):
+    rng = np.random.default_rng(n + M)
+    ld = (M + 3) // 4 * 4
+    Kh = np.zeros((n, ld), np.float32)
+    Kh[:, :M] = rng.random((n, M), dtype=np.float32)
+    v = rng.standard_normal(M)
+    w = rng.standard_normal(n)
+    from odx.backend import Knm
+    K = Knm(); K.K = dev(Kh); K.n, K.M, K.ld = n, M, ld
+    K64 = Kh[:, :M].astype(np.float64)
+    out = be.ktk(K, v=dev(v), w=dev(w)).cpu().numpy()
+    ref = K64.T @ (K64 @ v + w)
+    assert np.abs(out - ref).max() <= 1e-12 * np.abs(ref).max() + 1e-12
+    out = be.ktk(K, w=dev(w)).cpu().numpy()
+    assert np.abs(out - K64.T @ w).max() <= 1e-12 * np.abs(ref).max() + 1e-12
+    out2 = be.ktk(K, v=dev(v)).cpu().numpy()
+    out3 = be.ktk(K, v=dev(v)).cpu().numpy()
+    assert np.array_equal(out2, out3)  # fixed-order reduction: bitwise reproducible
+
+
+@pytest.mark.parametrize("M", [1, 100, 128, 129, 300, 1000, 1537])
+def test_potrf_trtri(be, M):
+    from odx import hip
+    rng = np.random.default_rng(M)
+    G = rng.standard_normal((M, M + 20))
+    A = G @ G.T / (M + 20) + 0.1 * np.eye(M)
+    ld = (M + 1) // 2 * 2
+    Ah = np.zeros((M, ld)); Ah[:, :M] = np.tril(A)
+    Ah[:, :M] += np.triu(rng.standard_normal((M, M)), 1) * 0  # upper part is not read
+    dA = dev(Ah)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ws = torch.empty(max(be.lib.odx_potrf_workspace_bytes(M), 16), dtype=torch.uint8, device="cuda")
+    hip.check(be.lib.odx_potrf_f64(_p(dA), ld, M, _p(info), _p(ws), ws.numel(), be._stream()))
+    L = dA.cpu().numpy()[:, :M]
+    assert int(info.item()) == 0
+    Lref = sla.cholesky(A, lower=True)
+    assert np.abs(L - Lref).max() < 1e-10
+    assert np.all(np.triu(L, 1) == 0)
+    Li = torch.zeros((M, ld), dtype=torch.float64, device="cuda")
+    Lit = torch.zeros((M, ld), dtype=torch.float64, device="cuda")
+    ws2 = torch.empty(max(be.lib.odx_trtri_workspace_bytes(M), 16), dtype=torch.uint8, device="cuda")
+    hip.check(be.lib.odx_trtri_f64(_p(dA), ld, M, _p(Li), _p(Lit), ld, _p(ws2), ws2.numel(), be._stream()))
+    Liref = np.linalg.inv(Lref)
+    assert np.abs(Li.cpu().numpy()[:, :M] - Liref).max() < 1e-9 * max(1.0, np.abs(Liref).max())
+    assert np.abs(Lit.cpu().numpy()[:, :M] - Liref.T).max() < 1e-9 * max(1.0, np.abs(Liref).max())
+
+
+def test_potrf_reports_bad_pivot(be):
+    from odx import hip
+    M = 200
+    A = np.eye(M); A[150, 150] = -1.0
+    dA = dev(A)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ws = torch.empty(be.lib.odx_potrf_workspace_bytes(M), dtype=torch.uint8, device="cuda")
+    hip.check(be.lib.odx_potrf_f64(_p(dA), M, M, _p(info), _p(ws), ws.numel(), be._stream()))
+    assert int(info.item()) == 151
+
+
+@pytest.mark.parametrize("M,D,sigma,lam", [(500, 256, 10.0, 1e-5), (333, 64, 5.0, 1e-4), (1300, 1024, 15.0, 1e-5)])
+def test_precond_identities(be, M, D, sigma, lam):
+    from oracle import falkon_ref as fr
+    from tests.synth import blob_problem
+    Z, _, _ = blob_problem(M, D, seed=M)
+    Zf = be.features(torch.from_numpy(Z))
+    eps = 1e-5
+    P = be.precond(Zf, sigma, lam, eps)
+    be.check_precond(P)
+    ref = fr.Preconditioner(Z.astype(np.float64), sigma, lam, eps, np.float64)
+    Ti = np.linalg.inv(ref.T)   # T upper
+    Ai = np.linalg.inv(ref.A)
+    sc = lambda a: max(1.0, np.abs(a).max())
+    assert np.abs(P.LTit.cpu().numpy()[:, :M] - Ti).max() < 1e-7 * sc(Ti)
+    assert np.abs(P.LTi.cpu().numpy()[:, :M] - Ti.T).max() < 1e-7 * sc(Ti)
+    assert np.abs(P.LAit.cpu().numpy()[:, :M] - Ai).max() < 1e-7 * sc(Ai)
+    assert np.abs(P.LAi.cpu().numpy()[:, :M] - Ai.T).max() < 1e-7 * sc(Ai)
+    x = np.random.default_rng(0).standard_normal(M)
+    z = np.random.default_rng(1).standard_normal(M)
+    got = be.trmv(P, "LTi", dev(x), alpha=0.5, beta=2.0, z=dev(z)).cpu().numpy()
+    assert np.abs(got - (0.5 * Ti.T @ x + 2.0 * z)).max() < 1e-8 * sc(Ti) * 10
+
+
+@pytest.mark.parametrize("n,M,D,sigma,lam", [(5000, 500, 256, 10.0, 1e-5), (5000, 500, 256, 15.0, 1e-5),
+                                              (3000, 300, 1024, 15.0, 1e-5), (2500, 1000, 2048, 5.0, 1e-4),
+                                              (777, 129, 36, 5.0, 1e-3)])
+def test_falkon_fit_alpha_parity(be, n, M, D, sigma, lam):
+    """The north-star bar: learned alphas within 1e-4 relative of the reference algorithm
+    evaluated in exact (f64) arithmetic with falkon's f32-regime constants, same inputs."""
+    import odx
+    from oracle import falkon_ref as fr
+    from tests.synth import blob_problem, centres
+    X, y, rng = blob_problem(n, D, seed=n + M)
+    idx = centres(y, M, rng)
+    ref, Z = fr.falkon_fit(X.astype(np.float64), y.astype(np.float64), idx, sigma, lam, maxiter=20,
+                           dtype=np.float64, pc_eps=1e-5, cg_epsilon=1e-7)
+    F = be.features(torch.from_numpy(X))
+    Zf = be.rows(F, idx)
+    alpha = odx.falkon_fit(be, F, be.vec(y), Zf, sigma, lam, 20).cpu().numpy()
+    rel = np.linalg.norm(alpha - ref[:, 0]) / np.linalg.norm(ref[:, 0])
+    assert rel < 1e-4, rel
+    # and the scores it produces
+    pred = be.mmv(F, Zf, sigma, torch.from_numpy(alpha)).cpu().numpy()
+    pref = fr.falkon_predict(X.astype(np.float64), Z, ref, sigma)
+    assert np.abs(pred - pref).max() < 1e-4
+
+
+def test_mmv_block_structure(be):
+    from odx.falkon import block_ranges
+    from oracle import falkon_ref as fr
+    from tests.synth import blob_problem
+    D, sigma = 256, 10.0
+    X, _, rng = blob_problem(700, D, seed=3)
+    Ms = [130, 0, 257, 64]
+    models = []
+    for m in Ms:
+        if m == 0:
+            models.append(None)
+        else:
+            Zc, _, _ = blob_problem(m, D, seed=100 + m)
+            models.append((Zc, rng.standard_normal(m)))
+    ref = fr.scores_parallel(X.astype(np.float64), [None if m is None else (m[0].astype(np.float64), m[1]) for m in models],
+                             sigma, missing_fill=0.0, background=False)
+    ny = np.concatenate([m[0] for m in models if m is not None])
+    V = np.zeros((ny.shape[0], len(models)))
+    r = 0
+    for i, m in enumerate(models):
+        if m is not None:
+            V[r:r + m[0].shape[0], i] = m[1]
+            r += m[0].shape[0]
+    Vt = torch.from_numpy(V).cuda()
+    rg = block_ranges(Vt)
+    assert rg.cpu().tolist() == [[0, 130], [0, 0], [130, 387], [387, 451]]
+    got = be.mmv(be.features(torch.from_numpy(X)), be.features(torch.from_numpy(ny)), sigma, Vt, rg).cpu().numpy()
+    assert np.abs(got - ref).max() < 5e-5 * max(1.0, np.abs(ref).max())
+    dense = be.mmv(be.features(torch.from_numpy(X)), be.features(torch.from_numpy(ny)), sigma, Vt, None).cpu().numpy()
+    assert np.abs(dense - ref).max() < 5e-5 * max(1.0, np.abs(ref).max())
