@@ -1,0 +1,339 @@
+#!/usr/bin/env python3
+"""Headline benchmark: FALKON fit + infer samples/sec (N=1e6, D=1024, M=1e4, 30 classes).
+
+One "step" = one pass of the hot path over the whole synthetic job: for each of the C classes
+fit a FALKON classifier on the N rows (Nystroem centres by the reference rule, f64
+preconditioner, f32 K_nM build, 20 CG iterations on the stored K_nM) and score all N rows with
+it.  The N rows are sharded contiguously over the ranks (one process per GPU); each CG
+iteration exchanges one all-reduce of an (M,) f64 vector (RCCL).  N is the job size at every
+GPU count => "scaling": "strong".
+
+    python bench.py [--gpus N --steps K --warmup W] [--n 1000000 --D 1024 --M 10000 --classes 30]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the round prompt).  Inputs are resident in HBM before
+the timed region.  `roofline` is measured live with HIP events around the dominant kernel's
+launches; `cpu_baseline` times the numpy oracle on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "online-detection_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: Peak FP32 (matrix)
+HBM_PEAK_GBS = 8000.0          # HBM3E spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--D", type=int, default=1024)
+    ap.add_argument("--M", type=int, default=10_000)
+    ap.add_argument("--classes", type=int, default=30)
+    ap.add_argument("--sigma", type=float, default=15.0)
+    ap.add_argument("--lam", type=float, default=1e-5)
+    ap.add_argument("--maxiter", type=int, default=20)
+    ap.add_argument("--warmup-classes", type=int, default=2, help="classes run per warm-up step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=20000)
+    ap.add_argument("--check", action="store_true", help="verify one class against the oracle on a row sample")
+    return ap.parse_args()
+
+
+def synth_rows(n_lo, n_hi, D, C, seed, device):
+    """Rows [n_lo, n_hi) of the synthetic job: class blobs mu_c + 0.7 eps, normalised with the
+    reference rule (x - mean) * 20 / mean_norm (OnlineRegionClassifier.py:224-227); row i has
+    class id i % C (one-vs-rest labels, N/C positives per class).  Generated in blocks from
+    per-block seeds so any shard can be produced independently and identically."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    mu = torch.randn(C, D, generator=g).to(device)
+    X = torch.empty((n_hi - n_lo, D), dtype=torch.float32, device=device)
+    blk = 65536
+    for b0 in range((n_lo // blk) * blk, n_hi, blk):
+        gb = torch.Generator(device=device).manual_seed(seed * 1000003 + b0 // blk)
+        e = torch.randn((blk, D), generator=gb, device=device, dtype=torch.float32)
+        ids = (torch.arange(b0, b0 + blk, device=device) % C)
+        rows = mu[ids] + 0.7 * e
+        lo, hi = max(b0, n_lo), min(b0 + blk, n_hi)
+        X[lo - n_lo:hi - n_lo] = rows[lo - b0:hi - b0]
+    # population statistics of this generator (mean of the blob centres; E|x| by sampling)
+    mean = mu.mean(0)
+    X -= mean
+    # the blob spread and the noise make |x|^2 ~ |mu_c - mean|^2 + 0.49 D: use the exact expectation
+    mean_norm = torch.sqrt(((mu - mean) ** 2).sum(1) + 0.49 * D).mean()
+    X *= 20.0 / mean_norm
+    return X
+
+
+def centre_indices(N, C, M, seed):
+    """Reference rule (FALKONWrapper.compute_indices_selection): <= M/2 positives first (sampled
+    with replacement when there are more), negatives fill up to M.  Host-side, seeded, identical
+    on every rank; positives of class c are the rows i with i % C == c."""
+    out = []
+    rng = np.random.default_rng(seed)
+    for c in range(C):
+        npos = (N - c + C - 1) // C
+        if npos > M // 2:
+            p = rng.integers(0, npos, M // 2) * C + c
+        else:
+            p = np.arange(npos) * C + c
+        nneg = N - npos
+        k = M - p.shape[0]
+        if nneg > k:
+            q = rng.integers(0, nneg, k)
+        else:
+            q = np.arange(nneg)
+        # q-th row (in order) with r % C != c: block b = q // (C-1), p = q % (C-1), r = b C + p + (p >= c)
+        neg = q + (q // (C - 1)) + ((q % (C - 1)) >= c) if C > 1 else q
+        out.append(np.concatenate([p, neg]).astype(np.int64))
+    return out
+
+
+class Phase:
+    """Accumulates device time of one kernel family with HIP events on the launch stream."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        self.b.record()
+        self.pairs.append((self.a, self.b))
+
+    def total_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.pairs)
+
+    def count(self):
+        return len(self.pairs)
+
+    def reset(self):
+        self.pairs = []
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", init_method="env://")
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    device = torch.device("cuda", torch.cuda.current_device())
+
+    import odx
+    from odx.backend import Features
+    from odx.dist import RowShard
+    from odx.solver import SolverOptions
+
+    be = odx.get_backend()
+    shard = RowShard()
+    N, D, M, C = args.n, args.D, args.M, args.classes
+    lo, hi = shard.bounds(N)
+    n_loc = hi - lo
+    seed = 1234 + 3
+    X = synth_rows(lo, hi, D, C, seed, device)
+    F = be.features(X)
+    row_ids = torch.arange(lo, hi, device=device)
+    cidx = centre_indices(N, C, M, seed)
+    ldk = (M + 3) // 4 * 4
+    kbuf = torch.empty(n_loc * ldk, dtype=torch.float32, device=device)
+    scores = torch.empty((n_loc, C), dtype=torch.float32, device=device)
+    opt = SolverOptions(check_pivots=False)
+    ph = {k: Phase() for k in ("knm", "ktk", "precond", "mmv")}
+
+    def gather_centres(idx):
+        """Z = X_global[idx]: every rank contributes the rows it owns, one all-reduce sums them."""
+        gi = torch.from_numpy(idx).to(device)
+        mine = (gi >= lo) & (gi < hi)
+        Z = torch.zeros((idx.shape[0], D), dtype=torch.float32, device=device)
+        Z[mine] = X[gi[mine] - lo]
+        shard.allreduce(Z)
+        return be.features(Z)
+
+    def run_class(c, timed):
+        Zf = gather_centres(cidx[c])
+        y = torch.where((row_ids % C) == c, 1.0, -1.0).to(torch.float64)
+        alpha = fit(be, F, y, Zf, timed)
+        with ph["mmv"] if timed else _null():
+            be.mmv(F, Zf, args.sigma, alpha, None, out=scores[:, c:c + 1])
+        return alpha, Zf
+
+    def fit(be, F, y, Zf, timed):
+        # odx.solver.falkon_fit with per-phase event brackets
+        n = float(N)
+        lam = args.lam
+        ar = shard.allreduce
+        with ph["precond"] if timed else _null():
+            P = be.precond(Zf, args.sigma, lam, opt.pc_epsilon)
+        with ph["knm"] if timed else _null():
+            K = be.knm(F, Zf, args.sigma, out=kbuf)
+
+        def ktk(**kw):
+            with ph["ktk"] if timed else _null():
+                r = be.ktk(K, **kw)
+            return ar(r)
+
+        def mmv(s, out):
+            v = be.trmv(P, "LAit", s)
+            t = be.trmv(P, "LTit", v)
+            cc = ktk(v=t)
+            u = be.trmv(P, "LTi", cc, alpha=1.0 / n, beta=lam, z=v)
+            return be.trmv(P, "LAi", u, out=out)
+
+        b0 = ktk(w=y * (1.0 / n))
+        B = be.trmv(P, "LAi", be.trmv(P, "LTi", b0))
+        Xv, R, Pv, AP = be.zeros(M), be.zeros(M), be.zeros(M), be.zeros(M)
+        state = be.zeros(4)
+        be.cg_init(B, Xv, R, Pv, state)
+        tol = opt.cg_tolerance ** 2
+        for it in range(args.maxiter):
+            mmv(Pv, AP)
+            full = (it + 1) % opt.cg_full_gradient_every == 0
+            be.cg_step(Xv, R, Pv, AP, state, opt.cg_epsilon, full)
+            if full:
+                mmv(Xv, AP)
+                R.copy_(B)
+                be.axpby(-1.0, AP, 1.0, R)
+            be.cg_finish(R, Pv, state, opt.cg_epsilon, tol)
+        return be.trmv(P, "LTit", be.trmv(P, "LAit", Xv))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up (untimed): a few classes are enough to touch every kernel and allocation
+    for _ in range(args.warmup):
+        for c in range(min(args.warmup_classes, C)):
+            run_class(c, False)
+    barrier()
+
+    # ---- timed region: exactly K steps
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        for c in range(C):
+            last = run_class(c, True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    ms_per_step = dt * 1e3 / args.steps
+    value = N * args.steps / dt
+
+    if rank == 0:
+        # dominant kernel family: the Gaussian MFMA contraction (K_nM build + fused scoring)
+        gauss_ms = ph["knm"].total_ms() + ph["mmv"].total_ms()
+        gauss_launches = ph["knm"].count() + ph["mmv"].count()
+        flops_per_launch = 2.0 * n_loc * M * D
+        ktk_ms = ph["ktk"].total_ms()
+        ktk_launches = ph["ktk"].count()
+        bytes_per_pass = float(n_loc) * M * 4
+        dom_gauss = gauss_ms >= ktk_ms
+        if dom_gauss:
+            ach = flops_per_launch * gauss_launches / (gauss_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gauss_knm_f32_kernel+gauss_mmv_f32_kernel", "achieved": round(ach, 2),
+                    "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": None, "avg_launch_ms": round(gauss_ms / max(gauss_launches, 1), 3)}
+        else:
+            ach = bytes_per_pass * ktk_launches / (ktk_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "knm_pass_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_ms": round(ktk_ms / max(ktk_launches, 1), 3)}
+        phases = {k: round(v.total_ms() / args.steps, 2) for k, v in ph.items()}
+        phases["ktk_GBps"] = round(bytes_per_pass * ktk_launches / max(ktk_ms * 1e-3, 1e-9) / 1e9, 1)
+        phases["gauss_TFLOPs"] = round(flops_per_launch * gauss_launches / max(gauss_ms * 1e-3, 1e-9) / 1e12, 2)
+        out = {
+            "metric": "FALKON fit+infer samples/sec (N=1e6 D=1024 M=1e4)",
+            "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32 K_nM (f32-input MFMA) + f64 solver",
+            "data": "synthetic",
+            "config": {"workload": "%d-class one-vs-rest FALKON fit + score-all, N=%d D=%d M=%d, %d CG iterations, "
+                                   "rows sharded over %d GPU(s)" % (C, N, D, M, args.maxiter, world),
+                       "N": N, "D": D, "M": M, "classes": C, "sigma": args.sigma, "lambda": args.lam,
+                       "rows_per_gpu": n_loc},
+            "roofline": roof,
+            "phases_ms_per_step_rank0": phases,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        if args.check:
+            out["check"] = check_against_oracle(be, F, last, X, row_ids, args, C - 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def cpu_baseline(args):
+    """The CPU path of the same algorithm (numpy f32 restatement of falkon's in-core fit with a
+    stored K_nM, then predict) for ONE class on a bounded row sample, timed on this host."""
+    from oracle import falkon_ref as fr
+    try:
+        from threadpoolctl import threadpool_info
+        thr = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        thr = os.cpu_count() or 1
+    ns, D, M = args.cpu_sample_rows, args.D, min(args.M, 4000)
+    rng = np.random.default_rng(7)
+    X = rng.standard_normal((ns, D)).astype(np.float32)
+    X *= 20.0 / np.sqrt(D)
+    y = np.where(np.arange(ns) % args.classes == 0, 1.0, -1.0).astype(np.float32)
+    idx = fr.compute_indices_selection(y, M, lambda h, s: rng.integers(0, h, s))
+    t0 = time.perf_counter()
+    alpha, Z = fr.falkon_fit(X, y, idx, args.sigma, args.lam, maxiter=args.maxiter, dtype=np.float32)
+    fr.falkon_predict(X, Z, alpha, args.sigma, np.float32)
+    dt = time.perf_counter() - t0
+    return {"value": round(ns / (dt * args.classes), 2), "unit": "samples/s", "cores": int(thr), "kind": "port",
+            "sample": "oracle/falkon_ref.py (numpy f32, stored K_nM): 1 class fit+predict on %d rows, D=%d, M=%d "
+                      "in %.1f s; value = rows / (seconds x %d classes); M reduced from %d to bound the O(M^3) "
+                      "host Cholesky" % (ns, D, M, dt, args.classes, args.M)}
+
+
+def check_against_oracle(be, F, last, X, row_ids, args, c):
+    """Scores of the last fitted class on 2000 local rows vs the oracle's predict with the same alpha."""
+    from oracle import falkon_ref as fr
+    alpha, Zf = last
+    rows = X[:2000].cpu().numpy().astype(np.float64)
+    ref = fr.falkon_predict(rows, Zf.X.cpu().numpy().astype(np.float64), alpha.cpu().numpy()[:, None], args.sigma)
+    Fs = be.features(X[:2000])
+    got = be.mmv(Fs, Zf, args.sigma, alpha).cpu().numpy()
+    return {"max_abs_score_diff_vs_oracle_predict": float(np.abs(got - ref).max())}
+
+
+if __name__ == "__main__":
+    main()

@@ -9,73 +9,227 @@ namespace odx {
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------- diagonal block: chol + inverse
-// One 1024-thread workgroup.  A (jb x jb, lower part read) -> L in place (strict upper zeroed),
-// Dinv (NB x NB, ld NB) = L^-1 (lower, zero elsewhere).  Rows/cols >= jb are padded with the
-// identity so the loops are uniform.
-template <int NB>
-__global__ __launch_bounds__(1024) void potrf_diag_kernel(double* __restrict__ A, int64_t lda, int jb,
-                                                          double* __restrict__ Dinv, int32_t* __restrict__ info,
-                                                          int info_base) {
-  constexpr int LD = NB + 1;
-  __shared__ double s[NB * LD];
-  const int tid = threadIdx.x;
-  const int tx = tid & 31, ty = tid >> 5;  // 32 x 32
-  for (int e = tid; e < NB * NB; e += 1024) {
-    const int i = e / NB, j = e % NB;
+// One 512-thread workgroup owns a 128 x 128 diagonal block in LDS (rows padded to 129 f64)
+// and works on it in 32-wide panels, so there are a dozen workgroup barriers instead of one
+// per column:
+//   chol32_wave     : wave 0 factors a 32 x 32 diagonal block, one row per lane, pivots and
+//                     columns exchanged by v_readlane
+//   inv32_wave      : wave 0 inverts a 32 x 32 lower-triangular block, one column per lane,
+//                     L read from LDS as broadcasts
+//   panel / trailing: every thread owns <= 6 panel outputs / a 6 x 3 register tile
+// Rows/cols >= jb are padded with the identity so every loop is uniform.
+constexpr int DB_NB = POTRF_NB;   // 128
+constexpr int DB_LD = DB_NB + 1;  // LDS row stride (f64): odd => column walks are conflict-free
+constexpr int DB_XLD = 33;
+constexpr int DB_NT = 512;       // threads: 8 waves => 256 VGPRs per lane for the one-wave 32 x 32 steps
+constexpr int DB_PQ = 3072 / DB_NT;  // panel outputs per thread (96 rows x 32 cols at most)
+
+// value of v in lane `src` (compile-time constant) as a wave-uniform scalar: v_readlane_b32 x 2
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+__device__ __forceinline__ void chol32_wave(double* s, int J, int jb, int32_t* info, int info_base, int lane) {
+  const int l = lane & 31;
+  double row[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) row[k] = s[(J + l) * DB_LD + J + k];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    double piv = readlane_f64(row[c], c);
+    if (!(piv > 0.0)) {
+      if (lane == 0 && J + c < jb && *info == 0) *info = info_base + J + c + 1;
+      piv = 1.0;
+    }
+    const double d = sqrt(piv);
+    const double inv = 1.0 / d;
+    const double lc = (l > c) ? row[c] * inv : ((l == c) ? d : 0.0);
+    row[c] = lc;
+#pragma unroll
+    for (int k = c + 1; k < 32; ++k) row[k] = fma(-lc, readlane_f64(lc, k), row[k]);
+  }
+  if (lane < 32) {
+#pragma unroll
+    for (int k = 0; k < 32; ++k) s[(J + l) * DB_LD + J + k] = (k <= l) ? row[k] : 0.0;
+  }
+}
+
+// xi (32 x 33, lower, zeros above) = inverse of the lower-triangular block of s at (J, J)
+__device__ __forceinline__ void inv32_wave(const double* s, int J, double* xi, int lane) {
+  const int c = lane & 31;
+  double x[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    double acc = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < i; ++k) acc = fma(-s[(J + i) * DB_LD + J + k], x[k], acc);
+    x[i] = acc / s[(J + i) * DB_LD + J + i];
+  }
+  if (lane < 32) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) xi[i * DB_XLD + c] = x[i];
+  }
+}
+
+// In-LDS blocked Cholesky of the 128 x 128 block (lower in, lower out, strict upper zero).
+__device__ __forceinline__ void lds_chol_128(double* s, double* xi, int jb, int32_t* info, int info_base) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tx = tid & 31, ty = tid >> 5;
+  for (int J = 0; J < DB_NB; J += 32) {
+    if (wave == 0) {
+      chol32_wave(s, J, jb, info, info_base, lane);
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the block's LDS writes before its reads
+      inv32_wave(s, J, xi, lane);
+    }
+    __syncthreads();
+    const int nrem = DB_NB - J - 32;  // rows below the panel
+    if (nrem > 0) {
+      // panel: L21[i][c] = sum_k A21[i][k] * X11[c][k]
+      double pv[DB_PQ];
+#pragma unroll
+      for (int q = 0; q < DB_PQ; ++q) {
+        const int e = tid + DB_NT * q;
+        const int i = J + 32 + (e >> 5), c = e & 31;
+        double a = 0.0;
+        if (i < DB_NB) {
+#pragma unroll 8
+          for (int k = 0; k < 32; ++k) a = fma(s[i * DB_LD + J + k], xi[c * DB_XLD + k], a);
+        }
+        pv[q] = a;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < DB_PQ; ++q) {
+        const int e = tid + DB_NT * q;
+        const int i = J + 32 + (e >> 5), c = e & 31;
+        if (i < DB_NB) s[i * DB_LD + J + c] = pv[q];
+      }
+      __syncthreads();
+      // trailing update (lower blocks): s[i][k] -= sum_c L21[i][c] L21[k][c]
+      const int na = nrem >> 5;  // 32-row blocks left: 3, 2, 1
+      double acc[6][3];
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[a][b] = 0.0;
+      const int ib = J + 32 + ty, kb = J + 32 + tx;  // ty in [0, 16): rows ib + 16 a; cols kb + 32 b
+#pragma unroll 4
+      for (int c = 0; c < 32; ++c) {
+        double av[6], bv[3];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) av[a] = (a < 2 * na) ? s[(ib + 16 * a) * DB_LD + J + c] : 0.0;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) bv[b] = (b < na) ? s[(kb + 32 * b) * DB_LD + J + c] : 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int b = 0; b <= (a >> 1); ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
+      }
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b <= (a >> 1); ++b)
+          if (a < 2 * na) s[(ib + 16 * a) * DB_LD + kb + 32 * b] -= acc[a][b];
+      __syncthreads();
+    }
+  }
+}
+
+// In-place inverse of the lower-triangular 128 x 128 block in LDS, block column by block column
+// from the right:  X_JJ = L_JJ^-1;  X_[below,J] = -X_[below,below] (L_[below,J] X_JJ).
+__device__ __forceinline__ void lds_trinv_128(double* s, double* xi) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int J = DB_NB - 32; J >= 0; J -= 32) {
+    __syncthreads();
+    if (wave == 0) inv32_wave(s, J, xi, lane);
+    __syncthreads();
+    const int nrem = DB_NB - J - 32;
+    if (nrem > 0) {
+      double w[DB_PQ];
+      // W[i][c] = sum_k L[i][J+k] X_JJ[k][c]
+#pragma unroll
+      for (int q = 0; q < DB_PQ; ++q) {
+        const int e = tid + DB_NT * q;
+        const int i = J + 32 + (e >> 5), c = e & 31;
+        double a = 0.0;
+        if (i < DB_NB) {
+#pragma unroll 8
+          for (int k = 0; k < 32; ++k) a = fma(s[i * DB_LD + J + k], xi[k * DB_XLD + c], a);
+        }
+        w[q] = a;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < DB_PQ; ++q) {
+        const int e = tid + DB_NT * q;
+        const int i = J + 32 + (e >> 5), c = e & 31;
+        if (i < DB_NB) s[i * DB_LD + J + c] = w[q];
+      }
+      __syncthreads();
+      // Y[i][c] = -sum_{k = J+32 .. i} X[i][k] W[k][c]
+#pragma unroll
+      for (int q = 0; q < DB_PQ; ++q) {
+        const int e = tid + DB_NT * q;
+        const int i = J + 32 + (e >> 5), c = e & 31;
+        double a = 0.0;
+        if (i < DB_NB) {
+          for (int k = J + 32; k <= i; ++k) a = fma(s[i * DB_LD + k], s[k * DB_LD + J + c], a);
+        }
+        w[q] = -a;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < DB_PQ; ++q) {
+        const int e = tid + DB_NT * q;
+        const int i = J + 32 + (e >> 5), c = e & 31;
+        if (i < DB_NB) s[i * DB_LD + J + c] = w[q];
+      }
+    }
+    for (int e = tid; e < 1024; e += DB_NT) {  // the diagonal block itself
+      const int r = e >> 5, c = e & 31;
+      s[(J + r) * DB_LD + J + c] = xi[r * DB_XLD + c];
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void lds_load_lower_128(double* s, const double* __restrict__ A, int64_t lda, int jb) {
+  for (int e = threadIdx.x; e < DB_NB * DB_NB; e += DB_NT) {
+    const int i = e >> 7, j = e & 127;
     double v = 0.0;
     if (i < jb && j <= i) v = A[(int64_t)i * lda + j];
     else if (i == j) v = 1.0;
-    s[i * LD + j] = v;
-  }
-  for (int j = 0; j < NB; ++j) {
-    __syncthreads();
-    double d = s[j * LD + j];
-    if (!(d > 0.0)) {
-      if (tid == 0 && j < jb && *info == 0) *info = info_base + j + 1;
-      d = 1.0;
-    }
-    const double dj = sqrt(d);
-    const double inv = 1.0 / dj;
-    __syncthreads();
-    if (tid == 0) s[j * LD + j] = dj;
-    for (int i = j + 1 + tid; i < NB; i += 1024) s[i * LD + j] *= inv;
-    __syncthreads();
-    // trailing update of the lower triangle: s[i][k] -= s[i][j] * s[k][j], j < k <= i
-    for (int i = j + 1 + ty; i < NB; i += 32) {
-      const double lij = s[i * LD + j];
-      for (int k = j + 1 + tx; k <= i; k += 32) s[i * LD + k] -= lij * s[k * LD + j];
-    }
+    s[i * DB_LD + j] = v;
   }
   __syncthreads();
-  for (int e = tid; e < jb * jb; e += 1024) {
+}
+
+__device__ __forceinline__ void lds_store_dinv_128(const double* s, double* __restrict__ Dinv, int jb) {
+  for (int e = threadIdx.x; e < DB_NB * DB_NB; e += DB_NT) {
+    const int i = e >> 7, j = e & 127;
+    Dinv[e] = (i < jb && j <= i) ? s[i * DB_LD + j] : 0.0;
+  }
+}
+
+// A (jb x jb, lower part read) -> L in place (strict upper zeroed); Dinv (128 x 128, ld 128) = L^-1.
+template <int NB>
+__global__ __launch_bounds__(DB_NT) void potrf_diag_kernel(double* __restrict__ A, int64_t lda, int jb,
+                                                          double* __restrict__ Dinv, int32_t* __restrict__ info,
+                                                          int info_base) {
+  static_assert(NB == DB_NB, "diagonal-block kernels are built for NB = 128");
+  __shared__ double s[DB_NB * DB_LD];
+  __shared__ double xi[32 * DB_XLD];
+  lds_load_lower_128(s, A, lda, jb);
+  lds_chol_128(s, xi, jb, info, info_base);
+  for (int e = threadIdx.x; e < jb * jb; e += DB_NT) {
     const int i = e / jb, j = e % jb;
-    A[(int64_t)i * lda + j] = (j <= i) ? s[i * LD + j] : 0.0;
+    A[(int64_t)i * lda + j] = (j <= i) ? s[i * DB_LD + j] : 0.0;
   }
-  // in-place inverse of the lower-triangular factor, last column first:
-  //   X[j][j] = 1 / L[j][j];  X[i][j] = -X[j][j] * sum_{k=j+1..i} X[i][k] L[k][j]   (i > j)
-  // 8 lanes share one row i and split the k range.
-  const int row = tid >> 3, part = tid & 7;
-  for (int j = NB - 1; j >= 0; --j) {
-    __syncthreads();
-    const double xjj = 1.0 / s[j * LD + j];
-    double y = 0.0;
-    if (row > j) {
-      for (int k = j + 1 + part; k <= row; k += 8) y = fma(s[row * LD + k], s[k * LD + j], y);
-    }
-    y += __shfl_xor(y, 1);
-    y += __shfl_xor(y, 2);
-    y += __shfl_xor(y, 4);
-    __syncthreads();
-    if (part == 0) {
-      if (row > j) s[row * LD + j] = -xjj * y;
-      else if (row == j) s[j * LD + j] = xjj;
-    }
-  }
-  __syncthreads();
-  for (int e = tid; e < NB * NB; e += 1024) {
-    const int i = e / NB, j = e % NB;
-    Dinv[e] = (i < jb && j <= i) ? s[i * LD + j] : 0.0;
-  }
+  lds_trinv_128(s, xi);
+  lds_store_dinv_128(s, Dinv, jb);
 }
 
 // ---------------------------------------------------------------- small utility kernels
@@ -210,7 +364,7 @@ int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hi
     const int jb = (int)(M - k0 < NB ? M - k0 : NB);
     double* Akk = A + k0 * lda + k0;
     double* D = Dinv + b * NB * NB;
-    hipLaunchKernelGGL(potrf_diag_kernel<NB>, dim3(1), dim3(1024), 0, stream, Akk, lda, jb, D, info, (int)k0);
+    hipLaunchKernelGGL(potrf_diag_kernel<NB>, dim3(1), dim3(DB_NT), 0, stream, Akk, lda, jb, D, info, (int)k0);
     ODX_CHECK_LAUNCH("potrf_diag");
     const int64_t m = M - k0 - jb;
     if (m <= 0) break;
@@ -333,44 +487,15 @@ extern "C" int64_t odx_trtri_workspace_bytes(int64_t M) {
 }
 
 // Stand-alone triangular inverse (tests, RLS): re-derives the diagonal-block inverses from L.
-__global__ __launch_bounds__(1024) void trtri_diag_kernel(const double* __restrict__ L, int64_t ldl, int64_t M,
+__global__ __launch_bounds__(DB_NT) void trtri_diag_kernel(const double* __restrict__ L, int64_t ldl, int64_t M,
                                                           double* __restrict__ Dinv) {
-  constexpr int NB = POTRF_NB;
-  constexpr int LD = NB + 1;
-  __shared__ double s[NB * LD];
-  const int tid = threadIdx.x;
-  const int64_t r0 = (int64_t)blockIdx.x * NB;
-  const int jb = (int)(M - r0 < NB ? M - r0 : NB);
-  for (int e = tid; e < NB * NB; e += 1024) {
-    const int i = e / NB, j = e % NB;
-    double v = 0.0;
-    if (i < jb && j <= i) v = L[(r0 + i) * ldl + r0 + j];
-    else if (i == j) v = 1.0;
-    s[i * LD + j] = v;
-  }
-  const int row = tid >> 3, part = tid & 7;
-  for (int j = NB - 1; j >= 0; --j) {
-    __syncthreads();
-    const double xjj = 1.0 / s[j * LD + j];
-    double y = 0.0;
-    if (row > j) {
-      for (int k = j + 1 + part; k <= row; k += 8) y = fma(s[row * LD + k], s[k * LD + j], y);
-    }
-    y += __shfl_xor(y, 1);
-    y += __shfl_xor(y, 2);
-    y += __shfl_xor(y, 4);
-    __syncthreads();
-    if (part == 0) {
-      if (row > j) s[row * LD + j] = -xjj * y;
-      else if (row == j) s[j * LD + j] = xjj;
-    }
-  }
-  __syncthreads();
-  double* D = Dinv + (int64_t)blockIdx.x * NB * NB;
-  for (int e = tid; e < NB * NB; e += 1024) {
-    const int i = e / NB, j = e % NB;
-    D[e] = (i < jb && j <= i) ? s[i * LD + j] : 0.0;
-  }
+  __shared__ double s[DB_NB * DB_LD];
+  __shared__ double xi[32 * DB_XLD];
+  const int64_t r0 = (int64_t)blockIdx.x * DB_NB;
+  const int jb = (int)(M - r0 < DB_NB ? M - r0 : DB_NB);
+  lds_load_lower_128(s, L + r0 * ldl + r0, ldl, jb);
+  lds_trinv_128(s, xi);
+  lds_store_dinv_128(s, Dinv + (int64_t)blockIdx.x * DB_NB * DB_NB, jb);
 }
 
 extern "C" int odx_trtri_f64(const double* L, int64_t ldl, int64_t M, double* Li, double* Lit, int64_t ld,
@@ -385,7 +510,7 @@ extern "C" int odx_trtri_f64(const double* L, int64_t ldl, int64_t M, double* Li
   hipStream_t s = as_stream(stream);
   double* Dinv = static_cast<double*>(workspace);
   double* WT = Dinv + ceil_div(M, POTRF_NB) * POTRF_NB * POTRF_NB;
-  hipLaunchKernelGGL(trtri_diag_kernel, dim3((unsigned)ceil_div(M, POTRF_NB)), dim3(1024), 0, s, L, ldl, M, Dinv);
+  hipLaunchKernelGGL(trtri_diag_kernel, dim3((unsigned)ceil_div(M, POTRF_NB)), dim3(DB_NT), 0, s, L, ldl, M, Dinv);
   ODX_CHECK_LAUNCH("trtri_diag");
   ODX_PROPAGATE(fill_f64(Li, ld, M, M, 0.0, s));
   ODX_PROPAGATE(fill_f64(Lit, ld, M, M, 0.0, s));

@@ -46,8 +46,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams<T> p) 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const bool st = (p.flags & ODX_GEMM_STORE_T) != 0;
+  // Epilogue in batches of one tile-row (TN x NREG values): all reads of C first, then all
+  // writes — C may alias itself across iterations, so an interleaved read/modify/write would
+  // be serialised one memory round trip per element.
+  const bool has_beta = p.beta != T(0);
 #pragma unroll
-  for (int tm = 0; tm < Tr::TM; ++tm)
+  for (int tm = 0; tm < Tr::TM; ++tm) {
+    T cv[Tr::TN][Tr::NREG];
+    if (has_beta) {
+#pragma unroll
+      for (int tn = 0; tn < Tr::TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < Tr::NREG; ++r) {
+          const int64_t row = i0 + wr * 64 + gemm_acc_row<T>(tm, r, lane);
+          const int64_t col = j0 + wc * 64 + gemm_acc_col<T>(tn, lane);
+          cv[tn][r] = (row < m && col < n) ? C[st ? col * p.ldc + row : row * p.ldc + col] : T(0);
+        }
+    }
 #pragma unroll
     for (int tn = 0; tn < Tr::TN; ++tn)
 #pragma unroll
@@ -55,13 +70,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams<T> p) 
         const int64_t row = i0 + wr * 64 + gemm_acc_row<T>(tm, r, lane);
         const int64_t col = j0 + wc * 64 + gemm_acc_col<T>(tn, lane);
         if (row < m && col < n) {
-          const int64_t idx = st ? col * p.ldc + row : row * p.ldc + col;
           T val = p.alpha * acc[tm][tn][r];
-          if (p.beta != T(0)) val += p.beta * C[idx];
-          C[idx] = val;
+          if (has_beta) val += p.beta * cv[tn][r];
+          C[st ? col * p.ldc + row : row * p.ldc + col] = val;
           if (C2) C2[col * p.ldc2 + row] = val;
         }
       }
+  }
 }
 
 template <typename T>

@@ -56,7 +56,10 @@ struct GemmStage {
 
 // One operand tile: 128 rows x 128 B.  Thread t fetches 16-B segments idx = t + 256 p:
 // row = idx >> 3, seg = idx & 7.  Rows >= nrows and k >= K read as zero.
-template <typename T>
+// CLEAN = the whole k-tile lies inside [0, K): no per-element masking, so the four loads issue
+// back to back and are only waited for at the LDS store (a mask applied right after each load
+// would serialise them behind s_waitcnt vmcnt(0)).
+template <typename T, bool CLEAN>
 __device__ __forceinline__ void gemm_load_operand(u32x4 (&r)[4], const T* __restrict__ base, int64_t ld,
                                                   int64_t row0, int64_t nrows, int64_t k0, int64_t K) {
   constexpr int EPV = GemmTraits<T>::EPV;
@@ -69,7 +72,9 @@ __device__ __forceinline__ void gemm_load_operand(u32x4 (&r)[4], const T* __rest
     const int64_t gr = row0 + row;
     const int64_t kk = k0 + seg * EPV;
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (gr < nrows && kk < K) {
+    if (CLEAN) {
+      if (gr < nrows) v = *reinterpret_cast<const u32x4*>(base + gr * ld + kk);
+    } else if (gr < nrows && kk < K) {
       v = *reinterpret_cast<const u32x4*>(base + gr * ld + kk);
       if (kk + EPV > K) {  // ragged k tail inside this 16-B segment
         T* e = reinterpret_cast<T*>(&v);
@@ -79,6 +84,19 @@ __device__ __forceinline__ void gemm_load_operand(u32x4 (&r)[4], const T* __rest
       }
     }
     r[p] = v;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void gemm_load_stage(GemmStage<T>& st, const T* __restrict__ A, int64_t lda, int64_t m,
+                                                const T* __restrict__ B, int64_t ldb, int64_t n, int64_t i0,
+                                                int64_t j0, int64_t kt, int64_t ke) {
+  if (kt + GemmTraits<T>::BK <= ke) {
+    gemm_load_operand<T, true>(st.a, A, lda, i0, m, kt, ke);
+    gemm_load_operand<T, true>(st.b, B, ldb, j0, n, kt, ke);
+  } else {
+    gemm_load_operand<T, false>(st.a, A, lda, i0, m, kt, ke);
+    gemm_load_operand<T, false>(st.b, B, ldb, j0, n, kt, ke);
   }
 }
 
@@ -166,16 +184,14 @@ __device__ __forceinline__ void gemm_mainloop(typename GemmTraits<T>::Acc (&acc)
   const int wr = wave >> 1, wc = wave & 1;
   if (kb >= ke) return;
   GemmStage<T> st;
-  gemm_load_operand<T>(st.a, A, lda, i0, m, kb, ke);
-  gemm_load_operand<T>(st.b, B, ldb, j0, n, kb, ke);
+  gemm_load_stage<T>(st, A, lda, m, B, ldb, n, i0, j0, kb, ke);
   for (int64_t kt = kb; kt < ke; kt += BK) {
     __syncthreads();  // everyone finished reading the previous k-tile
     gemm_store_operand(st.a, ldsA);
     gemm_store_operand(st.b, ldsB);
     __syncthreads();
     if (kt + BK < ke) {  // next k-tile's global loads fly under this tile's MFMAs
-      gemm_load_operand<T>(st.a, A, lda, i0, m, kt + BK, ke);
-      gemm_load_operand<T>(st.b, B, ldb, j0, n, kt + BK, ke);
+      gemm_load_stage<T>(st, A, lda, m, B, ldb, n, i0, j0, kt + BK, ke);
     }
     gemm_compute_ktile(acc, ldsA, ldsB, wr, wc, lane);
   }

@@ -1,0 +1,212 @@
+"""On-line region classifier: the Minibootstrap hard-negative mining loop around a classifier
+plug-in, z-score normalisation and stand-alone scoring.  Behaviour follows
+src/modules/region-classifier/OnlineRegionClassifier.py:19-227 (host tensors) and
+OnlineRegionClassifier_incore.py:16-224 (device tensors); the two differ in where tensors
+live, in that the in-core variant skips the easy-negative pruning after the last batch
+(_incore.py:130) and in the `return_caches` / `normalized` options (_incore.py:79-82,158-183).
+
+State machine per class i with positives P and negative batches N_0..N_{B-1}
+(thresholds from the YAML: HARD_THRESH -0.7, EASY_THRESH -0.9):
+    cache = (P, N_0);  model = train(cache)
+    for j >= 1:  cache.neg += N_j[ predict(model, N_j) > HARD ];  model = train(cache)
+    after each train (in-core: except the last): cache.neg = cache.neg[ predict(model, cache.neg) >= EASY ]
+A class without positives or without negatives gets model None.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+import yaml
+
+from .boxlist import get_boxlist_class
+
+
+def _device():
+    return 'cuda' if torch.cuda.is_available() else 'cpu'
+
+
+class OnlineRegionClassifierBase:
+    incore = True
+
+    def __init__(self, classifier, positives, negatives, stats=None, cfg_path=None, is_rpn=False,
+                 is_segmentation=False):
+        if cfg_path is not None:
+            with open(cfg_path) as fid:
+                self.cfg = yaml.load(fid, Loader=yaml.FullLoader)
+            if is_rpn:
+                self.cfg = self.cfg['RPN']
+            section = self.cfg['ONLINE_SEGMENTATION' if is_segmentation else 'ONLINE_REGION_CLASSIFIER']
+            self.classifier_options = section['CLASSIFIER']
+            self.lam = section['CLASSIFIER']['lambda']
+            self.sigma = section['CLASSIFIER']['sigma']
+            self.hard_tresh = section['MINIBOOTSTRAP']['HARD_THRESH']
+            self.easy_tresh = section['MINIBOOTSTRAP']['EASY_THRESH']
+            self.mean = 0
+            self.std = 0
+            self.mean_norm = 0
+            self.is_rpn = is_rpn
+        else:
+            print('Config file path not given. cfg variable set to None.')
+            self.cfg = None
+        self.classifier = classifier
+        self.negatives = negatives
+        self.positives = positives
+        self.num_classes = len(self.cfg['CHOSEN_CLASSES'])
+        if is_rpn:
+            self.num_classes += 1
+        if stats:
+            self.stats = stats
+            self.mean = stats['mean']
+            self.std = stats['std']
+            self.mean_norm = stats['mean_norm']
+        self.normalized = False
+        self.is_segmentation = is_segmentation
+        self.return_caches = False
+
+    def loadRegionClassifier(self) -> None:
+        pass
+
+    def processOptions(self, opts):
+        for key, attr in (('num_classes', 'num_classes'), ('imset_train', 'train_imset'),
+                          ('classifier_options', 'classifier_options'), ('is_rpn', 'is_rpn'), ('lam', 'lam'),
+                          ('sigma', 'sigma')):
+            if key in opts:
+                setattr(self, attr, opts[key])
+        if self.incore:
+            if 'return_caches' in opts:
+                self.return_caches = opts['return_caches']
+            if 'normalized' in opts:
+                self.normalized = opts['normalized']
+
+    def updateModel(self, cache):
+        X_neg, X_pos = cache['neg'], cache['pos']
+        X = torch.cat((X_pos, X_neg), 0)
+        dev = X.device if self.incore else 'cpu'
+        y = torch.cat((torch.ones(len(X_pos), device=dev), -torch.ones(len(X_neg), device=dev)), 0)
+        if self.sigma is not None and self.lam is not None:
+            print('Updating model with lambda: {} and sigma: {}'.format(self.lam, self.sigma))
+            return self.classifier.train(X, y, sigma=self.sigma, lam=self.lam)
+        print('Updating model with default lambda and sigma')
+        return self.classifier.train(X, y)
+
+    def _host(self, t):
+        return t if self.incore else t.cpu()
+
+    def trainWithMinibootstrap(self, negatives, positives, output_dir=None):
+        caches, model = [], []
+        t_start = time.time()
+        for i in range(self.num_classes - 1):
+            if len(positives[i]) == 0 or len(negatives[i]) == 0:
+                model.append(None)
+                caches.append({})
+                continue
+            print('---------------------- Training Class number {} ----------------------'.format(i))
+            nb = len(negatives[i])
+            for j in range(nb):
+                t_iter = time.time()
+                last = j == nb - 1
+                if j == 0:
+                    caches.append({'pos': self._host(positives[i]), 'neg': self._host(negatives[i][0])})
+                    model.append(None)
+                else:
+                    t_hard = time.time()
+                    batch = self._host(negatives[i][j])
+                    scores = self.classifier.predict(model[i], batch)
+                    hard_idx = torch.where(scores > self.hard_tresh)[0]
+                    caches[i]['neg'] = torch.cat((caches[i]['neg'], batch[hard_idx]), 0)
+                    print('Hard negatives selected in {} seconds'.format(time.time() - t_hard))
+                    print('Chosen {} hard negatives from the {}th batch'.format(len(hard_idx), j))
+                print('Traning with {} positives and {} negatives'.format(len(caches[i]['pos']), len(caches[i]['neg'])))
+                t_update = time.time()
+                model[i] = self.updateModel(caches[i])
+                print('Model updated in {} seconds'.format(time.time() - t_update))
+                t_easy = time.time()
+                if len(caches[i]['neg']) != 0 and not (self.incore and last):
+                    scores = self.classifier.predict(model[i], caches[i]['neg'])
+                    keep_idx = torch.where(scores >= self.easy_tresh)[0]
+                    removed = len(caches[i]['neg']) - len(keep_idx)
+                    caches[i]['neg'] = caches[i]['neg'][keep_idx]
+                    print('Easy negatives selected in {} seconds'.format(time.time() - t_easy))
+                    print('Removed {} easy negatives. {} Remaining'.format(removed, len(caches[i]['neg'])))
+                    print('Iteration {}th done in {} seconds'.format(j, time.time() - t_iter))
+                if last and not self.return_caches:
+                    caches[i] = None  # free the class's cache
+                    if torch.cuda.is_available():
+                        torch.cuda.empty_cache()
+        training_time = time.time() - t_start
+        print('Online Classifier trained in {} seconds'.format(training_time))
+        if output_dir:
+            if self.is_rpn:
+                head = "RPN's Online Classifier training time"
+            elif self.is_segmentation:
+                head = "Online Segmentation training time"
+            else:
+                head = "Detector's Online Classifier training time"
+            with open(os.path.join(output_dir, "result.txt"), "a") as fid:
+                fid.write("{}: {}min:{}s \n".format(head, int(training_time / 60), round(training_time % 60)))
+        if self.return_caches:
+            self.caches = caches
+        return model
+
+    def trainRegionClassifier(self, opts=None, output_dir=None):
+        if opts is not None:
+            self.processOptions(opts)
+        print('Training Online Region Classifier')
+        negatives, positives = self.negatives, self.positives
+        if not self.incore:
+            ref = negatives[0][0].device
+            self.mean, self.std, self.mean_norm = self.mean.to(ref), self.std.to(ref), self.mean_norm.to(ref)
+        if not self.normalized:
+            for i in range(self.num_classes - 1):
+                if len(positives[i]):
+                    positives[i] = self.zScores(positives[i])
+                for j in range(len(negatives[i])):
+                    if len(negatives[i][j]):
+                        negatives[i][j] = self.zScores(negatives[i][j])
+            self.normalized = True
+        model = self.trainWithMinibootstrap(negatives, positives, output_dir=output_dir)
+        if self.incore and self.return_caches:
+            return model, self.caches
+        return model
+
+    def testRegionClassifier(self, model, test_boxes):
+        print('Online Region Classifier testing')
+        BoxList = get_boxlist_class()
+        dev = _device()
+        predictions = []
+        total = 0.0
+        try:
+            for c in range(self.num_classes - 1):
+                model[c].ny_points_ = model[c].ny_points_.to(dev)
+                model[c].alpha_ = model[c].alpha_.to(dev)
+        except Exception:
+            pass
+        if not self.incore:
+            self.mean, self.std, self.mean_norm = (torch.as_tensor(self.mean).to(dev), torch.as_tensor(self.std).to(dev),
+                                                   torch.as_tensor(self.mean_norm).to(dev))
+        for entry in test_boxes:
+            if entry is None:
+                continue
+            keep = np.nonzero(entry['gt'] == 0)
+            boxes = entry['boxes'][keep, :][0]
+            X_test = torch.tensor(entry['feat'][keep, :][0], device=dev)
+            t0 = time.time()
+            if self.mean_norm != 0:
+                X_test = self.zScores(X_test)
+            scores = -torch.ones((len(boxes), self.num_classes))
+            for c in range(self.num_classes - 1):
+                scores[:, c + 1] = torch.squeeze(self.classifier.predict(model[c], X_test))
+            total += time.time() - t0
+            b = BoxList(torch.from_numpy(boxes), (entry['img_size'][0], entry['img_size'][1]), mode="xyxy")
+            b.add_field("scores", scores.to('cpu'))
+            predictions.append(b)
+        print('Average image testing time: {} seconds.'.format(total / len(test_boxes)))
+        return predictions
+
+    def predict(self, dataset) -> None:
+        pass
+
+    def zScores(self, feat, target_norm=20):
+        feat = feat - self.mean
+        return feat * (target_norm / self.mean_norm.item())

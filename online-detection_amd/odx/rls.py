@@ -1,0 +1,177 @@
+"""Per-class RLS bounding-box regressors (A7) and their application (A8).
+
+Training follows RegionRefinerTrainer.train / solve
+(src/modules/region-refiner/region_refiner_trainer/train_region_refiner.py:25-119): per class,
+targets are centred and whitened in f64 (mu, S = Y'Y/n, eig, T = W diag((D + 1e-3)^-1/2) W',
+T_inv), a bias column is appended to the features, R = chol(X'X + lam I) and each of the four
+targets is solved with two triangular solves; per-sample losses 0.5 (X w - y)^2 ride along.
+Here the O(n D^2) Gram, the Cholesky, the solves and the residuals are libodx kernels
+(odx_rls_gram_f64 / odx_rls_solve_f64 / odx_rls_predict_rows_f64, all f64); the 4 x 4 whitening
+is host-side glue.  The Gram accumulates over row shards, so with a RowShard the partial
+(D+1)^2 + 4 (D+1) sums are all-reduced once per class before the solve.
+
+Application follows RegionPredictor.predict (region_predictor/predict_regions.py:16-80).
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import backend as _backend
+
+
+def _device():
+    return 'cuda' if torch.cuda.is_available() else 'cpu'
+
+
+def whiten_targets(Yi):
+    """mu, T, T_inv (f64) of train_region_refiner.py:61-67 for targets Yi (n, 4) f64."""
+    mu = torch.mean(Yi, dim=0)
+    Yc = Yi - mu
+    S = torch.matmul(Yc.t(), Yc) / Yc.size()[0]
+    evals, W = torch.linalg.eigh(S)     # S is symmetric: same T as the reference's general eig
+    root = torch.sqrt(evals + 0.001)
+    T = W @ torch.diag(1.0 / root) @ W.t()
+    T_inv = W @ torch.diag(root) @ W.t()
+    return mu, Yc, T, T_inv
+
+
+class RegionRefinerTrainer:
+    def __init__(self, cfg, lmbd, is_rpn, shard=None):
+        self.cfg = cfg
+        self.lambd = lmbd
+        self.COXY = None
+        self.is_rpn = is_rpn
+        self.shard = shard
+
+    def __call__(self, COXY, output_dir=None):
+        self.COXY = COXY
+        return self.train(output_dir=output_dir)
+
+    def train(self, output_dir=None):
+        be = _backend.get_backend()
+        dev = _device()
+        chosen_classes = self.cfg['CHOSEN_CLASSES']
+        start_index = 0 if self.is_rpn else 1
+        num_clss = len(chosen_classes)
+        models = np.empty((0))
+        F = be.features(self.COXY['X'])
+        Call = self.COXY['C'].to(F.X.device)
+        Yall = self.COXY['Y'].to(F.X.device)
+        D = F.D
+        D1 = D + 1
+        ldg = (D1 + 1) // 2 * 2
+        start_time = time.time()
+        for i in range(start_index, num_clss):
+            print('Training regressor for class %s (%d/%d)' % (chosen_classes[i], i, num_clss - 1))
+            I = torch.where(Call == i)[0]
+            print('Training with %i examples' % len(I))
+            n_loc = len(I)
+            n_tot = n_loc if self.shard is None else self.shard.total(n_loc)
+            if n_tot == 0:
+                models = np.append(models, {'mu': None, 'T': None, 'T_inv': None, 'Beta': None})
+                print('No indices for class %s' % (chosen_classes[i]))
+                continue
+            Yi = Yall[I].type(torch.float64)
+            if self.shard is not None and self.shard.enabled:
+                mu, Yc, T, T_inv = self._whiten_sharded(Yi, n_tot)
+            else:
+                mu, Yc, T, T_inv = whiten_targets(Yi)
+            Yw = torch.matmul(Yc, T)                                     # (n, 4) whitened targets
+            Yt = torch.zeros((4, (n_loc + 15) // 16 * 16 + 16), dtype=torch.float64, device=Yw.device)
+            Yt[:, :n_loc] = Yw.t()
+            G = torch.zeros((D1, ldg), dtype=torch.float64, device=Yw.device)
+            XtY = torch.zeros((4, ldg), dtype=torch.float64, device=Yw.device)
+            be.rls_gram(F, I.contiguous(), Yt, G, XtY)
+            if self.shard is not None:
+                self.shard.allreduce(G)
+                self.shard.allreduce(XtY)
+            W, info = be.rls_solve(G, D, self.lambd, XtY)               # (4, D+1) f64
+            if int(info.item()) != 0:
+                raise RuntimeError('RLS Cholesky failed for class %s (pivot %d)' % (chosen_classes[i], int(info.item()) - 1))
+            P = be.rls_predict_rows(F, I.contiguous(), W)                # (n, 4) = [X 1] w
+            losses = 0.5 * (P - Yw) ** 2
+            Beta = {}
+            for k in range(4):
+                Beta[str(k)] = {'weights': W[k, :D1].to(dev).type(torch.float32),
+                                'losses': losses[:, k].type(torch.float32)}
+            models = np.append(models, {'mu': mu.to(dev).type(torch.float32), 'T': T.to(dev).type(torch.float32),
+                                        'T_inv': T_inv.to(dev).type(torch.float32), 'Beta': Beta})
+            mean_losses = torch.stack([Beta[str(k)]['losses'].mean() for k in range(4)]) if n_loc else None
+            print('Mean losses:', mean_losses)
+        training_time = time.time() - start_time
+        print('Time required to train %d regressors: %f seconds.' % (num_clss - 1, training_time))
+        if output_dir:
+            with open(os.path.join(output_dir, "result.txt"), "a") as fid:
+                if self.is_rpn:
+                    fid.write("RPN's Online Region Refiner training time: {}min:{}s \n".format(
+                        int(training_time / 60), round(training_time % 60)))
+                else:
+                    fid.write("Detector's Online Region Refiner training time: {}min:{}s \n \n".format(
+                        int(training_time / 60), round(training_time % 60)))
+        return models
+
+    def _whiten_sharded(self, Yi, n_tot):
+        """Target statistics over all row shards: sum and second moment all-reduced (4 + 16 numbers)."""
+        s1 = Yi.sum(0)
+        self.shard.allreduce(s1)
+        mu = s1 / n_tot
+        Yc = Yi - mu
+        S = torch.matmul(Yc.t(), Yc)
+        self.shard.allreduce(S)
+        S = S / n_tot
+        evals, W = torch.linalg.eigh(S)
+        root = torch.sqrt(evals + 0.001)
+        return mu, Yc, W @ torch.diag(1.0 / root) @ W.t(), W @ torch.diag(root) @ W.t()
+
+
+class RegionPredictor:
+    def __init__(self, cfg, models):
+        self.cfg = cfg
+        self.models = models
+
+    def __call__(self, boxes, features, normalize_features=False, stats=None):
+        # the reference drops its normalisation arguments here (predict_regions.py:13)
+        return self.predict(boxes, features, normalize_features=False, stats=None)
+
+    def predict(self, boxes, features, normalize_features=False, stats=None):
+        be = _backend.get_backend()
+        dev = _device()
+        num_clss = len(self.cfg['CHOSEN_CLASSES'])
+        img_width, img_height = boxes[0].size[0], boxes[0].size[1]
+        for i in range(len(boxes)):
+            keep = np.nonzero(features[i]['gt'] == 0)          # ground-truth rows are excluded
+            feat = torch.tensor(features[i]['feat'][keep, :][0], device=dev)
+            if normalize_features:
+                feat = (feat - stats['mean']) * (20 / stats['mean_norm'].item())
+            F = be.features(feat)
+            ex_box = boxes[i].bbox.to(dev)
+            num_boxes = ex_box.size()[0]
+            out = [ex_box]
+            for j in range(1, num_clss):
+                m = self.models[j - 1]
+                W = torch.stack([m['Beta'][str(k)]['weights'] for k in range(4)]).to(F.X.device, torch.float64)
+                Y = be.rls_predict_rows(F, None, W.contiguous()).to(torch.float32)     # F w + b
+                Y = torch.matmul(Y, m['T_inv'].to(Y.device)) + m['mu'].to(Y.device)
+                out.append(decode_boxes(ex_box, Y, img_width, img_height, plus=float(np.spacing(1))))
+            boxes[i].bbox = torch.cat(out, dim=1).view((num_boxes, num_clss, 4))
+        return boxes
+
+
+def decode_boxes(ex_box, Y, img_width, img_height, plus):
+    """Box decoding of predict_regions.py:50-70: widths are x2 - x1 + `plus` (np.spacing(1) there,
+    1 in py_od_utils.decode_boxes_detector), the far corner is centre + w/2 - 1, clamped to the image."""
+    src_w = ex_box[:, 2] - ex_box[:, 0] + plus
+    src_h = ex_box[:, 3] - ex_box[:, 1] + plus
+    ctr_x = ex_box[:, 0] + 0.5 * src_w
+    ctr_y = ex_box[:, 1] + 0.5 * src_h
+    pred_ctr_x = Y[:, 0] * src_w + ctr_x
+    pred_ctr_y = Y[:, 1] * src_h + ctr_y
+    pred_w = torch.exp(Y[:, 2]) * src_w
+    pred_h = torch.exp(Y[:, 3]) * src_h
+    x1 = torch.clamp(pred_ctr_x - 0.5 * pred_w, min=0)
+    y1 = torch.clamp(pred_ctr_y - 0.5 * pred_h, min=0)
+    x2 = torch.clamp(pred_ctr_x + 0.5 * pred_w - 1, max=img_width - 1)
+    y2 = torch.clamp(pred_ctr_y + 0.5 * pred_h - 1, max=img_height - 1)
+    return torch.stack([x1, y1, x2, y2], dim=1)

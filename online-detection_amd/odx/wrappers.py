@@ -1,0 +1,103 @@
+"""FALKONWrapper: the reference's classifier plug-in for OnlineRegionClassifier, rebuilt on the
+odx estimators.  Behaviour follows
+src/modules/region-classifier/FALKONWrapper_with_centers_selection.py:16-95 (CPU / out-of-core)
+and ..._incore.py:16-99 (GPU resident): YAML keys, defaults with a printed notice, the Nystroem
+index rule (<= M/2 positives first, then negatives, sampled with replacement through the global
+torch RNG), M = len(indices), a deep copy of the fitted model as the return value."""
+import copy
+import sys
+
+import torch
+import yaml
+
+from . import falkon as _falkon
+
+
+class CenterSelector:
+    """MyCenterSelector (MyCenterSelector.py:3-15): hand the estimator pre-chosen rows."""
+
+    def __init__(self, center_indices):
+        self.center_indices = center_indices
+
+    def select(self, X, Y):
+        picked = X[self.center_indices, :]
+        if picked.dim() > 2:
+            picked = picked.squeeze()
+        if Y is None:
+            return picked
+        return picked, Y[self.center_indices, :]
+
+
+class FALKONWrapperBase:
+    incore = True
+
+    def __init__(self, cfg_path=None, is_rpn=False, is_segmentation=False):
+        if cfg_path is not None:
+            with open(cfg_path) as fid:
+                self.cfg = yaml.load(fid, Loader=yaml.FullLoader)
+            if is_rpn:
+                self.cfg = self.cfg['RPN']
+        section = 'ONLINE_SEGMENTATION' if is_segmentation else 'ONLINE_REGION_CLASSIFIER'
+        opts = self.cfg[section]['CLASSIFIER']
+        if 'sigma' in opts:
+            self.sigma = opts['sigma']
+        else:
+            print('Sigma not given for creating Falkon, default value is used.')
+            self.sigma = 5
+        if 'lambda' in opts:
+            self.lam = opts['lambda']
+        else:
+            print('Lambda not given for creating Falkon, default value is used.')
+            self.lam = 0.001
+        self.kernel = None
+        self.nyst_centers = opts['M']
+        if self.incore:
+            self.maxiter = 20  # falkon's default number of CG iterations
+
+    # the estimator classes are attributes so tests can swap in recorders
+    estimator_incore = _falkon.InCoreFalkon
+    estimator_cpu = _falkon.Falkon
+    kernel_cls = _falkon.GaussianKernel
+    options_cls = _falkon.FalkonOptions
+    selector_cls = CenterSelector
+
+    def train(self, X, y, sigma=None, lam=None):
+        sigma = self.sigma if sigma is None else sigma
+        lam = self.lam if lam is None else lam
+        self.kernel = self.kernel_cls(sigma=sigma)
+        indices = self.compute_indices_selection(y)
+        if self.incore:
+            if isinstance(indices, int):
+                indices = [indices]
+            opt = self.options_cls(min_cuda_iter_size_32=0, min_cuda_iter_size_64=0, keops_active="no",
+                                   min_cuda_pc_size_32=0, min_cuda_pc_size_64=0, store_kernel_d_threshold=250)
+            self.model = self.estimator_incore(kernel=self.kernel, penalty=lam, M=len(indices), maxiter=self.maxiter,
+                                               center_selection=self.selector_cls(indices), options=opt)
+        else:
+            opt = self.options_cls(min_cuda_iter_size_32=0, min_cuda_iter_size_64=0, keops_active="no")
+            self.model = self.estimator_cpu(kernel=self.kernel, penalty=lam, M=len(indices),
+                                            center_selection=self.selector_cls(indices), options=opt)
+        if self.model is None:
+            print('Model is None in trainRegionClassifier function')
+            sys.exit(0)
+        self.model.fit(X, y)
+        return copy.deepcopy(self.model)
+
+    def predict(self, model, X_np, y=None):
+        if y is not None:
+            return model.predict(X_np, y)
+        return model.predict(X_np)
+
+    def test(self):
+        pass
+
+    def compute_indices_selection(self, y):
+        half = int(self.nyst_centers / 2)
+        pos = (y == 1).nonzero()
+        if pos.size()[0] > half:
+            pos = pos[torch.randint(pos.size()[0], (half,))]
+        neg = (y == -1).nonzero()
+        room = self.nyst_centers - pos.size()[0]
+        if neg.size()[0] > room:
+            neg = neg[torch.randint(neg.size()[0], (room,))]
+        return torch.cat((pos, neg), dim=0).squeeze().tolist()

@@ -1,0 +1,71 @@
+"""The C-ABI boundary without a GPU: libodx.so loads, exports every function include/odx.h
+declares, and the ctypes binding table (odx/hip.py) has the same names and arities.  No compute
+call is made here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from odx import hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "odx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    out = {}
+    for m in re.finditer(r"\b(?:int|int64_t|const char\*)\s+(odx_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+    return out
+
+
+def test_library_is_built():
+    assert os.path.exists(hip.lib_path()), "run `make -C online-detection_amd/csrc` or __graft_entry__.build()"
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    funcs = header_functions()
+    assert len(funcs) >= 25
+    lib = ctypes.CDLL(hip.lib_path())
+    for name, nargs in funcs.items():
+        assert hasattr(lib, name), "libodx.so does not export %s" % name
+        assert name in hip.SIGNATURES, "odx/hip.py does not bind %s" % name
+        assert len(hip.SIGNATURES[name][1]) == nargs, "%s: header has %d args, binding %d" % (name, nargs, len(hip.SIGNATURES[name][1]))
+    assert set(hip.SIGNATURES) == set(funcs), set(hip.SIGNATURES) ^ set(funcs)
+
+
+def test_host_side_queries_work_without_a_gpu():
+    lib = hip.load()
+    assert lib.odx_version() >= 100
+    assert isinstance(lib.odx_last_error_string(), bytes)
+    assert lib.odx_potrf_workspace_bytes(300) == 3 * 128 * 128 * 8
+    assert lib.odx_rls_solve_workspace_bytes(1024) > 0
+
+
+def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch):
+    import torch
+    import odx
+    from odx import backend
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    backend.set_backend(None)
+    with pytest.raises(hip.OdxUnavailable):
+        odx.get_backend()
+    # and with a missing library
+    monkeypatch.setattr(hip, "_LIB", None)
+    monkeypatch.setattr(hip, "_LIB_PATH", "/nonexistent/libodx.so")
+    with pytest.raises(hip.OdxUnavailable):
+        hip.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "online-detection_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)

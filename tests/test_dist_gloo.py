@@ -1,0 +1,92 @@
+"""N > 1 on CPU: world_size-2 (and 3, ragged) gloo processes run the product's sharded FALKON
+driver (odx.solver + odx.dist.RowShard) over contiguous row shards with the numpy-oracle backend,
+and must reproduce the single-process fit; the sharded RLS Gram likewise."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import odx
+        from odx.dist import RowShard
+        from odx.rls import RegionRefinerTrainer
+        from tests.oracle_backend import OracleBackend
+        from tests.synth import blob_problem, centres
+        odx.set_backend(OracleBackend(np.float64))
+        be = odx.get_backend()
+        X, y, rng = blob_problem(n, 32, seed=77)
+        idx = centres(y, 96, rng)
+        shard = RowShard()
+        lo, hi = shard.bounds(n)
+        assert shard.total(hi - lo) == n
+        F = be.features(torch.from_numpy(X[lo:hi]))
+        Zf = be.features(torch.from_numpy(X[idx]))          # centres replicated on every rank
+        alpha = odx.falkon_fit(be, F, be.vec(y[lo:hi]), Zf, 6.0, 1e-4, 20, n_total=n, allreduce=shard.allreduce)
+        # sharded RLS: every rank holds a slice of COXY
+        g = torch.Generator().manual_seed(5)
+        Xr = torch.randn(300, 12, generator=g)
+        Cr = torch.randint(1, 3, (300, 1), generator=g).float()
+        Yr = torch.randn(300, 4, generator=g) * 0.2
+        l2, h2 = shard.bounds(300)
+        cfg = {"CHOSEN_CLASSES": {0: "bg", 1: "a", 2: "b"}, "REGION_REFINER": {"opts": {"lambda": 5.0}}}
+        import io
+        from contextlib import redirect_stdout
+        with redirect_stdout(io.StringIO()):
+            models = RegionRefinerTrainer(cfg, 5.0, False, shard=shard)({"C": Cr[l2:h2], "O": None, "X": Xr[l2:h2], "Y": Yr[l2:h2]})
+        W = np.stack([models[0]["Beta"][str(k)]["weights"].numpy() for k in range(4)])
+        if rank == 0:
+            ret["alpha"] = alpha.numpy()
+            ret["W"] = W
+            ret["T"] = models[0]["T"].numpy()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 1200), (3, 1001)])
+def test_sharded_fit_equals_single_process(world, n):
+    import odx
+    from oracle import falkon_ref as fr
+    from oracle import rls_ref
+    from tests.synth import blob_problem, centres
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, n, ret), nprocs=world, join=True)
+    X, y, rng = blob_problem(n, 32, seed=77)
+    idx = centres(y, 96, rng)
+    ref, _ = fr.falkon_fit(X.astype(np.float64), y, idx, 6.0, 1e-4, maxiter=20, dtype=np.float64, pc_eps=1e-5, cg_epsilon=1e-7)
+    a = ret["alpha"]
+    assert np.linalg.norm(a - ref[:, 0]) / np.linalg.norm(ref[:, 0]) < 1e-6
+    g = torch.Generator().manual_seed(5)
+    Xr = torch.randn(300, 12, generator=g)
+    Cr = torch.randint(1, 3, (300, 1), generator=g).float()
+    Yr = torch.randn(300, 4, generator=g) * 0.2
+    m = rls_ref.train(Cr.numpy(), Xr.numpy(), Yr.numpy(), 3, 5.0)[0]
+    assert np.abs(ret["W"] - m["W"]).max() < 2e-6 and np.abs(ret["T"] - m["T"]).max() < 2e-6
+
+
+def test_shard_bounds_cover_rows_exactly():
+    from odx.dist import shard_bounds
+    for n in (0, 1, 7, 1000, 1000003):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [h - l for l, h in b]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,297 @@
+"""Host logic of the product (solver, estimator objects, drop-in modules) on CPU, driven through
+the numpy-oracle backend (tests/oracle_backend.py) and checked against the oracle and against
+the golden vectors the reference itself produced (tests/golden/*.npz, *.json)."""
+import copy
+import io
+import json
+import os
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+import torch
+
+import odx
+from oracle import falkon_ref as fr
+from tests import dropin
+from tests.oracle_backend import OracleBackend
+from tests.synth import blob_problem, centres
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(autouse=True)
+def oracle_backend():
+    odx.set_backend(OracleBackend(np.float64))
+    yield
+    odx.set_backend(None)
+
+
+def quiet(fn, *a, **kw):
+    with redirect_stdout(io.StringIO()):
+        return fn(*a, **kw)
+
+
+# ------------------------------------------------------------------ solver / estimator objects
+@pytest.mark.parametrize("sigma,lam", [(5.0, 1e-3), (10.0, 1e-5)])
+def test_solver_equals_oracle(sigma, lam):
+    X, y, rng = blob_problem(1500, 48, seed=31)
+    idx = centres(y, 150, rng)
+    be = odx.get_backend()
+    F = be.features(torch.from_numpy(X))
+    alpha = odx.falkon_fit(be, F, be.vec(y), be.rows(F, idx), sigma, lam, 20).numpy()
+    ref, _ = fr.falkon_fit(X.astype(np.float64), y, idx, sigma, lam, maxiter=20, dtype=np.float64, pc_eps=1e-5,
+                           cg_epsilon=1e-7)
+    assert np.linalg.norm(alpha - ref[:, 0]) / np.linalg.norm(ref[:, 0]) < 1e-6
+
+
+def test_estimator_surface():
+    X, y, rng = blob_problem(600, 24, seed=8)
+    idx = centres(y, 60, rng)
+    from odx.wrappers import CenterSelector
+    m = odx.InCoreFalkon(kernel=odx.GaussianKernel(sigma=6.0), penalty=1e-3, M=len(idx), maxiter=20,
+                         center_selection=CenterSelector(idx), options=odx.FalkonOptions(keops_active="no"))
+    Xt, yt = torch.from_numpy(X), torch.from_numpy(y)
+    assert m.fit(Xt, yt) is m
+    assert m.M == 60 and tuple(m.ny_points_.shape) == (60, 24) and tuple(m.alpha_.shape) == (60, 1)
+    p = m.predict(Xt[:7])
+    assert tuple(p.shape) == (7, 1) and p.dtype == torch.float32
+    ref, Z = fr.falkon_fit(X.astype(np.float64), y, idx, 6.0, 1e-3, dtype=np.float64, pc_eps=1e-5, cg_epsilon=1e-7)
+    assert np.abs(p.numpy() - fr.falkon_predict(X[:7].astype(np.float64), Z, ref, 6.0)).max() < 1e-5
+    # what the callers do with a model: truthiness, deep copy, re-assignable tensors, pickle round trip
+    assert bool(m)
+    m2 = copy.deepcopy(m)
+    m2.alpha_ = m2.alpha_.to("cpu")
+    m2.ny_points_ = m2.ny_points_.to("cpu")
+    buf = io.BytesIO()
+    torch.save([m2, None], buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)[0]
+    assert torch.equal(m3.alpha_, m.alpha_) and m3.kernel.sigma == 6.0 and m3.M == 60
+    # kernel.mmv with a block-structured alpha_parallel (roi_box_predictors.py:140-160)
+    alpha_par = torch.zeros(120, 2, dtype=torch.float64)
+    alpha_par[:60, 0] = m.alpha_[:, 0]
+    alpha_par[60:, 1] = 2 * m.alpha_[:, 0]
+    s = m.kernel.mmv(Xt[:7], torch.cat([m.ny_points_, m.ny_points_]), alpha_par)
+    assert np.allclose(s[:, 0].numpy(), p[:, 0].numpy(), atol=1e-6) and np.allclose(s[:, 1].numpy(), 2 * p[:, 0].numpy(), atol=1e-5)
+
+
+def test_multi_output_fit_is_rejected_loudly():
+    m = odx.InCoreFalkon(kernel=odx.GaussianKernel(5.0), penalty=1e-3, M=10)
+    with pytest.raises(ValueError):
+        m.fit(torch.randn(50, 4), torch.randn(50, 2))
+
+
+def test_block_ranges():
+    from odx.falkon import block_ranges
+    v = torch.zeros(10, 4)
+    v[2:5, 0] = 1
+    v[5:10, 2] = -1
+    v[0, 3] = 3
+    assert block_ranges(v).tolist() == [[2, 5], [0, 0], [5, 10], [0, 1]]
+
+
+# ------------------------------------------------------------------ FALKONWrapper call contract
+@pytest.mark.parametrize("variant,modname", [("incore", "FALKONWrapper_with_centers_selection_incore"),
+                                              ("cpu", "FALKONWrapper_with_centers_selection")])
+def test_falkon_wrapper_contract_matches_reference(variant, modname):
+    contract = json.load(open(os.path.join(GOLD, "wrapper_contract.json")))[variant]
+    mod = dropin.load(modname)
+    rec = {"ctor": [], "fit": [], "select": []}
+
+    class Recorder:
+        def __init__(self, **kw):
+            from odx.falkon import FalkonOptions, GaussianKernel
+            rec["ctor"].append({k: (dict(v.extra) if isinstance(v, FalkonOptions) else
+                                    ("GaussianKernel(%g)" % v.sigma if isinstance(v, GaussianKernel) else
+                                     ("MyCenterSelector" if k == "center_selection" else v))) for k, v in kw.items()})
+            self.cs = kw["center_selection"]
+
+        def fit(self, X, y):
+            Z = self.cs.select(X, None)
+            rec["select"].append({"returns_tensor": bool(torch.is_tensor(Z)), "shape": list(Z.shape)})
+            rec["fit"].append({"X": list(X.shape), "y": list(y.shape), "y_dtype": str(y.dtype)})
+
+        def predict(self, X):
+            return torch.zeros(X.shape[0], 1)
+
+    w = mod.FALKONWrapper(cfg_path=os.path.join(GOLD, "cfg_bootstrap.yaml"))
+    w.estimator_incore = w.estimator_cpu = Recorder
+    assert {"sigma": w.sigma, "lam": w.lam, "nyst_centers": w.nyst_centers, "maxiter": getattr(w, "maxiter", None)} == contract["attrs"]
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(100, 8, generator=g)
+    y = torch.cat([torch.ones(30), -torch.ones(70)])
+    torch.manual_seed(77)
+    assert w.compute_indices_selection(y) == contract["indices_seed77"]
+    torch.manual_seed(77)
+    model = w.train(X, y, sigma=7.0, lam=0.01)
+    assert list(w.predict(model, X[:5]).shape) == contract["predict_shape"]
+    assert rec["ctor"] == contract["record"]["ctor"]
+    assert rec["fit"] == contract["record"]["fit"]
+    assert rec["select"] == contract["record"]["select"]
+    assert w.compute_indices_selection(torch.cat([torch.ones(5), -torch.ones(9)])) == contract["indices_small"]
+    assert isinstance(w.compute_indices_selection(torch.tensor([1.0])), int) == contract["indices_single_is_int"]
+
+
+# ------------------------------------------------------------------ minibootstrap state machine
+class RidgeClassifier:
+    """Same deterministic stand-in the golden generator plugged into the REFERENCE's loop."""
+
+    def __init__(self, lam=1.0):
+        self.lam = lam
+        self.calls = []
+
+    def train(self, X, y, sigma=None, lam=None):
+        A = torch.cat([X.double(), torch.ones(len(X), 1, dtype=torch.float64)], 1)
+        w = torch.linalg.solve(A.T @ A + self.lam * torch.eye(A.shape[1], dtype=torch.float64), A.T @ y.double())
+        self.calls.append(["train", int((y == 1).sum()), int((y == -1).sum())])
+        return {"w": w}
+
+    def predict(self, model, X, y=None):
+        A = torch.cat([X.double(), torch.ones(len(X), 1, dtype=torch.float64)], 1)
+        self.calls.append(["predict", len(X)])
+        return (A @ model["w"]).float().view(-1, 1)
+
+
+@pytest.mark.parametrize("variant,modname", [("cpu", "OnlineRegionClassifier"), ("incore", "OnlineRegionClassifier_incore")])
+def test_minibootstrap_matches_reference_trace(variant, modname):
+    G = np.load(os.path.join(GOLD, "bootstrap_golden.npz"))
+    mod = dropin.load(modname)
+    C, ITER = int(G["C"]), int(G["ITER"])
+    pos = [torch.from_numpy(G["pos_%d" % c]) for c in range(C)]
+    neg = [[torch.from_numpy(G["neg_%d_%d" % (c, j)]) for j in range(ITER)] for c in range(C)]
+    stats = {"mean": torch.from_numpy(G["mean"]), "std": torch.ones(int(G["D"])), "mean_norm": torch.tensor(float(G["mean_norm"]))}
+    clf = RidgeClassifier()
+    orc = mod.OnlineRegionClassifier(clf, pos, neg, stats, cfg_path=os.path.join(GOLD, "cfg_bootstrap.yaml"))
+    models = quiet(orc.trainRegionClassifier)
+    assert clf.calls == json.loads(str(G[variant + "_calls"]))
+    assert len(models) == C
+    for c, m in enumerate(models):
+        assert (m is None) == bool(G["%s_model_%d_none" % (variant, c)])
+        if m is not None:
+            assert np.allclose(m["w"].numpy(), G["%s_model_%d_w" % (variant, c)], rtol=1e-9, atol=1e-12)
+    assert np.allclose(pos[0].numpy(), G[variant + "_pos0_normalized"])  # normalised in place, once
+    assert orc.normalized
+    if variant == "incore":
+        tb = [{"boxes": G["test_boxes_%d" % im], "feat": G["test_feat_%d" % im], "gt": G["test_gt_%d" % im],
+               "img_size": (320, 240)} for im in range(2)]
+        orc2 = mod.OnlineRegionClassifier(RidgeClassifier(), pos, neg, stats, cfg_path=os.path.join(GOLD, "cfg_bootstrap.yaml"))
+        preds = quiet(orc2.testRegionClassifier, [models[0], models[0], models[2]], tb)
+        for im in range(2):
+            sc = preds[im].get_field("scores").numpy()
+            assert sc.shape == G["test_scores_%d" % im].shape and np.allclose(sc, G["test_scores_%d" % im], atol=1e-6)
+            assert np.all(sc[:, 0] == -1)  # background column of the stand-alone scorer
+
+
+def test_minibootstrap_return_caches_and_options():
+    G = np.load(os.path.join(GOLD, "bootstrap_golden.npz"))
+    mod = dropin.load("OnlineRegionClassifier_incore")
+    C, ITER = int(G["C"]), int(G["ITER"])
+    pos = [torch.from_numpy(G["pos_%d" % c]) for c in range(C)]
+    neg = [[torch.from_numpy(G["neg_%d_%d" % (c, j)]) for j in range(ITER)] for c in range(C)]
+    stats = {"mean": torch.from_numpy(G["mean"]), "std": torch.ones(int(G["D"])), "mean_norm": torch.tensor(float(G["mean_norm"]))}
+    orc = mod.OnlineRegionClassifier(RidgeClassifier(), pos, neg, stats, cfg_path=os.path.join(GOLD, "cfg_bootstrap.yaml"))
+    models, caches = quiet(orc.trainRegionClassifier, {"return_caches": True, "lam": 0.5, "sigma": 3})
+    assert orc.lam == 0.5 and orc.sigma == 3 and len(caches) == C
+    assert caches[1] == {} and models[1] is None and set(caches[0]) == {"pos", "neg"}
+
+
+# ------------------------------------------------------------------ py_od_utils
+def test_py_od_utils_match_reference():
+    H = np.load(os.path.join(GOLD, "helpers_golden.npz"))
+    u = dropin.load("py_od_utils")
+    C, D = 3, 16
+    positives = [torch.from_numpy(H["pos_%d" % c]) for c in range(C)]
+    negatives = [[torch.from_numpy(H["neg_%d_%d" % (c, j)]) for j in range(3)] for c in range(C)]
+    torch.manual_seed(1234)
+    st = quiet(u.computeFeatStatistics_torch, positives, negatives, num_samples=90, features_dim=D, cpu_tensor=True,
+               pos_fraction=0.8)
+    assert np.allclose(st["mean"].cpu().numpy(), H["stats_mean"], atol=1e-6)
+    assert np.allclose(st["std"].cpu().numpy(), H["stats_std"], atol=1e-6)
+    assert np.allclose(st["mean_norm"].cpu().numpy(), H["stats_mean_norm"], atol=1e-6)
+    COXY = {"C": torch.from_numpy(H["coxy_C"]), "O": None, "X": torch.from_numpy(H["coxy_X"]), "Y": None}
+    stc = {k: v.cpu() for k, v in st.items()}
+    assert np.allclose(u.normalize_COXY(dict(COXY), stc, cpu=True)["X"].numpy(), H["coxy_X_normalized"], atol=1e-6)
+    pf = u.load_positives_from_COXY({"C": COXY["C"][:, 0].clone(), "X": COXY["X"].clone()})
+    assert len(pf) == int(H["pos_from_coxy_n"])
+    for i, p in enumerate(pf):
+        assert np.array_equal(p.numpy(), H["pos_from_coxy_%d" % i])
+    torch.manual_seed(99)
+    sh = u.shuffle_negatives([[b.clone() for b in nb] for nb in negatives], batch_size=40, num_batches=3)
+    for c in range(C):
+        for j in range(3):
+            assert np.array_equal(sh[c][j].numpy(), H["shuf_%d_%d" % (c, j)])
+    assert np.allclose(u.zScores(positives[0].numpy(), stc["mean"], stc["mean_norm"]).numpy(), H["zscores"], atol=1e-6)
+    sel = dropin.load("MyCenterSelector")
+    Xs, Ys, idx = torch.from_numpy(H["sel_X"]), torch.from_numpy(H["sel_Y"]), H["sel_idx"].tolist()
+    assert np.array_equal(sel.MyCenterSelector(idx).select(Xs, None).numpy(), H["sel_out_X"])
+    xo, yo = sel.MyCenterSelector(idx).select(Xs, Ys)
+    assert np.array_equal(xo.numpy(), H["sel_out_X2"]) and np.array_equal(yo.numpy(), H["sel_out_Y2"])
+
+
+def test_decode_boxes_detector_and_feature_cache_roundtrip(tmp_path):
+    R = np.load(os.path.join(GOLD, "rls_golden.npz"))
+    u = dropin.load("py_od_utils")
+    from odx.boxlist import BoxList
+    out = u.decode_boxes_detector(BoxList(torch.from_numpy(R["apply_boxes_0"]), (320, 240)), torch.from_numpy(R["decode_in"]))
+    assert np.allclose(out.numpy(), R["decode_out"], atol=1e-4)
+    # on-disk feature cache layout (py_od_utils.py:153-217)
+    d = str(tmp_path)
+    for c in range(2):
+        for b in range(2):
+            torch.save(torch.full((3, 4), float(10 * c + b)), os.path.join(d, "positives_cl_%d_batch_%d" % (c, b)))
+            torch.save(torch.full((2, 4), -float(10 * c + b)), os.path.join(d, "negatives_cl_%d_batch_%d" % (c, b)))
+    torch.save(torch.ones(5, 4), os.path.join(d, "reg_x_batch_0"))
+    torch.save(torch.ones(5, 1), os.path.join(d, "reg_c_batch_0"))
+    torch.save(torch.ones(5, 4), os.path.join(d, "reg_y_batch_0"))
+    pos, neg = u.load_features_classifier(d, cpu_tensor=True)
+    assert [tuple(p.shape) for p in pos] == [(6, 4), (6, 4)] and [len(n) for n in neg] == [2, 2]
+    assert float(neg[1][1][0, 0]) == -11.0
+    pos_s, neg_s = u.load_features_classifier(d, is_segm=True, cpu_tensor=True)
+    assert tuple(neg_s[0].shape) == (4, 4)
+    coxy = u.load_features_regressor(d)
+    assert tuple(coxy["X"].shape) == (5, 4) and coxy["O"] is None
+
+
+# ------------------------------------------------------------------ RLS modules
+@pytest.mark.parametrize("tag,is_rpn", [("det", False), ("rpn", True)])
+def test_region_refiner_matches_reference(tag, is_rpn, tmp_path):
+    import yaml
+    R = np.load(os.path.join(GOLD, "rls_golden.npz"))
+    cfg = {"CHOSEN_CLASSES": {i: str(c) for i, c in enumerate(R["classes"])}, "REGION_REFINER": {"opts": {"lambda": float(R["lambda"])}}}
+    if is_rpn:
+        cfg = {"RPN": cfg}
+    path = str(tmp_path / "cfg.yaml")
+    yaml.safe_dump(cfg, open(path, "w"))
+    rr = dropin.load("region_refiner").RegionRefiner(path, is_rpn=is_rpn)
+    C = torch.from_numpy(R["C"] if not is_rpn else R["C"] - 1)
+    models = quiet(rr.trainRegionRefiner, {"C": C, "O": None, "X": torch.from_numpy(R["X"]), "Y": torch.from_numpy(R["Y"])},
+                   output_dir=str(tmp_path))
+    assert isinstance(models, np.ndarray) and len(models) == int(R[tag + "_num_models"])
+    for i, m in enumerate(models):
+        assert set(m) == {"mu", "T", "T_inv", "Beta"}
+        if bool(R["%s_%d_none" % (tag, i)]):
+            assert m["Beta"] is None and m["mu"] is None
+            continue
+        assert set(m["Beta"]) == {"0", "1", "2", "3"} and m["mu"].dtype == torch.float32
+        for key in ("mu", "T", "T_inv"):
+            assert np.allclose(m[key].cpu().numpy(), R["%s_%d_%s" % (tag, i, key)], atol=2e-6)
+        W = np.stack([m["Beta"][str(k)]["weights"].cpu().numpy() for k in range(4)])
+        assert np.abs(W - R["%s_%d_W" % (tag, i)]).max() < 2e-6
+        L = np.stack([m["Beta"][str(k)]["losses"].cpu().numpy() for k in range(4)])
+        assert np.abs(L - R["%s_%d_losses" % (tag, i)]).max() < 1e-5
+    line = open(os.path.join(str(tmp_path), "result.txt")).read()
+    assert line.startswith("RPN's Online Region Refiner training time" if is_rpn else "Detector's Online Region Refiner training time")
+    if not is_rpn:
+        from odx.boxlist import BoxList
+        import yaml as _y
+        cfg3 = {"CHOSEN_CLASSES": {0: "_background_", 1: "a", 2: "b"}, "REGION_REFINER": {"opts": {"lambda": 10.0}}}
+        p3 = str(tmp_path / "cfg3.yaml")
+        _y.safe_dump(cfg3, open(p3, "w"))
+        rr3 = dropin.load("region_refiner").RegionRefiner(p3)
+        boxes = [BoxList(torch.from_numpy(R["apply_boxes_%d" % im]), (320, 240)) for im in range(2)]
+        feats = [{"feat": R["apply_feat_%d" % im], "gt": R["apply_gt_%d" % im]} for im in range(2)]
+        res = rr3.predict(boxes, feats, models=models[:2])
+        for im in range(2):
+            assert tuple(res[im].bbox.shape) == R["apply_out_%d" % im].shape
+            assert np.abs(res[im].bbox.cpu().numpy() - R["apply_out_%d" % im]).max() < 2e-3
