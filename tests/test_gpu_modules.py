@@ -1,0 +1,205 @@
+"""The drop-in modules on the MI355X, through libodx.so, against (a) golden vectors produced by
+the reference's own code and (b) the same host logic driven by the f64 oracle."""
+import io
+import json
+import os
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from tests import dropin  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def quiet(fn, *a, **kw):
+    with redirect_stdout(io.StringIO()):
+        return fn(*a, **kw)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def hip_backend():
+    import odx
+    odx.set_backend(None)
+    be = odx.get_backend()
+    assert be.name == "hip-gfx950"
+    yield be
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    quiet(g.smoke)
+
+
+@pytest.mark.parametrize("tag,is_rpn", [("det", False), ("rpn", True)])
+def test_region_refiner_on_gpu_matches_reference(tag, is_rpn, tmp_path):
+    import yaml
+    R = np.load(os.path.join(GOLD, "rls_golden.npz"))
+    cfg = {"CHOSEN_CLASSES": {i: str(c) for i, c in enumerate(R["classes"])}, "REGION_REFINER": {"opts": {"lambda": float(R["lambda"])}}}
+    if is_rpn:
+        cfg = {"RPN": cfg}
+    path = str(tmp_path / "cfg.yaml")
+    yaml.safe_dump(cfg, open(path, "w"))
+    rr = dropin.load("region_refiner").RegionRefiner(path, is_rpn=is_rpn)
+    C = torch.from_numpy(R["C"] if not is_rpn else R["C"] - 1).cuda()
+    models = quiet(rr.trainRegionRefiner, {"C": C, "O": None, "X": torch.from_numpy(R["X"]).cuda(), "Y": torch.from_numpy(R["Y"]).cuda()})
+    assert len(models) == int(R[tag + "_num_models"])
+    for i, m in enumerate(models):
+        if bool(R["%s_%d_none" % (tag, i)]):
+            assert m["Beta"] is None
+            continue
+        assert m["mu"].is_cuda and m["Beta"]["0"]["weights"].is_cuda
+        for key in ("mu", "T", "T_inv"):
+            assert np.allclose(m[key].cpu().numpy(), R["%s_%d_%s" % (tag, i, key)], atol=2e-6)
+        W = np.stack([m["Beta"][str(k)]["weights"].cpu().numpy() for k in range(4)])
+        assert np.abs(W - R["%s_%d_W" % (tag, i)]).max() < 2e-6
+        L = np.stack([m["Beta"][str(k)]["losses"].cpu().numpy() for k in range(4)])
+        assert np.abs(L - R["%s_%d_losses" % (tag, i)]).max() < 1e-5
+    if not is_rpn:
+        from odx.boxlist import BoxList
+        cfg3 = {"CHOSEN_CLASSES": {0: "_background_", 1: "a", 2: "b"}, "REGION_REFINER": {"opts": {"lambda": 10.0}}}
+        p3 = str(tmp_path / "cfg3.yaml")
+        yaml.safe_dump(cfg3, open(p3, "w"))
+        rr3 = dropin.load("region_refiner").RegionRefiner(p3)
+        boxes = [BoxList(torch.from_numpy(R["apply_boxes_%d" % im]), (320, 240)) for im in range(2)]
+        feats = [{"feat": R["apply_feat_%d" % im], "gt": R["apply_gt_%d" % im]} for im in range(2)]
+        res = rr3.predict(boxes, feats, models=models[:2])
+        for im in range(2):
+            assert np.abs(res[im].bbox.cpu().numpy() - R["apply_out_%d" % im]).max() < 2e-3
+
+
+def test_rls_large_d_against_oracle(hip_backend):
+    """D = 2048 (the detector's feature size): D + 1 = 2049 exercises ragged tiles everywhere."""
+    from oracle import rls_ref
+    rng = np.random.default_rng(0)
+    n, D = 3000, 2048
+    X = (rng.standard_normal((n, D)) * 0.5 + 0.2).astype(np.float32)
+    Y = (rng.standard_normal((n, 4)) * 0.2).astype(np.float32)
+    C = np.ones((n, 1), np.float32)
+    from odx.rls import RegionRefinerTrainer
+    cfg = {"CHOSEN_CLASSES": {0: "bg", 1: "a"}, "REGION_REFINER": {"opts": {"lambda": 1000.0}}}
+    models = quiet(RegionRefinerTrainer(cfg, 1000.0, False), {"C": torch.from_numpy(C).cuda(), "O": None,
+                                                               "X": torch.from_numpy(X).cuda(), "Y": torch.from_numpy(Y).cuda()})
+    ref = rls_ref.train_class(X, Y, 1000.0)
+    W = np.stack([models[0]["Beta"][str(k)]["weights"].cpu().numpy() for k in range(4)])
+    assert np.abs(W - ref["W"]).max() < 1e-6 * max(1.0, np.abs(ref["W"]).max())
+
+
+class OracleFalkonClassifier:
+    """Test-side classifier plug-in: the reference wrapper's index rule + the f64 oracle fit."""
+
+    def __init__(self, M, maxiter=20):
+        self.M, self.maxiter = M, maxiter
+        self.sizes = []
+
+    def train(self, X, y, sigma=None, lam=None):
+        from oracle import falkon_ref as fr
+        Xn, yn = X.cpu().numpy().astype(np.float64), y.cpu().numpy().astype(np.float64)
+        idx = fr.compute_indices_selection(yn, self.M, lambda high, size: torch.randint(high, (size,)).numpy())
+        if isinstance(idx, int):
+            idx = [idx]
+        alpha, Z = fr.falkon_fit(Xn, yn, idx, sigma, lam, maxiter=self.maxiter, dtype=np.float64, pc_eps=1e-5, cg_epsilon=1e-7)
+        self.sizes.append((int((yn == 1).sum()), int((yn == -1).sum())))
+        return {"alpha": alpha, "Z": Z, "sigma": sigma}
+
+    def predict(self, model, X, y=None):
+        from oracle import falkon_ref as fr
+        p = fr.falkon_predict(X.cpu().numpy().astype(np.float64), model["Z"], model["alpha"], model["sigma"])
+        return torch.from_numpy(p).float().to(X.device)
+
+
+def test_minibootstrap_with_falkon_on_gpu_matches_oracle_pipeline(tmp_path):
+    """Reference-regime training: 3 classes x 4 negative batches, FALKON on the GPU inside the
+    hard/easy-negative loop, against the identical loop with the f64 oracle plugged in."""
+    import yaml
+    D, C, ITER, M = 64, 3, 4, 120
+    classes = ["_background_", "a", "b", "c"]
+    cfg = {"NUM_CLASSES": 4, "ONLINE_REGION_CLASSIFIER": {"MINIBOOTSTRAP": {"EASY_THRESH": -0.9, "HARD_THRESH": -0.7},
+                                                          "CLASSIFIER": {"lambda": 0.001, "sigma": 8, "M": M, "kernel_type": "gauss"}},
+           "CHOSEN_CLASSES": {i: c for i, c in enumerate(classes)}}
+    path = str(tmp_path / "cfg.yaml")
+    yaml.safe_dump(cfg, open(path, "w"))
+    g = torch.Generator().manual_seed(17)
+    mus = torch.randn(C, D, generator=g) * 1.2
+
+    def data():
+        gg = torch.Generator().manual_seed(18)
+        pos, neg = [], []
+        for c in range(C):
+            npos = [150, 0, 90][c]
+            pos.append((mus[c] + 0.6 * torch.randn(npos, D, generator=gg)).cuda() if npos else torch.empty((0, D)).cuda())
+            neg.append([(mus[(c + 1 + j % 2) % C] * (0.4 + 0.15 * j) + 0.9 * torch.randn(200, D, generator=gg)).cuda() for j in range(ITER)])
+        return pos, neg
+
+    stats = {"mean": torch.zeros(D).cuda(), "std": torch.ones(D).cuda(), "mean_norm": torch.tensor(8.0).cuda()}
+    wrapper = dropin.load("FALKONWrapper_with_centers_selection_incore").FALKONWrapper(cfg_path=path)
+    orc_mod = dropin.load("OnlineRegionClassifier_incore")
+    pos, neg = data()
+    torch.manual_seed(5)
+    models = quiet(orc_mod.OnlineRegionClassifier(wrapper, pos, neg, stats, cfg_path=path).trainRegionClassifier,
+                   output_dir=str(tmp_path))
+    pos2, neg2 = data()
+    oc = OracleFalkonClassifier(M)
+    torch.manual_seed(5)
+    ref_models = quiet(orc_mod.OnlineRegionClassifier(oc, pos2, neg2, stats, cfg_path=path).trainRegionClassifier)
+    assert [m is None for m in models] == [False, True, False] == [m is None for m in ref_models]
+    for m, r in zip(models, ref_models):
+        if m is None:
+            continue
+        assert m.M == r["Z"].shape[0] and tuple(m.alpha_.shape) == (m.M, 1)
+        assert np.allclose(m.ny_points_.cpu().numpy(), r["Z"], atol=1e-6)        # same centres => same selection trace
+        a = m.alpha_.cpu().numpy()
+        assert np.linalg.norm(a - r["alpha"]) / np.linalg.norm(r["alpha"]) < 1e-4
+    assert "Detector's Online Classifier training time" in open(os.path.join(str(tmp_path), "result.txt")).read()
+    # stand-alone scoring and the model-list device helper
+    u = dropin.load("py_od_utils")
+    cpu_models = [None if m is None else m for m in models]
+    for m in cpu_models:
+        if m is not None:
+            m.alpha_, m.ny_points_ = m.alpha_.cpu(), m.ny_points_.cpu()
+    moved = u.falkon_models_to_cuda(cpu_models)
+    assert moved[0].alpha_.is_cuda and moved[0].ny_points_.is_cuda
+
+
+def test_falkon_cpu_variant_returns_host_model(tmp_path):
+    import yaml
+    cfg = {"ONLINE_REGION_CLASSIFIER": {"MINIBOOTSTRAP": {"EASY_THRESH": -0.9, "HARD_THRESH": -0.7},
+                                        "CLASSIFIER": {"lambda": 0.001, "sigma": 6, "M": 50}}, "CHOSEN_CLASSES": {0: "bg", 1: "a"}}
+    path = str(tmp_path / "cfg.yaml")
+    yaml.safe_dump(cfg, open(path, "w"))
+    w = dropin.load("FALKONWrapper_with_centers_selection").FALKONWrapper(cfg_path=path)
+    from tests.synth import blob_problem
+    X, y, _ = blob_problem(400, 32, seed=2)
+    torch.manual_seed(0)
+    m = w.train(torch.from_numpy(X), torch.from_numpy(y))
+    assert not m.alpha_.is_cuda and not m.ny_points_.is_cuda and m.M == 50
+    p = w.predict(m, torch.from_numpy(X[:9]))
+    assert tuple(p.shape) == (9, 1) and not p.is_cuda
+
+
+def test_edge_cases(hip_backend):
+    """Single centre, centres fewer than M, duplicate centres, all-same labels are all legal."""
+    import odx
+    from oracle import falkon_ref as fr
+    from tests.synth import blob_problem
+    be = hip_backend
+    X, y, rng = blob_problem(500, 36, seed=12)
+    F = be.features(torch.from_numpy(X))
+    # duplicate centres (sampling with replacement) => singular K_MM, the jitter keeps chol alive
+    idx = [3, 3, 3, 10, 10, 42, 99, 99, 7, 8, 9, 11]
+    Zf = be.rows(F, idx)
+    alpha = odx.falkon_fit(be, F, be.vec(y), Zf, 6.0, 1e-3, 20)
+    ref, Z = fr.falkon_fit(X.astype(np.float64), y, idx, 6.0, 1e-3, dtype=np.float64, pc_eps=1e-5, cg_epsilon=1e-7)
+    pred = be.mmv(F, Zf, 6.0, alpha).cpu().numpy()
+    assert np.abs(pred - fr.falkon_predict(X.astype(np.float64), Z, ref, 6.0)).max() < 1e-4
+    # a single centre
+    Z1 = be.rows(F, [5])
+    a1 = odx.falkon_fit(be, F, be.vec(y), Z1, 6.0, 1e-3, 20)
+    r1, _ = fr.falkon_fit(X.astype(np.float64), y, [5], 6.0, 1e-3, dtype=np.float64, pc_eps=1e-5, cg_epsilon=1e-7)
+    assert abs(float(a1[0]) - r1[0, 0]) < 1e-6 * max(1.0, abs(r1[0, 0]))
+    # empty prediction batch
+    assert tuple(be.mmv(be.features(torch.zeros(0, 36)), Zf, 6.0, alpha).shape) == (0, 1)

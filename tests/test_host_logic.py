@@ -295,3 +295,40 @@ def test_region_refiner_matches_reference(tag, is_rpn, tmp_path):
         for im in range(2):
             assert tuple(res[im].bbox.shape) == R["apply_out_%d" % im].shape
             assert np.abs(res[im].bbox.cpu().numpy() - R["apply_out_%d" % im]).max() < 2e-3
+
+
+# ------------------------------------------------------------------ INTEGRATION.md route 2
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/modules/region-classifier"),
+                    reason="reference checkout only exists in the build container")
+def test_reference_wrapper_runs_unchanged_on_odx_falkon(monkeypatch):
+    """sys.modules['falkon'] = odx.falkon: the REFERENCE's own FALKONWrapper (CPU variant) trains and
+    predicts through odx.  (CPU test, never runs on the GPU box.)"""
+    import sys
+    import types
+    import odx.falkon
+    monkeypatch.setitem(sys.modules, "falkon", odx.falkon)
+    opts = types.ModuleType("falkon.options")
+    opts.FalkonOptions = odx.falkon.FalkonOptions
+    opts.__all__ = ["FalkonOptions"]
+    monkeypatch.setitem(sys.modules, "falkon.options", opts)
+    ref_dir = "/root/reference/src/modules/region-classifier"
+    src = open(os.path.join(ref_dir, "FALKONWrapper_with_centers_selection.py")).read()
+    mod = types.ModuleType("ref_wrapper_under_test")
+    mod.__file__ = os.path.join(ref_dir, "FALKONWrapper_with_centers_selection.py")
+    monkeypatch.syspath_prepend(ref_dir)
+    for name in ("ClassifierAbstract", "MyCenterSelector"):
+        monkeypatch.delitem(sys.modules, name, raising=False)
+    exec(compile(src, mod.__file__, "exec"), mod.__dict__)
+    for name in ("ClassifierAbstract", "MyCenterSelector"):
+        sys.modules.pop(name, None)
+    w = mod.FALKONWrapper(cfg_path=os.path.join(GOLD, "cfg_bootstrap.yaml"))
+    X, y, rng = blob_problem(300, 16, seed=4)
+    Xt, yt = torch.from_numpy(X), torch.from_numpy(y)
+    torch.manual_seed(3)
+    model = quiet(w.train, Xt, yt)
+    torch.manual_seed(3)
+    idx = fr.compute_indices_selection(y, 40, lambda high, size: torch.randint(high, (size,)).numpy())
+    ref, Z = fr.falkon_fit(X.astype(np.float64), y, idx, 10.0, 1e-3, maxiter=20, dtype=np.float64, pc_eps=1e-5, cg_epsilon=1e-7)
+    assert np.linalg.norm(model.alpha_.numpy() - ref) / np.linalg.norm(ref) < 1e-6
+    p = w.predict(model, Xt[:6])
+    assert tuple(p.shape) == (6, 1)
