@@ -4,11 +4,12 @@
 One "step" = one pass of the hot path over the whole synthetic job: for each of the C classes
 fit a FALKON classifier on the N rows (Nystroem centres by the reference rule, f64
 preconditioner, f32 K_nM build, 20 CG iterations on the stored K_nM) and score all N rows with
-it.  The N rows are sharded contiguously over the ranks (one process per GPU); each CG
-iteration exchanges one all-reduce of an (M,) f64 vector (RCCL).  N is the job size at every
+it.  The N rows are sharded contiguously over the ranks (one process per GPU); classes go in batches of
+world-size, each rank building the preconditioner of one class of the batch; each CG iteration
+exchanges one broadcast and one all-reduce of an (M,) f64 vector (RCCL).  N is the job size at every
 GPU count => "scaling": "strong".
 
-    python bench.py [--gpus N --steps K --warmup W] [--n 1000000 --D 1024 --M 10000 --classes 30]
+    python bench.py [--gpus N --steps K --warmup W] [--rows 1000000 --dim 1024 --centres 10000 --classes 30]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line (contract in the round prompt).  Inputs are resident in HBM before
@@ -38,17 +39,21 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1_000_000)
-    ap.add_argument("--D", type=int, default=1024)
-    ap.add_argument("--M", type=int, default=10_000)
+    ap.add_argument("--rows", dest="n", type=int, default=1_000_000)
+    ap.add_argument("--dim", dest="D", type=int, default=1024)
+    ap.add_argument("--centres", dest="M", type=int, default=10_000)
     ap.add_argument("--classes", type=int, default=30)
     ap.add_argument("--sigma", type=float, default=15.0)
     ap.add_argument("--lam", type=float, default=1e-5)
     ap.add_argument("--maxiter", type=int, default=20)
     ap.add_argument("--warmup-classes", type=int, default=2, help="classes run per warm-up step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=20000)
+    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0 = pick by host core count")
     ap.add_argument("--check", action="store_true", help="verify one class against the oracle on a row sample")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only for the "
+                    "single-device debugging mode below")
+    ap.add_argument("--single-device", action="store_true",
+                    help="debugging: every rank uses cuda:0 (exercises the sharded path on a 1-GPU box)")
     return ap.parse_args()
 
 
@@ -133,8 +138,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", init_method="env://")
+        torch.cuda.set_device(0 if args.single_device else local_rank)
+        dist.init_process_group(backend=args.dist_backend, init_method="env://")
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0:
@@ -171,52 +176,29 @@ def main():
         shard.allreduce(Z)
         return be.features(Z)
 
-    def run_class(c, timed):
-        Zf = gather_centres(cidx[c])
-        y = torch.where((row_ids % C) == c, 1.0, -1.0).to(torch.float64)
-        alpha = fit(be, F, y, Zf, timed)
-        with ph["mmv"] if timed else _null():
-            be.mmv(F, Zf, args.sigma, alpha, None, out=scores[:, c:c + 1])
-        return alpha, Zf
-
-    def fit(be, F, y, Zf, timed):
-        # odx.solver.falkon_fit with per-phase event brackets
-        n = float(N)
-        lam = args.lam
-        ar = shard.allreduce
-        with ph["precond"] if timed else _null():
-            P = be.precond(Zf, args.sigma, lam, opt.pc_epsilon)
-        with ph["knm"] if timed else _null():
-            K = be.knm(F, Zf, args.sigma, out=kbuf)
-
-        def ktk(**kw):
-            with ph["ktk"] if timed else _null():
-                r = be.ktk(K, **kw)
-            return ar(r)
-
-        def mmv(s, out):
-            v = be.trmv(P, "LAit", s)
-            t = be.trmv(P, "LTit", v)
-            cc = ktk(v=t)
-            u = be.trmv(P, "LTi", cc, alpha=1.0 / n, beta=lam, z=v)
-            return be.trmv(P, "LAi", u, out=out)
-
-        b0 = ktk(w=y * (1.0 / n))
-        B = be.trmv(P, "LAi", be.trmv(P, "LTi", b0))
-        Xv, R, Pv, AP = be.zeros(M), be.zeros(M), be.zeros(M), be.zeros(M)
-        state = be.zeros(4)
-        be.cg_init(B, Xv, R, Pv, state)
-        tol = opt.cg_tolerance ** 2
-        for it in range(args.maxiter):
-            mmv(Pv, AP)
-            full = (it + 1) % opt.cg_full_gradient_every == 0
-            be.cg_step(Xv, R, Pv, AP, state, opt.cg_epsilon, full)
-            if full:
-                mmv(Xv, AP)
-                R.copy_(B)
-                be.axpby(-1.0, AP, 1.0, R)
-            be.cg_finish(R, Pv, state, opt.cg_epsilon, tol)
-        return be.trmv(P, "LTit", be.trmv(P, "LAit", Xv))
+    def run_classes(classes, timed):
+        """Classes are processed in batches of `world`: first every rank builds the preconditioner
+        of the class it owns in the batch (owner = position in the batch: all ranks busy at once,
+        nothing replicated), then the batch's classes are fitted one after the other with the
+        rows sharded over all ranks (owner-computes CG, odx.solver.falkon_fit) and scored."""
+        out = None
+        for b0 in range(0, len(classes), world):
+            batch = classes[b0:b0 + world]
+            Zs = [gather_centres(cidx[c]) for c in batch]
+            P = None
+            if rank < len(batch):
+                with ph["precond"] if timed else _null():
+                    P = be.precond(Zs[rank], args.sigma, args.lam, opt.pc_epsilon)
+            for pos, c in enumerate(batch):
+                y = torch.where((row_ids % C) == c, 1.0, -1.0).to(torch.float64)
+                alpha = odx.falkon_fit(be, F, y, Zs[pos], args.sigma, args.lam, args.maxiter, opt, n_total=N,
+                                       knm_out=kbuf, phase=(lambda name: ph[name]) if timed else None,
+                                       precond=P if pos == rank else None, shard=shard, owner=pos)
+                with ph["mmv"] if timed else _null():
+                    be.mmv(F, Zs[pos], args.sigma, alpha, None, out=scores[:, c:c + 1])
+                out = (alpha, Zs[pos])
+            del P
+        return out
 
     def barrier():
         torch.cuda.synchronize()
@@ -226,16 +208,14 @@ def main():
 
     # ---- warm-up (untimed): a few classes are enough to touch every kernel and allocation
     for _ in range(args.warmup):
-        for c in range(min(args.warmup_classes, C)):
-            run_class(c, False)
+        run_classes(list(range(min(max(args.warmup_classes, world), C))), False)
     barrier()
 
     # ---- timed region: exactly K steps
     t0 = time.perf_counter()
     last = None
     for _ in range(args.steps):
-        for c in range(C):
-            last = run_class(c, True)
+        last = run_classes(list(range(C)), True)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -308,7 +288,9 @@ def cpu_baseline(args):
         thr = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         thr = os.cpu_count() or 1
-    ns, D, M = args.cpu_sample_rows, args.D, min(args.M, 4000)
+    big_host = thr >= 64
+    ns = args.cpu_sample_rows if args.cpu_sample_rows > 0 else (100000 if big_host else 20000)
+    D, M = args.D, (args.M if big_host else min(args.M, 4000))
     rng = np.random.default_rng(7)
     X = rng.standard_normal((ns, D)).astype(np.float32)
     X *= 20.0 / np.sqrt(D)
@@ -320,8 +302,9 @@ def cpu_baseline(args):
     dt = time.perf_counter() - t0
     return {"value": round(ns / (dt * args.classes), 2), "unit": "samples/s", "cores": int(thr), "kind": "port",
             "sample": "oracle/falkon_ref.py (numpy f32, stored K_nM): 1 class fit+predict on %d rows, D=%d, M=%d "
-                      "in %.1f s; value = rows / (seconds x %d classes); M reduced from %d to bound the O(M^3) "
-                      "host Cholesky" % (ns, D, M, dt, args.classes, args.M)}
+                      "in %.1f s; value = rows / (seconds x %d classes)%s" % (
+                          ns, D, M, dt, args.classes,
+                          "" if M == args.M else "; M reduced from %d to bound the O(M^3) host Cholesky" % args.M)}
 
 
 def check_against_oracle(be, F, last, X, row_ids, args, c):

@@ -353,30 +353,51 @@ int fill_f64(double* A, int64_t lda, int64_t rows, int64_t cols, double value, h
   return ODX_OK;
 }
 
-// Right-looking blocked Cholesky (lower), NB = 128:
-//   L11 = chol(A11), D = L11^-1            (one workgroup, LDS)
-//   L21 = A21 D'                           (NT GEMM, in place: one column tile per row panel)
-//   A22 -= L21 L21'                        (NT GEMM, lower tiles only)
+// Two-level right-looking blocked Cholesky (lower).  Outer panels of 512 columns, inner blocks
+// of NB = 128:
+//   inner, per 128-block inside the panel:
+//     L11 = chol(A11), D = L11^-1          (one workgroup, LDS)
+//     L21 = A21 D'                         (NT GEMM, in place: one column tile per row panel)
+//     A[below, rest of panel] -= L21 L21[rest of panel]'      (k = 128, only <= 384 columns wide)
+//   outer, per panel:
+//     A22 -= L21 L21'                      (k = 512: one read-modify-write of the trailing matrix
+//                                           per 512 columns instead of per 128, MFMA-bound)
+constexpr int POTRF_NBO = 512;
+
 int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hipStream_t stream) {
   constexpr int NB = POTRF_NB;
   ODX_REQUIRE(lda % 2 == 0 && aligned16(A) && aligned16(Dinv), "potrf_f64: A/Dinv must be 16-byte aligned, lda even");
-  for (int64_t k0 = 0, b = 0; k0 < M; k0 += NB, ++b) {
-    const int jb = (int)(M - k0 < NB ? M - k0 : NB);
-    double* Akk = A + k0 * lda + k0;
-    double* D = Dinv + b * NB * NB;
-    hipLaunchKernelGGL(potrf_diag_kernel<NB>, dim3(1), dim3(DB_NT), 0, stream, Akk, lda, jb, D, info, (int)k0);
-    ODX_CHECK_LAUNCH("potrf_diag");
-    const int64_t m = M - k0 - jb;
-    if (m <= 0) break;
-    double* A21 = A + (k0 + jb) * lda + k0;
-    GemmParams<double> t;
-    t.A = A21; t.lda = lda; t.B = D; t.ldb = NB; t.C = A21; t.ldc = lda;
-    t.m = m; t.n = jb; t.k = jb; t.alpha = 1.0; t.beta = 0.0; t.flags = ODX_GEMM_B_LOWER;
-    ODX_PROPAGATE(launch_gemm_f64(t, stream));
-    GemmParams<double> u;
-    u.A = A21; u.lda = lda; u.B = A21; u.ldb = lda; u.C = A + (k0 + jb) * lda + (k0 + jb); u.ldc = lda;
-    u.m = m; u.n = m; u.k = jb; u.alpha = -1.0; u.beta = 1.0; u.flags = ODX_GEMM_LOWER_ONLY;
-    ODX_PROPAGATE(launch_gemm_f64(u, stream));
+  for (int64_t K0 = 0; K0 < M; K0 += POTRF_NBO) {
+    const int64_t kbo = M - K0 < POTRF_NBO ? M - K0 : POTRF_NBO;
+    for (int64_t k0 = K0; k0 < K0 + kbo; k0 += NB) {
+      const int jb = (int)(M - k0 < NB ? M - k0 : NB);
+      double* D = Dinv + (k0 / NB) * NB * NB;
+      hipLaunchKernelGGL(potrf_diag_kernel<NB>, dim3(1), dim3(DB_NT), 0, stream, A + k0 * lda + k0, lda, jb, D, info,
+                         (int)k0);
+      ODX_CHECK_LAUNCH("potrf_diag");
+      const int64_t m = M - k0 - jb;
+      if (m <= 0) break;
+      double* A21 = A + (k0 + jb) * lda + k0;
+      GemmParams<double> t;
+      t.A = A21; t.lda = lda; t.B = D; t.ldb = NB; t.C = A21; t.ldc = lda;
+      t.m = m; t.n = jb; t.k = jb; t.alpha = 1.0; t.beta = 0.0; t.flags = ODX_GEMM_B_LOWER;
+      ODX_PROPAGATE(launch_gemm_f64(t, stream));
+      const int64_t pc = (K0 + kbo) - (k0 + jb);  // panel columns right of this block
+      if (pc > 0) {
+        GemmParams<double> u;
+        u.A = A21; u.lda = lda; u.B = A21; u.ldb = lda; u.C = A + (k0 + jb) * lda + (k0 + jb); u.ldc = lda;
+        u.m = m; u.n = pc; u.k = jb; u.alpha = -1.0; u.beta = 1.0; u.flags = ODX_GEMM_LOWER_ONLY;
+        ODX_PROPAGATE(launch_gemm_f64(u, stream));
+      }
+    }
+    const int64_t mt = M - K0 - kbo;
+    if (mt > 0) {
+      double* P = A + (K0 + kbo) * lda + K0;
+      GemmParams<double> u;
+      u.A = P; u.lda = lda; u.B = P; u.ldb = lda; u.C = A + (K0 + kbo) * (lda + 1); u.ldc = lda;
+      u.m = mt; u.n = mt; u.k = kbo; u.alpha = -1.0; u.beta = 1.0; u.flags = ODX_GEMM_LOWER_ONLY;
+      ODX_PROPAGATE(launch_gemm_f64(u, stream));
+    }
   }
   return ODX_OK;
 }

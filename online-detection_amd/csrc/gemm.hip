@@ -21,8 +21,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams<T> p) 
   }
   const int64_t n = p.n;
   const int64_t tiles_n = (n + GEMM_BN - 1) / GEMM_BN;
-  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t bi = wg / tiles_n, bj = wg % tiles_n;
+  // Tile order: workgroups b and b + 8 share an XCD (round-robin dispatch), so XCD x walks the
+  // tile rows x, x + 8, ... left to right: neighbours in time share the A row panel in that XCD's
+  // L2, and triangular work (lower-only output, k-ranges clipped by a triangular operand) is
+  // spread evenly over the XCDs instead of piling the long rows onto the last one.
+  const int64_t xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int64_t bi = xcd + 8 * (local / tiles_n), bj = local % tiles_n;
   const int64_t i0 = bi * GEMM_BM, j0 = bj * GEMM_BN;
   if (i0 >= m) return;
   if ((p.flags & ODX_GEMM_LOWER_ONLY) && j0 > i0 + GEMM_BM - 1) return;
@@ -46,10 +50,83 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams<T> p) 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const bool st = (p.flags & ODX_GEMM_STORE_T) != 0;
-  // Epilogue in batches of one tile-row (TN x NREG values): all reads of C first, then all
-  // writes — C may alias itself across iterations, so an interleaved read/modify/write would
-  // be serialised one memory round trip per element.
   const bool has_beta = p.beta != T(0);
+
+  if (p.vec_epilogue) {
+    // Epilogue staged through LDS in four 32-row slabs: accumulators -> LDS (as stored, or
+    // transposed), then every thread moves whole 16-byte segments, so C is read and written in
+    // full 1-KB rows (the MFMA accumulator layout alone gives 8-byte pieces of 4 rows per
+    // instruction) and the transposed / dual stores are as coalesced as the plain one.
+    constexpr int EPV = Tr::EPV;
+    constexpr int SLAB = 32;
+    constexpr int LDN = GEMM_BN + EPV;    // normal:      slab[r][c], r < 32,  c < 128
+    constexpr int LDT = SLAB + EPV;       // transposed:  slab[c][r], c < 128, r < 32
+    static_assert(sizeof(T) * SLAB * LDN <= GEMM_LDS_BYTES && sizeof(T) * GEMM_BN * LDT <= GEMM_LDS_BYTES, "slab");
+    T* slab = reinterpret_cast<T*>(lds);
+    typedef T VecT __attribute__((ext_vector_type(Tr::EPV)));
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int r0 = pass * SLAB;                       // tile rows [r0, r0 + 32)
+#pragma unroll
+      for (int variant = 0; variant < 2; ++variant) {   // 0: the C store, 1: the transposed copy C2
+        const bool tr = variant == 0 ? st : true;
+        if (variant == 1 && C2 == nullptr) continue;
+        __syncthreads();
+        if (wr == (pass >> 1)) {
+#pragma unroll
+          for (int tmh = 0; tmh < Tr::TM / 2; ++tmh) {
+            const int tm = (pass & 1) * (Tr::TM / 2) + tmh;
+#pragma unroll
+            for (int tn = 0; tn < Tr::TN; ++tn)
+#pragma unroll
+              for (int r = 0; r < Tr::NREG; ++r) {
+                const int rr = wr * 64 + gemm_acc_row<T>(tm, r, lane) - r0;
+                const int cc = wc * 64 + gemm_acc_col<T>(tn, lane);
+                slab[tr ? cc * LDT + rr : rr * LDN + cc] = acc[tm][tn][r];
+              }
+          }
+        }
+        __syncthreads();
+        // out(a, b): a = slow index, b = fast (contiguous) index of the destination
+        const int na = tr ? GEMM_BN : SLAB, nb = tr ? SLAB : GEMM_BN;
+        const int ldslab = tr ? LDT : LDN;
+        T* dst = variant == 0 ? C : C2;
+        const int64_t ldd = variant == 0 ? p.ldc : p.ldc2;
+        const int64_t a0 = tr ? j0 : i0 + r0, b0 = tr ? i0 + r0 : j0;
+        const int64_t alim = tr ? n : m, blim = tr ? m : n;
+        const int segs = nb / EPV;
+        for (int e = tid; e < na * segs; e += GEMM_THREADS) {
+          const int a = e / segs, b = (e % segs) * EPV;
+          const int64_t ga = a0 + a, gb = b0 + b;
+          if (ga >= alim || gb >= blim) continue;
+          VecT v = *reinterpret_cast<const VecT*>(slab + a * ldslab + b);
+          T* g = dst + ga * ldd + gb;
+          if (gb + EPV <= blim) {
+            VecT o;
+            if (variant == 0 && has_beta) {
+              const VecT c = *reinterpret_cast<const VecT*>(g);
+#pragma unroll
+              for (int q = 0; q < EPV; ++q) o[q] = p.alpha * v[q] + p.beta * c[q];
+            } else {
+#pragma unroll
+              for (int q = 0; q < EPV; ++q) o[q] = p.alpha * v[q];
+            }
+            *reinterpret_cast<VecT*>(g) = o;
+          } else {
+            for (int q = 0; q < EPV && gb + q < blim; ++q) {
+              T o = p.alpha * v[q];
+              if (variant == 0 && has_beta) o += p.beta * g[q];
+              g[q] = o;
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+
+  // scalar epilogue (unaligned C): batches of one tile-row, all reads of C before the writes
 #pragma unroll
   for (int tm = 0; tm < Tr::TM; ++tm) {
     T cv[Tr::TN][Tr::NREG];
@@ -87,10 +164,13 @@ static int launch_gemm(const GemmParams<T>& p, hipStream_t stream, const char* n
   ODX_REQUIRE(p.lda % EPV == 0 && p.ldb % EPV == 0, "%s: lda/ldb must be multiples of %d elements", name, EPV);
   ODX_REQUIRE(aligned16(p.A) && aligned16(p.B), "%s: A/B must be 16-byte aligned", name);
   ODX_REQUIRE(p.strideA % EPV == 0 && p.strideB % EPV == 0, "%s: batch strides must keep 16-byte alignment", name);
-  const int64_t tiles = ceil_div(p.m, GEMM_BM) * ceil_div(p.n, GEMM_BN);
+  const int64_t tiles = 8 * ceil_div(ceil_div(p.m, GEMM_BM), 8) * ceil_div(p.n, GEMM_BN);
   ODX_REQUIRE(tiles < (1ll << 31) && p.batches < 65536, "%s: grid too large", name);
   dim3 grid((unsigned)tiles, (unsigned)p.batches, 1);
-  hipLaunchKernelGGL(gemm_nt_kernel<T>, grid, dim3(GEMM_THREADS), 0, stream, p);
+  GemmParams<T> q = p;
+  q.vec_epilogue = aligned16(p.C) && p.ldc % EPV == 0 && p.strideC % EPV == 0 &&
+                   (p.C2 == nullptr || (aligned16(p.C2) && p.ldc2 % EPV == 0 && p.strideC2 % EPV == 0));
+  hipLaunchKernelGGL(gemm_nt_kernel<T>, grid, dim3(GEMM_THREADS), 0, stream, q);
   ODX_CHECK_LAUNCH(name);
   return ODX_OK;
 }

@@ -19,6 +19,7 @@ struct GemmParams {
   // ragged batches (trtri levels): m_b = clamp(ragged_total - ragged_off - b * ragged_step, 0, m)
   int64_t ragged_total = 0, ragged_off = 0, ragged_step = 0;
   int ragged_k_is_m = 0;               // k_b = m_b (GEMM 2 of a trtri level)
+  int vec_epilogue = 0;                // set by the launcher: C (and C2) allow 16-byte accesses
 };
 
 int launch_gemm_f64(const GemmParams<double>& p, hipStream_t stream);

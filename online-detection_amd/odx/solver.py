@@ -24,8 +24,16 @@ class SolverOptions:
     check_pivots: bool = True           # one host sync after the fit to report a failed Cholesky
 
 
+class _NoPhase:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
 def falkon_fit(be, F, y, Zf, sigma, lam, maxiter=20, opt=None, n_total=None, allreduce=None, knm_out=None,
-               return_knm=False):
+               return_knm=False, phase=None, precond=None, shard=None, owner=None):
     """Fit one binary FALKON problem.
 
     be        backend (odx.backend.HipBackend in the product)
@@ -35,43 +43,83 @@ def falkon_fit(be, F, y, Zf, sigma, lam, maxiter=20, opt=None, n_total=None, all
     n_total   number of rows over all shards (default: F.n)
     allreduce callable summing an f64 device vector in place over the row shards
               (odx.dist.RowShard.allreduce); None for a single shard
-    returns   alpha (M,) f64 device vector
+    shard, owner
+              owner-computes mode for row shards (odx.dist.RowShard + a rank id): only `owner`
+              holds the preconditioner and the CG state.  Per CG step the owner broadcasts the
+              (M,) direction T^-1 A^-1 p, every rank runs its K_nM pass, the partials are
+              all-reduced, and the owner alone applies the preconditioner and updates the
+              iterate; alpha is broadcast at the end.  Ranks other than the owner pass
+              precond=None and never build one.  Without `shard` every rank does everything
+              (replicated mode) and only `allreduce` is used.
+    phase     optional callable name -> context manager bracketing the launches of one kernel
+              family ("precond", "knm", "ktk"); bench.py hangs HIP-event timers on it
+    precond   an already computed preconditioner for (Zf, sigma, lam) to reuse
+    returns   alpha (M,) f64 device vector (on every rank)
     """
     opt = opt or SolverOptions()
     n = float(F.n if n_total is None else n_total)
     M = Zf.n
+    if shard is not None and allreduce is None:
+        allreduce = shard.allreduce
     ar = allreduce if allreduce is not None else (lambda v: v)
+    ph = phase if phase is not None else (lambda name: _NoPhase())
+    owned = shard is None or owner is None or shard.rank == owner   # this rank runs the M-sized algebra
+    bcast = (lambda v: shard.broadcast(v, src=owner)) if (shard is not None and owner is not None) else (lambda v: v)
 
-    P = be.precond(Zf, sigma, lam, opt.pc_epsilon)
-    K = be.knm(F, Zf, sigma, out=knm_out)
+    P = precond
+    if owned and P is None:
+        with ph("precond"):
+            P = be.precond(Zf, sigma, lam, opt.pc_epsilon)
+    with ph("knm"):
+        K = be.knm(F, Zf, sigma, out=knm_out)
+
+    def ktk(**kw):
+        with ph("ktk"):
+            r = be.ktk(K, **kw)
+        return ar(r)
+
+    t = be.zeros(M)
+    v = be.zeros(M)
 
     def mmv(s, out):
-        v = be.trmv(P, "LAit", s)                      # A^-1 s
-        t = be.trmv(P, "LTit", v)                      # T^-1 A^-1 s
-        cc = ar(be.ktk(K, v=t))                        # K' K t, summed over shards
-        u = be.trmv(P, "LTi", cc, alpha=1.0 / n, beta=lam, z=v)   # T^-T cc / n + lam v
-        return be.trmv(P, "LAi", u, out=out)           # A^-T u
+        """out = A^-T [ T^-T K'K (T^-1 A^-1 s) / n + lam A^-1 s ]  (owner); every rank passes over K."""
+        if owned:
+            be.trmv(P, "LAit", s, out=v)               # A^-1 s
+            be.trmv(P, "LTit", v, out=t)               # T^-1 A^-1 s
+        bcast(t)
+        cc = ktk(v=t)                                  # K' K t, summed over shards
+        if owned:
+            u = be.trmv(P, "LTi", cc, alpha=1.0 / n, beta=lam, z=v)   # T^-T cc / n + lam v
+            be.trmv(P, "LAi", u, out=out)              # A^-T u
 
     yn = y * (1.0 / n)
-    b0 = ar(be.ktk(K, w=yn))                           # K' (y / n)
-    B = be.trmv(P, "LAi", be.trmv(P, "LTi", b0))       # A^-T T^-T b0
-
+    b0 = ktk(w=yn)                                     # K' (y / n)
     X, R, Pv, AP = be.zeros(M), be.zeros(M), be.zeros(M), be.zeros(M)
     state = be.zeros(4)
-    be.cg_init(B, X, R, Pv, state)
+    if owned:
+        B = be.trmv(P, "LAi", be.trmv(P, "LTi", b0))   # A^-T T^-T b0
+        be.cg_init(B, X, R, Pv, state)
     tol = opt.cg_tolerance ** 2
     for it in range(maxiter):
         mmv(Pv, AP)
         full = (it + 1) % opt.cg_full_gradient_every == 0
-        be.cg_step(X, R, Pv, AP, state, opt.cg_epsilon, full)
+        if owned:
+            be.cg_step(X, R, Pv, AP, state, opt.cg_epsilon, full)
+        if it == maxiter - 1:
+            break    # the residual / direction update of the last step cannot change the returned X
         if full:
             mmv(X, AP)
-            R.copy_(B)
-            be.axpby(-1.0, AP, 1.0, R)                 # R = B - mmv(X)
-        be.cg_finish(R, Pv, state, opt.cg_epsilon, tol)
-    alpha = be.trmv(P, "LTit", be.trmv(P, "LAit", X))  # T^-1 A^-1 beta
-    if opt.check_pivots:
-        be.check_precond(P)
+            if owned:
+                R.copy_(B)
+                be.axpby(-1.0, AP, 1.0, R)             # R = B - mmv(X)
+        if owned:
+            be.cg_finish(R, Pv, state, opt.cg_epsilon, tol)
+    alpha = be.zeros(M)
+    if owned:
+        be.trmv(P, "LTit", be.trmv(P, "LAit", X), out=alpha)   # T^-1 A^-1 beta
+        if opt.check_pivots:
+            be.check_precond(P)
+    bcast(alpha)
     if return_knm:
         return alpha, K
     return alpha

@@ -38,6 +38,14 @@ def _worker(rank, world, port, n, ret):
         F = be.features(torch.from_numpy(X[lo:hi]))
         Zf = be.features(torch.from_numpy(X[idx]))          # centres replicated on every rank
         alpha = odx.falkon_fit(be, F, be.vec(y[lo:hi]), Zf, 6.0, 1e-4, 20, n_total=n, allreduce=shard.allreduce)
+        # owner-computes mode: only the last rank ever builds / applies the preconditioner
+        calls = []
+        orig = be.precond
+        be.precond = lambda *a, **k: (calls.append(rank), orig(*a, **k))[1]
+        alpha_own = odx.falkon_fit(be, F, be.vec(y[lo:hi]), Zf, 6.0, 1e-4, 20, n_total=n, shard=shard, owner=world - 1)
+        be.precond = orig
+        assert calls == ([rank] if rank == world - 1 else []), calls
+        assert torch.allclose(alpha_own, alpha, rtol=1e-9, atol=1e-12)
         # sharded RLS: every rank holds a slice of COXY
         g = torch.Generator().manual_seed(5)
         Xr = torch.randn(300, 12, generator=g)
