@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const T* __restrict__ X
 }
 
 // ---------------------------------------------------------------- K_nM (f32)
-__global__ __launch_bounds__(GEMM_THREADS) void gauss_knm_f32_kernel(
+__global__ __launch_bounds__(GEMM_THREADS, 3) void gauss_knm_f32_kernel(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ xsq, int64_t n,
     const float* __restrict__ Z, int64_t ldz, const float* __restrict__ zsq, int64_t M, int D, float gamma,
     float* __restrict__ K, int64_t ldk) {
@@ -72,65 +72,62 @@ __global__ __launch_bounds__(GEMM_THREADS) void gauss_knm_f32_kernel(
 }
 
 // ---------------------------------------------------------------- fused scoring (f32 K, f64 sums)
-__global__ __launch_bounds__(GEMM_THREADS) void gauss_mmv_f32_kernel(
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gauss_mmv_f32_kernel(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ xsq, int64_t n,
     const float* __restrict__ Z, int64_t ldz, const float* __restrict__ zsq, int D, float gamma,
     const double* __restrict__ V, int64_t ldv, const int32_t* __restrict__ ranges, float* __restrict__ out,
     int64_t ldo) {
   __shared__ __attribute__((aligned(16))) char lds[GEMM_LDS_BYTES];
   __shared__ double red[2][2][64];
+  __shared__ float xs_s[GEMM_BM];
   const int c = blockIdx.y;
   const int64_t s0 = ranges[2 * c], s1 = ranges[2 * c + 1];
   const int64_t i0 = (int64_t)blockIdx.x * GEMM_BM;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
 
-  double rowacc[2][16];
-#pragma unroll
-  for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) rowacc[tm][r] = 0.0;
-
-  float xs[2][16];
-#pragma unroll
-  for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t row = i0 + wr * 64 + gemm_acc_row<float>(tm, r, lane);
-      xs[tm][r] = row < n ? xsq[row] : 0.f;
-    }
+  if (threadIdx.x < GEMM_BM) xs_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] : 0.f;
+  // Running row sums: the wave owns 64 rows x 64 columns of every K tile; lane l keeps the f64
+  // total of row slot (l & 31) of its lane half, i.e. of row wr*64 + slot_row(l & 31, l >> 5).
+  double tot = 0.0;
 
   for (int64_t j0 = s0; j0 < s1; j0 += GEMM_BN) {
     f32x16 acc[2][2];
     gemm_zero_acc<float>(acc);
     gemm_mainloop<float>(acc, X, ldx, n, Z + j0 * ldz, ldz, s1 - j0, i0, 0, 0, D, lds);
+    float zs[2];
+    double al[2];
+    bool cv[2];
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) {
       const int64_t col = j0 + wc * 64 + gemm_acc_col<float>(tn, lane);
-      const bool cv = col < s1;
-      const float zs = cv ? zsq[col] : 0.f;
-      const double al = cv ? V[col * ldv + c] : 0.0;
+      cv[tn] = col < s1;
+      zs[tn] = cv[tn] ? zsq[col] : 0.f;
+      al[tn] = cv[tn] ? V[col * ldv + c] : 0.0;
+    }
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
+    for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float d2 = fmaf(-2.f, acc[tm][tn][r], xs[tm][r]) + zs;
+      for (int r = 0; r < 16; ++r) {
+        const float xs = xs_s[wr * 64 + gemm_acc_row<float>(tm, r, lane)];
+        double v = 0.0;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          float d2 = fmaf(-2.f, acc[tm][tn][r], xs) + zs[tn];
           d2 = fmaxf(d2, 0.f);
-          const float kv = cv ? expf(d2 * gamma) : 0.f;
-          rowacc[tm][r] = fma((double)kv, al, rowacc[tm][r]);
+          const float kv = cv[tn] ? expf(d2 * gamma) : 0.f;
+          v = fma((double)kv, al[tn], v);
         }
-    }
+        // sum over the 32 lanes holding this row's columns (the two lane halves stay apart)
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((lane & 31) == tm * 16 + r) tot += v;
+      }
   }
-  // sum over the 32 lanes that hold the columns of one row (keep the two lane halves apart)
-#pragma unroll
-  for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      double v = rowacc[tm][r];
-#pragma unroll
-      for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-      if ((lane & 31) == 0) red[wr][wc][gemm_acc_row<float>(tm, r, lane)] = v;
-    }
+  {
+    const int slot = lane & 31;
+    red[wr][wc][gemm_acc_row<float>(slot >> 4, slot & 15, lane)] = tot;
+  }
   __syncthreads();
   if (threadIdx.x < 128) {
     const int w = threadIdx.x >> 6, rr = threadIdx.x & 63;

@@ -6,10 +6,12 @@
 
 namespace odx {
 
-template <typename T>
+template <typename T, int BN>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams<T> p) {
-  __shared__ __attribute__((aligned(16))) char lds[GEMM_LDS_BYTES];
   using Tr = GemmTraits<T>;
+  constexpr int TN = GemmTileN<T, BN>::TN;
+  constexpr int LDS_BYTES = (GEMM_BM + BN) * GEMM_LDS_ROW;
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   const int b = blockIdx.y;
   int64_t m = p.m, k = p.k;
   if (p.ragged_total > 0) {
@@ -20,14 +22,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams<T> p) 
     if (p.ragged_k_is_m) k = mb;
   }
   const int64_t n = p.n;
-  const int64_t tiles_n = (n + GEMM_BN - 1) / GEMM_BN;
+  const int64_t tiles_n = (n + BN - 1) / BN;
   // Tile order: workgroups b and b + 8 share an XCD (round-robin dispatch), so XCD x walks the
   // tile rows x, x + 8, ... left to right: neighbours in time share the A row panel in that XCD's
   // L2, and triangular work (lower-only output, k-ranges clipped by a triangular operand) is
   // spread evenly over the XCDs instead of piling the long rows onto the last one.
   const int64_t xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
   const int64_t bi = xcd + 8 * (local / tiles_n), bj = local % tiles_n;
-  const int64_t i0 = bi * GEMM_BM, j0 = bj * GEMM_BN;
+  const int64_t i0 = bi * GEMM_BM, j0 = bj * BN;
   if (i0 >= m) return;
   if ((p.flags & ODX_GEMM_LOWER_ONLY) && j0 > i0 + GEMM_BM - 1) return;
 
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams<T> p) 
   if (p.flags & ODX_GEMM_A_UPPER) kb = max(kb, i0);
   if (p.flags & ODX_GEMM_B_UPPER) kb = max(kb, j0);
   if (p.flags & ODX_GEMM_A_LOWER) ke = min(ke, i0 + GEMM_BM);
-  if (p.flags & ODX_GEMM_B_LOWER) ke = min(ke, j0 + GEMM_BN);
+  if (p.flags & ODX_GEMM_B_LOWER) ke = min(ke, j0 + BN);
   kb = (kb / Tr::BK) * Tr::BK;
 
   const T* A = p.A + (int64_t)b * p.strideA;
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams<T> p) 
   T* C = p.C + (int64_t)b * p.strideC;
   T* C2 = p.C2 ? p.C2 + (int64_t)b * p.strideC2 : nullptr;
 
-  typename Tr::Acc acc[Tr::TM][Tr::TN];
+  typename Tr::Acc acc[Tr::TM][TN];
   gemm_zero_acc<T>(acc);
   gemm_mainloop<T>(acc, A, p.lda, m, B, p.ldb, n, i0, j0, kb, ke, lds);
 
@@ -59,9 +61,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams<T> p) 
     // instruction) and the transposed / dual stores are as coalesced as the plain one.
     constexpr int EPV = Tr::EPV;
     constexpr int SLAB = 32;
-    constexpr int LDN = GEMM_BN + EPV;    // normal:      slab[r][c], r < 32,  c < 128
-    constexpr int LDT = SLAB + EPV;       // transposed:  slab[c][r], c < 128, r < 32
-    static_assert(sizeof(T) * SLAB * LDN <= GEMM_LDS_BYTES && sizeof(T) * GEMM_BN * LDT <= GEMM_LDS_BYTES, "slab");
+    constexpr int LDN = BN + EPV;         // normal:      slab[r][c], r < 32, c < BN
+    constexpr int LDT = SLAB + EPV;       // transposed:  slab[c][r], c < BN, r < 32
+    static_assert(sizeof(T) * SLAB * LDN <= LDS_BYTES && sizeof(T) * BN * LDT <= LDS_BYTES, "slab");
     T* slab = reinterpret_cast<T*>(lds);
     typedef T VecT __attribute__((ext_vector_type(Tr::EPV)));
     const int tid = threadIdx.x;
@@ -78,18 +80,18 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams<T> p) 
           for (int tmh = 0; tmh < Tr::TM / 2; ++tmh) {
             const int tm = (pass & 1) * (Tr::TM / 2) + tmh;
 #pragma unroll
-            for (int tn = 0; tn < Tr::TN; ++tn)
+            for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
               for (int r = 0; r < Tr::NREG; ++r) {
                 const int rr = wr * 64 + gemm_acc_row<T>(tm, r, lane) - r0;
-                const int cc = wc * 64 + gemm_acc_col<T>(tn, lane);
+                const int cc = wc * (BN / 2) + gemm_acc_col<T>(tn, lane);
                 slab[tr ? cc * LDT + rr : rr * LDN + cc] = acc[tm][tn][r];
               }
           }
         }
         __syncthreads();
         // out(a, b): a = slow index, b = fast (contiguous) index of the destination
-        const int na = tr ? GEMM_BN : SLAB, nb = tr ? SLAB : GEMM_BN;
+        const int na = tr ? BN : SLAB, nb = tr ? SLAB : BN;
         const int ldslab = tr ? LDT : LDN;
         T* dst = variant == 0 ? C : C2;
         const int64_t ldd = variant == 0 ? p.ldc : p.ldc2;
@@ -129,23 +131,23 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams<T> p) 
   // scalar epilogue (unaligned C): batches of one tile-row, all reads of C before the writes
 #pragma unroll
   for (int tm = 0; tm < Tr::TM; ++tm) {
-    T cv[Tr::TN][Tr::NREG];
+    T cv[TN][Tr::NREG];
     if (has_beta) {
 #pragma unroll
-      for (int tn = 0; tn < Tr::TN; ++tn)
+      for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
         for (int r = 0; r < Tr::NREG; ++r) {
           const int64_t row = i0 + wr * 64 + gemm_acc_row<T>(tm, r, lane);
-          const int64_t col = j0 + wc * 64 + gemm_acc_col<T>(tn, lane);
+          const int64_t col = j0 + wc * (BN / 2) + gemm_acc_col<T>(tn, lane);
           cv[tn][r] = (row < m && col < n) ? C[st ? col * p.ldc + row : row * p.ldc + col] : T(0);
         }
     }
 #pragma unroll
-    for (int tn = 0; tn < Tr::TN; ++tn)
+    for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int r = 0; r < Tr::NREG; ++r) {
         const int64_t row = i0 + wr * 64 + gemm_acc_row<T>(tm, r, lane);
-        const int64_t col = j0 + wc * 64 + gemm_acc_col<T>(tn, lane);
+        const int64_t col = j0 + wc * (BN / 2) + gemm_acc_col<T>(tn, lane);
         if (row < m && col < n) {
           T val = p.alpha * acc[tm][tn][r];
           if (has_beta) val += p.beta * cv[tn][r];
@@ -164,13 +166,21 @@ static int launch_gemm(const GemmParams<T>& p, hipStream_t stream, const char* n
   ODX_REQUIRE(p.lda % EPV == 0 && p.ldb % EPV == 0, "%s: lda/ldb must be multiples of %d elements", name, EPV);
   ODX_REQUIRE(aligned16(p.A) && aligned16(p.B), "%s: A/B must be 16-byte aligned", name);
   ODX_REQUIRE(p.strideA % EPV == 0 && p.strideB % EPV == 0, "%s: batch strides must keep 16-byte alignment", name);
-  const int64_t tiles = 8 * ceil_div(ceil_div(p.m, GEMM_BM), 8) * ceil_div(p.n, GEMM_BN);
+  // 128 x 64 tiles (two or three workgroups per CU hide each other's barriers and load latency)
+  // unless the product is computed in place over its own A operand: then one workgroup must own
+  // every column of a row panel (n <= 128), which needs the 128-wide tile.
+  const bool inplace = static_cast<const void*>(p.C) == static_cast<const void*>(p.A);
+  if (inplace) ODX_REQUIRE(p.n <= GEMM_BN, "%s: in-place product needs n <= %d", name, GEMM_BN);
+  const bool narrow = sizeof(T) == 8 && !inplace;   // f64: 128 x 64 tiles; f32 keeps 128 x 128
+  const int bn = narrow ? 64 : GEMM_BN;
+  const int64_t tiles = 8 * ceil_div(ceil_div(p.m, GEMM_BM), 8) * ceil_div(p.n, bn);
   ODX_REQUIRE(tiles < (1ll << 31) && p.batches < 65536, "%s: grid too large", name);
   dim3 grid((unsigned)tiles, (unsigned)p.batches, 1);
   GemmParams<T> q = p;
   q.vec_epilogue = aligned16(p.C) && p.ldc % EPV == 0 && p.strideC % EPV == 0 &&
                    (p.C2 == nullptr || (aligned16(p.C2) && p.ldc2 % EPV == 0 && p.strideC2 % EPV == 0));
-  hipLaunchKernelGGL(gemm_nt_kernel<T>, grid, dim3(GEMM_THREADS), 0, stream, q);
+  if (!narrow) hipLaunchKernelGGL((gemm_nt_kernel<T, GEMM_BN>), grid, dim3(GEMM_THREADS), 0, stream, q);
+  else hipLaunchKernelGGL((gemm_nt_kernel<T, 64>), grid, dim3(GEMM_THREADS), 0, stream, q);
   ODX_CHECK_LAUNCH(name);
   return ODX_OK;
 }

@@ -37,7 +37,7 @@ template <>
 struct GemmTraits<float> {
   static constexpr int BK = 32;   // elements per k-tile
   static constexpr int EPV = 4;   // elements per 16 B
-  static constexpr int TM = 2, TN = 2, MT = 32, NREG = 16;
+  static constexpr int TM = 2, TN = 2, MT = 32, NREG = 16;  // TN for a 128-wide tile
   typedef f32x16 Acc;
 };
 template <>
@@ -47,11 +47,17 @@ struct GemmTraits<double> {
   static constexpr int TM = 4, TN = 4, MT = 16, NREG = 4;
   typedef f64x4 Acc;
 };
+// MFMA tiles across a wave's share (BN / 2 columns) of a BN-wide block tile
+template <typename T, int BN>
+struct GemmTileN {
+  static constexpr int TN = BN / 2 / GemmTraits<T>::MT;
+  static_assert(TN >= 1, "block tile too narrow for this MFMA shape");
+};
 
-template <typename T>
+template <typename T, int BN = GEMM_BN>
 struct GemmStage {
   u32x4 a[4];
-  u32x4 b[4];
+  u32x4 b[BN / 32];   // BN rows x 8 segments / 256 threads
 };
 
 // One operand tile: 128 rows x 128 B.  Thread t fetches 16-B segments idx = t + 256 p:
@@ -59,13 +65,13 @@ struct GemmStage {
 // CLEAN = the whole k-tile lies inside [0, K): no per-element masking, so the four loads issue
 // back to back and are only waited for at the LDS store (a mask applied right after each load
 // would serialise them behind s_waitcnt vmcnt(0)).
-template <typename T, bool CLEAN>
-__device__ __forceinline__ void gemm_load_operand(u32x4 (&r)[4], const T* __restrict__ base, int64_t ld,
+template <typename T, bool CLEAN, int NP>
+__device__ __forceinline__ void gemm_load_operand(u32x4 (&r)[NP], const T* __restrict__ base, int64_t ld,
                                                   int64_t row0, int64_t nrows, int64_t k0, int64_t K) {
   constexpr int EPV = GemmTraits<T>::EPV;
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < NP; ++p) {
     const int idx = tid + GEMM_THREADS * p;
     const int row = idx >> 3;
     const int seg = idx & 7;
@@ -87,65 +93,70 @@ __device__ __forceinline__ void gemm_load_operand(u32x4 (&r)[4], const T* __rest
   }
 }
 
-template <typename T>
-__device__ __forceinline__ void gemm_load_stage(GemmStage<T>& st, const T* __restrict__ A, int64_t lda, int64_t m,
+template <typename T, int BN>
+__device__ __forceinline__ void gemm_load_stage(GemmStage<T, BN>& st, const T* __restrict__ A, int64_t lda, int64_t m,
                                                 const T* __restrict__ B, int64_t ldb, int64_t n, int64_t i0,
                                                 int64_t j0, int64_t kt, int64_t ke) {
   if (kt + GemmTraits<T>::BK <= ke) {
-    gemm_load_operand<T, true>(st.a, A, lda, i0, m, kt, ke);
-    gemm_load_operand<T, true>(st.b, B, ldb, j0, n, kt, ke);
+    gemm_load_operand<T, true, 4>(st.a, A, lda, i0, m, kt, ke);
+    gemm_load_operand<T, true, BN / 32>(st.b, B, ldb, j0, n, kt, ke);
   } else {
-    gemm_load_operand<T, false>(st.a, A, lda, i0, m, kt, ke);
-    gemm_load_operand<T, false>(st.b, B, ldb, j0, n, kt, ke);
+    gemm_load_operand<T, false, 4>(st.a, A, lda, i0, m, kt, ke);
+    gemm_load_operand<T, false, BN / 32>(st.b, B, ldb, j0, n, kt, ke);
   }
 }
 
-__device__ __forceinline__ void gemm_store_operand(const u32x4 (&r)[4], char* lds) {
+template <int NP>
+__device__ __forceinline__ void gemm_store_operand(const u32x4 (&r)[NP], char* lds) {
   const int tid = threadIdx.x;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < NP; ++p) {
     const int idx = tid + GEMM_THREADS * p;
     *reinterpret_cast<u32x4*>(lds + (idx >> 3) * GEMM_LDS_ROW + (idx & 7) * 16) = r[p];
   }
 }
 
 // MFMA work of one k-tile held in LDS.  wr / wc = wave row / column (0..1).
-__device__ __forceinline__ void gemm_compute_ktile(f32x16 (&acc)[2][2], const char* ldsA, const char* ldsB,
+template <int TN>
+__device__ __forceinline__ void gemm_compute_ktile(f32x16 (&acc)[2][TN], const char* ldsA, const char* ldsB,
                                                    int wr, int wc, int lane) {
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    f32x4 a[2], b[2];
+    f32x4 a[2], b[TN];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < 2; ++t)
       a[t] = *reinterpret_cast<const f32x4*>(ldsA + (wr * 64 + t * 32 + r) * GEMM_LDS_ROW + (ks * 8 + h * 4) * 4);
-      b[t] = *reinterpret_cast<const f32x4*>(ldsB + (wc * 64 + t * 32 + r) * GEMM_LDS_ROW + (ks * 8 + h * 4) * 4);
-    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+      b[t] = *reinterpret_cast<const f32x4*>(ldsB + (wc * 32 * TN + t * 32 + r) * GEMM_LDS_ROW + (ks * 8 + h * 4) * 4);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
+        for (int tn = 0; tn < TN; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][s], b[tn][s], acc[tm][tn], 0, 0, 0);
   }
 }
 
-__device__ __forceinline__ void gemm_compute_ktile(f64x4 (&acc)[4][4], const char* ldsA, const char* ldsB,
+template <int TN>
+__device__ __forceinline__ void gemm_compute_ktile(f64x4 (&acc)[4][TN], const char* ldsA, const char* ldsB,
                                                    int wr, int wc, int lane) {
   const int r = lane & 15, kq = lane >> 4;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    double a[4], b[4];
+    double a[4], b[TN];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 4; ++t)
       a[t] = *reinterpret_cast<const double*>(ldsA + (wr * 64 + t * 16 + r) * GEMM_LDS_ROW + (ks * 4 + kq) * 8);
-      b[t] = *reinterpret_cast<const double*>(ldsB + (wc * 64 + t * 16 + r) * GEMM_LDS_ROW + (ks * 4 + kq) * 8);
-    }
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+      b[t] = *reinterpret_cast<const double*>(ldsB + (wc * 16 * TN + t * 16 + r) * GEMM_LDS_ROW + (ks * 4 + kq) * 8);
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn)
+      for (int tn = 0; tn < TN; ++tn)
         acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
   }
 }
@@ -170,12 +181,19 @@ __device__ __forceinline__ int gemm_acc_col<float>(int tn, int lane) { return tn
 template <>
 __device__ __forceinline__ int gemm_acc_col<double>(int tn, int lane) { return tn * 16 + (lane & 15); }
 
-// acc += A[i0.., kb..ke) * B[j0.., kb..ke)'.  kb must be a multiple of BK.  lds: GEMM_LDS_BYTES.
-template <typename T>
-__device__ __forceinline__ void gemm_mainloop(typename GemmTraits<T>::Acc (&acc)[GemmTraits<T>::TM][GemmTraits<T>::TN],
+// acc += A[i0.., kb..ke) * B[j0.., kb..ke)'.  kb must be a multiple of BK.  lds: one k-tile,
+// (GEMM_BM + BN) * GEMM_LDS_ROW bytes.  The next k-tile's global loads are issued before the
+// MFMA work of the current one and land in registers; two barriers per k-tile order the LDS
+// refill.  (Measured on MI355X: a second LDS buffer with one barrier per k-tile, and a two-deep
+// register prefetch, both run at the same rate as this form — the 128 x 128 f32 tile sits at
+// ~76 % MFMA-busy whatever the staging scheme — so the smallest LDS footprint is kept and spent
+// on a third resident workgroup per CU instead.)
+template <typename T, int TN>
+__device__ __forceinline__ void gemm_mainloop(typename GemmTraits<T>::Acc (&acc)[GemmTraits<T>::TM][TN],
                                               const T* __restrict__ A, int64_t lda, int64_t m,
                                               const T* __restrict__ B, int64_t ldb, int64_t n, int64_t i0,
                                               int64_t j0, int64_t kb, int64_t ke, char* lds) {
+  constexpr int BN = 2 * TN * GemmTraits<T>::MT;
   constexpr int BK = GemmTraits<T>::BK;
   char* ldsA = lds;
   char* ldsB = lds + GEMM_BM * GEMM_LDS_ROW;
@@ -183,26 +201,24 @@ __device__ __forceinline__ void gemm_mainloop(typename GemmTraits<T>::Acc (&acc)
   const int wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   if (kb >= ke) return;
-  GemmStage<T> st;
-  gemm_load_stage<T>(st, A, lda, m, B, ldb, n, i0, j0, kb, ke);
+  GemmStage<T, BN> st;
+  gemm_load_stage<T, BN>(st, A, lda, m, B, ldb, n, i0, j0, kb, ke);
   for (int64_t kt = kb; kt < ke; kt += BK) {
     __syncthreads();  // everyone finished reading the previous k-tile
     gemm_store_operand(st.a, ldsA);
     gemm_store_operand(st.b, ldsB);
     __syncthreads();
-    if (kt + BK < ke) {  // next k-tile's global loads fly under this tile's MFMAs
-      gemm_load_stage<T>(st, A, lda, m, B, ldb, n, i0, j0, kt + BK, ke);
-    }
+    if (kt + BK < ke) gemm_load_stage<T, BN>(st, A, lda, m, B, ldb, n, i0, j0, kt + BK, ke);
     gemm_compute_ktile(acc, ldsA, ldsB, wr, wc, lane);
   }
 }
 
-template <typename T>
-__device__ __forceinline__ void gemm_zero_acc(typename GemmTraits<T>::Acc (&acc)[GemmTraits<T>::TM][GemmTraits<T>::TN]) {
+template <typename T, int TN>
+__device__ __forceinline__ void gemm_zero_acc(typename GemmTraits<T>::Acc (&acc)[GemmTraits<T>::TM][TN]) {
 #pragma unroll
   for (int tm = 0; tm < GemmTraits<T>::TM; ++tm)
 #pragma unroll
-    for (int tn = 0; tn < GemmTraits<T>::TN; ++tn)
+    for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int r = 0; r < GemmTraits<T>::NREG; ++r) acc[tm][tn][r] = T(0);
 }

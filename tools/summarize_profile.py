@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_round.sh output directory into the markdown committed under profiles/."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+d = sys.argv[1]
+print("# rocprofv3 summary (%s)\n" % os.path.basename(d))
+try:
+    b = json.loads(open(os.path.join(d, "bench_n1.json")).read().strip().splitlines()[-1])
+    print("bench.py (un-profiled): value %.1f %s, %.1f ms/step, roofline %s\n" % (b["value"], b["unit"], b["ms_per_step"], json.dumps(b["roofline"])))
+    print("phases (ms/step, rank 0): %s\n" % json.dumps(b["phases_ms_per_step_rank0"]))
+    print("cpu_baseline: %s\n" % json.dumps(b.get("cpu_baseline")))
+except Exception as e:  # noqa: BLE001
+    print("(no bench line: %s)\n" % e)
+stats = os.path.join(d, "bench_kernel_stats.csv")
+if os.path.exists(stats):
+    print("## `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline` (top kernels)\n")
+    print("| kernel | calls | total ms | avg us | % |")
+    print("|---|---|---|---|---|")
+    for r in list(csv.DictReader(open(stats)))[:14]:
+        print("| `%s` | %s | %.1f | %.1f | %s |" % (r["Name"].split("(")[0][-60:], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                  float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    print()
+print("## PMC passes on one launch of each hot kernel at the headline shard shape (n=1e6, M=1e4, D=1024)\n")
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+dur = collections.defaultdict(list)
+for f in sorted(glob.glob(os.path.join(d, "pmc_*counter_collection.csv"))):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if "odx::gauss_knm" in k or "odx::gauss_mmv" in k or "odx::knm_pass" in k:
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for f in sorted(glob.glob(os.path.join(d, "pmc_*kernel_trace.csv"))):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if k in agg:
+            dur[k].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e6)
+for k, v in agg.items():
+    c = {n: sum(x) / len(x) for n, x in v.items()}
+    ms = min(dur[k]) if dur[k] else float("nan")
+    line = "* `%s`: %.2f ms/launch" % (k, ms)
+    if "FETCH_SIZE" in c:
+        # guide: on gfx950 FETCH_SIZE (KiB) counts 64 B per 128-B request for wide coalesced reads -> x2
+        rd = 2 * c["FETCH_SIZE"] * 1024
+        wr = c.get("WRITE_SIZE", 0.0) * 1024
+        line += "; HBM read %.2f GB (FETCH_SIZE x2 correction), write %.2f GB" % (rd / 1e9, wr / 1e9)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+        line += "; MFMA busy %.1f %% (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8))" % (
+            100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0))
+    if "SQ_LDS_BANK_CONFLICT" in c:
+        line += "; LDS bank-conflict cycles %.3g of %.3g LDS-active" % (c["SQ_LDS_BANK_CONFLICT"], c.get("SQ_LDS_IDX_ACTIVE", 0))
+    print(line)
+    print("  raw: " + json.dumps({n: float("%.5g" % x) for n, x in c.items()}))
