@@ -169,6 +169,24 @@ int odx_rls_solve_f64(double* G, int64_t ldg, int D, double lam, const double* X
 int odx_rls_predict_rows_f64(const float* X, int64_t ldx, int D, const int64_t* idx, int64_t nc,
                              const double* W, int64_t ldw, double* P, int64_t ldp, odx_stream_t stream);
 
+/* ---------------------------------------------------------------- A11: RoIAlign forward, NMS
+ * The two maskrcnn_benchmark CUDA ops on the on-line path:
+ *   Pooler -> ROIAlign(14x14, spatial_scale 1/16, sampling_ratio 0)
+ *     (mrcnn_modified/modeling/roi_heads/box_head/roi_box_feature_extractors.py:21-25,47)
+ *   boxlist_nms (mrcnn_modified/modeling/rpn/inference.py:116-121;
+ *     src/modules/accuracy-evaluator/OnlineDetectionPostProcessor.py:55-57)
+ * feat (N, C, H, W) f32; rois (R, 5) = (batch index, x1, y1, x2, y2) in image pixels;
+ * out (R, C, PH, PW), PH * PW <= 256; legacy (aligned = False) sampling, sampling_ratio 0 =
+ * adaptive ceil(roi / bins).                                                               */
+int odx_roi_align_fwd_f32(const float* feat, int N, int C, int H, int W, const float* rois, int R,
+                          float spatial_scale, int PH, int PW, int sampling_ratio, float* out,
+                          odx_stream_t stream);
+/* Greedy NMS over boxes (R, 4) xyxy ALREADY SORTED by descending score, areas with the +1
+ * pixel convention: keep[i] = 1 unless an earlier kept box overlaps i with IoU > threshold.  */
+int64_t odx_nms_workspace_bytes(int R);
+int odx_nms_f32(const float* boxes_sorted, int R, float iou_threshold, unsigned char* keep,
+                void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,7 +32,8 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-__device__ __forceinline__ void chol32_wave(double* s, int J, int jb, int32_t* info, int info_base, int lane) {
+__device__ __forceinline__ void chol32_wave(double* s, double* rd, int J, int jb, int32_t* info, int info_base,
+                                            int lane) {
   const int l = lane & 31;
   double row[32];
 #pragma unroll
@@ -44,8 +45,13 @@ __device__ __forceinline__ void chol32_wave(double* s, int J, int jb, int32_t* i
       if (lane == 0 && J + c < jb && *info == 0) *info = info_base + J + c + 1;
       piv = 1.0;
     }
-    const double d = sqrt(piv);
-    const double inv = 1.0 / d;
+    // 1/sqrt by the hardware estimate + two Newton steps (the IEEE sqrt and divide sequences sit on
+    // the serial critical path of the factorisation; |rel. err| after refinement < 2^-52)
+    double inv = __builtin_amdgcn_rsq(piv);
+    inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+    inv = inv * fma(-0.5 * piv * inv, inv, 1.5);
+    const double d = piv * inv;
+    if (l == c) rd[c] = inv;
     const double lc = (l > c) ? row[c] * inv : ((l == c) ? d : 0.0);
     row[c] = lc;
 #pragma unroll
@@ -58,7 +64,7 @@ __device__ __forceinline__ void chol32_wave(double* s, int J, int jb, int32_t* i
 }
 
 // xi (32 x 33, lower, zeros above) = inverse of the lower-triangular block of s at (J, J)
-__device__ __forceinline__ void inv32_wave(const double* s, int J, double* xi, int lane) {
+__device__ __forceinline__ void inv32_wave(const double* s, const double* rd, int J, double* xi, int lane) {
   const int c = lane & 31;
   double x[32];
 #pragma unroll
@@ -66,7 +72,7 @@ __device__ __forceinline__ void inv32_wave(const double* s, int J, double* xi, i
     double acc = (i == c) ? 1.0 : 0.0;
 #pragma unroll
     for (int k = 0; k < i; ++k) acc = fma(-s[(J + i) * DB_LD + J + k], x[k], acc);
-    x[i] = acc / s[(J + i) * DB_LD + J + i];
+    x[i] = acc * rd[i];
   }
   if (lane < 32) {
 #pragma unroll
@@ -75,16 +81,19 @@ __device__ __forceinline__ void inv32_wave(const double* s, int J, double* xi, i
 }
 
 // In-LDS blocked Cholesky of the 128 x 128 block (lower in, lower out, strict upper zero).
-__device__ __forceinline__ void lds_chol_128(double* s, double* xi, int jb, int32_t* info, int info_base) {
+__device__ __forceinline__ void lds_chol_128(double* s, double* xi, double* rd, double* __restrict__ gx, int jb,
+                                             int32_t* info, int info_base) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tx = tid & 31, ty = tid >> 5;
   for (int J = 0; J < DB_NB; J += 32) {
     if (wave == 0) {
-      chol32_wave(s, J, jb, info, info_base, lane);
+      chol32_wave(s, rd, J, jb, info, info_base, lane);
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the block's LDS writes before its reads
-      inv32_wave(s, J, xi, lane);
+      inv32_wave(s, rd, J, xi, lane);
     }
     __syncthreads();
+    // the inverse phase needs X_JJ again: park it in global scratch (L2) instead of re-deriving it
+    for (int e = tid; e < 1024; e += DB_NT) gx[(J >> 5) * 1024 + e] = xi[(e >> 5) * DB_XLD + (e & 31)];
     const int nrem = DB_NB - J - 32;  // rows below the panel
     if (nrem > 0) {
       // panel: L21[i][c] = sum_k A21[i][k] * X11[c][k]
@@ -140,11 +149,18 @@ __device__ __forceinline__ void lds_chol_128(double* s, double* xi, int jb, int3
 
 // In-place inverse of the lower-triangular 128 x 128 block in LDS, block column by block column
 // from the right:  X_JJ = L_JJ^-1;  X_[below,J] = -X_[below,below] (L_[below,J] X_JJ).
-__device__ __forceinline__ void lds_trinv_128(double* s, double* xi) {
+template <bool CACHED>
+__device__ __forceinline__ void lds_trinv_128(double* s, double* xi, double* rd, const double* __restrict__ gx) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int J = DB_NB - 32; J >= 0; J -= 32) {
     __syncthreads();
-    if (wave == 0) inv32_wave(s, J, xi, lane);
+    if (CACHED) {
+      for (int e = tid; e < 1024; e += DB_NT) xi[(e >> 5) * DB_XLD + (e & 31)] = gx[(J >> 5) * 1024 + e];
+    } else {
+      if (tid < 32) rd[tid] = 1.0 / s[(J + tid) * DB_LD + J + tid];
+      __syncthreads();
+      if (wave == 0) inv32_wave(s, rd, J, xi, lane);
+    }
     __syncthreads();
     const int nrem = DB_NB - J - 32;
     if (nrem > 0) {
@@ -222,13 +238,18 @@ __global__ __launch_bounds__(DB_NT) void potrf_diag_kernel(double* __restrict__ 
   static_assert(NB == DB_NB, "diagonal-block kernels are built for NB = 128");
   __shared__ double s[DB_NB * DB_LD];
   __shared__ double xi[32 * DB_XLD];
+  __shared__ double rd[32];
+  // Dinv doubles as the scratch for the four 32 x 32 diagonal inverses until it is overwritten
+  // with the full inverse at the end (4096 doubles at its tail are not touched in between)
+  double* gx = Dinv + DB_NB * DB_NB - 4096;
   lds_load_lower_128(s, A, lda, jb);
-  lds_chol_128(s, xi, jb, info, info_base);
+  lds_chol_128(s, xi, rd, gx, jb, info, info_base);
   for (int e = threadIdx.x; e < jb * jb; e += DB_NT) {
     const int i = e / jb, j = e % jb;
     A[(int64_t)i * lda + j] = (j <= i) ? s[i * DB_LD + j] : 0.0;
   }
-  lds_trinv_128(s, xi);
+  __threadfence_block();
+  lds_trinv_128<true>(s, xi, rd, gx);
   lds_store_dinv_128(s, Dinv, jb);
 }
 
@@ -514,8 +535,9 @@ __global__ __launch_bounds__(DB_NT) void trtri_diag_kernel(const double* __restr
   __shared__ double xi[32 * DB_XLD];
   const int64_t r0 = (int64_t)blockIdx.x * DB_NB;
   const int jb = (int)(M - r0 < DB_NB ? M - r0 : DB_NB);
+  __shared__ double rd[32];
   lds_load_lower_128(s, L + r0 * ldl + r0, ldl, jb);
-  lds_trinv_128(s, xi);
+  lds_trinv_128<false>(s, xi, rd, nullptr);
   lds_store_dinv_128(s, Dinv + (int64_t)blockIdx.x * DB_NB * DB_NB, jb);
 }
 

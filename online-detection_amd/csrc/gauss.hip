@@ -38,9 +38,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 3) void gauss_knm_f32_kernel(
     const float* __restrict__ Z, int64_t ldz, const float* __restrict__ zsq, int64_t M, int D, float gamma,
     float* __restrict__ K, int64_t ldk) {
   __shared__ __attribute__((aligned(16))) char lds[GEMM_LDS_BYTES];
+  // Tile order: every XCD gets a contiguous run of tiles (xcd_remap), and inside it tiles are
+  // walked in bands of 8 row panels, column panel by column panel, so the ~100 tiles resident on
+  // an XCD at one time form an 8 x 12 patch: each X panel is shared by 12 and each Z panel by 8
+  // of them in that XCD's L2 (instead of 1-2 row panels x 79 column panels, where every Z slice
+  // is fetched from the Infinity Cache once per tile).
+  constexpr int64_t GR = 8;
   const int64_t tiles_n = (M + GEMM_BN - 1) / GEMM_BN;
   const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t i0 = (wg / tiles_n) * GEMM_BM, j0 = (wg % tiles_n) * GEMM_BN;
+  const int64_t band = wg / (GR * tiles_n), within = wg % (GR * tiles_n);
+  const int64_t i0 = (band * GR + within % GR) * GEMM_BM, j0 = (within / GR) * GEMM_BN;
+  if (i0 >= n) return;
 
   f32x16 acc[2][2];
   gemm_zero_acc<float>(acc);
@@ -208,7 +216,7 @@ extern "C" int odx_gauss_knm_f32(const float* X, int64_t ldx, const float* xsq, 
   ODX_REQUIRE(ldx % 4 == 0 && ldz % 4 == 0 && ldx >= D && ldz >= D && aligned16(X) && aligned16(Z),
               "odx_gauss_knm_f32: X/Z must be 16-byte aligned with ld %% 4 == 0 and ld >= D");
   ODX_REQUIRE(ldk % 4 == 0 && ldk >= round_up(M, 4) && aligned16(K), "odx_gauss_knm_f32: K must be 16-byte aligned, ldk %% 4 == 0, ldk >= roundup(M, 4)");
-  const int64_t tiles = ceil_div(n, GEMM_BM) * ceil_div(M, GEMM_BN);
+  const int64_t tiles = round_up(ceil_div(n, GEMM_BM), 8) * ceil_div(M, GEMM_BN);
   ODX_REQUIRE(tiles < (1ll << 31), "odx_gauss_knm_f32: grid too large");
   hipLaunchKernelGGL(gauss_knm_f32_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, as_stream(stream), X, ldx,
                      xsq, n, Z, ldz, zsq, M, D, (float)(-0.5 / (sigma * sigma)), K, ldk);

@@ -1,0 +1,182 @@
+// Feature-forward helpers of the detection heads: RoIAlign forward and NMS, the two
+// ops the reference reaches through maskrcnn_benchmark's CUDA extension
+// (mrcnn_modified/modeling/roi_heads/box_head/roi_box_feature_extractors.py:21-25,47 -> Pooler ->
+//  ROIAlign; mrcnn_modified/modeling/rpn/inference.py:116-121 and
+//  src/modules/accuracy-evaluator/OnlineDetectionPostProcessor.py:55-57 -> boxlist_nms).
+// Semantics restated from the published operators (Mask R-CNN RoIAlign in its legacy
+// "aligned = False" form with adaptive sampling when sampling_ratio == 0; greedy NMS with the
+// +1 pixel-area convention); parity unpinned by the reference (the extension is not vendored).
+#include "odx_common.h"
+
+namespace odx {
+
+// ---------------------------------------------------------------- RoIAlign forward
+// feat (N, C, H, W) f32, rois (R, 5) = (batch index, x1, y1, x2, y2), out (R, C, PH, PW).
+// One 256-thread workgroup per (roi, chunk of CCH channels): thread t owns output bin t of the
+// PH x PW grid (PH * PW <= 256); the sample positions and bilinear weights of a bin are the same
+// for every channel, so they are formed once per sample and reused across the chunk's channels.
+constexpr int ROI_CCH = 16;
+
+__global__ __launch_bounds__(256) void roi_align_fwd_kernel(const float* __restrict__ feat, int N, int C, int H, int W,
+                                                            const float* __restrict__ rois, int R, float scale, int PH,
+                                                            int PW, int sampling_ratio, float* __restrict__ out) {
+  const int r = blockIdx.x;
+  const int c0 = blockIdx.y * ROI_CCH;
+  const int t = threadIdx.x;
+  if (t >= PH * PW) return;
+  const int ph = t / PW, pw = t % PW;
+  const float* roi = rois + (int64_t)r * 5;
+  const int b = (int)roi[0];
+  const float x1 = roi[1] * scale, y1 = roi[2] * scale, x2 = roi[3] * scale, y2 = roi[4] * scale;
+  const float rw = fmaxf(x2 - x1, 1.f), rh = fmaxf(y2 - y1, 1.f);   // malformed RoIs become 1 x 1
+  const float bw = rw / (float)PW, bh = rh / (float)PH;
+  const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)PH);
+  const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)PW);
+  const float count = (float)(gh * gw);
+  float acc[ROI_CCH];
+#pragma unroll
+  for (int k = 0; k < ROI_CCH; ++k) acc[k] = 0.f;
+  const int nch = min(ROI_CCH, C - c0);
+  const float* base = feat + ((int64_t)b * C + c0) * H * W;
+  if (b >= 0 && b < N) {
+    for (int iy = 0; iy < gh; ++iy) {
+      float y = y1 + ph * bh + (iy + 0.5f) * bh / (float)gh;
+      for (int ix = 0; ix < gw; ++ix) {
+        float x = x1 + pw * bw + (ix + 0.5f) * bw / (float)gw;
+        if (y < -1.f || y > (float)H || x < -1.f || x > (float)W) continue;   // sample outside: contributes 0
+        float yy = fmaxf(y, 0.f), xx = fmaxf(x, 0.f);
+        int yl = (int)yy, xl = (int)xx, yh, xh;
+        if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else { yh = yl + 1; }
+        if (xl >= W - 1) { xh = xl = W - 1; xx = (float)xl; } else { xh = xl + 1; }
+        const float ly = yy - yl, lx = xx - xl, hy = 1.f - ly, hx = 1.f - lx;
+        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+        const int i1 = yl * W + xl, i2 = yl * W + xh, i3 = yh * W + xl, i4 = yh * W + xh;
+#pragma unroll
+        for (int k = 0; k < ROI_CCH; ++k) {
+          if (k < nch) {
+            const float* p = base + (int64_t)k * H * W;
+            acc[k] += w1 * p[i1] + w2 * p[i2] + w3 * p[i3] + w4 * p[i4];
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < ROI_CCH; ++k)
+    if (k < nch) out[(((int64_t)r * C + c0 + k) * PH + ph) * PW + pw] = acc[k] / count;
+}
+
+// ---------------------------------------------------------------- NMS
+// boxes (R, 4) xyxy sorted by descending score.  Pass 1: 64 x 64 blocks of the suppression
+// relation as 64-bit masks (one wavefront ballot's worth per row: bit j of mask[i][cb] = box
+// cb*64+j is suppressed by box i, j after i).  Pass 2: one wave walks the boxes in order; lane w
+// holds word w of the "removed" set.
+__device__ __forceinline__ float box_iou_plus1(const float* a, const float* b) {
+  const float l = fmaxf(a[0], b[0]), r = fminf(a[2], b[2]);
+  const float t = fmaxf(a[1], b[1]), bt = fminf(a[3], b[3]);
+  const float w = fmaxf(r - l + 1.f, 0.f), h = fmaxf(bt - t + 1.f, 0.f);
+  const float inter = w * h;
+  const float sa = (a[2] - a[0] + 1.f) * (a[3] - a[1] + 1.f);
+  const float sb = (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f);
+  return inter / (sa + sb - inter);
+}
+
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int R, float thr,
+                                                      unsigned long long* __restrict__ mask, int words) {
+  const int rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb) return;  // only boxes after i can be suppressed by i
+  __shared__ float cbx[64 * 4];
+  const int lane = threadIdx.x;
+  const int cj = cb * 64 + lane;
+  if (cj < R) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cbx[lane * 4 + q] = boxes[(int64_t)cj * 4 + q];
+  }
+  __syncthreads();
+  const int i = rb * 64 + lane;
+  if (i >= R) return;
+  float me[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) me[q] = boxes[(int64_t)i * 4 + q];
+  unsigned long long bits = 0ull;
+  const int ncol = min(64, R - cb * 64);
+  const int start = (rb == cb) ? lane + 1 : 0;
+  for (int j = start; j < ncol; ++j)
+    if (box_iou_plus1(me, cbx + j * 4) > thr) bits |= 1ull << j;
+  mask[(int64_t)i * words + cb] = bits;
+}
+
+__global__ __launch_bounds__(64) void nms_reduce_kernel(const unsigned long long* __restrict__ mask, int R, int words,
+                                                        unsigned char* __restrict__ keep) {
+  const int lane = threadIdx.x;
+  // lane w owns removed-words w, w + 64, ... (R <= 64 * 64 * NW boxes)
+  constexpr int NW = 4;
+  unsigned long long removed[NW];
+#pragma unroll
+  for (int q = 0; q < NW; ++q) removed[q] = 0ull;
+  for (int i = 0; i < R; ++i) {
+    const int wi = i >> 6;
+    unsigned long long word = 0ull;
+#pragma unroll
+    for (int q = 0; q < NW; ++q)
+      if ((wi >> 6) == q) word = removed[q];
+    // broadcast the word that holds bit i from its owner lane
+    const unsigned lo = (unsigned)__shfl((int)(word & 0xffffffffull), wi & 63);
+    const unsigned hi = (unsigned)__shfl((int)(word >> 32), wi & 63);
+    const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+    const bool gone = (w >> (i & 63)) & 1ull;
+    if (lane == 0) keep[i] = gone ? 0 : 1;
+    if (!gone) {
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        const int col = lane + 64 * q;
+        if (col < words && col >= wi) removed[q] |= mask[(int64_t)i * words + col];
+      }
+    }
+  }
+}
+
+}  // namespace odx
+
+using namespace odx;
+
+extern "C" int odx_roi_align_fwd_f32(const float* feat, int N, int C, int H, int W, const float* rois, int R,
+                                     float spatial_scale, int PH, int PW, int sampling_ratio, float* out,
+                                     odx_stream_t stream) {
+  if (R <= 0 || C <= 0) return ODX_OK;
+  ODX_REQUIRE(feat && rois && out && N > 0 && H > 0 && W > 0, "odx_roi_align_fwd_f32: bad argument");
+  ODX_REQUIRE(PH > 0 && PW > 0 && PH * PW <= 256, "odx_roi_align_fwd_f32: PH * PW must be in 1..256");
+  ODX_REQUIRE((int64_t)H * W < (1ll << 31) && ceil_div(C, ROI_CCH) < 65536, "odx_roi_align_fwd_f32: map too large");
+  dim3 grid((unsigned)R, (unsigned)ceil_div(C, ROI_CCH));
+  hipLaunchKernelGGL(roi_align_fwd_kernel, grid, dim3(256), 0, as_stream(stream), feat, N, C, H, W, rois, R,
+                     spatial_scale, PH, PW, sampling_ratio, out);
+  ODX_CHECK_LAUNCH("odx_roi_align_fwd_f32");
+  return ODX_OK;
+}
+
+extern "C" int64_t odx_nms_workspace_bytes(int R) {
+  if (R <= 0) return 0;
+  const int64_t words = ceil_div(R, 64);
+  return (int64_t)R * words * 8;
+}
+
+extern "C" int odx_nms_f32(const float* boxes_sorted, int R, float iou_threshold, unsigned char* keep, void* workspace,
+                           int64_t workspace_bytes, odx_stream_t stream) {
+  if (R <= 0) return ODX_OK;
+  ODX_REQUIRE(boxes_sorted && keep && workspace, "odx_nms_f32: null pointer");
+  ODX_REQUIRE(R <= 64 * 64 * 4, "odx_nms_f32: at most 16384 boxes");
+  if (workspace_bytes < odx_nms_workspace_bytes(R)) {
+    set_error("odx_nms_f32: workspace too small");
+    return ODX_ERR_WORKSPACE;
+  }
+  const int words = (int)ceil_div(R, 64);
+  hipStream_t s = as_stream(stream);
+  ODX_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)odx_nms_workspace_bytes(R), s));
+  auto* mask = static_cast<unsigned long long*>(workspace);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)words, (unsigned)words), dim3(64), 0, s, boxes_sorted, R,
+                     iou_threshold, mask, words);
+  ODX_CHECK_LAUNCH("odx_nms_f32(mask)");
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(64), 0, s, mask, R, words, keep);
+  ODX_CHECK_LAUNCH("odx_nms_f32(reduce)");
+  return ODX_OK;
+}

@@ -234,6 +234,35 @@ class HipBackend:
         return Pm
 
 
+    # ------------------------------------------------------------------ feature-forward ops (A11)
+    def roi_align(self, feat, rois, spatial_scale, output_size, sampling_ratio=0):
+        """maskrcnn_benchmark.layers.ROIAlign forward: feat (N, C, H, W) f32, rois (R, 5)."""
+        feat = feat.to(device=self.device, dtype=torch.float32).contiguous()
+        rois = rois.to(device=self.device, dtype=torch.float32).contiguous()
+        N, C, H, W = feat.shape
+        PH, PW = output_size
+        R = rois.shape[0]
+        out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=self.device)
+        hip.check(self.lib.odx_roi_align_fwd_f32(_p(feat), N, C, H, W, _p(rois), R, float(spatial_scale), PH, PW,
+                                                 int(sampling_ratio), _p(out), self._stream()), "odx_roi_align_fwd_f32")
+        return out
+
+    def nms(self, boxes, scores, iou_threshold):
+        """Indices of the boxes kept by greedy NMS, in descending score order (maskrcnn_benchmark
+        layers.nms contract)."""
+        boxes = boxes.to(device=self.device, dtype=torch.float32)
+        R = boxes.shape[0]
+        if R == 0:
+            return torch.empty(0, dtype=torch.int64, device=self.device)
+        order = torch.argsort(scores.to(self.device), descending=True, stable=True)
+        sb = boxes.index_select(0, order).contiguous()
+        keep = torch.empty(R, dtype=torch.uint8, device=self.device)
+        ws = self._workspace("nms", self.lib.odx_nms_workspace_bytes(R))
+        hip.check(self.lib.odx_nms_f32(_p(sb), R, float(iou_threshold), _p(keep), _p(ws), ws.numel(), self._stream()),
+                  "odx_nms_f32")
+        return order[keep.bool()]
+
+
 _BACKEND = None
 
 

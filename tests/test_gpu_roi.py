@@ -1,0 +1,47 @@
+"""RoIAlign forward and NMS on the MI355X against the plain-loop oracle (oracle/roi_ref.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def be():
+    import odx
+    odx.set_backend(None)
+    return odx.get_backend()
+
+
+@pytest.mark.parametrize("C,H,W,PH,PW,sr", [(20, 19, 25, 14, 14, 0), (5, 38, 50, 7, 7, 2), (33, 10, 12, 14, 14, 0)])
+def test_roi_align_matches_oracle(be, C, H, W, PH, PW, sr):
+    from oracle import roi_ref
+    rng = np.random.default_rng(C + H)
+    feat = rng.standard_normal((2, C, H, W)).astype(np.float32)
+    R = 9
+    xy = rng.random((R, 2)) * np.array([W * 16 * 0.7, H * 16 * 0.7])
+    wh = rng.random((R, 2)) * np.array([W * 16 * 0.5, H * 16 * 0.5]) + 1
+    rois = np.concatenate([rng.integers(0, 2, (R, 1)), xy, xy + wh], axis=1).astype(np.float32)
+    rois[0, 1:] = [0, 0, 5, 5]                                # tiny box: size clamps to 1 cell
+    rois[1, 1:] = [W * 16 - 30, H * 16 - 30, W * 16 + 40, H * 16 + 40]   # sticks out of the map
+    rois[2, 1:] = [-50, -40, 60, 70]                          # negative corner
+    got = be.roi_align(torch.from_numpy(feat), torch.from_numpy(rois), 1.0 / 16, (PH, PW), sr).cpu().numpy()
+    ref = roi_ref.roi_align(feat, rois, 1.0 / 16, (PH, PW), sr)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("R,thr", [(1, 0.5), (63, 0.3), (64, 0.7), (300, 0.3), (1000, 0.7), (2500, 0.5)])
+def test_nms_matches_oracle(be, R, thr):
+    from oracle import roi_ref
+    rng = np.random.default_rng(R)
+    ctr = rng.random((R, 2)) * 400
+    wh = rng.random((R, 2)) * 120 + 4
+    boxes = np.concatenate([ctr - wh / 2, ctr + wh / 2], axis=1).astype(np.float32)
+    boxes[R // 2] = boxes[0]                                  # an exact duplicate
+    scores = rng.random(R).astype(np.float32)
+    scores[R // 3] = scores[0]                                # a score tie (stable order)
+    got = be.nms(torch.from_numpy(boxes), torch.from_numpy(scores), thr).cpu().numpy()
+    ref = roi_ref.nms(boxes, scores, thr)
+    assert np.array_equal(got, ref)
+    assert tuple(be.nms(torch.zeros(0, 4), torch.zeros(0), thr).shape) == (0,)
