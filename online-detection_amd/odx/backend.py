@@ -234,6 +234,15 @@ class HipBackend:
         return Pm
 
 
+    # ------------------------------------------------------------------ dense f32 product (RLS apply)
+    def gemm_nt(self, Fa, Fb):
+        """(n, m) f32 = Fa.X (n, D) @ Fb.X (m, D)' on the f32 MFMA core (exact f32 fmaf chain)."""
+        out = torch.empty((Fa.n, Fb.n), dtype=torch.float32, device=self.device)
+        if Fa.n and Fb.n:
+            hip.check(self.lib.odx_gemm_nt_f32(_p(Fa.X), Fa.ld, _p(Fb.X), Fb.ld, _p(out), Fb.n, Fa.n, Fb.n, Fa.D,
+                                               1.0, 0.0, 0, self._stream()), "odx_gemm_nt_f32")
+        return out
+
     # ------------------------------------------------------------------ feature-forward ops (A11)
     def roi_align(self, feat, rois, spatial_scale, output_size, sampling_ratio=0):
         """maskrcnn_benchmark.layers.ROIAlign forward: feat (N, C, H, W) f32, rois (R, 5)."""

@@ -341,8 +341,138 @@ def make_wrapper_contract():
     print("wrapper_contract.json written")
 
 
+# --------------------------------------------------------------------------- A8 / A9: test-time heads
+def _strip_imports(src):
+    keep = []
+    for line in src.splitlines():
+        st = line.strip()
+        if st.startswith(("from mrcnn_modified", "from maskrcnn_benchmark", "from .")):
+            continue
+        keep.append(line)
+    return "\n".join(keep)
+
+
+class _Registry(dict):
+    def register(self, name):
+        def deco(cls):
+            self[name] = cls
+            return cls
+        return deco
+
+
+class FakeKernel:
+    """f64 Gaussian mmv: the heads only need *a* kernel object with falkon's mmv signature."""
+
+    def __init__(self, sigma):
+        self.sigma = sigma
+
+    def mmv(self, X1, X2, v, out=None):
+        d2 = torch.cdist(X1.double(), X2.double()) ** 2
+        r = (torch.exp(-d2 / (2 * self.sigma ** 2)) @ v.double()).float()
+        if out is not None:
+            out.copy_(r)
+            return out
+        return r
+
+
+class FakeModel:
+    def __init__(self, ny, alpha, kernel):
+        self.ny_points_, self.alpha_, self.M, self.kernel = ny, alpha, ny.shape[0], kernel
+
+    def predict(self, X):
+        return self.kernel.mmv(X, self.ny_points_, self.alpha_)
+
+
+def make_heads():
+    from torch import nn
+    reg = types.SimpleNamespace(ROI_BOX_PREDICTOR=_Registry(), RPN_HEADS=_Registry())
+    base = "src/modules/feature-extractor/mrcnn_modified/modeling/"
+    ns_box = {"registry": reg, "__name__": "ref_roi_box_predictors"}
+    src = _strip_imports(open(os.path.join(REF, base, "roi_heads/box_head/roi_box_predictors.py")).read())
+    exec(compile(src.replace("'cuda'", "'cpu'"), "roi_box_predictors.py", "exec"), ns_box)
+    ns_rpn = {"registry": reg, "__name__": "ref_rpn"}
+    src = _strip_imports(open(os.path.join(REF, base, "rpn/rpn.py")).read())
+    exec(compile(src.replace("'cuda'", "'cpu'"), "rpn.py", "exec"), ns_rpn)
+    BoxPred, RPNHead = reg.ROI_BOX_PREDICTOR["OnlineDetectionBOXPredictor"], reg.RPN_HEADS["OnlineRPNHead"]
+
+    g = torch.Generator().manual_seed(41)
+    D, out = 16, {}
+    kern = FakeKernel(6.0)
+
+    def models(Ms):
+        ms = []
+        for m in Ms:
+            ms.append(None if m == 0 else FakeModel(torch.randn(m, D, generator=g) * 3, torch.randn(m, 1, generator=g), kern))
+        return ms
+
+    def regressors(n, none_at):
+        arr = np.empty((0))
+        for j in range(n):
+            if j in none_at:
+                arr = np.append(arr, {"mu": None, "T": None, "T_inv": None, "Beta": None})
+                continue
+            A = torch.randn(4, 4, generator=g) * 0.3
+            arr = np.append(arr, {"mu": torch.randn(4, generator=g) * 0.1, "T": torch.eye(4), "T_inv": A @ A.t() + torch.eye(4),
+                                  "Beta": {str(k): {"weights": torch.randn(D + 1, generator=g) * 0.2, "losses": None} for k in range(4)}})
+        return arr
+
+    def dump_models(tag, ms, rs):
+        out[tag + "_Ms"] = np.array([0 if m is None else m.M for m in ms])
+        for i, m in enumerate(ms):
+            if m is not None:
+                out["%s_ny_%d" % (tag, i)], out["%s_alpha_%d" % (tag, i)] = m.ny_points_.numpy(), m.alpha_.numpy()
+        out[tag + "_reg_none"] = np.array([r["Beta"] is None for r in rs])
+        for j, r in enumerate(rs):
+            if r["Beta"] is not None:
+                out["%s_reg_W_%d" % (tag, j)] = np.stack([r["Beta"][str(k)]["weights"].numpy() for k in range(4)])
+                out["%s_reg_Tinv_%d" % (tag, j)], out["%s_reg_mu_%d" % (tag, j)] = r["T_inv"].numpy(), r["mu"].numpy()
+
+    stats = {"mean": torch.randn(D, generator=g) * 0.2, "mean_norm": torch.tensor(5.0)}
+    out["stats_mean"], out["stats_mean_norm"], out["sigma"] = stats["mean"].numpy(), np.float64(5.0), np.float64(6.0)
+    # ---- detector head
+    cls_models, regs = models([7, 0, 12, 5]), regressors(4, {1})
+    dump_models("det", cls_models, regs)
+    x = torch.randn(9, D, 1, 1, generator=g) * 3
+    out["det_x"] = x.view(9, D).numpy()
+    for par in (True, False):
+        for norm_reg in (False, True):
+            h = BoxPred.__new__(BoxPred)
+            nn.Module.__init__(h)
+            h.avgpool = nn.AdaptiveAvgPool2d(1)
+            h.parallel_inference, h.normalize_features_regressors, h.feat_size = par, norm_reg, D
+            h.classifiers, h.regressors, h.stats = cls_models, regs, stats
+            with torch.no_grad():
+                sc, bb = h.forward(x)
+            tag = "det_par%d_norm%d" % (par, norm_reg)
+            out[tag + "_scores"], out[tag + "_bbox"] = sc.numpy(), bb.numpy()
+    # ---- RPN head
+    A_, H, W = 6, 4, 5
+    rpn_models, rpn_regs = models([8, 8, 0, 6, 8, 8]), regressors(A_, {4})
+    dump_models("rpn", rpn_models, rpn_regs)
+    t_in = torch.randn(1, D, H, W, generator=g)
+    for par in (True, False):
+        h = RPNHead.__new__(RPNHead)
+        nn.Module.__init__(h)
+        h.conv = nn.Conv2d(D, D, 3, 1, 1)
+        torch.manual_seed(8)
+        nn.init.normal_(h.conv.weight, std=0.2)
+        nn.init.constant_(h.conv.bias, 0.1)
+        h.parallel_inference, h.feat_size, h.height, h.width, h.num_clss, h.area = par, None, None, None, A_, None
+        h.classifiers, h.regressors, h.stats = rpn_models, rpn_regs, stats
+        with torch.no_grad():
+            out["rpn_act"] = torch.relu(h.conv(t_in)).numpy()
+            logits, bbox = h.forward([t_in])
+        out["rpn_par%d_logits" % par], out["rpn_par%d_bbox" % par] = logits[0].numpy(), bbox[0].numpy()
+    np.savez_compressed(os.path.join(OUT, "heads_golden.npz"), **out)
+    print("heads_golden.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
+    if "--only-heads" in sys.argv:
+        make_heads()
+        sys.exit(0)
     utils = make_rls()
     make_bootstrap()
     make_helpers(utils)
     make_wrapper_contract()
+    make_heads()

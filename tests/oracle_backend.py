@@ -128,6 +128,9 @@ class OracleBackend:
             return out
         return res
 
+    def gemm_nt(self, Fa, Fb):
+        return (Fa.X.double() @ Fb.X.double().t()).float()
+
     # RLS
     def rls_gram(self, F, idx, Yt, G, XtY):
         X = F.X[idx].double()

@@ -203,3 +203,44 @@ def test_edge_cases(hip_backend):
     assert abs(float(a1[0]) - r1[0, 0]) < 1e-6 * max(1.0, abs(r1[0, 0]))
     # empty prediction batch
     assert tuple(be.mmv(be.features(torch.zeros(0, 36)), Zf, 6.0, alpha).shape) == (0, 1)
+
+
+def test_heads_on_gpu_match_reference(hip_backend):
+    """Batched FALKON scoring + folded RLS GEMM against the reference's own head code outputs."""
+    from tests.test_host_logic import check_heads_against_reference
+    check_heads_against_reference(atol=2e-4)
+
+
+def test_heads_at_reference_scale(hip_backend):
+    """300 RoIs x D=2048 against 30 classes x M=2000 (the detector's test-time shape)."""
+    from odx.heads import OnlineBoxPredictor
+    from oracle import falkon_ref as fr
+    import odx
+    rng = np.random.default_rng(0)
+    D, C, M, R = 2048, 30, 2000, 300
+
+    class Mdl:
+        pass
+    cls = []
+    for c in range(C):
+        if c == 7:
+            cls.append(None)
+            continue
+        m = Mdl()
+        m.ny_points_ = torch.from_numpy((rng.standard_normal((M, D)) * (20 / D ** 0.5)).astype(np.float32))
+        m.alpha_ = torch.from_numpy(rng.standard_normal((M, 1)))
+        m.M, m.kernel = M, odx.GaussianKernel(20.0)
+        cls.append(m)
+    regs = np.array([{"mu": torch.zeros(4), "T": torch.eye(4), "T_inv": torch.eye(4),
+                      "Beta": {str(k): {"weights": torch.from_numpy(rng.standard_normal(D + 1).astype(np.float32) * 0.01), "losses": None}
+                               for k in range(4)}} for _ in range(C)], dtype=object)
+    x = torch.from_numpy((rng.standard_normal((R, D)) * (20 / D ** 0.5)).astype(np.float32))
+    sc, bb = OnlineBoxPredictor(cls, regs, None)(x)
+    assert tuple(sc.shape) == (R, C + 1) and tuple(bb.shape) == (R, 4 * (C + 1))
+    for c in (0, 12, 29):
+        ref = fr.falkon_predict(x.numpy().astype(np.float64), cls[c].ny_points_.numpy().astype(np.float64), cls[c].alpha_.numpy(), 20.0)
+        assert np.abs(sc[:, c + 1].cpu().numpy() - ref[:, 0]).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    assert torch.all(sc[:, 8] == 0) and torch.all(sc[:, 0] == -2)
+    W = np.stack([regs[3]["Beta"][str(k)]["weights"].numpy() for k in range(4)]).astype(np.float64)
+    refb = x.numpy().astype(np.float64) @ W[:, :-1].T + W[:, -1]
+    assert np.abs(bb[:, 16:20].cpu().numpy() - refb).max() < 1e-4

@@ -332,3 +332,62 @@ def test_reference_wrapper_runs_unchanged_on_odx_falkon(monkeypatch):
     assert np.linalg.norm(model.alpha_.numpy() - ref) / np.linalg.norm(ref) < 1e-6
     p = w.predict(model, Xt[:6])
     assert tuple(p.shape) == (6, 1)
+
+
+# ------------------------------------------------------------------ test-time heads (A8 / A9)
+class _GoldModel:
+    def __init__(self, ny, alpha, sigma):
+        self.ny_points_, self.alpha_, self.M = torch.from_numpy(ny), torch.from_numpy(alpha), ny.shape[0]
+        self.kernel = odx.GaussianKernel(sigma)
+
+
+def _gold_models(H, tag):
+    cls = [None if m == 0 else _GoldModel(H["%s_ny_%d" % (tag, i)], H["%s_alpha_%d" % (tag, i)], float(H["sigma"]))
+           for i, m in enumerate(H[tag + "_Ms"])]
+    regs = []
+    for j, none in enumerate(H[tag + "_reg_none"]):
+        if none:
+            regs.append({"mu": None, "T": None, "T_inv": None, "Beta": None})
+        else:
+            W = H["%s_reg_W_%d" % (tag, j)]
+            regs.append({"mu": torch.from_numpy(H["%s_reg_mu_%d" % (tag, j)]), "T": torch.eye(4),
+                         "T_inv": torch.from_numpy(H["%s_reg_Tinv_%d" % (tag, j)]),
+                         "Beta": {str(k): {"weights": torch.from_numpy(W[k]), "losses": None} for k in range(4)}})
+    stats = {"mean": torch.from_numpy(H["stats_mean"]), "mean_norm": torch.tensor(float(H["stats_mean_norm"]))}
+    return cls, np.array(regs, dtype=object), stats
+
+
+def check_heads_against_reference(atol=2e-4):
+    """Shared by the CPU (oracle backend) and GPU suites: the product heads against the outputs
+    of the reference's own FastRCNNPredictor / RPNHead code (tests/golden/heads_golden.npz)."""
+    from odx.heads import OnlineBoxPredictor, OnlineRPNHead
+    H = np.load(os.path.join(GOLD, "heads_golden.npz"))
+    cls, regs, stats = _gold_models(H, "det")
+    x = torch.from_numpy(H["det_x"])
+    for par in (1, 0):
+        for norm in (0, 1):
+            head = OnlineBoxPredictor(cls, regs, stats, parallel_inference=bool(par), normalize_features_regressors=bool(norm))
+            sc, bb = head(x)
+            tag = "det_par%d_norm%d" % (par, norm)
+            assert tuple(sc.shape) == H[tag + "_scores"].shape and tuple(bb.shape) == H[tag + "_bbox"].shape
+            assert np.abs(sc.cpu().numpy() - H[tag + "_scores"]).max() < atol, tag
+            assert np.abs(bb.cpu().numpy() - H[tag + "_bbox"]).max() < atol, tag
+            sc2, _ = head(x.reshape(9, -1, 1, 1))          # 4-D input is average-pooled
+            assert torch.allclose(sc2, sc)
+    cls, regs, stats = _gold_models(H, "rpn")
+    t = torch.from_numpy(H["rpn_act"])
+    for par in (1, 0):
+        lg, bb = OnlineRPNHead(cls, regs, stats, parallel_inference=bool(par))(t)
+        assert tuple(lg.shape) == H["rpn_par%d_logits" % par].shape
+        assert np.abs(lg.cpu().numpy() - H["rpn_par%d_logits" % par]).max() < atol
+        assert np.abs(bb.cpu().numpy() - H["rpn_par%d_bbox" % par]).max() < atol
+    # model hot-swap invalidates the cached concatenations
+    head = OnlineRPNHead(cls, regs, stats)
+    a, _ = head(t)
+    head.set_models(cls[:3] + [None, None, None], regs, stats)
+    b, _ = head(t)
+    assert torch.allclose(a[:, :2], b[:, :2]) and torch.all(b[:, 3:] == -2)
+
+
+def test_heads_match_reference():
+    check_heads_against_reference()
