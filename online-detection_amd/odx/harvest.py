@@ -1,0 +1,206 @@
+"""Train-time feature harvesting for the on-line detector (A11): turns the pooled RoI features
+of one image at a time into the structures the on-line trainers consume —
+    positives[c]        (p_c, D)   ground-truth RoI features of class c
+    negatives[c][b]     (<= BATCH_SIZE, D) minibootstrap batches of background RoIs of class c
+    COXY                regressor rows: X features, Y box targets, C class ids
+and collects `test_boxes` entries at test time.
+
+Behaviour follows ROIBoxHead (mrcnn_modified/modeling/roi_heads/box_head/box_head_getProposals.py):
+initialize_online_detection_params :37-88, add_new_class :90-99, forward_train :107-292,
+forward_test :295-334, and the final assembly of FeatureExtractorDetector.train
+(feature_extractor_detector/extract_features_detector.py:255-292).  The global torch RNG is
+consumed in the reference's order (one randint per class per image), so seeded runs pick the
+same rows.  Details kept on purpose: proposals arrive with the ground-truth boxes prepended
+(generalized_rcnn_getProposals.py:90-96) and regression targets are taken against those
+prepended rows (:181); coordinates are clamped to [0, size-1]; IoU uses the +1 convention
+(utils/evaluations.py:4-18); `negatives_to_pick = ceil(BATCH_SIZE * ITERATIONS / NUM_IMAGES)`
+rows per class per image are spread over the class's still-open batches.
+
+MI355X form: IoU against all ground-truth boxes is one broadcast op instead of a per-box loop,
+and batches grow into preallocated device buffers (no O(n^2) torch.cat chains).
+"""
+import math
+
+import numpy as np
+import torch
+
+
+def box_iou_plus1(gt, prop):
+    """(G, R) IoU, +1 pixel convention, 0 where boxes do not touch (utils/evaluations.py:4-18)."""
+    xmin = torch.max(gt[:, None, 0], prop[None, :, 0])
+    ymin = torch.max(gt[:, None, 1], prop[None, :, 1])
+    xmax = torch.min(gt[:, None, 2], prop[None, :, 2])
+    ymax = torch.min(gt[:, None, 3], prop[None, :, 3])
+    w, h = xmax - xmin + 1, ymax - ymin + 1
+    inter = w * h
+    ga = ((gt[:, 2] - gt[:, 0] + 1) * (gt[:, 3] - gt[:, 1] + 1))[:, None]
+    pa = ((prop[:, 2] - prop[:, 0] + 1) * (prop[:, 3] - prop[:, 1] + 1))[None, :]
+    ov = inter / (ga + pa - inter)
+    return torch.where((w > 0) & (h > 0), ov, torch.zeros_like(ov))
+
+
+class _Growing:
+    """Append-only (rows, D) buffer with amortised growth."""
+
+    def __init__(self, D, device, dtype=torch.float32, cap=256):
+        self.buf = torch.empty((cap, D) if D else (cap,), dtype=dtype, device=device)
+        self.n = 0
+
+    def append(self, rows):
+        k = rows.shape[0]
+        if self.n + k > self.buf.shape[0]:
+            cap = max(2 * self.buf.shape[0], self.n + k)
+            nb = torch.empty((cap,) + tuple(self.buf.shape[1:]), dtype=self.buf.dtype, device=self.buf.device)
+            nb[: self.n] = self.buf[: self.n]
+            self.buf = nb
+        self.buf[self.n:self.n + k] = rows.to(self.buf.device)
+        self.n += k
+
+    def view(self):
+        return self.buf[: self.n]
+
+
+def clamp_boxes_(b, img_size):
+    b[:, 0].clamp_(0, img_size[0] - 1)
+    b[:, 2].clamp_(0, img_size[0] - 1)
+    b[:, 1].clamp_(0, img_size[1] - 1)
+    b[:, 3].clamp_(0, img_size[1] - 1)
+    return b
+
+
+class DetectorHarvester:
+    def __init__(self, feat_dim, num_classes, iterations, batch_size, num_images, neg_iou_thresh=0.3,
+                 reg_min_overlap=0.6, compute_gt_positives=True, shuffle_negatives=False, device=None):
+        self.D = feat_dim
+        self.iterations = iterations
+        self.batch_size = batch_size
+        self.num_images = num_images
+        self.neg_iou_thresh = neg_iou_thresh
+        self.reg_min_overlap = reg_min_overlap
+        self.compute_gt_positives = compute_gt_positives
+        self.shuffle_negatives = shuffle_negatives
+        self.device = device or ('cuda' if torch.cuda.is_available() else 'cpu')
+        self.num_classes = 0
+        self._pos, self._neg, self.current_batch = [], [], []
+        self.still_to_complete = []
+        for _ in range(num_classes):
+            self.add_new_class()
+        self.negatives_to_pick = None
+        self._X = _Growing(feat_dim, self.device)
+        self._Y = _Growing(4, self.device)
+        self._C = _Growing(1, self.device)
+        self.O = None
+        self.test_boxes = []
+
+    def add_new_class(self):
+        """Incremental use (box_head_getProposals.py:90-99): one more class with empty batches."""
+        self.still_to_complete.append(self.num_classes)
+        self.num_classes += 1
+        self._pos.append(_Growing(self.D, self.device))
+        if self.shuffle_negatives:
+            self._neg.append([_Growing(self.D, self.device, cap=self.batch_size)])
+        else:
+            self._neg.append([_Growing(self.D, self.device, cap=self.batch_size) for _ in range(self.iterations)])
+        self.current_batch.append(0)
+
+    # ------------------------------------------------------------------ train time
+    def add_image(self, x, proposals, gt_bbox, gt_labels_list, img_size):
+        """x (R, D) pooled features of `proposals` (R, 4) whose first len(gt) rows are the ground
+        truth boxes; gt_bbox (G, 4); gt_labels_list: class ids 1..C of the G boxes."""
+        if self.negatives_to_pick is None:
+            self.negatives_to_pick = math.ceil((self.batch_size * self.iterations) / self.num_images)
+        x = x.reshape(x.size(0), -1)
+        prop = clamp_boxes_(proposals.clone().float(), img_size)
+        gt = clamp_boxes_(gt_bbox.clone().float(), img_size)
+        R, G = prop.shape[0], gt.shape[0]
+        overlap = torch.zeros((R, self.num_classes), dtype=torch.float32, device=x.device)
+        assoc = torch.full((R,), -1, dtype=torch.int64, device=x.device)
+        if G:
+            iou = box_iou_plus1(gt.to(x.device), prop.to(x.device))                     # (G, R)
+            for j in range(G):                                                           # per-class maxima
+                c = gt_labels_list[j] - 1
+                overlap[:, c] = torch.max(overlap[:, c], iou[j])
+            # gt with the largest IoU per proposal; strict '>' in the reference keeps the FIRST maximum
+            best, arg = iou.max(dim=0)
+            first = (iou == best[None, :]).float().argmax(dim=0)
+            assoc = torch.where(best > 0, first, assoc)
+        prop_d = prop.to(x.device)
+        for i in range(len(gt_labels_list)):
+            c = gt_labels_list[i] - 1
+            if self.compute_gt_positives:
+                self._pos[c].append(x[i].view(1, -1))
+            pos_ids = (overlap[:, c] > self.reg_min_overlap) & (assoc == i)
+            ex = prop_d[pos_ids].view(-1, 4)
+            tgt = prop_d[i].view(1, 4).expand_as(ex)                                     # the prepended gt row
+            sw, sh = ex[:, 2] - ex[:, 0] + 1, ex[:, 3] - ex[:, 1] + 1
+            sx, sy = ex[:, 0] + 0.5 * sw, ex[:, 1] + 0.5 * sh
+            gw, gh = tgt[:, 2] - tgt[:, 0] + 1, tgt[:, 3] - tgt[:, 1] + 1
+            gx, gy = tgt[:, 0] + 0.5 * gw, tgt[:, 1] + 0.5 * gh
+            target = torch.stack(((gx - sx) / sw, (gy - sy) / sh, torch.log(gw / sw), torch.log(gh / sh)), dim=1)
+            self._Y.append(target)
+            self._C.append(torch.full((int(pos_ids.sum()), 1), float(gt_labels_list[i]), device=x.device))
+            self._X.append(x[pos_ids].view(-1, self.D))
+        if not self.shuffle_negatives:
+            self._fill_batches(x, overlap, gt_labels_list)
+        else:
+            for i in range(self.num_classes):
+                neg_i = self._sample_negatives(x, overlap, i, gt_labels_list)
+                last = self._neg[i][-1]
+                last.append(neg_i)
+                if last.n >= self.batch_size:
+                    self._neg[i].append(_Growing(self.D, self.device, cap=self.batch_size))
+
+    def _sample_negatives(self, x, overlap, i, gt_labels_list):
+        if i + 1 not in gt_labels_list:
+            return x[torch.randint(x.size(0), (self.negatives_to_pick,))].view(-1, self.D)
+        neg_i = x[overlap[:, i] < self.neg_iou_thresh].view(-1, self.D)
+        if neg_i.size(0) > 0:
+            neg_i = neg_i[torch.randint(neg_i.size(0), (self.negatives_to_pick,))].view(-1, self.D)
+        return neg_i
+
+    def _fill_batches(self, x, overlap, gt_labels_list):
+        done = []
+        for i in self.still_to_complete:
+            neg_i = self._sample_negatives(x, overlap, i, gt_labels_list)
+            per_batch = math.ceil(self.negatives_to_pick / self.iterations)
+            taken = 0
+            for b in range(self.current_batch[i], self.iterations):
+                cur = self._neg[i][b]
+                if cur.n >= self.batch_size:
+                    self.current_batch[i] += 1
+                    if self.current_batch[i] >= self.iterations:
+                        done.append(i)
+                    continue
+                end = int(taken + min(per_batch, self.batch_size - cur.n, self.negatives_to_pick - taken))
+                cur.append(neg_i[taken:end].view(-1, self.D))
+                taken = end
+                if taken == self.negatives_to_pick:
+                    break
+        for i in done:
+            self.still_to_complete.remove(i)
+
+    # ------------------------------------------------------------------ test time
+    def add_test_image(self, x, proposals, gt_label_count, img_size):
+        """forward_test (:295-334): store boxes / features / gt flags for stand-alone scoring."""
+        x = x.reshape(x.size(0), -1)
+        prop = clamp_boxes_(proposals.clone().float(), img_size)
+        gt = np.zeros((prop.shape[0], 1), dtype=bool)
+        gt[:gt_label_count] = True
+        self.test_boxes.append({'boxes': prop.cpu().numpy(), 'feat': x.cpu().numpy(), 'gt': gt, 'img_size': np.array(img_size)})
+
+    # ------------------------------------------------------------------ results
+    def finalize(self, use_only_gt_positives=True):
+        """negatives, positives, COXY as returned by FeatureExtractorDetector.train
+        (extract_features_detector.py:255-292)."""
+        COXY = {'C': self._C.view().clone(), 'O': self.O, 'X': self._X.view().clone(), 'Y': self._Y.view().clone()}
+        positives = [p.view().clone() for p in self._pos] if (use_only_gt_positives and self.compute_gt_positives) else None
+        negatives = []
+        for i in range(self.num_classes):
+            if self.shuffle_negatives:
+                total = torch.cat([g.view() for g in self._neg[i]])
+                perm = torch.randperm(len(total))
+                bs = self.batch_size
+                negatives.append([total[perm[min(j * bs, len(perm)):min((j + 1) * bs, len(perm))]] for j in range(self.iterations)])
+            else:
+                negatives.append([g.view().clone() for g in self._neg[i]])
+        return negatives, positives, COXY

@@ -467,7 +467,96 @@ def make_heads():
     print("heads_golden.npz:", len(out), "arrays")
 
 
+# --------------------------------------------------------------------------- A11: detector harvesting
+class ResizableBoxList(BoxList):
+    def resize(self, size):
+        rw, rh = size[0] / self.size[0], size[1] / self.size[1]
+        b = self.bbox.clone().float()
+        b[:, 0::2] *= rw
+        b[:, 1::2] *= rh
+        return ResizableBoxList(b, size, self.mode)
+
+
+def make_harvest():
+    from torch import nn
+    base = "src/modules/feature-extractor/mrcnn_modified/"
+    ev = load_ref(base + "utils/evaluations.py", "ref_evaluations")
+    src = _strip_imports(open(os.path.join(REF, base, "modeling/roi_heads/box_head/box_head_getProposals.py")).read())
+    ns = {"compute_overlap_torch": ev.compute_overlap_torch, "__name__": "ref_box_head_getProposals"}
+    exec(compile(src.replace("'cuda'", "'cpu'"), "box_head_getProposals.py", "exec"), ns)
+    Head = ns["ROIBoxHead"]
+    D, C, ITER, BS, NIMG = 10, 3, 3, 12, 6
+    out = {"D": np.int64(D), "C": np.int64(C), "ITER": np.int64(ITER), "BS": np.int64(BS), "NIMG": np.int64(NIMG)}
+    g = torch.Generator().manual_seed(77)
+    images = []
+    for im in range(NIMG):
+        G = [2, 1, 0, 2, 1, 3][im]
+        labels = [[1, 3], [2], [], [3, 3], [1], [2, 1, 3]][im]
+        gt = torch.rand(G, 2, generator=g) * 150
+        gt = torch.cat([gt, gt + 30 + torch.rand(G, 2, generator=g) * 80], 1)
+        R = 25
+        jit = []
+        for k in range(R):                        # proposals: jittered copies of the gts + random boxes
+            if G and k % 2 == 0:
+                j = gt[k % G] + (torch.rand(4, generator=g) - 0.5) * 24
+            else:
+                a = torch.rand(2, generator=g) * 200
+                j = torch.cat([a, a + 10 + torch.rand(2, generator=g) * 90])
+            jit.append(j)
+        prop = torch.stack(jit)
+        prop[3] = torch.tensor([-5.0, -3.0, 400.0, 300.0])  # sticks out of the 320 x 240 image
+        allp = torch.cat([gt, prop])
+        x = torch.randn(G + R, D, generator=g)
+        images.append((x, allp, gt, labels))
+        out["x_%d" % im], out["prop_%d" % im], out["gt_%d" % im], out["labels_%d" % im] = x.numpy(), allp.numpy(), gt.numpy(), np.array(labels, dtype=np.int64)
+    for shuffle in (False, True):
+        h = Head.__new__(Head)
+        nn.Module.__init__(h)
+        dcfg = types.SimpleNamespace(NUM_CLASSES=C, ITERATIONS=ITER, BATCH_SIZE=BS, EXTRACT_ONLY_GT_POSITIVES=True,
+                                     SHUFFLE_NEGATIVES=shuffle, NEG_IOU_THRESH=0.3, FEATURES_DEVICE="cpu")
+        h.cfg = types.SimpleNamespace(MINIBOOTSTRAP=types.SimpleNamespace(DETECTOR=dcfg), DEMO=types.SimpleNamespace(INCREMENTAL_TRAIN=False),
+                                      REGRESSORS=types.SimpleNamespace(MIN_OVERLAP=0.6), NUM_IMAGES=NIMG)
+        h.training_device = "cpu"
+        h.save_features = False
+        h.avgpool = nn.AdaptiveAvgPool2d(1)
+        h.feature_extractor = types.SimpleNamespace(out_channels=D)
+        h.initialize_online_detection_params()
+        torch.manual_seed(123)
+        for (x, allp, gt, labels) in images:
+            h.feature_extractor = lambda features, proposals, _x=x: _x.view(_x.shape[0], D, 1, 1)
+            h.feature_extractor.out_channels = D
+            gl = torch.tensor(labels, dtype=torch.uint8).view(-1, 1) if labels else None
+            h.forward_train(None, [ResizableBoxList(allp.clone(), (320, 240))], gt_bbox=ResizableBoxList(gt.clone(), (320, 240)),
+                            gt_label=gl, img_size=[320, 240], gt_labels_list=labels)
+        tag = "shuf" if shuffle else "fill"
+        out[tag + "_C"] = torch.cat(h.C).numpy()
+        out[tag + "_X"], out[tag + "_Y"] = torch.cat(h.X).numpy(), torch.cat(h.Y).numpy()
+        for c in range(C):
+            out["%s_pos_%d" % (tag, c)] = torch.cat(h.positives[c]).numpy()
+            if shuffle:
+                out["%s_neg_%d" % (tag, c)] = torch.cat(h.negatives[c]).numpy()
+            else:
+                for b in range(ITER):
+                    out["%s_neg_%d_%d" % (tag, c, b)] = h.negatives[c][b].numpy()
+        if not shuffle:
+            out["fill_still_to_complete"] = np.array(h.still_to_complete, dtype=np.int64)
+            x, allp, gt, labels = images[0]
+            h.feature_extractor = lambda features, proposals, _x=x: _x.view(_x.shape[0], D, 1, 1)
+            h.forward_test(None, [ResizableBoxList(allp.clone(), (320, 240))], gt_bbox=ResizableBoxList(gt.clone(), (320, 240)),
+                           gt_label=torch.tensor(labels, dtype=torch.uint8).view(-1, 1), img_size=[320, 240], gt_labels_list=labels)
+            tb = h.test_boxes[0]
+            out["test_boxes"], out["test_feat"], out["test_gt"] = tb["boxes"], tb["feat"], tb["gt"]
+    # IoU helper on its own
+    out["iou_gt"], out["iou_prop"] = images[0][2][0].numpy(), images[0][1].numpy()
+    out["iou_out"] = ev.compute_overlap_torch(images[0][2][0], images[0][1]).numpy()
+    np.savez_compressed(os.path.join(OUT, "harvest_golden.npz"), **out)
+    print("harvest_golden.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
+    if "--only-harvest" in sys.argv:
+        make_harvest()
+        sys.exit(0)
     if "--only-heads" in sys.argv:
         make_heads()
         sys.exit(0)
@@ -476,3 +565,4 @@ if __name__ == "__main__":
     make_helpers(utils)
     make_wrapper_contract()
     make_heads()
+    make_harvest()

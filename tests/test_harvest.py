@@ -1,0 +1,74 @@
+"""Detector feature harvesting (A11) against golden vectors produced by the reference's own
+ROIBoxHead.forward_train / forward_test (tests/golden/harvest_golden.npz), and the IoU helper
+against the reference's compute_overlap_torch."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from odx.harvest import DetectorHarvester, box_iou_plus1
+from oracle import roi_ref
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "harvest_golden.npz"))
+
+
+def _run(shuffle):
+    D, C, ITER, BS, NIMG = (int(G[k]) for k in ("D", "C", "ITER", "BS", "NIMG"))
+    h = DetectorHarvester(D, C, ITER, BS, NIMG, shuffle_negatives=shuffle, device="cpu")
+    torch.manual_seed(123)
+    for im in range(NIMG):
+        h.add_image(torch.from_numpy(G["x_%d" % im]), torch.from_numpy(G["prop_%d" % im]), torch.from_numpy(G["gt_%d" % im]),
+                    G["labels_%d" % im].tolist(), [320, 240])
+    return h
+
+
+def test_fill_mode_matches_reference():
+    h = _run(False)
+    C, ITER = int(G["C"]), int(G["ITER"])
+    assert h.still_to_complete == G["fill_still_to_complete"].tolist()
+    negatives, positives, COXY = h.finalize()
+    assert np.array_equal(COXY["C"].numpy(), G["fill_C"])
+    assert np.array_equal(COXY["X"].numpy(), G["fill_X"])
+    assert np.allclose(COXY["Y"].numpy(), G["fill_Y"], atol=1e-6)
+    assert COXY["O"] is None
+    for c in range(C):
+        assert np.array_equal(positives[c].numpy(), G["fill_pos_%d" % c])
+        assert len(negatives[c]) == ITER
+        for b in range(ITER):
+            assert np.array_equal(negatives[c][b].numpy(), G["fill_neg_%d_%d" % (c, b)]), (c, b)
+    h.add_test_image(torch.from_numpy(G["x_0"]), torch.from_numpy(G["prop_0"]), len(G["labels_0"]), [320, 240])
+    tb = h.test_boxes[0]
+    assert np.array_equal(tb["boxes"], G["test_boxes"]) and np.array_equal(tb["feat"], G["test_feat"])
+    assert np.array_equal(tb["gt"], G["test_gt"]) and tb["img_size"].tolist() == [320, 240]
+
+
+def test_shuffle_mode_matches_reference_before_the_final_permutation():
+    h = _run(True)
+    C = int(G["C"])
+    for c in range(C):
+        total = torch.cat([g.view() for g in h._neg[c]]).numpy()
+        assert np.array_equal(total, G["shuf_neg_%d" % c])
+        assert np.array_equal(h._pos[c].view().numpy(), G["shuf_pos_%d" % c])
+    assert np.array_equal(h._X.view().numpy(), G["shuf_X"])
+    negatives, _, _ = h.finalize()
+    assert all(len(n) == int(G["ITER"]) for n in negatives)
+    assert sum(len(b) for b in negatives[0]) == min(len(G["shuf_neg_0"]), int(G["ITER"]) * int(G["BS"]))
+
+
+def test_iou_matches_reference_and_oracle():
+    gt, prop = torch.from_numpy(G["iou_gt"]), torch.from_numpy(G["iou_prop"])
+    got = box_iou_plus1(gt[None], prop)[0].numpy()
+    assert np.allclose(got, G["iou_out"], atol=1e-6)
+    assert np.allclose(roi_ref.compute_overlap(G["iou_gt"], G["iou_prop"]), G["iou_out"], atol=1e-6)
+
+
+def test_add_new_class_and_empty_images():
+    h = DetectorHarvester(4, 1, 2, 3, 2, device="cpu")
+    h.add_new_class()
+    assert h.num_classes == 2 and h.still_to_complete == [0, 1]
+    torch.manual_seed(0)
+    h.add_image(torch.randn(5, 4), torch.rand(5, 4) * 50, torch.zeros(0, 4), [], [100, 100])
+    negatives, positives, COXY = h.finalize()
+    assert COXY["X"].shape == (0, 4) and positives[0].shape == (0, 4)
+    assert sum(len(b) for b in negatives[1]) == 3
