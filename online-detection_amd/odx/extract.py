@@ -1,0 +1,250 @@
+"""Feature-extraction forward (A11 / A12 front end): Mask R-CNN R-50-C4 trunk -> RPN -> RoIAlign ->
+conv5 head -> pooled RoI features, one image at a time, feeding odx.harvest at train time and the
+on-line heads (odx.heads) at test time.
+
+What the reference does here lives almost entirely in maskrcnn_benchmark (build_backbone, RPN
+post-processing, Pooler/ROIAlign, nms; not vendored, unpinned HEAD) driven by
+mrcnn_modified/modeling/detector/generalized_rcnn_getProposals.py:39-100,
+mrcnn_modified/modeling/roi_heads/box_head/roi_box_feature_extractors.py:13-52 and
+mrcnn_modified/engine/feature_proposal_extractor.py:228-281.  This module restates that graph
+with the architecture constants of the shipped configs (R-50-C4, FrozenBatchNorm, stride-in-1x1
+bottlenecks, 15 anchors = 3 ratios x 5 sizes at stride 16, RPN pre/post-NMS 6000/300 @ 0.7,
+RoIAlign 14 x 14 @ 1/16 with adaptive sampling, conv5 head -> D = 2048):
+  * convolutions / pooling are PyTorch-ROCm ops (MIOpen) — plumbing per the project scope;
+  * RoIAlign and NMS are the hand-written HIP kernels of csrc/roi.hip;
+  * the RPN / box heads switch to the on-line FALKON + RLS heads when models are supplied.
+No pretrained weights or datasets exist in this environment: weights are random (seeded) unless
+a state dict is given, and images come from the caller.  PARITY UNPINNED (structure only).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import backend as _backend
+from .harvest import DetectorHarvester
+from .heads import OnlineBoxPredictor, OnlineRPNHead
+
+
+# ---------------------------------------------------------------------------- anchors
+def cell_anchors(stride=16, sizes=(32, 64, 128, 256, 512), aspect_ratios=(0.5, 1.0, 2.0)):
+    """Detectron anchor windows around one stride x stride cell: ratios enumerated first, sizes
+    second (rpn/anchor_generator.py:216-243 — the order `classifier = ind % 15` decodes)."""
+    base = float(stride)
+    ctr = 0.5 * (base - 1.0)
+    out = []
+    for r in aspect_ratios:
+        w0 = round(math.sqrt(base * base / r))
+        h0 = round(w0 * r)
+        for s in sizes:
+            k = s / base
+            w, h = w0 * k, h0 * k
+            out.append([ctr - 0.5 * (w - 1), ctr - 0.5 * (h - 1), ctr + 0.5 * (w - 1), ctr + 0.5 * (h - 1)])
+    return torch.tensor(out, dtype=torch.float32)
+
+
+def grid_anchors(H, W, stride, cells):
+    """(H * W * A, 4): location-major (y, then x), anchor-type-minor (anchor_generator.py:73-95)."""
+    sx = torch.arange(0, W * stride, stride, dtype=torch.float32, device=cells.device)
+    sy = torch.arange(0, H * stride, stride, dtype=torch.float32, device=cells.device)
+    yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+    shifts = torch.stack((xx.reshape(-1), yy.reshape(-1), xx.reshape(-1), yy.reshape(-1)), dim=1)
+    return (shifts.view(-1, 1, 4) + cells.view(1, -1, 4)).reshape(-1, 4)
+
+
+def decode_deltas(deltas, boxes, clamp=math.log(1000.0 / 16)):
+    """BoxCoder(weights=(1, 1, 1, 1)).decode with the +1 width convention."""
+    w = boxes[:, 2] - boxes[:, 0] + 1
+    h = boxes[:, 3] - boxes[:, 1] + 1
+    cx, cy = boxes[:, 0] + 0.5 * w, boxes[:, 1] + 0.5 * h
+    dx, dy = deltas[:, 0], deltas[:, 1]
+    dw, dh = deltas[:, 2].clamp(max=clamp), deltas[:, 3].clamp(max=clamp)
+    pcx, pcy = dx * w + cx, dy * h + cy
+    pw, ph = torch.exp(dw) * w, torch.exp(dh) * h
+    return torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw - 1, pcy + 0.5 * ph - 1), dim=1)
+
+
+def rpn_proposals(objectness, box_regression, anchors, img_size, pre_nms_top_n=6000, post_nms_top_n=300,
+                  nms_thresh=0.7, min_size=0):
+    """RPNPostProcessor.forward_for_single_feature_map (rpn/inference.py:76-123) for one image:
+    sigmoid, top-k, decode, clip, drop small boxes, NMS (HIP kernel), keep post_nms_top_n.
+    objectness (1, A, H, W), box_regression (1, 4A, H, W); img_size = (width, height)."""
+    be = _backend.get_backend()
+    _, A, H, W = objectness.shape
+    obj = objectness.permute(0, 2, 3, 1).reshape(-1).sigmoid()
+    reg = box_regression.view(1, A, 4, H, W).permute(0, 3, 4, 1, 2).reshape(-1, 4)
+    k = min(pre_nms_top_n, obj.numel())
+    score, idx = obj.topk(k, sorted=True)
+    boxes = decode_deltas(reg[idx], anchors.to(reg.device)[idx])
+    boxes[:, 0].clamp_(0, img_size[0] - 1)
+    boxes[:, 2].clamp_(0, img_size[0] - 1)
+    boxes[:, 1].clamp_(0, img_size[1] - 1)
+    boxes[:, 3].clamp_(0, img_size[1] - 1)
+    ws, hs = boxes[:, 2] - boxes[:, 0] + 1, boxes[:, 3] - boxes[:, 1] + 1
+    ok = (ws >= min_size) & (hs >= min_size)
+    boxes, score = boxes[ok], score[ok]
+    keep = be.nms(boxes, score, nms_thresh)[:post_nms_top_n]
+    return boxes[keep], score[keep]
+
+
+# ---------------------------------------------------------------------------- network
+class FrozenBatchNorm2d(nn.Module):
+    def __init__(self, n):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+
+    def forward(self, x):
+        scale = self.weight * self.running_var.rsqrt()
+        shift = self.bias - self.running_mean * scale
+        return x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, cin, mid, cout, stride):
+        super().__init__()
+        self.down = None
+        if cin != cout or stride != 1:
+            self.down = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), FrozenBatchNorm2d(cout))
+        self.conv1, self.bn1 = nn.Conv2d(cin, mid, 1, stride, bias=False), FrozenBatchNorm2d(mid)   # stride in the 1x1
+        self.conv2, self.bn2 = nn.Conv2d(mid, mid, 3, 1, 1, bias=False), FrozenBatchNorm2d(mid)
+        self.conv3, self.bn3 = nn.Conv2d(mid, cout, 1, bias=False), FrozenBatchNorm2d(cout)
+
+    def forward(self, x):
+        idn = x if self.down is None else self.down(x)
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = F.relu(self.bn2(self.conv2(y)))
+        return F.relu(self.bn3(self.conv3(y)) + idn)
+
+
+def _stage(cin, mid, cout, blocks, stride):
+    layers = [Bottleneck(cin, mid, cout, stride)] + [Bottleneck(cout, mid, cout, 1) for _ in range(blocks - 1)]
+    return nn.Sequential(*layers)
+
+
+class ResNet50C4(nn.Module):
+    out_channels = 1024
+
+    def __init__(self, width=64):
+        super().__init__()
+        w = width
+        self.conv1, self.bn1 = nn.Conv2d(3, w, 7, 2, 3, bias=False), FrozenBatchNorm2d(w)
+        self.layer1 = _stage(w, w, 4 * w, 3, 1)
+        self.layer2 = _stage(4 * w, 2 * w, 8 * w, 4, 2)
+        self.layer3 = _stage(8 * w, 4 * w, 16 * w, 6, 2)
+        self.out_channels = 16 * w
+
+    def forward(self, x):
+        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, 2, 1)
+        return self.layer3(self.layer2(self.layer1(x)))
+
+
+class Conv5Head(nn.Module):
+    """ResNet stage 5 on 14 x 14 RoI crops -> 7 x 7 x 2048 (ResNet50Conv5ROIFeatureExtractor.head)."""
+
+    def __init__(self, cin=1024):
+        super().__init__()
+        self.layer4 = _stage(cin, cin // 2, 2 * cin, 3, 2)
+        self.out_channels = 2 * cin
+
+    def forward(self, x):
+        return self.layer4(x)
+
+
+class OnlineDetectionModel(nn.Module):
+    """backbone -> RPN -> (gt boxes prepended) -> RoIAlign -> conv5 head -> avg-pooled features."""
+
+    def __init__(self, width=64, num_anchors=15, pre_nms_top_n=6000, post_nms_top_n=300, rpn_nms=0.7, resolution=14,
+                 seed=0):
+        super().__init__()
+        g = torch.random.get_rng_state()
+        torch.manual_seed(seed)
+        self.backbone = ResNet50C4(width)
+        C = self.backbone.out_channels
+        self.rpn_conv = nn.Conv2d(C, C, 3, 1, 1)
+        self.rpn_logits = nn.Conv2d(C, num_anchors, 1)
+        self.rpn_deltas = nn.Conv2d(C, 4 * num_anchors, 1)
+        for l in (self.rpn_conv, self.rpn_logits, self.rpn_deltas):
+            nn.init.normal_(l.weight, std=0.01)
+            nn.init.constant_(l.bias, 0)
+        self.head = Conv5Head(C)
+        torch.random.set_rng_state(g)
+        self.stride = 16
+        self.cells = cell_anchors(self.stride)
+        self.pre_nms_top_n, self.post_nms_top_n, self.rpn_nms, self.resolution = pre_nms_top_n, post_nms_top_n, rpn_nms, resolution
+        self.online_rpn = None          # odx.heads.OnlineRPNHead once FALKON RPN models exist
+        self.online_box = None          # odx.heads.OnlineBoxPredictor
+
+    @property
+    def feat_dim(self):
+        return self.head.out_channels
+
+    def rpn_activation(self, c4):
+        return F.relu(self.rpn_conv(c4))
+
+    @torch.no_grad()
+    def proposals(self, c4, img_size):
+        t = self.rpn_activation(c4)
+        if self.online_rpn is not None:
+            logits, deltas = self.online_rpn(t)
+        else:
+            logits, deltas = self.rpn_logits(t), self.rpn_deltas(t)
+        anchors = grid_anchors(c4.shape[2], c4.shape[3], self.stride, self.cells.to(c4.device))
+        return rpn_proposals(logits, deltas, anchors, img_size, self.pre_nms_top_n, self.post_nms_top_n, self.rpn_nms)
+
+    @torch.no_grad()
+    def roi_features(self, c4, boxes):
+        """(R, D): RoIAlign 14 x 14 @ 1/stride (HIP) -> conv5 head -> global average pool."""
+        be = _backend.get_backend()
+        rois = torch.cat((torch.zeros((boxes.shape[0], 1), device=boxes.device), boxes), dim=1)
+        crops = be.roi_align(c4, rois, 1.0 / self.stride, (self.resolution, self.resolution), 0)
+        return self.head(crops).mean(dim=(2, 3))
+
+    @torch.no_grad()
+    def forward(self, image, gt_boxes=None):
+        """image (1, 3, H, W) already normalised / resized; returns (boxes (R, 4), feats (R, D), c4)
+        with the ground-truth boxes prepended to the proposals (generalized_rcnn_getProposals.py:90-96)."""
+        c4 = self.backbone(image)
+        img_size = (image.shape[3], image.shape[2])
+        boxes, _ = self.proposals(c4, img_size)
+        if gt_boxes is not None and len(gt_boxes):
+            boxes = torch.cat((gt_boxes.to(boxes.device).float(), boxes), dim=0)
+        return boxes, self.roi_features(c4, boxes), c4
+
+
+class DetectorFeatureExtractor:
+    """The per-image harvest loop of FeatureExtractorDetector.train
+    (feature_extractor_detector/extract_features_detector.py:96-292 with
+    engine/feature_proposal_extractor.py:228-281): images are walked one at a time; with several
+    ranks each takes every world-th image and keeps the rows it harvested (already row-sharded
+    for the trainers)."""
+
+    def __init__(self, model, num_classes, iterations=10, batch_size=2000, neg_iou_thresh=0.3, reg_min_overlap=0.6,
+                 shuffle_negatives=False, rank=0, world=1):
+        self.model, self.rank, self.world = model, rank, world
+        self.kw = dict(num_classes=num_classes, iterations=iterations, batch_size=batch_size, neg_iou_thresh=neg_iou_thresh,
+                       reg_min_overlap=reg_min_overlap, shuffle_negatives=shuffle_negatives)
+
+    def train(self, samples, use_only_gt_positives=True):
+        """samples: sequence of (image (1,3,H,W), gt_boxes (G,4), gt_labels list[int] 1..C)."""
+        samples = list(samples)[self.rank::self.world]
+        dev = next(self.model.parameters()).device
+        hv = DetectorHarvester(self.model.feat_dim, num_images=max(len(samples), 1), device=dev, **self.kw)
+        for image, gt_boxes, gt_labels in samples:
+            image = image.to(dev)
+            boxes, feats, _ = self.model(image, gt_boxes)
+            hv.add_image(feats, boxes, gt_boxes.to(dev), list(gt_labels), [image.shape[3], image.shape[2]])
+        return hv.finalize(use_only_gt_positives)
+
+    def test(self, samples):
+        samples = list(samples)[self.rank::self.world]
+        dev = next(self.model.parameters()).device
+        hv = DetectorHarvester(self.model.feat_dim, num_images=max(len(samples), 1), device=dev, **self.kw)
+        for image, gt_boxes, gt_labels in samples:
+            image = image.to(dev)
+            boxes, feats, _ = self.model(image, gt_boxes)
+            hv.add_test_image(feats, boxes, len(gt_labels), [image.shape[3], image.shape[2]])
+        return hv.test_boxes

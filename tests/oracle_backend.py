@@ -131,6 +131,14 @@ class OracleBackend:
     def gemm_nt(self, Fa, Fb):
         return (Fa.X.double() @ Fb.X.double().t()).float()
 
+    def roi_align(self, feat, rois, spatial_scale, output_size, sampling_ratio=0):
+        from oracle import roi_ref
+        return torch.from_numpy(roi_ref.roi_align(feat.numpy(), rois.numpy(), spatial_scale, output_size, sampling_ratio)).float()
+
+    def nms(self, boxes, scores, thr):
+        from oracle import roi_ref
+        return torch.from_numpy(roi_ref.nms(boxes.numpy(), scores.numpy(), thr))
+
     # RLS
     def rls_gram(self, F, idx, Yt, G, XtY):
         X = F.X[idx].double()

@@ -1,0 +1,112 @@
+"""Feature-extraction forward (structure; parity unpinned: no weights, images or maskrcnn_benchmark
+exist here).  CPU: anchors, box decoding, proposal generation and the harvest loop on a tiny network
+with the oracle backend.  GPU: the same pipeline end to end on the MI355X, then on-line training and
+the test-time heads on what it harvested."""
+import io
+import os
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+import torch
+
+import odx
+from odx.extract import (DetectorFeatureExtractor, OnlineDetectionModel, cell_anchors, decode_deltas, grid_anchors)
+from tests import dropin
+
+
+def test_cell_anchors_follow_the_detectron_enumeration():
+    a = cell_anchors(16)
+    assert a.shape == (15, 4)
+    # ratio-major, size-minor; 0-based windows centred on 7.5 (anchor_generator.py:216-243)
+    assert a[0].tolist() == [-15.0, -4.0, 30.0, 19.0]          # ratio 0.5, size 32
+    assert a[2].tolist() == [-84.0, -40.0, 99.0, 55.0]         # ratio 0.5, size 128
+    assert a[7].tolist() == [-56.0, -56.0, 71.0, 71.0]         # ratio 1, size 128
+    assert a[14].tolist() == [-168.0, -344.0, 183.0, 359.0]    # ratio 2, size 512
+    g = grid_anchors(2, 3, 16, a)
+    assert g.shape == (2 * 3 * 15, 4)
+    assert torch.equal(g[15:30], a + torch.tensor([16.0, 0, 16, 0]))     # x advances first
+    assert torch.equal(g[45:60], a + torch.tensor([0.0, 16, 0, 16]))
+
+
+def test_decode_deltas_identity_and_shift():
+    b = torch.tensor([[10.0, 20, 49, 79]])
+    assert torch.allclose(decode_deltas(torch.zeros(1, 4), b), b)
+    d = decode_deltas(torch.tensor([[0.5, 0.0, 0.6931472, 0.0]]), b)
+    assert torch.allclose(d, torch.tensor([[10.0, 20, 89, 79]]), atol=1e-3)
+
+
+def _samples(n, H, W, C, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i in range(n):
+        img = torch.randn(1, 3, H, W, generator=g)
+        G = 1 + i % 2
+        xy = torch.rand(G, 2, generator=g) * torch.tensor([W * 0.5, H * 0.5])
+        gt = torch.cat([xy, xy + 20 + torch.rand(G, 2, generator=g) * torch.tensor([W * 0.4, H * 0.4])], 1)
+        out.append((img, gt, [1 + (i + k) % C for k in range(G)]))
+    return out
+
+
+def test_harvest_loop_on_cpu_with_oracle_backend():
+    from tests.oracle_backend import OracleBackend
+    odx.set_backend(OracleBackend(np.float64))
+    try:
+        model = OnlineDetectionModel(width=4, post_nms_top_n=12, pre_nms_top_n=60, resolution=4).eval()
+        ex = DetectorFeatureExtractor(model, num_classes=2, iterations=2, batch_size=8)
+        torch.manual_seed(0)
+        neg, pos, COXY = ex.train(_samples(3, 64, 80, 2))
+        D = model.feat_dim
+        assert D == 128 and len(neg) == 2 and all(len(n) == 2 for n in neg)
+        assert all(b.shape[1] == D for n in neg for b in n) and pos[0].shape[1] == D
+        assert sum(len(p) for p in pos) == 1 + 2 + 1                # one row per ground-truth box
+        assert COXY["X"].shape[1] == D and COXY["Y"].shape[1] == 4 and len(COXY["C"]) == len(COXY["X"])
+        tb = ex.test(_samples(2, 64, 80, 2))
+        assert len(tb) == 2 and tb[0]["feat"].shape[1] == D and tb[0]["gt"].sum() == 1
+        # rank / world sharding of the image stream
+        ex2 = DetectorFeatureExtractor(model, num_classes=2, iterations=2, batch_size=8, rank=1, world=2)
+        assert len(ex2.test(_samples(3, 64, 80, 2))) == 1
+    finally:
+        odx.set_backend(None)
+
+
+@pytest.mark.gpu
+def test_end_to_end_pipeline_on_gpu(tmp_path):
+    """extract -> stats -> FALKON minibootstrap -> RLS -> test-time heads, all through libodx."""
+    import yaml
+    odx.set_backend(None)
+    C = 3
+    cfg = {"NUM_CLASSES": C + 1, "CHOSEN_CLASSES": {i: ("bg" if i == 0 else "obj%d" % i) for i in range(C + 1)},
+           "ONLINE_REGION_CLASSIFIER": {"MINIBOOTSTRAP": {"EASY_THRESH": -0.9, "HARD_THRESH": -0.7},
+                                        "CLASSIFIER": {"lambda": 0.001, "sigma": 10, "M": 64, "kernel_type": "gauss"}},
+           "REGION_REFINER": {"opts": {"lambda": 10.0}},
+           "MINIBOOTSTRAP": {"DETECTOR": {"NUM_CLASSES": C, "ITERATIONS": 2, "BATCH_SIZE": 40, "NEG_IOU_THRESH": 0.3}},
+           "REGRESSORS": {"MIN_OVERLAP": 0.6}}
+    path = str(tmp_path / "cfg.yaml")
+    yaml.safe_dump(cfg, open(path, "w"))
+    fe = dropin.load("feature_extractor").FeatureExtractor(path, path)
+    model = OnlineDetectionModel(width=16, post_nms_top_n=40, pre_nms_top_n=400).cuda().eval()   # D = 512
+    samples = _samples(8, 192, 256, C, seed=3)
+    torch.manual_seed(1)
+    negatives, positives, COXY = fe.extractFeatures(True, output_dir=str(tmp_path), cfg_options={"samples": samples, "model": model})
+    assert positives[0].is_cuda and positives[0].shape[1] == 512 and len(negatives) == C
+    u = dropin.load("py_od_utils")
+    with redirect_stdout(io.StringIO()):
+        stats = u.computeFeatStatistics_torch(positives, negatives, features_dim=512, pos_fraction=0.8)
+        clf = dropin.load("FALKONWrapper_with_centers_selection_incore").FALKONWrapper(cfg_path=path)
+        orc = dropin.load("OnlineRegionClassifier_incore").OnlineRegionClassifier(clf, positives, negatives, stats, cfg_path=path)
+        models = u.falkon_models_to_cuda(orc.trainRegionClassifier())
+        regs = dropin.load("region_refiner").RegionRefiner(path).trainRegionRefiner(u.normalize_COXY(COXY, stats))
+    assert len(models) == C and len(regs) == C
+    fe.falkon_detector_models, fe.regressors_detector_models, fe.stats_detector = models, regs, stats
+    test_boxes = fe.extractFeatures(False, cfg_options={"samples": samples[:2], "model": model})
+    assert len(test_boxes) == 2
+    with redirect_stdout(io.StringIO()):
+        preds = orc.testRegionClassifier(models, test_boxes)
+    assert tuple(preds[0].get_field("scores").shape)[1] == C + 1
+    # in-network test-time head on one image's RoI features
+    boxes, feats, _ = model(samples[0][0].cuda(), None)
+    scores, deltas = model.online_box(feats)
+    assert tuple(scores.shape) == (boxes.shape[0], C + 1) and tuple(deltas.shape) == (boxes.shape[0], 4 * (C + 1))
+    assert torch.isfinite(scores).all() and torch.isfinite(deltas).all()
+    assert "Detector's feature extraction time" in open(os.path.join(str(tmp_path), "result.txt")).read()
