@@ -204,3 +204,147 @@ class DetectorHarvester:
             else:
                 negatives.append([g.view().clone() for g in self._neg[i]])
         return negatives, positives, COXY
+
+
+class RPNHarvester:
+    """Train-time harvesting for the on-line RPN (A12): one FALKON problem per anchor type.
+    Behaviour follows RPNModule.forward (mrcnn_modified/modeling/rpn/rpn_getProposals.py:180-463):
+      * anchors (location-major, type-minor) that cross the image border are dropped for good
+        (:224-225); anchor k sits at feature cell ((k // A) // W, (k // A) % W) and belongs to
+        classifier k % A (:211-215);
+      * per image, IoU (+1 convention) of every kept anchor with every ground-truth box; each anchor
+        is associated with its best ground truth (:262-271);
+      * negatives of type i: anchors of that type with IoU < NEG_IOU_THRESH, a with-replacement
+        sample of `negatives_to_pick` when there are more, spread over the still-open batches
+        (:274-331) — or appended to one growing list when SHUFFLE_NEGATIVES (:333-362);
+      * positives: anchors with IoU > POS_IOU_THRESH, plus, for a ground truth none of whose
+        coordinates appears among the positives' associated boxes (the reference's tensor `in`
+        test, :369), the anchors associated with it that reach its maximum IoU (:366-381);
+      * features are the (D,) columns of the RPN activation at the anchors' cells; positives also
+        yield regressor rows X / Y (box targets against the associated ground truth) / C (anchor type).
+    The reference gathers each row through an index_select square + diagonal pick (:316-321); here it
+    is one advanced-indexing gather.
+    """
+
+    def __init__(self, feat_dim, num_classes, iterations, batch_size, num_images, neg_iou_thresh=0.3,
+                 pos_iou_thresh=0.7, shuffle_negatives=False, device=None):
+        self.D, self.A = feat_dim, num_classes
+        self.iterations, self.batch_size, self.num_images = iterations, batch_size, num_images
+        self.neg_iou_thresh, self.pos_iou_thresh = neg_iou_thresh, pos_iou_thresh
+        self.shuffle_negatives = shuffle_negatives
+        self.device = device or ('cuda' if torch.cuda.is_available() else 'cpu')
+        self.negatives_to_pick = None
+        self.anchors = None
+        self._pos = [_Growing(feat_dim, self.device) for _ in range(num_classes)]
+        if shuffle_negatives:
+            self._neg = [[_Growing(feat_dim, self.device, cap=batch_size)] for _ in range(num_classes)]
+        else:
+            self._neg = [[_Growing(feat_dim, self.device, cap=batch_size) for _ in range(iterations)] for _ in range(num_classes)]
+        self.current_batch = [0] * num_classes
+        self._X, self._Y, self._C = _Growing(feat_dim, self.device), _Growing(4, self.device), _Growing(1, self.device)
+        self.O = None
+
+    def _setup(self, anchors_all, img_size, W):
+        n = anchors_all.shape[0]
+        k = torch.arange(n, device=anchors_all.device)
+        loc = k // self.A
+        vis = (anchors_all[:, 0] >= 0) & (anchors_all[:, 1] >= 0) & (anchors_all[:, 2] < img_size[0]) & (anchors_all[:, 3] < img_size[1])
+        self.anchors = anchors_all[vis]
+        self.rows, self.cols = (loc // W)[vis], (loc % W)[vis]
+        self.cls = (k % self.A)[vis]
+        # Anchor types without a visible anchor are dropped the way the reference does it — by
+        # removing from the list it is iterating (:227-229), which skips the element after every
+        # removal: of a run of empty types only every other one is dropped.  Kept on purpose.
+        self.still_to_complete = list(range(self.A))
+        for i in self.still_to_complete:
+            if not bool((self.cls == i).any()):
+                self.still_to_complete.remove(i)
+        self.anchors_ids = list(self.still_to_complete)
+
+    def _gather(self, t, sel):
+        return t[:, self.rows[sel], self.cols[sel]].t().reshape(-1, self.D)
+
+    def add_image(self, t, anchors_all, img_size, gt_bbox):
+        """t (D, H, W) RPN activation of the image; anchors_all (H*W*A, 4) from grid_anchors;
+        img_size (width, height); gt_bbox (G >= 1, 4) in the same pixel frame."""
+        if self.negatives_to_pick is None:
+            self.negatives_to_pick = math.ceil((self.batch_size * self.iterations) / self.num_images)
+        if self.anchors is None:
+            self._setup(anchors_all.to(t.device), img_size, t.shape[2])
+        gt = gt_bbox.to(t.device).float()
+        ious = torch.squeeze(box_iou_plus1(gt, self.anchors))
+        if gt.shape[0] > 1:
+            ious, idx = torch.max(ious, dim=0)
+            assoc = gt[idx]
+        else:
+            ious = ious.reshape(-1)
+            assoc = gt[0].expand(self.anchors.shape[0], 4)
+        neg_mask = ious < self.neg_iou_thresh
+        types = self.still_to_complete if not self.shuffle_negatives else range(self.A)
+        done = []
+        for i in list(types):
+            cand = torch.nonzero(neg_mask & (self.cls == i)).reshape(-1)
+            if cand.numel() > self.negatives_to_pick:
+                cand = cand[torch.randint(cand.numel(), (self.negatives_to_pick,)).to(cand.device)]
+            if self.shuffle_negatives:
+                last = self._neg[i][-1]
+                last.append(self._gather(t, cand))
+                if last.n >= self.batch_size:
+                    self._neg[i].append(_Growing(self.D, self.device, cap=self.batch_size))
+                continue
+            per_batch = math.ceil(self.negatives_to_pick / self.iterations)
+            taken = 0
+            for b in range(self.current_batch[i], self.iterations):
+                cur = self._neg[i][b]
+                if cur.n >= self.batch_size:
+                    self.current_batch[i] += 1
+                    if self.current_batch[i] >= self.iterations:
+                        done.append(i)
+                    continue
+                end = int(taken + min(per_batch, self.batch_size - cur.n, self.negatives_to_pick - taken, cand.numel() - taken))
+                cur.append(self._gather(t, cand[taken:end]))
+                taken = end
+                if taken == self.negatives_to_pick:
+                    break
+        for i in done:
+            self.still_to_complete.remove(i)
+        # positives
+        pos = torch.nonzero(ious > self.pos_iou_thresh).reshape(-1)
+        pos_gt = assoc[pos]
+        for g in gt:
+            if bool((g[None, :] == pos_gt).any()):       # the reference's `elem in tensor`: ANY coordinate match
+                continue
+            mine = (assoc == g[None, :]).all(dim=1)
+            if bool(mine.any()):
+                best = ious[mine].max()
+                extra = torch.nonzero(mine & (ious == best)).reshape(-1)
+                pos = torch.cat((pos, extra))
+                pos_gt = assoc[pos]
+        for i in torch.unique(self.cls[pos]).tolist():
+            sel = pos[self.cls[pos] == i]
+            feat = self._gather(t, sel)
+            self._pos[i].append(feat)
+            ex, tg = self.anchors[sel], assoc[sel]
+            sw, sh = ex[:, 2] - ex[:, 0] + 1, ex[:, 3] - ex[:, 1] + 1
+            sx, sy = ex[:, 0] + 0.5 * sw, ex[:, 1] + 0.5 * sh
+            gw, gh = tg[:, 2] - tg[:, 0] + 1, tg[:, 3] - tg[:, 1] + 1
+            gx, gy = tg[:, 0] + 0.5 * gw, tg[:, 1] + 0.5 * gh
+            self._Y.append(torch.stack(((gx - sx) / sw, (gy - sy) / sh, torch.log(gw / sw), torch.log(gh / sh)), dim=1))
+            self._C.append(torch.full((sel.numel(), 1), float(i), device=t.device))
+            self._X.append(feat)
+
+    def finalize(self):
+        """negatives, positives, COXY as returned by FeatureExtractorRPN.train
+        (feature_extractor_RPN/extract_features_RPN.py:218)."""
+        COXY = {'C': self._C.view().clone(), 'O': self.O, 'X': self._X.view().clone(), 'Y': self._Y.view().clone()}
+        positives = [p.view().clone() for p in self._pos]
+        negatives = []
+        for i in range(self.A):
+            if self.shuffle_negatives:
+                total = torch.cat([g.view() for g in self._neg[i]])
+                perm = torch.randperm(len(total))
+                bs = self.batch_size
+                negatives.append([total[perm[min(j * bs, len(perm)):min((j + 1) * bs, len(perm))]] for j in range(self.iterations)])
+            else:
+                negatives.append([g.view().clone() for g in self._neg[i]])
+        return negatives, positives, COXY

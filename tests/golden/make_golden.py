@@ -553,7 +553,132 @@ def make_harvest():
     print("harvest_golden.npz:", len(out), "arrays")
 
 
+# --------------------------------------------------------------------------- A12: RPN harvesting
+class FieldBoxList:
+    """Stand-in for maskrcnn_benchmark's BoxList with what RPNModule.forward touches: fields that
+    follow indexing, copy_with_fields, resize, size."""
+
+    def __init__(self, bbox, image_size, mode="xyxy"):
+        self.bbox, self.size, self.mode, self.extra_fields = bbox, image_size, mode, {}
+
+    def add_field(self, k, v):
+        self.extra_fields[k] = v
+
+    def get_field(self, k):
+        return self.extra_fields[k]
+
+    def fields(self):
+        return list(self.extra_fields)
+
+    def copy_with_fields(self, fields):
+        b = FieldBoxList(self.bbox, self.size, self.mode)
+        for f in fields:
+            b.add_field(f, self.get_field(f))
+        return b
+
+    def resize(self, size):
+        rw, rh = size[0] / self.size[0], size[1] / self.size[1]
+        b = self.bbox.clone().float()
+        b[:, 0::2] *= rw
+        b[:, 1::2] *= rh
+        return FieldBoxList(b, size, self.mode)
+
+    def __getitem__(self, item):
+        b = FieldBoxList(self.bbox[item], self.size, self.mode)
+        for k, v in self.extra_fields.items():
+            b.add_field(k, v[item])
+        return b
+
+    def __len__(self):
+        return self.bbox.shape[0]
+
+
+def ref_boxlist_iou(b1, b2):
+    """maskrcnn_benchmark.structures.boxlist_ops.boxlist_iou (TO_REMOVE = 1), restated."""
+    a1 = (b1.bbox[:, 2] - b1.bbox[:, 0] + 1) * (b1.bbox[:, 3] - b1.bbox[:, 1] + 1)
+    a2 = (b2.bbox[:, 2] - b2.bbox[:, 0] + 1) * (b2.bbox[:, 3] - b2.bbox[:, 1] + 1)
+    lt = torch.max(b1.bbox[:, None, :2], b2.bbox[:, :2])
+    rb = torch.min(b1.bbox[:, None, 2:], b2.bbox[:, 2:])
+    wh = (rb - lt + 1).clamp(min=0)
+    inter = wh[:, :, 0] * wh[:, :, 1]
+    return inter / (a1[:, None] + a2 - inter)
+
+
+def ref_cat_boxlist(bl):
+    out = FieldBoxList(torch.cat([b.bbox for b in bl]), bl[0].size, bl[0].mode)
+    for f in bl[0].fields():
+        out.add_field(f, torch.cat([b.get_field(f) for b in bl]))
+    return out
+
+
+def make_rpn_harvest():
+    from torch import nn
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT), os.pardir, "online-detection_amd"))
+    from odx.extract import cell_anchors, grid_anchors
+    base = "src/modules/feature-extractor/mrcnn_modified/"
+    src = _strip_imports(open(os.path.join(REF, base, "modeling/rpn/rpn_getProposals.py")).read())
+    reg = types.SimpleNamespace(RPN_HEADS=_Registry())
+    ns = {"registry": reg, "boxlist_iou": ref_boxlist_iou, "cat_boxlist": ref_cat_boxlist, "BoxList": FieldBoxList,
+          "__name__": "ref_rpn_getProposals"}
+    exec(compile(src.replace("'cuda'", "'cpu'"), "rpn_getProposals.py", "exec"), ns)
+    RPN = ns["RPNModule"]
+    D, A, H, W, ITER, BS, NIMG = 6, 15, 9, 12, 2, 10, 4
+    img = (W * 16, H * 16)
+    anchors_all = grid_anchors(H, W, 16, cell_anchors(16))
+    vis = (anchors_all[:, 0] >= 0) & (anchors_all[:, 1] >= 0) & (anchors_all[:, 2] < img[0]) & (anchors_all[:, 3] < img[1])
+    out = {"D": np.int64(D), "A": np.int64(A), "H": np.int64(H), "W": np.int64(W), "ITER": np.int64(ITER), "BS": np.int64(BS),
+           "NIMG": np.int64(NIMG), "anchors": anchors_all.numpy()}
+    g = torch.Generator().manual_seed(91)
+    images = []
+    for im in range(NIMG):
+        G = [1, 2, 3, 2][im]
+        xy = torch.rand(G, 2, generator=g) * torch.tensor([img[0] * 0.5, img[1] * 0.5])
+        gt = torch.cat([xy, xy + 24 + torch.rand(G, 2, generator=g) * torch.tensor([img[0] * 0.4, img[1] * 0.4])], 1)
+        gt[0] = torch.tensor([[31.0, 31.0, 96.0, 96.0], [20.0, 40.0, 111.0, 85.0], [8.0, 8.0, 71.0, 135.0], [40.0, 30.0, 167.0, 93.0]][im])
+        t = torch.randn(D, H, W, generator=g)
+        images.append((t, gt))
+        out["t_%d" % im], out["gt_%d" % im] = t.numpy(), gt.numpy()
+    for shuffle in (False, True):
+        m = RPN.__new__(RPN)
+        nn.Module.__init__(m)
+        rcfg = types.SimpleNamespace(NUM_CLASSES=A, ITERATIONS=ITER, BATCH_SIZE=BS, NEG_IOU_THRESH=0.3, POS_IOU_THRESH=0.7,
+                                     SHUFFLE_NEGATIVES=shuffle, FEATURES_DEVICE="cpu")
+        m.cfg = types.SimpleNamespace(MINIBOOTSTRAP=types.SimpleNamespace(RPN=rcfg), DEMO=types.SimpleNamespace(INCREMENTAL_TRAIN=False),
+                                      NUM_IMAGES=NIMG)
+        m.save_features = False
+        m.prev_classifiers = m.prev_feature_ids = None
+
+        def anchor_generator(images_, features_):
+            b = FieldBoxList(anchors_all.clone(), img)
+            b.add_field("visibility", vis.clone())
+            return [[b]]
+        m.anchor_generator = anchor_generator
+        m.initialize_online_rpn_params()
+        torch.manual_seed(321)
+        with redirect_stdout(io.StringIO()):
+            for (t, gt) in images:
+                m.head = lambda feats, _t=t: [_t.unsqueeze(0)]
+                m.forward(None, None, gt_bbox=FieldBoxList(gt.clone(), img), img_size=None)
+        tag = "shuf" if shuffle else "fill"
+        out[tag + "_C"], out[tag + "_X"], out[tag + "_Y"] = torch.cat(m.C).numpy(), torch.cat(m.X).numpy(), torch.cat(m.Y).numpy()
+        for c in range(A):
+            out["%s_pos_%d" % (tag, c)] = torch.cat(m.positives[c]).numpy()
+            if shuffle:
+                out["%s_neg_%d" % (tag, c)] = torch.cat(m.negatives[c]).numpy()
+            else:
+                for b in range(ITER):
+                    out["%s_neg_%d_%d" % (tag, c, b)] = m.negatives[c][b].numpy()
+        if not shuffle:
+            out["fill_still_to_complete"] = np.array(m.still_to_complete, dtype=np.int64)
+            out["fill_anchors_ids"] = np.array(m.anchors_ids, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "rpn_harvest_golden.npz"), **out)
+    print("rpn_harvest_golden.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
+    if "--only-rpn-harvest" in sys.argv:
+        make_rpn_harvest()
+        sys.exit(0)
     if "--only-harvest" in sys.argv:
         make_harvest()
         sys.exit(0)
@@ -566,3 +691,4 @@ if __name__ == "__main__":
     make_wrapper_contract()
     make_heads()
     make_harvest()
+    make_rpn_harvest()

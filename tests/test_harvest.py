@@ -72,3 +72,44 @@ def test_add_new_class_and_empty_images():
     negatives, positives, COXY = h.finalize()
     assert COXY["X"].shape == (0, 4) and positives[0].shape == (0, 4)
     assert sum(len(b) for b in negatives[1]) == 3
+
+
+# ------------------------------------------------------------------ on-line RPN harvesting (A12)
+R = np.load(os.path.join(os.path.dirname(__file__), "golden", "rpn_harvest_golden.npz"))
+
+
+def _run_rpn(shuffle):
+    from odx.harvest import RPNHarvester
+    D, A, H, W, ITER, BS, NIMG = (int(R[k]) for k in ("D", "A", "H", "W", "ITER", "BS", "NIMG"))
+    h = RPNHarvester(D, A, ITER, BS, NIMG, shuffle_negatives=shuffle, device="cpu")
+    anchors = torch.from_numpy(R["anchors"])
+    torch.manual_seed(321)
+    for im in range(NIMG):
+        h.add_image(torch.from_numpy(R["t_%d" % im]), anchors, (W * 16, H * 16), torch.from_numpy(R["gt_%d" % im]))
+    return h
+
+
+def test_rpn_fill_mode_matches_reference():
+    """Against the reference's own RPNModule.forward (rpn_getProposals.py) run on the same inputs."""
+    from odx.extract import cell_anchors, grid_anchors
+    assert np.array_equal(grid_anchors(int(R["H"]), int(R["W"]), 16, cell_anchors(16)).numpy(), R["anchors"])
+    h = _run_rpn(False)
+    A, ITER = int(R["A"]), int(R["ITER"])
+    assert h.anchors_ids == R["fill_anchors_ids"].tolist()
+    assert h.still_to_complete == R["fill_still_to_complete"].tolist()
+    negatives, positives, COXY = h.finalize()
+    assert np.array_equal(COXY["C"].numpy(), R["fill_C"]) and np.array_equal(COXY["X"].numpy(), R["fill_X"])
+    assert np.allclose(COXY["Y"].numpy(), R["fill_Y"], atol=1e-6)
+    for c in range(A):
+        assert np.array_equal(positives[c].numpy(), R["fill_pos_%d" % c]), c
+        for b in range(ITER):
+            assert np.array_equal(negatives[c][b].numpy(), R["fill_neg_%d_%d" % (c, b)]), (c, b)
+    assert sum(len(p) for p in positives) > 0 and len(COXY["X"]) == sum(len(p) for p in positives)
+
+
+def test_rpn_shuffle_mode_matches_reference_before_the_final_permutation():
+    h = _run_rpn(True)
+    for c in range(int(R["A"])):
+        assert np.array_equal(torch.cat([g.view() for g in h._neg[c]]).numpy(), R["shuf_neg_%d" % c]), c
+        assert np.array_equal(h._pos[c].view().numpy(), R["shuf_pos_%d" % c])
+    assert np.array_equal(h._X.view().numpy(), R["shuf_X"])
