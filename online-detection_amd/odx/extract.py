@@ -23,8 +23,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import backend as _backend
-from .harvest import DetectorHarvester
-from .heads import OnlineBoxPredictor, OnlineRPNHead
+from .harvest import DetectorHarvester, MaskHarvester, RPNHarvester, project_masks_on_boxes
+from .heads import OnlineBoxPredictor, OnlineMaskPredictor, OnlineRPNHead  # noqa: F401
 
 
 # ---------------------------------------------------------------------------- anchors
@@ -158,7 +158,7 @@ class OnlineDetectionModel(nn.Module):
     """backbone -> RPN -> (gt boxes prepended) -> RoIAlign -> conv5 head -> avg-pooled features."""
 
     def __init__(self, width=64, num_anchors=15, pre_nms_top_n=6000, post_nms_top_n=300, rpn_nms=0.7, resolution=14,
-                 seed=0):
+                 seed=0, mask_dim=256):
         super().__init__()
         g = torch.random.get_rng_state()
         torch.manual_seed(seed)
@@ -171,12 +171,18 @@ class OnlineDetectionModel(nn.Module):
             nn.init.normal_(l.weight, std=0.01)
             nn.init.constant_(l.bias, 0)
         self.head = Conv5Head(C)
+        # mask branch: ConvTranspose 2C -> mask_dim, k2 s2 (roi_mask_predictors.py:24): 7x7 -> 14x14 pixel rows
+        self.conv5_mask = nn.ConvTranspose2d(2 * C, mask_dim, 2, 2, 0)
+        nn.init.kaiming_normal_(self.conv5_mask.weight, mode="fan_out", nonlinearity="relu")
+        nn.init.constant_(self.conv5_mask.bias, 0)
         torch.random.set_rng_state(g)
         self.stride = 16
         self.cells = cell_anchors(self.stride)
         self.pre_nms_top_n, self.post_nms_top_n, self.rpn_nms, self.resolution = pre_nms_top_n, post_nms_top_n, rpn_nms, resolution
         self.online_rpn = None          # odx.heads.OnlineRPNHead once FALKON RPN models exist
         self.online_box = None          # odx.heads.OnlineBoxPredictor
+        self.online_mask = None         # odx.heads.OnlineMaskPredictor
+        self.mask_dim = mask_dim
 
     @property
     def feat_dim(self):
@@ -196,12 +202,22 @@ class OnlineDetectionModel(nn.Module):
         return rpn_proposals(logits, deltas, anchors, img_size, self.pre_nms_top_n, self.post_nms_top_n, self.rpn_nms)
 
     @torch.no_grad()
-    def roi_features(self, c4, boxes):
-        """(R, D): RoIAlign 14 x 14 @ 1/stride (HIP) -> conv5 head -> global average pool."""
+    def roi_head_maps(self, c4, boxes):
+        """(R, D, r/2, r/2): RoIAlign r x r @ 1/stride (HIP kernel) -> conv5 head."""
         be = _backend.get_backend()
         rois = torch.cat((torch.zeros((boxes.shape[0], 1), device=boxes.device), boxes), dim=1)
         crops = be.roi_align(c4, rois, 1.0 / self.stride, (self.resolution, self.resolution), 0)
-        return self.head(crops).mean(dim=(2, 3))
+        return self.head(crops)
+
+    @torch.no_grad()
+    def roi_features(self, c4, boxes):
+        """(R, D): conv5 head maps, global average pooled."""
+        return self.roi_head_maps(c4, boxes).mean(dim=(2, 3))
+
+    @torch.no_grad()
+    def mask_activation(self, head_maps):
+        """(R, mask_dim, r, r) = relu(conv5_mask(head maps))  (roi_mask_predictors.py:38)."""
+        return F.relu(self.conv5_mask(head_maps))
 
     @torch.no_grad()
     def forward(self, image, gt_boxes=None):
@@ -248,3 +264,63 @@ class DetectorFeatureExtractor:
             boxes, feats, _ = self.model(image, gt_boxes)
             hv.add_test_image(feats, boxes, len(gt_labels), [image.shape[3], image.shape[2]])
         return hv.test_boxes
+
+
+def _unpack(sample):
+    image, gt_boxes, gt_labels = sample[0], sample[1], sample[2]
+    masks = sample[3] if len(sample) > 3 else None
+    return image, gt_boxes, gt_labels, masks
+
+
+class OnlineFeatureExtractor:
+    """One pass over the images that harvests everything the "Ours" pipeline trains on
+    (FeatureExtractorRPNDetector.train, feature_extractor_RPN_detector/extract_features_rpn_detector.py:105-369):
+    on-line RPN rows per anchor type, detector rows per class (on the pretrained RPN's proposals with
+    the ground truth prepended) and, optionally, segmentation pixel rows per class.
+    `parts` selects what is harvested: any of "rpn", "detector", "mask"."""
+
+    def __init__(self, model, num_classes, parts=("rpn", "detector"), det=None, rpn=None, mask=None, rank=0, world=1):
+        self.model, self.C, self.parts, self.rank, self.world = model, num_classes, tuple(parts), rank, world
+        self.det_kw = dict(iterations=10, batch_size=2000, neg_iou_thresh=0.3, reg_min_overlap=0.6, shuffle_negatives=False)
+        self.rpn_kw = dict(iterations=10, batch_size=2000, neg_iou_thresh=0.3, pos_iou_thresh=0.7, shuffle_negatives=False)
+        self.mask_kw = dict(batch_size=20000, sampling_factor=0.3)
+        self.det_kw.update(det or {})
+        self.rpn_kw.update(rpn or {})
+        self.mask_kw.update(mask or {})
+
+    def train(self, samples, use_only_gt_positives=True):
+        samples = list(samples)[self.rank::self.world]
+        m = self.model
+        dev = next(m.parameters()).device
+        n = max(len(samples), 1)
+        hv_det = DetectorHarvester(m.feat_dim, self.C, num_images=n, device=dev, **self.det_kw) if "detector" in self.parts else None
+        hv_rpn = RPNHarvester(m.backbone.out_channels, m.cells.shape[0], num_images=n, device=dev, **self.rpn_kw) if "rpn" in self.parts else None
+        hv_mask = MaskHarvester(m.mask_dim, self.C, device=dev, **self.mask_kw) if "mask" in self.parts else None
+        for sample in samples:
+            image, gt_boxes, gt_labels, masks = _unpack(sample)
+            image, gt_boxes = image.to(dev), gt_boxes.to(dev).float()
+            img_size = (image.shape[3], image.shape[2])
+            with torch.no_grad():
+                c4 = m.backbone(image)
+                if hv_rpn is not None and len(gt_boxes):
+                    anchors = grid_anchors(c4.shape[2], c4.shape[3], m.stride, m.cells.to(dev))
+                    hv_rpn.add_image(m.rpn_activation(c4)[0], anchors, img_size, gt_boxes)
+                if hv_det is None and hv_mask is None:
+                    continue
+                boxes, _ = m.proposals(c4, img_size)
+                if len(gt_boxes):
+                    boxes = torch.cat((gt_boxes, boxes), dim=0)
+                maps = m.roi_head_maps(c4, boxes)
+                if hv_det is not None:
+                    hv_det.add_image(maps.mean(dim=(2, 3)), boxes, gt_boxes, list(gt_labels), [img_size[0], img_size[1]])
+                if hv_mask is not None and masks is not None and len(gt_labels):
+                    act = m.mask_activation(maps[:len(gt_labels)])
+                    hv_mask.add_image(act, project_masks_on_boxes(masks.to(dev), gt_boxes, act.shape[2]), list(gt_labels))
+        out = {}
+        if hv_rpn is not None:
+            out["rpn"] = hv_rpn.finalize()
+        if hv_det is not None:
+            out["detector"] = hv_det.finalize(use_only_gt_positives)
+        if hv_mask is not None:
+            out["mask"] = hv_mask.finalize()
+        return out

@@ -348,3 +348,62 @@ class RPNHarvester:
             else:
                 negatives.append([g.view().clone() for g in self._neg[i]])
         return negatives, positives, COXY
+
+
+def project_masks_on_boxes(masks, boxes, M):
+    """Crop each object's full-image binary mask to its box and resize to M x M
+    (mask_head_getProposals.py:15-46 -> SegmentationMask.crop / resize of maskrcnn_benchmark's binary-mask
+    representation: integer-rounded crop window, bilinear resize without corner alignment, truncated
+    back to {0, 1}).  masks (G, H, W) bool/uint8, boxes (G, 4) xyxy -> (G, M, M) float32.
+    Done on the masks' device (the reference does it object by object on the CPU, :35).
+    PARITY UNPINNED (the mask containers are maskrcnn_benchmark's, not vendored)."""
+    out = []
+    H, W = masks.shape[1], masks.shape[2]
+    for m, b in zip(masks, boxes):
+        x1, y1, x2, y2 = [int(round(float(v))) for v in b]
+        x1, y1 = min(max(x1, 0), W - 1), min(max(y1, 0), H - 1)
+        x2, y2 = min(max(x2, 0), W - 1), min(max(y2, 0), H - 1)
+        x2, y2 = max(x2, x1 + 1), max(y2, y1 + 1)
+        crop = m[y1:y2, x1:x2].float()[None, None]
+        r = torch.nn.functional.interpolate(crop, size=(M, M), mode="bilinear", align_corners=False)[0, 0]
+        out.append((r + 1e-6).to(torch.uint8).float())   # truncation, made robust to 0.99999994-style fuzz
+    if not out:
+        return torch.empty(0, dtype=torch.float32, device=masks.device)
+    return torch.stack(out)
+
+
+class MaskHarvester:
+    """Train-time harvesting for the on-line segmentation head (A13): every pixel of the S x S mask
+    activation of a ground-truth RoI is a D-dimensional row; pixels whose projected ground-truth mask
+    is >= 0.5 are positives of the object's class, the others negatives of that same class, each
+    sub-sampled to SAMPLING_FACTOR with a fresh randperm (ROIMaskHead.forward,
+    mrcnn_modified/modeling/roi_heads/mask_head/mask_head_getProposals.py:83-143)."""
+
+    def __init__(self, feat_dim, num_classes, batch_size=20000, sampling_factor=0.3, device=None):
+        self.D, self.batch_size, self.sampling_factor = feat_dim, batch_size, sampling_factor
+        self.device = device or ('cuda' if torch.cuda.is_available() else 'cpu')
+        self.num_classes = 0
+        self._pos, self._neg = [], []
+        for _ in range(num_classes):
+            self.add_new_class()
+
+    def add_new_class(self):
+        self.num_classes += 1
+        self._pos.append(_Growing(self.D, self.device, cap=1024))
+        self._neg.append(_Growing(self.D, self.device, cap=1024))
+
+    def add_image(self, mask_features, masks_gt, gt_labels_list):
+        """mask_features (G, D, S, S) = relu(conv5_mask(head features of the ground-truth RoIs));
+        masks_gt (G, S, S) from project_masks_on_boxes; gt_labels_list class ids 1..C."""
+        for i in range(len(mask_features)):
+            rows = mask_features[i].permute(1, 2, 0).reshape(-1, mask_features.size(1))
+            mg = masks_gt[i].reshape(rows.size(0)).to(rows.device)
+            c = gt_labels_list[i] - 1
+            for sel, store in ((torch.where(mg >= 0.5)[0], self._pos[c]), (torch.where(mg < 0.5)[0], self._neg[c])):
+                if self.sampling_factor < 1.0:
+                    sel = sel[torch.randperm(len(sel))[:int(self.sampling_factor * len(sel))].to(sel.device)]
+                store.append(rows[sel])
+
+    def finalize(self):
+        """negatives, positives as tensors per class (extract_features_detector.py:273-278)."""
+        return [g.view().clone() for g in self._neg], [g.view().clone() for g in self._pos]

@@ -149,3 +149,28 @@ class OnlineRPNHead(_OnlineHead):
         return logits, bbox
 
     forward = __call__
+
+
+class OnlineMaskPredictor(_OnlineHead):
+    """Per-pixel FALKON scores (R, C+1, S, S) from the mask activation m = relu(conv5_mask(x)) of
+    shape (R, D, S, S): MaskRCNNC4Predictor.forward's on-line branch, predict_pixel_FALKON[_parallel]
+    (mrcnn_modified/modeling/roi_heads/mask_head/roi_mask_predictors.py:37-99).  Every pixel is a
+    row; background channel -2; the reference's transpose / index gymnastics (:66-70,95-99) amount to
+    (R, S*S, C+1) -> (R, C+1, S, S)."""
+    background = True
+    missing_parallel = 0.0
+
+    def __init__(self, classifiers=None, stats=None, parallel_inference=True):
+        super().__init__(classifiers, None, stats, parallel_inference)
+
+    def __call__(self, m):
+        be = _backend.get_backend()
+        R, D, S, _ = m.shape
+        x = m.permute(0, 2, 3, 1).reshape(-1, D)
+        x = (x - self.stats['mean'].to(x.device)) * (20 / self.stats['mean_norm'].to(x.device))
+        s = self._scores(be.features(x), x.shape[0])
+        C = len(self.classifiers)
+        s = torch.cat((torch.full((x.shape[0], 1), -2.0, dtype=torch.float32, device=s.device), s), dim=1)
+        return s.view(R, S * S, C + 1).permute(0, 2, 1).reshape(R, C + 1, S, S)
+
+    forward = __call__

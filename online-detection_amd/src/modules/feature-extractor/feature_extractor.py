@@ -20,7 +20,7 @@ import _odx_path  # noqa: F401,E402
 import torch  # noqa: E402
 import yaml  # noqa: E402
 from FeatureExtractorAbstract import FeatureExtractorAbstract  # noqa: E402
-from odx.extract import DetectorFeatureExtractor, OnlineDetectionModel  # noqa: E402
+from odx.extract import DetectorFeatureExtractor, OnlineDetectionModel, OnlineFeatureExtractor  # noqa: E402
 from odx.heads import OnlineBoxPredictor, OnlineRPNHead  # noqa: E402
 
 
@@ -71,41 +71,81 @@ class FeatureExtractor(FeatureExtractorAbstract):
                                                   self.stats_detector)
         return model
 
-    def extractFeatures(self, is_train, output_dir=None, save_features=False, extract_features_segmentation=False,
-                        use_only_gt_positives_detection=True, cfg_options={}):
+    _NEED_SAMPLES = ("dataset loading (iCWT / YCB-V / HO-3D through maskrcnn_benchmark) is outside this repository: pass the "
+                     "image stream as cfg_options['samples'] = [(image, gt_boxes, gt_labels[, masks]), ...]")
+
+    def _kw(self, cfg, section):
+        kw = {}
+        for key, name in (('ITERATIONS', 'iterations'), ('BATCH_SIZE', 'batch_size'), ('NEG_IOU_THRESH', 'neg_iou_thresh'),
+                          ('SHUFFLE_NEGATIVES', 'shuffle_negatives'), ('POS_IOU_THRESH', 'pos_iou_thresh')):
+            v = _mb(cfg, key, None, section)
+            if v is not None and not (section == 'DETECTOR' and key == 'POS_IOU_THRESH'):
+                kw[name] = v
+        return kw
+
+    def _harvest(self, cfg_path, parts, is_train, use_only_gt_positives, cfg_options, output_dir, label):
         if 'samples' not in cfg_options:
-            raise NotImplementedError(
-                "dataset loading (iCWT / YCB-V / HO-3D through maskrcnn_benchmark) is outside this repository: pass the "
-                "image stream as cfg_options['samples'] = [(image, gt_boxes, gt_labels), ...]")
-        if extract_features_segmentation:
-            raise NotImplementedError("mask-head feature harvesting (A13) is not built yet")
-        cfg = self._cfg(self.cfg_path_target_task)
+            raise NotImplementedError(self._NEED_SAMPLES)
+        cfg = self._cfg(cfg_path)
         model = self._model(cfg_options)
-        rank = int(os.environ.get('RANK', '0'))
-        world = int(os.environ.get('WORLD_SIZE', '1'))
-        ex = DetectorFeatureExtractor(model, num_classes=_mb(cfg, 'NUM_CLASSES', cfg_options.get('num_classes', 30)),
-                                      iterations=_mb(cfg, 'ITERATIONS', 10), batch_size=_mb(cfg, 'BATCH_SIZE', 2000),
-                                      neg_iou_thresh=_mb(cfg, 'NEG_IOU_THRESH', 0.3),
-                                      reg_min_overlap=(cfg.get('REGRESSORS') or {}).get('MIN_OVERLAP', 0.6),
-                                      shuffle_negatives=_mb(cfg, 'SHUFFLE_NEGATIVES', False), rank=rank, world=world)
+        rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+        num_classes = _mb(cfg, 'NUM_CLASSES', cfg_options.get('num_classes', 30))
+        det_kw = self._kw(cfg, 'DETECTOR')
+        det_kw['reg_min_overlap'] = (cfg.get('REGRESSORS') or {}).get('MIN_OVERLAP', 0.6)
+        seg = cfg.get('SEGMENTATION') or {}
+        mask_kw = {k2: seg[k1] for k1, k2 in (('BATCH_SIZE', 'batch_size'), ('SAMPLING_FACTOR', 'sampling_factor')) if k1 in seg}
         if torch.cuda.is_available():
             torch.cuda.synchronize()
-        self.start_of_feature_extraction_time_detection = time.time()
+        t0 = time.time()
         if not is_train:
-            return ex.test(cfg_options['samples'])
-        negatives, positives, COXY = ex.train(cfg_options['samples'], use_only_gt_positives_detection)
+            ex = DetectorFeatureExtractor(model, num_classes=num_classes, rank=rank, world=world, **{
+                'iterations': det_kw.get('iterations', 10), 'batch_size': det_kw.get('batch_size', 2000)})
+            return t0, ex.test(cfg_options['samples'])
+        ex = OnlineFeatureExtractor(model, num_classes, parts=parts, det=det_kw, rpn=self._kw(cfg, 'RPN'), mask=mask_kw,
+                                    rank=rank, world=world)
+        out = ex.train(cfg_options['samples'], use_only_gt_positives)
         if output_dir:
             with open(os.path.join(output_dir, "result.txt"), "a") as fid:
-                dt = time.time() - self.start_of_feature_extraction_time_detection
-                fid.write("Detector's feature extraction time: {}min:{}s \n".format(int(dt / 60), round(dt % 60)))
-        return negatives, positives, COXY
+                dt = time.time() - t0
+                fid.write("{} feature extraction time: {}min:{}s \n".format(label, int(dt / 60), round(dt % 60)))
+        return t0, out
+
+    def extractFeatures(self, is_train, output_dir=None, save_features=False, extract_features_segmentation=False,
+                        use_only_gt_positives_detection=True, cfg_options={}):
+        """-> negatives, positives, COXY[, segmentation negatives, positives]  (extract_features_detector.py:278-292);
+        test time -> test_boxes."""
+        parts = ("detector", "mask") if extract_features_segmentation else ("detector",)
+        t0, out = self._harvest(self.cfg_path_target_task, parts, is_train, use_only_gt_positives_detection, cfg_options,
+                                output_dir, "Detector's")
+        self.start_of_feature_extraction_time_detection = t0
+        if not is_train:
+            return out
+        neg, pos, COXY = out["detector"]
+        if extract_features_segmentation:
+            return neg, pos, COXY, out["mask"][0], out["mask"][1]
+        return neg, pos, COXY
 
     def extractRPNFeatures(self, is_train, output_dir=None, save_features=False, cfg_options={}):
-        raise NotImplementedError("on-line RPN feature harvesting (A12) is not built yet")
+        """-> RPN negatives, positives, COXY  (feature_extractor_RPN/extract_features_RPN.py:218)."""
+        t0, out = self._harvest(self.cfg_path_RPN, ("rpn",), True, True, cfg_options, output_dir, "RPN's")
+        self.start_of_feature_extraction_time_RPN = t0
+        return out["rpn"]
 
     def extractFeaturesRPNDetector(self, is_train, output_dir=None, save_features=False, extract_features_segmentation=False,
                                    use_only_gt_positives_detection=True, cfg_options={}):
-        raise NotImplementedError("joint RPN + detector harvesting (A12 / A13) is not built yet")
+        """One pass -> (rpn negatives, positives, COXY, detector negatives, positives, COXY[, segmentation negatives,
+        positives])  (feature_extractor_RPN_detector/extract_features_rpn_detector.py:354-364); test time -> test_boxes."""
+        parts = ("rpn", "detector", "mask") if extract_features_segmentation else ("rpn", "detector")
+        t0, out = self._harvest(self.cfg_path_target_task, parts, is_train, use_only_gt_positives_detection, cfg_options,
+                                output_dir, "RPN and detector's")
+        self.start_of_feature_extraction_time = t0
+        self.end_of_feature_extraction_time = time.time()
+        if not is_train:
+            return out
+        res = tuple(out["rpn"]) + tuple(out["detector"])
+        if extract_features_segmentation:
+            res = res + tuple(out["mask"])
+        return res
 
     def trainFeatureExtractor(self, *args, **kwargs):
         raise NotImplementedError("SGD training of the Mask R-CNN baselines is out of scope (SURVEY §2 row 21)")

@@ -346,7 +346,7 @@ def _strip_imports(src):
     keep = []
     for line in src.splitlines():
         st = line.strip()
-        if st.startswith(("from mrcnn_modified", "from maskrcnn_benchmark", "from .")):
+        if st.startswith(("from mrcnn_modified", "from maskrcnn_benchmark", "from .", "from falkon", "import falkon")):
             continue
         keep.append(line)
     return "\n".join(keep)
@@ -463,6 +463,25 @@ def make_heads():
             out["rpn_act"] = torch.relu(h.conv(t_in)).numpy()
             logits, bbox = h.forward([t_in])
         out["rpn_par%d_logits" % par], out["rpn_par%d_bbox" % par] = logits[0].numpy(), bbox[0].numpy()
+    # ---- mask head (roi_mask_predictors.py:37-99)
+    reg.ROI_MASK_PREDICTOR = _Registry()
+    ns_mask = {"registry": reg, "Conv2d": nn.Conv2d, "ConvTranspose2d": nn.ConvTranspose2d, "__name__": "ref_roi_mask_predictors"}
+    src = _strip_imports(open(os.path.join(REF, base, "roi_heads/mask_head/roi_mask_predictors.py")).read())
+    exec(compile(src.replace("'cuda'", "'cpu'"), "roi_mask_predictors.py", "exec"), ns_mask)
+    MaskPred = reg.ROI_MASK_PREDICTOR["MaskRCNNC4Predictor"]
+    mask_models = models([9, 0, 7])
+    dump_models("mask", mask_models, regressors(0, set()))
+    xin = torch.randn(3, 24, 3, 3, generator=g)
+    for par in (True, False):
+        h = MaskPred.__new__(MaskPred)
+        nn.Module.__init__(h)
+        torch.manual_seed(5)
+        h.conv5_mask = nn.ConvTranspose2d(24, D, 2, 2, 0)
+        h.parallel_inference, h.feat_size = par, D
+        h.classifiers, h.stats = mask_models, stats
+        with torch.no_grad():
+            out["mask_act"] = torch.relu(h.conv5_mask(xin)).numpy()
+            out["mask_par%d_out" % par] = h.forward(xin).numpy()
     np.savez_compressed(os.path.join(OUT, "heads_golden.npz"), **out)
     print("heads_golden.npz:", len(out), "arrays")
 
@@ -675,7 +694,86 @@ def make_rpn_harvest():
     print("rpn_harvest_golden.npz:", len(out), "arrays")
 
 
+# --------------------------------------------------------------------------- A13: mask harvesting
+def make_mask_harvest():
+    from torch import nn
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT), os.pardir, "online-detection_amd"))
+    from odx.harvest import project_masks_on_boxes as my_project
+    base = "src/modules/feature-extractor/mrcnn_modified/"
+    src = _strip_imports(open(os.path.join(REF, base, "modeling/roi_heads/mask_head/mask_head_getProposals.py")).read())
+    ns = {"BoxList": FieldBoxList, "__name__": "ref_mask_head_getProposals"}
+    exec(compile(src.replace("'cuda'", "'cpu'"), "mask_head_getProposals.py", "exec"), ns)
+    Head = ns["ROIMaskHead"]
+
+    class OneMask:                      # what project_masks_on_boxes needs from a SegmentationMask item
+        def __init__(self, m):
+            self.m = m
+
+        def crop(self, box):
+            self.box = box
+            return self
+
+        def resize(self, size):
+            self.M = size[0]
+            return self
+
+        def get_mask_tensor(self):
+            return my_project(self.m[None], self.box[None], self.M)[0]
+
+    class Masks:
+        def __init__(self, masks, size):
+            self.masks, self.size = masks, size
+
+        def __iter__(self):
+            return iter([OneMask(m) for m in self.masks])
+
+    D, C, Cin, S = 8, 3, 12, 6
+    g = torch.Generator().manual_seed(55)
+    out = {"D": np.int64(D), "C": np.int64(C), "S": np.int64(S)}
+    h = Head.__new__(Head)
+    nn.Module.__init__(h)
+    h.cfg = types.SimpleNamespace(MODEL=types.SimpleNamespace(ROI_MASK_HEAD={"FEATURE_EXTRACTOR": "ResNet50Conv5ROIFeatureExtractor",
+                                                                               "SHARE_BOX_FEATURE_EXTRACTOR": True}),
+                                  MINIBOOTSTRAP=types.SimpleNamespace(DETECTOR=types.SimpleNamespace(NUM_CLASSES=C)),
+                                  SEGMENTATION=types.SimpleNamespace(BATCH_SIZE=60, SAMPLING_FACTOR=0.3, FEATURES_DEVICE="cpu"))
+    h.cfg.MODEL.ROI_MASK_HEAD = type("D", (dict,), {"SHARE_BOX_FEATURE_EXTRACTOR": True})({"FEATURE_EXTRACTOR": "ResNet50Conv5ROIFeatureExtractor"})
+    h.save_features, h.training_device = False, "cpu"
+    torch.manual_seed(9)
+    conv = nn.ConvTranspose2d(Cin, D, 2, 2, 0)
+    h.predictor = types.SimpleNamespace(conv5_mask=conv, mask_fcn_logits=types.SimpleNamespace(in_channels=D))
+    h.initialize_online_segmentation_params()
+    torch.manual_seed(77)
+    for im in range(3):
+        G = [2, 1, 2][im]
+        labels = [[1, 3], [2], [3, 1]][im]
+        Himg, Wimg = 60, 80
+        masks = torch.zeros(G, Himg, Wimg, dtype=torch.uint8)
+        boxes = torch.zeros(G, 4)
+        for k in range(G):
+            x1, y1 = int(torch.randint(0, 30, (1,), generator=g)), int(torch.randint(0, 20, (1,), generator=g))
+            w, hh = int(torch.randint(12, 40, (1,), generator=g)), int(torch.randint(10, 30, (1,), generator=g))
+            boxes[k] = torch.tensor([x1, y1, x1 + w, y1 + hh], dtype=torch.float32)
+            yy, xx = torch.meshgrid(torch.arange(Himg), torch.arange(Wimg), indexing="ij")
+            masks[k] = ((((xx - (x1 + w / 2)) / (w / 2)) ** 2 + ((yy - (y1 + hh / 2)) / (hh / 2)) ** 2) <= 1).to(torch.uint8)
+        feats = torch.randn(G + 4, Cin, S // 2, S // 2, generator=g)        # gt rows first, then other RoIs
+        gtb = FieldBoxList(boxes.clone(), (Wimg, Himg))
+        gtb.convert = lambda mode, _b=gtb: _b
+        gtb.add_field("masks", Masks(masks, (Wimg, Himg)))
+        with torch.no_grad():
+            h.forward(feats, None, labels, gtb)
+            out["act_%d" % im] = torch.relu(conv(feats[:G])).numpy()
+        out["masks_%d" % im], out["boxes_%d" % im], out["labels_%d" % im] = masks.numpy(), boxes.numpy(), np.array(labels)
+    for c in range(C):
+        out["pos_%d" % c] = torch.cat(h.positives[c]).detach().numpy()
+        out["neg_%d" % c] = torch.cat(h.negatives[c]).detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "mask_harvest_golden.npz"), **out)
+    print("mask_harvest_golden.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
+    if "--only-mask-harvest" in sys.argv:
+        make_mask_harvest()
+        sys.exit(0)
     if "--only-rpn-harvest" in sys.argv:
         make_rpn_harvest()
         sys.exit(0)
@@ -692,3 +790,4 @@ if __name__ == "__main__":
     make_heads()
     make_harvest()
     make_rpn_harvest()
+    make_mask_harvest()

@@ -110,3 +110,98 @@ def test_end_to_end_pipeline_on_gpu(tmp_path):
     assert tuple(scores.shape) == (boxes.shape[0], C + 1) and tuple(deltas.shape) == (boxes.shape[0], 4 * (C + 1))
     assert torch.isfinite(scores).all() and torch.isfinite(deltas).all()
     assert "Detector's feature extraction time" in open(os.path.join(str(tmp_path), "result.txt")).read()
+
+
+def _samples_with_masks(n, H, W, C, seed=0):
+    out = []
+    for (img, gt, labels) in _samples(n, H, W, C, seed):
+        masks = torch.zeros(len(labels), H, W, dtype=torch.uint8)
+        for k, b in enumerate(gt):
+            x1, y1, x2, y2 = [int(v) for v in b]
+            masks[k, y1 + 2:max(y2 - 2, y1 + 3), x1 + 2:max(x2 - 2, x1 + 3)] = 1
+        out.append((img, gt, labels, masks))
+    return out
+
+
+def test_joint_harvest_on_cpu_with_oracle_backend():
+    from odx.extract import OnlineFeatureExtractor
+    from tests.oracle_backend import OracleBackend
+    odx.set_backend(OracleBackend(np.float64))
+    try:
+        model = OnlineDetectionModel(width=4, post_nms_top_n=10, pre_nms_top_n=40, resolution=4, mask_dim=6).eval()
+        ex = OnlineFeatureExtractor(model, 2, parts=("rpn", "detector", "mask"), det=dict(iterations=2, batch_size=8),
+                                    rpn=dict(iterations=2, batch_size=6), mask=dict(batch_size=50, sampling_factor=0.5))
+        torch.manual_seed(0)
+        out = ex.train(_samples_with_masks(3, 96, 128, 2))
+        rn, rp, rc = out["rpn"]
+        assert len(rn) == 15 and len(rp) == 15 and rc["X"].shape[1] == 64 and rc["Y"].shape[1] == 4
+        dn, dp, dc = out["detector"]
+        assert len(dn) == 2 and dp[0].shape[1] == 128
+        mn, mp = out["mask"]
+        assert len(mn) == 2 and mp[0].shape[1] == 6 and sum(len(x) for x in mp) > 0
+    finally:
+        odx.set_backend(None)
+
+
+@pytest.mark.gpu
+def test_full_ours_pipeline_on_gpu(tmp_path):
+    """extractFeaturesRPNDetector (RPN + detector + segmentation rows in one pass), then the three
+    on-line trainings of run_experiment_online_rpn_ood_oos.py:98-114,127-162,252-259 and the
+    in-network test-time heads, all on the MI355X."""
+    import yaml
+    odx.set_backend(None)
+    C = 2
+    base = {"NUM_CLASSES": C + 1, "CHOSEN_CLASSES": {i: ("bg" if i == 0 else "obj%d" % i) for i in range(C + 1)},
+            "ONLINE_REGION_CLASSIFIER": {"MINIBOOTSTRAP": {"EASY_THRESH": -0.9, "HARD_THRESH": -0.7},
+                                         "CLASSIFIER": {"lambda": 0.001, "sigma": 10, "M": 48, "kernel_type": "gauss"}},
+            "ONLINE_SEGMENTATION": {"MINIBOOTSTRAP": {"EASY_THRESH": -0.9, "HARD_THRESH": -0.7},
+                                    "CLASSIFIER": {"lambda": 0.0001, "sigma": 5, "M": 40, "kernel_type": "gauss"}},
+            "REGION_REFINER": {"opts": {"lambda": 10.0}},
+            "MINIBOOTSTRAP": {"DETECTOR": {"NUM_CLASSES": C, "ITERATIONS": 2, "BATCH_SIZE": 30, "NEG_IOU_THRESH": 0.3},
+                              "RPN": {"NUM_CLASSES": 15, "ITERATIONS": 2, "BATCH_SIZE": 20, "NEG_IOU_THRESH": 0.3, "POS_IOU_THRESH": 0.7}},
+            "SEGMENTATION": {"BATCH_SIZE": 500, "SAMPLING_FACTOR": 0.5}, "REGRESSORS": {"MIN_OVERLAP": 0.6}}
+    cfg = dict(base)
+    rpn_cfg = dict(base)
+    rpn_cfg["CHOSEN_CLASSES"] = {i: "anchor%d" % i for i in range(15)}     # 15 anchor types; is_rpn adds 1 (OnlineRegionClassifier.py:52-53)
+    rpn_cfg["REGION_REFINER"] = {"opts": {"lambda": 0.01}}
+    cfg["RPN"] = rpn_cfg
+    path = str(tmp_path / "cfg.yaml")
+    yaml.safe_dump(cfg, open(path, "w"))
+    fe = dropin.load("feature_extractor").FeatureExtractor(path, path)
+    model = OnlineDetectionModel(width=16, post_nms_top_n=30, pre_nms_top_n=300, mask_dim=32).cuda().eval()
+    samples = _samples_with_masks(6, 192, 256, C, seed=5)
+    torch.manual_seed(2)
+    rn, rp, rcoxy, dn, dp, dcoxy, sn, sp = fe.extractFeaturesRPNDetector(True, extract_features_segmentation=True,
+                                                                        cfg_options={"samples": samples, "model": model})
+    assert len(rn) == 15 and rcoxy["X"].shape[1] == 256 and dp[0].shape[1] == 512 and sp[0].shape[1] == 32
+    u = dropin.load("py_od_utils")
+    W, ORC, RR = (dropin.load(m) for m in ("FALKONWrapper_with_centers_selection_incore", "OnlineRegionClassifier_incore", "region_refiner"))
+    with redirect_stdout(io.StringIO()):
+        # RPN
+        st_rpn = u.computeFeatStatistics_torch(rp, rn, features_dim=256, pos_fraction=0.8)
+        m_rpn = u.falkon_models_to_cuda(ORC.OnlineRegionClassifier(W.FALKONWrapper(cfg_path=path, is_rpn=True), rp, rn, st_rpn,
+                                                                   cfg_path=path, is_rpn=True).trainRegionClassifier())
+        r_rpn = RR.RegionRefiner(path, is_rpn=True).trainRegionRefiner(u.normalize_COXY(rcoxy, st_rpn))
+        # detector
+        st_det = u.computeFeatStatistics_torch(dp, dn, features_dim=512, pos_fraction=0.8)
+        m_det = u.falkon_models_to_cuda(ORC.OnlineRegionClassifier(W.FALKONWrapper(cfg_path=path), dp, dn, st_det, cfg_path=path).trainRegionClassifier())
+        r_det = RR.RegionRefiner(path).trainRegionRefiner(dcoxy)
+        # segmentation: negatives wrapped as a one-batch list (run_experiment_online_rpn_ood_oos.py:254)
+        st_seg = u.computeFeatStatistics_torch(sp, [[x] for x in sn], features_dim=32, pos_fraction=0.8)
+        m_seg = u.falkon_models_to_cuda(ORC.OnlineRegionClassifier(W.FALKONWrapper(cfg_path=path, is_segmentation=True), sp, [[x] for x in sn],
+                                                                   st_seg, cfg_path=path, is_segmentation=True).trainRegionClassifier())
+    assert len(m_rpn) == 15 and len(r_rpn) == 15 and len(m_det) == C and len(m_seg) == C
+    # inject into the network: on-line RPN proposals -> detector head -> mask head
+    from odx.heads import OnlineBoxPredictor, OnlineMaskPredictor, OnlineRPNHead
+    model.online_rpn = OnlineRPNHead(m_rpn, r_rpn, st_rpn)
+    model.online_box = OnlineBoxPredictor(m_det, r_det, st_det)
+    model.online_mask = OnlineMaskPredictor(m_seg, st_seg)
+    img = samples[0][0].cuda()
+    with torch.no_grad():
+        c4 = model.backbone(img)
+        boxes, obj = model.proposals(c4, (img.shape[3], img.shape[2]))
+        maps = model.roi_head_maps(c4, boxes)
+        scores, deltas = model.online_box(maps)
+        pix = model.online_mask(model.mask_activation(maps[:5]))
+    assert boxes.shape[0] > 0 and tuple(scores.shape) == (boxes.shape[0], C + 1) and tuple(deltas.shape) == (boxes.shape[0], 4 * (C + 1))
+    assert tuple(pix.shape) == (5, C + 1, 14, 14) and torch.isfinite(pix).all() and torch.isfinite(scores).all()

@@ -113,3 +113,35 @@ def test_rpn_shuffle_mode_matches_reference_before_the_final_permutation():
         assert np.array_equal(torch.cat([g.view() for g in h._neg[c]]).numpy(), R["shuf_neg_%d" % c]), c
         assert np.array_equal(h._pos[c].view().numpy(), R["shuf_pos_%d" % c])
     assert np.array_equal(h._X.view().numpy(), R["shuf_X"])
+
+
+# ------------------------------------------------------------------ on-line segmentation harvesting (A13)
+def test_mask_harvest_matches_reference():
+    """Pixel sampling / bookkeeping against the reference's own ROIMaskHead.forward
+    (mask_head_getProposals.py) on the same activations, masks and RNG seed."""
+    from odx.harvest import MaskHarvester, project_masks_on_boxes
+    Mg = np.load(os.path.join(os.path.dirname(__file__), "golden", "mask_harvest_golden.npz"))
+    D, C, S = int(Mg["D"]), int(Mg["C"]), int(Mg["S"])
+    h = MaskHarvester(D, C, batch_size=60, sampling_factor=0.3, device="cpu")
+    torch.manual_seed(77)
+    for im in range(3):
+        act = torch.from_numpy(Mg["act_%d" % im])
+        mg = project_masks_on_boxes(torch.from_numpy(Mg["masks_%d" % im]), torch.from_numpy(Mg["boxes_%d" % im]), S)
+        assert mg.shape == (act.shape[0], S, S) and set(np.unique(mg.numpy())) <= {0.0, 1.0}
+        h.add_image(act, mg, Mg["labels_%d" % im].tolist())
+    negatives, positives = h.finalize()
+    for c in range(C):
+        assert np.allclose(positives[c].numpy(), Mg["pos_%d" % c], atol=1e-6), c
+        assert np.allclose(negatives[c].numpy(), Mg["neg_%d" % c], atol=1e-6), c
+    assert sum(len(p) for p in positives) > 0 and sum(len(n) for n in negatives) > 0
+
+
+def test_project_masks_on_boxes_basics():
+    from odx.harvest import project_masks_on_boxes
+    m = torch.zeros(2, 40, 40, dtype=torch.uint8)
+    m[0, 10:30, 10:30] = 1
+    m[1, :, :20] = 1
+    out = project_masks_on_boxes(m, torch.tensor([[10.0, 10, 30, 30], [0.0, 0, 40, 40]]), 14)
+    assert out.shape == (2, 14, 14) and bool((out[0] == 1).all())
+    assert bool((out[1][:, :6] == 1).all()) and bool((out[1][:, 8:] == 0).all())
+    assert project_masks_on_boxes(torch.zeros(0, 8, 8), torch.zeros(0, 4), 14).shape == (0,)

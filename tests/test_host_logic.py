@@ -381,6 +381,13 @@ def check_heads_against_reference(atol=2e-4):
         assert tuple(lg.shape) == H["rpn_par%d_logits" % par].shape
         assert np.abs(lg.cpu().numpy() - H["rpn_par%d_logits" % par]).max() < atol
         assert np.abs(bb.cpu().numpy() - H["rpn_par%d_bbox" % par]).max() < atol
+    from odx.heads import OnlineMaskPredictor
+    cls, _, stats = _gold_models(H, "mask")
+    for par in (1, 0):
+        got = OnlineMaskPredictor(cls, stats, parallel_inference=bool(par))(torch.from_numpy(H["mask_act"]))
+        assert tuple(got.shape) == H["mask_par%d_out" % par].shape
+        assert np.abs(got.cpu().numpy() - H["mask_par%d_out" % par]).max() < atol
+    cls, regs, stats = _gold_models(H, "rpn")
     # model hot-swap invalidates the cached concatenations
     head = OnlineRPNHead(cls, regs, stats)
     a, _ = head(t)
