@@ -561,13 +561,40 @@ extern "C" int odx_trtri_f64(const double* L, int64_t ldl, int64_t M, double* Li
 }
 
 // ---------------------------------------------------------------- FALKON preconditioner
-// workspace: Zd (M x ldzd) | zsq (M, padded) | W0 (M x ld) | W1 (M x ld) | W2 (M x ld) | Dinv
+// workspace: Zd (M x ldzd) | zsq (M, padded) | W0 | W1 | W2 | W3 (M x ld each) | DinvT | DinvA
+//
+// Two independent chains run side by side once L_T exists: the inverse of L_T (batched GEMMs that
+// fill the chip) and  T T'/M + lam I -> L_A  (a latency-bound chain of small kernels).  The first
+// goes to an internal side stream, forked and joined with events around it; everything stays
+// asynchronous with respect to the host.
 static int64_t precond_ld(int64_t M) { return round_up(M, 2); }
+
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  int device = -1;
+};
+
+static int side_stream(SideStream** out) {
+  static thread_local SideStream ss[16];
+  int dev = 0;
+  ODX_CHECK_HIP(hipGetDevice(&dev));
+  ODX_REQUIRE(dev >= 0 && dev < 16, "side_stream: device index out of range");
+  SideStream& s = ss[dev];
+  if (s.stream == nullptr) {
+    ODX_CHECK_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    ODX_CHECK_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
+    ODX_CHECK_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+    s.device = dev;
+  }
+  *out = &s;
+  return ODX_OK;
+}
 
 extern "C" int64_t odx_falkon_precond_workspace_bytes(int64_t M, int D) {
   if (M <= 0 || D <= 0) return 0;
   const int64_t ld = precond_ld(M), ldzd = round_up(D, 2);
-  int64_t dbl = M * ldzd + round_up(M, 2) + 3 * M * ld + ceil_div(M, POTRF_NB) * POTRF_NB * POTRF_NB;
+  int64_t dbl = M * ldzd + round_up(M, 2) + 4 * M * ld + 2 * ceil_div(M, POTRF_NB) * POTRF_NB * POTRF_NB;
   return dbl * (int64_t)sizeof(double);
 }
 
@@ -584,13 +611,19 @@ extern "C" int odx_falkon_precond_f64(const float* Z, int64_t ldz, int64_t M, in
     return ODX_ERR_WORKSPACE;
   }
   hipStream_t s = as_stream(stream);
+  SideStream* side = nullptr;
+  ODX_PROPAGATE(side_stream(&side));
+  hipStream_t s2 = side->stream;
   const int64_t wld = precond_ld(M), ldzd = round_up(D, 2);
+  const int64_t dsz = ceil_div(M, POTRF_NB) * POTRF_NB * POTRF_NB;
   double* Zd = static_cast<double*>(workspace);
   double* zsq = Zd + M * ldzd;
   double* W0 = zsq + round_up(M, 2);
   double* W1 = W0 + M * wld;
   double* W2 = W1 + M * wld;
-  double* Dinv = W2 + M * wld;
+  double* W3 = W2 + M * wld;
+  double* DinvT = W3 + M * wld;
+  double* DinvA = DinvT + dsz;
 
   ODX_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), s));
   ODX_CHECK_HIP(hipMemsetAsync(Zd, 0, (size_t)(M * ldzd) * sizeof(double), s));
@@ -598,11 +631,17 @@ extern "C" int odx_falkon_precond_f64(const float* Z, int64_t ldz, int64_t M, in
   // W0 = K_MM + eps*M*I (lower), then L_T in place
   ODX_CHECK_HIP(hipMemsetAsync(W0, 0, (size_t)(M * wld) * sizeof(double), s));
   ODX_PROPAGATE(gauss_kmm_f64(Zd, ldzd, M, D, sigma, eps * (double)M, W0, wld, zsq, s));
-  ODX_PROPAGATE(potrf_f64(W0, wld, M, Dinv, info, s));
-  // W1 = L_T' = T (upper)
+  ODX_PROPAGATE(potrf_f64(W0, wld, M, DinvT, info, s));
+  // fork: inverses of L_T on the side stream (scratch W3)
+  ODX_CHECK_HIP(hipEventRecord(side->fork, s));
+  ODX_CHECK_HIP(hipStreamWaitEvent(s2, side->fork, 0));
+  ODX_PROPAGATE(fill_f64(LTi, ld, M, M, 0.0, s2));
+  ODX_PROPAGATE(fill_f64(LTit, ld, M, M, 0.0, s2));
+  ODX_PROPAGATE(trtri_from_diag_f64(W0, wld, M, DinvT, LTi, LTit, ld, W3, s2));
+  ODX_CHECK_HIP(hipEventRecord(side->join, s2));
+  // main: W1 = L_T' = T (upper); W2 = T T' / M + lam I (lower tiles); L_A in place in W2
   ODX_CHECK_HIP(hipMemsetAsync(W1, 0, (size_t)(M * wld) * sizeof(double), s));
   ODX_PROPAGATE(transpose_f64(W0, wld, W1, wld, M, M, s));
-  // W2 = T T' / M + lam I (lower tiles)
   ODX_CHECK_HIP(hipMemsetAsync(W2, 0, (size_t)(M * wld) * sizeof(double), s));
   {
     GemmParams<double> g;
@@ -612,14 +651,11 @@ extern "C" int odx_falkon_precond_f64(const float* Z, int64_t ldz, int64_t M, in
     ODX_PROPAGATE(launch_gemm_f64(g, s));
   }
   ODX_PROPAGATE(add_diag_f64(W2, wld, M, lam, s));
-  // inverses of L_T (W1 is free now: use it as the trtri scratch)
-  ODX_PROPAGATE(fill_f64(LTi, ld, M, M, 0.0, s));
-  ODX_PROPAGATE(fill_f64(LTit, ld, M, M, 0.0, s));
-  ODX_PROPAGATE(trtri_from_diag_f64(W0, wld, M, Dinv, LTi, LTit, ld, W1, s));
-  // L_A in place in W2, then its inverses (W0 is free now)
-  ODX_PROPAGATE(potrf_f64(W2, wld, M, Dinv, info, s));
+  ODX_PROPAGATE(potrf_f64(W2, wld, M, DinvA, info, s));
+  // join, then the inverses of L_A (scratch W1: T is no longer needed)
+  ODX_CHECK_HIP(hipStreamWaitEvent(s, side->join, 0));
   ODX_PROPAGATE(fill_f64(LAi, ld, M, M, 0.0, s));
   ODX_PROPAGATE(fill_f64(LAit, ld, M, M, 0.0, s));
-  ODX_PROPAGATE(trtri_from_diag_f64(W2, wld, M, Dinv, LAi, LAit, ld, W0, s));
+  ODX_PROPAGATE(trtri_from_diag_f64(W2, wld, M, DinvA, LAi, LAit, ld, W1, s));
   return ODX_OK;
 }
