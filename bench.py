@@ -261,7 +261,7 @@ def main():
             "roofline": roof,
             "phases_ms_per_step_rank0": phases,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args)
         if args.check:
             out["check"] = check_against_oracle(be, F, last, X, row_ids, args, C - 1)
