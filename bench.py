@@ -176,28 +176,49 @@ def main():
         shard.allreduce(Z)
         return be.features(Z)
 
-    def run_classes(classes, timed):
-        """Classes are processed in batches of `world`: first every rank builds the preconditioner
-        of the class it owns in the batch (owner = position in the batch: all ranks busy at once,
-        nothing replicated), then the batch's classes are fitted one after the other with the
-        rows sharded over all ranks (owner-computes CG, odx.solver.falkon_fit) and scored."""
-        out = None
-        for b0 in range(0, len(classes), world):
-            batch = classes[b0:b0 + world]
-            Zs = [gather_centres(cidx[c]) for c in batch]
-            P = None
-            if rank < len(batch):
+    side = torch.cuda.Stream()
+    ld_p = (M + 1) // 2 * 2
+    pbuf = [torch.empty((4, M, ld_p), dtype=torch.float64, device=device) for _ in range(2)]   # current + next batch
+
+    def prepare(batch, slot, timed):
+        """Centres of the batch's classes (one all-reduce each, main stream) and, on the side stream,
+        the preconditioner of the class this rank owns in the batch (owner = position in the batch)."""
+        Zs = [gather_centres(cidx[c]) for c in batch]
+        P, ev = None, None
+        if rank < len(batch):
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
                 with ph["precond"] if timed else _null():
-                    P = be.precond(Zs[rank], args.sigma, args.lam, opt.pc_epsilon)
+                    P = be.precond(Zs[rank], args.sigma, args.lam, opt.pc_epsilon, out=pbuf[slot])
+                ev = torch.cuda.Event()
+                ev.record(side)
+        return Zs, P, ev
+
+    def run_classes(classes, timed):
+        """Classes are processed in batches of `world`.  Every rank builds the preconditioner of the
+        class it owns in a batch (nothing replicated) on a side stream, one batch ahead, so that the
+        f64 factorisations overlap the HBM-bound CG passes of the batch in flight; the batch's classes
+        are then fitted one after the other with the rows sharded over all ranks (owner-computes CG,
+        odx.solver.falkon_fit) and scored."""
+        out = None
+        batches = [classes[b0:b0 + world] for b0 in range(0, len(classes), world)]
+        nxt = prepare(batches[0], 0, timed)
+        for bi, batch in enumerate(batches):
+            Zs, P, ev = nxt
+            if bi + 1 < len(batches):
+                nxt = prepare(batches[bi + 1], (bi + 1) % 2, timed)
             for pos, c in enumerate(batch):
                 y = torch.where((row_ids % C) == c, 1.0, -1.0).to(torch.float64)
+                mine = pos == rank
                 alpha = odx.falkon_fit(be, F, y, Zs[pos], args.sigma, args.lam, args.maxiter, opt, n_total=N,
                                        knm_out=kbuf, phase=(lambda name: ph[name]) if timed else None,
-                                       precond=P if pos == rank else None, shard=shard, owner=pos)
+                                       precond=P if mine else None, shard=shard, owner=pos,
+                                       precond_ready=(lambda: torch.cuda.current_stream().wait_event(ev)) if mine else None)
                 with ph["mmv"] if timed else _null():
                     be.mmv(F, Zs[pos], args.sigma, alpha, None, out=scores[:, c:c + 1])
                 out = (alpha, Zs[pos])
-            del P
+            # the side stream must not start overwriting this slot (two batches ahead) before its last reader is done
+            side.wait_stream(torch.cuda.current_stream())
         return out
 
     def barrier():

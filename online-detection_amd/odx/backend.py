@@ -106,12 +106,13 @@ class HipBackend:
         return Features(buf[:, :F.D], F.sq.index_select(0, idx), F.D)
 
     # ------------------------------------------------------------------ FALKON pieces
-    def precond(self, Zf, sigma, lam, eps):
+    def precond(self, Zf, sigma, lam, eps, out=None):
+        """`out`: optional preallocated (4, M, ld) f64 tensor (e.g. owned by another stream)."""
         M, D = Zf.n, Zf.D
         ld = (M + 1) // 2 * 2
         P = Precond()
         P.M, P.ld = M, ld
-        mats = torch.empty((4, M, ld), dtype=torch.float64, device=self.device)
+        mats = out if out is not None else torch.empty((4, M, ld), dtype=torch.float64, device=self.device)
         P.LTi, P.LTit, P.LAi, P.LAit = mats[0], mats[1], mats[2], mats[3]
         P.info = torch.zeros(1, dtype=torch.int32, device=self.device)
         nbytes = self.lib.odx_falkon_precond_workspace_bytes(M, D)

@@ -33,7 +33,7 @@ class _NoPhase:
 
 
 def falkon_fit(be, F, y, Zf, sigma, lam, maxiter=20, opt=None, n_total=None, allreduce=None, knm_out=None,
-               return_knm=False, phase=None, precond=None, shard=None, owner=None):
+               return_knm=False, phase=None, precond=None, shard=None, owner=None, precond_ready=None):
     """Fit one binary FALKON problem.
 
     be        backend (odx.backend.HipBackend in the product)
@@ -54,6 +54,10 @@ def falkon_fit(be, F, y, Zf, sigma, lam, maxiter=20, opt=None, n_total=None, all
     phase     optional callable name -> context manager bracketing the launches of one kernel
               family ("precond", "knm", "ktk"); bench.py hangs HIP-event timers on it
     precond   an already computed preconditioner for (Zf, sigma, lam) to reuse
+    precond_ready
+              optional callable invoked once, right before the preconditioner is first applied
+              (after the K_nM build and the right-hand-side pass were issued): lets a preconditioner
+              that is still being computed on another stream overlap with them
     returns   alpha (M,) f64 device vector (on every rank)
     """
     opt = opt or SolverOptions()
@@ -97,6 +101,8 @@ def falkon_fit(be, F, y, Zf, sigma, lam, maxiter=20, opt=None, n_total=None, all
     X, R, Pv, AP = be.zeros(M), be.zeros(M), be.zeros(M), be.zeros(M)
     state = be.zeros(4)
     if owned:
+        if precond_ready is not None:
+            precond_ready()
         B = be.trmv(P, "LAi", be.trmv(P, "LTi", b0))   # A^-T T^-T b0
         be.cg_init(B, X, R, Pv, state)
     tol = opt.cg_tolerance ** 2
