@@ -770,7 +770,173 @@ def make_mask_harvest():
     print("mask_harvest_golden.npz:", len(out), "arrays")
 
 
+# --------------------------------------------------------------------------- f3: post-processing + VOC evaluation
+def ref_nms_keep(boxes, scores, thresh):
+    """maskrcnn_benchmark layers.nms (absent dependency, restated): greedy, +1 areas, suppress on iou > thresh."""
+    order = torch.argsort(scores, descending=True, stable=True)
+    b = boxes[order].double()
+    area = (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1)
+    dead = torch.zeros(len(b), dtype=torch.bool)
+    keep = []
+    for i in range(len(b)):
+        if dead[i]:
+            continue
+        keep.append(i)
+        w = (torch.min(b[i, 2], b[i + 1:, 2]) - torch.max(b[i, 0], b[i + 1:, 0]) + 1).clamp(min=0)
+        h = (torch.min(b[i, 3], b[i + 1:, 3]) - torch.max(b[i, 1], b[i + 1:, 1]) + 1).clamp(min=0)
+        iou = w * h / (area[i] + area[i + 1:] - w * h)
+        dead[i + 1:] |= iou > thresh
+    return order[torch.tensor(keep, dtype=torch.int64)]
+
+
+def ref_boxlist_nms(boxlist, thresh, max_proposals=-1, score_field="scores"):
+    return boxlist[ref_nms_keep(boxlist.bbox, boxlist.get_field(score_field), thresh)]
+
+
+class _ClipBoxList(FieldBoxList):
+    def clip_to_image(self, remove_empty=True):
+        self.bbox[:, 0].clamp_(min=0, max=self.size[0] - 1)
+        self.bbox[:, 1].clamp_(min=0, max=self.size[1] - 1)
+        self.bbox[:, 2].clamp_(min=0, max=self.size[0] - 1)
+        self.bbox[:, 3].clamp_(min=0, max=self.size[1] - 1)
+        return self
+
+    def resize(self, size):
+        r = FieldBoxList.resize(self, size)
+        return _ClipBoxList(r.bbox, r.size, r.mode)
+
+    def __getitem__(self, item):
+        b = _ClipBoxList(self.bbox[item], self.size, self.mode)
+        for k, v in self.extra_fields.items():
+            b.add_field(k, v[item])
+        return b
+
+
+class _PostProcessorBase:
+    """box_head.inference.PostProcessor: only what OnlineDetectionPostProcessor inherits."""
+
+    def __init__(self, score_thresh, nms, detections_per_img):
+        self.score_thresh, self.nms, self.detections_per_img = score_thresh, nms, detections_per_img
+
+    def prepare_boxlist(self, boxes, scores, image_shape):
+        b = _ClipBoxList(boxes.reshape(-1, 4), image_shape)
+        b.add_field("scores", scores.reshape(-1))
+        return b
+
+
+def make_postprocess():
+    utils = load_ref("src/py_od_utils.py", "py_od_utils")
+    src = _strip_imports(open(os.path.join(REF, "src/modules/accuracy-evaluator/OnlineDetectionPostProcessor.py")).read())
+    src = src.replace("from py_od_utils import decode_boxes_detector", "")
+
+    def cat(bl):
+        out = _ClipBoxList(torch.cat([b.bbox for b in bl]), bl[0].size, bl[0].mode)
+        for f in bl[0].fields():
+            out.add_field(f, torch.cat([b.get_field(f) for b in bl]))
+        return out
+    ns = {"PostProcessor": _PostProcessorBase, "BoxList": _ClipBoxList, "boxlist_nms": ref_boxlist_nms, "cat_boxlist": cat,
+          "decode_boxes_detector": utils.decode_boxes_detector, "__name__": "ref_postproc"}
+    exec(compile(src.replace("'cuda'", "'cpu'"), "OnlineDetectionPostProcessor.py", "exec"), ns)
+    PP = ns["OnlineDetectionPostProcessor"]
+    out = {}
+    g = torch.Generator().manual_seed(4242)
+    cases = [dict(R=60, C=4, thr=-2.0, nms=0.3, dpi=100, psz=(320, 240), isz=(320, 240)),
+             dict(R=300, C=6, thr=-2.0, nms=0.3, dpi=100, psz=(640, 480), isz=(320, 240)),
+             dict(R=80, C=3, thr=0.2, nms=0.5, dpi=12, psz=(200, 160), isz=(400, 320)),
+             dict(R=25, C=3, thr=5.0, nms=0.3, dpi=100, psz=(200, 160), isz=(200, 160))]
+    out["n_cases"] = np.int64(len(cases))
+    for ci, c in enumerate(cases):
+        R, C = c["R"], c["C"] + 1
+        ctr = torch.rand(6, 2, generator=g) * torch.tensor([c["psz"][0] * 0.7, c["psz"][1] * 0.7])
+        pick = torch.randint(0, 6, (R,), generator=g)
+        xy = (ctr[pick] + torch.randn(R, 2, generator=g) * 6).clamp(min=0)
+        wh = 30 + torch.rand(R, 2, generator=g) * 60
+        props = torch.cat([xy, torch.min(xy + wh, torch.tensor([c["psz"][0] - 1.0, c["psz"][1] - 1.0]))], 1)
+        scores = torch.randn(R, C, generator=g)
+        deltas = torch.randn(R, 4 * C, generator=g) * 0.15
+        pp = PP(c["thr"], c["nms"], c["dpi"])
+        res = pp.forward((scores.clone(), deltas.clone()), [_ClipBoxList(props.clone(), c["psz"])], C, c["isz"])
+        out["c%d_meta" % ci] = np.array([R, C, c["dpi"], c["psz"][0], c["psz"][1], c["isz"][0], c["isz"][1]], dtype=np.int64)
+        out["c%d_thr" % ci] = np.array([c["thr"], c["nms"]], dtype=np.float64)
+        out["c%d_props" % ci], out["c%d_scores" % ci], out["c%d_deltas" % ci] = props.numpy(), scores.numpy(), deltas.numpy()
+        out["c%d_boxes" % ci] = res.bbox.numpy()
+        out["c%d_out_scores" % ci] = res.get_field("scores").numpy()
+        out["c%d_labels" % ci] = res.get_field("labels").numpy()
+    np.savez_compressed(os.path.join(OUT, "postprocess_golden.npz"), **out)
+    print("postprocess_golden.npz:", len(out), "arrays", [out["c%d_labels" % i].shape[0] for i in range(len(cases))])
+
+
+def make_eval():
+    base = "src/modules/feature-extractor/mrcnn_modified/"
+    src = open(os.path.join(REF, base, "data/datasets/evaluation/icubworld/icw_eval.py")).read()
+    keep = []
+    for line in src.splitlines():
+        if line.strip().startswith(("from maskrcnn_benchmark", "from mrcnn_modified", "from py_od_utils", "import cv2")):
+            continue
+        keep.append(line)
+    ns = {"BoxList": FieldBoxList, "boxlist_iou": lambda a, b: ref_boxlist_iou(_t(a), _t(b)), "__name__": "ref_icw_eval"}
+
+    def _t(b):
+        b.bbox = torch.as_tensor(b.bbox)
+        return b
+    with redirect_stdout(io.StringIO()):
+        exec(compile("\n".join(keep).replace("'cuda'", "'cpu'"), "icw_eval.py", "exec"), ns)
+    rng = np.random.RandomState(77)
+    out = {}
+    NIMG, NCLS = 12, 5
+    preds, gts = [], []
+    for im in range(NIMG):
+        G = rng.randint(0, 4)
+        gxy = rng.rand(G, 2) * 200
+        gb = np.concatenate([gxy, gxy + 30 + rng.rand(G, 2) * 80], 1).astype(np.float32)
+        gl = rng.randint(1, NCLS, size=G)
+        gd = rng.rand(G) < 0.2
+        P = rng.randint(0, 9)
+        rows = []
+        for _ in range(P):
+            if G and rng.rand() < 0.7:
+                k = rng.randint(G)
+                rows.append((gb[k] + rng.randn(4) * rng.choice([2.0, 12.0]), gl[k] if rng.rand() < 0.8 else rng.randint(1, NCLS)))
+            else:
+                xy = rng.rand(2) * 200
+                rows.append((np.concatenate([xy, xy + 30 + rng.rand(2) * 80]), rng.randint(1, NCLS + 1)))
+        pb = np.array([r[0] for r in rows], dtype=np.float32).reshape(-1, 4)
+        pl = np.array([r[1] for r in rows], dtype=np.int64)
+        ps = rng.randn(P).astype(np.float32)
+        if P > 3:
+            ps[1] = ps[0]          # tie
+        for k, v in (("pb", pb), ("pl", pl), ("ps", ps), ("gb", gb), ("gl", gl.astype(np.int64)), ("gd", gd)):
+            out["%s_%d" % (k, im)] = v
+        p = FieldBoxList(torch.from_numpy(pb), (320, 240))
+        p.add_field("labels", torch.from_numpy(pl))
+        p.add_field("scores", torch.from_numpy(ps))
+        q = FieldBoxList(torch.from_numpy(gb), (320, 240))
+        q.add_field("labels", torch.from_numpy(gl.astype(np.int64)))
+        q.add_field("difficult", torch.from_numpy(gd))
+        preds.append(p)
+        gts.append(q)
+    out["NIMG"] = np.int64(NIMG)
+    with np.errstate(all="ignore"):
+        for thr in (0.5, 0.7):
+            for m07 in (True, False):
+                r = ns["eval_detection_icw"](preds, gts, iou_thresh=thr, use_07_metric=m07)
+                tag = "iou%02d_%s" % (int(thr * 100), "voc07" if m07 else "area")
+                out[tag + "_ap"], out[tag + "_map"] = np.asarray(r["ap"], dtype=np.float64), np.float64(r["map"])
+        prec, rec = ns["calc_detection_icw_prec_rec"](gts, preds, 0.5)
+    for l in range(len(prec)):
+        out["prec_%d" % l] = np.array([]) if prec[l] is None else np.asarray(prec[l], dtype=np.float64)
+        out["rec_%d" % l] = np.array([]) if rec[l] is None else np.asarray(rec[l], dtype=np.float64)
+        out["has_%d" % l] = np.array([prec[l] is not None, rec[l] is not None])
+    out["n_cls"] = np.int64(len(prec))
+    np.savez_compressed(os.path.join(OUT, "eval_golden.npz"), **out)
+    print("eval_golden.npz:", len(out), "arrays; mAP@0.5 voc07 =", out["iou50_voc07_map"])
+
+
 if __name__ == "__main__":
+    if "--only-postprocess" in sys.argv:
+        make_postprocess()
+        make_eval()
+        sys.exit(0)
     if "--only-mask-harvest" in sys.argv:
         make_mask_harvest()
         sys.exit(0)
@@ -791,3 +957,5 @@ if __name__ == "__main__":
     make_harvest()
     make_rpn_harvest()
     make_mask_harvest()
+    make_postprocess()
+    make_eval()

@@ -1,0 +1,110 @@
+"""Row f3: detection post-processing and VOC-style evaluation against vectors produced by the reference's own
+OnlineDetectionPostProcessor / icw_eval code (tests/golden/make_golden.py --only-postprocess)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import odx
+from odx.postprocess import average_precision, average_recall, detection_prec_rec, eval_detection, postprocess_detections
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def check_postprocess_cases(device):
+    g = np.load(os.path.join(GOLD, "postprocess_golden.npz"))
+    for ci in range(int(g["n_cases"])):
+        R, C, dpi, pw, ph, iw, ih = (int(v) for v in g["c%d_meta" % ci])
+        thr, nms = (float(v) for v in g["c%d_thr" % ci])
+        res = postprocess_detections(torch.from_numpy(g["c%d_scores" % ci]).to(device), torch.from_numpy(g["c%d_deltas" % ci]).to(device),
+                                     torch.from_numpy(g["c%d_props" % ci]).to(device), (iw, ih), score_thresh=thr, nms_thresh=nms,
+                                     detections_per_img=dpi, proposals_size=(pw, ph))
+        assert res["labels"].cpu().numpy().tolist() == g["c%d_labels" % ci].tolist(), ci
+        np.testing.assert_array_equal(res["scores"].cpu().numpy(), g["c%d_out_scores" % ci])
+        np.testing.assert_allclose(res["boxes"].cpu().numpy().reshape(-1, 4), g["c%d_boxes" % ci].reshape(-1, 4), rtol=0, atol=1e-4)
+
+
+def test_postprocess_matches_reference_on_cpu_with_oracle_backend():
+    from tests.oracle_backend import OracleBackend
+    odx.set_backend(OracleBackend(np.float64))
+    try:
+        check_postprocess_cases("cpu")
+    finally:
+        odx.set_backend(None)
+
+
+@pytest.mark.gpu
+def test_postprocess_matches_reference_on_gpu():
+    odx.set_backend(None)
+    check_postprocess_cases("cuda")
+
+
+def _load_eval():
+    g = np.load(os.path.join(GOLD, "eval_golden.npz"))
+    preds, gts = [], []
+    for im in range(int(g["NIMG"])):
+        preds.append({"boxes": g["pb_%d" % im], "labels": g["pl_%d" % im], "scores": g["ps_%d" % im]})
+        gts.append({"boxes": g["gb_%d" % im], "labels": g["gl_%d" % im], "difficult": g["gd_%d" % im]})
+    return g, preds, gts
+
+
+def test_precision_recall_match_reference():
+    g, preds, gts = _load_eval()
+    prec, rec = detection_prec_rec(preds, gts, 0.5)
+    assert len(prec) == int(g["n_cls"])
+    for l in range(len(prec)):
+        hp, hr = g["has_%d" % l]
+        assert (prec[l] is not None) == bool(hp) and (rec[l] is not None) == bool(hr)
+        if hp:
+            np.testing.assert_array_equal(prec[l], g["prec_%d" % l])
+        if hr:
+            np.testing.assert_array_equal(rec[l], g["rec_%d" % l])
+
+
+@pytest.mark.parametrize("thr", [0.5, 0.7])
+@pytest.mark.parametrize("m07", [True, False])
+def test_ap_matches_reference(thr, m07):
+    g, preds, gts = _load_eval()
+    r = eval_detection(preds, gts, iou_thresh=thr, use_07_metric=m07)
+    tag = "iou%02d_%s" % (int(thr * 100), "voc07" if m07 else "area")
+    np.testing.assert_allclose(r["ap"], g[tag + "_ap"], rtol=0, atol=1e-12, equal_nan=True)
+    assert abs(r["map"] - float(g[tag + "_map"])) < 1e-12
+
+
+def test_eval_edge_cases():
+    assert detection_prec_rec([], []) == ([None], [None])
+    assert np.isnan(average_precision([None], [None])).all()
+    # one perfect detection, one duplicate -> AP 1.0 under both metrics (duplicate ranks below)
+    gt = [{"boxes": np.array([[10, 10, 50, 50]], np.float32), "labels": np.array([1])}]
+    pr = [{"boxes": np.array([[10, 10, 50, 50], [11, 11, 50, 50]], np.float32), "labels": np.array([1, 1]), "scores": np.array([0.9, 0.8], np.float32)}]
+    r = eval_detection(pr, gt, use_07_metric=True)
+    assert r["ap"][1] == pytest.approx(1.0) and np.isnan(r["ap"][0])
+    assert eval_detection(pr, gt, use_07_metric=False)["ap"][1] == pytest.approx(1.0)
+    assert average_recall([0.75, 0.4, 1.0]) == pytest.approx(2 * (0.25 + 0 + 0.5) / 3)
+    assert average_recall([]) == 0.0
+
+
+def test_dropin_class_contract():
+    """The reference-named class, imported the way the reference imports it, gives the golden result."""
+    import importlib.util
+    from odx.boxlist import BoxList
+    from tests.oracle_backend import OracleBackend
+    path = os.path.join(os.path.dirname(__file__), os.pardir, "online-detection_amd", "src", "modules", "accuracy-evaluator",
+                        "OnlineDetectionPostProcessor.py")
+    spec = importlib.util.spec_from_file_location("OnlineDetectionPostProcessor", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = np.load(os.path.join(GOLD, "postprocess_golden.npz"))
+    R, C, dpi, pw, ph, iw, ih = (int(v) for v in g["c2_meta"])
+    thr, nms = (float(v) for v in g["c2_thr"])
+    odx.set_backend(OracleBackend(np.float64))
+    try:
+        pp = mod.OnlineDetectionPostProcessor(score_thresh=thr, nms=nms, detections_per_img=dpi)
+        out = pp((torch.from_numpy(g["c2_scores"]), torch.from_numpy(g["c2_deltas"])), [BoxList(torch.from_numpy(g["c2_props"]), (pw, ph))],
+                 C, (iw, ih))
+    finally:
+        odx.set_backend(None)
+    assert out.size == (iw, ih) and len(out) == dpi
+    assert out.get_field("labels").tolist() == g["c2_labels"].tolist()
+    np.testing.assert_allclose(out.bbox.numpy(), g["c2_boxes"], atol=1e-4)
