@@ -65,6 +65,26 @@ int odx_gauss_mmv_f32(const float* X, int64_t ldx, const float* xsq, int64_t n,
                       const double* V, int64_t ldv, const int32_t* ranges, int T,
                       float* out, int64_t ldo, odx_stream_t stream);
 
+/* ---------------------------------------------------------------- A3 / A5 on the f16 matrix cores
+ * The same two operations (same reference call sites as odx_gauss_knm_f32 / odx_gauss_mmv_f32 above) with
+ * the X Z' contraction on v_mfma_f32_32x32x16_f16 at f32 accuracy: every f32 value is split once into two
+ * f16 terms (hi + lo, after a power-of-two scale) and  x.z = hi.hi + hi.lo + lo.hi  accumulates in f32.
+ *
+ * odx_split_f16 packs an f32 matrix for those kernels.  P: n rows of ldp 4-byte units, ldp % 4 == 0,
+ * ldp >= roundup(D, 64); k-tile t (features 64 t .. 64 t + 63) of a row is 256 contiguous bytes, 64 f16 "hi"
+ * then 64 f16 "lo"; features past D are zero.  meta: 2 DEVICE floats; on return meta[0] = the scale that was
+ * applied (2^(13 - e) for max |x| = 1.m x 2^e), meta[1] = bits of max |x| (scratch).  Rows gathered from P
+ * keep the same meta.                                                                              */
+int odx_split_f16(const float* X, int64_t ldx, int64_t n, int D, void* P, int64_t ldp, float* meta,
+                  odx_stream_t stream);
+int odx_gauss_knm_h2(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
+                     const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int D,
+                     double sigma, float* K, int64_t ldk, odx_stream_t stream);
+int odx_gauss_mmv_h2(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
+                     const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int D, double sigma,
+                     const double* V, int64_t ldv, const int32_t* ranges, int T,
+                     float* out, int64_t ldo, odx_stream_t stream);
+
 /* ---------------------------------------------------------------- A4: CG pass on stored K
  * falkon's incore_fdmmv on the stored K_nM (selected by store_kernel_d_threshold=250,
  * FALKONWrapper_with_centers_selection_incore.py:56):  out = K' (K v + w)  for one shard

@@ -1,0 +1,394 @@
+// Gaussian-kernel blocks with the -2 X Z' contraction on the f16 matrix cores (gfx950), at f32 accuracy.
+//
+// Every f32 operand value is split once into two f16 terms, x * s = hi + lo (s a power of two that puts
+// max |x| into [2^13, 2^14)): hi carries the top 11 significant bits, lo the next 11.  Then
+//     x . z  =  (hi_x . hi_z  +  hi_x . lo_z  +  lo_x . hi_z) / (s_x s_z)   (+ a lo.lo term of relative size 2^-22)
+// Each f16 x f16 product is exact in f32 and v_mfma_f32_32x32x16_f16 accumulates in f32, so the contraction
+// keeps ~22 bits per factor — tools/precision_study.py: the fitted alpha moves exactly as with the all-f32
+// v_mfma_f32_32x32x2_f32 chain — at 3 MFMAs of the f16 rate (16 x the f32 MFMA rate) per f32 MFMA replaced.
+//
+// Packed operand ("h2") layout, produced by odx_split_f16: a row is ldp 4-byte units; k-tile t of a row
+// (64 consecutive features) is 256 contiguous bytes: 64 f16 hi, then 64 f16 lo.  Features past D are zero.
+// Tile: 256 threads (2 x 2 waves), 128 x 128 outputs, a k-tile = 128 rows x 256 B per operand through LDS rows of
+// 272 B (17 x 16 B, odd => the 16-lane groups of ds_read_b128 hit 16 distinct 16-B slots).
+#include "gemm_core.h"
+#include "odx_internal.h"
+
+namespace odx {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int H2_KT = 64;                   // features per k-tile
+constexpr int H2_ROW = 272;                 // LDS bytes per tile row
+constexpr int H2_LDS_BYTES = (GEMM_BM + GEMM_BN) * H2_ROW;  // 69,632 B -> two workgroups per CU
+
+// ---------------------------------------------------------------- split
+__global__ __launch_bounds__(256) void absmax_f32_kernel(const float* __restrict__ X, int64_t ldx, int64_t n, int D,
+                                                         unsigned int* __restrict__ out) {
+  unsigned int m = 0;
+  const int lane = threadIdx.x & 63;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * 4) {
+    const float* x = X + r * ldx;
+    for (int c = lane * 4; c < D; c += 256) {     // ldx % 4 == 0 and X 16-byte aligned (checked by the caller)
+      const u32x4 v = *reinterpret_cast<const u32x4*>(x + c);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (c + q < D) m = max(m, v[q] & 0x7fffffffu);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, off));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// scale = 2^(13 - e) for absmax = 1.m x 2^e  (1 for an all-zero, denormal or non-finite matrix)
+__device__ __forceinline__ float h2_scale_from_absmax(unsigned int bits) {
+  const int ef = (int)((bits >> 23) & 0xffu);
+  if (ef == 0 || ef == 255) return 1.f;
+  int se = 127 + 13 - (ef - 127);
+  se = se < 1 ? 1 : (se > 254 ? 254 : se);
+  return __uint_as_float((unsigned int)se << 23);
+}
+
+__global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ X, int64_t ldx, int64_t n, int D,
+                                                        uint32_t* __restrict__ P, int64_t ldp, float* __restrict__ meta) {
+  const float s = h2_scale_from_absmax(__float_as_uint(meta[1]));
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) meta[0] = s;
+  const int groups = (int)((D + H2_KT - 1) / H2_KT) * 8;  // 8-feature groups per row, zero padded to whole k-tiles
+  const int64_t row = blockIdx.y;
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= groups) return;
+  const float* x = X + row * ldx + (int64_t)g * 8;
+  float v[8];
+  if (g * 8 + 8 <= D) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x), b = *reinterpret_cast<const f32x4*>(x + 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[q] = a[q]; v[4 + q] = b[q]; }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (g * 8 + q < D) ? x[q] : 0.f;
+  }
+  f16x8 hi, lo;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float t = v[q] * s;
+    const _Float16 h = (_Float16)t;
+    hi[q] = h;
+    lo[q] = (_Float16)(t - (float)h);
+  }
+  uint32_t* dst = P + row * ldp + (int64_t)(g >> 3) * 64 + (g & 7) * 4;   // 4-byte units
+  *reinterpret_cast<f16x8*>(dst) = hi;
+  *reinterpret_cast<f16x8*>(dst + 32) = lo;
+}
+
+// ---------------------------------------------------------------- tile mainloop
+struct H2Stage {
+  u32x4 a[8], b[8];
+};
+
+// Rows past the operand's end are read as its last row (never branch around a load: the eight loads of an operand
+// issue back to back); whatever they produce is masked in the epilogues.  voff: per-thread 32-bit offsets (4-byte
+// units) from the uniform tile base, so the loads take the scalar-base + vector-offset form.
+__device__ __forceinline__ void h2_row_offsets(uint32_t (&voff)[8], int64_t ld, int64_t row0, int64_t nrows) {
+  const int tid = threadIdx.x;
+  const int last = (int)(nrows - 1 - row0);          // >= 0: the tile starts inside the operand
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int r = (tid >> 4) + 16 * p;
+    voff[p] = (uint32_t)(r < last ? r : last) * (uint32_t)ld + (uint32_t)(tid & 15) * 4u;
+  }
+}
+
+__device__ __forceinline__ void h2_load_operand(u32x4 (&r)[8], const uint32_t* __restrict__ tile, const uint32_t (&voff)[8]) {
+#pragma unroll
+  for (int p = 0; p < 8; ++p) r[p] = *reinterpret_cast<const u32x4*>(tile + voff[p]);
+}
+
+__device__ __forceinline__ void h2_store_operand(const u32x4 (&r)[8], char* lds) {
+  const int tid = threadIdx.x;
+  char* d = lds + (tid >> 4) * H2_ROW + (tid & 15) * 16;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) *reinterpret_cast<u32x4*>(d + 16 * p * H2_ROW) = r[p];
+}
+
+__device__ __forceinline__ void h2_compute_ktile(f32x16 (&acc)[2][2], const char* ldsA, const char* ldsB, int wr, int wc,
+                                                 int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const char* pa = ldsA + (wr * 64 + r) * H2_ROW + h * 16;
+  const char* pb = ldsB + (wc * 64 + r) * H2_ROW + h * 16;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      ah[t] = *reinterpret_cast<const f16x8*>(pa + t * 32 * H2_ROW + ks * 32);
+      al[t] = *reinterpret_cast<const f16x8*>(pa + t * 32 * H2_ROW + ks * 32 + 128);
+      bh[t] = *reinterpret_cast<const f16x8*>(pb + t * 32 * H2_ROW + ks * 32);
+      bl[t] = *reinterpret_cast<const f16x8*>(pb + t * 32 * H2_ROW + ks * 32 + 128);
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+      }
+  }
+}
+
+// acc += (scaled) A[i0.., :] B[j0.., :]' over `ktiles` k-tiles
+__device__ __forceinline__ void h2_mainloop(f32x16 (&acc)[2][2], const uint32_t* __restrict__ A, int64_t lda, int64_t m,
+                                            const uint32_t* __restrict__ B, int64_t ldb, int64_t n, int64_t i0, int64_t j0,
+                                            int ktiles, char* lds) {
+  char* ldsA = lds;
+  char* ldsB = lds + GEMM_BM * H2_ROW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  uint32_t offa[8], offb[8];
+  h2_row_offsets(offa, lda, i0, m);
+  h2_row_offsets(offb, ldb, j0, n);
+  const uint32_t* ta = A + i0 * lda;
+  const uint32_t* tb = B + j0 * ldb;
+  H2Stage st;
+  h2_load_operand(st.a, ta, offa);
+  h2_load_operand(st.b, tb, offb);
+  for (int kt = 0; kt < ktiles; ++kt) {
+    __syncthreads();
+    h2_store_operand(st.a, ldsA);
+    h2_store_operand(st.b, ldsB);
+    __syncthreads();
+    if (kt + 1 < ktiles) {
+      ta += H2_KT;
+      tb += H2_KT;
+      h2_load_operand(st.a, ta, offa);
+      h2_load_operand(st.b, tb, offb);
+    }
+    h2_compute_ktile(acc, ldsA, ldsB, wr, wc, lane);
+  }
+}
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+// ---------------------------------------------------------------- K_nM
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gauss_knm_h2_kernel(
+    const uint32_t* __restrict__ PX, int64_t ldpx, const float* __restrict__ metax, const float* __restrict__ xsq, int64_t n,
+    const uint32_t* __restrict__ PZ, int64_t ldpz, const float* __restrict__ metaz, const float* __restrict__ zsq, int64_t M,
+    int ktiles, float gamma_log2e, float* __restrict__ K, int64_t ldk) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int64_t GR = 8;   // banded tile order inside an XCD's run of tiles (see gauss_knm_f32_kernel)
+  const int64_t tiles_n = (M + GEMM_BN - 1) / GEMM_BN;
+  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t band = wg / (GR * tiles_n), within = wg % (GR * tiles_n);
+  const int64_t i0 = (band * GR + within % GR) * GEMM_BM, j0 = (within / GR) * GEMM_BN;
+  if (i0 >= n) return;
+
+  __shared__ __attribute__((aligned(16))) float xs_s[GEMM_BM];
+  if (threadIdx.x < GEMM_BM) xs_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] : 0.f;
+
+  f32x16 acc[2][2];
+  gemm_zero_acc<float>(acc);
+  h2_mainloop(acc, PX, ldpx, n, PZ, ldpz, M, i0, j0, ktiles, lds);
+
+  const float m2 = -2.f / (metax[0] * metaz[0]);   // powers of two: exact
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  if (i0 + GEMM_BM <= n && j0 + GEMM_BN <= M) {
+    // interior tile: no masks; 32-bit offsets from the uniform tile corner
+    float* tile = K + i0 * ldk + j0;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int cl = wc * 64 + tn * 32 + (lane & 31);
+      const float zs = zsq[j0 + cl];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int rl = wr * 64 + tm * 32 + 8 * g + 4 * (lane >> 5);
+          const f32x4 xs = *reinterpret_cast<const f32x4*>(&xs_s[rl]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float d2 = fmaf(m2, acc[tm][tn][4 * g + q], xs[q]) + zs;
+            d2 = fmaxf(d2, 0.f);
+            tile[(uint32_t)(rl + q) * (uint32_t)ldk + (uint32_t)cl] = __builtin_amdgcn_exp2f(d2 * gamma_log2e);
+          }
+        }
+    }
+    return;
+  }
+  const int64_t mpad = (M + 3) & ~int64_t(3);
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int64_t col = j0 + wc * 64 + gemm_acc_col<float>(tn, lane);
+    const float zs = col < M ? zsq[col] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = wr * 64 + gemm_acc_row<float>(tm, r, lane);
+        const int64_t row = i0 + rl;
+        if (row < n && col < mpad) {
+          float v = 0.f;
+          if (col < M) {
+            float d2 = fmaf(m2, acc[tm][tn][r], xs_s[rl]) + zs;
+            d2 = fmaxf(d2, 0.f);
+            v = __builtin_amdgcn_exp2f(d2 * gamma_log2e);
+          }
+          K[row * ldk + col] = v;
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------- fused scoring
+// out[:, c] = K(X, Z[range c]) V[range c, c]; per-lane f64 partial sums over all column tiles, one cross-lane
+// reduction at the end.
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gauss_mmv_h2_kernel(
+    const uint32_t* __restrict__ PX, int64_t ldpx, const float* __restrict__ metax, const float* __restrict__ xsq, int64_t n,
+    const uint32_t* __restrict__ PZ, int64_t ldpz, const float* __restrict__ metaz, const float* __restrict__ zsq, int ktiles,
+    float gamma_log2e, const double* __restrict__ V, int64_t ldv, const int32_t* __restrict__ ranges,
+    float* __restrict__ out, int64_t ldo) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  __shared__ double red[2][2][64];
+  __shared__ float xs_s[GEMM_BM];
+  const int c = blockIdx.y;
+  const int64_t s0 = ranges[2 * c], s1 = ranges[2 * c + 1];
+  const int64_t i0 = (int64_t)blockIdx.x * GEMM_BM;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const float m2 = -2.f / (metax[0] * metaz[0]);
+
+  if (threadIdx.x < GEMM_BM) xs_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] : 0.f;
+  // Lane l ends every tile with the f64 sum, over the tile's 64 columns of this wave, of row slot (l & 31) of its lane
+  // half (slot = 16 tm + r): a reduce-scatter butterfly over the 32 lanes of the half (31 exchanges per tile instead of
+  // 32 x 5 for row-by-row reductions, and one running total per lane instead of 32).
+  double tot = 0.0;
+  const bool b16 = lane & 16, b8 = lane & 8, b4 = lane & 4, b2 = lane & 2, b1 = lane & 1;
+
+  for (int64_t j0 = s0; j0 < s1; j0 += GEMM_BN) {
+    f32x16 acc[2][2];
+    gemm_zero_acc<float>(acc);
+    h2_mainloop(acc, PX, ldpx, n, PZ + j0 * ldpz, ldpz, s1 - j0, i0, 0, ktiles, lds);
+    float zs[2];
+    double al[2];
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      const int64_t col = j0 + wc * 64 + gemm_acc_col<float>(tn, lane);
+      const bool cv = col < s1;
+      zs[tn] = cv ? zsq[col] : 0.f;
+      al[tn] = cv ? V[col * ldv + c] : 0.0;     // weight 0 removes the columns past the range
+    }
+    double w16[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double v[2];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        const float xs = xs_s[wr * 64 + gemm_acc_row<float>(tm, r, lane)];
+        v[tm] = 0.0;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          float d2 = fmaf(m2, acc[tm][tn][r], xs) + zs[tn];
+          d2 = fmaxf(d2, 0.f);
+          v[tm] = fma((double)__builtin_amdgcn_exp2f(d2 * gamma_log2e), al[tn], v[tm]);
+        }
+      }
+      w16[r] = (b16 ? v[1] : v[0]) + __shfl_xor(b16 ? v[0] : v[1], 16);
+    }
+    double w8[8], w4[4], w2[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w8[j] = (b8 ? w16[j + 8] : w16[j]) + __shfl_xor(b8 ? w16[j] : w16[j + 8], 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w4[j] = (b4 ? w8[j + 4] : w8[j]) + __shfl_xor(b4 ? w8[j] : w8[j + 4], 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) w2[j] = (b2 ? w4[j + 2] : w4[j]) + __shfl_xor(b2 ? w4[j] : w4[j + 2], 2);
+    tot += (b1 ? w2[1] : w2[0]) + __shfl_xor(b1 ? w2[0] : w2[1], 1);
+  }
+  {
+    const int slot = lane & 31;
+    red[wr][wc][gemm_acc_row<float>(slot >> 4, slot & 15, lane)] = tot;
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int w = threadIdx.x >> 6, rr = threadIdx.x & 63;
+    const int64_t row = i0 + w * 64 + rr;
+    if (row < n) out[row * ldo + c] = (float)(red[w][0][rr] + red[w][1][rr]);
+  }
+}
+
+static int h2_enable_lds(const void* fn) {   // > 64 KiB of LDS per workgroup has to be asked for
+  ODX_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES));
+  return ODX_OK;
+}
+
+}  // namespace odx
+
+using namespace odx;
+
+extern "C" int odx_split_f16(const float* X, int64_t ldx, int64_t n, int D, void* P, int64_t ldp, float* meta,
+                             odx_stream_t stream) {
+  ODX_REQUIRE(meta, "odx_split_f16: meta is null");
+  hipStream_t s = as_stream(stream);
+  ODX_CHECK_HIP(hipMemsetAsync(meta, 0, 2 * sizeof(float), s));
+  if (n <= 0) {
+    // scale of an empty matrix: 1
+    hipLaunchKernelGGL(split_f16_kernel, dim3(1, 1), dim3(256), 0, s, X, ldx, 0, 0, (uint32_t*)P, ldp, meta);
+    ODX_CHECK_LAUNCH("odx_split_f16");
+    return ODX_OK;
+  }
+  ODX_REQUIRE(X && P && D > 0 && ldx >= D && ldx % 4 == 0 && aligned16(X), "odx_split_f16: X must be 16-byte aligned with ldx %% 4 == 0 and ldx >= D");
+  ODX_REQUIRE(ldp >= round_up(D, H2_KT) && ldp % 4 == 0 && aligned16(P), "odx_split_f16: P must be 16-byte aligned, ldp %% 4 == 0, ldp >= roundup(D, 64)");
+  ODX_REQUIRE(n < 65536ll * 32768, "odx_split_f16: too many rows");
+  const unsigned blocks = (unsigned)(ceil_div(n, 4) > 4096 ? 4096 : ceil_div(n, 4));
+  hipLaunchKernelGGL(absmax_f32_kernel, dim3(blocks), dim3(256), 0, s, X, ldx, n, D, reinterpret_cast<unsigned int*>(meta + 1));
+  ODX_CHECK_LAUNCH("odx_split_f16(absmax)");
+  const int groups = (int)ceil_div(D, H2_KT) * 8;
+  // rows ride on grid.y (<= 65535 per launch)
+  for (int64_t r0 = 0; r0 < n; r0 += 65535) {
+    const int64_t nr = n - r0 < 65535 ? n - r0 : 65535;
+    hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)ceil_div(groups, 256), (unsigned)nr), dim3(256), 0, s, X + r0 * ldx,
+                       ldx, nr, D, (uint32_t*)P + r0 * ldp, ldp, meta);
+    ODX_CHECK_LAUNCH("odx_split_f16");
+  }
+  return ODX_OK;
+}
+
+extern "C" int odx_gauss_knm_h2(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
+                                const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int D,
+                                double sigma, float* K, int64_t ldk, odx_stream_t stream) {
+  if (n <= 0 || M <= 0) return ODX_OK;
+  ODX_REQUIRE(PX && PZ && metax && metaz && xsq && zsq && K && D > 0 && sigma > 0, "odx_gauss_knm_h2: bad argument");
+  const int64_t dp = round_up(D, H2_KT);
+  ODX_REQUIRE(ldpx % 4 == 0 && ldpz % 4 == 0 && ldpx >= dp && ldpz >= dp && aligned16(PX) && aligned16(PZ),
+              "odx_gauss_knm_h2: packed operands must be 16-byte aligned with ld %% 4 == 0 and ld >= roundup(D, 64)");
+  ODX_REQUIRE(ldk % 4 == 0 && ldk >= round_up(M, 4) && aligned16(K), "odx_gauss_knm_h2: K must be 16-byte aligned, ldk %% 4 == 0, ldk >= roundup(M, 4)");
+  const int64_t tiles = round_up(ceil_div(n, GEMM_BM), 8) * ceil_div(M, GEMM_BN);
+  ODX_REQUIRE(tiles < (1ll << 31), "odx_gauss_knm_h2: grid too large");
+  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2_kernel)));
+  hipLaunchKernelGGL(gauss_knm_h2_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), H2_LDS_BYTES, as_stream(stream),
+                     (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq, M, (int)(dp / H2_KT),
+                     (float)(-0.5 / (sigma * sigma)) * LOG2E, K, ldk);
+  ODX_CHECK_LAUNCH("odx_gauss_knm_h2");
+  return ODX_OK;
+}
+
+extern "C" int odx_gauss_mmv_h2(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
+                                const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int D, double sigma,
+                                const double* V, int64_t ldv, const int32_t* ranges, int C, float* out, int64_t ldo,
+                                odx_stream_t stream) {
+  if (n <= 0 || C <= 0) return ODX_OK;
+  ODX_REQUIRE(PX && PZ && metax && metaz && xsq && zsq && V && ranges && out && D > 0 && sigma > 0 && ldv >= C,
+              "odx_gauss_mmv_h2: bad argument");
+  const int64_t dp = round_up(D, H2_KT);
+  ODX_REQUIRE(ldpx % 4 == 0 && ldpz % 4 == 0 && ldpx >= dp && ldpz >= dp && aligned16(PX) && aligned16(PZ),
+              "odx_gauss_mmv_h2: packed operands must be 16-byte aligned with ld %% 4 == 0 and ld >= roundup(D, 64)");
+  ODX_REQUIRE(ldo >= C && C < 65536, "odx_gauss_mmv_h2: ldo < C or too many classes");
+  const int64_t rb = ceil_div(n, GEMM_BM);
+  ODX_REQUIRE(rb < (1ll << 31), "odx_gauss_mmv_h2: grid too large");
+  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_mmv_h2_kernel)));
+  hipLaunchKernelGGL(gauss_mmv_h2_kernel, dim3((unsigned)rb, (unsigned)C), dim3(GEMM_THREADS), H2_LDS_BYTES,
+                     as_stream(stream), (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq,
+                     (int)(dp / H2_KT), (float)(-0.5 / (sigma * sigma)) * LOG2E, V, ldv, ranges, out, ldo);
+  ODX_CHECK_LAUNCH("odx_gauss_mmv_h2");
+  return ODX_OK;
+}

@@ -15,6 +15,7 @@ Interface used by the host logic (any backend provides exactly this):
     vec(x) / zeros(n) f64 vectors on the backend's device
 """
 import ctypes
+import os
 
 import torch
 
@@ -26,11 +27,13 @@ def _p(t):
 
 
 class Features:
-    """Row-major f32 rows (n x D, leading dimension a multiple of 4) plus their squared norms."""
-    __slots__ = ("X", "sq", "n", "D", "ld")
+    """Row-major f32 rows (n x D, leading dimension a multiple of 4) plus their squared norms and, once a
+    Gaussian-kernel call has needed it, the packed two-term f16 split of the rows (P, meta: odx_split_f16)."""
+    __slots__ = ("X", "sq", "n", "D", "ld", "P", "meta")
 
-    def __init__(self, X, sq, D):
+    def __init__(self, X, sq, D, P=None, meta=None):
         self.X, self.sq, self.n, self.D, self.ld = X, sq, X.shape[0], D, X.stride(0) if X.shape[0] else X.shape[1]
+        self.P, self.meta = P, meta
 
 
 class Precond:
@@ -49,6 +52,11 @@ class HipBackend:
         self.lib = hip.require_gpu()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._ws = {}
+        # "h2": X Z' of the Gaussian kernels on the f16 matrix cores via the two-term split (f32 accuracy);
+        # "f32": the all-f32 MFMA chain.  Both are HIP paths of libodx; there is no other.
+        self.gauss = os.environ.get("ODX_GAUSS", "h2")
+        if self.gauss not in ("h2", "f32"):
+            raise ValueError("ODX_GAUSS must be 'h2' or 'f32', got %r" % self.gauss)
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -98,12 +106,23 @@ class HipBackend:
         return Features(X, sq, D)
 
     def rows(self, F, idx):
-        """MyCenterSelector.select: gather rows (and their norms) by index."""
+        """MyCenterSelector.select: gather rows (their norms, and their packed split if it exists) by index."""
         idx = torch.as_tensor(idx, dtype=torch.int64, device=self.device).reshape(-1)
         ld = (F.D + 3) // 4 * 4
         buf = torch.zeros((idx.numel(), ld), dtype=torch.float32, device=self.device)
         buf[:, :F.D] = F.X.index_select(0, idx)
-        return Features(buf[:, :F.D], F.sq.index_select(0, idx), F.D)
+        P = F.P.index_select(0, idx) if F.P is not None else None
+        return Features(buf[:, :F.D], F.sq.index_select(0, idx), F.D, P, F.meta if P is not None else None)
+
+    def pack(self, F):
+        """Make sure F carries its packed f16 split (odx_split_f16); returns F."""
+        if F.P is None:
+            ldp = (F.D + 63) // 64 * 64
+            F.P = torch.empty((F.n, ldp), dtype=torch.int32, device=self.device)
+            F.meta = torch.zeros(2, dtype=torch.float32, device=self.device)
+            hip.check(self.lib.odx_split_f16(_p(F.X), F.ld, F.n, F.D, _p(F.P), ldp, _p(F.meta), self._stream()),
+                      "odx_split_f16")
+        return F
 
     # ------------------------------------------------------------------ FALKON pieces
     def precond(self, Zf, sigma, lam, eps, out=None):
@@ -138,8 +157,14 @@ class HipBackend:
             K.K = out.view(-1)[: n * ld].view(n, ld)
         else:
             K.K = torch.empty((n, ld), dtype=torch.float32, device=self.device)
-        hip.check(self.lib.odx_gauss_knm_f32(_p(F.X), F.ld, _p(F.sq), n, _p(Zf.X), Zf.ld, _p(Zf.sq), M, F.D,
-                                             float(sigma), _p(K.K), ld, self._stream()), "odx_gauss_knm_f32")
+        if self.gauss == "h2":
+            self.pack(F), self.pack(Zf)
+            hip.check(self.lib.odx_gauss_knm_h2(_p(F.P), F.P.stride(0), _p(F.meta), _p(F.sq), n, _p(Zf.P), Zf.P.stride(0),
+                                                _p(Zf.meta), _p(Zf.sq), M, F.D, float(sigma), _p(K.K), ld, self._stream()),
+                      "odx_gauss_knm_h2")
+        else:
+            hip.check(self.lib.odx_gauss_knm_f32(_p(F.X), F.ld, _p(F.sq), n, _p(Zf.X), Zf.ld, _p(Zf.sq), M, F.D,
+                                                 float(sigma), _p(K.K), ld, self._stream()), "odx_gauss_knm_f32")
         return K
 
     def ktk(self, K, v=None, w=None, out=None):
@@ -198,9 +223,15 @@ class HipBackend:
             return out
         if Mtot == 0:
             return out.zero_()
-        hip.check(self.lib.odx_gauss_mmv_f32(_p(F.X), F.ld, _p(F.sq), F.n, _p(Zf.X), Zf.ld, _p(Zf.sq), F.D,
-                                             float(sigma), _p(V), V.stride(0), _p(ranges), T, _p(out), out.stride(0),
-                                             self._stream()), "odx_gauss_mmv_f32")
+        if self.gauss == "h2":
+            self.pack(F), self.pack(Zf)
+            hip.check(self.lib.odx_gauss_mmv_h2(_p(F.P), F.P.stride(0), _p(F.meta), _p(F.sq), F.n, _p(Zf.P), Zf.P.stride(0),
+                                                _p(Zf.meta), _p(Zf.sq), F.D, float(sigma), _p(V), V.stride(0), _p(ranges), T,
+                                                _p(out), out.stride(0), self._stream()), "odx_gauss_mmv_h2")
+        else:
+            hip.check(self.lib.odx_gauss_mmv_f32(_p(F.X), F.ld, _p(F.sq), F.n, _p(Zf.X), Zf.ld, _p(Zf.sq), F.D,
+                                                 float(sigma), _p(V), V.stride(0), _p(ranges), T, _p(out), out.stride(0),
+                                                 self._stream()), "odx_gauss_mmv_f32")
         return out
 
     # ------------------------------------------------------------------ RLS (A7)

@@ -17,6 +17,14 @@ def be():
     return odx.get_backend()
 
 
+@pytest.fixture(params=["h2", "f32"])
+def gauss(be, request):
+    """Run a test once per Gaussian-kernel contraction: f16 split on the f16 matrix cores, and all-f32 MFMA."""
+    old, be.gauss = be.gauss, request.param
+    yield request.param
+    be.gauss = old
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
@@ -79,7 +87,7 @@ def test_gemm_flags(be):
 
 
 @pytest.mark.parametrize("n,M,D,sigma", [(1000, 500, 256, 10.0), (333, 130, 1024, 15.0), (129, 7, 36, 5.0), (64, 2000, 2048, 20.0)])
-def test_gauss_knm(be, n, M, D, sigma):
+def test_gauss_knm(be, gauss, n, M, D, sigma):
     from oracle import falkon_ref as fr
     from tests.synth import blob_problem
     X, y, rng = blob_problem(n + M, D, seed=n + M + D)
@@ -96,6 +104,33 @@ def test_gauss_knm(be, n, M, D, sigma):
     Z2 = be.features(torch.from_numpy(X[:5].copy()))
     K2 = be.knm(F, Z2, sigma).K.cpu().numpy()
     assert np.all(np.abs(np.diag(K2[:5, :5]) - 1.0) < 1e-4)
+
+
+@pytest.mark.parametrize("n,D,scale", [(300, 256, 1.0), (5, 36, 1e-3), (70000, 64, 37.0), (129, 1000, 5e4), (3, 8, 0.0)])
+def test_split_f16(be, n, D, scale):
+    """odx_split_f16: hi + lo reproduces scale * x to 2^-22 relative (to the matrix max), layout as documented."""
+    rng = np.random.default_rng(n + D)
+    X = (rng.standard_normal((n, D)) * scale).astype(np.float32)
+    F = be.pack(be.features(torch.from_numpy(X)))
+    s, amax_bits = F.meta.cpu().numpy().view(np.float32)[0], F.meta.cpu().numpy().view(np.uint32)[1]
+    amax = np.abs(X).max()
+    assert amax_bits == np.float32(amax).view(np.uint32)
+    if amax > 0:
+        assert 2.0 ** 13 <= amax * s < 2.0 ** 14 and np.log2(s) == np.round(np.log2(s))
+    else:
+        assert s == 1.0
+    Dp = (D + 63) // 64 * 64
+    P = F.P.cpu().numpy().view(np.float16).reshape(n, Dp // 64, 2, 64)
+    hi = P[:, :, 0, :].reshape(n, Dp).astype(np.float64)
+    lo = P[:, :, 1, :].reshape(n, Dp).astype(np.float64)
+    assert np.all(hi[:, D:] == 0) and np.all(lo[:, D:] == 0)
+    want = X.astype(np.float64) * float(s)
+    assert np.array_equal(hi[:, :D].astype(np.float16), (X * s).astype(np.float16))       # hi = RN_f16(s x)
+    assert np.abs(hi[:, :D] + lo[:, :D] - want).max() <= 2.0 ** -22 * max(amax * s, 1e-30) * 1.01 + 2.0 ** -25
+    # rows gathered from a packed matrix keep the packing
+    idx = rng.integers(0, n, 7)
+    Z = be.rows(F, idx)
+    assert Z.meta is F.meta and torch.equal(Z.P, F.P[torch.from_numpy(idx).cuda()])
 
 
 @pytest.mark.parametrize("n,M", [(1000, 500), (4097, 2000), (37, 130), (700, 3000), (520, 10000), (300, 12001), (200, 20000)])
@@ -183,7 +218,7 @@ def test_precond_identities(be, M, D, sigma, lam):
 @pytest.mark.parametrize("n,M,D,sigma,lam", [(5000, 500, 256, 10.0, 1e-5), (5000, 500, 256, 15.0, 1e-5),
                                               (3000, 300, 1024, 15.0, 1e-5), (2500, 1000, 2048, 5.0, 1e-4),
                                               (777, 129, 36, 5.0, 1e-3)])
-def test_falkon_fit_alpha_parity(be, n, M, D, sigma, lam):
+def test_falkon_fit_alpha_parity(be, gauss, n, M, D, sigma, lam):
     """The north-star bar: learned alphas within 1e-4 relative of the reference algorithm
     evaluated in exact (f64) arithmetic with falkon's f32-regime constants, same inputs."""
     import odx
@@ -204,7 +239,7 @@ def test_falkon_fit_alpha_parity(be, n, M, D, sigma, lam):
     assert np.abs(pred - pref).max() < 1e-4
 
 
-def test_mmv_block_structure(be):
+def test_mmv_block_structure(be, gauss):
     from odx.falkon import block_ranges
     from oracle import falkon_ref as fr
     from tests.synth import blob_problem

@@ -98,12 +98,16 @@ def main():
             Z = X[:M].clone()
             F, Zf = be.features(X), be.features(Z)
             buf = torch.empty(n * ((M + 3) // 4 * 4), device="cuda")
-            ms = timeit(lambda: be.knm(F, Zf, 15.0, out=buf))
-            print("gauss_knm n=%d M=%d D=%d: %.3f ms  %.1f TFLOP/s" % (n, M, D, ms, 2.0 * n * M * D / ms / 1e9))
             al = torch.randn(M, dtype=torch.float64, device="cuda")
             out = torch.empty(n, 1, device="cuda")
-            ms = timeit(lambda: be.mmv(F, Zf, 15.0, al, None, out=out))
-            print("gauss_mmv n=%d M=%d D=%d: %.3f ms  %.1f TFLOP/s" % (n, M, D, ms, 2.0 * n * M * D / ms / 1e9))
+            ms = timeit(lambda: hip.check(lib.odx_split_f16(_p(F.X), F.ld, n, D, _p(buf), (D + 63) // 64 * 64, _p(out), be._stream())))
+            print("split_f16 n=%d D=%d: %.3f ms  %.0f GB/s (read + write)" % (n, D, ms, n * D * 8.0 / ms / 1e6))
+            for mode in ("f32", "h2"):
+                be.gauss = mode
+                ms = timeit(lambda: be.knm(F, Zf, 15.0, out=buf))
+                print("gauss_knm[%s] n=%d M=%d D=%d: %.3f ms  %.1f TFLOP/s" % (mode, n, M, D, ms, 2.0 * n * M * D / ms / 1e9))
+                ms = timeit(lambda: be.mmv(F, Zf, 15.0, al, None, out=out))
+                print("gauss_mmv[%s] n=%d M=%d D=%d: %.3f ms  %.1f TFLOP/s" % (mode, n, M, D, ms, 2.0 * n * M * D / ms / 1e9))
 
 
 if __name__ == "__main__":
