@@ -125,8 +125,9 @@ class HipBackend:
         return F
 
     # ------------------------------------------------------------------ FALKON pieces
-    def precond(self, Zf, sigma, lam, eps, out=None):
-        """`out`: optional preallocated (4, M, ld) f64 tensor (e.g. owned by another stream)."""
+    def precond(self, Zf, sigma, lam, eps, out=None, ws_key="precond"):
+        """`out`: optional preallocated (4, M, ld) f64 tensor (e.g. owned by another stream); `ws_key` names the
+        scratch buffer, so that factorisations in flight on different streams do not share one."""
         M, D = Zf.n, Zf.D
         ld = (M + 1) // 2 * 2
         P = Precond()
@@ -135,7 +136,7 @@ class HipBackend:
         P.LTi, P.LTit, P.LAi, P.LAit = mats[0], mats[1], mats[2], mats[3]
         P.info = torch.zeros(1, dtype=torch.int32, device=self.device)
         nbytes = self.lib.odx_falkon_precond_workspace_bytes(M, D)
-        ws = self._workspace("precond", nbytes)
+        ws = self._workspace(ws_key, nbytes)
         hip.check(self.lib.odx_falkon_precond_f64(_p(Zf.X), Zf.ld, M, D, float(sigma), float(lam), float(eps),
                                                   _p(P.LTi), _p(P.LTit), _p(P.LAi), _p(P.LAit), ld, _p(P.info),
                                                   _p(ws), ws.numel(), self._stream()), "odx_falkon_precond_f64")
