@@ -11,6 +11,7 @@
 // (64 consecutive features) is 256 contiguous bytes: 64 f16 hi, then 64 f16 lo.  Features past D are zero.
 // Tile: 256 threads (2 x 2 waves), 128 x 128 outputs, a k-tile = 128 rows x 256 B per operand through LDS rows of
 // 272 B (17 x 16 B, odd => the 16-lane groups of ds_read_b128 hit 16 distinct 16-B slots).
+#include <stdlib.h>
 #include "gemm_core.h"
 #include "odx_internal.h"
 
@@ -316,6 +317,211 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gauss_mmv_h2_kernel(
   }
 }
 
+// ================================================================ 16x16x32 variant
+// Same tile and packed operands, v_mfma_f32_16x16x32_f16 (4 x 4 blocks per wave).  LDS rows are exactly 256 B with the
+// 16-byte slots of a row XOR-swizzled by (row & 15): logical slot q (hi chunks 0..7, lo chunks 8..15) lives at
+// q ^ (row & 15).  A 16-lane group of ds_read_b128 then touches lanes of two k-groups whose chunk numbers differ only in
+// their low two bits, which keeps the 16 slots distinct (conflict-free), with no padding: 64 KiB per workgroup.
+constexpr int S16_ROW = 256;
+constexpr int S16_LDS_BYTES = (GEMM_BM + GEMM_BN) * S16_ROW;   // 65,536 B
+
+__device__ __forceinline__ void s16_store_operand(const u32x4 (&r)[8], char* lds) {
+  const int tid = threadIdx.x;
+  const int row = tid >> 4;
+  char* d = lds + row * S16_ROW + (((tid & 15) ^ (row & 15)) << 4);     // (row + 16 p) & 15 == row & 15
+#pragma unroll
+  for (int p = 0; p < 8; ++p) *reinterpret_cast<u32x4*>(d + 16 * p * S16_ROW) = r[p];
+}
+
+__device__ __forceinline__ void s16_compute_ktile(f32x4 (&acc)[4][4], const char* ldsA, const char* ldsB, int wr, int wc,
+                                                  int lane) {
+  const int r = lane & 15, g = lane >> 4;
+  const char* pa = ldsA + (wr * 64 + r) * S16_ROW;
+  const char* pb = ldsB + (wc * 64 + r) * S16_ROW;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int hi = (((ks * 4 + g) ^ r) << 4), lo = hi ^ 128;
+    f16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      ah[t] = *reinterpret_cast<const f16x8*>(pa + t * 16 * S16_ROW + hi);
+      al[t] = *reinterpret_cast<const f16x8*>(pa + t * 16 * S16_ROW + lo);
+      bh[t] = *reinterpret_cast<const f16x8*>(pb + t * 16 * S16_ROW + hi);
+      bl[t] = *reinterpret_cast<const f16x8*>(pb + t * 16 * S16_ROW + lo);
+    }
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+      }
+  }
+}
+
+__device__ __forceinline__ void s16_mainloop(f32x4 (&acc)[4][4], const uint32_t* __restrict__ A, int64_t lda, int64_t m,
+                                             const uint32_t* __restrict__ B, int64_t ldb, int64_t n, int64_t i0, int64_t j0,
+                                             int ktiles, char* lds) {
+  char* ldsA = lds;
+  char* ldsB = lds + GEMM_BM * S16_ROW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  uint32_t offa[8], offb[8];
+  h2_row_offsets(offa, lda, i0, m);
+  h2_row_offsets(offb, ldb, j0, n);
+  const uint32_t* ta = A + i0 * lda;
+  const uint32_t* tb = B + j0 * ldb;
+  H2Stage st;
+  h2_load_operand(st.a, ta, offa);
+  h2_load_operand(st.b, tb, offb);
+  for (int kt = 0; kt < ktiles; ++kt) {
+    __syncthreads();
+    s16_store_operand(st.a, ldsA);
+    s16_store_operand(st.b, ldsB);
+    __syncthreads();
+    if (kt + 1 < ktiles) {
+      ta += H2_KT;
+      tb += H2_KT;
+      h2_load_operand(st.a, ta, offa);
+      h2_load_operand(st.b, tb, offb);
+    }
+    s16_compute_ktile(acc, ldsA, ldsB, wr, wc, lane);
+  }
+}
+
+__device__ __forceinline__ void s16_zero(f32x4 (&acc)[4][4]) {
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// accumulator element (tm, tn, q) of a wave's 64 x 64 share: row 16 tm + 4 (lane >> 4) + q, column 16 tn + (lane & 15)
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gauss_knm_h2s16_kernel(
+    const uint32_t* __restrict__ PX, int64_t ldpx, const float* __restrict__ metax, const float* __restrict__ xsq, int64_t n,
+    const uint32_t* __restrict__ PZ, int64_t ldpz, const float* __restrict__ metaz, const float* __restrict__ zsq, int64_t M,
+    int ktiles, float gamma_log2e, float* __restrict__ K, int64_t ldk, int gr) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int64_t GR = gr;
+  const int64_t tiles_n = (M + GEMM_BN - 1) / GEMM_BN;
+  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t band = wg / (GR * tiles_n), within = wg % (GR * tiles_n);
+  const int64_t i0 = (band * GR + within % GR) * GEMM_BM, j0 = (within / GR) * GEMM_BN;
+  if (i0 >= n) return;
+
+  __shared__ __attribute__((aligned(16))) float xs_s[GEMM_BM];
+  if (threadIdx.x < GEMM_BM) xs_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] : 0.f;
+
+  f32x4 acc[4][4];
+  s16_zero(acc);
+  s16_mainloop(acc, PX, ldpx, n, PZ, ldpz, M, i0, j0, ktiles, lds);
+
+  const float m2 = -2.f / (metax[0] * metaz[0]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const bool interior = i0 + GEMM_BM <= n && j0 + GEMM_BN <= M;
+  const int64_t mpad = (M + 3) & ~int64_t(3);
+  float* tile = K + i0 * ldk + j0;
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) {
+    const int cl = wc * 64 + tn * 16 + (lane & 15);
+    const float zs = (j0 + cl < M) ? zsq[j0 + cl] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      const int rl = wr * 64 + tm * 16 + 4 * (lane >> 4);
+      const f32x4 xs = *reinterpret_cast<const f32x4*>(&xs_s[rl]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float d2 = fmaf(m2, acc[tm][tn][q], xs[q]) + zs;
+        d2 = fmaxf(d2, 0.f);
+        const float v = __builtin_amdgcn_exp2f(d2 * gamma_log2e);
+        if (interior) {
+          tile[(uint32_t)(rl + q) * (uint32_t)ldk + (uint32_t)cl] = v;
+        } else if (i0 + rl + q < n && j0 + cl < mpad) {
+          tile[(int64_t)(rl + q) * ldk + cl] = (j0 + cl < M) ? v : 0.f;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gauss_mmv_h2s16_kernel(
+    const uint32_t* __restrict__ PX, int64_t ldpx, const float* __restrict__ metax, const float* __restrict__ xsq, int64_t n,
+    const uint32_t* __restrict__ PZ, int64_t ldpz, const float* __restrict__ metaz, const float* __restrict__ zsq, int ktiles,
+    float gamma_log2e, const double* __restrict__ V, int64_t ldv, const int32_t* __restrict__ ranges,
+    float* __restrict__ out, int64_t ldo) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  __shared__ double red[2][2][64];
+  __shared__ __attribute__((aligned(16))) float xs_s[GEMM_BM];
+  const int c = blockIdx.y;
+  const int64_t s0 = ranges[2 * c], s1 = ranges[2 * c + 1];
+  const int64_t i0 = (int64_t)blockIdx.x * GEMM_BM;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const float m2 = -2.f / (metax[0] * metaz[0]);
+
+  if (threadIdx.x < GEMM_BM) xs_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] : 0.f;
+  // Lane l ends every tile with the f64 sum over the tile's 64 columns of this wave of row slot (l & 15) of its lane
+  // quarter (slot = 4 tm + q, row 16 tm + 4 (l >> 4) + q): a reduce-scatter butterfly over the 16 lanes of the quarter.
+  double tot = 0.0;
+  const bool b8 = lane & 8, b4 = lane & 4, b2 = lane & 2, b1 = lane & 1;
+
+  for (int64_t j0 = s0; j0 < s1; j0 += GEMM_BN) {
+    f32x4 acc[4][4];
+    s16_zero(acc);
+    s16_mainloop(acc, PX, ldpx, n, PZ + j0 * ldpz, ldpz, s1 - j0, i0, 0, ktiles, lds);
+    float zs[4];
+    double al[4];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int64_t col = j0 + wc * 64 + tn * 16 + (lane & 15);
+      const bool cv = col < s1;
+      zs[tn] = cv ? zsq[col] : 0.f;
+      al[tn] = cv ? V[col * ldv + c] : 0.0;
+    }
+    double w8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {       // slots j (tm = j >> 2) and j + 8 (tm = 2 + (j >> 2)), q = j & 3
+      double v[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int tm = 2 * u + (j >> 2), q = j & 3;
+        const float xs = xs_s[wr * 64 + tm * 16 + 4 * (lane >> 4) + q];
+        v[u] = 0.0;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+          float d2 = fmaf(m2, acc[tm][tn][q], xs) + zs[tn];
+          d2 = fmaxf(d2, 0.f);
+          v[u] = fma((double)__builtin_amdgcn_exp2f(d2 * gamma_log2e), al[tn], v[u]);
+        }
+      }
+      w8[j] = (b8 ? v[1] : v[0]) + __shfl_xor(b8 ? v[0] : v[1], 8);
+    }
+    double w4[4], w2[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w4[j] = (b4 ? w8[j + 4] : w8[j]) + __shfl_xor(b4 ? w8[j] : w8[j + 4], 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) w2[j] = (b2 ? w4[j + 2] : w4[j]) + __shfl_xor(b2 ? w4[j] : w4[j + 2], 2);
+    tot += (b1 ? w2[1] : w2[0]) + __shfl_xor(b1 ? w2[0] : w2[1], 1);
+  }
+  {
+    const int slot = lane & 15;
+    red[wr][wc][(slot >> 2) * 16 + 4 * (lane >> 4) + (slot & 3)] = tot;
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int w = threadIdx.x >> 6, rr = threadIdx.x & 63;
+    const int64_t row = i0 + w * 64 + rr;
+    if (row < n) out[row * ldo + c] = (float)(red[w][0][rr] + red[w][1][rr]);
+  }
+}
+
+static int h2_shape() {   // development switch between the two MFMA shapes
+  static const int shape = (getenv("ODX_H2_SHAPE") && atoi(getenv("ODX_H2_SHAPE")) == 32) ? 32 : 16;
+  return shape;
+}
+
 static int h2_enable_lds(const void* fn) {   // > 64 KiB of LDS per workgroup has to be asked for
   ODX_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES));
   return ODX_OK;
@@ -362,8 +568,17 @@ extern "C" int odx_gauss_knm_h2(const void* PX, int64_t ldpx, const float* metax
   ODX_REQUIRE(ldpx % 4 == 0 && ldpz % 4 == 0 && ldpx >= dp && ldpz >= dp && aligned16(PX) && aligned16(PZ),
               "odx_gauss_knm_h2: packed operands must be 16-byte aligned with ld %% 4 == 0 and ld >= roundup(D, 64)");
   ODX_REQUIRE(ldk % 4 == 0 && ldk >= round_up(M, 4) && aligned16(K), "odx_gauss_knm_h2: K must be 16-byte aligned, ldk %% 4 == 0, ldk >= roundup(M, 4)");
-  const int64_t tiles = round_up(ceil_div(n, GEMM_BM), 8) * ceil_div(M, GEMM_BN);
+  const int gr = 8;   // band height of the tile order: 2..32 measured within 2 % of each other at n = 2.5e5, M = 1e4
+  const int64_t tiles = round_up(ceil_div(n, GEMM_BM), gr) * ceil_div(M, GEMM_BN);
   ODX_REQUIRE(tiles < (1ll << 31), "odx_gauss_knm_h2: grid too large");
+  if (h2_shape() == 16) {
+    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2s16_kernel)));
+    hipLaunchKernelGGL(gauss_knm_h2s16_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), S16_LDS_BYTES, as_stream(stream),
+                       (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq, M, (int)(dp / H2_KT),
+                       (float)(-0.5 / (sigma * sigma)) * LOG2E, K, ldk, gr);
+    ODX_CHECK_LAUNCH("odx_gauss_knm_h2");
+    return ODX_OK;
+  }
   ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2_kernel)));
   hipLaunchKernelGGL(gauss_knm_h2_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), H2_LDS_BYTES, as_stream(stream),
                      (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq, M, (int)(dp / H2_KT),
@@ -385,6 +600,14 @@ extern "C" int odx_gauss_mmv_h2(const void* PX, int64_t ldpx, const float* metax
   ODX_REQUIRE(ldo >= C && C < 65536, "odx_gauss_mmv_h2: ldo < C or too many classes");
   const int64_t rb = ceil_div(n, GEMM_BM);
   ODX_REQUIRE(rb < (1ll << 31), "odx_gauss_mmv_h2: grid too large");
+  if (h2_shape() == 16) {
+    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_mmv_h2s16_kernel)));
+    hipLaunchKernelGGL(gauss_mmv_h2s16_kernel, dim3((unsigned)rb, (unsigned)C), dim3(GEMM_THREADS), S16_LDS_BYTES,
+                       as_stream(stream), (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq,
+                       (int)(dp / H2_KT), (float)(-0.5 / (sigma * sigma)) * LOG2E, V, ldv, ranges, out, ldo);
+    ODX_CHECK_LAUNCH("odx_gauss_mmv_h2");
+    return ODX_OK;
+  }
   ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_mmv_h2_kernel)));
   hipLaunchKernelGGL(gauss_mmv_h2_kernel, dim3((unsigned)rb, (unsigned)C), dim3(GEMM_THREADS), H2_LDS_BYTES,
                      as_stream(stream), (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq,
