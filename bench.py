@@ -5,9 +5,9 @@ One "step" = one pass of the hot path over the whole synthetic job: for each of 
 fit a FALKON classifier on the N rows (Nystroem centres by the reference rule, f64
 preconditioner, f32 K_nM build, 20 CG iterations on the stored K_nM) and score all N rows with
 it.  The N rows are sharded contiguously over the ranks (one process per GPU); classes go in batches of
-world-size, each rank building the preconditioner of one class of the batch; each CG iteration
-exchanges one broadcast and one all-reduce of an (M,) f64 vector (RCCL).  N is the job size at every
-GPU count => "scaling": "strong".
+world-size, each rank owning (preconditioner + CG state of) one class of the batch; the batch advances in
+lock step and each CG iteration exchanges one all-gather and one reduce-scatter of a (world, M) f64
+matrix (RCCL).  N is the job size at every GPU count => "scaling": "strong".
 
     python bench.py [--gpus N --steps K --warmup W] [--rows 1000000 --dim 1024 --centres 10000 --classes 30]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -164,7 +164,7 @@ def main():
     row_ids = torch.arange(lo, hi, device=device)
     cidx = centre_indices(N, C, M, seed)
     ldk = (M + 3) // 4 * 4
-    kbuf = torch.empty(n_loc * ldk, dtype=torch.float32, device=device)
+    kbufs = [torch.empty(n_loc * ldk, dtype=torch.float32, device=device) for _ in range(world)]   # N x M f32 per GPU in all
     scores = torch.empty((n_loc, C), dtype=torch.float32, device=device)
     opt = SolverOptions(check_pivots=False)
     ph = {k: Phase() for k in ("knm", "ktk", "precond", "mmv")}
@@ -203,11 +203,10 @@ def main():
         return Zs, P, ev
 
     def run_classes(classes, timed):
-        """Classes are processed in batches of `world`.  Every rank builds the preconditioner of the
-        class it owns in a batch (nothing replicated) on a side stream, one batch ahead, so that the
-        f64 factorisations overlap the HBM-bound CG passes of the batch in flight; the batch's classes
-        are then fitted one after the other with the rows sharded over all ranks (owner-computes CG,
-        odx.solver.falkon_fit) and scored."""
+        """Classes are processed in batches of `world`.  Every rank builds the preconditioner of the class it owns in
+        a batch (nothing replicated) on a side stream, `depth` batches ahead.  The batch's classes are then fitted
+        together in lock step with the rows sharded over all ranks (odx.solver.falkon_fit_lockstep: per CG step one
+        all-gather of the directions, one pass per class over the local K_nM shard, one reduce-scatter) and scored."""
         out = None
         batches = [classes[b0:b0 + world] for b0 in range(0, len(classes), world)]
         ready = {bi: prepare(batches[bi], bi % nslot, timed) for bi in range(min(depth, len(batches)))}
@@ -215,16 +214,16 @@ def main():
             if bi + depth < len(batches):
                 ready[bi + depth] = prepare(batches[bi + depth], (bi + depth) % nslot, timed)
             Zs, P, ev = ready.pop(bi)
+            ys = [torch.where((row_ids % C) == c, 1.0, -1.0).to(torch.float64) for c in batch]
+            mine = rank < len(batch)
+            alphas = odx.falkon_fit_lockstep(be, F, ys, Zs, args.sigma, args.lam, args.maxiter, opt, n_total=N, shard=shard,
+                                             knm_outs=kbufs[:len(batch)], phase=(lambda name: ph[name]) if timed else None,
+                                             precond=P if mine else None,
+                                             precond_ready=(lambda: torch.cuda.current_stream().wait_event(ev)) if mine else None)
             for pos, c in enumerate(batch):
-                y = torch.where((row_ids % C) == c, 1.0, -1.0).to(torch.float64)
-                mine = pos == rank
-                alpha = odx.falkon_fit(be, F, y, Zs[pos], args.sigma, args.lam, args.maxiter, opt, n_total=N,
-                                       knm_out=kbuf, phase=(lambda name: ph[name]) if timed else None,
-                                       precond=P if mine else None, shard=shard, owner=pos,
-                                       precond_ready=(lambda: torch.cuda.current_stream().wait_event(ev)) if mine else None)
                 with ph["mmv"] if timed else _null():
-                    be.mmv(F, Zs[pos], args.sigma, alpha, None, out=scores[:, c:c + 1])
-                out = (alpha, Zs[pos])
+                    be.mmv(F, Zs[pos], args.sigma, alphas[pos], None, out=scores[:, c:c + 1])
+            out = (alphas[-1], Zs[-1])
         return out
 
     def barrier():

@@ -46,3 +46,30 @@ class RowShard:
         if self.enabled:
             dist.broadcast(t, src=src, group=self.group)
         return t
+
+    # ---- collectives of the lock-step multi-class fit (odx.solver.falkon_fit_lockstep) -------------------
+    def _has_reduce_scatter(self):
+        return dist.get_backend(self.group) == "nccl"       # RCCL; gloo has neither primitive for device-style use
+
+    def gather_rows(self, mine, out):
+        """out (world, M) <- row r = rank r's `mine` (M,).  One all-gather."""
+        if not self.enabled:
+            out[0].copy_(mine)
+        elif self._has_reduce_scatter():
+            dist.all_gather_into_tensor(out, mine, group=self.group)
+        else:
+            out.zero_()
+            out[self.rank].copy_(mine)
+            dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
+        return out
+
+    def reduce_scatter_rows(self, partials, out):
+        """out (M,) <- sum over ranks of their partials[self.rank]  (partials: (world, M)).  One reduce-scatter."""
+        if not self.enabled:
+            out.copy_(partials[0])
+        elif self._has_reduce_scatter():
+            dist.reduce_scatter_tensor(out, partials, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.all_reduce(partials, op=dist.ReduceOp.SUM, group=self.group)
+            out.copy_(partials[self.rank])
+        return out

@@ -129,3 +129,101 @@ def falkon_fit(be, F, y, Zf, sigma, lam, maxiter=20, opt=None, n_total=None, all
     if return_knm:
         return alpha, K
     return alpha
+
+
+def falkon_fit_lockstep(be, F, ys, Zfs, sigma, lam, maxiter=20, opt=None, n_total=None, shard=None, knm_outs=None,
+                        phase=None, precond=None, precond_ready=None):
+    """Fit up to `world` binary problems at once over row shards, one owner rank per problem.
+
+    Problem b (labels ys[b], centres Zfs[b]) is owned by rank b: only that rank holds its preconditioner and CG
+    state.  All problems advance through the same CG schedule in lock step, so one iteration costs every rank
+        its own problem's triangular products                      (all ranks busy: no owner-only serial section)
+        one all-gather of the B directions T^-1 A^-1 p             ((world, M) f64)
+        B passes over its row shard of the B stored K_nM           (HBM-bound, the bulk)
+        one reduce-scatter handing each owner the sum of its partials
+    instead of, per problem, a broadcast, a pass and an all-reduce with the other ranks idle during the owner's
+    algebra (falkon_fit's owner mode).  The arithmetic per problem is exactly falkon_fit's.
+
+    ys, Zfs     lists of B <= world label vectors / centre Features (identical on every rank)
+    knm_outs    optional list of B preallocated f32 buffers for the K_nM shards
+    precond     this rank's problem's preconditioner (rank < B), or None to build it here
+    returns     list of B alpha vectors (M,) f64, on every rank
+    """
+    from .dist import RowShard
+    opt = opt or SolverOptions()
+    shard = shard if shard is not None else RowShard()
+    world, rank = shard.world, shard.rank
+    B = len(Zfs)
+    if B > world or len(ys) != B:
+        raise ValueError("falkon_fit_lockstep: %d problems for %d ranks" % (B, world))
+    n = float(F.n if n_total is None else n_total)
+    M = Zfs[0].n
+    if any(z.n != M for z in Zfs):
+        raise ValueError("falkon_fit_lockstep: every problem needs the same number of centres")
+    ph = phase if phase is not None else (lambda name: _NoPhase())
+    owned = rank < B
+    P = precond
+    if owned and P is None:
+        with ph("precond"):
+            P = be.precond(Zfs[rank], sigma, lam, opt.pc_epsilon)
+    Ks = []
+    for b in range(B):
+        with ph("knm"):
+            Ks.append(be.knm(F, Zfs[b], sigma, out=None if knm_outs is None else knm_outs[b]))
+
+    Mp = (M + 1) // 2 * 2                             # rows of the exchanged matrices stay 16-byte aligned
+    Tall = be.zeros(world * Mp).view(world, Mp)       # gathered directions
+    CC = be.zeros(world * Mp).view(world, Mp)         # this rank's partials, one row per problem
+    tbuf, ccbuf, v = be.zeros(Mp), be.zeros(Mp), be.zeros(M)
+    t, cc = tbuf[:M], ccbuf[:M]
+
+    def passes(use_w):
+        for b in range(B):
+            with ph("ktk"):
+                if use_w:
+                    be.ktk(Ks[b], w=ys[b] * (1.0 / n), out=CC[b, :M])
+                else:
+                    be.ktk(Ks[b], v=Tall[b, :M], out=CC[b, :M])
+        return shard.reduce_scatter_rows(CC, ccbuf)
+
+    def mmv(s, out):
+        if owned:
+            be.trmv(P, "LAit", s, out=v)
+            be.trmv(P, "LTit", v, out=t)
+        shard.gather_rows(tbuf, Tall)
+        passes(False)
+        if owned:
+            u = be.trmv(P, "LTi", cc, alpha=1.0 / n, beta=lam, z=v)
+            be.trmv(P, "LAi", u, out=out)
+
+    passes(True)                                     # K' (y / n) of every problem
+    X, R, Pv, AP = be.zeros(M), be.zeros(M), be.zeros(M), be.zeros(M)
+    state = be.zeros(4)
+    Bv = None
+    if owned:
+        if precond_ready is not None:
+            precond_ready()
+        Bv = be.trmv(P, "LAi", be.trmv(P, "LTi", cc))
+        be.cg_init(Bv, X, R, Pv, state)
+    tol = opt.cg_tolerance ** 2
+    for it in range(maxiter):
+        mmv(Pv, AP)
+        full = (it + 1) % opt.cg_full_gradient_every == 0
+        if owned:
+            be.cg_step(X, R, Pv, AP, state, opt.cg_epsilon, full)
+        if it == maxiter - 1:
+            break
+        if full:
+            mmv(X, AP)
+            if owned:
+                R.copy_(Bv)
+                be.axpby(-1.0, AP, 1.0, R)
+        if owned:
+            be.cg_finish(R, Pv, state, opt.cg_epsilon, tol)
+    tbuf.zero_()
+    if owned:
+        be.trmv(P, "LTit", be.trmv(P, "LAit", X), out=t)
+        if opt.check_pivots:
+            be.check_precond(P)
+    shard.gather_rows(tbuf, Tall)
+    return [Tall[b, :M].clone() for b in range(B)]

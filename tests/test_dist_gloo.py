@@ -98,3 +98,58 @@ def test_shard_bounds_cover_rows_exactly():
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             sizes = [h - l for l, h in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _lockstep_worker(rank, world, port, n, B, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import odx
+        from odx.dist import RowShard
+        from tests.oracle_backend import OracleBackend
+        from tests.synth import blob_problem, centres
+        odx.set_backend(OracleBackend(np.float64))
+        be = odx.get_backend()
+        X, y, rng = blob_problem(n, 24, seed=13)
+        shard = RowShard()
+        lo, hi = shard.bounds(n)
+        F = be.features(torch.from_numpy(X[lo:hi]))
+        M = 61                                             # odd: exercises the padded exchange rows
+        ys, Zfs = [], []
+        for b in range(B):
+            yb = np.where(np.arange(n) % 5 == b, 1.0, -1.0)
+            ys.append(be.vec(yb[lo:hi]))
+            Zfs.append(be.features(torch.from_numpy(X[centres(yb.astype(np.float32), M, np.random.default_rng(b))])))
+        built = []
+        orig = be.precond
+        be.precond = lambda *a, **k: (built.append(rank), orig(*a, **k))[1]
+        alphas = odx.falkon_fit_lockstep(be, F, ys, Zfs, 5.0, 1e-4, 20, n_total=n, shard=shard)
+        be.precond = orig
+        assert built == ([rank] if rank < B else []), built            # one preconditioner per owner, none elsewhere
+        # the same problems one at a time in owner mode
+        for b in range(B):
+            ref = odx.falkon_fit(be, F, ys[b], Zfs[b], 5.0, 1e-4, 20, n_total=n, shard=shard, owner=b)
+            assert torch.allclose(alphas[b], ref, rtol=1e-9, atol=1e-12), b
+        if rank == world - 1:
+            ret["alphas"] = [a.numpy() for a in alphas]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,B", [(2, 2), (3, 2)])
+def test_lockstep_fit_equals_one_at_a_time(world, B):
+    """falkon_fit_lockstep (one all-gather + one reduce-scatter per CG step for B problems) gives every problem the
+    alpha of its own owner-mode fit, and of the single-process oracle."""
+    from oracle import falkon_ref as fr
+    from tests.synth import blob_problem, centres
+    n = 900
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_lockstep_worker, args=(world, port, n, B, ret), nprocs=world, join=True)
+    X, y, rng = blob_problem(n, 24, seed=13)
+    for b in range(B):
+        yb = np.where(np.arange(n) % 5 == b, 1.0, -1.0)
+        idx = centres(yb.astype(np.float32), 61, np.random.default_rng(b))
+        ref, _ = fr.falkon_fit(X.astype(np.float64), yb, idx, 5.0, 1e-4, maxiter=20, dtype=np.float64, pc_eps=1e-5, cg_epsilon=1e-7)
+        a = ret["alphas"][b]
+        assert np.linalg.norm(a - ref[:, 0]) / np.linalg.norm(ref[:, 0]) < 1e-6
