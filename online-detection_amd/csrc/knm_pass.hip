@@ -130,13 +130,19 @@ __global__ __launch_bounds__(NT) void knm_pass_kernel(const float* __restrict__ 
   }
 }
 
+// out[j] = sum_g slab[g][j] in a fixed order: a workgroup owns 64 columns; its 4 waves take the slabs g = w, w + 4, ...
+// (coalesced 512-B row segments), then wave 0 adds the 4 partial sums in wave order.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const double* __restrict__ slab, int64_t slab_ld, int nslab,
                                                           int64_t M, double* __restrict__ out) {
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= M) return;
+  __shared__ double part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t j = (int64_t)blockIdx.x * 64 + lane;
   double s = 0.0;
-  for (int g = 0; g < nslab; ++g) s += slab[(int64_t)g * slab_ld + j];
-  out[j] = s;
+  if (j < M)
+    for (int g = wave; g < nslab; g += 4) s += slab[(int64_t)g * slab_ld + j];
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && j < M) out[j] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
 struct PassCfg {
@@ -215,7 +221,7 @@ extern "C" int odx_knm_fwd_bwd(const float* K, int64_t ldk, int64_t n, int64_t M
   else if (cfg.nt == 512 && cfg.ch == 6) ODX_PASS_LAUNCH(512, 6, 2);
   else ODX_PASS_LAUNCH(1024, 5, 1);
   ODX_CHECK_LAUNCH("odx_knm_fwd_bwd");
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, s, slab, slab_ld, grid, M,
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(M, 64)), dim3(256), 0, s, slab, slab_ld, grid, M,
                      out);
   ODX_CHECK_LAUNCH("odx_knm_fwd_bwd(reduce)");
   return ODX_OK;
