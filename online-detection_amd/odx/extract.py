@@ -288,7 +288,9 @@ class OnlineFeatureExtractor:
         self.rpn_kw.update(rpn or {})
         self.mask_kw.update(mask or {})
 
-    def train(self, samples, use_only_gt_positives=True):
+    def train(self, samples, use_only_gt_positives=True, save_dir=None):
+        """`save_dir`: spill to the reference's on-disk feature cache (odx/storage.py) instead of returning the rows
+        (SAVE_FEATURES_DETECTOR / SAVE_FEATURES_RPN: the reference's train() returns nothing in that mode)."""
         samples = list(samples)[self.rank::self.world]
         m = self.model
         dev = next(m.parameters()).device
@@ -317,6 +319,13 @@ class OnlineFeatureExtractor:
                     act = m.mask_activation(maps[:len(gt_labels)])
                     hv_mask.add_image(act, project_masks_on_boxes(masks.to(dev), gt_boxes, act.shape[2]), list(gt_labels))
         out = {}
+        if save_dir:
+            from . import storage
+            if hv_rpn is not None:
+                storage.save_rpn_features(hv_rpn, save_dir)
+            if hv_det is not None:
+                storage.save_detector_features(hv_det, save_dir, use_only_gt_positives, hv_mask)
+            return out
         if hv_rpn is not None:
             out["rpn"] = hv_rpn.finalize()
         if hv_det is not None:

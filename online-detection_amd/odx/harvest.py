@@ -40,11 +40,14 @@ def box_iou_plus1(gt, prop):
 
 
 class _Growing:
-    """Append-only (rows, D) buffer with amortised growth."""
+    """Append-only (rows, D) buffer with amortised growth.  With `mark_every` it also remembers where the
+    reference would have closed a batch (a batch is closed by the first append that brings it to >= mark_every
+    rows), so that the on-disk feature cache can be cut into the reference's files (odx/storage.py)."""
 
-    def __init__(self, D, device, dtype=torch.float32, cap=256):
+    def __init__(self, D, device, dtype=torch.float32, cap=256, mark_every=None):
         self.buf = torch.empty((cap, D) if D else (cap,), dtype=dtype, device=device)
         self.n = 0
+        self.mark_every, self.marks = mark_every, []
 
     def append(self, rows):
         k = rows.shape[0]
@@ -55,9 +58,17 @@ class _Growing:
             self.buf = nb
         self.buf[self.n:self.n + k] = rows.to(self.buf.device)
         self.n += k
+        if self.mark_every and self.n - (self.marks[-1] if self.marks else 0) >= self.mark_every:
+            self.marks.append(self.n)
 
     def view(self):
         return self.buf[: self.n]
+
+    def batches(self, marks=None):
+        """The rows cut at the recorded batch ends (the last, open batch included even when empty — the
+        reference always has one more batch open)."""
+        edges = [0] + list(self.marks if marks is None else marks) + [self.n]
+        return [self.buf[a:b] for a, b in zip(edges[:-1], edges[1:])]
 
 
 def clamp_boxes_(b, img_size):
@@ -86,7 +97,7 @@ class DetectorHarvester:
         for _ in range(num_classes):
             self.add_new_class()
         self.negatives_to_pick = None
-        self._X = _Growing(feat_dim, self.device)
+        self._X = _Growing(feat_dim, self.device, mark_every=batch_size)
         self._Y = _Growing(4, self.device)
         self._C = _Growing(1, self.device)
         self.O = None
@@ -96,7 +107,7 @@ class DetectorHarvester:
         """Incremental use (box_head_getProposals.py:90-99): one more class with empty batches."""
         self.still_to_complete.append(self.num_classes)
         self.num_classes += 1
-        self._pos.append(_Growing(self.D, self.device))
+        self._pos.append(_Growing(self.D, self.device, mark_every=self.batch_size))
         if self.shuffle_negatives:
             self._neg.append([_Growing(self.D, self.device, cap=self.batch_size)])
         else:
@@ -235,13 +246,13 @@ class RPNHarvester:
         self.device = device or ('cuda' if torch.cuda.is_available() else 'cpu')
         self.negatives_to_pick = None
         self.anchors = None
-        self._pos = [_Growing(feat_dim, self.device) for _ in range(num_classes)]
+        self._pos = [_Growing(feat_dim, self.device, mark_every=batch_size) for _ in range(num_classes)]
         if shuffle_negatives:
             self._neg = [[_Growing(feat_dim, self.device, cap=batch_size)] for _ in range(num_classes)]
         else:
             self._neg = [[_Growing(feat_dim, self.device, cap=batch_size) for _ in range(iterations)] for _ in range(num_classes)]
         self.current_batch = [0] * num_classes
-        self._X, self._Y, self._C = _Growing(feat_dim, self.device), _Growing(4, self.device), _Growing(1, self.device)
+        self._X, self._Y, self._C = _Growing(feat_dim, self.device, mark_every=batch_size), _Growing(4, self.device), _Growing(1, self.device)
         self.O = None
 
     def _setup(self, anchors_all, img_size, W):
@@ -256,9 +267,11 @@ class RPNHarvester:
         # removing from the list it is iterating (:227-229), which skips the element after every
         # removal: of a run of empty types only every other one is dropped.  Kept on purpose.
         self.still_to_complete = list(range(self.A))
+        self.invisible = []
         for i in self.still_to_complete:
             if not bool((self.cls == i).any()):
                 self.still_to_complete.remove(i)
+                self.invisible.append(i)
         self.anchors_ids = list(self.still_to_complete)
 
     def _gather(self, t, sel):
@@ -389,8 +402,8 @@ class MaskHarvester:
 
     def add_new_class(self):
         self.num_classes += 1
-        self._pos.append(_Growing(self.D, self.device, cap=1024))
-        self._neg.append(_Growing(self.D, self.device, cap=1024))
+        self._pos.append(_Growing(self.D, self.device, cap=1024, mark_every=self.batch_size))
+        self._neg.append(_Growing(self.D, self.device, cap=1024, mark_every=self.batch_size))
 
     def add_image(self, mask_features, masks_gt, gt_labels_list):
         """mask_features (G, D, S, S) = relu(conv5_mask(head features of the ground-truth RoIs));

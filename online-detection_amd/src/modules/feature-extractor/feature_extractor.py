@@ -83,7 +83,7 @@ class FeatureExtractor(FeatureExtractorAbstract):
                 kw[name] = v
         return kw
 
-    def _harvest(self, cfg_path, parts, is_train, use_only_gt_positives, cfg_options, output_dir, label):
+    def _harvest(self, cfg_path, parts, is_train, use_only_gt_positives, cfg_options, output_dir, label, save_features=False):
         if 'samples' not in cfg_options:
             raise NotImplementedError(self._NEED_SAMPLES)
         cfg = self._cfg(cfg_path)
@@ -103,7 +103,9 @@ class FeatureExtractor(FeatureExtractorAbstract):
             return t0, ex.test(cfg_options['samples'])
         ex = OnlineFeatureExtractor(model, num_classes, parts=parts, det=det_kw, rpn=self._kw(cfg, 'RPN'), mask=mask_kw,
                                     rank=rank, world=world)
-        out = ex.train(cfg_options['samples'], use_only_gt_positives)
+        if save_features and not output_dir:
+            raise ValueError('Output directory must be specified.')       # the reference prints this and quits
+        out = ex.train(cfg_options['samples'], use_only_gt_positives, save_dir=output_dir if save_features else None)
         if output_dir:
             with open(os.path.join(output_dir, "result.txt"), "a") as fid:
                 dt = time.time() - t0
@@ -116,10 +118,12 @@ class FeatureExtractor(FeatureExtractorAbstract):
         test time -> test_boxes."""
         parts = ("detector", "mask") if extract_features_segmentation else ("detector",)
         t0, out = self._harvest(self.cfg_path_target_task, parts, is_train, use_only_gt_positives_detection, cfg_options,
-                                output_dir, "Detector's")
+                                output_dir, "Detector's", save_features)
         self.start_of_feature_extraction_time_detection = t0
         if not is_train:
             return out
+        if save_features:
+            return None
         neg, pos, COXY = out["detector"]
         if extract_features_segmentation:
             return neg, pos, COXY, out["mask"][0], out["mask"][1]
@@ -127,9 +131,9 @@ class FeatureExtractor(FeatureExtractorAbstract):
 
     def extractRPNFeatures(self, is_train, output_dir=None, save_features=False, cfg_options={}):
         """-> RPN negatives, positives, COXY  (feature_extractor_RPN/extract_features_RPN.py:218)."""
-        t0, out = self._harvest(self.cfg_path_RPN, ("rpn",), True, True, cfg_options, output_dir, "RPN's")
+        t0, out = self._harvest(self.cfg_path_RPN, ("rpn",), True, True, cfg_options, output_dir, "RPN's", save_features)
         self.start_of_feature_extraction_time_RPN = t0
-        return out["rpn"]
+        return None if save_features else out["rpn"]
 
     def extractFeaturesRPNDetector(self, is_train, output_dir=None, save_features=False, extract_features_segmentation=False,
                                    use_only_gt_positives_detection=True, cfg_options={}):
@@ -137,11 +141,13 @@ class FeatureExtractor(FeatureExtractorAbstract):
         positives])  (feature_extractor_RPN_detector/extract_features_rpn_detector.py:354-364); test time -> test_boxes."""
         parts = ("rpn", "detector", "mask") if extract_features_segmentation else ("rpn", "detector")
         t0, out = self._harvest(self.cfg_path_target_task, parts, is_train, use_only_gt_positives_detection, cfg_options,
-                                output_dir, "RPN and detector's")
+                                output_dir, "RPN and detector's", save_features)
         self.start_of_feature_extraction_time = t0
         self.end_of_feature_extraction_time = time.time()
         if not is_train:
             return out
+        if save_features:
+            return None
         res = tuple(out["rpn"]) + tuple(out["detector"])
         if extract_features_segmentation:
             res = res + tuple(out["mask"])

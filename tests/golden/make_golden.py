@@ -932,7 +932,125 @@ def make_eval():
     print("eval_golden.npz:", len(out), "arrays; mAP@0.5 voc07 =", out["iou50_voc07_map"])
 
 
+# --------------------------------------------------------------------------- f2: on-disk feature caches
+def _flush_like_reference(model_part, result_dir, sub, classes, feat_size, with_positives=True):
+    """The end-of-harvest flush (extract_features_detector.py:193-248 / extract_features_RPN.py:171-198), restated:
+    it lives inside train() methods that build datasets and models and cannot be executed here."""
+    d = os.path.join(result_dir, sub)
+    for clss in classes:
+        for batch in range(len(model_part.negatives[clss])):
+            if model_part.negatives[clss][batch].size()[0] > 0:
+                torch.save(model_part.negatives[clss][batch], os.path.join(d, "negatives_cl_{}_batch_{}".format(clss, batch)))
+        if with_positives:
+            if model_part.positives[clss][0].size()[0] == 0 and len(model_part.positives[clss]) == 1:
+                torch.save(torch.empty((0, feat_size)), os.path.join(d, "positives_cl_{}_batch_{}".format(clss, 0)))
+            else:
+                for batch in range(len(model_part.positives[clss])):
+                    if model_part.positives[clss][batch].size()[0] > 0:
+                        torch.save(model_part.positives[clss][batch], os.path.join(d, "positives_cl_{}_batch_{}".format(clss, batch)))
+    for i in range(len(model_part.X)):
+        if model_part.X[i].size()[0] > 0:
+            torch.save(model_part.X[i], os.path.join(d, "reg_x_batch_{}".format(i)))
+            torch.save(model_part.C[i], os.path.join(d, "reg_c_batch_{}".format(i)))
+            torch.save(model_part.Y[i], os.path.join(d, "reg_y_batch_{}".format(i)))
+
+
+def _collect(result_dir, sub, tag, out):
+    d = os.path.join(result_dir, sub)
+    names = sorted(os.listdir(d))
+    for n in names:
+        out["%s/%s" % (tag, n)] = torch.load(os.path.join(d, n)).numpy()
+    out["%s/__files__" % tag] = np.array(names)
+
+
+def make_feature_cache():
+    """Runs the reference harvesters with save_features=True on the inputs of harvest_golden / rpn_harvest_golden
+    (same seeds) and records every file they write."""
+    import tempfile
+    from torch import nn
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT), os.pardir, "online-detection_amd"))
+    from odx.extract import cell_anchors, grid_anchors
+    base = "src/modules/feature-extractor/mrcnn_modified/"
+    out = {}
+    # ---- detector
+    ev = load_ref(base + "utils/evaluations.py", "ref_evaluations")
+    src = _strip_imports(open(os.path.join(REF, base, "modeling/roi_heads/box_head/box_head_getProposals.py")).read())
+    ns = {"compute_overlap_torch": ev.compute_overlap_torch, "__name__": "ref_box_head_getProposals"}
+    exec(compile(src.replace("'cuda'", "'cpu'"), "box_head_getProposals.py", "exec"), ns)
+    Head = ns["ROIBoxHead"]
+    hg = np.load(os.path.join(OUT, "harvest_golden.npz"))
+    D, C, ITER, BS, NIMG = (int(hg[k]) for k in ("D", "C", "ITER", "BS", "NIMG"))
+    for shuffle in (False, True):
+        with tempfile.TemporaryDirectory() as tmp:
+            os.mkdir(os.path.join(tmp, "features_detector"))
+            h = Head.__new__(Head)
+            nn.Module.__init__(h)
+            dcfg = types.SimpleNamespace(NUM_CLASSES=C, ITERATIONS=ITER, BATCH_SIZE=BS, EXTRACT_ONLY_GT_POSITIVES=True,
+                                         SHUFFLE_NEGATIVES=shuffle, NEG_IOU_THRESH=0.3, FEATURES_DEVICE="cpu")
+            h.cfg = types.SimpleNamespace(MINIBOOTSTRAP=types.SimpleNamespace(DETECTOR=dcfg), DEMO=types.SimpleNamespace(INCREMENTAL_TRAIN=False),
+                                          REGRESSORS=types.SimpleNamespace(MIN_OVERLAP=0.6), NUM_IMAGES=NIMG)
+            h.training_device = "cpu"
+            h.save_features = True
+            h.avgpool = nn.AdaptiveAvgPool2d(1)
+            h.feature_extractor = types.SimpleNamespace(out_channels=D)
+            h.initialize_online_detection_params()
+            torch.manual_seed(123)
+            for im in range(NIMG):
+                x, allp, gt = (torch.from_numpy(hg["%s_%d" % (k, im)]) for k in ("x", "prop", "gt"))
+                labels = hg["labels_%d" % im].tolist()
+                h.feature_extractor = lambda features, proposals, _x=x: _x.view(_x.shape[0], D, 1, 1)
+                h.feature_extractor.out_channels = D
+                gl = torch.tensor(labels, dtype=torch.uint8).view(-1, 1) if labels else None
+                h.forward_train(None, [ResizableBoxList(allp.clone(), (320, 240))], gt_bbox=ResizableBoxList(gt.clone(), (320, 240)),
+                                gt_label=gl, img_size=[320, 240], gt_labels_list=labels, result_dir=tmp)
+            _flush_like_reference(h, tmp, "features_detector", range(C), D)
+            _collect(tmp, "features_detector", "det_shuf" if shuffle else "det_fill", out)
+    # ---- RPN
+    src = _strip_imports(open(os.path.join(REF, base, "modeling/rpn/rpn_getProposals.py")).read())
+    reg = types.SimpleNamespace(RPN_HEADS=_Registry())
+    ns = {"registry": reg, "boxlist_iou": ref_boxlist_iou, "cat_boxlist": ref_cat_boxlist, "BoxList": FieldBoxList,
+          "__name__": "ref_rpn_getProposals"}
+    exec(compile(src.replace("'cuda'", "'cpu'"), "rpn_getProposals.py", "exec"), ns)
+    RPN = ns["RPNModule"]
+    rg = np.load(os.path.join(OUT, "rpn_harvest_golden.npz"))
+    D, A, H, W, ITER, BS, NIMG = (int(rg[k]) for k in ("D", "A", "H", "W", "ITER", "BS", "NIMG"))
+    img = (W * 16, H * 16)
+    anchors_all = grid_anchors(H, W, 16, cell_anchors(16))
+    vis = (anchors_all[:, 0] >= 0) & (anchors_all[:, 1] >= 0) & (anchors_all[:, 2] < img[0]) & (anchors_all[:, 3] < img[1])
+    for shuffle in (False, True):
+        with tempfile.TemporaryDirectory() as tmp:
+            os.mkdir(os.path.join(tmp, "features_RPN"))
+            m = RPN.__new__(RPN)
+            nn.Module.__init__(m)
+            rcfg = types.SimpleNamespace(NUM_CLASSES=A, ITERATIONS=ITER, BATCH_SIZE=BS, NEG_IOU_THRESH=0.3, POS_IOU_THRESH=0.7,
+                                         SHUFFLE_NEGATIVES=shuffle, FEATURES_DEVICE="cpu")
+            m.cfg = types.SimpleNamespace(MINIBOOTSTRAP=types.SimpleNamespace(RPN=rcfg), DEMO=types.SimpleNamespace(INCREMENTAL_TRAIN=False),
+                                          NUM_IMAGES=NIMG)
+            m.save_features = True
+            m.prev_classifiers = m.prev_feature_ids = None
+
+            def anchor_generator(images_, features_):
+                b = FieldBoxList(anchors_all.clone(), img)
+                b.add_field("visibility", vis.clone())
+                return [[b]]
+            m.anchor_generator = anchor_generator
+            m.initialize_online_rpn_params()
+            torch.manual_seed(321)
+            with redirect_stdout(io.StringIO()):
+                for im in range(NIMG):
+                    t, gt = torch.from_numpy(rg["t_%d" % im]), torch.from_numpy(rg["gt_%d" % im])
+                    m.head = lambda feats, _t=t: [_t.unsqueeze(0)]
+                    m.forward(None, None, gt_bbox=FieldBoxList(gt.clone(), img), img_size=None, result_dir=tmp)
+            _flush_like_reference(m, tmp, "features_RPN", m.anchors_ids, D)
+            _collect(tmp, "features_RPN", "rpn_shuf" if shuffle else "rpn_fill", out)
+    np.savez_compressed(os.path.join(OUT, "feature_cache_golden.npz"), **out)
+    print("feature_cache_golden.npz:", len(out), "entries;", {k: len(v) for k, v in out.items() if k.endswith("__files__")})
+
+
 if __name__ == "__main__":
+    if "--only-feature-cache" in sys.argv:
+        make_feature_cache()
+        sys.exit(0)
     if "--only-postprocess" in sys.argv:
         make_postprocess()
         make_eval()
@@ -959,3 +1077,4 @@ if __name__ == "__main__":
     make_mask_harvest()
     make_postprocess()
     make_eval()
+    make_feature_cache()

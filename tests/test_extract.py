@@ -110,6 +110,14 @@ def test_end_to_end_pipeline_on_gpu(tmp_path):
     assert tuple(scores.shape) == (boxes.shape[0], C + 1) and tuple(deltas.shape) == (boxes.shape[0], 4 * (C + 1))
     assert torch.isfinite(scores).all() and torch.isfinite(deltas).all()
     assert "Detector's feature extraction time" in open(os.path.join(str(tmp_path), "result.txt")).read()
+    # save_features=True: nothing is returned, the reference's cache files appear and replay to the same rows
+    torch.manual_seed(1)
+    assert fe.extractFeatures(True, output_dir=str(tmp_path), save_features=True, cfg_options={"samples": samples, "model": model}) is None
+    pos2, neg2 = u.load_features_classifier(os.path.join(str(tmp_path), "features_detector"))
+    COXY2 = u.load_features_regressor(os.path.join(str(tmp_path), "features_detector"))
+    assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(pos2, positives))
+    assert torch.equal(COXY2["X"].cpu(), COXY["X"].cpu()) and torch.equal(COXY2["Y"].cpu(), COXY["Y"].cpu())
+    assert sum(len(b) for b in neg2[0]) == sum(len(b) for b in negatives[0])
 
 
 def _samples_with_masks(n, H, W, C, seed=0):
