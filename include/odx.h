@@ -207,6 +207,14 @@ int64_t odx_nms_workspace_bytes(int R);
 int odx_nms_f32(const float* boxes_sorted, int R, float iou_threshold, unsigned char* keep,
                 void* workspace, int64_t workspace_bytes, odx_stream_t stream);
 
+/* Masker / paste_mask_in_image (mrcnn_modified/modeling/roi_heads/mask_head/inference.py:119-191), all detections
+ * of one image at once: masks (R, S, S) f32 probabilities, boxes (R, 4) xyxy f32 -> out (R, im_h, im_w) u8 0/1:
+ * zero-pad by `padding`, expand the box by (S + 2 padding) / S, truncate to integers, bilinear resize
+ * (align_corners = False) to the box, `> thresh`, cropped to the image.                                        */
+int odx_paste_masks_u8(const float* masks, const float* boxes, int R, int S, int im_h, int im_w, float thresh,
+                       int padding, unsigned char* out, odx_stream_t stream);
+
+
 #ifdef __cplusplus
 }
 #endif

@@ -136,6 +136,47 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const unsigned long long
   }
 }
 
+// ---------------------------------------------------------------- mask pasting (Masker / paste_mask_in_image)
+// One thread per image pixel and detection: zero-pad the S x S mask by `padding`, grow the box by the same ratio,
+// truncate it to integers, resize the padded mask to the box bilinearly (align_corners = False) and threshold.
+__global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restrict__ masks, const float* __restrict__ boxes,
+                                                          int R, int S, int im_h, int im_w, float thresh, int padding,
+                                                          unsigned char* __restrict__ out) {
+  const int r = blockIdx.y;
+  const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= (int64_t)im_h * im_w) return;
+  const int y = (int)(pix / im_w), x = (int)(pix - (int64_t)y * im_w);
+  const int Sp = S + 2 * padding;
+  const float scale = (float)Sp / (float)S;
+  const float* b = boxes + 4 * r;
+  float w_half = (b[2] - b[0]) * 0.5f, h_half = (b[3] - b[1]) * 0.5f;
+  const float x_c = (b[2] + b[0]) * 0.5f, y_c = (b[3] + b[1]) * 0.5f;
+  w_half *= scale;
+  h_half *= scale;
+  const int bx0 = (int)(x_c - w_half), bx2 = (int)(x_c + w_half), by0 = (int)(y_c - h_half), by2 = (int)(y_c + h_half);
+  const int w = max(bx2 - bx0 + 1, 1), h = max(by2 - by0 + 1, 1);
+  const int x_0 = max(bx0, 0), x_1 = min(bx2 + 1, im_w), y_0 = max(by0, 0), y_1 = min(by2 + 1, im_h);
+  unsigned char v = 0;
+  if (x >= x_0 && x < x_1 && y >= y_0 && y < y_1) {
+    const float sx = (float)Sp / (float)w, sy = (float)Sp / (float)h;
+    float fx = sx * ((float)(x - bx0) + 0.5f) - 0.5f, fy = sy * ((float)(y - by0) + 0.5f) - 0.5f;
+    fx = fx < 0.f ? 0.f : fx;
+    fy = fy < 0.f ? 0.f : fy;
+    const int ix0 = (int)fx, iy0 = (int)fy;
+    const int ix1 = ix0 + (ix0 < Sp - 1 ? 1 : 0), iy1 = iy0 + (iy0 < Sp - 1 ? 1 : 0);
+    const float lx1 = fx - (float)ix0, ly1 = fy - (float)iy0, lx0 = 1.f - lx1, ly0 = 1.f - ly1;
+    const float* m = masks + (int64_t)r * S * S;
+    auto at = [&](int yy, int xx) -> float {
+      yy -= padding;
+      xx -= padding;
+      return (yy >= 0 && yy < S && xx >= 0 && xx < S) ? m[yy * S + xx] : 0.f;
+    };
+    const float val = ly0 * (lx0 * at(iy0, ix0) + lx1 * at(iy0, ix1)) + ly1 * (lx0 * at(iy1, ix0) + lx1 * at(iy1, ix1));
+    v = val > thresh ? 1 : 0;
+  }
+  out[((int64_t)r * im_h + y) * im_w + x] = v;
+}
+
 }  // namespace odx
 
 using namespace odx;
@@ -178,5 +219,16 @@ extern "C" int odx_nms_f32(const float* boxes_sorted, int R, float iou_threshold
   ODX_CHECK_LAUNCH("odx_nms_f32(mask)");
   hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(64), 0, s, mask, R, words, keep);
   ODX_CHECK_LAUNCH("odx_nms_f32(reduce)");
+  return ODX_OK;
+}
+
+extern "C" int odx_paste_masks_u8(const float* masks, const float* boxes, int R, int S, int im_h, int im_w, float thresh,
+                                  int padding, unsigned char* out, odx_stream_t stream) {
+  if (R <= 0) return ODX_OK;
+  ODX_REQUIRE(masks && boxes && out && S > 0 && im_h > 0 && im_w > 0 && padding >= 0, "odx_paste_masks_u8: bad argument");
+  ODX_REQUIRE(R < 65536 && (int64_t)im_h * im_w < (1ll << 31), "odx_paste_masks_u8: too many detections or pixels");
+  hipLaunchKernelGGL(paste_masks_kernel, dim3((unsigned)ceil_div((int64_t)im_h * im_w, 256), (unsigned)R), dim3(256), 0,
+                     as_stream(stream), masks, boxes, R, S, im_h, im_w, thresh, padding, out);
+  ODX_CHECK_LAUNCH("odx_paste_masks_u8");
   return ODX_OK;
 }

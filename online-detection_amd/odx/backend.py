@@ -289,6 +289,17 @@ class HipBackend:
                                                  int(sampling_ratio), _p(out), self._stream()), "odx_roi_align_fwd_f32")
         return out
 
+    def paste_masks(self, masks, boxes, im_h, im_w, thresh=0.5, padding=1):
+        """Masker: masks (R, S, S) f32, boxes (R, 4) -> (R, im_h, im_w) bool."""
+        masks = masks.to(device=self.device, dtype=torch.float32).contiguous()
+        boxes = boxes.to(device=self.device, dtype=torch.float32).contiguous()
+        R, S = masks.shape[0], masks.shape[-1]
+        out = torch.empty((R, im_h, im_w), dtype=torch.uint8, device=self.device)
+        if R:
+            hip.check(self.lib.odx_paste_masks_u8(_p(masks), _p(boxes), R, S, int(im_h), int(im_w), float(thresh), int(padding),
+                                                  _p(out), self._stream()), "odx_paste_masks_u8")
+        return out.bool()
+
     def nms(self, boxes, scores, iou_threshold):
         """Indices of the boxes kept by greedy NMS, in descending score order (maskrcnn_benchmark
         layers.nms contract)."""

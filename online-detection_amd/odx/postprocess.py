@@ -1,5 +1,8 @@
 """Test-time detection post-processing and VOC-style evaluation ("next" row f3).
 
+masks            MaskPostProcessor + Masker (mrcnn_modified/modeling/roi_heads/mask_head/inference.py:27-62,119-191):
+                 sigmoid of the pixel scores, channel of the predicted label, pasted into the image on the GPU;
+                 segmentation AP = the same matching with mask IoU, `difficult` not consulted (icw_eval.py:404-518).
 post-processing  OnlineDetectionPostProcessor.forward / filter_results
                  (src/modules/accuracy-evaluator/OnlineDetectionPostProcessor.py:12-79): decode the
                  per-class box deltas against the proposals (+1 widths, clamp), clip, keep scores
@@ -17,7 +20,7 @@ import numpy as np
 import torch
 
 from . import backend as _backend
-from .utils import decode_boxes_detector
+from .utils import decode_boxes_detector, mask_iou
 
 
 class _Boxes:
@@ -92,6 +95,17 @@ class OnlineDetectionPostProcessor:
     __call__ = forward
 
 
+def select_class_masks(x, labels):
+    """x (R, C+1, S, S) pixel scores -> (R, S, S) probabilities of each detection's own label (inference.py:38-45)."""
+    idx = torch.arange(x.shape[0], device=x.device)
+    return x.sigmoid()[idx, labels.to(x.device)]
+
+
+def paste_masks(mask_prob, boxes, img_size, thresh=0.5, padding=1):
+    """Masker: (R, S, S) probabilities + (R, 4) boxes -> (R, height, width) bool, img_size = (width, height)."""
+    return _backend.get_backend().paste_masks(mask_prob, boxes, img_size[1], img_size[0], thresh, padding)
+
+
 def _iou_plus1(a, b):
     lt = np.maximum(a[:, None, :2], b[None, :, :2])
     rb = np.minimum(a[:, None, 2:], b[None, :, 2:])
@@ -102,14 +116,16 @@ def _iou_plus1(a, b):
     return inter / (aa[:, None] + ab[None, :] - inter)
 
 
-def detection_prec_rec(preds, gts, iou_thresh=0.5):
+def detection_prec_rec(preds, gts, iou_thresh=0.5, key="boxes"):
     """preds: per image dict(boxes, labels, scores); gts: per image dict(boxes, labels[, difficult]).
+    key="masks": pasted (K, H, W) masks instead of boxes, mask IoU, `difficult` ignored (segmentation AP).
     Returns (prec, rec): lists indexed by class id (None where undefined)."""
     n_pos, score, match = defaultdict(int), defaultdict(list), defaultdict(list)
+    seg = key == "masks"
     for p, g in zip(preds, gts):
-        pb, pl, ps = (np.asarray(p[k]) for k in ("boxes", "labels", "scores"))
-        gb, gl = np.asarray(g["boxes"]), np.asarray(g["labels"])
-        gd = np.asarray(g.get("difficult", np.zeros(len(gl), dtype=bool))).astype(bool)
+        pb, pl, ps = (np.asarray(p[k]) for k in (key, "labels", "scores"))
+        gb, gl = np.asarray(g[key]), np.asarray(g["labels"])
+        gd = np.zeros(len(gl), dtype=bool) if seg else np.asarray(g.get("difficult", np.zeros(len(gl), dtype=bool))).astype(bool)
         for l in np.unique(np.concatenate((pl, gl)).astype(int)):
             pm = pl == l
             order = ps[pm].argsort()[::-1]
@@ -123,10 +139,14 @@ def detection_prec_rec(preds, gts, iou_thresh=0.5):
             if len(gbl) == 0:
                 match[l].extend((0,) * pbl.shape[0])
                 continue
-            a, b = pbl.copy(), gbl.copy()      # arithmetic stays in the boxes' own dtype (f32 from the heads)
-            a[:, 2:] += 1          # VOC evaluates integer-typed boxes
-            b[:, 2:] += 1
-            iou = _iou_plus1(a, b)
+            if seg:
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    iou = mask_iou(pbl.astype(bool), np.rint(gbl).astype(bool))
+            else:
+                a, b = pbl.copy(), gbl.copy()      # arithmetic stays in the boxes' own dtype (f32 from the heads)
+                a[:, 2:] += 1          # VOC evaluates integer-typed boxes
+                b[:, 2:] += 1
+                iou = _iou_plus1(a, b)
             idx = iou.argmax(axis=1)
             idx[iou.max(axis=1) < iou_thresh] = -1
             taken = np.zeros(len(gbl), dtype=bool)
@@ -168,8 +188,8 @@ def average_precision(prec, rec, use_07_metric=True):
     return ap
 
 
-def eval_detection(preds, gts, iou_thresh=0.5, use_07_metric=True):
-    prec, rec = detection_prec_rec(preds, gts, iou_thresh)
+def eval_detection(preds, gts, iou_thresh=0.5, use_07_metric=True, key="boxes"):
+    prec, rec = detection_prec_rec(preds, gts, iou_thresh, key)
     ap = average_precision(prec, rec, use_07_metric)
     return {"ap": ap, "map": np.nanmean(ap)}
 

@@ -97,3 +97,36 @@ def compute_overlap(gt, prop):
     ov = inter / (ga + pa - inter)
     ov = np.where(xmax - xmin + 1 > 0, ov, 0.0)
     return np.where(ymax - ymin + 1 > 0, ov, 0.0)
+
+
+def paste_mask(mask, box, im_h, im_w, thresh=0.5, padding=1):
+    """paste_mask_in_image (mrcnn_modified/modeling/roi_heads/mask_head/inference.py:119-159) in plain loops:
+    zero-pad, expand the box by (S + 2 pad) / S, truncate to int, bilinear resize (align_corners=False, f32), threshold."""
+    f = np.float32
+    S = mask.shape[-1]
+    Sp = S + 2 * padding
+    pm = np.zeros((Sp, Sp), dtype=f)
+    pm[padding:Sp - padding, padding:Sp - padding] = mask
+    scale = f(float(Sp) / S)
+    b = np.asarray(box, dtype=f)
+    w_half, h_half = (b[2] - b[0]) * f(0.5) * scale, (b[3] - b[1]) * f(0.5) * scale
+    x_c, y_c = (b[2] + b[0]) * f(0.5), (b[3] + b[1]) * f(0.5)
+    bx0, bx2, by0, by2 = int(x_c - w_half), int(x_c + w_half), int(y_c - h_half), int(y_c + h_half)
+    w, h = max(bx2 - bx0 + 1, 1), max(by2 - by0 + 1, 1)
+    out = np.zeros((im_h, im_w), dtype=bool)
+    sx, sy = f(Sp) / f(w), f(Sp) / f(h)
+    for y in range(max(by0, 0), min(by2 + 1, im_h)):
+        fy = max(sy * (f(y - by0) + f(0.5)) - f(0.5), f(0))
+        iy0 = int(fy)
+        iy1 = iy0 + (1 if iy0 < Sp - 1 else 0)
+        ly1 = f(fy - f(iy0))
+        ly0 = f(1) - ly1
+        for x in range(max(bx0, 0), min(bx2 + 1, im_w)):
+            fx = max(sx * (f(x - bx0) + f(0.5)) - f(0.5), f(0))
+            ix0 = int(fx)
+            ix1 = ix0 + (1 if ix0 < Sp - 1 else 0)
+            lx1 = f(fx - f(ix0))
+            lx0 = f(1) - lx1
+            v = ly0 * (lx0 * pm[iy0, ix0] + lx1 * pm[iy0, ix1]) + ly1 * (lx0 * pm[iy1, ix0] + lx1 * pm[iy1, ix1])
+            out[y, x] = v > thresh
+    return out

@@ -1047,7 +1047,111 @@ def make_feature_cache():
     print("feature_cache_golden.npz:", len(out), "entries;", {k: len(v) for k, v in out.items() if k.endswith("__files__")})
 
 
+# --------------------------------------------------------------------------- f3: mask pasting + segmentation AP
+def make_masks():
+    import torch.nn.functional as Fn
+    base = "src/modules/feature-extractor/mrcnn_modified/"
+    src = open(os.path.join(REF, base, "modeling/roi_heads/mask_head/inference.py")).read()
+    src = "\n".join(l for l in src.splitlines() if not l.strip().startswith("from maskrcnn_benchmark"))
+
+    class _BL(FieldBoxList):
+        def convert(self, mode):
+            return self
+
+        def has_field(self, k):
+            return k in self.extra_fields
+    ns = {"interpolate": Fn.interpolate, "BoxList": _BL, "__name__": "ref_mask_inference"}
+    exec(compile(src, "mask_inference.py", "exec"), ns)
+    out = {}
+    g = torch.Generator().manual_seed(2024)
+    S, H, W, R = 14, 60, 80, 9
+    logits = torch.randn(R, 4, S, S, generator=g) * 2
+    labels = torch.randint(1, 4, (R,), generator=g)
+    boxes = torch.rand(R, 2, generator=g) * torch.tensor([50.0, 30.0])
+    boxes = torch.cat([boxes, boxes + 6 + torch.rand(R, 2, generator=g) * 35], 1)
+    boxes[0] = torch.tensor([-6.3, -4.2, 20.7, 18.1])          # sticks out top-left
+    boxes[1] = torch.tensor([60.0, 40.0, 95.5, 75.2])          # sticks out bottom-right
+    boxes[2] = torch.tensor([30.2, 20.9, 30.9, 21.3])          # sub-pixel box
+    boxes[3] = torch.tensor([10.0, 10.0, 40.0, 12.0])          # thin
+    pp = ns["MaskPostProcessor"](ns["Masker"](threshold=0.5, padding=1))
+    bl = _BL(boxes.clone(), (W, H))
+    bl.add_field("labels", labels)
+    res = pp(logits.clone(), [bl])[0]
+    out["logits"], out["labels"], out["boxes"] = logits.numpy(), labels.numpy(), boxes.numpy()
+    out["HW"] = np.array([H, W], dtype=np.int64)
+    out["pasted"] = res.get_field("mask").numpy().squeeze(1)
+    prob = logits.sigmoid()[torch.arange(R), labels]
+    out["prob"] = prob.numpy()
+    # segmentation AP on pasted masks (icw_eval.eval_segmentation_ycbv), masks given unpasted as the reference does
+    esrc = open(os.path.join(REF, base, "data/datasets/evaluation/icubworld/icw_eval.py")).read()
+    esrc = "\n".join(l for l in esrc.splitlines() if not l.strip().startswith(("from maskrcnn_benchmark", "from mrcnn_modified", "from py_od_utils", "import cv2")))
+    utils = load_ref("src/py_od_utils.py", "py_od_utils")
+    ens = {"BoxList": _BL, "boxlist_iou": None, "Masker": ns["Masker"], "mask_iou": utils.mask_iou, "__name__": "ref_icw_eval_seg"}
+    with redirect_stdout(io.StringIO()):
+        exec(compile(esrc.replace("'cuda'", "'cpu'"), "icw_eval.py", "exec"), ens)
+
+    class _GTMasks:
+        def __init__(self, m):
+            self.m = m
+
+        def get_mask_tensor(self):
+            return self.m
+    rng = np.random.RandomState(5)
+    preds, gts = [], []
+    NIMG = 14
+    out["seg_NIMG"] = np.int64(NIMG)
+    for im in range(NIMG):
+        G = rng.randint(1, 4)
+        gm = np.zeros((G, H, W), dtype=np.float32)
+        gl = rng.randint(1, 4, size=G)
+        gboxes = []
+        for k in range(G):
+            x1, y1 = rng.randint(0, W - 30), rng.randint(0, H - 25)
+            x2, y2 = x1 + rng.randint(12, 29), y1 + rng.randint(10, 24)
+            gm[k, y1:y2, x1:x2] = 1.0
+            gboxes.append([x1, y1, x2 - 1, y2 - 1])
+        P = rng.randint(1, 5)
+        pm = torch.rand(P, 1, S, S, generator=g)
+        pbx, hits = [], []
+        for k in range(P):
+            if rng.rand() < 0.75:
+                j = rng.randint(G)
+                b = np.array(gboxes[j], dtype=np.float32) + rng.randn(4) * 1.5
+                pm[k, 0] = 0.5 + 0.5 * torch.rand(S, S, generator=g)          # mostly "inside"
+                hit = j
+            else:
+                x1, y1 = rng.randint(0, W - 30), rng.randint(0, H - 25)
+                b = np.array([x1, y1, x1 + rng.randint(8, 29), y1 + rng.randint(8, 24)], dtype=np.float32)
+                hit = rng.randint(G)
+            pbx.append(b)
+            hits.append(hit)
+        pbx = np.array(pbx, dtype=np.float32)
+        pl = np.array([gl[hits[k]] if rng.rand() < 0.85 else rng.randint(1, 4) for k in range(P)], dtype=np.int64)
+        ps = rng.rand(P).astype(np.float32)
+        p = _BL(torch.from_numpy(pbx), (W, H))
+        p.add_field("labels", torch.from_numpy(pl))
+        p.add_field("scores", torch.from_numpy(ps))
+        p.add_field("mask", pm)
+        q = _BL(torch.tensor(gboxes, dtype=torch.float32), (W, H))
+        q.add_field("labels", torch.from_numpy(gl.astype(np.int64)))
+        q.add_field("difficult", torch.zeros(G, dtype=torch.uint8))
+        q.add_field("masks", _GTMasks(torch.from_numpy(gm)))
+        preds.append(p)
+        gts.append(q)
+        for k, v in (("seg_pm", pm.numpy().squeeze(1)), ("seg_pb", pbx), ("seg_pl", pl), ("seg_ps", ps), ("seg_gm", gm), ("seg_gl", gl.astype(np.int64))):
+            out["%s_%d" % (k, im)] = v
+    with np.errstate(all="ignore"):
+        for m07 in (True, False):
+            r = ens["eval_segmentation_ycbv"](preds, gts, iou_thresh=0.5, use_07_metric=m07)
+            out["seg_ap_%s" % ("voc07" if m07 else "area")] = np.asarray(r["ap"], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "masks_golden.npz"), **out)
+    print("masks_golden.npz:", len(out), "arrays; pasted pixels", int(out["pasted"].sum()), "seg AP", out["seg_ap_voc07"])
+
+
 if __name__ == "__main__":
+    if "--only-masks" in sys.argv:
+        make_masks()
+        sys.exit(0)
     if "--only-feature-cache" in sys.argv:
         make_feature_cache()
         sys.exit(0)
@@ -1078,3 +1182,4 @@ if __name__ == "__main__":
     make_postprocess()
     make_eval()
     make_feature_cache()
+    make_masks()

@@ -135,6 +135,12 @@ class OracleBackend:
         from oracle import roi_ref
         return torch.from_numpy(roi_ref.roi_align(feat.numpy(), rois.numpy(), spatial_scale, output_size, sampling_ratio)).float()
 
+    def paste_masks(self, masks, boxes, im_h, im_w, thresh=0.5, padding=1):
+        from oracle import roi_ref
+        m, b = masks.numpy(), boxes.numpy()
+        return torch.from_numpy(np.stack([roi_ref.paste_mask(m[i], b[i], im_h, im_w, thresh, padding) for i in range(len(m))])
+                                if len(m) else np.zeros((0, im_h, im_w), dtype=bool))
+
     def nms(self, boxes, scores, thr):
         from oracle import roi_ref
         return torch.from_numpy(roi_ref.nms(boxes.numpy(), scores.numpy(), thr))

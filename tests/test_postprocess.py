@@ -108,3 +108,62 @@ def test_dropin_class_contract():
     assert out.size == (iw, ih) and len(out) == dpi
     assert out.get_field("labels").tolist() == g["c2_labels"].tolist()
     np.testing.assert_allclose(out.bbox.numpy(), g["c2_boxes"], atol=1e-4)
+
+
+# ------------------------------------------------------------------ masks: class selection, pasting, segmentation AP
+MG = np.load(os.path.join(GOLD, "masks_golden.npz"))
+
+
+def check_pasting(device):
+    from odx.postprocess import paste_masks, select_class_masks
+    H, W = (int(v) for v in MG["HW"])
+    prob = select_class_masks(torch.from_numpy(MG["logits"]).to(device), torch.from_numpy(MG["labels"]))
+    np.testing.assert_allclose(prob.cpu().numpy(), MG["prob"], atol=1e-6)
+    got = paste_masks(torch.from_numpy(MG["prob"]).to(device), torch.from_numpy(MG["boxes"]).to(device), (W, H)).cpu().numpy()
+    ref = MG["pasted"].astype(bool)
+    assert got.shape == ref.shape
+    # identical apart from pixels whose interpolated value sits within rounding of the 0.5 threshold
+    assert (got != ref).sum() <= 2, int((got != ref).sum())
+    assert got[2].sum() == ref[2].sum() and got[0].any() and got[1].any()       # sub-pixel and out-of-image boxes
+
+
+def test_mask_pasting_oracle_matches_reference():
+    from tests.oracle_backend import OracleBackend
+    odx.set_backend(OracleBackend(np.float64))
+    try:
+        check_pasting("cpu")
+    finally:
+        odx.set_backend(None)
+
+
+@pytest.mark.gpu
+def test_mask_pasting_on_gpu_matches_reference_and_oracle():
+    from oracle import roi_ref
+    odx.set_backend(None)
+    check_pasting("cuda")
+    be = odx.get_backend()
+    g = torch.Generator().manual_seed(1)
+    masks, boxes = torch.rand(7, 28, 28, generator=g), torch.rand(7, 4, generator=g) * 40
+    boxes[:, 2:] += boxes[:, :2] + 3
+    got = be.paste_masks(masks, boxes, 50, 70).cpu().numpy()
+    want = np.stack([roi_ref.paste_mask(masks[i].numpy(), boxes[i].numpy(), 50, 70) for i in range(7)])
+    assert (got != want).sum() <= 2
+    assert be.paste_masks(masks[:0], boxes[:0], 50, 70).shape == (0, 50, 70)
+
+
+def test_segmentation_ap_matches_reference():
+    from tests.oracle_backend import OracleBackend
+    from odx.postprocess import paste_masks
+    H, W = (int(v) for v in MG["HW"])
+    odx.set_backend(OracleBackend(np.float64))
+    try:
+        preds, gts = [], []
+        for im in range(int(MG["seg_NIMG"])):
+            pasted = paste_masks(torch.from_numpy(MG["seg_pm_%d" % im]), torch.from_numpy(MG["seg_pb_%d" % im]), (W, H)).numpy()
+            preds.append({"masks": pasted, "labels": MG["seg_pl_%d" % im], "scores": MG["seg_ps_%d" % im]})
+            gts.append({"masks": MG["seg_gm_%d" % im], "labels": MG["seg_gl_%d" % im]})
+    finally:
+        odx.set_backend(None)
+    for m07 in (True, False):
+        r = eval_detection(preds, gts, 0.5, m07, key="masks")
+        np.testing.assert_allclose(r["ap"], MG["seg_ap_%s" % ("voc07" if m07 else "area")], atol=1e-12, equal_nan=True)
