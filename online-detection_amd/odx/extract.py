@@ -188,6 +188,21 @@ class OnlineDetectionModel(nn.Module):
     def feat_dim(self):
         return self.head.out_channels
 
+    def update_model(self, models_rpn=None, models_detection=None, models_segmentation=None):
+        """Swap trained on-line models into the running pipeline, each a dict {'classifiers', 'regressors', 'stats'}
+        (segmentation: no regressors) — the demo's OnlineSegmentationDemo.update_model
+        (mrcnn_modified/demo/predictor_online_segmentation.py:404-425).  A head is created on first use and its
+        batched-inference caches are dropped whenever its models change, so a class added with one more FALKON + RLS
+        fit (append to the lists, call this) is live on the next image without touching the other classes."""
+        from . import heads
+        for attr, cls, models in (("online_rpn", heads.OnlineRPNHead, models_rpn), ("online_box", heads.OnlineBoxPredictor, models_detection),
+                                  ("online_mask", heads.OnlineMaskPredictor, models_segmentation)):
+            if not models:
+                continue
+            if getattr(self, attr) is None:
+                setattr(self, attr, cls())
+            getattr(self, attr).set_models(models["classifiers"], models.get("regressors"), models["stats"])
+
     def rpn_activation(self, c4):
         return F.relu(self.rpn_conv(c4))
 

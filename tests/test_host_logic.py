@@ -398,3 +398,55 @@ def check_heads_against_reference(atol=2e-4):
 
 def test_heads_match_reference():
     check_heads_against_reference()
+
+
+# ------------------------------------------------------------------ f4: adding a class to a running pipeline
+def test_add_a_class_without_touching_the_others():
+    """Train two classes, put them in the test-time head, then train a third with one more FALKON + RLS fit, append
+    and update_model: the first two classes score and regress exactly as before, the new column is the new model's
+    own stand-alone prediction (demo contract: predictor_online_segmentation.py:404-425, box_head_getProposals.py:90-99)."""
+    from odx.extract import OnlineDetectionModel
+    from odx.harvest import DetectorHarvester
+    from odx.rls import RegionRefinerTrainer
+    from odx.wrappers import CenterSelector
+    D = 24
+    rng = np.random.default_rng(11)
+    mus = rng.standard_normal((3, D)) * 2
+
+    def rows(c, n):
+        return torch.from_numpy((mus[c] + rng.standard_normal((n, D))).astype(np.float32))
+
+    def fit_class(c):
+        X = torch.cat([rows(c, 60), rows((c + 1) % 3, 90), rows((c + 2) % 3, 90)])
+        y = torch.cat([torch.ones(60), -torch.ones(180)])
+        m = odx.InCoreFalkon(kernel=odx.GaussianKernel(6.0), penalty=1e-4, M=80, maxiter=20,
+                             center_selection=CenterSelector(list(range(0, 240, 3))))
+        m.fit(X, y)
+        return m
+
+    def fit_regressors(classes):
+        Xr = torch.cat([rows(c, 40) for c in classes])
+        Cr = torch.cat([torch.full((40, 1), float(k + 1)) for k in range(len(classes))])
+        Yr = torch.from_numpy(rng.standard_normal((len(Xr), 4)).astype(np.float32)) * 0.1
+        cfg = {"CHOSEN_CLASSES": {i: "c%d" % i for i in range(len(classes) + 1)}, "REGION_REFINER": {"opts": {"lambda": 1.0}}}
+        return list(quiet(RegionRefinerTrainer(cfg, 1.0, False), {"C": Cr, "O": None, "X": Xr, "Y": Yr}))
+
+    stats = {"mean": torch.zeros(D), "std": torch.ones(D), "mean_norm": torch.tensor(20.0)}
+    clfs, regs = [fit_class(0), fit_class(1)], fit_regressors([0, 1])
+    model = OnlineDetectionModel(width=8)
+    model.update_model(models_detection={"classifiers": clfs, "regressors": regs, "stats": stats})
+    F = torch.cat([rows(0, 5), rows(1, 5), rows(2, 5)])
+    s2, d2 = model.online_box(F)
+    assert tuple(s2.shape) == (15, 3) and tuple(d2.shape) == (15, 12)
+    # a harvester grows by one class the same way
+    hv = DetectorHarvester(D, 2, 2, 10, 4, device="cpu")
+    hv.add_new_class()
+    assert hv.num_classes == 3 and len(hv._neg) == 3 and hv.still_to_complete == [0, 1, 2]
+    # one more FALKON + RLS fit, appended
+    new_clf, new_reg = fit_class(2), fit_regressors([2])
+    model.update_model(models_detection={"classifiers": clfs + [new_clf], "regressors": regs + new_reg, "stats": stats})
+    s3, d3 = model.online_box(F)
+    assert tuple(s3.shape) == (15, 4) and tuple(d3.shape) == (15, 16)
+    assert torch.equal(s3[:, :3], s2) and torch.equal(d3[:, :12], d2)
+    Fn = (F - stats["mean"]) * (20.0 / stats["mean_norm"])
+    assert torch.allclose(s3[:, 3], new_clf.predict(Fn).squeeze(1).float(), atol=1e-5)
