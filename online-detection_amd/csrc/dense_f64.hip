@@ -374,6 +374,38 @@ int fill_f64(double* A, int64_t lda, int64_t rows, int64_t cols, double value, h
   return ODX_OK;
 }
 
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  int device = -1;
+};
+
+// Internal helper streams (per host thread and device): slot 0 forks the inverse of L_T inside the preconditioner,
+// slot 1 carries the look-ahead trailing updates of potrf_f64.  Everything is ordered with events; the host never waits.
+static int side_stream(SideStream** out, int slot = 0) {
+  static thread_local SideStream ss[16][2];
+  int dev = 0;
+  ODX_CHECK_HIP(hipGetDevice(&dev));
+  ODX_REQUIRE(dev >= 0 && dev < 16 && slot >= 0 && slot < 2, "side_stream: device index out of range");
+  SideStream& s = ss[dev][slot];
+  if (s.stream == nullptr) {
+    if (slot == 1) {
+      // The look-ahead updates are bulk work that must not starve the latency-bound chain they overlap with: lowest
+      // priority, so freed CU slots go to the chain's small kernels first.
+      int lo = 0, hi = 0;
+      ODX_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      ODX_CHECK_HIP(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, lo));
+    } else {
+      ODX_CHECK_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    }
+    ODX_CHECK_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
+    ODX_CHECK_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+    s.device = dev;
+  }
+  *out = &s;
+  return ODX_OK;
+}
+
 // Two-level right-looking blocked Cholesky (lower).  Outer panels of 512 columns, inner blocks
 // of NB = 128:
 //   inner, per 128-block inside the panel:
@@ -388,6 +420,9 @@ constexpr int POTRF_NBO = 512;
 int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hipStream_t stream) {
   constexpr int NB = POTRF_NB;
   ODX_REQUIRE(lda % 2 == 0 && aligned16(A) && aligned16(Dinv), "potrf_f64: A/Dinv must be 16-byte aligned, lda even");
+  SideStream* look = nullptr;
+  ODX_PROPAGATE(side_stream(&look, 1));
+  bool pending = false;      // a trailing update is in flight on the helper stream
   for (int64_t K0 = 0; K0 < M; K0 += POTRF_NBO) {
     const int64_t kbo = M - K0 < POTRF_NBO ? M - K0 : POTRF_NBO;
     for (int64_t k0 = K0; k0 < K0 + kbo; k0 += NB) {
@@ -413,13 +448,35 @@ int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hi
     }
     const int64_t mt = M - K0 - kbo;
     if (mt > 0) {
+      // Trailing update with look-ahead: the next panel's columns are brought up to date on the main stream (a thin
+      // GEMM), so its latency-bound chain of diagonal blocks can start at once; the rest of the trailing matrix (the
+      // bulk of the flops) is updated on the helper stream meanwhile.  The next thin update touches columns the helper
+      // is still writing, so it waits for the helper first.
       double* P = A + (K0 + kbo) * lda + K0;
+      const int64_t nw = mt < POTRF_NBO ? mt : POTRF_NBO;      // width of the next panel
+      if (pending) {
+        ODX_CHECK_HIP(hipStreamWaitEvent(stream, look->join, 0));
+        pending = false;
+      }
       GemmParams<double> u;
       u.A = P; u.lda = lda; u.B = P; u.ldb = lda; u.C = A + (K0 + kbo) * (lda + 1); u.ldc = lda;
-      u.m = mt; u.n = mt; u.k = kbo; u.alpha = -1.0; u.beta = 1.0; u.flags = ODX_GEMM_LOWER_ONLY;
+      u.m = mt; u.n = nw; u.k = kbo; u.alpha = -1.0; u.beta = 1.0; u.flags = ODX_GEMM_LOWER_ONLY;
       ODX_PROPAGATE(launch_gemm_f64(u, stream));
+      const int64_t mr = mt - nw;
+      if (mr > 0) {
+        ODX_CHECK_HIP(hipEventRecord(look->fork, stream));
+        ODX_CHECK_HIP(hipStreamWaitEvent(look->stream, look->fork, 0));
+        double* P2 = P + nw * lda;
+        GemmParams<double> r;
+        r.A = P2; r.lda = lda; r.B = P2; r.ldb = lda; r.C = A + (K0 + kbo + nw) * (lda + 1); r.ldc = lda;
+        r.m = mr; r.n = mr; r.k = kbo; r.alpha = -1.0; r.beta = 1.0; r.flags = ODX_GEMM_LOWER_ONLY;
+        ODX_PROPAGATE(launch_gemm_f64(r, look->stream));
+        ODX_CHECK_HIP(hipEventRecord(look->join, look->stream));
+        pending = true;
+      }
     }
   }
+  if (pending) ODX_CHECK_HIP(hipStreamWaitEvent(stream, look->join, 0));
   return ODX_OK;
 }
 
@@ -568,28 +625,6 @@ extern "C" int odx_trtri_f64(const double* L, int64_t ldl, int64_t M, double* Li
 // goes to an internal side stream, forked and joined with events around it; everything stays
 // asynchronous with respect to the host.
 static int64_t precond_ld(int64_t M) { return round_up(M, 2); }
-
-struct SideStream {
-  hipStream_t stream = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  int device = -1;
-};
-
-static int side_stream(SideStream** out) {
-  static thread_local SideStream ss[16];
-  int dev = 0;
-  ODX_CHECK_HIP(hipGetDevice(&dev));
-  ODX_REQUIRE(dev >= 0 && dev < 16, "side_stream: device index out of range");
-  SideStream& s = ss[dev];
-  if (s.stream == nullptr) {
-    ODX_CHECK_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-    ODX_CHECK_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
-    ODX_CHECK_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
-    s.device = dev;
-  }
-  *out = &s;
-  return ODX_OK;
-}
 
 extern "C" int64_t odx_falkon_precond_workspace_bytes(int64_t M, int D) {
   if (M <= 0 || D <= 0) return 0;
