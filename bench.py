@@ -267,7 +267,7 @@ def main():
             if be.gauss == "h2":
                 # algorithmic flops (2 n M D) against the dense f16 MFMA peak; the two-term split issues 3 f16 MFMAs per
                 # algorithmic product, so this formulation's own ceiling is peak / 3 (frac_of_split_ceiling)
-                roof = {"bound": "mfma", "kernel": "gauss_knm_h2_kernel+gauss_mmv_h2_kernel", "achieved": round(ach, 2),
+                roof = {"bound": "mfma", "kernel": "gauss_knm_h2s16_kernel+gauss_mmv_h2s16_kernel", "achieved": round(ach, 2),
                         "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / F16_MFMA_PEAK_TFLOPS, 4),
                         "frac_of_split_ceiling": round(3 * ach / F16_MFMA_PEAK_TFLOPS, 4),
                         "traffic": None, "avg_launch_ms": round(gauss_ms / max(gauss_launches, 1), 3)}
@@ -280,6 +280,8 @@ def main():
             roof = {"bound": "hbm", "kernel": "knm_pass_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "avg_launch_ms": round(ktk_ms / max(ktk_launches, 1), 3)}
+        if (n_loc, M, D) == (1_000_000, 10_000, 1024):
+            roof["traffic"], roof["traffic_unit"] = profiled_traffic_gb(roof["kernel"])
         phases = {k: round(v.total_ms() / args.steps, 2) for k, v in ph.items()}
         phases["ktk_GBps"] = round(bytes_per_pass * ktk_launches / max(ktk_ms * 1e-3, 1e-9) / 1e9, 1)
         phases["gauss_TFLOPs"] = round(flops_per_launch * gauss_launches / max(gauss_ms * 1e-3, 1e-9) / 1e12, 2)
@@ -313,6 +315,24 @@ class _null:
 
     def __exit__(self, *a):
         return False
+
+
+def profiled_traffic_gb(kernel_names):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc_*: the
+    counters cannot be read from inside this process): FETCH_SIZE (KiB, doubled per the gfx950 correction of the
+    guide) + WRITE_SIZE (KiB), averaged over the profiled launches at this same shard shape.  None if absent."""
+    import csv
+    tot, found = 0.0, False
+    for counter, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        path = os.path.join(ROOT, "profiles", "r01_pmc_%s_counter_collection.csv" % counter)
+        if not os.path.exists(path):
+            return None, None
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+                if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in kernel_names.split("+"))]
+        if vals:
+            found = True
+            tot += mult * 1024.0 * sum(vals) / len(vals)
+    return (round(tot / 1e9, 2), "GB per launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE (profiles/r01_pmc_*)") if found else (None, None)
 
 
 def cpu_baseline(args):
