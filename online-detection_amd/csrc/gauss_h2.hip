@@ -568,6 +568,7 @@ extern "C" int odx_gauss_knm_h2(const void* PX, int64_t ldpx, const float* metax
   ODX_REQUIRE(ldpx % 4 == 0 && ldpz % 4 == 0 && ldpx >= dp && ldpz >= dp && aligned16(PX) && aligned16(PZ),
               "odx_gauss_knm_h2: packed operands must be 16-byte aligned with ld %% 4 == 0 and ld >= roundup(D, 64)");
   ODX_REQUIRE(ldk % 4 == 0 && ldk >= round_up(M, 4) && aligned16(K), "odx_gauss_knm_h2: K must be 16-byte aligned, ldk %% 4 == 0, ldk >= roundup(M, 4)");
+  ODX_REQUIRE(ldpx < (1 << 24) && ldpz < (1 << 24) && ldk < (1 << 24), "odx_gauss_knm_h2: leading dimensions must stay below 2^24 (32-bit tile offsets)");
   const int gr = 8;   // band height of the tile order: 2..32 measured within 2 % of each other at n = 2.5e5, M = 1e4
   const int64_t tiles = round_up(ceil_div(n, GEMM_BM), gr) * ceil_div(M, GEMM_BN);
   ODX_REQUIRE(tiles < (1ll << 31), "odx_gauss_knm_h2: grid too large");
@@ -598,6 +599,7 @@ extern "C" int odx_gauss_mmv_h2(const void* PX, int64_t ldpx, const float* metax
   ODX_REQUIRE(ldpx % 4 == 0 && ldpz % 4 == 0 && ldpx >= dp && ldpz >= dp && aligned16(PX) && aligned16(PZ),
               "odx_gauss_mmv_h2: packed operands must be 16-byte aligned with ld %% 4 == 0 and ld >= roundup(D, 64)");
   ODX_REQUIRE(ldo >= C && C < 65536, "odx_gauss_mmv_h2: ldo < C or too many classes");
+  ODX_REQUIRE(ldpx < (1 << 24) && ldpz < (1 << 24), "odx_gauss_mmv_h2: leading dimensions must stay below 2^24 (32-bit tile offsets)");
   const int64_t rb = ceil_div(n, GEMM_BM);
   ODX_REQUIRE(rb < (1ll << 31), "odx_gauss_mmv_h2: grid too large");
   if (h2_shape() == 16) {

@@ -133,6 +133,26 @@ def test_split_f16(be, n, D, scale):
     assert Z.meta is F.meta and torch.equal(Z.P, F.P[torch.from_numpy(idx).cuda()])
 
 
+@pytest.mark.parametrize("n,M,D", [(1, 1, 8), (0, 5, 16), (3, 0, 16), (130, 1, 70), (1, 300, 64)])
+def test_gauss_edge_shapes(be, gauss, n, M, D):
+    """Empty and one-row / one-centre operands, D not a multiple of the k-tile."""
+    from oracle import falkon_ref as fr
+    rng = np.random.default_rng(n + 7 * M + D)
+    X, Z = rng.standard_normal((n, D)).astype(np.float32), rng.standard_normal((M, D)).astype(np.float32)
+    F, Zf = be.features(torch.from_numpy(X)), be.features(torch.from_numpy(Z))
+    K = be.knm(F, Zf, 4.0)
+    assert tuple(K.K.shape) == (n, (M + 3) // 4 * 4)
+    if n and M:
+        ref = fr.gaussian_kernel(X.astype(np.float64), Z.astype(np.float64), 4.0)
+        assert np.abs(K.K.cpu().numpy()[:, :M] - ref).max() < 2e-5
+    al = rng.standard_normal((M, 2))
+    out = be.mmv(F, Zf, 4.0, torch.from_numpy(al))
+    assert tuple(out.shape) == (n, 2)
+    if n:
+        want = fr.gaussian_kernel(X.astype(np.float64), Z.astype(np.float64), 4.0) @ al if M else np.zeros((n, 2))
+        assert np.abs(out.cpu().numpy() - want).max() < 1e-4
+
+
 @pytest.mark.parametrize("n,M", [(1000, 500), (4097, 2000), (37, 130), (700, 3000), (520, 10000), (300, 12001), (200, 20000)])
 def test_knm_fwd_bwd(be, n, M):
     rng = np.random.default_rng(n + M)
