@@ -3,14 +3,14 @@
 // Every f32 operand value is split once into two f16 terms, x * s = hi + lo (s a power of two that puts
 // max |x| into [2^13, 2^14)): hi carries the top 11 significant bits, lo the next 11.  Then
 //     x . z  =  (hi_x . hi_z  +  hi_x . lo_z  +  lo_x . hi_z) / (s_x s_z)   (+ a lo.lo term of relative size 2^-22)
-// Each f16 x f16 product is exact in f32 and v_mfma_f32_32x32x16_f16 accumulates in f32, so the contraction
+// Each f16 x f16 product is exact in f32 and v_mfma_f32_16x16x32_f16 accumulates in f32, so the contraction
 // keeps ~22 bits per factor — tools/precision_study.py: the fitted alpha moves exactly as with the all-f32
 // v_mfma_f32_32x32x2_f32 chain — at 3 MFMAs of the f16 rate (16 x the f32 MFMA rate) per f32 MFMA replaced.
 //
 // Packed operand ("h2") layout, produced by odx_split_f16: a row is ldp 4-byte units; k-tile t of a row
 // (64 consecutive features) is 256 contiguous bytes: 64 f16 hi, then 64 f16 lo.  Features past D are zero.
-// Tile: 256 threads (2 x 2 waves), 128 x 128 outputs, a k-tile = 128 rows x 256 B per operand through LDS rows of
-// 272 B (17 x 16 B, odd => the 16-lane groups of ds_read_b128 hit 16 distinct 16-B slots).
+// Tile: 256 threads (2 x 2 waves), 128 x 128 outputs, a k-tile = 128 rows x 256 B per operand through XOR-swizzled
+// 256-B LDS rows (see the tile core below).
 #include <stdlib.h>
 #include "gemm_core.h"
 #include "odx_internal.h"
@@ -20,8 +20,6 @@ namespace odx {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int H2_KT = 64;                   // features per k-tile
-constexpr int H2_ROW = 272;                 // LDS bytes per tile row
-constexpr int H2_LDS_BYTES = (GEMM_BM + GEMM_BN) * H2_ROW;  // 69,632 B -> two workgroups per CU
 
 // ---------------------------------------------------------------- split
 __global__ __launch_bounds__(256) void absmax_f32_kernel(const float* __restrict__ X, int64_t ldx, int64_t n, int D,
@@ -105,220 +103,10 @@ __device__ __forceinline__ void h2_load_operand(u32x4 (&r)[8], const uint32_t* _
   for (int p = 0; p < 8; ++p) r[p] = *reinterpret_cast<const u32x4*>(tile + voff[p]);
 }
 
-__device__ __forceinline__ void h2_store_operand(const u32x4 (&r)[8], char* lds) {
-  const int tid = threadIdx.x;
-  char* d = lds + (tid >> 4) * H2_ROW + (tid & 15) * 16;
-#pragma unroll
-  for (int p = 0; p < 8; ++p) *reinterpret_cast<u32x4*>(d + 16 * p * H2_ROW) = r[p];
-}
-
-__device__ __forceinline__ void h2_compute_ktile(f32x16 (&acc)[2][2], const char* ldsA, const char* ldsB, int wr, int wc,
-                                                 int lane) {
-  const int r = lane & 31, h = lane >> 5;
-  const char* pa = ldsA + (wr * 64 + r) * H2_ROW + h * 16;
-  const char* pb = ldsB + (wc * 64 + r) * H2_ROW + h * 16;
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    f16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      ah[t] = *reinterpret_cast<const f16x8*>(pa + t * 32 * H2_ROW + ks * 32);
-      al[t] = *reinterpret_cast<const f16x8*>(pa + t * 32 * H2_ROW + ks * 32 + 128);
-      bh[t] = *reinterpret_cast<const f16x8*>(pb + t * 32 * H2_ROW + ks * 32);
-      bl[t] = *reinterpret_cast<const f16x8*>(pb + t * 32 * H2_ROW + ks * 32 + 128);
-    }
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-      }
-  }
-}
-
-// acc += (scaled) A[i0.., :] B[j0.., :]' over `ktiles` k-tiles
-__device__ __forceinline__ void h2_mainloop(f32x16 (&acc)[2][2], const uint32_t* __restrict__ A, int64_t lda, int64_t m,
-                                            const uint32_t* __restrict__ B, int64_t ldb, int64_t n, int64_t i0, int64_t j0,
-                                            int ktiles, char* lds) {
-  char* ldsA = lds;
-  char* ldsB = lds + GEMM_BM * H2_ROW;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  uint32_t offa[8], offb[8];
-  h2_row_offsets(offa, lda, i0, m);
-  h2_row_offsets(offb, ldb, j0, n);
-  const uint32_t* ta = A + i0 * lda;
-  const uint32_t* tb = B + j0 * ldb;
-  H2Stage st;
-  h2_load_operand(st.a, ta, offa);
-  h2_load_operand(st.b, tb, offb);
-  for (int kt = 0; kt < ktiles; ++kt) {
-    __syncthreads();
-    h2_store_operand(st.a, ldsA);
-    h2_store_operand(st.b, ldsB);
-    __syncthreads();
-    if (kt + 1 < ktiles) {
-      ta += H2_KT;
-      tb += H2_KT;
-      h2_load_operand(st.a, ta, offa);
-      h2_load_operand(st.b, tb, offb);
-    }
-    h2_compute_ktile(acc, ldsA, ldsB, wr, wc, lane);
-  }
-}
-
 constexpr float LOG2E = 1.4426950408889634f;
 
-// ---------------------------------------------------------------- K_nM
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gauss_knm_h2_kernel(
-    const uint32_t* __restrict__ PX, int64_t ldpx, const float* __restrict__ metax, const float* __restrict__ xsq, int64_t n,
-    const uint32_t* __restrict__ PZ, int64_t ldpz, const float* __restrict__ metaz, const float* __restrict__ zsq, int64_t M,
-    int ktiles, float gamma_log2e, float* __restrict__ K, int64_t ldk) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  constexpr int64_t GR = 8;   // banded tile order inside an XCD's run of tiles (see gauss_knm_f32_kernel)
-  const int64_t tiles_n = (M + GEMM_BN - 1) / GEMM_BN;
-  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t band = wg / (GR * tiles_n), within = wg % (GR * tiles_n);
-  const int64_t i0 = (band * GR + within % GR) * GEMM_BM, j0 = (within / GR) * GEMM_BN;
-  if (i0 >= n) return;
-
-  __shared__ __attribute__((aligned(16))) float xs_s[GEMM_BM];
-  if (threadIdx.x < GEMM_BM) xs_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] : 0.f;
-
-  f32x16 acc[2][2];
-  gemm_zero_acc<float>(acc);
-  h2_mainloop(acc, PX, ldpx, n, PZ, ldpz, M, i0, j0, ktiles, lds);
-
-  const float m2 = -2.f / (metax[0] * metaz[0]);   // powers of two: exact
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  if (i0 + GEMM_BM <= n && j0 + GEMM_BN <= M) {
-    // interior tile: no masks; 32-bit offsets from the uniform tile corner
-    float* tile = K + i0 * ldk + j0;
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const int cl = wc * 64 + tn * 32 + (lane & 31);
-      const float zs = zsq[j0 + cl];
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int rl = wr * 64 + tm * 32 + 8 * g + 4 * (lane >> 5);
-          const f32x4 xs = *reinterpret_cast<const f32x4*>(&xs_s[rl]);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float d2 = fmaf(m2, acc[tm][tn][4 * g + q], xs[q]) + zs;
-            d2 = fmaxf(d2, 0.f);
-            tile[(uint32_t)(rl + q) * (uint32_t)ldk + (uint32_t)cl] = __builtin_amdgcn_exp2f(d2 * gamma_log2e);
-          }
-        }
-    }
-    return;
-  }
-  const int64_t mpad = (M + 3) & ~int64_t(3);
-#pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const int64_t col = j0 + wc * 64 + gemm_acc_col<float>(tn, lane);
-    const float zs = col < M ? zsq[col] : 0.f;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rl = wr * 64 + gemm_acc_row<float>(tm, r, lane);
-        const int64_t row = i0 + rl;
-        if (row < n && col < mpad) {
-          float v = 0.f;
-          if (col < M) {
-            float d2 = fmaf(m2, acc[tm][tn][r], xs_s[rl]) + zs;
-            d2 = fmaxf(d2, 0.f);
-            v = __builtin_amdgcn_exp2f(d2 * gamma_log2e);
-          }
-          K[row * ldk + col] = v;
-        }
-      }
-  }
-}
-
-// ---------------------------------------------------------------- fused scoring
-// out[:, c] = K(X, Z[range c]) V[range c, c]; per-lane f64 partial sums over all column tiles, one cross-lane
-// reduction at the end.
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gauss_mmv_h2_kernel(
-    const uint32_t* __restrict__ PX, int64_t ldpx, const float* __restrict__ metax, const float* __restrict__ xsq, int64_t n,
-    const uint32_t* __restrict__ PZ, int64_t ldpz, const float* __restrict__ metaz, const float* __restrict__ zsq, int ktiles,
-    float gamma_log2e, const double* __restrict__ V, int64_t ldv, const int32_t* __restrict__ ranges,
-    float* __restrict__ out, int64_t ldo) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  __shared__ double red[2][2][64];
-  __shared__ float xs_s[GEMM_BM];
-  const int c = blockIdx.y;
-  const int64_t s0 = ranges[2 * c], s1 = ranges[2 * c + 1];
-  const int64_t i0 = (int64_t)blockIdx.x * GEMM_BM;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const float m2 = -2.f / (metax[0] * metaz[0]);
-
-  if (threadIdx.x < GEMM_BM) xs_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] : 0.f;
-  // Lane l ends every tile with the f64 sum, over the tile's 64 columns of this wave, of row slot (l & 31) of its lane
-  // half (slot = 16 tm + r): a reduce-scatter butterfly over the 32 lanes of the half (31 exchanges per tile instead of
-  // 32 x 5 for row-by-row reductions, and one running total per lane instead of 32).
-  double tot = 0.0;
-  const bool b16 = lane & 16, b8 = lane & 8, b4 = lane & 4, b2 = lane & 2, b1 = lane & 1;
-
-  for (int64_t j0 = s0; j0 < s1; j0 += GEMM_BN) {
-    f32x16 acc[2][2];
-    gemm_zero_acc<float>(acc);
-    h2_mainloop(acc, PX, ldpx, n, PZ + j0 * ldpz, ldpz, s1 - j0, i0, 0, ktiles, lds);
-    float zs[2];
-    double al[2];
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      const int64_t col = j0 + wc * 64 + gemm_acc_col<float>(tn, lane);
-      const bool cv = col < s1;
-      zs[tn] = cv ? zsq[col] : 0.f;
-      al[tn] = cv ? V[col * ldv + c] : 0.0;     // weight 0 removes the columns past the range
-    }
-    double w16[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      double v[2];
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
-        const float xs = xs_s[wr * 64 + gemm_acc_row<float>(tm, r, lane)];
-        v[tm] = 0.0;
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-          float d2 = fmaf(m2, acc[tm][tn][r], xs) + zs[tn];
-          d2 = fmaxf(d2, 0.f);
-          v[tm] = fma((double)__builtin_amdgcn_exp2f(d2 * gamma_log2e), al[tn], v[tm]);
-        }
-      }
-      w16[r] = (b16 ? v[1] : v[0]) + __shfl_xor(b16 ? v[0] : v[1], 16);
-    }
-    double w8[8], w4[4], w2[2];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) w8[j] = (b8 ? w16[j + 8] : w16[j]) + __shfl_xor(b8 ? w16[j] : w16[j + 8], 8);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w4[j] = (b4 ? w8[j + 4] : w8[j]) + __shfl_xor(b4 ? w8[j] : w8[j + 4], 4);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) w2[j] = (b2 ? w4[j + 2] : w4[j]) + __shfl_xor(b2 ? w4[j] : w4[j + 2], 2);
-    tot += (b1 ? w2[1] : w2[0]) + __shfl_xor(b1 ? w2[0] : w2[1], 1);
-  }
-  {
-    const int slot = lane & 31;
-    red[wr][wc][gemm_acc_row<float>(slot >> 4, slot & 15, lane)] = tot;
-  }
-  __syncthreads();
-  if (threadIdx.x < 128) {
-    const int w = threadIdx.x >> 6, rr = threadIdx.x & 63;
-    const int64_t row = i0 + w * 64 + rr;
-    if (row < n) out[row * ldo + c] = (float)(red[w][0][rr] + red[w][1][rr]);
-  }
-}
-
-// ================================================================ 16x16x32 variant
-// Same tile and packed operands, v_mfma_f32_16x16x32_f16 (4 x 4 blocks per wave).  LDS rows are exactly 256 B with the
+// ---------------------------------------------------------------- tile core
+// v_mfma_f32_16x16x32_f16, 4 x 4 blocks per wave.  LDS rows are exactly 256 B with the
 // 16-byte slots of a row XOR-swizzled by (row & 15): logical slot q (hi chunks 0..7, lo chunks 8..15) lives at
 // q ^ (row & 15).  A 16-lane group of ds_read_b128 then touches lanes of two k-groups whose chunk numbers differ only in
 // their low two bits, which keeps the 16 slots distinct (conflict-free), with no padding: 64 KiB per workgroup.
@@ -446,17 +234,30 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gauss_knm_h2s16_kernel(
   }
 }
 
+// Fused scoring, tiled in two dimensions: a workgroup owns one 128-row block and one GROUP of `tg` consecutive column
+// tiles of class c's centre range, and leaves its f64 partial row sums in slab[c][group][row]; mmv_reduce_kernel adds
+// the groups in fixed order.  Workgroups are ordered like the K_nM build (bands of 8 row blocks x all groups inside an
+// XCD's run), so the X panel of a row block is shared in L2 by the groups working on it and a Z tile by the row blocks
+// of the band — one workgroup per row block walking all 79 column tiles re-fetched its 512-KB X panel for every tile
+// (458 GB of L2 misses per launch at n = 1e6, M = 1e4, against 132 GB for the build).
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gauss_mmv_h2s16_kernel(
     const uint32_t* __restrict__ PX, int64_t ldpx, const float* __restrict__ metax, const float* __restrict__ xsq, int64_t n,
     const uint32_t* __restrict__ PZ, int64_t ldpz, const float* __restrict__ metaz, const float* __restrict__ zsq, int ktiles,
-    float gamma_log2e, const double* __restrict__ V, int64_t ldv, const int32_t* __restrict__ ranges,
-    float* __restrict__ out, int64_t ldo) {
+    float gamma_log2e, const double* __restrict__ V, int64_t ldv, const int32_t* __restrict__ ranges, int tg, int G,
+    double* __restrict__ slab, int64_t slab_ld) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   __shared__ double red[2][2][64];
   __shared__ __attribute__((aligned(16))) float xs_s[GEMM_BM];
+  constexpr int64_t GR = 8;
   const int c = blockIdx.y;
-  const int64_t s0 = ranges[2 * c], s1 = ranges[2 * c + 1];
-  const int64_t i0 = (int64_t)blockIdx.x * GEMM_BM;
+  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t band = wg / (GR * G), within = wg % (GR * G);
+  const int64_t i0 = (band * GR + within % GR) * GEMM_BM;
+  const int g = (int)(within / GR);
+  const int64_t r0 = ranges[2 * c], r1 = ranges[2 * c + 1];
+  const int64_t s0 = r0 + (int64_t)g * tg * GEMM_BN;
+  const int64_t s1 = (s0 + (int64_t)tg * GEMM_BN < r1) ? s0 + (int64_t)tg * GEMM_BN : r1;
+  if (i0 >= n || s0 >= r1) return;       // mmv_reduce_kernel only visits the groups that exist
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const float m2 = -2.f / (metax[0] * metaz[0]);
@@ -470,7 +271,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gauss_mmv_h2s16_kernel(
   for (int64_t j0 = s0; j0 < s1; j0 += GEMM_BN) {
     f32x4 acc[4][4];
     s16_zero(acc);
-    s16_mainloop(acc, PX, ldpx, n, PZ + j0 * ldpz, ldpz, s1 - j0, i0, 0, ktiles, lds);
+    s16_mainloop(acc, PX, ldpx, n, PZ + j0 * ldpz, ldpz, r1 - j0, i0, 0, ktiles, lds);
     float zs[4];
     double al[4];
 #pragma unroll
@@ -478,7 +279,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gauss_mmv_h2s16_kernel(
       const int64_t col = j0 + wc * 64 + tn * 16 + (lane & 15);
       const bool cv = col < s1;
       zs[tn] = cv ? zsq[col] : 0.f;
-      al[tn] = cv ? V[col * ldv + c] : 0.0;
+      al[tn] = cv ? V[col * ldv + c] : 0.0;     // weight 0 removes the columns past the group / range
     }
     double w8[8];
 #pragma unroll
@@ -513,17 +314,28 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gauss_mmv_h2s16_kernel(
   if (threadIdx.x < 128) {
     const int w = threadIdx.x >> 6, rr = threadIdx.x & 63;
     const int64_t row = i0 + w * 64 + rr;
-    if (row < n) out[row * ldo + c] = (float)(red[w][0][rr] + red[w][1][rr]);
+    if (row < n) slab[((int64_t)c * G + g) * slab_ld + row] = red[w][0][rr] + red[w][1][rr];
   }
 }
 
-static int h2_shape() {   // development switch between the two MFMA shapes
-  static const int shape = (getenv("ODX_H2_SHAPE") && atoi(getenv("ODX_H2_SHAPE")) == 32) ? 32 : 16;
-  return shape;
+__global__ __launch_bounds__(256) void mmv_reduce_kernel(const double* __restrict__ slab, int64_t slab_ld, int G, int tg,
+                                                         const int32_t* __restrict__ ranges, int64_t n,
+                                                         float* __restrict__ out, int64_t ldo) {
+  const int c = blockIdx.y;
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= n) return;
+  const int64_t len = (int64_t)ranges[2 * c + 1] - ranges[2 * c];
+  const int64_t tiles = len > 0 ? (len + GEMM_BN - 1) / GEMM_BN : 0;
+  const int groups = (int)((tiles + tg - 1) / tg);
+  double s = 0.0;
+  for (int g = 0; g < groups; ++g) s += slab[((int64_t)c * G + g) * slab_ld + row];
+  out[row * ldo + c] = (float)s;
 }
 
+constexpr int MMV_TG = 8;   // column tiles per workgroup
+
 static int h2_enable_lds(const void* fn) {   // > 64 KiB of LDS per workgroup has to be asked for
-  ODX_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, H2_LDS_BYTES));
+  ODX_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, S16_LDS_BYTES));
   return ODX_OK;
 }
 
@@ -572,48 +384,48 @@ extern "C" int odx_gauss_knm_h2(const void* PX, int64_t ldpx, const float* metax
   const int gr = 8;   // band height of the tile order: 2..32 measured within 2 % of each other at n = 2.5e5, M = 1e4
   const int64_t tiles = round_up(ceil_div(n, GEMM_BM), gr) * ceil_div(M, GEMM_BN);
   ODX_REQUIRE(tiles < (1ll << 31), "odx_gauss_knm_h2: grid too large");
-  if (h2_shape() == 16) {
-    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2s16_kernel)));
-    hipLaunchKernelGGL(gauss_knm_h2s16_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), S16_LDS_BYTES, as_stream(stream),
-                       (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq, M, (int)(dp / H2_KT),
-                       (float)(-0.5 / (sigma * sigma)) * LOG2E, K, ldk, gr);
-    ODX_CHECK_LAUNCH("odx_gauss_knm_h2");
-    return ODX_OK;
-  }
-  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2_kernel)));
-  hipLaunchKernelGGL(gauss_knm_h2_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), H2_LDS_BYTES, as_stream(stream),
+  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2s16_kernel)));
+  hipLaunchKernelGGL(gauss_knm_h2s16_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), S16_LDS_BYTES, as_stream(stream),
                      (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq, M, (int)(dp / H2_KT),
-                     (float)(-0.5 / (sigma * sigma)) * LOG2E, K, ldk);
+                     (float)(-0.5 / (sigma * sigma)) * LOG2E, K, ldk, gr);
   ODX_CHECK_LAUNCH("odx_gauss_knm_h2");
   return ODX_OK;
 }
 
+extern "C" int64_t odx_gauss_mmv_h2_workspace_bytes(int64_t n, int64_t Mtot, int T) {
+  if (n <= 0 || Mtot <= 0 || T <= 0) return 0;
+  const int64_t G = ceil_div(ceil_div(Mtot, GEMM_BN), MMV_TG);
+  return (int64_t)T * G * round_up(n, 2) * (int64_t)sizeof(double);
+}
+
 extern "C" int odx_gauss_mmv_h2(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
-                                const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int D, double sigma,
-                                const double* V, int64_t ldv, const int32_t* ranges, int C, float* out, int64_t ldo,
-                                odx_stream_t stream) {
+                                const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t Mtot, int D,
+                                double sigma, const double* V, int64_t ldv, const int32_t* ranges, int C, float* out,
+                                int64_t ldo, void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
   if (n <= 0 || C <= 0) return ODX_OK;
-  ODX_REQUIRE(PX && PZ && metax && metaz && xsq && zsq && V && ranges && out && D > 0 && sigma > 0 && ldv >= C,
+  ODX_REQUIRE(PX && PZ && metax && metaz && xsq && zsq && V && ranges && out && D > 0 && sigma > 0 && ldv >= C && Mtot > 0,
               "odx_gauss_mmv_h2: bad argument");
   const int64_t dp = round_up(D, H2_KT);
   ODX_REQUIRE(ldpx % 4 == 0 && ldpz % 4 == 0 && ldpx >= dp && ldpz >= dp && aligned16(PX) && aligned16(PZ),
               "odx_gauss_mmv_h2: packed operands must be 16-byte aligned with ld %% 4 == 0 and ld >= roundup(D, 64)");
   ODX_REQUIRE(ldo >= C && C < 65536, "odx_gauss_mmv_h2: ldo < C or too many classes");
   ODX_REQUIRE(ldpx < (1 << 24) && ldpz < (1 << 24), "odx_gauss_mmv_h2: leading dimensions must stay below 2^24 (32-bit tile offsets)");
-  const int64_t rb = ceil_div(n, GEMM_BM);
-  ODX_REQUIRE(rb < (1ll << 31), "odx_gauss_mmv_h2: grid too large");
-  if (h2_shape() == 16) {
-    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_mmv_h2s16_kernel)));
-    hipLaunchKernelGGL(gauss_mmv_h2s16_kernel, dim3((unsigned)rb, (unsigned)C), dim3(GEMM_THREADS), S16_LDS_BYTES,
-                       as_stream(stream), (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq,
-                       (int)(dp / H2_KT), (float)(-0.5 / (sigma * sigma)) * LOG2E, V, ldv, ranges, out, ldo);
-    ODX_CHECK_LAUNCH("odx_gauss_mmv_h2");
-    return ODX_OK;
+  if (workspace == nullptr || workspace_bytes < odx_gauss_mmv_h2_workspace_bytes(n, Mtot, C)) {
+    set_error("odx_gauss_mmv_h2: workspace too small");
+    return ODX_ERR_WORKSPACE;
   }
-  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_mmv_h2_kernel)));
-  hipLaunchKernelGGL(gauss_mmv_h2_kernel, dim3((unsigned)rb, (unsigned)C), dim3(GEMM_THREADS), H2_LDS_BYTES,
+  const int G = (int)ceil_div(ceil_div(Mtot, GEMM_BN), MMV_TG);
+  const int64_t wgs = round_up(ceil_div(n, GEMM_BM), 8) * G;
+  ODX_REQUIRE(wgs < (1ll << 31), "odx_gauss_mmv_h2: grid too large");
+  double* slab = static_cast<double*>(workspace);
+  const int64_t slab_ld = round_up(n, 2);
+  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_mmv_h2s16_kernel)));
+  hipLaunchKernelGGL(gauss_mmv_h2s16_kernel, dim3((unsigned)wgs, (unsigned)C), dim3(GEMM_THREADS), S16_LDS_BYTES,
                      as_stream(stream), (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq,
-                     (int)(dp / H2_KT), (float)(-0.5 / (sigma * sigma)) * LOG2E, V, ldv, ranges, out, ldo);
+                     (int)(dp / H2_KT), (float)(-0.5 / (sigma * sigma)) * LOG2E, V, ldv, ranges, MMV_TG, G, slab, slab_ld);
   ODX_CHECK_LAUNCH("odx_gauss_mmv_h2");
+  hipLaunchKernelGGL(mmv_reduce_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)C), dim3(256), 0, as_stream(stream), slab,
+                     slab_ld, G, MMV_TG, ranges, n, out, ldo);
+  ODX_CHECK_LAUNCH("odx_gauss_mmv_h2(reduce)");
   return ODX_OK;
 }

@@ -226,9 +226,10 @@ class HipBackend:
             return out.zero_()
         if self.gauss == "h2":
             self.pack(F), self.pack(Zf)
+            ws = self._workspace("mmv", self.lib.odx_gauss_mmv_h2_workspace_bytes(F.n, Mtot, T))
             hip.check(self.lib.odx_gauss_mmv_h2(_p(F.P), F.P.stride(0), _p(F.meta), _p(F.sq), F.n, _p(Zf.P), Zf.P.stride(0),
-                                                _p(Zf.meta), _p(Zf.sq), F.D, float(sigma), _p(V), V.stride(0), _p(ranges), T,
-                                                _p(out), out.stride(0), self._stream()), "odx_gauss_mmv_h2")
+                                                _p(Zf.meta), _p(Zf.sq), Mtot, F.D, float(sigma), _p(V), V.stride(0), _p(ranges), T,
+                                                _p(out), out.stride(0), _p(ws), ws.numel(), self._stream()), "odx_gauss_mmv_h2")
         else:
             hip.check(self.lib.odx_gauss_mmv_f32(_p(F.X), F.ld, _p(F.sq), F.n, _p(Zf.X), Zf.ld, _p(Zf.sq), F.D,
                                                  float(sigma), _p(V), V.stride(0), _p(ranges), T, _p(out), out.stride(0),
