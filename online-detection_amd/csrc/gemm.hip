@@ -7,7 +7,7 @@
 namespace odx {
 
 template <typename T, int BN>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_nt_kernel(GemmParams<T> p) {
+__global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 8 && BN == 64) ? 3 : 1) void gemm_nt_kernel(GemmParams<T> p) {
   using Tr = GemmTraits<T>;
   constexpr int TN = GemmTileN<T, BN>::TN;
   constexpr int LDS_BYTES = (GEMM_BM + BN) * GEMM_LDS_ROW;
