@@ -94,6 +94,10 @@ int odx_gauss_mmv_h2(const void* PX, int64_t ldpx, const float* metax, const flo
  * of rows.  K (n x M) f32; v (M) f64 or NULL; w (n) f64 or NULL; out (M) f64.
  * One read of K per call.  Deterministic (fixed-order slab reduction).                  */
 int64_t odx_knm_fwd_bwd_workspace_bytes(int64_t n, int64_t M);
+/* The pass kernel is persistent (one workgroup per CU for M > 4096) and would otherwise hold every CU for its whole
+ * run (6.5 ms at n = 1e6, M = 1e4).  Reserving `cus` CUs (0 = none, the default) lets small kernels of concurrent
+ * streams — the preconditioner of the next class — make progress during the passes; a process-wide setting. */
+int odx_set_pass_reserved_cus(int cus);
 int odx_knm_fwd_bwd(const float* K, int64_t ldk, int64_t n, int64_t M,
                     const double* v, const double* w, double* out,
                     void* workspace, int64_t workspace_bytes, odx_stream_t stream);

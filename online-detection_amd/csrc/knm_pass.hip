@@ -145,6 +145,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const double* __restri
   if (wave == 0 && j < M) out[j] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
+static int g_reserved_cus = 0;
+
 struct PassCfg {
   int nt, ch, r, wg_per_cu;
 };
@@ -165,7 +167,9 @@ static int grid_for(const PassCfg& cfg, int64_t n) {
   int cus = odx_device_cus();
   if (cus <= 0) cus = 256;
   const int64_t nblk = ceil_div(n, cfg.r);
-  int64_t g = (int64_t)cus * cfg.wg_per_cu;
+  // One-workgroup-per-CU configurations can leave CUs to concurrent streams (odx_set_pass_reserved_cus).
+  const int reserve = (cfg.wg_per_cu == 1 && g_reserved_cus < cus / 2) ? g_reserved_cus : 0;
+  int64_t g = (int64_t)(cus - reserve) * cfg.wg_per_cu;
   if (g > nblk) g = nblk;
   if (g < 1) g = 1;
   return (int)g;
@@ -174,6 +178,12 @@ static int grid_for(const PassCfg& cfg, int64_t n) {
 }  // namespace odx
 
 using namespace odx;
+
+extern "C" int odx_set_pass_reserved_cus(int cus) {
+  ODX_REQUIRE(cus >= 0, "odx_set_pass_reserved_cus: negative count");
+  g_reserved_cus = cus;
+  return ODX_OK;
+}
 
 extern "C" int64_t odx_knm_fwd_bwd_workspace_bytes(int64_t n, int64_t M) {
   PassCfg cfg;

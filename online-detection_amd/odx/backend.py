@@ -168,6 +168,10 @@ class HipBackend:
                                                  float(sigma), _p(K.K), ld, self._stream()), "odx_gauss_knm_f32")
         return K
 
+    def reserve_cus_during_passes(self, cus):
+        """Leave `cus` CUs free while the persistent CG pass kernel runs, for work queued on other streams."""
+        hip.check(self.lib.odx_set_pass_reserved_cus(int(cus)), "odx_set_pass_reserved_cus")
+
     def ktk(self, K, v=None, w=None, out=None):
         """out = K' (K v + w) over this shard (f64)."""
         if out is None:
