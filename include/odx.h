@@ -80,7 +80,7 @@ int odx_split_f16(const float* X, int64_t ldx, int64_t n, int D, void* P, int64_
 int odx_gauss_knm_h2(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
                      const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int D,
                      double sigma, float* K, int64_t ldk, odx_stream_t stream);
-/* Scoring is tiled over (row block, group of 8 column tiles); the f64 partial sums of the groups pass through
+/* Scoring is tiled over (row block, group of 4 column tiles); the f64 partial sums of the groups pass through
  * `workspace` (odx_gauss_mmv_h2_workspace_bytes(n, Mtot, T)) and are added in fixed order.  Mtot = rows of V / PZ. */
 int64_t odx_gauss_mmv_h2_workspace_bytes(int64_t n, int64_t Mtot, int T);
 int odx_gauss_mmv_h2(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void mmv_reduce_kernel(const double* __restric
   out[row * ldo + c] = (float)s;
 }
 
-constexpr int MMV_TG = 8;   // column tiles per workgroup
+constexpr int MMV_TG = 4;   // column tiles per workgroup (2 / 4 / 8 / 16 / 40 measured: 342 / 341 / 335 / 321 / 305 TF)
 
 static int h2_enable_lds(const void* fn) {   // > 64 KiB of LDS per workgroup has to be asked for
   ODX_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, S16_LDS_BYTES));
