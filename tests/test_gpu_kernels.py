@@ -174,6 +174,25 @@ def test_knm_fwd_bwd(be, n, M):
     assert np.array_equal(out2, out3)  # fixed-order reduction: bitwise reproducible
 
 
+def test_pass_with_reserved_cus_gives_the_same_sums(be):
+    """Leaving CUs to other streams changes the slab count, not the result beyond f64 summation order."""
+    from odx.backend import Knm
+    rng = np.random.default_rng(5)
+    n, M = 3000, 6000
+    Kh = rng.random((n, M), dtype=np.float32)
+    K = Knm(); K.K = dev(Kh); K.n, K.M, K.ld = n, M, M
+    v = dev(rng.standard_normal(M))
+    try:
+        a = be.ktk(K, v=v).cpu().numpy()
+        be.reserve_cus_during_passes(32)
+        b = be.ktk(K, v=v).cpu().numpy()
+        be.reserve_cus_during_passes(1000)      # more than half the chip: ignored
+        c = be.ktk(K, v=v).cpu().numpy()
+    finally:
+        be.reserve_cus_during_passes(0)
+    assert np.abs(a - b).max() <= 1e-12 * np.abs(a).max() and np.array_equal(a, c)
+
+
 @pytest.mark.parametrize("M", [1, 100, 128, 129, 300, 1000, 1537])
 def test_potrf_trtri(be, M):
     from odx import hip
