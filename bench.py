@@ -187,7 +187,7 @@ def main():
     # holds all 256 CUs (6.5 ms a time, 22 times per class) that chain stands still and the fit ends up waiting for it
     # (measured: 430 ms from first to last kernel against a 330 ms class period).  32 CUs left to it during the passes
     # cost the HBM-bound passes less than the waiting did: 9.84 -> 9.53 s per step (8 / 16 / 48 / 64 CUs: 9.91 / 9.98 /
-    # 9.61 / 9.82 s).
+    # 9.61 / 9.82 s; a high-priority side stream instead of reserved CUs: 9.60 s; both: 9.44 s — within run-to-run noise).
     be.reserve_cus_during_passes(args.reserve_cus)
     nslot = depth + 1
     sides = [torch.cuda.Stream() for _ in range(nslot)]
