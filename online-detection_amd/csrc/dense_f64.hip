@@ -231,7 +231,9 @@ __device__ __forceinline__ void lds_store_dinv_128(const double* s, double* __re
 }
 
 // A (jb x jb, lower part read) -> L in place (strict upper zeroed); Dinv (128 x 128, ld 128) = L^-1.
-template <int NB>
+// WITH_INV = false stops after the factorisation: the four 32 x 32 diagonal inverses stay parked in the tail of the
+// block's Dinv slot (where trsm128_kernel reads them) and the 128 x 128 inverse is left to a batched pass.
+template <int NB, bool WITH_INV>
 __global__ __launch_bounds__(DB_NT) void potrf_diag_kernel(double* __restrict__ A, int64_t lda, int jb,
                                                           double* __restrict__ Dinv, int32_t* __restrict__ info,
                                                           int info_base) {
@@ -248,10 +250,115 @@ __global__ __launch_bounds__(DB_NT) void potrf_diag_kernel(double* __restrict__ 
     const int i = e / jb, j = e % jb;
     A[(int64_t)i * lda + j] = (j <= i) ? s[i * DB_LD + j] : 0.0;
   }
+  if (!WITH_INV) return;
   __threadfence_block();
   lds_trinv_128<true>(s, xi, rd, gx);
   lds_store_dinv_128(s, Dinv, jb);
 }
+
+// L21 <- A21 L11^-T for a 128-wide panel by block forward substitution over four 32-column blocks, using the
+// 32 x 32 diagonal inverses X_JJ left by potrf_diag_kernel<.., false>:
+//     L21[:, J] = (A21[:, J] - sum_{k < 32 J} L21[:, k] L11[J, k]') X_JJ'
+// One workgroup owns 32 rows; everything it needs sits in LDS (33 + 25 + 8 + 8 KB).  This replaces a generic in-place
+// GEMM against the explicit 128 x 128 inverse, which put that inverse (45 us on one CU) on the critical path of
+// every block step.
+constexpr int TS_R = 64;          // rows per workgroup
+constexpr int TS_TLD = 130;       // LDS row strides (f64): 4 r + 2 kq banks over a 32-lane half => conflict-free ds_read_b64
+constexpr int TS_BLD = 34;
+typedef double f64x4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void trsm128_kernel(double* __restrict__ A21, int64_t lda, int64_t m,
+                                                      const double* __restrict__ L11, const double* __restrict__ gx) {
+  extern __shared__ __attribute__((aligned(16))) double ts_lds[];
+  double* T = ts_lds;                                  // TS_R x TS_TLD; columns of block J double as S
+  double* Lb = T + TS_R * TS_TLD;                      // 6 blocks L11[J, I] (I < J), each 32 x TS_BLD, [c][k]
+  double* Xb = Lb + 6 * 32 * TS_BLD;                   // 4 blocks X_JJ, each 32 x TS_BLD, [c][k], zero above the diagonal
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * TS_R;
+  const int rows = (int)(m - r0 < TS_R ? m - r0 : TS_R);
+  // everything this workgroup needs, in one round of loads: all the 16-byte loads of a thread are issued before the
+  // first of them is consumed (a load -> LDS store loop would wait out the L2 latency once per element)
+  {
+    f64x2 vt[16], vl[12], vx[8];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {                  // T: 64 rows x 64 pairs
+      const int e = tid + 256 * q, r = e >> 6, c = (e & 63) * 2;
+      vt[q] = (r < rows) ? *reinterpret_cast<const f64x2*>(A21 + (r0 + r) * lda + c) : f64x2{0.0, 0.0};
+    }
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {                  // 6 blocks x 32 rows x 16 pairs
+      const int e = tid + 256 * q, blk = e >> 9, i = (e >> 4) & 31, k = (e & 15) * 2;
+      const int J = blk < 1 ? 1 : (blk < 3 ? 2 : 3), I = blk - (J * (J - 1)) / 2;
+      vl[q] = *reinterpret_cast<const f64x2*>(L11 + (int64_t)(32 * J + i) * lda + 32 * I + k);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) vx[q] = *reinterpret_cast<const f64x2*>(gx + (tid + 256 * q) * 2);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int e = tid + 256 * q, r = e >> 6, c = (e & 63) * 2;
+      *reinterpret_cast<f64x2*>(&T[r * TS_TLD + c]) = vt[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+      const int e = tid + 256 * q, blk = e >> 9, i = (e >> 4) & 31, k = (e & 15) * 2;
+      *reinterpret_cast<f64x2*>(&Lb[(blk * 32 + i) * TS_BLD + k]) = vl[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = (tid + 256 * q) * 2;
+      *reinterpret_cast<f64x2*>(&Xb[((e >> 10) * 32 + ((e >> 5) & 31)) * TS_BLD + (e & 31)]) = vx[q];
+    }
+  }
+  __syncthreads();
+  // 64 x 32 outputs per column block = 4 x 2 MFMA tiles of 16 x 16; wave w owns row tile w, both column tiles.
+  const int ar = wave * 16 + (lane & 15), kq = lane >> 4, bc = lane & 15;
+#pragma unroll
+  for (int J = 0; J < 4; ++J) {
+    f64x4v s0 = {0.0, 0.0, 0.0, 0.0}, s1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int I = 0; I < J; ++I) {
+      const double* lb = Lb + (((J * (J - 1)) / 2 + I) * 32) * TS_BLD;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const double a = T[ar * TS_TLD + 32 * I + 4 * ks + kq];
+        s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, lb[bc * TS_BLD + 4 * ks + kq], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, lb[(16 + bc) * TS_BLD + 4 * ks + kq], s1, 0, 0, 0);
+      }
+    }
+    // S = A21[:, J] - (L21[:, < J] L11[J, < J]'), written over the J columns of T (only this wave's rows)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = wave * 16 + (lane >> 4) + 4 * q;
+      T[r * TS_TLD + 32 * J + bc] -= s0[q];
+      T[r * TS_TLD + 32 * J + 16 + bc] -= s1[q];
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);    // lgkmcnt(0): this wave's own LDS writes before it reads them back
+    __builtin_amdgcn_wave_barrier();
+    f64x4v y0 = {0.0, 0.0, 0.0, 0.0}, y1 = {0.0, 0.0, 0.0, 0.0};
+    const double* xb = Xb + (J * 32) * TS_BLD;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const double a = T[ar * TS_TLD + 32 * J + 4 * ks + kq];
+      y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[bc * TS_BLD + 4 * ks + kq], y0, 0, 0, 0);
+      y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, xb[(16 + bc) * TS_BLD + 4 * ks + kq], y1, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();       // every lane of the wave has read S before it is overwritten
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = wave * 16 + (lane >> 4) + 4 * q;
+      T[r * TS_TLD + 32 * J + bc] = y0[q];
+      T[r * TS_TLD + 32 * J + 16 + bc] = y1[q];
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int e = tid + 256 * q, r = e >> 6, c = (e & 63) * 2;
+    if (r < rows) *reinterpret_cast<f64x2*>(A21 + (r0 + r) * lda + c) = *reinterpret_cast<const f64x2*>(&T[r * TS_TLD + c]);
+  }
+}
+constexpr int TS_LDS_BYTES = (TS_R * TS_TLD + 10 * 32 * TS_BLD) * (int)sizeof(double);   // 153,600 B
 
 // ---------------------------------------------------------------- small utility kernels
 __global__ __launch_bounds__(256) void transpose_f64_kernel(const double* __restrict__ src, int64_t lds_,
@@ -374,6 +481,19 @@ int fill_f64(double* A, int64_t lda, int64_t rows, int64_t cols, double value, h
   return ODX_OK;
 }
 
+// 128 x 128 inverses of all diagonal blocks of a lower-triangular L, one workgroup per block.
+__global__ __launch_bounds__(DB_NT) void trtri_diag_kernel(const double* __restrict__ L, int64_t ldl, int64_t M,
+                                                          double* __restrict__ Dinv) {
+  __shared__ double s[DB_NB * DB_LD];
+  __shared__ double xi[32 * DB_XLD];
+  const int64_t r0 = (int64_t)blockIdx.x * DB_NB;
+  const int jb = (int)(M - r0 < DB_NB ? M - r0 : DB_NB);
+  __shared__ double rd[32];
+  lds_load_lower_128(s, L + r0 * ldl + r0, ldl, jb);
+  lds_trinv_128<false>(s, xi, rd, nullptr);
+  lds_store_dinv_128(s, Dinv + (int64_t)blockIdx.x * DB_NB * DB_NB, jb);
+}
+
 struct SideStream {
   hipStream_t stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
@@ -420,6 +540,8 @@ constexpr int POTRF_NBO = 512;
 int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hipStream_t stream) {
   constexpr int NB = POTRF_NB;
   ODX_REQUIRE(lda % 2 == 0 && aligned16(A) && aligned16(Dinv), "potrf_f64: A/Dinv must be 16-byte aligned, lda even");
+  ODX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    TS_LDS_BYTES));
   SideStream* look = nullptr;
   ODX_PROPAGATE(side_stream(&look, 1));
   bool pending = false;      // a trailing update is in flight on the helper stream
@@ -428,16 +550,15 @@ int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hi
     for (int64_t k0 = K0; k0 < K0 + kbo; k0 += NB) {
       const int jb = (int)(M - k0 < NB ? M - k0 : NB);
       double* D = Dinv + (k0 / NB) * NB * NB;
-      hipLaunchKernelGGL(potrf_diag_kernel<NB>, dim3(1), dim3(DB_NT), 0, stream, A + k0 * lda + k0, lda, jb, D, info,
-                         (int)k0);
+      hipLaunchKernelGGL((potrf_diag_kernel<NB, false>), dim3(1), dim3(DB_NT), 0, stream, A + k0 * lda + k0, lda, jb, D,
+                         info, (int)k0);
       ODX_CHECK_LAUNCH("potrf_diag");
       const int64_t m = M - k0 - jb;
       if (m <= 0) break;
       double* A21 = A + (k0 + jb) * lda + k0;
-      GemmParams<double> t;
-      t.A = A21; t.lda = lda; t.B = D; t.ldb = NB; t.C = A21; t.ldc = lda;
-      t.m = m; t.n = jb; t.k = jb; t.alpha = 1.0; t.beta = 0.0; t.flags = ODX_GEMM_B_LOWER;
-      ODX_PROPAGATE(launch_gemm_f64(t, stream));
+      hipLaunchKernelGGL(trsm128_kernel, dim3((unsigned)ceil_div(m, TS_R)), dim3(256), TS_LDS_BYTES, stream, A21, lda, m,
+                         A + k0 * lda + k0, D + NB * NB - 4096);
+      ODX_CHECK_LAUNCH("trsm128");
       const int64_t pc = (K0 + kbo) - (k0 + jb);  // panel columns right of this block
       if (pc > 0) {
         GemmParams<double> u;
@@ -477,6 +598,9 @@ int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hi
     }
   }
   if (pending) ODX_CHECK_HIP(hipStreamWaitEvent(stream, look->join, 0));
+  // Dinv: the 128 x 128 inverses of all diagonal blocks in one batched launch (off the block-by-block critical path)
+  hipLaunchKernelGGL(trtri_diag_kernel, dim3((unsigned)ceil_div(M, NB)), dim3(DB_NT), 0, stream, A, lda, M, Dinv);
+  ODX_CHECK_LAUNCH("trtri_diag");
   return ODX_OK;
 }
 
@@ -583,19 +707,6 @@ extern "C" int odx_potrf_f64(double* A, int64_t lda, int64_t M, int32_t* info, v
 extern "C" int64_t odx_trtri_workspace_bytes(int64_t M) {
   if (M <= 0) return 0;
   return odx_potrf_workspace_bytes(M) + M * M * (int64_t)sizeof(double);
-}
-
-// Stand-alone triangular inverse (tests, RLS): re-derives the diagonal-block inverses from L.
-__global__ __launch_bounds__(DB_NT) void trtri_diag_kernel(const double* __restrict__ L, int64_t ldl, int64_t M,
-                                                          double* __restrict__ Dinv) {
-  __shared__ double s[DB_NB * DB_LD];
-  __shared__ double xi[32 * DB_XLD];
-  const int64_t r0 = (int64_t)blockIdx.x * DB_NB;
-  const int jb = (int)(M - r0 < DB_NB ? M - r0 : DB_NB);
-  __shared__ double rd[32];
-  lds_load_lower_128(s, L + r0 * ldl + r0, ldl, jb);
-  lds_trinv_128<false>(s, xi, rd, nullptr);
-  lds_store_dinv_128(s, Dinv + (int64_t)blockIdx.x * DB_NB * DB_NB, jb);
 }
 
 extern "C" int odx_trtri_f64(const double* L, int64_t ldl, int64_t M, double* Li, double* Lit, int64_t ld,
