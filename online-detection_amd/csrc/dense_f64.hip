@@ -7,6 +7,7 @@
 namespace odx {
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef double f64x4v __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------- diagonal block: chol + inverse
 // One 512-thread workgroup owns a 128 x 128 diagonal block in LDS (rows padded to 129 f64)
@@ -84,7 +85,6 @@ __device__ __forceinline__ void inv32_wave(const double* s, const double* rd, in
 __device__ __forceinline__ void lds_chol_128(double* s, double* xi, double* rd, double* __restrict__ gx, int jb,
                                              int32_t* info, int info_base) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tx = tid & 31, ty = tid >> 5;
   for (int J = 0; J < DB_NB; J += 32) {
     if (wave == 0) {
       chol32_wave(s, rd, J, jb, info, info_base, lane);
@@ -96,52 +96,48 @@ __device__ __forceinline__ void lds_chol_128(double* s, double* xi, double* rd, 
     for (int e = tid; e < 1024; e += DB_NT) gx[(J >> 5) * 1024 + e] = xi[(e >> 5) * DB_XLD + (e & 31)];
     const int nrem = DB_NB - J - 32;  // rows below the panel
     if (nrem > 0) {
-      // panel: L21[i][c] = sum_k A21[i][k] * X11[c][k]
-      double pv[DB_PQ];
+      // Both products run on v_mfma_f64_16x16x4_f64 (16 x 16 tiles dealt round-robin to the 8 waves); operands come
+      // straight from LDS: lane l feeds row / column (l & 15), k = 4 ks + (l >> 4).
+      const int tr = lane & 15, kq = lane >> 4, nt16 = nrem >> 4;
+      // panel: L21[i][c] = sum_k A21[i][k] * X11[c][k]       (nrem x 32, k = 32)
+      f64x4v pacc[2];
 #pragma unroll
-      for (int q = 0; q < DB_PQ; ++q) {
-        const int e = tid + DB_NT * q;
-        const int i = J + 32 + (e >> 5), c = e & 31;
-        double a = 0.0;
-        if (i < DB_NB) {
-#pragma unroll 8
-          for (int k = 0; k < 32; ++k) a = fma(s[i * DB_LD + J + k], xi[c * DB_XLD + k], a);
+      for (int u = 0; u < 2; ++u) {
+        const int t = wave + 8 * u;
+        pacc[u] = f64x4v{0.0, 0.0, 0.0, 0.0};
+        if (t < 2 * nt16) {
+          const int tm = t >> 1, tn = t & 1;
+          const double* pa = s + (J + 32 + tm * 16 + tr) * DB_LD + J + kq;
+          const double* pb = xi + (tn * 16 + tr) * DB_XLD + kq;
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) pacc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * ks], pb[4 * ks], pacc[u], 0, 0, 0);
         }
-        pv[q] = a;
+      }
+      __syncthreads();      // every tile has read its A21 rows before any of them is overwritten
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = wave + 8 * u;
+        if (t < 2 * nt16) {
+          const int tm = t >> 1, tn = t & 1;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) s[(J + 32 + tm * 16 + kq + 4 * q) * DB_LD + J + tn * 16 + tr] = pacc[u][q];
+        }
       }
       __syncthreads();
+      // trailing update, lower tiles (a >= b): s[i][k2] -= sum_c L21[i][c] L21[k2][c]      (k = 32)
+      const int ntl = nt16 * (nt16 + 1) / 2;
+#pragma unroll 1
+      for (int t = wave; t < ntl; t += 8) {
+        int ta = 0, tb = t;
+        while (tb > ta) { tb -= ta + 1; ++ta; }          // t -> (ta, tb), tb <= ta
+        const double* pa = s + (J + 32 + ta * 16 + tr) * DB_LD + J + kq;
+        const double* pb = s + (J + 32 + tb * 16 + tr) * DB_LD + J + kq;
+        f64x4v acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int q = 0; q < DB_PQ; ++q) {
-        const int e = tid + DB_NT * q;
-        const int i = J + 32 + (e >> 5), c = e & 31;
-        if (i < DB_NB) s[i * DB_LD + J + c] = pv[q];
+        for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * ks], pb[4 * ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[(J + 32 + ta * 16 + kq + 4 * q) * DB_LD + J + 32 + tb * 16 + tr] -= acc[q];
       }
-      __syncthreads();
-      // trailing update (lower blocks): s[i][k] -= sum_c L21[i][c] L21[k][c]
-      const int na = nrem >> 5;  // 32-row blocks left: 3, 2, 1
-      double acc[6][3];
-#pragma unroll
-      for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) acc[a][b] = 0.0;
-      const int ib = J + 32 + ty, kb = J + 32 + tx;  // ty in [0, 16): rows ib + 16 a; cols kb + 32 b
-#pragma unroll 4
-      for (int c = 0; c < 32; ++c) {
-        double av[6], bv[3];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) av[a] = (a < 2 * na) ? s[(ib + 16 * a) * DB_LD + J + c] : 0.0;
-#pragma unroll
-        for (int b = 0; b < 3; ++b) bv[b] = (b < na) ? s[(kb + 32 * b) * DB_LD + J + c] : 0.0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-          for (int b = 0; b <= (a >> 1); ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
-      }
-#pragma unroll
-      for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int b = 0; b <= (a >> 1); ++b)
-          if (a < 2 * na) s[(ib + 16 * a) * DB_LD + kb + 32 * b] -= acc[a][b];
       __syncthreads();
     }
   }
@@ -265,7 +261,6 @@ __global__ __launch_bounds__(DB_NT) void potrf_diag_kernel(double* __restrict__ 
 constexpr int TS_R = 64;          // rows per workgroup
 constexpr int TS_TLD = 130;       // LDS row strides (f64): 4 r + 2 kq banks over a 32-lane half => conflict-free ds_read_b64
 constexpr int TS_BLD = 34;
-typedef double f64x4v __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void trsm128_kernel(double* __restrict__ A21, int64_t lda, int64_t m,
                                                       const double* __restrict__ L11, const double* __restrict__ gx) {
   extern __shared__ __attribute__((aligned(16))) double ts_lds[];
