@@ -48,8 +48,10 @@ def parse():
     ap.add_argument("--lam", type=float, default=1e-5)
     ap.add_argument("--maxiter", type=int, default=20)
     ap.add_argument("--warmup-classes", type=int, default=2, help="classes run per warm-up step")
-    ap.add_argument("--precond-depth", type=int, default=0, help="batches of preconditioners in flight ahead of the fit (default 1; deeper look-ahead measured within 1 %%)")
-    ap.add_argument("--reserve-cus", type=int, default=32, help="CUs the persistent pass kernel leaves to the side streams")
+    ap.add_argument("--precond-depth", type=int, default=0, help="batches of preconditioners in flight ahead of the fit (default 3)")
+    ap.add_argument("--reserve-cus", type=int, default=0, help="CUs the persistent pass kernel leaves to the side streams")
+    ap.add_argument("--precond-before-fit", dest="precond_after_fit", action="store_false",
+                    help="issue the look-ahead preconditioner before the batch's fit instead of behind its CG")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0 = pick by host core count")
     ap.add_argument("--check", action="store_true", help="verify one class against the oracle on a row sample")
@@ -182,12 +184,16 @@ def main():
     # Preconditioners are built `depth` batches ahead, each on its own side stream with its own output slot and
     # scratch, so the chains of small latency-bound factorisation kernels fill gaps of the main stream.  (Measured on
     # one GPU: depth 1, 2, 3 within 1 % of each other — what the factorisations cost is CU time, not latency.)
-    depth = args.precond_depth if args.precond_depth > 0 else 1
-    # The next batch's preconditioner is a chain of ~1500 small kernels on a side stream; while the persistent pass kernel
-    # holds all 256 CUs (6.5 ms a time, 22 times per class) that chain stands still and the fit ends up waiting for it
-    # (measured: 430 ms from first to last kernel against a 330 ms class period).  32 CUs left to it during the passes
-    # cost the HBM-bound passes less than the waiting did: 9.84 -> 9.53 s per step (8 / 16 / 48 / 64 CUs: 9.91 / 9.98 /
-    # 9.61 / 9.82 s; a high-priority side stream instead of reserved CUs: 9.60 s; both: 9.44 s — within run-to-run noise).
+    depth = args.precond_depth if args.precond_depth > 0 else 3
+    # Scheduling of the look-ahead preconditioners (chains of ~1500 small f64 kernels, ~57 ms alone) against the main
+    # stream, measured on one GPU at the headline size (s per step | pass rate in the timed region):
+    #   issued before the batch's fit, depth 1, passes on all CUs          9.73-9.98 | 5.8-6.1 TB/s  (the persistent pass
+    #       kernel holds every CU 6.5 ms at a time, the chain stands still through the CG and the fit waits for it)
+    #   same, pass kernel leaves 32 CUs free (--precond-before-fit --reserve-cus 32 --precond-depth 1)
+    #                                                                        9.36-9.60 | 5.0-5.3 TB/s
+    #   issued behind the batch's CG (runs beside the MFMA-bound scoring / next build), depth 1    9.93 | 6.2 TB/s
+    #   issued behind the CG, depth 3 (default)                              9.66-9.71 | 5.8-5.9 TB/s
+    # The default keeps the HBM-bound passes (the dominant kernel) close to their own rate at 1-3 % of whole-job time.
     be.reserve_cus_during_passes(args.reserve_cus)
     nslot = depth + 1
     sides = [torch.cuda.Stream() for _ in range(nslot)]
@@ -218,7 +224,7 @@ def main():
         batches = [classes[b0:b0 + world] for b0 in range(0, len(classes), world)]
         ready = {bi: prepare(batches[bi], bi % nslot, timed) for bi in range(min(depth, len(batches)))}
         for bi, batch in enumerate(batches):
-            if bi + depth < len(batches):
+            if not args.precond_after_fit and bi + depth < len(batches):
                 ready[bi + depth] = prepare(batches[bi + depth], (bi + depth) % nslot, timed)
             Zs, P, ev = ready.pop(bi)
             ys = [torch.where((row_ids % C) == c, 1.0, -1.0).to(torch.float64) for c in batch]
@@ -227,6 +233,10 @@ def main():
                                              knm_outs=kbufs[:len(batch)], phase=(lambda name: ph[name]) if timed else None,
                                              precond=P if mine else None,
                                              precond_ready=(lambda: torch.cuda.current_stream().wait_event(ev)) if mine else None)
+            if args.precond_after_fit and bi + depth < len(batches):
+                # issued behind this batch's CG in stream order: the factorisations then run beside the MFMA-bound scoring of
+                # this batch and K_nM build of the next, and the HBM-bound passes keep the chip to themselves
+                ready[bi + depth] = prepare(batches[bi + depth], (bi + depth) % nslot, timed)
             for pos, c in enumerate(batch):
                 with ph["mmv"] if timed else _null():
                     be.mmv(F, Zs[pos], args.sigma, alphas[pos], None, out=scores[:, c:c + 1])
