@@ -56,3 +56,18 @@ for k, v in agg.items():
         line += "; LDS bank-conflict cycles %.3g of %.3g LDS-active" % (c["SQ_LDS_BANK_CONFLICT"], c.get("SQ_LDS_IDX_ACTIVE", 0))
     print(line)
     print("  raw: " + json.dumps({n: float("%.5g" % x) for n, x in c.items()}))
+
+print("""
+## Reading notes
+
+* The preconditioner kernels (`gemm_nt_kernel<double, ..>`, `potrf_diag_kernel`, `trsm128_kernel`, `trtri_diag_kernel`,
+  `gauss_kmm_f64_kernel`) run on side streams beside the main stream's kernels.  Their durations in the stats table are
+  first-wave-to-last-wave times that include waiting for a free CU behind the main stream's workgroups (a
+  `trsm128_kernel` takes 14 us and a `potrf_diag_kernel` 75 us on an idle GPU): the table's percentages add up to more
+  than the wall time and say nothing about how much of the GPU those kernels used.
+* `knm_pass_kernel`: algorithmic bytes per launch = n x M x 4 (40.0 GB at n = 1e6, M = 1e4); the FETCH_SIZE counter
+  (doubled per the gfx950 correction of the guide) gives the same number: K_nM is read exactly once per pass.
+* The Gaussian kernels issue 3 f16 MFMAs per algorithmic product (two-term f16 split); MFMA-busy ~53 % at the
+  ~1.8 GHz the chip holds under them (GRBM_GUI_ACTIVE / 8 / time).  Their FETCH_SIZE counts L2 misses, most of them served
+  by the Infinity Cache (unique input: 4.1 GB of packed X + 41 MB of packed Z per launch).
+""")
