@@ -81,10 +81,11 @@ int odx_gauss_knm_h2(const void* PX, int64_t ldpx, const float* metax, const flo
                      const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int D,
                      double sigma, float* K, int64_t ldk, odx_stream_t stream);
 /* Scoring is tiled over (row block, group of 4 column tiles); the f64 partial sums of the groups pass through
- * `workspace` (odx_gauss_mmv_h2_workspace_bytes(n, Mtot, T)) and are added in fixed order.  Mtot = rows of V / PZ. */
-int64_t odx_gauss_mmv_h2_workspace_bytes(int64_t n, int64_t Mtot, int T);
+ * `workspace` (odx_gauss_mmv_h2_workspace_bytes(n, max_range, T)) and are added in fixed order.  max_range must be
+ * >= the longest per-column row range (ranges[2c+1] - ranges[2c]); pass the number of rows of V when unknown. */
+int64_t odx_gauss_mmv_h2_workspace_bytes(int64_t n, int64_t max_range, int T);
 int odx_gauss_mmv_h2(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
-                     const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t Mtot, int D,
+                     const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t max_range, int D,
                      double sigma, const double* V, int64_t ldv, const int32_t* ranges, int T,
                      float* out, int64_t ldo, void* workspace, int64_t workspace_bytes, odx_stream_t stream);
 

@@ -326,7 +326,8 @@ __global__ __launch_bounds__(256) void mmv_reduce_kernel(const double* __restric
   if (row >= n) return;
   const int64_t len = (int64_t)ranges[2 * c + 1] - ranges[2 * c];
   const int64_t tiles = len > 0 ? (len + GEMM_BN - 1) / GEMM_BN : 0;
-  const int groups = (int)((tiles + tg - 1) / tg);
+  int groups = (int)((tiles + tg - 1) / tg);
+  groups = groups < G ? groups : G;     // the caller promised max_range >= every range length
   double s = 0.0;
   for (int g = 0; g < groups; ++g) s += slab[((int64_t)c * G + g) * slab_ld + row];
   out[row * ldo + c] = (float)s;
@@ -392,29 +393,31 @@ extern "C" int odx_gauss_knm_h2(const void* PX, int64_t ldpx, const float* metax
   return ODX_OK;
 }
 
-extern "C" int64_t odx_gauss_mmv_h2_workspace_bytes(int64_t n, int64_t Mtot, int T) {
-  if (n <= 0 || Mtot <= 0 || T <= 0) return 0;
-  const int64_t G = ceil_div(ceil_div(Mtot, GEMM_BN), MMV_TG);
-  return (int64_t)T * G * round_up(n, 2) * (int64_t)sizeof(double);
+// groups of column tiles (counted from the range's own first row) a centre range of at most `max_range` rows spans
+static int64_t mmv_groups(int64_t max_range) { return ceil_div(ceil_div(max_range, GEMM_BN), MMV_TG); }
+
+extern "C" int64_t odx_gauss_mmv_h2_workspace_bytes(int64_t n, int64_t max_range, int T) {
+  if (n <= 0 || max_range <= 0 || T <= 0) return 0;
+  return (int64_t)T * mmv_groups(max_range) * round_up(n, 2) * (int64_t)sizeof(double);
 }
 
 extern "C" int odx_gauss_mmv_h2(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
-                                const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t Mtot, int D,
+                                const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t max_range, int D,
                                 double sigma, const double* V, int64_t ldv, const int32_t* ranges, int C, float* out,
                                 int64_t ldo, void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
   if (n <= 0 || C <= 0) return ODX_OK;
-  ODX_REQUIRE(PX && PZ && metax && metaz && xsq && zsq && V && ranges && out && D > 0 && sigma > 0 && ldv >= C && Mtot > 0,
+  ODX_REQUIRE(PX && PZ && metax && metaz && xsq && zsq && V && ranges && out && D > 0 && sigma > 0 && ldv >= C && max_range > 0,
               "odx_gauss_mmv_h2: bad argument");
   const int64_t dp = round_up(D, H2_KT);
   ODX_REQUIRE(ldpx % 4 == 0 && ldpz % 4 == 0 && ldpx >= dp && ldpz >= dp && aligned16(PX) && aligned16(PZ),
               "odx_gauss_mmv_h2: packed operands must be 16-byte aligned with ld %% 4 == 0 and ld >= roundup(D, 64)");
   ODX_REQUIRE(ldo >= C && C < 65536, "odx_gauss_mmv_h2: ldo < C or too many classes");
   ODX_REQUIRE(ldpx < (1 << 24) && ldpz < (1 << 24), "odx_gauss_mmv_h2: leading dimensions must stay below 2^24 (32-bit tile offsets)");
-  if (workspace == nullptr || workspace_bytes < odx_gauss_mmv_h2_workspace_bytes(n, Mtot, C)) {
+  if (workspace == nullptr || workspace_bytes < odx_gauss_mmv_h2_workspace_bytes(n, max_range, C)) {
     set_error("odx_gauss_mmv_h2: workspace too small");
     return ODX_ERR_WORKSPACE;
   }
-  const int G = (int)ceil_div(ceil_div(Mtot, GEMM_BN), MMV_TG);
+  const int G = (int)mmv_groups(max_range);
   const int64_t wgs = round_up(ceil_div(n, GEMM_BM), 8) * G;
   ODX_REQUIRE(wgs < (1ll << 31), "odx_gauss_mmv_h2: grid too large");
   double* slab = static_cast<double*>(workspace);

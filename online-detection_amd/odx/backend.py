@@ -209,9 +209,10 @@ class HipBackend:
         hip.check(self.lib.odx_axpby_f64(float(a), _p(x), float(b), _p(y), y.numel(), self._stream()), "odx_axpby_f64")
 
     # ------------------------------------------------------------------ scoring
-    def mmv(self, F, Zf, sigma, V, ranges=None, out=None):
+    def mmv(self, F, Zf, sigma, V, ranges=None, out=None, max_range=None):
         """(n, T) f32 = K(F, Zf) @ V with V (Mtot, T) f64; ``ranges`` (T, 2) int32 row ranges of the
-        non-zero block of each column (None = dense)."""
+        non-zero block of each column (None = dense); ``max_range``: an upper bound of the range lengths when the
+        caller knows one (sizes the launch; default Mtot)."""
         V = V.to(device=self.device, dtype=torch.float64)
         if V.dim() == 1:
             V = V[:, None]
@@ -230,9 +231,10 @@ class HipBackend:
             return out.zero_()
         if self.gauss == "h2":
             self.pack(F), self.pack(Zf)
-            ws = self._workspace("mmv", self.lib.odx_gauss_mmv_h2_workspace_bytes(F.n, Mtot, T))
+            mr = Mtot if max_range is None else max(1, min(int(max_range), Mtot))
+            ws = self._workspace("mmv", self.lib.odx_gauss_mmv_h2_workspace_bytes(F.n, mr, T))
             hip.check(self.lib.odx_gauss_mmv_h2(_p(F.P), F.P.stride(0), _p(F.meta), _p(F.sq), F.n, _p(Zf.P), Zf.P.stride(0),
-                                                _p(Zf.meta), _p(Zf.sq), Mtot, F.D, float(sigma), _p(V), V.stride(0), _p(ranges), T,
+                                                _p(Zf.meta), _p(Zf.sq), mr, F.D, float(sigma), _p(V), V.stride(0), _p(ranges), T,
                                                 _p(out), out.stride(0), _p(ws), ws.numel(), self._stream()), "odx_gauss_mmv_h2")
         else:
             hip.check(self.lib.odx_gauss_mmv_f32(_p(F.X), F.ld, _p(F.sq), F.n, _p(Zf.X), Zf.ld, _p(Zf.sq), F.D,

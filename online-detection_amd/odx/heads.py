@@ -79,9 +79,10 @@ class _OnlineHead:
                     V[row:row + m.M, i] = m.alpha_.to(dev, torch.float64).reshape(-1)
                     ranges[i, 0], ranges[i, 1] = row, row + m.M
                     row += m.M
-            self._cls_cache = (be.features(ny), V, ranges.to(dev), live[0].kernel.sigma)
-        Zf, V, ranges, sigma = self._cls_cache
-        s = be.mmv(F, Zf, sigma, V, ranges)
+            longest = int((ranges[:, 1] - ranges[:, 0]).max()) if C else 0
+            self._cls_cache = (be.features(ny), V, ranges.to(dev), live[0].kernel.sigma, longest)
+        Zf, V, ranges, sigma, longest = self._cls_cache
+        s = be.mmv(F, Zf, sigma, V, ranges, max_range=longest)
         for i, m in enumerate(self.classifiers):
             if not m:
                 s[:, i] = fill

@@ -117,7 +117,7 @@ class OracleBackend:
     def axpby(self, a, x, b, y):
         y.mul_(b).add_(a * x)
 
-    def mmv(self, F, Zf, sigma, V, ranges=None, out=None):
+    def mmv(self, F, Zf, sigma, V, ranges=None, out=None, max_range=None):
         V = torch.as_tensor(V, dtype=torch.float64)
         if V.dim() == 1:
             V = V[:, None]
