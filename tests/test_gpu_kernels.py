@@ -278,6 +278,23 @@ def test_falkon_fit_alpha_parity(be, gauss, n, M, D, sigma, lam):
     assert np.abs(pred - pref).max() < 1e-4
 
 
+def test_fit_is_bitwise_reproducible(be):
+    """No float atomics anywhere on the path (slab reductions in fixed order, look-ahead streams only reorder
+    independent work): two fits of the same problem give identical bits."""
+    import odx
+    from tests.synth import blob_problem, centres
+    X, y, rng = blob_problem(6000, 256, seed=21)
+    idx = centres(y, 700, rng)
+    F = be.features(torch.from_numpy(X))
+    Zf = be.rows(F, idx)
+    a = odx.falkon_fit(be, F, be.vec(y), Zf, 10.0, 1e-5, 20).cpu().numpy()
+    b = odx.falkon_fit(be, F, be.vec(y), Zf, 10.0, 1e-5, 20).cpu().numpy()
+    assert np.array_equal(a, b)
+    s1 = be.mmv(F, Zf, 10.0, torch.from_numpy(a)).cpu().numpy()
+    s2 = be.mmv(F, Zf, 10.0, torch.from_numpy(a)).cpu().numpy()
+    assert np.array_equal(s1, s2)
+
+
 def test_mmv_block_structure(be, gauss):
     from odx.falkon import block_ranges
     from oracle import falkon_ref as fr
