@@ -301,7 +301,8 @@ def main():
         if be.gauss == "h2":
             # algorithmic flops (2 n M D) against the dense f16 MFMA peak; the two-term split issues 3 f16 MFMAs per
             # algorithmic product, so this formulation's own ceiling is peak / 3 (frac_of_split_ceiling)
-            roof_g = {"bound": "mfma", "kernel": "gauss_knm_h2s16_kernel+gauss_mmv_h2s16_kernel", "achieved": round(gach, 2),
+            core = "h2w256" if be.lib.odx_gauss_h2_tile(n_loc, M) == 256 else "h2s16"
+            roof_g = {"bound": "mfma", "kernel": "gauss_knm_%s_kernel+gauss_mmv_%s_kernel" % (core, core), "achieved": round(gach, 2),
                       "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gach / F16_MFMA_PEAK_TFLOPS, 4),
                       "frac_of_split_ceiling": round(3 * gach / F16_MFMA_PEAK_TFLOPS, 4),
                       "traffic": None, "avg_launch_ms": round(gauss_ms / max(gauss_launches, 1), 3)}

@@ -71,16 +71,20 @@ int odx_gauss_mmv_f32(const float* X, int64_t ldx, const float* xsq, int64_t n,
  * f16 terms (hi + lo, after a power-of-two scale) and  x.z = hi.hi + hi.lo + lo.hi  accumulates in f32.
  *
  * odx_split_f16 packs an f32 matrix for those kernels.  P: n rows of ldp 4-byte units, ldp % 4 == 0,
- * ldp >= roundup(D, 64); k-tile t (features 64 t .. 64 t + 63) of a row is 256 contiguous bytes, 64 f16 "hi"
- * then 64 f16 "lo"; features past D are zero.  meta: 2 DEVICE floats; on return meta[0] = the scale that was
+ * ldp >= roundup(D, 64); granule t (features 32 t .. 32 t + 31) of a row is 128 contiguous bytes, 32 f16 "hi"
+ * then 32 f16 "lo"; features past D are zero.  meta: 2 DEVICE floats; on return meta[0] = the scale that was
  * applied (2^(13 - e) for max |x| = 1.m x 2^e), meta[1] = bits of max |x| (scratch).  Rows gathered from P
  * keep the same meta.                                                                              */
 int odx_split_f16(const float* X, int64_t ldx, int64_t n, int D, void* P, int64_t ldp, float* meta,
                   odx_stream_t stream);
+/* Side of the square output tile (128 or 256) odx_gauss_knm_h2 uses for an n x M block; 0 for an empty one. */
+int odx_gauss_h2_tile(int64_t n, int64_t M);
 int odx_gauss_knm_h2(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
                      const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int D,
                      double sigma, float* K, int64_t ldk, odx_stream_t stream);
-/* Scoring is tiled over (row block, group of 4 column tiles); the f64 partial sums of the groups pass through
+/* Two tile cores serve both calls: 256 x 256 outputs per workgroup (half the L2 traffic per product) once a launch
+ * has >= 512 such tiles, 128 x 128 below that; the environment variable ODX_H2_TILE=128|256 pins one.
+ * Scoring is tiled over (row block, group of 512 centre columns); the f64 partial sums of the groups pass through
  * `workspace` (odx_gauss_mmv_h2_workspace_bytes(n, max_range, T)) and are added in fixed order.  max_range must be
  * >= the longest per-column row range (ranges[2c+1] - ranges[2c]); pass the number of rows of V when unknown. */
 int64_t odx_gauss_mmv_h2_workspace_bytes(int64_t n, int64_t max_range, int T);

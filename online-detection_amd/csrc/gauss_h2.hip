@@ -7,10 +7,17 @@
 // keeps ~22 bits per factor — tools/precision_study.py: the fitted alpha moves exactly as with the all-f32
 // v_mfma_f32_32x32x2_f32 chain — at 3 MFMAs of the f16 rate (16 x the f32 MFMA rate) per f32 MFMA replaced.
 //
-// Packed operand ("h2") layout, produced by odx_split_f16: a row is ldp 4-byte units; k-tile t of a row
-// (64 consecutive features) is 256 contiguous bytes: 64 f16 hi, then 64 f16 lo.  Features past D are zero.
-// Tile: 256 threads (2 x 2 waves), 128 x 128 outputs, a k-tile = 128 rows x 256 B per operand through XOR-swizzled
-// 256-B LDS rows (see the tile core below).
+// Packed operand ("h2") layout, produced by odx_split_f16: a row is ldp 4-byte units; granule t of a row
+// (32 consecutive features) is 128 contiguous, 128-byte aligned bytes — one cache line: 32 f16 hi, then 32 f16 lo.
+// Features past D are zero; ldp covers a whole number of 64-feature pairs of granules.
+// Two tile cores read it:
+//   "s16"  128 x 128 outputs, 256 threads (2 x 2 waves of 64 x 64), k-tile = two granules through XOR-swizzled 256-B
+//          LDS rows, two workgroups per CU.  Draws (128 + 128) x 4 B of operand per k from L2 for 128 x 128 products:
+//          at the headline shapes that is 10.7 TB/s of L2 -> LDS traffic and the L2, not the MFMA, sets its pace
+//          (with two of the three MFMAs removed it still takes 68 % of its time).  Kept for small problems.
+//   "w256" 256 x 256 outputs, 512 threads (2 x 4 waves of 128 x 64), k-stage = one granule through XOR-swizzled 128-B
+//          LDS rows, double-buffered (2 x 64 KiB), one barrier per stage, one workgroup per CU: half the L2 traffic
+//          per product.
 #include <stdlib.h>
 #include "gemm_core.h"
 #include "odx_internal.h"
@@ -75,9 +82,9 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
     hi[q] = h;
     lo[q] = (_Float16)(t - (float)h);
   }
-  uint32_t* dst = P + row * ldp + (int64_t)(g >> 3) * 64 + (g & 7) * 4;   // 4-byte units
+  uint32_t* dst = P + row * ldp + (int64_t)(g >> 2) * 32 + (g & 3) * 4;   // 4-byte units: granule, 16-B chunk
   *reinterpret_cast<f16x8*>(dst) = hi;
-  *reinterpret_cast<f16x8*>(dst + 32) = lo;
+  *reinterpret_cast<f16x8*>(dst + 16) = lo;
 }
 
 // ---------------------------------------------------------------- tile mainloop
@@ -106,9 +113,9 @@ __device__ __forceinline__ void h2_load_operand(u32x4 (&r)[8], const uint32_t* _
 constexpr float LOG2E = 1.4426950408889634f;
 
 // ---------------------------------------------------------------- tile core
-// v_mfma_f32_16x16x32_f16, 4 x 4 blocks per wave.  LDS rows are exactly 256 B with the
-// 16-byte slots of a row XOR-swizzled by (row & 15): logical slot q (hi chunks 0..7, lo chunks 8..15) lives at
-// q ^ (row & 15).  A 16-lane group of ds_read_b128 then touches lanes of two k-groups whose chunk numbers differ only in
+// v_mfma_f32_16x16x32_f16, 4 x 4 blocks per wave.  LDS rows are exactly 256 B (two granules) with the
+// 16-byte slots of a row XOR-swizzled by (row & 15): logical slot q (granule ks: hi chunks 8 ks .. 8 ks + 3, lo chunks
+// 8 ks + 4 .. 8 ks + 7) lives at q ^ (row & 15).  A 16-lane group of ds_read_b128 then touches lanes of two k-groups whose chunk numbers differ only in
 // their low two bits, which keeps the 16 slots distinct (conflict-free), with no padding: 64 KiB per workgroup.
 constexpr int S16_ROW = 256;
 constexpr int S16_LDS_BYTES = (GEMM_BM + GEMM_BN) * S16_ROW;   // 65,536 B
@@ -128,7 +135,7 @@ __device__ __forceinline__ void s16_compute_ktile(f32x4 (&acc)[4][4], const char
   const char* pb = ldsB + (wc * 64 + r) * S16_ROW;
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    const int hi = (((ks * 4 + g) ^ r) << 4), lo = hi ^ 128;
+    const int hi = (((ks * 8 + g) ^ r) << 4), lo = hi ^ 64;
     f16x8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -318,14 +325,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gauss_mmv_h2s16_kernel(
   }
 }
 
-__global__ __launch_bounds__(256) void mmv_reduce_kernel(const double* __restrict__ slab, int64_t slab_ld, int G, int tg,
+__global__ __launch_bounds__(256) void mmv_reduce_kernel(const double* __restrict__ slab, int64_t slab_ld, int G, int tg, int bn,
                                                          const int32_t* __restrict__ ranges, int64_t n,
                                                          float* __restrict__ out, int64_t ldo) {
   const int c = blockIdx.y;
   const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (row >= n) return;
   const int64_t len = (int64_t)ranges[2 * c + 1] - ranges[2 * c];
-  const int64_t tiles = len > 0 ? (len + GEMM_BN - 1) / GEMM_BN : 0;
+  const int64_t tiles = len > 0 ? (len + bn - 1) / bn : 0;
   int groups = (int)((tiles + tg - 1) / tg);
   groups = groups < G ? groups : G;     // the caller promised max_range >= every range length
   double s = 0.0;
@@ -333,11 +340,278 @@ __global__ __launch_bounds__(256) void mmv_reduce_kernel(const double* __restric
   out[row * ldo + c] = (float)s;
 }
 
+// ---------------------------------------------------------------- 256 x 256 tile core ("w256")
+// 512 threads = 8 waves as 2 (rows) x 4 (columns); a wave owns 128 x 64 outputs = 8 x 4 blocks of v_mfma_f32_16x16x32_f16
+// (128 accumulator registers).  A k-stage is one granule (32 features = 128 B) of 256 rows of each operand: 64 KiB, held
+// twice.  Stage s + 1 is written to the other buffer and stage s + 2 is fetched into registers while stage s is
+// multiplied: one barrier per stage.  LDS rows are exactly 128 B; the 16-byte slot q of row r lives at q ^ ((r >> 1) & 7):
+// rows of equal parity share their banks, and a 16-lane group of ds_read_b128 reads, per parity, 4 rows at chunk c and 4
+// rows at chunk c ^ 1 whose keys (r >> 1) are all different => 16 distinct slots, conflict-free; a ds_write_b128 group
+// of 8 lanes writes the 8 slots of one row.
+constexpr int W_BM = 256, W_BN = 256, W_THREADS = 512;
+constexpr int W_KS = 32;                                  // features per stage (one granule)
+constexpr int W_ROW = 128;                                // bytes per LDS row
+constexpr int W_OPND_BYTES = W_BM * W_ROW;                // 32,768
+constexpr int W_STAGE_BYTES = 2 * W_OPND_BYTES;           // 65,536
+constexpr int W_LDS_BYTES = 2 * W_STAGE_BYTES;            // 131,072
+
+struct WStage {
+  u32x4 a[4], b[4];
+};
+
+// thread t: 16-byte chunk t & 7 of rows (t >> 3) + 64 p.  Rows past the operand's end are read as its last row.
+__device__ __forceinline__ void w_row_offsets(uint32_t (&voff)[4], int64_t ld, int64_t row0, int64_t nrows) {
+  const int tid = threadIdx.x;
+  const int64_t l64 = nrows - 1 - row0;               // >= 0: the tile starts inside the operand
+  const int last = l64 < W_BM - 1 ? (int)l64 : W_BM - 1;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = (tid >> 3) + 64 * p;
+    voff[p] = (uint32_t)(r < last ? r : last) * (uint32_t)ld + (uint32_t)(tid & 7) * 4u;
+  }
+}
+
+__device__ __forceinline__ void w_load_operand(u32x4 (&r)[4], const uint32_t* __restrict__ tile, const uint32_t (&voff)[4]) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) r[p] = *reinterpret_cast<const u32x4*>(tile + voff[p]);
+}
+
+__device__ __forceinline__ void w_store_operand(const u32x4 (&r)[4], char* lds) {
+  const int tid = threadIdx.x;
+  const int row = tid >> 3;
+  char* d = lds + row * W_ROW + (((tid & 7) ^ ((row >> 1) & 7)) << 4);   // ((row + 64 p) >> 1) & 7 == (row >> 1) & 7
+#pragma unroll
+  for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(d + 64 * p * W_ROW) = r[p];
+}
+
+__device__ __forceinline__ void w_compute_stage(f32x4 (&acc)[8][4], const char* ldsA, const char* ldsB, int wr, int wc,
+                                                int lane) {
+  const int r = lane & 15, g = lane >> 4;
+  const int hi = ((g ^ ((r >> 1) & 7)) << 4), lo = hi ^ 64;
+  const char* pa = ldsA + (wr * 128 + r) * W_ROW;
+  const char* pb = ldsB + (wc * 64 + r) * W_ROW;
+  f16x8 bh[4], bl[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    bh[t] = *reinterpret_cast<const f16x8*>(pb + t * 16 * W_ROW + hi);
+    bl[t] = *reinterpret_cast<const f16x8*>(pb + t * 16 * W_ROW + lo);
+  }
+#pragma unroll
+  for (int tm = 0; tm < 8; ++tm) {
+    const f16x8 ah = *reinterpret_cast<const f16x8*>(pa + tm * 16 * W_ROW + hi);
+    const f16x8 al = *reinterpret_cast<const f16x8*>(pa + tm * 16 * W_ROW + lo);
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[tn], acc[tm][tn], 0, 0, 0);
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[tn], acc[tm][tn], 0, 0, 0);
+      acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[tn], acc[tm][tn], 0, 0, 0);
+    }
+  }
+}
+
+// acc += A[i0 .. i0 + 256, :] . B[j0 .. j0 + 256, :]' over `stages` granules.  Ends on a barrier (LDS reusable at once).
+__device__ __forceinline__ void w_mainloop(f32x4 (&acc)[8][4], const uint32_t* __restrict__ A, int64_t lda, int64_t m,
+                                           const uint32_t* __restrict__ B, int64_t ldb, int64_t n, int64_t i0, int64_t j0,
+                                           int stages, char* lds) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  uint32_t offa[4], offb[4];
+  w_row_offsets(offa, lda, i0, m);
+  w_row_offsets(offb, ldb, j0, n);
+  const uint32_t* ta = A + i0 * lda;
+  const uint32_t* tb = B + j0 * ldb;
+  WStage st;
+  w_load_operand(st.a, ta, offa);
+  w_load_operand(st.b, tb, offb);
+  w_store_operand(st.a, lds);
+  w_store_operand(st.b, lds + W_OPND_BYTES);
+  if (stages > 1) {
+    ta += W_KS;
+    tb += W_KS;
+    w_load_operand(st.a, ta, offa);
+    w_load_operand(st.b, tb, offb);
+  }
+  __syncthreads();
+  for (int s = 0; s < stages; ++s) {
+    char* cur = lds + (s & 1) * W_STAGE_BYTES;
+    if (s + 1 < stages) {
+      char* nxt = lds + ((s + 1) & 1) * W_STAGE_BYTES;      // last read during stage s - 1, before the barrier that ended it
+      w_store_operand(st.a, nxt);
+      w_store_operand(st.b, nxt + W_OPND_BYTES);
+      if (s + 2 < stages) {
+        ta += W_KS;
+        tb += W_KS;
+        w_load_operand(st.a, ta, offa);
+        w_load_operand(st.b, tb, offb);
+      }
+    }
+    w_compute_stage(acc, cur, cur + W_OPND_BYTES, wr, wc, lane);
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ void w_zero(f32x4 (&acc)[8][4]) {
+#pragma unroll
+  for (int tm = 0; tm < 8; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// accumulator element (tm, tn, q) of a wave's 128 x 64 share: row 16 tm + 4 (lane >> 4) + q, column 16 tn + (lane & 15)
+__global__ __launch_bounds__(W_THREADS, 1) void gauss_knm_h2w256_kernel(
+    const uint32_t* __restrict__ PX, int64_t ldpx, const float* __restrict__ metax, const float* __restrict__ xsq, int64_t n,
+    const uint32_t* __restrict__ PZ, int64_t ldpz, const float* __restrict__ metaz, const float* __restrict__ zsq, int64_t M,
+    int stages, float gamma_log2e, float* __restrict__ K, int64_t ldk, int gr) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int64_t GR = gr;
+  const int64_t tiles_n = (M + W_BN - 1) / W_BN;
+  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t band = wg / (GR * tiles_n), within = wg % (GR * tiles_n);
+  const int64_t i0 = (band * GR + within % GR) * W_BM, j0 = (within / GR) * W_BN;
+  if (i0 >= n) return;
+
+  __shared__ __attribute__((aligned(16))) float xs_s[W_BM];
+  if (threadIdx.x < W_BM) xs_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] : 0.f;
+
+  f32x4 acc[8][4];
+  w_zero(acc);
+  w_mainloop(acc, PX, ldpx, n, PZ, ldpz, M, i0, j0, stages, lds);      // its barriers also publish xs_s
+
+  const float m2 = -2.f / (metax[0] * metaz[0]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const bool interior = i0 + W_BM <= n && j0 + W_BN <= M;
+  const int64_t mpad = (M + 3) & ~int64_t(3);
+  float* tile = K + i0 * ldk + j0;
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) {
+    const int cl = wc * 64 + tn * 16 + (lane & 15);
+    const float zs = (j0 + cl < M) ? zsq[j0 + cl] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 8; ++tm) {
+      const int rl = wr * 128 + tm * 16 + 4 * (lane >> 4);
+      const f32x4 xs = *reinterpret_cast<const f32x4*>(&xs_s[rl]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float d2 = fmaf(m2, acc[tm][tn][q], xs[q]) + zs;
+        d2 = fmaxf(d2, 0.f);
+        const float v = __builtin_amdgcn_exp2f(d2 * gamma_log2e);
+        if (interior) {
+          tile[(uint32_t)(rl + q) * (uint32_t)ldk + (uint32_t)cl] = v;
+        } else if (i0 + rl + q < n && j0 + cl < mpad) {
+          tile[(int64_t)(rl + q) * ldk + cl] = (j0 + cl < M) ? v : 0.f;
+        }
+      }
+    }
+  }
+}
+
+// Fused scoring on the 256 x 256 core: same decomposition as gauss_mmv_h2s16_kernel (row block x group of `tg` column
+// tiles, f64 partial row sums per group in the slab, mmv_reduce_kernel adds the groups), 256-row blocks, 256-column tiles.
+__global__ __launch_bounds__(W_THREADS, 1) void gauss_mmv_h2w256_kernel(
+    const uint32_t* __restrict__ PX, int64_t ldpx, const float* __restrict__ metax, const float* __restrict__ xsq, int64_t n,
+    const uint32_t* __restrict__ PZ, int64_t ldpz, const float* __restrict__ metaz, const float* __restrict__ zsq, int stages,
+    float gamma_log2e, const double* __restrict__ V, int64_t ldv, const int32_t* __restrict__ ranges, int tg, int G,
+    double* __restrict__ slab, int64_t slab_ld) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  __shared__ double red[4][W_BM];
+  __shared__ __attribute__((aligned(16))) float xs_s[W_BM];
+  constexpr int64_t GR = 8;
+  const int c = blockIdx.y;
+  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t band = wg / (GR * G), within = wg % (GR * G);
+  const int64_t i0 = (band * GR + within % GR) * W_BM;
+  const int g = (int)(within / GR);
+  const int64_t r0 = ranges[2 * c], r1 = ranges[2 * c + 1];
+  const int64_t s0 = r0 + (int64_t)g * tg * W_BN;
+  const int64_t s1 = (s0 + (int64_t)tg * W_BN < r1) ? s0 + (int64_t)tg * W_BN : r1;
+  if (i0 >= n || s0 >= r1) return;       // mmv_reduce_kernel only visits the groups that exist
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const float m2 = -2.f / (metax[0] * metaz[0]);
+
+  if (threadIdx.x < W_BM) xs_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] : 0.f;
+  // Lane l ends every tile with two f64 sums over the tile's 64 columns of this wave: for half h of the wave's rows,
+  // row slot (l & 15) of its lane quarter (slot = 4 tm' + q, row 64 h + 16 tm' + 4 (l >> 4) + q).
+  double tot[2] = {0.0, 0.0};
+  const bool b8 = lane & 8, b4 = lane & 4, b2 = lane & 2, b1 = lane & 1;
+
+  for (int64_t j0 = s0; j0 < s1; j0 += W_BN) {
+    f32x4 acc[8][4];
+    w_zero(acc);
+    w_mainloop(acc, PX, ldpx, n, PZ + j0 * ldpz, ldpz, r1 - j0, i0, 0, stages, lds);
+    float zs[4];
+    double al[4];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int64_t col = j0 + wc * 64 + tn * 16 + (lane & 15);
+      const bool cv = col < s1;
+      zs[tn] = cv ? zsq[col] : 0.f;
+      al[tn] = cv ? V[col * ldv + c] : 0.0;     // weight 0 removes the columns past the group / range
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      double w8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {       // slots j (tm' = j >> 2) and j + 8 (tm' = 2 + (j >> 2)), q = j & 3
+        double v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int tm = 4 * h + 2 * u + (j >> 2), q = j & 3;
+          const float xs = xs_s[wr * 128 + tm * 16 + 4 * (lane >> 4) + q];
+          v[u] = 0.0;
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) {
+            float d2 = fmaf(m2, acc[tm][tn][q], xs) + zs[tn];
+            d2 = fmaxf(d2, 0.f);
+            v[u] = fma((double)__builtin_amdgcn_exp2f(d2 * gamma_log2e), al[tn], v[u]);
+          }
+        }
+        w8[j] = (b8 ? v[1] : v[0]) + __shfl_xor(b8 ? v[0] : v[1], 8);
+      }
+      double w4[4], w2[2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w4[j] = (b4 ? w8[j + 4] : w8[j]) + __shfl_xor(b4 ? w8[j] : w8[j + 4], 4);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) w2[j] = (b2 ? w4[j + 2] : w4[j]) + __shfl_xor(b2 ? w4[j] : w4[j + 2], 2);
+      tot[h] += (b1 ? w2[1] : w2[0]) + __shfl_xor(b1 ? w2[0] : w2[1], 1);
+    }
+  }
+  {
+    const int slot = lane & 15;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      red[wc][wr * 128 + 64 * h + (slot >> 2) * 16 + 4 * (lane >> 4) + (slot & 3)] = tot[h];
+  }
+  __syncthreads();
+  if (threadIdx.x < W_BM) {
+    const int64_t row = i0 + threadIdx.x;
+    if (row < n)
+      slab[((int64_t)c * G + g) * slab_ld + row] =
+          (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
+}
+
 constexpr int MMV_TG = 4;   // column tiles per workgroup (2 / 4 / 8 / 16 / 40 measured: 342 / 341 / 335 / 321 / 305 TF)
 
-static int h2_enable_lds(const void* fn) {   // > 64 KiB of LDS per workgroup has to be asked for
-  ODX_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, S16_LDS_BYTES));
+constexpr int W_MMV_TG = 2; // column tiles per workgroup on the 256 x 256 core (same 512 columns as 4 tiles of 128)
+
+static int h2_enable_lds(const void* fn, int bytes = S16_LDS_BYTES) {   // > 64 KiB of LDS per workgroup has to be asked for
+  ODX_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   return ODX_OK;
+}
+
+// Tile core for a launch of `tiles256` 256 x 256 tiles: the wide core once it fills the chip twice over, the 128 x 128
+// core (4 x as many, smaller workgroups) below that.  ODX_H2_TILE=128 | 256 pins one (tests, measurements).
+static bool h2_use_w256(int64_t tiles256) {
+  static int pinned = -1;
+  if (pinned < 0) {
+    const char* e = getenv("ODX_H2_TILE");
+    pinned = e ? atoi(e) : 0;
+  }
+  if (pinned == 128) return false;
+  if (pinned == 256) return true;
+  return tiles256 >= 512;
 }
 
 }  // namespace odx
@@ -372,6 +646,11 @@ extern "C" int odx_split_f16(const float* X, int64_t ldx, int64_t n, int D, void
   return ODX_OK;
 }
 
+extern "C" int odx_gauss_h2_tile(int64_t n, int64_t M) {
+  if (n <= 0 || M <= 0) return 0;
+  return h2_use_w256(ceil_div(n, W_BM) * ceil_div(M, W_BN)) ? W_BM : GEMM_BM;
+}
+
 extern "C" int odx_gauss_knm_h2(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
                                 const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int D,
                                 double sigma, float* K, int64_t ldk, odx_stream_t stream) {
@@ -383,6 +662,16 @@ extern "C" int odx_gauss_knm_h2(const void* PX, int64_t ldpx, const float* metax
   ODX_REQUIRE(ldk % 4 == 0 && ldk >= round_up(M, 4) && aligned16(K), "odx_gauss_knm_h2: K must be 16-byte aligned, ldk %% 4 == 0, ldk >= roundup(M, 4)");
   ODX_REQUIRE(ldpx < (1 << 24) && ldpz < (1 << 24) && ldk < (1 << 24), "odx_gauss_knm_h2: leading dimensions must stay below 2^24 (32-bit tile offsets)");
   const int gr = 8;   // band height of the tile order: 2..32 measured within 2 % of each other at n = 2.5e5, M = 1e4
+  if (h2_use_w256(ceil_div(n, W_BM) * ceil_div(M, W_BN))) {
+    const int64_t wt = round_up(ceil_div(n, W_BM), gr) * ceil_div(M, W_BN);
+    ODX_REQUIRE(wt < (1ll << 31), "odx_gauss_knm_h2: grid too large");
+    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2w256_kernel), W_LDS_BYTES));
+    hipLaunchKernelGGL(gauss_knm_h2w256_kernel, dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
+                       (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq, M, (int)(dp / W_KS),
+                       (float)(-0.5 / (sigma * sigma)) * LOG2E, K, ldk, gr);
+    ODX_CHECK_LAUNCH("odx_gauss_knm_h2(w256)");
+    return ODX_OK;
+  }
   const int64_t tiles = round_up(ceil_div(n, GEMM_BM), gr) * ceil_div(M, GEMM_BN);
   ODX_REQUIRE(tiles < (1ll << 31), "odx_gauss_knm_h2: grid too large");
   ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2s16_kernel)));
@@ -417,18 +706,35 @@ extern "C" int odx_gauss_mmv_h2(const void* PX, int64_t ldpx, const float* metax
     set_error("odx_gauss_mmv_h2: workspace too small");
     return ODX_ERR_WORKSPACE;
   }
+  double* slab = static_cast<double*>(workspace);
+  const int64_t slab_ld = round_up(n, 2);
+  {
+    const int64_t Gw = ceil_div(ceil_div(max_range, W_BN), W_MMV_TG);      // <= mmv_groups(max_range): the slab is large enough
+    if (h2_use_w256(ceil_div(n, W_BM) * Gw * C)) {
+      const int64_t wgs = round_up(ceil_div(n, W_BM), 8) * Gw;
+      ODX_REQUIRE(wgs < (1ll << 31), "odx_gauss_mmv_h2: grid too large");
+      ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_mmv_h2w256_kernel), W_LDS_BYTES));
+      hipLaunchKernelGGL(gauss_mmv_h2w256_kernel, dim3((unsigned)wgs, (unsigned)C), dim3(W_THREADS), W_LDS_BYTES,
+                         as_stream(stream), (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq,
+                         (int)(dp / W_KS), (float)(-0.5 / (sigma * sigma)) * LOG2E, V, ldv, ranges, W_MMV_TG, (int)Gw, slab,
+                         slab_ld);
+      ODX_CHECK_LAUNCH("odx_gauss_mmv_h2(w256)");
+      hipLaunchKernelGGL(mmv_reduce_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)C), dim3(256), 0, as_stream(stream),
+                         slab, slab_ld, (int)Gw, W_MMV_TG, W_BN, ranges, n, out, ldo);
+      ODX_CHECK_LAUNCH("odx_gauss_mmv_h2(reduce)");
+      return ODX_OK;
+    }
+  }
   const int G = (int)mmv_groups(max_range);
   const int64_t wgs = round_up(ceil_div(n, GEMM_BM), 8) * G;
   ODX_REQUIRE(wgs < (1ll << 31), "odx_gauss_mmv_h2: grid too large");
-  double* slab = static_cast<double*>(workspace);
-  const int64_t slab_ld = round_up(n, 2);
   ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_mmv_h2s16_kernel)));
   hipLaunchKernelGGL(gauss_mmv_h2s16_kernel, dim3((unsigned)wgs, (unsigned)C), dim3(GEMM_THREADS), S16_LDS_BYTES,
                      as_stream(stream), (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq,
                      (int)(dp / H2_KT), (float)(-0.5 / (sigma * sigma)) * LOG2E, V, ldv, ranges, MMV_TG, G, slab, slab_ld);
   ODX_CHECK_LAUNCH("odx_gauss_mmv_h2");
   hipLaunchKernelGGL(mmv_reduce_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)C), dim3(256), 0, as_stream(stream), slab,
-                     slab_ld, G, MMV_TG, ranges, n, out, ldo);
+                     slab_ld, G, MMV_TG, GEMM_BN, ranges, n, out, ldo);
   ODX_CHECK_LAUNCH("odx_gauss_mmv_h2(reduce)");
   return ODX_OK;
 }

@@ -120,7 +120,7 @@ def test_split_f16(be, n, D, scale):
     else:
         assert s == 1.0
     Dp = (D + 63) // 64 * 64
-    P = F.P.cpu().numpy().view(np.float16).reshape(n, Dp // 64, 2, 64)
+    P = F.P.cpu().numpy().view(np.float16).reshape(n, Dp // 32, 2, 32)     # granule = 32 f16 hi, then 32 f16 lo (128 B)
     hi = P[:, :, 0, :].reshape(n, Dp).astype(np.float64)
     lo = P[:, :, 1, :].reshape(n, Dp).astype(np.float64)
     assert np.all(hi[:, D:] == 0) and np.all(lo[:, D:] == 0)
