@@ -384,20 +384,14 @@ __device__ __forceinline__ void w_store_operand(const u32x4 (&r)[4], char* lds) 
   for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(d + 64 * p * W_ROW) = r[p];
 }
 
-__device__ __forceinline__ void w_compute_stage(f32x4 (&acc)[8][4], const char* ldsA, const char* ldsB, int wr, int wc,
-                                                int lane) {
-  const int r = lane & 15, g = lane >> 4;
-  const int hi = ((g ^ ((r >> 1) & 7)) << 4), lo = hi ^ 64;
-  const char* pa = ldsA + (wr * 128 + r) * W_ROW;
-  const char* pb = ldsB + (wc * 64 + r) * W_ROW;
-  f16x8 bh[4], bl[4];
+// One stage in four parts of two row blocks (24 MFMAs) each.  Between the parts the wave puts a quarter of stage s + 1
+// (two of its eight 16-byte pieces) into the other LDS buffer and re-issues the loads of those two registers for stage
+// s + 2: the LDS stores (64 KiB per stage at ~79 B/clk = 830 cycles of the LDS port) and the load issue then run under the
+// MFMA work instead of in front of it, and every register has exactly one stage of MFMA time to be refilled.
+__device__ __forceinline__ void w_compute_part(f32x4 (&acc)[8][4], const char* pa, const f16x8 (&bh)[4], const f16x8 (&bl)[4],
+                                               int hi, int lo, int tm0) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    bh[t] = *reinterpret_cast<const f16x8*>(pb + t * 16 * W_ROW + hi);
-    bl[t] = *reinterpret_cast<const f16x8*>(pb + t * 16 * W_ROW + lo);
-  }
-#pragma unroll
-  for (int tm = 0; tm < 8; ++tm) {
+  for (int tm = tm0; tm < tm0 + 2; ++tm) {
     const f16x8 ah = *reinterpret_cast<const f16x8*>(pa + tm * 16 * W_ROW + hi);
     const f16x8 al = *reinterpret_cast<const f16x8*>(pa + tm * 16 * W_ROW + lo);
 #pragma unroll
@@ -409,45 +403,86 @@ __device__ __forceinline__ void w_compute_stage(f32x4 (&acc)[8][4], const char* 
   }
 }
 
-// acc += A[i0 .. i0 + 256, :] . B[j0 .. j0 + 256, :]' over `stages` granules.  Ends on a barrier (LDS reusable at once).
+struct WAddr {
+  uint32_t offa[4], offb[4];   // global: per-thread offsets of its four rows of each operand (4-byte units)
+  int sto;                     // LDS: this thread's 16-byte slot of rows (tid >> 3) + 64 p of an operand image
+  int fa, fb, hi, lo;          // LDS: fragment rows of this lane in the A / B image, hi / lo chunk inside a row
+};
+
+// STORE: stage s + 1 exists (its registers go to `nxt`); LOAD: stage s + 2 exists (re-issue the loads).  Compile-time
+// flags keep the loop body free of branches, so the compiler can count its vmcnt waits exactly.
+template <bool STORE, bool LOAD>
+__device__ __forceinline__ void w_stage(f32x4 (&acc)[8][4], WStage& st, const char* cur, char* nxt,
+                                        const uint32_t* __restrict__ ta2, const uint32_t* __restrict__ tb2, const WAddr& ad) {
+  f16x8 bh[4], bl[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    bh[t] = *reinterpret_cast<const f16x8*>(cur + ad.fb + t * 16 * W_ROW + ad.hi);
+    bl[t] = *reinterpret_cast<const f16x8*>(cur + ad.fb + t * 16 * W_ROW + ad.lo);
+  }
+#pragma unroll
+  for (int part = 0; part < 4; ++part) {
+    w_compute_part(acc, cur + ad.fa, bh, bl, ad.hi, ad.lo, 2 * part);
+    if (STORE) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int p = 2 * (part & 1) + q;
+        if (part < 2) {
+          *reinterpret_cast<u32x4*>(nxt + ad.sto + 64 * p * W_ROW) = st.a[p];
+          if (LOAD) st.a[p] = *reinterpret_cast<const u32x4*>(ta2 + ad.offa[p]);
+        } else {
+          *reinterpret_cast<u32x4*>(nxt + W_OPND_BYTES + ad.sto + 64 * p * W_ROW) = st.b[p];
+          if (LOAD) st.b[p] = *reinterpret_cast<const u32x4*>(tb2 + ad.offb[p]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();
+}
+
+// acc += A[i0 .. i0 + 256, :] . B[j0 .. j0 + 256, :]' over `stages` >= 1 granules.  Ends on a barrier (LDS reusable at once).
 __device__ __forceinline__ void w_mainloop(f32x4 (&acc)[8][4], const uint32_t* __restrict__ A, int64_t lda, int64_t m,
                                            const uint32_t* __restrict__ B, int64_t ldb, int64_t n, int64_t i0, int64_t j0,
                                            int stages, char* lds) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
-  uint32_t offa[4], offb[4];
-  w_row_offsets(offa, lda, i0, m);
-  w_row_offsets(offb, ldb, j0, n);
+  WAddr ad;
+  w_row_offsets(ad.offa, lda, i0, m);
+  w_row_offsets(ad.offb, ldb, j0, n);
   const uint32_t* ta = A + i0 * lda;
   const uint32_t* tb = B + j0 * ldb;
+  const int srow = tid >> 3;
+  ad.sto = srow * W_ROW + (((tid & 7) ^ ((srow >> 1) & 7)) << 4);
+  const int r = lane & 15, g = lane >> 4;
+  ad.hi = ((g ^ ((r >> 1) & 7)) << 4);
+  ad.lo = ad.hi ^ 64;
+  ad.fa = (wr * 128 + r) * W_ROW;
+  ad.fb = W_OPND_BYTES + (wc * 64 + r) * W_ROW;
+
   WStage st;
-  w_load_operand(st.a, ta, offa);
-  w_load_operand(st.b, tb, offb);
+  w_load_operand(st.a, ta, ad.offa);
+  w_load_operand(st.b, tb, ad.offb);
   w_store_operand(st.a, lds);
   w_store_operand(st.b, lds + W_OPND_BYTES);
   if (stages > 1) {
-    ta += W_KS;
-    tb += W_KS;
-    w_load_operand(st.a, ta, offa);
-    w_load_operand(st.b, tb, offb);
+    w_load_operand(st.a, ta + W_KS, ad.offa);
+    w_load_operand(st.b, tb + W_KS, ad.offb);
   }
   __syncthreads();
-  for (int s = 0; s < stages; ++s) {
-    char* cur = lds + (s & 1) * W_STAGE_BYTES;
-    if (s + 1 < stages) {
-      char* nxt = lds + ((s + 1) & 1) * W_STAGE_BYTES;      // last read during stage s - 1, before the barrier that ended it
-      w_store_operand(st.a, nxt);
-      w_store_operand(st.b, nxt + W_OPND_BYTES);
-      if (s + 2 < stages) {
-        ta += W_KS;
-        tb += W_KS;
-        w_load_operand(st.a, ta, offa);
-        w_load_operand(st.b, tb, offb);
-      }
-    }
-    w_compute_stage(acc, cur, cur + W_OPND_BYTES, wr, wc, lane);
-    __syncthreads();
+  int s = 0;
+  for (; s + 2 < stages; ++s) {
+    // nxt was last read during stage s - 1, before the barrier that ended it
+    w_stage<true, true>(acc, st, lds + (s & 1) * W_STAGE_BYTES, lds + ((s + 1) & 1) * W_STAGE_BYTES,
+                        ta + (int64_t)(s + 2) * W_KS, tb + (int64_t)(s + 2) * W_KS, ad);
   }
+  if (s + 1 < stages) {
+    w_stage<true, false>(acc, st, lds + (s & 1) * W_STAGE_BYTES, lds + ((s + 1) & 1) * W_STAGE_BYTES, ta, tb, ad);
+    ++s;
+  }
+  w_stage<false, false>(acc, st, lds + (s & 1) * W_STAGE_BYTES, lds, ta, tb, ad);
 }
 
 __device__ __forceinline__ void w_zero(f32x4 (&acc)[8][4]) {
@@ -594,7 +629,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_mmv_h2w256_kernel(
 
 constexpr int MMV_TG = 4;   // column tiles per workgroup (2 / 4 / 8 / 16 / 40 measured: 342 / 341 / 335 / 321 / 305 TF)
 
-constexpr int W_MMV_TG = 2; // column tiles per workgroup on the 256 x 256 core (same 512 columns as 4 tiles of 128)
+constexpr int W_MMV_TG = 2; // column tiles per workgroup on the 256 x 256 core (1 / 2 / 4 / 8 measured: 409 / 419 / 412 / 395 TF)
 
 static int h2_enable_lds(const void* fn, int bytes = S16_LDS_BYTES) {   // > 64 KiB of LDS per workgroup has to be asked for
   ODX_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -663,12 +698,13 @@ extern "C" int odx_gauss_knm_h2(const void* PX, int64_t ldpx, const float* metax
   ODX_REQUIRE(ldpx < (1 << 24) && ldpz < (1 << 24) && ldk < (1 << 24), "odx_gauss_knm_h2: leading dimensions must stay below 2^24 (32-bit tile offsets)");
   const int gr = 8;   // band height of the tile order: 2..32 measured within 2 % of each other at n = 2.5e5, M = 1e4
   if (h2_use_w256(ceil_div(n, W_BM) * ceil_div(M, W_BN))) {
-    const int64_t wt = round_up(ceil_div(n, W_BM), gr) * ceil_div(M, W_BN);
+    const int wgr = 4;   // 2 / 4 / 8 / 16 / 32 measured: 395 / 397 / 391 / 376 / 347 TF
+    const int64_t wt = round_up(ceil_div(n, W_BM), wgr) * ceil_div(M, W_BN);
     ODX_REQUIRE(wt < (1ll << 31), "odx_gauss_knm_h2: grid too large");
     ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2w256_kernel), W_LDS_BYTES));
     hipLaunchKernelGGL(gauss_knm_h2w256_kernel, dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
                        (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq, M, (int)(dp / W_KS),
-                       (float)(-0.5 / (sigma * sigma)) * LOG2E, K, ldk, gr);
+                       (float)(-0.5 / (sigma * sigma)) * LOG2E, K, ldk, wgr);
     ODX_CHECK_LAUNCH("odx_gauss_knm_h2(w256)");
     return ODX_OK;
   }
