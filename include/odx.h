@@ -77,7 +77,10 @@ int odx_gauss_mmv_f32(const float* X, int64_t ldx, const float* xsq, int64_t n,
  * keep the same meta.                                                                              */
 int odx_split_f16(const float* X, int64_t ldx, int64_t n, int D, void* P, int64_t ldp, float* meta,
                   odx_stream_t stream);
-/* Side of the square output tile (128 or 256) odx_gauss_knm_h2 uses for an n x M block; 0 for an empty one. */
+/* odx_set_h2_tile pins the tile core (128 or 256; 0 = automatic, the default): a process-wide setting for tests and
+ * measurements.  odx_gauss_h2_tile: side of the square output tile odx_gauss_knm_h2 uses for an n x M block under the
+ * current setting; 0 for an empty block. */
+int odx_set_h2_tile(int tile);
 int odx_gauss_h2_tile(int64_t n, int64_t M);
 int odx_gauss_knm_h2(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
                      const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int D,

@@ -637,21 +637,30 @@ static int h2_enable_lds(const void* fn, int bytes = S16_LDS_BYTES) {   // > 64 
 }
 
 // Tile core for a launch of `tiles256` 256 x 256 tiles: the wide core once it fills the chip twice over, the 128 x 128
-// core (4 x as many, smaller workgroups) below that.  ODX_H2_TILE=128 | 256 pins one (tests, measurements).
+// core (4 x as many, smaller workgroups) below that.  odx_set_h2_tile(128 | 256) pins one (tests, measurements); the
+// environment variable ODX_H2_TILE gives the initial setting.
+static int g_h2_tile = -1;
+
 static bool h2_use_w256(int64_t tiles256) {
-  static int pinned = -1;
-  if (pinned < 0) {
+  if (g_h2_tile < 0) {
     const char* e = getenv("ODX_H2_TILE");
-    pinned = e ? atoi(e) : 0;
+    const int v = e ? atoi(e) : 0;
+    g_h2_tile = (v == 128 || v == 256) ? v : 0;
   }
-  if (pinned == 128) return false;
-  if (pinned == 256) return true;
+  if (g_h2_tile == 128) return false;
+  if (g_h2_tile == 256) return true;
   return tiles256 >= 512;
 }
 
 }  // namespace odx
 
 using namespace odx;
+
+extern "C" int odx_set_h2_tile(int tile) {
+  ODX_REQUIRE(tile == 0 || tile == 128 || tile == 256, "odx_set_h2_tile: tile must be 0 (automatic), 128 or 256");
+  g_h2_tile = tile;
+  return ODX_OK;
+}
 
 extern "C" int odx_split_f16(const float* X, int64_t ldx, int64_t n, int D, void* P, int64_t ldp, float* meta,
                              odx_stream_t stream) {

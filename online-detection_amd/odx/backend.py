@@ -168,6 +168,10 @@ class HipBackend:
                                                  float(sigma), _p(K.K), ld, self._stream()), "odx_gauss_knm_f32")
         return K
 
+    def pin_gauss_tile(self, tile):
+        """Pin the tile core of the f16-split Gaussian kernels (128 or 256); 0 = chosen per launch (default)."""
+        hip.check(self.lib.odx_set_h2_tile(int(tile)), "odx_set_h2_tile")
+
     def reserve_cus_during_passes(self, cus):
         """Leave `cus` CUs free while the persistent CG pass kernel runs, for work queued on other streams."""
         hip.check(self.lib.odx_set_pass_reserved_cus(int(cus)), "odx_set_pass_reserved_cus")

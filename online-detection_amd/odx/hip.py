@@ -35,6 +35,7 @@ SIGNATURES = {
     "odx_gauss_mmv_f32": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _f64, _vp, _i64, _vp, _i32, _vp, _i64, _vp]),
     "odx_split_f16": (_i32, [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp]),
     "odx_gauss_h2_tile": (_i32, [_i64, _i64]),
+    "odx_set_h2_tile": (_i32, [_i32]),
     "odx_gauss_knm_h2": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _f64, _vp, _i64, _vp]),
     "odx_gauss_mmv_h2_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "odx_gauss_mmv_h2": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _f64, _vp, _i64, _vp, _i32, _vp, _i64,

@@ -17,12 +17,15 @@ def be():
     return odx.get_backend()
 
 
-@pytest.fixture(params=["h2", "f32"])
+@pytest.fixture(params=["h2", "h2w256", "f32"])
 def gauss(be, request):
-    """Run a test once per Gaussian-kernel contraction: f16 split on the f16 matrix cores, and all-f32 MFMA."""
-    old, be.gauss = be.gauss, request.param
+    """Run a test once per Gaussian-kernel variant: f16 split on the f16 matrix cores with the 128 x 128 and with the
+    256 x 256 tile core (pinned: left alone the library picks by problem size), and all-f32 MFMA."""
+    old, be.gauss = be.gauss, request.param[:2] if request.param.startswith("h2") else request.param
+    be.pin_gauss_tile({"h2": 128, "h2w256": 256}.get(request.param, 0))
     yield request.param
     be.gauss = old
+    be.pin_gauss_tile(0)
 
 
 def _p(t):
@@ -325,3 +328,53 @@ def test_mmv_block_structure(be, gauss):
     assert np.abs(got - ref).max() < 5e-5 * max(1.0, np.abs(ref).max())
     dense = be.mmv(be.features(torch.from_numpy(X)), be.features(torch.from_numpy(ny)), sigma, Vt, None).cpu().numpy()
     assert np.abs(dense - ref).max() < 5e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_headline_shape_one_class(be):
+    """One class at BASELINE.json's full size (N = 1e6, D = 1024, M = 1e4, the shard one GPU holds), through properties
+    that do not need an oracle run of that size: sampled K_nM entries and sampled scores against the f64 oracle, the
+    CG pass against row halves (every row read exactly once) and its linearity, and bitwise repeatability."""
+    import odx
+    from odx.backend import Knm
+    from oracle import falkon_ref as fr
+    n, D, M, sigma, lam = 1_000_000, 1024, 10_000, 15.0, 1e-5
+    g = torch.Generator(device="cuda").manual_seed(5)
+    X = torch.randn((n, D), generator=g, device="cuda") * (20.0 / D ** 0.5)
+    X[::30] += 0.25                                                  # a positive class with some structure
+    y = torch.full((n,), -1.0, dtype=torch.float64, device="cuda")
+    y[::30] = 1.0
+    idx = torch.cat([torch.arange(0, n, 30, device="cuda")[:M // 2], torch.arange(1, n, 199, device="cuda")[:M - M // 2]])
+    F = be.features(X)
+    Zf = be.features(X.index_select(0, idx))
+    assert be.lib.odx_gauss_h2_tile(n, M) == 256                     # the headline launch runs on the wide tile core
+    alpha, K = odx.falkon_fit(be, F, y, Zf, sigma, lam, 20, return_knm=True)
+    assert torch.isfinite(alpha).all()
+    # (a) sampled entries of the stored K_nM, edges of the tile grid included
+    rows = np.array([0, 1, 255, 256, 257, 4095, 123457, 500000, 999743, 999744, 999999])
+    cols = np.array([0, 1, 127, 128, 255, 256, 5000, 9983, 9984, 9999])
+    Zh = Zf.X.cpu().numpy().astype(np.float64)
+    ref = fr.gaussian_kernel(X[rows].cpu().numpy().astype(np.float64), Zh[cols], sigma)
+    got = K.K[rows][:, cols].cpu().numpy()
+    assert np.abs(got - ref).max() < 2e-5
+    assert float(K.K[:, M:].abs().max()) == 0.0 if K.ld > M else True
+    # (b) sampled scores against the oracle's predict with the same alpha
+    srows = np.concatenate([np.arange(0, 300), np.arange(499900, 500100), np.arange(n - 300, n)])
+    pref = fr.falkon_predict(X[srows].cpu().numpy().astype(np.float64), Zh, alpha.cpu().numpy()[:, None], sigma)
+    scores = be.mmv(F, Zf, sigma, alpha)
+    assert np.abs(scores[srows].cpu().numpy() - pref).max() < 1e-4 * max(1.0, np.abs(pref).max())
+    # (c) the CG pass: halves add up, linear in v, repeatable bit for bit
+    v1 = torch.randn(M, dtype=torch.float64, device="cuda", generator=g)
+    v2 = torch.randn(M, dtype=torch.float64, device="cuda", generator=g)
+    full = be.ktk(K, v=v1)
+    assert torch.equal(full, be.ktk(K, v=v1))
+    parts = torch.zeros_like(full)
+    for lo, hi in ((0, 499_999), (499_999, n)):
+        Kh = Knm()
+        Kh.n, Kh.M, Kh.ld, Kh.K = hi - lo, M, K.ld, K.K[lo:hi]
+        parts += be.ktk(Kh, v=v1)
+    assert float((parts - full).abs().max()) <= 1e-11 * float(full.abs().max())
+    lin = be.ktk(K, v=v1 + 2.0 * v2) - (full + 2.0 * be.ktk(K, v=v2))
+    assert float(lin.abs().max()) <= 1e-11 * float(full.abs().max())
+    # (d) the fit repeats bit for bit at this size too
+    alpha2 = odx.falkon_fit(be, F, y, Zf, sigma, lam, 20, knm_out=K.K.view(-1))
+    assert torch.equal(alpha, alpha2)
