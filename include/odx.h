@@ -85,6 +85,15 @@ int odx_gauss_h2_tile(int64_t n, int64_t M);
 int odx_gauss_knm_h2(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
                      const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int D,
                      double sigma, float* K, int64_t ldk, odx_stream_t stream);
+/* Build with the right-hand side of the fit fused in (A4: b = K_nM' (y / n), the first of the passes
+ * FALKONWrapper_with_centers_selection_incore.py:56-68 -> InCoreFalkon.fit makes over K_nM): writes K as
+ * odx_gauss_knm_h2 does and ktw[j] = sum_i K_ij w_i (f64, fixed-order sums), so that pass over the stored K_nM is
+ * never made.  Runs on the 256 x 256 tile core at every size.  w: n f64 weights; ktw: M f64. */
+int64_t odx_gauss_knm_h2_rhs_workspace_bytes(int64_t n, int64_t M);
+int odx_gauss_knm_h2_rhs(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
+                         const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int D,
+                         double sigma, float* K, int64_t ldk, const double* w, double* ktw, void* workspace,
+                         int64_t workspace_bytes, odx_stream_t stream);
 /* Two tile cores serve both calls: 256 x 256 outputs per workgroup (half the L2 traffic per product) once a launch
  * has >= 512 such tiles, 128 x 128 below that; the environment variable ODX_H2_TILE=128|256 pins one.
  * Scoring is tiled over (row block, group of 512 centre columns); the f64 partial sums of the groups pass through

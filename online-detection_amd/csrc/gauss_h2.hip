@@ -493,10 +493,14 @@ __device__ __forceinline__ void w_zero(f32x4 (&acc)[8][4]) {
 }
 
 // accumulator element (tm, tn, q) of a wave's 128 x 64 share: row 16 tm + 4 (lane >> 4) + q, column 16 tn + (lane & 15)
+// RHS: also leave wslab[row block][j] = sum over the tile's rows i of K_ij w_i (f64): the column sums K' w of the
+// right-hand side of the fit come out of the build, and the first pass over the stored K_nM is not needed.
+template <bool RHS>
 __global__ __launch_bounds__(W_THREADS, 1) void gauss_knm_h2w256_kernel(
     const uint32_t* __restrict__ PX, int64_t ldpx, const float* __restrict__ metax, const float* __restrict__ xsq, int64_t n,
     const uint32_t* __restrict__ PZ, int64_t ldpz, const float* __restrict__ metaz, const float* __restrict__ zsq, int64_t M,
-    int stages, float gamma_log2e, float* __restrict__ K, int64_t ldk, int gr) {
+    int stages, float gamma_log2e, float* __restrict__ K, int64_t ldk, int gr, const double* __restrict__ w,
+    double* __restrict__ wslab, int64_t wslab_ld) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int64_t GR = gr;
   const int64_t tiles_n = (M + W_BN - 1) / W_BN;
@@ -506,7 +510,11 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_knm_h2w256_kernel(
   if (i0 >= n) return;
 
   __shared__ __attribute__((aligned(16))) float xs_s[W_BM];
-  if (threadIdx.x < W_BM) xs_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] : 0.f;
+  __shared__ double ws_s[RHS ? W_BM : 1];
+  if (threadIdx.x < W_BM) {
+    xs_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] : 0.f;
+    if (RHS) ws_s[threadIdx.x] = (i0 + threadIdx.x < n) ? w[i0 + threadIdx.x] : 0.0;   // rows past the end weigh nothing
+  }
 
   f32x4 acc[8][4];
   w_zero(acc);
@@ -518,19 +526,27 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_knm_h2w256_kernel(
   const bool interior = i0 + W_BM <= n && j0 + W_BN <= M;
   const int64_t mpad = (M + 3) & ~int64_t(3);
   float* tile = K + i0 * ldk + j0;
+  double csum[4] = {0.0, 0.0, 0.0, 0.0};
+  float zs[4];
 #pragma unroll
   for (int tn = 0; tn < 4; ++tn) {
     const int cl = wc * 64 + tn * 16 + (lane & 15);
-    const float zs = (j0 + cl < M) ? zsq[j0 + cl] : 0.f;
+    zs[tn] = (j0 + cl < M) ? zsq[j0 + cl] : 0.f;
+  }
 #pragma unroll
-    for (int tm = 0; tm < 8; ++tm) {
-      const int rl = wr * 128 + tm * 16 + 4 * (lane >> 4);
-      const f32x4 xs = *reinterpret_cast<const f32x4*>(&xs_s[rl]);
+  for (int tm = 0; tm < 8; ++tm) {
+    const int rl = wr * 128 + tm * 16 + 4 * (lane >> 4);
+    const f32x4 xs = *reinterpret_cast<const f32x4*>(&xs_s[rl]);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float d2 = fmaf(m2, acc[tm][tn][q], xs[q]) + zs;
+    for (int q = 0; q < 4; ++q) {
+      const double wq = RHS ? ws_s[rl + q] : 0.0;
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const int cl = wc * 64 + tn * 16 + (lane & 15);
+        float d2 = fmaf(m2, acc[tm][tn][q], xs[q]) + zs[tn];
         d2 = fmaxf(d2, 0.f);
         const float v = __builtin_amdgcn_exp2f(d2 * gamma_log2e);
+        if (RHS) csum[tn] = fma((double)v, wq, csum[tn]);
         if (interior) {
           tile[(uint32_t)(rl + q) * (uint32_t)ldk + (uint32_t)cl] = v;
         } else if (i0 + rl + q < n && j0 + cl < mpad) {
@@ -538,6 +554,21 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_knm_h2w256_kernel(
         }
       }
     }
+    if (RHS) __builtin_amdgcn_sched_barrier(0);      // keep the row weights of later blocks out of registers until needed
+  }
+  if (RHS) {
+    // lanes l, l + 16, l + 32, l + 48 hold the same column: add them, then the two row halves of the tile through LDS
+    double* red2 = reinterpret_cast<double*>(lds);          // the stage buffers are free: the main loop ended on a barrier
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      double c = csum[tn];
+      c += __shfl_xor(c, 16);
+      c += __shfl_xor(c, 32);
+      if (lane < 16) red2[wr * W_BN + wc * 64 + tn * 16 + lane] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < W_BN && j0 + threadIdx.x < M)
+      wslab[(i0 / W_BM) * wslab_ld + j0 + threadIdx.x] = red2[threadIdx.x] + red2[W_BN + threadIdx.x];
   }
 }
 
@@ -690,6 +721,28 @@ extern "C" int odx_split_f16(const float* X, int64_t ldx, int64_t n, int D, void
   return ODX_OK;
 }
 
+static int launch_knm_w256(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n, const void* PZ,
+                           int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int64_t dp, double sigma, float* K,
+                           int64_t ldk, const double* w, double* wslab, int64_t wslab_ld, odx_stream_t stream) {
+  const int wgr = 4;   // band height of the tile order; 2 / 4 / 8 / 16 / 32 measured: 395 / 397 / 391 / 376 / 347 TF
+  const int64_t wt = round_up(ceil_div(n, W_BM), wgr) * ceil_div(M, W_BN);
+  ODX_REQUIRE(wt < (1ll << 31), "odx_gauss_knm_h2: grid too large");
+  const float g2 = (float)(-0.5 / (sigma * sigma)) * LOG2E;
+  if (w != nullptr) {
+    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2w256_kernel<true>), W_LDS_BYTES));
+    hipLaunchKernelGGL(gauss_knm_h2w256_kernel<true>, dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
+                       (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq, M, (int)(dp / W_KS), g2, K,
+                       ldk, wgr, w, wslab, wslab_ld);
+  } else {
+    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2w256_kernel<false>), W_LDS_BYTES));
+    hipLaunchKernelGGL(gauss_knm_h2w256_kernel<false>, dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
+                       (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq, M, (int)(dp / W_KS), g2, K,
+                       ldk, wgr, nullptr, nullptr, 0);
+  }
+  ODX_CHECK_LAUNCH("odx_gauss_knm_h2(w256)");
+  return ODX_OK;
+}
+
 extern "C" int odx_gauss_h2_tile(int64_t n, int64_t M) {
   if (n <= 0 || M <= 0) return 0;
   return h2_use_w256(ceil_div(n, W_BM) * ceil_div(M, W_BN)) ? W_BM : GEMM_BM;
@@ -706,17 +759,8 @@ extern "C" int odx_gauss_knm_h2(const void* PX, int64_t ldpx, const float* metax
   ODX_REQUIRE(ldk % 4 == 0 && ldk >= round_up(M, 4) && aligned16(K), "odx_gauss_knm_h2: K must be 16-byte aligned, ldk %% 4 == 0, ldk >= roundup(M, 4)");
   ODX_REQUIRE(ldpx < (1 << 24) && ldpz < (1 << 24) && ldk < (1 << 24), "odx_gauss_knm_h2: leading dimensions must stay below 2^24 (32-bit tile offsets)");
   const int gr = 8;   // band height of the tile order: 2..32 measured within 2 % of each other at n = 2.5e5, M = 1e4
-  if (h2_use_w256(ceil_div(n, W_BM) * ceil_div(M, W_BN))) {
-    const int wgr = 4;   // 2 / 4 / 8 / 16 / 32 measured: 395 / 397 / 391 / 376 / 347 TF
-    const int64_t wt = round_up(ceil_div(n, W_BM), wgr) * ceil_div(M, W_BN);
-    ODX_REQUIRE(wt < (1ll << 31), "odx_gauss_knm_h2: grid too large");
-    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2w256_kernel), W_LDS_BYTES));
-    hipLaunchKernelGGL(gauss_knm_h2w256_kernel, dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
-                       (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq, M, (int)(dp / W_KS),
-                       (float)(-0.5 / (sigma * sigma)) * LOG2E, K, ldk, wgr);
-    ODX_CHECK_LAUNCH("odx_gauss_knm_h2(w256)");
-    return ODX_OK;
-  }
+  if (h2_use_w256(ceil_div(n, W_BM) * ceil_div(M, W_BN)))
+    return launch_knm_w256(PX, ldpx, metax, xsq, n, PZ, ldpz, metaz, zsq, M, dp, sigma, K, ldk, nullptr, nullptr, 0, stream);
   const int64_t tiles = round_up(ceil_div(n, GEMM_BM), gr) * ceil_div(M, GEMM_BN);
   ODX_REQUIRE(tiles < (1ll << 31), "odx_gauss_knm_h2: grid too large");
   ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2s16_kernel)));
@@ -725,6 +769,36 @@ extern "C" int odx_gauss_knm_h2(const void* PX, int64_t ldpx, const float* metax
                      (float)(-0.5 / (sigma * sigma)) * LOG2E, K, ldk, gr);
   ODX_CHECK_LAUNCH("odx_gauss_knm_h2");
   return ODX_OK;
+}
+
+extern "C" int64_t odx_gauss_knm_h2_rhs_workspace_bytes(int64_t n, int64_t M) {
+  if (n <= 0 || M <= 0) return 0;
+  return ceil_div(n, W_BM) * round_up(M, 4) * (int64_t)sizeof(double);
+}
+
+extern "C" int odx_gauss_knm_h2_rhs(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
+                                    const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int D,
+                                    double sigma, float* K, int64_t ldk, const double* w, double* ktw, void* workspace,
+                                    int64_t workspace_bytes, odx_stream_t stream) {
+  ODX_REQUIRE(M > 0 && ktw, "odx_gauss_knm_h2_rhs: M <= 0 or null output");
+  if (n <= 0) {
+    ODX_CHECK_HIP(hipMemsetAsync(ktw, 0, (size_t)M * sizeof(double), as_stream(stream)));
+    return ODX_OK;
+  }
+  ODX_REQUIRE(PX && PZ && metax && metaz && xsq && zsq && K && w && D > 0 && sigma > 0, "odx_gauss_knm_h2_rhs: bad argument");
+  const int64_t dp = round_up(D, H2_KT);
+  ODX_REQUIRE(ldpx % 4 == 0 && ldpz % 4 == 0 && ldpx >= dp && ldpz >= dp && aligned16(PX) && aligned16(PZ),
+              "odx_gauss_knm_h2_rhs: packed operands must be 16-byte aligned with ld %% 4 == 0 and ld >= roundup(D, 64)");
+  ODX_REQUIRE(ldk % 4 == 0 && ldk >= round_up(M, 4) && aligned16(K), "odx_gauss_knm_h2_rhs: K must be 16-byte aligned, ldk %% 4 == 0, ldk >= roundup(M, 4)");
+  ODX_REQUIRE(ldpx < (1 << 24) && ldpz < (1 << 24) && ldk < (1 << 24), "odx_gauss_knm_h2_rhs: leading dimensions must stay below 2^24 (32-bit tile offsets)");
+  if (workspace == nullptr || workspace_bytes < odx_gauss_knm_h2_rhs_workspace_bytes(n, M)) {
+    set_error("odx_gauss_knm_h2_rhs: workspace too small");
+    return ODX_ERR_WORKSPACE;
+  }
+  const int64_t wld = round_up(M, 4);
+  ODX_PROPAGATE(launch_knm_w256(PX, ldpx, metax, xsq, n, PZ, ldpz, metaz, zsq, M, dp, sigma, K, ldk, w,
+                                static_cast<double*>(workspace), wld, stream));
+  return slab_reduce_f64(static_cast<const double*>(workspace), wld, (int)ceil_div(n, W_BM), M, ktw, as_stream(stream));
 }
 
 // groups of column tiles (counted from the range's own first row) a centre range of at most `max_range` rows spans

@@ -12,7 +12,7 @@
 //
 // Requirements: ldk % 4 == 0, K 16-byte aligned, columns [M, roundup(M,4)) of K are zero
 // (odx_gauss_knm_f32 writes them so).
-#include "odx_common.h"
+#include "odx_internal.h"
 
 namespace odx {
 
@@ -178,6 +178,12 @@ static int grid_for(const PassCfg& cfg, int64_t n) {
 }  // namespace odx
 
 using namespace odx;
+
+int odx::slab_reduce_f64(const double* slab, int64_t slab_ld, int nslab, int64_t M, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(M, 64)), dim3(256), 0, s, slab, slab_ld, nslab, M, out);
+  ODX_CHECK_LAUNCH("slab_reduce_f64");
+  return ODX_OK;
+}
 
 extern "C" int odx_set_pass_reserved_cus(int cus) {
   ODX_REQUIRE(cus >= 0, "odx_set_pass_reserved_cus: negative count");

@@ -36,6 +36,9 @@ int transpose_f64(const double* src, int64_t lds, double* dst, int64_t ldd, int6
 int add_diag_f64(double* A, int64_t lda, int64_t M, double value, hipStream_t stream);
 int fill_f64(double* A, int64_t lda, int64_t rows, int64_t cols, double value, hipStream_t stream);
 
+// knm_pass.hip: out[j] = sum_g slab[g][j], g = 0 .. nslab - 1, in a fixed order
+int slab_reduce_f64(const double* slab, int64_t slab_ld, int nslab, int64_t M, double* out, hipStream_t stream);
+
 // gauss.hip
 int gauss_kmm_f64(const double* Zd, int64_t ldz, int64_t M, int D, double sigma, double diag_add, double* Kmm,
                   int64_t ldk, double* zsq /* M */, hipStream_t stream);

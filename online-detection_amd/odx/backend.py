@@ -168,6 +168,33 @@ class HipBackend:
                                                  float(sigma), _p(K.K), ld, self._stream()), "odx_gauss_knm_f32")
         return K
 
+    def knm_rhs(self, F, Zf, sigma, w, out=None, rhs_out=None):
+        """K_nM and this shard's K_nM' w (the right-hand side of the fit) in one go.  With the f16-split kernels on the
+        wide tile core the column sums come out of the build itself; otherwise (small blocks, ODX_GAUSS=f32) the build is
+        followed by one pass over the stored block.  Returns (K, K'w)."""
+        n, M = F.n, Zf.n
+        if rhs_out is None:
+            rhs_out = torch.empty(M, dtype=torch.float64, device=self.device)
+        if not (self.gauss == "h2" and n > 0 and self.lib.odx_gauss_h2_tile(n, M) == 256):
+            K = self.knm(F, Zf, sigma, out=out)
+            return K, self.ktk(K, w=w, out=rhs_out)
+        ld = (M + 3) // 4 * 4
+        K = Knm()
+        K.n, K.M, K.ld = n, M, ld
+        if out is not None:
+            if out.numel() < n * ld or out.dtype != torch.float32:
+                raise ValueError("knm: out buffer too small")
+            K.K = out.view(-1)[: n * ld].view(n, ld)
+        else:
+            K.K = torch.empty((n, ld), dtype=torch.float32, device=self.device)
+        self.pack(F), self.pack(Zf)
+        w = w.to(dtype=torch.float64, device=self.device).contiguous()
+        ws = self._workspace("knm_rhs", self.lib.odx_gauss_knm_h2_rhs_workspace_bytes(n, M))
+        hip.check(self.lib.odx_gauss_knm_h2_rhs(_p(F.P), F.P.stride(0), _p(F.meta), _p(F.sq), n, _p(Zf.P), Zf.P.stride(0),
+                                                _p(Zf.meta), _p(Zf.sq), M, F.D, float(sigma), _p(K.K), ld, _p(w), _p(rhs_out),
+                                                _p(ws), ws.numel(), self._stream()), "odx_gauss_knm_h2_rhs")
+        return K, rhs_out
+
     def pin_gauss_tile(self, tile):
         """Pin the tile core of the f16-split Gaussian kernels (128 or 256); 0 = chosen per launch (default)."""
         hip.check(self.lib.odx_set_h2_tile(int(tile)), "odx_set_h2_tile")

@@ -37,6 +37,9 @@ SIGNATURES = {
     "odx_gauss_h2_tile": (_i32, [_i64, _i64]),
     "odx_set_h2_tile": (_i32, [_i32]),
     "odx_gauss_knm_h2": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _f64, _vp, _i64, _vp]),
+    "odx_gauss_knm_h2_rhs_workspace_bytes": (_i64, [_i64, _i64]),
+    "odx_gauss_knm_h2_rhs": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _f64, _vp, _i64, _vp, _vp, _vp, _i64,
+                                    _vp]),
     "odx_gauss_mmv_h2_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "odx_gauss_mmv_h2": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _f64, _vp, _i64, _vp, _i32, _vp, _i64,
                                 _vp, _i64, _vp]),

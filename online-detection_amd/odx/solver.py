@@ -4,7 +4,7 @@ Restates what ``InCoreFalkon(...).fit(X, y)`` does at the reference's call site
 (src/modules/region-classifier/FALKONWrapper_with_centers_selection_incore.py:56-68) with
 falkon's upstream defaults for the f32 regime the reference runs in:
     T = chol(K_MM + eps M I)', A = chol(T T'/M + lam I)'          (preconditioner, f64 here)
-    b = A^-T T^-T K_nM' (y / n)
+    b = A^-T T^-T K_nM' (y / n)                                   (K_nM' (y / n) comes out of the K_nM build)
     CG, maxiter steps, on  beta -> A^-T [ T^-T K_nM' (K_nM T^-1 A^-1 beta) / n + lam A^-1 beta ]
     alpha = T^-1 A^-1 beta
 Every array op is a libodx kernel reached through the backend; this file only sequences
@@ -74,8 +74,9 @@ def falkon_fit(be, F, y, Zf, sigma, lam, maxiter=20, opt=None, n_total=None, all
     if owned and P is None:
         with ph("precond"):
             P = be.precond(Zf, sigma, lam, opt.pc_epsilon)
+    yn = y * (1.0 / n)
     with ph("knm"):
-        K = be.knm(F, Zf, sigma, out=knm_out)
+        K, b0 = be.knm_rhs(F, Zf, sigma, yn, out=knm_out)   # K_nM and this shard's K' (y / n), out of the same launch
 
     def ktk(**kw):
         with ph("ktk"):
@@ -96,8 +97,7 @@ def falkon_fit(be, F, y, Zf, sigma, lam, maxiter=20, opt=None, n_total=None, all
             u = be.trmv(P, "LTi", cc, alpha=1.0 / n, beta=lam, z=v)   # T^-T cc / n + lam v
             be.trmv(P, "LAi", u, out=out)              # A^-T u
 
-    yn = y * (1.0 / n)
-    b0 = ktk(w=yn)                                     # K' (y / n)
+    b0 = ar(b0)                                        # K' (y / n), summed over shards
     X, R, Pv, AP = be.zeros(M), be.zeros(M), be.zeros(M), be.zeros(M)
     state = be.zeros(4)
     if owned:
@@ -166,24 +166,21 @@ def falkon_fit_lockstep(be, F, ys, Zfs, sigma, lam, maxiter=20, opt=None, n_tota
     if owned and P is None:
         with ph("precond"):
             P = be.precond(Zfs[rank], sigma, lam, opt.pc_epsilon)
-    Ks = []
-    for b in range(B):
-        with ph("knm"):
-            Ks.append(be.knm(F, Zfs[b], sigma, out=None if knm_outs is None else knm_outs[b]))
-
     Mp = (M + 1) // 2 * 2                             # rows of the exchanged matrices stay 16-byte aligned
     Tall = be.zeros(world * Mp).view(world, Mp)       # gathered directions
     CC = be.zeros(world * Mp).view(world, Mp)         # this rank's partials, one row per problem
+    Ks = []
+    for b in range(B):
+        with ph("knm"):                               # K_nM shard and this shard's K' (y / n) of problem b in one launch
+            Ks.append(be.knm_rhs(F, Zfs[b], sigma, ys[b] * (1.0 / n), out=None if knm_outs is None else knm_outs[b],
+                                 rhs_out=CC[b, :M])[0])
     tbuf, ccbuf, v = be.zeros(Mp), be.zeros(Mp), be.zeros(M)
     t, cc = tbuf[:M], ccbuf[:M]
 
-    def passes(use_w):
+    def passes():
         for b in range(B):
             with ph("ktk"):
-                if use_w:
-                    be.ktk(Ks[b], w=ys[b] * (1.0 / n), out=CC[b, :M])
-                else:
-                    be.ktk(Ks[b], v=Tall[b, :M], out=CC[b, :M])
+                be.ktk(Ks[b], v=Tall[b, :M], out=CC[b, :M])
         return shard.reduce_scatter_rows(CC, ccbuf)
 
     def mmv(s, out):
@@ -191,12 +188,12 @@ def falkon_fit_lockstep(be, F, ys, Zfs, sigma, lam, maxiter=20, opt=None, n_tota
             be.trmv(P, "LAit", s, out=v)
             be.trmv(P, "LTit", v, out=t)
         shard.gather_rows(tbuf, Tall)
-        passes(False)
+        passes()
         if owned:
             u = be.trmv(P, "LTi", cc, alpha=1.0 / n, beta=lam, z=v)
             be.trmv(P, "LAi", u, out=out)
 
-    passes(True)                                     # K' (y / n) of every problem
+    shard.reduce_scatter_rows(CC, ccbuf)             # K' (y / n) of every problem: each owner gets the sum of its row
     X, R, Pv, AP = be.zeros(M), be.zeros(M), be.zeros(M), be.zeros(M)
     state = be.zeros(4)
     Bv = None

@@ -67,6 +67,10 @@ class OracleBackend:
         K.n, K.M, K.ld = F.n, Zf.n, Zf.n
         return K
 
+    def knm_rhs(self, F, Zf, sigma, w, out=None, rhs_out=None):
+        K = self.knm(F, Zf, sigma, out=out)
+        return K, self.ktk(K, w=w, out=rhs_out)
+
     def ktk(self, K, v=None, w=None, out=None):
         Kd = K.K.double()
         t = Kd @ v if v is not None else torch.zeros(K.n, dtype=torch.float64)

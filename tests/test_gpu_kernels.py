@@ -109,6 +109,29 @@ def test_gauss_knm(be, gauss, n, M, D, sigma):
     assert np.all(np.abs(np.diag(K2[:5, :5]) - 1.0) < 1e-4)
 
 
+@pytest.mark.parametrize("n,M,D,sigma", [(1000, 500, 256, 10.0), (333, 130, 1024, 15.0), (700, 257, 70, 5.0), (256, 256, 64, 8.0)])
+def test_gauss_knm_with_fused_rhs(be, gauss, n, M, D, sigma):
+    """knm_rhs: K_nM as odx_gauss_knm_* writes it and K_nM' w (the fit's right-hand side) from the same call — out of the
+    build kernel's epilogue on the wide tile core, by one pass over the stored block otherwise."""
+    from oracle import falkon_ref as fr
+    rng = np.random.default_rng(n + M)
+    X = (rng.standard_normal((n, D)) * (20.0 / np.sqrt(D))).astype(np.float32)
+    Z = X[rng.integers(0, n, M)].copy()
+    w = rng.standard_normal(n)
+    F, Zf = be.features(torch.from_numpy(X)), be.features(torch.from_numpy(Z))
+    K, ktw = be.knm_rhs(F, Zf, sigma, torch.from_numpy(w).cuda())
+    got = K.K.cpu().numpy()
+    ref = fr.gaussian_kernel(X.astype(np.float64), Z.astype(np.float64), sigma)
+    assert np.abs(got[:, :M] - ref).max() < 2e-5
+    assert np.all(got[:, M:] == 0)
+    want = got[:, :M].astype(np.float64).T @ w          # the sums are over the f32 entries that were stored
+    assert np.abs(ktw.cpu().numpy() - want).max() <= 1e-12 * max(1.0, np.abs(want).max()) * n
+    # into caller-provided storage, twice: same bits
+    out = torch.empty(M + 2, dtype=torch.float64, device="cuda")
+    _, again = be.knm_rhs(F, Zf, sigma, torch.from_numpy(w).cuda(), out=K.K.view(-1), rhs_out=out[:M])
+    assert torch.equal(again, ktw)
+
+
 @pytest.mark.parametrize("n,D,scale", [(300, 256, 1.0), (5, 36, 1e-3), (70000, 64, 37.0), (129, 1000, 5e4), (3, 8, 0.0)])
 def test_split_f16(be, n, D, scale):
     """odx_split_f16: hi + lo reproduces scale * x to 2^-22 relative (to the matrix max), layout as documented."""
