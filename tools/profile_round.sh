@@ -15,4 +15,4 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_
 done
 python tools/summarize_profile.py $OUT > $OUT/summary.md
 cat $OUT/summary.md
-rm -f $OUT/*kernel_trace.csv $OUT/*agent_info.csv
+rm -f $OUT/*agent_info.csv $OUT/bench_kernel_trace.csv

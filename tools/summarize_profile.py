@@ -44,6 +44,8 @@ for k, v in agg.items():
     c = {n: sum(x) / len(x) for n, x in v.items()}
     ms = min(dur[k]) if dur[k] else float("nan")
     line = "* `%s`: %.2f ms/launch" % (k, ms)
+    if "GRBM_GUI_ACTIVE" in c and ms == ms:
+        line += " at %.2f GHz" % (c["GRBM_GUI_ACTIVE"] / 8 / ms / 1e6)
     if "FETCH_SIZE" in c:
         # guide: on gfx950 FETCH_SIZE (KiB) counts 64 B per 128-B request for wide coalesced reads -> x2
         rd = 2 * c["FETCH_SIZE"] * 1024
@@ -67,7 +69,11 @@ print("""
   than the wall time and say nothing about how much of the GPU those kernels used.
 * `knm_pass_kernel`: algorithmic bytes per launch = n x M x 4 (40.0 GB at n = 1e6, M = 1e4); the FETCH_SIZE counter
   (doubled per the gfx950 correction of the guide) gives the same number: K_nM is read exactly once per pass.
-* The Gaussian kernels issue 3 f16 MFMAs per algorithmic product (two-term f16 split); MFMA-busy ~53 % at the
-  ~1.8 GHz the chip holds under them (GRBM_GUI_ACTIVE / 8 / time).  Their FETCH_SIZE counts L2 misses, most of them served
-  by the Infinity Cache (unique input: 4.1 GB of packed X + 41 MB of packed Z per launch).
+* The Gaussian kernels issue 3 f16 MFMAs per algorithmic product (two-term f16 split); MFMA-busy and the clock the chip
+  holds under them (GRBM_GUI_ACTIVE / 8 / time) are in the lines above: 62-63 % at ~1.9 GHz on the 256 x 256 tile core, i.e.
+  ~1.25 PFLOP/s of f16 MFMA issued on random data.  Their FETCH_SIZE counts L2 misses, most of them served by the Infinity
+  Cache (unique input: 4.1 GB of packed X + 41 MB of packed Z per launch).  In the bench table the same kernels take
+  ~10 ms longer per launch than alone: the f64 MFMA work of the look-ahead preconditioners runs beside them.
+* `gauss_knm_h2w256_kernel<true>` is the build with the fit's right-hand side K' (y / n) fused in (what the bench runs);
+  the PMC passes launch the plain build `<false>`.
 """)
