@@ -1,0 +1,83 @@
+"""Parity at the shapes BASELINE.json names as configs 2 and 4 (config 1 is `test_falkon_fit_alpha_parity`'s first case,
+config 3's single-GPU shard is `test_headline_shape_one_class`): the whole fit on the MI355X against the f64 oracle
+(oracle/falkon_ref.py) on the same seeded inputs, alphas within 1e-4 relative as BASELINE.json's north star states."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def be():
+    import odx
+    return odx.get_backend()
+
+
+def _blobs(n, D, C, seed):
+    """C class blobs, rows i of class i % C, normalised with the reference rule (OnlineRegionClassifier.py:224-227)."""
+    rng = np.random.default_rng(seed)
+    mu = rng.standard_normal((C, D))
+    X = mu[np.arange(n) % C] + 0.7 * rng.standard_normal((n, D))
+    X -= X.mean(0)
+    X *= 20.0 / np.linalg.norm(X, axis=1).mean()
+    return np.ascontiguousarray(X.astype(np.float32)), rng
+
+
+def test_config2_thirty_classes_n1e5_m2000(be):
+    """Config 2's FALKON half: 30 one-vs-rest classes on N = 1e5, D = 1024, M = 2000 (sigma = 15, lambda = 1e-5, 20 CG
+    steps).  All 30 are fitted and scored on the GPU; two of them are checked against the oracle (alpha 1e-4, scores),
+    all of them through the labels they were fitted on."""
+    import odx
+    from oracle import falkon_ref as fr
+    n, D, M, C, sigma, lam = 100_000, 1024, 2000, 30, 15.0, 1e-5
+    X, rng = _blobs(n, D, C, seed=1234 + 2)
+    F = be.features(torch.from_numpy(X))
+    cls = np.arange(n) % C
+    scores = torch.empty((n, C), dtype=torch.float32, device="cuda")
+    kept = {}
+    for c in range(C):
+        y = np.where(cls == c, 1.0, -1.0).astype(np.float32)
+        idx = fr.compute_indices_selection(y, M, lambda high, size: rng.integers(0, high, size))
+        Zf = be.rows(F, idx)
+        alpha = odx.falkon_fit(be, F, be.vec(y), Zf, sigma, lam, 20)
+        be.mmv(F, Zf, sigma, alpha, None, out=scores[:, c:c + 1])
+        if c in (0, 17):
+            kept[c] = (y, idx, alpha.cpu().numpy())
+    pred = scores.argmax(1).cpu().numpy()
+    assert (pred == cls).mean() > 0.99                      # separable blobs: every class learned
+    Xd = X.astype(np.float64)
+    for c, (y, idx, alpha) in kept.items():
+        ref, Z = fr.falkon_fit(Xd, y.astype(np.float64), idx, sigma, lam, maxiter=20, dtype=np.float64, pc_eps=1e-5,
+                               cg_epsilon=1e-7)
+        rel = np.linalg.norm(alpha - ref[:, 0]) / np.linalg.norm(ref[:, 0])
+        assert rel < 1e-4, (c, rel)
+        rows = np.arange(0, n, 997)
+        pref = fr.falkon_predict(Xd[rows], Z, ref, sigma)
+        assert np.abs(scores[rows, c].cpu().numpy() - pref[:, 0]).max() < 1e-4
+
+
+def test_config4_mask_pixels_d256_m2000(be):
+    """Config 4's shape: one class of the on-line segmentation head, 7 x 7 x 256 mask features as D = 256 pixel rows,
+    M = 2000, sigma = 10, a single fit per class (no minibootstrap, run_experiment_online_rpn_ood_oos.py:254) — at
+    2e5 rows, the size the f64 oracle holds on the host (the reference scale is 5e5 per class; nothing in the path
+    depends on n beyond the row loop the headline-shape test covers)."""
+    import odx
+    from oracle import falkon_ref as fr
+    n, D, M, sigma, lam = 200_000, 256, 2000, 10.0, 1e-5
+    X, rng = _blobs(n, D, 2, seed=1234 + 4)
+    y = np.where(np.arange(n) % 2 == 0, 1.0, -1.0).astype(np.float32)      # foreground / background pixels of the class
+    flip = rng.random(n) < 0.05
+    y[flip] = -y[flip]                                                      # label noise: not separable
+    idx = fr.compute_indices_selection(y, M, lambda high, size: rng.integers(0, high, size))
+    F = be.features(torch.from_numpy(X))
+    Zf = be.rows(F, idx)
+    alpha = odx.falkon_fit(be, F, be.vec(y), Zf, sigma, lam, 20).cpu().numpy()
+    ref, Z = fr.falkon_fit(X.astype(np.float64), y.astype(np.float64), idx, sigma, lam, maxiter=20, dtype=np.float64,
+                           pc_eps=1e-5, cg_epsilon=1e-7)
+    rel = np.linalg.norm(alpha - ref[:, 0]) / np.linalg.norm(ref[:, 0])
+    assert rel < 1e-4, rel
+    rows = np.arange(0, n, 499)
+    got = be.mmv(be.features(torch.from_numpy(X[rows])), Zf, sigma, torch.from_numpy(alpha)).cpu().numpy()
+    assert np.abs(got - fr.falkon_predict(X[rows].astype(np.float64), Z, ref, sigma)).max() < 1e-4
