@@ -16,6 +16,7 @@ RoIAlign 14 x 14 @ 1/16 with adaptive sampling, conv5 head -> D = 2048):
 No pretrained weights or datasets exist in this environment: weights are random (seeded) unless
 a state dict is given, and images come from the caller.  PARITY UNPINNED (structure only).
 """
+import contextlib
 import math
 
 import torch
@@ -158,8 +159,12 @@ class OnlineDetectionModel(nn.Module):
     """backbone -> RPN -> (gt boxes prepended) -> RoIAlign -> conv5 head -> avg-pooled features."""
 
     def __init__(self, width=64, num_anchors=15, pre_nms_top_n=6000, post_nms_top_n=300, rpn_nms=0.7, resolution=14,
-                 seed=0, mask_dim=256):
+                 seed=0, mask_dim=256, compute_dtype=None):
+        """compute_dtype: None = f32 convolutions; torch.bfloat16 = the convolutions under bf16 autocast (BASELINE
+        config 2's forward; 126 instead of 89 images/s at 600 x 800 with 300 RoIs).  Everything handed on — the C4 map the
+        RoIAlign kernel reads, RoI features, RPN rows, mask pixel rows — is f32 either way."""
         super().__init__()
+        self.compute_dtype = compute_dtype
         g = torch.random.get_rng_state()
         torch.manual_seed(seed)
         self.backbone = ResNet50C4(width)
@@ -188,6 +193,17 @@ class OnlineDetectionModel(nn.Module):
     def feat_dim(self):
         return self.head.out_channels
 
+    def _amp(self):
+        if self.compute_dtype is None:
+            return contextlib.nullcontext()
+        return torch.autocast("cuda", dtype=self.compute_dtype)
+
+    @torch.no_grad()
+    def c4(self, image):
+        """(1, C, H/16, W/16) f32 trunk features."""
+        with self._amp():
+            return self.backbone(image).float()
+
     def update_model(self, models_rpn=None, models_detection=None, models_segmentation=None):
         """Swap trained on-line models into the running pipeline, each a dict {'classifiers', 'regressors', 'stats'}
         (segmentation: no regressors) — the demo's OnlineSegmentationDemo.update_model
@@ -204,7 +220,8 @@ class OnlineDetectionModel(nn.Module):
             getattr(self, attr).set_models(models["classifiers"], models.get("regressors"), models["stats"])
 
     def rpn_activation(self, c4):
-        return F.relu(self.rpn_conv(c4))
+        with self._amp():
+            return F.relu(self.rpn_conv(c4)).float()
 
     @torch.no_grad()
     def proposals(self, c4, img_size):
@@ -212,7 +229,8 @@ class OnlineDetectionModel(nn.Module):
         if self.online_rpn is not None:
             logits, deltas = self.online_rpn(t)
         else:
-            logits, deltas = self.rpn_logits(t), self.rpn_deltas(t)
+            with self._amp():
+                logits, deltas = self.rpn_logits(t).float(), self.rpn_deltas(t).float()
         anchors = grid_anchors(c4.shape[2], c4.shape[3], self.stride, self.cells.to(c4.device))
         return rpn_proposals(logits, deltas, anchors, img_size, self.pre_nms_top_n, self.post_nms_top_n, self.rpn_nms)
 
@@ -222,7 +240,8 @@ class OnlineDetectionModel(nn.Module):
         be = _backend.get_backend()
         rois = torch.cat((torch.zeros((boxes.shape[0], 1), device=boxes.device), boxes), dim=1)
         crops = be.roi_align(c4, rois, 1.0 / self.stride, (self.resolution, self.resolution), 0)
-        return self.head(crops)
+        with self._amp():
+            return self.head(crops).float()
 
     @torch.no_grad()
     def roi_features(self, c4, boxes):
@@ -232,13 +251,14 @@ class OnlineDetectionModel(nn.Module):
     @torch.no_grad()
     def mask_activation(self, head_maps):
         """(R, mask_dim, r, r) = relu(conv5_mask(head maps))  (roi_mask_predictors.py:38)."""
-        return F.relu(self.conv5_mask(head_maps))
+        with self._amp():
+            return F.relu(self.conv5_mask(head_maps)).float()
 
     @torch.no_grad()
     def forward(self, image, gt_boxes=None):
         """image (1, 3, H, W) already normalised / resized; returns (boxes (R, 4), feats (R, D), c4)
         with the ground-truth boxes prepended to the proposals (generalized_rcnn_getProposals.py:90-96)."""
-        c4 = self.backbone(image)
+        c4 = self.c4(image)
         img_size = (image.shape[3], image.shape[2])
         boxes, _ = self.proposals(c4, img_size)
         if gt_boxes is not None and len(gt_boxes):
@@ -318,7 +338,7 @@ class OnlineFeatureExtractor:
             image, gt_boxes = image.to(dev), gt_boxes.to(dev).float()
             img_size = (image.shape[3], image.shape[2])
             with torch.no_grad():
-                c4 = m.backbone(image)
+                c4 = m.c4(image)
                 if hv_rpn is not None and len(gt_boxes):
                     anchors = grid_anchors(c4.shape[2], c4.shape[3], m.stride, m.cells.to(dev))
                     hv_rpn.add_image(m.rpn_activation(c4)[0], anchors, img_size, gt_boxes)

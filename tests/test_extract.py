@@ -123,6 +123,25 @@ def test_end_to_end_pipeline_on_gpu(tmp_path):
     assert sum(len(b) for b in neg2[0]) == sum(len(b) for b in negatives[0])
 
 
+@pytest.mark.gpu
+def test_forward_under_bf16_autocast_hands_on_f32():
+    """compute_dtype=torch.bfloat16 (BASELINE config 2's forward): same proposals machinery, f32 outputs, RoI features
+    within bf16 rounding of the f32 forward on the same boxes."""
+    from odx.extract import OnlineDetectionModel
+    m32 = OnlineDetectionModel(width=16, post_nms_top_n=40, pre_nms_top_n=400, seed=4).cuda().eval()
+    m16 = OnlineDetectionModel(width=16, post_nms_top_n=40, pre_nms_top_n=400, seed=4, compute_dtype=torch.bfloat16).cuda().eval()
+    img = _samples(1, 192, 256, 3, seed=5)[0][0].cuda()
+    c32, c16 = m32.c4(img), m16.c4(img)
+    assert c16.dtype == torch.float32 and c16.shape == c32.shape
+    assert float((c16 - c32).norm() / c32.norm()) < 3e-2
+    boxes, _ = m32.proposals(c32, (256, 192))
+    f32, f16 = m32.roi_features(c32, boxes), m16.roi_features(c32, boxes)
+    assert f16.dtype == torch.float32 and torch.isfinite(f16).all()
+    assert float((f16 - f32).norm() / f32.norm()) < 3e-2
+    b16, feats, _ = m16(img, None)
+    assert feats.dtype == torch.float32 and feats.shape == (b16.shape[0], m16.feat_dim)
+
+
 def _samples_with_masks(n, H, W, C, seed=0):
     out = []
     for (img, gt, labels) in _samples(n, H, W, C, seed):
