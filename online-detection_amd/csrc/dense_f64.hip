@@ -412,7 +412,8 @@ __global__ __launch_bounds__(256) void place_diag_inverses_kernel(const double* 
   }
 }
 
-// y[i] = alpha * sum_{j in tri range} Tri[i][j] x[j] + beta * z[i]; one wave per row.
+// y[i] = alpha * sum_{j in tri range} Tri[i][j] x[j] + beta * z[i]; one wave per row, 16-byte loads, four of them in
+// flight per lane (four partial sums) over the aligned pairs of the row's range; the odd elements at its ends go to lane 0.
 __global__ __launch_bounds__(256) void trmv_f64_kernel(const double* __restrict__ Tri, int64_t ld, int64_t M,
                                                        int uplo, const double* __restrict__ x, double alpha,
                                                        double beta, const double* __restrict__ z,
@@ -422,20 +423,29 @@ __global__ __launch_bounds__(256) void trmv_f64_kernel(const double* __restrict_
   if (i >= M) return;
   const int64_t jlo = uplo ? i : 0, jhi = uplo ? M : i + 1;  // [jlo, jhi)
   const double* row = Tri + i * ld;
-  double s = 0.0;
-  const int64_t p0 = jlo >> 1, p1 = (jhi + 1) >> 1;  // pairs of columns; ld is even so pairs are 16-B aligned
-  for (int64_t p = p0 + lane; p < p1; p += 64) {
-    const int64_t j = p * 2;
-    if (j >= jlo && j + 1 < jhi) {
-      const f64x2 a = *reinterpret_cast<const f64x2*>(row + j);
-      const f64x2 b = *reinterpret_cast<const f64x2*>(x + j);
-      s = fma(a[0], b[0], s);
-      s = fma(a[1], b[1], s);
-    } else {
-      if (j >= jlo && j < jhi) s = fma(row[j], x[j], s);
-      if (j + 1 >= jlo && j + 1 < jhi) s = fma(row[j + 1], x[j + 1], s);
-    }
+  const int64_t q0 = (jlo + 1) >> 1, q1 = jhi >> 1;           // whole pairs [2 q0, 2 q1); ld is even so pairs are 16-B aligned
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (lane == 0) {
+    if (jlo & 1) s0 = row[jlo] * x[jlo];
+    if (jhi & 1) s1 = row[jhi - 1] * x[jhi - 1];
   }
+  int64_t p = q0 + lane;
+  for (; p + 192 < q1; p += 256) {
+    const f64x2 a0 = *reinterpret_cast<const f64x2*>(row + 2 * p), a1 = *reinterpret_cast<const f64x2*>(row + 2 * (p + 64));
+    const f64x2 a2 = *reinterpret_cast<const f64x2*>(row + 2 * (p + 128)), a3 = *reinterpret_cast<const f64x2*>(row + 2 * (p + 192));
+    const f64x2 b0 = *reinterpret_cast<const f64x2*>(x + 2 * p), b1 = *reinterpret_cast<const f64x2*>(x + 2 * (p + 64));
+    const f64x2 b2 = *reinterpret_cast<const f64x2*>(x + 2 * (p + 128)), b3 = *reinterpret_cast<const f64x2*>(x + 2 * (p + 192));
+    s0 = fma(a0[1], b0[1], fma(a0[0], b0[0], s0));
+    s1 = fma(a1[1], b1[1], fma(a1[0], b1[0], s1));
+    s2 = fma(a2[1], b2[1], fma(a2[0], b2[0], s2));
+    s3 = fma(a3[1], b3[1], fma(a3[0], b3[0], s3));
+  }
+  for (; p < q1; p += 64) {
+    const f64x2 a = *reinterpret_cast<const f64x2*>(row + 2 * p);
+    const f64x2 b = *reinterpret_cast<const f64x2*>(x + 2 * p);
+    s0 = fma(a[1], b[1], fma(a[0], b[0], s0));
+  }
+  double s = (s0 + s1) + (s2 + s3);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
   if (lane == 0) {
