@@ -548,7 +548,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_knm_h2w256_kernel(
         const float v = __builtin_amdgcn_exp2f(d2 * gamma_log2e);
         if (RHS) csum[tn] = fma((double)v, wq, csum[tn]);
         if (interior) {
-          tile[(uint32_t)(rl + q) * (uint32_t)ldk + (uint32_t)cl] = v;
+          tile[(uint32_t)(rl + q) * (uint32_t)ldk + (uint32_t)cl] = v;   // (non-temporal stores: no difference)
         } else if (i0 + rl + q < n && j0 + cl < mpad) {
           tile[(int64_t)(rl + q) * ldk + cl] = (j0 + cl < M) ? v : 0.f;
         }
