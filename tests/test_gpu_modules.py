@@ -14,6 +14,7 @@ torch = pytest.importorskip("torch")
 from tests import dropin  # noqa: E402
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def quiet(fn, *a, **kw):
@@ -244,3 +245,42 @@ def test_heads_at_reference_scale(hip_backend):
     W = np.stack([regs[3]["Beta"][str(k)]["weights"].numpy() for k in range(4)]).astype(np.float64)
     refb = x.numpy().astype(np.float64) @ W[:, :-1].T + W[:, -1]
     assert np.abs(bb[:, 16:20].cpu().numpy() - refb).max() < 1e-4
+
+
+def test_rccl_collectives_of_the_lockstep_fit_single_rank():
+    """The RCCL calls of the sharded fit (odx/dist.py: all_gather_into_tensor / reduce_scatter_tensor / all_reduce /
+    broadcast on f64 and f32 device tensors) in a one-rank process group on the real backend: same entry points, dtypes
+    and shapes as an 8-GPU run, which this box cannot host.  Runs in a child process so the group never leaks into the
+    other tests."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(os.getcwd(), "online-detection_amd"))
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", init_method="env://")
+from odx.dist import RowShard
+sh = RowShard()
+sh.enabled, sh.world, sh.rank = True, 1, 0            # one rank, but through the collective code path
+M = 10001
+Mp = (M + 1) // 2 * 2
+mine = torch.randn(Mp, dtype=torch.float64, device="cuda")
+out = torch.zeros((1, Mp), dtype=torch.float64, device="cuda")
+sh.gather_rows(mine, out)
+assert torch.equal(out[0], mine)
+partials = torch.randn((1, Mp), dtype=torch.float64, device="cuda")
+got = torch.zeros(Mp, dtype=torch.float64, device="cuda")
+sh.reduce_scatter_rows(partials, got)
+assert torch.equal(got, partials[0])
+Z = torch.randn((1000, 1024), device="cuda")
+assert torch.equal(sh.allreduce(Z.clone()), Z)
+v = torch.randn(M, dtype=torch.float64, device="cuda")
+assert torch.equal(sh.broadcast(v.clone(), src=0), v)
+assert sh.total(12345) == 12345
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("RCCL-OK")
+'''
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert "RCCL-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
