@@ -401,3 +401,53 @@ def test_headline_shape_one_class(be):
     # (d) the fit repeats bit for bit at this size too
     alpha2 = odx.falkon_fit(be, F, y, Zf, sigma, lam, 20, knm_out=K.K.view(-1))
     assert torch.equal(alpha, alpha2)
+
+
+def test_gauss_random_shapes_stay_inside_their_buffers(be, gauss):
+    """Seeded sweep over ragged (n, M, D): build (+ fused right-hand side), fused scoring with per-column centre ranges
+    and the CG pass against the oracle, with sentinels behind every output buffer (the tile cores clamp their loads and
+    mask their stores; nothing may land outside n x ld, M or n x T)."""
+    from oracle import falkon_ref as fr
+    rng = np.random.default_rng(20261003)
+    for case in range(14):
+        n, M, D = int(rng.integers(1, 700)), int(rng.integers(1, 600)), int(rng.integers(1, 40)) * int(rng.integers(1, 9))
+        sigma = float(rng.uniform(4.0, 20.0))
+        X = (rng.standard_normal((n, D)) * (20.0 / np.sqrt(D))).astype(np.float32)
+        Z = (rng.standard_normal((M, D)) * (20.0 / np.sqrt(D))).astype(np.float32)
+        Z[: min(M, n) // 2] = X[: min(M, n) // 2]
+        F, Zf = be.features(torch.from_numpy(X)), be.features(torch.from_numpy(Z))
+        ld = (M + 3) // 4 * 4
+        Kbuf = torch.full((n * ld + 64,), float("nan"), device="cuda")
+        rhs = torch.full((M + 8,), float("nan"), dtype=torch.float64, device="cuda")
+        w = rng.standard_normal(n)
+        K, ktw = be.knm_rhs(F, Zf, sigma, torch.from_numpy(w).cuda(), out=Kbuf, rhs_out=rhs[:M])
+        ref = fr.gaussian_kernel(X.astype(np.float64), Z.astype(np.float64), sigma)
+        got = K.K.cpu().numpy()
+        assert np.abs(got[:, :M] - ref).max() < 2e-5, (case, n, M, D)
+        assert np.all(got[:, M:] == 0)
+        assert torch.isnan(Kbuf[n * ld:]).all() and torch.isnan(rhs[M:]).all(), (case, n, M, D)
+        want = got[:, :M].astype(np.float64).T @ w
+        assert np.abs(ktw.cpu().numpy() - want).max() <= 1e-11 * max(1.0, np.abs(want).max()) * n
+        # the CG pass on that block
+        v = rng.standard_normal(M)
+        cc = torch.full((M + 8,), float("nan"), dtype=torch.float64, device="cuda")
+        be.ktk(K, v=torch.from_numpy(v).cuda(), out=cc[:M])
+        g64 = got[:, :M].astype(np.float64)
+        wantc = g64.T @ (g64 @ v)
+        assert np.abs(cc[:M].cpu().numpy() - wantc).max() <= 1e-10 * max(1.0, np.abs(wantc).max()) * n
+        assert torch.isnan(cc[M:]).all()
+        # fused scoring of T columns, each over its own range of centres
+        T = int(rng.integers(1, 5))
+        cuts = np.sort(rng.integers(0, M + 1, T - 1)) if T > 1 else np.array([], dtype=np.int64)
+        edges = np.concatenate([[0], cuts, [M]]).astype(np.int32)
+        V = np.zeros((M, T))
+        ranges = np.zeros((T, 2), dtype=np.int32)
+        for t in range(T):
+            ranges[t] = (edges[t], edges[t + 1])
+            V[edges[t]:edges[t + 1], t] = rng.standard_normal(edges[t + 1] - edges[t])
+        sbuf = torch.full((n * T + 16,), float("nan"), device="cuda")
+        out = sbuf[: n * T].view(n, T)
+        be.mmv(F, Zf, sigma, torch.from_numpy(V).cuda(), torch.from_numpy(ranges).cuda(), out=out)
+        wants = ref @ V
+        assert np.abs(out.cpu().numpy() - wants).max() < 5e-5 * max(1.0, np.abs(wants).max()), (case, n, M, D, T)
+        assert torch.isnan(sbuf[n * T:]).all()
