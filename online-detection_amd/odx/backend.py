@@ -63,7 +63,12 @@ class HipBackend:
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _workspace(self, key, nbytes):
+        """Scratch buffer of a call site, one per stream it has been used on (fits issued on different streams must not
+        share scratch; the main stream keeps the bare key)."""
         nbytes = max(int(nbytes), 16)
+        cur = torch.cuda.current_stream(self.device)
+        if cur != torch.cuda.default_stream(self.device):
+            key = (key, cur.cuda_stream)
         buf = self._ws.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = None
@@ -143,7 +148,11 @@ class HipBackend:
         return P
 
     def check_precond(self, P):
-        info = int(P.info.item())
+        self.check_info(P.info)
+
+    def check_info(self, info):
+        """One host synchronisation: raise if a Cholesky of the preconditioner met a non-positive pivot."""
+        info = int(info.item())
         if info != 0:
             raise hip.OdxError("FALKON preconditioner: non-positive pivot at index %d (Cholesky failed)" % (info - 1))
 

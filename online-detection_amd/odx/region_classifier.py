@@ -63,6 +63,7 @@ class OnlineRegionClassifierBase:
         self.normalized = False
         self.is_segmentation = is_segmentation
         self.return_caches = False
+        self.class_streams = 0          # > 0: classes trained concurrently on that many streams (opts['class_streams'])
 
     def loadRegionClassifier(self) -> None:
         pass
@@ -78,6 +79,8 @@ class OnlineRegionClassifierBase:
                 self.return_caches = opts['return_caches']
             if 'normalized' in opts:
                 self.normalized = opts['normalized']
+            if 'class_streams' in opts:
+                self.class_streams = int(opts['class_streams'])
 
     def updateModel(self, cache):
         X_neg, X_pos = cache['neg'], cache['pos']
@@ -149,6 +152,83 @@ class OnlineRegionClassifierBase:
             self.caches = caches
         return model
 
+    def trainWithMinibootstrapStreams(self, negatives, positives, output_dir=None):
+        """The same per-class state machine with the classes advancing together, one negative batch at a time, their
+        fits and predictions issued on `class_streams` HIP streams (opt-in: opts['class_streams'] = k, in-core only).
+        A fit of the reference regime (M ~ 2000, n ~ 1e4) is a chain of ~ 400 small dependent kernels that leaves
+        most of the chip idle; classes are independent, so their chains overlap.  The host synchronises per class only
+        where the sizes of the next step depend on scores (hard / easy negative selection).
+
+        What differs from trainWithMinibootstrap: the order in which the global torch RNG would be consumed.  The
+        reference draws Nystroem centres class by class (all batches of class 0, then class 1, ...), and whether a fit
+        draws at all depends on the outcome of the previous pruning, so that order cannot be kept while classes overlap.
+        This mode takes ONE draw from the global stream and gives class c its own mt19937 stream seeded from it: every
+        class sees the same rule (FALKONWrapper.compute_indices_selection) with independent draws; results do not depend
+        on the number of streams."""
+        from . import solver
+        C = self.num_classes - 1
+        k = max(1, int(self.class_streams))
+        main = torch.cuda.current_stream()
+        streams = [torch.cuda.Stream() for _ in range(k)]
+        for s in streams:
+            s.wait_stream(main)
+        seed0 = int(torch.randint(2 ** 62, (1,)).item())
+        active = [i for i in range(C) if len(positives[i]) != 0 and len(negatives[i]) != 0]
+        rng = {i: torch.Generator().manual_seed(seed0 + i).get_state() for i in active}
+        caches, model = [{} for _ in range(C)], [None] * C
+        t_start = time.time()
+        nb = max([len(negatives[i]) for i in active] or [0])
+        for j in range(nb):
+            todo = [i for i in active if j < len(negatives[i])]
+            scores = {}
+            if j > 0:
+                for i in todo:
+                    with torch.cuda.stream(streams[i % k]):
+                        scores[i] = self.classifier.predict(model[i], negatives[i][j])
+            with solver.deferred_pivot_checks():
+                for i in todo:
+                    with torch.cuda.stream(streams[i % k]):
+                        if j == 0:
+                            caches[i] = {'pos': positives[i], 'neg': negatives[i][0]}
+                        else:
+                            hard_idx = torch.where(scores[i] > self.hard_tresh)[0]
+                            caches[i]['neg'] = torch.cat((caches[i]['neg'], negatives[i][j][hard_idx]), 0)
+                            print('Class {}: chosen {} hard negatives from the {}th batch'.format(i, len(hard_idx), j))
+                        print('Class {}: traning with {} positives and {} negatives'.format(
+                            i, len(caches[i]['pos']), len(caches[i]['neg'])))
+                        with torch.random.fork_rng(devices=[]):
+                            torch.set_rng_state(rng[i])
+                            model[i] = self.updateModel(caches[i])
+                            rng[i] = torch.get_rng_state()
+            prune = [i for i in todo if len(caches[i]['neg']) != 0 and j != len(negatives[i]) - 1]
+            for i in prune:
+                with torch.cuda.stream(streams[i % k]):
+                    scores[i] = self.classifier.predict(model[i], caches[i]['neg'])
+            for i in prune:
+                with torch.cuda.stream(streams[i % k]):
+                    keep_idx = torch.where(scores[i] >= self.easy_tresh)[0]
+                    removed = len(caches[i]['neg']) - len(keep_idx)
+                    caches[i]['neg'] = caches[i]['neg'][keep_idx]
+                    print('Class {}: removed {} easy negatives. {} Remaining'.format(i, removed, len(caches[i]['neg'])))
+        for s in streams:
+            main.wait_stream(s)
+        for i in active:                      # made on a side stream, used from here on by the caller's stream
+            for t in (model[i].alpha_, model[i].ny_points_) + (tuple(caches[i].values()) if self.return_caches else ()):
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(main)
+            if not self.return_caches:
+                caches[i] = None
+        training_time = time.time() - t_start
+        print('Online Classifier trained in {} seconds'.format(training_time))
+        if output_dir:
+            head = ("RPN's Online Classifier training time" if self.is_rpn else
+                    "Online Segmentation training time" if self.is_segmentation else "Detector's Online Classifier training time")
+            with open(os.path.join(output_dir, "result.txt"), "a") as fid:
+                fid.write("{}: {}min:{}s \n".format(head, int(training_time / 60), round(training_time % 60)))
+        if self.return_caches:
+            self.caches = caches
+        return model
+
     def trainRegionClassifier(self, opts=None, output_dir=None):
         if opts is not None:
             self.processOptions(opts)
@@ -165,7 +245,10 @@ class OnlineRegionClassifierBase:
                     if len(negatives[i][j]):
                         negatives[i][j] = self.zScores(negatives[i][j])
             self.normalized = True
-        model = self.trainWithMinibootstrap(negatives, positives, output_dir=output_dir)
+        if self.incore and self.class_streams > 0 and torch.cuda.is_available():
+            model = self.trainWithMinibootstrapStreams(negatives, positives, output_dir=output_dir)
+        else:
+            model = self.trainWithMinibootstrap(negatives, positives, output_dir=output_dir)
         if self.incore and self.return_caches:
             return model, self.caches
         return model

@@ -24,6 +24,35 @@ class SolverOptions:
     check_pivots: bool = True           # one host sync after the fit to report a failed Cholesky
 
 
+_DEFERRED = None     # while a deferred_pivot_checks() block is open: the (backend, info) pairs still to be looked at
+
+
+class deferred_pivot_checks:
+    """Fits issued inside the block do not synchronise with the host to look at their Cholesky status; every status is
+    checked when the block closes.  Lets the host enqueue several independent fits (on several streams) back to back."""
+
+    def __enter__(self):
+        global _DEFERRED
+        self._prev, self.items = _DEFERRED, []
+        _DEFERRED = self.items
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        global _DEFERRED
+        _DEFERRED = self._prev
+        if exc_type is None:
+            for be, info in self.items:
+                be.check_info(info)
+        return False
+
+
+def _check_pivots(be, P):
+    if _DEFERRED is not None and hasattr(be, "check_info") and hasattr(P, "info"):
+        _DEFERRED.append((be, P.info))
+    else:
+        be.check_precond(P)
+
+
 class _NoPhase:
     def __enter__(self):
         return self
@@ -124,7 +153,7 @@ def falkon_fit(be, F, y, Zf, sigma, lam, maxiter=20, opt=None, n_total=None, all
     if owned:
         be.trmv(P, "LTit", be.trmv(P, "LAit", X), out=alpha)   # T^-1 A^-1 beta
         if opt.check_pivots:
-            be.check_precond(P)
+            _check_pivots(be, P)
     bcast(alpha)
     if return_knm:
         return alpha, K
@@ -221,6 +250,6 @@ def falkon_fit_lockstep(be, F, ys, Zfs, sigma, lam, maxiter=20, opt=None, n_tota
     if owned:
         be.trmv(P, "LTit", be.trmv(P, "LAit", X), out=t)
         if opt.check_pivots:
-            be.check_precond(P)
+            _check_pivots(be, P)
     shard.gather_rows(tbuf, Tall)
     return [Tall[b, :M].clone() for b in range(B)]

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--positives", type=int, default=800)
     ap.add_argument("--sigma", type=float, default=15.0)
+    ap.add_argument("--streams", type=int, default=0, help="opts['class_streams']: classes trained concurrently (0 = reference order)")
     args = ap.parse_args()
     C, D, IT = args.classes, args.dim, args.iters
     names = ["_background_"] + ["c%d" % i for i in range(C)]
@@ -60,12 +61,12 @@ def main():
             orc = orc_mod.OnlineRegionClassifier(clf, pos, neg, stats, cfg_path=path)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            models = orc.trainRegionClassifier()
+            models = orc.trainRegionClassifier(opts={"class_streams": args.streams} if args.streams else None)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         fits = sum(1 for m in models if m is not None) * IT
-        print("rep %d: %d classes x %d batches (D = %d, M = 2000, %d positives): %.2f s = %.1f ms per (class, batch) "
-              "[1 fit + 2 predicts + cache bookkeeping]" % (rep, C, IT, D, args.positives, dt, dt / fits * 1e3))
+        print("rep %d: %d classes x %d batches (D = %d, M = 2000, %d positives, class_streams = %d): %.2f s = %.1f ms per (class, batch) "
+              "[1 fit + 2 predicts + cache bookkeeping]" % (rep, C, IT, D, args.positives, args.streams, dt, dt / fits * 1e3))
     # the 30 box regressors on 1e4 rows per class
     n = 10000 * C
     COXY = {"C": (torch.arange(n, device="cuda") % C + 1).float().reshape(-1, 1), "X": torch.randn((n, D), device="cuda", generator=g),
