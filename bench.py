@@ -48,10 +48,10 @@ def parse():
     ap.add_argument("--lam", type=float, default=1e-5)
     ap.add_argument("--maxiter", type=int, default=20)
     ap.add_argument("--warmup-classes", type=int, default=2, help="classes run per warm-up step")
-    ap.add_argument("--precond-depth", type=int, default=0, help="batches of preconditioners in flight ahead of the fit (default 3)")
+    ap.add_argument("--precond-depth", type=int, default=0, help="batches of preconditioners in flight ahead of the fit (default 2)")
     ap.add_argument("--reserve-cus", type=int, default=0, help="CUs the persistent pass kernel leaves to the side streams")
-    ap.add_argument("--precond-before-fit", dest="precond_after_fit", action="store_false",
-                    help="issue the look-ahead preconditioner before the batch's fit instead of behind its CG")
+    ap.add_argument("--precond-behind-cg", dest="precond_after_fit", action="store_true",
+                    help="issue the look-ahead preconditioner behind the batch's CG instead of before its fit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0 = pick by host core count")
     ap.add_argument("--check", action="store_true", help="verify one class against the oracle on a row sample")
@@ -189,16 +189,16 @@ def main():
     # Preconditioners are built `depth` batches ahead, each on its own side stream with its own output slot and
     # scratch, so the chains of small latency-bound factorisation kernels fill gaps of the main stream.  (Measured on
     # one GPU: depth 1, 2, 3 within 1 % of each other — what the factorisations cost is CU time, not latency.)
-    depth = args.precond_depth if args.precond_depth > 0 else 3
-    # Scheduling of the look-ahead preconditioners (chains of ~1500 small f64 kernels, ~57 ms alone) against the main
-    # stream, measured on one GPU at the headline size (s per step | pass rate in the timed region):
-    #   issued before the batch's fit, depth 1, passes on all CUs          9.73-9.98 | 5.8-6.1 TB/s  (the persistent pass
-    #       kernel holds every CU 6.5 ms at a time, the chain stands still through the CG and the fit waits for it)
-    #   same, pass kernel leaves 32 CUs free (--precond-before-fit --reserve-cus 32 --precond-depth 1)
-    #                                                                        9.36-9.60 | 5.0-5.3 TB/s
-    #   issued behind the batch's CG (runs beside the MFMA-bound scoring / next build), depth 1    9.93 | 6.2 TB/s
-    #   issued behind the CG, depth 3 (default)                              9.66-9.71 | 5.8-5.9 TB/s
-    # The default keeps the HBM-bound passes (the dominant kernel) close to their own rate at 1-3 % of whole-job time.
+    depth = args.precond_depth if args.precond_depth > 0 else 2
+    # Scheduling of the look-ahead preconditioners (chains of ~1500 small f64 kernels, ~57 ms alone, each chain with its own
+    # pair of helper streams) against the main stream.  The main stream is busy 99 % of the time, so whatever the schedule
+    # the preconditioners' MFMA work (~30 ms per class) is paid somewhere; measured on one GPU at the headline size, three
+    # runs each on the same box (s per step):
+    #   issued before the batch's fit, 2 batches ahead (default)                     8.68-8.71
+    #   issued before the batch's fit, 3 batches ahead                               8.88
+    #   issued behind the batch's CG, 2 / 3 batches ahead (--precond-behind-cg)      8.96 / 9.09
+    #   issued before the fit, 1 batch ahead                                         8.97
+    #   (helper streams shared by all chains, behind the CG, 3 ahead: 8.84-8.87; --reserve-cus 16 / 32 change < 1 %)
     be.reserve_cus_during_passes(args.reserve_cus)
     nslot = depth + 1
     sides = [torch.cuda.Stream() for _ in range(nslot)]

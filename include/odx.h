@@ -160,6 +160,19 @@ int odx_cg_finish(const double* R, double* P, double* state, double cg_eps, doub
 /* y = a*x + b*y (f64), used for R = B - mmv(X) */
 int odx_axpby_f64(double a, const double* x, double b, double* y, int64_t M, odx_stream_t stream);
 
+/* The whole CG loop of one unsharded fit as a single call (the launches above in falkon's order; see
+ * online-detection_amd/odx/solver.py for the same loop statement by statement, which is also the form used when rows are
+ * sharded and a collective sits inside every iteration):
+ *   B = A^-T T^-T b0;  maxiter x { AP = A^-T[T^-T K'K(T^-1 A^-1 P)/n_total + lam A^-1 P]; step; (every
+ *   full_gradient_every-th: R = B - mmv(X)); finish };  alpha = T^-1 A^-1 X.
+ * K: the stored n x M f32 block; LTi / LTit / LAi / LAit: the four inverse factors of odx_falkon_precond_f64 (ld = ldp);
+ * b0 = K'(y / n_total) (M, f64: odx_gauss_knm_h2_rhs or odx_knm_fwd_bwd with w); alpha: M f64 out. */
+int64_t odx_falkon_cg_workspace_bytes(int64_t n, int64_t M);
+int odx_falkon_cg_f64(const float* K, int64_t ldk, int64_t n, int64_t M, const double* LTi, const double* LTit,
+                      const double* LAi, const double* LAit, int64_t ldp, const double* b0, double n_total,
+                      double lam, int maxiter, int full_gradient_every, double cg_epsilon, double cg_tolerance,
+                      double* alpha, void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+
 /* ---------------------------------------------------------------- dense f64 building blocks
  * (exported for the parity tests and for the RLS path)                                   */
 /* C (m x n) = alpha * A (m x k) B' (n x k) + beta * C ; flags below */

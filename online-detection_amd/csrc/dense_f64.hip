@@ -3,6 +3,7 @@
 // The O(M^3) work runs as NT GEMMs on v_mfma_f64_16x16x4_f64 (gemm.hip); only the 128 x 128
 // diagonal blocks are factored / inverted by a single workgroup inside LDS.
 #include "odx_internal.h"
+#include <vector>
 
 namespace odx {
 
@@ -505,14 +506,30 @@ struct SideStream {
   int device = -1;
 };
 
-// Internal helper streams (per host thread and device): slot 0 forks the inverse of L_T inside the preconditioner,
-// slot 1 carries the look-ahead trailing updates of potrf_f64.  Everything is ordered with events; the host never waits.
-static int side_stream(SideStream** out, int slot = 0) {
-  static thread_local SideStream ss[16][2];
+// Internal helper streams, a pair per (host thread, device, calling stream): slot 0 forks the inverse of L_T inside the
+// preconditioner, slot 1 carries the look-ahead trailing updates of potrf_f64.  Keyed by the calling stream so that
+// factorisations issued on different streams (classes trained side by side) do not queue behind each other on one
+// helper.  Everything is ordered with events; the host never waits.
+static int side_stream(SideStream** out, int slot, hipStream_t caller) {
+  struct Entry {
+    int device;
+    hipStream_t caller;
+    SideStream ss[2];
+  };
+  static thread_local std::vector<Entry*> pool;
   int dev = 0;
   ODX_CHECK_HIP(hipGetDevice(&dev));
-  ODX_REQUIRE(dev >= 0 && dev < 16 && slot >= 0 && slot < 2, "side_stream: device index out of range");
-  SideStream& s = ss[dev][slot];
+  ODX_REQUIRE(slot >= 0 && slot < 2, "side_stream: bad slot");
+  Entry* e = nullptr;
+  for (Entry* c : pool)
+    if (c->device == dev && c->caller == caller) e = c;
+  if (e == nullptr) {
+    e = new Entry();
+    e->device = dev;
+    e->caller = caller;
+    pool.push_back(e);
+  }
+  SideStream& s = e->ss[slot];
   if (s.stream == nullptr) {
     if (slot == 1) {
       // The look-ahead updates are bulk work that must not starve the latency-bound chain they overlap with: lowest
@@ -548,7 +565,7 @@ int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hi
   ODX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     TS_LDS_BYTES));
   SideStream* look = nullptr;
-  ODX_PROPAGATE(side_stream(&look, 1));
+  ODX_PROPAGATE(side_stream(&look, 1, stream));
   bool pending = false;      // a trailing update is in flight on the helper stream
   for (int64_t K0 = 0; K0 < M; K0 += POTRF_NBO) {
     const int64_t kbo = M - K0 < POTRF_NBO ? M - K0 : POTRF_NBO;
@@ -763,7 +780,7 @@ extern "C" int odx_falkon_precond_f64(const float* Z, int64_t ldz, int64_t M, in
   }
   hipStream_t s = as_stream(stream);
   SideStream* side = nullptr;
-  ODX_PROPAGATE(side_stream(&side));
+  ODX_PROPAGATE(side_stream(&side, 0, s));
   hipStream_t s2 = side->stream;
   const int64_t wld = precond_ld(M), ldzd = round_up(D, 2);
   const int64_t dsz = ceil_div(M, POTRF_NB) * POTRF_NB * POTRF_NB;

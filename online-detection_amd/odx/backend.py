@@ -224,6 +224,19 @@ class HipBackend:
                                            self._stream()), "odx_knm_fwd_bwd")
         return out
 
+    def cg_solve(self, K, P, b0, n_total, lam, maxiter, opt):
+        """The CG loop of an unsharded fit in one library call (odx_falkon_cg_f64); returns alpha (M,) f64."""
+        alpha = torch.empty(K.M, dtype=torch.float64, device=self.device)
+        nbytes = self.lib.odx_falkon_cg_workspace_bytes(max(K.n, 1), K.M)
+        if nbytes < 0:
+            raise hip.OdxError("odx_falkon_cg_f64: M = %d is outside the supported range" % K.M)
+        ws = self._workspace("cg_solve", nbytes)
+        hip.check(self.lib.odx_falkon_cg_f64(_p(K.K), K.ld, K.n, K.M, _p(P.LTi), _p(P.LTit), _p(P.LAi), _p(P.LAit), P.ld, _p(b0),
+                                             float(n_total), float(lam), int(maxiter), int(opt.cg_full_gradient_every),
+                                             float(opt.cg_epsilon), float(opt.cg_tolerance), _p(alpha), _p(ws), ws.numel(),
+                                             self._stream()), "odx_falkon_cg_f64")
+        return alpha
+
     _TRI = {"LTi": 0, "LTit": 1, "LAi": 0, "LAit": 1}
 
     def trmv(self, P, name, x, alpha=1.0, beta=0.0, z=None, out=None):

@@ -127,6 +127,16 @@ def falkon_fit(be, F, y, Zf, sigma, lam, maxiter=20, opt=None, n_total=None, all
             be.trmv(P, "LAi", u, out=out)              # A^-T u
 
     b0 = ar(b0)                                        # K' (y / n), summed over shards
+    if shard is None and allreduce is None and phase is None and hasattr(be, "cg_solve"):
+        # one shard, nothing to time per kernel family: the loop below as one library call (odx_falkon_cg_f64)
+        if precond_ready is not None:
+            precond_ready()
+        alpha = be.cg_solve(K, P, b0, n, lam, maxiter, opt)
+        if opt.check_pivots:
+            _check_pivots(be, P)
+        if return_knm:
+            return alpha, K
+        return alpha
     X, R, Pv, AP = be.zeros(M), be.zeros(M), be.zeros(M), be.zeros(M)
     state = be.zeros(4)
     if owned:

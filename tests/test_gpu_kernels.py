@@ -451,3 +451,26 @@ def test_gauss_random_shapes_stay_inside_their_buffers(be, gauss):
         wants = ref @ V
         assert np.abs(out.cpu().numpy() - wants).max() < 5e-5 * max(1.0, np.abs(wants).max()), (case, n, M, D, T)
         assert torch.isnan(sbuf[n * T:]).all()
+
+
+@pytest.mark.parametrize("n,M,D,maxiter", [(3000, 300, 256, 20), (700, 129, 36, 7), (5000, 1000, 64, 25)])
+def test_cg_loop_in_one_call_equals_the_loop_issued_from_python(be, n, M, D, maxiter):
+    """odx_falkon_cg_f64 (what an unsharded fit runs) against the statement-by-statement loop of odx/solver.py (what
+    sharded fits run, forced here by passing a phase hook): the same launches in the same order, so the same bits."""
+    import odx
+    from tests.synth import blob_problem, centres
+
+    class Null:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    X, y, rng = blob_problem(n, D, seed=n + M)
+    idx = centres(y, M, rng)
+    F = be.features(torch.from_numpy(X))
+    Zf = be.rows(F, idx)
+    a = odx.falkon_fit(be, F, be.vec(y), Zf, 10.0, 1e-5, maxiter)
+    b = odx.falkon_fit(be, F, be.vec(y), Zf, 10.0, 1e-5, maxiter, phase=lambda name: Null())
+    assert torch.equal(a, b)

@@ -62,11 +62,12 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             models = orc.trainRegionClassifier(opts={"class_streams": args.streams} if args.streams else None)
+            t_host = time.perf_counter() - t0
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         fits = sum(1 for m in models if m is not None) * IT
         print("rep %d: %d classes x %d batches (D = %d, M = 2000, %d positives, class_streams = %d): %.2f s = %.1f ms per (class, batch) "
-              "[1 fit + 2 predicts + cache bookkeeping]" % (rep, C, IT, D, args.positives, args.streams, dt, dt / fits * 1e3))
+              "[1 fit + 2 predicts + cache bookkeeping]; host returned after %.2f s" % (rep, C, IT, D, args.positives, args.streams, dt, dt / fits * 1e3, t_host))
     # the 30 box regressors on 1e4 rows per class
     n = 10000 * C
     COXY = {"C": (torch.arange(n, device="cuda") % C + 1).float().reshape(-1, 1), "X": torch.randn((n, D), device="cuda", generator=g),
