@@ -398,7 +398,12 @@ def test_headline_shape_one_class(be):
     assert float((parts - full).abs().max()) <= 1e-11 * float(full.abs().max())
     lin = be.ktk(K, v=v1 + 2.0 * v2) - (full + 2.0 * be.ktk(K, v=v2))
     assert float(lin.abs().max()) <= 1e-11 * float(full.abs().max())
-    # (d) the fit repeats bit for bit at this size too
+    # (d) the right-hand side the build kernel leaves behind = one pass over the block it stored
+    yn = y * (1.0 / n)
+    K2, b0 = be.knm_rhs(F, Zf, sigma, yn, out=K.K.view(-1))
+    b0_pass = be.ktk(K2, w=yn)
+    assert float((b0 - b0_pass).abs().max()) <= 1e-12 * max(1.0, float(b0_pass.abs().max())) * 1e3
+    # (e) the fit repeats bit for bit at this size too
     alpha2 = odx.falkon_fit(be, F, y, Zf, sigma, lam, 20, knm_out=K.K.view(-1))
     assert torch.equal(alpha, alpha2)
 
