@@ -154,25 +154,59 @@ class DetectorHarvester:
         if not self.shuffle_negatives:
             self._fill_batches(x, overlap, gt_labels_list)
         else:
-            for i in range(self.num_classes):
-                neg_i = self._sample_negatives(x, overlap, i, gt_labels_list)
+            classes = list(range(self.num_classes))
+            feats_all, lens = self._sample_all(x, overlap, classes, gt_labels_list)
+            at = 0
+            for i, n_i in zip(classes, lens):
                 last = self._neg[i][-1]
-                last.append(neg_i)
+                last.append(feats_all[at:at + n_i])
+                at += n_i
                 if last.n >= self.batch_size:
                     self._neg[i].append(_Growing(self.D, self.device, cap=self.batch_size))
 
-    def _sample_negatives(self, x, overlap, i, gt_labels_list):
-        if i + 1 not in gt_labels_list:
-            return x[torch.randint(x.size(0), (self.negatives_to_pick,))].view(-1, self.D)
-        neg_i = x[overlap[:, i] < self.neg_iou_thresh].view(-1, self.D)
-        if neg_i.size(0) > 0:
-            neg_i = neg_i[torch.randint(neg_i.size(0), (self.negatives_to_pick,))].view(-1, self.D)
-        return neg_i
+    def _sample_all(self, x, overlap, classes, gt_labels_list):
+        """The negatives of one image for every class of `classes`, in that order, with one gather
+        (box_head_getProposals.py:213-222 per class): returns the sampled rows of
+        all classes back to back and the number of rows of each.  The draws come from the global RNG class by class as
+        in the reference (one randint per class: over all R rows for a class that is not in the image, over its
+        candidates — rows overlapping its boxes by less than NEG_IOU_THRESH — for a class that is, none when it has no
+        candidate); only the classes present in the image need anything read back from the device (their counts)."""
+        k = self.negatives_to_pick
+        present = [i for i in classes if i + 1 in gt_labels_list]
+        cand, counts = {}, {}
+        if present:
+            masks = overlap[:, present] < self.neg_iou_thresh                               # (R, len(present))
+            for i, c in zip(present, masks.sum(0).tolist()):
+                counts[i] = c
+            for j, i in enumerate(present):
+                cand[i] = torch.nonzero(masks[:, j]).reshape(-1)
+        host_picks, plan, lens = [], [], []
+        for i in classes:
+            if i in counts:
+                if counts[i] > 0:
+                    plan.append(("dev", i, torch.randint(counts[i], (k,))))
+                    lens.append(k)
+                else:
+                    lens.append(0)
+            else:
+                p = torch.randint(x.size(0), (k,))
+                plan.append(("host", len(host_picks), None))
+                host_picks.append(p)
+                lens.append(k)
+        if not plan:
+            return torch.empty((0, self.D), dtype=x.dtype, device=x.device), lens
+        hp = torch.stack(host_picks).to(x.device) if host_picks else None                  # one copy for all absent classes
+        parts = [hp[j] if kind == "host" else cand[j][p.to(x.device)] for kind, j, p in plan]
+        return x[torch.cat(parts)].view(-1, self.D), lens
 
     def _fill_batches(self, x, overlap, gt_labels_list):
         done = []
-        for i in self.still_to_complete:
-            neg_i = self._sample_negatives(x, overlap, i, gt_labels_list)
+        classes = list(self.still_to_complete)
+        feats_all, lens = self._sample_all(x, overlap, classes, gt_labels_list)
+        at = 0
+        for i, n_i in zip(classes, lens):
+            neg_i = feats_all[at:at + n_i]
+            at += n_i
             per_batch = math.ceil(self.negatives_to_pick / self.iterations)
             taken = 0
             for b in range(self.current_batch[i], self.iterations):
@@ -293,15 +327,35 @@ class RPNHarvester:
             ious = ious.reshape(-1)
             assoc = gt[0].expand(self.anchors.shape[0], 4)
         neg_mask = ious < self.neg_iou_thresh
-        types = self.still_to_complete if not self.shuffle_negatives else range(self.A)
+        types = list(self.still_to_complete if not self.shuffle_negatives else range(self.A))
+        # All anchor types at once on the device: candidates per type counted in one reduction (one host read), the
+        # candidates ordered by type with a stable sort (ascending anchor index inside a type, as torch.nonzero gives
+        # them), one gather of the sampled anchors' features.  What stays on the host is what the reference fixes there:
+        # the with-replacement draws, type by type from the global RNG, and the bookkeeping of the open batches.
+        counts = (neg_mask[:, None] & (self.cls[:, None] == torch.arange(self.A, device=t.device)[None, :])).sum(0).tolist()
+        order = torch.argsort(torch.where(neg_mask, self.cls, torch.full_like(self.cls, self.A)), stable=True)
+        starts, acc = [], 0
+        for c in counts:
+            starts.append(acc)
+            acc += c
+        picks, lens = [], []
+        for i in types:
+            c = counts[i]
+            p = torch.randint(c, (self.negatives_to_pick,)) if c > self.negatives_to_pick else torch.arange(c)
+            picks.append(p + starts[i])
+            lens.append(p.numel())
+        if picks and sum(lens):
+            feats_all = self._gather(t, order[torch.cat(picks).to(t.device)])
+        else:
+            feats_all = torch.empty((0, self.D), dtype=t.dtype, device=t.device)
         done = []
-        for i in list(types):
-            cand = torch.nonzero(neg_mask & (self.cls == i)).reshape(-1)
-            if cand.numel() > self.negatives_to_pick:
-                cand = cand[torch.randint(cand.numel(), (self.negatives_to_pick,)).to(cand.device)]
+        at = 0
+        for i, n_i in zip(types, lens):
+            feat_i = feats_all[at:at + n_i]
+            at += n_i
             if self.shuffle_negatives:
                 last = self._neg[i][-1]
-                last.append(self._gather(t, cand))
+                last.append(feat_i)
                 if last.n >= self.batch_size:
                     self._neg[i].append(_Growing(self.D, self.device, cap=self.batch_size))
                 continue
@@ -314,8 +368,8 @@ class RPNHarvester:
                     if self.current_batch[i] >= self.iterations:
                         done.append(i)
                     continue
-                end = int(taken + min(per_batch, self.batch_size - cur.n, self.negatives_to_pick - taken, cand.numel() - taken))
-                cur.append(self._gather(t, cand[taken:end]))
+                end = int(taken + min(per_batch, self.batch_size - cur.n, self.negatives_to_pick - taken, n_i - taken))
+                cur.append(feat_i[taken:end])
                 taken = end
                 if taken == self.negatives_to_pick:
                     break
