@@ -12,6 +12,10 @@ matrix (RCCL).  N is the job size at every GPU count => "scaling": "strong".
     python bench.py [--gpus N --steps K --warmup W] [--rows 1000000 --dim 1024 --centres 10000 --classes 30]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself: the parent touches no
+GPU, runs `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child process, relays rank 0's JSON line
+and exits with the child's status (no retry).
+
 Rank 0 prints ONE JSON line (contract in the round prompt).  Inputs are resident in HBM before
 the timed region.  `roofline` is measured live with HIP events around the dominant kernel's
 launches; `cpu_baseline` times the numpy oracle on the host cores on a bounded sample.
@@ -53,6 +57,7 @@ def parse():
     ap.add_argument("--precond-behind-cg", dest="precond_after_fit", action="store_true",
                     help="issue the look-ahead preconditioner behind the batch's CG instead of before its fit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the rls / forward / minibootstrap extra keys (N = 1 only)")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0 = pick by host core count")
     ap.add_argument("--check", action="store_true", help="verify one class against the oracle on a row sample")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only for the "
@@ -137,19 +142,64 @@ class Phase:
         self.pairs = []
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as ONE child process tree
+    (python -m torch.distributed.run, one process per GPU) and relay rank 0's JSON line.  This parent never
+    initialises the GPU (no HIP call before or after the child), never execs, never retries: the child's exit status
+    is this process's exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out                       # rank 0's result: printed last, alone on stdout
+        elif out:
+            print(out, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc != 0:
+        print("bench.py: the %d-rank child exited with status %d" % (args.gpus, rc), file=sys.stderr)
+        sys.exit(rc if 0 < rc < 256 else 1)
+    if line is None:
+        print("bench.py: the ranks printed no result line", file=sys.stderr)
+        sys.exit(1)
+    print(line, flush=True)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and rank == 0:       # under a launcher the launcher decides; the line reports what ran
+        print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; running %d" % (args.gpus, world, world),
+              file=sys.stderr)
     if world > 1:
         torch.cuda.set_device(0 if args.single_device else local_rank)
         dist.init_process_group(backend=args.dist_backend, init_method="env://")
     else:
         torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
     device = torch.device("cuda", torch.cuda.current_device())
+    # the rank count the result line reports is the one a real collective saw, not an argument echoed back
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, dtype=torch.float64, device=device)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(one.item())))
+        if ranks_seen != dist.get_world_size():
+            print("bench.py: all-reduce saw %d ranks, world size is %d" % (ranks_seen, dist.get_world_size()), file=sys.stderr)
+            sys.exit(3)
 
     import odx
     from odx.backend import Features
@@ -170,7 +220,8 @@ def main():
     ldk = (M + 3) // 4 * 4
     kbufs = [torch.empty(n_loc * ldk, dtype=torch.float32, device=device) for _ in range(world)]   # N x M f32 per GPU in all
     scores = torch.empty((n_loc, C), dtype=torch.float32, device=device)
-    opt = SolverOptions(check_pivots=False)
+    opt = SolverOptions(check_pivots=False)       # no host sync inside the timed region: every status is read after it
+    infos = []                                    # Cholesky status words of every preconditioner built in the timed region
     ph = {k: Phase() for k in ("knm", "ktk", "precond", "mmv")}
 
     def gather_centres(idx):
@@ -218,6 +269,8 @@ def main():
                     P = be.precond(Zs[rank], args.sigma, args.lam, opt.pc_epsilon, out=pbuf[slot], ws_key="precond%d" % slot)
                 ev = torch.cuda.Event()
                 ev.record(side)
+            if timed:
+                infos.append(P.info)
         return Zs, P, ev
 
     def run_classes(classes, timed):
@@ -293,6 +346,16 @@ def main():
     ms_per_step = dt * 1e3 / args.steps
     value = N * args.steps / dt
 
+    # ---- health of what was timed (outside the timing): no failed Cholesky, every score finite, on every rank
+    bad_pivots = int(sum(int(i.item() != 0) for i in infos))
+    finite = bool(torch.isfinite(scores).all().item())
+    hl = torch.tensor([bad_pivots, 0 if finite else 1], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(hl, op=dist.ReduceOp.SUM)
+    health = {"failed_choleskys": int(hl[0].item()), "ranks_with_nonfinite_scores": int(hl[1].item()),
+              "preconditioners_checked_rank0": len(infos)}
+    healthy = health["failed_choleskys"] == 0 and health["ranks_with_nonfinite_scores"] == 0
+
     if rank == 0:
         # dominant kernel family: the Gaussian MFMA contraction (K_nM build + fused scoring)
         gauss_ms = ph["knm"].total_ms() + ph["mmv"].total_ms()
@@ -336,7 +399,7 @@ def main():
         phases["gauss_TFLOPs"] = round(flops_per_launch * gauss_launches / max(gauss_ms * 1e-3, 1e-9) / 1e12, 2)
         out = {
             "metric": "FALKON fit+infer samples/sec (N=1e6 D=1024 M=1e4)",
-            "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 1), "unit": "samples/s", "n_gpus": ranks_seen, "ranks": ranks_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": ("f32 K_nM (X Z' as a two-term f16 split on the f16 MFMA, f32 accumulate) + f64 solver" if be.gauss == "h2"
                                                         else "f32 K_nM (f32-input MFMA) + f64 solver"),
@@ -348,15 +411,28 @@ def main():
             "roofline": roof,
             "roofline_second_family": roof2,
             "phases_ms_per_step_rank0": phases,
+            "health": health,
         }
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args)
         if args.check:
             out["check"] = check_against_oracle(be, F, last, X, row_ids, args, C - 1)
+        if not args.no_extras and world == 1:
+            # the other halves of BASELINE configs 2 and 3 (RLS regressors, feature forward) and the reference-regime
+            # minibootstrap: measured after and outside the timed headline region, with its buffers released first
+            del kbufs[:], pbuf[:]
+            last = F = X = scores = None
+            be.release_workspaces()
+            torch.cuda.empty_cache()
+            from tools import bench_extras
+            out.update(bench_extras.collect(args))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if not healthy:
+        print("bench.py: unhealthy run: %s" % json.dumps(health), file=sys.stderr)
+        sys.exit(4)
 
 
 class _null:
@@ -368,21 +444,32 @@ class _null:
 
 
 def profiled_traffic_gb(kernel_names):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc_*: the
-    counters cannot be read from inside this process): FETCH_SIZE (KiB, doubled per the gfx950 correction of the
-    guide) + WRITE_SIZE (KiB), averaged over the profiled launches at this same shard shape.  None if absent."""
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes
+    (profiles/rNN_pmc_*: the counters cannot be read from inside this process): FETCH_SIZE (KiB, doubled per the gfx950
+    correction of the guide) + WRITE_SIZE (KiB), median over the profiled launches at this same shard shape.  The file
+    stem the number came from is named in the unit string.  None if absent."""
     import csv
-    tot, found = 0.0, False
-    for counter, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
-        path = os.path.join(ROOT, "profiles", "r01_pmc_%s_counter_collection.csv" % counter)
-        if not os.path.exists(path):
-            return None, None
-        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-                if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in kernel_names.split("+"))]
-        if vals:
-            found = True
-            tot += mult * 1024.0 * sum(vals) / len(vals)
-    return (round(tot / 1e9, 2), "GB per launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE (profiles/r01_pmc_*)") if found else (None, None)
+    import glob
+    import re
+    import statistics
+    stems = sorted({re.match(r"(r\d+)_pmc_", os.path.basename(f)).group(1)
+                    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*_counter_collection.csv"))
+                    if re.match(r"r\d+_pmc_", os.path.basename(f))})
+    for stem in reversed(stems):
+        tot, found = 0.0, 0
+        for counter, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+            path = os.path.join(ROOT, "profiles", "%s_pmc_%s_counter_collection.csv" % (stem, counter))
+            if not os.path.exists(path):
+                break
+            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+                    if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in kernel_names.split("+"))]
+            if vals:
+                found += 1
+                tot += mult * 1024.0 * statistics.median(vals)
+        if found == 2:
+            return round(tot / 1e9, 2), ("GB per launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, from the committed "
+                                         "profiles/%s_pmc_* (not measured in this run)" % stem)
+    return None, None
 
 
 def cpu_baseline(args):

@@ -10,9 +10,11 @@
  *   - asynchronous on `stream` (a hipStream_t passed as void*); no allocation, no sync;
  *     workspace sizes come from the *_workspace_bytes twins;
  *   - one host thread per device.
- * Precision policy: the n x M Gaussian block K_nM is formed and stored in
- * f32 (f32-input MFMA, exact fmaf chain); everything M x M and every M-vector, including
- * the accumulations inside the K_nM passes, is f64.
+ * Precision policy: the n x M Gaussian block K_nM is formed at f32 accuracy and
+ * stored in f32 — by default on the f16 matrix cores through a two-term f16 split of every f32
+ * operand value (odx_gauss_*_h2, v_mfma_f32_16x16x32_f16 with f32 accumulation), alternatively
+ * on the f32-input MFMA (odx_gauss_*_f32, exact fmaf chain); everything M x M and every
+ * M-vector, including the accumulations inside the K_nM passes, is f64.
  */
 #ifndef ODX_H
 #define ODX_H
@@ -67,7 +69,7 @@ int odx_gauss_mmv_f32(const float* X, int64_t ldx, const float* xsq, int64_t n,
 
 /* ---------------------------------------------------------------- A3 / A5 on the f16 matrix cores
  * The same two operations (same reference call sites as odx_gauss_knm_f32 / odx_gauss_mmv_f32 above) with
- * the X Z' contraction on v_mfma_f32_32x32x16_f16 at f32 accuracy: every f32 value is split once into two
+ * the X Z' contraction on v_mfma_f32_16x16x32_f16 at f32 accuracy: every f32 value is split once into two
  * f16 terms (hi + lo, after a power-of-two scale) and  x.z = hi.hi + hi.lo + lo.hi  accumulates in f32.
  *
  * odx_split_f16 packs an f32 matrix for those kernels.  P: n rows of ldp 4-byte units, ldp % 4 == 0,

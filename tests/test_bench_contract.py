@@ -9,8 +9,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _newest_bench_line():
+    import glob
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1.json")))[-1]
+
+
 def test_committed_bench_line_has_the_contracted_shape():
-    line = open(os.path.join(ROOT, "profiles", "r01_bench_n1.json")).read().strip().splitlines()[-1]
+    line = open(_newest_bench_line()).read().strip().splitlines()[-1]
     d = json.loads(line)
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["metric"].split(" at ")[0] == base["metric"].split(" at ")[0]
@@ -32,3 +37,41 @@ def test_bench_accepts_the_driver_flags():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in out.stdout
+
+
+def test_gpus_n_without_a_launcher_starts_n_ranks(monkeypatch, capsys):
+    """`python bench.py --gpus 8` (the driver's command) must start 8 ranks itself: the parent builds ONE
+    `python -m torch.distributed.run --nproc-per-node 8 ... bench.py <same flags>` child on 127.0.0.1, relays the
+    result line and exits with the child's status — checked here with a stand-in for the child process."""
+    import importlib.util
+    import io
+    import pytest
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, stdout=None, env=None, text=None):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = io.StringIO('noise\n{"metric": "m", "n_gpus": 8}\n')
+            self.rc = seen.get("rc", 0)
+
+        def wait(self):
+            return self.rc
+
+    import subprocess as sp
+    monkeypatch.setattr(sp, "Popen", FakeProc)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    bench.main()
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+    assert cmd[-7].endswith("bench.py") and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert capsys.readouterr().out.strip() == '{"metric": "m", "n_gpus": 8}'
+    seen["rc"] = 7                                       # a failed child is a failed bench: no retry, same status
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7

@@ -1,6 +1,7 @@
-"""Parity at the shapes BASELINE.json names as configs 2 and 4 (config 1 is `test_falkon_fit_alpha_parity`'s first case,
-config 3's single-GPU shard is `test_headline_shape_one_class`): the whole fit on the MI355X against the f64 oracle
-(oracle/falkon_ref.py) on the same seeded inputs, alphas within 1e-4 relative as BASELINE.json's north star states."""
+"""Parity at the shapes BASELINE.json names as configs 2, 4 and 5 and config 3's RLS half (config 1 is
+`test_falkon_fit_alpha_parity`'s first case, config 3's single-GPU FALKON shard is `test_headline_shape_one_class`): the
+whole fit on the MI355X against the f64 oracle (oracle/falkon_ref.py, oracle/rls_ref.py) on the same seeded inputs,
+alphas within 1e-4 relative as BASELINE.json's north star states."""
 import numpy as np
 import pytest
 
@@ -81,3 +82,54 @@ def test_config4_mask_pixels_d256_m2000(be):
     rows = np.arange(0, n, 499)
     got = be.mmv(be.features(torch.from_numpy(X[rows])), Zf, sigma, torch.from_numpy(alpha)).cpu().numpy()
     assert np.abs(got - fr.falkon_predict(X[rows].astype(np.float64), Z, ref, sigma)).max() < 1e-4
+
+
+def test_config5_shard_shape_one_class(be):
+    """Config 5 (100 classes, N = 5e6, D = 1024, M = 2e4 on 8 GPUs): the shard one GPU holds — 625 000 rows, a 50 GB f32
+    K_nM block — for one class through the shipping f16-split path (f32-accurate K; the fp8 contraction BASELINE names is
+    a throughput-only variant), with the size-independent properties of the headline-shape test: sampled
+    K_nM entries and scores against the f64 oracle, pass additivity / linearity, the fused right-hand side, bitwise
+    repeatability.  M = 2e4 is the widest configuration of the pass kernel and the largest preconditioner (four
+    20 000^2 f64 factors)."""
+    from tests.test_gpu_kernels import full_size_properties
+    full_size_properties(be, 625_000, 1024, 20_000, 15.0, 1e-5)
+    be.release_workspaces()
+    torch.cuda.empty_cache()
+
+
+def test_config3_rls_thirty_regressors_n3e5(be):
+    """Config 3's RLS half: COXY with n = 3e5 rows, D = 1024, 30 classes, lambda = 1000 through the drop-in
+    RegionRefinerTrainer on the GPU; three classes (first, middle, last) against oracle/rls_ref.py, which is pinned to the
+    reference's own RegionRefinerTrainer (tests/test_oracle_rls.py), every class through its normal equations."""
+    from contextlib import redirect_stdout
+    import io
+    from odx.rls import RegionRefinerTrainer
+    from oracle import rls_ref
+    n, D, C, lam = 300_000, 1024, 30, 1000.0
+    g = torch.Generator(device="cuda").manual_seed(1234 + 3)
+    X = torch.randn((n, D), generator=g, device="cuda") * 0.6 + 0.15
+    cls = (torch.arange(n, device="cuda") % C) + 1
+    Wtrue = torch.randn((C, D, 4), generator=g, device="cuda") * 0.02
+    Y = torch.empty((n, 4), device="cuda")
+    for c in range(C):
+        I = torch.where(cls == c + 1)[0]
+        Y[I] = X[I] @ Wtrue[c] + 0.1 * torch.randn((len(I), 4), generator=g, device="cuda")
+    cfg = {"CHOSEN_CLASSES": {i: ("c%d" % i if i else "_background_") for i in range(C + 1)},
+           "REGION_REFINER": {"opts": {"lambda": lam}}}
+    with redirect_stdout(io.StringIO()):
+        models = RegionRefinerTrainer(cfg, lam, False)({"C": cls.float().view(-1, 1), "O": None, "X": X, "Y": Y})
+    assert len(models) == C
+    Xh, Yh, ch = X.cpu().numpy(), Y.cpu().numpy(), cls.cpu().numpy()
+    for c in range(C):
+        m = models[c]
+        W = torch.stack([m["Beta"][str(k)]["weights"] for k in range(4)]).double()        # (4, D + 1)
+        assert W.is_cuda and torch.isfinite(W).all()
+        if c in (0, 14, 29):
+            I = np.where(ch == c + 1)[0]
+            ref = rls_ref.train_class(Xh[I], Yh[I], lam)
+            scale = max(1.0, float(np.abs(ref["W"]).max()))
+            assert np.abs(W.cpu().numpy() - ref["W"]).max() < 2e-6 * scale, c                # f32 hand-out of f64 weights
+            for key in ("mu", "T", "T_inv"):
+                assert np.allclose(m[key].cpu().numpy(), ref[key], atol=2e-6), (c, key)
+            L = np.stack([m["Beta"][str(k)]["losses"].cpu().numpy() for k in range(4)])
+            assert np.abs(L - ref["losses"]).max() < 1e-5 * max(1.0, float(ref["losses"].max())), c

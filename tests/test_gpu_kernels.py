@@ -357,10 +357,15 @@ def test_headline_shape_one_class(be):
     """One class at BASELINE.json's full size (N = 1e6, D = 1024, M = 1e4, the shard one GPU holds), through properties
     that do not need an oracle run of that size: sampled K_nM entries and sampled scores against the f64 oracle, the
     CG pass against row halves (every row read exactly once) and its linearity, and bitwise repeatability."""
+    full_size_properties(be, 1_000_000, 1024, 10_000, 15.0, 1e-5)
+
+
+def full_size_properties(be, n, D, M, sigma, lam):
+    """The size-independent checks of one class at a BASELINE shard shape (also used for config 5's shard,
+    tests/test_gpu_configs.py)."""
     import odx
     from odx.backend import Knm
     from oracle import falkon_ref as fr
-    n, D, M, sigma, lam = 1_000_000, 1024, 10_000, 15.0, 1e-5
     g = torch.Generator(device="cuda").manual_seed(5)
     X = torch.randn((n, D), generator=g, device="cuda") * (20.0 / D ** 0.5)
     X[::30] += 0.25                                                  # a positive class with some structure
@@ -373,15 +378,15 @@ def test_headline_shape_one_class(be):
     alpha, K = odx.falkon_fit(be, F, y, Zf, sigma, lam, 20, return_knm=True)
     assert torch.isfinite(alpha).all()
     # (a) sampled entries of the stored K_nM, edges of the tile grid included
-    rows = np.array([0, 1, 255, 256, 257, 4095, 123457, 500000, 999743, 999744, 999999])
-    cols = np.array([0, 1, 127, 128, 255, 256, 5000, 9983, 9984, 9999])
+    rows = np.array([0, 1, 255, 256, 257, 4095, 123457, n // 2, n // 256 * 256 - 1, n // 256 * 256, n - 1])
+    cols = np.array([0, 1, 127, 128, 255, 256, M // 2, M // 256 * 256 - 1, M // 256 * 256, M - 1])
     Zh = Zf.X.cpu().numpy().astype(np.float64)
     ref = fr.gaussian_kernel(X[rows].cpu().numpy().astype(np.float64), Zh[cols], sigma)
     got = K.K[rows][:, cols].cpu().numpy()
     assert np.abs(got - ref).max() < 2e-5
     assert float(K.K[:, M:].abs().max()) == 0.0 if K.ld > M else True
     # (b) sampled scores against the oracle's predict with the same alpha
-    srows = np.concatenate([np.arange(0, 300), np.arange(499900, 500100), np.arange(n - 300, n)])
+    srows = np.concatenate([np.arange(0, 300), np.arange(n // 2 - 100, n // 2 + 100), np.arange(n - 300, n)])
     pref = fr.falkon_predict(X[srows].cpu().numpy().astype(np.float64), Zh, alpha.cpu().numpy()[:, None], sigma)
     scores = be.mmv(F, Zf, sigma, alpha)
     assert np.abs(scores[srows].cpu().numpy() - pref).max() < 1e-4 * max(1.0, np.abs(pref).max())
@@ -391,7 +396,7 @@ def test_headline_shape_one_class(be):
     full = be.ktk(K, v=v1)
     assert torch.equal(full, be.ktk(K, v=v1))
     parts = torch.zeros_like(full)
-    for lo, hi in ((0, 499_999), (499_999, n)):
+    for lo, hi in ((0, n // 2 - 1), (n // 2 - 1, n)):
         Kh = Knm()
         Kh.n, Kh.M, Kh.ld, Kh.K = hi - lo, M, K.ld, K.K[lo:hi]
         parts += be.ktk(Kh, v=v1)

@@ -286,6 +286,25 @@ print("RCCL-OK")
     assert "RCCL-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_bench_starts_its_own_ranks_and_matches_the_oracle():
+    """`python bench.py --gpus 2` (the driver's form, no launcher around it): the parent starts the two ranks itself, the
+    ranks shard the rows and run the lock-step fit with its per-iteration exchange (gloo here: both ranks share this
+    box's one GPU), and the result line reports the rank count the collective saw plus the oracle check."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--single-device", "--dist-backend", "gloo", "--rows", "40000", "--centres", "1024", "--classes", "4",
+                        "--check", "--no-cpu-baseline", "--no-extras"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["config"]["rows_per_gpu"] == 20000
+    assert out["check"]["max_abs_score_diff_vs_oracle_predict"] < 1e-4
+    assert out["health"]["failed_choleskys"] == 0 and out["health"]["ranks_with_nonfinite_scores"] == 0
+
+
 def test_minibootstrap_on_class_streams_does_not_depend_on_the_stream_count(tmp_path):
     """opts['class_streams'] = k trains the classes concurrently on k streams with one RNG stream per class: the models
     are the same bits for k = 1 and k = 3 (deterministic kernels, per-stream scratch), classes without data stay None,

@@ -20,9 +20,20 @@ from tests.synth import blob_problem, centres
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
+# Reference-pinned checks that only need torch ops / the product backend also run on HIP tensors (`-m gpu`).
+DEVICES = ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)]
+
+
 @pytest.fixture(autouse=True)
-def oracle_backend():
-    odx.set_backend(OracleBackend(np.float64))
+def oracle_backend(request):
+    """CPU arms drive the host logic through the numpy-oracle backend; the cuda arms of the device-parametrised
+    tests run on the product's HIP backend (libodx.so)."""
+    params = getattr(getattr(request.node, "callspec", None), "params", {})
+    if params.get("device") == "cuda":
+        odx.set_backend(None)
+        assert odx.get_backend().name == "hip-gfx950"
+    else:
+        odx.set_backend(OracleBackend(np.float64))
     yield
     odx.set_backend(None)
 
@@ -197,57 +208,69 @@ def test_minibootstrap_return_caches_and_options():
 
 
 # ------------------------------------------------------------------ py_od_utils
-def test_py_od_utils_match_reference():
+@pytest.mark.parametrize("device", DEVICES)
+def test_py_od_utils_match_reference(device):
+    """A10 against vectors from the reference's own py_od_utils / MyCenterSelector; the cuda arm keeps every tensor
+    (feature lists, COXY, statistics) on the MI355X as the drivers do."""
     H = np.load(os.path.join(GOLD, "helpers_golden.npz"))
     u = dropin.load("py_od_utils")
     C, D = 3, 16
-    positives = [torch.from_numpy(H["pos_%d" % c]) for c in range(C)]
-    negatives = [[torch.from_numpy(H["neg_%d_%d" % (c, j)]) for j in range(3)] for c in range(C)]
+    cpu = device == "cpu"
+    positives = [torch.from_numpy(H["pos_%d" % c]).to(device) for c in range(C)]
+    negatives = [[torch.from_numpy(H["neg_%d_%d" % (c, j)]).to(device) for j in range(3)] for c in range(C)]
     torch.manual_seed(1234)
-    st = quiet(u.computeFeatStatistics_torch, positives, negatives, num_samples=90, features_dim=D, cpu_tensor=True,
+    st = quiet(u.computeFeatStatistics_torch, positives, negatives, num_samples=90, features_dim=D, cpu_tensor=cpu,
                pos_fraction=0.8)
+    if not cpu:
+        assert all(v.is_cuda for v in st.values())
     assert np.allclose(st["mean"].cpu().numpy(), H["stats_mean"], atol=1e-6)
     assert np.allclose(st["std"].cpu().numpy(), H["stats_std"], atol=1e-6)
     assert np.allclose(st["mean_norm"].cpu().numpy(), H["stats_mean_norm"], atol=1e-6)
-    COXY = {"C": torch.from_numpy(H["coxy_C"]), "O": None, "X": torch.from_numpy(H["coxy_X"]), "Y": None}
-    stc = {k: v.cpu() for k, v in st.items()}
-    assert np.allclose(u.normalize_COXY(dict(COXY), stc, cpu=True)["X"].numpy(), H["coxy_X_normalized"], atol=1e-6)
+    COXY = {"C": torch.from_numpy(H["coxy_C"]).to(device), "O": None, "X": torch.from_numpy(H["coxy_X"]).to(device), "Y": None}
+    stc = {k: v.to(device) for k, v in st.items()}
+    Xn = u.normalize_COXY(dict(COXY), stc, cpu=cpu)["X"]
+    assert Xn.device.type == device and np.allclose(Xn.cpu().numpy(), H["coxy_X_normalized"], atol=1e-6)
     pf = u.load_positives_from_COXY({"C": COXY["C"][:, 0].clone(), "X": COXY["X"].clone()})
     assert len(pf) == int(H["pos_from_coxy_n"])
     for i, p in enumerate(pf):
-        assert np.array_equal(p.numpy(), H["pos_from_coxy_%d" % i])
+        assert p.device.type == device and np.array_equal(p.cpu().numpy(), H["pos_from_coxy_%d" % i])
     torch.manual_seed(99)
     sh = u.shuffle_negatives([[b.clone() for b in nb] for nb in negatives], batch_size=40, num_batches=3)
     for c in range(C):
         for j in range(3):
-            assert np.array_equal(sh[c][j].numpy(), H["shuf_%d_%d" % (c, j)])
-    assert np.allclose(u.zScores(positives[0].numpy(), stc["mean"], stc["mean_norm"]).numpy(), H["zscores"], atol=1e-6)
+            assert sh[c][j].device.type == device and np.array_equal(sh[c][j].cpu().numpy(), H["shuf_%d_%d" % (c, j)])
+    z = u.zScores(positives[0].cpu().numpy(), stc["mean"].cpu(), stc["mean_norm"].cpu())
+    assert np.allclose(z.numpy(), H["zscores"], atol=1e-6)
     sel = dropin.load("MyCenterSelector")
-    Xs, Ys, idx = torch.from_numpy(H["sel_X"]), torch.from_numpy(H["sel_Y"]), H["sel_idx"].tolist()
-    assert np.array_equal(sel.MyCenterSelector(idx).select(Xs, None).numpy(), H["sel_out_X"])
+    Xs, Ys, idx = torch.from_numpy(H["sel_X"]).to(device), torch.from_numpy(H["sel_Y"]).to(device), H["sel_idx"].tolist()
+    assert np.array_equal(sel.MyCenterSelector(idx).select(Xs, None).cpu().numpy(), H["sel_out_X"])
     xo, yo = sel.MyCenterSelector(idx).select(Xs, Ys)
-    assert np.array_equal(xo.numpy(), H["sel_out_X2"]) and np.array_equal(yo.numpy(), H["sel_out_Y2"])
+    assert xo.device.type == device
+    assert np.array_equal(xo.cpu().numpy(), H["sel_out_X2"]) and np.array_equal(yo.cpu().numpy(), H["sel_out_Y2"])
 
 
-def test_decode_boxes_detector_and_feature_cache_roundtrip(tmp_path):
+@pytest.mark.parametrize("device", DEVICES)
+def test_decode_boxes_detector_and_feature_cache_roundtrip(tmp_path, device):
     R = np.load(os.path.join(GOLD, "rls_golden.npz"))
     u = dropin.load("py_od_utils")
     from odx.boxlist import BoxList
-    out = u.decode_boxes_detector(BoxList(torch.from_numpy(R["apply_boxes_0"]), (320, 240)), torch.from_numpy(R["decode_in"]))
-    assert np.allclose(out.numpy(), R["decode_out"], atol=1e-4)
+    out = u.decode_boxes_detector(BoxList(torch.from_numpy(R["apply_boxes_0"]).to(device), (320, 240)),
+                                  torch.from_numpy(R["decode_in"]).to(device))
+    assert out.device.type == device and np.allclose(out.cpu().numpy(), R["decode_out"], atol=1e-4)
     # on-disk feature cache layout (py_od_utils.py:153-217)
     d = str(tmp_path)
     for c in range(2):
         for b in range(2):
-            torch.save(torch.full((3, 4), float(10 * c + b)), os.path.join(d, "positives_cl_%d_batch_%d" % (c, b)))
-            torch.save(torch.full((2, 4), -float(10 * c + b)), os.path.join(d, "negatives_cl_%d_batch_%d" % (c, b)))
-    torch.save(torch.ones(5, 4), os.path.join(d, "reg_x_batch_0"))
-    torch.save(torch.ones(5, 1), os.path.join(d, "reg_c_batch_0"))
-    torch.save(torch.ones(5, 4), os.path.join(d, "reg_y_batch_0"))
-    pos, neg = u.load_features_classifier(d, cpu_tensor=True)
+            torch.save(torch.full((3, 4), float(10 * c + b), device=device), os.path.join(d, "positives_cl_%d_batch_%d" % (c, b)))
+            torch.save(torch.full((2, 4), -float(10 * c + b), device=device), os.path.join(d, "negatives_cl_%d_batch_%d" % (c, b)))
+    torch.save(torch.ones(5, 4, device=device), os.path.join(d, "reg_x_batch_0"))
+    torch.save(torch.ones(5, 1, device=device), os.path.join(d, "reg_c_batch_0"))
+    torch.save(torch.ones(5, 4, device=device), os.path.join(d, "reg_y_batch_0"))
+    pos, neg = u.load_features_classifier(d, cpu_tensor=(device == "cpu"))
+    assert pos[0].device.type == device
     assert [tuple(p.shape) for p in pos] == [(6, 4), (6, 4)] and [len(n) for n in neg] == [2, 2]
     assert float(neg[1][1][0, 0]) == -11.0
-    pos_s, neg_s = u.load_features_classifier(d, is_segm=True, cpu_tensor=True)
+    pos_s, neg_s = u.load_features_classifier(d, is_segm=True, cpu_tensor=(device == "cpu"))
     assert tuple(neg_s[0].shape) == (4, 4)
     coxy = u.load_features_regressor(d)
     assert tuple(coxy["X"].shape) == (5, 4) and coxy["O"] is None
@@ -401,7 +424,8 @@ def test_heads_match_reference():
 
 
 # ------------------------------------------------------------------ f4: adding a class to a running pipeline
-def test_add_a_class_without_touching_the_others():
+@pytest.mark.parametrize("device", DEVICES)
+def test_add_a_class_without_touching_the_others(device):
     """Train two classes, put them in the test-time head, then train a third with one more FALKON + RLS fit, append
     and update_model: the first two classes score and regress exactly as before, the new column is the new model's
     own stand-alone prediction (demo contract: predictor_online_segmentation.py:404-425, box_head_getProposals.py:90-99)."""
@@ -414,11 +438,11 @@ def test_add_a_class_without_touching_the_others():
     mus = rng.standard_normal((3, D)) * 2
 
     def rows(c, n):
-        return torch.from_numpy((mus[c] + rng.standard_normal((n, D))).astype(np.float32))
+        return torch.from_numpy((mus[c] + rng.standard_normal((n, D))).astype(np.float32)).to(device)
 
     def fit_class(c):
         X = torch.cat([rows(c, 60), rows((c + 1) % 3, 90), rows((c + 2) % 3, 90)])
-        y = torch.cat([torch.ones(60), -torch.ones(180)])
+        y = torch.cat([torch.ones(60), -torch.ones(180)]).to(device)
         m = odx.InCoreFalkon(kernel=odx.GaussianKernel(6.0), penalty=1e-4, M=80, maxiter=20,
                              center_selection=CenterSelector(list(range(0, 240, 3))))
         m.fit(X, y)
@@ -426,20 +450,20 @@ def test_add_a_class_without_touching_the_others():
 
     def fit_regressors(classes):
         Xr = torch.cat([rows(c, 40) for c in classes])
-        Cr = torch.cat([torch.full((40, 1), float(k + 1)) for k in range(len(classes))])
-        Yr = torch.from_numpy(rng.standard_normal((len(Xr), 4)).astype(np.float32)) * 0.1
+        Cr = torch.cat([torch.full((40, 1), float(k + 1)) for k in range(len(classes))]).to(device)
+        Yr = torch.from_numpy(rng.standard_normal((len(Xr), 4)).astype(np.float32)).to(device) * 0.1
         cfg = {"CHOSEN_CLASSES": {i: "c%d" % i for i in range(len(classes) + 1)}, "REGION_REFINER": {"opts": {"lambda": 1.0}}}
         return list(quiet(RegionRefinerTrainer(cfg, 1.0, False), {"C": Cr, "O": None, "X": Xr, "Y": Yr}))
 
-    stats = {"mean": torch.zeros(D), "std": torch.ones(D), "mean_norm": torch.tensor(20.0)}
+    stats = {"mean": torch.zeros(D, device=device), "std": torch.ones(D, device=device), "mean_norm": torch.tensor(20.0, device=device)}
     clfs, regs = [fit_class(0), fit_class(1)], fit_regressors([0, 1])
-    model = OnlineDetectionModel(width=8)
+    model = OnlineDetectionModel(width=8).to(device)
     model.update_model(models_detection={"classifiers": clfs, "regressors": regs, "stats": stats})
     F = torch.cat([rows(0, 5), rows(1, 5), rows(2, 5)])
     s2, d2 = model.online_box(F)
     assert tuple(s2.shape) == (15, 3) and tuple(d2.shape) == (15, 12)
     # a harvester grows by one class the same way
-    hv = DetectorHarvester(D, 2, 2, 10, 4, device="cpu")
+    hv = DetectorHarvester(D, 2, 2, 10, 4, device=device)
     hv.add_new_class()
     assert hv.num_classes == 3 and len(hv._neg) == 3 and hv.still_to_complete == [0, 1, 2]
     # one more FALKON + RLS fit, appended
@@ -449,4 +473,5 @@ def test_add_a_class_without_touching_the_others():
     assert tuple(s3.shape) == (15, 4) and tuple(d3.shape) == (15, 16)
     assert torch.equal(s3[:, :3], s2) and torch.equal(d3[:, :12], d2)
     Fn = (F - stats["mean"]) * (20.0 / stats["mean_norm"])
+    assert s3.device.type == device
     assert torch.allclose(s3[:, 3], new_clf.predict(Fn).squeeze(1).float(), atol=1e-5)

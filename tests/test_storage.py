@@ -11,7 +11,7 @@ import torch
 
 from odx import storage
 from odx.utils import load_features_classifier, load_features_regressor
-from tests.test_harvest import _run, _run_rpn
+from tests.test_harvest import DEVICES, _run, _run_rpn
 
 CACHE = np.load(os.path.join(os.path.dirname(__file__), "golden", "feature_cache_golden.npz"))
 
@@ -20,7 +20,7 @@ def _compare_dir(d, tag):
     want = CACHE["%s/__files__" % tag].tolist()
     assert sorted(os.listdir(d)) == want
     for n in want:
-        got, ref = torch.load(os.path.join(d, n)).numpy(), CACHE["%s/%s" % (tag, n)]
+        got, ref = torch.load(os.path.join(d, n)).cpu().numpy(), CACHE["%s/%s" % (tag, n)]
         assert got.shape == ref.shape, (tag, n, got.shape, ref.shape)
         if n.startswith("reg_y"):
             assert np.allclose(got, ref, atol=1e-6), (tag, n)
@@ -28,45 +28,48 @@ def _compare_dir(d, tag):
             assert np.array_equal(got, ref), (tag, n)
 
 
+@pytest.mark.parametrize("device", DEVICES)
 @pytest.mark.parametrize("shuffle", [False, True])
-def test_detector_cache_files_equal_the_reference(tmp_path, shuffle):
-    h = _run(shuffle)
+def test_detector_cache_files_equal_the_reference(tmp_path, shuffle, device):
+    h = _run(shuffle, device)
     storage.save_detector_features(h, str(tmp_path))
     _compare_dir(str(tmp_path / "features_detector"), "det_shuf" if shuffle else "det_fill")
     # and the readers give back what finalize() returns
-    pos, neg = load_features_classifier(str(tmp_path / "features_detector"))
+    pos, neg = load_features_classifier(str(tmp_path / "features_detector"), cpu_tensor=(device == "cpu"))
     negatives, positives, COXY = h.finalize()
     for c in range(h.num_classes):
-        assert torch.equal(pos[c], positives[c])
+        assert pos[c].device.type == device and torch.equal(pos[c], positives[c])
         if not shuffle:
             assert all(torch.equal(a, b) for a, b in zip(neg[c], [n for n in negatives[c] if len(n)]))
     back = load_features_regressor(str(tmp_path / "features_detector"))
-    assert torch.equal(back["X"], COXY["X"]) and torch.equal(back["C"], COXY["C"]) and torch.equal(back["Y"], COXY["Y"])
+    assert all(torch.equal(back[k].cpu(), COXY[k].cpu()) for k in ("X", "C", "Y"))
 
 
+@pytest.mark.parametrize("device", DEVICES)
 @pytest.mark.parametrize("shuffle", [False, True])
-def test_rpn_cache_files_equal_the_reference(tmp_path, shuffle):
-    h = _run_rpn(shuffle)
+def test_rpn_cache_files_equal_the_reference(tmp_path, shuffle, device):
+    h = _run_rpn(shuffle, device)
     storage.save_rpn_features(h, str(tmp_path))
     _compare_dir(str(tmp_path / "features_RPN"), "rpn_shuf" if shuffle else "rpn_fill")
 
 
-def test_segmentation_cache_roundtrip(tmp_path):
+@pytest.mark.parametrize("device", DEVICES)
+def test_segmentation_cache_roundtrip(tmp_path, device):
     from odx.harvest import MaskHarvester
     torch.manual_seed(0)
-    det = _run(False)
-    m = MaskHarvester(6, 3, batch_size=40, sampling_factor=0.5, device="cpu")
+    det = _run(False, device)
+    m = MaskHarvester(6, 3, batch_size=40, sampling_factor=0.5, device=device)
     for _ in range(9):
-        feats = torch.randn(2, 6, 7, 7)
-        m.add_image(feats, (torch.rand(2, 7, 7) > 0.5).float(), [1, 3])        # class 2 never appears
+        feats = torch.randn(2, 6, 7, 7).to(device)
+        m.add_image(feats, (torch.rand(2, 7, 7) > 0.5).float().to(device), [1, 3])        # class 2 never appears
     storage.save_detector_features(det, str(tmp_path), mask_harvester=m)
     files = sorted(os.listdir(tmp_path / "features_segmentation"))
     assert "positives_cl_1_batch_0" in files and torch.load(tmp_path / "features_segmentation" / "positives_cl_1_batch_0").shape == (0, 6)
     assert any(f.startswith("positives_cl_0_batch_1") for f in files)            # cut where a batch reached 40 rows
-    pos, neg = load_features_classifier(str(tmp_path / "features_segmentation"), is_segm=True)
+    pos, neg = load_features_classifier(str(tmp_path / "features_segmentation"), is_segm=True, cpu_tensor=(device == "cpu"))
     n_ref, p_ref = m.finalize()
     for c in (0, 2):
-        assert torch.equal(pos[c], p_ref[c]) and torch.equal(neg[c], n_ref[c])
+        assert pos[c].device.type == device and torch.equal(pos[c], p_ref[c]) and torch.equal(neg[c], n_ref[c])
 
 
 def test_model_files_roundtrip_and_falkon_names(tmp_path):

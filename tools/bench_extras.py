@@ -1,0 +1,143 @@
+"""Driver-visible numbers for the halves of BASELINE configs 2 and 3 that the headline metric does not time
+(bench.py adds them to its JSON line as extra keys, measured OUTSIDE the timed headline region, rank 0, N = 1 only):
+
+  rls            config 3's second half: the 30 per-class RLS box regressors on COXY n = 3e5, D = 1024, lambda = 1000
+                 (train_region_refiner.py:25-119) through the drop-in trainer, with the numpy-f64 oracle timed beside it
+                 on one class (a bounded sample) on the host cores
+  forward        config 2's first half: OnlineDetectionModel.forward on a synthetic 600 x 800 image, 300 RoIs,
+                 f32 and bf16 autocast, random weights (feature_proposal_extractor.py:228-281)
+  minibootstrap  the reference regime (OnlineRegionClassifier_incore.py:96-155): 30 classes x 10 negative batches of
+                 2000 rows, M = 2000, D = 2048, in the reference's sequential order and in the opt-in class-parallel mode
+"""
+import io
+import os
+import sys
+import tempfile
+import time
+from contextlib import redirect_stdout
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F64_MFMA_PEAK_TFLOPS = 78.6    # /opt/skills/guides/MI355X_MICROARCH.md: FP64 matrix
+
+
+def _sync_time(fn):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = fn()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, out
+
+
+def rls_extra(n=300_000, D=1024, C=30, lam=1000.0, cpu=True):
+    from odx.rls import RegionRefinerTrainer
+    g = torch.Generator(device="cuda").manual_seed(1234 + 3)
+    X = torch.randn((n, D), generator=g, device="cuda") * 0.6 + 0.15
+    cls = (torch.arange(n, device="cuda") % C) + 1
+    Y = torch.randn((n, 4), generator=g, device="cuda") * 0.2
+    cfg = {"CHOSEN_CLASSES": {i: "c%d" % i for i in range(C + 1)}, "REGION_REFINER": {"opts": {"lambda": lam}}}
+    COXY = {"C": cls.float().view(-1, 1), "O": None, "X": X, "Y": Y}
+    best = None
+    for _ in range(3):                                  # first repetition warms kernels and allocations
+        with redirect_stdout(io.StringIO()):
+            dt, models = _sync_time(lambda: RegionRefinerTrainer(cfg, lam, False)(COXY))
+        best = dt if best is None else min(best, dt)
+    nc = n // C
+    flop = C * (nc * (D + 1.0) ** 2 + (D + 1.0) ** 3 / 3)           # lower-triangle Gram + Cholesky, per class
+    out = {"workload": "%d RLS box regressors, COXY n=%d D=%d lambda=%g (%d rows per class), f64" % (C, n, D, lam, nc),
+           "ms": round(best * 1e3, 2), "regressors_per_s": round(C / best, 1),
+           "achieved_TFLOPs_f64": round(flop / best / 1e12, 2), "peak_TFLOPs_f64_mfma": F64_MFMA_PEAK_TFLOPS}
+    if cpu:
+        from oracle import rls_ref
+        I = torch.where(cls == 1)[0]
+        Xh, Yh = X[I].cpu().numpy(), Y[I].cpu().numpy()
+        t0 = time.perf_counter()
+        ref = rls_ref.train_class(Xh, Yh, lam)
+        dtc = time.perf_counter() - t0
+        W = torch.stack([models[0]["Beta"][str(k)]["weights"] for k in range(4)]).cpu().numpy()
+        out["cpu_baseline"] = {"value": round(1.0 / dtc, 2), "unit": "regressors/s", "kind": "port", "cores": int(torch.get_num_threads()),
+                               "sample": "oracle/rls_ref.py (numpy/scipy f64) on 1 class of %d rows in %.2f s" % (len(I), dtc)}
+        out["max_abs_weight_diff_vs_oracle_class1"] = float(np.abs(W - ref["W"]).max())
+    return out
+
+
+def forward_extra(height=600, width=800, rois=300, reps=8):
+    from odx.extract import OnlineDetectionModel
+    dev = torch.device("cuda")
+    model = OnlineDetectionModel(post_nms_top_n=rois).to(dev).eval()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    img = torch.randn((1, 3, height, width), device=dev, generator=g)
+    out = {"workload": "R-50-C4 trunk + RPN proposals (HIP NMS) + RoIAlign (HIP) + conv5 head on one synthetic %dx%d image, "
+                       "%d RoIs, random weights" % (height, width, rois)}
+    for name, ctx in (("f32", torch.autocast("cuda", enabled=False)), ("bf16", torch.autocast("cuda", dtype=torch.bfloat16))):
+        with torch.no_grad(), ctx:
+            for _ in range(3):
+                model(img)
+            dt, _ = _sync_time(lambda: [model(img) for _ in range(reps)])
+        out["images_per_s_" + name] = round(reps / dt, 1)
+        out["ms_per_image_" + name] = round(dt / reps * 1e3, 2)
+    return out
+
+
+def minibootstrap_extra(C=30, D=2048, IT=10, positives=800, sigma=15.0, modes=(("sequential", None), ("class_streams4", {"class_streams": 4}))):
+    import yaml
+    from tests import dropin
+    names = ["_background_"] + ["c%d" % i for i in range(C)]
+    cfg = {"NUM_CLASSES": C + 1,
+           "ONLINE_REGION_CLASSIFIER": {"MINIBOOTSTRAP": {"EASY_THRESH": -0.9, "HARD_THRESH": -0.7},
+                                        "CLASSIFIER": {"lambda": 0.0001, "sigma": sigma, "M": 2000, "kernel_type": "gauss"}},
+           "CHOSEN_CLASSES": {i: c for i, c in enumerate(names)}}
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, "cfg.yaml")
+    yaml.safe_dump(cfg, open(path, "w"))
+    g = torch.Generator(device="cuda").manual_seed(1)
+    mu = torch.randn((C, D), device="cuda", generator=g)
+
+    def data():
+        pos = [mu[c] + 0.7 * torch.randn((positives, D), device="cuda", generator=g) for c in range(C)]
+        neg = [[mu[(c + 1 + j) % C] * 0.5 + 0.8 * torch.randn((2000, D), device="cuda", generator=g) for j in range(IT)] for c in range(C)]
+        return pos, neg
+
+    u = dropin.load("py_od_utils")
+    clf_mod = dropin.load("FALKONWrapper_with_centers_selection_incore")
+    orc_mod = dropin.load("OnlineRegionClassifier_incore")
+    out = {"workload": "%d classes x %d negative batches of 2000 rows, %d positives, D=%d, M=2000 (1 fit + 2 predicts per class and "
+                       "batch) through OnlineRegionClassifier_incore.trainRegionClassifier" % (C, IT, positives, D)}
+    for name, opts in modes:
+        best = None
+        for rep in range(2):                      # the first repetition warms every kernel and allocation
+            pos, neg = data()
+            with redirect_stdout(io.StringIO()):
+                torch.manual_seed(7)
+                stats = u.computeFeatStatistics_torch(pos, neg, features_dim=D, pos_fraction=0.8)
+                orc = orc_mod.OnlineRegionClassifier(clf_mod.FALKONWrapper(cfg_path=path), pos, neg, stats, cfg_path=path)
+                dt, models = _sync_time(lambda: orc.trainRegionClassifier(opts=dict(opts) if opts else None))
+            best = dt if best is None else min(best, dt)
+        out["s_" + name] = round(best, 3)
+        out["trained_" + name] = sum(1 for m in models if m is not None)
+    return out
+
+
+def collect(args):
+    """Everything above; a failing extra is reported as its error string, never as a missing headline."""
+    out = {}
+    for key, fn in (("rls", lambda: rls_extra(cpu=not args.no_cpu_baseline)), ("forward", forward_extra),
+                    ("minibootstrap", minibootstrap_extra)):
+        try:
+            out[key] = fn()
+        except Exception as e:          # noqa: BLE001 — an extra must not take the headline line down with it
+            out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+    return out
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "online-detection_amd"))
+    import json
+
+    class _A:
+        no_cpu_baseline = False
+    print(json.dumps(collect(_A()), indent=1))

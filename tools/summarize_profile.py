@@ -5,7 +5,15 @@ import csv
 import glob
 import json
 import os
+import statistics
 import sys
+
+
+def robust(x):
+    """Per-counter median over the profiled dispatches.  A plain mean let one outlier sample (a GRBM_GUI_ACTIVE read of
+    3e10 on one dispatch in round 1) print a "43.76 GHz" clock into the committed summary."""
+    return statistics.median(x)
+
 
 d = sys.argv[1]
 print("# rocprofv3 summary (%s)\n" % os.path.basename(d))
@@ -23,7 +31,7 @@ if os.path.exists(stats):
     print("## `rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline` (top kernels)\n")
     print("| kernel | calls | total ms | avg us | % |")
     print("|---|---|---|---|---|")
-    for r in list(csv.DictReader(open(stats)))[:14]:
+    for r in list(csv.DictReader(open(stats)))[:16]:
         print("| `%s` | %s | %.1f | %.1f | %s |" % (r["Name"].split("(")[0][-60:], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                   float(r["AverageNs"]) / 1e3, r["Percentage"]))
     print()
@@ -41,11 +49,15 @@ for f in sorted(glob.glob(os.path.join(d, "pmc_*kernel_trace.csv"))):
         if k in agg:
             dur[k].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e6)
 for k, v in agg.items():
-    c = {n: sum(x) / len(x) for n, x in v.items()}
-    ms = min(dur[k]) if dur[k] else float("nan")
+    c = {n: robust(x) for n, x in v.items()}
+    ms = statistics.median(dur[k]) if dur[k] else float("nan")
     line = "* `%s`: %.2f ms/launch" % (k, ms)
-    if "GRBM_GUI_ACTIVE" in c and ms == ms:
-        line += " at %.2f GHz" % (c["GRBM_GUI_ACTIVE"] / 8 / ms / 1e6)
+    ghz = c["GRBM_GUI_ACTIVE"] / 8 / ms / 1e6 if ("GRBM_GUI_ACTIVE" in c and ms == ms) else None
+    if ghz is not None and not 0.3 < ghz < 3.0:
+        line += " (GRBM_GUI_ACTIVE sample implausible: %.3g cycles; clock and MFMA-busy not derived)" % c["GRBM_GUI_ACTIVE"]
+        c.pop("GRBM_GUI_ACTIVE")
+    elif ghz is not None:
+        line += " at %.2f GHz" % ghz
     if "FETCH_SIZE" in c:
         # guide: on gfx950 FETCH_SIZE (KiB) counts 64 B per 128-B request for wide coalesced reads -> x2
         rd = 2 * c["FETCH_SIZE"] * 1024
