@@ -120,6 +120,13 @@ int odx_set_pass_reserved_cus(int cus);
 int odx_knm_fwd_bwd(const float* K, int64_t ldk, int64_t n, int64_t M,
                     const double* v, const double* w, double* out,
                     void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+/* Two products from ONE read of K:  out = K' (K v),  out2 = K' (K v2)  — the pass of a CG step whose periodic
+ * full-residual recomputation (falkon: every 10th iteration, R = B - W x) rides along: W x_new = W x_old + a W p.
+ * Available where both vectors fit in LDS (M <= 10 000); the workspace query returns ODX_ERR_UNSUPPORTED (< 0)
+ * otherwise and callers issue two odx_knm_fwd_bwd passes. */
+int64_t odx_knm_fwd_bwd2_workspace_bytes(int64_t n, int64_t M);
+int odx_knm_fwd_bwd2(const float* K, int64_t ldk, int64_t n, int64_t M, const double* v, const double* v2,
+                     double* out, double* out2, void* workspace, int64_t workspace_bytes, odx_stream_t stream);
 
 /* ---------------------------------------------------------------- A4: preconditioner (f64)
  * FalkonPreconditioner.init as run by InCoreFalkon.fit with min_cuda_pc_size_*=0
@@ -137,6 +144,17 @@ int odx_falkon_precond_f64(const float* Z, int64_t ldz, int64_t M, int D, double
                            double lam, double eps, double* LTi, double* LTit, double* LAi,
                            double* LAit, int64_t ld, int32_t* info,
                            void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+/* The same preconditioner for B <= 32 independent classes at once (the reference trains its classes one after the
+ * other, OnlineRegionClassifier_incore.py:96-155 — each `classifier.train` call above builds one; the classes are
+ * independent, so here every launch of the factorisation chain advances all B).  Z[b] / ldz[b] / M[b]: HOST arrays of
+ * the classes' centre pointers (device), leading dimensions and centre counts, M[b] <= Mmax.  out: B blocks,
+ * out_stride elements apart (>= 4 Mmax ld), each holding LTi | LTit | LAi | LAit as four Mmax x ld matrices whose
+ * leading M[b] x M[b] blocks are class b's factors (the rest is the factor of an identity border).  info: B words. */
+int64_t odx_falkon_precond_batched_workspace_bytes(int64_t Mmax, int D, int B);
+int odx_falkon_precond_batched_f64(const float* const* Z, const int64_t* ldz, const int64_t* M, int B,
+                                   int64_t Mmax, int D, double sigma, double lam, double eps,
+                                   double* out, int64_t ld, int64_t out_stride, int32_t* info,
+                                   void* workspace, int64_t workspace_bytes, odx_stream_t stream);
 
 /* y = op(Tri) x for a triangular M x M f64 matrix, rows as dot products.
  * uplo: 0 = lower (uses columns j <= i), 1 = upper (j >= i).
@@ -159,6 +177,10 @@ int odx_cg_step(double* X, double* R, const double* P, const double* AP, double*
                 double cg_eps, int full_grad, int64_t M, odx_stream_t stream);
 int odx_cg_finish(const double* R, double* P, double* state, double cg_eps, double tol,
                   int64_t M, odx_stream_t stream);
+/* R = B - (AX + a AP), a = state[3] (the step just taken): the periodic full residual B - W x_new from W x_old and W p
+ * (x_new = x_old + a p), both of which one odx_knm_fwd_bwd2 pass delivers; no-op once the stop flag is up. */
+int odx_cg_residual(const double* B, const double* AX, const double* AP, const double* state,
+                    double* R, int64_t M, odx_stream_t stream);
 /* y = a*x + b*y (f64), used for R = B - mmv(X) */
 int odx_axpby_f64(double a, const double* x, double b, double* y, int64_t M, odx_stream_t stream);
 

@@ -82,6 +82,18 @@ __global__ __launch_bounds__(1024) void cg_finish_kernel(const double* __restric
   }
 }
 
+// R = B - (AX + a AP) with a = state[3], the step cg_step_kernel has just taken: the full residual B - W x_new of the
+// periodic recomputation, from W x_old and W p (W is linear, x_new = x_old + a p) — both products come out of one
+// two-vector pass over K_nM (odx_knm_fwd_bwd2) made BEFORE the step.
+__global__ __launch_bounds__(256) void cg_residual_kernel(const double* __restrict__ B, const double* __restrict__ AX,
+                                                          const double* __restrict__ AP, const double* __restrict__ state,
+                                                          double* __restrict__ R, int64_t M) {
+  if (state[2] != 0.0) return;
+  const double a = state[3];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < M) R[i] = B[i] - fma(a, AP[i], AX[i]);
+}
+
 __global__ __launch_bounds__(256) void axpby_kernel(double a, const double* __restrict__ x, double b,
                                                     double* __restrict__ y, int64_t M) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -114,6 +126,15 @@ extern "C" int odx_cg_finish(const double* R, double* P, double* state, double c
   ODX_REQUIRE(R && P && state && M > 0, "odx_cg_finish: bad argument");
   hipLaunchKernelGGL(cg_finish_kernel, dim3(1), dim3(1024), 0, as_stream(stream), R, P, state, cg_eps, tol, M);
   ODX_CHECK_LAUNCH("odx_cg_finish");
+  return ODX_OK;
+}
+
+extern "C" int odx_cg_residual(const double* B, const double* AX, const double* AP, const double* state, double* R,
+                               int64_t M, odx_stream_t stream) {
+  ODX_REQUIRE(B && AX && AP && state && R && M > 0, "odx_cg_residual: bad argument");
+  hipLaunchKernelGGL(cg_residual_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, as_stream(stream), B, AX, AP,
+                     state, R, M);
+  ODX_CHECK_LAUNCH("odx_cg_residual");
   return ODX_OK;
 }
 

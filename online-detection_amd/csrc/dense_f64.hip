@@ -233,8 +233,11 @@ __device__ __forceinline__ void lds_store_dinv_128(const double* s, double* __re
 template <int NB, bool WITH_INV>
 __global__ __launch_bounds__(DB_NT) void potrf_diag_kernel(double* __restrict__ A, int64_t lda, int jb,
                                                           double* __restrict__ Dinv, int32_t* __restrict__ info,
-                                                          int info_base) {
+                                                          int info_base, int64_t zstrideA, int64_t zstrideD) {
   static_assert(NB == DB_NB, "diagonal-block kernels are built for NB = 128");
+  A += (int64_t)blockIdx.x * zstrideA;        // one workgroup per matrix of the class batch
+  Dinv += (int64_t)blockIdx.x * zstrideD;
+  info += blockIdx.x;
   __shared__ double s[DB_NB * DB_LD];
   __shared__ double xi[32 * DB_XLD];
   __shared__ double rd[32];
@@ -263,8 +266,12 @@ constexpr int TS_R = 64;          // rows per workgroup
 constexpr int TS_TLD = 130;       // LDS row strides (f64): 4 r + 2 kq banks over a 32-lane half => conflict-free ds_read_b64
 constexpr int TS_BLD = 34;
 __global__ __launch_bounds__(256) void trsm128_kernel(double* __restrict__ A21, int64_t lda, int64_t m,
-                                                      const double* __restrict__ L11, const double* __restrict__ gx) {
+                                                      const double* __restrict__ L11, const double* __restrict__ gx,
+                                                      int64_t zstrideA, int64_t zstrideD) {
   extern __shared__ __attribute__((aligned(16))) double ts_lds[];
+  A21 += (int64_t)blockIdx.y * zstrideA;      // blockIdx.y = matrix of the class batch
+  L11 += (int64_t)blockIdx.y * zstrideA;
+  gx += (int64_t)blockIdx.y * zstrideD;
   double* T = ts_lds;                                  // TS_R x TS_TLD; columns of block J double as S
   double* Lb = T + TS_R * TS_TLD;                      // 6 blocks L11[J, I] (I < J), each 32 x TS_BLD, [c][k]
   double* Xb = Lb + 6 * 32 * TS_BLD;                   // 4 blocks X_JJ, each 32 x TS_BLD, [c][k], zero above the diagonal
@@ -359,8 +366,10 @@ constexpr int TS_LDS_BYTES = (TS_R * TS_TLD + 10 * 32 * TS_BLD) * (int)sizeof(do
 // ---------------------------------------------------------------- small utility kernels
 __global__ __launch_bounds__(256) void transpose_f64_kernel(const double* __restrict__ src, int64_t lds_,
                                                             double* __restrict__ dst, int64_t ldd, int64_t rows,
-                                                            int64_t cols) {
+                                                            int64_t cols, int64_t zstride_src, int64_t zstride_dst) {
   __shared__ double tile[32][33];
+  src += (int64_t)blockIdx.z * zstride_src;
+  dst += (int64_t)blockIdx.z * zstride_dst;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
 #pragma unroll
@@ -376,7 +385,9 @@ __global__ __launch_bounds__(256) void transpose_f64_kernel(const double* __rest
   }
 }
 
-__global__ __launch_bounds__(256) void add_diag_f64_kernel(double* A, int64_t lda, int64_t M, double value) {
+__global__ __launch_bounds__(256) void add_diag_f64_kernel(double* A, int64_t lda, int64_t M, double value,
+                                                           int64_t zstride) {
+  A += (int64_t)blockIdx.y * zstride;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < M) A[i * lda + i] += value;
 }
@@ -399,7 +410,11 @@ __global__ __launch_bounds__(256) void convert_kernel(const S* __restrict__ src,
 // copies the NB x NB diagonal inverses onto the diagonals of Li (as is) and Lit (transposed)
 __global__ __launch_bounds__(256) void place_diag_inverses_kernel(const double* __restrict__ Dinv, int nb,
                                                                   int64_t M, double* __restrict__ Li,
-                                                                  double* __restrict__ Lit, int64_t ld) {
+                                                                  double* __restrict__ Lit, int64_t ld,
+                                                                  int64_t zstrideD, int64_t zstrideO) {
+  Dinv += (int64_t)blockIdx.z * zstrideD;
+  Li += (int64_t)blockIdx.z * zstrideO;
+  Lit += (int64_t)blockIdx.z * zstrideO;
   const int b = blockIdx.y;
   const int64_t r0 = (int64_t)b * nb;
   const double* D = Dinv + (int64_t)b * nb * nb;
@@ -458,18 +473,20 @@ __global__ __launch_bounds__(256) void trmv_f64_kernel(const double* __restrict_
 
 // ---------------------------------------------------------------- host drivers
 int transpose_f64(const double* src, int64_t lds_, double* dst, int64_t ldd, int64_t rows, int64_t cols,
-                  hipStream_t stream) {
-  if (rows <= 0 || cols <= 0) return ODX_OK;
-  dim3 grid((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows, 32));
-  ODX_REQUIRE(grid.y < 65536, "transpose_f64: too many rows");
-  hipLaunchKernelGGL(transpose_f64_kernel, grid, dim3(256), 0, stream, src, lds_, dst, ldd, rows, cols);
+                  hipStream_t stream, int zcount, int64_t zstride_src, int64_t zstride_dst) {
+  if (rows <= 0 || cols <= 0 || zcount <= 0) return ODX_OK;
+  dim3 grid((unsigned)ceil_div(cols, 32), (unsigned)ceil_div(rows, 32), (unsigned)zcount);
+  ODX_REQUIRE(grid.y < 65536 && zcount < 65536, "transpose_f64: too many rows");
+  hipLaunchKernelGGL(transpose_f64_kernel, grid, dim3(256), 0, stream, src, lds_, dst, ldd, rows, cols, zstride_src,
+                     zstride_dst);
   ODX_CHECK_LAUNCH("transpose_f64");
   return ODX_OK;
 }
 
-int add_diag_f64(double* A, int64_t lda, int64_t M, double value, hipStream_t stream) {
-  if (M <= 0) return ODX_OK;
-  hipLaunchKernelGGL(add_diag_f64_kernel, dim3((unsigned)ceil_div(M, 256)), dim3(256), 0, stream, A, lda, M, value);
+int add_diag_f64(double* A, int64_t lda, int64_t M, double value, hipStream_t stream, int zcount, int64_t zstride) {
+  if (M <= 0 || zcount <= 0) return ODX_OK;
+  hipLaunchKernelGGL(add_diag_f64_kernel, dim3((unsigned)ceil_div(M, 256), (unsigned)zcount), dim3(256), 0, stream, A,
+                     lda, M, value, zstride);
   ODX_CHECK_LAUNCH("add_diag_f64");
   return ODX_OK;
 }
@@ -489,8 +506,11 @@ int fill_f64(double* A, int64_t lda, int64_t rows, int64_t cols, double value, h
 
 // 128 x 128 inverses of all diagonal blocks of a lower-triangular L, one workgroup per block.
 __global__ __launch_bounds__(DB_NT) void trtri_diag_kernel(const double* __restrict__ L, int64_t ldl, int64_t M,
-                                                          double* __restrict__ Dinv) {
+                                                          double* __restrict__ Dinv, int64_t zstrideA,
+                                                          int64_t zstrideD) {
   __shared__ double s[DB_NB * DB_LD];
+  L += (int64_t)blockIdx.y * zstrideA;
+  Dinv += (int64_t)blockIdx.y * zstrideD;
   __shared__ double xi[32 * DB_XLD];
   const int64_t r0 = (int64_t)blockIdx.x * DB_NB;
   const int jb = (int)(M - r0 < DB_NB ? M - r0 : DB_NB);
@@ -559,9 +579,15 @@ static int side_stream(SideStream** out, int slot, hipStream_t caller) {
 //                                           per 512 columns instead of per 128, MFMA-bound)
 constexpr int POTRF_NBO = 512;
 
-int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hipStream_t stream) {
+int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hipStream_t stream, const ZBatch& zb) {
   constexpr int NB = POTRF_NB;
   ODX_REQUIRE(lda % 2 == 0 && aligned16(A) && aligned16(Dinv), "potrf_f64: A/Dinv must be 16-byte aligned, lda even");
+  const int Z = zb.count;
+  ODX_REQUIRE(Z >= 1 && Z <= ODX_MAX_ZBATCH && zb.strideA % 2 == 0 && zb.strideD % 2 == 0,
+              "potrf_f64: class batch of 1..%d matrices, even strides", ODX_MAX_ZBATCH);
+  auto zgemm = [&](GemmParams<double>& g) {      // the same product for every matrix of the class batch
+    g.zbatches = Z; g.zstrideA = zb.strideA; g.zstrideB = zb.strideA; g.zstrideC = zb.strideA;
+  };
   ODX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     TS_LDS_BYTES));
   SideStream* look = nullptr;
@@ -572,20 +598,21 @@ int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hi
     for (int64_t k0 = K0; k0 < K0 + kbo; k0 += NB) {
       const int jb = (int)(M - k0 < NB ? M - k0 : NB);
       double* D = Dinv + (k0 / NB) * NB * NB;
-      hipLaunchKernelGGL((potrf_diag_kernel<NB, false>), dim3(1), dim3(DB_NT), 0, stream, A + k0 * lda + k0, lda, jb, D,
-                         info, (int)k0);
+      hipLaunchKernelGGL((potrf_diag_kernel<NB, false>), dim3((unsigned)Z), dim3(DB_NT), 0, stream, A + k0 * lda + k0, lda,
+                         jb, D, info, (int)k0, zb.strideA, zb.strideD);
       ODX_CHECK_LAUNCH("potrf_diag");
       const int64_t m = M - k0 - jb;
       if (m <= 0) break;
       double* A21 = A + (k0 + jb) * lda + k0;
-      hipLaunchKernelGGL(trsm128_kernel, dim3((unsigned)ceil_div(m, TS_R)), dim3(256), TS_LDS_BYTES, stream, A21, lda, m,
-                         A + k0 * lda + k0, D + NB * NB - 4096);
+      hipLaunchKernelGGL(trsm128_kernel, dim3((unsigned)ceil_div(m, TS_R), (unsigned)Z), dim3(256), TS_LDS_BYTES, stream,
+                         A21, lda, m, A + k0 * lda + k0, D + NB * NB - 4096, zb.strideA, zb.strideD);
       ODX_CHECK_LAUNCH("trsm128");
       const int64_t pc = (K0 + kbo) - (k0 + jb);  // panel columns right of this block
       if (pc > 0) {
         GemmParams<double> u;
         u.A = A21; u.lda = lda; u.B = A21; u.ldb = lda; u.C = A + (k0 + jb) * lda + (k0 + jb); u.ldc = lda;
         u.m = m; u.n = pc; u.k = jb; u.alpha = -1.0; u.beta = 1.0; u.flags = ODX_GEMM_LOWER_ONLY;
+        zgemm(u);
         ODX_PROPAGATE(launch_gemm_f64(u, stream));
       }
     }
@@ -604,6 +631,7 @@ int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hi
       GemmParams<double> u;
       u.A = P; u.lda = lda; u.B = P; u.ldb = lda; u.C = A + (K0 + kbo) * (lda + 1); u.ldc = lda;
       u.m = mt; u.n = nw; u.k = kbo; u.alpha = -1.0; u.beta = 1.0; u.flags = ODX_GEMM_LOWER_ONLY;
+      zgemm(u);
       ODX_PROPAGATE(launch_gemm_f64(u, stream));
       const int64_t mr = mt - nw;
       if (mr > 0) {
@@ -613,6 +641,7 @@ int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hi
         GemmParams<double> r;
         r.A = P2; r.lda = lda; r.B = P2; r.ldb = lda; r.C = A + (K0 + kbo + nw) * (lda + 1); r.ldc = lda;
         r.m = mr; r.n = mr; r.k = kbo; r.alpha = -1.0; r.beta = 1.0; r.flags = ODX_GEMM_LOWER_ONLY;
+        zgemm(r);
         ODX_PROPAGATE(launch_gemm_f64(r, look->stream));
         ODX_CHECK_HIP(hipEventRecord(look->join, look->stream));
         pending = true;
@@ -621,7 +650,8 @@ int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hi
   }
   if (pending) ODX_CHECK_HIP(hipStreamWaitEvent(stream, look->join, 0));
   // Dinv: the 128 x 128 inverses of all diagonal blocks in one batched launch (off the block-by-block critical path)
-  hipLaunchKernelGGL(trtri_diag_kernel, dim3((unsigned)ceil_div(M, NB)), dim3(DB_NT), 0, stream, A, lda, M, Dinv);
+  hipLaunchKernelGGL(trtri_diag_kernel, dim3((unsigned)ceil_div(M, NB), (unsigned)Z), dim3(DB_NT), 0, stream, A, lda, M,
+                     Dinv, zb.strideA, zb.strideD);
   ODX_CHECK_LAUNCH("trtri_diag");
   return ODX_OK;
 }
@@ -632,12 +662,15 @@ int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hi
 //   GEMM 2:  X21 = -X22 WT'         A = X22 (lower), B = WT;  X21 -> Li, X21' -> Lit
 // Li and Lit must be zero on entry outside what is written here.  WT: >= M*M doubles.
 int trtri_from_diag_f64(const double* L, int64_t ldl, int64_t M, const double* Dinv, double* Li, double* Lit,
-                        int64_t ld, double* WT, hipStream_t stream) {
+                        int64_t ld, double* WT, hipStream_t stream, const ZBatch& zb) {
   constexpr int NB = POTRF_NB;
   ODX_REQUIRE(ld % 2 == 0 && ldl % 2 == 0, "trtri_f64: leading dimensions must be even");
+  const int Z = zb.count;
+  ODX_REQUIRE(Z >= 1 && Z <= ODX_MAX_ZBATCH && zb.strideA % 2 == 0 && zb.strideO % 2 == 0 && zb.strideW % 2 == 0,
+              "trtri_f64: class batch of 1..%d matrices, even strides", ODX_MAX_ZBATCH);
   const int nblk = (int)ceil_div(M, NB);
-  hipLaunchKernelGGL(place_diag_inverses_kernel, dim3(16, (unsigned)nblk), dim3(256), 0, stream, Dinv, NB, M, Li,
-                     Lit, ld);
+  hipLaunchKernelGGL(place_diag_inverses_kernel, dim3(16, (unsigned)nblk, (unsigned)Z), dim3(256), 0, stream, Dinv, NB, M,
+                     Li, Lit, ld, zb.strideD, zb.strideO);
   ODX_CHECK_LAUNCH("place_diag_inverses");
   for (int64_t s = NB; s < M; s *= 2) {
     const int nb = (int)ceil_div(M, 2 * s);  // pairs; the last may be ragged or empty
@@ -650,6 +683,7 @@ int trtri_from_diag_f64(const double* L, int64_t ldl, int64_t M, const double* D
     g1.batches = nb;
     g1.strideA = 2 * s * (ldl + 1); g1.strideB = 2 * s * (ld + 1); g1.strideC = s * s;
     g1.ragged_total = M; g1.ragged_off = s; g1.ragged_step = 2 * s;
+    g1.zbatches = Z; g1.zstrideA = zb.strideA; g1.zstrideB = zb.strideO; g1.zstrideC = zb.strideW;
     ODX_PROPAGATE(launch_gemm_f64(g1, stream));
     GemmParams<double> g2;
     g2.A = Li + s * (ld + 1); g2.lda = ld;             // X22 of pair 0
@@ -661,6 +695,7 @@ int trtri_from_diag_f64(const double* L, int64_t ldl, int64_t M, const double* D
     g2.batches = nb;
     g2.strideA = 2 * s * (ld + 1); g2.strideB = s * s; g2.strideC = 2 * s * (ld + 1); g2.strideC2 = 2 * s * (ld + 1);
     g2.ragged_total = M; g2.ragged_off = s; g2.ragged_step = 2 * s; g2.ragged_k_is_m = 1;
+    g2.zbatches = Z; g2.zstrideA = zb.strideO; g2.zstrideB = zb.strideW; g2.zstrideC = zb.strideO; g2.zstrideC2 = zb.strideO;
     ODX_PROPAGATE(launch_gemm_f64(g2, stream));
   }
   return ODX_OK;
@@ -743,7 +778,8 @@ extern "C" int odx_trtri_f64(const double* L, int64_t ldl, int64_t M, double* Li
   hipStream_t s = as_stream(stream);
   double* Dinv = static_cast<double*>(workspace);
   double* WT = Dinv + ceil_div(M, POTRF_NB) * POTRF_NB * POTRF_NB;
-  hipLaunchKernelGGL(trtri_diag_kernel, dim3((unsigned)ceil_div(M, POTRF_NB)), dim3(DB_NT), 0, s, L, ldl, M, Dinv);
+  hipLaunchKernelGGL(trtri_diag_kernel, dim3((unsigned)ceil_div(M, POTRF_NB)), dim3(DB_NT), 0, s, L, ldl, M, Dinv,
+                     (int64_t)0, (int64_t)0);
   ODX_CHECK_LAUNCH("trtri_diag");
   ODX_PROPAGATE(fill_f64(Li, ld, M, M, 0.0, s));
   ODX_PROPAGATE(fill_f64(Lit, ld, M, M, 0.0, s));
@@ -826,4 +862,98 @@ extern "C" int odx_falkon_precond_f64(const float* Z, int64_t ldz, int64_t M, in
   ODX_PROPAGATE(fill_f64(LAit, ld, M, M, 0.0, s));
   ODX_PROPAGATE(trtri_from_diag_f64(W2, wld, M, DinvA, LAi, LAit, ld, W1, s));
   return ODX_OK;
+}
+
+// ---------------------------------------------------------------- FALKON preconditioners of a class batch
+// The same computation as odx_falkon_precond_f64 for B independent classes at once: every kernel of the two blocked
+// Choleskys, the T T' product and the two triangular inverses takes the class as one more grid dimension, so the
+// ~1500-launch dependent chain of ONE preconditioner advances all B of them (the chain is latency-bound: per 128-column
+// block a one-workgroup diagonal factorisation, a panel solve and a rank-128 update — B classes fill B times as much of
+// the chip per launch).  Classes may have different numbers of centres M_b <= Mmax: matrix b is K_MM_b bordered with an
+// identity block up to Mmax, whose Cholesky factor / inverse is the bordered factor / inverse — the leading M_b x M_b
+// blocks of the outputs are what the single-class call produces (same block boundaries, the padding only adds exact
+// zeros to the sums), and the CG reads only those.
+// workspace: per class  Zd (Mmax x ldzd) | zsq (Mmax, padded)   then   W0[B] | W1[B] | W2[B] | W3[B] | DinvT[B] | DinvA[B]
+extern "C" int64_t odx_falkon_precond_batched_workspace_bytes(int64_t Mmax, int D, int B) {
+  if (Mmax <= 0 || D <= 0 || B <= 0) return 0;
+  const int64_t ld = precond_ld(Mmax), ldzd = round_up(D, 2);
+  const int64_t per = Mmax * ldzd + round_up(Mmax, 2) + 4 * Mmax * ld + 2 * ceil_div(Mmax, POTRF_NB) * POTRF_NB * POTRF_NB;
+  return per * B * (int64_t)sizeof(double);
+}
+
+extern "C" int odx_falkon_precond_batched_f64(const float* const* Z, const int64_t* ldz, const int64_t* M, int B,
+                                              int64_t Mmax, int D, double sigma, double lam, double eps, double* out,
+                                              int64_t ld, int64_t out_stride, int32_t* info, void* workspace,
+                                              int64_t workspace_bytes, odx_stream_t stream) {
+  ODX_REQUIRE(B >= 1 && B <= ODX_MAX_ZBATCH, "odx_falkon_precond_batched_f64: 1 <= B <= %d classes per call", ODX_MAX_ZBATCH);
+  ODX_REQUIRE(Z && ldz && M && out && info && workspace && Mmax > 0 && D > 0 && sigma > 0,
+              "odx_falkon_precond_batched_f64: null pointer or bad size");
+  ODX_REQUIRE(ld % 2 == 0 && ld >= Mmax && aligned16(out) && out_stride % 2 == 0 && out_stride >= 4 * Mmax * ld,
+              "odx_falkon_precond_batched_f64: out must be 16-byte aligned, ld even >= Mmax, out_stride >= 4 Mmax ld");
+  ODX_REQUIRE(aligned16(workspace), "odx_falkon_precond_batched_f64: workspace must be 16-byte aligned");
+  for (int b = 0; b < B; ++b)
+    ODX_REQUIRE(Z[b] && M[b] > 0 && M[b] <= Mmax, "odx_falkon_precond_batched_f64: class %d: need 0 < M <= Mmax", b);
+  if (workspace_bytes < odx_falkon_precond_batched_workspace_bytes(Mmax, D, B)) {
+    set_error("odx_falkon_precond_batched_f64: workspace too small");
+    return ODX_ERR_WORKSPACE;
+  }
+  hipStream_t s = as_stream(stream);
+  SideStream* side = nullptr;
+  ODX_PROPAGATE(side_stream(&side, 0, s));
+  hipStream_t s2 = side->stream;
+  const int64_t wld = precond_ld(Mmax), ldzd = round_up(D, 2);
+  const int64_t dsz = ceil_div(Mmax, POTRF_NB) * POTRF_NB * POTRF_NB;
+  const int64_t zper = Mmax * ldzd + round_up(Mmax, 2), wsz = Mmax * wld;
+  double* Zd0 = static_cast<double*>(workspace);
+  double* W0 = Zd0 + (int64_t)B * zper;
+  double* W1 = W0 + (int64_t)B * wsz;
+  double* W2 = W1 + (int64_t)B * wsz;
+  double* W3 = W2 + (int64_t)B * wsz;
+  double* DinvT = W3 + (int64_t)B * wsz;
+  double* DinvA = DinvT + (int64_t)B * dsz;
+  double* LTi = out, *LTit = out + Mmax * ld, *LAi = out + 2 * Mmax * ld, *LAit = out + 3 * Mmax * ld;
+
+  ODX_CHECK_HIP(hipMemsetAsync(info, 0, (size_t)B * sizeof(int32_t), s));
+  ODX_CHECK_HIP(hipMemsetAsync(Zd0, 0, (size_t)((int64_t)B * zper) * sizeof(double), s));
+  ODX_CHECK_HIP(hipMemsetAsync(W0, 0, (size_t)(3 * (int64_t)B * wsz) * sizeof(double), s));      // W0, W1, W2
+  // W0_b = [K_MM_b + eps M_b I, 0; 0, I]  (lower)
+  for (int b = 0; b < B; ++b) {
+    double* Zd = Zd0 + (int64_t)b * zper;
+    ODX_PROPAGATE(odx_convert_f32_f64(Z[b], ldz[b], Zd, ldzd, M[b], D, stream));
+    ODX_PROPAGATE(gauss_kmm_f64(Zd, ldzd, M[b], D, sigma, eps * (double)M[b], W0 + (int64_t)b * wsz, wld, Zd + Mmax * ldzd, s));
+    if (M[b] < Mmax) ODX_PROPAGATE(add_diag_f64(W0 + (int64_t)b * wsz + M[b] * (wld + 1), wld, Mmax - M[b], 1.0, s));
+  }
+  ZBatch zt;
+  zt.count = B; zt.strideA = wsz; zt.strideD = dsz; zt.strideO = out_stride; zt.strideW = wsz;
+  ODX_PROPAGATE(potrf_f64(W0, wld, Mmax, DinvT, info, s, zt));
+  // fork: inverses of all L_T on the side stream (scratch W3)
+  ODX_CHECK_HIP(hipEventRecord(side->fork, s));
+  ODX_CHECK_HIP(hipStreamWaitEvent(s2, side->fork, 0));
+  for (int b = 0; b < B; ++b) {
+    ODX_PROPAGATE(fill_f64(LTi + (int64_t)b * out_stride, ld, Mmax, Mmax, 0.0, s2));
+    ODX_PROPAGATE(fill_f64(LTit + (int64_t)b * out_stride, ld, Mmax, Mmax, 0.0, s2));
+  }
+  ODX_PROPAGATE(trtri_from_diag_f64(W0, wld, Mmax, DinvT, LTi, LTit, ld, W3, s2, zt));
+  ODX_CHECK_HIP(hipEventRecord(side->join, s2));
+  // main: W1 = L_T' = T; W2 = T T' / M_b + lam I; L_A in place in W2
+  ODX_PROPAGATE(transpose_f64(W0, wld, W1, wld, Mmax, Mmax, s, B, wsz, wsz));
+  {
+    GemmParams<double> g;
+    g.A = W1; g.lda = wld; g.B = W1; g.ldb = wld; g.C = W2; g.ldc = wld;
+    g.m = Mmax; g.n = Mmax; g.k = Mmax; g.beta = 0.0;
+    g.flags = ODX_GEMM_LOWER_ONLY | ODX_GEMM_A_UPPER | ODX_GEMM_B_UPPER;
+    g.zbatches = B; g.zstrideA = wsz; g.zstrideB = wsz; g.zstrideC = wsz;
+    g.zalpha_on = 1;
+    for (int b = 0; b < B; ++b) g.zalpha[b] = 1.0 / (double)M[b];
+    ODX_PROPAGATE(launch_gemm_f64(g, s));
+  }
+  ODX_PROPAGATE(add_diag_f64(W2, wld, Mmax, lam, s, B, wsz));
+  ODX_PROPAGATE(potrf_f64(W2, wld, Mmax, DinvA, info, s, zt));
+  // join, then the inverses of L_A (scratch W1: T is no longer needed)
+  ODX_CHECK_HIP(hipStreamWaitEvent(s, side->join, 0));
+  for (int b = 0; b < B; ++b) {
+    ODX_PROPAGATE(fill_f64(LAi + (int64_t)b * out_stride, ld, Mmax, Mmax, 0.0, s));
+    ODX_PROPAGATE(fill_f64(LAit + (int64_t)b * out_stride, ld, Mmax, Mmax, 0.0, s));
+  }
+  return trtri_from_diag_f64(W2, wld, Mmax, DinvA, LAi, LAit, ld, W1, s, zt);
 }

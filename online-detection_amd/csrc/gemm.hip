@@ -40,10 +40,12 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 8 && BN == 64) ? 3 : 1)
   if (p.flags & ODX_GEMM_B_LOWER) ke = min(ke, j0 + BN);
   kb = (kb / Tr::BK) * Tr::BK;
 
-  const T* A = p.A + (int64_t)b * p.strideA;
-  const T* B = p.B + (int64_t)b * p.strideB;
-  T* C = p.C + (int64_t)b * p.strideC;
-  T* C2 = p.C2 ? p.C2 + (int64_t)b * p.strideC2 : nullptr;
+  const int z = blockIdx.z;
+  const T* A = p.A + (int64_t)b * p.strideA + (int64_t)z * p.zstrideA;
+  const T* B = p.B + (int64_t)b * p.strideB + (int64_t)z * p.zstrideB;
+  T* C = p.C + (int64_t)b * p.strideC + (int64_t)z * p.zstrideC;
+  T* C2 = p.C2 ? p.C2 + (int64_t)b * p.strideC2 + (int64_t)z * p.zstrideC2 : nullptr;
+  const T alpha = p.zalpha_on ? p.zalpha[z] : p.alpha;
 
   typename Tr::Acc acc[Tr::TM][TN];
   gemm_zero_acc<T>(acc);
@@ -109,15 +111,15 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 8 && BN == 64) ? 3 : 1)
             if (variant == 0 && has_beta) {
               const VecT c = *reinterpret_cast<const VecT*>(g);
 #pragma unroll
-              for (int q = 0; q < EPV; ++q) o[q] = p.alpha * v[q] + p.beta * c[q];
+              for (int q = 0; q < EPV; ++q) o[q] = alpha * v[q] + p.beta * c[q];
             } else {
 #pragma unroll
-              for (int q = 0; q < EPV; ++q) o[q] = p.alpha * v[q];
+              for (int q = 0; q < EPV; ++q) o[q] = alpha * v[q];
             }
             *reinterpret_cast<VecT*>(g) = o;
           } else {
             for (int q = 0; q < EPV && gb + q < blim; ++q) {
-              T o = p.alpha * v[q];
+              T o = alpha * v[q];
               if (variant == 0 && has_beta) o += p.beta * g[q];
               g[q] = o;
             }
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 8 && BN == 64) ? 3 : 1)
         const int64_t row = i0 + wr * 64 + gemm_acc_row<T>(tm, r, lane);
         const int64_t col = j0 + wc * (BN / 2) + gemm_acc_col<T>(tn, lane);
         if (row < m && col < n) {
-          T val = p.alpha * acc[tm][tn][r];
+          T val = alpha * acc[tm][tn][r];
           if (has_beta) val += p.beta * cv[tn][r];
           C[st ? col * p.ldc + row : row * p.ldc + col] = val;
           if (C2) C2[col * p.ldc2 + row] = val;
@@ -175,10 +177,12 @@ static int launch_gemm(const GemmParams<T>& p, hipStream_t stream, const char* n
   const int bn = narrow ? 64 : GEMM_BN;
   const int64_t tiles = 8 * ceil_div(ceil_div(p.m, GEMM_BM), 8) * ceil_div(p.n, bn);
   ODX_REQUIRE(tiles < (1ll << 31) && p.batches < 65536, "%s: grid too large", name);
-  dim3 grid((unsigned)tiles, (unsigned)p.batches, 1);
+  ODX_REQUIRE(p.zbatches >= 1 && p.zbatches <= ODX_MAX_ZBATCH, "%s: 1 <= zbatches <= %d", name, ODX_MAX_ZBATCH);
+  ODX_REQUIRE(p.zstrideA % EPV == 0 && p.zstrideB % EPV == 0, "%s: class strides must keep 16-byte alignment", name);
+  dim3 grid((unsigned)tiles, (unsigned)p.batches, (unsigned)p.zbatches);
   GemmParams<T> q = p;
-  q.vec_epilogue = aligned16(p.C) && p.ldc % EPV == 0 && p.strideC % EPV == 0 &&
-                   (p.C2 == nullptr || (aligned16(p.C2) && p.ldc2 % EPV == 0 && p.strideC2 % EPV == 0));
+  q.vec_epilogue = aligned16(p.C) && p.ldc % EPV == 0 && p.strideC % EPV == 0 && p.zstrideC % EPV == 0 &&
+                   (p.C2 == nullptr || (aligned16(p.C2) && p.ldc2 % EPV == 0 && p.strideC2 % EPV == 0 && p.zstrideC2 % EPV == 0));
   if (!narrow) hipLaunchKernelGGL((gemm_nt_kernel<T, GEMM_BN>), grid, dim3(GEMM_THREADS), 0, stream, q);
   else hipLaunchKernelGGL((gemm_nt_kernel<T, 64>), grid, dim3(GEMM_THREADS), 0, stream, q);
   ODX_CHECK_LAUNCH(name);

@@ -4,6 +4,8 @@
 
 namespace odx {
 
+constexpr int ODX_MAX_ZBATCH = 32;    // classes per batched launch (kernel-argument arrays are sized by it)
+
 template <typename T>
 struct GemmParams {
   const T* A = nullptr; int64_t lda = 0;
@@ -20,6 +22,12 @@ struct GemmParams {
   int64_t ragged_total = 0, ragged_off = 0, ragged_step = 0;
   int ragged_k_is_m = 0;               // k_b = m_b (GEMM 2 of a trtri level)
   int vec_epilogue = 0;                // set by the launcher: C (and C2) allow 16-byte accesses
+  // second batch dimension over blockIdx.z: the same product for `zbatches` independent matrices (the classes of a
+  // batched preconditioner), operands zstride* elements apart, each with its own alpha (zalpha[z], when zalpha_on)
+  int zbatches = 1;
+  int64_t zstrideA = 0, zstrideB = 0, zstrideC = 0, zstrideC2 = 0;
+  int zalpha_on = 0;
+  T zalpha[ODX_MAX_ZBATCH] = {};
 };
 
 int launch_gemm_f64(const GemmParams<double>& p, hipStream_t stream);
@@ -27,13 +35,22 @@ int launch_gemm_f32(const GemmParams<float>& p, hipStream_t stream);
 
 // dense_f64.hip
 constexpr int POTRF_NB = 128;
-int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv /* nblk x NB x NB */, int32_t* info,
-              hipStream_t stream);
+// A class batch: `count` matrices of identical shape, `stride*` elements apart (count = 1: the plain single-matrix call).
+// Every kernel of the factorisation takes the batch as one more grid dimension, so one launch advances all classes.
+struct ZBatch {
+  int count = 1;
+  int64_t strideA = 0;      // between the matrices being factored / inverted
+  int64_t strideD = 0;      // between their Dinv blocks
+  int64_t strideO = 0;      // between their outputs (Li / Lit)
+  int64_t strideW = 0;      // between their scratch (WT)
+};
+int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv /* nblk x NB x NB */, int32_t* info /* one per matrix */,
+              hipStream_t stream, const ZBatch& zb = ZBatch());
 int trtri_from_diag_f64(const double* L, int64_t ldl, int64_t M, const double* Dinv, double* Li, double* Lit,
-                        int64_t ld, double* WT, hipStream_t stream);
+                        int64_t ld, double* WT, hipStream_t stream, const ZBatch& zb = ZBatch());
 int transpose_f64(const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols,
-                  hipStream_t stream);
-int add_diag_f64(double* A, int64_t lda, int64_t M, double value, hipStream_t stream);
+                  hipStream_t stream, int zcount = 1, int64_t zstride_src = 0, int64_t zstride_dst = 0);
+int add_diag_f64(double* A, int64_t lda, int64_t M, double value, hipStream_t stream, int zcount = 1, int64_t zstride = 0);
 int fill_f64(double* A, int64_t lda, int64_t rows, int64_t cols, double value, hipStream_t stream);
 
 // knm_pass.hip: out[j] = sum_g slab[g][j], g = 0 .. nslab - 1, in a fixed order

@@ -147,6 +147,42 @@ class HipBackend:
                                                   _p(ws), ws.numel(), self._stream()), "odx_falkon_precond_f64")
         return P
 
+    MAX_CLASS_BATCH = 32        # ODX_MAX_ZBATCH of libodx
+
+    def precond_batched(self, Zfs, sigma, lam, eps, out=None, ws_key="precond_batched"):
+        """The preconditioners of len(Zfs) <= 32 independent classes with ONE chain of launches
+        (odx_falkon_precond_batched_f64): returns one Precond per class, views into a shared (B, 4, Mmax, ld) f64 block
+        (`out` when given) whose leading M_b x M_b blocks equal, bit for bit, what precond() makes for that class."""
+        B = len(Zfs)
+        if not 1 <= B <= self.MAX_CLASS_BATCH:
+            raise ValueError("precond_batched: 1..%d classes per call, got %d" % (self.MAX_CLASS_BATCH, B))
+        D = Zfs[0].D
+        if any(z.D != D for z in Zfs):
+            raise ValueError("precond_batched: every class needs the same feature dimension")
+        Ms = [int(z.n) for z in Zfs]
+        Mmax = max(Ms)
+        ld = (Mmax + 1) // 2 * 2
+        if out is None:
+            out = torch.empty((B, 4, Mmax, ld), dtype=torch.float64, device=self.device)
+        if out.dtype != torch.float64 or out.dim() != 4 or out.shape[0] < B or tuple(out.shape[1:]) != (4, Mmax, ld) or not out.is_contiguous():
+            raise ValueError("precond_batched: out must be a contiguous (>= %d, 4, %d, %d) f64 tensor" % (B, Mmax, ld))
+        info = torch.zeros(B, dtype=torch.int32, device=self.device)
+        ws = self._workspace(ws_key, self.lib.odx_falkon_precond_batched_workspace_bytes(Mmax, D, B))
+        zp = (ctypes.c_void_p * B)(*[z.X.data_ptr() for z in Zfs])
+        zl = (ctypes.c_int64 * B)(*[int(z.ld) for z in Zfs])
+        zm = (ctypes.c_int64 * B)(*Ms)
+        hip.check(self.lib.odx_falkon_precond_batched_f64(zp, zl, zm, B, Mmax, D, float(sigma), float(lam), float(eps), _p(out), ld,
+                                                          4 * Mmax * ld, _p(info), _p(ws), ws.numel(), self._stream()),
+                  "odx_falkon_precond_batched_f64")
+        Ps = []
+        for b, M in enumerate(Ms):
+            P = Precond()
+            P.M, P.ld = M, ld
+            P.LTi, P.LTit, P.LAi, P.LAit = (out[b, k, :M] for k in range(4))
+            P.info = info[b:b + 1]
+            Ps.append(P)
+        return Ps
+
     def check_precond(self, P):
         self.check_info(P.info)
 
@@ -223,6 +259,28 @@ class HipBackend:
         hip.check(self.lib.odx_knm_fwd_bwd(_p(K.K), K.ld, K.n, K.M, _p(v), _p(w), _p(out), _p(ws), ws.numel(),
                                            self._stream()), "odx_knm_fwd_bwd")
         return out
+
+    def can_ktk2(self, K):
+        """Whether the two-vector pass exists at this block's width (both vectors must fit in LDS: M <= 10 000)."""
+        return self.lib.odx_knm_fwd_bwd2_workspace_bytes(max(K.n, 1), K.M) >= 0
+
+    def ktk2(self, K, v1, v2, out1=None, out2=None):
+        """out1 = K' (K v1), out2 = K' (K v2) over this shard from ONE read of K (odx_knm_fwd_bwd2)."""
+        if out1 is None:
+            out1 = torch.empty(K.M, dtype=torch.float64, device=self.device)
+        if out2 is None:
+            out2 = torch.empty(K.M, dtype=torch.float64, device=self.device)
+        nbytes = self.lib.odx_knm_fwd_bwd2_workspace_bytes(max(K.n, 1), K.M)
+        if nbytes < 0:
+            raise hip.OdxError("odx_knm_fwd_bwd2: M = %d is outside the two-vector configurations" % K.M)
+        ws = self._workspace("ktk", nbytes)
+        hip.check(self.lib.odx_knm_fwd_bwd2(_p(K.K), K.ld, K.n, K.M, _p(v1), _p(v2), _p(out1), _p(out2), _p(ws), ws.numel(),
+                                            self._stream()), "odx_knm_fwd_bwd2")
+        return out1, out2
+
+    def cg_residual(self, B, AX, AP, state, R):
+        """R = B - (AX + a AP), a = the step cg_step has just taken (state[3])."""
+        hip.check(self.lib.odx_cg_residual(_p(B), _p(AX), _p(AP), _p(state), _p(R), R.numel(), self._stream()), "odx_cg_residual")
 
     def cg_solve(self, K, P, b0, n_total, lam, maxiter, opt):
         """The CG loop of an unsharded fit in one library call (odx_falkon_cg_f64); returns alpha (M,) f64."""

@@ -49,8 +49,13 @@ SIGNATURES = {
     "odx_knm_fwd_bwd_workspace_bytes": (_i64, [_i64, _i64]),
     "odx_set_pass_reserved_cus": (_i32, [_i32]),
     "odx_knm_fwd_bwd": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "odx_knm_fwd_bwd2_workspace_bytes": (_i64, [_i64, _i64]),
+    "odx_knm_fwd_bwd2": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "odx_cg_residual": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "odx_falkon_precond_workspace_bytes": (_i64, [_i64, _i32]),
     "odx_falkon_precond_f64": (_i32, [_vp, _i64, _i64, _i32, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),
+    "odx_falkon_precond_batched_workspace_bytes": (_i64, [_i64, _i32, _i32]),
+    "odx_falkon_precond_batched_f64": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _f64, _f64, _f64, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
     "odx_trmv_f64": (_i32, [_vp, _i64, _i64, _i32, _vp, _f64, _f64, _vp, _vp, _vp]),
     "odx_cg_init": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "odx_cg_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _f64, _i32, _i64, _vp]),

@@ -13,6 +13,8 @@ step sizes, residual norms and the stop flag stay on the device.
 """
 from dataclasses import dataclass
 
+import torch
+
 
 @dataclass
 class SolverOptions:
@@ -59,6 +61,13 @@ class _NoPhase:
 
     def __exit__(self, *exc):
         return False
+
+
+def _can_fold(be, K, M, rows_per_rank):
+    """The two-vector pass exists for this block width and pays for itself: a pass reads 4 n M bytes, the second vector's
+    four extra triangular products 16 M^2.  Decided from quantities every rank agrees on (M and the job's rows per rank),
+    never from the local shard length, so that all ranks issue the same collectives."""
+    return bool(hasattr(be, "ktk2") and be.can_ktk2(K) and rows_per_rank >= 8 * M)
 
 
 def falkon_fit(be, F, y, Zf, sigma, lam, maxiter=20, opt=None, n_total=None, allreduce=None, knm_out=None,
@@ -126,6 +135,37 @@ def falkon_fit(be, F, y, Zf, sigma, lam, maxiter=20, opt=None, n_total=None, all
             u = be.trmv(P, "LTi", cc, alpha=1.0 / n, beta=lam, z=v)   # T^-T cc / n + lam v
             be.trmv(P, "LAi", u, out=out)              # A^-T u
 
+    # The periodic full residual R = B - W x (falkon: every cg_full_gradient_every-th step) without a pass of its own:
+    # W is linear and x_new = x_old + a p, so W x_new = W x_old + a W p, and W x_old comes out of the SAME read of K_nM
+    # as this step's W p (a two-vector pass, backend.ktk2).  Same value up to f64 rounding, and still computed from fresh
+    # products, so it keeps removing the recursive drift the recomputation exists for.  Used where the pass dominates
+    # the second vector's four extra triangular products (wide, tall blocks); otherwise the plain sequence below.
+    if shard is not None:
+        can_fold = _can_fold(be, K, M, int(n) // shard.world)
+    else:
+        can_fold = allreduce is None and _can_fold(be, K, M, int(n))
+    tt2 = be.zeros(2 * ((M + 1) // 2 * 2)).view(2, -1) if can_fold else None
+    v2 = be.zeros(M) if can_fold else None
+
+    def mmv2(s1, out1, s2, out2):
+        """out1 = W s1 and out2 = W s2 from one read of K."""
+        t1, t2 = tt2[0, :M], tt2[1, :M]
+        if owned:
+            be.trmv(P, "LAit", s1, out=v)
+            be.trmv(P, "LTit", v, out=t1)
+            be.trmv(P, "LAit", s2, out=v2)
+            be.trmv(P, "LTit", v2, out=t2)
+        bcast(tt2)
+        with ph("ktk"):
+            c1, c2 = be.ktk2(K, t1, t2)
+        cc2 = torch.stack((c1, c2))
+        ar(cc2)
+        if owned:
+            u = be.trmv(P, "LTi", cc2[0], alpha=1.0 / n, beta=lam, z=v)
+            be.trmv(P, "LAi", u, out=out1)
+            u = be.trmv(P, "LTi", cc2[1], alpha=1.0 / n, beta=lam, z=v2)
+            be.trmv(P, "LAi", u, out=out2)
+
     b0 = ar(b0)                                        # K' (y / n), summed over shards
     if shard is None and allreduce is None and phase is None and hasattr(be, "cg_solve"):
         # one shard, nothing to time per kernel family: the loop below as one library call (odx_falkon_cg_f64)
@@ -138,6 +178,7 @@ def falkon_fit(be, F, y, Zf, sigma, lam, maxiter=20, opt=None, n_total=None, all
             return alpha, K
         return alpha
     X, R, Pv, AP = be.zeros(M), be.zeros(M), be.zeros(M), be.zeros(M)
+    AX = be.zeros(M) if can_fold else None
     state = be.zeros(4)
     if owned:
         if precond_ready is not None:
@@ -146,13 +187,20 @@ def falkon_fit(be, F, y, Zf, sigma, lam, maxiter=20, opt=None, n_total=None, all
         be.cg_init(B, X, R, Pv, state)
     tol = opt.cg_tolerance ** 2
     for it in range(maxiter):
-        mmv(Pv, AP)
         full = (it + 1) % opt.cg_full_gradient_every == 0
+        fold = can_fold and full and it != maxiter - 1
+        if fold:
+            mmv2(Pv, AP, X, AX)                        # W p and W x_old
+        else:
+            mmv(Pv, AP)
         if owned:
             be.cg_step(X, R, Pv, AP, state, opt.cg_epsilon, full)
         if it == maxiter - 1:
             break    # the residual / direction update of the last step cannot change the returned X
-        if full:
+        if full and fold:
+            if owned:
+                be.cg_residual(B, AX, AP, state, R)    # R = B - (W x_old + a W p) = B - W x_new
+        elif full:
             mmv(X, AP)
             if owned:
                 R.copy_(B)
@@ -232,8 +280,33 @@ def falkon_fit_lockstep(be, F, ys, Zfs, sigma, lam, maxiter=20, opt=None, n_tota
             u = be.trmv(P, "LTi", cc, alpha=1.0 / n, beta=lam, z=v)
             be.trmv(P, "LAi", u, out=out)
 
+    # the periodic full residual folded into the neighbouring step's pass (see falkon_fit): the exchanged matrices carry
+    # two vectors per problem for that one iteration — still one all-gather and one reduce-scatter
+    can_fold = B > 0 and _can_fold(be, Ks[0], M, int(n) // world)
+    if can_fold:
+        tbuf2, ccbuf2, v2 = be.zeros(2 * Mp), be.zeros(2 * Mp), be.zeros(M)
+        Tall2 = be.zeros(world * 2 * Mp).view(world, 2 * Mp)
+        CC2 = be.zeros(world * 2 * Mp).view(world, 2 * Mp)
+
+    def mmv2(s1, out1, s2, out2):
+        if owned:
+            be.trmv(P, "LAit", s1, out=v)
+            be.trmv(P, "LTit", v, out=tbuf2[:M])
+            be.trmv(P, "LAit", s2, out=v2)
+            be.trmv(P, "LTit", v2, out=tbuf2[Mp:Mp + M])
+        shard.gather_rows(tbuf2, Tall2)
+        for b in range(B):
+            with ph("ktk"):
+                be.ktk2(Ks[b], Tall2[b, :M], Tall2[b, Mp:Mp + M], out1=CC2[b, :M], out2=CC2[b, Mp:Mp + M])
+        shard.reduce_scatter_rows(CC2, ccbuf2)
+        if owned:
+            u = be.trmv(P, "LTi", ccbuf2[:M], alpha=1.0 / n, beta=lam, z=v)
+            be.trmv(P, "LAi", u, out=out1)
+            u = be.trmv(P, "LTi", ccbuf2[Mp:Mp + M], alpha=1.0 / n, beta=lam, z=v2)
+            be.trmv(P, "LAi", u, out=out2)
+
     shard.reduce_scatter_rows(CC, ccbuf)             # K' (y / n) of every problem: each owner gets the sum of its row
-    X, R, Pv, AP = be.zeros(M), be.zeros(M), be.zeros(M), be.zeros(M)
+    X, R, Pv, AP, AX = be.zeros(M), be.zeros(M), be.zeros(M), be.zeros(M), be.zeros(M)
     state = be.zeros(4)
     Bv = None
     if owned:
@@ -243,13 +316,20 @@ def falkon_fit_lockstep(be, F, ys, Zfs, sigma, lam, maxiter=20, opt=None, n_tota
         be.cg_init(Bv, X, R, Pv, state)
     tol = opt.cg_tolerance ** 2
     for it in range(maxiter):
-        mmv(Pv, AP)
         full = (it + 1) % opt.cg_full_gradient_every == 0
+        fold = can_fold and full and it != maxiter - 1
+        if fold:
+            mmv2(Pv, AP, X, AX)
+        else:
+            mmv(Pv, AP)
         if owned:
             be.cg_step(X, R, Pv, AP, state, opt.cg_epsilon, full)
         if it == maxiter - 1:
             break
-        if full:
+        if full and fold:
+            if owned:
+                be.cg_residual(Bv, AX, AP, state, R)
+        elif full:
             mmv(X, AP)
             if owned:
                 R.copy_(Bv)

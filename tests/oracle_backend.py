@@ -82,6 +82,19 @@ class OracleBackend:
             return out
         return r
 
+    fold = True     # offer the two-vector pass (solver.py folds the periodic full residual into it)
+
+    def can_ktk2(self, K):
+        return self.fold
+
+    def ktk2(self, K, v1, v2, out1=None, out2=None):
+        return self.ktk(K, v=v1, out=out1), self.ktk(K, v=v2, out=out2)
+
+    def cg_residual(self, B, AX, AP, state, R):
+        if state[2] != 0:
+            return
+        R.copy_(B - (AX + state[3] * AP))
+
     def trmv(self, P, name, x, alpha=1.0, beta=0.0, z=None, out=None):
         r = alpha * (getattr(P, name) @ x)
         if beta != 0.0:

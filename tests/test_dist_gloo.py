@@ -142,7 +142,7 @@ def test_lockstep_fit_equals_one_at_a_time(world, B):
     alpha of its own owner-mode fit, and of the single-process oracle."""
     from oracle import falkon_ref as fr
     from tests.synth import blob_problem, centres
-    n = 900
+    n = 1200      # 600 rows per rank at world 2: the folded full residual (two vectors per problem in the exchange); 400 at world 3: the plain sequence
     port = _free_port()
     ret = mp.Manager().dict()
     mp.spawn(_lockstep_worker, args=(world, port, n, B, ret), nprocs=world, join=True)

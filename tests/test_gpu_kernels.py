@@ -200,6 +200,42 @@ def test_knm_fwd_bwd(be, n, M):
     assert np.array_equal(out2, out3)  # fixed-order reduction: bitwise reproducible
 
 
+@pytest.mark.parametrize("n,M", [(5000, 4100), (3001, 10000), (2000, 7001), (100, 8192)])
+def test_two_vector_pass_equals_two_passes(be, n, M):
+    """odx_knm_fwd_bwd2: K' (K v1) and K' (K v2) from one read of K against the single-vector pass and the f64 oracle."""
+    from odx.backend import Knm
+    rng = np.random.default_rng(n + M)
+    ld = (M + 3) // 4 * 4
+    Kh = rng.random((n, ld)).astype(np.float32)
+    Kh[:, M:] = 0.0
+    K = Knm()
+    K.K, K.n, K.M, K.ld = torch.from_numpy(Kh).cuda(), n, M, ld
+    assert be.can_ktk2(K)
+    v1, v2 = rng.standard_normal(M), rng.standard_normal(M) * 1e-3
+    o1 = torch.full((M + 4,), float("nan"), dtype=torch.float64, device="cuda")
+    o2 = torch.full((M + 4,), float("nan"), dtype=torch.float64, device="cuda")
+    be.ktk2(K, be.vec(v1), be.vec(v2), out1=o1[:M], out2=o2[:M])
+    assert torch.isnan(o1[M:]).all() and torch.isnan(o2[M:]).all()
+    Kd = Kh[:, :M].astype(np.float64)
+    for got, v in ((o1[:M], v1), (o2[:M], v2)):
+        ref = Kd.T @ (Kd @ v)
+        assert np.abs(got.cpu().numpy() - ref).max() <= 1e-11 * np.abs(ref).max()
+        single = be.ktk(K, v=be.vec(v))
+        assert float((got - single).abs().max()) <= 1e-12 * float(single.abs().max())
+    a1, a2 = be.ktk2(K, be.vec(v1), be.vec(v2))
+    assert torch.equal(a1, o1[:M]) and torch.equal(a2, o2[:M])             # repeatable bit for bit
+
+
+def test_two_vector_pass_is_refused_where_it_does_not_fit(be):
+    from odx.backend import Knm
+    for M in (500, 4096, 10240, 20000):
+        K = Knm()
+        K.K, K.n, K.M, K.ld = torch.zeros((8, (M + 3) // 4 * 4), device="cuda"), 8, M, (M + 3) // 4 * 4
+        assert not be.can_ktk2(K)
+        with pytest.raises(Exception):
+            be.ktk2(K, be.zeros(M), be.zeros(M))
+
+
 def test_pass_with_reserved_cus_gives_the_same_sums(be):
     """Leaving CUs to other streams changes the slab count, not the result beyond f64 summation order."""
     from odx.backend import Knm
@@ -278,6 +314,34 @@ def test_precond_identities(be, M, D, sigma, lam):
     z = np.random.default_rng(1).standard_normal(M)
     got = be.trmv(P, "LTi", dev(x), alpha=0.5, beta=2.0, z=dev(z)).cpu().numpy()
     assert np.abs(got - (0.5 * Ti.T @ x + 2.0 * z)).max() < 1e-8 * sc(Ti) * 10
+
+
+@pytest.mark.parametrize("Ms,D", [((500, 333, 700), 64), ((1300, 1300), 256), ((129,), 36), ((40, 1537, 128, 640, 257), 70)])
+def test_batched_precond_equals_the_single_class_one_bit_for_bit(be, Ms, D):
+    """odx_falkon_precond_batched_f64 advances the factorisations of several classes with one chain of launches; classes
+    with fewer centres are bordered with an identity block.  The leading M_b x M_b blocks of its outputs must be the
+    very bits the single-class call produces (same block boundaries, the border adds exact zeros only)."""
+    rng = np.random.default_rng(sum(Ms) + D)
+    sigma, lam = 9.0, 1e-4
+    Zfs = []
+    for M in Ms:
+        Z = (rng.standard_normal((M, D)) * (20.0 / np.sqrt(D))).astype(np.float32)
+        Z[M // 2:] = Z[: M - M // 2] + 0.01 * rng.standard_normal((M - M // 2, D)).astype(np.float32)   # near-duplicate centres
+        Zfs.append(be.features(torch.from_numpy(Z)))
+    Ps = be.precond_batched(Zfs, sigma, lam, 1e-5)
+    for Zf, Pb in zip(Zfs, Ps):
+        P1 = be.precond(Zf, sigma, lam, 1e-5)
+        assert int(Pb.info.item()) == 0 and int(P1.info.item()) == 0
+        for name in ("LTi", "LTit", "LAi", "LAit"):
+            a, b = getattr(P1, name)[:, :P1.M], getattr(Pb, name)[:, :Pb.M]
+            assert torch.equal(a, b), (Zf.n, name, float((a - b).abs().max()))
+        x = torch.randn(Pb.M, dtype=torch.float64, device="cuda")
+        assert torch.equal(be.trmv(P1, "LAit", x), be.trmv(Pb, "LAit", x))      # strided views feed the CG's products as they are
+    # a failed Cholesky is reported for its own class only
+    bad = be.features(torch.zeros((50, D)))                                     # K_MM = all ones: singular without jitter
+    good = be.features(torch.from_numpy((rng.standard_normal((60, D)) * (20.0 / np.sqrt(D))).astype(np.float32)))
+    Pbad = be.precond_batched([good, bad], sigma, 0.0, 0.0)
+    assert int(Pbad[0].info.item()) == 0 and int(Pbad[1].info.item()) != 0
 
 
 @pytest.mark.parametrize("n,M,D,sigma,lam", [(5000, 500, 256, 10.0, 1e-5), (5000, 500, 256, 15.0, 1e-5),
@@ -371,7 +435,9 @@ def full_size_properties(be, n, D, M, sigma, lam):
     X[::30] += 0.25                                                  # a positive class with some structure
     y = torch.full((n,), -1.0, dtype=torch.float64, device="cuda")
     y[::30] = 1.0
-    idx = torch.cat([torch.arange(0, n, 30, device="cuda")[:M // 2], torch.arange(1, n, 199, device="cuda")[:M - M // 2]])
+    step = max(1, (n - 1) // (M - M // 2))                          # 199 at the headline shape
+    idx = torch.cat([torch.arange(0, n, 30, device="cuda")[:M // 2], torch.arange(1, n, step, device="cuda")[:M - M // 2]])
+    assert idx.numel() == M
     F = be.features(X)
     Zf = be.features(X.index_select(0, idx))
     assert be.lib.odx_gauss_h2_tile(n, M) == 256                     # the headline launch runs on the wide tile core
@@ -403,6 +469,10 @@ def full_size_properties(be, n, D, M, sigma, lam):
     assert float((parts - full).abs().max()) <= 1e-11 * float(full.abs().max())
     lin = be.ktk(K, v=v1 + 2.0 * v2) - (full + 2.0 * be.ktk(K, v=v2))
     assert float(lin.abs().max()) <= 1e-11 * float(full.abs().max())
+    if be.can_ktk2(K):                                               # both products from one read of K (M <= 10 000)
+        two = be.ktk2(K, v1, v2)
+        assert float((two[0] - full).abs().max()) <= 1e-11 * float(full.abs().max())
+        assert float((two[1] - be.ktk(K, v=v2)).abs().max()) <= 1e-11 * float(full.abs().max())
     # (d) the right-hand side the build kernel leaves behind = one pass over the block it stored
     yn = y * (1.0 / n)
     K2, b0 = be.knm_rhs(F, Zf, sigma, yn, out=K.K.view(-1))

@@ -56,6 +56,30 @@ def test_solver_equals_oracle(sigma, lam):
     assert np.linalg.norm(alpha - ref[:, 0]) / np.linalg.norm(ref[:, 0]) < 1e-6
 
 
+def test_folded_full_residual_equals_the_recomputation():
+    """The periodic residual recomputation folded into the neighbouring step's two-vector pass (solver.py: W x_new =
+    W x_old + a W p) gives the iterate of the plain sequence (its own pass for R = B - W x) up to f64 rounding — at
+    iteration counts that end before, on and after a recomputation step."""
+    X, y, rng = blob_problem(1500, 48, seed=32)
+    idx = centres(y, 150, rng)
+    for maxiter in (9, 10, 11, 20, 25):
+        out = {}
+        for fold in (True, False):
+            be = OracleBackend(np.float64)
+            be.fold = fold
+            calls = {"ktk": 0, "ktk2": 0}
+            k1, k2 = be.ktk, be.ktk2
+            be.ktk = lambda *a, _k=k1, **kw: (calls.__setitem__("ktk", calls["ktk"] + 1), _k(*a, **kw))[1]
+            be.ktk2 = lambda *a, _k=k2, **kw: (calls.__setitem__("ktk2", calls["ktk2"] + 1), _k(*a, **kw))[1]
+            F = be.features(torch.from_numpy(X))
+            out[fold] = (odx.falkon_fit(be, F, be.vec(y), be.rows(F, idx), 10.0, 1e-5, maxiter).numpy(), dict(calls))
+        (a, ca), (b, cb) = out[True], out[False]
+        # f64 rounding of the two evaluation orders, amplified by the system's conditioning: ~1e-11 .. 1e-10 measured
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-8, maxiter
+        nfull = sum(1 for it in range(maxiter - 1) if (it + 1) % 10 == 0)
+        assert ca["ktk2"] == nfull and cb["ktk2"] == 0
+
+
 def test_estimator_surface():
     X, y, rng = blob_problem(600, 24, seed=8)
     idx = centres(y, 60, rng)

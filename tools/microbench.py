@@ -91,6 +91,10 @@ def main():
             v = torch.randn(M, dtype=torch.float64, device="cuda")
             ms = timeit(lambda: be.ktk(K, v=v))
             print("knm_fwd_bwd n=%d M=%d: %.3f ms  %.0f GB/s" % (n, M, ms, n * M * 4.0 / ms / 1e6))
+            if be.can_ktk2(K):
+                v2 = torch.randn(M, dtype=torch.float64, device="cuda")
+                ms = timeit(lambda: be.ktk2(K, v, v2))
+                print("knm_fwd_bwd2 (two vectors, one read) n=%d M=%d: %.3f ms  %.0f GB/s" % (n, M, ms, n * M * 4.0 / ms / 1e6))
             del K
     if "rls" in which:
         # per-class RLS box regressor (A7): f64 Gram of the class's rows + 4 right-hand sides, Cholesky solve, predictions.
