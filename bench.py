@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--maxiter", type=int, default=20)
     ap.add_argument("--warmup-classes", type=int, default=2, help="classes run per warm-up step")
     ap.add_argument("--precond-depth", type=int, default=0, help="batches of preconditioners in flight ahead of the fit (default 2)")
+    ap.add_argument("--precond-batch", type=int, default=0, help="classes whose preconditioners one batched launch chain builds "
+                    "(odx_falkon_precond_batched_f64), one group ahead of the fits; 1 = one chain per class (--precond-depth applies); "
+                    "default: min(6, classes this rank owns)")
     ap.add_argument("--reserve-cus", type=int, default=0, help="CUs the persistent pass kernel leaves to the side streams")
     ap.add_argument("--precond-behind-cg", dest="precond_after_fit", action="store_true",
                     help="issue the look-ahead preconditioner behind the batch's CG instead of before its fit")
@@ -254,11 +257,13 @@ def main():
     nslot = depth + 1
     sides = [torch.cuda.Stream() for _ in range(nslot)]
     ld_p = (M + 1) // 2 * 2
-    pbuf = [torch.empty((4, M, ld_p), dtype=torch.float64, device=device) for _ in range(nslot)]
+    pbuf = []      # per-class mode (--precond-batch 1): one output slot per chain in flight, allocated below
 
     def prepare(batch, slot, timed):
         """Centres of the batch's classes (one all-reduce each, main stream) and, on the slot's side stream,
         the preconditioner of the class this rank owns in the batch (owner = position in the batch)."""
+        while len(pbuf) < nslot:
+            pbuf.append(torch.empty((4, M, ld_p), dtype=torch.float64, device=device))
         Zs = [gather_centres(cidx_dev[c]) for c in batch]
         P, ev = None, None
         if rank < len(batch):
@@ -273,6 +278,34 @@ def main():
                 infos.append(P.info)
         return Zs, P, ev
 
+    # ---- class-batched preconditioners (default): the factorisation chain of ONE preconditioner is ~1500 dependent small
+    # launches that leave most of the chip idle; odx_falkon_precond_batched_f64 advances G classes with the same chain.
+    # This rank's owned classes are taken G at a time; group g + 1 is built on the side stream while group g is fitted.
+    owned_total = len([b0 for b0 in range(0, C, world) if b0 + rank < C])
+    G = args.precond_batch if args.precond_batch > 0 else max(1, min(6, owned_total))
+    if G > 1:
+        gside = torch.cuda.Stream()
+        pgroup = [torch.empty((G, 4, M, ld_p), dtype=torch.float64, device=device) for _ in range(2)]
+
+    def prepare_group(group, slot, timed):
+        """Centres of every class of the group's batches (main stream) and, on the side stream, the preconditioners of the
+        classes this rank owns among them, all by one batched call.  Returns one (Zs, P, event) per batch."""
+        Zs_all = [[gather_centres(cidx_dev[c]) for c in batch] for batch in group]
+        own = [k for k, batch in enumerate(group) if rank < len(batch)]
+        Ps, ev = {}, None
+        if own:
+            gside.wait_stream(torch.cuda.current_stream())   # the slot's last readers were issued, the centres exist
+            with torch.cuda.stream(gside):
+                with ph["precond"] if timed else _null():
+                    plist = be.precond_batched([Zs_all[k][rank] for k in own], args.sigma, args.lam, opt.pc_epsilon,
+                                               out=pgroup[slot][:len(own)], ws_key="precond_group")
+                ev = torch.cuda.Event()
+                ev.record(gside)
+            Ps = dict(zip(own, plist))
+            if timed:
+                infos.extend(p.info for p in plist)
+        return [(Zs_all[k], Ps.get(k), ev) for k in range(len(group))]
+
     def run_classes(classes, timed):
         """Classes are processed in batches of `world`.  Every rank builds the preconditioner of the class it owns in
         a batch (nothing replicated) on a side stream, `depth` batches ahead.  The batch's classes are then fitted
@@ -280,9 +313,28 @@ def main():
         all-gather of the directions, one pass per class over the local K_nM shard, one reduce-scatter) and scored."""
         out = None
         batches = [classes[b0:b0 + world] for b0 in range(0, len(classes), world)]
-        ready = {bi: prepare(batches[bi], bi % nslot, timed) for bi in range(min(depth, len(batches)))}
+        if G > 1:
+            # group sizes 1, 2, 3, then G: nothing but the first class's preconditioner is waited for at the start of a
+            # step (it overlaps that class's K_nM build, as in the per-class mode); every later group is built while the
+            # group before it is being fitted
+            groups, g0 = [], 0
+            for size in (1, 2, 3):
+                if g0 < len(batches) and size < G:
+                    groups.append(list(range(g0, min(g0 + size, len(batches)))))
+                    g0 += size
+            while g0 < len(batches):
+                groups.append(list(range(g0, min(g0 + G, len(batches)))))
+                g0 += G
+            first_of = {grp[0]: gi for gi, grp in enumerate(groups)}
+            ready = dict(zip(groups[0], prepare_group([batches[bi] for bi in groups[0]], 0, timed)))
+        else:
+            ready = {bi: prepare(batches[bi], bi % nslot, timed) for bi in range(min(depth, len(batches)))}
         for bi, batch in enumerate(batches):
-            if not args.precond_after_fit and bi + depth < len(batches):
+            if G > 1:
+                gi = first_of.get(bi)
+                if gi is not None and gi + 1 < len(groups):  # one group ahead, on the side stream
+                    ready.update(zip(groups[gi + 1], prepare_group([batches[k] for k in groups[gi + 1]], (gi + 1) % 2, timed)))
+            elif not args.precond_after_fit and bi + depth < len(batches):
                 ready[bi + depth] = prepare(batches[bi + depth], (bi + depth) % nslot, timed)
             Zs, P, ev = ready.pop(bi)
             ys = [torch.where((row_ids % C) == c, 1.0, -1.0).to(torch.float64) for c in batch]
@@ -291,7 +343,7 @@ def main():
                                              knm_outs=kbufs[:len(batch)], phase=(lambda name: ph[name]) if timed else None,
                                              precond=P if mine else None,
                                              precond_ready=(lambda: torch.cuda.current_stream().wait_event(ev)) if mine else None)
-            if args.precond_after_fit and bi + depth < len(batches):
+            if G == 1 and args.precond_after_fit and bi + depth < len(batches):
                 # issued behind this batch's CG in stream order: the factorisations then run beside the MFMA-bound scoring of
                 # this batch and K_nM build of the next, and the HBM-bound passes keep the chip to themselves
                 ready[bi + depth] = prepare(batches[bi + depth], (bi + depth) % nslot, timed)
@@ -407,7 +459,7 @@ def main():
             "config": {"workload": "%d-class one-vs-rest FALKON fit + score-all, N=%d D=%d M=%d, %d CG iterations, "
                                    "rows sharded over %d GPU(s)" % (C, N, D, M, args.maxiter, world),
                        "N": N, "D": D, "M": M, "classes": C, "sigma": args.sigma, "lambda": args.lam,
-                       "rows_per_gpu": n_loc},
+                       "rows_per_gpu": n_loc, "preconditioners_per_batched_chain": G},
             "roofline": roof,
             "roofline_second_family": roof2,
             "phases_ms_per_step_rank0": phases,
@@ -421,6 +473,8 @@ def main():
             # the other halves of BASELINE configs 2 and 3 (RLS regressors, feature forward) and the reference-regime
             # minibootstrap: measured after and outside the timed headline region, with its buffers released first
             del kbufs[:], pbuf[:]
+            if G > 1:
+                del pgroup[:]
             last = F = X = scores = None
             be.release_workspaces()
             torch.cuda.empty_cache()

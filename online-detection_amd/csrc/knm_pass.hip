@@ -158,6 +158,146 @@ __global__ __launch_bounds__(NT) void knm_pass_kernel(const float* __restrict__ 
     }
 }
 
+
+// ---------------------------------------------------------------- two vectors, one read of K
+// out = K' (K v1), out2 = K' (K v2): the same persistent row-block scheme with two sets of row dots and column sums.  The
+// second set of f64 column sums needs the registers the addressing of the plain kernel takes (64-bit pointers per load,
+// per-chunk validity predicates), so this kernel loads K through buffer descriptors instead: one descriptor per row,
+// built from wave-uniform scalars (row base, row length in bytes — zero records for rows past n), the per-lane part is
+// one 32-bit byte offset per chunk, and chunks past the row's end read as zero by the hardware range check (no branches
+// in the streaming loop).  Both vectors sit in dynamic LDS as f64 (2 x roundup(M, 4) x 8 B: M <= ~10 200).
+typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
+
+template <int NT, int CH, int R>
+__global__ __launch_bounds__(NT) void knm_pass2_kernel(const float* __restrict__ K, int64_t ldk, int64_t n, int64_t M,
+                                                       const double* __restrict__ v1, const double* __restrict__ v2,
+                                                       double* __restrict__ slab, int64_t slab_ld) {
+  constexpr int NW = NT / 64;
+  extern __shared__ __attribute__((aligned(16))) double vs2[];       // [2][vcap]
+  __shared__ double red[2][NW][2 * R];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nchunk = (int)((M + 3) >> 2);
+  const int vcap = nchunk * 4;
+  const int64_t nblk = (n + R - 1) / R;
+  for (int i = tid; i < vcap; i += NT) {
+    vs2[i] = i < M ? v1[i] : 0.0;
+    vs2[vcap + i] = i < M ? v2[i] : 0.0;
+  }
+  const int voff = tid * 16;        // the only per-lane part of a K address: byte offset inside a (row, chunk column) window
+  double acc[2][CH][4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[q][c][e] = 0.0;
+
+  f32x4 kr[R][CH];
+  const int row_bytes = nchunk * 16;
+  auto load_block = [&](int64_t blk, int c) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      // descriptor of the window [chunk column c of row `row`]: base and length are wave-uniform scalars; lanes whose
+      // chunk lies past the row's end (or rows past n: zero records) get zeros from the range check
+      const int64_t row = blk * R + r;
+      const bool in = row < n;
+      const float* base = K + (in ? row : 0) * ldk + c * NT * 4;
+      const int left = row_bytes - c * NT * 16;
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, (in && left > 0) ? left : 0, 0x00020000);
+      const u32x4b raw = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+      kr[r][c] = __builtin_bit_cast(f32x4, raw);
+    }
+  };
+
+  int64_t blk = blockIdx.x;
+  if (blk < nblk) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) load_block(blk, c);
+  }
+  __syncthreads();  // vs2 is complete
+  int pp = 0;
+  for (; blk < nblk; blk += gridDim.x) {
+    double t[2][R];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) t[q][r] = 0.0;
+    // phase 1: row dots with both vectors.  The v entries a thread needs are the same for every block, so the compiler
+    // would lift their LDS reads out of the loop and hold 2 x CH x 4 doubles (80 VGPRs) for good: an opaque zero added to
+    // the index keeps the reads inside the loop (LDS traffic is a few % of its bandwidth here).
+    int zofs;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zofs));
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int ch = tid + c * NT + zofs;
+        const int vi = (ch < nchunk ? ch : nchunk - 1) * 4;      // any valid entry where K reads as zero
+        const f64x2 a = *reinterpret_cast<const f64x2*>(&vs2[q * vcap + vi]);
+        const f64x2 b = *reinterpret_cast<const f64x2*>(&vs2[q * vcap + vi + 2]);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          t[q][r] = fma((double)kr[r][c][0], a[0], t[q][r]);
+          t[q][r] = fma((double)kr[r][c][1], a[1], t[q][r]);
+          t[q][r] = fma((double)kr[r][c][2], b[0], t[q][r]);
+          t[q][r] = fma((double)kr[r][c][3], b[1], t[q][r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        double s = t[q][r];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) red[pp][wave][q * R + r] = s;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        double s = 0.0;
+#pragma unroll
+        for (int u = 0; u < NW; ++u) s += red[pp][u][q * R + r];
+        t[q][r] = s;
+      }
+    pp ^= 1;
+    // The f32 -> f64 conversions of phase 1 must not stay live into phase 2 (the compiler would keep 2 x R x CH x 4
+    // doubles beside the floats they came from and spill): an empty asm makes the K registers opaque here, so phase 2
+    // converts again from the f32 registers (a quarter-rate VALU op on an HBM-bound kernel).
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int r = 0; r < R; ++r) asm volatile("" : "+v"(kr[r][c]));
+    // phase 2: column sums, and the next block's loads re-issued chunk by chunk
+    const int64_t nxt = blk + gridDim.x;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[q][c][e] = fma((double)kr[r][c][e], t[q][r], acc[q][c][e]);
+      if (nxt < nblk) load_block(nxt, c);
+    }
+  }
+  double* my = slab + (int64_t)blockIdx.x * slab_ld * 2;
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = tid + c * NT;
+      if (ch < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) my[q * slab_ld + (int64_t)ch * 4 + e] = acc[q][c][e];
+      }
+    }
+}
+
 // out[j] = sum_g slab[g][j] in a fixed order: a workgroup owns 64 columns; its 4 waves take the slabs g = w, w + 4, ...
 // (coalesced 512-B row segments), then wave 0 adds the 4 partial sums in wave order.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const double* __restrict__ slab, int64_t slab_ld, int nslab,
@@ -249,10 +389,10 @@ extern "C" int64_t odx_knm_fwd_bwd_workspace_bytes(int64_t n, int64_t M) {
                      slab, slab_ld)
 #define ODX_PASS2_LAUNCH(NT_, CH_, R_)                                                                                  \
   do {                                                                                                                  \
-    ODX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knm_pass_kernel<NT_, CH_, R_, 2>),                  \
+    ODX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knm_pass2_kernel<NT_, CH_, R_>),                    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                          \
-    hipLaunchKernelGGL((knm_pass_kernel<NT_, CH_, R_, 2>), dim3(grid), dim3(NT_), lds2, s, K, ldk, n, M, v, v2,      \
-                       nullptr, slab, slab_ld);                                                                         \
+    hipLaunchKernelGGL((knm_pass2_kernel<NT_, CH_, R_>), dim3(grid), dim3(NT_), lds2, s, K, ldk, n, M, v, v2, slab,   \
+                       slab_ld);                                                                                        \
   } while (0)
 
 extern "C" int odx_knm_fwd_bwd(const float* K, int64_t ldk, int64_t n, int64_t M, const double* v, const double* w,
