@@ -135,6 +135,69 @@ class _FalkonBase:
         return True
 
 
+def fit_batch(estimators, Xs, Ys, streams=None):
+    """Fit several independent estimators (the classes of one Minibootstrap round) with ONE batched preconditioner
+    launch chain (backend.precond_batched) instead of one ~400-launch chain each; the K_nM build and the CG of every
+    class then run as in ``fit`` — on `streams` round-robin when given (the classes are independent), each reusing its
+    slice of the batched factors.  Every estimator ends up exactly as its own ``fit(X, Y)`` would leave it (same bits:
+    the batched factors equal the single-class ones).  The reference has no counterpart: it trains the classes one
+    after the other (OnlineRegionClassifier_incore.py:96-155)."""
+    be = _backend.get_backend()
+    if not hasattr(be, "precond_batched"):
+        for est, X, Y in zip(estimators, Xs, Ys):
+            est.fit(X, Y)
+        return estimators
+    Fs, Zfs, yvs = [], [], []
+    for est, X, Y in zip(estimators, Xs, Ys):
+        F = be.features(X)
+        if isinstance(est.center_selection, str):
+            Zf = be.rows(F, torch.randperm(F.n)[: est.M])
+        else:
+            sel = est.center_selection.select(F.X, None)
+            Zf = be.features(sel[0] if isinstance(sel, tuple) else sel)
+        est.M = Zf.n
+        y = torch.as_tensor(Y).reshape(F.n, -1)
+        if y.shape[1] != 1:
+            raise ValueError("odx FALKON fits one right-hand side per model; got Y with %d columns" % y.shape[1])
+        Fs.append(F), Zfs.append(Zf), yvs.append(be.vec(y[:, 0]))
+    # classes that share (sigma, penalty, jitter) share a chain; the reference's classes always do
+    groups = {}
+    for i, est in enumerate(estimators):
+        o = est.options.solver_options()
+        groups.setdefault((float(est.kernel.sigma), float(est.penalty), o.pc_epsilon), []).append(i)
+    Ps = [None] * len(estimators)
+    for (sigma, lam, eps), members in groups.items():
+        for c0 in range(0, len(members), be.MAX_CLASS_BATCH):
+            chunk = members[c0:c0 + be.MAX_CLASS_BATCH]
+            for i, P in zip(chunk, be.precond_batched([Zfs[i] for i in chunk], sigma, lam, eps, ws_key="precond_batched_fit")):
+                Ps[i] = P
+    cur = torch.cuda.current_stream() if streams else None
+    if streams:
+        for s in streams:
+            s.wait_stream(cur)
+    for i, est in enumerate(estimators):
+        ctx = torch.cuda.stream(streams[i % len(streams)]) if streams else _nullcontext()
+        with ctx:
+            alpha = falkon_fit(be, Fs[i], yvs[i], Zfs[i], est.kernel.sigma, float(est.penalty), int(est.maxiter),
+                               est.options.solver_options(), precond=Ps[i])
+            ny = Zfs[i].X.contiguous() if Zfs[i].X.stride(0) != Zfs[i].D else Zfs[i].X
+            est.alpha_, est.ny_points_ = alpha.reshape(-1, 1), ny
+            if est._cpu_model:
+                est.alpha_, est.ny_points_ = est.alpha_.cpu(), est.ny_points_.cpu()
+    if streams:
+        for s in streams:
+            cur.wait_stream(s)
+    return estimators
+
+
+class _nullcontext:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class InCoreFalkon(_FalkonBase):
     """GPU-resident estimator (FALKONWrapper_with_centers_selection_incore.py:58-68)."""
 

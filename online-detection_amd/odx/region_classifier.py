@@ -64,6 +64,7 @@ class OnlineRegionClassifierBase:
         self.is_segmentation = is_segmentation
         self.return_caches = False
         self.class_streams = 0          # > 0: classes trained concurrently on that many streams (opts['class_streams'])
+        self.class_batch = 0            # > 0: the classes of a round fitted by one batched call, on that many streams (opts['class_batch'])
 
     def loadRegionClassifier(self) -> None:
         pass
@@ -81,6 +82,8 @@ class OnlineRegionClassifierBase:
                 self.normalized = opts['normalized']
             if 'class_streams' in opts:
                 self.class_streams = int(opts['class_streams'])
+            if 'class_batch' in opts:
+                self.class_batch = int(opts['class_batch'])
 
     def updateModel(self, cache):
         X_neg, X_pos = cache['neg'], cache['pos']
@@ -229,6 +232,91 @@ class OnlineRegionClassifierBase:
             self.caches = caches
         return model
 
+    def trainWithMinibootstrapBatched(self, negatives, positives, output_dir=None):
+        """The per-class state machine with the classes advancing together one negative batch at a time (as in
+        trainWithMinibootstrapStreams) and ALL fits of a round made by one `classifier.train_batch` call: their
+        preconditioners — per class a dependent chain of ~400 small factorisation kernels, the bulk of a fit at the
+        reference's sizes (M ~ 2000, n ~ 3-10 k) — come out of ONE batched launch chain (odx_falkon_precond_batched_f64),
+        the K_nM builds and CG loops of the classes run side by side on `class_batch` streams.  Opt-in
+        (opts['class_batch'] = k, in-core only).  Each class sees exactly the arithmetic of its own sequential fit (the
+        batched factors are bit-identical to the single-class ones): with the same Nystroem indices the models equal the
+        sequential mode's bit for bit.  As in the streams mode the indices themselves come from one RNG stream per class
+        (seeded from one draw of the global stream), because the reference's class-major order of global draws cannot be
+        kept when classes advance together."""
+        C = self.num_classes - 1
+        k = max(1, int(self.class_batch))
+        main = torch.cuda.current_stream()
+        streams = [torch.cuda.Stream() for _ in range(k)]
+        seed0 = int(torch.randint(2 ** 62, (1,)).item())
+        active = [i for i in range(C) if len(positives[i]) != 0 and len(negatives[i]) != 0]
+        rng = {i: torch.Generator().manual_seed(seed0 + i).get_state() for i in active}
+        caches, model = [{} for _ in range(C)], [None] * C
+        t_start = time.time()
+        nb = max([len(negatives[i]) for i in active] or [0])
+
+        def on_streams(items, fn):
+            """fn(i) for every class on its stream; the streams start after what the caller's stream has queued and
+            the caller's stream continues after them."""
+            for s in streams:
+                s.wait_stream(main)
+            out = {}
+            for i in items:
+                with torch.cuda.stream(streams[i % k]):
+                    out[i] = fn(i)
+            for s in streams:
+                main.wait_stream(s)
+            return out
+
+        for j in range(nb):
+            todo = [i for i in active if j < len(negatives[i])]
+            if j == 0:
+                for i in todo:
+                    caches[i] = {'pos': positives[i], 'neg': negatives[i][0]}
+            else:
+                scores = on_streams(todo, lambda i: self.classifier.predict(model[i], negatives[i][j]))
+                for i in todo:
+                    hard_idx = torch.where(scores[i] > self.hard_tresh)[0]
+                    caches[i]['neg'] = torch.cat((caches[i]['neg'], negatives[i][j][hard_idx]), 0)
+                    print('Class {}: chosen {} hard negatives from the {}th batch'.format(i, len(hard_idx), j))
+            Xs, ys = [], []
+            for i in todo:
+                X_pos, X_neg = caches[i]['pos'], caches[i]['neg']
+                print('Class {}: traning with {} positives and {} negatives'.format(i, len(X_pos), len(X_neg)))
+                Xs.append(torch.cat((X_pos, X_neg), 0))
+                ys.append(torch.cat((torch.ones(len(X_pos), device=X_pos.device), -torch.ones(len(X_neg), device=X_pos.device)), 0))
+
+            def with_class_rng(pos, fn):
+                i = todo[pos]
+                with torch.random.fork_rng(devices=[]):
+                    torch.set_rng_state(rng[i])
+                    out = fn()
+                    rng[i] = torch.get_rng_state()
+                return out
+
+            fitted = self.classifier.train_batch(Xs, ys, sigma=self.sigma, lam=self.lam, index_rng=with_class_rng, streams=streams)
+            for i, m in zip(todo, fitted):
+                model[i] = m
+            prune = [i for i in todo if len(caches[i]['neg']) != 0 and j != len(negatives[i]) - 1]
+            scores = on_streams(prune, lambda i: self.classifier.predict(model[i], caches[i]['neg']))
+            for i in prune:
+                keep_idx = torch.where(scores[i] >= self.easy_tresh)[0]
+                removed = len(caches[i]['neg']) - len(keep_idx)
+                caches[i]['neg'] = caches[i]['neg'][keep_idx]
+                print('Class {}: removed {} easy negatives. {} Remaining'.format(i, removed, len(caches[i]['neg'])))
+        for i in active:
+            if not self.return_caches:
+                caches[i] = None
+        training_time = time.time() - t_start
+        print('Online Classifier trained in {} seconds'.format(training_time))
+        if output_dir:
+            head = ("RPN's Online Classifier training time" if self.is_rpn else
+                    "Online Segmentation training time" if self.is_segmentation else "Detector's Online Classifier training time")
+            with open(os.path.join(output_dir, "result.txt"), "a") as fid:
+                fid.write("{}: {}min:{}s \n".format(head, int(training_time / 60), round(training_time % 60)))
+        if self.return_caches:
+            self.caches = caches
+        return model
+
     def trainRegionClassifier(self, opts=None, output_dir=None):
         if opts is not None:
             self.processOptions(opts)
@@ -245,7 +333,9 @@ class OnlineRegionClassifierBase:
                     if len(negatives[i][j]):
                         negatives[i][j] = self.zScores(negatives[i][j])
             self.normalized = True
-        if self.incore and self.class_streams > 0 and torch.cuda.is_available():
+        if self.incore and self.class_batch > 0 and torch.cuda.is_available() and hasattr(self.classifier, 'train_batch'):
+            model = self.trainWithMinibootstrapBatched(negatives, positives, output_dir=output_dir)
+        elif self.incore and self.class_streams > 0 and torch.cuda.is_available():
             model = self.trainWithMinibootstrapStreams(negatives, positives, output_dir=output_dir)
         else:
             model = self.trainWithMinibootstrap(negatives, positives, output_dir=output_dir)

@@ -83,6 +83,30 @@ class FALKONWrapperBase:
         self.model.fit(X, y)
         return copy.deepcopy(self.model)
 
+    def train_batch(self, Xs, ys, sigma=None, lam=None, index_rng=None, streams=None):
+        """`train` for several independent classes at once (one Minibootstrap round): the same index rule, estimator
+        construction and deep-copied result per class, with the fits sharing one batched preconditioner launch chain
+        (odx.falkon.fit_batch).  index_rng: optional callable (i, fn) that runs fn under class i's own RNG state — the
+        reference draws the Nystroem indices from the global RNG class by class; here the classes of a round are
+        selected back to back, so callers that need reproducible draws give every class its own stream."""
+        sigma = self.sigma if sigma is None else sigma
+        lam = self.lam if lam is None else lam
+        self.kernel = self.kernel_cls(sigma=sigma)
+        models = []
+        for i, (X, y) in enumerate(zip(Xs, ys)):
+            indices = index_rng(i, lambda: self.compute_indices_selection(y)) if index_rng else self.compute_indices_selection(y)
+            if isinstance(indices, int):
+                indices = [indices]
+            opt = self.options_cls(min_cuda_iter_size_32=0, min_cuda_iter_size_64=0, keops_active="no",
+                                   min_cuda_pc_size_32=0, min_cuda_pc_size_64=0, store_kernel_d_threshold=250)
+            cls = self.estimator_incore if self.incore else self.estimator_cpu
+            kw = {"maxiter": self.maxiter} if self.incore else {}
+            models.append(cls(kernel=self.kernel_cls(sigma=sigma), penalty=lam, M=len(indices),
+                              center_selection=self.selector_cls(indices), options=opt, **kw))
+        _falkon.fit_batch(models, Xs, ys, streams=streams)
+        self.model = models[-1] if models else None
+        return [copy.deepcopy(m) for m in models]
+
     def predict(self, model, X_np, y=None):
         if y is not None:
             return model.predict(X_np, y)

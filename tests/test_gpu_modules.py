@@ -305,6 +305,68 @@ def test_bench_starts_its_own_ranks_and_matches_the_oracle():
     assert out["health"]["failed_choleskys"] == 0 and out["health"]["ranks_with_nonfinite_scores"] == 0
 
 
+def test_batched_minibootstrap_equals_the_sequential_one_bit_for_bit(tmp_path):
+    """opts['class_batch'] = k fits all classes of a Minibootstrap round with one batched preconditioner launch chain and
+    runs their K_nM builds / CG loops on k streams.  Fed the same Nystroem indices (the wrapper's index rule replaced by a
+    deterministic one, so that the order in which classes consume the RNG does not matter) it must reproduce the
+    reference-order sequential training bit for bit: same models, same caches — for k = 1 and k = 3, with a class without
+    positives, a class with fewer negative batches and classes whose fits have different numbers of centres."""
+    import yaml
+    D, C, ITER, M = 64, 5, 4, 120
+    classes = ["_background_", "a", "b", "c", "d", "e"]
+    cfg = {"NUM_CLASSES": 6, "ONLINE_REGION_CLASSIFIER": {"MINIBOOTSTRAP": {"EASY_THRESH": -0.9, "HARD_THRESH": -0.7},
+                                                          "CLASSIFIER": {"lambda": 0.001, "sigma": 8, "M": M, "kernel_type": "gauss"}},
+           "CHOSEN_CLASSES": {i: c for i, c in enumerate(classes)}}
+    path = str(tmp_path / "cfg.yaml")
+    yaml.safe_dump(cfg, open(path, "w"))
+    g = torch.Generator().manual_seed(41)
+    mus = torch.randn(C, D, generator=g) * 1.2
+
+    def data():
+        gg = torch.Generator().manual_seed(42)
+        pos, neg = [], []
+        for c in range(C):
+            npos = [150, 0, 90, 200, 20][c]                              # class 4: 20 positives + 60 negatives < M centres
+            pos.append((mus[c] + 0.6 * torch.randn(npos, D, generator=gg)).cuda() if npos else torch.empty((0, D)).cuda())
+            nbatch = ITER if c != 3 else ITER - 1
+            nneg = 200 if c != 4 else 60
+            neg.append([(mus[(c + 1 + j % 2) % C] * (0.4 + 0.15 * j) + 0.9 * torch.randn(nneg, D, generator=gg)).cuda() for j in range(nbatch)])
+        return pos, neg
+
+    stats = {"mean": torch.zeros(D).cuda(), "std": torch.ones(D).cuda(), "mean_norm": torch.tensor(8.0).cuda()}
+    orc_mod = dropin.load("OnlineRegionClassifier_incore")
+    wrap_mod = dropin.load("FALKONWrapper_with_centers_selection_incore")
+
+    def injected(y):
+        """<= M / 2 positives first, then negatives up to M, evenly spaced: the reference rule without its random draws."""
+        pos, neg = (y == 1).nonzero().reshape(-1).tolist(), (y == -1).nonzero().reshape(-1).tolist()
+        pos = pos[:: max(1, len(pos) // (M // 2))][: M // 2]
+        room = M - len(pos)
+        neg = neg[:: max(1, len(neg) // room)][:room]
+        return pos + neg
+
+    out = {}
+    for mode, opts in (("seq", {"return_caches": True}), ("b1", {"class_batch": 1, "return_caches": True}),
+                       ("b3", {"class_batch": 3, "return_caches": True})):
+        pos, neg = data()
+        w = wrap_mod.FALKONWrapper(cfg_path=path)
+        w.compute_indices_selection = injected
+        torch.manual_seed(5)
+        out[mode] = quiet(orc_mod.OnlineRegionClassifier(w, pos, neg, stats, cfg_path=path).trainRegionClassifier, opts=opts)
+    (ms, cs) = out["seq"]
+    assert [m is None for m in ms] == [False, True, False, False, False]
+    assert ms[4].M < M                                                   # the ragged member of the batch
+    for mode in ("b1", "b3"):
+        mb, cb = out[mode]
+        for c in range(C):
+            assert (ms[c] is None) == (mb[c] is None)
+            if ms[c] is None:
+                continue
+            assert torch.equal(ms[c].ny_points_, mb[c].ny_points_), (mode, c)
+            assert torch.equal(ms[c].alpha_, mb[c].alpha_), (mode, c, float((ms[c].alpha_ - mb[c].alpha_).abs().max()))
+            assert torch.equal(cs[c]["neg"], cb[c]["neg"]) and torch.equal(cs[c]["pos"], cb[c]["pos"])
+
+
 def test_minibootstrap_on_class_streams_does_not_depend_on_the_stream_count(tmp_path):
     """opts['class_streams'] = k trains the classes concurrently on k streams with one RNG stream per class: the models
     are the same bits for k = 1 and k = 3 (deterministic kernels, per-stream scratch), classes without data stay None,

@@ -7,7 +7,7 @@
   forward        config 2's first half: OnlineDetectionModel.forward on a synthetic 600 x 800 image, 300 RoIs,
                  f32 and bf16 autocast, random weights (feature_proposal_extractor.py:228-281)
   minibootstrap  the reference regime (OnlineRegionClassifier_incore.py:96-155): 30 classes x 10 negative batches of
-                 2000 rows, M = 2000, D = 2048, in the reference's sequential order and in the opt-in class-parallel mode
+                 2000 rows, M = 2000, D = 2048, in the reference's sequential order and in the opt-in class-parallel modes (streams; batched preconditioners)
 """
 import io
 import os
@@ -81,7 +81,7 @@ def forward_extra(height=600, width=800, rois=300, reps=8):
     return out
 
 
-def minibootstrap_extra(C=30, D=2048, IT=10, positives=800, sigma=15.0, modes=(("sequential", None), ("class_streams4", {"class_streams": 4}))):
+def minibootstrap_extra(C=30, D=2048, IT=10, positives=800, sigma=15.0, modes=(("sequential", None), ("class_streams4", {"class_streams": 4}), ("class_batch4", {"class_batch": 4}))):
     import yaml
     from tests import dropin
     names = ["_background_"] + ["c%d" % i for i in range(C)]
