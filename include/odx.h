@@ -196,6 +196,19 @@ int odx_falkon_cg_f64(const float* K, int64_t ldk, int64_t n, int64_t M, const d
                       const double* LAi, const double* LAit, int64_t ldp, const double* b0, double n_total,
                       double lam, int maxiter, int full_gradient_every, double cg_epsilon, double cg_tolerance,
                       double* alpha, void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+/* The same loop for B <= 32 independent fits in lock step — the classes of one Minibootstrap round, which the reference
+ * trains one after the other (OnlineRegionClassifier_incore.py:96-155): every launch carries the class as a grid
+ * dimension, so the round costs the launches of ONE fit; per class the arithmetic (and so alpha, bit for bit) is
+ * odx_falkon_cg_f64's.  HOST arrays K / ldk / n / M / n_total describe the classes' stored blocks; P: the output block
+ * of odx_falkon_precond_batched_f64 (four p_rows x ldp factors per class, p_stride apart); b0 and alpha: B vectors
+ * vstride apart.  The classes must share one pass configuration (same bracket of M): the workspace query returns < 0
+ * otherwise and callers fall back to one odx_falkon_cg_f64 per class. */
+int64_t odx_falkon_cg_batched_workspace_bytes(int B, const int64_t* n, const int64_t* M);
+int odx_falkon_cg_batched_f64(int B, const float* const* K, const int64_t* ldk, const int64_t* n, const int64_t* M,
+                              const double* P, int64_t ldp, int64_t p_rows, int64_t p_stride,
+                              const double* b0, int64_t vstride, const double* n_total, double lam,
+                              int maxiter, int full_gradient_every, double cg_epsilon, double cg_tolerance,
+                              double* alpha, void* workspace, int64_t workspace_bytes, odx_stream_t stream);
 
 /* ---------------------------------------------------------------- dense f64 building blocks
  * (exported for the parity tests and for the RLS path)                                   */

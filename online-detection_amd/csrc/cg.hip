@@ -1,7 +1,7 @@
 // Conjugate-gradient vector updates (f64, length M, one right-hand side), scalars on device.
 // state[0] = rs_old, state[1] = rs_new, state[2] = stop flag (0 / 1), state[3] = last step size.
 // One 1024-thread workgroup per call: M <= ~20k, so these are latency-sized, not bandwidth-sized.
-#include "odx_common.h"
+#include "odx_internal.h"
 
 namespace odx {
 
@@ -18,9 +18,9 @@ __device__ __forceinline__ double block_sum_1024(double v, double* red) {
   return s;
 }
 
-__global__ __launch_bounds__(1024) void cg_init_kernel(const double* __restrict__ B, double* __restrict__ X,
-                                                       double* __restrict__ R, double* __restrict__ P,
-                                                       double* __restrict__ state, int64_t M) {
+__device__ __forceinline__ void cg_init_body(const double* __restrict__ B, double* __restrict__ X,
+                                             double* __restrict__ R, double* __restrict__ P,
+                                             double* __restrict__ state, int64_t M) {
   __shared__ double red[16];
   double s = 0.0;
   for (int64_t i = threadIdx.x; i < M; i += 1024) {
@@ -39,10 +39,9 @@ __global__ __launch_bounds__(1024) void cg_init_kernel(const double* __restrict_
   }
 }
 
-__global__ __launch_bounds__(1024) void cg_step_kernel(double* __restrict__ X, double* __restrict__ R,
-                                                       const double* __restrict__ P, const double* __restrict__ AP,
-                                                       double* __restrict__ state, double cg_eps, int full_grad,
-                                                       int64_t M) {
+__device__ __forceinline__ void cg_step_body(double* __restrict__ X, double* __restrict__ R,
+                                             const double* __restrict__ P, const double* __restrict__ AP,
+                                             double* __restrict__ state, double cg_eps, int full_grad, int64_t M) {
   __shared__ double red[16];
   if (state[2] != 0.0) return;
   double s = 0.0;
@@ -56,9 +55,8 @@ __global__ __launch_bounds__(1024) void cg_step_kernel(double* __restrict__ X, d
   if (threadIdx.x == 0) state[3] = a;
 }
 
-__global__ __launch_bounds__(1024) void cg_finish_kernel(const double* __restrict__ R, double* __restrict__ P,
-                                                         double* __restrict__ state, double cg_eps, double tol,
-                                                         int64_t M) {
+__device__ __forceinline__ void cg_finish_body(const double* __restrict__ R, double* __restrict__ P,
+                                               double* __restrict__ state, double cg_eps, double tol, int64_t M) {
   __shared__ double red[16];
   if (state[2] != 0.0) return;
   double s = 0.0;
@@ -82,6 +80,52 @@ __global__ __launch_bounds__(1024) void cg_finish_kernel(const double* __restric
   }
 }
 
+__global__ __launch_bounds__(1024) void cg_init_kernel(const double* __restrict__ B, double* __restrict__ X,
+                                                       double* __restrict__ R, double* __restrict__ P,
+                                                       double* __restrict__ state, int64_t M) {
+  cg_init_body(B, X, R, P, state, M);
+}
+__global__ __launch_bounds__(1024) void cg_step_kernel(double* __restrict__ X, double* __restrict__ R,
+                                                       const double* __restrict__ P, const double* __restrict__ AP,
+                                                       double* __restrict__ state, double cg_eps, int full_grad,
+                                                       int64_t M) {
+  cg_step_body(X, R, P, AP, state, cg_eps, full_grad, M);
+}
+__global__ __launch_bounds__(1024) void cg_finish_kernel(const double* __restrict__ R, double* __restrict__ P,
+                                                         double* __restrict__ state, double cg_eps, double tol,
+                                                         int64_t M) {
+  cg_finish_body(R, P, state, cg_eps, tol, M);
+}
+
+// ---- the same updates for the classes of a batch: one workgroup per class, vectors vstride apart, 4 state words each
+__global__ __launch_bounds__(1024) void cg_init_batched_kernel(VecBatch vb, const double* __restrict__ B,
+                                                               double* __restrict__ X, double* __restrict__ R,
+                                                               double* __restrict__ P, double* __restrict__ state,
+                                                               int64_t vs) {
+  const int64_t b = blockIdx.x;
+  cg_init_body(B + b * vs, X + b * vs, R + b * vs, P + b * vs, state + 4 * b, vb.M[b]);
+}
+__global__ __launch_bounds__(1024) void cg_step_batched_kernel(VecBatch vb, double* __restrict__ X, double* __restrict__ R,
+                                                               const double* __restrict__ P, const double* __restrict__ AP,
+                                                               double* __restrict__ state, double cg_eps, int full_grad,
+                                                               int64_t vs) {
+  const int64_t b = blockIdx.x;
+  cg_step_body(X + b * vs, R + b * vs, P + b * vs, AP + b * vs, state + 4 * b, cg_eps, full_grad, vb.M[b]);
+}
+__global__ __launch_bounds__(1024) void cg_finish_batched_kernel(VecBatch vb, const double* __restrict__ R,
+                                                                 double* __restrict__ P, double* __restrict__ state,
+                                                                 double cg_eps, double tol, int64_t vs) {
+  const int64_t b = blockIdx.x;
+  cg_finish_body(R + b * vs, P + b * vs, state + 4 * b, cg_eps, tol, vb.M[b]);
+}
+// R = B - AX (the periodic full residual in its plain form: y = a x + b y of odx_axpby_f64 with a = -1, b = 1 on a copy of B)
+__global__ __launch_bounds__(256) void cg_full_residual_batched_kernel(VecBatch vb, const double* __restrict__ B,
+                                                                       const double* __restrict__ AX, double* __restrict__ R,
+                                                                       int64_t vs) {
+  const int64_t b = blockIdx.y, i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < vb.M[b]) R[b * vs + i] = -1.0 * AX[b * vs + i] + 1.0 * B[b * vs + i];
+}
+
 // R = B - (AX + a AP) with a = state[3], the step cg_step_kernel has just taken: the full residual B - W x_new of the
 // periodic recomputation, from W x_old and W p (W is linear, x_new = x_old + a p) — both products come out of one
 // two-vector pass over K_nM (odx_knm_fwd_bwd2) made BEFORE the step.
@@ -98,6 +142,42 @@ __global__ __launch_bounds__(256) void axpby_kernel(double a, const double* __re
                                                     double* __restrict__ y, int64_t M) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < M) y[i] = a * x[i] + (b != 0.0 ? b * y[i] : 0.0);
+}
+
+static int vb_max(const VecBatch& vb) {
+  int mm = 0;
+  for (int b = 0; b < vb.B; ++b) mm = vb.M[b] > mm ? vb.M[b] : mm;
+  return mm;
+}
+
+int cg_init_batched(const VecBatch& vb, const double* Bv, double* X, double* R, double* P, double* state, int64_t vstride,
+                    hipStream_t stream) {
+  hipLaunchKernelGGL(cg_init_batched_kernel, dim3((unsigned)vb.B), dim3(1024), 0, stream, vb, Bv, X, R, P, state, vstride);
+  ODX_CHECK_LAUNCH("cg_init_batched");
+  return ODX_OK;
+}
+int cg_step_batched(const VecBatch& vb, double* X, double* R, const double* P, const double* AP, double* state,
+                    double cg_eps, int full_grad, int64_t vstride, hipStream_t stream) {
+  hipLaunchKernelGGL(cg_step_batched_kernel, dim3((unsigned)vb.B), dim3(1024), 0, stream, vb, X, R, P, AP, state, cg_eps,
+                     full_grad, vstride);
+  ODX_CHECK_LAUNCH("cg_step_batched");
+  return ODX_OK;
+}
+int cg_finish_batched(const VecBatch& vb, const double* R, double* P, double* state, double cg_eps, double tol,
+                      int64_t vstride, hipStream_t stream) {
+  hipLaunchKernelGGL(cg_finish_batched_kernel, dim3((unsigned)vb.B), dim3(1024), 0, stream, vb, R, P, state, cg_eps, tol,
+                     vstride);
+  ODX_CHECK_LAUNCH("cg_finish_batched");
+  return ODX_OK;
+}
+int cg_full_residual_batched(const VecBatch& vb, const double* Bv, const double* AX, double* R, int64_t vstride,
+                             hipStream_t stream) {
+  const int mm = vb_max(vb);
+  if (mm <= 0) return ODX_OK;
+  hipLaunchKernelGGL(cg_full_residual_batched_kernel, dim3((unsigned)ceil_div(mm, 256), (unsigned)vb.B), dim3(256), 0,
+                     stream, vb, Bv, AX, R, vstride);
+  ODX_CHECK_LAUNCH("cg_full_residual_batched");
+  return ODX_OK;
 }
 
 }  // namespace odx

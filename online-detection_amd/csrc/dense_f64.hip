@@ -430,10 +430,9 @@ __global__ __launch_bounds__(256) void place_diag_inverses_kernel(const double* 
 
 // y[i] = alpha * sum_{j in tri range} Tri[i][j] x[j] + beta * z[i]; one wave per row, 16-byte loads, four of them in
 // flight per lane (four partial sums) over the aligned pairs of the row's range; the odd elements at its ends go to lane 0.
-__global__ __launch_bounds__(256) void trmv_f64_kernel(const double* __restrict__ Tri, int64_t ld, int64_t M,
-                                                       int uplo, const double* __restrict__ x, double alpha,
-                                                       double beta, const double* __restrict__ z,
-                                                       double* __restrict__ y) {
+__device__ __forceinline__ void trmv_row(const double* __restrict__ Tri, int64_t ld, int64_t M, int uplo,
+                                         const double* __restrict__ x, double alpha, double beta,
+                                         const double* __restrict__ z, double* __restrict__ y) {
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= M) return;
@@ -469,6 +468,25 @@ __global__ __launch_bounds__(256) void trmv_f64_kernel(const double* __restrict_
     if (beta != 0.0) r += beta * z[i];
     y[i] = r;
   }
+}
+
+__global__ __launch_bounds__(256) void trmv_f64_kernel(const double* __restrict__ Tri, int64_t ld, int64_t M,
+                                                       int uplo, const double* __restrict__ x, double alpha,
+                                                       double beta, const double* __restrict__ z,
+                                                       double* __restrict__ y) {
+  trmv_row(Tri, ld, M, uplo, x, alpha, beta, z, y);
+}
+
+// The same product for the classes of a batch (blockIdx.y = class): factors tri_stride apart, vectors vstride apart,
+// each class with its own size and (when `scaled`) its own alpha.  Per class the arithmetic of trmv_f64_kernel.
+__global__ __launch_bounds__(256) void trmv_batched_kernel(const double* __restrict__ Tri, int64_t ld, int64_t tri_stride,
+                                                           int uplo, VecBatch vb, const double* __restrict__ x,
+                                                           int64_t xstride, int scaled, double beta,
+                                                           const double* __restrict__ z, int64_t zstride,
+                                                           double* __restrict__ y, int64_t ystride) {
+  const int b = blockIdx.y;
+  trmv_row(Tri + (int64_t)b * tri_stride, ld, vb.M[b], uplo, x + (int64_t)b * xstride, scaled ? vb.scale[b] : 1.0, beta,
+           z ? z + (int64_t)b * zstride : nullptr, y + (int64_t)b * ystride);
 }
 
 // ---------------------------------------------------------------- host drivers
@@ -653,6 +671,18 @@ int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hi
   hipLaunchKernelGGL(trtri_diag_kernel, dim3((unsigned)ceil_div(M, NB), (unsigned)Z), dim3(DB_NT), 0, stream, A, lda, M,
                      Dinv, zb.strideA, zb.strideD);
   ODX_CHECK_LAUNCH("trtri_diag");
+  return ODX_OK;
+}
+
+int trmv_batched_f64(const double* Tri, int64_t ld, int64_t tri_stride, int uplo, const VecBatch& vb, const double* x,
+                     int64_t xstride, bool scaled, double beta, const double* z, int64_t zstride, double* y,
+                     int64_t ystride, hipStream_t stream) {
+  int mm = 0;
+  for (int b = 0; b < vb.B; ++b) mm = vb.M[b] > mm ? vb.M[b] : mm;
+  if (mm <= 0) return ODX_OK;
+  hipLaunchKernelGGL(trmv_batched_kernel, dim3((unsigned)ceil_div(mm, 4), (unsigned)vb.B), dim3(256), 0, stream, Tri, ld,
+                     tri_stride, uplo, vb, x, xstride, scaled ? 1 : 0, beta, z, zstride, y, ystride);
+  ODX_CHECK_LAUNCH("trmv_batched_f64");
   return ODX_OK;
 }
 
@@ -916,23 +946,30 @@ extern "C" int odx_falkon_precond_batched_f64(const float* const* Z, const int64
   ODX_CHECK_HIP(hipMemsetAsync(info, 0, (size_t)B * sizeof(int32_t), s));
   ODX_CHECK_HIP(hipMemsetAsync(Zd0, 0, (size_t)((int64_t)B * zper) * sizeof(double), s));
   ODX_CHECK_HIP(hipMemsetAsync(W0, 0, (size_t)(3 * (int64_t)B * wsz) * sizeof(double), s));      // W0, W1, W2
-  // W0_b = [K_MM_b + eps M_b I, 0; 0, I]  (lower)
-  for (int b = 0; b < B; ++b) {
-    double* Zd = Zd0 + (int64_t)b * zper;
-    ODX_PROPAGATE(odx_convert_f32_f64(Z[b], ldz[b], Zd, ldzd, M[b], D, stream));
-    ODX_PROPAGATE(gauss_kmm_f64(Zd, ldzd, M[b], D, sigma, eps * (double)M[b], W0 + (int64_t)b * wsz, wld, Zd + Mmax * ldzd, s));
-    if (M[b] < Mmax) ODX_PROPAGATE(add_diag_f64(W0 + (int64_t)b * wsz + M[b] * (wld + 1), wld, Mmax - M[b], 1.0, s));
+  // every output factor starts as zero (the inverses are written triangle by triangle): one fill for the whole block
+  if (out_stride == 4 * Mmax * ld) {
+    ODX_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)((int64_t)B * out_stride) * sizeof(double), s));
+  } else {
+    for (int b = 0; b < B; ++b)
+      ODX_CHECK_HIP(hipMemsetAsync(out + (int64_t)b * out_stride, 0, (size_t)(4 * Mmax * ld) * sizeof(double), s));
   }
+  // W0_b = [K_MM_b + eps M_b I, 0; 0, I]  (lower): the K_MM of all classes by one launch
+  VecBatch kb;
+  kb.B = B;
+  for (int b = 0; b < B; ++b) {
+    ODX_PROPAGATE(odx_convert_f32_f64(Z[b], ldz[b], Zd0 + (int64_t)b * zper, ldzd, M[b], D, stream));
+    kb.M[b] = (int)M[b];
+    kb.scale[b] = eps * (double)M[b];
+  }
+  ODX_PROPAGATE(gauss_kmm_f64_batched(Zd0, ldzd, zper, Mmax * ldzd, kb, D, sigma, W0, wld, wsz, s));
+  for (int b = 0; b < B; ++b)
+    if (M[b] < Mmax) ODX_PROPAGATE(add_diag_f64(W0 + (int64_t)b * wsz + M[b] * (wld + 1), wld, Mmax - M[b], 1.0, s));
   ZBatch zt;
   zt.count = B; zt.strideA = wsz; zt.strideD = dsz; zt.strideO = out_stride; zt.strideW = wsz;
   ODX_PROPAGATE(potrf_f64(W0, wld, Mmax, DinvT, info, s, zt));
   // fork: inverses of all L_T on the side stream (scratch W3)
   ODX_CHECK_HIP(hipEventRecord(side->fork, s));
   ODX_CHECK_HIP(hipStreamWaitEvent(s2, side->fork, 0));
-  for (int b = 0; b < B; ++b) {
-    ODX_PROPAGATE(fill_f64(LTi + (int64_t)b * out_stride, ld, Mmax, Mmax, 0.0, s2));
-    ODX_PROPAGATE(fill_f64(LTit + (int64_t)b * out_stride, ld, Mmax, Mmax, 0.0, s2));
-  }
   ODX_PROPAGATE(trtri_from_diag_f64(W0, wld, Mmax, DinvT, LTi, LTit, ld, W3, s2, zt));
   ODX_CHECK_HIP(hipEventRecord(side->join, s2));
   // main: W1 = L_T' = T; W2 = T T' / M_b + lam I; L_A in place in W2
@@ -951,9 +988,5 @@ extern "C" int odx_falkon_precond_batched_f64(const float* const* Z, const int64
   ODX_PROPAGATE(potrf_f64(W2, wld, Mmax, DinvA, info, s, zt));
   // join, then the inverses of L_A (scratch W1: T is no longer needed)
   ODX_CHECK_HIP(hipStreamWaitEvent(s, side->join, 0));
-  for (int b = 0; b < B; ++b) {
-    ODX_PROPAGATE(fill_f64(LAi + (int64_t)b * out_stride, ld, Mmax, Mmax, 0.0, s));
-    ODX_PROPAGATE(fill_f64(LAit + (int64_t)b * out_stride, ld, Mmax, Mmax, 0.0, s));
-  }
   return trtri_from_diag_f64(W2, wld, Mmax, DinvA, LAi, LAit, ld, W1, s, zt);
 }

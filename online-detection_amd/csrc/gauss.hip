@@ -1,7 +1,7 @@
 // Gaussian-kernel blocks on the MFMA tile core (gfx950).
 //   odx_gauss_knm_f32 : K_nM = exp(gamma * max(0, |x|^2 + |z|^2 - 2 x.z)), stored f32 (A3)
 //   odx_gauss_mmv_f32 : out[:, c] = K(X, Z[range c]) V[range c, c], K never stored, f64 sums (A5/A9)
-//   gauss_kmm_f64     : K_MM in f64 for the preconditioner (lower tiles only)
+//   gauss_kmm_f64     : K_MM in f64 for the preconditioner (lower triangle; f64 GEMM + elementwise epilogue)
 // The -2 X Z' contraction runs on v_mfma_f32_32x32x2_f32 (bit-exact f32 fmaf chain); the
 // norm broadcast, clamp, scale and exp are fused into the accumulator epilogue, so the
 // distance matrix never touches memory.
@@ -144,54 +144,75 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gauss_mmv_f32_kernel(
   }
 }
 
-// ---------------------------------------------------------------- K_MM (f64, lower tiles)
-__global__ __launch_bounds__(GEMM_THREADS) void gauss_kmm_f64_kernel(const double* __restrict__ Zd, int64_t ldz,
-                                                                    const double* __restrict__ zsq, int64_t M, int D,
-                                                                    double gamma, double diag_add,
-                                                                    double* __restrict__ Kmm, int64_t ldk) {
-  __shared__ __attribute__((aligned(16))) char lds[GEMM_LDS_BYTES];
-  const int64_t tiles_n = (M + GEMM_BN - 1) / GEMM_BN;
-  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t i0 = (wg / tiles_n) * GEMM_BM, j0 = (wg % tiles_n) * GEMM_BN;
-  if (j0 > i0 + GEMM_BM - 1) return;  // lower triangle only
-
-  f64x4 acc[4][4];
-  gemm_zero_acc<double>(acc);
-  gemm_mainloop<double>(acc, Zd, ldz, M, Zd, ldz, M, i0, j0, 0, D, lds);
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-#pragma unroll
-  for (int tn = 0; tn < 4; ++tn) {
-    const int64_t col = j0 + wc * 64 + gemm_acc_col<double>(tn, lane);
-    const double zs = col < M ? zsq[col] : 0.0;
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t row = i0 + wr * 64 + gemm_acc_row<double>(tm, r, lane);
-        if (row < M && col < M) {
-          double d2 = fma(-2.0, acc[tm][tn][r], zsq[row]) + zs;
-          d2 = fmax(d2, 0.0);
-          double v = exp(d2 * gamma);
-          if (row == col) v += diag_add;
-          Kmm[row * ldk + col] = v;
-        }
-      }
+// ---------------------------------------------------------------- K_MM (f64, lower triangle)
+__global__ __launch_bounds__(256) void row_sqnorm_f64_batched_kernel(const double* __restrict__ Zd, int64_t ldz,
+                                                                     int64_t z_stride, int64_t zsq_off, VecBatch vb, int D) {
+  const int64_t b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= vb.M[b]) return;
+  const double* x = Zd + b * z_stride + row * ldz;
+  double s = 0.0;
+  const int nvec = D / 2;
+  for (int c = lane; c < nvec; c += 64) {
+    const f64x2 v = *reinterpret_cast<const f64x2*>(x + c * 2);
+    s = fma(v[0], v[0], s);
+    s = fma(v[1], v[1], s);
   }
+  for (int d = nvec * 2 + lane; d < D; d += 64) s = fma(x[d], x[d], s);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) (const_cast<double*>(Zd) + b * z_stride + zsq_off)[row] = s;
 }
 
+// K_MM = exp(gamma max(0, |z_i|^2 + |z_j|^2 - 2 z_i.z_j)) (+ diag) on the lower triangle, in two steps: the Gram block
+// Z Z' by the f64 NT GEMM (128 x 64 tiles, three workgroups per CU: 60 TFLOP/s where the one-workgroup 128 x 128 tile
+// kernel above reaches 20), then this elementwise pass over the lower triangle (0.3 ms at M = 1e4).
+__global__ __launch_bounds__(256) void kmm_epilogue_kernel(double* __restrict__ Kmm, int64_t ldk, int64_t k_stride,
+                                                           const double* __restrict__ zsq, int64_t zsq_stride, VecBatch vb,
+                                                           double gamma) {
+  const int64_t b = blockIdx.z, row = blockIdx.y;
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= vb.M[b] || col > row) return;
+  const double* zs = zsq + b * zsq_stride;
+  double* g = Kmm + b * k_stride + row * ldk + col;
+  double d2 = fma(-2.0, *g, zs[row]) + zs[col];
+  d2 = fmax(d2, 0.0);
+  double v = exp(d2 * gamma);
+  if (row == col) v += vb.scale[b];
+  *g = v;
+}
+
+int gauss_kmm_f64_batched(const double* Zd, int64_t ldz, int64_t z_stride, int64_t zsq_off, const VecBatch& vb, int D,
+                          double sigma, double* Kmm, int64_t ldk, int64_t k_stride, hipStream_t stream) {
+  ODX_REQUIRE(ldz % 2 == 0 && z_stride % 2 == 0 && aligned16(Zd), "gauss_kmm_f64_batched: Zd must be 16-byte aligned, even strides");
+  int mm = 0;
+  for (int b = 0; b < vb.B; ++b) mm = vb.M[b] > mm ? vb.M[b] : mm;
+  if (mm <= 0) return ODX_OK;
+  hipLaunchKernelGGL(row_sqnorm_f64_batched_kernel, dim3((unsigned)ceil_div(mm, 4), (unsigned)vb.B), dim3(256), 0, stream, Zd,
+                     ldz, z_stride, zsq_off, vb, D);
+  ODX_CHECK_LAUNCH("row_sqnorm_f64_batched");
+  GemmParams<double> g;                      // rows past a class's M are zero in Zd: their Gram entries come out zero
+  g.A = Zd; g.lda = ldz; g.B = Zd; g.ldb = ldz; g.C = Kmm; g.ldc = ldk;
+  g.m = mm; g.n = mm; g.k = D; g.alpha = 1.0; g.beta = 0.0; g.flags = ODX_GEMM_LOWER_ONLY;
+  g.zbatches = vb.B; g.zstrideA = z_stride; g.zstrideB = z_stride; g.zstrideC = k_stride;
+  ODX_PROPAGATE(launch_gemm_f64(g, stream));
+  ODX_REQUIRE(mm < 65536, "gauss_kmm_f64: M must be below 65536");
+  hipLaunchKernelGGL(kmm_epilogue_kernel, dim3((unsigned)ceil_div(mm, 256), (unsigned)mm, (unsigned)vb.B), dim3(256), 0, stream,
+                     Kmm, ldk, k_stride, Zd + zsq_off, z_stride, vb, -0.5 / (sigma * sigma));
+  ODX_CHECK_LAUNCH("kmm_epilogue");
+  return ODX_OK;
+}
+
+// one class: Zd (M x ldz) with its squared norms written to zsq
 int gauss_kmm_f64(const double* Zd, int64_t ldz, int64_t M, int D, double sigma, double diag_add, double* Kmm,
                   int64_t ldk, double* zsq, hipStream_t stream) {
   ODX_REQUIRE(ldz % 2 == 0 && aligned16(Zd), "gauss_kmm_f64: Zd must be 16-byte aligned with even ld");
-  hipLaunchKernelGGL((row_sqnorm_kernel<double, f64x2>), dim3((unsigned)ceil_div(M, 4)), dim3(256), 0, stream, Zd,
-                     ldz, M, D, zsq);
-  ODX_CHECK_LAUNCH("row_sqnorm_f64");
-  const int64_t t = ceil_div(M, GEMM_BM);
-  hipLaunchKernelGGL(gauss_kmm_f64_kernel, dim3((unsigned)(t * t)), dim3(GEMM_THREADS), 0, stream, Zd, ldz, zsq, M,
-                     D, -0.5 / (sigma * sigma), diag_add, Kmm, ldk);
-  ODX_CHECK_LAUNCH("gauss_kmm_f64");
-  return ODX_OK;
+  VecBatch vb;
+  vb.B = 1;
+  vb.M[0] = (int)M;
+  vb.scale[0] = diag_add;
+  return gauss_kmm_f64_batched(Zd, ldz, 0, zsq - Zd, vb, D, sigma, Kmm, ldk, 0, stream);
 }
 
 }  // namespace odx

@@ -12,6 +12,8 @@
 //
 // Requirements: ldk % 4 == 0, K 16-byte aligned, columns [M, roundup(M,4)) of K are zero
 // (odx_gauss_knm_f32 writes them so).
+#include <algorithm>
+
 #include "odx_internal.h"
 
 namespace odx {
@@ -24,10 +26,10 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 // pass of its own.  With NV = 2 both vectors sit in dynamic LDS (2 x roundup(M, 4) x 8 B, M <= 10 000 on the 512-thread
 // configurations) and the slab of a workgroup holds its two column-sum vectors back to back.
 template <int NT, int CH, int R, int NV>
-__global__ __launch_bounds__(NT) void knm_pass_kernel(const float* __restrict__ K, int64_t ldk, int64_t n, int64_t M,
-                                                      const double* __restrict__ v, const double* __restrict__ v2,
-                                                      const double* __restrict__ w, double* __restrict__ slab,
-                                                      int64_t slab_ld) {
+__device__ __forceinline__ void knm_pass_body(const float* __restrict__ K, int64_t ldk, int64_t n, int64_t M,
+                                              const double* __restrict__ v, const double* __restrict__ v2,
+                                              const double* __restrict__ w, double* __restrict__ slab, int64_t slab_ld,
+                                              const int64_t wg, const int64_t nwg) {
   constexpr int NW = NT / 64;
   constexpr int VCAP = (NT * CH * 4 < 20000) ? NT * CH * 4 : 20000;  // 160,000 B of the 163,840 B LDS at most
   __shared__ __attribute__((aligned(16))) double vs_static[NV == 1 ? VCAP : 2];
@@ -68,14 +70,14 @@ __global__ __launch_bounds__(NT) void knm_pass_kernel(const float* __restrict__ 
     }
   };
 
-  int64_t blk = blockIdx.x;
+  int64_t blk = wg;
   if (blk < nblk) {
 #pragma unroll
     for (int c = 0; c < CH; ++c) load_block(blk, c);
   }
   __syncthreads();  // vs is complete
   int pp = 0;
-  for (; blk < nblk; blk += gridDim.x) {
+  for (; blk < nblk; blk += nwg) {
     double t[NV][R];
     if (v != nullptr) {
       // phase 1: row dots
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(NT) void knm_pass_kernel(const float* __restrict__ 
       }
     }
     // phase 2: column sums, and the next block's loads re-issued chunk by chunk
-    const int64_t nxt = blk + gridDim.x;
+    const int64_t nxt = blk + nwg;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
 #pragma unroll
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(NT) void knm_pass_kernel(const float* __restrict__ 
       if (nxt < nblk) load_block(nxt, c);
     }
   }
-  double* my = slab + (int64_t)blockIdx.x * slab_ld * NV;
+  double* my = slab + wg * slab_ld * NV;
 #pragma unroll
   for (int q = 0; q < NV; ++q)
 #pragma unroll
@@ -158,6 +160,53 @@ __global__ __launch_bounds__(NT) void knm_pass_kernel(const float* __restrict__ 
     }
 }
 
+
+template <int NT, int CH, int R, int NV>
+__global__ __launch_bounds__(NT) void knm_pass_kernel(const float* __restrict__ K, int64_t ldk, int64_t n, int64_t M,
+                                                      const double* __restrict__ v, const double* __restrict__ v2,
+                                                      const double* __restrict__ w, double* __restrict__ slab,
+                                                      int64_t slab_ld) {
+  knm_pass_body<NT, CH, R, NV>(K, ldk, n, M, v, v2, w, slab, slab_ld, blockIdx.x, gridDim.x);
+}
+
+// The same pass for the classes of a batch (blockIdx.y = class): class b's block is walked by grid[b] workgroups exactly as
+// its own odx_knm_fwd_bwd launch would walk it (same workgroup -> rows assignment, same slab order), so the sums are the
+// single-class call's bit for bit.  Vectors and slabs of the classes lie vstride / slab_stride elements apart.
+struct PassBatch {
+  const float* K[ODX_MAX_ZBATCH];
+  int64_t ldk[ODX_MAX_ZBATCH];
+  int64_t n[ODX_MAX_ZBATCH];
+  int M[ODX_MAX_ZBATCH];
+  int grid[ODX_MAX_ZBATCH];
+};
+
+template <int NT, int CH, int R>
+__global__ __launch_bounds__(NT) void knm_pass_batched_kernel(PassBatch pb, const double* __restrict__ v, int64_t vstride,
+                                                              double* __restrict__ slab, int64_t slab_ld,
+                                                              int64_t slab_stride) {
+  const int b = blockIdx.y;
+  if ((int)blockIdx.x >= pb.grid[b]) return;
+  knm_pass_body<NT, CH, R, 1>(pb.K[b], pb.ldk[b], pb.n[b], pb.M[b], v + (int64_t)b * vstride, nullptr, nullptr,
+                              slab + (int64_t)b * slab_stride, slab_ld, blockIdx.x, pb.grid[b]);
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_batched_kernel(PassBatch pb, const double* __restrict__ slab,
+                                                                  int64_t slab_ld, int64_t slab_stride,
+                                                                  double* __restrict__ out, int64_t ostride) {
+  __shared__ double part[4][64];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t j = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t M = pb.M[b];
+  const int nslab = pb.grid[b];
+  const double* base = slab + (int64_t)b * slab_stride;
+  double s = 0.0;
+  if (j < M)
+    for (int g = wave; g < nslab; g += 4) s += base[(int64_t)g * slab_ld + j];
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && j < M) out[(int64_t)b * ostride + j] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+}
 
 // ---------------------------------------------------------------- two vectors, one read of K
 // out = K' (K v1), out2 = K' (K v2): the same persistent row-block scheme with two sets of row dots and column sums.  The
@@ -356,6 +405,92 @@ static int grid_for(const PassCfg& cfg, int64_t n) {
   if (g > nblk) g = nblk;
   if (g < 1) g = 1;
   return (int)g;
+}
+
+// ---- class-batched pass (internal; the batched CG of solve.cpp drives it)
+bool knm_pass_batch_cfg(int B, const int64_t* M, int* nt, int* ch, int* r) {
+  PassCfg c0;
+  for (int b = 0; b < B; ++b) {
+    PassCfg c;
+    if (M[b] <= 0 || !pick_cfg(M[b], &c)) return false;
+    if (b == 0) c0 = c;
+    else if (c.nt != c0.nt || c.ch != c0.ch || c.r != c0.r) return false;
+  }
+  if (nt) *nt = c0.nt;
+  if (ch) *ch = c0.ch;
+  if (r) *r = c0.r;
+  return B > 0;
+}
+
+static void batch_geometry(int B, const int64_t* n, const int64_t* M, const PassCfg& cfg, int* gmax, int64_t* slab_ld) {
+  int g = 1;
+  int64_t mm = 1;
+  for (int b = 0; b < B; ++b) {
+    if (n[b] > 0) g = std::max(g, grid_for(cfg, n[b]));
+    mm = std::max(mm, M[b]);
+  }
+  *gmax = g;
+  *slab_ld = round_up(mm, 4);
+}
+
+int64_t knm_pass_batched_workspace_bytes(int B, const int64_t* n, const int64_t* M) {
+  PassCfg cfg;
+  int nt, ch, r;
+  if (!knm_pass_batch_cfg(B, M, &nt, &ch, &r) || !pick_cfg(M[0], &cfg)) return ODX_ERR_UNSUPPORTED;
+  int gmax;
+  int64_t slab_ld;
+  batch_geometry(B, n, M, cfg, &gmax, &slab_ld);
+  return (int64_t)B * gmax * slab_ld * (int64_t)sizeof(double);
+}
+
+#define ODX_PASSB_LAUNCH(NT_, CH_, R_)                                                                               \
+  hipLaunchKernelGGL((knm_pass_batched_kernel<NT_, CH_, R_>), dim3(gmax, B), dim3(NT_), 0, s, pb, v, vstride, slab, \
+                     slab_ld, slab_stride)
+
+// out[b] = K_b' (K_b v[b]) for the B classes of a batch with ONE pass launch and ONE reduce launch; class b is handled
+// exactly as odx_knm_fwd_bwd(K_b, ..) would handle it (same configuration, same workgroup count, same slab order).
+int knm_pass_batched(int B, const float* const* K, const int64_t* ldk, const int64_t* n, const int64_t* M, const double* v,
+                     int64_t vstride, double* out, int64_t ostride, void* workspace, int64_t workspace_bytes,
+                     hipStream_t s) {
+  ODX_REQUIRE(B >= 1 && B <= ODX_MAX_ZBATCH, "knm_pass_batched: 1..%d classes", ODX_MAX_ZBATCH);
+  PassCfg cfg;
+  ODX_REQUIRE(knm_pass_batch_cfg(B, M, nullptr, nullptr, nullptr) && pick_cfg(M[0], &cfg),
+              "knm_pass_batched: the classes of a batch must share one pass configuration");
+  int gmax;
+  int64_t slab_ld;
+  batch_geometry(B, n, M, cfg, &gmax, &slab_ld);
+  const int64_t slab_stride = (int64_t)gmax * slab_ld;
+  if (workspace == nullptr || workspace_bytes < (int64_t)B * slab_stride * (int64_t)sizeof(double)) {
+    set_error("knm_pass_batched: workspace too small");
+    return ODX_ERR_WORKSPACE;
+  }
+  PassBatch pb;
+  for (int b = 0; b < ODX_MAX_ZBATCH; ++b) {
+    const bool on = b < B;
+    pb.K[b] = on ? K[b] : nullptr;
+    pb.ldk[b] = on ? ldk[b] : 0;
+    pb.n[b] = on ? n[b] : 0;
+    pb.M[b] = on ? (int)M[b] : 0;
+    pb.grid[b] = (on && n[b] > 0) ? grid_for(cfg, n[b]) : 0;
+    if (on && n[b] > 0)
+      ODX_REQUIRE(K[b] && ldk[b] % 4 == 0 && ldk[b] >= round_up(M[b], 4) && aligned16(K[b]),
+                  "knm_pass_batched: class %d: K must be 16-byte aligned with ldk %% 4 == 0, ldk >= roundup(M, 4)", b);
+  }
+  double* slab = static_cast<double*>(workspace);
+  if (cfg.nt == 256 && cfg.ch == 1) ODX_PASSB_LAUNCH(256, 1, 16);
+  else if (cfg.nt == 256 && cfg.ch == 2) ODX_PASSB_LAUNCH(256, 2, 8);
+  else if (cfg.nt == 256 && cfg.ch == 4) ODX_PASSB_LAUNCH(256, 4, 4);
+  else if (cfg.nt == 512 && cfg.ch == 4) ODX_PASSB_LAUNCH(512, 4, 4);
+  else if (cfg.nt == 512 && cfg.ch == 5) ODX_PASSB_LAUNCH(512, 5, 4);
+  else if (cfg.nt == 512 && cfg.ch == 6) ODX_PASSB_LAUNCH(512, 6, 2);
+  else ODX_PASSB_LAUNCH(1024, 5, 1);
+  ODX_CHECK_LAUNCH("knm_pass_batched");
+  int64_t mm = 1;
+  for (int b = 0; b < B; ++b) mm = std::max(mm, M[b]);
+  hipLaunchKernelGGL(slab_reduce_batched_kernel, dim3((unsigned)ceil_div(mm, 64), B), dim3(256), 0, s, pb, slab, slab_ld,
+                     slab_stride, out, ostride);
+  ODX_CHECK_LAUNCH("knm_pass_batched(reduce)");
+  return ODX_OK;
 }
 
 }  // namespace odx

@@ -56,8 +56,36 @@ int fill_f64(double* A, int64_t lda, int64_t rows, int64_t cols, double value, h
 // knm_pass.hip: out[j] = sum_g slab[g][j], g = 0 .. nslab - 1, in a fixed order
 int slab_reduce_f64(const double* slab, int64_t slab_ld, int nslab, int64_t M, double* out, hipStream_t stream);
 
+// knm_pass.hip: the CG pass for a batch of classes (one launch; per class the arithmetic of odx_knm_fwd_bwd)
+bool knm_pass_batch_cfg(int B, const int64_t* M, int* nt, int* ch, int* r);
+int64_t knm_pass_batched_workspace_bytes(int B, const int64_t* n, const int64_t* M);
+int knm_pass_batched(int B, const float* const* K, const int64_t* ldk, const int64_t* n, const int64_t* M, const double* v,
+                     int64_t vstride, double* out, int64_t ostride, void* workspace, int64_t workspace_bytes,
+                     hipStream_t stream);
+
+// dense_f64.hip / cg.hip: class-batched small algebra of the CG (blockIdx.y = class; vectors vstride apart)
+struct VecBatch {
+  int B = 1;
+  int M[ODX_MAX_ZBATCH] = {};
+  double scale[ODX_MAX_ZBATCH] = {};     // per-class alpha of a triangular product (1 / n_total)
+};
+int trmv_batched_f64(const double* Tri, int64_t ld, int64_t tri_stride, int uplo, const VecBatch& vb, const double* x,
+                     int64_t xstride, bool scaled, double beta, const double* z, int64_t zstride, double* y,
+                     int64_t ystride, hipStream_t stream);
+int cg_init_batched(const VecBatch& vb, const double* Bv, double* X, double* R, double* P, double* state, int64_t vstride,
+                    hipStream_t stream);
+int cg_step_batched(const VecBatch& vb, double* X, double* R, const double* P, const double* AP, double* state,
+                    double cg_eps, int full_grad, int64_t vstride, hipStream_t stream);
+int cg_finish_batched(const VecBatch& vb, const double* R, double* P, double* state, double cg_eps, double tol,
+                      int64_t vstride, hipStream_t stream);
+int cg_full_residual_batched(const VecBatch& vb, const double* Bv, const double* AX, double* R, int64_t vstride,
+                             hipStream_t stream);
+
 // gauss.hip
 int gauss_kmm_f64(const double* Zd, int64_t ldz, int64_t M, int D, double sigma, double diag_add, double* Kmm,
                   int64_t ldk, double* zsq /* M */, hipStream_t stream);
+
+int gauss_kmm_f64_batched(const double* Zd, int64_t ldz, int64_t z_stride, int64_t zsq_off, const VecBatch& vb, int D,
+                          double sigma, double* Kmm, int64_t ldk, int64_t k_stride, hipStream_t stream);
 
 }  // namespace odx

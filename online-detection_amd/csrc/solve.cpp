@@ -6,7 +6,7 @@
 //
 // Reference: InCoreFalkon.fit -> ConjugateGradient.solve at FALKONWrapper_with_centers_selection_incore.py:56-68
 // (falkon's defaults: 20 iterations, residual recomputed every 10).
-#include "odx_common.h"
+#include "odx_internal.h"
 
 using namespace odx;
 
@@ -90,4 +90,85 @@ extern "C" int odx_falkon_cg_f64(const float* K, int64_t ldk, int64_t n, int64_t
   }
   ODX_PROPAGATE(odx_trmv_f64(LAit, ldp, M, 1, X, 1.0, 0.0, nullptr, v, stream));
   return odx_trmv_f64(LTit, ldp, M, 1, v, 1.0, 0.0, nullptr, alpha, stream);            // alpha = T^-1 A^-1 beta
+}
+
+// ---------------------------------------------------------------- the same loop for a batch of classes in lock step
+// B independent fits (the classes of one Minibootstrap round, OnlineRegionClassifier_incore.py:96-155) advance through
+// the CG schedule together: every launch of the loop above is issued ONCE with the class as a grid dimension, so a round
+// of 30 fits costs the ~170 launches of one.  Per class the arithmetic is exactly odx_falkon_cg_f64's (same kernels' bodies,
+// same pass configuration and workgroup count, same slab order): alpha comes out bit-identical to the one-class call.
+// The classes must share one pass configuration (odx_falkon_cg_batched_workspace_bytes < 0 otherwise).  A class whose
+// residual meets the tolerance raises its own stop flag and coasts.
+extern "C" int64_t odx_falkon_cg_batched_workspace_bytes(int B, const int64_t* n, const int64_t* M) {
+  if (B < 1 || B > ODX_MAX_ZBATCH || !n || !M) return ODX_ERR_INVALID;
+  const int64_t pass = knm_pass_batched_workspace_bytes(B, n, M);
+  if (pass < 0) return pass;
+  int64_t mm = 1;
+  for (int b = 0; b < B; ++b) mm = M[b] > mm ? M[b] : mm;
+  const int64_t Mp = round_up(mm, 2);
+  return ((int64_t)B * (9 * Mp + 4)) * (int64_t)sizeof(double) + round_up(pass, 16);
+}
+
+extern "C" int odx_falkon_cg_batched_f64(int B, const float* const* K, const int64_t* ldk, const int64_t* n, const int64_t* M,
+                                         const double* P, int64_t ldp, int64_t p_rows, int64_t p_stride, const double* b0,
+                                         int64_t vstride, const double* n_total, double lam, int maxiter,
+                                         int full_gradient_every, double cg_epsilon, double cg_tolerance, double* alpha,
+                                         void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
+  ODX_REQUIRE(B >= 1 && B <= ODX_MAX_ZBATCH && K && ldk && n && M && P && b0 && n_total && alpha && maxiter >= 0 &&
+                  full_gradient_every > 0,
+              "odx_falkon_cg_batched_f64: bad argument");
+  const int64_t need = odx_falkon_cg_batched_workspace_bytes(B, n, M);
+  ODX_REQUIRE(need >= 0, "odx_falkon_cg_batched_f64: the classes of a batch must share one pass configuration");
+  if (workspace == nullptr || workspace_bytes < need || !aligned16(workspace)) {
+    set_error("odx_falkon_cg_batched_f64: workspace too small or not 16-byte aligned");
+    return ODX_ERR_WORKSPACE;
+  }
+  VecBatch vb;
+  vb.B = B;
+  int64_t mm = 1;
+  for (int b = 0; b < B; ++b) {
+    ODX_REQUIRE(M[b] > 0 && M[b] <= p_rows && n[b] >= 0 && n_total[b] > 0, "odx_falkon_cg_batched_f64: class %d: bad sizes", b);
+    vb.M[b] = (int)M[b];
+    vb.scale[b] = 1.0 / n_total[b];
+    mm = M[b] > mm ? M[b] : mm;
+  }
+  ODX_REQUIRE(vstride >= mm && vstride % 2 == 0 && ldp % 2 == 0 && p_stride >= 4 * p_rows * ldp,
+              "odx_falkon_cg_batched_f64: vstride even >= max M, ldp even, p_stride >= 4 p_rows ldp");
+  const int64_t Mp = round_up(mm, 2);
+  double* w = static_cast<double*>(workspace);
+  const int64_t V = (int64_t)B * Mp;            // one vector per class, Mp apart
+  double *v = w, *t = w + V, *cc = w + 2 * V, *u = w + 3 * V, *Bv = w + 4 * V, *X = w + 5 * V, *R = w + 6 * V,
+         *Pv = w + 7 * V, *AP = w + 8 * V, *state = w + 9 * V;
+  void* pass_ws = state + 4 * B;
+  const int64_t pass_bytes = workspace_bytes - ((int64_t)B * (9 * Mp + 4)) * (int64_t)sizeof(double);
+  hipStream_t s = as_stream(stream);
+  const double *LTi = P, *LTit = P + p_rows * ldp, *LAi = P + 2 * p_rows * ldp, *LAit = P + 3 * p_rows * ldp;
+
+  auto mmv = [&](const double* src, double* out) -> int {
+    ODX_PROPAGATE(trmv_batched_f64(LAit, ldp, p_stride, 1, vb, src, Mp, false, 0.0, nullptr, 0, v, Mp, s));
+    ODX_PROPAGATE(trmv_batched_f64(LTit, ldp, p_stride, 1, vb, v, Mp, false, 0.0, nullptr, 0, t, Mp, s));
+    ODX_PROPAGATE(knm_pass_batched(B, K, ldk, n, M, t, Mp, cc, Mp, pass_ws, pass_bytes, s));
+    ODX_PROPAGATE(trmv_batched_f64(LTi, ldp, p_stride, 0, vb, cc, Mp, true, lam, v, Mp, u, Mp, s));
+    return trmv_batched_f64(LAi, ldp, p_stride, 0, vb, u, Mp, false, 0.0, nullptr, 0, out, Mp, s);
+  };
+
+  ODX_CHECK_HIP(hipMemsetAsync(state, 0, (size_t)(4 * B) * sizeof(double), s));
+  // b0 arrives vstride apart; the loop's vectors are Mp apart: u <- T^-T b0, Bv <- A^-T u
+  ODX_PROPAGATE(trmv_batched_f64(LTi, ldp, p_stride, 0, vb, b0, vstride, false, 0.0, nullptr, 0, u, Mp, s));
+  ODX_PROPAGATE(trmv_batched_f64(LAi, ldp, p_stride, 0, vb, u, Mp, false, 0.0, nullptr, 0, Bv, Mp, s));
+  ODX_PROPAGATE(cg_init_batched(vb, Bv, X, R, Pv, state, Mp, s));
+  const double tol = cg_tolerance * cg_tolerance;
+  for (int it = 0; it < maxiter; ++it) {
+    ODX_PROPAGATE(mmv(Pv, AP));
+    const int full = ((it + 1) % full_gradient_every) == 0;
+    ODX_PROPAGATE(cg_step_batched(vb, X, R, Pv, AP, state, cg_epsilon, full, Mp, s));
+    if (it == maxiter - 1) break;
+    if (full) {
+      ODX_PROPAGATE(mmv(X, AP));
+      ODX_PROPAGATE(cg_full_residual_batched(vb, Bv, AP, R, Mp, s));                  // R = B - mmv(X)
+    }
+    ODX_PROPAGATE(cg_finish_batched(vb, R, Pv, state, cg_epsilon, tol, Mp, s));
+  }
+  ODX_PROPAGATE(trmv_batched_f64(LAit, ldp, p_stride, 1, vb, X, Mp, false, 0.0, nullptr, 0, v, Mp, s));
+  return trmv_batched_f64(LTit, ldp, p_stride, 1, vb, v, Mp, false, 0.0, nullptr, 0, alpha, vstride, s);
 }

@@ -38,7 +38,7 @@ class Features:
 
 class Precond:
     """Inverse Cholesky factors of the FALKON preconditioner, f64, row-major (M x ld)."""
-    __slots__ = ("LTi", "LTit", "LAi", "LAit", "M", "ld", "info")
+    __slots__ = ("LTi", "LTit", "LAi", "LAit", "M", "ld", "info", "block_rows")
 
 
 class Knm:
@@ -180,6 +180,7 @@ class HipBackend:
             P.M, P.ld = M, ld
             P.LTi, P.LTit, P.LAi, P.LAit = (out[b, k, :M] for k in range(4))
             P.info = info[b:b + 1]
+            P.block_rows = Mmax                  # rows of each factor's slot in the shared block (cg_solve_batched)
             Ps.append(P)
         return Ps
 
@@ -295,6 +296,34 @@ class HipBackend:
                                              self._stream()), "odx_falkon_cg_f64")
         return alpha
 
+    def cg_solve_batched(self, Ks, Ps, b0s, n_totals, lam, maxiter, opt):
+        """The CG loops of len(Ks) <= 32 independent fits in lock step, one launch sequence for all of them
+        (odx_falkon_cg_batched_f64).  Ps: the Preconds of ONE precond_batched call, in order (they share a block);
+        b0s: (B, vstride) f64.  Returns alpha (B, vstride) f64 — row b's first M_b entries are class b's alpha, bit for
+        bit what cg_solve gives — or None when the classes do not share a pass configuration."""
+        B = len(Ks)
+        n = (ctypes.c_int64 * B)(*[int(k.n) for k in Ks])
+        M = (ctypes.c_int64 * B)(*[int(k.M) for k in Ks])
+        nbytes = self.lib.odx_falkon_cg_batched_workspace_bytes(B, n, M)
+        if nbytes < 0:
+            return None
+        base = Ps[0].LTi
+        p_rows, ldp = Ps[0].block_rows, Ps[0].ld
+        p_stride = 4 * p_rows * ldp
+        for b, P in enumerate(Ps):
+            if P.LTi.data_ptr() != base.data_ptr() + b * p_stride * 8 or P.ld != ldp:
+                raise ValueError("cg_solve_batched: the preconditioners must be consecutive members of one precond_batched block")
+        kp = (ctypes.c_void_p * B)(*[k.K.data_ptr() for k in Ks])
+        kl = (ctypes.c_int64 * B)(*[int(k.ld) for k in Ks])
+        nt = (ctypes.c_double * B)(*[float(x) for x in n_totals])
+        alpha = torch.zeros_like(b0s)
+        ws = self._workspace("cg_solve_batched", nbytes)
+        hip.check(self.lib.odx_falkon_cg_batched_f64(B, kp, kl, n, M, _p(base), ldp, p_rows, p_stride, _p(b0s), b0s.stride(0), nt,
+                                                     float(lam), int(maxiter), int(opt.cg_full_gradient_every), float(opt.cg_epsilon),
+                                                     float(opt.cg_tolerance), _p(alpha), _p(ws), ws.numel(), self._stream()),
+                  "odx_falkon_cg_batched_f64")
+        return alpha
+
     _TRI = {"LTi": 0, "LTit": 1, "LAi": 0, "LAit": 1}
 
     def trmv(self, P, name, x, alpha=1.0, beta=0.0, z=None, out=None):
@@ -332,7 +361,10 @@ class HipBackend:
         if Mtot != Zf.n:
             raise ValueError("mmv: V has %d rows but there are %d centres" % (Mtot, Zf.n))
         if ranges is None:
-            ranges = torch.tensor([[0, Mtot]] * T, dtype=torch.int32, device=self.device)
+            key = ("dense_ranges", Mtot, T)          # a host -> device copy per call otherwise (a predict is ~50 us of GPU work)
+            ranges = self._ws.get(key)
+            if ranges is None:
+                ranges = self._ws[key] = torch.tensor([[0, Mtot]] * T, dtype=torch.int32, device=self.device)
         ranges = ranges.to(device=self.device, dtype=torch.int32).contiguous()
         if out is None:
             out = torch.empty((F.n, T), dtype=torch.float32, device=self.device)

@@ -56,7 +56,7 @@ class GaussianKernel:
         v = torch.as_tensor(v)
         if v.dim() == 1:
             v = v[:, None]
-        ranges = block_ranges(v)
+        ranges = block_ranges(v) if v.shape[1] > 1 else None      # one column (model.predict): every centre counts
         res = be.mmv(F, Zf, self.sigma, v, ranges)
         if out is not None:
             out.copy_(res)
@@ -165,25 +165,41 @@ def fit_batch(estimators, Xs, Ys, streams=None):
     for i, est in enumerate(estimators):
         o = est.options.solver_options()
         groups.setdefault((float(est.kernel.sigma), float(est.penalty), o.pc_epsilon), []).append(i)
-    Ps = [None] * len(estimators)
+    from . import solver as _solver
+    cur = torch.cuda.current_stream() if streams else None
     for (sigma, lam, eps), members in groups.items():
         for c0 in range(0, len(members), be.MAX_CLASS_BATCH):
             chunk = members[c0:c0 + be.MAX_CLASS_BATCH]
-            for i, P in zip(chunk, be.precond_batched([Zfs[i] for i in chunk], sigma, lam, eps, ws_key="precond_batched_fit")):
-                Ps[i] = P
-    cur = torch.cuda.current_stream() if streams else None
-    if streams:
-        for s in streams:
-            s.wait_stream(cur)
-    for i, est in enumerate(estimators):
-        ctx = torch.cuda.stream(streams[i % len(streams)]) if streams else _nullcontext()
-        with ctx:
-            alpha = falkon_fit(be, Fs[i], yvs[i], Zfs[i], est.kernel.sigma, float(est.penalty), int(est.maxiter),
-                               est.options.solver_options(), precond=Ps[i])
-            ny = Zfs[i].X.contiguous() if Zfs[i].X.stride(0) != Zfs[i].D else Zfs[i].X
-            est.alpha_, est.ny_points_ = alpha.reshape(-1, 1), ny
-            if est._cpu_model:
-                est.alpha_, est.ny_points_ = est.alpha_.cpu(), est.ny_points_.cpu()
+            Ps = be.precond_batched([Zfs[i] for i in chunk], sigma, lam, eps, ws_key="precond_batched_fit")
+            opts = [estimators[i].options.solver_options() for i in chunk]
+            iters = {int(estimators[i].maxiter) for i in chunk}
+            same = len(iters) == 1 and all(o == opts[0] for o in opts) and hasattr(be, "cg_solve_batched")
+            alphas = None
+            if same:
+                # K_nM builds (one launch each), then ALL CG loops of the chunk in lock step: one launch sequence
+                Mmax = max(Zfs[i].n for i in chunk)
+                b0s = torch.zeros((len(chunk), (Mmax + 1) // 2 * 2), dtype=torch.float64, device=be.device)
+                Ks = []
+                for row, i in enumerate(chunk):
+                    K, _ = be.knm_rhs(Fs[i], Zfs[i], sigma, yvs[i] * (1.0 / Fs[i].n), rhs_out=b0s[row, :Zfs[i].n])
+                    Ks.append(K)
+                alphas = be.cg_solve_batched(Ks, Ps, b0s, [Fs[i].n for i in chunk], lam, iters.pop(), opts[0])
+            for row, (i, P) in enumerate(zip(chunk, Ps)):
+                est = estimators[i]
+                if alphas is not None:
+                    alpha = alphas[row, :Zfs[i].n].clone()
+                    if opts[row].check_pivots:
+                        _solver._check_pivots(be, P)
+                else:       # classes in different pass configurations (or a backend without the batched loop): one CG each
+                    if streams:
+                        streams[i % len(streams)].wait_stream(cur)
+                    with (torch.cuda.stream(streams[i % len(streams)]) if streams else _nullcontext()):
+                        alpha = falkon_fit(be, Fs[i], yvs[i], Zfs[i], est.kernel.sigma, float(est.penalty), int(est.maxiter),
+                                           opts[row], precond=P)
+                ny = Zfs[i].X.contiguous() if Zfs[i].X.stride(0) != Zfs[i].D else Zfs[i].X
+                est.alpha_, est.ny_points_ = alpha.reshape(-1, 1), ny
+                if est._cpu_model:
+                    est.alpha_, est.ny_points_ = est.alpha_.cpu(), est.ny_points_.cpu()
     if streams:
         for s in streams:
             cur.wait_stream(s)

@@ -243,6 +243,7 @@ class OnlineRegionClassifierBase:
         sequential mode's bit for bit.  As in the streams mode the indices themselves come from one RNG stream per class
         (seeded from one draw of the global stream), because the reference's class-major order of global draws cannot be
         kept when classes advance together."""
+        from . import solver
         C = self.num_classes - 1
         k = max(1, int(self.class_batch))
         main = torch.cuda.current_stream()
@@ -293,7 +294,8 @@ class OnlineRegionClassifierBase:
                     rng[i] = torch.get_rng_state()
                 return out
 
-            fitted = self.classifier.train_batch(Xs, ys, sigma=self.sigma, lam=self.lam, index_rng=with_class_rng, streams=streams)
+            with solver.deferred_pivot_checks():       # every Cholesky status of the round is read once, after the round's fits are queued
+                fitted = self.classifier.train_batch(Xs, ys, sigma=self.sigma, lam=self.lam, index_rng=with_class_rng, streams=streams)
             for i, m in zip(todo, fitted):
                 model[i] = m
             prune = [i for i in todo if len(caches[i]['neg']) != 0 and j != len(negatives[i]) - 1]
