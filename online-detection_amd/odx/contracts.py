@@ -1,6 +1,6 @@
 """The reference's abstract module APIs (ClassifierAbstract, RegionClassifierAbstract,
 RegionRefinerAbstract, FeatureExtractorAbstract) as generated ABCs: a name plus the list of
-methods a concrete module must provide."""
+methods a concrete module must provide (AccuracyEvaluatorAbstract likewise)."""
 from abc import ABC, abstractmethod
 
 
@@ -26,3 +26,6 @@ RegionRefinerAbstract = make_contract(
 FeatureExtractorAbstract = make_contract(
     "FeatureExtractorAbstract", ["extractFeatures"],
     "feature extractor module (reference: src/modules/FeatureExtractorAbstract.py:4-22)")
+AccuracyEvaluatorAbstract = make_contract(
+    "AccuracyEvaluatorAbstract", ["evaluateAccuracyDetection"],
+    "accuracy evaluator module (reference: src/modules/accuracy-evaluator/AccuracyEvaluatorAbstract.py:4-10)")

@@ -89,6 +89,80 @@ def rpn_proposals(objectness, box_regression, anchors, img_size, pre_nms_top_n=6
     return boxes[keep], score[keep]
 
 
+# ---------------------------------------------------------------------------- image pre-processing
+PIXEL_MEAN_BGR255 = (102.9801, 115.9465, 122.7717)     # cfg.INPUT.PIXEL_MEAN of the shipped configs (Detectron BGR-255)
+
+
+def preprocess_image(image, min_size=600, pixel_mean=PIXEL_MEAN_BGR255, pixel_std=(1.0, 1.0, 1.0), to_bgr255=True):
+    """The reference's test/harvest-time transform (engine/feature_proposal_extractor.py:86-113: ToPILImage ->
+    Resize(MIN_SIZE_TEST) -> ToTensor -> x 255 (TO_BGR255) -> Normalize(PIXEL_MEAN, PIXEL_STD)) as one op sequence on the
+    image's device.  image: (H, W, 3) uint8 in BGR order, as the reference hands it over (inference.py:231-234).
+    Resize(int) brings the SHORTER side to min_size keeping the aspect ratio (the longer one truncated, torchvision's
+    rule) with PIL's bilinear filter, i.e. a triangle filter whose support grows with the down-scaling factor
+    (antialias=True below is that filter) and a result rounded back to 8 bits.  Returns (1, 3, H', W') f32 and the
+    (width, height) it was resized to.  PARITY UNPINNED by the reference (PIL / torchvision are not importable here);
+    tests/test_extract.py restates the filter in numpy."""
+    if image.dim() != 3 or image.shape[2] != 3:
+        raise ValueError("preprocess_image: expected an (H, W, 3) image, got %s" % (tuple(image.shape),))
+    H, W = int(image.shape[0]), int(image.shape[1])
+    if H <= W:
+        nh, nw = int(min_size), int(min_size * W / H)
+    else:
+        nh, nw = int(min_size * H / W), int(min_size)
+    x = image.permute(2, 0, 1).unsqueeze(0).to(torch.float32)
+    if (nh, nw) != (H, W):
+        x = F.interpolate(x, size=(nh, nw), mode="bilinear", align_corners=False, antialias=True)
+        x = torch.floor(x + 0.5).clamp_(0, 255)                     # PIL stores the resized image as 8-bit
+    if not to_bgr255:
+        x = x[:, [2, 1, 0]] / 255.0
+    mean = torch.tensor(pixel_mean, dtype=torch.float32, device=x.device).view(1, 3, 1, 1)
+    std = torch.tensor(pixel_std, dtype=torch.float32, device=x.device).view(1, 3, 1, 1)
+    return (x - mean) / std, (nw, nh)
+
+
+# ---------------------------------------------------------------------------- reference checkpoints
+_REF_KEY_RULES = (("backbone.body.stem.", "backbone."), ("backbone.body.", "backbone."),
+                  ("rpn.head.conv.", "rpn_conv."), ("rpn.head.cls_logits.", "rpn_logits."), ("rpn.head.bbox_pred.", "rpn_deltas."),
+                  ("roi_heads.box.feature_extractor.head.", "head."), ("roi_heads.mask.predictor.conv5_mask.", "conv5_mask."))
+_REF_KEY_IGNORED = ("roi_heads.box.predictor.", "roi_heads.mask.predictor.mask_fcn_logits.", "roi_heads.mask.feature_extractor.",
+                    "rpn.anchor_generator.")
+
+
+def remap_reference_state_dict(state_dict):
+    """Parameter names of a maskrcnn_benchmark / Detectron R-50-C4 Mask R-CNN checkpoint (the reference's
+    `feature_extractor_*.pth` and `e2e_mask_rcnn_R-50-C4_1x`, loaded by DetectronCheckpointer at
+    extract_features_detector.py:150-170) -> this module's names.  Accepts the bare state dict or the checkpoint dict
+    with its "model" entry, with or without DistributedDataParallel's "module." prefix.  Returns (mapped, ignored, unknown):
+    `ignored` are entries this pipeline replaces by the on-line heads (the SGD-trained class / box / mask predictors, the
+    shared mask feature extractor, anchor buffers); `unknown` are names no rule covers — callers should treat a non-empty
+    list as an error.  The names are those of maskrcnn_benchmark's ResNet / RPNHead / ResNet50Conv5ROIFeatureExtractor /
+    MaskRCNNC4Predictor modules (not vendored here: restated, PARITY UNPINNED)."""
+    sd = state_dict.get("model", state_dict) if isinstance(state_dict, dict) else state_dict
+    mapped, ignored, unknown = {}, [], []
+    for key, val in sd.items():
+        k = key[len("module."):] if key.startswith("module.") else key
+        if any(k.startswith(p) for p in _REF_KEY_IGNORED):
+            ignored.append(key)
+            continue
+        for src, dst in _REF_KEY_RULES:
+            if k.startswith(src):
+                mapped[dst + k[len(src):].replace(".downsample.", ".down.")] = val
+                break
+        else:
+            unknown.append(key)
+    return mapped, ignored, unknown
+
+
+def load_reference_checkpoint(model, state_dict, strict=True):
+    """Load a reference-named checkpoint into an OnlineDetectionModel; raises when names are left over on either side."""
+    mapped, ignored, unknown = remap_reference_state_dict(state_dict)
+    res = model.load_state_dict(mapped, strict=False)
+    if strict and (unknown or res.missing_keys or res.unexpected_keys):
+        raise KeyError("reference checkpoint does not match the model: unknown %s, missing %s, unexpected %s"
+                       % (unknown[:5], list(res.missing_keys)[:5], list(res.unexpected_keys)[:5]))
+    return ignored
+
+
 # ---------------------------------------------------------------------------- network
 class FrozenBatchNorm2d(nn.Module):
     def __init__(self, n):
@@ -264,6 +338,30 @@ class OnlineDetectionModel(nn.Module):
         if gt_boxes is not None and len(gt_boxes):
             boxes = torch.cat((gt_boxes.to(boxes.device).float(), boxes), dim=0)
         return boxes, self.roi_features(c4, boxes), c4
+
+
+def detect(model, image, orig_size=None, score_thresh=-2.0, nms_thresh=0.3, detections_per_img=100, with_masks=False):
+    """Test-time forward of one pre-processed image (1, 3, H, W) with the model's on-line heads
+    (GeneralizedRCNN.forward at test time: RPN proposals -> RoI features -> OnlineBoxPredictor -> post-processing in the
+    ORIGINAL image frame, generalized_rcnn.py + OnlineDetectionPostProcessor.py:12-79; masks of the kept detections
+    through OnlineMaskPredictor + Masker when with_masks).  orig_size = (width, height) of the image before resizing.
+    Returns dict(boxes, scores, labels[, masks]) or None, and the proposals."""
+    from .postprocess import paste_masks, postprocess_detections, select_class_masks
+    if model.online_box is None:
+        raise RuntimeError("detect: the model has no on-line box predictor (update_model(models_detection=...))")
+    c4 = model.c4(image)
+    img_size = (image.shape[3], image.shape[2])
+    orig_size = tuple(orig_size) if orig_size is not None else img_size
+    boxes, _ = model.proposals(c4, img_size)
+    maps = model.roi_head_maps(c4, boxes)
+    scores, deltas = model.online_box(maps.mean(dim=(2, 3)))
+    res = postprocess_detections(scores, deltas, boxes, orig_size, score_thresh, nms_thresh, detections_per_img,
+                                 proposals_size=img_size)
+    if res is not None and with_masks and model.online_mask is not None and len(res["boxes"]):
+        back = res["boxes"] * res["boxes"].new_tensor([img_size[0] / orig_size[0], img_size[1] / orig_size[1]] * 2)
+        pix = model.online_mask(model.mask_activation(model.roi_head_maps(c4, back)))
+        res["masks"] = paste_masks(select_class_masks(pix, res["labels"]), res["boxes"], orig_size)
+    return res, boxes
 
 
 class DetectorFeatureExtractor:

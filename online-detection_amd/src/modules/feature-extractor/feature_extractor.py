@@ -8,6 +8,9 @@ and load Detectron weights; datasets, weights and that package are outside this 
 `cfg_options`:
     cfg_options['samples']  iterable of (image (1, 3, H, W) float tensor, gt_boxes (G, 4), gt_labels list[int])
     cfg_options['model']    an odx.extract.OnlineDetectionModel (default: R-50-C4, seeded random weights)
+    cfg_options['shard_images']  True: under a multi-process launcher each rank harvests only its images (rank::world);
+                                 default False — every rank sees every image, so the drop-in trainers downstream (which
+                                 are not sharded) build identical models on all ranks
 The MINIBOOTSTRAP / REGRESSORS values are read from the feature-extraction YAML when present.
 """
 import os
@@ -88,7 +91,14 @@ class FeatureExtractor(FeatureExtractorAbstract):
             raise NotImplementedError(self._NEED_SAMPLES)
         cfg = self._cfg(cfg_path)
         model = self._model(cfg_options)
-        rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+        # Images are sharded over the ranks of a launcher ONLY on request (cfg_options['shard_images'] = True): the trainers
+        # these features go to (OnlineRegionClassifier, RegionRefiner, computeFeatStatistics_torch) see the rows they are
+        # given, so a silent split would train every rank's models on 1 / world of the data.  With the option every rank
+        # returns the rows of its own images (rank::world) and the caller is responsible for training on shards
+        # (odx.solver.falkon_fit(shard=...), RegionRefinerTrainer(shard=...)) — the multi-GPU route bench.py exercises.
+        rank, world = 0, 1
+        if cfg_options.get('shard_images'):
+            rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
         num_classes = _mb(cfg, 'NUM_CLASSES', cfg_options.get('num_classes', 30))
         det_kw = self._kw(cfg, 'DETECTOR')
         det_kw['reg_min_overlap'] = (cfg.get('REGRESSORS') or {}).get('MIN_OVERLAP', 0.6)

@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "online-detection_amd", "src")
-for sub in ("", "modules/region-classifier", "modules/region-refiner", "modules/feature-extractor", "modules"):
+for sub in ("", "modules/region-classifier", "modules/region-refiner", "modules/feature-extractor", "modules/accuracy-evaluator", "modules"):
     p = os.path.join(SRC, sub) if sub else SRC
     if p not in sys.path:
         sys.path.append(p)

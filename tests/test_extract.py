@@ -111,6 +111,7 @@ def test_end_to_end_pipeline_on_gpu(tmp_path):
     assert tuple(scores.shape) == (boxes.shape[0], C + 1) and tuple(deltas.shape) == (boxes.shape[0], 4 * (C + 1))
     assert torch.isfinite(scores).all() and torch.isfinite(deltas).all()
     assert "Detector's feature extraction time" in open(os.path.join(str(tmp_path), "result.txt")).read()
+    _check_accuracy_evaluator(path, str(tmp_path), model, samples[:4], models, regs, stats, C)
     # save_features=True: nothing is returned, the reference's cache files appear and replay to the same rows
     torch.manual_seed(1)
     assert fe.extractFeatures(True, output_dir=str(tmp_path), save_features=True, cfg_options={"samples": samples, "model": model}) is None
@@ -235,3 +236,174 @@ def test_full_ours_pipeline_on_gpu(tmp_path):
         pix = model.online_mask(model.mask_activation(maps[:5]))
     assert boxes.shape[0] > 0 and tuple(scores.shape) == (boxes.shape[0], C + 1) and tuple(deltas.shape) == (boxes.shape[0], 4 * (C + 1))
     assert tuple(pix.shape) == (5, C + 1, 14, 14) and torch.isfinite(pix).all() and torch.isfinite(scores).all()
+
+
+# ------------------------------------------------------------------ accuracy_evaluator drop-in
+def _check_accuracy_evaluator(cfg_path, out_dir, model, samples, models, regs, stats, C):
+    """The drop-in AccuracyEvaluator (the class experiments/run_experiment_* import by bare name): heads injected through
+    its attributes, detections post-processed and scored with the reference's VOC-style AP, result.txt lines in the
+    reference's format; its numbers equal the pieces called by hand."""
+    from odx.extract import detect
+    from odx.postprocess import eval_detection
+    ae = dropin.load("accuracy_evaluator").AccuracyEvaluator(cfg_path, cfg_path)
+    assert ae.falkon_detector_models is None and ae.regions_post_nms is None and ae.train_in_cpu is False
+    ae.falkon_detector_models, ae.regressors_detector_models, ae.stats_detector = models, regs, stats
+    with redirect_stdout(io.StringIO()):
+        res = ae.evaluateAccuracyDetection(False, output_dir=out_dir, evaluate_segmentation=False,
+                                           cfg_options={"samples": samples, "model": model})
+    assert set(res) == {"ap", "map"} and (np.isnan(res["map"]) or 0.0 <= res["map"] <= 1.0)
+    text = open(os.path.join(out_dir, "result.txt")).read()
+    assert "Detection mAP50: " in text and "{:<26}: ".format("obj1") in text
+    dev = next(model.parameters()).device
+    preds, gts = [], []
+    for img, gt, labels in samples:
+        r, _ = detect(model, img.to(dev), (img.shape[3], img.shape[2]))
+        preds.append({k: v.cpu().numpy() for k, v in r.items()})
+        gts.append({"boxes": gt.numpy(), "labels": np.asarray(labels)})
+    by_hand = eval_detection(preds, gts, 0.5, True)
+    np.testing.assert_allclose(np.nan_to_num(res["ap"]), np.nan_to_num(by_hand["ap"]), atol=1e-12)
+    with pytest.raises(NotImplementedError):
+        ae.evaluateAccuracyDetection(False)
+
+
+def test_accuracy_evaluator_dropin_on_cpu_with_oracle_backend(tmp_path):
+    import yaml
+    from tests.oracle_backend import OracleBackend
+    odx.set_backend(OracleBackend(np.float64))
+    try:
+        C = 2
+        cfg = {"NUM_CLASSES": C + 1, "CHOSEN_CLASSES": {i: ("bg" if i == 0 else "obj%d" % i) for i in range(C + 1)},
+               "ONLINE_REGION_CLASSIFIER": {"MINIBOOTSTRAP": {"EASY_THRESH": -0.9, "HARD_THRESH": -0.7},
+                                            "CLASSIFIER": {"lambda": 0.001, "sigma": 10, "M": 16, "kernel_type": "gauss"}},
+               "REGION_REFINER": {"opts": {"lambda": 10.0}},
+               "MINIBOOTSTRAP": {"DETECTOR": {"NUM_CLASSES": C, "ITERATIONS": 2, "BATCH_SIZE": 12, "NEG_IOU_THRESH": 0.3}},
+               "REGRESSORS": {"MIN_OVERLAP": 0.6}, "EVALUATION": {"IOU_THRESHOLDS": [0.5], "USE_VOC07_METRIC": True}}
+        path = str(tmp_path / "cfg.yaml")
+        yaml.safe_dump(cfg, open(path, "w"))
+        model = OnlineDetectionModel(width=4, post_nms_top_n=12, pre_nms_top_n=60, resolution=4).eval()
+        samples = _samples(4, 64, 80, C, seed=5)
+        fe = dropin.load("feature_extractor").FeatureExtractor(path, path)
+        u = dropin.load("py_od_utils")
+        torch.manual_seed(2)
+        with redirect_stdout(io.StringIO()):
+            negatives, positives, COXY = fe.extractFeatures(True, cfg_options={"samples": samples, "model": model})
+            stats = u.computeFeatStatistics_torch(positives, negatives, features_dim=model.feat_dim, pos_fraction=0.8, cpu_tensor=True)
+            stats = {k: v.cpu() for k, v in stats.items()}
+            clf = dropin.load("FALKONWrapper_with_centers_selection").FALKONWrapper(cfg_path=path)
+            orc = dropin.load("OnlineRegionClassifier").OnlineRegionClassifier(clf, positives, negatives, stats, cfg_path=path)
+            models = orc.trainRegionClassifier()
+            regs = dropin.load("region_refiner").RegionRefiner(path).trainRegionRefiner(u.normalize_COXY(COXY, stats, cpu=True))
+        _check_accuracy_evaluator(path, str(tmp_path), model, samples, models, regs, stats, C)
+    finally:
+        odx.set_backend(None)
+
+
+# ------------------------------------------------------------------ image pre-processing (feature_proposal_extractor.py:86-113)
+def _pil_style_resize_u8(img, nh, nw):
+    """numpy restatement of PIL's bilinear Image.resize on 8-bit images (what torchvision's Resize calls): a separable
+    triangle filter whose support is scaled by the down-scaling factor, horizontal pass then vertical pass, each pass
+    rounded to 8 bits (PIL resamples in two 8-bit passes)."""
+    def coeffs(insize, outsize):
+        scale = insize / outsize
+        fs = max(scale, 1.0)
+        support = 1.0 * fs
+        out = []
+        for xx in range(outsize):
+            center = (xx + 0.5) * scale
+            xmin = max(int(center - support + 0.5), 0)
+            xmax = min(int(center + support + 0.5), insize)
+            w = np.array([max(0.0, 1.0 - abs((x + xmin - center + 0.5) / fs)) for x in range(xmax - xmin)])
+            out.append((xmin, w / w.sum()))
+        return out
+
+    def one_pass(a, axis, outsize):
+        a = np.moveaxis(a, axis, 0).astype(np.float64)
+        res = np.stack([np.tensordot(w, a[x0:x0 + len(w)], axes=(0, 0)) for x0, w in coeffs(a.shape[0], outsize)])
+        return np.moveaxis(np.clip(np.floor(res + 0.5), 0, 255), 0, axis)
+
+    return one_pass(one_pass(img, 1, nw), 0, nh)
+
+
+DEVICES = ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)]
+
+
+@pytest.mark.parametrize("device", DEVICES)
+@pytest.mark.parametrize("H,W", [(480, 640), (300, 200), (600, 800), (75, 100)])
+def test_preprocess_image_against_a_numpy_restatement(H, W, device):
+    from odx.extract import PIXEL_MEAN_BGR255, preprocess_image
+    rng = np.random.default_rng(H + W)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    img[: H // 3] = (np.linspace(0, 255, W)[None, :, None] + np.zeros((H // 3, 1, 3))).astype(np.uint8)   # a smooth region too
+    out, (nw, nh) = preprocess_image(torch.from_numpy(img).to(device), min_size=600)
+    # torchvision's Resize(600): shorter side -> 600, the longer one int(600 * long / short)
+    assert (nh, nw) == ((600, int(600 * W / H)) if H <= W else (int(600 * H / W), 600))
+    assert tuple(out.shape) == (1, 3, nh, nw) and out.dtype == torch.float32 and out.device.type == device
+    ref = _pil_style_resize_u8(img, nh, nw) if (nh, nw) != (H, W) else img.astype(np.float64)
+    ref = np.transpose(ref, (2, 0, 1)) - np.array(PIXEL_MEAN_BGR255)[:, None, None]
+    diff = np.abs(out[0].cpu().numpy() - ref)
+    # PIL rounds after each of its two passes, the fused filter once: a few pixels differ by one grey level
+    assert diff.max() <= 1.0 + 1e-4 and (diff > 1e-3).mean() < 0.35 and diff.mean() < 0.2, (diff.max(), (diff > 1e-3).mean())
+
+
+def test_reference_checkpoint_names_round_trip():
+    """A state dict under maskrcnn_benchmark's names (R-50-C4 Mask R-CNN: backbone.body.stem / layerN.M.downsample,
+    rpn.head.{conv,cls_logits,bbox_pred}, roi_heads.box.feature_extractor.head.layer4, roi_heads.mask.predictor.conv5_mask,
+    plus the SGD-trained predictors this pipeline replaces), wrapped as a DDP checkpoint, loads into the model exactly."""
+    from odx.extract import load_reference_checkpoint, remap_reference_state_dict
+    src = OnlineDetectionModel(width=8, seed=1)
+    ref_sd = {}
+    for k, v in src.state_dict().items():
+        k2 = k.replace(".down.", ".downsample.")
+        if k2.startswith("backbone.conv1") or k2.startswith("backbone.bn1"):
+            k2 = "backbone.body.stem." + k2[len("backbone."):]
+        elif k2.startswith("backbone."):
+            k2 = "backbone.body." + k2[len("backbone."):]
+        elif k2.startswith("rpn_conv."):
+            k2 = "rpn.head.conv." + k2[len("rpn_conv."):]
+        elif k2.startswith("rpn_logits."):
+            k2 = "rpn.head.cls_logits." + k2[len("rpn_logits."):]
+        elif k2.startswith("rpn_deltas."):
+            k2 = "rpn.head.bbox_pred." + k2[len("rpn_deltas."):]
+        elif k2.startswith("head."):
+            k2 = "roi_heads.box.feature_extractor.head." + k2[len("head."):]
+        elif k2.startswith("conv5_mask."):
+            k2 = "roi_heads.mask.predictor.conv5_mask." + k2[len("conv5_mask."):]
+        ref_sd["module." + k2] = v.clone()
+    ref_sd["module.roi_heads.box.predictor.cls_score.weight"] = torch.zeros(31, 16)
+    ref_sd["module.roi_heads.mask.predictor.mask_fcn_logits.weight"] = torch.zeros(31, 8, 1, 1)
+    ref_sd["module.rpn.anchor_generator.cell_anchors.0"] = torch.zeros(15, 4)
+    dst = OnlineDetectionModel(width=8, seed=2)
+    assert not torch.equal(dst.state_dict()["backbone.conv1.weight"], src.state_dict()["backbone.conv1.weight"])
+    ignored = load_reference_checkpoint(dst, {"model": ref_sd, "iteration": 7})
+    assert len(ignored) == 3
+    for k, v in src.state_dict().items():
+        assert torch.equal(dst.state_dict()[k], v), k
+    mapped, _, unknown = remap_reference_state_dict({"backbone.fpn.fpn_inner1.weight": torch.zeros(1)})
+    assert unknown == ["backbone.fpn.fpn_inner1.weight"] and not mapped
+    with pytest.raises(KeyError):
+        load_reference_checkpoint(dst, {"backbone.fpn.fpn_inner1.weight": torch.zeros(1)})
+
+
+def test_dropin_feature_extractor_shards_images_only_on_request(monkeypatch):
+    """Under a launcher (RANK / WORLD_SIZE set) the drop-in FeatureExtractor must hand every rank ALL images unless
+    cfg_options['shard_images'] asks for the split: the trainers downstream are not sharded."""
+    from tests.oracle_backend import OracleBackend
+    odx.set_backend(OracleBackend(np.float64))
+    try:
+        fe_mod = dropin.load("feature_extractor")
+        model = OnlineDetectionModel(width=4, post_nms_top_n=12, pre_nms_top_n=60, resolution=4).eval()
+        samples = _samples(4, 64, 80, 2)
+        monkeypatch.setenv("RANK", "1")
+        monkeypatch.setenv("WORLD_SIZE", "2")
+        out = {}
+        for shard in (False, True):
+            torch.manual_seed(0)
+            fe = fe_mod.FeatureExtractor()
+            with redirect_stdout(io.StringIO()):
+                neg, pos, COXY = fe.extractFeatures(True, cfg_options={"samples": samples, "model": model, "num_classes": 2,
+                                                                      "shard_images": shard})
+            out[shard] = sum(len(p) for p in pos)
+        assert out[False] == sum(len(s[2]) for s in samples)                # every ground-truth box of every image
+        assert out[True] == sum(len(s[2]) for s in samples[1::2])           # rank 1 of 2: images 1 and 3
+    finally:
+        odx.set_backend(None)

@@ -167,3 +167,47 @@ def test_segmentation_ap_matches_reference():
     for m07 in (True, False):
         r = eval_detection(preds, gts, 0.5, m07, key="masks")
         np.testing.assert_allclose(r["ap"], MG["seg_ap_%s" % ("voc07" if m07 else "area")], atol=1e-12, equal_nan=True)
+
+
+def test_standalone_accuracy_evaluator_dropin(tmp_path):
+    """`import AccuracyEvaluator as ae` (the stand-alone O-OD evaluator of the reference): post-processing of the
+    per-image BoxLists that testRegionClassifier / RegionRefiner.predict leave, then the reference's AP — on the golden
+    post-processing case its kept detections are the reference's, and detections equal to the ground truth score AP 1."""
+    import yaml
+    from odx.boxlist import BoxList
+    from tests import dropin
+    from tests.oracle_backend import OracleBackend
+    g = np.load(os.path.join(GOLD, "postprocess_golden.npz"))
+    R, C, dpi, pw, ph, iw, ih = (int(v) for v in g["c2_meta"])
+    thr, nms = (float(v) for v in g["c2_thr"])
+    cfg = {"NUM_CLASSES": C, "CHOSEN_CLASSES": {i: "obj%d" % i for i in range(C)},
+           "EVALUATION": {"SCORE_THRESH": thr, "NMS": nms, "DETECTIONS_PER_IMAGE": dpi, "IOU_THRESHOLDS": [0.5]}}
+    path = str(tmp_path / "cfg.yaml")
+    yaml.safe_dump(cfg, open(path, "w"))
+
+    class Dataset:
+        def __init__(self, gts):
+            self.gts = gts
+
+        def get_groundtruth(self, i):
+            return self.gts[i]
+
+    odx.set_backend(OracleBackend(np.float64))
+    try:
+        ev = dropin.load("AccuracyEvaluator").AccuracyEvaluator(path, str(tmp_path))
+        # image 0: ground truth = the golden kept detections themselves -> every class present scores AP 1
+        kept = BoxList(torch.from_numpy(g["c2_boxes"]), (iw, ih))
+        kept.add_field("labels", torch.from_numpy(g["c2_labels"]))
+        # predictions: already decoded per-class boxes (R, C, 4) + scores (R, C), as RegionRefiner.predict leaves them
+        from odx.utils import decode_boxes_detector
+        props = torch.from_numpy(g["c2_props"]) * torch.tensor([iw / pw, ih / ph, iw / pw, ih / ph])
+        dec = decode_boxes_detector(BoxList(props, (iw, ih)), torch.from_numpy(g["c2_deltas"])[:, :4 * C])
+        pred = BoxList(dec.reshape(R, C, 4), (iw, ih))
+        pred.add_field("scores", torch.from_numpy(g["c2_scores"])[:, :C])
+        with __import__("contextlib").redirect_stdout(__import__("io").StringIO()):
+            res = ev.evaluate(Dataset([kept]), [pred])
+    finally:
+        odx.set_backend(None)
+    present = sorted(set(g["c2_labels"].tolist()))
+    assert all(abs(res["ap"][c] - 1.0) < 1e-12 for c in present) and abs(res["map"] - 1.0) < 1e-12
+    assert "Detection mAP50: 1.0000" in open(os.path.join(str(tmp_path), "result.txt")).read()
