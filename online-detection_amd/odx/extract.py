@@ -178,7 +178,35 @@ class FrozenBatchNorm2d(nn.Module):
         return x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
 
 
-class Bottleneck(nn.Module):
+class _FoldedBN(nn.Module):
+    """Frozen batch norm is an affine map per channel: y = conv(x) * scale + shift with constants fixed at load time, so
+    it is folded into the convolution it follows (w * scale, bias = shift) — one MIOpen call per layer instead of the
+    convolution plus six elementwise kernels over the whole activation that evaluating rsqrt / scale / shift per
+    forward costs (53 layers per image).  The folded tensors are derived data: rebuilt after any move (`_apply`) or
+    state-dict load; parameters and buffers keep the reference's names and values."""
+
+    def __init__(self):
+        super().__init__()
+        self._folded = {}
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._folded.clear())
+
+    def _apply(self, fn, *a, **kw):
+        self._folded.clear()
+        return super()._apply(fn, *a, **kw)
+
+    def conv_bn(self, name_conv, name_bn, x):
+        wb = self._folded.get(name_conv)
+        conv = getattr(self, name_conv) if isinstance(name_conv, str) else name_conv
+        if wb is None:
+            bn = getattr(self, name_bn) if isinstance(name_bn, str) else name_bn
+            with torch.no_grad():
+                scale = bn.weight * bn.running_var.rsqrt()
+                wb = ((conv.weight * scale.view(-1, 1, 1, 1)).contiguous(), (bn.bias - bn.running_mean * scale).contiguous())
+            self._folded[name_conv] = wb
+        return F.conv2d(x, wb[0], wb[1], conv.stride, conv.padding)
+
+
+class Bottleneck(_FoldedBN):
     def __init__(self, cin, mid, cout, stride):
         super().__init__()
         self.down = None
@@ -189,10 +217,20 @@ class Bottleneck(nn.Module):
         self.conv3, self.bn3 = nn.Conv2d(mid, cout, 1, bias=False), FrozenBatchNorm2d(cout)
 
     def forward(self, x):
-        idn = x if self.down is None else self.down(x)
-        y = F.relu(self.bn1(self.conv1(x)))
-        y = F.relu(self.bn2(self.conv2(y)))
-        return F.relu(self.bn3(self.conv3(y)) + idn)
+        if self.down is None:
+            idn = x
+        else:
+            wb = self._folded.get("down")
+            if wb is None:
+                conv, bn = self.down[0], self.down[1]
+                with torch.no_grad():
+                    scale = bn.weight * bn.running_var.rsqrt()
+                    wb = ((conv.weight * scale.view(-1, 1, 1, 1)).contiguous(), (bn.bias - bn.running_mean * scale).contiguous())
+                self._folded["down"] = wb
+            idn = F.conv2d(x, wb[0], wb[1], self.down[0].stride, self.down[0].padding)
+        y = F.relu(self.conv_bn("conv1", "bn1", x))
+        y = F.relu(self.conv_bn("conv2", "bn2", y))
+        return F.relu(self.conv_bn("conv3", "bn3", y) + idn)
 
 
 def _stage(cin, mid, cout, blocks, stride):
@@ -200,7 +238,7 @@ def _stage(cin, mid, cout, blocks, stride):
     return nn.Sequential(*layers)
 
 
-class ResNet50C4(nn.Module):
+class ResNet50C4(_FoldedBN):
     out_channels = 1024
 
     def __init__(self, width=64):
@@ -213,7 +251,7 @@ class ResNet50C4(nn.Module):
         self.out_channels = 16 * w
 
     def forward(self, x):
-        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, 2, 1)
+        x = F.max_pool2d(F.relu(self.conv_bn("conv1", "bn1", x)), 3, 2, 1)
         return self.layer3(self.layer2(self.layer1(x)))
 
 
@@ -412,8 +450,10 @@ class OnlineFeatureExtractor:
     the ground truth prepended) and, optionally, segmentation pixel rows per class.
     `parts` selects what is harvested: any of "rpn", "detector", "mask"."""
 
-    def __init__(self, model, num_classes, parts=("rpn", "detector"), det=None, rpn=None, mask=None, rank=0, world=1):
+    def __init__(self, model, num_classes, parts=("rpn", "detector"), det=None, rpn=None, mask=None, rank=0, world=1,
+                 pipeline=True):
         self.model, self.C, self.parts, self.rank, self.world = model, num_classes, tuple(parts), rank, world
+        self.pipeline = pipeline        # on a GPU: forward of the next image on a second thread / stream while this one is harvested
         self.det_kw = dict(iterations=10, batch_size=2000, neg_iou_thresh=0.3, reg_min_overlap=0.6, shuffle_negatives=False)
         self.rpn_kw = dict(iterations=10, batch_size=2000, neg_iou_thresh=0.3, pos_iou_thresh=0.7, shuffle_negatives=False)
         self.mask_kw = dict(batch_size=20000, sampling_factor=0.3)
@@ -431,26 +471,86 @@ class OnlineFeatureExtractor:
         hv_det = DetectorHarvester(m.feat_dim, self.C, num_images=n, device=dev, **self.det_kw) if "detector" in self.parts else None
         hv_rpn = RPNHarvester(m.backbone.out_channels, m.cells.shape[0], num_images=n, device=dev, **self.rpn_kw) if "rpn" in self.parts else None
         hv_mask = MaskHarvester(m.mask_dim, self.C, device=dev, **self.mask_kw) if "mask" in self.parts else None
-        for sample in samples:
+
+        def forward_one(sample):
+            """Everything of an image that does not depend on the harvesters' state: trunk, RPN activation, proposals
+            (+ ground truth), head maps, mask activation."""
             image, gt_boxes, gt_labels, masks = _unpack(sample)
             image, gt_boxes = image.to(dev), gt_boxes.to(dev).float()
             img_size = (image.shape[3], image.shape[2])
+            item = {"gt_boxes": gt_boxes, "gt_labels": list(gt_labels), "img_size": img_size}
             with torch.no_grad():
                 c4 = m.c4(image)
                 if hv_rpn is not None and len(gt_boxes):
-                    anchors = grid_anchors(c4.shape[2], c4.shape[3], m.stride, m.cells.to(dev))
-                    hv_rpn.add_image(m.rpn_activation(c4)[0], anchors, img_size, gt_boxes)
+                    item["anchors"] = grid_anchors(c4.shape[2], c4.shape[3], m.stride, m.cells.to(dev))
+                    item["t"] = m.rpn_activation(c4)[0]
                 if hv_det is None and hv_mask is None:
-                    continue
+                    return item
                 boxes, _ = m.proposals(c4, img_size)
                 if len(gt_boxes):
                     boxes = torch.cat((gt_boxes, boxes), dim=0)
                 maps = m.roi_head_maps(c4, boxes)
+                item["boxes"] = boxes
                 if hv_det is not None:
-                    hv_det.add_image(maps.mean(dim=(2, 3)), boxes, gt_boxes, list(gt_labels), [img_size[0], img_size[1]])
+                    item["feats"] = maps.mean(dim=(2, 3))
                 if hv_mask is not None and masks is not None and len(gt_labels):
-                    act = m.mask_activation(maps[:len(gt_labels)])
-                    hv_mask.add_image(act, project_masks_on_boxes(masks.to(dev), gt_boxes, act.shape[2]), list(gt_labels))
+                    item["act"] = m.mask_activation(maps[:len(gt_labels)])
+                    item["mg"] = project_masks_on_boxes(masks.to(dev), gt_boxes, item["act"].shape[2])
+            return item
+
+        def harvest_one(item):
+            """The stateful part, in image order: RNG draws, batch bookkeeping, rows into the buffers."""
+            if "t" in item:
+                hv_rpn.add_image(item["t"], item["anchors"], item["img_size"], item["gt_boxes"])
+            if "feats" in item:
+                hv_det.add_image(item["feats"], item["boxes"], item["gt_boxes"], item["gt_labels"], list(item["img_size"]))
+            if "act" in item:
+                hv_mask.add_image(item["act"], item["mg"], item["gt_labels"])
+
+        if dev.type == "cuda" and self.pipeline and len(samples) > 1:
+            # Two host threads, two streams: the forward of image k + 1 (57 convolutions to enqueue, two host <-> GPU
+            # round trips in the proposal stage) runs while image k is harvested (its own host <-> GPU round trips for the
+            # data-dependent sizes).  Harvesting stays strictly in image order on the caller's thread and stream, so the
+            # RNG draws and every buffer are what the sequential loop produces.
+            import queue
+            import threading
+            main = torch.cuda.current_stream()
+            fwd = torch.cuda.Stream()
+            fwd.wait_stream(main)
+            q = queue.Queue(maxsize=2)
+
+            def producer():
+                try:
+                    torch.cuda.set_device(dev)
+                    with torch.cuda.stream(fwd):
+                        for sample in samples:
+                            item = forward_one(sample)
+                            ev = torch.cuda.Event()
+                            ev.record(fwd)
+                            q.put((item, ev))
+                    q.put((None, None))
+                except BaseException as e:      # noqa: BLE001 — handed to the consumer thread
+                    q.put((e, None))
+
+            th = threading.Thread(target=producer, daemon=True)
+            th.start()
+            while True:
+                item, ev = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    th.join()
+                    raise item
+                main.wait_event(ev)
+                for v in item.values():
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(main)
+                harvest_one(item)
+            th.join()
+            fwd.synchronize()
+        else:
+            for sample in samples:
+                harvest_one(forward_one(sample))
         out = {}
         if save_dir:
             from . import storage

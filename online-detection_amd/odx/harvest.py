@@ -16,8 +16,12 @@ prepended rows (:181); coordinates are clamped to [0, size-1]; IoU uses the +1 c
 (utils/evaluations.py:4-18); `negatives_to_pick = ceil(BATCH_SIZE * ITERATIONS / NUM_IMAGES)`
 rows per class per image are spread over the class's still-open batches.
 
-MI355X form: IoU against all ground-truth boxes is one broadcast op instead of a per-box loop,
-and batches grow into preallocated device buffers (no O(n^2) torch.cat chains).
+MI355X form: IoU against all ground-truth boxes is one broadcast op instead of a per-box loop; the
+negatives of ALL classes of an image land in one preallocated (class, batch, row, D) device tensor with
+one gather + one index_copy_ (the reference appends per class and open batch, several hundred small
+copies per image, and grows its batches with O(n^2) torch.cat chains); the positives / regressor rows
+of all ground-truth boxes come from one nonzero() and one copy per buffer.  The host keeps what the
+reference fixes there: the order of the global RNG draws and the integer bookkeeping of open batches.
 """
 import math
 
@@ -49,17 +53,24 @@ class _Growing:
         self.n = 0
         self.mark_every, self.marks = mark_every, []
 
-    def append(self, rows):
+    def append(self, rows, seg_lens=None):
+        """seg_lens: the row counts of the appends the reference would have made for these rows (one per ground-truth box
+        / anchor type): the rows land with ONE device copy, the batch-closing rule is still applied append by append."""
         k = rows.shape[0]
         if self.n + k > self.buf.shape[0]:
             cap = max(2 * self.buf.shape[0], self.n + k)
             nb = torch.empty((cap,) + tuple(self.buf.shape[1:]), dtype=self.buf.dtype, device=self.buf.device)
             nb[: self.n] = self.buf[: self.n]
             self.buf = nb
-        self.buf[self.n:self.n + k] = rows.to(self.buf.device)
+        if k:
+            self.buf[self.n:self.n + k] = rows.to(self.buf.device)
+        at = self.n
         self.n += k
-        if self.mark_every and self.n - (self.marks[-1] if self.marks else 0) >= self.mark_every:
-            self.marks.append(self.n)
+        if self.mark_every:
+            for seg in ([k] if seg_lens is None else seg_lens):
+                at += seg
+                if at - (self.marks[-1] if self.marks else 0) >= self.mark_every:
+                    self.marks.append(at)
 
     def view(self):
         return self.buf[: self.n]
@@ -69,6 +80,70 @@ class _Growing:
         reference always has one more batch open)."""
         edges = [0] + list(self.marks if marks is None else marks) + [self.n]
         return [self.buf[a:b] for a, b in zip(edges[:-1], edges[1:])]
+
+
+class _Slot:
+    """One (class, batch) window of the negatives store of a _SlotGrid, with the interface of a _Growing buffer
+    (n, view, append)."""
+
+    def __init__(self, grid, cls, b):
+        self.grid, self.cls, self.b, self.n = grid, cls, b, 0
+        self.mark_every, self.marks = None, []
+
+    def view(self):
+        return self.grid.store[self.cls, self.b, : self.n]
+
+    def append(self, rows):
+        k = rows.shape[0]
+        self.grid.store[self.cls, self.b, self.n:self.n + k] = rows.to(self.grid.store.device)
+        self.n += k
+
+
+class _SlotGrid:
+    """Negatives of the fill mode: a batch never grows past batch_size rows, so every (class, batch) has a fixed home in
+    ONE (classes, batches, batch_size, D) tensor.  `plan` records, on the host, where the rows sampled for an image go
+    (the reference's bookkeeping, integer arithmetic only); `commit` moves all of them with one gather + one
+    index_copy_ — the reference (and round 1 here) appends them piece by piece, one small device copy per class and
+    open batch: several hundred per image at 30 classes x 10 batches."""
+
+    def __init__(self, D, iterations, batch_size, device):
+        self.D, self.iterations, self.batch_size, self.device = D, iterations, batch_size, device
+        self.store = torch.empty((0, iterations, batch_size, D), dtype=torch.float32, device=device)
+        self.classes = 0
+        self.dst, self.src = [], []
+
+    def add_class(self):
+        if self.classes == self.store.shape[0]:                       # grow (construction reserves the exact count)
+            cap = max(1, 2 * self.store.shape[0])
+            new = torch.empty((cap,) + tuple(self.store.shape[1:]), dtype=torch.float32, device=self.device)
+            new[: self.classes] = self.store[: self.classes]
+            self.store = new
+        c = self.classes
+        self.classes += 1
+        return [_Slot(self, c, b) for b in range(self.iterations)]
+
+    def reserve(self, classes):
+        if classes > self.store.shape[0]:
+            new = torch.empty((classes,) + tuple(self.store.shape[1:]), dtype=torch.float32, device=self.device)
+            new[: self.classes] = self.store[: self.classes]
+            self.store = new
+
+    def plan(self, slot, src_start, k):
+        if k > 0:
+            base = (slot.cls * self.iterations + slot.b) * self.batch_size + slot.n
+            self.dst.append((base, k))
+            self.src.append(src_start)
+            slot.n += k
+
+    def commit(self, rows):
+        """rows: the sampled rows of the image, all classes back to back (the `src_start` frame of plan)."""
+        if not self.dst:
+            return
+        dst = np.concatenate([np.arange(base, base + k, dtype=np.int64) for base, k in self.dst])
+        src = np.concatenate([np.arange(s0, s0 + k, dtype=np.int64) for s0, (_, k) in zip(self.src, self.dst)])
+        self.dst, self.src = [], []
+        idx = torch.from_numpy(np.stack((dst, src))).to(rows.device, non_blocking=True)     # one host -> device copy
+        self.store.view(-1, self.D).index_copy_(0, idx[0], rows.index_select(0, idx[1]))
 
 
 def clamp_boxes_(b, img_size):
@@ -94,6 +169,9 @@ class DetectorHarvester:
         self.num_classes = 0
         self._pos, self._neg, self.current_batch = [], [], []
         self.still_to_complete = []
+        self._grid = None if shuffle_negatives else _SlotGrid(feat_dim, iterations, batch_size, self.device)
+        if self._grid is not None:
+            self._grid.reserve(num_classes)
         for _ in range(num_classes):
             self.add_new_class()
         self.negatives_to_pick = None
@@ -111,7 +189,7 @@ class DetectorHarvester:
         if self.shuffle_negatives:
             self._neg.append([_Growing(self.D, self.device, cap=self.batch_size)])
         else:
-            self._neg.append([_Growing(self.D, self.device, cap=self.batch_size) for _ in range(self.iterations)])
+            self._neg.append(self._grid.add_class())
         self.current_batch.append(0)
 
     # ------------------------------------------------------------------ train time
@@ -136,21 +214,28 @@ class DetectorHarvester:
             first = (iou == best[None, :]).float().argmax(dim=0)
             assoc = torch.where(best > 0, first, assoc)
         prop_d = prop.to(x.device)
-        for i in range(len(gt_labels_list)):
-            c = gt_labels_list[i] - 1
+        if G:
+            # All ground-truth boxes at once (the reference walks them one by one, box_head_getProposals.py:151-226):
+            # sel[j, r] = proposal r regresses onto box j; nonzero() lists the pairs box-major, row-minor — the order of
+            # the reference's appends — with one host synchronisation per image instead of several per box.
+            cls = torch.tensor([l - 1 for l in gt_labels_list], dtype=torch.int64, device=x.device)
             if self.compute_gt_positives:
-                self._pos[c].append(x[i].view(1, -1))
-            pos_ids = (overlap[:, c] > self.reg_min_overlap) & (assoc == i)
-            ex = prop_d[pos_ids].view(-1, 4)
-            tgt = prop_d[i].view(1, 4).expand_as(ex)                                     # the prepended gt row
+                for c in sorted(set(gt_labels_list)):                      # rows of a class in ground-truth order
+                    rows_c = [i for i, l in enumerate(gt_labels_list) if l == c]
+                    self._pos[c - 1].append(x[rows_c].view(-1, self.D), seg_lens=[1] * len(rows_c))
+            sel = (overlap[:, cls].t() > self.reg_min_overlap) & (assoc[None, :] == torch.arange(G, device=x.device)[:, None])
+            pairs = sel.nonzero()
+            seg = torch.bincount(pairs[:, 0], minlength=G).tolist()
+            j_idx, r_idx = pairs[:, 0], pairs[:, 1]
+            ex, tgt = prop_d[r_idx], prop_d[j_idx]                          # tgt: the prepended ground-truth rows
             sw, sh = ex[:, 2] - ex[:, 0] + 1, ex[:, 3] - ex[:, 1] + 1
             sx, sy = ex[:, 0] + 0.5 * sw, ex[:, 1] + 0.5 * sh
             gw, gh = tgt[:, 2] - tgt[:, 0] + 1, tgt[:, 3] - tgt[:, 1] + 1
             gx, gy = tgt[:, 0] + 0.5 * gw, tgt[:, 1] + 0.5 * gh
             target = torch.stack(((gx - sx) / sw, (gy - sy) / sh, torch.log(gw / sw), torch.log(gh / sh)), dim=1)
-            self._Y.append(target)
-            self._C.append(torch.full((int(pos_ids.sum()), 1), float(gt_labels_list[i]), device=x.device))
-            self._X.append(x[pos_ids].view(-1, self.D))
+            self._Y.append(target, seg_lens=seg)
+            self._C.append((cls[j_idx] + 1).to(torch.float32).view(-1, 1), seg_lens=seg)
+            self._X.append(x[r_idx].view(-1, self.D), seg_lens=seg)
         if not self.shuffle_negatives:
             self._fill_batches(x, overlap, gt_labels_list)
         else:
@@ -204,10 +289,10 @@ class DetectorHarvester:
         classes = list(self.still_to_complete)
         feats_all, lens = self._sample_all(x, overlap, classes, gt_labels_list)
         at = 0
+        per_batch = math.ceil(self.negatives_to_pick / self.iterations)
         for i, n_i in zip(classes, lens):
-            neg_i = feats_all[at:at + n_i]
-            at += n_i
-            per_batch = math.ceil(self.negatives_to_pick / self.iterations)
+            # where the reference would append this class's rows (box_head_getProposals.py:226-290), as integer
+            # bookkeeping on the host; the rows themselves move once, for all classes, in _SlotGrid.commit
             taken = 0
             for b in range(self.current_batch[i], self.iterations):
                 cur = self._neg[i][b]
@@ -217,10 +302,13 @@ class DetectorHarvester:
                         done.append(i)
                     continue
                 end = int(taken + min(per_batch, self.batch_size - cur.n, self.negatives_to_pick - taken))
-                cur.append(neg_i[taken:end].view(-1, self.D))
+                lo, hi = min(taken, n_i), min(end, n_i)          # a class without candidates has no rows: neg_i[taken:end] is empty
+                self._grid.plan(cur, at + lo, hi - lo)
                 taken = end
                 if taken == self.negatives_to_pick:
                     break
+            at += n_i
+        self._grid.commit(feats_all)
         for i in done:
             self.still_to_complete.remove(i)
 
@@ -282,9 +370,12 @@ class RPNHarvester:
         self.anchors = None
         self._pos = [_Growing(feat_dim, self.device, mark_every=batch_size) for _ in range(num_classes)]
         if shuffle_negatives:
+            self._grid = None
             self._neg = [[_Growing(feat_dim, self.device, cap=batch_size)] for _ in range(num_classes)]
         else:
-            self._neg = [[_Growing(feat_dim, self.device, cap=batch_size) for _ in range(iterations)] for _ in range(num_classes)]
+            self._grid = _SlotGrid(feat_dim, iterations, batch_size, self.device)
+            self._grid.reserve(num_classes)
+            self._neg = [self._grid.add_class() for _ in range(num_classes)]
         self.current_batch = [0] * num_classes
         self._X, self._Y, self._C = _Growing(feat_dim, self.device, mark_every=batch_size), _Growing(4, self.device), _Growing(1, self.device)
         self.O = None
@@ -369,10 +460,12 @@ class RPNHarvester:
                         done.append(i)
                     continue
                 end = int(taken + min(per_batch, self.batch_size - cur.n, self.negatives_to_pick - taken, n_i - taken))
-                cur.append(feat_i[taken:end])
+                self._grid.plan(cur, at - n_i + taken, end - taken)       # rows move once for all types (commit below)
                 taken = end
                 if taken == self.negatives_to_pick:
                     break
+        if self._grid is not None:
+            self._grid.commit(feats_all)
         for i in done:
             self.still_to_complete.remove(i)
         # positives
@@ -387,18 +480,28 @@ class RPNHarvester:
                 extra = torch.nonzero(mine & (ious == best)).reshape(-1)
                 pos = torch.cat((pos, extra))
                 pos_gt = assoc[pos]
-        for i in torch.unique(self.cls[pos]).tolist():
-            sel = pos[self.cls[pos] == i]
-            feat = self._gather(t, sel)
-            self._pos[i].append(feat)
-            ex, tg = self.anchors[sel], assoc[sel]
-            sw, sh = ex[:, 2] - ex[:, 0] + 1, ex[:, 3] - ex[:, 1] + 1
-            sx, sy = ex[:, 0] + 0.5 * sw, ex[:, 1] + 0.5 * sh
-            gw, gh = tg[:, 2] - tg[:, 0] + 1, tg[:, 3] - tg[:, 1] + 1
-            gx, gy = tg[:, 0] + 0.5 * gw, tg[:, 1] + 0.5 * gh
-            self._Y.append(torch.stack(((gx - sx) / sw, (gy - sy) / sh, torch.log(gw / sw), torch.log(gh / sh)), dim=1))
-            self._C.append(torch.full((sel.numel(), 1), float(i), device=t.device))
-            self._X.append(feat)
+        # The reference walks the anchor types that have positives in ascending order and, per type, appends its rows
+        # (rpn_getProposals.py:383-449).  Here: a stable sort by type gives that order for all types at once, one gather
+        # fetches every positive's features, and each buffer receives one copy; one host read (the per-type counts).
+        pcls = self.cls[pos]
+        order_p = torch.argsort(pcls, stable=True)
+        sel = pos[order_p]
+        per_type = torch.bincount(pcls, minlength=self.A).tolist()
+        feat = self._gather(t, sel)
+        ex, tg = self.anchors[sel], assoc[sel]
+        sw, sh = ex[:, 2] - ex[:, 0] + 1, ex[:, 3] - ex[:, 1] + 1
+        sx, sy = ex[:, 0] + 0.5 * sw, ex[:, 1] + 0.5 * sh
+        gw, gh = tg[:, 2] - tg[:, 0] + 1, tg[:, 3] - tg[:, 1] + 1
+        gx, gy = tg[:, 0] + 0.5 * gw, tg[:, 1] + 0.5 * gh
+        seg = [k for k in per_type if k]
+        at = 0
+        for i, k in enumerate(per_type):
+            if k:
+                self._pos[i].append(feat[at:at + k])
+                at += k
+        self._Y.append(torch.stack(((gx - sx) / sw, (gy - sy) / sh, torch.log(gw / sw), torch.log(gh / sh)), dim=1), seg_lens=seg)
+        self._C.append(pcls[order_p].to(torch.float32).view(-1, 1), seg_lens=seg)
+        self._X.append(feat, seg_lens=seg)
 
     def finalize(self):
         """negatives, positives, COXY as returned by FeatureExtractorRPN.train

@@ -407,3 +407,46 @@ def test_dropin_feature_extractor_shards_images_only_on_request(monkeypatch):
         assert out[True] == sum(len(s[2]) for s in samples[1::2])           # rank 1 of 2: images 1 and 3
     finally:
         odx.set_backend(None)
+
+
+@pytest.mark.gpu
+def test_pipelined_harvest_equals_the_sequential_loop():
+    """OnlineFeatureExtractor runs the forward of image k + 1 on a second thread / stream while image k is harvested.
+    Harvesting stays in image order on the caller's thread, so every buffer must be what the plain loop gives (same row
+    counts and batch structure; values equal up to the run-to-run noise MIOpen convolutions are allowed)."""
+    from odx.extract import OnlineFeatureExtractor
+    odx.set_backend(None)
+    C = 4
+    model = OnlineDetectionModel(width=16, post_nms_top_n=60, pre_nms_top_n=600).cuda().eval()
+    samples = []
+    for (img, gt, labels) in _samples(7, 192, 256, C, seed=9):
+        masks = torch.zeros((len(labels), 192, 256), dtype=torch.uint8)
+        for j, b in enumerate(gt):
+            x1, y1, x2, y2 = [int(v) for v in b]
+            masks[j, y1:y2, x1:x2] = 1
+        samples.append((img, gt, labels, masks))
+    out = {}
+    for pipe in (False, True):
+        torch.manual_seed(11)
+        ex = OnlineFeatureExtractor(model, C, parts=("rpn", "detector", "mask"), det={"iterations": 2, "batch_size": 30},
+                                    rpn={"iterations": 2, "batch_size": 30}, mask={"batch_size": 200}, pipeline=pipe)
+        out[pipe] = ex.train(samples)
+    a, b = out[False], out[True]
+
+    def same(x, y):
+        assert tuple(x.shape) == tuple(y.shape)
+        assert x.numel() == 0 or float((x - y).abs().max()) < 1e-3 * max(1.0, float(x.abs().max()))
+
+    for part in ("rpn", "detector"):
+        (na, pa, ca), (nb, pb, cb) = a[part], b[part]
+        for x, y in zip(pa, pb):
+            same(x, y)
+        for bx, by in zip(na, nb):
+            assert len(bx) == len(by)
+            for x, y in zip(bx, by):
+                same(x, y)
+        for k in ("C", "X", "Y"):
+            same(ca[k], cb[k])
+    for xa, xb in zip(a["mask"][0] + a["mask"][1], b["mask"][0] + b["mask"][1]):
+        same(xa, xb)
+    assert sum(len(p) for p in a["detector"][1]) == sum(len(s[2]) for s in samples)
