@@ -263,6 +263,26 @@ int odx_rls_solve_f64(double* G, int64_t ldg, int D, double lam, const double* X
 int odx_rls_predict_rows_f64(const float* X, int64_t ldx, int D, const int64_t* idx, int64_t nc,
                              const double* W, int64_t ldw, double* P, int64_t ldp, odx_stream_t stream);
 
+/* The regressors of C <= 32 classes at once (the reference trains them one after the other,
+ * train_region_refiner.py:27-98; they are independent): every kernel takes the class as a grid dimension.
+ *   gram:  idx_pad (DEVICE, npad entries): the row ids class after class, each class's segment starting at a multiple of
+ *          16 and padded with -1; seg_off / seg_len (HOST, C entries): start and true length of the segments; Yt (4 x ldy):
+ *          the whitened targets in the same padded order.  G (C blocks g_stride apart, (D+1) x ldg lower) += Gram,
+ *          XtY (C blocks xy_stride apart, 4 x ldxy) += Yt [X 1] — one gather, one Gram GEMM, one X'Y GEMM.
+ *   solve: per class as odx_rls_solve_f64; W: C blocks w_stride apart, 4 x ldw; info: C words.
+ * Two calls so that a row-sharded caller can all-reduce G and XtY in between. */
+int64_t odx_rls_gram_batched_workspace_bytes(int64_t npad, int D);
+int odx_rls_gram_batched_f64(const float* X, int64_t ldx, int D, const int64_t* idx_pad, int64_t npad,
+                             const int64_t* seg_off, const int64_t* seg_len, int C,
+                             const double* Yt, int64_t ldy, double* G, int64_t ldg, int64_t g_stride,
+                             double* XtY, int64_t ldxy, int64_t xy_stride,
+                             void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+int64_t odx_rls_solve_batched_workspace_bytes(int D, int C);
+int odx_rls_solve_batched_f64(double* G, int64_t ldg, int64_t g_stride, int D, int C, double lam,
+                              const double* XtY, int64_t ldxy, int64_t xy_stride,
+                              double* W, int64_t ldw, int64_t w_stride, int32_t* info,
+                              void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+
 /* ---------------------------------------------------------------- A11: RoIAlign forward, NMS
  * The two maskrcnn_benchmark CUDA ops on the on-line path:
  *   Pooler -> ROIAlign(14x14, spatial_scale 1/16, sampling_ratio 0)

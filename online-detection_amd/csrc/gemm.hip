@@ -13,7 +13,7 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 8 && BN == 64) ? 3 : 1)
   constexpr int LDS_BYTES = (GEMM_BM + BN) * GEMM_LDS_ROW;
   __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
   const int b = blockIdx.y;
-  int64_t m = p.m, k = p.k;
+  int64_t m = p.m, k = p.zk_on ? p.zklen[blockIdx.z] : p.k;
   if (p.ragged_total > 0) {
     int64_t mb = p.ragged_total - p.ragged_off - (int64_t)b * p.ragged_step;
     if (mb > p.m) mb = p.m;
@@ -43,6 +43,10 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 8 && BN == 64) ? 3 : 1)
   const int z = blockIdx.z;
   const T* A = p.A + (int64_t)b * p.strideA + (int64_t)z * p.zstrideA;
   const T* B = p.B + (int64_t)b * p.strideB + (int64_t)z * p.zstrideB;
+  if (p.zk_on) {                          // (read before the k-range clipping below uses k)
+    A += p.zkoff[z];
+    B += p.zkoff[z];
+  }
   T* C = p.C + (int64_t)b * p.strideC + (int64_t)z * p.zstrideC;
   T* C2 = p.C2 ? p.C2 + (int64_t)b * p.strideC2 + (int64_t)z * p.zstrideC2 : nullptr;
   const T alpha = p.zalpha_on ? p.zalpha[z] : p.alpha;
@@ -179,6 +183,9 @@ static int launch_gemm(const GemmParams<T>& p, hipStream_t stream, const char* n
   ODX_REQUIRE(tiles < (1ll << 31) && p.batches < 65536, "%s: grid too large", name);
   ODX_REQUIRE(p.zbatches >= 1 && p.zbatches <= ODX_MAX_ZBATCH, "%s: 1 <= zbatches <= %d", name, ODX_MAX_ZBATCH);
   ODX_REQUIRE(p.zstrideA % EPV == 0 && p.zstrideB % EPV == 0, "%s: class strides must keep 16-byte alignment", name);
+  if (p.zk_on)
+    for (int z = 0; z < p.zbatches; ++z)
+      ODX_REQUIRE(p.zkoff[z] % EPV == 0 && p.zklen[z] >= 0, "%s: per-class k windows must start 16-byte aligned", name);
   dim3 grid((unsigned)tiles, (unsigned)p.batches, (unsigned)p.zbatches);
   GemmParams<T> q = p;
   q.vec_epilogue = aligned16(p.C) && p.ldc % EPV == 0 && p.strideC % EPV == 0 && p.zstrideC % EPV == 0 &&

@@ -28,6 +28,11 @@ struct GemmParams {
   int64_t zstrideA = 0, zstrideB = 0, zstrideC = 0, zstrideC2 = 0;
   int zalpha_on = 0;
   T zalpha[ODX_MAX_ZBATCH] = {};
+  // per-class window of the contraction axis (the RLS Grams of a class batch: class z owns columns
+  // [zkoff[z], zkoff[z] + zklen[z]) of the shared operands): A and B advance by zkoff[z], k = zklen[z]
+  int zk_on = 0;
+  int64_t zkoff[ODX_MAX_ZBATCH] = {};
+  int64_t zklen[ODX_MAX_ZBATCH] = {};
 };
 
 int launch_gemm_f64(const GemmParams<double>& p, hipStream_t stream);

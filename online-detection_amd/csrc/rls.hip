@@ -56,6 +56,35 @@ __global__ __launch_bounds__(256) void rls_predict_rows_kernel(const float* __re
   if (lane < 4) P[i * ldp + lane] = s[lane] + W[lane * ldw + D];
 }
 
+// The same gather for the rows of ALL classes at once: idx holds the row ids class after class, every class's segment
+// padded to a multiple of 16 entries with -1 (a padded column is all zero, its bias entry too).
+__global__ __launch_bounds__(256) void rls_gather_transpose_all_kernel(const float* __restrict__ X, int64_t ldx, int D,
+                                                                       const int64_t* __restrict__ idx, int64_t npad,
+                                                                       double* __restrict__ Xt, int64_t ldt) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t r0 = (int64_t)blockIdx.x * 32, d0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t r = r0 + ty + q * 8, d = d0 + tx;
+    double v = 0.0;
+    if (r < npad) {
+      const int64_t row = idx[r];
+      if (row >= 0) {
+        if (d < D) v = (double)X[row * ldx + d];
+        else if (d == D) v = 1.0;
+      }
+    }
+    tile[ty + q * 8][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t d = d0 + ty + q * 8, r = r0 + tx;
+    if (d <= D && r < ldt) Xt[d * ldt + r] = tile[tx][ty + q * 8];
+  }
+}
+
 static int64_t rls_chunk(int64_t workspace_bytes, int D) {
   const int64_t D1 = D + 1;
   int64_t chunk = workspace_bytes / (D1 * (int64_t)sizeof(double));
@@ -152,5 +181,105 @@ extern "C" int odx_rls_predict_rows_f64(const float* X, int64_t ldx, int D, cons
   hipLaunchKernelGGL(rls_predict_rows_kernel, dim3((unsigned)ceil_div(nc, 4)), dim3(256), 0, as_stream(stream), X, ldx,
                      D, idx, nc, W, ldw, P, ldp);
   ODX_CHECK_LAUNCH("odx_rls_predict_rows_f64");
+  return ODX_OK;
+}
+
+// ---------------------------------------------------------------- the regressors of a class batch
+// RegionRefinerTrainer trains its classes one after the other (train_region_refiner.py:27-98); they are independent, and
+// at the reference's sizes (D + 1 = 1025 .. 2049, a few thousand rows per class) one class fills neither the f64 matrix
+// cores (a Gram of 1025 x 1025 outputs is ~80 tiles for 256 CUs) nor the launch queue (its Cholesky is a chain of
+// dependent small kernels).  Here every kernel of the per-class path takes the class as a grid dimension:
+//   odx_rls_gram_batched_f64   one gather of all classes' rows (sorted by class, segments padded to 16) + ONE Gram GEMM and
+//                              ONE X'Y GEMM whose class z contracts over its own column window
+//   odx_rls_solve_batched_f64  + lam I, Cholesky, triangular inverses and the eight triangular products for all classes
+// with the arithmetic of odx_rls_gram_f64 / odx_rls_solve_f64 per class.  The split in two calls leaves room for the
+// all-reduce of the Grams when rows are sharded.
+extern "C" int64_t odx_rls_gram_batched_workspace_bytes(int64_t npad, int D) {
+  if (npad <= 0 || D <= 0) return 0;
+  return round_up(npad, 16) * (int64_t)(D + 1) * (int64_t)sizeof(double);
+}
+
+extern "C" int odx_rls_gram_batched_f64(const float* X, int64_t ldx, int D, const int64_t* idx_pad, int64_t npad,
+                                        const int64_t* seg_off, const int64_t* seg_len, int C, const double* Yt,
+                                        int64_t ldy, double* G, int64_t ldg, int64_t g_stride, double* XtY,
+                                        int64_t ldxy, int64_t xy_stride, void* workspace, int64_t workspace_bytes,
+                                        odx_stream_t stream) {
+  ODX_REQUIRE(C >= 1 && C <= ODX_MAX_ZBATCH, "odx_rls_gram_batched_f64: 1..%d classes per call", ODX_MAX_ZBATCH);
+  if (npad <= 0) return ODX_OK;
+  ODX_REQUIRE(X && idx_pad && seg_off && seg_len && Yt && G && XtY && workspace && D > 0, "odx_rls_gram_batched_f64: bad argument");
+  const int64_t D1 = D + 1, ldt = round_up(npad, 16);
+  ODX_REQUIRE(ldy % 2 == 0 && ldy >= ldt && aligned16(Yt) && aligned16(workspace), "odx_rls_gram_batched_f64: Yt/workspace 16-byte aligned, ldy even >= padded rows");
+  ODX_REQUIRE(ldg >= D1 && ldxy >= D1 && g_stride >= D1 * ldg && xy_stride >= 4 * ldxy, "odx_rls_gram_batched_f64: output strides too small");
+  if (workspace_bytes < odx_rls_gram_batched_workspace_bytes(npad, D)) {
+    set_error("odx_rls_gram_batched_f64: workspace too small");
+    return ODX_ERR_WORKSPACE;
+  }
+  hipStream_t s = as_stream(stream);
+  double* Xt = static_cast<double*>(workspace);
+  dim3 grid((unsigned)ceil_div(ldt, 32), (unsigned)ceil_div(D1, 32));
+  hipLaunchKernelGGL(rls_gather_transpose_all_kernel, grid, dim3(256), 0, s, X, ldx, D, idx_pad, npad, Xt, ldt);
+  ODX_CHECK_LAUNCH("rls_gather_transpose_all");
+  GemmParams<double> g;
+  g.A = Xt; g.lda = ldt; g.B = Xt; g.ldb = ldt; g.C = G; g.ldc = ldg;
+  g.m = D1; g.n = D1; g.k = 0; g.alpha = 1.0; g.beta = 1.0; g.flags = ODX_GEMM_LOWER_ONLY;
+  g.zbatches = C; g.zstrideC = g_stride; g.zk_on = 1;
+  GemmParams<double> h;
+  h.A = Yt; h.lda = ldy; h.B = Xt; h.ldb = ldt; h.C = XtY; h.ldc = ldxy;
+  h.m = 4; h.n = D1; h.k = 0; h.alpha = 1.0; h.beta = 1.0;
+  h.zbatches = C; h.zstrideC = xy_stride; h.zk_on = 1;
+  for (int c = 0; c < C; ++c) {
+    ODX_REQUIRE(seg_off[c] % 16 == 0 && seg_len[c] >= 0 && seg_off[c] + seg_len[c] <= npad,
+                "odx_rls_gram_batched_f64: class %d: segment must start at a multiple of 16 inside the padded index array", c);
+    g.zkoff[c] = h.zkoff[c] = seg_off[c];
+    g.zklen[c] = h.zklen[c] = seg_len[c];
+  }
+  ODX_PROPAGATE(launch_gemm_f64(g, s));
+  return launch_gemm_f64(h, s);
+}
+
+// workspace per class: Dinv | WT (D1*D1) | Li (D1 x ld) | Lit (D1 x ld) | z (4 x ld)
+extern "C" int64_t odx_rls_solve_batched_workspace_bytes(int D, int C) {
+  if (D <= 0 || C <= 0) return 0;
+  const int64_t D1 = D + 1, ld = round_up(D1, 2);
+  const int64_t per = ceil_div(D1, POTRF_NB) * POTRF_NB * POTRF_NB + round_up(D1 * D1, 2) + 2 * D1 * ld + 4 * ld;
+  return per * C * (int64_t)sizeof(double);
+}
+
+extern "C" int odx_rls_solve_batched_f64(double* G, int64_t ldg, int64_t g_stride, int D, int C, double lam, const double* XtY,
+                                         int64_t ldxy, int64_t xy_stride, double* W, int64_t ldw, int64_t w_stride,
+                                         int32_t* info, void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
+  ODX_REQUIRE(C >= 1 && C <= ODX_MAX_ZBATCH, "odx_rls_solve_batched_f64: 1..%d classes per call", ODX_MAX_ZBATCH);
+  ODX_REQUIRE(G && XtY && W && info && workspace && D > 0, "odx_rls_solve_batched_f64: bad argument");
+  const int64_t D1 = D + 1, ld = round_up(D1, 2);
+  ODX_REQUIRE(ldg % 2 == 0 && ldg >= D1 && g_stride % 2 == 0 && g_stride >= D1 * ldg && aligned16(G),
+              "odx_rls_solve_batched_f64: G 16-byte aligned, even ldg >= D + 1, even class stride");
+  ODX_REQUIRE(ldxy % 2 == 0 && ldxy >= D1 && xy_stride % 2 == 0 && aligned16(XtY) && ldw % 2 == 0 && ldw >= D1 && w_stride % 2 == 0 &&
+                  aligned16(W) && aligned16(workspace),
+              "odx_rls_solve_batched_f64: XtY / W / workspace 16-byte aligned with even strides");
+  if (workspace_bytes < odx_rls_solve_batched_workspace_bytes(D, C)) {
+    set_error("odx_rls_solve_batched_f64: workspace too small");
+    return ODX_ERR_WORKSPACE;
+  }
+  hipStream_t s = as_stream(stream);
+  const int64_t dsz = ceil_div(D1, POTRF_NB) * POTRF_NB * POTRF_NB, wtsz = round_up(D1 * D1, 2), lsz = D1 * ld;
+  double* Dinv = static_cast<double*>(workspace);
+  double* WT = Dinv + (int64_t)C * dsz;
+  double* Li = WT + (int64_t)C * wtsz;
+  double* Lit = Li + (int64_t)C * lsz;
+  double* z = Lit + (int64_t)C * lsz;
+  ODX_CHECK_HIP(hipMemsetAsync(info, 0, (size_t)C * sizeof(int32_t), s));
+  ODX_CHECK_HIP(hipMemsetAsync(Li, 0, (size_t)(2 * (int64_t)C * lsz) * sizeof(double), s));       // Li and Lit
+  ODX_PROPAGATE(add_diag_f64(G, ldg, D1, lam, s, C, g_stride));
+  ZBatch zb;
+  zb.count = C; zb.strideA = g_stride; zb.strideD = dsz; zb.strideO = lsz; zb.strideW = wtsz;
+  ODX_PROPAGATE(potrf_f64(G, ldg, D1, Dinv, info, s, zb));
+  ODX_PROPAGATE(trtri_from_diag_f64(G, ldg, D1, Dinv, Li, Lit, ld, WT, s, zb));
+  VecBatch vb;
+  vb.B = C;
+  for (int c = 0; c < C; ++c) vb.M[c] = (int)D1;
+  for (int k = 0; k < 4; ++k) {
+    ODX_PROPAGATE(trmv_batched_f64(Li, ld, lsz, 0, vb, XtY + k * ldxy, xy_stride, false, 0.0, nullptr, 0, z + k * ld, 4 * ld, s));
+    ODX_PROPAGATE(trmv_batched_f64(Lit, ld, lsz, 1, vb, z + k * ld, 4 * ld, false, 0.0, nullptr, 0, W + k * ldw, w_stride, s));
+  }
   return ODX_OK;
 }

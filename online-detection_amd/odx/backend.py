@@ -408,6 +408,35 @@ class HipBackend:
                   "odx_rls_solve_f64")
         return W, info
 
+    def rls_train_batched(self, F, idx_pad, seg_off, seg_len, Yt, lam, allreduce=None):
+        """The RLS solves of len(seg_len) <= 32 classes with one launch chain (odx_rls_gram_batched_f64 +
+        odx_rls_solve_batched_f64).  idx_pad: device int64 row ids class after class, every segment starting at a multiple
+        of 16 and padded with -1; seg_off / seg_len: python lists; Yt (4, ldy) f64 whitened targets in the same padded
+        order.  allreduce: optional callable summing a tensor over row shards (applied to the Grams and X'Y).  Returns
+        W (C, 4, ldw) f64 and info (C,) int32."""
+        C, D = len(seg_len), F.D
+        D1 = D + 1
+        ld = (D1 + 1) // 2 * 2
+        npad = int(idx_pad.numel())
+        G = torch.zeros((C, D1, ld), dtype=torch.float64, device=self.device)
+        XtY = torch.zeros((C, 4, ld), dtype=torch.float64, device=self.device)
+        W = torch.empty((C, 4, ld), dtype=torch.float64, device=self.device)
+        info = torch.zeros(C, dtype=torch.int32, device=self.device)
+        so = (ctypes.c_int64 * C)(*[int(v) for v in seg_off])
+        sl = (ctypes.c_int64 * C)(*[int(v) for v in seg_len])
+        if npad:
+            ws = self._workspace("rls_gram_batched", self.lib.odx_rls_gram_batched_workspace_bytes(npad, D))
+            hip.check(self.lib.odx_rls_gram_batched_f64(_p(F.X), F.ld, D, _p(idx_pad), npad, so, sl, C, _p(Yt), Yt.stride(0), _p(G), ld,
+                                                        D1 * ld, _p(XtY), ld, 4 * ld, _p(ws), ws.numel(), self._stream()),
+                      "odx_rls_gram_batched_f64")
+        if allreduce is not None:
+            allreduce(G)
+            allreduce(XtY)
+        ws = self._workspace("rls_solve_batched", self.lib.odx_rls_solve_batched_workspace_bytes(D, C))
+        hip.check(self.lib.odx_rls_solve_batched_f64(_p(G), ld, D1 * ld, D, C, float(lam), _p(XtY), ld, 4 * ld, _p(W), ld, 4 * ld,
+                                                     _p(info), _p(ws), ws.numel(), self._stream()), "odx_rls_solve_batched_f64")
+        return W, info
+
     def rls_predict_rows(self, F, idx, W):
         nc = F.n if idx is None else idx.numel()
         Pm = torch.empty((nc, 4), dtype=torch.float64, device=self.device)

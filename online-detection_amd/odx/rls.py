@@ -51,6 +51,126 @@ class RegionRefinerTrainer:
 
     def train(self, output_dir=None):
         be = _backend.get_backend()
+        if hasattr(be, "rls_train_batched") and len(self.cfg['CHOSEN_CLASSES']) - (0 if self.is_rpn else 1) > 1:
+            return self._train_batched(be, output_dir)
+        return self._train_sequential(be, output_dir)
+
+    def _train_batched(self, be, output_dir=None):
+        """All classes at once.  The reference's loop (train_region_refiner.py:27-98) handles one class per iteration —
+        gather its rows, whiten its targets, form its Gram, factor, solve, evaluate its losses; the classes are
+        independent, and at these sizes one class neither fills the f64 matrix cores nor hides its chain of small
+        factorisation kernels.  Here: rows sorted by class once (stable: a class's rows keep their order), the target
+        statistics per class from contiguous segments, then ONE gather + ONE Gram GEMM + ONE X'Y GEMM + ONE batched
+        Cholesky / inverse / solve chain for up to 32 classes (backend.rls_train_batched), and the per-class losses.
+        Per class the arithmetic is the sequential path's; printed lines and the returned object array are the same."""
+        dev = _device()
+        chosen_classes = self.cfg['CHOSEN_CLASSES']
+        start_index = 0 if self.is_rpn else 1
+        num_clss = len(chosen_classes)
+        ids = list(range(start_index, num_clss))
+        F = be.features(self.COXY['X'])
+        xdev = F.X.device
+        Call = self.COXY['C'].to(xdev).reshape(-1)
+        Yall = self.COXY['Y'].to(xdev)
+        D, D1 = F.D, F.D + 1
+        start_time = time.time()
+        Cl = Call.to(torch.int64)
+        order = torch.argsort(Cl, stable=True)
+        counts_all = torch.bincount(Cl.clamp(min=0), minlength=num_clss)[:num_clss].tolist()     # the one host read of the sizes
+        first = {}
+        acc = int((Cl < 0).sum().item()) if Cl.numel() and bool((Cl < 0).any()) else 0
+        for c in range(num_clss):
+            first[c] = acc
+            acc += counts_all[c]
+        n_loc = {c: counts_all[c] for c in ids}
+        n_tot = {c: (n_loc[c] if self.shard is None else self.shard.total(n_loc[c])) for c in ids}
+        models = {}
+        Wall, infos, rows_of, Yw_of, whit = {}, {}, {}, {}, {}
+        live = [c for c in ids if n_tot[c] > 0]
+        for g0 in range(0, len(live), be.MAX_CLASS_BATCH):
+            group = live[g0:g0 + be.MAX_CLASS_BATCH]
+            seg_off, seg_len, at = [], [], 0
+            for c in group:
+                seg_off.append(at)
+                seg_len.append(n_loc[c])
+                at += (n_loc[c] + 15) // 16 * 16
+            npad = at
+            idx_pad = torch.full((max(npad, 1),), -1, dtype=torch.int64, device=xdev)[:npad]
+            Yt = torch.zeros((4, max(npad, 16)), dtype=torch.float64, device=xdev)
+            # target statistics per class from its (contiguous) segment; the 4 x 4 eigen-decompositions of the whole group
+            # in one batched call (a 4 x 4 eigh on the GPU costs a solver launch + synchronisation: ~1 ms per class otherwise)
+            mus, Ycs, Ss = [], [], []
+            for c in group:
+                I = order[first[c]:first[c] + n_loc[c]]
+                rows_of[c] = I
+                Yi = Yall[I].type(torch.float64)
+                if self.shard is not None and self.shard.enabled:
+                    s1 = Yi.sum(0)
+                    self.shard.allreduce(s1)
+                    mu = s1 / n_tot[c]
+                    Yc = Yi - mu
+                    S = torch.matmul(Yc.t(), Yc)
+                    self.shard.allreduce(S)
+                    S = S / n_tot[c]
+                else:
+                    mu = torch.mean(Yi, dim=0)
+                    Yc = Yi - mu
+                    S = torch.matmul(Yc.t(), Yc) / Yc.size()[0]
+                mus.append(mu), Ycs.append(Yc), Ss.append(S)
+            # (on the host: 4 x 4 matrices — the GPU solver costs ~8 ms for the batch, mostly launch + synchronisation)
+            S_all = torch.stack(Ss)
+            evals, Wv = torch.linalg.eigh(S_all.cpu())
+            evals, Wv = evals.to(S_all.device), Wv.to(S_all.device)
+            root = torch.sqrt(evals + 0.001)
+            Ts = Wv @ torch.diag_embed(1.0 / root) @ Wv.transpose(1, 2)
+            Tis = Wv @ torch.diag_embed(root) @ Wv.transpose(1, 2)
+            for k, (c, off) in enumerate(zip(group, seg_off)):
+                Yw = torch.matmul(Ycs[k], Ts[k])
+                whit[c], Yw_of[c] = (mus[k], Ts[k], Tis[k]), Yw
+                idx_pad[off:off + n_loc[c]] = rows_of[c]
+                Yt[:, off:off + n_loc[c]] = Yw.t()
+            W, info = be.rls_train_batched(F, idx_pad, seg_off, seg_len, Yt, self.lambd,
+                                           allreduce=self.shard.allreduce if self.shard is not None else None)
+            bad = info.tolist()
+            for k, c in enumerate(group):
+                if bad[k] != 0:
+                    raise RuntimeError('RLS Cholesky failed for class %s (pivot %d)' % (chosen_classes[c], bad[k] - 1))
+                Wall[c] = W[k]
+        entries, means = {}, []
+        for i in live:
+            mu, T, T_inv = whit[i]
+            P = be.rls_predict_rows(F, rows_of[i].contiguous(), Wall[i])
+            losses = (0.5 * (P - Yw_of[i]) ** 2).type(torch.float32)
+            Beta = {str(k): {'weights': Wall[i][k, :D1].to(dev).type(torch.float32), 'losses': losses[:, k]} for k in range(4)}
+            entries[i] = {'mu': mu.to(dev).type(torch.float32), 'T': T.to(dev).type(torch.float32),
+                          'T_inv': T_inv.to(dev).type(torch.float32), 'Beta': Beta}
+            means.append(losses.mean(0) if n_loc[i] else torch.full((4,), float('nan'), device=losses.device))
+        mean_host = dict(zip(live, torch.stack(means).tolist())) if live else {}      # one host read for the printed lines
+        out = np.empty((0))
+        for i in ids:
+            print('Training regressor for class %s (%d/%d)' % (chosen_classes[i], i, num_clss - 1))
+            print('Training with %i examples' % n_loc[i])
+            if n_tot[i] == 0:
+                out = np.append(out, {'mu': None, 'T': None, 'T_inv': None, 'Beta': None})
+                print('No indices for class %s' % (chosen_classes[i]))
+                continue
+            out = np.append(out, entries[i])
+            print('Mean losses:', mean_host[i] if n_loc[i] else None)
+        self._report_time(time.time() - start_time, num_clss, output_dir)
+        return out
+
+    def _report_time(self, training_time, num_clss, output_dir):
+        print('Time required to train %d regressors: %f seconds.' % (num_clss - 1, training_time))
+        if output_dir:
+            with open(os.path.join(output_dir, "result.txt"), "a") as fid:
+                if self.is_rpn:
+                    fid.write("RPN's Online Region Refiner training time: {}min:{}s \n".format(
+                        int(training_time / 60), round(training_time % 60)))
+                else:
+                    fid.write("Detector's Online Region Refiner training time: {}min:{}s \n \n".format(
+                        int(training_time / 60), round(training_time % 60)))
+
+    def _train_sequential(self, be, output_dir=None):
         dev = _device()
         chosen_classes = self.cfg['CHOSEN_CLASSES']
         start_index = 0 if self.is_rpn else 1
@@ -100,16 +220,7 @@ class RegionRefinerTrainer:
                                         'T_inv': T_inv.to(dev).type(torch.float32), 'Beta': Beta})
             mean_losses = torch.stack([Beta[str(k)]['losses'].mean() for k in range(4)]) if n_loc else None
             print('Mean losses:', mean_losses)
-        training_time = time.time() - start_time
-        print('Time required to train %d regressors: %f seconds.' % (num_clss - 1, training_time))
-        if output_dir:
-            with open(os.path.join(output_dir, "result.txt"), "a") as fid:
-                if self.is_rpn:
-                    fid.write("RPN's Online Region Refiner training time: {}min:{}s \n".format(
-                        int(training_time / 60), round(training_time % 60)))
-                else:
-                    fid.write("Detector's Online Region Refiner training time: {}min:{}s \n \n".format(
-                        int(training_time / 60), round(training_time % 60)))
+        self._report_time(time.time() - start_time, num_clss, output_dir)
         return models
 
     def _whiten_sharded(self, Yi, n_tot):

@@ -90,6 +90,38 @@ def test_rls_large_d_against_oracle(hip_backend):
     assert np.abs(W - ref["W"]).max() < 1e-6 * max(1.0, np.abs(ref["W"]).max())
 
 
+def test_batched_rls_equals_the_class_by_class_loop(hip_backend):
+    """RegionRefinerTrainer trains all classes with one launch chain (one gather, one Gram GEMM over per-class column
+    windows, batched Cholesky / inverses / triangular products); per class the result must be the class-by-class
+    loop's (the reference's order of work) — ragged class sizes, a class without rows, more classes than one batch."""
+    from odx.rls import RegionRefinerTrainer
+    rng = np.random.default_rng(5)
+    D, C = 70, 35                                         # 35 classes: two batches (32 + 3)
+    sizes = [int(v) for v in rng.integers(1, 400, C)]
+    sizes[3], sizes[20] = 0, 17
+    X = torch.from_numpy(rng.standard_normal((sum(sizes), D)).astype(np.float32) * 0.5 + 0.1).cuda()
+    Y = torch.from_numpy(rng.standard_normal((sum(sizes), 4)).astype(np.float32) * 0.2).cuda()
+    Cl = torch.from_numpy(np.repeat(np.arange(1, C + 1), sizes).astype(np.float32)).cuda()
+    perm = torch.from_numpy(rng.permutation(sum(sizes))).cuda()
+    COXY = {"C": Cl[perm].view(-1, 1), "O": None, "X": X[perm], "Y": Y[perm]}
+    cfg = {"CHOSEN_CLASSES": {i: "c%d" % i for i in range(C + 1)}, "REGION_REFINER": {"opts": {"lambda": 10.0}}}
+    tr = RegionRefinerTrainer(cfg, 10.0, False)
+    tr.COXY = COXY
+    got = quiet(tr._train_batched, hip_backend)
+    ref = quiet(tr._train_sequential, hip_backend)
+    assert len(got) == len(ref) == C
+    for c, (a, b) in enumerate(zip(got, ref)):
+        assert (a["Beta"] is None) == (b["Beta"] is None) == (sizes[c] == 0), c
+        if a["Beta"] is None:
+            continue
+        for key in ("mu", "T", "T_inv"):
+            assert torch.allclose(a[key], b[key], atol=1e-6), (c, key)
+        for k in range(4):
+            wa, wb = a["Beta"][str(k)]["weights"], b["Beta"][str(k)]["weights"]
+            assert float((wa - wb).abs().max()) <= 1e-6 * max(1.0, float(wb.abs().max())), (c, k)
+            assert torch.allclose(a["Beta"][str(k)]["losses"], b["Beta"][str(k)]["losses"], atol=1e-6), (c, k)
+
+
 class OracleFalkonClassifier:
     """Test-side classifier plug-in: the reference wrapper's index rule + the f64 oracle fit."""
 

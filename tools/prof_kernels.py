@@ -19,6 +19,8 @@ for _ in range(2):
     K = be.knm(F, Zf, 15.0)
     v = torch.randn(M, dtype=torch.float64, device="cuda")
     be.ktk(K, v=v)
+    if be.can_ktk2(K):
+        be.ktk2(K, v, torch.randn(M, dtype=torch.float64, device="cuda"))     # the two-vector pass of the folded full residual
     al = torch.randn(M, dtype=torch.float64, device="cuda")
     be.mmv(F, Zf, 15.0, al)
 torch.cuda.synchronize()

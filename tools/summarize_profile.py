@@ -41,7 +41,7 @@ dur = collections.defaultdict(list)
 for f in sorted(glob.glob(os.path.join(d, "pmc_*counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if "odx::gauss_knm" in k or "odx::gauss_mmv" in k or "odx::knm_pass" in k:
+        if "odx::gauss_knm" in k or "odx::gauss_mmv" in k or "odx::knm_pass" in k:      # incl. knm_pass2_kernel
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in sorted(glob.glob(os.path.join(d, "pmc_*kernel_trace.csv"))):
     for r in csv.DictReader(open(f)):
@@ -81,11 +81,13 @@ print("""
   than the wall time and say nothing about how much of the GPU those kernels used.
 * `knm_pass_kernel`: algorithmic bytes per launch = n x M x 4 (40.0 GB at n = 1e6, M = 1e4); the FETCH_SIZE counter
   (doubled per the gfx950 correction of the guide) gives the same number: K_nM is read exactly once per pass.
+  `knm_pass2_kernel` (one launch per class: the CG step whose periodic full residual rides along) reads the same
+  40 GB once and forms two products from them.
 * The Gaussian kernels issue 3 f16 MFMAs per algorithmic product (two-term f16 split); MFMA-busy and the clock the chip
   holds under them (GRBM_GUI_ACTIVE / 8 / time) are in the lines above: 62-63 % at ~1.9 GHz on the 256 x 256 tile core, i.e.
   ~1.25 PFLOP/s of f16 MFMA issued on random data.  Their FETCH_SIZE counts L2 misses, most of them served by the Infinity
   Cache (unique input: 4.1 GB of packed X + 41 MB of packed Z per launch).  In the bench table the same kernels take
-  ~10 ms longer per launch than alone: the f64 MFMA work of the look-ahead preconditioners runs beside them.
+  longer per launch than alone: the f64 MFMA work of the look-ahead (class-batched) preconditioners runs beside them.
 * `gauss_knm_h2w256_kernel<true>` is the build with the fit's right-hand side K' (y / n) fused in (what the bench runs);
   the PMC passes launch the plain build `<false>`.
 """)
