@@ -281,8 +281,10 @@ def main():
     # ---- class-batched preconditioners (default): the factorisation chain of ONE preconditioner is ~1500 dependent small
     # launches that leave most of the chip idle; odx_falkon_precond_batched_f64 advances G classes with the same chain.
     # This rank's owned classes are taken G at a time; group g + 1 is built on the side stream while group g is fitted.
-    owned_total = len([b0 for b0 in range(0, C, world) if b0 + rank < C])
-    G = args.precond_batch if args.precond_batch > 0 else max(1, min(6, owned_total))
+    # (the group size must be the same on every rank — the centres of a group's classes are assembled with collectives —
+    # so it is derived from the number of lock-step batches, not from how many classes this rank happens to own)
+    n_batches = (C + world - 1) // world
+    G = args.precond_batch if args.precond_batch > 0 else max(1, min(6, n_batches))
     if G > 1:
         gside = torch.cuda.Stream()
         pgroup = [torch.empty((G, 4, M, ld_p), dtype=torch.float64, device=device) for _ in range(2)]
@@ -555,14 +557,24 @@ def cpu_baseline(args):
 
 
 def check_against_oracle(be, F, last, X, row_ids, args, c):
-    """Scores of the last fitted class on 2000 local rows vs the oracle's predict with the same alpha."""
+    """Scores of the last fitted class on 2000 local rows vs the oracle's predict with the same alpha; and, when the job is
+    small enough for the f64 oracle to fit it on the host (N x M <= 5e7), the class's alpha itself against the oracle's
+    fit on ALL rows (regenerated here from the job's seeds) — under several ranks that is the sharded, lock-step fit
+    against the single-process algorithm."""
     from oracle import falkon_ref as fr
     alpha, Zf = last
     rows = X[:2000].cpu().numpy().astype(np.float64)
     ref = fr.falkon_predict(rows, Zf.X.cpu().numpy().astype(np.float64), alpha.cpu().numpy()[:, None], args.sigma)
     Fs = be.features(X[:2000])
     got = be.mmv(Fs, Zf, args.sigma, alpha).cpu().numpy()
-    return {"max_abs_score_diff_vs_oracle_predict": float(np.abs(got - ref).max())}
+    out = {"max_abs_score_diff_vs_oracle_predict": float(np.abs(got - ref).max())}
+    if args.n * args.M <= 5e7:
+        Xall = synth_rows(0, args.n, args.D, args.classes, 1234 + 3, X.device).cpu().numpy().astype(np.float64)
+        y = np.where(np.arange(args.n) % args.classes == c, 1.0, -1.0)
+        idx = centre_indices(args.n, args.classes, args.M, 1234 + 3)[c]
+        a_ref, _ = fr.falkon_fit(Xall, y, idx, args.sigma, args.lam, maxiter=args.maxiter, dtype=np.float64, pc_eps=1e-5, cg_epsilon=1e-7)
+        out["alpha_rel_err_vs_oracle_fit"] = float(np.linalg.norm(alpha.cpu().numpy() - a_ref[:, 0]) / np.linalg.norm(a_ref[:, 0]))
+    return out
 
 
 if __name__ == "__main__":

@@ -318,22 +318,29 @@ print("RCCL-OK")
     assert "RCCL-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_bench_starts_its_own_ranks_and_matches_the_oracle():
+@pytest.mark.parametrize("ranks,classes,rows,centres", [(2, 4, 80000, 4200), (3, 4, 40000, 1024)])
+def test_bench_starts_its_own_ranks_and_matches_the_oracle(ranks, classes, rows, centres):
     """`python bench.py --gpus 2` (the driver's form, no launcher around it): the parent starts the two ranks itself, the
     ranks shard the rows and run the lock-step fit with its per-iteration exchange (gloo here: both ranks share this
     box's one GPU), and the result line reports the rank count the collective saw plus the oracle check."""
     import subprocess
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-                        "--single-device", "--dist-backend", "gloo", "--rows", "40000", "--centres", "1024", "--classes", "4",
+    # (3 ranks, 4 classes: lock-step batches of 3 and 1 — two ranks own nothing in the second batch; class-batched
+    # preconditioner groups of different sizes per rank, identical collectives on all of them)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "1",
+                        "--single-device", "--dist-backend", "gloo", "--rows", str(rows), "--centres", str(centres), "--classes", str(classes),
                         "--check", "--no-cpu-baseline", "--no-extras"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["config"]["rows_per_gpu"] == 20000
+    # (2 ranks, M = 4200, 40 000 rows per rank: the sharded fit folds its periodic full residual — two vectors per class in
+    # that iteration's exchange)
+    assert out["n_gpus"] == ranks and out["ranks"] == ranks and out["config"]["rows_per_gpu"] == rows // ranks + (1 if rows % ranks else 0)
     assert out["check"]["max_abs_score_diff_vs_oracle_predict"] < 1e-4
+    if rows * centres <= 5e7:                          # the sharded lock-step fit against the oracle's single-process fit
+        assert out["check"]["alpha_rel_err_vs_oracle_fit"] < 1e-4
     assert out["health"]["failed_choleskys"] == 0 and out["health"]["ranks_with_nonfinite_scores"] == 0
 
 
@@ -379,7 +386,7 @@ def test_batched_minibootstrap_equals_the_sequential_one_bit_for_bit(tmp_path):
 
     out = {}
     for mode, opts in (("seq", {"return_caches": True}), ("b1", {"class_batch": 1, "return_caches": True}),
-                       ("b3", {"class_batch": 3, "return_caches": True})):
+                       ("b3", {"class_batch": 3, "return_caches": True}), ("s3", {"class_streams": 3, "return_caches": True})):
         pos, neg = data()
         w = wrap_mod.FALKONWrapper(cfg_path=path)
         w.compute_indices_selection = injected
@@ -388,7 +395,7 @@ def test_batched_minibootstrap_equals_the_sequential_one_bit_for_bit(tmp_path):
     (ms, cs) = out["seq"]
     assert [m is None for m in ms] == [False, True, False, False, False]
     assert ms[4].M < M                                                   # the ragged member of the batch
-    for mode in ("b1", "b3"):
+    for mode in ("b1", "b3", "s3"):                # the class-streams mode too: same per-class draws => same bits
         mb, cb = out[mode]
         for c in range(C):
             assert (ms[c] is None) == (mb[c] is None)
