@@ -525,21 +525,48 @@ def project_masks_on_boxes(masks, boxes, M):
     (mask_head_getProposals.py:15-46 -> SegmentationMask.crop / resize of maskrcnn_benchmark's binary-mask
     representation: integer-rounded crop window, bilinear resize without corner alignment, truncated
     back to {0, 1}).  masks (G, H, W) bool/uint8, boxes (G, 4) xyxy -> (G, M, M) float32.
-    Done on the masks' device (the reference does it object by object on the CPU, :35).
+    All objects at once on the masks' device (the reference does it object by object on the CPU, :35): the crop
+    windows come to the host in one read, the bilinear resize of every crop is evaluated as four gathers from the full
+    masks with the source coordinates / weights of torch's upsample_bilinear2d (align_corners=False: src = scale (i + 0.5)
+    - 0.5 clamped at 0, second tap clamped to the crop's last pixel).
     PARITY UNPINNED (the mask containers are maskrcnn_benchmark's, not vendored)."""
-    out = []
+    G = masks.shape[0]
+    if G == 0:
+        return torch.empty(0, dtype=torch.float32, device=masks.device)
     H, W = masks.shape[1], masks.shape[2]
-    for m, b in zip(masks, boxes):
-        x1, y1, x2, y2 = [int(round(float(v))) for v in b]
+    win = []
+    for bx in boxes.tolist():                                   # one host read for all objects
+        x1, y1, x2, y2 = [int(round(float(v))) for v in bx]
         x1, y1 = min(max(x1, 0), W - 1), min(max(y1, 0), H - 1)
         x2, y2 = min(max(x2, 0), W - 1), min(max(y2, 0), H - 1)
-        x2, y2 = max(x2, x1 + 1), max(y2, y1 + 1)
-        crop = m[y1:y2, x1:x2].float()[None, None]
-        r = torch.nn.functional.interpolate(crop, size=(M, M), mode="bilinear", align_corners=False)[0, 0]
-        out.append((r + 1e-6).to(torch.uint8).float())   # truncation, made robust to 0.99999994-style fuzz
-    if not out:
-        return torch.empty(0, dtype=torch.float32, device=masks.device)
-    return torch.stack(out)
+        win.append((x1, y1, max(x2, x1 + 1), max(y2, y1 + 1)))
+    dev = masks.device
+    wt = torch.tensor(win, dtype=torch.int64).to(dev)           # (G, 4)
+    x1, y1 = wt[:, 0:1], wt[:, 1:2]
+    cw, ch = (wt[:, 2:3] - x1), (wt[:, 3:4] - y1)               # crop sizes (G, 1)
+    i = torch.arange(M, dtype=torch.float32, device=dev)[None, :]
+
+    def taps(size):
+        scale = size.to(torch.float32) / float(M)
+        src = (scale * (i + 0.5) - 0.5).clamp_(min=0.0)
+        i0 = src.floor().to(torch.int64)
+        i0 = torch.minimum(i0, size - 1)
+        i1 = torch.minimum(i0 + 1, size - 1)
+        l1 = src - i0.to(torch.float32)
+        return i0, i1, 1.0 - l1, l1
+
+    xa, xb, wxa, wxb = taps(cw)                                 # (G, M) each
+    ya, yb, wya, wyb = taps(ch)
+    g = torch.arange(G, device=dev)[:, None, None]
+    mf = masks
+
+    def tap(yy, xx):
+        return mf[g, (y1 + yy)[:, :, None], (x1 + xx)[:, None, :]].to(torch.float32)
+
+    top = wxa[:, None, :] * tap(ya, xa) + wxb[:, None, :] * tap(ya, xb)
+    bot = wxa[:, None, :] * tap(yb, xa) + wxb[:, None, :] * tap(yb, xb)
+    r = wya[:, :, None] * top + wyb[:, :, None] * bot
+    return (r + 1e-6).to(torch.uint8).float()                   # truncation, made robust to 0.99999994-style fuzz
 
 
 class MaskHarvester:
@@ -564,15 +591,35 @@ class MaskHarvester:
 
     def add_image(self, mask_features, masks_gt, gt_labels_list):
         """mask_features (G, D, S, S) = relu(conv5_mask(head features of the ground-truth RoIs));
-        masks_gt (G, S, S) from project_masks_on_boxes; gt_labels_list class ids 1..C."""
-        for i in range(len(mask_features)):
-            rows = mask_features[i].permute(1, 2, 0).reshape(-1, mask_features.size(1))
-            mg = masks_gt[i].reshape(rows.size(0)).to(rows.device)
+        masks_gt (G, S, S) from project_masks_on_boxes; gt_labels_list class ids 1..C.
+        All objects of the image at once: per object the pixels are ordered positives-first by a stable sort (ascending
+        pixel index inside each group, as torch.where lists them), the sizes come to the host in one read, the random
+        sub-sampling draws are made object by object, positives then negatives, from the global RNG as in the reference,
+        and every class buffer receives one copy."""
+        G = len(mask_features)
+        if G == 0:
+            return
+        D, S2 = mask_features.size(1), mask_features.size(2) * mask_features.size(3)
+        dev = mask_features.device
+        rows = mask_features.permute(0, 2, 3, 1).reshape(G * S2, D)
+        is_pos = masks_gt.reshape(G, S2).to(dev) >= 0.5
+        order = torch.argsort((~is_pos).to(torch.int8), dim=1, stable=True)        # positives first, each group ascending
+        npos = is_pos.sum(1).tolist()                                             # the one host read
+        picks = {}                                                                # (class, kind) -> [(object, tensor of local picks)]
+        for i in range(G):
             c = gt_labels_list[i] - 1
-            for sel, store in ((torch.where(mg >= 0.5)[0], self._pos[c]), (torch.where(mg < 0.5)[0], self._neg[c])):
+            for kind, start, cnt in ((0, 0, npos[i]), (1, npos[i], S2 - npos[i])):
                 if self.sampling_factor < 1.0:
-                    sel = sel[torch.randperm(len(sel))[:int(self.sampling_factor * len(sel))].to(sel.device)]
-                store.append(rows[sel])
+                    p = torch.randperm(cnt)[:int(self.sampling_factor * cnt)]
+                else:
+                    p = torch.arange(cnt)
+                picks.setdefault((c, kind), []).append((i, p + start))
+        for (c, kind), lst in picks.items():
+            loc = torch.cat([p for _, p in lst])
+            obj = torch.cat([torch.full((len(p),), i, dtype=torch.int64) for i, p in lst])
+            idx = torch.stack((obj, loc)).to(dev, non_blocking=True)
+            sel = order[idx[0], idx[1]] + idx[0] * S2
+            (self._pos if kind == 0 else self._neg)[c].append(rows.index_select(0, sel), seg_lens=[len(p) for _, p in lst])
 
     def finalize(self):
         """negatives, positives as tensors per class (extract_features_detector.py:273-278)."""

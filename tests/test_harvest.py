@@ -169,3 +169,36 @@ def test_project_masks_on_boxes_basics(device):
     assert out.shape == (2, 14, 14) and bool((out[0] == 1).all())
     assert bool((out[1][:, :6] == 1).all()) and bool((out[1][:, 8:] == 0).all())
     assert project_masks_on_boxes(torch.zeros(0, 8, 8), torch.zeros(0, 4), 14).shape == (0,)
+
+
+def _project_one_by_one(masks, boxes, M):
+    """The per-object formulation (crop, F.interpolate, truncate) the batched project_masks_on_boxes must reproduce."""
+    out = []
+    H, W = masks.shape[1], masks.shape[2]
+    for m, b in zip(masks, boxes):
+        x1, y1, x2, y2 = [int(round(float(v))) for v in b]
+        x1, y1 = min(max(x1, 0), W - 1), min(max(y1, 0), H - 1)
+        x2, y2 = min(max(x2, 0), W - 1), min(max(y2, 0), H - 1)
+        x2, y2 = max(x2, x1 + 1), max(y2, y1 + 1)
+        crop = m[y1:y2, x1:x2].float()[None, None]
+        r = torch.nn.functional.interpolate(crop, size=(M, M), mode="bilinear", align_corners=False)[0, 0]
+        out.append((r + 1e-6).to(torch.uint8).float())
+    return torch.stack(out)
+
+
+@pytest.mark.parametrize("device", DEVICES)
+def test_batched_mask_projection_equals_the_per_object_resize(device):
+    from odx.harvest import project_masks_on_boxes
+    g = torch.Generator().manual_seed(12)
+    H, W, G = 97, 131, 40
+    masks = (torch.rand((G, H, W), generator=g) > 0.35).to(torch.uint8)
+    for k in range(G):                                    # blobs, so that the crops are not pure noise
+        cy, cx = int(torch.randint(H, (1,), generator=g)), int(torch.randint(W, (1,), generator=g))
+        masks[k, max(cy - 20, 0):cy + 20, max(cx - 25, 0):cx + 25] = 1
+    xy = torch.rand((G, 2), generator=g) * torch.tensor([W * 0.8, H * 0.8]) - 5.0          # some boxes start outside the image
+    wh = torch.cat((torch.rand((G // 2, 2), generator=g) * 90 + 1, torch.rand((G - G // 2, 2), generator=g) * 6))   # up- and down-scaling
+    boxes = torch.cat((xy, xy + wh), 1)
+    for M in (14, 7, 28):
+        got = project_masks_on_boxes(masks.to(device), boxes.to(device), M).cpu()
+        ref = _project_one_by_one(masks, boxes, M)
+        assert got.shape == ref.shape and torch.equal(got, ref), (M, int((got != ref).sum()))
