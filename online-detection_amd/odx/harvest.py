@@ -541,27 +541,31 @@ def project_masks_on_boxes(masks, boxes, M):
         x2, y2 = min(max(x2, 0), W - 1), min(max(y2, 0), H - 1)
         win.append((x1, y1, max(x2, x1 + 1), max(y2, y1 + 1)))
     dev = masks.device
-    wt = torch.tensor(win, dtype=torch.int64).to(dev)           # (G, 4)
-    x1, y1 = wt[:, 0:1], wt[:, 1:2]
-    cw, ch = (wt[:, 2:3] - x1), (wt[:, 3:4] - y1)               # crop sizes (G, 1)
-    i = torch.arange(M, dtype=torch.float32, device=dev)[None, :]
+    wn = np.asarray(win, dtype=np.int64)                        # (G, 4)
+    i = np.arange(M, dtype=np.float32)[None, :]
 
-    def taps(size):
-        scale = size.to(torch.float32) / float(M)
-        src = (scale * (i + 0.5) - 0.5).clamp_(min=0.0)
-        i0 = src.floor().to(torch.int64)
-        i0 = torch.minimum(i0, size - 1)
-        i1 = torch.minimum(i0 + 1, size - 1)
-        l1 = src - i0.to(torch.float32)
-        return i0, i1, 1.0 - l1, l1
+    def taps(first, size):
+        """Source taps of one axis on the host, in f32 exactly as upsample_bilinear2d forms them (the scale is a host-side
+        f32 quotient there too); returned as absolute pixel coordinates in the full mask."""
+        size = size[:, None]
+        scale = size.astype(np.float32) / np.float32(M)
+        src = np.maximum(scale * (i + np.float32(0.5)) - np.float32(0.5), np.float32(0.0))
+        i0 = np.minimum(np.floor(src).astype(np.int64), size - 1)
+        i1 = np.minimum(i0 + 1, size - 1)
+        l1 = (src - i0.astype(np.float32)).astype(np.float32)
+        return first[:, None] + i0, first[:, None] + i1, np.float32(1.0) - l1, l1
 
-    xa, xb, wxa, wxb = taps(cw)                                 # (G, M) each
-    ya, yb, wya, wyb = taps(ch)
+    xa, xb, wxa, wxb = taps(wn[:, 0], wn[:, 2] - wn[:, 0])       # (G, M) each
+    ya, yb, wya, wyb = taps(wn[:, 1], wn[:, 3] - wn[:, 1])
+    idx = torch.from_numpy(np.stack((xa, xb, ya, yb))).to(dev, non_blocking=True)
+    wts = torch.from_numpy(np.stack((wxa, wxb, wya, wyb))).to(dev, non_blocking=True)
+    xa, xb, ya, yb = idx[0], idx[1], idx[2], idx[3]
+    wxa, wxb, wya, wyb = wts[0], wts[1], wts[2], wts[3]
     g = torch.arange(G, device=dev)[:, None, None]
     mf = masks
 
     def tap(yy, xx):
-        return mf[g, (y1 + yy)[:, :, None], (x1 + xx)[:, None, :]].to(torch.float32)
+        return mf[g, yy[:, :, None], xx[:, None, :]].to(torch.float32)
 
     top = wxa[:, None, :] * tap(ya, xa) + wxb[:, None, :] * tap(ya, xb)
     bot = wxa[:, None, :] * tap(yb, xa) + wxb[:, None, :] * tap(yb, xb)
