@@ -42,9 +42,12 @@ class deferred_pivot_checks:
     def __exit__(self, exc_type, exc, tb):
         global _DEFERRED
         _DEFERRED = self._prev
-        if exc_type is None:
-            for be, info in self.items:
-                be.check_info(info)
+        if exc_type is None and self.items:
+            # one host read for all status words of the block (they are 1-element device tensors)
+            vals = torch.cat([info.reshape(-1)[:1] for _, info in self.items]).tolist()
+            for (be, info), v in zip(self.items, vals):
+                if v != 0:
+                    be.check_info(info)          # raises with the backend's message
         return False
 
 

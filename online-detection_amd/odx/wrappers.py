@@ -97,8 +97,13 @@ class FALKONWrapperBase:
         lam = self.lam if lam is None else lam
         self.kernel = self.kernel_cls(sigma=sigma)
         models = []
+        # the index rule as shipped keeps its result as a tensor (same draws, same order; no 2000-element python list per
+        # class and round); a subclass or an instance that replaces compute_indices_selection is called as is
+        own_rule = (type(self).compute_indices_selection is FALKONWrapperBase.compute_indices_selection
+                    and "compute_indices_selection" not in self.__dict__)
+        rule = self._indices_tensor if own_rule else self.compute_indices_selection
         for i, (X, y) in enumerate(zip(Xs, ys)):
-            indices = index_rng(i, lambda: self.compute_indices_selection(y)) if index_rng else self.compute_indices_selection(y)
+            indices = index_rng(i, lambda: rule(y)) if index_rng else rule(y)
             if isinstance(indices, int):
                 indices = [indices]
             opt = self.options_cls(min_cuda_iter_size_32=0, min_cuda_iter_size_64=0, keops_active="no",
@@ -120,7 +125,8 @@ class FALKONWrapperBase:
     def test(self):
         pass
 
-    def compute_indices_selection(self, y):
+    def _indices_tensor(self, y):
+        """compute_indices_selection up to its final `.squeeze().tolist()`: (k,) int64 tensor on y's device."""
         half = int(self.nyst_centers / 2)
         pos = (y == 1).nonzero()
         if pos.size()[0] > half:
@@ -129,4 +135,7 @@ class FALKONWrapperBase:
         room = self.nyst_centers - pos.size()[0]
         if neg.size()[0] > room:
             neg = neg[torch.randint(neg.size()[0], (room,))]
-        return torch.cat((pos, neg), dim=0).squeeze().tolist()
+        return torch.cat((pos, neg), dim=0).reshape(-1)
+
+    def compute_indices_selection(self, y):
+        return self._indices_tensor(y).squeeze().tolist()
