@@ -111,6 +111,26 @@ def test_estimator_surface():
     assert np.allclose(s[:, 0].numpy(), p[:, 0].numpy(), atol=1e-6) and np.allclose(s[:, 1].numpy(), 2 * p[:, 0].numpy(), atol=1e-5)
 
 
+def test_train_batch_on_a_backend_without_batched_kernels_equals_train():
+    """FALKONWrapper.train_batch (the class-batched Minibootstrap's entry point) on a backend that has no batched
+    preconditioner (the numpy-oracle backend of this suite): every class is fitted on its own, with the same result as
+    `train` given the same index draws."""
+    mod = dropin.load("FALKONWrapper_with_centers_selection_incore")
+    w = mod.FALKONWrapper(cfg_path=os.path.join(GOLD, "cfg_bootstrap.yaml"))
+    Xs, ys = [], []
+    for seed in (1, 2, 3):
+        X, y, _ = blob_problem(260 + 20 * seed, 16, seed=seed)
+        Xs.append(torch.from_numpy(X)), ys.append(torch.from_numpy(y))
+    torch.manual_seed(9)
+    batch = quiet(w.train_batch, Xs, ys, sigma=7.0, lam=0.01)
+    torch.manual_seed(9)
+    single = [quiet(w.train, X, y, sigma=7.0, lam=0.01) for X, y in zip(Xs, ys)]
+    assert len(batch) == 3
+    for a, b in zip(batch, single):
+        assert a.M == b.M and torch.equal(a.ny_points_, b.ny_points_) and torch.equal(a.alpha_, b.alpha_)
+        assert tuple(a.predict(Xs[0][:5]).shape) == (5, 1)
+
+
 def test_multi_output_fit_is_rejected_loudly():
     m = odx.InCoreFalkon(kernel=odx.GaussianKernel(5.0), penalty=1e-3, M=10)
     with pytest.raises(ValueError):
