@@ -533,6 +533,47 @@ def test_gauss_random_shapes_stay_inside_their_buffers(be, gauss):
         assert torch.isnan(sbuf[n * T:]).all()
 
 
+def test_lockstep_cg_of_a_class_batch_equals_the_single_class_loops(be):
+    """odx_falkon_cg_batched_f64: the CG loops of several independent fits as ONE launch sequence.  Per class the alpha
+    must be the very bits odx_falkon_cg_f64 gives (ragged n and M inside one pass configuration, a class that converges
+    at once, 32 classes = the largest batch); classes from different pass configurations are refused (None)."""
+    from odx.solver import SolverOptions
+    rng = np.random.default_rng(77)
+    D, sigma, lam, opt = 48, 7.0, 1e-4, SolverOptions(check_pivots=False)
+    specs = [(900, 300), (50, 257), (1500, 512), (777, 333)] + [(400 + 13 * k, 260 + 7 * k) for k in range(28)]     # 32 classes, every M in the first pass configuration (<= 256 float4 chunks per row)
+    Fs, Zfs, ys = [], [], []
+    for n, M in specs:
+        X = (rng.standard_normal((n, D)) * (20.0 / np.sqrt(D))).astype(np.float32)
+        F = be.features(torch.from_numpy(X))
+        Fs.append(F)
+        Zfs.append(be.rows(F, np.sort(rng.choice(n, size=min(M, n), replace=False))) if M <= n else be.features(torch.from_numpy(
+            (rng.standard_normal((M, D)) * (20.0 / np.sqrt(D))).astype(np.float32))))
+        ys.append(be.vec(np.where(rng.random(n) < 0.2, 1.0, -1.0)))
+    ys[1] = be.vec(np.zeros(specs[1][0]))                     # zero right-hand side: converged before the first step
+    Ps = be.precond_batched(Zfs, sigma, lam, opt.pc_epsilon)
+    Mmax = max(z.n for z in Zfs)
+    b0s = torch.zeros((len(specs), (Mmax + 1) // 2 * 2), dtype=torch.float64, device="cuda")
+    Ks = []
+    for i, (F, Zf, y) in enumerate(zip(Fs, Zfs, ys)):
+        K, _ = be.knm_rhs(F, Zf, sigma, y * (1.0 / F.n), rhs_out=b0s[i, :Zf.n])
+        Ks.append(K)
+    alphas = be.cg_solve_batched(Ks, Ps, b0s, [F.n for F in Fs], lam, 20, opt)
+    assert alphas is not None
+    for i, (K, P) in enumerate(zip(Ks, Ps)):
+        single = be.cg_solve(K, P, b0s[i, :K.M].clone(), K.n, lam, 20, opt)
+        assert torch.equal(alphas[i, :K.M], single), (i, specs[i], float((alphas[i, :K.M] - single).abs().max()))
+        assert torch.isfinite(single).all()
+    assert float(alphas[1].abs().max()) == 0.0
+    # a class whose M falls into another pass configuration cannot join the batch
+    Fb = be.features(torch.from_numpy((rng.standard_normal((3000, D)) * (20.0 / np.sqrt(D))).astype(np.float32)))
+    Zb = be.rows(Fb, np.arange(1500))
+    Pb = be.precond_batched([Zfs[0], Zb], sigma, lam, opt.pc_epsilon)
+    b2 = torch.zeros((2, 1500), dtype=torch.float64, device="cuda")
+    K0, _ = be.knm_rhs(Fs[0], Zfs[0], sigma, ys[0] * (1.0 / Fs[0].n), rhs_out=b2[0, :Zfs[0].n])
+    K1, _ = be.knm_rhs(Fb, Zb, sigma, be.vec(np.ones(3000)) * (1.0 / 3000), rhs_out=b2[1, :1500])
+    assert be.cg_solve_batched([K0, K1], Pb, b2, [Fs[0].n, 3000], lam, 20, opt) is None
+
+
 @pytest.mark.parametrize("n,M,D,maxiter", [(3000, 300, 256, 20), (700, 129, 36, 7), (5000, 1000, 64, 25)])
 def test_cg_loop_in_one_call_equals_the_loop_issued_from_python(be, n, M, D, maxiter):
     """odx_falkon_cg_f64 (what an unsharded fit runs) against the statement-by-statement loop of odx/solver.py (what
