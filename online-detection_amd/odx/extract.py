@@ -518,36 +518,51 @@ class OnlineFeatureExtractor:
             fwd = torch.cuda.Stream()
             fwd.wait_stream(main)
             q = queue.Queue(maxsize=2)
+            stop = threading.Event()
+
+            def put(x):
+                while not stop.is_set():
+                    try:
+                        q.put(x, timeout=0.1)
+                        return True
+                    except queue.Full:
+                        pass
+                return False
 
             def producer():
                 try:
                     torch.cuda.set_device(dev)
                     with torch.cuda.stream(fwd):
                         for sample in samples:
+                            if stop.is_set():
+                                return
                             item = forward_one(sample)
                             ev = torch.cuda.Event()
                             ev.record(fwd)
-                            q.put((item, ev))
-                    q.put((None, None))
+                            if not put((item, ev)):
+                                return
+                    put((None, None))
                 except BaseException as e:      # noqa: BLE001 — handed to the consumer thread
-                    q.put((e, None))
+                    put((e, None))
 
             th = threading.Thread(target=producer, daemon=True)
             th.start()
-            while True:
-                item, ev = q.get()
-                if item is None:
-                    break
-                if isinstance(item, BaseException):
-                    th.join()
-                    raise item
-                main.wait_event(ev)
-                for v in item.values():
-                    if torch.is_tensor(v) and v.is_cuda:
-                        v.record_stream(main)
-                harvest_one(item)
-            th.join()
-            fwd.synchronize()
+            try:
+                while True:
+                    item, ev = q.get()
+                    if item is None:
+                        break
+                    if isinstance(item, BaseException):
+                        raise item
+                    main.wait_event(ev)
+                    for v in item.values():
+                        if torch.is_tensor(v) and v.is_cuda:
+                            v.record_stream(main)
+                    harvest_one(item)
+            finally:
+                stop.set()                      # a failed harvest must not leave the forward thread blocked on the queue
+                th.join()
+                fwd.synchronize()
         else:
             for sample in samples:
                 harvest_one(forward_one(sample))
