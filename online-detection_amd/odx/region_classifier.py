@@ -268,15 +268,15 @@ class OnlineRegionClassifierBase:
                 main.wait_stream(s)
             return out
 
+        next_scores = {}        # class -> scores of its NEXT negative batch under its current model (made with the pruning predicts)
         for j in range(nb):
             todo = [i for i in active if j < len(negatives[i])]
             if j == 0:
                 for i in todo:
                     caches[i] = {'pos': positives[i], 'neg': negatives[i][0]}
             else:
-                scores = on_streams(todo, lambda i: self.classifier.predict(model[i], negatives[i][j]))
                 for i in todo:
-                    hard_idx = torch.where(scores[i] > self.hard_tresh)[0]
+                    hard_idx = torch.where(next_scores.pop(i) > self.hard_tresh)[0]
                     caches[i]['neg'] = torch.cat((caches[i]['neg'], negatives[i][j][hard_idx]), 0)
                     print('Class {}: chosen {} hard negatives from the {}th batch'.format(i, len(hard_idx), j))
             Xs, ys = [], []
@@ -299,7 +299,16 @@ class OnlineRegionClassifierBase:
             for i, m in zip(todo, fitted):
                 model[i] = m
             prune = [i for i in todo if len(caches[i]['neg']) != 0 and j != len(negatives[i]) - 1]
-            scores = on_streams(prune, lambda i: self.classifier.predict(model[i], caches[i]['neg']))
+            ahead = [i for i in todo if j + 1 < len(negatives[i])]
+            # the two predicts a class's fresh model is used for — pruning its cache now, mining its next batch at the start
+            # of the next round — in ONE phase on the streams (the next batch is known; the reference scores it first thing
+            # in the next iteration with this same model, OnlineRegionClassifier_incore.py:112-116)
+            both = on_streams(sorted(set(prune) | set(ahead)),
+                              lambda i: (self.classifier.predict(model[i], caches[i]['neg']) if i in prune else None,
+                                         self.classifier.predict(model[i], negatives[i][j + 1]) if i in ahead else None))
+            scores = {i: both[i][0] for i in prune}
+            for i in ahead:
+                next_scores[i] = both[i][1]
             for i in prune:
                 keep_idx = torch.where(scores[i] >= self.easy_tresh)[0]
                 removed = len(caches[i]['neg']) - len(keep_idx)
