@@ -724,7 +724,10 @@ extern "C" int odx_split_f16(const float* X, int64_t ldx, int64_t n, int D, void
 static int launch_knm_w256(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n, const void* PZ,
                            int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int64_t dp, double sigma, float* K,
                            int64_t ldk, const double* w, double* wslab, int64_t wslab_ld, odx_stream_t stream) {
-  const int wgr = 4;   // band height of the tile order; 2 / 4 / 8 / 16 / 32 measured: 395 / 397 / 391 / 376 / 347 TF
+  // band height of the tile order; 2 / 4 / 8 / 16 / 32 measured alone: 395 / 397 / 391 / 376 / 347 TF
+  // (ODX_H2_BAND overrides it for experiments: a taller band re-streams the centres from the Infinity Cache less often)
+  static const int wgr_env = [] { const char* e = getenv("ODX_H2_BAND"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 64) ? v : 0; }();
+  const int wgr = wgr_env ? wgr_env : 4;
   const int64_t wt = round_up(ceil_div(n, W_BM), wgr) * ceil_div(M, W_BN);
   ODX_REQUIRE(wt < (1ll << 31), "odx_gauss_knm_h2: grid too large");
   const float g2 = (float)(-0.5 / (sigma * sigma)) * LOG2E;
