@@ -804,12 +804,23 @@ extern "C" int odx_gauss_knm_h2_rhs(const void* PX, int64_t ldpx, const float* m
   return slab_reduce_f64(static_cast<const double*>(workspace), wld, (int)ceil_div(n, W_BM), M, ktw, as_stream(stream));
 }
 
+// Column tiles per workgroup on the 128 x 128 core: MMV_TG when that still gives every CU two workgroups, fewer for
+// small scoring calls (a Minibootstrap predict of 2000 rows against 2000 centres is 16 x 16 tiles: 64 workgroups of 4
+// tiles each left three quarters of the chip idle for 300 us; 256 workgroups of one tile take 90 us).  A function of the
+// call's shape only, so equal calls give equal bits.
+static int mmv_tg(int64_t n, int64_t max_range, int C) {
+  const int64_t rb = ceil_div(n, GEMM_BM), ct = ceil_div(max_range, GEMM_BN);
+  int tg = MMV_TG;
+  while (tg > 1 && rb * ceil_div(ct, tg) * C < 512) tg >>= 1;
+  return tg;
+}
+
 // groups of column tiles (counted from the range's own first row) a centre range of at most `max_range` rows spans
-static int64_t mmv_groups(int64_t max_range) { return ceil_div(ceil_div(max_range, GEMM_BN), MMV_TG); }
+static int64_t mmv_groups(int64_t max_range, int tg) { return ceil_div(ceil_div(max_range, GEMM_BN), tg); }
 
 extern "C" int64_t odx_gauss_mmv_h2_workspace_bytes(int64_t n, int64_t max_range, int T) {
   if (n <= 0 || max_range <= 0 || T <= 0) return 0;
-  return (int64_t)T * mmv_groups(max_range) * round_up(n, 2) * (int64_t)sizeof(double);
+  return (int64_t)T * mmv_groups(max_range, mmv_tg(n, max_range, T)) * round_up(n, 2) * (int64_t)sizeof(double);
 }
 
 extern "C" int odx_gauss_mmv_h2(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
@@ -847,16 +858,17 @@ extern "C" int odx_gauss_mmv_h2(const void* PX, int64_t ldpx, const float* metax
       return ODX_OK;
     }
   }
-  const int G = (int)mmv_groups(max_range);
+  const int tg = mmv_tg(n, max_range, C);
+  const int G = (int)mmv_groups(max_range, tg);
   const int64_t wgs = round_up(ceil_div(n, GEMM_BM), 8) * G;
   ODX_REQUIRE(wgs < (1ll << 31), "odx_gauss_mmv_h2: grid too large");
   ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_mmv_h2s16_kernel)));
   hipLaunchKernelGGL(gauss_mmv_h2s16_kernel, dim3((unsigned)wgs, (unsigned)C), dim3(GEMM_THREADS), S16_LDS_BYTES,
                      as_stream(stream), (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq,
-                     (int)(dp / H2_KT), (float)(-0.5 / (sigma * sigma)) * LOG2E, V, ldv, ranges, MMV_TG, G, slab, slab_ld);
+                     (int)(dp / H2_KT), (float)(-0.5 / (sigma * sigma)) * LOG2E, V, ldv, ranges, tg, G, slab, slab_ld);
   ODX_CHECK_LAUNCH("odx_gauss_mmv_h2");
   hipLaunchKernelGGL(mmv_reduce_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)C), dim3(256), 0, as_stream(stream), slab,
-                     slab_ld, G, MMV_TG, GEMM_BN, ranges, n, out, ldo);
+                     slab_ld, G, tg, GEMM_BN, ranges, n, out, ldo);
   ODX_CHECK_LAUNCH("odx_gauss_mmv_h2(reduce)");
   return ODX_OK;
 }

@@ -26,8 +26,12 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 8 && BN == 64) ? 3 : 1)
   // Tile order: workgroups b and b + 8 share an XCD (round-robin dispatch), so XCD x walks the
   // tile rows x, x + 8, ... left to right: neighbours in time share the A row panel in that XCD's
   // L2, and triangular work (lower-only output, k-ranges clipped by a triangular operand) is
-  // spread evenly over the XCDs instead of piling the long rows onto the last one.
-  const int64_t xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  // spread evenly over the XCDs instead of piling the long rows onto the last one.  gridDim.x is a multiple of 8, so
+  // the physical XCD of a workgroup is blockIdx.x & 7 whatever its batch; the batch index rotates which tile rows that
+  // XCD gets: a batch of many small products (m <= 128: ONE tile row, i.e. one XCD per product without the rotation —
+  // the merge levels of the triangular inverse, the last trailing updates of a Cholesky) covers all eight XCDs, and
+  // the uneven row weights of triangular work average out over the batch.
+  const int64_t xcd = (blockIdx.x + blockIdx.y + blockIdx.z) & 7, local = blockIdx.x >> 3;
   const int64_t bi = xcd + 8 * (local / tiles_n), bj = local % tiles_n;
   const int64_t i0 = bi * GEMM_BM, j0 = bj * BN;
   if (i0 >= m) return;

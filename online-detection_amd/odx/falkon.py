@@ -170,19 +170,30 @@ def fit_batch(estimators, Xs, Ys, streams=None):
     for (sigma, lam, eps), members in groups.items():
         for c0 in range(0, len(members), be.MAX_CLASS_BATCH):
             chunk = members[c0:c0 + be.MAX_CLASS_BATCH]
-            Ps = be.precond_batched([Zfs[i] for i in chunk], sigma, lam, eps, ws_key="precond_batched_fit")
             opts = [estimators[i].options.solver_options() for i in chunk]
             iters = {int(estimators[i].maxiter) for i in chunk}
             same = len(iters) == 1 and all(o == opts[0] for o in opts) and hasattr(be, "cg_solve_batched")
-            alphas = None
             if same:
-                # K_nM builds (one launch each), then ALL CG loops of the chunk in lock step: one launch sequence
                 Mmax = max(Zfs[i].n for i in chunk)
                 b0s = torch.zeros((len(chunk), (Mmax + 1) // 2 * 2), dtype=torch.float64, device=be.device)
+                if streams:
+                    for s in streams:           # before the chain is queued: the builds below start beside it, not after it
+                        s.wait_stream(cur)
+            Ps = be.precond_batched([Zfs[i] for i in chunk], sigma, lam, eps, ws_key="precond_batched_fit")
+            alphas = None
+            if same:
+                # K_nM builds (f16 split of the rows, one Gaussian launch, the right-hand side: ~10 short kernels per
+                # class) on the streams while the factorisation chain runs, then ALL CG loops of the chunk in lock step
                 Ks = []
                 for row, i in enumerate(chunk):
-                    K, _ = be.knm_rhs(Fs[i], Zfs[i], sigma, yvs[i] * (1.0 / Fs[i].n), rhs_out=b0s[row, :Zfs[i].n])
+                    with (torch.cuda.stream(streams[row % len(streams)]) if streams else _nullcontext()):
+                        K, _ = be.knm_rhs(Fs[i], Zfs[i], sigma, yvs[i] * (1.0 / Fs[i].n), rhs_out=b0s[row, :Zfs[i].n])
+                        if streams:
+                            K.K.record_stream(cur)      # allocated on a side stream, read by the CG on the caller's
                     Ks.append(K)
+                if streams:
+                    for s in streams:
+                        cur.wait_stream(s)
                 alphas = be.cg_solve_batched(Ks, Ps, b0s, [Fs[i].n for i in chunk], lam, iters.pop(), opts[0])
             for row, (i, P) in enumerate(zip(chunk, Ps)):
                 est = estimators[i]

@@ -268,7 +268,7 @@ class OnlineRegionClassifierBase:
                 main.wait_stream(s)
             return out
 
-        next_scores = {}        # class -> scores of its NEXT negative batch under its current model (made with the pruning predicts)
+        next_hard = {}          # class -> hard-negative rows of its NEXT batch under its current model (scored with the pruning predicts)
         for j in range(nb):
             todo = [i for i in active if j < len(negatives[i])]
             if j == 0:
@@ -276,7 +276,7 @@ class OnlineRegionClassifierBase:
                     caches[i] = {'pos': positives[i], 'neg': negatives[i][0]}
             else:
                 for i in todo:
-                    hard_idx = torch.where(next_scores.pop(i) > self.hard_tresh)[0]
+                    hard_idx = next_hard.pop(i)
                     caches[i]['neg'] = torch.cat((caches[i]['neg'], negatives[i][j][hard_idx]), 0)
                     print('Class {}: chosen {} hard negatives from the {}th batch'.format(i, len(hard_idx), j))
             Xs, ys = [], []
@@ -306,11 +306,14 @@ class OnlineRegionClassifierBase:
             both = on_streams(sorted(set(prune) | set(ahead)),
                               lambda i: (self.classifier.predict(model[i], caches[i]['neg']) if i in prune else None,
                                          self.classifier.predict(model[i], negatives[i][j + 1]) if i in ahead else None))
-            scores = {i: both[i][0] for i in prune}
-            for i in ahead:
-                next_scores[i] = both[i][1]
-            for i in prune:
-                keep_idx = torch.where(scores[i] >= self.easy_tresh)[0]
+            # every selection of the phase — the rows a class keeps (score >= easy threshold) and the hard negatives of
+            # its next batch (score > hard threshold) — from ONE nonzero() over the concatenated scores, i.e. one host
+            # synchronisation per round instead of one per torch.where; each class's indices are its slice of the
+            # result, in the same (ascending) order torch.where gives
+            keep, hard = self._select_rows([both[i][0] for i in prune], [both[i][1] for i in ahead])
+            for i, hard_idx in zip(ahead, hard):
+                next_hard[i] = hard_idx
+            for i, keep_idx in zip(prune, keep):
                 removed = len(caches[i]['neg']) - len(keep_idx)
                 caches[i]['neg'] = caches[i]['neg'][keep_idx]
                 print('Class {}: removed {} easy negatives. {} Remaining'.format(i, removed, len(caches[i]['neg'])))
@@ -327,6 +330,27 @@ class OnlineRegionClassifierBase:
         if self.return_caches:
             self.caches = caches
         return model
+
+    def _select_rows(self, easy_scores, hard_scores):
+        """Row indices with score >= easy threshold for each vector of `easy_scores` and with score > hard threshold for
+        each of `hard_scores` — what torch.where(...)[0] returns vector by vector, from one nonzero() and one host read."""
+        vecs = [v.reshape(-1) for v in easy_scores] + [v.reshape(-1) for v in hard_scores]
+        if not vecs:
+            return [], []
+        lens = [int(v.numel()) for v in vecs]
+        flat = torch.cat(vecs)
+        ends = np.cumsum(lens)
+        split = int(ends[len(easy_scores) - 1]) if easy_scores else 0
+        mask = torch.empty(flat.shape, dtype=torch.bool, device=flat.device)
+        torch.ge(flat[:split], self.easy_tresh, out=mask[:split])
+        torch.gt(flat[split:], self.hard_tresh, out=mask[split:])
+        nz = mask.nonzero().reshape(-1)
+        cuts = np.searchsorted(nz.cpu().numpy(), ends, side='left')
+        out, a, off = [], 0, 0
+        for b, e in zip(cuts, ends):
+            out.append(nz[a:b] - off)
+            a, off = int(b), int(e)
+        return out[:len(easy_scores)], out[len(easy_scores):]
 
     def trainRegionClassifier(self, opts=None, output_dir=None):
         if opts is not None:

@@ -99,9 +99,12 @@ class AccuracyEvaluator(AccuracyEvaluatorAbstract):
                 image, _ = preprocess_image(image, min_size=(cfg.get('INPUT') or {}).get('MIN_SIZE_TEST', 600))
             else:
                 orig = (int(image.shape[3]), int(image.shape[2]))
-            res, _ = detect(model, image, orig, score_thresh, nms, per_img, with_masks=do_masks and gt_masks is not None)
+            want_masks = do_masks and gt_masks is not None
+            res, _ = detect(model, image, orig, score_thresh, nms, per_img, with_masks=want_masks)
             if res is None:
                 res = {"boxes": torch.zeros((0, 4)), "scores": torch.zeros(0), "labels": torch.zeros(0, dtype=torch.int64)}
+            if want_masks and "masks" not in res:                  # an image without detections still counts its ground truth
+                res["masks"] = torch.zeros((0, orig[1], orig[0]), dtype=torch.uint8)
             preds.append({k: v.cpu().numpy() for k, v in res.items()})
             g = {"boxes": gt_boxes.numpy(), "labels": np.asarray(gt_labels, dtype=np.int64)}
             if difficult is not None:

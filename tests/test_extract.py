@@ -236,6 +236,22 @@ def test_full_ours_pipeline_on_gpu(tmp_path):
         pix = model.online_mask(model.mask_activation(maps[:5]))
     assert boxes.shape[0] > 0 and tuple(scores.shape) == (boxes.shape[0], C + 1) and tuple(deltas.shape) == (boxes.shape[0], 4 * (C + 1))
     assert tuple(pix.shape) == (5, C + 1, 14, 14) and torch.isfinite(pix).all() and torch.isfinite(scores).all()
+    # the experiment driver's last step (run_experiment_online_rpn_ood_oos.py:291-307): AccuracyEvaluator with all three
+    # sets of on-line models injected, detection AND segmentation AP written in the reference's result.txt format
+    fresh = OnlineDetectionModel(width=16, post_nms_top_n=30, pre_nms_top_n=300, mask_dim=32).cuda().eval()
+    fresh.load_state_dict(model.state_dict())
+    ae = dropin.load("accuracy_evaluator").AccuracyEvaluator(path, path)
+    ae.falkon_rpn_models, ae.regressors_rpn_models, ae.stats_rpn = m_rpn, r_rpn, st_rpn
+    ae.falkon_detector_models, ae.regressors_detector_models, ae.stats_detector = m_det, r_det, st_det
+    ae.falkon_segmentation_models, ae.stats_segmentation = m_seg, st_seg
+    ae.regions_post_nms = 25
+    with redirect_stdout(io.StringIO()):
+        res = ae.evaluateAccuracyDetection(False, output_dir=str(tmp_path), evaluate_segmentation=True,
+                                           cfg_options={"samples": samples[:4], "model": fresh})
+    assert fresh.post_nms_top_n == 25 and fresh.online_rpn is not None and fresh.online_mask is not None
+    assert set(res) == {"ap", "map"}
+    text = open(os.path.join(str(tmp_path), "result.txt")).read()
+    assert "Detection mAP50: " in text and "Segmentation mAP50: " in text
 
 
 # ------------------------------------------------------------------ accuracy_evaluator drop-in

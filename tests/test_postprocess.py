@@ -83,6 +83,14 @@ def test_eval_edge_cases():
     assert eval_detection(pr, gt, use_07_metric=False)["ap"][1] == pytest.approx(1.0)
     assert average_recall([0.75, 0.4, 1.0]) == pytest.approx(2 * (0.25 + 0 + 0.5) / 3)
     assert average_recall([]) == 0.0
+    # segmentation AP: an image without detections (empty (0, H, W) masks) still counts its ground truth -> recall 1/2
+    m = np.zeros((1, 8, 8), np.uint8)
+    m[0, 2:6, 2:6] = 1
+    gts = [{"boxes": gt[0]["boxes"], "labels": np.array([1]), "masks": m}] * 2
+    prs = [{"boxes": gt[0]["boxes"], "labels": np.array([1]), "scores": np.array([0.9], np.float32), "masks": m},
+           {"boxes": np.zeros((0, 4), np.float32), "labels": np.zeros(0, np.int64), "scores": np.zeros(0, np.float32), "masks": np.zeros((0, 8, 8), np.uint8)}]
+    prec, rec = detection_prec_rec(prs, gts, 0.5, key="masks")
+    assert prec[1].tolist() == [1.0] and rec[1].tolist() == [0.5]
 
 
 def test_dropin_class_contract():
