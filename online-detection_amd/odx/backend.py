@@ -29,11 +29,12 @@ def _p(t):
 class Features:
     """Row-major f32 rows (n x D, leading dimension a multiple of 4) plus their squared norms and, once a
     Gaussian-kernel call has needed it, the packed two-term f16 split of the rows (P, meta: odx_split_f16)."""
-    __slots__ = ("X", "sq", "n", "D", "ld", "P", "meta")
+    __slots__ = ("X", "sq", "n", "D", "ld", "P", "meta", "own_pack")
 
     def __init__(self, X, sq, D, P=None, meta=None):
         self.X, self.sq, self.n, self.D, self.ld = X, sq, X.shape[0], D, X.stride(0) if X.shape[0] else X.shape[1]
         self.P, self.meta = P, meta
+        self.own_pack = P is None       # False: P was gathered from another matrix's split and carries ITS scale
 
 
 class Precond:

@@ -52,7 +52,7 @@ class GaussianKernel:
         detected and only its non-zero row range per column is visited."""
         be = _backend.get_backend()
         F = be.features(X1)
-        Zf = be.features(X2)
+        Zf = X2 if (hasattr(X2, "sq") or hasattr(X2, "n")) and not torch.is_tensor(X2) else be.features(X2)     # a backend's Features
         v = torch.as_tensor(v)
         if v.dim() == 1:
             v = v[:, None]
@@ -121,12 +121,41 @@ class _FalkonBase:
         if self._cpu_model:
             self.alpha_ = self.alpha_.cpu()
             self.ny_points_ = self.ny_points_.cpu()
+        else:
+            self._centres(Zf)
         return self
+
+    def _centres(self, Zf=None):
+        """The centres as kernel operands (row norms, packed f16 split), kept with the model while `ny_points_` is the
+        same, unmodified tensor: a predict is ~100 us of GPU work and re-deriving them was a third of its launches.
+        Same bits as a fresh derivation (the split's scale comes from the centres alone)."""
+        be, ny = _backend.get_backend(), self.ny_points_
+        if Zf is not None:
+            if ny is Zf.X and getattr(Zf, "own_pack", True):
+                self._zf = (ny, ny._version, be, Zf)
+            return Zf
+        c = self.__dict__.get("_zf")
+        if c is not None and c[0] is ny and c[1] == ny._version and c[2] is be:
+            if ny.is_cuda:          # possibly made on another stream than the one that scores with them now
+                cur = torch.cuda.current_stream()
+                for t in (c[3].X, c[3].sq, getattr(c[3], "P", None), getattr(c[3], "meta", None)):
+                    if t is not None:
+                        t.record_stream(cur)
+            return c[3]
+        Zf = be.features(ny)
+        if torch.is_tensor(ny):
+            self._zf = (ny, ny._version, be, Zf)
+        return Zf
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_zf", None)          # derived data, tied to this process's backend: not copied, not pickled
+        return d
 
     def predict(self, X):
         if self.alpha_ is None:
             raise RuntimeError("predict called before fit")
-        res = self.kernel.mmv(X, self.ny_points_, self.alpha_)
+        res = self.kernel.mmv(X, self._centres(), self.alpha_)
         if self._cpu_model and not (torch.is_tensor(X) and X.is_cuda):
             res = res.cpu()
         return res
@@ -211,6 +240,8 @@ def fit_batch(estimators, Xs, Ys, streams=None):
                 est.alpha_, est.ny_points_ = alpha.reshape(-1, 1), ny
                 if est._cpu_model:
                     est.alpha_, est.ny_points_ = est.alpha_.cpu(), est.ny_points_.cpu()
+                else:
+                    est._centres(Zfs[i])
     if streams:
         for s in streams:
             cur.wait_stream(s)

@@ -284,7 +284,9 @@ class OnlineRegionClassifierBase:
                 X_pos, X_neg = caches[i]['pos'], caches[i]['neg']
                 print('Class {}: traning with {} positives and {} negatives'.format(i, len(X_pos), len(X_neg)))
                 Xs.append(torch.cat((X_pos, X_neg), 0))
-                ys.append(torch.cat((torch.ones(len(X_pos), device=X_pos.device), -torch.ones(len(X_neg), device=X_pos.device)), 0))
+                # labels on the host: the Nystroem index rule reads them (two nonzero() per class — host synchronisations
+                # when the labels live on the GPU); the fit uploads its own f64 copy
+                ys.append(torch.cat((torch.ones(len(X_pos)), -torch.ones(len(X_neg))), 0))
 
             def with_class_rng(pos, fn):
                 i = todo[pos]

@@ -103,6 +103,14 @@ def test_estimator_surface():
     buf.seek(0)
     m3 = torch.load(buf, weights_only=False)[0]
     assert torch.equal(m3.alpha_, m.alpha_) and m3.kernel.sigma == 6.0 and m3.M == 60
+    # the centres' kernel operands stay with the model while ny_points_ is the same, unmodified tensor — and only then
+    assert "_zf" in m.__dict__ and "_zf" not in m2.__dict__ and "_zf" not in m3.__dict__
+    assert torch.equal(m3.predict(Xt[:7]), p) and torch.equal(m.predict(Xt[:7]), p) and m3._zf[3] is m3._centres()
+    m3.ny_points_[0] += 1.0                                            # in place: the version counter moves
+    p_moved = m3.predict(Xt[:7])
+    assert not torch.equal(p_moved, p)
+    m3.ny_points_ = m.ny_points_.clone()                               # re-assigned (falkon_models_to_cuda does this)
+    assert torch.equal(m3.predict(Xt[:7]), p)
     # kernel.mmv with a block-structured alpha_parallel (roi_box_predictors.py:140-160)
     alpha_par = torch.zeros(120, 2, dtype=torch.float64)
     alpha_par[:60, 0] = m.alpha_[:, 0]
