@@ -65,6 +65,8 @@ class OnlineRegionClassifierBase:
         self.return_caches = False
         self.class_streams = 0          # > 0: classes trained concurrently on that many streams (opts['class_streams'])
         self.class_batch = 0            # > 0: the classes of a round fitted by one batched call, on that many streams (opts['class_batch'])
+        self.class_rng = False          # one RNG stream per class for the Nystroem draws (opts['class_rng']; implied by the three modes above/below)
+        self.class_shard = False        # classes round-robin over the ranks of torch.distributed, models gathered at the end (opts['class_shard'])
 
     def loadRegionClassifier(self) -> None:
         pass
@@ -75,6 +77,10 @@ class OnlineRegionClassifierBase:
                           ('sigma', 'sigma')):
             if key in opts:
                 setattr(self, attr, opts[key])
+        if 'class_rng' in opts:
+            self.class_rng = bool(opts['class_rng'])
+        if 'class_shard' in opts:
+            self.class_shard = bool(opts['class_shard'])
         if self.incore:
             if 'return_caches' in opts:
                 self.return_caches = opts['return_caches']
@@ -99,11 +105,77 @@ class OnlineRegionClassifierBase:
     def _host(self, t):
         return t if self.incore else t.cpu()
 
+    # ---- classes over ranks ("reference-regime minibootstrap": independent units, no data-path collective) --
+    def _ranks(self):
+        """(rank, world) of the class sharding: (0, 1) unless opts['class_shard'] and an initialised process group."""
+        import torch.distributed as dist
+        if self.class_shard and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+
+    def _owned(self, i):
+        rank, world = self._ranks()
+        return i % world == rank
+
+    def _class_seed(self):
+        """One draw from the global RNG (class c's own stream is seeded seed + c); rank 0's draw on every rank."""
+        seed = torch.randint(2 ** 62, (1,))
+        if self._ranks()[1] > 1:
+            import torch.distributed as dist
+            comm = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+            seed = seed.to(comm)
+            dist.broadcast(seed, src=0)
+        return int(seed.item())
+
+    def _gather_models(self, model):
+        """Every rank ends with every class's model: class i's (ny_points_, alpha_) broadcast by its owner i % world.
+        Two small collectives per class after the training — none during it."""
+        rank, world = self._ranks()
+        if world == 1:
+            return model
+        import torch.distributed as dist
+        comm = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+        C = len(model)
+        shapes = torch.zeros((C, 2), dtype=torch.int64)
+        for i, m in enumerate(model):
+            if m is not None and i % world == rank:
+                shapes[i, 0], shapes[i, 1] = m.ny_points_.shape
+        shapes = shapes.to(comm)
+        dist.all_reduce(shapes)
+        shapes = shapes.tolist()
+        for i in range(C):
+            M, D = shapes[i]
+            if M == 0:
+                continue
+            owner = i % world
+            if owner == rank:
+                where = model[i].ny_points_.device
+                ny = model[i].ny_points_.to(comm, torch.float32).contiguous()
+                alpha = model[i].alpha_.to(comm, torch.float64).contiguous()
+            else:
+                where = _device() if self.incore else 'cpu'
+                ny = torch.empty((M, D), dtype=torch.float32, device=comm)
+                alpha = torch.empty((M, 1), dtype=torch.float64, device=comm)
+            dist.broadcast(ny, src=owner)
+            dist.broadcast(alpha, src=owner)
+            if owner != rank:
+                if not hasattr(self.classifier, 'model_from_tensors'):
+                    raise RuntimeError("opts['class_shard'] needs a classifier with model_from_tensors (odx FALKONWrapper)")
+                model[i] = self.classifier.model_from_tensors(ny.to(where), alpha.to(where), sigma=self.sigma, lam=self.lam)
+        return model
+
     def trainWithMinibootstrap(self, negatives, positives, output_dir=None):
         caches, model = [], []
         t_start = time.time()
+        # per-class RNG streams (opts['class_rng'], implied by opts['class_shard']): class c draws its Nystroem centres
+        # from its own generator seeded from ONE draw of the global stream, so a class's model does not depend on which
+        # other classes this process trains; default: the reference's class-major use of the global stream
+        rng = None
+        if self.class_rng or self._ranks()[1] > 1:
+            seed0 = self._class_seed()
+            rng = {i: torch.Generator().manual_seed(seed0 + i).get_state() for i in range(self.num_classes - 1)}
         for i in range(self.num_classes - 1):
-            if len(positives[i]) == 0 or len(negatives[i]) == 0:
+            if len(positives[i]) == 0 or len(negatives[i]) == 0 or not self._owned(i):
                 model.append(None)
                 caches.append({})
                 continue
@@ -125,7 +197,13 @@ class OnlineRegionClassifierBase:
                     print('Chosen {} hard negatives from the {}th batch'.format(len(hard_idx), j))
                 print('Traning with {} positives and {} negatives'.format(len(caches[i]['pos']), len(caches[i]['neg'])))
                 t_update = time.time()
-                model[i] = self.updateModel(caches[i])
+                if rng is None:
+                    model[i] = self.updateModel(caches[i])
+                else:
+                    with torch.random.fork_rng(devices=[]):
+                        torch.set_rng_state(rng[i])
+                        model[i] = self.updateModel(caches[i])
+                        rng[i] = torch.get_rng_state()
                 print('Model updated in {} seconds'.format(time.time() - t_update))
                 t_easy = time.time()
                 if len(caches[i]['neg']) != 0 and not (self.incore and last):
@@ -175,8 +253,8 @@ class OnlineRegionClassifierBase:
         streams = [torch.cuda.Stream() for _ in range(k)]
         for s in streams:
             s.wait_stream(main)
-        seed0 = int(torch.randint(2 ** 62, (1,)).item())
-        active = [i for i in range(C) if len(positives[i]) != 0 and len(negatives[i]) != 0]
+        seed0 = self._class_seed()
+        active = [i for i in range(C) if len(positives[i]) != 0 and len(negatives[i]) != 0 and self._owned(i)]
         rng = {i: torch.Generator().manual_seed(seed0 + i).get_state() for i in active}
         caches, model = [{} for _ in range(C)], [None] * C
         t_start = time.time()
@@ -248,8 +326,8 @@ class OnlineRegionClassifierBase:
         k = max(1, int(self.class_batch))
         main = torch.cuda.current_stream()
         streams = [torch.cuda.Stream() for _ in range(k)]
-        seed0 = int(torch.randint(2 ** 62, (1,)).item())
-        active = [i for i in range(C) if len(positives[i]) != 0 and len(negatives[i]) != 0]
+        seed0 = self._class_seed()
+        active = [i for i in range(C) if len(positives[i]) != 0 and len(negatives[i]) != 0 and self._owned(i)]
         rng = {i: torch.Generator().manual_seed(seed0 + i).get_state() for i in active}
         caches, model = [{} for _ in range(C)], [None] * C
         t_start = time.time()
@@ -376,6 +454,7 @@ class OnlineRegionClassifierBase:
             model = self.trainWithMinibootstrapStreams(negatives, positives, output_dir=output_dir)
         else:
             model = self.trainWithMinibootstrap(negatives, positives, output_dir=output_dir)
+        model = self._gather_models(model)
         if self.incore and self.return_caches:
             return model, self.caches
         return model

@@ -117,6 +117,18 @@ class FALKONWrapperBase:
         self.model = models[-1] if models else None
         return models       # fresh objects per call: nothing of the wrapper aliases them, so no deep copy is needed
 
+    def model_from_tensors(self, ny_points, alpha, sigma=None, lam=None):
+        """An estimator as `train` returns it, around centres and coefficients that were trained elsewhere (another rank
+        of a class-sharded Minibootstrap, a model file): same class, kernel, penalty and M = number of centres."""
+        sigma = self.sigma if sigma is None else sigma
+        lam = self.lam if lam is None else lam
+        cls = self.estimator_incore if self.incore else self.estimator_cpu
+        kw = {"maxiter": self.maxiter} if self.incore else {}
+        m = cls(kernel=self.kernel_cls(sigma=sigma), penalty=lam, M=int(ny_points.shape[0]), center_selection=None,
+                options=self.options_cls(keops_active="no"), **kw)
+        m.ny_points_, m.alpha_ = ny_points, alpha.reshape(-1, 1)
+        return m
+
     def predict(self, model, X_np, y=None):
         if y is not None:
             return model.predict(X_np, y)

@@ -153,3 +153,82 @@ def test_lockstep_fit_equals_one_at_a_time(world, B):
         ref, _ = fr.falkon_fit(X.astype(np.float64), yb, idx, 5.0, 1e-4, maxiter=20, dtype=np.float64, pc_eps=1e-5, cg_epsilon=1e-7)
         a = ret["alphas"][b]
         assert np.linalg.norm(a - ref[:, 0]) / np.linalg.norm(ref[:, 0]) < 1e-6
+
+
+# ------------------------------------------------------------------ classes over ranks (Minibootstrap regime)
+def _minibootstrap_problem(path):
+    """4 classes (one without positives), 3 negative batches each, through the drop-in classes and the odx FALKONWrapper."""
+    import yaml
+    C, D = 4, 16
+    cfg = {"NUM_CLASSES": C + 1, "CHOSEN_CLASSES": {i: ("bg" if i == 0 else "obj%d" % i) for i in range(C + 1)},
+           "ONLINE_REGION_CLASSIFIER": {"MINIBOOTSTRAP": {"EASY_THRESH": -0.9, "HARD_THRESH": -0.7},
+                                        "CLASSIFIER": {"lambda": 0.001, "sigma": 6.0, "M": 24, "kernel_type": "gauss"}}}
+    with open(path, "w") as fid:
+        yaml.safe_dump(cfg, fid)
+    g = torch.Generator().manual_seed(11)
+    mu = torch.randn((C, D), generator=g) * 2
+    pos = [mu[c] + 0.6 * torch.randn((40, D), generator=g) if c != 2 else torch.empty((0, D)) for c in range(C)]
+    neg = [[mu[(c + 1 + j) % C] * 0.6 + 0.9 * torch.randn((60, D), generator=g) for j in range(3)] for c in range(C)]
+    return C, pos, neg
+
+
+def _train_minibootstrap(path, pos, neg, opts):
+    import io
+    from contextlib import redirect_stdout
+    from tests import dropin
+    W, ORC = dropin.load("FALKONWrapper_with_centers_selection_incore"), dropin.load("OnlineRegionClassifier_incore")
+    torch.manual_seed(3)
+    with redirect_stdout(io.StringIO()):
+        orc = ORC.OnlineRegionClassifier(W.FALKONWrapper(cfg_path=path), [p.clone() for p in pos], [[b.clone() for b in bs] for bs in neg],
+                                         None, cfg_path=path)
+        return orc.trainRegionClassifier(opts=dict(opts, normalized=True))
+
+
+def _class_shard_worker(rank, world, port, path, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import odx
+        from tests.oracle_backend import OracleBackend
+        odx.set_backend(OracleBackend(np.float64))
+        C, pos, neg = _minibootstrap_problem(path + ".%d" % rank)
+        fits = []
+        be = odx.get_backend()
+        orig = be.precond
+        be.precond = lambda *a, **k: (fits.append(1), orig(*a, **k))[1]
+        models = _train_minibootstrap(path + ".%d" % rank, pos, neg, {"class_shard": True})
+        be.precond = orig
+        ret[rank] = ([None if m is None else (m.ny_points_.numpy(), m.alpha_.numpy(), m.M, m.kernel.sigma) for m in models], len(fits))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_class_sharded_minibootstrap_equals_single_process(world, tmp_path):
+    """opts['class_shard']: every rank trains the classes i % world == rank and ends with ALL models, bit for bit those of
+    one process that gives each class its own RNG stream (opts['class_rng']); no rank trains another rank's classes."""
+    import odx
+    from tests.oracle_backend import OracleBackend
+    path = str(tmp_path / "cfg.yaml")
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_class_shard_worker, args=(world, port, path, ret), nprocs=world, join=True)
+    odx.set_backend(OracleBackend(np.float64))
+    try:
+        C, pos, neg = _minibootstrap_problem(path)
+        ref = _train_minibootstrap(path, pos, neg, {"class_rng": True})
+        plain = _train_minibootstrap(path, pos, neg, {})
+    finally:
+        odx.set_backend(None)
+    assert ref[2] is None and all(ref[c] is not None for c in (0, 1, 3))
+    assert not all(torch.equal(ref[c].alpha_, plain[c].alpha_) for c in (0, 1, 3))      # the per-class streams are a different draw order
+    for rank in range(world):
+        models, nfits = ret[rank]
+        assert nfits == 3 * sum(1 for c in (0, 1, 3) if c % world == rank)              # 3 batches per owned class, nothing else
+        for c in range(C):
+            if ref[c] is None:
+                assert models[c] is None
+                continue
+            ny, alpha, M, sigma = models[c]
+            assert np.array_equal(ny, ref[c].ny_points_.numpy()) and np.array_equal(alpha, ref[c].alpha_.numpy())
+            assert M == ref[c].M and sigma == 6.0

@@ -3,6 +3,7 @@ the reference's own code and (b) the same host logic driven by the f64 oracle.""
 import io
 import json
 import os
+import sys
 from contextlib import redirect_stdout
 
 import numpy as np
@@ -437,12 +438,23 @@ def test_minibootstrap_on_class_streams_does_not_depend_on_the_stream_count(tmp_
     orc_mod = dropin.load("OnlineRegionClassifier_incore")
     wrap_mod = dropin.load("FALKONWrapper_with_centers_selection_incore")
     out = {}
-    for k in (1, 3, 0):
+    for k in (1, 3, 0, "seq_rng", "batch"):
         pos, neg = data()
         torch.manual_seed(5)
         orc = orc_mod.OnlineRegionClassifier(wrap_mod.FALKONWrapper(cfg_path=path), pos, neg, stats, cfg_path=path)
-        out[k] = quiet(orc.trainRegionClassifier, opts={"class_streams": k, "return_caches": True} if k else None)
+        opts = ({"class_rng": True, "return_caches": True} if k == "seq_rng" else {"class_batch": 2, "return_caches": True} if k == "batch"
+                else {"class_streams": k, "return_caches": True} if k else None)
+        out[k] = quiet(orc.trainRegionClassifier, opts=opts)
     (m1, c1), (m3, c3), ms = out[1], out[3], out[0]
+    # the reference-order sequential loop with one RNG stream per class (opts['class_rng']) and the class-batch mode draw
+    # what the streams mode draws: same models and caches, bit for bit, with the REAL index rule
+    for other in ("seq_rng", "batch"):
+        mo, co = out[other]
+        for c in range(C):
+            assert (m1[c] is None) == (mo[c] is None)
+            if m1[c] is not None:
+                assert torch.equal(m1[c].alpha_, mo[c].alpha_) and torch.equal(m1[c].ny_points_, mo[c].ny_points_), (other, c)
+                assert torch.equal(c1[c]["neg"], co[c]["neg"]), (other, c)
     assert [m is None for m in m1] == [False, True, False, False] == [m is None for m in m3] == [m is None for m in ms]
     for c, (a, b, s) in enumerate(zip(m1, m3, ms)):
         if a is None:
@@ -458,3 +470,29 @@ def test_minibootstrap_on_class_streams_does_not_depend_on_the_stream_count(tmp_
     for ca, cb in zip(c1, c3):
         if ca:
             assert torch.equal(ca["neg"], cb["neg"]) and torch.equal(ca["pos"], cb["pos"])
+
+
+def test_class_sharded_minibootstrap_on_gpu(tmp_path):
+    """opts['class_shard'] on the HIP backend: two ranks (one process each, sharing this box's GPU, gloo for the final
+    model exchange) train the classes i % 2 == rank in the class-batch mode and both end with ALL models — bit for bit the
+    models of one process in the same mode (per-class RNG streams; batched factors do not depend on the batch's members)."""
+    import subprocess
+    import socket
+    from tests import dist_minibootstrap_worker as w
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "tests", "dist_minibootstrap_worker.py"), str(tmp_path)],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    ref = w.train(str(tmp_path / "cfg_ref.yaml"), {"class_batch": 2})
+    assert [m is None for m in ref] == [False, True, False, False, False]
+    for rank in range(2):
+        got = torch.load(str(tmp_path / ("models_%d.pt" % rank)), weights_only=False)
+        for c, (a, b) in enumerate(zip(ref, got)):
+            assert (a is None) == (b is None), (rank, c)
+            if a is not None:
+                assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (rank, c)
