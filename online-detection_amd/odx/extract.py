@@ -194,15 +194,22 @@ class _FoldedBN(nn.Module):
         self._folded.clear()
         return super()._apply(fn, *a, **kw)
 
-    def conv_bn(self, name_conv, name_bn, x):
-        wb = self._folded.get(name_conv)
-        conv = getattr(self, name_conv) if isinstance(name_conv, str) else name_conv
+    def _fold(self, key, conv, bn, x):
+        """(weight, bias) of conv followed by the frozen batch norm, in the dtype the convolution will run in: under
+        autocast the folded tensors are kept in the autocast dtype too — autocast's own cast of an f32 weight is redone
+        on every call (53 weight tensors per image; the bf16 trunk was slower than the f32 one for it)."""
+        dt = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled("cuda")) else conv.weight.dtype
+        wb = self._folded.get((key, dt))
         if wb is None:
-            bn = getattr(self, name_bn) if isinstance(name_bn, str) else name_bn
             with torch.no_grad():
                 scale = bn.weight * bn.running_var.rsqrt()
-                wb = ((conv.weight * scale.view(-1, 1, 1, 1)).contiguous(), (bn.bias - bn.running_mean * scale).contiguous())
-            self._folded[name_conv] = wb
+                wb = ((conv.weight * scale.view(-1, 1, 1, 1)).to(dt).contiguous(), (bn.bias - bn.running_mean * scale).to(dt).contiguous())
+            self._folded[(key, dt)] = wb
+        return wb
+
+    def conv_bn(self, name_conv, name_bn, x):
+        conv, bn = getattr(self, name_conv), getattr(self, name_bn)
+        wb = self._fold(name_conv, conv, bn, x)
         return F.conv2d(x, wb[0], wb[1], conv.stride, conv.padding)
 
 
@@ -220,13 +227,7 @@ class Bottleneck(_FoldedBN):
         if self.down is None:
             idn = x
         else:
-            wb = self._folded.get("down")
-            if wb is None:
-                conv, bn = self.down[0], self.down[1]
-                with torch.no_grad():
-                    scale = bn.weight * bn.running_var.rsqrt()
-                    wb = ((conv.weight * scale.view(-1, 1, 1, 1)).contiguous(), (bn.bias - bn.running_mean * scale).contiguous())
-                self._folded["down"] = wb
+            wb = self._fold("down", self.down[0], self.down[1], x)
             idn = F.conv2d(x, wb[0], wb[1], self.down[0].stride, self.down[0].padding)
         y = F.relu(self.conv_bn("conv1", "bn1", x))
         y = F.relu(self.conv_bn("conv2", "bn2", y))

@@ -40,12 +40,17 @@ def main():
     ap.add_argument("--rois", type=int, default=300)
     ap.add_argument("--height", type=int, default=600)
     ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--graph", action="store_true", help="also time the trunk replayed from a captured HIP graph")
+    ap.add_argument("--channels-last", action="store_true", help="model and image in NHWC memory format")
     args = ap.parse_args()
     be = odx.get_backend()
     dev = torch.device("cuda")
     model = OnlineDetectionModel(post_nms_top_n=args.rois).to(dev).eval()
     g = torch.Generator(device="cuda").manual_seed(1)
     img = torch.randn((1, 3, args.height, args.width), device=dev, generator=g)
+    if args.channels_last:
+        model = model.to(memory_format=torch.channels_last)
+        img = img.contiguous(memory_format=torch.channels_last)
 
     for name, ctx in (("f32", torch.autocast("cuda", enabled=False)), ("bf16 autocast", torch.autocast("cuda", dtype=torch.bfloat16))):
         with torch.no_grad(), ctx:
@@ -60,6 +65,21 @@ def main():
             crops = be.roi_align(c4f, rois, 1.0 / 16, (14, 14), 0)
             t_head = timeit(lambda: model.head(crops).mean(dim=(2, 3)))
             t_all = timeit(lambda: model(img))
+            if args.graph:
+                static = img.clone()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        model.backbone(static)
+                torch.cuda.current_stream().wait_stream(side)
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    out_static = model.backbone(static)
+                ref = model.backbone(img)
+                gr.replay()
+                torch.cuda.synchronize()
+                print("  trunk as a captured graph: %.2f ms (max abs diff vs eager %.3g)" % (timeit(lambda: gr.replay()), float((out_static.float() - ref.float()).abs().max())))
         C = c4.shape[1]
         out_bytes = R * C * 14 * 14 * 4
         print("[%s] %dx%d image, %d RoIs: trunk %.2f ms | RPN head + proposals (top-k, HIP NMS) %.2f ms | RoIAlign %.3f ms "
