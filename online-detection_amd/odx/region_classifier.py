@@ -65,8 +65,12 @@ class OnlineRegionClassifierBase:
         self.return_caches = False
         self.class_streams = 0          # > 0: classes trained concurrently on that many streams (opts['class_streams'])
         self.class_batch = 0            # > 0: the classes of a round fitted by one batched call, on that many streams (opts['class_batch'])
+        # the experiment drivers call trainRegionClassifier() without options: ODX_CLASS_BATCH / ODX_CLASS_STREAMS /
+        # ODX_CLASS_SHARD in the environment select the same opt-ins without touching a driver (opts still win)
+        self.class_batch = int(os.environ.get("ODX_CLASS_BATCH", "0") or 0)
+        self.class_streams = int(os.environ.get("ODX_CLASS_STREAMS", "0") or 0)
         self.class_rng = False          # one RNG stream per class for the Nystroem draws (opts['class_rng']; implied by the three modes above/below)
-        self.class_shard = False        # classes round-robin over the ranks of torch.distributed, models gathered at the end (opts['class_shard'])
+        self.class_shard = os.environ.get("ODX_CLASS_SHARD", "0") not in ("", "0")   # classes round-robin over the ranks of torch.distributed, models gathered at the end (opts['class_shard'])
 
     def loadRegionClassifier(self) -> None:
         pass
