@@ -194,9 +194,23 @@ extern "C" int odx_rls_predict_rows_f64(const float* X, int64_t ldx, int D, cons
 //   odx_rls_solve_batched_f64  + lam I, Cholesky, triangular inverses and the eight triangular products for all classes
 // with the arithmetic of odx_rls_gram_f64 / odx_rls_solve_f64 per class.  The split in two calls leaves room for the
 // all-reduce of the Grams when rows are sharded.
+// workspace: Xt ((D + 1) x ldt) | Y5 (5 x ldt: the four target rows and the ones row) | O5 (32 classes x 5 x ldo)
 extern "C" int64_t odx_rls_gram_batched_workspace_bytes(int64_t npad, int D) {
   if (npad <= 0 || D <= 0) return 0;
-  return round_up(npad, 16) * (int64_t)(D + 1) * (int64_t)sizeof(double);
+  const int64_t ldt = round_up(npad, 16), ldo = round_up((int64_t)D + 1, 2);
+  return (ldt * (int64_t)(D + 1) + 5 * ldt + (int64_t)ODX_MAX_ZBATCH * 5 * ldo) * (int64_t)sizeof(double);
+}
+
+// XtY[c] (4 x D1) += O5[c] rows 0..3;  G[c] row D (the bias row of the lower triangle) += O5[c] row 4
+__global__ __launch_bounds__(256) void rls_fold_bias_kernel(const double* __restrict__ O5, int64_t ldo, int D1, double* __restrict__ XtY,
+                                                            int64_t ldxy, int64_t xy_stride, double* __restrict__ G, int64_t ldg,
+                                                            int64_t g_stride) {
+  const int c = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= D1) return;
+  const double* o = O5 + (int64_t)c * 5 * ldo;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) XtY[(int64_t)c * xy_stride + r * ldxy + j] += o[r * ldo + j];
+  G[(int64_t)c * g_stride + (int64_t)(D1 - 1) * ldg + j] += o[4 * ldo + j];
 }
 
 extern "C" int odx_rls_gram_batched_f64(const float* X, int64_t ldx, int D, const int64_t* idx_pad, int64_t npad,
@@ -219,14 +233,23 @@ extern "C" int odx_rls_gram_batched_f64(const float* X, int64_t ldx, int D, cons
   dim3 grid((unsigned)ceil_div(ldt, 32), (unsigned)ceil_div(D1, 32));
   hipLaunchKernelGGL(rls_gather_transpose_all_kernel, grid, dim3(256), 0, s, X, ldx, D, idx_pad, npad, Xt, ldt);
   ODX_CHECK_LAUNCH("rls_gather_transpose_all");
+  // The bias column makes the Gram (D + 1) x (D + 1): at D = 1024 a ninth tile row holding ONE row, a fifth of the
+  // workgroups of the lower triangle.  The D x D part is one GEMM over whole tile rows; the bias row [X 1]' 1 rides along
+  // with the four target rows (a 5 x (D + 1) product, one tile row either way) and is folded into G afterwards.
+  double* Y5 = Xt + ldt * D1;
+  double* O5 = Y5 + 5 * ldt;
+  const int64_t ldo = round_up(D1, 2);
+  ODX_CHECK_HIP(hipMemcpy2DAsync(Y5, (size_t)ldt * sizeof(double), Yt, (size_t)ldy * sizeof(double), (size_t)ldt * sizeof(double), 4,
+                                 hipMemcpyDeviceToDevice, s));
+  ODX_CHECK_HIP(hipMemcpyAsync(Y5 + 4 * ldt, Xt + (int64_t)D * ldt, (size_t)ldt * sizeof(double), hipMemcpyDeviceToDevice, s));
   GemmParams<double> g;
   g.A = Xt; g.lda = ldt; g.B = Xt; g.ldb = ldt; g.C = G; g.ldc = ldg;
-  g.m = D1; g.n = D1; g.k = 0; g.alpha = 1.0; g.beta = 1.0; g.flags = ODX_GEMM_LOWER_ONLY;
+  g.m = D; g.n = D; g.k = 0; g.alpha = 1.0; g.beta = 1.0; g.flags = ODX_GEMM_LOWER_ONLY;
   g.zbatches = C; g.zstrideC = g_stride; g.zk_on = 1;
   GemmParams<double> h;
-  h.A = Yt; h.lda = ldy; h.B = Xt; h.ldb = ldt; h.C = XtY; h.ldc = ldxy;
-  h.m = 4; h.n = D1; h.k = 0; h.alpha = 1.0; h.beta = 1.0;
-  h.zbatches = C; h.zstrideC = xy_stride; h.zk_on = 1;
+  h.A = Y5; h.lda = ldt; h.B = Xt; h.ldb = ldt; h.C = O5; h.ldc = ldo;
+  h.m = 5; h.n = D1; h.k = 0; h.alpha = 1.0; h.beta = 0.0;
+  h.zbatches = C; h.zstrideC = 5 * ldo; h.zk_on = 1;
   for (int c = 0; c < C; ++c) {
     ODX_REQUIRE(seg_off[c] % 16 == 0 && seg_len[c] >= 0 && seg_off[c] + seg_len[c] <= npad,
                 "odx_rls_gram_batched_f64: class %d: segment must start at a multiple of 16 inside the padded index array", c);
@@ -234,7 +257,11 @@ extern "C" int odx_rls_gram_batched_f64(const float* X, int64_t ldx, int D, cons
     g.zklen[c] = h.zklen[c] = seg_len[c];
   }
   ODX_PROPAGATE(launch_gemm_f64(g, s));
-  return launch_gemm_f64(h, s);
+  ODX_PROPAGATE(launch_gemm_f64(h, s));
+  hipLaunchKernelGGL(rls_fold_bias_kernel, dim3((unsigned)ceil_div(D1, 256), (unsigned)C), dim3(256), 0, s, O5, ldo, (int)D1, XtY, ldxy,
+                     xy_stride, G, ldg, g_stride);
+  ODX_CHECK_LAUNCH("rls_fold_bias");
+  return ODX_OK;
 }
 
 // workspace per class: Dinv | WT (D1*D1) | Li (D1 x ld) | Lit (D1 x ld) | z (4 x ld)

@@ -438,9 +438,11 @@ class HipBackend:
                                                      _p(info), _p(ws), ws.numel(), self._stream()), "odx_rls_solve_batched_f64")
         return W, info
 
-    def rls_predict_rows(self, F, idx, W):
+    def rls_predict_rows(self, F, idx, W, out=None):
         nc = F.n if idx is None else idx.numel()
-        Pm = torch.empty((nc, 4), dtype=torch.float64, device=self.device)
+        Pm = torch.empty((nc, 4), dtype=torch.float64, device=self.device) if out is None else out
+        if tuple(Pm.shape) != (nc, 4) or Pm.dtype != torch.float64 or not Pm.is_contiguous():
+            raise ValueError("rls_predict_rows: out must be a contiguous (%d, 4) f64 tensor" % nc)
         if nc:
             hip.check(self.lib.odx_rls_predict_rows_f64(_p(F.X), F.ld, F.D, _p(idx), nc, _p(W), W.stride(0), _p(Pm), 4,
                                                         self._stream()), "odx_rls_predict_rows_f64")

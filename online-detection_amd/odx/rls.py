@@ -97,14 +97,36 @@ class RegionRefinerTrainer:
             npad = at
             idx_pad = torch.full((max(npad, 1),), -1, dtype=torch.int64, device=xdev)[:npad]
             Yt = torch.zeros((4, max(npad, 16)), dtype=torch.float64, device=xdev)
-            # target statistics per class from its (contiguous) segment; the 4 x 4 eigen-decompositions of the whole group
-            # in one batched call (a 4 x 4 eigh on the GPU costs a solver launch + synchronisation: ~1 ms per class otherwise)
-            mus, Ycs, Ss = [], [], []
-            for c in group:
-                I = order[first[c]:first[c] + n_loc[c]]
-                rows_of[c] = I
-                Yi = Yall[I].type(torch.float64)
-                if self.shard is not None and self.shard.enabled:
+            sharded = self.shard is not None and self.shard.enabled
+            if not sharded:
+                # target statistics, whitening and the padded (index, target) arrays of the whole group in ~20 launches:
+                # the rows of the group's classes are one contiguous run of `order`; they are laid out as a zero-padded
+                # (class, row, 4) block, so that means, second moments and the whitening products are batched reductions /
+                # matrix products (per class the same sums over the same rows as the class-by-class loop, in a different
+                # order of additions: results agree to rounding)
+                G_ = len(group)
+                lens = torch.tensor(seg_len, dtype=torch.int64)
+                nmax = max(seg_len)
+                lo = first[group[0]]
+                run = order[lo:lo + sum(seg_len)] if all(first[group[k + 1]] == first[group[k]] + seg_len[k] for k in range(G_ - 1)) \
+                    else torch.cat([order[first[c]:first[c] + n_loc[c]] for c in group])
+                total = int(sum(seg_len))
+                lens_d = lens.to(xdev)
+                gid = torch.repeat_interleave(torch.arange(G_, device=xdev), lens_d, output_size=total)      # class slot of every row
+                starts = torch.tensor(np.concatenate(([0], np.cumsum(seg_len)[:-1])), dtype=torch.int64).to(xdev)
+                pos = torch.arange(total, device=xdev) - starts[gid]                                         # row's rank inside its class
+                Ypad = torch.zeros((G_, nmax, 4), dtype=torch.float64, device=xdev)
+                Ypad[gid, pos] = Yall[run].type(torch.float64)
+                cnt = lens_d.type(torch.float64).clamp(min=1).view(G_, 1)
+                mu_all = Ypad.sum(1) / cnt
+                live_rows = (torch.arange(nmax, device=xdev).view(1, nmax) < lens_d.view(G_, 1)).unsqueeze(2)
+                Yc_all = (Ypad - mu_all.unsqueeze(1)) * live_rows
+                S_all = torch.bmm(Yc_all.transpose(1, 2), Yc_all) / cnt.view(G_, 1, 1)
+            else:
+                mus, Ycs, Ss = [], [], []
+                for c in group:
+                    I = order[first[c]:first[c] + n_loc[c]]
+                    Yi = Yall[I].type(torch.float64)
                     s1 = Yi.sum(0)
                     self.shard.allreduce(s1)
                     mu = s1 / n_tot[c]
@@ -112,23 +134,31 @@ class RegionRefinerTrainer:
                     S = torch.matmul(Yc.t(), Yc)
                     self.shard.allreduce(S)
                     S = S / n_tot[c]
-                else:
-                    mu = torch.mean(Yi, dim=0)
-                    Yc = Yi - mu
-                    S = torch.matmul(Yc.t(), Yc) / Yc.size()[0]
-                mus.append(mu), Ycs.append(Yc), Ss.append(S)
+                    mus.append(mu), Ycs.append(Yc), Ss.append(S)
+                S_all = torch.stack(Ss)
             # (on the host: 4 x 4 matrices — the GPU solver costs ~8 ms for the batch, mostly launch + synchronisation)
-            S_all = torch.stack(Ss)
             evals, Wv = torch.linalg.eigh(S_all.cpu())
             evals, Wv = evals.to(S_all.device), Wv.to(S_all.device)
             root = torch.sqrt(evals + 0.001)
             Ts = Wv @ torch.diag_embed(1.0 / root) @ Wv.transpose(1, 2)
             Tis = Wv @ torch.diag_embed(root) @ Wv.transpose(1, 2)
-            for k, (c, off) in enumerate(zip(group, seg_off)):
-                Yw = torch.matmul(Ycs[k], Ts[k])
-                whit[c], Yw_of[c] = (mus[k], Ts[k], Tis[k]), Yw
-                idx_pad[off:off + n_loc[c]] = rows_of[c]
-                Yt[:, off:off + n_loc[c]] = Yw.t()
+            if not sharded:
+                Yw_all = torch.bmm(Yc_all, Ts)[gid, pos]                                   # (rows of the group, 4), class-sorted
+                dest = torch.tensor(seg_off, dtype=torch.int64).to(xdev)[gid] + pos
+                idx_pad[dest] = run
+                Yt[:, dest] = Yw_all.t()
+                a = 0
+                for k, c in enumerate(group):
+                    rows_of[c] = run[a:a + n_loc[c]]
+                    whit[c], Yw_of[c] = (mu_all[k], Ts[k], Tis[k]), Yw_all[a:a + n_loc[c]]
+                    a += n_loc[c]
+            else:
+                for k, (c, off) in enumerate(zip(group, seg_off)):
+                    rows_of[c] = order[first[c]:first[c] + n_loc[c]]
+                    Yw = torch.matmul(Ycs[k], Ts[k])
+                    whit[c], Yw_of[c] = (mus[k], Ts[k], Tis[k]), Yw
+                    idx_pad[off:off + n_loc[c]] = rows_of[c]
+                    Yt[:, off:off + n_loc[c]] = Yw.t()
             W, info = be.rls_train_batched(F, idx_pad, seg_off, seg_len, Yt, self.lambd,
                                            allreduce=self.shard.allreduce if self.shard is not None else None)
             bad = info.tolist()
@@ -136,14 +166,24 @@ class RegionRefinerTrainer:
                 if bad[k] != 0:
                     raise RuntimeError('RLS Cholesky failed for class %s (pivot %d)' % (chosen_classes[c], bad[k] - 1))
                 Wall[c] = W[k]
+        # the training losses of all classes: one prediction launch per class into ONE (rows, 4) array, the elementwise
+        # part once over all of it (per class it was ~15 short launches: 5 ms of a 30-ms call); every class keeps its own
+        # contiguous copies, as the class-by-class loop hands them out (a saved model must not drag the whole array along)
         entries, means = {}, []
+        at, span = 0, {}
         for i in live:
-            mu, T, T_inv = whit[i]
-            P = be.rls_predict_rows(F, rows_of[i].contiguous(), Wall[i])
-            losses = (0.5 * (P - Yw_of[i]) ** 2).type(torch.float32)
-            Beta = {str(k): {'weights': Wall[i][k, :D1].to(dev).type(torch.float32), 'losses': losses[:, k]} for k in range(4)}
-            entries[i] = {'mu': mu.to(dev).type(torch.float32), 'T': T.to(dev).type(torch.float32),
-                          'T_inv': T_inv.to(dev).type(torch.float32), 'Beta': Beta}
+            span[i] = (at, at + n_loc[i])
+            at += n_loc[i]
+        P_all = torch.empty((at, 4), dtype=torch.float64, device=xdev)
+        for i in live:
+            be.rls_predict_rows(F, rows_of[i].contiguous(), Wall[i], out=P_all[span[i][0]:span[i][1]])
+        losses_all = (0.5 * (P_all - torch.cat([Yw_of[i] for i in live])) ** 2).type(torch.float32) if live else None
+        W32 = torch.stack([Wall[i][:, :D1] for i in live]).to(dev).type(torch.float32) if live else None
+        stats32 = torch.stack([torch.cat((whit[i][0].reshape(1, 4), whit[i][1], whit[i][2])) for i in live]).to(dev).type(torch.float32) if live else None
+        for j, i in enumerate(live):
+            losses = losses_all[span[i][0]:span[i][1]].clone()
+            Beta = {str(k): {'weights': W32[j, k].clone(), 'losses': losses[:, k]} for k in range(4)}
+            entries[i] = {'mu': stats32[j, 0].clone(), 'T': stats32[j, 1:5].clone(), 'T_inv': stats32[j, 5:9].clone(), 'Beta': Beta}
             means.append(losses.mean(0) if n_loc[i] else torch.full((4,), float('nan'), device=losses.device))
         mean_host = dict(zip(live, torch.stack(means).tolist())) if live else {}      # one host read for the printed lines
         out = np.empty((0))
