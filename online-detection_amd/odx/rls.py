@@ -263,6 +263,53 @@ class RegionRefinerTrainer:
         self._report_time(time.time() - start_time, num_clss, output_dir)
         return models
 
+    def solve(self, X, y, lmbd, X_test=None, Y_test=None, indices=None):
+        """The reference's per-class solver as a method of its own (train_region_refiner.py:100-119): X (n, D + 1) with
+        the bias column last, y (n, 4) whitened targets; per coordinate k the ridge solution of (X'X + lmbd I) w = X'y_k
+        (over the rows indices[k] when given) and the losses 0.5 (X w - y_k)^2.  Runs on the same kernels as `train`
+        (Gram, Cholesky, triangular inverses, predictions) when X is f32 features with a column of ones appended —
+        what `train` builds; any other matrix goes through a dense f64 solve."""
+        be = _backend.get_backend()
+        dev = _device()
+        X, y = torch.as_tensor(X), torch.as_tensor(y)
+        n, D1 = X.shape
+        feats = X[:, :-1]
+        native = (hasattr(be, "rls_gram") and D1 >= 2 and bool((X[:, -1] == 1).all())
+                  and bool((feats.to(torch.float32).to(X.dtype) == feats).all()))
+        out = {}
+        if native:
+            F = be.features(feats.to(torch.float32))
+            xdev = F.X.device
+            W_all = None
+            for k in range(4):
+                if indices is not None or W_all is None:
+                    I = (torch.arange(n, device=xdev) if indices is None else torch.as_tensor(indices[k]).to(xdev)).to(torch.int64)
+                    if I.dtype == torch.bool:
+                        I = I.nonzero().reshape(-1)
+                    nc = I.numel()
+                    Yt = torch.zeros((4, (nc + 15) // 16 * 16 + 16), dtype=torch.float64, device=xdev)
+                    Yt[:, :nc] = y.to(xdev, torch.float64)[I].t()
+                    ldg = (D1 + 1) // 2 * 2
+                    G = torch.zeros((D1, ldg), dtype=torch.float64, device=xdev)
+                    XtY = torch.zeros((4, ldg), dtype=torch.float64, device=xdev)
+                    be.rls_gram(F, I.contiguous(), Yt, G, XtY)
+                    W_all, info = be.rls_solve(G, D1 - 1, lmbd, XtY)
+                    if int(info.item()) != 0:
+                        raise RuntimeError('RLS Cholesky failed (pivot %d)' % (int(info.item()) - 1))
+                    P = be.rls_predict_rows(F, I.contiguous(), W_all)
+                    Ysub = y.to(xdev, torch.float64)[I]
+                out[str(k)] = {'weights': W_all[k, :D1].to(dev).type(torch.float32),
+                               'losses': (0.5 * (P[:, k] - Ysub[:, k]) ** 2).type(torch.float32)}
+            return out
+        X64, y64 = X.to(torch.float64), y.to(torch.float64)
+        for k in range(4):
+            Xs, ys = (X64, y64) if indices is None else (X64[indices[k]], y64[indices[k]])
+            R = torch.linalg.cholesky(Xs.t() @ Xs + lmbd * torch.eye(D1, device=Xs.device, dtype=torch.float64))
+            z = torch.linalg.solve_triangular(R, (Xs.t() @ ys[:, k]).view(D1, 1), upper=False)
+            w = torch.linalg.solve_triangular(R.t(), z, upper=True).view(D1)
+            out[str(k)] = {'weights': w.to(dev).type(torch.float32), 'losses': (0.5 * (Xs @ w - ys[:, k]) ** 2).type(torch.float32)}
+        return out
+
     def _whiten_sharded(self, Yi, n_tot):
         """Target statistics over all row shards: sum and second moment all-reduced (4 + 16 numbers)."""
         s1 = Yi.sum(0)

@@ -48,6 +48,46 @@ def computeFeatStatistics_torch(positives, negatives, num_samples=4000, features
             'mean_norm': torch.mean(norms).to(out_dev)}
 
 
+def computeFeatStatistics(positives, negatives, feature_folder, is_rpn, num_samples=4000, basedir=None):
+    """The older statistics helper (py_od_utils.py:8-56): the cached `stats` file of the feature folder if it loads, else
+    mean / std / mean-norm over rows drawn through the global NUMPY RNG (one `randint` per class with positives, one
+    `choice` per non-empty negative batch, in that order), seeded with the first row of the last class that has
+    positives, and saved to that file.  Returns the tuple (mean, std, mean_norm).  `basedir`: directory the relative
+    cache path starts from (default: the drop-in `src` directory, as the reference's starts from its own)."""
+    if basedir is None:
+        basedir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'src')
+    if not is_rpn:
+        stats_path = os.path.join(basedir, '..', 'Data', 'feat_cache', feature_folder, 'stats')
+    else:
+        stats_path = os.path.join(basedir, '..', 'Data', 'feat_cache_RPN', feature_folder, 'rpn_stats')
+    try:
+        l = torch.load(stats_path)
+        return torch.as_tensor(l['mean']), torch.as_tensor(l['std']), torch.as_tensor(l['mean_norm'])
+    except Exception:
+        pass
+    print('Computing features statistics')
+    num_classes = len(positives)
+    take_from_pos = math.ceil((num_samples / num_classes) * (1 / 10))
+    take_from_neg = math.ceil(((num_samples / num_classes) * (9 / 10)) / len(negatives[0]))
+    rows, norms = [], []
+    for i in range(num_classes):                       # the seed row: the LAST class with positives wins
+        if len(positives[i]) != 0:
+            first = positives[i][0].cpu().numpy()
+            rows, norms = [first[None, :]], [np.linalg.norm(first).reshape(1, 1)]
+    for i in range(num_classes):
+        if len(positives[i]) != 0:
+            picked = positives[i][np.random.randint(len(positives[i]), size=take_from_pos)].cpu().numpy()
+            rows.append(picked), norms.append(np.linalg.norm(picked, axis=1)[:, None])
+        for batch in negatives[i]:
+            if len(batch) != 0:
+                picked = batch[np.random.choice(len(batch), size=take_from_neg)].cpu().numpy()
+                rows.append(picked), norms.append(np.linalg.norm(picked, axis=1)[:, None])
+    sampled, ns = np.vstack(rows), np.vstack(norms)
+    mean, std, mean_norm = torch.tensor(np.mean(sampled, axis=0)), torch.tensor(np.std(sampled, axis=0)), torch.tensor(np.mean(ns))
+    torch.save({'mean': mean, 'std': std, 'mean_norm': mean_norm}, stats_path)
+    return mean, std, mean_norm
+
+
 def zScores(feat, mean, mean_norm, target_norm=20):
     """py_od_utils.py:98-102"""
     feat = torch.tensor(feat)

@@ -1148,12 +1148,53 @@ def make_masks():
     print("masks_golden.npz:", len(out), "arrays; pasted pixels", int(out["pasted"].sum()), "seg AP", out["seg_ap_voc07"])
 
 
+def make_featstats():
+    """computeFeatStatistics (py_od_utils.py:8-56), the numpy-RNG variant with the stats cache file: run from a scratch
+    copy of the module namespace whose __file__ points into a temporary directory, so the cache file is written there."""
+    import tempfile
+    utils = load_ref("src/py_od_utils.py", "ref_py_od_utils_stats")
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "Data", "feat_cache", "folder"))
+    os.makedirs(os.path.join(tmp, "Data", "feat_cache_RPN", "folder"))
+    utils.__dict__["__file__"] = os.path.join(tmp, "src", "py_od_utils.py")
+    os.makedirs(os.path.join(tmp, "src"))
+    out = {}
+    g = torch.Generator().manual_seed(31)
+    D, C = 12, 4
+    positives = [torch.randn(20 + 3 * c, D, generator=g) + c for c in range(C)]
+    positives[3] = torch.empty((0, D))
+    negatives = [[torch.randn(25, D, generator=g) - c for _ in range(3)] for c in range(C)]
+    negatives[1][2] = torch.empty((0, D))
+    for c in range(C):
+        out["pos_%d" % c] = positives[c].numpy()
+        for j in range(3):
+            out["neg_%d_%d" % (c, j)] = negatives[c][j].numpy()
+    for tag, is_rpn in (("det", False), ("rpn", True)):
+        np.random.seed(77)
+        with redirect_stdout(io.StringIO()):
+            mean, std, mean_norm = utils.computeFeatStatistics(positives, negatives, "folder", is_rpn, num_samples=120)
+        out[tag + "_mean"], out[tag + "_std"], out[tag + "_mean_norm"] = mean.numpy(), std.numpy(), mean_norm.numpy()
+        path = os.path.join(tmp, "Data", "feat_cache_RPN" if is_rpn else "feat_cache", "folder", "rpn_stats" if is_rpn else "stats")
+        saved = torch.load(path)
+        out[tag + "_saved_mean"] = saved["mean"].numpy()
+        # second call: the cache file answers, no draw is made
+        state = np.random.get_state()[1].copy()
+        with redirect_stdout(io.StringIO()):
+            m2, _, _ = utils.computeFeatStatistics(positives, negatives, "folder", is_rpn, num_samples=120)
+        assert np.array_equal(state, np.random.get_state()[1]) and np.array_equal(m2.numpy(), mean.numpy())
+    np.savez_compressed(os.path.join(OUT, "featstats_golden.npz"), **out)
+    print("featstats_golden.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     if "--only-masks" in sys.argv:
         make_masks()
         sys.exit(0)
     if "--only-feature-cache" in sys.argv:
         make_feature_cache()
+        sys.exit(0)
+    if "--only-featstats" in sys.argv:
+        make_featstats()
         sys.exit(0)
     if "--only-postprocess" in sys.argv:
         make_postprocess()
@@ -1183,3 +1224,4 @@ if __name__ == "__main__":
     make_eval()
     make_feature_cache()
     make_masks()
+    make_featstats()

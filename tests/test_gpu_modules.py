@@ -61,6 +61,17 @@ def test_region_refiner_on_gpu_matches_reference(tag, is_rpn, tmp_path):
         assert np.abs(W - R["%s_%d_W" % (tag, i)]).max() < 2e-6
         L = np.stack([m["Beta"][str(k)]["losses"].cpu().numpy() for k in range(4)])
         assert np.abs(L - R["%s_%d_losses" % (tag, i)]).max() < 1e-5
+    # RegionRefinerTrainer.solve on its own (train_region_refiner.py:100-119) on HIP tensors: the reference's inputs of one
+    # class (f64 rows + bias column, whitened targets) -> that class's golden weights and losses
+    from odx.rls import RegionRefinerTrainer, whiten_targets
+    tr = RegionRefinerTrainer({"CHOSEN_CLASSES": {}}, float(R["lambda"]), is_rpn)
+    i = next(k for k in range(len(models)) if not bool(R["%s_%d_none" % (tag, k)]))
+    rows = (C.reshape(-1) == (i if is_rpn else i + 1)).nonzero().reshape(-1)
+    Xi = torch.cat((torch.from_numpy(R["X"]).cuda()[rows].double(), torch.ones((len(rows), 1), dtype=torch.float64, device="cuda")), dim=1)
+    mu, Yc, T, _ = whiten_targets(torch.from_numpy(R["Y"]).cuda()[rows].double())
+    beta = tr.solve(Xi, Yc @ T, float(R["lambda"]))
+    assert np.abs(np.stack([beta[str(k)]["weights"].cpu().numpy() for k in range(4)]) - R["%s_%d_W" % (tag, i)]).max() < 2e-6
+    assert np.abs(np.stack([beta[str(k)]["losses"].cpu().numpy() for k in range(4)]) - R["%s_%d_losses" % (tag, i)]).max() < 1e-5
     if not is_rpn:
         from odx.boxlist import BoxList
         cfg3 = {"CHOSEN_CLASSES": {0: "_background_", 1: "a", 2: "b"}, "REGION_REFINER": {"opts": {"lambda": 10.0}}}

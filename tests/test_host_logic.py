@@ -261,6 +261,31 @@ def test_minibootstrap_return_caches_and_options():
 
 # ------------------------------------------------------------------ py_od_utils
 @pytest.mark.parametrize("device", DEVICES)
+def test_feat_statistics_with_cache_file_match_reference(device, tmp_path):
+    """computeFeatStatistics (the numpy-RNG variant with the `stats` cache file, py_od_utils.py:8-56) against the
+    reference's own run: same draws, same statistics, same file; the second call is answered by the file without a draw."""
+    H = np.load(os.path.join(GOLD, "featstats_golden.npz"))
+    from odx.utils import computeFeatStatistics
+    assert dropin.load("py_od_utils").computeFeatStatistics is computeFeatStatistics
+    C = 4
+    positives = [torch.from_numpy(H["pos_%d" % c]).to(device) for c in range(C)]
+    negatives = [[torch.from_numpy(H["neg_%d_%d" % (c, j)]).to(device) for j in range(3)] for c in range(C)]
+    base = str(tmp_path / "src")
+    os.makedirs(base)
+    for tag, is_rpn in (("det", False), ("rpn", True)):
+        os.makedirs(str(tmp_path / "Data" / ("feat_cache_RPN" if is_rpn else "feat_cache") / "folder"))
+        np.random.seed(77)
+        mean, std, mean_norm = quiet(computeFeatStatistics, positives, negatives, "folder", is_rpn, num_samples=120, basedir=base)
+        assert np.array_equal(mean.numpy(), H[tag + "_mean"]) and np.array_equal(std.numpy(), H[tag + "_std"])
+        assert np.array_equal(mean_norm.numpy(), H[tag + "_mean_norm"])
+        saved = torch.load(str(tmp_path / "Data" / ("feat_cache_RPN" if is_rpn else "feat_cache") / "folder" / ("rpn_stats" if is_rpn else "stats")))
+        assert np.array_equal(saved["mean"].numpy(), H[tag + "_saved_mean"])
+        state = np.random.get_state()[1].copy()
+        m2, _, _ = quiet(computeFeatStatistics, positives, negatives, "folder", is_rpn, num_samples=120, basedir=base)
+        assert np.array_equal(state, np.random.get_state()[1]) and torch.equal(m2, mean)
+
+
+@pytest.mark.parametrize("device", DEVICES)
 def test_py_od_utils_match_reference(device):
     """A10 against vectors from the reference's own py_od_utils / MyCenterSelector; the cuda arm keeps every tensor
     (feature lists, COXY, statistics) on the MI355X as the drivers do."""
@@ -357,6 +382,28 @@ def test_region_refiner_matches_reference(tag, is_rpn, tmp_path):
         assert np.abs(L - R["%s_%d_losses" % (tag, i)]).max() < 1e-5
     line = open(os.path.join(str(tmp_path), "result.txt")).read()
     assert line.startswith("RPN's Online Region Refiner training time" if is_rpn else "Detector's Online Region Refiner training time")
+    # RegionRefinerTrainer.solve on its own (train_region_refiner.py:100-119): fed what the reference's train feeds it
+    # (f64 rows with the bias column appended, whitened targets) it returns the golden weights / losses of that class
+    from odx.rls import RegionRefinerTrainer, whiten_targets
+    tr = RegionRefinerTrainer({"CHOSEN_CLASSES": cfg["RPN"]["CHOSEN_CLASSES"] if is_rpn else cfg["CHOSEN_CLASSES"]}, float(R["lambda"]), is_rpn)
+    i = next(k for k in range(len(models)) if not bool(R["%s_%d_none" % (tag, k)]))
+    rows = (C.reshape(-1) == (i if is_rpn else i + 1)).nonzero().reshape(-1)
+    Xi = torch.cat((torch.from_numpy(R["X"])[rows].double(), torch.ones((len(rows), 1), dtype=torch.float64)), dim=1)
+    mu, Yc, T, _ = whiten_targets(torch.from_numpy(R["Y"])[rows].double())
+    Yw = Yc @ T
+    beta = tr.solve(Xi, Yw, float(R["lambda"]))
+    assert np.abs(np.stack([beta[str(k)]["weights"].cpu().numpy() for k in range(4)]) - R["%s_%d_W" % (tag, i)]).max() < 2e-6
+    assert np.abs(np.stack([beta[str(k)]["losses"].cpu().numpy() for k in range(4)]) - R["%s_%d_losses" % (tag, i)]).max() < 1e-5
+    # per-coordinate row subsets (`indices`), and a matrix that is not "features + ones" (dense f64 route): against numpy
+    sub = [torch.arange(k, len(rows), 2) for k in range(4)]
+    lam = float(R["lambda"])
+    for Xm in (Xi, Xi * 1.000000123):
+        got = tr.solve(Xm, Yw, lam, indices=sub)
+        for k in range(4):
+            A, b = Xm[sub[k]].numpy(), Yw[sub[k], k].numpy()
+            w = np.linalg.solve(A.T @ A + lam * np.eye(A.shape[1]), A.T @ b)
+            assert np.abs(got[str(k)]["weights"].cpu().numpy() - w).max() < 2e-6 * max(1.0, np.abs(w).max())
+            assert np.abs(got[str(k)]["losses"].cpu().numpy() - 0.5 * (A @ w - b) ** 2).max() < 1e-5
     if not is_rpn:
         from odx.boxlist import BoxList
         import yaml as _y
