@@ -75,7 +75,7 @@ print("""
 ## Reading notes
 
 * The preconditioner kernels (`gemm_nt_kernel<double, ..>`, `potrf_diag_kernel`, `trsm128_kernel`, `trtri_diag_kernel`,
-  `gauss_kmm_f64_kernel`) run on side streams beside the main stream's kernels.  Their durations in the stats table are
+  `kmm_epilogue_kernel`) run on side streams beside the main stream's kernels.  Their durations in the stats table are
   first-wave-to-last-wave times that include waiting for a free CU behind the main stream's workgroups (a
   `trsm128_kernel` takes 14 us and a `potrf_diag_kernel` 75 us on an idle GPU): the table's percentages add up to more
   than the wall time and say nothing about how much of the GPU those kernels used.
