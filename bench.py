@@ -190,7 +190,10 @@ def main():
               file=sys.stderr)
     if world > 1:
         torch.cuda.set_device(0 if args.single_device else local_rank)
-        dist.init_process_group(backend=args.dist_backend, init_method="env://")
+        kw = {}
+        if args.dist_backend == "nccl":           # bind the RCCL communicator to this rank's GPU at creation (barriers included)
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        dist.init_process_group(backend=args.dist_backend, init_method="env://", **kw)
     else:
         torch.cuda.set_device(0)
     device = torch.device("cuda", torch.cuda.current_device())
