@@ -32,7 +32,11 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 8 && BN == 64) ? 3 : 1)
   // the merge levels of the triangular inverse, the last trailing updates of a Cholesky) covers all eight XCDs, and
   // the uneven row weights of triangular work average out over the batch.
   const int64_t xcd = (blockIdx.x + blockIdx.y + blockIdx.z) & 7, local = blockIdx.x >> 3;
-  const int64_t bi = xcd + 8 * (local / tiles_n), bj = local % tiles_n;
+  // lower-only output of a plain product: row r carries r + 1 tiles, so XCD x with rows x, x + 8, ... ends up 9 % over
+  // the mean at 79 tile rows; alternate groups of eight rows run backwards (x, 15 - x, 16 + x, ...), which evens the sums
+  const int64_t grp = local / tiles_n;
+  const bool serp = (p.flags & ODX_GEMM_LOWER_ONLY) && !(p.flags & (ODX_GEMM_A_UPPER | ODX_GEMM_B_UPPER | ODX_GEMM_A_LOWER | ODX_GEMM_B_LOWER));
+  const int64_t bi = 8 * grp + ((serp && (grp & 1)) ? 7 - xcd : xcd), bj = local % tiles_n;
   const int64_t i0 = bi * GEMM_BM, j0 = bj * BN;
   if (i0 >= m) return;
   if ((p.flags & ODX_GEMM_LOWER_ONLY) && j0 > i0 + GEMM_BM - 1) return;
