@@ -69,6 +69,9 @@ class OnlineRegionClassifierBase:
         # ODX_CLASS_SHARD in the environment select the same opt-ins without touching a driver (opts still win)
         self.class_batch = int(os.environ.get("ODX_CLASS_BATCH", "0") or 0)
         self.class_streams = int(os.environ.get("ODX_CLASS_STREAMS", "0") or 0)
+        # 'auto': the reference's order of draws with the classes advancing together when that can be predicted (GPU,
+        # stock index rule); 'sequential': always the class-by-class loop (opts['reference_order'], ODX_REFERENCE_ORDER)
+        self.reference_order = os.environ.get("ODX_REFERENCE_ORDER", "auto")
         self.class_rng = False          # one RNG stream per class for the Nystroem draws (opts['class_rng']; implied by the three modes above/below)
         self.class_shard = os.environ.get("ODX_CLASS_SHARD", "0") not in ("", "0")   # classes round-robin over the ranks of torch.distributed, models gathered at the end (opts['class_shard'])
 
@@ -83,6 +86,8 @@ class OnlineRegionClassifierBase:
                 setattr(self, attr, opts[key])
         if 'class_rng' in opts:
             self.class_rng = bool(opts['class_rng'])
+        if 'reference_order' in opts:
+            self.reference_order = str(opts['reference_order'])
         if 'class_shard' in opts:
             self.class_shard = bool(opts['class_shard'])
         if self.incore:
@@ -314,7 +319,57 @@ class OnlineRegionClassifierBase:
             self.caches = caches
         return model
 
-    def trainWithMinibootstrapBatched(self, negatives, positives, output_dir=None):
+    def _fits_together(self, negatives, positives):
+        """Whether the K_nM blocks and caches of all classes of a round fit beside each other (the class-by-class loop
+        holds one class at a time): an upper bound of their bytes against a quarter of the free device memory."""
+        try:
+            M = int(self.classifier.nyst_centers)
+            rows = sum(len(positives[i]) + sum(len(b) for b in negatives[i]) for i in range(self.num_classes - 1)
+                       if len(positives[i]) != 0 and len(negatives[i]) != 0)
+            D = next((int(positives[i].shape[1]) for i in range(self.num_classes - 1) if len(positives[i]) != 0), 0)
+            need = rows * (M * 4 + D * 12) + (self.num_classes - 1) * 4 * M * M * 8
+            return need < torch.cuda.mem_get_info()[0] // 4
+        except Exception:
+            return False
+
+    def _reference_stream_positions(self, negatives, positives):
+        """Where in the GLOBAL torch RNG stream every class's Nystroem draws start when the classes are trained one after
+        the other (the reference's order), predicted without training anything.  The stock index rule draws, per fit,
+        `half` values when a class has more than `half` positives and `room` values when its cache holds more than `room`
+        negatives (wrappers.py:_indices_tensor; torch.randint advances the generator by one 32-bit draw per value for
+        every bound below 2^24).  Positives never change, so the first count is known; the second is PREDICTED as `room`
+        for every fit (a cache is 2000+ rows against room <= M) and checked fit by fit by the caller.  Returns
+        (per-class generator states, per-class room, state after all classes) or None when the rule is not the stock one
+        or a bound is out of range."""
+        from .wrappers import FALKONWrapperBase
+        clf = self.classifier
+        stock = (isinstance(clf, FALKONWrapperBase) and type(clf).compute_indices_selection is FALKONWrapperBase.compute_indices_selection
+                 and type(clf)._indices_tensor is FALKONWrapperBase._indices_tensor
+                 and "compute_indices_selection" not in clf.__dict__ and "_indices_tensor" not in clf.__dict__)
+        if not stock or self._ranks()[1] > 1:
+            return None
+        M = int(clf.nyst_centers)
+        half = int(M / 2)
+        g = torch.Generator()
+        g.set_state(torch.get_rng_state())
+        states, rooms = {}, {}
+        for i in range(self.num_classes - 1):
+            if len(positives[i]) == 0 or len(negatives[i]) == 0:
+                continue
+            n_pos = len(positives[i])
+            if n_pos + sum(len(b) for b in negatives[i]) >= 2 ** 24:
+                return None
+            pos_draw = half if n_pos > half else 0
+            rooms[i] = M - min(n_pos, half)
+            states[i] = g.get_state()
+            count = len(negatives[i]) * (pos_draw + max(rooms[i], 0))
+            if rooms[i] <= 0:
+                return None
+            if count:
+                torch.randint(2, (count,), generator=g)
+        return states, rooms, g.get_state()
+
+    def trainWithMinibootstrapBatched(self, negatives, positives, output_dir=None, reference_rng=None):
         """The per-class state machine with the classes advancing together one negative batch at a time (as in
         trainWithMinibootstrapStreams) and ALL fits of a round made by one `classifier.train_batch` call: their
         preconditioners — per class a dependent chain of ~400 small factorisation kernels, the bulk of a fit at the
@@ -327,12 +382,19 @@ class OnlineRegionClassifierBase:
         kept when classes advance together."""
         from . import solver
         C = self.num_classes - 1
-        k = max(1, int(self.class_batch))
+        k = max(1, int(self.class_batch)) if self.class_batch > 0 else 4
         main = torch.cuda.current_stream()
         streams = [torch.cuda.Stream() for _ in range(k)]
-        seed0 = self._class_seed()
         active = [i for i in range(C) if len(positives[i]) != 0 and len(negatives[i]) != 0 and self._owned(i)]
-        rng = {i: torch.Generator().manual_seed(seed0 + i).get_state() for i in active}
+        if reference_rng is None:
+            seed0 = self._class_seed()
+            rng = {i: torch.Generator().manual_seed(seed0 + i).get_state() for i in active}
+            rooms = None
+        else:
+            # every class draws from the global stream's own segment for it (see _reference_stream_positions): the
+            # reference's class-major draws exactly, as long as every fit draws what was predicted — checked below
+            rng, rooms, final_state = reference_rng
+            rng = dict(rng)
         caches, model = [{} for _ in range(C)], [None] * C
         t_start = time.time()
         nb = max([len(negatives[i]) for i in active] or [0])
@@ -361,6 +423,8 @@ class OnlineRegionClassifierBase:
                     hard_idx = next_hard.pop(i)
                     caches[i]['neg'] = torch.cat((caches[i]['neg'], negatives[i][j][hard_idx]), 0)
                     print('Class {}: chosen {} hard negatives from the {}th batch'.format(i, len(hard_idx), j))
+            if rooms is not None and any(len(caches[i]['neg']) <= rooms[i] for i in todo):
+                return None      # a fit that draws fewer values than predicted: the later classes' positions in the stream are off
             Xs, ys = [], []
             for i in todo:
                 X_pos, X_neg = caches[i]['pos'], caches[i]['neg']
@@ -404,6 +468,8 @@ class OnlineRegionClassifierBase:
         for i in active:
             if not self.return_caches:
                 caches[i] = None
+        if reference_rng is not None:
+            torch.set_rng_state(final_state)          # the global stream where the class-by-class loop leaves it
         training_time = time.time() - t_start
         print('Online Classifier trained in {} seconds'.format(training_time))
         if output_dir:
@@ -457,7 +523,18 @@ class OnlineRegionClassifierBase:
         elif self.incore and self.class_streams > 0 and torch.cuda.is_available():
             model = self.trainWithMinibootstrapStreams(negatives, positives, output_dir=output_dir)
         else:
-            model = self.trainWithMinibootstrap(negatives, positives, output_dir=output_dir)
+            model = None
+            if (self.incore and self.reference_order == 'auto' and not self.class_rng and torch.cuda.is_available()
+                    and hasattr(self.classifier, 'train_batch') and self._fits_together(negatives, positives)):
+                # the reference's order of Nystroem draws, the classes advancing together: every class reads its own
+                # segment of the global RNG stream, predicted in advance; a fit that would draw differently (a cache that
+                # shrank below the room for negative centres) makes the attempt return None and the plain loop runs
+                where = self._reference_stream_positions(negatives, positives)
+                if where is not None:
+                    model = self.trainWithMinibootstrapBatched(negatives, positives, output_dir=output_dir, reference_rng=where)
+            self.last_order = 'reference order, classes together' if model is not None else 'reference order, class by class'
+            if model is None:
+                model = self.trainWithMinibootstrap(negatives, positives, output_dir=output_dir)
         model = self._gather_models(model)
         if self.incore and self.return_caches:
             return model, self.caches

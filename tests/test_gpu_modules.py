@@ -507,3 +507,50 @@ def test_class_sharded_minibootstrap_on_gpu(tmp_path):
             assert (a is None) == (b is None), (rank, c)
             if a is not None:
                 assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (rank, c)
+
+
+@pytest.mark.parametrize("neg_rows,expect", [(200, "reference order, classes together"), (60, "reference order, class by class")])
+def test_default_mode_keeps_the_reference_order_of_draws(tmp_path, neg_rows, expect):
+    """Without options the classes advance together AND every class draws its Nystroem centres from the global torch RNG
+    exactly where the reference's class-by-class loop would: models, caches and the RNG state afterwards equal the forced
+    class-by-class loop bit for bit (real index rule).  With 60-row negative batches class 4 has fewer negatives than room
+    for negative centres, draws nothing, the prediction of the stream positions fails and the plain loop runs instead."""
+    import yaml
+    D, C, ITER, M = 64, 5, 4, 120
+    cfg = {"NUM_CLASSES": 6, "ONLINE_REGION_CLASSIFIER": {"MINIBOOTSTRAP": {"EASY_THRESH": -0.9, "HARD_THRESH": -0.7},
+                                                          "CLASSIFIER": {"lambda": 0.001, "sigma": 8, "M": M, "kernel_type": "gauss"}},
+           "CHOSEN_CLASSES": {i: "c%d" % i for i in range(6)}}
+    path = str(tmp_path / "cfg.yaml")
+    yaml.safe_dump(cfg, open(path, "w"))
+    g = torch.Generator().manual_seed(71)
+    mus = torch.randn(C, D, generator=g) * 1.2
+
+    def data():
+        gg = torch.Generator().manual_seed(72)
+        pos, neg = [], []
+        for c in range(C):
+            npos = [150, 0, 90, 200, 20][c]
+            pos.append((mus[c] + 0.6 * torch.randn(npos, D, generator=gg)).cuda() if npos else torch.empty((0, D)).cuda())
+            nneg = neg_rows if c == 4 else 200
+            neg.append([(mus[(c + 1 + j % 2) % C] * (0.4 + 0.15 * j) + 0.9 * torch.randn(nneg, D, generator=gg)).cuda()
+                        for j in range(ITER if c != 3 else ITER - 1)])
+        return pos, neg
+
+    stats = {"mean": torch.zeros(D).cuda(), "std": torch.ones(D).cuda(), "mean_norm": torch.tensor(8.0).cuda()}
+    orc_mod = dropin.load("OnlineRegionClassifier_incore")
+    wrap_mod = dropin.load("FALKONWrapper_with_centers_selection_incore")
+    out = {}
+    for mode, opts in (("auto", {"return_caches": True}), ("loop", {"return_caches": True, "reference_order": "sequential"})):
+        pos, neg = data()
+        torch.manual_seed(5)
+        orc = orc_mod.OnlineRegionClassifier(wrap_mod.FALKONWrapper(cfg_path=path), pos, neg, stats, cfg_path=path)
+        models, caches = quiet(orc.trainRegionClassifier, opts=opts)
+        out[mode] = (models, caches, torch.get_rng_state(), orc.last_order)
+    assert out["auto"][3] == expect and out["loop"][3] == "reference order, class by class"
+    assert torch.equal(out["auto"][2], out["loop"][2])                      # the global stream ends where the loop leaves it
+    for c in range(C):
+        a, b = out["auto"][0][c], out["loop"][0][c]
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a.ny_points_, b.ny_points_) and torch.equal(a.alpha_, b.alpha_), c
+            assert torch.equal(out["auto"][1][c]["neg"], out["loop"][1][c]["neg"]), c

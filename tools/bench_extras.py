@@ -81,7 +81,8 @@ def forward_extra(height=600, width=800, rois=300, reps=8):
     return out
 
 
-def minibootstrap_extra(C=30, D=2048, IT=10, positives=800, sigma=15.0, modes=(("sequential", None), ("class_streams4", {"class_streams": 4}), ("class_batch4", {"class_batch": 4}))):
+def minibootstrap_extra(C=30, D=2048, IT=10, positives=800, sigma=15.0, modes=(("default", None), ("class_by_class_loop", {"reference_order": "sequential"}), ("class_streams4", {"class_streams": 4}),
+                               ("class_batch4", {"class_batch": 4}))):
     import yaml
     from tests import dropin
     names = ["_background_"] + ["c%d" % i for i in range(C)]
@@ -117,6 +118,8 @@ def minibootstrap_extra(C=30, D=2048, IT=10, positives=800, sigma=15.0, modes=((
             best = dt if best is None else min(best, dt)
         out["s_" + name] = round(best, 3)
         out["trained_" + name] = sum(1 for m in models if m is not None)
+        if name == "default":
+            out["default_ran_as"] = getattr(orc, "last_order", "class by class")
     return out
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Host-side profile (cProfile) of the reference-regime Minibootstrap in one of its modes; development aid.
-    python tools/minibootstrap_profile.py [sequential|class_streams|class_batch] [k]"""
+    python tools/minibootstrap_profile.py [default|sequential|class_streams|class_batch] [k]"""
 import cProfile
 import io
 import os
@@ -17,7 +17,7 @@ from tools import bench_extras  # noqa: E402
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "class_batch"
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-opts = None if mode == "sequential" else {mode: k}
+opts = {"reference_order": "sequential"} if mode == "sequential" else (None if mode == "default" else {mode: k})
 bench_extras.minibootstrap_extra(modes=((mode, opts),))          # warm
 pr = cProfile.Profile()
 pr.enable()
