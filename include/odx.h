@@ -300,6 +300,13 @@ int odx_roi_align_fwd_f32(const float* feat, int N, int C, int H, int W, const f
 int64_t odx_nms_workspace_bytes(int R);
 int odx_nms_f32(const float* boxes_sorted, int R, float iou_threshold, unsigned char* keep,
                 void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+/* The per-class NMS loop of the detection post-processing (OnlineDetectionPostProcessor.py:51-66: for every
+ * foreground class threshold, boxlist_nms, collect) as ONE launch pair: B independent box sets, set b = counts[b] <= Rmax
+ * boxes sorted by descending score in slot b of boxes_sorted (B, Rmax, 4); keep (B, Rmax) u8.  counts is a DEVICE array:
+ * no host read between the score threshold and the suppression.  */
+int64_t odx_nms_batched_workspace_bytes(int Rmax, int B);
+int odx_nms_batched_f32(const float* boxes_sorted, const int32_t* counts, int Rmax, int B, float iou_threshold,
+                        unsigned char* keep, void* workspace, int64_t workspace_bytes, odx_stream_t stream);
 
 /* Masker / paste_mask_in_image (mrcnn_modified/modeling/roi_heads/mask_head/inference.py:119-191), all detections
  * of one image at once: masks (R, S, S) f32 probabilities, boxes (R, 4) xyxy f32 -> out (R, im_h, im_w) u8 0/1:

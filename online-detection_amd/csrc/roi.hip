@@ -81,10 +81,19 @@ __device__ __forceinline__ float box_iou_plus1(const float* a, const float* b) {
   return inter / (sa + sb - inter);
 }
 
+// counts != nullptr: a batch of independent box sets (the classes of an image), set z = blockIdx.z holding counts[z]
+// boxes in a slot of Rmax (boxes, mask and keep advance by whole slots); otherwise one set of R boxes.
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int R, float thr,
-                                                      unsigned long long* __restrict__ mask, int words) {
+                                                      unsigned long long* __restrict__ mask, int words,
+                                                      const int* __restrict__ counts) {
   const int rb = blockIdx.y, cb = blockIdx.x;
   if (cb < rb) return;  // only boxes after i can be suppressed by i
+  if (counts != nullptr) {
+    boxes += (int64_t)blockIdx.z * R * 4;
+    mask += (int64_t)blockIdx.z * R * words;
+    R = counts[blockIdx.z];
+    if (rb * 64 >= R || cb * 64 >= R) return;
+  }
   __shared__ float cbx[64 * 4];
   const int lane = threadIdx.x;
   const int cj = cb * 64 + lane;
@@ -118,13 +127,20 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
 // memory); then the mask rows of the block's survivors are OR-ed into the set, eight rows' loads in flight at a time.
 // (Walking the boxes one by one made every kept box a dependent global load: 2.8 ms at R = 6000, now 0.2 ms.)
 __global__ __launch_bounds__(64) void nms_reduce_kernel(const unsigned long long* __restrict__ mask, int R, int words,
-                                                        unsigned char* __restrict__ keep) {
+                                                        unsigned char* __restrict__ keep, const int* __restrict__ counts) {
   const int lane = threadIdx.x;
+  if (counts != nullptr) {                // batch: one wave per box set; rows of the mask keep the slot's stride `words`
+    mask += (int64_t)blockIdx.x * R * words;
+    keep += (int64_t)blockIdx.x * R;
+    R = counts[blockIdx.x];
+    if (R <= 0) return;
+  }
+  const int nwords = (R + 63) >> 6;       // words that hold boxes of this set (<= words)
   constexpr int NW = 4;      // R <= 64 * 64 * NW boxes
   unsigned long long removed[NW];
 #pragma unroll
   for (int q = 0; q < NW; ++q) removed[q] = 0ull;
-  for (int wi = 0; wi < words; ++wi) {
+  for (int wi = 0; wi < nwords; ++wi) {
     unsigned long long word = 0ull;
 #pragma unroll
     for (int q = 0; q < NW; ++q)
@@ -133,7 +149,7 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const unsigned long long
     const int i = wi * 64 + lane;
     const unsigned long long d = (i < R) ? mask[(int64_t)i * words + wi] : 0ull;   // bits above the lane's own box only
     unsigned long long alive = ~cur;
-    if (wi == words - 1 && (R & 63)) alive &= (1ull << (R & 63)) - 1ull;
+    if (wi == nwords - 1 && (R & 63)) alive &= (1ull << (R & 63)) - 1ull;
 #pragma unroll
     for (int b = 0; b < 64; ++b) {
       const unsigned long long db = readlane_u64(d, b);
@@ -157,7 +173,7 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const unsigned long long
 #pragma unroll
         for (int q = 0; q < NW; ++q) {
           const int col = lane + 64 * q;
-          v[u][q] = (row[u] >= 0 && col < words && col > wi) ? mask[row[u] + col] : 0ull;
+          v[u][q] = (row[u] >= 0 && col < nwords && col > wi) ? mask[row[u] + col] : 0ull;
         }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
@@ -246,10 +262,41 @@ extern "C" int odx_nms_f32(const float* boxes_sorted, int R, float iou_threshold
   ODX_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)odx_nms_workspace_bytes(R), s));
   auto* mask = static_cast<unsigned long long*>(workspace);
   hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)words, (unsigned)words), dim3(64), 0, s, boxes_sorted, R,
-                     iou_threshold, mask, words);
+                     iou_threshold, mask, words, (const int*)nullptr);
   ODX_CHECK_LAUNCH("odx_nms_f32(mask)");
-  hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(64), 0, s, mask, R, words, keep);
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(64), 0, s, mask, R, words, keep, (const int*)nullptr);
   ODX_CHECK_LAUNCH("odx_nms_f32(reduce)");
+  return ODX_OK;
+}
+
+// B independent box sets (the classes of an image after the score threshold) with one launch pair: set b holds counts[b]
+// <= Rmax boxes, sorted by descending score, in slot b of boxes_sorted (B, Rmax, 4); keep (B, Rmax) gets 1 for the
+// survivors of set b's greedy NMS and 0 elsewhere (incl. the unused tail of a slot).  counts lives on the device: the
+// caller needs no host read between thresholding and suppression.
+extern "C" int64_t odx_nms_batched_workspace_bytes(int Rmax, int B) {
+  if (Rmax <= 0 || B <= 0) return 0;
+  return (int64_t)B * odx_nms_workspace_bytes(Rmax);
+}
+
+extern "C" int odx_nms_batched_f32(const float* boxes_sorted, const int32_t* counts, int Rmax, int B, float iou_threshold,
+                                   unsigned char* keep, void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
+  if (Rmax <= 0 || B <= 0) return ODX_OK;
+  ODX_REQUIRE(boxes_sorted && counts && keep && workspace, "odx_nms_batched_f32: null pointer");
+  ODX_REQUIRE(Rmax <= 64 * 64 * 4 && B < 65536, "odx_nms_batched_f32: at most 16384 boxes per set, 65535 sets");
+  if (workspace_bytes < odx_nms_batched_workspace_bytes(Rmax, B)) {
+    set_error("odx_nms_batched_f32: workspace too small");
+    return ODX_ERR_WORKSPACE;
+  }
+  const int words = (int)ceil_div(Rmax, 64);
+  hipStream_t s = as_stream(stream);
+  ODX_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)odx_nms_batched_workspace_bytes(Rmax, B), s));
+  ODX_CHECK_HIP(hipMemsetAsync(keep, 0, (size_t)B * Rmax, s));
+  auto* mask = static_cast<unsigned long long*>(workspace);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)words, (unsigned)words, (unsigned)B), dim3(64), 0, s, boxes_sorted, Rmax,
+                     iou_threshold, mask, words, counts);
+  ODX_CHECK_LAUNCH("odx_nms_batched_f32(mask)");
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3((unsigned)B), dim3(64), 0, s, mask, Rmax, words, keep, counts);
+  ODX_CHECK_LAUNCH("odx_nms_batched_f32(reduce)");
   return ODX_OK;
 }
 

@@ -497,6 +497,20 @@ class HipBackend:
                   "odx_nms_f32")
         return order[keep.bool()]
 
+    def nms_batched(self, boxes_sorted, counts, iou_threshold):
+        """Greedy NMS of B independent box sets with one launch pair: boxes_sorted (B, Rmax, 4) f32, set b's counts[b]
+        boxes first in its slot, sorted by descending score; counts (B,) int32 ON THE DEVICE.  Returns keep (B, Rmax) bool."""
+        B, Rmax = int(boxes_sorted.shape[0]), int(boxes_sorted.shape[1])
+        keep = torch.empty((B, Rmax), dtype=torch.uint8, device=self.device)
+        if B == 0 or Rmax == 0:
+            return keep.bool()
+        boxes_sorted = boxes_sorted.to(device=self.device, dtype=torch.float32).contiguous()
+        counts = counts.to(device=self.device, dtype=torch.int32).contiguous()
+        ws = self._workspace("nms_batched", self.lib.odx_nms_batched_workspace_bytes(Rmax, B))
+        hip.check(self.lib.odx_nms_batched_f32(_p(boxes_sorted), _p(counts), Rmax, B, float(iou_threshold), _p(keep), _p(ws),
+                                               ws.numel(), self._stream()), "odx_nms_batched_f32")
+        return keep.bool()
+
 
 _BACKEND = None
 

@@ -52,18 +52,32 @@ def filter_results(boxes, cls_scores, img_size, score_thresh=-2.0, nms_thresh=0.
     boxes[..., 2].clamp_(0, img_size[0] - 1)
     boxes[..., 1].clamp_(0, img_size[1] - 1)
     boxes[..., 3].clamp_(0, img_size[1] - 1)
-    out_b, out_s, out_l = [], [], []
     keep_all = cls_scores > score_thresh
-    for j in range(1, num_classes):                       # 0 is the background slot
-        inds = keep_all[:, j].nonzero().squeeze(1)
-        sj, bj = cls_scores[inds, j], boxes[inds, j]
-        k = be.nms(bj, sj, nms_thresh) if inds.numel() else inds
-        out_b.append(bj[k])
-        out_s.append(sj[k])
-        out_l.append(torch.full((k.numel(),), j, dtype=torch.int64, device=sj.device))
-    if not out_b:
+    if num_classes < 2:
         return None
-    b, s, l = torch.cat(out_b), torch.cat(out_s), torch.cat(out_l)
+    if hasattr(be, "nms_batched") and boxes.shape[0] > 0:
+        # all foreground classes at once: the rows of a class that pass the threshold sorted by descending score (stable,
+        # ties in row order — what the class-by-class loop below does with nonzero() + a stable argsort), ONE launch pair
+        # for the suppression of every class, ONE nonzero() for the survivors (class-major, rank order = the order the loop
+        # concatenates in).  The loop costs ~10 launches and two host round trips per class: 5-6 ms per image at 30 classes.
+        fg = keep_all[:, 1:].t()                                                      # (C, R)
+        sc = torch.where(fg, cls_scores[:, 1:].t(), cls_scores.new_full((), float("-inf")))
+        order = torch.argsort(sc, dim=1, descending=True, stable=True)
+        sc = torch.gather(sc, 1, order)
+        bs = torch.gather(boxes[:, 1:].permute(1, 0, 2), 1, order.unsqueeze(2).expand(-1, -1, 4)).contiguous()
+        keep = be.nms_batched(bs, fg.sum(1), nms_thresh)
+        cls, rank = keep.nonzero(as_tuple=True)
+        b, s, l = bs[cls, rank], sc[cls, rank], cls + 1
+    else:
+        out_b, out_s, out_l = [], [], []
+        for j in range(1, num_classes):                       # 0 is the background slot
+            inds = keep_all[:, j].nonzero().squeeze(1)
+            sj, bj = cls_scores[inds, j], boxes[inds, j]
+            k = be.nms(bj, sj, nms_thresh) if inds.numel() else inds
+            out_b.append(bj[k])
+            out_s.append(sj[k])
+            out_l.append(torch.full((k.numel(),), j, dtype=torch.int64, device=sj.device))
+        b, s, l = torch.cat(out_b), torch.cat(out_s), torch.cat(out_l)
     n = s.numel()
     if n > detections_per_img > 0:
         thresh, _ = torch.kthvalue(s.cpu(), n - detections_per_img + 1)

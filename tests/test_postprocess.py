@@ -219,3 +219,42 @@ def test_standalone_accuracy_evaluator_dropin(tmp_path):
     present = sorted(set(g["c2_labels"].tolist()))
     assert all(abs(res["ap"][c] - 1.0) < 1e-12 for c in present) and abs(res["map"] - 1.0) < 1e-12
     assert "Detection mAP50: 1.0000" in open(os.path.join(str(tmp_path), "result.txt")).read()
+
+
+@pytest.mark.gpu
+def test_all_class_nms_equals_the_class_by_class_loop():
+    """filter_results on the MI355X suppresses every class with one launch pair (odx_nms_batched_f32); result = the
+    class-by-class loop's (threshold, stable sort, odx_nms_f32 per class) — same boxes, scores, labels, in the same
+    order — with ragged classes: one class without any row above the threshold, one with a single row, ties in the scores."""
+    import odx
+    from odx import postprocess as pp
+    odx.set_backend(None)
+    be = odx.get_backend()
+    g = torch.Generator().manual_seed(12)
+    R, C = 333, 9
+    xy = torch.rand((R, 2), generator=g) * torch.tensor([500.0, 300.0])
+    wh = 30 + torch.rand((R, 2), generator=g) * 150
+    props = torch.cat((xy, xy + wh), dim=1).cuda()
+    deltas = (torch.randn((R, 4 * (C + 1)), generator=g) * 0.15).cuda()
+    scores = (torch.randn((R, C + 1), generator=g) * 0.5 - 0.6)
+    scores[:, 3] = -5.0                                   # no row of class 3 passes
+    scores[:, 5] = -5.0
+    scores[17, 5] = 0.4                                   # exactly one row of class 5 passes
+    scores[40:60, 7] = 0.25                               # ties
+    scores = scores.cuda()
+    for thr, per_img in ((-1.0, 100), (-0.5, 0), (-2.0, 40)):
+        got = pp.postprocess_detections(scores, deltas, props, (640, 480), thr, 0.3, per_img)
+
+        class Loop:                                       # the same backend without the batched entry point
+            def __getattr__(self, name):
+                if name == "nms_batched":
+                    raise AttributeError(name)
+                return getattr(be, name)
+        odx.set_backend(Loop())
+        try:
+            ref = pp.postprocess_detections(scores, deltas, props, (640, 480), thr, 0.3, per_img)
+        finally:
+            odx.set_backend(None)
+        assert len(ref["scores"]) > 0
+        for key in ("boxes", "scores", "labels"):
+            assert torch.equal(got[key], ref[key]), (thr, key)
