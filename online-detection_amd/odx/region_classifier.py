@@ -19,6 +19,7 @@ import numpy as np
 import torch
 import yaml
 
+from . import backend as _backend
 from .boxlist import get_boxlist_class
 
 
@@ -555,6 +556,13 @@ class OnlineRegionClassifierBase:
         if not self.incore:
             self.mean, self.std, self.mean_norm = (torch.as_tensor(self.mean).to(dev), torch.as_tensor(self.std).to(dev),
                                                    torch.as_tensor(self.mean_norm).to(dev))
+        fused = None
+        if (dev == 'cuda' and self.num_classes > 2 and len(model) >= self.num_classes - 1
+                and all(m is not None and getattr(m, 'alpha_', None) is not None and hasattr(getattr(m, 'kernel', None), 'sigma')
+                        for m in model[:self.num_classes - 1])
+                and len({float(m.kernel.sigma) for m in model[:self.num_classes - 1]}) == 1):
+            from .heads import _OnlineHead
+            fused = _OnlineHead(list(model[:self.num_classes - 1]), None, None)
         for entry in test_boxes:
             if entry is None:
                 continue
@@ -565,8 +573,13 @@ class OnlineRegionClassifierBase:
             if self.mean_norm != 0:
                 X_test = self.zScores(X_test)
             scores = -torch.ones((len(boxes), self.num_classes))
-            for c in range(self.num_classes - 1):
-                scores[:, c + 1] = torch.squeeze(self.classifier.predict(model[c], X_test))
+            if fused is not None:
+                # all classes with ONE fused scoring launch over the concatenated centres (what the in-network detector
+                # head does, odx.heads._OnlineHead._scores) instead of num_classes - 1 predicts per image
+                scores[:, 1:] = fused._scores(_backend.get_backend().features(X_test), len(boxes)).to(scores.device)
+            else:
+                for c in range(self.num_classes - 1):
+                    scores[:, c + 1] = torch.squeeze(self.classifier.predict(model[c], X_test))
             total += time.time() - t0
             b = BoxList(torch.from_numpy(boxes), (entry['img_size'][0], entry['img_size'][1]), mode="xyxy")
             b.add_field("scores", scores.to('cpu'))

@@ -105,6 +105,12 @@ def test_end_to_end_pipeline_on_gpu(tmp_path):
     with redirect_stdout(io.StringIO()):
         preds = orc.testRegionClassifier(models, test_boxes)
     assert tuple(preds[0].get_field("scores").shape)[1] == C + 1
+    # (testRegionClassifier scores all classes of an image with one fused launch: equal to one predict per class)
+    keep0 = np.nonzero(test_boxes[0]["gt"] == 0)
+    X0 = orc.zScores(torch.tensor(test_boxes[0]["feat"][keep0, :][0], device="cuda"))
+    one_by_one = torch.cat([clf.predict(models[c], X0) for c in range(C)], dim=1).cpu()
+    fused = preds[0].get_field("scores")
+    assert torch.all(fused[:, 0] == -1) and float((fused[:, 1:] - one_by_one).abs().max()) < 1e-5
     # in-network test-time head on one image's RoI features
     boxes, feats, _ = model(samples[0][0].cuda(), None)
     scores, deltas = model.online_box(feats)
