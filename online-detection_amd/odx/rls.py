@@ -346,6 +346,19 @@ class RegionPredictor:
             F = be.features(feat)
             ex_box = boxes[i].bbox.to(dev)
             num_boxes = ex_box.size()[0]
+            if hasattr(be, "gemm_nt") and all(m['Beta'] is not None for m in self.models[:num_clss - 1]):
+                # all classes at once (what the in-network head does, odx.heads): the regressors with T_inv and mu folded
+                # in as ONE (4 (C - 1), D) weight matrix, one f32 GEMM per image, one decode over (boxes, classes) —
+                # instead of ~30 launches per class and image
+                fold = getattr(self, "_fold", None)
+                if fold is None or fold[0] is not self.models or fold[1] != F.D:
+                    from .heads import _fold_regressors
+                    Wt, bias = _fold_regressors(list(self.models[:num_clss - 1]), F.D, False)
+                    fold = self._fold = (self.models, F.D, be.features(Wt.to(F.X.device)), bias.to(F.X.device))
+                Y = (be.gemm_nt(F, fold[2]) + fold[3]).view(num_boxes, num_clss - 1, 4)
+                dec = decode_boxes(ex_box.unsqueeze(1), Y, img_width, img_height, plus=float(np.spacing(1)))
+                boxes[i].bbox = torch.cat((ex_box.view(num_boxes, 1, 4), dec), dim=1)
+                continue
             out = [ex_box]
             for j in range(1, num_clss):
                 m = self.models[j - 1]
@@ -360,16 +373,17 @@ class RegionPredictor:
 def decode_boxes(ex_box, Y, img_width, img_height, plus):
     """Box decoding of predict_regions.py:50-70: widths are x2 - x1 + `plus` (np.spacing(1) there,
     1 in py_od_utils.decode_boxes_detector), the far corner is centre + w/2 - 1, clamped to the image."""
-    src_w = ex_box[:, 2] - ex_box[:, 0] + plus
-    src_h = ex_box[:, 3] - ex_box[:, 1] + plus
-    ctr_x = ex_box[:, 0] + 0.5 * src_w
-    ctr_y = ex_box[:, 1] + 0.5 * src_h
-    pred_ctr_x = Y[:, 0] * src_w + ctr_x
-    pred_ctr_y = Y[:, 1] * src_h + ctr_y
-    pred_w = torch.exp(Y[:, 2]) * src_w
-    pred_h = torch.exp(Y[:, 3]) * src_h
+    # (ex_box (R, 4) with Y (R, 4), or ex_box (R, 1, 4) with Y (R, K, 4) for all classes at once: the last axis is the box)
+    src_w = ex_box[..., 2] - ex_box[..., 0] + plus
+    src_h = ex_box[..., 3] - ex_box[..., 1] + plus
+    ctr_x = ex_box[..., 0] + 0.5 * src_w
+    ctr_y = ex_box[..., 1] + 0.5 * src_h
+    pred_ctr_x = Y[..., 0] * src_w + ctr_x
+    pred_ctr_y = Y[..., 1] * src_h + ctr_y
+    pred_w = torch.exp(Y[..., 2]) * src_w
+    pred_h = torch.exp(Y[..., 3]) * src_h
     x1 = torch.clamp(pred_ctr_x - 0.5 * pred_w, min=0)
     y1 = torch.clamp(pred_ctr_y - 0.5 * pred_h, min=0)
     x2 = torch.clamp(pred_ctr_x + 0.5 * pred_w - 1, max=img_width - 1)
     y2 = torch.clamp(pred_ctr_y + 0.5 * pred_h - 1, max=img_height - 1)
-    return torch.stack([x1, y1, x2, y2], dim=1)
+    return torch.stack([x1, y1, x2, y2], dim=-1)
