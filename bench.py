@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--precond-behind-cg", dest="precond_after_fit", action="store_true",
                     help="issue the look-ahead preconditioner behind the batch's CG instead of before its fit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the rls / forward / minibootstrap extra keys (N = 1 only)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the rls / forward / detect / minibootstrap extra keys (N = 1 only)")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0 = pick by host core count")
     ap.add_argument("--check", action="store_true", help="verify one class against the oracle on a row sample")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only for the "

@@ -81,6 +81,42 @@ def forward_extra(height=600, width=800, rois=300, reps=8):
     return out
 
 
+def detect_extra(height=600, width=800, rois=300, C=30, M=1000, reps=10):
+    """One test-time image end to end (odx.extract.detect: trunk, RPN proposals, RoIAlign, conv5 head, the on-line box
+    head of C FALKON classifiers + C box regressors, decode / threshold / per-class NMS / top-k): ms per image, with the
+    post-processing also timed on its own.  Random weights and random models (shape only)."""
+    import odx
+    from odx.extract import OnlineDetectionModel, detect
+    from odx.heads import OnlineBoxPredictor
+    from odx.postprocess import postprocess_detections
+    dev = torch.device("cuda")
+    model = OnlineDetectionModel(post_nms_top_n=rois).to(dev).eval()
+    D = model.feat_dim
+    g = torch.Generator().manual_seed(4)
+    clfs = []
+    for c in range(C):
+        m = odx.InCoreFalkon(kernel=odx.GaussianKernel(20.0), penalty=1e-4, M=M)
+        m.ny_points_ = (torch.randn(M, D, generator=g) * (20.0 / D ** 0.5)).to(dev)
+        m.alpha_ = (torch.randn(M, 1, generator=g, dtype=torch.float64) * 0.05).to(dev)
+        clfs.append(m)
+    regs = [{"mu": torch.zeros(4), "T": torch.eye(4), "T_inv": torch.eye(4),
+             "Beta": {str(k): {"weights": torch.randn(D + 1, generator=g) * 0.01} for k in range(4)}} for _ in range(C)]
+    stats = {"mean": torch.zeros(D, device=dev), "std": torch.ones(D, device=dev), "mean_norm": torch.tensor(20.0, device=dev)}
+    model.online_box = OnlineBoxPredictor(clfs, regs, stats)
+    img = torch.randn((1, 3, height, width), generator=g).to(dev)
+    with torch.no_grad():
+        for _ in range(3):
+            res, boxes = detect(model, img, (width, height), -2.0, 0.3, 100)
+        dt, _ = _sync_time(lambda: [detect(model, img, (width, height), -2.0, 0.3, 100) for _ in range(reps)])
+        maps = model.roi_head_maps(model.c4(img), boxes)
+        scores, deltas = model.online_box(maps.mean(dim=(2, 3)))
+        dtp, _ = _sync_time(lambda: [postprocess_detections(scores, deltas, boxes, (width, height), -2.0, 0.3, 100) for _ in range(reps)])
+    return {"workload": "detect(): %dx%d image, %d proposals, %d FALKON classifiers (M=%d, D=%d) + %d box regressors, decode + "
+                        "per-class NMS + top-100, f32" % (height, width, boxes.shape[0], C, M, D, C),
+            "ms_per_image": round(dt / reps * 1e3, 2), "images_per_s": round(reps / dt, 1),
+            "postprocessing_ms": round(dtp / reps * 1e3, 2), "detections": 0 if res is None else int(len(res["scores"]))}
+
+
 def minibootstrap_extra(C=30, D=2048, IT=10, positives=800, sigma=15.0, modes=(("default", None), ("class_by_class_loop", {"reference_order": "sequential"}), ("class_streams4", {"class_streams": 4}),
                                ("class_batch4", {"class_batch": 4}))):
     import yaml
@@ -126,7 +162,7 @@ def minibootstrap_extra(C=30, D=2048, IT=10, positives=800, sigma=15.0, modes=((
 def collect(args):
     """Everything above; a failing extra is reported as its error string, never as a missing headline."""
     out = {}
-    for key, fn in (("rls", lambda: rls_extra(cpu=not args.no_cpu_baseline)), ("forward", forward_extra),
+    for key, fn in (("rls", lambda: rls_extra(cpu=not args.no_cpu_baseline)), ("forward", forward_extra), ("detect", detect_extra),
                     ("minibootstrap", minibootstrap_extra)):
         try:
             out[key] = fn()
