@@ -234,6 +234,37 @@ class Bottleneck(_FoldedBN):
         return F.relu(self.conv_bn("conv3", "bn3", y) + idn)
 
 
+def _bottleneck_rows(blk, x, R, H, W):
+    """One Bottleneck on activations kept as a (R * H * W, C) row matrix (NHWC): the 1 x 1 convolutions ARE matrix products
+    over those rows and the 3 x 3 one is a product over a 9-tap gather of them, so the block is three (four with the
+    projection) library GEMMs with the folded batch-norm bias added by the GEMM, instead of MIOpen convolutions on 7 x 7
+    maps (74 TF in f32 for the whole head; the same products as GEMMs run at 95-117 TF).  A stride (always in the 1 x 1
+    convolutions here, STRIDE_IN_1X1) is applied by the caller: x holds the rows of the positions that survive it."""
+    dt = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled("cuda")) else blk.conv1.weight.dtype
+
+    def mat(key, conv, bn, taps=False):
+        c = blk._folded.get((key + "/rows", dt))
+        if c is None:
+            w, b = blk._fold(key, conv, bn, x)
+            w = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1) if taps else w.reshape(w.shape[0], -1)     # (out, ky kx in)
+            c = blk._folded[(key + "/rows", dt)] = (w.t().contiguous(), b)
+        return c
+    if blk.down is None:
+        idn = x
+    else:
+        wd, bd = mat("down", blk.down[0], blk.down[1])
+        idn = torch.addmm(bd, x, wd)
+    w1, b1 = mat("conv1", blk.conv1, blk.bn1)
+    y = torch.addmm(b1, x, w1).relu_()
+    mid = y.shape[1]
+    yp = F.pad(y.view(R, H, W, mid), (0, 0, 1, 1, 1, 1))
+    cols = torch.cat([yp[:, ky:ky + H, kx:kx + W, :] for ky in range(3) for kx in range(3)], dim=3).view(R * H * W, 9 * mid)
+    w2, b2 = mat("conv2", blk.conv2, blk.bn2, taps=True)
+    y = torch.addmm(b2, cols, w2).relu_()
+    w3, b3 = mat("conv3", blk.conv3, blk.bn3)
+    return torch.addmm(b3, y, w3).add_(idn).relu_()
+
+
 def _stage(cin, mid, cout, blocks, stride):
     layers = [Bottleneck(cin, mid, cout, stride)] + [Bottleneck(cout, mid, cout, 1) for _ in range(blocks - 1)]
     return nn.Sequential(*layers)
@@ -264,8 +295,23 @@ class Conv5Head(nn.Module):
         self.layer4 = _stage(cin, cin // 2, 2 * cin, 3, 2)
         self.out_channels = 2 * cin
 
-    def forward(self, x):
+    def forward_conv(self, x):
+        """The stage as convolutions (what `forward` computes, kept as the reference of its test)."""
         return self.layer4(x)
+
+    def forward(self, x):
+        blocks = list(self.layer4)
+        st = blocks[0].conv1.stride[0]
+        if any(b.conv1.stride[0] != 1 for b in blocks[1:]) or blocks[0].conv2.stride[0] != 1 or x.shape[0] == 0:
+            return self.layer4(x)
+        xs = x[:, :, ::st, ::st]                                   # the positions a stride-`st` 1 x 1 convolution reads
+        R, C, H, W = xs.shape
+        rows = xs.permute(0, 2, 3, 1).reshape(R * H * W, C)
+        if torch.is_autocast_enabled("cuda") and rows.is_cuda:
+            rows = rows.to(torch.get_autocast_dtype("cuda"))
+        for blk in blocks:
+            rows = _bottleneck_rows(blk, rows, R, H, W)
+        return rows.view(R, H, W, -1).permute(0, 3, 1, 2)          # (R, 2048, H, W) as a view of the NHWC rows
 
 
 class OnlineDetectionModel(nn.Module):
@@ -365,7 +411,7 @@ class OnlineDetectionModel(nn.Module):
     def mask_activation(self, head_maps):
         """(R, mask_dim, r, r) = relu(conv5_mask(head maps))  (roi_mask_predictors.py:38)."""
         with self._amp():
-            return F.relu(self.conv5_mask(head_maps)).float()
+            return F.relu(self.conv5_mask(head_maps.contiguous())).float()      # (the head hands out an NHWC-strided view)
 
     @torch.no_grad()
     def forward(self, image, gt_boxes=None):

@@ -15,6 +15,28 @@ from odx.extract import (DetectorFeatureExtractor, OnlineDetectionModel, cell_an
 from tests import dropin
 
 
+@pytest.mark.parametrize("device", ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def test_conv5_head_as_row_gemms_equals_the_convolutions(device):
+    """Conv5Head.forward keeps the RoI activations as (RoIs x positions, channels) rows and runs the stage as GEMMs on the
+    folded weights (1 x 1 convolutions directly, the 3 x 3 one over a 9-tap gather); same numbers as the convolutions."""
+    from odx.extract import Conv5Head
+    torch.manual_seed(0)
+    head = Conv5Head(64).eval()
+    for m in head.modules():
+        if hasattr(m, "running_var"):
+            m.running_var.uniform_(0.5, 1.5)
+            m.running_mean.normal_()
+            m.weight.data.normal_(1, 0.1)
+            m.bias.data.normal_()
+    head = head.to(device)
+    for shape in ((7, 64, 14, 14), (3, 64, 9, 11), (1, 64, 2, 2)):
+        x = torch.randn(shape, device=device)
+        with torch.no_grad():
+            a, b = head.forward_conv(x), head(x)
+        assert a.shape == b.shape and float((a - b).abs().max()) < 2e-5 * max(1.0, float(a.abs().max()))
+    assert head(torch.empty((0, 64, 14, 14), device=device)).shape[0] == 0
+
+
 def test_cell_anchors_follow_the_detectron_enumeration():
     a = cell_anchors(16)
     assert a.shape == (15, 4)
