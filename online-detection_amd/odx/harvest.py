@@ -139,8 +139,12 @@ class _SlotGrid:
         """rows: the sampled rows of the image, all classes back to back (the `src_start` frame of plan)."""
         if not self.dst:
             return
-        dst = np.concatenate([np.arange(base, base + k, dtype=np.int64) for base, k in self.dst])
-        src = np.concatenate([np.arange(s0, s0 + k, dtype=np.int64) for s0, (_, k) in zip(self.src, self.dst)])
+        # (several hundred (start, count) runs per image: expanded with a handful of array operations, not one arange per run)
+        runs = np.asarray(self.dst, dtype=np.int64).reshape(-1, 2)
+        ks = runs[:, 1]
+        ramp = np.arange(int(ks.sum()), dtype=np.int64) - np.repeat(np.cumsum(ks) - ks, ks)
+        dst = np.repeat(runs[:, 0], ks) + ramp
+        src = np.repeat(np.asarray(self.src, dtype=np.int64), ks) + ramp
         self.dst, self.src = [], []
         idx = torch.from_numpy(np.stack((dst, src))).to(rows.device, non_blocking=True)     # one host -> device copy
         self.store.view(-1, self.D).index_copy_(0, idx[0], rows.index_select(0, idx[1]))
