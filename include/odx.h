@@ -300,6 +300,11 @@ int odx_roi_align_fwd_f32(const float* feat, int N, int C, int H, int W, const f
 int64_t odx_nms_workspace_bytes(int R);
 int odx_nms_f32(const float* boxes_sorted, int R, float iou_threshold, unsigned char* keep,
                 void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+/* odx_nms_f32 with an upper bound on the survivors: keep[i] = 1 for the first max_keep of them only — what
+ * `nms(...)[:post_nms_top_n]` selects (mrcnn_modified/modeling/rpn/inference.py:116-121) — without visiting the
+ * candidates behind the last one.  */
+int odx_nms_first_f32(const float* boxes_sorted, int R, float iou_threshold, int max_keep, unsigned char* keep,
+                      void* workspace, int64_t workspace_bytes, odx_stream_t stream);
 /* The per-class NMS loop of the detection post-processing (OnlineDetectionPostProcessor.py:51-66: for every
  * foreground class threshold, boxlist_nms, collect) as ONE launch pair: B independent box sets, set b = counts[b] <= Rmax
  * boxes sorted by descending score in slot b of boxes_sorted (B, Rmax, 4); keep (B, Rmax) u8.  counts is a DEVICE array:

@@ -126,9 +126,13 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
 // mask block (one word per lane) resolves the suppression inside the block with scalar bit operations (64 steps, no
 // memory); then the mask rows of the block's survivors are OR-ed into the set, eight rows' loads in flight at a time.
 // (Walking the boxes one by one made every kept box a dependent global load: 2.8 ms at R = 6000, now 0.2 ms.)
+// max_keep > 0: stop after that many survivors (keep must be zero on entry: the boxes behind the last survivor are not
+// visited) — the RPN keeps the first 300 of up to 6000 candidates, reached after a few hundred of them.
 __global__ __launch_bounds__(64) void nms_reduce_kernel(const unsigned long long* __restrict__ mask, int R, int words,
-                                                        unsigned char* __restrict__ keep, const int* __restrict__ counts) {
+                                                        unsigned char* __restrict__ keep, const int* __restrict__ counts,
+                                                        int max_keep) {
   const int lane = threadIdx.x;
+  int kept = 0;
   if (counts != nullptr) {                // batch: one wave per box set; rows of the mask keep the slot's stride `words`
     mask += (int64_t)blockIdx.x * R * words;
     keep += (int64_t)blockIdx.x * R;
@@ -155,7 +159,13 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const unsigned long long
       const unsigned long long db = readlane_u64(d, b);
       if ((alive >> b) & 1ull) alive &= ~db;
     }
+    if (max_keep > 0) {
+      int room = max_keep - kept;
+      while (__builtin_popcountll(alive) > room) alive &= ~(1ull << (63 - __builtin_clzll(alive)));   // drop the last survivors
+      kept += __builtin_popcountll(alive);
+    }
     if (i < R) keep[i] = (unsigned char)((alive >> lane) & 1ull);
+    if (max_keep > 0 && kept >= max_keep) return;
     unsigned long long a = alive;
     while (a) {
       int64_t row[8];
@@ -264,8 +274,32 @@ extern "C" int odx_nms_f32(const float* boxes_sorted, int R, float iou_threshold
   hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)words, (unsigned)words), dim3(64), 0, s, boxes_sorted, R,
                      iou_threshold, mask, words, (const int*)nullptr);
   ODX_CHECK_LAUNCH("odx_nms_f32(mask)");
-  hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(64), 0, s, mask, R, words, keep, (const int*)nullptr);
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(64), 0, s, mask, R, words, keep, (const int*)nullptr, 0);
   ODX_CHECK_LAUNCH("odx_nms_f32(reduce)");
+  return ODX_OK;
+}
+
+// The same with an upper bound on the survivors: keep[i] = 1 for the first max_keep survivors only (what
+// `nms(...)[:post_nms_top_n]` selects, rpn/inference.py:116-121) without walking the candidates behind them.
+extern "C" int odx_nms_first_f32(const float* boxes_sorted, int R, float iou_threshold, int max_keep, unsigned char* keep,
+                                 void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
+  if (R <= 0) return ODX_OK;
+  ODX_REQUIRE(boxes_sorted && keep && workspace && max_keep > 0, "odx_nms_first_f32: null pointer or max_keep <= 0");
+  ODX_REQUIRE(R <= 64 * 64 * 4, "odx_nms_first_f32: at most 16384 boxes");
+  if (workspace_bytes < odx_nms_workspace_bytes(R)) {
+    set_error("odx_nms_first_f32: workspace too small");
+    return ODX_ERR_WORKSPACE;
+  }
+  const int words = (int)ceil_div(R, 64);
+  hipStream_t s = as_stream(stream);
+  ODX_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)odx_nms_workspace_bytes(R), s));
+  ODX_CHECK_HIP(hipMemsetAsync(keep, 0, (size_t)R, s));
+  auto* mask = static_cast<unsigned long long*>(workspace);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)words, (unsigned)words), dim3(64), 0, s, boxes_sorted, R,
+                     iou_threshold, mask, words, (const int*)nullptr);
+  ODX_CHECK_LAUNCH("odx_nms_first_f32(mask)");
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(64), 0, s, mask, R, words, keep, (const int*)nullptr, max_keep);
+  ODX_CHECK_LAUNCH("odx_nms_first_f32(reduce)");
   return ODX_OK;
 }
 
@@ -295,7 +329,7 @@ extern "C" int odx_nms_batched_f32(const float* boxes_sorted, const int32_t* cou
   hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)words, (unsigned)words, (unsigned)B), dim3(64), 0, s, boxes_sorted, Rmax,
                      iou_threshold, mask, words, counts);
   ODX_CHECK_LAUNCH("odx_nms_batched_f32(mask)");
-  hipLaunchKernelGGL(nms_reduce_kernel, dim3((unsigned)B), dim3(64), 0, s, mask, Rmax, words, keep, counts);
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3((unsigned)B), dim3(64), 0, s, mask, Rmax, words, keep, counts, 0);
   ODX_CHECK_LAUNCH("odx_nms_batched_f32(reduce)");
   return ODX_OK;
 }

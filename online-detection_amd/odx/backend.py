@@ -482,20 +482,30 @@ class HipBackend:
                                                   _p(out), self._stream()), "odx_paste_masks_u8")
         return out.bool()
 
-    def nms(self, boxes, scores, iou_threshold):
+    def nms(self, boxes, scores, iou_threshold, max_keep=0, sorted_desc=False):
         """Indices of the boxes kept by greedy NMS, in descending score order (maskrcnn_benchmark
-        layers.nms contract)."""
+        layers.nms contract).  max_keep > 0: only the first max_keep of them (= nms(...)[:max_keep], without visiting the
+        candidates behind the last one); sorted_desc: the caller's boxes already are in descending score order (top-k
+        output) — no second sort, no gather."""
         boxes = boxes.to(device=self.device, dtype=torch.float32)
         R = boxes.shape[0]
         if R == 0:
             return torch.empty(0, dtype=torch.int64, device=self.device)
-        order = torch.argsort(scores.to(self.device), descending=True, stable=True)
-        sb = boxes.index_select(0, order).contiguous()
+        if sorted_desc:
+            order, sb = None, boxes.contiguous()
+        else:
+            order = torch.argsort(scores.to(self.device), descending=True, stable=True)
+            sb = boxes.index_select(0, order).contiguous()
         keep = torch.empty(R, dtype=torch.uint8, device=self.device)
         ws = self._workspace("nms", self.lib.odx_nms_workspace_bytes(R))
-        hip.check(self.lib.odx_nms_f32(_p(sb), R, float(iou_threshold), _p(keep), _p(ws), ws.numel(), self._stream()),
-                  "odx_nms_f32")
-        return order[keep.bool()]
+        if max_keep and max_keep > 0:
+            hip.check(self.lib.odx_nms_first_f32(_p(sb), R, float(iou_threshold), int(max_keep), _p(keep), _p(ws), ws.numel(),
+                                                 self._stream()), "odx_nms_first_f32")
+        else:
+            hip.check(self.lib.odx_nms_f32(_p(sb), R, float(iou_threshold), _p(keep), _p(ws), ws.numel(), self._stream()),
+                      "odx_nms_f32")
+        kept = keep.bool().nonzero().reshape(-1)
+        return kept if order is None else order[kept]
 
     def nms_batched(self, boxes_sorted, counts, iou_threshold):
         """Greedy NMS of B independent box sets with one launch pair: boxes_sorted (B, Rmax, 4) f32, set b's counts[b]

@@ -82,10 +82,16 @@ def rpn_proposals(objectness, box_regression, anchors, img_size, pre_nms_top_n=6
     boxes[:, 2].clamp_(0, img_size[0] - 1)
     boxes[:, 1].clamp_(0, img_size[1] - 1)
     boxes[:, 3].clamp_(0, img_size[1] - 1)
-    ws, hs = boxes[:, 2] - boxes[:, 0] + 1, boxes[:, 3] - boxes[:, 1] + 1
-    ok = (ws >= min_size) & (hs >= min_size)
-    boxes, score = boxes[ok], score[ok]
-    keep = be.nms(boxes, score, nms_thresh)[:post_nms_top_n]
+    if min_size > 0:            # (sides are >= 0 + ... by construction: with the shipped min_size = 0 nothing is dropped)
+        ws, hs = boxes[:, 2] - boxes[:, 0] + 1, boxes[:, 3] - boxes[:, 1] + 1
+        ok = (ws >= min_size) & (hs >= min_size)
+        boxes, score = boxes[ok], score[ok]
+    # top-k hands the candidates over in descending score order, and only the first post_nms_top_n survivors are used:
+    # no second sort, and the suppression stops at the last one it needs (a few hundred of the 6000 candidates in)
+    try:
+        keep = be.nms(boxes, score, nms_thresh, max_keep=post_nms_top_n, sorted_desc=True)
+    except TypeError:            # a backend with the plain contract (tests' oracle backend)
+        keep = be.nms(boxes, score, nms_thresh)[:post_nms_top_n]
     return boxes[keep], score[keep]
 
 

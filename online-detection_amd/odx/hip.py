@@ -84,6 +84,7 @@ SIGNATURES = {
     "odx_roi_align_fwd_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _f32, _i32, _i32, _i32, _vp, _vp]),
     "odx_nms_workspace_bytes": (_i64, [_i32]),
     "odx_nms_f32": (_i32, [_vp, _i32, _f32, _vp, _vp, _i64, _vp]),
+    "odx_nms_first_f32": (_i32, [_vp, _i32, _f32, _i32, _vp, _vp, _i64, _vp]),
     "odx_nms_batched_workspace_bytes": (_i64, [_i32, _i32]),
     "odx_nms_batched_f32": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _i64, _vp]),
     "odx_paste_masks_u8": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),

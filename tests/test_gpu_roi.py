@@ -45,3 +45,24 @@ def test_nms_matches_oracle(be, R, thr):
     ref = roi_ref.nms(boxes, scores, thr)
     assert np.array_equal(got, ref)
     assert tuple(be.nms(torch.zeros(0, 4), torch.zeros(0), thr).shape) == (0,)
+
+
+def test_nms_first_k_equals_the_full_suppression_truncated():
+    """be.nms(max_keep=k) (odx_nms_first_f32: the suppression stops at the k-th survivor) = be.nms()[:k], also when the
+    caller hands the boxes over already sorted (sorted_desc=True, the RPN's top-k output) — sizes around the 64-box
+    words of the mask, k below / at / above the number of survivors."""
+    import odx
+    be = odx.get_backend()
+    g = torch.Generator().manual_seed(8)
+    for R in (1, 63, 64, 65, 700, 6000):
+        xy = torch.rand((R, 2), generator=g) * torch.tensor([700.0, 500.0])
+        wh = 20 + torch.rand((R, 2), generator=g) * 160
+        boxes = torch.cat((xy, xy + wh), dim=1).cuda()
+        scores = torch.rand(R, generator=g).cuda()
+        full = be.nms(boxes, scores, 0.7)
+        order = torch.argsort(scores, descending=True, stable=True)
+        for k in (1, 5, 300, int(full.numel()), int(full.numel()) + 7):
+            assert torch.equal(be.nms(boxes, scores, 0.7, max_keep=k), full[:k]), (R, k)
+            got = be.nms(boxes[order], scores[order], 0.7, max_keep=k, sorted_desc=True)
+            assert torch.equal(order[got], full[:k]), (R, k)
+        assert torch.equal(order[be.nms(boxes[order], scores[order], 0.7, sorted_desc=True)], full)
