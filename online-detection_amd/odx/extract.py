@@ -240,6 +240,15 @@ class Bottleneck(_FoldedBN):
         return F.relu(self.conv_bn("conv3", "bn3", y) + idn)
 
 
+def _addmm_relu(bias, x, w):
+    """relu(x @ w + bias) with the ReLU in the GEMM's epilogue where the library offers it (hipBLASLt through
+    torch._addmm_activation), as a second pass over the output otherwise."""
+    fused = getattr(torch, "_addmm_activation", None)
+    if fused is not None and x.is_cuda:
+        return fused(bias, x, w, use_gelu=False)
+    return torch.addmm(bias, x, w).relu_()
+
+
 def _bottleneck_rows(blk, x, R, H, W):
     """One Bottleneck on activations kept as a (R * H * W, C) row matrix (NHWC): the 1 x 1 convolutions ARE matrix products
     over those rows and the 3 x 3 one is a product over a 9-tap gather of them, so the block is three (four with the
@@ -261,12 +270,12 @@ def _bottleneck_rows(blk, x, R, H, W):
         wd, bd = mat("down", blk.down[0], blk.down[1])
         idn = torch.addmm(bd, x, wd)
     w1, b1 = mat("conv1", blk.conv1, blk.bn1)
-    y = torch.addmm(b1, x, w1).relu_()
+    y = _addmm_relu(b1, x, w1)
     mid = y.shape[1]
     yp = F.pad(y.view(R, H, W, mid), (0, 0, 1, 1, 1, 1))
     cols = torch.cat([yp[:, ky:ky + H, kx:kx + W, :] for ky in range(3) for kx in range(3)], dim=3).view(R * H * W, 9 * mid)
     w2, b2 = mat("conv2", blk.conv2, blk.bn2, taps=True)
-    y = torch.addmm(b2, cols, w2).relu_()
+    y = _addmm_relu(b2, cols, w2)
     w3, b3 = mat("conv3", blk.conv3, blk.bn3)
     return torch.addmm(b3, y, w3).add_(idn).relu_()
 
