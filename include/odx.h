@@ -295,6 +295,12 @@ int odx_rls_solve_batched_f64(double* G, int64_t ldg, int64_t g_stride, int D, i
 int odx_roi_align_fwd_f32(const float* feat, int N, int C, int H, int W, const float* rois, int R,
                           float spatial_scale, int PH, int PW, int sampling_ratio, float* out,
                           odx_stream_t stream);
+/* The same bins for a consumer that starts with a stride-`step` 1 x 1 convolution (ResNet50Conv5ROIFeatureExtractor's
+ * head, roi_box_feature_extractors.py:26-52 with STRIDE_IN_1X1): only the bins (ph, pw) with ph % step == pw % step == 0,
+ * as rows of an (R * ceil(PH / step) * ceil(PW / step), C) matrix (NHWC) — a quarter of the grid at 14 x 14, step 2.  */
+int odx_roi_align_rows_f32(const float* feat, int N, int C, int H, int W, const float* rois, int R,
+                           float spatial_scale, int PH, int PW, int sampling_ratio, int step, float* out_rows,
+                           odx_stream_t stream);
 /* Greedy NMS over boxes (R, 4) xyxy ALREADY SORTED by descending score, areas with the +1
  * pixel convention: keep[i] = 1 unless an earlier kept box overlaps i with IoU > threshold.  */
 int64_t odx_nms_workspace_bytes(int R);

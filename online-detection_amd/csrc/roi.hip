@@ -17,14 +17,27 @@ namespace odx {
 // for every channel, so they are formed once per sample and reused across the chunk's channels.
 constexpr int ROI_CCH = 16;
 
+// step > 0 ("rows" form): only the bins (ph, pw) with ph % step == 0 and pw % step == 0 are formed — the positions a
+// stride-`step` 1 x 1 convolution reads, a quarter of the 14 x 14 grid for the conv5 head — and written as rows of an
+// (R * OH * OW, C) matrix (NHWC), the layout the head's GEMMs consume; step == 0: the full (R, C, PH, PW) grid.
 __global__ __launch_bounds__(256) void roi_align_fwd_kernel(const float* __restrict__ feat, int N, int C, int H, int W,
                                                             const float* __restrict__ rois, int R, float scale, int PH,
-                                                            int PW, int sampling_ratio, float* __restrict__ out) {
+                                                            int PW, int sampling_ratio, float* __restrict__ out, int step) {
   const int r = blockIdx.x;
   const int c0 = blockIdx.y * ROI_CCH;
   const int t = threadIdx.x;
-  if (t >= PH * PW) return;
-  const int ph = t / PW, pw = t % PW;
+  int ph, pw, OW = 0, OH = 0;
+  if (step > 0) {
+    OH = (PH + step - 1) / step;
+    OW = (PW + step - 1) / step;
+    if (t >= OH * OW) return;
+    ph = (t / OW) * step;
+    pw = (t % OW) * step;
+  } else {
+    if (t >= PH * PW) return;
+    ph = t / PW;
+    pw = t % PW;
+  }
   const float* roi = rois + (int64_t)r * 5;
   const int b = (int)roi[0];
   const float x1 = roi[1] * scale, y1 = roi[2] * scale, x2 = roi[3] * scale, y2 = roi[4] * scale;
@@ -60,6 +73,13 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(const float* __restr
         }
       }
     }
+  }
+  if (step > 0) {
+    float* row = out + (((int64_t)r * OH + ph / step) * OW + pw / step) * C + c0;
+#pragma unroll
+    for (int k = 0; k < ROI_CCH; ++k)
+      if (k < nch) row[k] = acc[k] / count;
+    return;
   }
 #pragma unroll
   for (int k = 0; k < ROI_CCH; ++k)
@@ -247,8 +267,24 @@ extern "C" int odx_roi_align_fwd_f32(const float* feat, int N, int C, int H, int
   ODX_REQUIRE((int64_t)H * W < (1ll << 31) && ceil_div(C, ROI_CCH) < 65536, "odx_roi_align_fwd_f32: map too large");
   dim3 grid((unsigned)R, (unsigned)ceil_div(C, ROI_CCH));
   hipLaunchKernelGGL(roi_align_fwd_kernel, grid, dim3(256), 0, as_stream(stream), feat, N, C, H, W, rois, R,
-                     spatial_scale, PH, PW, sampling_ratio, out);
+                     spatial_scale, PH, PW, sampling_ratio, out, 0);
   ODX_CHECK_LAUNCH("odx_roi_align_fwd_f32");
+  return ODX_OK;
+}
+
+// RoIAlign for a consumer that starts with a stride-`step` 1 x 1 convolution (the conv5 head, STRIDE_IN_1X1): the bins
+// that convolution reads only, as rows of an (R * ceil(PH / step) * ceil(PW / step), C) matrix.
+extern "C" int odx_roi_align_rows_f32(const float* feat, int N, int C, int H, int W, const float* rois, int R,
+                                      float spatial_scale, int PH, int PW, int sampling_ratio, int step, float* out_rows,
+                                      odx_stream_t stream) {
+  if (R <= 0 || C <= 0) return ODX_OK;
+  ODX_REQUIRE(feat && rois && out_rows && N > 0 && H > 0 && W > 0 && step > 0, "odx_roi_align_rows_f32: bad argument");
+  ODX_REQUIRE(PH > 0 && PW > 0 && PH * PW <= 256, "odx_roi_align_rows_f32: PH * PW must be in 1..256");
+  ODX_REQUIRE((int64_t)H * W < (1ll << 31) && ceil_div(C, ROI_CCH) < 65536, "odx_roi_align_rows_f32: map too large");
+  dim3 grid((unsigned)R, (unsigned)ceil_div(C, ROI_CCH));
+  hipLaunchKernelGGL(roi_align_fwd_kernel, grid, dim3(256), 0, as_stream(stream), feat, N, C, H, W, rois, R,
+                     spatial_scale, PH, PW, sampling_ratio, out_rows, step);
+  ODX_CHECK_LAUNCH("odx_roi_align_rows_f32");
   return ODX_OK;
 }
 

@@ -471,6 +471,20 @@ class HipBackend:
                                                  int(sampling_ratio), _p(out), self._stream()), "odx_roi_align_fwd_f32")
         return out
 
+    def roi_align_rows(self, feat, rois, spatial_scale, output_size, sampling_ratio=0, step=2):
+        """RoIAlign for a head that starts with a stride-`step` 1 x 1 convolution: the bins that convolution reads only,
+        as an (R * OH * OW, C) row matrix (NHWC).  Returns (rows, (R, OH, OW))."""
+        feat = feat.to(device=self.device, dtype=torch.float32).contiguous()
+        rois = rois.to(device=self.device, dtype=torch.float32).contiguous()
+        N, C, H, W = feat.shape
+        PH, PW = output_size
+        R = rois.shape[0]
+        OH, OW = (PH + step - 1) // step, (PW + step - 1) // step
+        out = torch.empty((R * OH * OW, C), dtype=torch.float32, device=self.device)
+        hip.check(self.lib.odx_roi_align_rows_f32(_p(feat), N, C, H, W, _p(rois), R, float(spatial_scale), PH, PW,
+                                                  int(sampling_ratio), int(step), _p(out), self._stream()), "odx_roi_align_rows_f32")
+        return out, (R, OH, OW)
+
     def paste_masks(self, masks, boxes, im_h, im_w, thresh=0.5, padding=1):
         """Masker: masks (R, S, S) f32, boxes (R, 4) -> (R, im_h, im_w) bool."""
         masks = masks.to(device=self.device, dtype=torch.float32).contiguous()

@@ -314,19 +314,28 @@ class Conv5Head(nn.Module):
         """The stage as convolutions (what `forward` computes, kept as the reference of its test)."""
         return self.layer4(x)
 
-    def forward(self, x):
+    def rows_form(self):
+        """The stride of the first block's 1 x 1 convolutions when the stage can run as row GEMMs (strides only there), else 0."""
         blocks = list(self.layer4)
-        st = blocks[0].conv1.stride[0]
-        if any(b.conv1.stride[0] != 1 for b in blocks[1:]) or blocks[0].conv2.stride[0] != 1 or x.shape[0] == 0:
+        if any(b.conv1.stride[0] != 1 for b in blocks[1:]) or any(b.conv2.stride[0] != 1 for b in blocks):
+            return 0
+        return int(blocks[0].conv1.stride[0])
+
+    def forward_rows(self, rows, R, H, W):
+        """rows (R * H * W, C): the input at the positions the first block's strided 1 x 1 convolutions read (NHWC)."""
+        if torch.is_autocast_enabled("cuda") and rows.is_cuda:
+            rows = rows.to(torch.get_autocast_dtype("cuda"))
+        for blk in self.layer4:
+            rows = _bottleneck_rows(blk, rows, R, H, W)
+        return rows.view(R, H, W, -1).permute(0, 3, 1, 2)          # (R, 2048, H, W) as a view of the NHWC rows
+
+    def forward(self, x):
+        st = self.rows_form()
+        if st == 0 or x.shape[0] == 0:
             return self.layer4(x)
         xs = x[:, :, ::st, ::st]                                   # the positions a stride-`st` 1 x 1 convolution reads
         R, C, H, W = xs.shape
-        rows = xs.permute(0, 2, 3, 1).reshape(R * H * W, C)
-        if torch.is_autocast_enabled("cuda") and rows.is_cuda:
-            rows = rows.to(torch.get_autocast_dtype("cuda"))
-        for blk in blocks:
-            rows = _bottleneck_rows(blk, rows, R, H, W)
-        return rows.view(R, H, W, -1).permute(0, 3, 1, 2)          # (R, 2048, H, W) as a view of the NHWC rows
+        return self.forward_rows(xs.permute(0, 2, 3, 1).reshape(R * H * W, C), R, H, W)
 
 
 class OnlineDetectionModel(nn.Module):
@@ -413,6 +422,13 @@ class OnlineDetectionModel(nn.Module):
         """(R, D, r/2, r/2): RoIAlign r x r @ 1/stride (HIP kernel) -> conv5 head."""
         be = _backend.get_backend()
         rois = torch.cat((torch.zeros((boxes.shape[0], 1), device=boxes.device), boxes), dim=1)
+        st = self.head.rows_form() if hasattr(self.head, "rows_form") else 0
+        if st > 0 and hasattr(be, "roi_align_rows") and boxes.shape[0] > 0:
+            # the head's first 1 x 1 convolutions read every st-th position of the crop: RoIAlign forms those bins only,
+            # directly as the rows the head's GEMMs consume (no 14 x 14 crop, no NCHW -> NHWC copy)
+            rows, (R, OH, OW) = be.roi_align_rows(c4, rois, 1.0 / self.stride, (self.resolution, self.resolution), 0, step=st)
+            with self._amp():
+                return self.head.forward_rows(rows, R, OH, OW).float()
         crops = be.roi_align(c4, rois, 1.0 / self.stride, (self.resolution, self.resolution), 0)
         with self._amp():
             return self.head(crops).float()

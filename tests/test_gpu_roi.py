@@ -66,3 +66,22 @@ def test_nms_first_k_equals_the_full_suppression_truncated():
             got = be.nms(boxes[order], scores[order], 0.7, max_keep=k, sorted_desc=True)
             assert torch.equal(order[got], full[:k]), (R, k)
         assert torch.equal(order[be.nms(boxes[order], scores[order], 0.7, sorted_desc=True)], full)
+
+
+def test_roi_align_rows_is_the_strided_subset_of_the_grid():
+    """odx_roi_align_rows_f32 (the bins a stride-2 1 x 1 convolution reads, as NHWC rows) = the full RoIAlign grid
+    subsampled and permuted, bit for bit; odd grid sizes and steps 1 / 2 / 3."""
+    import odx
+    be = odx.get_backend()
+    g = torch.Generator().manual_seed(2)
+    feat = torch.randn((2, 37, 20, 27), generator=g).cuda()
+    R = 19
+    xy = torch.rand((R, 2), generator=g) * torch.tensor([300.0, 200.0])
+    wh = 10 + torch.rand((R, 2), generator=g) * 150
+    rois = torch.cat((torch.randint(0, 2, (R, 1), generator=g).float(), xy, xy + wh), dim=1).cuda()
+    for (PH, PW), step in (((14, 14), 2), ((7, 9), 2), ((14, 14), 1), ((13, 14), 3)):
+        full = be.roi_align(feat, rois, 1.0 / 16, (PH, PW), 0)
+        rows, (r, OH, OW) = be.roi_align_rows(feat, rois, 1.0 / 16, (PH, PW), 0, step=step)
+        ref = full[:, :, ::step, ::step]
+        assert (r, OH, OW) == (R, ref.shape[2], ref.shape[3])
+        assert torch.equal(rows.view(R, OH, OW, -1).permute(0, 3, 1, 2), ref)
