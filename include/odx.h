@@ -295,6 +295,20 @@ int odx_rls_solve_batched_f64(double* G, int64_t ldg, int64_t g_stride, int D, i
 int odx_roi_align_fwd_f32(const float* feat, int N, int C, int H, int W, const float* rois, int R,
                           float spatial_scale, int PH, int PW, int sampling_ratio, float* out,
                           odx_stream_t stream);
+/* odx_split_f16 of the 3 x 3 neighbourhood matrix of an NHWC row matrix Y (R * H * W rows of C channels, C % 8 == 0): row
+ * (r, h, w) of P holds, tap (ky, kx) after tap, the channels of Y's row (r, h + ky - 1, w + kx - 1), zeros outside the map
+ * — the operand of a 3 x 3 convolution with padding 1 run as a GEMM (K = 9 C), written in the packed form directly
+ * (P: (R H W) x ldp 4-byte units, ldp >= roundup(9 C, 64); meta as in odx_split_f16).  */
+int odx_split_f16_taps3x3(const float* Y, int64_t ldy, int64_t R, int H, int W, int C, void* P, int64_t ldp,
+                          float* meta, odx_stream_t stream);
+/* out (m x n) f32 = act(A B' + bias[col] + residual), A (m x K) and B (n x K) handed over in the packed two-term f16 form
+ * of odx_split_f16 (with their meta words): the f32 product at f32 accuracy on the f16 matrix cores (3 MFMAs per product,
+ * the Gaussian kernels' tile cores).  Replaces the convolutions of ResNet50Conv5ROIFeatureExtractor's head
+ * (roi_box_feature_extractors.py:26-52) run as GEMMs over (RoIs x positions, channels) rows: bias = the folded frozen batch
+ * norm, residual = the block's identity branch, relu = 1 for the ReLU behind it.  bias / residual may be NULL.  */
+int odx_gemm_h2_f32(const void* PA, int64_t ldpa, const float* metaa, int64_t m, const void* PB, int64_t ldpb,
+                    const float* metab, int64_t n, int K, const float* bias, const float* residual, int64_t ldr,
+                    int relu, float* out, int64_t ldo, odx_stream_t stream);
 /* The same bins for a consumer that starts with a stride-`step` 1 x 1 convolution (ResNet50Conv5ROIFeatureExtractor's
  * head, roi_box_feature_extractors.py:26-52 with STRIDE_IN_1X1): only the bins (ph, pw) with ph % step == pw % step == 0,
  * as rows of an (R * ceil(PH / step) * ceil(PW / step), C) matrix (NHWC) — a quarter of the grid at 14 x 14, step 2.  */

@@ -104,6 +104,48 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
   *reinterpret_cast<f16x8*>(dst + 16) = lo;
 }
 
+// The packed split of the 3 x 3 neighbourhood matrix of an NHWC row matrix Y (R * H * W rows of C channels): row (r, h, w)
+// of the result holds, tap (ky, kx) after tap, the C channels of Y's row (r, h + ky - 1, w + kx - 1) — zeros outside the
+// map.  That is the operand of a 3 x 3 convolution (padding 1) run as a GEMM; it is written in the packed form directly,
+// never as floats (9 x the bytes of Y).  C % 8 == 0; the scale comes from Y's own absmax (the zeros add nothing).
+__global__ __launch_bounds__(256) void split_f16_taps3x3_kernel(const float* __restrict__ Y, int64_t ldy, int H, int W, int C,
+                                                                uint32_t* __restrict__ P, int64_t ldp, float* __restrict__ meta,
+                                                                int64_t row0) {
+  const float s = h2_scale_from_absmax(__float_as_uint(meta[1]));
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) meta[0] = s;
+  const int D = 9 * C;
+  const int groups = (int)((D + H2_KT - 1) / H2_KT) * 8;
+  const int64_t row = row0 + blockIdx.y;
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= groups) return;
+  float v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = 0.f;
+  const int f = g * 8;                                   // first feature of the group: tap f / C, channel f % C
+  if (f < D) {
+    const int tap = f / C, c = f - tap * C;
+    const int w = (int)(row % W), h = (int)((row / W) % H);
+    const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
+    if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+      const float* x = Y + (row + (int64_t)(hh - h) * W + (ww - w)) * ldy + c;
+      const f32x4 a = *reinterpret_cast<const f32x4*>(x), b = *reinterpret_cast<const f32x4*>(x + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { v[q] = a[q]; v[4 + q] = b[q]; }
+    }
+  }
+  f16x8 hi, lo;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float t = v[q] * s;
+    const _Float16 hq = (_Float16)t;
+    hi[q] = hq;
+    lo[q] = (_Float16)(t - (float)hq);
+  }
+  uint32_t* dst = P + row * ldp + (int64_t)(g >> 2) * 32 + (g & 3) * 4;
+  *reinterpret_cast<f16x8*>(dst) = hi;
+  *reinterpret_cast<f16x8*>(dst + 16) = lo;
+}
+
 // ---------------------------------------------------------------- tile mainloop
 struct H2Stage {
   u32x4 a[8], b[8];
@@ -589,6 +631,82 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_knm_h2w256_kernel(
   }
 }
 
+// ---------------------------------------------------------------- plain products on the split tile cores
+// out (m x n) = act(A B' + bias[col] + residual) for operands in the packed two-term f16 form (odx_split_f16): the f32
+// product at f32 accuracy on the f16 matrix cores, 3 MFMAs per product — ~3 x the rate of the f32 MFMA path for the
+// GEMM-shaped layers of the feature forward (the conv5 head as row GEMMs).  Same tile order and main loops as the
+// Gaussian builds; the epilogue scales by 1 / (s_A s_B) (powers of two: exact) and adds bias / residual, optional ReLU.
+__device__ __forceinline__ float gemm_h2_finish(float acc, float inv, float b, const float* __restrict__ res, int64_t ldr,
+                                                int64_t row, int64_t col, int relu) {
+  float v = fmaf(acc, inv, b);
+  if (res != nullptr) v += res[row * ldr + col];
+  return relu ? fmaxf(v, 0.f) : v;
+}
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_h2s16_kernel(
+    const uint32_t* __restrict__ PA, int64_t ldpa, const float* __restrict__ metaa, int64_t m, const uint32_t* __restrict__ PB,
+    int64_t ldpb, const float* __restrict__ metab, int64_t n, int ktiles, const float* __restrict__ bias,
+    const float* __restrict__ res, int64_t ldr, int relu, float* __restrict__ out, int64_t ldo, int gr) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int64_t GR = gr;
+  const int64_t tiles_n = (n + GEMM_BN - 1) / GEMM_BN;
+  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t band = wg / (GR * tiles_n), within = wg % (GR * tiles_n);
+  const int64_t i0 = (band * GR + within % GR) * GEMM_BM, j0 = (within / GR) * GEMM_BN;
+  if (i0 >= m) return;
+  f32x4 acc[4][4];
+  s16_zero(acc);
+  s16_mainloop(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, ktiles, lds);
+  const float inv = 1.f / (metaa[0] * metab[0]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) {
+    const int64_t col = j0 + wc * 64 + tn * 16 + (lane & 15);
+    if (col >= n) continue;
+    const float b = bias != nullptr ? bias[col] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      const int64_t r0 = i0 + wr * 64 + tm * 16 + 4 * (lane >> 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (r0 + q < m) out[(r0 + q) * ldo + col] = gemm_h2_finish(acc[tm][tn][q], inv, b, res, ldr, r0 + q, col, relu);
+    }
+  }
+}
+
+__global__ __launch_bounds__(W_THREADS, 1) void gemm_h2w256_kernel(
+    const uint32_t* __restrict__ PA, int64_t ldpa, const float* __restrict__ metaa, int64_t m, const uint32_t* __restrict__ PB,
+    int64_t ldpb, const float* __restrict__ metab, int64_t n, int stages, const float* __restrict__ bias,
+    const float* __restrict__ res, int64_t ldr, int relu, float* __restrict__ out, int64_t ldo, int gr) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int64_t GR = gr;
+  const int64_t tiles_n = (n + W_BN - 1) / W_BN;
+  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t band = wg / (GR * tiles_n), within = wg % (GR * tiles_n);
+  const int64_t i0 = (band * GR + within % GR) * W_BM, j0 = (within / GR) * W_BN;
+  if (i0 >= m) return;
+  f32x4 acc[8][4];
+  w_zero(acc);
+  w_mainloop(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds);
+  const float inv = 1.f / (metaa[0] * metab[0]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) {
+    const int64_t col = j0 + wc * 64 + tn * 16 + (lane & 15);
+    if (col >= n) continue;
+    const float b = bias != nullptr ? bias[col] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 8; ++tm) {
+      const int64_t r0 = i0 + wr * 128 + tm * 16 + 4 * (lane >> 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (r0 + q < m) out[(r0 + q) * ldo + col] = gemm_h2_finish(acc[tm][tn][q], inv, b, res, ldr, r0 + q, col, relu);
+    }
+  }
+}
+
 // Fused scoring on the 256 x 256 core: same decomposition as gauss_mmv_h2s16_kernel (row block x group of `tg` column
 // tiles, f64 partial row sums per group in the slab, mmv_reduce_kernel adds the groups), 256-row blocks, 256-column tiles.
 __global__ __launch_bounds__(W_THREADS, 1) void gauss_mmv_h2w256_kernel(
@@ -760,6 +878,63 @@ static int launch_knm_w256(const void* PX, int64_t ldpx, const float* metax, con
                        ldk, wgr, nullptr, nullptr, 0);
   }
   ODX_CHECK_LAUNCH("odx_gauss_knm_h2(w256)");
+  return ODX_OK;
+}
+
+extern "C" int odx_split_f16_taps3x3(const float* Y, int64_t ldy, int64_t R, int H, int W, int C, void* P, int64_t ldp,
+                                     float* meta, odx_stream_t stream) {
+  ODX_REQUIRE(meta, "odx_split_f16_taps3x3: meta is null");
+  hipStream_t s = as_stream(stream);
+  ODX_CHECK_HIP(hipMemsetAsync(meta, 0, 2 * sizeof(float), s));
+  const int64_t n = R * H * W;
+  if (n <= 0) return ODX_OK;
+  ODX_REQUIRE(Y && P && H > 0 && W > 0 && C > 0 && C % 8 == 0 && ldy >= C && ldy % 4 == 0 && aligned16(Y),
+              "odx_split_f16_taps3x3: Y must be 16-byte aligned with ldy %% 4 == 0, ldy >= C, C %% 8 == 0");
+  const int D = 9 * C;
+  ODX_REQUIRE(ldp >= round_up(D, H2_KT) && ldp % 4 == 0 && aligned16(P), "odx_split_f16_taps3x3: P must be 16-byte aligned, ldp %% 4 == 0, ldp >= roundup(9 C, 64)");
+  ODX_REQUIRE(n < 65536ll * 32768, "odx_split_f16_taps3x3: too many rows");
+  const unsigned blocks = (unsigned)(ceil_div(n, 4) > 1024 ? 1024 : ceil_div(n, 4));
+  hipLaunchKernelGGL(absmax_f32_kernel, dim3(blocks), dim3(256), 0, s, Y, ldy, n, C, reinterpret_cast<unsigned int*>(meta + 1));
+  ODX_CHECK_LAUNCH("odx_split_f16_taps3x3(absmax)");
+  const int groups = (int)ceil_div(D, H2_KT) * 8;
+  for (int64_t r0 = 0; r0 < n; r0 += 65535) {            // rows ride on grid.y (<= 65535 per launch); the kernel takes
+    const int64_t nr = n - r0 < 65535 ? n - r0 : 65535;  // (h, w) from the global row index r0 + blockIdx.y
+    hipLaunchKernelGGL(split_f16_taps3x3_kernel, dim3((unsigned)ceil_div(groups, 256), (unsigned)nr), dim3(256), 0, s,
+                       Y, ldy, H, W, C, (uint32_t*)P, ldp, meta, r0);
+    ODX_CHECK_LAUNCH("odx_split_f16_taps3x3");
+  }
+  return ODX_OK;
+}
+
+extern "C" int odx_gemm_h2_f32(const void* PA, int64_t ldpa, const float* metaa, int64_t m, const void* PB, int64_t ldpb,
+                               const float* metab, int64_t n, int K, const float* bias, const float* residual, int64_t ldr,
+                               int relu, float* out, int64_t ldo, odx_stream_t stream) {
+  if (m <= 0 || n <= 0) return ODX_OK;
+  ODX_REQUIRE(PA && PB && metaa && metab && out && K > 0, "odx_gemm_h2_f32: bad argument");
+  const int64_t dp = round_up(K, H2_KT);
+  ODX_REQUIRE(ldpa % 4 == 0 && ldpb % 4 == 0 && ldpa >= dp && ldpb >= dp && aligned16(PA) && aligned16(PB),
+              "odx_gemm_h2_f32: packed operands must be 16-byte aligned with ld %% 4 == 0 and ld >= roundup(K, 64)");
+  ODX_REQUIRE(ldo >= n && (residual == nullptr || ldr >= n), "odx_gemm_h2_f32: ldo / ldr < n");
+  ODX_REQUIRE(ldpa < (1 << 24) && ldpb < (1 << 24), "odx_gemm_h2_f32: leading dimensions must stay below 2^24 (32-bit tile offsets)");
+  const int gr = 8;
+  const int64_t t256 = ceil_div(m, W_BM) * ceil_div(n, W_BN);
+  if (t256 >= 256) {           // the 256 x 256 core once it fills the chip (one workgroup per CU), else 128 x 128 tiles
+    const int64_t wt = round_up(ceil_div(m, W_BM), gr) * ceil_div(n, W_BN);
+    ODX_REQUIRE(wt < (1ll << 31), "odx_gemm_h2_f32: grid too large");
+    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2w256_kernel), W_LDS_BYTES));
+    hipLaunchKernelGGL(gemm_h2w256_kernel, dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
+                       (const uint32_t*)PA, ldpa, metaa, m, (const uint32_t*)PB, ldpb, metab, n, (int)(dp / W_KS), bias, residual,
+                       ldr, relu, out, ldo, gr);
+    ODX_CHECK_LAUNCH("odx_gemm_h2_f32(w256)");
+    return ODX_OK;
+  }
+  const int64_t tiles = round_up(ceil_div(m, GEMM_BM), gr) * ceil_div(n, GEMM_BN);
+  ODX_REQUIRE(tiles < (1ll << 31), "odx_gemm_h2_f32: grid too large");
+  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2s16_kernel)));
+  hipLaunchKernelGGL(gemm_h2s16_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), S16_LDS_BYTES, as_stream(stream),
+                     (const uint32_t*)PA, ldpa, metaa, m, (const uint32_t*)PB, ldpb, metab, n, (int)(dp / H2_KT), bias, residual,
+                     ldr, relu, out, ldo, gr);
+  ODX_CHECK_LAUNCH("odx_gemm_h2_f32");
   return ODX_OK;
 }
 

@@ -471,6 +471,53 @@ class HipBackend:
                                                  int(sampling_ratio), _p(out), self._stream()), "odx_roi_align_fwd_f32")
         return out
 
+    def packed(self, X):
+        """X (rows, K) f32 as a GEMM operand of gemm_h2: its packed two-term f16 split (no row norms)."""
+        X = X.to(device=self.device, dtype=torch.float32)
+        if X.stride(1) != 1 or X.stride(0) % 4 != 0 or X.data_ptr() % 16 != 0:
+            ld = (X.shape[1] + 3) // 4 * 4
+            buf = torch.zeros((X.shape[0], ld), dtype=torch.float32, device=self.device)
+            buf[:, :X.shape[1]] = X
+            X = buf[:, :X.shape[1]]
+        return self.pack(Features(X, None, X.shape[1]))
+
+    def packed_taps3x3(self, Y, R, H, W):
+        """The packed operand of a 3 x 3 convolution (padding 1) as a GEMM over the NHWC rows Y (R * H * W, C): K = 9 C,
+        tap after tap; written in the packed form directly (odx_split_f16_taps3x3)."""
+        C = Y.shape[1]
+        if C % 8 != 0 or Y.stride(1) != 1 or Y.stride(0) % 4 != 0 or Y.data_ptr() % 16 != 0 or Y.dtype != torch.float32:
+            yp = torch.nn.functional.pad(Y.reshape(R, H, W, C), (0, 0, 1, 1, 1, 1))
+            return self.packed(torch.cat([yp[:, ky:ky + H, kx:kx + W, :] for ky in range(3) for kx in range(3)], dim=3).reshape(R * H * W, 9 * C))
+        n, D = R * H * W, 9 * C
+        Fp = Features(Y, None, C)
+        Fp.n, Fp.D = n, D                              # the operand the GEMM sees; X stays the (n, C) source
+        Fp.P = torch.empty((n, (D + 63) // 64 * 64), dtype=torch.int32, device=self.device)
+        Fp.meta = torch.empty(2, dtype=torch.float32, device=self.device)
+        hip.check(self.lib.odx_split_f16_taps3x3(_p(Y), Y.stride(0), R, H, W, C, _p(Fp.P), Fp.P.stride(0), _p(Fp.meta), self._stream()),
+                  "odx_split_f16_taps3x3")
+        return Fp
+
+    def gemm_h2(self, A, B, bias=None, residual=None, relu=False):
+        """(m, n) f32 = act(A.X B.X' + bias + residual) for packed operands (`packed`): the f32 product at f32 accuracy on
+        the f16 matrix cores (odx_gemm_h2_f32)."""
+        m, n, K = A.n, B.n, A.D
+        if B.D != K:
+            raise ValueError("gemm_h2: inner dimensions differ (%d, %d)" % (K, B.D))
+        out = torch.empty((m, n), dtype=torch.float32, device=self.device)
+        if m == 0 or n == 0:
+            return out
+        if bias is not None:
+            bias = bias.to(device=self.device, dtype=torch.float32).contiguous()
+        ldr = 0
+        if residual is not None:
+            residual = residual.to(device=self.device, dtype=torch.float32)
+            if residual.stride(1) != 1:
+                residual = residual.contiguous()
+            ldr = residual.stride(0)
+        hip.check(self.lib.odx_gemm_h2_f32(_p(A.P), A.P.stride(0), _p(A.meta), m, _p(B.P), B.P.stride(0), _p(B.meta), n, K,
+                                           _p(bias), _p(residual), ldr, int(bool(relu)), _p(out), n, self._stream()), "odx_gemm_h2_f32")
+        return out
+
     def roi_align_rows(self, feat, rois, spatial_scale, output_size, sampling_ratio=0, step=2):
         """RoIAlign for a head that starts with a stride-`step` 1 x 1 convolution: the bins that convolution reads only,
         as an (R * OH * OW, C) row matrix (NHWC).  Returns (rows, (R, OH, OW))."""

@@ -249,6 +249,32 @@ def _addmm_relu(bias, x, w):
     return torch.addmm(bias, x, w).relu_()
 
 
+def _bottleneck_rows_h2(be, blk, x, R, H, W):
+    """The f32 form of _bottleneck_rows on the split-f16 tile cores (odx_gemm_h2_f32: f32 accuracy on the f16 matrix cores,
+    243-317 TF on these shapes against 95-117 TF for the f32 MFMA GEMMs): folded weights packed once per layer, every
+    activation matrix packed once (the block's input serves conv1 and the projection), bias / identity / ReLU in the
+    GEMM's epilogue."""
+    def wpack(key, conv, bn, taps=False):
+        c = blk._folded.get((key + "/h2", torch.float32))
+        if c is None:
+            w, b = blk._fold(key, conv, bn, x)
+            w = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1) if taps else w.reshape(w.shape[0], -1)     # (out, ky kx in)
+            c = blk._folded[(key + "/h2", torch.float32)] = (be.packed(w.float().contiguous()), b.float().contiguous())
+        return c
+    xp = be.packed(x)
+    if blk.down is None:
+        idn = x
+    else:
+        wd, bd = wpack("down", blk.down[0], blk.down[1])
+        idn = be.gemm_h2(xp, wd, bias=bd)
+    w1, b1 = wpack("conv1", blk.conv1, blk.bn1)
+    y = be.gemm_h2(xp, w1, bias=b1, relu=True)
+    w2, b2 = wpack("conv2", blk.conv2, blk.bn2, taps=True)
+    y = be.gemm_h2(be.packed_taps3x3(y, R, H, W), w2, bias=b2, relu=True)       # the 9-tap gather exists in packed form only
+    w3, b3 = wpack("conv3", blk.conv3, blk.bn3)
+    return be.gemm_h2(be.packed(y), w3, bias=b3, residual=idn, relu=True)
+
+
 def _bottleneck_rows(blk, x, R, H, W):
     """One Bottleneck on activations kept as a (R * H * W, C) row matrix (NHWC): the 1 x 1 convolutions ARE matrix products
     over those rows and the 3 x 3 one is a product over a 9-tap gather of them, so the block is three (four with the
@@ -256,6 +282,10 @@ def _bottleneck_rows(blk, x, R, H, W):
     maps (74 TF in f32 for the whole head; the same products as GEMMs run at 95-117 TF).  A stride (always in the 1 x 1
     convolutions here, STRIDE_IN_1X1) is applied by the caller: x holds the rows of the positions that survive it."""
     dt = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled("cuda")) else blk.conv1.weight.dtype
+    if x.is_cuda and dt == torch.float32 and x.dtype == torch.float32:
+        be = _backend.get_backend()
+        if hasattr(be, "gemm_h2"):
+            return _bottleneck_rows_h2(be, blk, x, R, H, W)
 
     def mat(key, conv, bn, taps=False):
         c = blk._folded.get((key + "/rows", dt))

@@ -82,6 +82,8 @@ SIGNATURES = {
     "odx_rls_solve_batched_f64": (_i32, [_vp, _i64, _i64, _i32, _i32, _f64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
     "odx_rls_predict_rows_f64": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "odx_roi_align_fwd_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _f32, _i32, _i32, _i32, _vp, _vp]),
+    "odx_split_f16_taps3x3": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "odx_gemm_h2_f32": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
     "odx_roi_align_rows_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _f32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "odx_nms_workspace_bytes": (_i64, [_i32]),
     "odx_nms_f32": (_i32, [_vp, _i32, _f32, _vp, _vp, _i64, _vp]),

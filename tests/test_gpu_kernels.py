@@ -595,3 +595,41 @@ def test_cg_loop_in_one_call_equals_the_loop_issued_from_python(be, n, M, D, max
     a = odx.falkon_fit(be, F, be.vec(y), Zf, 10.0, 1e-5, maxiter)
     b = odx.falkon_fit(be, F, be.vec(y), Zf, 10.0, 1e-5, maxiter, phase=lambda name: Null())
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("m,n,K", [(300, 70, 96), (1000, 512, 1024), (513, 257, 200), (4100, 2048, 512), (1, 1, 64)])
+def test_split_f16_gemm_with_bias_residual_relu(m, n, K):
+    """odx_gemm_h2_f32 (the Gaussian kernels' split tile cores as a plain product with an epilogue) against an f64
+    product: f32-level accuracy; bias, residual and ReLU combinations; both tile cores (the large case takes the 256 x 256 one)."""
+    import odx
+    be = odx.get_backend()
+    g = torch.Generator().manual_seed(m + n + K)
+    A = torch.randn((m, K), generator=g).cuda() * 3
+    B = torch.randn((n, K), generator=g).cuda() * 0.2
+    bias = torch.randn(n, generator=g).cuda()
+    res = torch.randn((m, n), generator=g).cuda()
+    Ap, Bp = be.packed(A), be.packed(B)
+    ref = A.double() @ B.double().t()
+    scale = float(ref.abs().max()) + 1e-30
+    for kw in ({}, {"bias": bias}, {"bias": bias, "relu": True}, {"bias": bias, "residual": res, "relu": True}, {"residual": res}):
+        want = ref + (kw["bias"].double() if "bias" in kw else 0) + (kw["residual"].double() if "residual" in kw else 0)
+        if kw.get("relu"):
+            want = want.clamp(min=0)
+        got = be.gemm_h2(Ap, Bp, **kw)
+        assert float((got.double() - want).abs().max()) < 3e-6 * scale + 1e-6, (kw.keys(), float((got.double() - want).abs().max()), scale)
+
+
+@pytest.mark.parametrize("R,H,W,C", [(5, 7, 7, 64), (3, 4, 9, 8), (1, 1, 1, 16), (2200, 6, 5, 8)])
+def test_packed_3x3_taps_equal_the_split_of_the_gathered_matrix(R, H, W, C):
+    """odx_split_f16_taps3x3 writes the packed operand of a 3 x 3 convolution-as-GEMM directly; same packed words and scale
+    as odx_split_f16 applied to the explicitly gathered (rows, 9 C) matrix (the last case spans several launches of
+    65535 rows)."""
+    import odx
+    be = odx.get_backend()
+    g = torch.Generator().manual_seed(R + H + W + C)
+    Y = torch.randn((R * H * W, C), generator=g).cuda()
+    yp = torch.nn.functional.pad(Y.view(R, H, W, C), (0, 0, 1, 1, 1, 1))
+    cols = torch.cat([yp[:, ky:ky + H, kx:kx + W, :] for ky in range(3) for kx in range(3)], dim=3).reshape(R * H * W, 9 * C).contiguous()
+    a, b = be.packed_taps3x3(Y, R, H, W), be.packed(cols)
+    assert a.n == b.n and a.D == b.D == 9 * C
+    assert torch.equal(a.meta, b.meta) and torch.equal(a.P[:, : b.P.shape[1]], b.P)
