@@ -559,9 +559,10 @@ class OnlineFeatureExtractor:
     `parts` selects what is harvested: any of "rpn", "detector", "mask"."""
 
     def __init__(self, model, num_classes, parts=("rpn", "detector"), det=None, rpn=None, mask=None, rank=0, world=1,
-                 pipeline=True):
+                 pipeline=True, trunk_batch=2):
         self.model, self.C, self.parts, self.rank, self.world = model, num_classes, tuple(parts), rank, world
         self.pipeline = pipeline        # on a GPU: forward of the next image on a second thread / stream while this one is harvested
+        self.trunk_batch = trunk_batch  # on a GPU: consecutive images of one size share a trunk call (1 = one image per call)
         self.det_kw = dict(iterations=10, batch_size=2000, neg_iou_thresh=0.3, reg_min_overlap=0.6, shuffle_negatives=False)
         self.rpn_kw = dict(iterations=10, batch_size=2000, neg_iou_thresh=0.3, pos_iou_thresh=0.7, shuffle_negatives=False)
         self.mask_kw = dict(batch_size=20000, sampling_factor=0.3)
@@ -580,15 +581,17 @@ class OnlineFeatureExtractor:
         hv_rpn = RPNHarvester(m.backbone.out_channels, m.cells.shape[0], num_images=n, device=dev, **self.rpn_kw) if "rpn" in self.parts else None
         hv_mask = MaskHarvester(m.mask_dim, self.C, device=dev, **self.mask_kw) if "mask" in self.parts else None
 
-        def forward_one(sample):
+        def forward_one(sample, c4=None):
             """Everything of an image that does not depend on the harvesters' state: trunk, RPN activation, proposals
-            (+ ground truth), head maps, mask activation."""
+            (+ ground truth), head maps, mask activation.  c4: the image's trunk features when they were computed with a
+            neighbour's (forward_items)."""
             image, gt_boxes, gt_labels, masks = _unpack(sample)
             image, gt_boxes = image.to(dev), gt_boxes.to(dev).float()
             img_size = (image.shape[3], image.shape[2])
             item = {"gt_boxes": gt_boxes, "gt_labels": list(gt_labels), "img_size": img_size}
             with torch.no_grad():
-                c4 = m.c4(image)
+                if c4 is None:
+                    c4 = m.c4(image)
                 if hv_rpn is not None and len(gt_boxes):
                     item["anchors"] = grid_anchors(c4.shape[2], c4.shape[3], m.stride, m.cells.to(dev))
                     item["t"] = m.rpn_activation(c4)[0]
@@ -605,6 +608,27 @@ class OnlineFeatureExtractor:
                     item["act"] = m.mask_activation(maps[:len(gt_labels)])
                     item["mg"] = project_masks_on_boxes(masks.to(dev), gt_boxes, item["act"].shape[2])
             return item
+
+        def forward_items(seq):
+            """forward_one for every sample, in order; consecutive images of one size go through the trunk together
+            (`trunk_batch` at a time): at batch 1 the trunk is 53 latency-bound library calls (1.6-1.9 ms for 64 GFLOP),
+            two images cost 2.4 ms.  Everything behind the trunk stays per image."""
+            k = max(1, int(self.trunk_batch)) if dev.type == "cuda" else 1
+            i = 0
+            while i < len(seq):
+                group = [seq[i]]
+                if k > 1:
+                    shape = tuple(_unpack(seq[i])[0].shape)
+                    while len(group) < k and i + len(group) < len(seq) and tuple(_unpack(seq[i + len(group)])[0].shape) == shape:
+                        group.append(seq[i + len(group)])
+                if len(group) == 1:
+                    yield forward_one(group[0])
+                else:
+                    with torch.no_grad():
+                        c4s = m.c4(torch.cat([_unpack(smp)[0].to(dev) for smp in group], dim=0))
+                    for j, smp in enumerate(group):
+                        yield forward_one(smp, c4s[j:j + 1])
+                i += len(group)
 
         def harvest_one(item):
             """The stateful part, in image order: RNG draws, batch bookkeeping, rows into the buffers."""
@@ -641,10 +665,9 @@ class OnlineFeatureExtractor:
                 try:
                     torch.cuda.set_device(dev)
                     with torch.cuda.stream(fwd):
-                        for sample in samples:
+                        for item in forward_items(samples):
                             if stop.is_set():
                                 return
-                            item = forward_one(sample)
                             ev = torch.cuda.Event()
                             ev.record(fwd)
                             if not put((item, ev)):
@@ -672,8 +695,8 @@ class OnlineFeatureExtractor:
                 th.join()
                 fwd.synchronize()
         else:
-            for sample in samples:
-                harvest_one(forward_one(sample))
+            for item in forward_items(samples):
+                harvest_one(item)
         out = {}
         if save_dir:
             from . import storage

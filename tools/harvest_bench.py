@@ -42,8 +42,8 @@ def main():
             masks[j, y1 + 10:y2 - 10, x1 + 10:x2 - 10] = 1
         samples.append((img.to(dev), boxes.to(dev), labels, masks.to(dev)))
 
-    def run(parts, pipeline=True):
-        ex = OnlineFeatureExtractor(model, C, parts=parts, pipeline=pipeline)
+    def run(parts, pipeline=True, tb=2):
+        ex = OnlineFeatureExtractor(model, C, parts=parts, pipeline=pipeline, trunk_batch=tb)
         torch.manual_seed(0)
         ex.train(samples[:3])                 # warm-up
         ts = []
@@ -67,8 +67,8 @@ def main():
         fwd = (time.perf_counter() - t0) / len(samples) * 1e3
     print("forward alone: %.2f ms per image" % fwd)
     for parts in (("detector",), ("rpn",), ("rpn", "detector"), ("rpn", "detector", "mask")):
-        print("forward + harvest %s: %.2f ms per image (median of 3: %.2f); without the forward / harvest pipeline: %.2f" % (
-            ("+".join(parts),) + run(parts) + (run(parts, False)[0],)))
+        print("forward + harvest %s: %.2f ms per image (median of 3: %.2f); one image per trunk call: %.2f; without the forward / harvest pipeline: %.2f" % (
+            ("+".join(parts),) + run(parts) + (run(parts, True, 1)[0], run(parts, False)[0],)))
 
 
 if __name__ == "__main__":
