@@ -219,7 +219,7 @@ def main():
     n_loc = hi - lo
     seed = 1234 + 3
     X = synth_rows(lo, hi, D, C, seed, device)
-    F = be.features(X)
+    F = None                                       # kernel operands of X (row norms, packed f16 split): derived inside every step
     row_ids = torch.arange(lo, hi, device=device)
     cidx = centre_indices(N, C, M, seed)
     cidx_dev = [torch.from_numpy(i).to(device) for i in cidx]     # inputs of the job: resident before the timed region
@@ -228,7 +228,7 @@ def main():
     scores = torch.empty((n_loc, C), dtype=torch.float32, device=device)
     opt = SolverOptions(check_pivots=False)       # no host sync inside the timed region: every status is read after it
     infos = []                                    # Cholesky status words of every preconditioner built in the timed region
-    ph = {k: Phase() for k in ("knm", "ktk", "precond", "mmv")}
+    ph = {k: Phase() for k in ("knm", "ktk", "ktk2", "precond", "mmv")}
 
     def gather_centres(idx):
         """Z = X_global[idx]: every rank contributes the rows it owns, one all-reduce sums them."""
@@ -366,6 +366,7 @@ def main():
 
     # ---- warm-up (untimed): a few classes are enough to touch every kernel and allocation
     for _ in range(args.warmup):
+        F = be.features(X)
         run_classes(list(range(min(max(args.warmup_classes, world), C))), False)
     barrier()
 
@@ -391,7 +392,7 @@ def main():
     t0 = time.perf_counter()
     last = None
     for _ in range(args.steps):
-        F.P = F.meta = None      # the packed f16 split of X is derived data: rebuilt inside every timed step
+        F = be.features(X)       # row norms now, the packed f16 split at the first Gaussian launch: derived data, inside the step
         last = run_classes(list(range(C)), True)
     barrier()
     dt = time.perf_counter() - t0
@@ -414,50 +415,60 @@ def main():
     healthy = health["failed_choleskys"] == 0 and health["ranks_with_nonfinite_scores"] == 0
 
     if rank == 0:
-        # the Gaussian MFMA contraction (K_nM build + fused scoring)
+        # Two kernel families, each with its own roofline object under a fixed key, compared family against family:
+        #   roofline_hbm   the CG passes over the stored K_nM: knm_pass_kernel (one vector) and knm_pass2_kernel (two vectors
+        #                  from one read; one launch per class), each also reported on its own
+        #   roofline_mfma  the Gaussian contraction: K_nM build + fused scoring (one tile core, two kernels)
+        # `roofline` is the family that took more device time in THIS run's timed region.
         gauss_ms = ph["knm"].total_ms() + ph["mmv"].total_ms()
         gauss_launches = ph["knm"].count() + ph["mmv"].count()
         flops_per_launch = 2.0 * n_loc * M * D
-        ktk_ms = ph["ktk"].total_ms()
-        ktk_launches = ph["ktk"].count()
+        p1_ms, p1_n = ph["ktk"].total_ms(), ph["ktk"].count()
+        p2_ms, p2_n = ph["ktk2"].total_ms(), ph["ktk2"].count()
+        pass_ms, pass_launches = p1_ms + p2_ms, p1_n + p2_n
         bytes_per_pass = float(n_loc) * M * 4
-        # `roofline` is the dominant KERNEL's: the CG pass (one kernel, a third of the GPU time) unless one of the two
-        # Gaussian kernels alone outweighs it; the Gaussian pair (build + fused scoring, one tile core) follows as the
-        # second family.  (Comparing the pair's sum against the pass made the primary object flip between boxes: the sum
-        # is within 4 % of the passes' time and moves with the clock the chip holds under MFMA load.)
-        dom_gauss = max(ph["knm"].total_ms(), ph["mmv"].total_ms()) >= ktk_ms
         gach = flops_per_launch * gauss_launches / max(gauss_ms * 1e-3, 1e-12) / 1e12
+
+        def per_kernel(ms, cnt, unit_work, scale):
+            return {"launches": cnt, "avg_launch_ms": round(ms / max(cnt, 1), 3),
+                    "achieved": round(unit_work * cnt / max(ms * 1e-3, 1e-12) / scale, 2)} if cnt else None
         if be.gauss == "h2":
             # algorithmic flops (2 n M D) against the dense f16 MFMA peak; the two-term split issues 3 f16 MFMAs per
             # algorithmic product, so this formulation's own ceiling is peak / 3 (frac_of_split_ceiling)
             core = "h2w256" if be.lib.odx_gauss_h2_tile(n_loc, M) == 256 else "h2s16"
-            roof_g = {"bound": "mfma", "kernel": "gauss_knm_%s_kernel+gauss_mmv_%s_kernel" % (core, core), "achieved": round(gach, 2),
-                      "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gach / F16_MFMA_PEAK_TFLOPS, 4),
-                      "frac_of_split_ceiling": round(3 * gach / F16_MFMA_PEAK_TFLOPS, 4),
-                      "traffic": None, "avg_launch_ms": round(gauss_ms / max(gauss_launches, 1), 3)}
+            gk = ("gauss_knm_%s_kernel" % core, "gauss_mmv_%s_kernel" % core)
+            gpeak = F16_MFMA_PEAK_TFLOPS
         else:
-            roof_g = {"bound": "mfma", "kernel": "gauss_knm_f32_kernel+gauss_mmv_f32_kernel", "achieved": round(gach, 2),
-                      "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(gach / F32_MFMA_PEAK_TFLOPS, 4),
-                      "traffic": None, "avg_launch_ms": round(gauss_ms / max(gauss_launches, 1), 3)}
-        pach = bytes_per_pass * ktk_launches / max(ktk_ms * 1e-3, 1e-12) / 1e9
-        roof_p = {"bound": "hbm", "kernel": "knm_pass_kernel", "achieved": round(pach, 1), "peak": HBM_PEAK_GBS,
-                  "unit": "GB/s", "frac": round(pach / HBM_PEAK_GBS, 4), "traffic": None,
-                  "avg_launch_ms": round(ktk_ms / max(ktk_launches, 1), 3)}
+            gk = ("gauss_knm_f32_kernel", "gauss_mmv_f32_kernel")
+            gpeak = F32_MFMA_PEAK_TFLOPS
+        roof_g = {"bound": "mfma", "kernel": "+".join(gk), "achieved": round(gach, 2), "peak": gpeak, "unit": "TFLOP/s",
+                  "frac": round(gach / gpeak, 4), "traffic": None, "avg_launch_ms": round(gauss_ms / max(gauss_launches, 1), 3),
+                  "family_ms_per_step": round(gauss_ms / args.steps, 2),
+                  "per_kernel": {gk[0]: per_kernel(ph["knm"].total_ms(), ph["knm"].count(), flops_per_launch, 1e12),
+                                 gk[1]: per_kernel(ph["mmv"].total_ms(), ph["mmv"].count(), flops_per_launch, 1e12)}}
+        if be.gauss == "h2":
+            roof_g["frac_of_split_ceiling"] = round(3 * gach / gpeak, 4)
+        pach = bytes_per_pass * pass_launches / max(pass_ms * 1e-3, 1e-12) / 1e9
+        roof_p = {"bound": "hbm", "kernel": "knm_pass_kernel" + ("+knm_pass2_kernel" if p2_n else ""), "achieved": round(pach, 1),
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pach / HBM_PEAK_GBS, 4), "traffic": None,
+                  "avg_launch_ms": round(pass_ms / max(pass_launches, 1), 3), "family_ms_per_step": round(pass_ms / args.steps, 2),
+                  "per_kernel": {"knm_pass_kernel": per_kernel(p1_ms, p1_n, bytes_per_pass, 1e9),
+                                 "knm_pass2_kernel": per_kernel(p2_ms, p2_n, bytes_per_pass, 1e9)}}
         if alone_gbps is not None:
             roof_p["achieved_alone"] = round(alone_gbps, 1)
             roof_p["frac_alone"] = round(alone_gbps / HBM_PEAK_GBS, 4)
-            roof_p["note"] = ("achieved: over the timed region, where %d CUs are left to the preconditioner stream and the pass "
-                              "shares HBM with it; achieved_alone: same kernel, same buffer, idle GPU, before the timed region"
-                              % args.reserve_cus)
-        roof, roof2 = (roof_g, roof_p) if dom_gauss else (roof_p, roof_g)     # dominant family first
+            roof_p["note"] = ("achieved: K_nM bytes of all pass launches / their device time over the timed region (a two-vector "
+                              "launch counts its ONE read of K_nM), where %d CUs are left to the preconditioner stream; "
+                              "achieved_alone: knm_pass_kernel, same buffer, idle GPU, before the timed region" % args.reserve_cus)
         if (n_loc, M, D) == (1_000_000, 10_000, 1024):
-            for r in (roof, roof2):
+            for r in (roof_g, roof_p):
                 r["traffic"], r["traffic_unit"] = profiled_traffic_gb(r["kernel"])
+        roof = roof_g if gauss_ms >= pass_ms else roof_p          # the family with more device time in this run
         phases = {k: round(v.total_ms() / args.steps, 2) for k, v in ph.items()}
         # the preconditioners run on side streams beside everything else: this is first-to-last-kernel time, not GPU time
         phases["precond_side_stream_span"] = phases.pop("precond")
-        phases["ktk_GBps"] = round(bytes_per_pass * ktk_launches / max(ktk_ms * 1e-3, 1e-9) / 1e9, 1)
-        phases["gauss_TFLOPs"] = round(flops_per_launch * gauss_launches / max(gauss_ms * 1e-3, 1e-9) / 1e12, 2)
+        phases["pass_GBps"] = round(pach, 1)
+        phases["gauss_TFLOPs"] = round(gach, 2)
         out = {
             "metric": "FALKON fit+infer samples/sec (N=1e6 D=1024 M=1e4)",
             "value": round(value, 1), "unit": "samples/s", "n_gpus": ranks_seen, "ranks": ranks_seen, "steps": args.steps,
@@ -470,7 +481,8 @@ def main():
                        "N": N, "D": D, "M": M, "classes": C, "sigma": args.sigma, "lambda": args.lam,
                        "rows_per_gpu": n_loc, "preconditioners_per_batched_chain": G},
             "roofline": roof,
-            "roofline_second_family": roof2,
+            "roofline_hbm": roof_p,
+            "roofline_mfma": roof_g,
             "phases_ms_per_step_rank0": phases,
             "health": health,
         }

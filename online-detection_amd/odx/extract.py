@@ -66,6 +66,17 @@ def decode_deltas(deltas, boxes, clamp=math.log(1000.0 / 16)):
     return torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw - 1, pcy + 0.5 * ph - 1), dim=1)
 
 
+def _nms_takes_max_keep(be):
+    """Whether the backend's nms has the early-stopping contract (max_keep / sorted_desc) — asked of its signature, so
+    that a TypeError raised INSIDE a backend's nms is never mistaken for a missing keyword."""
+    import inspect
+    try:
+        params = inspect.signature(be.nms).parameters
+    except (TypeError, ValueError):
+        return False
+    return "max_keep" in params and "sorted_desc" in params
+
+
 def rpn_proposals(objectness, box_regression, anchors, img_size, pre_nms_top_n=6000, post_nms_top_n=300,
                   nms_thresh=0.7, min_size=0):
     """RPNPostProcessor.forward_for_single_feature_map (rpn/inference.py:76-123) for one image:
@@ -88,9 +99,9 @@ def rpn_proposals(objectness, box_regression, anchors, img_size, pre_nms_top_n=6
         boxes, score = boxes[ok], score[ok]
     # top-k hands the candidates over in descending score order, and only the first post_nms_top_n survivors are used:
     # no second sort, and the suppression stops at the last one it needs (a few hundred of the 6000 candidates in)
-    try:
+    if _nms_takes_max_keep(be):
         keep = be.nms(boxes, score, nms_thresh, max_keep=post_nms_top_n, sorted_desc=True)
-    except TypeError:            # a backend with the plain contract (tests' oracle backend)
+    else:                        # a backend with the plain contract (tests' oracle backend)
         keep = be.nms(boxes, score, nms_thresh)[:post_nms_top_n]
     return boxes[keep], score[keep]
 
@@ -562,7 +573,11 @@ class OnlineFeatureExtractor:
                  pipeline=True, trunk_batch=2):
         self.model, self.C, self.parts, self.rank, self.world = model, num_classes, tuple(parts), rank, world
         self.pipeline = pipeline        # on a GPU: forward of the next image on a second thread / stream while this one is harvested
-        self.trunk_batch = trunk_batch  # on a GPU: consecutive images of one size share a trunk call (1 = one image per call)
+        # on a GPU: consecutive images of one size share a trunk call (1 = one image per call).  With > 1 a harvested row
+        # depends, in its last bits, on the image's neighbour in the list and on the rank sharding (the convolution library
+        # picks its algorithm per batch size) and differs in rounding from detect() / forward(), which see one image:
+        # trunk_batch = 1 (cfg_options['trunk_batch'] of the facade) is the per-image bit-reproducible setting
+        self.trunk_batch = trunk_batch
         self.det_kw = dict(iterations=10, batch_size=2000, neg_iou_thresh=0.3, reg_min_overlap=0.6, shuffle_negatives=False)
         self.rpn_kw = dict(iterations=10, batch_size=2000, neg_iou_thresh=0.3, pos_iou_thresh=0.7, shuffle_negatives=False)
         self.mask_kw = dict(batch_size=20000, sampling_factor=0.3)

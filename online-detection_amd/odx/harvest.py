@@ -147,7 +147,10 @@ class _SlotGrid:
         src = np.repeat(np.asarray(self.src, dtype=np.int64), ks) + ramp
         self.dst, self.src = [], []
         idx = torch.from_numpy(np.stack((dst, src))).to(rows.device, non_blocking=True)     # one host -> device copy
-        self.store.view(-1, self.D).index_copy_(0, idx[0], rows.index_select(0, idx[1]))
+        # the rows take the store's dtype / device here (f64 or f16 features, features of another device): index_copy_
+        # itself accepts neither, and by now `plan` has already counted the rows
+        picked = rows.index_select(0, idx[1]).to(device=self.store.device, dtype=self.store.dtype)
+        self.store.view(-1, self.D).index_copy_(0, idx[0].to(self.store.device), picked)
 
 
 def clamp_boxes_(b, img_size):

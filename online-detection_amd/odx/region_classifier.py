@@ -27,6 +27,22 @@ def _device():
     return 'cuda' if torch.cuda.is_available() else 'cpu'
 
 
+def _randint_advances_one_draw_per_value(g, shape):
+    """Whether `torch.randint(bound, (size,))` leaves a CPU generator where `torch.randint(2, (size,))` leaves it, for the
+    (positive bound, positive draws, negative bound, negative draws) a fit of the stock index rule makes: the property
+    `_reference_stream_positions` predicts every class's position in the global stream with (true for bounds below 2^24
+    on the torch builds seen; undocumented, hence asked of the running build).  Works on clones; `g` is not advanced."""
+    pos_bound, pos_draw, neg_bound, room = shape
+    a, b = torch.Generator(), torch.Generator()
+    a.set_state(g.get_state())
+    b.set_state(g.get_state())
+    if pos_draw:
+        torch.randint(int(pos_bound), (int(pos_draw),), generator=a)
+    torch.randint(int(neg_bound), (int(room),), generator=a)
+    torch.randint(2, (int(pos_draw) + int(room),), generator=b)
+    return bool(torch.equal(a.get_state(), b.get_state()))
+
+
 class OnlineRegionClassifierBase:
     incore = True
 
@@ -354,6 +370,7 @@ class OnlineRegionClassifierBase:
         g = torch.Generator()
         g.set_state(torch.get_rng_state())
         states, rooms = {}, {}
+        checked = set()
         for i in range(self.num_classes - 1):
             if len(positives[i]) == 0 or len(negatives[i]) == 0:
                 continue
@@ -366,6 +383,14 @@ class OnlineRegionClassifierBase:
             count = len(negatives[i]) * (pos_draw + max(rooms[i], 0))
             if rooms[i] <= 0:
                 return None
+            # run-time self-check of the consumption model (once per distinct draw shape): this torch build must advance
+            # the generator by exactly `size` draws of randint(2, ..) for the bounds and sizes this class will use —
+            # otherwise every later class would silently start at a wrong position; the plain loop is the answer then
+            shape = (n_pos if pos_draw else 0, pos_draw, max(len(b) for b in negatives[i]) + 1, rooms[i])
+            if shape not in checked:
+                if not _randint_advances_one_draw_per_value(g, shape):
+                    return None
+                checked.add(shape)
             if count:
                 torch.randint(2, (count,), generator=g)
         return states, rooms, g.get_state()

@@ -76,7 +76,7 @@ class RegionRefinerTrainer:
         start_time = time.time()
         Cl = Call.to(torch.int64)
         order = torch.argsort(Cl, stable=True)
-        counts_all = torch.bincount(Cl.clamp(min=0), minlength=num_clss)[:num_clss].tolist()     # the one host read of the sizes
+        counts_all = torch.bincount(Cl[Cl >= 0], minlength=num_clss)[:num_clss].tolist()     # the one host read of the sizes (negative labels belong to no class)
         first = {}
         acc = int((Cl < 0).sum().item()) if Cl.numel() and bool((Cl < 0).any()) else 0
         for c in range(num_clss):

@@ -93,7 +93,8 @@ def falkon_fit(be, F, y, Zf, sigma, lam, maxiter=20, opt=None, n_total=None, all
               precond=None and never build one.  Without `shard` every rank does everything
               (replicated mode) and only `allreduce` is used.
     phase     optional callable name -> context manager bracketing the launches of one kernel
-              family ("precond", "knm", "ktk"); bench.py hangs HIP-event timers on it
+              ("precond", "knm", "ktk" = the one-vector pass, "ktk2" = the two-vector pass); bench.py hangs
+              HIP-event timers on it
     precond   an already computed preconditioner for (Zf, sigma, lam) to reuse
     precond_ready
               optional callable invoked once, right before the preconditioner is first applied
@@ -159,7 +160,7 @@ def falkon_fit(be, F, y, Zf, sigma, lam, maxiter=20, opt=None, n_total=None, all
             be.trmv(P, "LAit", s2, out=v2)
             be.trmv(P, "LTit", v2, out=t2)
         bcast(tt2)
-        with ph("ktk"):
+        with ph("ktk2"):
             c1, c2 = be.ktk2(K, t1, t2)
         cc2 = torch.stack((c1, c2))
         ar(cc2)
@@ -299,7 +300,7 @@ def falkon_fit_lockstep(be, F, ys, Zfs, sigma, lam, maxiter=20, opt=None, n_tota
             be.trmv(P, "LTit", v2, out=tbuf2[Mp:Mp + M])
         shard.gather_rows(tbuf2, Tall2)
         for b in range(B):
-            with ph("ktk"):
+            with ph("ktk2"):
                 be.ktk2(Ks[b], Tall2[b, :M], Tall2[b, Mp:Mp + M], out1=CC2[b, :M], out2=CC2[b, Mp:Mp + M])
         shard.reduce_scatter_rows(CC2, ccbuf2)
         if owned:

@@ -53,12 +53,14 @@ def rls_extra(n=300_000, D=1024, C=30, lam=1000.0, cpu=True):
         from oracle import rls_ref
         I = torch.where(cls == 1)[0]
         Xh, Yh = X[I].cpu().numpy(), Y[I].cpu().numpy()
-        t0 = time.perf_counter()
-        ref = rls_ref.train_class(Xh, Yh, lam)
-        dtc = time.perf_counter() - t0
+        dtc = None
+        for _ in range(3):                              # a cold first call (BLAS threads, page faults) read 6 x slower once
+            t0 = time.perf_counter()
+            ref = rls_ref.train_class(Xh, Yh, lam)
+            dtc = min(time.perf_counter() - t0, dtc or 1e9)
         W = torch.stack([models[0]["Beta"][str(k)]["weights"] for k in range(4)]).cpu().numpy()
         out["cpu_baseline"] = {"value": round(1.0 / dtc, 2), "unit": "regressors/s", "kind": "port", "cores": int(torch.get_num_threads()),
-                               "sample": "oracle/rls_ref.py (numpy/scipy f64) on 1 class of %d rows in %.2f s" % (len(I), dtc)}
+                               "sample": "oracle/rls_ref.py (numpy/scipy f64) on 1 class of %d rows in %.2f s (best of 3)" % (len(I), dtc)}
         out["max_abs_weight_diff_vs_oracle_class1"] = float(np.abs(W - ref["W"]).max())
     return out
 
@@ -159,6 +161,158 @@ def minibootstrap_extra(C=30, D=2048, IT=10, positives=800, sigma=15.0, modes=((
     return out
 
 
+F16_MFMA_PEAK_TFLOPS = 2500.0   # same guide: dense f16 / bf16 MFMA
+F8_MFMA_PEAK_TFLOPS = 5000.0    # same guide: dense fp8 MFMA (MX-scaled K = 128 forms)
+HBM_PEAK_GBS = 8000.0
+
+
+def _blob_rows(n, D, C, seed, device):
+    """Rows of C class blobs (row i of class i % C), normalised with the reference rule (OnlineRegionClassifier.py:224-227)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    mu = torch.randn((C, D), generator=g, device=device)
+    X = torch.empty((n, D), dtype=torch.float32, device=device)
+    for b0 in range(0, n, 131072):
+        b1 = min(n, b0 + 131072)
+        X[b0:b1] = mu[torch.arange(b0, b1, device=device) % C] + 0.7 * torch.randn((b1 - b0, D), generator=g, device=device)
+    X -= mu.mean(0)
+    X *= 20.0 / torch.sqrt(((mu - mu.mean(0)) ** 2).sum(1) + 0.49 * D).mean()
+    return X
+
+
+def _centre_indices(y, M, rng):
+    """The reference's Nystroem index rule (FALKONWrapper_with_centers_selection_incore.py:87-99) on host labels: all
+    positives when there are at most M // 2, else M // 2 of them drawn with replacement; negatives fill up to M the same
+    way; positives first."""
+    pos, neg = np.flatnonzero(y == 1), np.flatnonzero(y == -1)
+    half = M // 2
+    p = pos[rng.integers(0, len(pos), half)] if len(pos) > half else pos
+    room = M - len(p)
+    q = neg[rng.integers(0, len(neg), room)] if len(neg) > room else neg
+    return np.concatenate([p, q]).astype(np.int64)
+
+
+def _events_ms(fn, reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def falkon_config_extra(name, C, n, D, M, sigma, lam, classes_run, labels="one_vs_rest", seed=1234, maxiter=20):
+    """One BASELINE config's FALKON leg on this GPU: `classes_run` of its C classes fitted (Nystroem centres by the
+    reference rule, class-batched preconditioner chain, K_nM build with the fused right-hand side, the CG loops of the
+    classes in lock step) and every row scored with each model.  Reports the config's metric (rows / seconds for ALL C
+    classes, extrapolated from the classes run when fewer) and, per kernel family, the rate of ONE launch at this shape
+    measured on its own against its roofline (F_K = 2 n M D flop, B_CG = n M s_K bytes per pass)."""
+    import odx
+    from odx.solver import SolverOptions
+    be = odx.get_backend()
+    dev = be.device
+    rows_c = 2 if labels == "pixels" else C
+    X = _blob_rows(n, D, rows_c, seed, dev)
+    rng = np.random.default_rng(seed)
+    ids = torch.arange(n, device=dev) % rows_c
+    opt = SolverOptions(check_pivots=False)
+    run = list(range(classes_run))
+
+    def labels_of(c):
+        if labels == "pixels":          # foreground / background pixels of class c's own boxes, 5 % label noise
+            g = torch.Generator(device=dev).manual_seed(seed + 17 * c)
+            y = torch.where(ids == 0, 1.0, -1.0)
+            return torch.where(torch.rand(n, generator=g, device=dev) < 0.05, -y, y).to(torch.float64)
+        return torch.where(ids == c, 1.0, -1.0).to(torch.float64)
+
+    def job():
+        F = be.features(X)
+        scores = torch.empty((n, len(run)), dtype=torch.float32, device=dev)
+        group = max(1, min(len(run), be.MAX_CLASS_BATCH, int(8e9 // (4 * M * M * 8))))     # factors of a chain: <= 8 GB
+        infos = []
+        for g0 in range(0, len(run), group):
+            cls = run[g0:g0 + group]
+            ys = [labels_of(c) for c in cls]
+            idx = [_centre_indices(np.asarray(y.cpu()), M, rng) for y in ys]
+            Zfs = [be.rows(F, torch.as_tensor(np.asarray(i))) for i in idx]
+            Ps = be.precond_batched(Zfs, sigma, lam, opt.pc_epsilon, ws_key="extra_precond")
+            infos.extend(p.info for p in Ps)
+            Mp = (M + 1) // 2 * 2
+            b0s = torch.zeros((len(cls), Mp), dtype=torch.float64, device=dev)
+            Ks = [be.knm_rhs(F, Zfs[k], sigma, ys[k] * (1.0 / n), rhs_out=b0s[k, :Zfs[k].n])[0] for k in range(len(cls))]
+            alphas = be.cg_solve_batched(Ks, Ps, b0s, [n] * len(cls), lam, maxiter, opt)
+            if alphas is None:          # outside the batched pass configurations (M = 2e4): one CG loop per class
+                alphas = torch.stack([torch.nn.functional.pad(be.cg_solve(Ks[k], Ps[k], b0s[k, :Zfs[k].n], n, lam, maxiter, opt),
+                                                              (0, Mp - Zfs[k].n)) for k in range(len(cls))])
+            del Ks
+            for k, c in enumerate(cls):
+                be.mmv(F, Zfs[k], sigma, alphas[k, :Zfs[k].n], None, out=scores[:, g0 + k:g0 + k + 1])
+        return scores, infos, (F, Zfs[-1], alphas[-1, :Zfs[-1].n])
+
+    job()                                                  # warms kernels, workspaces and the allocator
+    dt, (scores, infos, (F, Zf, alpha)) = _sync_time(job)
+    failed = int(sum(int(i.item() != 0) for i in infos))
+    finite = bool(torch.isfinite(scores).all().item())
+    s_all = dt * C / len(run)
+    out = {"workload": "%s: %d classes x (FALKON fit + score-all) on n=%d rows, D=%d, M=%d, sigma=%g, lambda=%g, %d CG iterations; "
+                       "%d class(es) run on this GPU%s" % (name, C, n, D, M, sigma, lam, maxiter, len(run),
+                                                          "" if len(run) == C else ", the config's time extrapolated linearly in the class count"),
+           "dtype": "f32 K_nM via two-term f16 split + f64 solver" if be.gauss == "h2" else "f32 K_nM (f32 MFMA) + f64 solver",
+           "s_classes_run": round(dt, 4), "classes_run": len(run), "samples_per_s": round(n / s_all, 1),
+           "samples_x_classes_per_s": round(n * C / s_all, 1), "failed_choleskys": failed, "scores_finite": finite}
+    if labels != "pixels" and len(run) == C:
+        out["argmax_accuracy_on_blobs"] = round(float((scores.argmax(1) == ids).float().mean().item()), 4)
+    # ---- one launch of each kernel family at this shape, alone
+    yv = labels_of(0) * (1.0 / n)
+    Kst = {}
+
+    def build():
+        Kst["K"] = be.knm_rhs(F, Zf, sigma, yv)[0]
+    ms_b = _events_ms(build, 3)
+    K = Kst["K"]
+    v = torch.ones(Zf.n, dtype=torch.float64, device=dev)
+    o = torch.empty(Zf.n, dtype=torch.float64, device=dev)
+    ms_p = _events_ms(lambda: be.ktk(K, v=v, out=o), 5)
+    sc = torch.empty((n, 1), dtype=torch.float32, device=dev)
+    ms_s = _events_ms(lambda: be.mmv(F, Zf, sigma, alpha, None, out=sc), 3)
+    flop = 2.0 * n * Zf.n * D
+    kbytes = float(n) * K.ld * 4
+    peak = F16_MFMA_PEAK_TFLOPS if be.gauss == "h2" else 157.3
+    tile = be.lib.odx_gauss_h2_tile(n, Zf.n) if be.gauss == "h2" else 0
+    out["kernels"] = {
+        "build": {"kernel": ("gauss_knm_h2w256_kernel<RHS>" if tile == 256 else "gauss_knm_h2s16_kernel + pass") if be.gauss == "h2" else "gauss_knm_f32_kernel",
+                  "ms": round(ms_b, 3), "TFLOPs": round(flop / ms_b / 1e9, 1), "frac_mfma": round(flop / ms_b / 1e9 / peak, 4),
+                  "K_write_GBps": round(kbytes / ms_b / 1e6, 1), "frac_hbm_write": round(kbytes / ms_b / 1e6 / HBM_PEAK_GBS, 4),
+                  "bound": "mfma" if flop / (peak * 1e12) > kbytes / (HBM_PEAK_GBS * 1e9) else "hbm (K write)"},
+        "pass": {"kernel": "knm_pass_kernel", "ms": round(ms_p, 3), "GBps": round(kbytes / ms_p / 1e6, 1),
+                 "frac_hbm": round(kbytes / ms_p / 1e6 / HBM_PEAK_GBS, 4), "bound": "hbm"},
+        "score": {"kernel": "gauss_mmv_h2w256_kernel" if tile == 256 else "gauss_mmv_h2s16_kernel", "ms": round(ms_s, 3),
+                  "TFLOPs": round(flop / ms_s / 1e9, 1), "frac_mfma": round(flop / ms_s / 1e9 / peak, 4), "bound": "mfma"}}
+    del K, Kst
+    return out
+
+
+def config_extras():
+    """BASELINE configs 2, 4 and 5 (FALKON legs) at the sizes BASELINE.json states, on one GPU: config 5 as the shard one
+    of its 8 GPUs holds (625 000 x 20 000), three of its 100 classes."""
+    out = {}
+    for key, kw in (("config2", dict(name="BASELINE config 2 (FALKON leg)", C=30, n=100_000, D=1024, M=2000, sigma=15.0, lam=1e-5,
+                                     classes_run=30, seed=1234 + 2)),
+                    ("config4", dict(name="BASELINE config 4 (O-OS mask-pixel rows, one fit per class)", C=21, n=500_000, D=256, M=2000,
+                                     sigma=10.0, lam=1e-5, classes_run=21, labels="pixels", seed=1234 + 4)),
+                    ("config5_shard", dict(name="BASELINE config 5, the 625 000-row shard of one of 8 GPUs", C=100, n=625_000, D=1024,
+                                           M=20_000, sigma=15.0, lam=1e-5, classes_run=3, seed=1234 + 5))):
+        try:
+            out[key] = falkon_config_extra(**kw)
+        except Exception as e:          # noqa: BLE001
+            out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        import odx
+        odx.get_backend().release_workspaces()
+        torch.cuda.empty_cache()
+    return out
+
+
 def collect(args):
     """Everything above; a failing extra is reported as its error string, never as a missing headline."""
     out = {}
@@ -169,6 +323,7 @@ def collect(args):
         except Exception as e:          # noqa: BLE001 — an extra must not take the headline line down with it
             out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
+    out.update(config_extras())
     return out
 
 

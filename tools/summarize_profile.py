@@ -20,8 +20,9 @@ print("# rocprofv3 summary (%s)\n" % os.path.basename(d))
 try:
     b = json.loads(open(os.path.join(d, "bench_n1.json")).read().strip().splitlines()[-1])
     print("bench.py (un-profiled): value %.1f %s, %.1f ms/step, roofline %s\n" % (b["value"], b["unit"], b["ms_per_step"], json.dumps(b["roofline"])))
-    if "roofline_second_family" in b:
-        print("second kernel family: %s\n" % json.dumps(b["roofline_second_family"]))
+    for key in ("roofline_hbm", "roofline_mfma", "roofline_second_family"):
+        if key in b:
+            print("%s: %s\n" % (key, json.dumps(b[key])))
     print("phases (ms/step, rank 0): %s\n" % json.dumps(b["phases_ms_per_step_rank0"]))
     print("cpu_baseline: %s\n" % json.dumps(b.get("cpu_baseline")))
 except Exception as e:  # noqa: BLE001
