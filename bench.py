@@ -210,6 +210,7 @@ def main():
     import odx
     from odx.backend import Features
     from odx.dist import RowShard
+    from odx.job import LockstepClassJob
     from odx.solver import SolverOptions
 
     be = odx.get_backend()
@@ -223,140 +224,30 @@ def main():
     row_ids = torch.arange(lo, hi, device=device)
     cidx = centre_indices(N, C, M, seed)
     cidx_dev = [torch.from_numpy(i).to(device) for i in cidx]     # inputs of the job: resident before the timed region
-    ldk = (M + 3) // 4 * 4
-    kbufs = [torch.empty(n_loc * ldk, dtype=torch.float32, device=device) for _ in range(world)]   # N x M f32 per GPU in all
-    scores = torch.empty((n_loc, C), dtype=torch.float32, device=device)
     opt = SolverOptions(check_pivots=False)       # no host sync inside the timed region: every status is read after it
     infos = []                                    # Cholesky status words of every preconditioner built in the timed region
     ph = {k: Phase() for k in ("knm", "ktk", "ktk2", "precond", "mmv")}
 
-    def gather_centres(idx):
-        """Z = X_global[idx]: every rank contributes the rows it owns, one all-reduce sums them."""
-        # no boolean-mask indexing here: it would make the host wait for the GPU (nonzero), and the ~1500 launches of the
-        # next preconditioner are then enqueued while the main stream has nothing to run (33 ms per class, measured)
-        gi = idx                                   # int64 device tensor of global row ids
-        if world == 1:
-            return be.features(X.index_select(0, gi))
-        mine = (gi >= lo) & (gi < hi)
-        Z = X.index_select(0, (gi - lo).clamp_(0, max(n_loc - 1, 0)))
-        Z *= mine.unsqueeze(1)
-        shard.allreduce(Z)
-        return be.features(Z)
-
-    # Preconditioners are built `depth` batches ahead, each on its own side stream with its own output slot and
-    # scratch, so the chains of small latency-bound factorisation kernels fill gaps of the main stream.  (Measured on
-    # one GPU: depth 1, 2, 3 within 1 % of each other — what the factorisations cost is CU time, not latency.)
-    depth = args.precond_depth if args.precond_depth > 0 else 2
-    # Scheduling of the look-ahead preconditioners (chains of ~1500 small f64 kernels, ~57 ms alone, each chain with its own
-    # pair of helper streams) against the main stream.  The main stream is busy 99 % of the time, so whatever the schedule
-    # the preconditioners' MFMA work (~30 ms per class) is paid somewhere; measured on one GPU at the headline size, three
-    # runs each on the same box (s per step):
-    #   issued before the batch's fit, 2 batches ahead (default)                     8.68-8.71
+    # The schedule (odx/job.py): classes in lock-step batches of `world`, every rank owning one class of a batch; the
+    # preconditioners of the classes a rank owns are built ahead on a side stream, by default class-batched (the
+    # factorisation chain of ONE preconditioner is ~1500 dependent small launches that leave most of the chip idle;
+    # odx_falkon_precond_batched_f64 advances G classes with the same chain: groups of 1, 2, 3, then G = 6 batches, group
+    # g + 1 built while group g is fitted).  --precond-batch 1 = one chain per class, `depth` batches ahead, each on its own
+    # side stream with its own output slot; measured on one GPU at the headline size, three runs each (s per step):
+    #   issued before the batch's fit, 2 batches ahead                               8.68-8.71
     #   issued before the batch's fit, 3 batches ahead                               8.88
     #   issued behind the batch's CG, 2 / 3 batches ahead (--precond-behind-cg)      8.96 / 9.09
     #   issued before the fit, 1 batch ahead                                         8.97
     #   (helper streams shared by all chains, behind the CG, 3 ahead: 8.84-8.87; --reserve-cus 16 / 32 change < 1 %)
     be.reserve_cus_during_passes(args.reserve_cus)
-    nslot = depth + 1
-    sides = [torch.cuda.Stream() for _ in range(nslot)]
-    ld_p = (M + 1) // 2 * 2
-    pbuf = []      # per-class mode (--precond-batch 1): one output slot per chain in flight, allocated below
-
-    def prepare(batch, slot, timed):
-        """Centres of the batch's classes (one all-reduce each, main stream) and, on the slot's side stream,
-        the preconditioner of the class this rank owns in the batch (owner = position in the batch)."""
-        while len(pbuf) < nslot:
-            pbuf.append(torch.empty((4, M, ld_p), dtype=torch.float64, device=device))
-        Zs = [gather_centres(cidx_dev[c]) for c in batch]
-        P, ev = None, None
-        if rank < len(batch):
-            side = sides[slot]
-            side.wait_stream(torch.cuda.current_stream())   # the slot's last reader is done, the centres exist
-            with torch.cuda.stream(side):
-                with ph["precond"] if timed else _null():
-                    P = be.precond(Zs[rank], args.sigma, args.lam, opt.pc_epsilon, out=pbuf[slot], ws_key="precond%d" % slot)
-                ev = torch.cuda.Event()
-                ev.record(side)
-            if timed:
-                infos.append(P.info)
-        return Zs, P, ev
-
-    # ---- class-batched preconditioners (default): the factorisation chain of ONE preconditioner is ~1500 dependent small
-    # launches that leave most of the chip idle; odx_falkon_precond_batched_f64 advances G classes with the same chain.
-    # This rank's owned classes are taken G at a time; group g + 1 is built on the side stream while group g is fitted.
-    # (the group size must be the same on every rank — the centres of a group's classes are assembled with collectives —
-    # so it is derived from the number of lock-step batches, not from how many classes this rank happens to own)
-    n_batches = (C + world - 1) // world
-    G = args.precond_batch if args.precond_batch > 0 else max(1, min(6, n_batches))
-    if G > 1:
-        gside = torch.cuda.Stream()
-        pgroup = [torch.empty((G, 4, M, ld_p), dtype=torch.float64, device=device) for _ in range(2)]
-
-    def prepare_group(group, slot, timed):
-        """Centres of every class of the group's batches (main stream) and, on the side stream, the preconditioners of the
-        classes this rank owns among them, all by one batched call.  Returns one (Zs, P, event) per batch."""
-        Zs_all = [[gather_centres(cidx_dev[c]) for c in batch] for batch in group]
-        own = [k for k, batch in enumerate(group) if rank < len(batch)]
-        Ps, ev = {}, None
-        if own:
-            gside.wait_stream(torch.cuda.current_stream())   # the slot's last readers were issued, the centres exist
-            with torch.cuda.stream(gside):
-                with ph["precond"] if timed else _null():
-                    plist = be.precond_batched([Zs_all[k][rank] for k in own], args.sigma, args.lam, opt.pc_epsilon,
-                                               out=pgroup[slot][:len(own)], ws_key="precond_group")
-                ev = torch.cuda.Event()
-                ev.record(gside)
-            Ps = dict(zip(own, plist))
-            if timed:
-                infos.extend(p.info for p in plist)
-        return [(Zs_all[k], Ps.get(k), ev) for k in range(len(group))]
+    job = LockstepClassJob(be, X, N, M, lambda c: torch.where((row_ids % C) == c, 1.0, -1.0).to(torch.float64), cidx_dev,
+                           args.sigma, args.lam, args.maxiter, opt, shard=shard, precond_batch=args.precond_batch,
+                           precond_depth=args.precond_depth, precond_after_fit=args.precond_after_fit)
+    G, ldk, scores = job.G, job.ldk, job.scores
+    kfmt = be.knm_format(n_loc, M)                 # storage of the K_nM shards ("u24" at the headline size, "f32" for small ones)
 
     def run_classes(classes, timed):
-        """Classes are processed in batches of `world`.  Every rank builds the preconditioner of the class it owns in
-        a batch (nothing replicated) on a side stream, `depth` batches ahead.  The batch's classes are then fitted
-        together in lock step with the rows sharded over all ranks (odx.solver.falkon_fit_lockstep: per CG step one
-        all-gather of the directions, one pass per class over the local K_nM shard, one reduce-scatter) and scored."""
-        out = None
-        batches = [classes[b0:b0 + world] for b0 in range(0, len(classes), world)]
-        if G > 1:
-            # group sizes 1, 2, 3, then G: nothing but the first class's preconditioner is waited for at the start of a
-            # step (it overlaps that class's K_nM build, as in the per-class mode); every later group is built while the
-            # group before it is being fitted
-            groups, g0 = [], 0
-            for size in (1, 2, 3):
-                if g0 < len(batches) and size < G:
-                    groups.append(list(range(g0, min(g0 + size, len(batches)))))
-                    g0 += size
-            while g0 < len(batches):
-                groups.append(list(range(g0, min(g0 + G, len(batches)))))
-                g0 += G
-            first_of = {grp[0]: gi for gi, grp in enumerate(groups)}
-            ready = dict(zip(groups[0], prepare_group([batches[bi] for bi in groups[0]], 0, timed)))
-        else:
-            ready = {bi: prepare(batches[bi], bi % nslot, timed) for bi in range(min(depth, len(batches)))}
-        for bi, batch in enumerate(batches):
-            if G > 1:
-                gi = first_of.get(bi)
-                if gi is not None and gi + 1 < len(groups):  # one group ahead, on the side stream
-                    ready.update(zip(groups[gi + 1], prepare_group([batches[k] for k in groups[gi + 1]], (gi + 1) % 2, timed)))
-            elif not args.precond_after_fit and bi + depth < len(batches):
-                ready[bi + depth] = prepare(batches[bi + depth], (bi + depth) % nslot, timed)
-            Zs, P, ev = ready.pop(bi)
-            ys = [torch.where((row_ids % C) == c, 1.0, -1.0).to(torch.float64) for c in batch]
-            mine = rank < len(batch)
-            alphas = odx.falkon_fit_lockstep(be, F, ys, Zs, args.sigma, args.lam, args.maxiter, opt, n_total=N, shard=shard,
-                                             knm_outs=kbufs[:len(batch)], phase=(lambda name: ph[name]) if timed else None,
-                                             precond=P if mine else None,
-                                             precond_ready=(lambda: torch.cuda.current_stream().wait_event(ev)) if mine else None)
-            if G == 1 and args.precond_after_fit and bi + depth < len(batches):
-                # issued behind this batch's CG in stream order: the factorisations then run beside the MFMA-bound scoring of
-                # this batch and K_nM build of the next, and the HBM-bound passes keep the chip to themselves
-                ready[bi + depth] = prepare(batches[bi + depth], (bi + depth) % nslot, timed)
-            for pos, c in enumerate(batch):
-                with ph["mmv"] if timed else _null():
-                    be.mmv(F, Zs[pos], args.sigma, alphas[pos], None, out=scores[:, c:c + 1])
-            out = (alphas[-1], Zs[-1])
-        return out
+        return job.run(F, classes, phases=ph if timed else None, infos=infos if timed else None)
 
     def barrier():
         torch.cuda.synchronize()
@@ -374,9 +265,7 @@ def main():
     # it deliberately shares the chip with the preconditioner stream, so its rate there is not the kernel's own.
     alone_gbps = None
     if args.warmup > 0 and n_loc > 0:
-        from odx.backend import Knm
-        Kw = Knm()
-        Kw.n, Kw.M, Kw.ld, Kw.K = n_loc, M, ldk, kbufs[0].view(n_loc, ldk)
+        Kw = be._knm_block(n_loc, M, kfmt, job.kbufs[0])      # the block the warm-up's last class left there
         vv, oo = torch.ones(M, dtype=torch.float64, device=device), torch.empty(M, dtype=torch.float64, device=device)
         be.ktk(Kw, v=vv, out=oo)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -385,7 +274,7 @@ def main():
             be.ktk(Kw, v=vv, out=oo)
         e1.record()
         torch.cuda.synchronize()
-        alone_gbps = 3 * float(n_loc) * M * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        alone_gbps = 3 * float(be.knm_bytes(n_loc, M)) / (e0.elapsed_time(e1) * 1e-3) / 1e9
     barrier()
 
     # ---- timed region: exactly K steps
@@ -426,7 +315,8 @@ def main():
         p1_ms, p1_n = ph["ktk"].total_ms(), ph["ktk"].count()
         p2_ms, p2_n = ph["ktk2"].total_ms(), ph["ktk2"].count()
         pass_ms, pass_launches = p1_ms + p2_ms, p1_n + p2_n
-        bytes_per_pass = float(n_loc) * M * 4
+        bytes_per_pass = float(be.knm_bytes(n_loc, M))      # the stored shard, read exactly once per launch (n M s_K)
+        pk = ("knm_pass_kernel", "knm_pass2_kernel") if kfmt == "f32" else ("knm_passq_kernel<NV=1>", "knm_passq_kernel<NV=2>")
         gach = flops_per_launch * gauss_launches / max(gauss_ms * 1e-3, 1e-12) / 1e12
 
         def per_kernel(ms, cnt, unit_work, scale):
@@ -449,17 +339,18 @@ def main():
         if be.gauss == "h2":
             roof_g["frac_of_split_ceiling"] = round(3 * gach / gpeak, 4)
         pach = bytes_per_pass * pass_launches / max(pass_ms * 1e-3, 1e-12) / 1e9
-        roof_p = {"bound": "hbm", "kernel": "knm_pass_kernel" + ("+knm_pass2_kernel" if p2_n else ""), "achieved": round(pach, 1),
+        roof_p = {"bound": "hbm", "kernel": pk[0] + ("+" + pk[1] if p2_n else ""), "achieved": round(pach, 1),
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(pach / HBM_PEAK_GBS, 4), "traffic": None,
                   "avg_launch_ms": round(pass_ms / max(pass_launches, 1), 3), "family_ms_per_step": round(pass_ms / args.steps, 2),
-                  "per_kernel": {"knm_pass_kernel": per_kernel(p1_ms, p1_n, bytes_per_pass, 1e9),
-                                 "knm_pass2_kernel": per_kernel(p2_ms, p2_n, bytes_per_pass, 1e9)}}
+                  "bytes_per_launch": bytes_per_pass, "storage": kfmt,
+                  "per_kernel": {pk[0]: per_kernel(p1_ms, p1_n, bytes_per_pass, 1e9),
+                                 pk[1]: per_kernel(p2_ms, p2_n, bytes_per_pass, 1e9)}}
         if alone_gbps is not None:
             roof_p["achieved_alone"] = round(alone_gbps, 1)
             roof_p["frac_alone"] = round(alone_gbps / HBM_PEAK_GBS, 4)
             roof_p["note"] = ("achieved: K_nM bytes of all pass launches / their device time over the timed region (a two-vector "
                               "launch counts its ONE read of K_nM), where %d CUs are left to the preconditioner stream; "
-                              "achieved_alone: knm_pass_kernel, same buffer, idle GPU, before the timed region" % args.reserve_cus)
+                              "achieved_alone: the one-vector kernel, same buffer, idle GPU, before the timed region" % args.reserve_cus)
         if (n_loc, M, D) == (1_000_000, 10_000, 1024):
             for r in (roof_g, roof_p):
                 r["traffic"], r["traffic_unit"] = profiled_traffic_gb(r["kernel"])
@@ -473,8 +364,9 @@ def main():
             "metric": "FALKON fit+infer samples/sec (N=1e6 D=1024 M=1e4)",
             "value": round(value, 1), "unit": "samples/s", "n_gpus": ranks_seen, "ranks": ranks_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": ("f32 K_nM (X Z' as a two-term f16 split on the f16 MFMA, f32 accumulate) + f64 solver" if be.gauss == "h2"
-                                                        else "f32 K_nM (f32-input MFMA) + f64 solver"),
+            "scaling": "strong", "vs_baseline": None, "dtype": (("f32-accurate K_nM (X Z' as a two-term f16 split on the f16 MFMA, f32 accumulate) stored as %s + f64 solver"
+                                                 % {"f32": "f32", "u24": "24-bit fixed point (step 2^-24)", "bf16": "bf16 (throughput only)"}[kfmt])
+                                                if be.gauss == "h2" else "f32 K_nM (f32-input MFMA) + f64 solver"),
             "data": "synthetic",
             "config": {"workload": "%d-class one-vs-rest FALKON fit + score-all, N=%d D=%d M=%d, %d CG iterations, "
                                    "rows sharded over %d GPU(s)" % (C, N, D, M, args.maxiter, world),
@@ -493,10 +385,8 @@ def main():
         if not args.no_extras and world == 1:
             # the other halves of BASELINE configs 2 and 3 (RLS regressors, feature forward) and the reference-regime
             # minibootstrap: measured after and outside the timed headline region, with its buffers released first
-            del kbufs[:], pbuf[:]
-            if G > 1:
-                del pgroup[:]
-            last = F = X = scores = None
+            job.release()
+            last = F = X = scores = job = None
             be.release_workspaces()
             torch.cuda.empty_cache()
             from tools import bench_extras
@@ -508,14 +398,6 @@ def main():
     if not healthy:
         print("bench.py: unhealthy run: %s" % json.dumps(health), file=sys.stderr)
         sys.exit(4)
-
-
-class _null:
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *a):
-        return False
 
 
 def profiled_traffic_gb(kernel_names):
@@ -537,7 +419,7 @@ def profiled_traffic_gb(kernel_names):
             if not os.path.exists(path):
                 break
             vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-                    if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in kernel_names.split("+"))]
+                    if r["Counter_Name"] == counter and any(k.split("<")[0] in r["Kernel_Name"] for k in kernel_names.split("+"))]
             if vals:
                 found += 1
                 tot += mult * 1024.0 * statistics.median(vals)

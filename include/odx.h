@@ -128,6 +128,36 @@ int64_t odx_knm_fwd_bwd2_workspace_bytes(int64_t n, int64_t M);
 int odx_knm_fwd_bwd2(const float* K, int64_t ldk, int64_t n, int64_t M, const double* v, const double* v2,
                      double* out, double* out2, void* workspace, int64_t workspace_bytes, odx_stream_t stream);
 
+/* ---------------------------------------------------------------- A4: compact storage of the stored K_nM
+ * The CG passes above are HBM-bound at the chip's copy rate, so their time is the bytes per entry of the stored block
+ * (falkon keeps it in the data's dtype: f32, FALKONWrapper_with_centers_selection_incore.py:56-68; config/defaults.py:466).
+ * Formats (tools/precision_storage_study.py has the effect of each on the fitted alpha):
+ *   ODX_KNM_F32   n x ld floats, ld = roundup(M, 4)                                          4 B / entry (parity format)
+ *   ODX_KNM_U24   24-bit fixed point on [0, 1]: q = round(K 2^24) as a u16 plane (q >> 8, `K`) and a u8 plane (q & 255,
+ *                 `Klo`), both n x ld, ld = roundup(M, 8).  Absolute step 2^-24 = f32's own on [0.5, 1)   3 B / entry
+ *   ODX_KNM_BF16  K rounded to bf16, n x ld u16, ld = roundup(M, 8)  (BASELINE config 2's throughput storage)  2 B / entry
+ * Pad columns [M, ld) are written as zero.  odx_gauss_knm_h2_store builds a block in any of the three on the 256 x 256
+ * tile core (16-byte stores per lane) and, when w is given, leaves ktw = K' w over the values it STORED (the fused
+ * right-hand side; workspace as odx_gauss_knm_h2_rhs_workspace_bytes).  odx_knm_fwd_bwd_q / odx_knm_fwd_bwd2_q are
+ * odx_knm_fwd_bwd / odx_knm_fwd_bwd2 on the two compact formats (M <= 20480; two vectors: 4096 < M <= ~10 000). */
+#define ODX_KNM_F32 0
+#define ODX_KNM_U24 1
+#define ODX_KNM_BF16 2
+int64_t odx_knm_ld(int64_t M, int fmt);
+int64_t odx_knm_bytes(int64_t n, int64_t M, int fmt);
+int odx_gauss_knm_h2_store(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
+                           const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int D,
+                           double sigma, int fmt, void* K, int64_t ldk, void* Klo, int64_t ldlo, const double* w,
+                           double* ktw, void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+int64_t odx_knm_fwd_bwd_q_workspace_bytes(int64_t n, int64_t M, int fmt);
+int odx_knm_fwd_bwd_q(const void* K, int64_t ldk, const void* Klo, int64_t ldlo, int fmt, int64_t n, int64_t M,
+                      const double* v, const double* w, double* out, void* workspace, int64_t workspace_bytes,
+                      odx_stream_t stream);
+int64_t odx_knm_fwd_bwd2_q_workspace_bytes(int64_t n, int64_t M, int fmt);
+int odx_knm_fwd_bwd2_q(const void* K, int64_t ldk, const void* Klo, int64_t ldlo, int fmt, int64_t n, int64_t M,
+                       const double* v, const double* v2, double* out, double* out2, void* workspace,
+                       int64_t workspace_bytes, odx_stream_t stream);
+
 /* ---------------------------------------------------------------- A4: preconditioner (f64)
  * FalkonPreconditioner.init as run by InCoreFalkon.fit with min_cuda_pc_size_*=0
  * (FALKONWrapper_with_centers_selection_incore.py:56):

@@ -419,13 +419,19 @@ struct WStage {
 };
 
 // thread t: 16-byte chunk t & 7 of rows (t >> 3) + 64 p.  Rows past the operand's end are read as its last row.
+// PERM (the B operand of the K_nM builds): LDS row 64 w + 16 t + r of the image holds operand row 64 w + 4 r + t, so that
+// the four accumulator blocks tn = 0..3 of a lane are four ADJACENT output columns 64 wc + 4 (lane & 15) + tn and the
+// epilogue stores 16 bytes per lane (a whole 256-byte row segment per 16 lanes) instead of four scattered floats.  The
+// image's geometry — and with it the conflict-free fragment reads — is unchanged: only which operand row a thread fetches.
+template <bool PERM>
 __device__ __forceinline__ void w_row_offsets(uint32_t (&voff)[4], int64_t ld, int64_t row0, int64_t nrows) {
   const int tid = threadIdx.x;
   const int64_t l64 = nrows - 1 - row0;               // >= 0: the tile starts inside the operand
   const int last = l64 < W_BM - 1 ? (int)l64 : W_BM - 1;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const int r = (tid >> 3) + 64 * p;
+    const int ri = (tid >> 3) + 64 * p;
+    const int r = PERM ? ((ri & ~63) | ((ri & 15) << 2) | ((ri >> 4) & 3)) : ri;
     voff[p] = (uint32_t)(r < last ? r : last) * (uint32_t)ld + (uint32_t)(tid & 7) * 4u;
   }
 }
@@ -502,6 +508,9 @@ __device__ __forceinline__ void w_stage(f32x4 (&acc)[8][4], WStage& st, const ch
 }
 
 // acc += A[i0 .. i0 + 256, :] . B[j0 .. j0 + 256, :]' over `stages` >= 1 granules.  Ends on a barrier (LDS reusable at once).
+// PERMB: the rows of B are fetched in the permuted order of w_row_offsets<true> (accumulator block tn of lane l is then
+// output column 64 wc + 4 (l & 15) + tn instead of 64 wc + 16 tn + (l & 15)).
+template <bool PERMB = false>
 __device__ __forceinline__ void w_mainloop(f32x4 (&acc)[8][4], const uint32_t* __restrict__ A, int64_t lda, int64_t m,
                                            const uint32_t* __restrict__ B, int64_t ldb, int64_t n, int64_t i0, int64_t j0,
                                            int stages, char* lds) {
@@ -509,8 +518,8 @@ __device__ __forceinline__ void w_mainloop(f32x4 (&acc)[8][4], const uint32_t* _
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   WAddr ad;
-  w_row_offsets(ad.offa, lda, i0, m);
-  w_row_offsets(ad.offb, ldb, j0, n);
+  w_row_offsets<false>(ad.offa, lda, i0, m);
+  w_row_offsets<PERMB>(ad.offb, ldb, j0, n);
   const uint32_t* ta = A + i0 * lda;
   const uint32_t* tb = B + j0 * ldb;
   const int srow = tid >> 3;
@@ -551,15 +560,39 @@ __device__ __forceinline__ void w_zero(f32x4 (&acc)[8][4]) {
     for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// accumulator element (tm, tn, q) of a wave's 128 x 64 share: row 16 tm + 4 (lane >> 4) + q, column 16 tn + (lane & 15)
-// RHS: also leave wslab[row block][j] = sum over the tile's rows i of K_ij w_i (f64): the column sums K' w of the
-// right-hand side of the fit come out of the build, and the first pass over the stored K_nM is not needed.
-template <bool RHS>
+// Storage formats of a K_nM block (what the CG passes stream):
+//   KF_F32   n x ldk floats (ldk = roundup(M, 4)), the parity format
+//   KF_U24   24-bit fixed point on [0, 1]: q = round(K 2^24) (2^24 - 1 for K = 1) as a u16 plane of q >> 8 and a u8 plane of
+//            q & 255 (both n x ld8, ld8 = roundup(M, 8)): 3 bytes per entry.  Absolute step 2^-24 — f32's own on [0.5, 1),
+//            coarser than f32 below; tools/precision_storage_study.py: alpha moves against the f64 evaluation as with f32
+//            storage on the problems whose entries sit near 1 (the ill-conditioned ones) and stays 5 x under the 1e-4 bar
+//            on the small-sigma ones where it is coarser
+//   KF_BF16  K rounded to bf16 (n x ld8 u16): BASELINE config 2's throughput-only storage, 2 bytes per entry
+enum { KF_F32 = 0, KF_U24 = 1, KF_BF16 = 2 };
+
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t u24_of(float v) {
+  const uint32_t q = (uint32_t)__builtin_rintf(v * 16777216.f);       // v in [0, 1]; exact scaling, one rounding
+  return q > 16777215u ? 16777215u : q;
+}
+
+__device__ __forceinline__ unsigned short bf16_of(float v) {          // round to nearest even (v is finite, >= 0)
+  const uint32_t u = __float_as_uint(v);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+// accumulator element (tm, tn, q) of a wave's 128 x 64 share (B rows permuted, w_mainloop<true>):
+// row 16 tm + 4 (lane >> 4) + q, column 4 (lane & 15) + tn — a lane holds four adjacent columns of every one of its rows.
+// RHS: also leave wslab[row block][j] = sum over the tile's rows i of K_ij w_i (f64), K_ij being the value the block
+// STORES (the dequantised one for KF_U24 / KF_BF16): the column sums K' w of the right-hand side of the fit come out of
+// the build, and the first pass over the stored K_nM is not needed.
+template <bool RHS, int FMT>
 __global__ __launch_bounds__(W_THREADS, 1) void gauss_knm_h2w256_kernel(
     const uint32_t* __restrict__ PX, int64_t ldpx, const float* __restrict__ metax, const float* __restrict__ xsq, int64_t n,
     const uint32_t* __restrict__ PZ, int64_t ldpz, const float* __restrict__ metaz, const float* __restrict__ zsq, int64_t M,
-    int stages, float gamma_log2e, float* __restrict__ K, int64_t ldk, int gr, const double* __restrict__ w,
-    double* __restrict__ wslab, int64_t wslab_ld) {
+    int stages, float gamma_log2e, void* __restrict__ Kp, int64_t ldk, unsigned char* __restrict__ Klo, int64_t ldlo, int gr,
+    const double* __restrict__ w, double* __restrict__ wslab, int64_t wslab_ld) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int64_t GR = gr;
   const int64_t tiles_n = (M + W_BN - 1) / W_BN;
@@ -577,20 +610,22 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_knm_h2w256_kernel(
 
   f32x4 acc[8][4];
   w_zero(acc);
-  w_mainloop(acc, PX, ldpx, n, PZ, ldpz, M, i0, j0, stages, lds);      // its barriers also publish xs_s
+  w_mainloop<true>(acc, PX, ldpx, n, PZ, ldpz, M, i0, j0, stages, lds);      // its barriers also publish xs_s
 
   const float m2 = -2.f / (metax[0] * metaz[0]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 2, wc = wave & 3;
+  const int cb = wc * 64 + 4 * (lane & 15);                 // first of this lane's four adjacent columns inside the tile
+  const int64_t mpad = FMT == KF_F32 ? ((M + 3) & ~int64_t(3)) : ((M + 7) & ~int64_t(7));
   const bool interior = i0 + W_BM <= n && j0 + W_BN <= M;
-  const int64_t mpad = (M + 3) & ~int64_t(3);
-  float* tile = K + i0 * ldk + j0;
+  const bool cols_in = j0 + cb < mpad;                      // groups of four: entirely inside the padded row or not at all
   double csum[4] = {0.0, 0.0, 0.0, 0.0};
   float zs[4];
+  bool cv[4];
 #pragma unroll
   for (int tn = 0; tn < 4; ++tn) {
-    const int cl = wc * 64 + tn * 16 + (lane & 15);
-    zs[tn] = (j0 + cl < M) ? zsq[j0 + cl] : 0.f;
+    cv[tn] = j0 + cb + tn < M;
+    zs[tn] = cv[tn] ? zsq[j0 + cb + tn] : 0.f;
   }
 #pragma unroll
   for (int tm = 0; tm < 8; ++tm) {
@@ -599,31 +634,57 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_knm_h2w256_kernel(
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const double wq = RHS ? ws_s[rl + q] : 0.0;
+      f32x4 v;
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) {
-        const int cl = wc * 64 + tn * 16 + (lane & 15);
         float d2 = fmaf(m2, acc[tm][tn][q], xs[q]) + zs[tn];
         d2 = fmaxf(d2, 0.f);
-        const float v = __builtin_amdgcn_exp2f(d2 * gamma_log2e);
-        if (RHS) csum[tn] = fma((double)v, wq, csum[tn]);
-        if (interior) {
-          tile[(uint32_t)(rl + q) * (uint32_t)ldk + (uint32_t)cl] = v;   // (non-temporal stores: no difference)
-        } else if (i0 + rl + q < n && j0 + cl < mpad) {
-          tile[(int64_t)(rl + q) * ldk + cl] = (j0 + cl < M) ? v : 0.f;
+        v[tn] = __builtin_amdgcn_exp2f(d2 * gamma_log2e);
+        if (!interior && !cv[tn]) v[tn] = 0.f;              // pad columns [M, mpad) are stored as zero
+      }
+      const bool store = interior || (i0 + rl + q < n && cols_in);
+      const int64_t off = (i0 + rl + q) * ldk + j0 + cb;
+      if (FMT == KF_F32) {
+        if (RHS) {
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) csum[tn] = fma((double)v[tn], wq, csum[tn]);
         }
+        if (store) *reinterpret_cast<f32x4*>(static_cast<float*>(Kp) + off) = v;      // (non-temporal stores: no difference)
+      } else if (FMT == KF_U24) {
+        uint32_t qv[4];
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+          qv[tn] = u24_of(v[tn]);
+          if (RHS) csum[tn] = fma((double)qv[tn], wq, csum[tn]);                       // scaled by 2^-24 below
+        }
+        if (store) {
+          const u16x4 hi = {(unsigned short)(qv[0] >> 8), (unsigned short)(qv[1] >> 8), (unsigned short)(qv[2] >> 8),
+                            (unsigned short)(qv[3] >> 8)};
+          *reinterpret_cast<u16x4*>(static_cast<unsigned short*>(Kp) + off) = hi;
+          *reinterpret_cast<uint32_t*>(Klo + (i0 + rl + q) * ldlo + j0 + cb) =
+              (qv[0] & 255u) | ((qv[1] & 255u) << 8) | ((qv[2] & 255u) << 16) | (qv[3] << 24);
+        }
+      } else {
+        u16x4 b;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+          b[tn] = bf16_of(v[tn]);
+          if (RHS) csum[tn] = fma((double)__uint_as_float((uint32_t)b[tn] << 16), wq, csum[tn]);
+        }
+        if (store) *reinterpret_cast<u16x4*>(static_cast<unsigned short*>(Kp) + off) = b;
       }
     }
     if (RHS) __builtin_amdgcn_sched_barrier(0);      // keep the row weights of later blocks out of registers until needed
   }
   if (RHS) {
-    // lanes l, l + 16, l + 32, l + 48 hold the same column: add them, then the two row halves of the tile through LDS
+    // lanes l, l + 16, l + 32, l + 48 hold the same columns: add them, then the two row halves of the tile through LDS
     double* red2 = reinterpret_cast<double*>(lds);          // the stage buffers are free: the main loop ended on a barrier
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
       double c = csum[tn];
       c += __shfl_xor(c, 16);
       c += __shfl_xor(c, 32);
-      if (lane < 16) red2[wr * W_BN + wc * 64 + tn * 16 + lane] = c;
+      if (lane < 16) red2[wr * W_BN + cb + tn] = FMT == KF_U24 ? c * 5.9604644775390625e-08 : c;   // 2^-24: exact
     }
     __syncthreads();
     if (threadIdx.x < W_BN && j0 + threadIdx.x < M)
@@ -856,9 +917,21 @@ extern "C" int odx_split_f16(const float* X, int64_t ldx, int64_t n, int D, void
   return ODX_OK;
 }
 
+template <bool RHS, int FMT>
+static int launch_knm_w256_t(unsigned wt, hipStream_t s, const uint32_t* PX, int64_t ldpx, const float* metax, const float* xsq,
+                             int64_t n, const uint32_t* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t M,
+                             int stages, float g2, void* K, int64_t ldk, unsigned char* Klo, int64_t ldlo, int wgr,
+                             const double* w, double* wslab, int64_t wslab_ld) {
+  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2w256_kernel<RHS, FMT>), W_LDS_BYTES));
+  hipLaunchKernelGGL((gauss_knm_h2w256_kernel<RHS, FMT>), dim3(wt), dim3(W_THREADS), W_LDS_BYTES, s, PX, ldpx, metax, xsq, n,
+                     PZ, ldpz, metaz, zsq, M, stages, g2, K, ldk, Klo, ldlo, wgr, w, wslab, wslab_ld);
+  return ODX_OK;
+}
+
 static int launch_knm_w256(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n, const void* PZ,
-                           int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int64_t dp, double sigma, float* K,
-                           int64_t ldk, const double* w, double* wslab, int64_t wslab_ld, odx_stream_t stream) {
+                           int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int64_t dp, double sigma, int fmt,
+                           void* K, int64_t ldk, void* Klo, int64_t ldlo, const double* w, double* wslab, int64_t wslab_ld,
+                           odx_stream_t stream) {
   // band height of the tile order; 2 / 4 / 8 / 16 / 32 measured alone: 395 / 397 / 391 / 376 / 347 TF
   // (ODX_H2_BAND overrides it for experiments: a taller band re-streams the centres from the Infinity Cache less often)
   static const int wgr_env = [] { const char* e = getenv("ODX_H2_BAND"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 64) ? v : 0; }();
@@ -866,17 +939,23 @@ static int launch_knm_w256(const void* PX, int64_t ldpx, const float* metax, con
   const int64_t wt = round_up(ceil_div(n, W_BM), wgr) * ceil_div(M, W_BN);
   ODX_REQUIRE(wt < (1ll << 31), "odx_gauss_knm_h2: grid too large");
   const float g2 = (float)(-0.5 / (sigma * sigma)) * LOG2E;
+  const int stages = (int)(dp / W_KS);
+  hipStream_t s = as_stream(stream);
+  const uint32_t *px = (const uint32_t*)PX, *pz = (const uint32_t*)PZ;
+  unsigned char* lo = static_cast<unsigned char*>(Klo);
+#define ODX_KNM_W256(RHS_, FMT_)                                                                                          \
+  ODX_PROPAGATE((launch_knm_w256_t<RHS_, FMT_>((unsigned)wt, s, px, ldpx, metax, xsq, n, pz, ldpz, metaz, zsq, M, stages, \
+                                               g2, K, ldk, lo, ldlo, wgr, w, wslab, wslab_ld)))
   if (w != nullptr) {
-    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2w256_kernel<true>), W_LDS_BYTES));
-    hipLaunchKernelGGL(gauss_knm_h2w256_kernel<true>, dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
-                       (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq, M, (int)(dp / W_KS), g2, K,
-                       ldk, wgr, w, wslab, wslab_ld);
+    if (fmt == KF_F32) ODX_KNM_W256(true, KF_F32);
+    else if (fmt == KF_U24) ODX_KNM_W256(true, KF_U24);
+    else ODX_KNM_W256(true, KF_BF16);
   } else {
-    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2w256_kernel<false>), W_LDS_BYTES));
-    hipLaunchKernelGGL(gauss_knm_h2w256_kernel<false>, dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
-                       (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq, M, (int)(dp / W_KS), g2, K,
-                       ldk, wgr, nullptr, nullptr, 0);
+    if (fmt == KF_F32) ODX_KNM_W256(false, KF_F32);
+    else if (fmt == KF_U24) ODX_KNM_W256(false, KF_U24);
+    else ODX_KNM_W256(false, KF_BF16);
   }
+#undef ODX_KNM_W256
   ODX_CHECK_LAUNCH("odx_gauss_knm_h2(w256)");
   return ODX_OK;
 }
@@ -955,7 +1034,7 @@ extern "C" int odx_gauss_knm_h2(const void* PX, int64_t ldpx, const float* metax
   ODX_REQUIRE(ldpx < (1 << 24) && ldpz < (1 << 24) && ldk < (1 << 24), "odx_gauss_knm_h2: leading dimensions must stay below 2^24 (32-bit tile offsets)");
   const int gr = 8;   // band height of the tile order: 2..32 measured within 2 % of each other at n = 2.5e5, M = 1e4
   if (h2_use_w256(ceil_div(n, W_BM) * ceil_div(M, W_BN)))
-    return launch_knm_w256(PX, ldpx, metax, xsq, n, PZ, ldpz, metaz, zsq, M, dp, sigma, K, ldk, nullptr, nullptr, 0, stream);
+    return launch_knm_w256(PX, ldpx, metax, xsq, n, PZ, ldpz, metaz, zsq, M, dp, sigma, KF_F32, K, ldk, nullptr, 0, nullptr, nullptr, 0, stream);
   const int64_t tiles = round_up(ceil_div(n, GEMM_BM), gr) * ceil_div(M, GEMM_BN);
   ODX_REQUIRE(tiles < (1ll << 31), "odx_gauss_knm_h2: grid too large");
   ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2s16_kernel)));
@@ -991,8 +1070,52 @@ extern "C" int odx_gauss_knm_h2_rhs(const void* PX, int64_t ldpx, const float* m
     return ODX_ERR_WORKSPACE;
   }
   const int64_t wld = round_up(M, 4);
-  ODX_PROPAGATE(launch_knm_w256(PX, ldpx, metax, xsq, n, PZ, ldpz, metaz, zsq, M, dp, sigma, K, ldk, w,
+  ODX_PROPAGATE(launch_knm_w256(PX, ldpx, metax, xsq, n, PZ, ldpz, metaz, zsq, M, dp, sigma, KF_F32, K, ldk, nullptr, 0, w,
                                 static_cast<double*>(workspace), wld, stream));
+  return slab_reduce_f64(static_cast<const double*>(workspace), wld, (int)ceil_div(n, W_BM), M, ktw, as_stream(stream));
+}
+
+extern "C" int64_t odx_knm_ld(int64_t M, int fmt) {
+  if (M <= 0) return 0;
+  return fmt == ODX_KNM_F32 ? round_up(M, 4) : round_up(M, 8);
+}
+
+extern "C" int64_t odx_knm_bytes(int64_t n, int64_t M, int fmt) {
+  if (n <= 0 || M <= 0) return 0;
+  const int64_t per = fmt == ODX_KNM_F32 ? 4 : (fmt == ODX_KNM_U24 ? 3 : 2);
+  return n * odx_knm_ld(M, fmt) * per;
+}
+
+extern "C" int odx_gauss_knm_h2_store(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
+                                      const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int D,
+                                      double sigma, int fmt, void* K, int64_t ldk, void* Klo, int64_t ldlo, const double* w,
+                                      double* ktw, void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
+  ODX_REQUIRE(M > 0, "odx_gauss_knm_h2_store: M <= 0");
+  ODX_REQUIRE(fmt == ODX_KNM_F32 || fmt == ODX_KNM_U24 || fmt == ODX_KNM_BF16, "odx_gauss_knm_h2_store: unknown storage format %d", fmt);
+  ODX_REQUIRE((w == nullptr) == (ktw == nullptr), "odx_gauss_knm_h2_store: w and ktw go together");
+  if (n <= 0) {
+    if (ktw) ODX_CHECK_HIP(hipMemsetAsync(ktw, 0, (size_t)M * sizeof(double), as_stream(stream)));
+    return ODX_OK;
+  }
+  ODX_REQUIRE(PX && PZ && metax && metaz && xsq && zsq && K && D > 0 && sigma > 0, "odx_gauss_knm_h2_store: bad argument");
+  const int64_t dp = round_up(D, H2_KT);
+  ODX_REQUIRE(ldpx % 4 == 0 && ldpz % 4 == 0 && ldpx >= dp && ldpz >= dp && aligned16(PX) && aligned16(PZ),
+              "odx_gauss_knm_h2_store: packed operands must be 16-byte aligned with ld %% 4 == 0 and ld >= roundup(D, 64)");
+  const int64_t ldmin = odx_knm_ld(M, fmt);
+  ODX_REQUIRE(ldk >= ldmin && ldk % (fmt == ODX_KNM_F32 ? 4 : 8) == 0 && aligned16(K),
+              "odx_gauss_knm_h2_store: K must be 16-byte aligned with ldk a multiple of %d and >= %lld", fmt == ODX_KNM_F32 ? 4 : 8, (long long)ldmin);
+  if (fmt == ODX_KNM_U24)
+    ODX_REQUIRE(Klo && ldlo >= ldmin && ldlo % 8 == 0 && aligned16(Klo), "odx_gauss_knm_h2_store: the low-byte plane must be 16-byte aligned with ldlo %% 8 == 0, ldlo >= roundup(M, 8)");
+  ODX_REQUIRE(ldpx < (1 << 24) && ldpz < (1 << 24) && ldk < (1 << 24), "odx_gauss_knm_h2_store: leading dimensions must stay below 2^24 (32-bit tile offsets)");
+  if (w != nullptr && (workspace == nullptr || workspace_bytes < odx_gauss_knm_h2_rhs_workspace_bytes(n, M))) {
+    set_error("odx_gauss_knm_h2_store: workspace too small");
+    return ODX_ERR_WORKSPACE;
+  }
+  const int64_t wld = round_up(M, 4);
+  const int kf = fmt == ODX_KNM_F32 ? KF_F32 : (fmt == ODX_KNM_U24 ? KF_U24 : KF_BF16);
+  ODX_PROPAGATE(launch_knm_w256(PX, ldpx, metax, xsq, n, PZ, ldpz, metaz, zsq, M, dp, sigma, kf, K, ldk, Klo, ldlo, w,
+                                static_cast<double*>(workspace), wld, stream));
+  if (w == nullptr) return ODX_OK;
   return slab_reduce_f64(static_cast<const double*>(workspace), wld, (int)ceil_div(n, W_BM), M, ktw, as_stream(stream));
 }
 

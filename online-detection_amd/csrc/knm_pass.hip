@@ -503,6 +503,12 @@ int odx::slab_reduce_f64(const double* slab, int64_t slab_ld, int nslab, int64_t
   return ODX_OK;
 }
 
+int odx::slab_reduce2_f64(const double* slab, int64_t slab_ld, int nslab, int64_t M, double* out, double* out2, hipStream_t s) {
+  hipLaunchKernelGGL(slab_reduce2_kernel, dim3((unsigned)ceil_div(M, 64), 2), dim3(256), 0, s, slab, slab_ld, nslab, M, out, out2);
+  ODX_CHECK_LAUNCH("slab_reduce2_f64");
+  return ODX_OK;
+}
+
 extern "C" int odx_set_pass_reserved_cus(int cus) {
   ODX_REQUIRE(cus >= 0, "odx_set_pass_reserved_cus: negative count");
   g_reserved_cus = cus;

@@ -1,0 +1,356 @@
+// The conjugate-gradient pass  out = K' (K v + w)  over a K_nM shard stored in one of the COMPACT formats of
+// gauss_h2.hip (odx_gauss_knm_h2_store): 24-bit fixed point (a u16 plane + a u8 plane, 3 bytes per entry) or bf16
+// (2 bytes per entry).  The pass is HBM-bound and already streams at the chip's copy rate (knm_pass.hip: 6.2 TB/s of the
+// 6.3 it delivers), so the only lever left on its time is the number of bytes per entry.
+//
+// Same persistent scheme as knm_pass_kernel / knm_pass2_kernel: a workgroup streams blocks of R rows; thread t owns the
+// 4-column chunks t, t + NT, ... (CH of them) of every row — 8 bytes of the u16 plane and, for the 24-bit format, 4 bytes
+// of the u8 plane per chunk: the same columns-per-thread as the f32 kernel, so the same (NT, CH) cover a row with the same
+// few idle lanes, at 3 instead of 4 registers per chunk (twice the rows per block in the same budget) —, keeps the
+// running column sums of K' t in registers as f64 and the R x CH chunks of the current block in registers as loaded
+// (never as doubles); v sits in LDS as f64.  Phase 1 forms the R row dots and reduces
+// them over the workgroup, phase 2 adds K[r, cols] t_r into the column sums and re-issues the next block's loads chunk by
+// chunk.  K is read through buffer descriptors (wave-uniform base and length per (row, chunk column) window, one 32-bit
+// per-lane offset): chunks past a row's end and rows past n read as zero by the hardware range check — no branches in
+// the streaming loop.  Slab per workgroup + fixed-order reduce: bitwise reproducible.
+//
+// Decoding: a 24-bit entry is assembled from its three bytes by ONE v_perm_b32 and converted by v_cvt_f64_u32 (exact);
+// the 2^-24 of the fixed-point scale is folded into v (phase 1) and into the slab write (phase 2).  A bf16 entry is a
+// shift / mask and v_cvt_f64_f32.
+#include <algorithm>
+
+#include "odx_internal.h"
+
+namespace odx {
+
+typedef unsigned int u32x4q __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2q __attribute__((ext_vector_type(2)));
+typedef double f64x2q __attribute__((ext_vector_type(2)));
+
+enum { QF_U24 = 1, QF_BF16 = 2 };      // = ODX_KNM_U24 / ODX_KNM_BF16
+
+template <int FMT>
+struct QChunk {
+  u32x2q hi;      // 4 u16: columns 4 c .. 4 c + 3 of the u16 plane
+  unsigned lo;    // their 4 low bytes (24-bit format only)
+};
+
+// entry e (0..3) of a chunk as a double: the integer q for QF_U24 (value = q 2^-24), the value itself for QF_BF16
+template <int FMT>
+__device__ __forceinline__ double q_entry(const QChunk<FMT>& k, int e) {
+  const unsigned h = k.hi[e >> 1];
+  if (FMT == QF_U24) {
+    // v_perm_b32: selector bytes 0..3 pick bytes of the second source (the low-byte dword), 4..7 bytes of the first (the
+    // u16 pair), 0x0c a zero byte: result = [low byte e | u16 << 8]
+    const unsigned sel = ((e & 1) ? 0x0c070600u : 0x0c050400u) | (unsigned)e;
+    return (double)__builtin_amdgcn_perm(h, k.lo, sel);
+  }
+  return (double)__uint_as_float((e & 1) ? (h & 0xffff0000u) : (h << 16));
+}
+
+template <int NT, int CH, int R, int NV, int FMT>
+__global__ __launch_bounds__(NT) void knm_passq_kernel(const unsigned short* __restrict__ Khi, int64_t ldk,
+                                                       const unsigned char* __restrict__ Klo, int64_t ldlo, int64_t n,
+                                                       int64_t M, const double* __restrict__ v1, const double* __restrict__ v2,
+                                                       const double* __restrict__ w, double* __restrict__ slab, int64_t slab_ld) {
+  constexpr int NW = NT / 64;
+  extern __shared__ __attribute__((aligned(16))) double vsq[];       // [NV][vcap]
+  __shared__ double red[2][NW][NV * R];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nchunk = (int)((M + 3) >> 2);
+  const int vcap = nchunk * 4;
+  const int64_t nblk = (n + R - 1) / R;
+  const double vscale = FMT == QF_U24 ? 5.9604644775390625e-08 : 1.0;      // 2^-24 (exact)
+  for (int i = tid; i < vcap; i += NT) {
+    vsq[i] = (v1 != nullptr && i < M) ? v1[i] * vscale : 0.0;
+    if (NV == 2) vsq[vcap + i] = i < M ? v2[i] * vscale : 0.0;
+  }
+  const int voff_hi = tid * 8, voff_lo = tid * 4;      // the only per-lane parts of a K address
+  double acc[NV][CH][4];
+#pragma unroll
+  for (int q = 0; q < NV; ++q)
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[q][c][e] = 0.0;
+
+  QChunk<FMT> kr[R][CH];
+  const int row_bytes_hi = nchunk * 8, row_bytes_lo = nchunk * 4;
+  auto load_block = [&](int64_t blk, int c) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      // descriptors of the windows [chunk column c of row `row`] of the two planes: base and length are wave-uniform
+      // scalars; lanes whose chunk lies past the row's end (or rows past n: zero records) get zeros from the range check
+      const int64_t row = blk * R + r;
+      const bool in = row < n;
+      const int64_t rr = in ? row : 0;
+      const int left_hi = row_bytes_hi - c * NT * 8;
+      const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<unsigned short*>(Khi + rr * ldk + (int64_t)c * NT * 4), (short)0, (in && left_hi > 0) ? left_hi : 0, 0x00020000);
+      kr[r][c].hi = __builtin_amdgcn_raw_buffer_load_b64(rh, voff_hi, 0, 0);
+      if (FMT == QF_U24) {
+        const int left_lo = row_bytes_lo - c * NT * 4;
+        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned char*>(Klo + rr * ldlo + (int64_t)c * NT * 4), (short)0, (in && left_lo > 0) ? left_lo : 0, 0x00020000);
+        kr[r][c].lo = __builtin_amdgcn_raw_buffer_load_b32(rl, voff_lo, 0, 0);
+      }
+    }
+  };
+
+  int64_t blk = blockIdx.x;
+  if (blk < nblk) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) load_block(blk, c);
+  }
+  __syncthreads();  // vsq is complete
+  int pp = 0;
+  for (; blk < nblk; blk += gridDim.x) {
+    double t[NV][R];
+#pragma unroll
+    for (int q = 0; q < NV; ++q)
+#pragma unroll
+      for (int r = 0; r < R; ++r) t[q][r] = 0.0;
+    if (v1 != nullptr) {
+      // phase 1: row dots.  An opaque zero in the LDS index keeps the (loop-invariant) reads of v inside the loop — hoisted
+      // they would hold NV x CH x 4 doubles for good (knm_pass2_kernel, same reason).
+      int zofs;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(zofs));
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+          const int ch = tid + c * NT + zofs;
+          const int vi = (ch < nchunk ? ch : nchunk - 1) * 4;      // any valid entries where K reads as zero
+          const f64x2q a = *reinterpret_cast<const f64x2q*>(&vsq[q * vcap + vi]);
+          const f64x2q b = *reinterpret_cast<const f64x2q*>(&vsq[q * vcap + vi + 2]);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            t[q][r] = fma(q_entry<FMT>(kr[r][c], 0), a[0], t[q][r]);
+            t[q][r] = fma(q_entry<FMT>(kr[r][c], 1), a[1], t[q][r]);
+            t[q][r] = fma(q_entry<FMT>(kr[r][c], 2), b[0], t[q][r]);
+            t[q][r] = fma(q_entry<FMT>(kr[r][c], 3), b[1], t[q][r]);
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NV; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          double s = t[q][r];
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+          if (lane == 0) red[pp][wave][q * R + r] = s;
+        }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < NV; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          double s = 0.0;
+#pragma unroll
+          for (int u = 0; u < NW; ++u) s += red[pp][u][q * R + r];
+          t[q][r] = s;
+        }
+      pp ^= 1;
+    }
+    if (NV == 1 && w != nullptr) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int64_t row = blk * R + r;
+        if (row < n) t[0][r] += w[row];
+      }
+    }
+    // the decoded doubles of phase 1 must not stay live into phase 2 (R x CH x 4 doubles: spills): make the raw registers
+    // opaque here, phase 2 decodes again
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        asm volatile("" : "+v"(kr[r][c].hi));
+        if (FMT == QF_U24) asm volatile("" : "+v"(kr[r][c].lo));
+      }
+    // phase 2: column sums, and the next block's loads re-issued chunk by chunk
+    const int64_t nxt = blk + gridDim.x;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const double kd = q_entry<FMT>(kr[r][c], e);
+#pragma unroll
+          for (int q = 0; q < NV; ++q) acc[q][c][e] = fma(kd, t[q][r], acc[q][c][e]);
+        }
+      if (nxt < nblk) load_block(nxt, c);
+    }
+  }
+  double* my = slab + (int64_t)blockIdx.x * slab_ld * NV;
+#pragma unroll
+  for (int q = 0; q < NV; ++q)
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = tid + c * NT;
+      if (ch < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) my[q * slab_ld + (int64_t)ch * 4 + e] = acc[q][c][e] * vscale;
+      }
+    }
+}
+
+struct QCfg {
+  int nt, ch, r, wg_per_cu;
+};
+
+static bool pick_qcfg(int64_t M, int nv, QCfg* cfg) {
+  const int64_t chunks = (M + 3) / 4;
+  if (nv == 1) {      // (NT, CH) as knm_pass.hip's pick_cfg; twice its rows per block where the registers allow
+    if (chunks <= 256) { *cfg = {256, 1, 16, 2}; return true; }
+    if (chunks <= 512) { *cfg = {256, 2, 8, 2}; return true; }
+    if (chunks <= 1024) { *cfg = {256, 4, 8, 2}; return true; }
+    if (chunks <= 2048) { *cfg = {512, 4, 8, 1}; return true; }
+    if (chunks <= 2560) { *cfg = {512, 5, 6, 1}; return true; }
+    if (chunks <= 3072) { *cfg = {512, 6, 4, 1}; return true; }
+    if (chunks <= 5120) { *cfg = {1024, 5, 1, 1}; return true; }
+    return false;
+  }
+  // two vectors: both in LDS (2 x roundup(M, 4) x 8 B beside the reduction scratch), a second set of column sums in registers
+  if (chunks <= 1024 || chunks > 2560) return false;
+  if (chunks <= 2048) *cfg = {512, 4, 2, 1};
+  else *cfg = {512, 5, 2, 1};
+  const int64_t lds = 2 * chunks * 4 * 8 + 2 * (cfg->nt / 64) * cfg->r * 2 * 8 + 64;
+  return lds <= 163840;
+}
+
+static int qgrid_for(const QCfg& cfg, int64_t n) {
+  int cus = odx_device_cus();
+  if (cus <= 0) cus = 256;
+  const int64_t nblk = ceil_div(n, cfg.r);
+  int64_t g = (int64_t)cus * cfg.wg_per_cu;
+  if (g > nblk) g = nblk;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+template <int NT, int CH, int R, int NV, int FMT>
+static int launch_passq(int grid, size_t lds, hipStream_t s, const void* K, int64_t ldk, const void* Klo, int64_t ldlo, int64_t n,
+                        int64_t M, const double* v, const double* v2, const double* w, double* slab, int64_t slab_ld) {
+  ODX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knm_passq_kernel<NT, CH, R, NV, FMT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((knm_passq_kernel<NT, CH, R, NV, FMT>), dim3(grid), dim3(NT), lds, s, static_cast<const unsigned short*>(K),
+                     ldk, static_cast<const unsigned char*>(Klo), ldlo, n, M, v, v2, w, slab, slab_ld);
+  return ODX_OK;
+}
+
+template <int NV, int FMT>
+static int dispatch_passq(const QCfg& cfg, int grid, size_t lds, hipStream_t s, const void* K, int64_t ldk, const void* Klo,
+                          int64_t ldlo, int64_t n, int64_t M, const double* v, const double* v2, const double* w, double* slab,
+                          int64_t slab_ld) {
+#define ODX_Q(NT_, CH_, R_) return launch_passq<NT_, CH_, R_, NV, FMT>(grid, lds, s, K, ldk, Klo, ldlo, n, M, v, v2, w, slab, slab_ld)
+  if constexpr (NV == 1) {
+    if (cfg.nt == 256 && cfg.ch == 1) ODX_Q(256, 1, 16);
+    if (cfg.nt == 256 && cfg.ch == 2) ODX_Q(256, 2, 8);
+    if (cfg.nt == 256 && cfg.ch == 4) ODX_Q(256, 4, 8);
+    if (cfg.nt == 512 && cfg.ch == 4) ODX_Q(512, 4, 8);
+    if (cfg.nt == 512 && cfg.ch == 5) ODX_Q(512, 5, 6);
+    if (cfg.nt == 512 && cfg.ch == 6) ODX_Q(512, 6, 4);
+    ODX_Q(1024, 5, 1);
+  } else {
+    if (cfg.ch == 4) ODX_Q(512, 4, 2);
+    ODX_Q(512, 5, 2);
+  }
+#undef ODX_Q
+}
+
+}  // namespace odx
+
+using namespace odx;
+
+static int check_q(const char* who, const void* K, int64_t ldk, const void* Klo, int64_t ldlo, int fmt, int64_t M) {
+  ODX_REQUIRE(fmt == ODX_KNM_U24 || fmt == ODX_KNM_BF16, "%s: storage format must be ODX_KNM_U24 or ODX_KNM_BF16 (got %d)", who, fmt);
+  // (row sub-blocks of a stored shard are valid arguments: the planes need the alignment of one chunk load only)
+  ODX_REQUIRE(K && ldk % 8 == 0 && ldk >= round_up(M, 8) && (reinterpret_cast<uintptr_t>(K) & 7u) == 0,
+              "%s: K must be 8-byte aligned with ldk %% 8 == 0, ldk >= roundup(M, 8)", who);
+  if (fmt == ODX_KNM_U24)
+    ODX_REQUIRE(Klo && ldlo % 8 == 0 && ldlo >= round_up(M, 8) && (reinterpret_cast<uintptr_t>(Klo) & 3u) == 0,
+                "%s: the low-byte plane must be 4-byte aligned with ldlo %% 8 == 0, ldlo >= roundup(M, 8)", who);
+  return ODX_OK;
+}
+
+extern "C" int64_t odx_knm_fwd_bwd_q_workspace_bytes(int64_t n, int64_t M, int fmt) {
+  QCfg cfg;
+  if (n <= 0 || M <= 0) return 0;
+  if ((fmt != ODX_KNM_U24 && fmt != ODX_KNM_BF16) || !pick_qcfg(M, 1, &cfg)) return ODX_ERR_UNSUPPORTED;
+  int cus = odx_device_cus();
+  if (cus <= 0) cus = 256;
+  return (int64_t)cus * cfg.wg_per_cu * round_up(M, 4) * (int64_t)sizeof(double);
+}
+
+extern "C" int odx_knm_fwd_bwd_q(const void* K, int64_t ldk, const void* Klo, int64_t ldlo, int fmt, int64_t n, int64_t M,
+                                 const double* v, const double* w, double* out, void* workspace, int64_t workspace_bytes,
+                                 odx_stream_t stream) {
+  ODX_REQUIRE(M > 0 && out, "odx_knm_fwd_bwd_q: M <= 0 or null out");
+  hipStream_t s = as_stream(stream);
+  if (n <= 0) {
+    ODX_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)M * sizeof(double), s));
+    return ODX_OK;
+  }
+  ODX_REQUIRE(v || w, "odx_knm_fwd_bwd_q: both v and w null");
+  ODX_PROPAGATE(check_q("odx_knm_fwd_bwd_q", K, ldk, Klo, ldlo, fmt, M));
+  QCfg cfg;
+  if (!pick_qcfg(M, 1, &cfg)) {
+    set_error("odx_knm_fwd_bwd_q: M = %lld exceeds the 20480 columns the compact-format pass kernels are built for", (long long)M);
+    return ODX_ERR_UNSUPPORTED;
+  }
+  const int grid = qgrid_for(cfg, n);
+  const int64_t slab_ld = round_up(M, 4);
+  if (workspace == nullptr || workspace_bytes < (int64_t)grid * slab_ld * (int64_t)sizeof(double)) {
+    set_error("odx_knm_fwd_bwd_q: workspace too small");
+    return ODX_ERR_WORKSPACE;
+  }
+  double* slab = static_cast<double*>(workspace);
+  const size_t lds = (size_t)slab_ld * sizeof(double);
+  if (fmt == ODX_KNM_U24) ODX_PROPAGATE((dispatch_passq<1, QF_U24>(cfg, grid, lds, s, K, ldk, Klo, ldlo, n, M, v, nullptr, w, slab, slab_ld)));
+  else ODX_PROPAGATE((dispatch_passq<1, QF_BF16>(cfg, grid, lds, s, K, ldk, nullptr, 0, n, M, v, nullptr, w, slab, slab_ld)));
+  ODX_CHECK_LAUNCH("odx_knm_fwd_bwd_q");
+  return slab_reduce_f64(slab, slab_ld, grid, M, out, s);
+}
+
+extern "C" int64_t odx_knm_fwd_bwd2_q_workspace_bytes(int64_t n, int64_t M, int fmt) {
+  QCfg cfg;
+  if (n <= 0 || M <= 0) return 0;
+  if ((fmt != ODX_KNM_U24 && fmt != ODX_KNM_BF16) || !pick_qcfg(M, 2, &cfg)) return ODX_ERR_UNSUPPORTED;
+  int cus = odx_device_cus();
+  if (cus <= 0) cus = 256;
+  return 2 * (int64_t)cus * cfg.wg_per_cu * round_up(M, 4) * (int64_t)sizeof(double);
+}
+
+extern "C" int odx_knm_fwd_bwd2_q(const void* K, int64_t ldk, const void* Klo, int64_t ldlo, int fmt, int64_t n, int64_t M,
+                                  const double* v, const double* v2, double* out, double* out2, void* workspace,
+                                  int64_t workspace_bytes, odx_stream_t stream) {
+  ODX_REQUIRE(M > 0 && out && out2, "odx_knm_fwd_bwd2_q: M <= 0 or null out");
+  hipStream_t s = as_stream(stream);
+  if (n <= 0) {
+    ODX_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)M * sizeof(double), s));
+    ODX_CHECK_HIP(hipMemsetAsync(out2, 0, (size_t)M * sizeof(double), s));
+    return ODX_OK;
+  }
+  ODX_REQUIRE(v && v2, "odx_knm_fwd_bwd2_q: null v or v2");
+  ODX_PROPAGATE(check_q("odx_knm_fwd_bwd2_q", K, ldk, Klo, ldlo, fmt, M));
+  QCfg cfg;
+  if (!pick_qcfg(M, 2, &cfg)) {
+    set_error("odx_knm_fwd_bwd2_q: M = %lld is outside the two-vector configurations (use two single passes)", (long long)M);
+    return ODX_ERR_UNSUPPORTED;
+  }
+  const int grid = qgrid_for(cfg, n);
+  const int64_t slab_ld = round_up(M, 4);
+  if (workspace == nullptr || workspace_bytes < 2 * (int64_t)grid * slab_ld * (int64_t)sizeof(double)) {
+    set_error("odx_knm_fwd_bwd2_q: workspace too small");
+    return ODX_ERR_WORKSPACE;
+  }
+  double* slab = static_cast<double*>(workspace);
+  const size_t lds = (size_t)(2 * slab_ld * sizeof(double));
+  if (fmt == ODX_KNM_U24) ODX_PROPAGATE((dispatch_passq<2, QF_U24>(cfg, grid, lds, s, K, ldk, Klo, ldlo, n, M, v, v2, nullptr, slab, slab_ld)));
+  else ODX_PROPAGATE((dispatch_passq<2, QF_BF16>(cfg, grid, lds, s, K, ldk, nullptr, 0, n, M, v, v2, nullptr, slab, slab_ld)));
+  ODX_CHECK_LAUNCH("odx_knm_fwd_bwd2_q");
+  return slab_reduce2_f64(slab, slab_ld, grid, M, out, out2, s);
+}

@@ -60,6 +60,8 @@ int fill_f64(double* A, int64_t lda, int64_t rows, int64_t cols, double value, h
 
 // knm_pass.hip: out[j] = sum_g slab[g][j], g = 0 .. nslab - 1, in a fixed order
 int slab_reduce_f64(const double* slab, int64_t slab_ld, int nslab, int64_t M, double* out, hipStream_t stream);
+// the same for the two vectors a two-product pass leaves per workgroup (slab g = [sums of v | sums of v2], 2 slab_ld apart)
+int slab_reduce2_f64(const double* slab, int64_t slab_ld, int nslab, int64_t M, double* out, double* out2, hipStream_t stream);
 
 // knm_pass.hip: the CG pass for a batch of classes (one launch; per class the arithmetic of odx_knm_fwd_bwd)
 bool knm_pass_batch_cfg(int B, const int64_t* M, int* nt, int* ch, int* r);

@@ -43,7 +43,33 @@ class Precond:
 
 
 class Knm:
-    __slots__ = ("K", "n", "M", "ld")
+    """A stored K_nM shard.  fmt "f32": K (n, ld) f32.  "u24": 24-bit fixed point — K (n, ld) int16 holds q >> 8 and lo
+    (n, ld) uint8 holds q & 255, q = round(K 2^24).  "bf16": K (n, ld) int16 holds the bf16 bit patterns.  (include/odx.h,
+    "compact storage of the stored K_nM")."""
+    __slots__ = ("K", "n", "M", "ld", "fmt", "lo")
+
+    def __init__(self):
+        self.fmt, self.lo = "f32", None
+
+    def dense(self):
+        """The block as an (n, M) f32 tensor (tests, diagnostics; exact for every format)."""
+        if self.fmt == "f32":
+            return self.K[:, :self.M]
+        if self.fmt == "u24":
+            q = ((self.K[:, :self.M].to(torch.int32) & 0xFFFF) << 8) | self.lo[:, :self.M].to(torch.int32)
+            return q.to(torch.float32) * (2.0 ** -24)
+        return ((self.K[:, :self.M].to(torch.int32) & 0xFFFF) << 16).view(torch.float32)
+
+    def rows(self, lo, hi):
+        """The sub-block of rows [lo, hi) as a view."""
+        sub = Knm()
+        sub.n, sub.M, sub.ld, sub.fmt = hi - lo, self.M, self.ld, self.fmt
+        sub.K = self.K[lo:hi]
+        sub.lo = self.lo[lo:hi] if self.lo is not None else None
+        return sub
+
+
+_KNM_CODE = {"f32": hip.KNM_F32, "u24": hip.KNM_U24, "bf16": hip.KNM_BF16}
 
 
 class HipBackend:
@@ -58,6 +84,14 @@ class HipBackend:
         self.gauss = os.environ.get("ODX_GAUSS", "h2")
         if self.gauss not in ("h2", "f32"):
             raise ValueError("ODX_GAUSS must be 'h2' or 'f32', got %r" % self.gauss)
+        # Storage of the K_nM block the CG passes stream (include/odx.h): "f32" always f32; "u24" / "bf16" always that compact
+        # format (f16-split kernels only); "auto" (default): 24-bit fixed point for the blocks whose passes are HBM-bound
+        # (>= 2^28 entries on the wide tile core: the headline, config 4 / 5 shards), f32 below — small fits gain nothing
+        # and keep the one-library-call CG.  tools/precision_storage_study.py: alpha against the f64 evaluation is the same
+        # with u24 as with f32 storage; bf16 is BASELINE config 2's throughput-only storage (alpha off by 1e-2..6e-1).
+        self.knm_storage = os.environ.get("ODX_KNM", "auto")
+        if self.knm_storage not in ("auto", "f32", "u24", "bf16"):
+            raise ValueError("ODX_KNM must be 'auto', 'f32', 'u24' or 'bf16', got %r" % self.knm_storage)
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -194,17 +228,48 @@ class HipBackend:
         if info != 0:
             raise hip.OdxError("FALKON preconditioner: non-positive pivot at index %d (Cholesky failed)" % (info - 1))
 
+    def knm_format(self, n, M):
+        """Storage format a K_nM block of this shape gets (see __init__)."""
+        if self.gauss != "h2" or n <= 0 or M <= 0:
+            return "f32"
+        if self.knm_storage in ("u24", "bf16"):
+            return self.knm_storage if self.lib.odx_knm_fwd_bwd_q_workspace_bytes(n, M, _KNM_CODE[self.knm_storage]) >= 0 else "f32"
+        if self.knm_storage == "auto" and n * M >= (1 << 28) and self.lib.odx_gauss_h2_tile(n, M) == 256 \
+                and self.lib.odx_knm_fwd_bwd_q_workspace_bytes(n, M, hip.KNM_U24) >= 0:
+            return "u24"
+        return "f32"
+
+    def knm_bytes(self, n, M):
+        """Bytes of the K_nM block knm() / knm_rhs() make for this shape (for preallocated `out` buffers)."""
+        return int(self.lib.odx_knm_bytes(max(n, 0), M, _KNM_CODE[self.knm_format(n, M)]))
+
+    def _knm_block(self, n, M, fmt, out):
+        K = Knm()
+        K.n, K.M, K.fmt = n, M, fmt
+        K.ld = ld = int(self.lib.odx_knm_ld(M, _KNM_CODE[fmt]))
+        per = {"f32": 4, "u24": 3, "bf16": 2}[fmt]
+        need = n * ld * per
+        if out is not None:
+            raw = out.view(-1).view(torch.uint8)
+            if raw.numel() < need or raw.data_ptr() % 16:
+                raise ValueError("knm: out buffer too small (%d < %d bytes) or not 16-byte aligned" % (raw.numel(), need))
+        else:
+            raw = torch.empty(max(need, 16), dtype=torch.uint8, device=self.device)
+        if fmt == "f32":
+            K.K = raw[: n * ld * 4].view(torch.float32).view(n, ld)
+        else:
+            K.K = raw[: n * ld * 2].view(torch.int16).view(n, ld)
+            if fmt == "u24":
+                K.lo = raw[n * ld * 2: n * ld * 3].view(n, ld)
+        return K
+
     def knm(self, F, Zf, sigma, out=None):
         n, M = F.n, Zf.n
-        ld = (M + 3) // 4 * 4
-        K = Knm()
-        K.n, K.M, K.ld = n, M, ld
-        if out is not None:
-            if out.numel() < n * ld or out.dtype != torch.float32:
-                raise ValueError("knm: out buffer too small")
-            K.K = out.view(-1)[: n * ld].view(n, ld)
-        else:
-            K.K = torch.empty((n, ld), dtype=torch.float32, device=self.device)
+        fmt = self.knm_format(n, M)
+        if fmt != "f32":
+            return self._knm_store(F, Zf, sigma, fmt, None, out, None)[0]
+        K = self._knm_block(n, M, "f32", out)
+        ld = K.ld
         if self.gauss == "h2":
             self.pack(F), self.pack(Zf)
             hip.check(self.lib.odx_gauss_knm_h2(_p(F.P), F.P.stride(0), _p(F.meta), _p(F.sq), n, _p(Zf.P), Zf.P.stride(0),
@@ -215,6 +280,24 @@ class HipBackend:
                                                  float(sigma), _p(K.K), ld, self._stream()), "odx_gauss_knm_f32")
         return K
 
+    def _knm_store(self, F, Zf, sigma, fmt, w, out, rhs_out):
+        """Build on the wide tile core into storage format `fmt` (odx_gauss_knm_h2_store), with the fused right-hand side
+        when w is given."""
+        n, M = F.n, Zf.n
+        K = self._knm_block(n, M, fmt, out)
+        self.pack(F), self.pack(Zf)
+        ws = None
+        if w is not None:
+            w = w.to(dtype=torch.float64, device=self.device).contiguous()
+            if rhs_out is None:
+                rhs_out = torch.empty(M, dtype=torch.float64, device=self.device)
+            ws = self._workspace("knm_rhs", self.lib.odx_gauss_knm_h2_rhs_workspace_bytes(n, M))
+        hip.check(self.lib.odx_gauss_knm_h2_store(_p(F.P), F.P.stride(0), _p(F.meta), _p(F.sq), n, _p(Zf.P), Zf.P.stride(0),
+                                                  _p(Zf.meta), _p(Zf.sq), M, F.D, float(sigma), _KNM_CODE[fmt], _p(K.K), K.ld,
+                                                  _p(K.lo), K.ld, _p(w), _p(rhs_out if w is not None else None), _p(ws),
+                                                  ws.numel() if ws is not None else 0, self._stream()), "odx_gauss_knm_h2_store")
+        return K, rhs_out
+
     def knm_rhs(self, F, Zf, sigma, w, out=None, rhs_out=None):
         """K_nM and this shard's K_nM' w (the right-hand side of the fit) in one go.  With the f16-split kernels on the
         wide tile core the column sums come out of the build itself; otherwise (small blocks, ODX_GAUSS=f32) the build is
@@ -222,25 +305,13 @@ class HipBackend:
         n, M = F.n, Zf.n
         if rhs_out is None:
             rhs_out = torch.empty(M, dtype=torch.float64, device=self.device)
+        fmt = self.knm_format(n, M)
+        if fmt != "f32" and n > 0:
+            return self._knm_store(F, Zf, sigma, fmt, w, out, rhs_out)
         if not (self.gauss == "h2" and n > 0 and self.lib.odx_gauss_h2_tile(n, M) == 256):
             K = self.knm(F, Zf, sigma, out=out)
             return K, self.ktk(K, w=w, out=rhs_out)
-        ld = (M + 3) // 4 * 4
-        K = Knm()
-        K.n, K.M, K.ld = n, M, ld
-        if out is not None:
-            if out.numel() < n * ld or out.dtype != torch.float32:
-                raise ValueError("knm: out buffer too small")
-            K.K = out.view(-1)[: n * ld].view(n, ld)
-        else:
-            K.K = torch.empty((n, ld), dtype=torch.float32, device=self.device)
-        self.pack(F), self.pack(Zf)
-        w = w.to(dtype=torch.float64, device=self.device).contiguous()
-        ws = self._workspace("knm_rhs", self.lib.odx_gauss_knm_h2_rhs_workspace_bytes(n, M))
-        hip.check(self.lib.odx_gauss_knm_h2_rhs(_p(F.P), F.P.stride(0), _p(F.meta), _p(F.sq), n, _p(Zf.P), Zf.P.stride(0),
-                                                _p(Zf.meta), _p(Zf.sq), M, F.D, float(sigma), _p(K.K), ld, _p(w), _p(rhs_out),
-                                                _p(ws), ws.numel(), self._stream()), "odx_gauss_knm_h2_rhs")
-        return K, rhs_out
+        return self._knm_store(F, Zf, sigma, "f32", w, out, rhs_out)
 
     def pin_gauss_tile(self, tile):
         """Pin the tile core of the f16-split Gaussian kernels (128 or 256); 0 = chosen per launch (default)."""
@@ -254,6 +325,15 @@ class HipBackend:
         """out = K' (K v + w) over this shard (f64)."""
         if out is None:
             out = torch.empty(K.M, dtype=torch.float64, device=self.device)
+        if K.fmt != "f32":
+            code = _KNM_CODE[K.fmt]
+            nbytes = self.lib.odx_knm_fwd_bwd_q_workspace_bytes(max(K.n, 1), K.M, code)
+            if nbytes < 0:
+                raise hip.OdxError("odx_knm_fwd_bwd_q: M = %d is outside the supported range" % K.M)
+            ws = self._workspace("ktk", nbytes)
+            hip.check(self.lib.odx_knm_fwd_bwd_q(_p(K.K), K.ld, _p(K.lo), K.ld, code, K.n, K.M, _p(v), _p(w), _p(out), _p(ws),
+                                                 ws.numel(), self._stream()), "odx_knm_fwd_bwd_q")
+            return out
         nbytes = self.lib.odx_knm_fwd_bwd_workspace_bytes(max(K.n, 1), K.M)
         if nbytes < 0:
             raise hip.OdxError("odx_knm_fwd_bwd: M = %d is outside the supported range" % K.M)
@@ -262,20 +342,29 @@ class HipBackend:
                                            self._stream()), "odx_knm_fwd_bwd")
         return out
 
+    def _ktk2_bytes(self, K):
+        if K.fmt != "f32":
+            return self.lib.odx_knm_fwd_bwd2_q_workspace_bytes(max(K.n, 1), K.M, _KNM_CODE[K.fmt])
+        return self.lib.odx_knm_fwd_bwd2_workspace_bytes(max(K.n, 1), K.M)
+
     def can_ktk2(self, K):
         """Whether the two-vector pass exists at this block's width (both vectors must fit in LDS: M <= 10 000)."""
-        return self.lib.odx_knm_fwd_bwd2_workspace_bytes(max(K.n, 1), K.M) >= 0
+        return self._ktk2_bytes(K) >= 0
 
     def ktk2(self, K, v1, v2, out1=None, out2=None):
-        """out1 = K' (K v1), out2 = K' (K v2) over this shard from ONE read of K (odx_knm_fwd_bwd2)."""
+        """out1 = K' (K v1), out2 = K' (K v2) over this shard from ONE read of K (odx_knm_fwd_bwd2[_q])."""
         if out1 is None:
             out1 = torch.empty(K.M, dtype=torch.float64, device=self.device)
         if out2 is None:
             out2 = torch.empty(K.M, dtype=torch.float64, device=self.device)
-        nbytes = self.lib.odx_knm_fwd_bwd2_workspace_bytes(max(K.n, 1), K.M)
+        nbytes = self._ktk2_bytes(K)
         if nbytes < 0:
             raise hip.OdxError("odx_knm_fwd_bwd2: M = %d is outside the two-vector configurations" % K.M)
         ws = self._workspace("ktk", nbytes)
+        if K.fmt != "f32":
+            hip.check(self.lib.odx_knm_fwd_bwd2_q(_p(K.K), K.ld, _p(K.lo), K.ld, _KNM_CODE[K.fmt], K.n, K.M, _p(v1), _p(v2),
+                                                  _p(out1), _p(out2), _p(ws), ws.numel(), self._stream()), "odx_knm_fwd_bwd2_q")
+            return out1, out2
         hip.check(self.lib.odx_knm_fwd_bwd2(_p(K.K), K.ld, K.n, K.M, _p(v1), _p(v2), _p(out1), _p(out2), _p(ws), ws.numel(),
                                             self._stream()), "odx_knm_fwd_bwd2")
         return out1, out2
@@ -303,6 +392,8 @@ class HipBackend:
         b0s: (B, vstride) f64.  Returns alpha (B, vstride) f64 — row b's first M_b entries are class b's alpha, bit for
         bit what cg_solve gives — or None when the classes do not share a pass configuration."""
         B = len(Ks)
+        if any(k.fmt != "f32" for k in Ks):         # the batched library loop streams f32 blocks only
+            return None
         n = (ctypes.c_int64 * B)(*[int(k.n) for k in Ks])
         M = (ctypes.c_int64 * B)(*[int(k.M) for k in Ks])
         nbytes = self.lib.odx_falkon_cg_batched_workspace_bytes(B, n, M)

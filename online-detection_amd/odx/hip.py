@@ -12,6 +12,7 @@ _LIB = None
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libodx.so")
 
 ODX_OK = 0
+KNM_F32, KNM_U24, KNM_BF16 = 0, 1, 2
 GEMM_LOWER_ONLY, GEMM_A_UPPER, GEMM_B_UPPER, GEMM_A_LOWER, GEMM_B_LOWER, GEMM_STORE_T = 1, 2, 4, 8, 16, 32
 
 
@@ -54,6 +55,14 @@ SIGNATURES = {
     "odx_knm_fwd_bwd": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "odx_knm_fwd_bwd2_workspace_bytes": (_i64, [_i64, _i64]),
     "odx_knm_fwd_bwd2": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "odx_knm_ld": (_i64, [_i64, _i32]),
+    "odx_knm_bytes": (_i64, [_i64, _i64, _i32]),
+    "odx_gauss_knm_h2_store": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _f64, _i32, _vp, _i64, _vp, _i64,
+                                      _vp, _vp, _vp, _i64, _vp]),
+    "odx_knm_fwd_bwd_q_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "odx_knm_fwd_bwd_q": (_i32, [_vp, _i64, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "odx_knm_fwd_bwd2_q_workspace_bytes": (_i64, [_i64, _i64, _i32]),
+    "odx_knm_fwd_bwd2_q": (_i32, [_vp, _i64, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "odx_cg_residual": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "odx_falkon_precond_workspace_bytes": (_i64, [_i64, _i32]),
     "odx_falkon_precond_f64": (_i32, [_vp, _i64, _i64, _i32, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),

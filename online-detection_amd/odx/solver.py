@@ -171,7 +171,7 @@ def falkon_fit(be, F, y, Zf, sigma, lam, maxiter=20, opt=None, n_total=None, all
             be.trmv(P, "LAi", u, out=out2)
 
     b0 = ar(b0)                                        # K' (y / n), summed over shards
-    if shard is None and allreduce is None and phase is None and hasattr(be, "cg_solve"):
+    if shard is None and allreduce is None and phase is None and hasattr(be, "cg_solve") and getattr(K, "fmt", "f32") == "f32":
         # one shard, nothing to time per kernel family: the loop below as one library call (odx_falkon_cg_f64)
         if precond_ready is not None:
             precond_ready()

@@ -232,3 +232,79 @@ def test_class_sharded_minibootstrap_equals_single_process(world, tmp_path):
             ny, alpha, M, sigma = models[c]
             assert np.array_equal(ny, ref[c].ny_points_.numpy()) and np.array_equal(alpha, ref[c].alpha_.numpy())
             assert M == ref[c].M and sigma == 6.0
+
+
+def _job_worker(rank, world, port, N, D, M, C, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import odx
+        from odx.dist import RowShard
+        from odx.job import LockstepClassJob
+        from tests.oracle_backend import OracleBackend
+        odx.set_backend(OracleBackend(np.float64))
+        be = odx.get_backend()
+        X, cidx = _job_problem(N, D, M, C)
+        shard = RowShard()
+        lo, hi = shard.bounds(N)
+        row_ids = torch.arange(lo, hi)
+        job = LockstepClassJob(be, torch.from_numpy(X[lo:hi]), N, M, lambda c: torch.where((row_ids % C) == c, 1.0, -1.0).double(),
+                               [torch.from_numpy(i) for i in cidx], 6.0, 1e-4, 20, shard=shard)
+        F = be.features(job.X)
+        alpha, _ = job.run(F)
+        ret[rank] = {"scores": job.scores.numpy().copy(), "trace": list(job.trace), "G": job.G, "alpha_last": alpha.numpy().copy()}
+    finally:
+        dist.destroy_process_group()
+
+
+def _job_problem(N, D, M, C):
+    rng = np.random.default_rng(99)
+    mu = rng.standard_normal((C, D))
+    X = mu[np.arange(N) % C] + 0.7 * rng.standard_normal((N, D))
+    X -= X.mean(0)
+    X *= 6.0 / np.linalg.norm(X, axis=1).mean()
+    X = np.ascontiguousarray(X.astype(np.float32))
+    cidx = []
+    for c in range(C):
+        pos = np.flatnonzero(np.arange(N) % C == c)
+        neg = np.flatnonzero(np.arange(N) % C != c)
+        cidx.append(np.concatenate([pos[: M // 2], neg[rng.integers(0, len(neg), M - min(M // 2, len(pos)))]]).astype(np.int64))
+    return X, cidx
+
+
+def test_headline_control_flow_on_eight_ranks():
+    """The headline job's own control flow (odx/job.py, what bench.py runs) as 8 gloo ranks on the CPU with the oracle
+    backend: 30 classes on 8 ranks -> lock-step batches of 8, 8, 8, 6 — in the last one two ranks own nothing —, the
+    owned classes' preconditioners in class-batched groups of 1 + 2 + 1 batches (n_batches = 4 -> G = 4), one all-gather + one
+    reduce-scatter per CG iteration for a whole batch.  Every rank must run exactly that schedule, and the scores of all 30
+    classes must equal a single process fitting the classes one after the other."""
+    import odx
+    from oracle import falkon_ref as fr
+    N, D, M, C, world = 2400, 16, 40, 30, 8
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_job_worker, args=(world, port, N, D, M, C, ret), nprocs=world, join=True)
+    assert sorted(ret.keys()) == list(range(world))
+    want_batches = [tuple(range(0, 8)), tuple(range(8, 16)), tuple(range(16, 24)), tuple(range(24, 30))]
+    for r in range(world):
+        t = ret[r]["trace"]
+        assert ret[r]["G"] == 4
+        assert [p for k, p in t if k == "fit"] == want_batches
+        owned = [p for k, p in t if k == "precond"]
+        # groups of batches [0], [1, 2], [3] (sizes 1, 2, 3 while smaller than G = 4, cut by the 4 batches there are): rank r
+        # owns class r of batch 0, then classes 8 + r and 16 + r, then — ranks 0..5 only — class 24 + r
+        assert owned == [(r,), (8 + r, 16 + r)] + ([(24 + r,)] if r < 6 else []), (r, owned)
+        # every group is issued one group ahead: the first two before the first fit, the third before the second fit
+        kinds = [k for k, _ in t]
+        assert kinds == (["precond", "precond", "fit", "precond", "fit", "fit", "fit"] if r < 6 else
+                         ["precond", "precond", "fit", "fit", "fit", "fit"]), (r, kinds)
+    scores = np.concatenate([ret[r]["scores"] for r in range(world)], axis=0)
+    X, cidx = _job_problem(N, D, M, C)
+    Xd = X.astype(np.float64)
+    for c in (0, 7, 8, 23, 24, 29):
+        y = np.where(np.arange(N) % C == c, 1.0, -1.0)
+        a, Z = fr.falkon_fit(Xd, y, cidx[c], 6.0, 1e-4, maxiter=20, dtype=np.float64, pc_eps=1e-5, cg_epsilon=1e-7)
+        want = fr.falkon_predict(Xd, Z, a, 6.0)[:, 0]
+        assert np.abs(scores[:, c] - want).max() < 1e-6 * max(1.0, np.abs(want).max()), c
+    assert (scores.argmax(1) == np.arange(N) % C).mean() > 0.9

@@ -494,3 +494,111 @@ def test_pipelined_harvest_equals_the_sequential_loop():
     for xa, xb in zip(a["mask"][0] + a["mask"][1], b["mask"][0] + b["mask"][1]):
         same(xa, xb)
     assert sum(len(p) for p in a["detector"][1]) == sum(len(s[2]) for s in samples)
+
+
+def _plain_roi_align(feat, boxes, scale, P):
+    """RoIAlign (maskrcnn_benchmark legacy form: no half-pixel shift, RoI sides clamped to >= 1, adaptive sampling grid
+    ceil(side / P), samples outside [-1, size] contribute 0) in plain f32 torch, one RoI at a time, every bin / sample /
+    channel of it at once.  feat (C, H, W), boxes (R, 4) -> (R, C, P, P)."""
+    C, H, W = feat.shape
+    out = torch.zeros((boxes.shape[0], C, P, P))
+    for r, b in enumerate(boxes):
+        x1, y1, x2, y2 = (b * scale).tolist()
+        rw, rh = max(x2 - x1, 1.0), max(y2 - y1, 1.0)
+        gw, gh = int(np.ceil(rw / P)), int(np.ceil(rh / P))
+        ys = y1 + (torch.arange(P)[:, None] + (torch.arange(gh)[None, :] + 0.5) / gh) * (rh / P)      # (P, gh)
+        xs = x1 + (torch.arange(P)[:, None] + (torch.arange(gw)[None, :] + 0.5) / gw) * (rw / P)      # (P, gw)
+
+        def taps(v, size):
+            ok = (v >= -1.0) & (v <= size)
+            v = v.clamp(min=0.0)
+            lo = v.floor().long()
+            top = lo >= size - 1
+            lo = torch.where(top, torch.full_like(lo, size - 1), lo)
+            hi = torch.where(top, lo, lo + 1)
+            frac = torch.where(top, torch.zeros_like(v), v - lo.float())
+            return lo, hi, frac, ok
+        yl, yh, fy, oky = taps(ys.reshape(-1), H)
+        xl, xh, fx, okx = taps(xs.reshape(-1), W)
+        wy0, wy1 = ((1 - fy) * oky)[None, :, None], (fy * oky)[None, :, None]
+        wx0, wx1 = ((1 - fx) * okx)[None, None, :], (fx * okx)[None, None, :]
+        v = (wy0 * wx0 * feat[:, yl][:, :, xl] + wy0 * wx1 * feat[:, yl][:, :, xh]
+             + wy1 * wx0 * feat[:, yh][:, :, xl] + wy1 * wx1 * feat[:, yh][:, :, xh])                   # (C, P gh, P gw)
+        out[r] = v.view(C, P, gh, P, gw).mean(dim=(2, 4))
+    return out
+
+
+@pytest.mark.gpu
+def test_forward_gpu_equals_plain_torch_cpu():
+    """The COMPOSITION of the forward — trunk with folded batch norm, the top-k's own order feeding the early-stopping NMS
+    (odx_nms_first_f32), RoIAlign of only the bins the head's stride-2 convolutions read written as NHWC rows
+    (odx_roi_align_rows_f32), the conv5 head as row GEMMs on the split-f16 tile cores, average pooling — on the MI355X
+    against an independent plain-f32 torch restatement of the same network on the CPU: convolution -> frozen batch norm ->
+    ReLU layer by layer (nothing folded), sigmoid / top-k / box decoding / clipping, a greedy NMS loop over all candidates
+    (oracle/roi_ref.nms) cut to post_nms_top_n afterwards, a full 14 x 14 RoIAlign, the stage-5 convolutions with their
+    stride, the mean.  Same seeded weights (batch-norm statistics randomised so that folding matters), reduced width.
+    Required: the SAME proposals (kept anchor ids, in order), boxes equal to 1e-3 px, RoI features within 1e-4 relative."""
+    import copy
+    import torch.nn.functional as Fn
+    from oracle import roi_ref
+    odx.set_backend(None)
+    torch.manual_seed(11)
+    model = OnlineDetectionModel(width=16, pre_nms_top_n=400, post_nms_top_n=48, seed=5).eval()
+    for m in model.modules():
+        if hasattr(m, "running_var"):
+            m.running_var.uniform_(0.5, 1.5)
+            m.running_mean.normal_(0, 0.1)
+            m.weight.data.normal_(1, 0.1)
+            m.bias.data.normal_(0, 0.1)
+    # objectness logits spread over a few units (well separated scores: the comparison is of the pipeline, not of how
+    # two libraries round a tie), box deltas large enough to move and overlap the candidates
+    model.rpn_logits.weight.data.normal_(0, 0.3)
+    model.rpn_deltas.weight.data.normal_(0, 0.05)
+    ref = copy.deepcopy(model)                                    # stays on the CPU
+    model = model.cuda()
+    img = torch.randn(1, 3, 320, 416)
+    gt = torch.tensor([[30.0, 40.0, 200.0, 260.0]])
+    with torch.no_grad():
+        boxes, feats, c4 = model(img.cuda(), gt)
+
+        # ---- the same network in plain torch on the CPU
+        def block(b, x):
+            idn = x if b.down is None else b.down[1](b.down[0](x))
+            y = Fn.relu(b.bn1(b.conv1(x)))
+            y = Fn.relu(b.bn2(b.conv2(y)))
+            return Fn.relu(b.bn3(b.conv3(y)) + idn)
+        bb = ref.backbone
+        x = Fn.max_pool2d(Fn.relu(bb.bn1(bb.conv1(img))), 3, 2, 1)
+        for stage in (bb.layer1, bb.layer2, bb.layer3):
+            for b in stage:
+                x = block(b, x)
+        c4_ref = x
+        t = Fn.relu(ref.rpn_conv(c4_ref))
+        logits, deltas = ref.rpn_logits(t), ref.rpn_deltas(t)
+        _, A, H, W = logits.shape
+        obj = logits.permute(0, 2, 3, 1).reshape(-1).sigmoid()
+        reg = deltas.view(1, A, 4, H, W).permute(0, 3, 4, 1, 2).reshape(-1, 4)
+        score, idx = obj.topk(min(ref.pre_nms_top_n, obj.numel()), sorted=True)
+        anchors = grid_anchors(H, W, ref.stride, ref.cells)
+        cand = decode_deltas(reg[idx], anchors[idx])
+        cand[:, 0::2] = cand[:, 0::2].clamp(0, img.shape[3] - 1)
+        cand[:, 1::2] = cand[:, 1::2].clamp(0, img.shape[2] - 1)
+        keep = torch.from_numpy(roi_ref.nms(cand.numpy(), score.numpy(), ref.rpn_nms))[: ref.post_nms_top_n]
+        boxes_ref = torch.cat((gt, cand[keep]), dim=0)
+        crops = _plain_roi_align(c4_ref[0], boxes_ref, 1.0 / ref.stride, ref.resolution)
+        y = crops
+        for b in ref.head.layer4:
+            y = block(b, y)
+        feats_ref = y.mean(dim=(2, 3))
+
+    assert float((c4.cpu() - c4_ref).abs().max()) < 1e-4 * float(c4_ref.abs().max())
+    assert boxes.shape == boxes_ref.shape, (boxes.shape, boxes_ref.shape)
+    # identical proposals: every kept candidate is the same anchor (its decoded box agrees to rounding), in the same order
+    assert float((boxes.cpu() - boxes_ref).abs().max()) < 1e-3, float((boxes.cpu() - boxes_ref).abs().max())
+    # and, directly, the same index set out of the same top-k order (recomputed on the CPU from the GPU's own trunk map)
+    t_g = Fn.relu(ref.rpn_conv(c4.cpu()))
+    obj_g = ref.rpn_logits(t_g).permute(0, 2, 3, 1).reshape(-1).sigmoid()
+    assert torch.equal(obj_g.topk(min(ref.pre_nms_top_n, obj_g.numel()), sorted=True)[1][keep], idx[keep])
+    rel = float((feats.cpu() - feats_ref).norm(dim=1).max() / feats_ref.norm(dim=1).max())
+    assert feats.shape == feats_ref.shape and rel < 1e-4, rel
+    assert float((feats.cpu() - feats_ref).abs().max()) < 1e-4 * float(feats_ref.abs().max())

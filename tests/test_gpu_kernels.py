@@ -17,19 +17,60 @@ def be():
     return odx.get_backend()
 
 
-@pytest.fixture(params=["h2", "h2w256", "f32"])
+@pytest.fixture(params=["h2", "h2w256", "f32", "h2w256u24"])
 def gauss(be, request):
     """Run a test once per Gaussian-kernel variant: f16 split on the f16 matrix cores with the 128 x 128 and with the
-    256 x 256 tile core (pinned: left alone the library picks by problem size), and all-f32 MFMA."""
-    old, be.gauss = be.gauss, request.param[:2] if request.param.startswith("h2") else request.param
-    be.pin_gauss_tile({"h2": 128, "h2w256": 256}.get(request.param, 0))
-    yield request.param
-    be.gauss = old
+    256 x 256 tile core (pinned: left alone the library picks by problem size), all-f32 MFMA, and the wide core with the
+    K_nM block stored as 24-bit fixed point (what large blocks get by default: backend.knm_format)."""
+    p = request.param
+    old, oldk = be.gauss, be.knm_storage
+    be.gauss = "f32" if p == "f32" else "h2"
+    be.knm_storage = "u24" if p.endswith("u24") else "f32"
+    be.pin_gauss_tile({"h2": 128, "h2w256": 256, "h2w256u24": 256}.get(p, 0))
+    yield p
+    be.gauss, be.knm_storage = old, oldk
     be.pin_gauss_tile(0)
+
+
+def kdense(K):
+    """(n, M) f32 numpy view of a stored block, whatever its storage format, after checking that its pad columns are zero."""
+    assert float(K.K[:, K.M:].abs().max()) == 0.0 if K.ld > K.M else True
+    if K.lo is not None and K.ld > K.M:
+        assert int(K.lo[:, K.M:].max()) == 0
+    return K.dense().cpu().numpy()
+
+
+def kraw(K):
+    """The block's storage as one flat byte tensor (to hand back as `out=`)."""
+    return K.K.view(-1).view(torch.uint8) if K.lo is None else torch.cat([K.K.view(-1).view(torch.uint8), K.lo.view(-1)])
 
 
 def _p(t):
     return ctypes.c_void_p(t.data_ptr())
+
+
+def ktol(sigma, variant="h2"):
+    """Absolute tolerance on a K_nM entry that pins "f32 accuracy" at kernel level: 1e-6 for the shipping f16-split
+    kernels (measured ~4e-7), widened only where f32 itself cannot do better — the f32 roundings of the two squared
+    norms and of their sum (|x|^2 ~ 400: ulp 3e-5) move d^2 by up to ~5e-5, i.e. K by 5e-5 / (2 sigma^2), which passes
+    1e-6 below sigma = 5.  A one-term f16 contraction (3.6e-5) or a bf16 one fails this by more than an order of
+    magnitude.  The all-f32 MFMA variant (ODX_GAUSS=f32) is a sequential f32 fmaf chain over D terms, rounded D times at
+    the magnitude of its partial sums (the split kernels round once per 32 exact products): its own error reaches
+    1.3e-6 at D = 2048, so it is held to 4e-6."""
+    return max(4e-6 if variant == "f32" else 1e-6, 5e-5 / (2.0 * sigma * sigma))
+
+
+def assert_k_close(got, ref, sigma, variant="h2", note=None):
+    """K_nM entries against the f64 kernel: `ktol` everywhere except on (near-)duplicate pairs (K > 0.99), where d^2 is the
+    difference of three numbers of size |x|^2 = 400 — two squared norms and an inner product accumulated in f32 over D
+    terms — each carrying f32 rounding of relative size ~1e-6 after the accumulation (measured on these tests: d^2 off by
+    2e-4 .. 8e-4, growing with D, for the split kernels and for the all-f32 chain alike, i.e. K off by that times
+    1 / (2 sigma^2)): there the bar is 8e-4 / sigma^2.  Any f32 evaluation of this formula has that property (the
+    reference's f32 falkon included); generic entries, where x . z is a fraction of |x|^2, are held to 1e-6."""
+    err = np.abs(np.asarray(got, dtype=np.float64) - ref)
+    near = ref > 0.99
+    assert err[~near].max(initial=0.0) < ktol(sigma, variant), (note, float(err[~near].max(initial=0.0)))
+    assert err[near].max(initial=0.0) < max(ktol(sigma, variant), 8e-4 / sigma ** 2), (note, float(err[near].max(initial=0.0)))
 
 
 def dev(a, dtype=None):
@@ -99,13 +140,13 @@ def test_gauss_knm(be, gauss, n, M, D, sigma):
     F, Zf = be.features(torch.from_numpy(X)), be.features(torch.from_numpy(Z))
     assert np.allclose(F.sq.cpu().numpy(), (X.astype(np.float64) ** 2).sum(1), rtol=1e-5)
     K = be.knm(F, Zf, sigma)
-    got = K.K.cpu().numpy()
+    assert K.fmt == ("u24" if gauss.endswith("u24") else "f32")
+    got = kdense(K)
     ref = fr.gaussian_kernel(X.astype(np.float64), Z.astype(np.float64), sigma)
-    assert np.abs(got[:, :M] - ref).max() < 2e-5
-    assert np.all(got[:, M:] == 0)
+    assert_k_close(got, ref, sigma, gauss)
     # duplicate centre / identical point -> clamp at 0 -> exactly 1
     Z2 = be.features(torch.from_numpy(X[:5].copy()))
-    K2 = be.knm(F, Z2, sigma).K.cpu().numpy()
+    K2 = kdense(be.knm(F, Z2, sigma))
     assert np.all(np.abs(np.diag(K2[:5, :5]) - 1.0) < 1e-4)
 
 
@@ -120,15 +161,14 @@ def test_gauss_knm_with_fused_rhs(be, gauss, n, M, D, sigma):
     w = rng.standard_normal(n)
     F, Zf = be.features(torch.from_numpy(X)), be.features(torch.from_numpy(Z))
     K, ktw = be.knm_rhs(F, Zf, sigma, torch.from_numpy(w).cuda())
-    got = K.K.cpu().numpy()
+    got = kdense(K)
     ref = fr.gaussian_kernel(X.astype(np.float64), Z.astype(np.float64), sigma)
-    assert np.abs(got[:, :M] - ref).max() < 2e-5
-    assert np.all(got[:, M:] == 0)
-    want = got[:, :M].astype(np.float64).T @ w          # the sums are over the f32 entries that were stored
+    assert_k_close(got, ref, sigma, gauss)
+    want = got.astype(np.float64).T @ w          # the sums are over the entries that were stored
     assert np.abs(ktw.cpu().numpy() - want).max() <= 1e-12 * max(1.0, np.abs(want).max()) * n
     # into caller-provided storage, twice: same bits
     out = torch.empty(M + 2, dtype=torch.float64, device="cuda")
-    _, again = be.knm_rhs(F, Zf, sigma, torch.from_numpy(w).cuda(), out=K.K.view(-1), rhs_out=out[:M])
+    _, again = be.knm_rhs(F, Zf, sigma, torch.from_numpy(w).cuda(), out=torch.empty(be.knm_bytes(n, M) + 16, dtype=torch.uint8, device="cuda"), rhs_out=out[:M])
     assert torch.equal(again, ktw)
 
 
@@ -167,10 +207,10 @@ def test_gauss_edge_shapes(be, gauss, n, M, D):
     X, Z = rng.standard_normal((n, D)).astype(np.float32), rng.standard_normal((M, D)).astype(np.float32)
     F, Zf = be.features(torch.from_numpy(X)), be.features(torch.from_numpy(Z))
     K = be.knm(F, Zf, 4.0)
-    assert tuple(K.K.shape) == (n, (M + 3) // 4 * 4)
+    assert tuple(K.K.shape) == (n, (M + 7) // 8 * 8 if K.fmt != "f32" else (M + 3) // 4 * 4)
     if n and M:
         ref = fr.gaussian_kernel(X.astype(np.float64), Z.astype(np.float64), 4.0)
-        assert np.abs(K.K.cpu().numpy()[:, :M] - ref).max() < 2e-5
+        assert_k_close(kdense(K), ref, 4.0, gauss)
     al = rng.standard_normal((M, 2))
     out = be.mmv(F, Zf, 4.0, torch.from_numpy(al))
     assert tuple(out.shape) == (n, 2)
@@ -224,6 +264,131 @@ def test_two_vector_pass_equals_two_passes(be, n, M):
         assert float((got - single).abs().max()) <= 1e-12 * float(single.abs().max())
     a1, a2 = be.ktk2(K, be.vec(v1), be.vec(v2))
     assert torch.equal(a1, o1[:M]) and torch.equal(a2, o2[:M])             # repeatable bit for bit
+
+
+def _compact_block(rng, n, M, fmt):
+    """A random K block in [0, 1] stored as `fmt` (u24 / bf16) with the library's layout, and the f64 values it encodes."""
+    from odx.backend import Knm
+    ld = (M + 7) // 8 * 8
+    K = Knm()
+    K.n, K.M, K.ld, K.fmt = n, M, ld, fmt
+    if fmt == "u24":
+        q = rng.integers(0, 1 << 24, (n, ld), dtype=np.int64)
+        q[:, M:] = 0
+        q[0, 0], q[-1, M - 1] = (1 << 24) - 1, 0                       # the extreme codes
+        K.K = torch.from_numpy((q >> 8).astype(np.uint16).view(np.int16)).cuda()
+        K.lo = torch.from_numpy((q & 255).astype(np.uint8)).cuda()
+        vals = q[:, :M].astype(np.float64) * 2.0 ** -24
+    else:
+        f = rng.random((n, ld)).astype(np.float32)
+        f[:, M:] = 0
+        bits = (f.view(np.uint32) >> 16).astype(np.uint16)               # truncation: any bf16 pattern will do
+        K.K = torch.from_numpy(bits.view(np.int16)).cuda()
+        vals = (bits.astype(np.uint32) << 16).view(np.float32)[:, :M].astype(np.float64)
+    return K, vals
+
+
+@pytest.mark.parametrize("fmt", ["u24", "bf16"])
+@pytest.mark.parametrize("n,M", [(1000, 500), (4097, 2000), (37, 130), (700, 3000), (1030, 4099), (520, 10000), (300, 12001),
+                                 (200, 20000), (3, 1), (65, 8)])
+def test_compact_pass(be, fmt, n, M):
+    """odx_knm_fwd_bwd_q: the CG pass over a K_nM block stored as 24-bit fixed point (u16 + u8 planes) or bf16 — every
+    thread / chunk configuration (M = 1 .. 20 000), rows not a multiple of the row block, against the f64 product of the
+    decoded values; decoding itself against Knm.dense(); bitwise repeatable."""
+    rng = np.random.default_rng(n + 3 * M)
+    K, vals = _compact_block(rng, n, M, fmt)
+    assert np.array_equal(K.dense().cpu().numpy().astype(np.float64), vals)
+    v, w = rng.standard_normal(M), rng.standard_normal(n)
+    out = torch.full((M + 4,), float("nan"), dtype=torch.float64, device="cuda")
+    be.ktk(K, v=dev(v), w=dev(w), out=out[:M])
+    ref = vals.T @ (vals @ v + w)
+    assert torch.isnan(out[M:]).all()
+    assert np.abs(out[:M].cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max() + 1e-12
+    assert np.abs(be.ktk(K, w=dev(w)).cpu().numpy() - vals.T @ w).max() <= 1e-12 * np.abs(ref).max() + 1e-12
+    a, b = be.ktk(K, v=dev(v)), be.ktk(K, v=dev(v))
+    assert torch.equal(a, b)
+    assert np.abs(a.cpu().numpy() - vals.T @ (vals @ v)).max() <= 1e-12 * np.abs(ref).max() + 1e-12
+    # halves add up
+    h = n // 2
+    if h:
+        parts = be.ktk(K.rows(0, h), v=dev(v)) + be.ktk(K.rows(h, n), v=dev(v))
+        assert float((parts - a).abs().max()) <= 1e-12 * float(a.abs().max()) + 1e-12
+
+
+@pytest.mark.parametrize("fmt", ["u24", "bf16"])
+@pytest.mark.parametrize("n,M", [(5000, 4100), (3001, 10000), (2000, 7001), (100, 8192)])
+def test_compact_two_vector_pass(be, fmt, n, M):
+    """odx_knm_fwd_bwd2_q against two single passes and the f64 product."""
+    rng = np.random.default_rng(n + M)
+    K, vals = _compact_block(rng, n, M, fmt)
+    assert be.can_ktk2(K)
+    v1, v2 = rng.standard_normal(M), rng.standard_normal(M) * 1e-3
+    o1 = torch.full((M + 4,), float("nan"), dtype=torch.float64, device="cuda")
+    o2 = torch.full((M + 4,), float("nan"), dtype=torch.float64, device="cuda")
+    be.ktk2(K, be.vec(v1), be.vec(v2), out1=o1[:M], out2=o2[:M])
+    assert torch.isnan(o1[M:]).all() and torch.isnan(o2[M:]).all()
+    for got, v in ((o1[:M], v1), (o2[:M], v2)):
+        ref = vals.T @ (vals @ v)
+        assert np.abs(got.cpu().numpy() - ref).max() <= 1e-11 * np.abs(ref).max()
+        single = be.ktk(K, v=be.vec(v))
+        assert float((got - single).abs().max()) <= 1e-12 * float(single.abs().max())
+    a1, a2 = be.ktk2(K, be.vec(v1), be.vec(v2))
+    assert torch.equal(a1, o1[:M]) and torch.equal(a2, o2[:M])
+    for Mbad in (500, 4096, 10240, 20000):
+        Kb, _ = _compact_block(rng, 8, Mbad, fmt)
+        assert not be.can_ktk2(Kb)
+
+
+@pytest.mark.parametrize("n,M,D,sigma", [(1000, 500, 256, 10.0), (333, 130, 1024, 15.0), (700, 257, 70, 5.0), (513, 1025, 64, 8.0)])
+def test_bf16_stored_knm(be, n, M, D, sigma):
+    """BASELINE config 2's throughput storage: K_nM rounded to bf16 by the build's epilogue (backend.knm_storage = "bf16").
+    Every entry is the round-to-nearest-even bf16 of the f32 entry the default build stores; the fused right-hand side is
+    the column sums of the STORED values; the pass runs on it."""
+    rng = np.random.default_rng(n + M)
+    X = (rng.standard_normal((n, D)) * (20.0 / np.sqrt(D))).astype(np.float32)
+    Z = X[rng.integers(0, n, M)].copy()
+    w = rng.standard_normal(n)
+    F, Zf = be.features(torch.from_numpy(X)), be.features(torch.from_numpy(Z))
+    old = be.knm_storage
+    try:
+        be.knm_storage = "f32"
+        be.pin_gauss_tile(256)
+        K32 = be.knm(F, Zf, sigma).dense()
+        be.knm_storage = "bf16"
+        K, ktw = be.knm_rhs(F, Zf, sigma, torch.from_numpy(w).cuda())
+    finally:
+        be.knm_storage = old
+        be.pin_gauss_tile(0)
+    assert K.fmt == "bf16"
+    got = kdense(K)
+    assert np.array_equal(got, K32.to(torch.bfloat16).to(torch.float32).cpu().numpy())
+    want = got.astype(np.float64).T @ w
+    assert np.abs(ktw.cpu().numpy() - want).max() <= 1e-12 * max(1.0, np.abs(want).max()) * n
+    v = rng.standard_normal(M)
+    g64 = got.astype(np.float64)
+    assert np.abs(be.ktk(K, v=dev(v)).cpu().numpy() - g64.T @ (g64 @ v)).max() <= 1e-10 * max(1.0, np.abs(g64.T @ (g64 @ v)).max()) * n
+
+
+def test_u24_stored_knm_is_the_rounded_f32_block(be):
+    """The 24-bit fixed-point block is the f32 block the default build stores, entry by entry rounded to the nearest
+    multiple of 2^-24 (saturating at 1 - 2^-24)."""
+    rng = np.random.default_rng(3)
+    n, M, D, sigma = 700, 513, 96, 9.0
+    X = (rng.standard_normal((n, D)) * (20.0 / np.sqrt(D))).astype(np.float32)
+    Z = X[rng.integers(0, n, M)].copy()
+    F, Zf = be.features(torch.from_numpy(X)), be.features(torch.from_numpy(Z))
+    old = be.knm_storage
+    try:
+        be.pin_gauss_tile(256)
+        be.knm_storage = "f32"
+        K32 = be.knm(F, Zf, sigma).dense().cpu().numpy().astype(np.float64)
+        be.knm_storage = "u24"
+        K = be.knm(F, Zf, sigma)
+    finally:
+        be.knm_storage = old
+        be.pin_gauss_tile(0)
+    q = np.minimum(np.rint(K32 * 2.0 ** 24), 2.0 ** 24 - 1)
+    assert np.array_equal(kdense(K).astype(np.float64), q * 2.0 ** -24)
 
 
 def test_two_vector_pass_is_refused_where_it_does_not_fit(be):
@@ -426,7 +591,8 @@ def test_headline_shape_one_class(be):
 
 def full_size_properties(be, n, D, M, sigma, lam):
     """The size-independent checks of one class at a BASELINE shard shape (also used for config 5's shard,
-    tests/test_gpu_configs.py)."""
+    tests/test_gpu_configs.py), in the storage format such a block gets by default (24-bit fixed point at these sizes;
+    ODX_KNM=f32 / backend.knm_storage = "f32" runs them on f32 storage)."""
     import odx
     from odx.backend import Knm
     from oracle import falkon_ref as fr
@@ -448,9 +614,11 @@ def full_size_properties(be, n, D, M, sigma, lam):
     cols = np.array([0, 1, 127, 128, 255, 256, M // 2, M // 256 * 256 - 1, M // 256 * 256, M - 1])
     Zh = Zf.X.cpu().numpy().astype(np.float64)
     ref = fr.gaussian_kernel(X[rows].cpu().numpy().astype(np.float64), Zh[cols], sigma)
-    got = K.K[rows][:, cols].cpu().numpy()
-    assert np.abs(got - ref).max() < 2e-5
+    got = torch.stack([K.rows(int(r), int(r) + 1).dense()[0] for r in rows])[:, cols].cpu().numpy()
+    assert_k_close(got, ref, sigma)
     assert float(K.K[:, M:].abs().max()) == 0.0 if K.ld > M else True
+    if K.lo is not None and K.ld > M:
+        assert int(K.lo[:, M:].max()) == 0
     # (b) sampled scores against the oracle's predict with the same alpha
     srows = np.concatenate([np.arange(0, 300), np.arange(n // 2 - 100, n // 2 + 100), np.arange(n - 300, n)])
     pref = fr.falkon_predict(X[srows].cpu().numpy().astype(np.float64), Zh, alpha.cpu().numpy()[:, None], sigma)
@@ -463,9 +631,7 @@ def full_size_properties(be, n, D, M, sigma, lam):
     assert torch.equal(full, be.ktk(K, v=v1))
     parts = torch.zeros_like(full)
     for lo, hi in ((0, n // 2 - 1), (n // 2 - 1, n)):
-        Kh = Knm()
-        Kh.n, Kh.M, Kh.ld, Kh.K = hi - lo, M, K.ld, K.K[lo:hi]
-        parts += be.ktk(Kh, v=v1)
+        parts += be.ktk(K.rows(lo, hi), v=v1)
     assert float((parts - full).abs().max()) <= 1e-11 * float(full.abs().max())
     lin = be.ktk(K, v=v1 + 2.0 * v2) - (full + 2.0 * be.ktk(K, v=v2))
     assert float(lin.abs().max()) <= 1e-11 * float(full.abs().max())
@@ -475,11 +641,14 @@ def full_size_properties(be, n, D, M, sigma, lam):
         assert float((two[1] - be.ktk(K, v=v2)).abs().max()) <= 1e-11 * float(full.abs().max())
     # (d) the right-hand side the build kernel leaves behind = one pass over the block it stored
     yn = y * (1.0 / n)
-    K2, b0 = be.knm_rhs(F, Zf, sigma, yn, out=K.K.view(-1))
+    raw = kraw(K) if K.lo is None else None          # (planar formats: a fresh buffer — the two planes are not one tensor)
+    K2, b0 = be.knm_rhs(F, Zf, sigma, yn, out=raw)
+    if raw is None:
+        del K
     b0_pass = be.ktk(K2, w=yn)
     assert float((b0 - b0_pass).abs().max()) <= 1e-12 * max(1.0, float(b0_pass.abs().max())) * 1e3
     # (e) the fit repeats bit for bit at this size too
-    alpha2 = odx.falkon_fit(be, F, y, Zf, sigma, lam, 20, knm_out=K.K.view(-1))
+    alpha2 = odx.falkon_fit(be, F, y, Zf, sigma, lam, 20, knm_out=kraw(K2) if K2.lo is None else None)
     assert torch.equal(alpha, alpha2)
 
 
@@ -496,23 +665,22 @@ def test_gauss_random_shapes_stay_inside_their_buffers(be, gauss):
         Z = (rng.standard_normal((M, D)) * (20.0 / np.sqrt(D))).astype(np.float32)
         Z[: min(M, n) // 2] = X[: min(M, n) // 2]
         F, Zf = be.features(torch.from_numpy(X)), be.features(torch.from_numpy(Z))
-        ld = (M + 3) // 4 * 4
-        Kbuf = torch.full((n * ld + 64,), float("nan"), device="cuda")
+        kb = be.knm_bytes(n, M)
+        Kbuf = torch.full((kb + 64,), 0xA5, dtype=torch.uint8, device="cuda")
         rhs = torch.full((M + 8,), float("nan"), dtype=torch.float64, device="cuda")
         w = rng.standard_normal(n)
         K, ktw = be.knm_rhs(F, Zf, sigma, torch.from_numpy(w).cuda(), out=Kbuf, rhs_out=rhs[:M])
         ref = fr.gaussian_kernel(X.astype(np.float64), Z.astype(np.float64), sigma)
-        got = K.K.cpu().numpy()
-        assert np.abs(got[:, :M] - ref).max() < 2e-5, (case, n, M, D)
-        assert np.all(got[:, M:] == 0)
-        assert torch.isnan(Kbuf[n * ld:]).all() and torch.isnan(rhs[M:]).all(), (case, n, M, D)
-        want = got[:, :M].astype(np.float64).T @ w
+        got = kdense(K)
+        assert_k_close(got, ref, sigma, gauss, (case, n, M, D, sigma))
+        assert bool((Kbuf[kb:] == 0xA5).all()) and torch.isnan(rhs[M:]).all(), (case, n, M, D)
+        want = got.astype(np.float64).T @ w
         assert np.abs(ktw.cpu().numpy() - want).max() <= 1e-11 * max(1.0, np.abs(want).max()) * n
         # the CG pass on that block
         v = rng.standard_normal(M)
         cc = torch.full((M + 8,), float("nan"), dtype=torch.float64, device="cuda")
         be.ktk(K, v=torch.from_numpy(v).cuda(), out=cc[:M])
-        g64 = got[:, :M].astype(np.float64)
+        g64 = got.astype(np.float64)
         wantc = g64.T @ (g64 @ v)
         assert np.abs(cc[:M].cpu().numpy() - wantc).max() <= 1e-10 * max(1.0, np.abs(wantc).max()) * n
         assert torch.isnan(cc[M:]).all()
