@@ -18,6 +18,7 @@
 // the 2^-24 of the fixed-point scale is folded into v (phase 1) and into the slab write (phase 2).  A bf16 entry is a
 // shift / mask and v_cvt_f64_f32.
 #include <algorithm>
+#include <stdlib.h>
 
 #include "odx_internal.h"
 
@@ -29,78 +30,89 @@ typedef double f64x2q __attribute__((ext_vector_type(2)));
 
 enum { QF_U24 = 1, QF_BF16 = 2 };      // = ODX_KNM_U24 / ODX_KNM_BF16
 
-template <int FMT>
+// A thread's chunk: CW = 4 consecutive columns of a row — two dwords of the u16 plane, one of the u8 plane (the f32 kernel's
+// columns per thread, so the same (NT, CH) cover a row; 8-column chunks with 16-byte loads measured no faster).
+constexpr int QCW = 4;
+template <int FMT, int CW>
 struct QChunk {
-  u32x2q hi;      // 4 u16: columns 4 c .. 4 c + 3 of the u16 plane
-  unsigned lo;    // their 4 low bytes (24-bit format only)
+  unsigned hi[CW / 2];
+  unsigned lo[CW / 4];
 };
 
-// entry e (0..3) of a chunk as a double: the integer q for QF_U24 (value = q 2^-24), the value itself for QF_BF16
-template <int FMT>
-__device__ __forceinline__ double q_entry(const QChunk<FMT>& k, int e) {
+// entry e (0 .. CW - 1) of a chunk as a double: the integer q for QF_U24 (value = q 2^-24), the value itself for QF_BF16
+template <int FMT, int CW>
+__device__ __forceinline__ double q_entry(const QChunk<FMT, CW>& k, int e) {
   const unsigned h = k.hi[e >> 1];
   if (FMT == QF_U24) {
     // v_perm_b32: selector bytes 0..3 pick bytes of the second source (the low-byte dword), 4..7 bytes of the first (the
-    // u16 pair), 0x0c a zero byte: result = [low byte e | u16 << 8]
-    const unsigned sel = ((e & 1) ? 0x0c070600u : 0x0c050400u) | (unsigned)e;
-    return (double)__builtin_amdgcn_perm(h, k.lo, sel);
+    // u16 pair), 0x0c a zero byte: result = [low byte (e & 3) | u16 << 8]
+    const unsigned sel = ((e & 1) ? 0x0c070600u : 0x0c050400u) | (unsigned)(e & 3);
+    return (double)__builtin_amdgcn_perm(h, k.lo[e >> 2], sel);
   }
   return (double)__uint_as_float((e & 1) ? (h & 0xffff0000u) : (h << 16));
 }
 
-template <int NT, int CH, int R, int NV, int FMT>
-__global__ __launch_bounds__(NT) void knm_passq_kernel(const unsigned short* __restrict__ Khi, int64_t ldk,
+template <int NT, int CH, int R, int NV, int FMT, int WPE>
+__global__ __launch_bounds__(NT, WPE) void knm_passq_kernel(const unsigned short* __restrict__ Khi, int64_t ldk,
                                                        const unsigned char* __restrict__ Klo, int64_t ldlo, int64_t n,
                                                        int64_t M, const double* __restrict__ v1, const double* __restrict__ v2,
                                                        const double* __restrict__ w, double* __restrict__ slab, int64_t slab_ld) {
   constexpr int NW = NT / 64;
+  constexpr int CW = QCW;
   extern __shared__ __attribute__((aligned(16))) double vsq[];       // [NV][vcap]
   __shared__ double red[2][NW][NV * R];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nchunk = (int)((M + 3) >> 2);
-  const int vcap = nchunk * 4;
+  const int nchunk = (int)((M + CW - 1) / CW);
+  const int vcap = nchunk * CW;
   const int64_t nblk = (n + R - 1) / R;
   const double vscale = FMT == QF_U24 ? 5.9604644775390625e-08 : 1.0;      // 2^-24 (exact)
   for (int i = tid; i < vcap; i += NT) {
     vsq[i] = (v1 != nullptr && i < M) ? v1[i] * vscale : 0.0;
     if (NV == 2) vsq[vcap + i] = i < M ? v2[i] * vscale : 0.0;
   }
-  const int voff_hi = tid * 8, voff_lo = tid * 4;      // the only per-lane parts of a K address
-  double acc[NV][CH][4];
+  double acc[NV][CH][CW];
 #pragma unroll
   for (int q = 0; q < NV; ++q)
 #pragma unroll
     for (int c = 0; c < CH; ++c)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[q][c][e] = 0.0;
+      for (int e = 0; e < CW; ++e) acc[q][c][e] = 0.0;
 
-  QChunk<FMT> kr[R][CH];
-  const int row_bytes_hi = nchunk * 8, row_bytes_lo = nchunk * 4;
-  auto load_block = [&](int64_t blk, int c) {
+  // Addressing.  ONE buffer descriptor per plane and row block (base = the block's first row, length = its rows that
+  // exist), built from scalars once per block; a load takes the lane's place inside a chunk column as its vector offset and
+  // [row inside the block] x [row stride] + [chunk column] as its scalar offset.  (A descriptor per (row, chunk column) window — the first form of this
+  // kernel — cost ~8 scalar instructions per load: ~1000 per wave and block against ~700 vector ones, and the scalar unit
+  // is shared by the CU's four SIMDs.)  Rows past n are read as the block's last existing row and their row dots are
+  // set to zero before phase 2, so they add nothing.  A lane whose chunk lies past the row's end reads the start of the
+  // next row instead of zeros: its v entries are forced to zero in phase 1 and its column sums are never stored.
+  QChunk<FMT, CW> kr[R][CH];
+  const int rowb_hi = (int)ldk * 2, rowb_lo = (int)ldlo;
+  const int voff_hi = tid * (2 * CW), voff_lo = tid * CW;      // the only per-lane part of an address: the chunk inside a
+                                                               // chunk column; row and chunk column ride on the scalar offset
+  __amdgpu_buffer_rsrc_t rs_hi, rs_lo;
+  int rows_open = R;
+  auto open_block = [&](int64_t blk) {
+    const int64_t row0 = blk * R;
+    rows_open = (int)(n - row0 < R ? n - row0 : R);
+    rs_hi = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Khi + row0 * ldk), (short)0, rows_open * rowb_hi, 0x00020000);
+    if (FMT == QF_U24)
+      rs_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(Klo + row0 * ldlo), (short)0, rows_open * rowb_lo, 0x00020000);
+  };
+  auto load_block = [&](int c) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      // descriptors of the windows [chunk column c of row `row`] of the two planes: base and length are wave-uniform
-      // scalars; lanes whose chunk lies past the row's end (or rows past n: zero records) get zeros from the range check
-      const int64_t row = blk * R + r;
-      const bool in = row < n;
-      const int64_t rr = in ? row : 0;
-      const int left_hi = row_bytes_hi - c * NT * 8;
-      const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<unsigned short*>(Khi + rr * ldk + (int64_t)c * NT * 4), (short)0, (in && left_hi > 0) ? left_hi : 0, 0x00020000);
-      kr[r][c].hi = __builtin_amdgcn_raw_buffer_load_b64(rh, voff_hi, 0, 0);
-      if (FMT == QF_U24) {
-        const int left_lo = row_bytes_lo - c * NT * 4;
-        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<unsigned char*>(Klo + rr * ldlo + (int64_t)c * NT * 4), (short)0, (in && left_lo > 0) ? left_lo : 0, 0x00020000);
-        kr[r][c].lo = __builtin_amdgcn_raw_buffer_load_b32(rl, voff_lo, 0, 0);
-      }
+      const int rr = r < rows_open ? r : rows_open - 1;
+      const u32x2q th = __builtin_amdgcn_raw_buffer_load_b64(rs_hi, voff_hi, rr * rowb_hi + c * (NT * 2 * CW), 0);
+      kr[r][c].hi[0] = th[0], kr[r][c].hi[1] = th[1];
+      if (FMT == QF_U24) kr[r][c].lo[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_lo, voff_lo, rr * rowb_lo + c * (NT * CW), 0);
     }
   };
 
   int64_t blk = blockIdx.x;
   if (blk < nblk) {
+    open_block(blk);
 #pragma unroll
-    for (int c = 0; c < CH; ++c) load_block(blk, c);
+    for (int c = 0; c < CH; ++c) load_block(c);
   }
   __syncthreads();  // vsq is complete
   int pp = 0;
@@ -112,7 +124,7 @@ __global__ __launch_bounds__(NT) void knm_passq_kernel(const unsigned short* __r
       for (int r = 0; r < R; ++r) t[q][r] = 0.0;
     if (v1 != nullptr) {
       // phase 1: row dots.  An opaque zero in the LDS index keeps the (loop-invariant) reads of v inside the loop — hoisted
-      // they would hold NV x CH x 4 doubles for good (knm_pass2_kernel, same reason).
+      // they would hold NV x CH x CW doubles for good (knm_pass2_kernel, same reason).
       int zofs;
       asm volatile("v_mov_b32 %0, 0" : "=v"(zofs));
 #pragma unroll
@@ -120,17 +132,21 @@ __global__ __launch_bounds__(NT) void knm_passq_kernel(const unsigned short* __r
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
           const int ch = tid + c * NT + zofs;
-          const int vi = (ch < nchunk ? ch : nchunk - 1) * 4;      // any valid entries where K reads as zero
-          const f64x2q a = *reinterpret_cast<const f64x2q*>(&vsq[q * vcap + vi]);
-          const f64x2q b = *reinterpret_cast<const f64x2q*>(&vsq[q * vcap + vi + 2]);
+          const bool cin = ch < nchunk;
+          const int vi = (cin ? ch : nchunk - 1) * CW;
+          double vv[CW];
 #pragma unroll
-          for (int r = 0; r < R; ++r) {
-            t[q][r] = fma(q_entry<FMT>(kr[r][c], 0), a[0], t[q][r]);
-            t[q][r] = fma(q_entry<FMT>(kr[r][c], 1), a[1], t[q][r]);
-            t[q][r] = fma(q_entry<FMT>(kr[r][c], 2), b[0], t[q][r]);
-            t[q][r] = fma(q_entry<FMT>(kr[r][c], 3), b[1], t[q][r]);
+          for (int u = 0; u < CW / 2; ++u) {
+            const f64x2q a = *reinterpret_cast<const f64x2q*>(&vsq[q * vcap + vi + 2 * u]);
+            vv[2 * u] = cin ? a[0] : 0.0;          // a chunk past the row's end holds the next row's entries, not zeros
+            vv[2 * u + 1] = cin ? a[1] : 0.0;
           }
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int e = 0; e < CW; ++e) t[q][r] = fma(q_entry<FMT, CW>(kr[r][c], e), vv[e], t[q][r]);
         }
+        __builtin_amdgcn_sched_barrier(0);      // one chunk column's decoded entries at a time (register pressure)
       }
 #pragma unroll
       for (int q = 0; q < NV; ++q)
@@ -153,35 +169,44 @@ __global__ __launch_bounds__(NT) void knm_passq_kernel(const unsigned short* __r
         }
       pp ^= 1;
     }
-    if (NV == 1 && w != nullptr) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int64_t row = blk * R + r;
-        if (row < n) t[0][r] += w[row];
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = blk * R + r;
+      if (row >= n) {                        // (the last block only) a repeated row, not a zero one, was read for it
+#pragma unroll
+        for (int q = 0; q < NV; ++q) t[q][r] = 0.0;
+      } else if (NV == 1 && w != nullptr) {
+        t[0][r] += w[row];
       }
     }
-    // the decoded doubles of phase 1 must not stay live into phase 2 (R x CH x 4 doubles: spills): make the raw registers
+    // the decoded doubles of phase 1 must not stay live into phase 2 (R x CH x CW doubles: spills): make the raw registers
     // opaque here, phase 2 decodes again
 #pragma unroll
     for (int c = 0; c < CH; ++c)
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        asm volatile("" : "+v"(kr[r][c].hi));
-        if (FMT == QF_U24) asm volatile("" : "+v"(kr[r][c].lo));
+#pragma unroll
+        for (int u = 0; u < CW / 2; ++u) asm volatile("" : "+v"(kr[r][c].hi[u]));
+        if (FMT == QF_U24) {
+#pragma unroll
+          for (int u = 0; u < CW / 4; ++u) asm volatile("" : "+v"(kr[r][c].lo[u]));
+        }
       }
     // phase 2: column sums, and the next block's loads re-issued chunk by chunk
     const int64_t nxt = blk + gridDim.x;
+    if (nxt < nblk) open_block(nxt);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const double kd = q_entry<FMT>(kr[r][c], e);
+        for (int e = 0; e < CW; ++e) {
+          const double kd = q_entry<FMT, CW>(kr[r][c], e);
 #pragma unroll
           for (int q = 0; q < NV; ++q) acc[q][c][e] = fma(kd, t[q][r], acc[q][c][e]);
         }
-      if (nxt < nblk) load_block(nxt, c);
+      if (nxt < nblk) load_block(c);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   double* my = slab + (int64_t)blockIdx.x * slab_ld * NV;
@@ -192,7 +217,8 @@ __global__ __launch_bounds__(NT) void knm_passq_kernel(const unsigned short* __r
       const int ch = tid + c * NT;
       if (ch < nchunk) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) my[q * slab_ld + (int64_t)ch * 4 + e] = acc[q][c][e] * vscale;
+        for (int e = 0; e < CW; ++e)
+          if ((int64_t)ch * CW + e < slab_ld) my[q * slab_ld + (int64_t)ch * CW + e] = acc[q][c][e] * vscale;
       }
     }
 }
@@ -201,13 +227,29 @@ struct QCfg {
   int nt, ch, r, wg_per_cu;
 };
 
-static bool pick_qcfg(int64_t M, int nv, QCfg* cfg) {
+// One-vector configurations.  Up to 8192 columns the pass runs as TWO 256-thread workgroups per CU, each with its own
+// copy of v in LDS: independent workgroups drift apart, so one multiplies while the other waits for memory — a single
+// 512-thread workgroup meets at its barrier every row block, its eight waves wait and compute together, and the decode's
+// extra vector work (a third more instructions per byte than the f32 kernel) then adds to the memory time instead of
+// hiding under it.  Measured at n = 5e5, M = 1e4, 24-bit format (tools/passq_bench.py):
+// 512 x 5 x 6 rows 5.2 TB/s; two register sets alternating across the barrier 5.0-5.1; 8-column chunks (16-byte loads)
+// 4.9-5.2; descriptors per (row, chunk) 5.2; 2 x (256 x 10 x 2 rows) 5.73 TB/s.  f32 kernel: 5.96.
+static bool pick_qcfg(int64_t M, int nv, int fmt, QCfg* cfg) {
   const int64_t chunks = (M + 3) / 4;
-  if (nv == 1) {      // (NT, CH) as knm_pass.hip's pick_cfg; twice its rows per block where the registers allow
+  if (nv == 1) {
+    // experiments: ODX_PASSQ_CFG="nt ch r" forces a configuration (must cover the row and be one of those built below)
+    if (const char* e = getenv("ODX_PASSQ_CFG")) {
+      int nt = 0, ch = 0, r = 0;
+      if (sscanf(e, "%d %d %d", &nt, &ch, &r) == 3 && (int64_t)nt * ch >= chunks) { *cfg = {nt, ch, r, nt <= 256 ? 2 : 1}; return true; }
+    }
     if (chunks <= 256) { *cfg = {256, 1, 16, 2}; return true; }
     if (chunks <= 512) { *cfg = {256, 2, 8, 2}; return true; }
     if (chunks <= 1024) { *cfg = {256, 4, 8, 2}; return true; }
-    if (chunks <= 2048) { *cfg = {512, 4, 8, 1}; return true; }
+    if (chunks <= 2048) { *cfg = {256, 8, 3, 2}; return true; }
+    // (2 x (256 x 10 x 2 rows) is 10 % faster alone at M = 1e4 but needs the CU's whole LDS for its two copies of v: beside
+    // the preconditioner stream of the headline job a CU holding one small workgroup of another kernel takes only ONE of
+    // the two, the displaced workgroup of the persistent grid runs after the others, and the pass loses more than it won
+    // — 5.10 against 5.30 TB/s inside bench.py.  ODX_PASSQ_CFG="256 10 2" selects it.)
     if (chunks <= 2560) { *cfg = {512, 5, 6, 1}; return true; }
     if (chunks <= 3072) { *cfg = {512, 6, 4, 1}; return true; }
     if (chunks <= 5120) { *cfg = {1024, 5, 1, 1}; return true; }
@@ -231,12 +273,12 @@ static int qgrid_for(const QCfg& cfg, int64_t n) {
   return (int)g;
 }
 
-template <int NT, int CH, int R, int NV, int FMT>
+template <int NT, int CH, int R, int NV, int FMT, int WPE = (NT >= 1024 ? 4 : 2)>
 static int launch_passq(int grid, size_t lds, hipStream_t s, const void* K, int64_t ldk, const void* Klo, int64_t ldlo, int64_t n,
                         int64_t M, const double* v, const double* v2, const double* w, double* slab, int64_t slab_ld) {
-  ODX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knm_passq_kernel<NT, CH, R, NV, FMT>),
+  ODX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knm_passq_kernel<NT, CH, R, NV, FMT, WPE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((knm_passq_kernel<NT, CH, R, NV, FMT>), dim3(grid), dim3(NT), lds, s, static_cast<const unsigned short*>(K),
+  hipLaunchKernelGGL((knm_passq_kernel<NT, CH, R, NV, FMT, WPE>), dim3(grid), dim3(NT), lds, s, static_cast<const unsigned short*>(K),
                      ldk, static_cast<const unsigned char*>(Klo), ldlo, n, M, v, v2, w, slab, slab_ld);
   return ODX_OK;
 }
@@ -250,6 +292,12 @@ static int dispatch_passq(const QCfg& cfg, int grid, size_t lds, hipStream_t s, 
     if (cfg.nt == 256 && cfg.ch == 1) ODX_Q(256, 1, 16);
     if (cfg.nt == 256 && cfg.ch == 2) ODX_Q(256, 2, 8);
     if (cfg.nt == 256 && cfg.ch == 4) ODX_Q(256, 4, 8);
+    if (cfg.nt == 256 && cfg.ch == 8) ODX_Q(256, 8, 3);
+    if (cfg.nt == 256 && cfg.ch == 10 && cfg.r == 2) ODX_Q(256, 10, 2);
+    if (cfg.nt == 256 && cfg.ch == 10) {
+      if constexpr (FMT == QF_BF16) ODX_Q(256, 10, 3);
+      else ODX_Q(256, 10, 2);
+    }
     if (cfg.nt == 512 && cfg.ch == 4) ODX_Q(512, 4, 8);
     if (cfg.nt == 512 && cfg.ch == 5) ODX_Q(512, 5, 6);
     if (cfg.nt == 512 && cfg.ch == 6) ODX_Q(512, 6, 4);
@@ -279,7 +327,7 @@ static int check_q(const char* who, const void* K, int64_t ldk, const void* Klo,
 extern "C" int64_t odx_knm_fwd_bwd_q_workspace_bytes(int64_t n, int64_t M, int fmt) {
   QCfg cfg;
   if (n <= 0 || M <= 0) return 0;
-  if ((fmt != ODX_KNM_U24 && fmt != ODX_KNM_BF16) || !pick_qcfg(M, 1, &cfg)) return ODX_ERR_UNSUPPORTED;
+  if ((fmt != ODX_KNM_U24 && fmt != ODX_KNM_BF16) || !pick_qcfg(M, 1, fmt, &cfg)) return ODX_ERR_UNSUPPORTED;
   int cus = odx_device_cus();
   if (cus <= 0) cus = 256;
   return (int64_t)cus * cfg.wg_per_cu * round_up(M, 4) * (int64_t)sizeof(double);
@@ -297,7 +345,7 @@ extern "C" int odx_knm_fwd_bwd_q(const void* K, int64_t ldk, const void* Klo, in
   ODX_REQUIRE(v || w, "odx_knm_fwd_bwd_q: both v and w null");
   ODX_PROPAGATE(check_q("odx_knm_fwd_bwd_q", K, ldk, Klo, ldlo, fmt, M));
   QCfg cfg;
-  if (!pick_qcfg(M, 1, &cfg)) {
+  if (!pick_qcfg(M, 1, fmt, &cfg)) {
     set_error("odx_knm_fwd_bwd_q: M = %lld exceeds the 20480 columns the compact-format pass kernels are built for", (long long)M);
     return ODX_ERR_UNSUPPORTED;
   }
@@ -318,7 +366,7 @@ extern "C" int odx_knm_fwd_bwd_q(const void* K, int64_t ldk, const void* Klo, in
 extern "C" int64_t odx_knm_fwd_bwd2_q_workspace_bytes(int64_t n, int64_t M, int fmt) {
   QCfg cfg;
   if (n <= 0 || M <= 0) return 0;
-  if ((fmt != ODX_KNM_U24 && fmt != ODX_KNM_BF16) || !pick_qcfg(M, 2, &cfg)) return ODX_ERR_UNSUPPORTED;
+  if ((fmt != ODX_KNM_U24 && fmt != ODX_KNM_BF16) || !pick_qcfg(M, 2, fmt, &cfg)) return ODX_ERR_UNSUPPORTED;
   int cus = odx_device_cus();
   if (cus <= 0) cus = 256;
   return 2 * (int64_t)cus * cfg.wg_per_cu * round_up(M, 4) * (int64_t)sizeof(double);
@@ -337,7 +385,7 @@ extern "C" int odx_knm_fwd_bwd2_q(const void* K, int64_t ldk, const void* Klo, i
   ODX_REQUIRE(v && v2, "odx_knm_fwd_bwd2_q: null v or v2");
   ODX_PROPAGATE(check_q("odx_knm_fwd_bwd2_q", K, ldk, Klo, ldlo, fmt, M));
   QCfg cfg;
-  if (!pick_qcfg(M, 2, &cfg)) {
+  if (!pick_qcfg(M, 2, fmt, &cfg)) {
     set_error("odx_knm_fwd_bwd2_q: M = %lld is outside the two-vector configurations (use two single passes)", (long long)M);
     return ODX_ERR_UNSUPPORTED;
   }
