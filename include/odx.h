@@ -158,6 +158,29 @@ int odx_knm_fwd_bwd2_q(const void* K, int64_t ldk, const void* Klo, int64_t ldlo
                        const double* v, const double* v2, double* out, double* out2, void* workspace,
                        int64_t workspace_bytes, odx_stream_t stream);
 
+/* ---------------------------------------------------------------- A3 / A5 with the fp8 contraction (BASELINE config 5)
+ * "fp8 (OCP e4m3) inputs to the X Z' MFMA, f32 accumulate, stress / throughput only" (cfg 5; the reference's own
+ * dtype is f32, config/defaults.py:466).  Each operand value is rounded ONCE to e4m3 (after a power-of-two scaling of the
+ * whole matrix), the products run on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales — a third of the MFMA issue
+ * slots of the f16-split kernels at a quarter of the operand bytes.  K entries come out ~1e-3 off, scores ~5e-3
+ * (tools/precision_scoring_study.py): NOT a parity path, never the default; ODX_GAUSS=f8 selects it in the Python backend.
+ * odx_split_f8: P8 row-major e4m3 bytes, row stride ldp8 bytes (ldp8 % 16 == 0, ldp8 >= roundup(D, 128)), features past D
+ * zero; meta[0] = the scale, meta[1] = max |x| (as odx_split_f16); qsq (n floats, may be NULL) = the squared norms of the
+ * ROUNDED rows, |e4m3(s x)|^2 / s^2 — what the f8 kernels take as xsq / zsq, so that d^2 is the squared distance of the
+ * rounded points (0 for duplicates) instead of mixing exact norms with a rounded inner product.
+ * odx_gauss_knm_f8_store = odx_gauss_knm_h2_store and odx_gauss_mmv_f8 = odx_gauss_mmv_h2 (same workspace queries) on such
+ * operands, always on the 256 x 256 tile core. */
+int odx_split_f8(const float* X, int64_t ldx, int64_t n, int D, void* P8, int64_t ldp8, float* meta, float* qsq,
+                 odx_stream_t stream);
+int odx_gauss_knm_f8_store(const void* PX, int64_t ldpx8, const float* metax, const float* xsq, int64_t n,
+                           const void* PZ, int64_t ldpz8, const float* metaz, const float* zsq, int64_t M, int D,
+                           double sigma, int fmt, void* K, int64_t ldk, void* Klo, int64_t ldlo, const double* w,
+                           double* ktw, void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+int odx_gauss_mmv_f8(const void* PX, int64_t ldpx8, const float* metax, const float* xsq, int64_t n,
+                     const void* PZ, int64_t ldpz8, const float* metaz, const float* zsq, int64_t max_range, int D,
+                     double sigma, const double* V, int64_t ldv, const int32_t* ranges, int T,
+                     float* out, int64_t ldo, void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+
 /* ---------------------------------------------------------------- A4: preconditioner (f64)
  * FalkonPreconditioner.init as run by InCoreFalkon.fit with min_cuda_pc_size_*=0
  * (FALKONWrapper_with_centers_selection_incore.py:56):

@@ -453,17 +453,41 @@ __device__ __forceinline__ void w_store_operand(const u32x4 (&r)[4], char* lds) 
 // (two of its eight 16-byte pieces) into the other LDS buffer and re-issues the loads of those two registers for stage
 // s + 2: the LDS stores (64 KiB per stage at ~79 B/clk = 830 cycles of the LDS port) and the load issue then run under the
 // MFMA work instead of in front of it, and every register has exactly one stage of MFMA time to be refilled.
+// CORE_H2: operands are two-term f16 splits, three v_mfma_f32_16x16x32_f16 per product block (lo.hi, hi.lo, hi.hi).
+// CORE_F8: operands are OCP e4m3 bytes (odx_split_f8): a stage's 128 bytes per row are 128 FEATURES, and the 16-byte
+// pieces a lane reads as "hi" and "lo" — chunks g and g + 4 of the row — are simply its 32 of them: ONE
+// v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales, 2^0) per product block.  Both operands split the row the same way,
+// so the order in which a lane group's 32 features enter the sum is the same permutation for A and B — a dot product does
+// not care.  Same loads, same LDS image, same stores: 4 x the features per stage in 1/3 of the MFMA issue slots.
+enum { CORE_H2 = 0, CORE_F8 = 1 };
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+constexpr int F8_SCALE_ONE = 0x7f7f7f7f;      // E8M0 exponent 127 = 2^0 in every byte (op_sel picks byte 0)
+
+__device__ __forceinline__ i32x8 f8_frag(const f16x8& lo16, const f16x8& hi16) {
+  const u32x4 a = __builtin_bit_cast(u32x4, lo16), b = __builtin_bit_cast(u32x4, hi16);
+  return i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+}
+
+template <int CORE>
 __device__ __forceinline__ void w_compute_part(f32x4 (&acc)[8][4], const char* pa, const f16x8 (&bh)[4], const f16x8 (&bl)[4],
                                                int hi, int lo, int tm0) {
 #pragma unroll
   for (int tm = tm0; tm < tm0 + 2; ++tm) {
     const f16x8 ah = *reinterpret_cast<const f16x8*>(pa + tm * 16 * W_ROW + hi);
     const f16x8 al = *reinterpret_cast<const f16x8*>(pa + tm * 16 * W_ROW + lo);
+    if (CORE == CORE_F8) {
+      const i32x8 a8 = f8_frag(ah, al);
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-      acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[tn], acc[tm][tn], 0, 0, 0);
-      acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[tn], acc[tm][tn], 0, 0, 0);
-      acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[tn], acc[tm][tn], 0, 0, 0);
+      for (int tn = 0; tn < 4; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, f8_frag(bh[tn], bl[tn]), acc[tm][tn], 0, 0, 0,
+                                                                        F8_SCALE_ONE, 0, F8_SCALE_ONE);
+    } else {
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[tn], acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[tn], acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[tn], acc[tm][tn], 0, 0, 0);
+      }
     }
   }
 }
@@ -476,7 +500,7 @@ struct WAddr {
 
 // STORE: stage s + 1 exists (its registers go to `nxt`); LOAD: stage s + 2 exists (re-issue the loads).  Compile-time
 // flags keep the loop body free of branches, so the compiler can count its vmcnt waits exactly.
-template <bool STORE, bool LOAD>
+template <bool STORE, bool LOAD, int CORE>
 __device__ __forceinline__ void w_stage(f32x4 (&acc)[8][4], WStage& st, const char* cur, char* nxt,
                                         const uint32_t* __restrict__ ta2, const uint32_t* __restrict__ tb2, const WAddr& ad) {
   f16x8 bh[4], bl[4];
@@ -487,7 +511,7 @@ __device__ __forceinline__ void w_stage(f32x4 (&acc)[8][4], WStage& st, const ch
   }
 #pragma unroll
   for (int part = 0; part < 4; ++part) {
-    w_compute_part(acc, cur + ad.fa, bh, bl, ad.hi, ad.lo, 2 * part);
+    w_compute_part<CORE>(acc, cur + ad.fa, bh, bl, ad.hi, ad.lo, 2 * part);
     if (STORE) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -510,7 +534,7 @@ __device__ __forceinline__ void w_stage(f32x4 (&acc)[8][4], WStage& st, const ch
 // acc += A[i0 .. i0 + 256, :] . B[j0 .. j0 + 256, :]' over `stages` >= 1 granules.  Ends on a barrier (LDS reusable at once).
 // PERMB: the rows of B are fetched in the permuted order of w_row_offsets<true> (accumulator block tn of lane l is then
 // output column 64 wc + 4 (l & 15) + tn instead of 64 wc + 16 tn + (l & 15)).
-template <bool PERMB = false>
+template <bool PERMB = false, int CORE = CORE_H2>
 __device__ __forceinline__ void w_mainloop(f32x4 (&acc)[8][4], const uint32_t* __restrict__ A, int64_t lda, int64_t m,
                                            const uint32_t* __restrict__ B, int64_t ldb, int64_t n, int64_t i0, int64_t j0,
                                            int stages, char* lds) {
@@ -543,14 +567,14 @@ __device__ __forceinline__ void w_mainloop(f32x4 (&acc)[8][4], const uint32_t* _
   int s = 0;
   for (; s + 2 < stages; ++s) {
     // nxt was last read during stage s - 1, before the barrier that ended it
-    w_stage<true, true>(acc, st, lds + (s & 1) * W_STAGE_BYTES, lds + ((s + 1) & 1) * W_STAGE_BYTES,
+    w_stage<true, true, CORE>(acc, st, lds + (s & 1) * W_STAGE_BYTES, lds + ((s + 1) & 1) * W_STAGE_BYTES,
                         ta + (int64_t)(s + 2) * W_KS, tb + (int64_t)(s + 2) * W_KS, ad);
   }
   if (s + 1 < stages) {
-    w_stage<true, false>(acc, st, lds + (s & 1) * W_STAGE_BYTES, lds + ((s + 1) & 1) * W_STAGE_BYTES, ta, tb, ad);
+    w_stage<true, false, CORE>(acc, st, lds + (s & 1) * W_STAGE_BYTES, lds + ((s + 1) & 1) * W_STAGE_BYTES, ta, tb, ad);
     ++s;
   }
-  w_stage<false, false>(acc, st, lds + (s & 1) * W_STAGE_BYTES, lds, ta, tb, ad);
+  w_stage<false, false, CORE>(acc, st, lds + (s & 1) * W_STAGE_BYTES, lds, ta, tb, ad);
 }
 
 __device__ __forceinline__ void w_zero(f32x4 (&acc)[8][4]) {
@@ -587,7 +611,7 @@ __device__ __forceinline__ unsigned short bf16_of(float v) {          // round t
 // RHS: also leave wslab[row block][j] = sum over the tile's rows i of K_ij w_i (f64), K_ij being the value the block
 // STORES (the dequantised one for KF_U24 / KF_BF16): the column sums K' w of the right-hand side of the fit come out of
 // the build, and the first pass over the stored K_nM is not needed.
-template <bool RHS, int FMT>
+template <bool RHS, int FMT, int CORE>
 __global__ __launch_bounds__(W_THREADS, 1) void gauss_knm_h2w256_kernel(
     const uint32_t* __restrict__ PX, int64_t ldpx, const float* __restrict__ metax, const float* __restrict__ xsq, int64_t n,
     const uint32_t* __restrict__ PZ, int64_t ldpz, const float* __restrict__ metaz, const float* __restrict__ zsq, int64_t M,
@@ -610,7 +634,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_knm_h2w256_kernel(
 
   f32x4 acc[8][4];
   w_zero(acc);
-  w_mainloop<true>(acc, PX, ldpx, n, PZ, ldpz, M, i0, j0, stages, lds);      // its barriers also publish xs_s
+  w_mainloop<true, CORE>(acc, PX, ldpx, n, PZ, ldpz, M, i0, j0, stages, lds);      // its barriers also publish xs_s
 
   const float m2 = -2.f / (metax[0] * metaz[0]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -770,6 +794,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void gemm_h2w256_kernel(
 
 // Fused scoring on the 256 x 256 core: same decomposition as gauss_mmv_h2s16_kernel (row block x group of `tg` column
 // tiles, f64 partial row sums per group in the slab, mmv_reduce_kernel adds the groups), 256-row blocks, 256-column tiles.
+template <int CORE>
 __global__ __launch_bounds__(W_THREADS, 1) void gauss_mmv_h2w256_kernel(
     const uint32_t* __restrict__ PX, int64_t ldpx, const float* __restrict__ metax, const float* __restrict__ xsq, int64_t n,
     const uint32_t* __restrict__ PZ, int64_t ldpz, const float* __restrict__ metaz, const float* __restrict__ zsq, int stages,
@@ -801,7 +826,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_mmv_h2w256_kernel(
   for (int64_t j0 = s0; j0 < s1; j0 += W_BN) {
     f32x4 acc[8][4];
     w_zero(acc);
-    w_mainloop(acc, PX, ldpx, n, PZ + j0 * ldpz, ldpz, r1 - j0, i0, 0, stages, lds);
+    w_mainloop<false, CORE>(acc, PX, ldpx, n, PZ + j0 * ldpz, ldpz, r1 - j0, i0, 0, stages, lds);
     float zs[4];
     double al[4];
 #pragma unroll
@@ -917,21 +942,23 @@ extern "C" int odx_split_f16(const float* X, int64_t ldx, int64_t n, int D, void
   return ODX_OK;
 }
 
-template <bool RHS, int FMT>
+template <bool RHS, int FMT, int CORE>
 static int launch_knm_w256_t(unsigned wt, hipStream_t s, const uint32_t* PX, int64_t ldpx, const float* metax, const float* xsq,
                              int64_t n, const uint32_t* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t M,
                              int stages, float g2, void* K, int64_t ldk, unsigned char* Klo, int64_t ldlo, int wgr,
                              const double* w, double* wslab, int64_t wslab_ld) {
-  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2w256_kernel<RHS, FMT>), W_LDS_BYTES));
-  hipLaunchKernelGGL((gauss_knm_h2w256_kernel<RHS, FMT>), dim3(wt), dim3(W_THREADS), W_LDS_BYTES, s, PX, ldpx, metax, xsq, n,
+  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2w256_kernel<RHS, FMT, CORE>), W_LDS_BYTES));
+  hipLaunchKernelGGL((gauss_knm_h2w256_kernel<RHS, FMT, CORE>), dim3(wt), dim3(W_THREADS), W_LDS_BYTES, s, PX, ldpx, metax, xsq, n,
                      PZ, ldpz, metaz, zsq, M, stages, g2, K, ldk, Klo, ldlo, wgr, w, wslab, wslab_ld);
   return ODX_OK;
 }
 
+// `core`: CORE_H2 (operands from odx_split_f16, ld in 4-byte units >= roundup(D, 64)) or CORE_F8 (operands from
+// odx_split_f8, ld in 4-byte units >= roundup(D, 128) / 4); `stages` = 128-byte pieces per operand row.
 static int launch_knm_w256(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n, const void* PZ,
-                           int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int64_t dp, double sigma, int fmt,
+                           int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int stages, double sigma, int fmt,
                            void* K, int64_t ldk, void* Klo, int64_t ldlo, const double* w, double* wslab, int64_t wslab_ld,
-                           odx_stream_t stream) {
+                           odx_stream_t stream, int core = CORE_H2) {
   // band height of the tile order; 2 / 4 / 8 / 16 / 32 measured alone: 395 / 397 / 391 / 376 / 347 TF
   // (ODX_H2_BAND overrides it for experiments: a taller band re-streams the centres from the Infinity Cache less often)
   static const int wgr_env = [] { const char* e = getenv("ODX_H2_BAND"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 64) ? v : 0; }();
@@ -939,22 +966,26 @@ static int launch_knm_w256(const void* PX, int64_t ldpx, const float* metax, con
   const int64_t wt = round_up(ceil_div(n, W_BM), wgr) * ceil_div(M, W_BN);
   ODX_REQUIRE(wt < (1ll << 31), "odx_gauss_knm_h2: grid too large");
   const float g2 = (float)(-0.5 / (sigma * sigma)) * LOG2E;
-  const int stages = (int)(dp / W_KS);
   hipStream_t s = as_stream(stream);
   const uint32_t *px = (const uint32_t*)PX, *pz = (const uint32_t*)PZ;
   unsigned char* lo = static_cast<unsigned char*>(Klo);
-#define ODX_KNM_W256(RHS_, FMT_)                                                                                          \
-  ODX_PROPAGATE((launch_knm_w256_t<RHS_, FMT_>((unsigned)wt, s, px, ldpx, metax, xsq, n, pz, ldpz, metaz, zsq, M, stages, \
-                                               g2, K, ldk, lo, ldlo, wgr, w, wslab, wslab_ld)))
-  if (w != nullptr) {
-    if (fmt == KF_F32) ODX_KNM_W256(true, KF_F32);
-    else if (fmt == KF_U24) ODX_KNM_W256(true, KF_U24);
-    else ODX_KNM_W256(true, KF_BF16);
+#define ODX_KNM_W256(RHS_, FMT_, CORE_)                                                                                        \
+  ODX_PROPAGATE((launch_knm_w256_t<RHS_, FMT_, CORE_>((unsigned)wt, s, px, ldpx, metax, xsq, n, pz, ldpz, metaz, zsq, M, stages, \
+                                                      g2, K, ldk, lo, ldlo, wgr, w, wslab, wslab_ld)))
+#define ODX_KNM_W256_F(RHS_, CORE_)                     \
+  do {                                                  \
+    if (fmt == KF_F32) ODX_KNM_W256(RHS_, KF_F32, CORE_);      \
+    else if (fmt == KF_U24) ODX_KNM_W256(RHS_, KF_U24, CORE_); \
+    else ODX_KNM_W256(RHS_, KF_BF16, CORE_);                   \
+  } while (0)
+  if (core == CORE_F8) {
+    if (w != nullptr) ODX_KNM_W256_F(true, CORE_F8);
+    else ODX_KNM_W256_F(false, CORE_F8);
   } else {
-    if (fmt == KF_F32) ODX_KNM_W256(false, KF_F32);
-    else if (fmt == KF_U24) ODX_KNM_W256(false, KF_U24);
-    else ODX_KNM_W256(false, KF_BF16);
+    if (w != nullptr) ODX_KNM_W256_F(true, CORE_H2);
+    else ODX_KNM_W256_F(false, CORE_H2);
   }
+#undef ODX_KNM_W256_F
 #undef ODX_KNM_W256
   ODX_CHECK_LAUNCH("odx_gauss_knm_h2(w256)");
   return ODX_OK;
@@ -1034,7 +1065,7 @@ extern "C" int odx_gauss_knm_h2(const void* PX, int64_t ldpx, const float* metax
   ODX_REQUIRE(ldpx < (1 << 24) && ldpz < (1 << 24) && ldk < (1 << 24), "odx_gauss_knm_h2: leading dimensions must stay below 2^24 (32-bit tile offsets)");
   const int gr = 8;   // band height of the tile order: 2..32 measured within 2 % of each other at n = 2.5e5, M = 1e4
   if (h2_use_w256(ceil_div(n, W_BM) * ceil_div(M, W_BN)))
-    return launch_knm_w256(PX, ldpx, metax, xsq, n, PZ, ldpz, metaz, zsq, M, dp, sigma, KF_F32, K, ldk, nullptr, 0, nullptr, nullptr, 0, stream);
+    return launch_knm_w256(PX, ldpx, metax, xsq, n, PZ, ldpz, metaz, zsq, M, (int)(dp / W_KS), sigma, KF_F32, K, ldk, nullptr, 0, nullptr, nullptr, 0, stream);
   const int64_t tiles = round_up(ceil_div(n, GEMM_BM), gr) * ceil_div(M, GEMM_BN);
   ODX_REQUIRE(tiles < (1ll << 31), "odx_gauss_knm_h2: grid too large");
   ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2s16_kernel)));
@@ -1070,7 +1101,7 @@ extern "C" int odx_gauss_knm_h2_rhs(const void* PX, int64_t ldpx, const float* m
     return ODX_ERR_WORKSPACE;
   }
   const int64_t wld = round_up(M, 4);
-  ODX_PROPAGATE(launch_knm_w256(PX, ldpx, metax, xsq, n, PZ, ldpz, metaz, zsq, M, dp, sigma, KF_F32, K, ldk, nullptr, 0, w,
+  ODX_PROPAGATE(launch_knm_w256(PX, ldpx, metax, xsq, n, PZ, ldpz, metaz, zsq, M, (int)(dp / W_KS), sigma, KF_F32, K, ldk, nullptr, 0, w,
                                 static_cast<double*>(workspace), wld, stream));
   return slab_reduce_f64(static_cast<const double*>(workspace), wld, (int)ceil_div(n, W_BM), M, ktw, as_stream(stream));
 }
@@ -1086,37 +1117,146 @@ extern "C" int64_t odx_knm_bytes(int64_t n, int64_t M, int fmt) {
   return n * odx_knm_ld(M, fmt) * per;
 }
 
-extern "C" int odx_gauss_knm_h2_store(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
-                                      const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int D,
-                                      double sigma, int fmt, void* K, int64_t ldk, void* Klo, int64_t ldlo, const double* w,
-                                      double* ktw, void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
-  ODX_REQUIRE(M > 0, "odx_gauss_knm_h2_store: M <= 0");
-  ODX_REQUIRE(fmt == ODX_KNM_F32 || fmt == ODX_KNM_U24 || fmt == ODX_KNM_BF16, "odx_gauss_knm_h2_store: unknown storage format %d", fmt);
-  ODX_REQUIRE((w == nullptr) == (ktw == nullptr), "odx_gauss_knm_h2_store: w and ktw go together");
+// ld (4-byte units) an operand row needs for `core`, and the 128-byte stages of a row
+static int64_t core_min_ld(int D, int core) { return core == CORE_F8 ? round_up(D, 128) / 4 : round_up(D, H2_KT); }
+static int core_stages(int D, int core) { return (int)(core_min_ld(D, core) / W_KS); }
+
+static int knm_store_impl(const char* who, int core, const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
+                          const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int D, double sigma,
+                          int fmt, void* K, int64_t ldk, void* Klo, int64_t ldlo, const double* w, double* ktw, void* workspace,
+                          int64_t workspace_bytes, odx_stream_t stream) {
+  ODX_REQUIRE(M > 0, "%s: M <= 0", who);
+  ODX_REQUIRE(fmt == ODX_KNM_F32 || fmt == ODX_KNM_U24 || fmt == ODX_KNM_BF16, "%s: unknown storage format %d", who, fmt);
+  ODX_REQUIRE((w == nullptr) == (ktw == nullptr), "%s: w and ktw go together", who);
   if (n <= 0) {
     if (ktw) ODX_CHECK_HIP(hipMemsetAsync(ktw, 0, (size_t)M * sizeof(double), as_stream(stream)));
     return ODX_OK;
   }
-  ODX_REQUIRE(PX && PZ && metax && metaz && xsq && zsq && K && D > 0 && sigma > 0, "odx_gauss_knm_h2_store: bad argument");
-  const int64_t dp = round_up(D, H2_KT);
+  ODX_REQUIRE(PX && PZ && metax && metaz && xsq && zsq && K && D > 0 && sigma > 0, "%s: bad argument", who);
+  const int64_t dp = core_min_ld(D, core);
   ODX_REQUIRE(ldpx % 4 == 0 && ldpz % 4 == 0 && ldpx >= dp && ldpz >= dp && aligned16(PX) && aligned16(PZ),
-              "odx_gauss_knm_h2_store: packed operands must be 16-byte aligned with ld %% 4 == 0 and ld >= roundup(D, 64)");
+              "%s: packed operands must be 16-byte aligned with ld %% 4 == 0 and ld >= %lld 4-byte units", who, (long long)dp);
   const int64_t ldmin = odx_knm_ld(M, fmt);
   ODX_REQUIRE(ldk >= ldmin && ldk % (fmt == ODX_KNM_F32 ? 4 : 8) == 0 && aligned16(K),
-              "odx_gauss_knm_h2_store: K must be 16-byte aligned with ldk a multiple of %d and >= %lld", fmt == ODX_KNM_F32 ? 4 : 8, (long long)ldmin);
+              "%s: K must be 16-byte aligned with ldk a multiple of %d and >= %lld", who, fmt == ODX_KNM_F32 ? 4 : 8, (long long)ldmin);
   if (fmt == ODX_KNM_U24)
-    ODX_REQUIRE(Klo && ldlo >= ldmin && ldlo % 8 == 0 && aligned16(Klo), "odx_gauss_knm_h2_store: the low-byte plane must be 16-byte aligned with ldlo %% 8 == 0, ldlo >= roundup(M, 8)");
-  ODX_REQUIRE(ldpx < (1 << 24) && ldpz < (1 << 24) && ldk < (1 << 24), "odx_gauss_knm_h2_store: leading dimensions must stay below 2^24 (32-bit tile offsets)");
+    ODX_REQUIRE(Klo && ldlo >= ldmin && ldlo % 8 == 0 && aligned16(Klo), "%s: the low-byte plane must be 16-byte aligned with ldlo %% 8 == 0, ldlo >= roundup(M, 8)", who);
+  ODX_REQUIRE(ldpx < (1 << 24) && ldpz < (1 << 24) && ldk < (1 << 24), "%s: leading dimensions must stay below 2^24 (32-bit tile offsets)", who);
   if (w != nullptr && (workspace == nullptr || workspace_bytes < odx_gauss_knm_h2_rhs_workspace_bytes(n, M))) {
-    set_error("odx_gauss_knm_h2_store: workspace too small");
+    set_error("%s: workspace too small", who);
     return ODX_ERR_WORKSPACE;
   }
   const int64_t wld = round_up(M, 4);
   const int kf = fmt == ODX_KNM_F32 ? KF_F32 : (fmt == ODX_KNM_U24 ? KF_U24 : KF_BF16);
-  ODX_PROPAGATE(launch_knm_w256(PX, ldpx, metax, xsq, n, PZ, ldpz, metaz, zsq, M, dp, sigma, kf, K, ldk, Klo, ldlo, w,
-                                static_cast<double*>(workspace), wld, stream));
+  ODX_PROPAGATE(launch_knm_w256(PX, ldpx, metax, xsq, n, PZ, ldpz, metaz, zsq, M, core_stages(D, core), sigma, kf, K, ldk, Klo, ldlo,
+                                w, static_cast<double*>(workspace), wld, stream, core));
   if (w == nullptr) return ODX_OK;
   return slab_reduce_f64(static_cast<const double*>(workspace), wld, (int)ceil_div(n, W_BM), M, ktw, as_stream(stream));
+}
+
+extern "C" int odx_gauss_knm_h2_store(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
+                                      const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t M, int D,
+                                      double sigma, int fmt, void* K, int64_t ldk, void* Klo, int64_t ldlo, const double* w,
+                                      double* ktw, void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
+  return knm_store_impl("odx_gauss_knm_h2_store", CORE_H2, PX, ldpx, metax, xsq, n, PZ, ldpz, metaz, zsq, M, D, sigma, fmt, K, ldk,
+                        Klo, ldlo, w, ktw, workspace, workspace_bytes, stream);
+}
+
+// ---------------------------------------------------------------- fp8 (OCP e4m3) contraction: BASELINE config 5's path
+// x . z with both operands rounded once to e4m3 (4 significant bits): K entries off by ~1e-3, scores by ~5e-3
+// (tools/precision_scoring_study.py) — a THROUGHPUT-ONLY variant, never the default; the fit's 1e-4 bar on alpha needs the
+// f16-split kernels.  odx_split_f8 packs rows as e4m3 bytes, x s with s a power of two putting max |x| into [128, 256)
+// (e4m3's largest finite value is 448): row = ldp8 bytes, ldp8 % 128 == 0, features past D zero; meta as odx_split_f16.
+__global__ __launch_bounds__(256) void split_f8_kernel(const float* __restrict__ X, int64_t ldx, int64_t n, int D,
+                                                       uint32_t* __restrict__ P, int64_t ldp, float* __restrict__ meta) {
+  // scale = 2^(7 - e) for absmax = 1.m x 2^e
+  const unsigned int bits = __float_as_uint(meta[1]);
+  const int ef = (int)((bits >> 23) & 0xffu);
+  float s = 1.f;
+  if (ef != 0 && ef != 255) {
+    int se = 127 + 7 - (ef - 127);
+    se = se < 1 ? 1 : (se > 254 ? 254 : se);
+    s = __uint_as_float((unsigned int)se << 23);
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) meta[0] = s;
+  const int groups = (int)((D + 127) / 128) * 16;        // 8-feature groups per row, zero padded to whole 128-byte stages
+  const int64_t row = blockIdx.y;
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= groups) return;
+  const float* x = X + row * ldx + (int64_t)g * 8;
+  float v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = (g * 8 + q < D) ? x[q] * s : 0.f;
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+  uint32_t* dst = P + row * ldp + (int64_t)g * 2;
+  dst[0] = (uint32_t)lo;
+  dst[1] = (uint32_t)hi;
+}
+
+// qsq[row] = |e4m3(s x_row)|^2 / s^2: the squared norm of the row AS THE CONTRACTION SEES IT.  With these norms
+// d^2 = |q(x)|^2 + |q(z)|^2 - 2 q(x) . q(z) is the squared distance of the rounded points: never negative beyond rounding,
+// exactly 0 for duplicates (K = 1), and off the true d^2 by unbiased rounding noise — with the norms of the unrounded rows
+// a duplicate pair came out at K = 0.93 (the rounding shrinks |q(x)|^2 by ~1 % of 400).  One wave per row.
+__global__ __launch_bounds__(256) void f8_row_sqnorm_kernel(const uint32_t* __restrict__ P, int64_t ldp, int64_t n, int dwords,
+                                                            const float* __restrict__ meta, float* __restrict__ qsq) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  float acc = 0.f;
+  for (int i = lane; i < dwords; i += 64) {
+    const uint32_t u = P[row * ldp + i];
+    const auto a = __builtin_amdgcn_cvt_pk_f32_fp8((int)u, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)u, true);
+    acc = fmaf(a[0], a[0], acc);
+    acc = fmaf(a[1], a[1], acc);
+    acc = fmaf(b[0], b[0], acc);
+    acc = fmaf(b[1], b[1], acc);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) qsq[row] = acc / (meta[0] * meta[0]);
+}
+
+extern "C" int odx_split_f8(const float* X, int64_t ldx, int64_t n, int D, void* P, int64_t ldp8, float* meta, float* qsq,
+                            odx_stream_t stream) {
+  ODX_REQUIRE(meta, "odx_split_f8: meta is null");
+  hipStream_t s = as_stream(stream);
+  ODX_CHECK_HIP(hipMemsetAsync(meta, 0, 2 * sizeof(float), s));
+  if (n <= 0) {
+    hipLaunchKernelGGL(split_f8_kernel, dim3(1, 1), dim3(256), 0, s, X, ldx, 0, 0, (uint32_t*)P, 0, meta);
+    ODX_CHECK_LAUNCH("odx_split_f8");
+    return ODX_OK;
+  }
+  ODX_REQUIRE(X && P && D > 0 && ldx >= D && ldx % 4 == 0 && aligned16(X), "odx_split_f8: X must be 16-byte aligned with ldx %% 4 == 0 and ldx >= D");
+  ODX_REQUIRE(ldp8 >= round_up(D, 128) && ldp8 % 16 == 0 && aligned16(P), "odx_split_f8: P must be 16-byte aligned, ldp8 %% 16 == 0, ldp8 >= roundup(D, 128) bytes");
+  const unsigned blocks = (unsigned)(ceil_div(n, 4) > 1024 ? 1024 : ceil_div(n, 4));
+  hipLaunchKernelGGL(absmax_f32_kernel, dim3(blocks), dim3(256), 0, s, X, ldx, n, D, reinterpret_cast<unsigned int*>(meta + 1));
+  ODX_CHECK_LAUNCH("odx_split_f8(absmax)");
+  const int groups = (int)ceil_div(D, 128) * 16;
+  for (int64_t r0 = 0; r0 < n; r0 += 65535) {
+    const int64_t nr = n - r0 < 65535 ? n - r0 : 65535;
+    hipLaunchKernelGGL(split_f8_kernel, dim3((unsigned)ceil_div(groups, 256), (unsigned)nr), dim3(256), 0, s, X + r0 * ldx, ldx, nr, D,
+                       (uint32_t*)P + r0 * (ldp8 / 4), ldp8 / 4, meta);
+    ODX_CHECK_LAUNCH("odx_split_f8");
+  }
+  if (qsq != nullptr) {
+    hipLaunchKernelGGL(f8_row_sqnorm_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, s, (const uint32_t*)P, ldp8 / 4, n,
+                       (int)(round_up(D, 128) / 4), meta, qsq);
+    ODX_CHECK_LAUNCH("odx_split_f8(norms)");
+  }
+  return ODX_OK;
+}
+
+extern "C" int odx_gauss_knm_f8_store(const void* PX, int64_t ldpx8, const float* metax, const float* xsq, int64_t n,
+                                      const void* PZ, int64_t ldpz8, const float* metaz, const float* zsq, int64_t M, int D,
+                                      double sigma, int fmt, void* K, int64_t ldk, void* Klo, int64_t ldlo, const double* w,
+                                      double* ktw, void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
+  ODX_REQUIRE(ldpx8 % 16 == 0 && ldpz8 % 16 == 0, "odx_gauss_knm_f8_store: operand row strides (bytes) must be multiples of 16");
+  return knm_store_impl("odx_gauss_knm_f8_store", CORE_F8, PX, ldpx8 / 4, metax, xsq, n, PZ, ldpz8 / 4, metaz, zsq, M, D, sigma, fmt, K,
+                        ldk, Klo, ldlo, w, ktw, workspace, workspace_bytes, stream);
 }
 
 // Column tiles per workgroup on the 128 x 128 core: MMV_TG when that still gives every CU two workgroups, fewer for
@@ -1138,6 +1278,25 @@ extern "C" int64_t odx_gauss_mmv_h2_workspace_bytes(int64_t n, int64_t max_range
   return (int64_t)T * mmv_groups(max_range, mmv_tg(n, max_range, T)) * round_up(n, 2) * (int64_t)sizeof(double);
 }
 
+template <int CORE>
+static int launch_mmv_w256(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n, const void* PZ,
+                           int64_t ldpz, const float* metaz, const float* zsq, int64_t max_range, int stages, double sigma,
+                           const double* V, int64_t ldv, const int32_t* ranges, int C, float* out, int64_t ldo, double* slab,
+                           int64_t slab_ld, odx_stream_t stream) {
+  const int64_t Gw = ceil_div(ceil_div(max_range, W_BN), W_MMV_TG);      // <= mmv_groups(max_range): the slab is large enough
+  const int64_t wgs = round_up(ceil_div(n, W_BM), 8) * Gw;
+  ODX_REQUIRE(wgs < (1ll << 31), "odx_gauss_mmv: grid too large");
+  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_mmv_h2w256_kernel<CORE>), W_LDS_BYTES));
+  hipLaunchKernelGGL(gauss_mmv_h2w256_kernel<CORE>, dim3((unsigned)wgs, (unsigned)C), dim3(W_THREADS), W_LDS_BYTES,
+                     as_stream(stream), (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq, stages,
+                     (float)(-0.5 / (sigma * sigma)) * LOG2E, V, ldv, ranges, W_MMV_TG, (int)Gw, slab, slab_ld);
+  ODX_CHECK_LAUNCH("odx_gauss_mmv(w256)");
+  hipLaunchKernelGGL(mmv_reduce_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)C), dim3(256), 0, as_stream(stream), slab,
+                     slab_ld, (int)Gw, W_MMV_TG, W_BN, ranges, n, out, ldo);
+  ODX_CHECK_LAUNCH("odx_gauss_mmv(reduce)");
+  return ODX_OK;
+}
+
 extern "C" int odx_gauss_mmv_h2(const void* PX, int64_t ldpx, const float* metax, const float* xsq, int64_t n,
                                 const void* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t max_range, int D,
                                 double sigma, const double* V, int64_t ldv, const int32_t* ranges, int C, float* out,
@@ -1156,23 +1315,9 @@ extern "C" int odx_gauss_mmv_h2(const void* PX, int64_t ldpx, const float* metax
   }
   double* slab = static_cast<double*>(workspace);
   const int64_t slab_ld = round_up(n, 2);
-  {
-    const int64_t Gw = ceil_div(ceil_div(max_range, W_BN), W_MMV_TG);      // <= mmv_groups(max_range): the slab is large enough
-    if (h2_use_w256(ceil_div(n, W_BM) * Gw * C)) {
-      const int64_t wgs = round_up(ceil_div(n, W_BM), 8) * Gw;
-      ODX_REQUIRE(wgs < (1ll << 31), "odx_gauss_mmv_h2: grid too large");
-      ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_mmv_h2w256_kernel), W_LDS_BYTES));
-      hipLaunchKernelGGL(gauss_mmv_h2w256_kernel, dim3((unsigned)wgs, (unsigned)C), dim3(W_THREADS), W_LDS_BYTES,
-                         as_stream(stream), (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq,
-                         (int)(dp / W_KS), (float)(-0.5 / (sigma * sigma)) * LOG2E, V, ldv, ranges, W_MMV_TG, (int)Gw, slab,
-                         slab_ld);
-      ODX_CHECK_LAUNCH("odx_gauss_mmv_h2(w256)");
-      hipLaunchKernelGGL(mmv_reduce_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)C), dim3(256), 0, as_stream(stream),
-                         slab, slab_ld, (int)Gw, W_MMV_TG, W_BN, ranges, n, out, ldo);
-      ODX_CHECK_LAUNCH("odx_gauss_mmv_h2(reduce)");
-      return ODX_OK;
-    }
-  }
+  if (h2_use_w256(ceil_div(n, W_BM) * ceil_div(ceil_div(max_range, W_BN), W_MMV_TG) * C))
+    return launch_mmv_w256<CORE_H2>(PX, ldpx, metax, xsq, n, PZ, ldpz, metaz, zsq, max_range, (int)(dp / W_KS), sigma, V, ldv, ranges,
+                                    C, out, ldo, slab, slab_ld, stream);
   const int tg = mmv_tg(n, max_range, C);
   const int G = (int)mmv_groups(max_range, tg);
   const int64_t wgs = round_up(ceil_div(n, GEMM_BM), 8) * G;
@@ -1186,4 +1331,25 @@ extern "C" int odx_gauss_mmv_h2(const void* PX, int64_t ldpx, const float* metax
                      slab_ld, G, tg, GEMM_BN, ranges, n, out, ldo);
   ODX_CHECK_LAUNCH("odx_gauss_mmv_h2(reduce)");
   return ODX_OK;
+}
+
+// Fused scoring with the e4m3 contraction (throughput-only, see odx_split_f8): always on the 256 x 256 core; workspace as
+// odx_gauss_mmv_h2_workspace_bytes.
+extern "C" int odx_gauss_mmv_f8(const void* PX, int64_t ldpx8, const float* metax, const float* xsq, int64_t n,
+                                const void* PZ, int64_t ldpz8, const float* metaz, const float* zsq, int64_t max_range, int D,
+                                double sigma, const double* V, int64_t ldv, const int32_t* ranges, int C, float* out,
+                                int64_t ldo, void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
+  if (n <= 0 || C <= 0) return ODX_OK;
+  ODX_REQUIRE(PX && PZ && metax && metaz && xsq && zsq && V && ranges && out && D > 0 && sigma > 0 && ldv >= C && max_range > 0,
+              "odx_gauss_mmv_f8: bad argument");
+  ODX_REQUIRE(ldpx8 % 16 == 0 && ldpz8 % 16 == 0 && ldpx8 >= round_up(D, 128) && ldpz8 >= round_up(D, 128) && aligned16(PX) && aligned16(PZ),
+              "odx_gauss_mmv_f8: packed operands must be 16-byte aligned with row strides %% 16 == 0 and >= roundup(D, 128) bytes");
+  ODX_REQUIRE(ldo >= C && C < 65536, "odx_gauss_mmv_f8: ldo < C or too many classes");
+  ODX_REQUIRE(ldpx8 < (1 << 26) && ldpz8 < (1 << 26), "odx_gauss_mmv_f8: row strides must stay below 2^26 bytes (32-bit tile offsets)");
+  if (workspace == nullptr || workspace_bytes < odx_gauss_mmv_h2_workspace_bytes(n, max_range, C)) {
+    set_error("odx_gauss_mmv_f8: workspace too small");
+    return ODX_ERR_WORKSPACE;
+  }
+  return launch_mmv_w256<CORE_F8>(PX, ldpx8 / 4, metax, xsq, n, PZ, ldpz8 / 4, metaz, zsq, max_range, core_stages(D, CORE_F8), sigma, V,
+                                  ldv, ranges, C, out, ldo, static_cast<double*>(workspace), round_up(n, 2), stream);
 }

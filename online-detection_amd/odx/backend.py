@@ -29,12 +29,13 @@ def _p(t):
 class Features:
     """Row-major f32 rows (n x D, leading dimension a multiple of 4) plus their squared norms and, once a
     Gaussian-kernel call has needed it, the packed two-term f16 split of the rows (P, meta: odx_split_f16)."""
-    __slots__ = ("X", "sq", "n", "D", "ld", "P", "meta", "own_pack")
+    __slots__ = ("X", "sq", "n", "D", "ld", "P", "meta", "own_pack", "P8", "meta8", "sq8")
 
     def __init__(self, X, sq, D, P=None, meta=None):
         self.X, self.sq, self.n, self.D, self.ld = X, sq, X.shape[0], D, X.stride(0) if X.shape[0] else X.shape[1]
         self.P, self.meta = P, meta
         self.own_pack = P is None       # False: P was gathered from another matrix's split and carries ITS scale
+        self.P8 = self.meta8 = self.sq8 = None     # e4m3 packing (odx_split_f8), made on demand by the throughput-only fp8 kernels
 
 
 class Precond:
@@ -82,12 +83,14 @@ class HipBackend:
         # "h2": X Z' of the Gaussian kernels on the f16 matrix cores via the two-term split (f32 accuracy);
         # "f32": the all-f32 MFMA chain.  Both are HIP paths of libodx; there is no other.
         self.gauss = os.environ.get("ODX_GAUSS", "h2")
-        if self.gauss not in ("h2", "f32"):
-            raise ValueError("ODX_GAUSS must be 'h2' or 'f32', got %r" % self.gauss)
+        # ("f8": BASELINE config 5's e4m3 contraction — throughput only, K entries ~1e-3 off; never a default)
+        if self.gauss not in ("h2", "f32", "f8"):
+            raise ValueError("ODX_GAUSS must be 'h2', 'f32' or 'f8', got %r" % self.gauss)
         # Storage of the K_nM block the CG passes stream (include/odx.h): "f32" always f32; "u24" / "bf16" always that compact
         # format (f16-split kernels only); "auto" (default): 24-bit fixed point for the blocks whose passes are HBM-bound
-        # (>= 2^28 entries on the wide tile core: the headline, config 4 / 5 shards), f32 below — small fits gain nothing
-        # and keep the one-library-call CG.  tools/precision_storage_study.py: alpha against the f64 evaluation is the same
+        # (>= 2^28 entries and more than 4096 centres on the wide tile core: the headline, config 5's shards), f32 below —
+        # narrow blocks (M = 2000: 0.75 ms per pass in either format) and small fits gain nothing and keep the one-call /
+        # class-batched CG loops, which stream f32.  tools/precision_storage_study.py: alpha against the f64 evaluation is the same
         # with u24 as with f32 storage; bf16 is BASELINE config 2's throughput-only storage (alpha off by 1e-2..6e-1).
         self.knm_storage = os.environ.get("ODX_KNM", "auto")
         if self.knm_storage not in ("auto", "f32", "u24", "bf16"):
@@ -152,7 +155,21 @@ class HipBackend:
         buf = torch.zeros((idx.numel(), ld), dtype=torch.float32, device=self.device)
         buf[:, :F.D] = F.X.index_select(0, idx)
         P = F.P.index_select(0, idx) if F.P is not None else None
-        return Features(buf[:, :F.D], F.sq.index_select(0, idx), F.D, P, F.meta if P is not None else None)
+        Z = Features(buf[:, :F.D], F.sq.index_select(0, idx), F.D, P, F.meta if P is not None else None)
+        if F.P8 is not None:
+            Z.P8, Z.meta8, Z.sq8 = F.P8.index_select(0, idx), F.meta8, F.sq8.index_select(0, idx)
+        return Z
+
+    def pack8(self, F):
+        """Make sure F carries its e4m3 packing (odx_split_f8); returns F."""
+        if F.P8 is None:
+            ldp8 = (F.D + 127) // 128 * 128
+            F.P8 = torch.empty((F.n, ldp8), dtype=torch.uint8, device=self.device)
+            F.meta8 = torch.zeros(2, dtype=torch.float32, device=self.device)
+            F.sq8 = torch.empty(F.n, dtype=torch.float32, device=self.device)
+            hip.check(self.lib.odx_split_f8(_p(F.X), F.ld, F.n, F.D, _p(F.P8), ldp8, _p(F.meta8), _p(F.sq8), self._stream()),
+                      "odx_split_f8")
+        return F
 
     def pack(self, F):
         """Make sure F carries its packed f16 split (odx_split_f16); returns F."""
@@ -230,11 +247,11 @@ class HipBackend:
 
     def knm_format(self, n, M):
         """Storage format a K_nM block of this shape gets (see __init__)."""
-        if self.gauss != "h2" or n <= 0 or M <= 0:
+        if self.gauss not in ("h2", "f8") or n <= 0 or M <= 0:
             return "f32"
         if self.knm_storage in ("u24", "bf16"):
             return self.knm_storage if self.lib.odx_knm_fwd_bwd_q_workspace_bytes(n, M, _KNM_CODE[self.knm_storage]) >= 0 else "f32"
-        if self.knm_storage == "auto" and n * M >= (1 << 28) and self.lib.odx_gauss_h2_tile(n, M) == 256 \
+        if self.knm_storage == "auto" and n * M >= (1 << 28) and M > 4096 and (self.gauss == "f8" or self.lib.odx_gauss_h2_tile(n, M) == 256) \
                 and self.lib.odx_knm_fwd_bwd_q_workspace_bytes(n, M, hip.KNM_U24) >= 0:
             return "u24"
         return "f32"
@@ -266,7 +283,7 @@ class HipBackend:
     def knm(self, F, Zf, sigma, out=None):
         n, M = F.n, Zf.n
         fmt = self.knm_format(n, M)
-        if fmt != "f32":
+        if fmt != "f32" or self.gauss == "f8":
             return self._knm_store(F, Zf, sigma, fmt, None, out, None)[0]
         K = self._knm_block(n, M, "f32", out)
         ld = K.ld
@@ -285,17 +302,20 @@ class HipBackend:
         when w is given."""
         n, M = F.n, Zf.n
         K = self._knm_block(n, M, fmt, out)
-        self.pack(F), self.pack(Zf)
+        f8 = self.gauss == "f8"
+        (self.pack8(F), self.pack8(Zf)) if f8 else (self.pack(F), self.pack(Zf))
         ws = None
         if w is not None:
             w = w.to(dtype=torch.float64, device=self.device).contiguous()
             if rhs_out is None:
                 rhs_out = torch.empty(M, dtype=torch.float64, device=self.device)
             ws = self._workspace("knm_rhs", self.lib.odx_gauss_knm_h2_rhs_workspace_bytes(n, M))
-        hip.check(self.lib.odx_gauss_knm_h2_store(_p(F.P), F.P.stride(0), _p(F.meta), _p(F.sq), n, _p(Zf.P), Zf.P.stride(0),
-                                                  _p(Zf.meta), _p(Zf.sq), M, F.D, float(sigma), _KNM_CODE[fmt], _p(K.K), K.ld,
-                                                  _p(K.lo), K.ld, _p(w), _p(rhs_out if w is not None else None), _p(ws),
-                                                  ws.numel() if ws is not None else 0, self._stream()), "odx_gauss_knm_h2_store")
+        fn, PX, mx, PZ, mz = ((self.lib.odx_gauss_knm_f8_store, F.P8, F.meta8, Zf.P8, Zf.meta8) if f8 else
+                              (self.lib.odx_gauss_knm_h2_store, F.P, F.meta, Zf.P, Zf.meta))
+        sqx, sqz = (F.sq8, Zf.sq8) if f8 else (F.sq, Zf.sq)
+        hip.check(fn(_p(PX), PX.stride(0), _p(mx), _p(sqx), n, _p(PZ), PZ.stride(0), _p(mz), _p(sqz), M, F.D, float(sigma),
+                     _KNM_CODE[fmt], _p(K.K), K.ld, _p(K.lo), K.ld, _p(w), _p(rhs_out if w is not None else None), _p(ws),
+                     ws.numel() if ws is not None else 0, self._stream()), "odx_gauss_knm_f8_store" if f8 else "odx_gauss_knm_h2_store")
         return K, rhs_out
 
     def knm_rhs(self, F, Zf, sigma, w, out=None, rhs_out=None):
@@ -306,7 +326,7 @@ class HipBackend:
         if rhs_out is None:
             rhs_out = torch.empty(M, dtype=torch.float64, device=self.device)
         fmt = self.knm_format(n, M)
-        if fmt != "f32" and n > 0:
+        if (fmt != "f32" or self.gauss == "f8") and n > 0:
             return self._knm_store(F, Zf, sigma, fmt, w, out, rhs_out)
         if not (self.gauss == "h2" and n > 0 and self.lib.odx_gauss_h2_tile(n, M) == 256):
             K = self.knm(F, Zf, sigma, out=out)
@@ -374,7 +394,10 @@ class HipBackend:
         hip.check(self.lib.odx_cg_residual(_p(B), _p(AX), _p(AP), _p(state), _p(R), R.numel(), self._stream()), "odx_cg_residual")
 
     def cg_solve(self, K, P, b0, n_total, lam, maxiter, opt):
-        """The CG loop of an unsharded fit in one library call (odx_falkon_cg_f64); returns alpha (M,) f64."""
+        """The CG loop of an unsharded fit in one library call (odx_falkon_cg_f64); returns alpha (M,) f64.  f32-stored
+        blocks only: the library loop streams K as floats (compact formats go through solver.falkon_fit's loop)."""
+        if K.fmt != "f32":
+            raise hip.OdxError("cg_solve: the one-call CG loop needs an f32-stored K_nM block, got %r" % K.fmt)
         alpha = torch.empty(K.M, dtype=torch.float64, device=self.device)
         nbytes = self.lib.odx_falkon_cg_workspace_bytes(max(K.n, 1), K.M)
         if nbytes < 0:
@@ -464,7 +487,14 @@ class HipBackend:
             return out
         if Mtot == 0:
             return out.zero_()
-        if self.gauss == "h2":
+        if self.gauss == "f8":
+            self.pack8(F), self.pack8(Zf)
+            mr = Mtot if max_range is None else max(1, min(int(max_range), Mtot))
+            ws = self._workspace("mmv", self.lib.odx_gauss_mmv_h2_workspace_bytes(F.n, mr, T))
+            hip.check(self.lib.odx_gauss_mmv_f8(_p(F.P8), F.P8.stride(0), _p(F.meta8), _p(F.sq8), F.n, _p(Zf.P8), Zf.P8.stride(0),
+                                                _p(Zf.meta8), _p(Zf.sq8), mr, F.D, float(sigma), _p(V), V.stride(0), _p(ranges), T,
+                                                _p(out), out.stride(0), _p(ws), ws.numel(), self._stream()), "odx_gauss_mmv_f8")
+        elif self.gauss == "h2":
             self.pack(F), self.pack(Zf)
             mr = Mtot if max_range is None else max(1, min(int(max_range), Mtot))
             ws = self._workspace("mmv", self.lib.odx_gauss_mmv_h2_workspace_bytes(F.n, mr, T))

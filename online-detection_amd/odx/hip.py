@@ -63,6 +63,11 @@ SIGNATURES = {
     "odx_knm_fwd_bwd_q": (_i32, [_vp, _i64, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "odx_knm_fwd_bwd2_q_workspace_bytes": (_i64, [_i64, _i64, _i32]),
     "odx_knm_fwd_bwd2_q": (_i32, [_vp, _i64, _vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "odx_split_f8": (_i32, [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp, _vp]),
+    "odx_gauss_knm_f8_store": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _f64, _i32, _vp, _i64, _vp, _i64,
+                                      _vp, _vp, _vp, _i64, _vp]),
+    "odx_gauss_mmv_f8": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _f64, _vp, _i64, _vp, _i32, _vp, _i64,
+                                _vp, _i64, _vp]),
     "odx_cg_residual": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "odx_falkon_precond_workspace_bytes": (_i64, [_i64, _i32]),
     "odx_falkon_precond_f64": (_i32, [_vp, _i64, _i64, _i32, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp]),

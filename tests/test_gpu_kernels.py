@@ -369,6 +369,66 @@ def test_bf16_stored_knm(be, n, M, D, sigma):
     assert np.abs(be.ktk(K, v=dev(v)).cpu().numpy() - g64.T @ (g64 @ v)).max() <= 1e-10 * max(1.0, np.abs(g64.T @ (g64 @ v)).max()) * n
 
 
+def _e4m3(x):
+    """Round to OCP e4m3fn (4 exponent bits, bias 7; 3 mantissa bits; subnormal step 2^-9; largest finite 448), nearest even."""
+    ax = np.abs(np.asarray(x, dtype=np.float64))
+    e = np.maximum(np.floor(np.log2(np.maximum(ax, 2.0 ** -30))), -6.0)
+    step = 2.0 ** (e - 3)
+    return np.sign(x) * np.minimum(np.rint(ax / step) * step, 448.0)
+
+
+@pytest.mark.parametrize("n,M,D,sigma", [(1000, 500, 256, 10.0), (333, 130, 1024, 15.0), (700, 257, 70, 5.0), (513, 1025, 200, 8.0)])
+def test_fp8_contraction(be, n, M, D, sigma):
+    """BASELINE config 5's path (ODX_GAUSS=f8): x . z with both operands rounded once to e4m3 on
+    v_mfma_scale_f32_16x16x128_f8f6f4.  Pinned against the same arithmetic in numpy — operands scaled by the power of two
+    that puts max |x| into [128, 256), rounded to e4m3, exact products, the squared norms of the rounded rows — to
+    the accuracy of the scaled MFMA's own summation (this fixes its lane -> feature map and the unit block scale), for the
+    build in all three storage formats, the fused right-hand side and the fused scoring.  Against the exact kernel the
+    entries are typically ~1e-3 off and at worst a few 1e-2 (asserted: a throughput-only path)."""
+    from oracle import falkon_ref as fr
+    rng = np.random.default_rng(n + M + D)
+    X = (rng.standard_normal((n, D)) * (20.0 / np.sqrt(D))).astype(np.float32)
+    Z = X[rng.integers(0, n, M)].copy()
+    Z[M // 2:] += (0.3 * rng.standard_normal((M - M // 2, D))).astype(np.float32)
+    w = rng.standard_normal(n)
+    al = rng.standard_normal((M, 2))
+
+    def q(A):
+        s = 2.0 ** (7 - np.floor(np.log2(np.abs(A).max())))
+        return _e4m3(A.astype(np.float64) * s), s
+    (Xq, sx), (Zq, sz) = q(X), q(Z)
+    sqx = ((Xq / sx) ** 2).sum(1)[:, None]              # the norms of the ROUNDED rows: d^2 = |q(x) - q(z)|^2
+    sqz = ((Zq / sz) ** 2).sum(1)[None, :]
+    Kq = np.exp(-np.maximum(sqx + sqz - 2.0 * (Xq @ Zq.T) / (sx * sz), 0.0) / (2 * sigma ** 2))
+    Kx = fr.gaussian_kernel(X.astype(np.float64), Z.astype(np.float64), sigma)
+    F, Zf = be.features(torch.from_numpy(X)), be.features(torch.from_numpy(Z))
+    old, oldk = be.gauss, be.knm_storage
+    try:
+        be.gauss = "f8"
+        for st in ("f32", "u24", "bf16"):
+            be.knm_storage = st
+            K, ktw = be.knm_rhs(F, Zf, sigma, torch.from_numpy(w).cuda())
+            assert K.fmt == st
+            got = kdense(K).astype(np.float64)
+            # (the scaled MFMA sums its 128 products with fewer bits than an f32 fmaf chain: x . z comes out ~6e-5
+            # relative off the exact sum of the same rounded operands, i.e. K up to ~1e-4 off where x . z ~ |x|^2; a wrong
+            # lane -> feature map or block scale would be off by O(1))
+            tol = max(5e-4, 0.05 / sigma ** 2) + (2.0 ** -8 if st == "bf16" else 0.0)
+            assert np.abs(got - Kq).max() < tol, (st, np.abs(got - Kq).max())
+            assert np.abs(got - Kx).max() < max(3e-2, 1.25 / sigma ** 2)       # what rounding both operands to 4 bits costs
+            want = got.T @ w
+            assert np.abs(ktw.cpu().numpy() - want).max() <= 1e-12 * max(1.0, np.abs(want).max()) * n
+        assert float(F.meta8[0]) == sx and float(Zf.meta8[0]) == sz
+        assert np.allclose(F.sq8.cpu().numpy(), sqx[:, 0], rtol=1e-5)
+        P8 = F.P8.cpu().numpy()
+        assert P8.shape[1] % 128 == 0 and not P8[:, D:].any()
+        sc = be.mmv(F, Zf, sigma, torch.from_numpy(al)).cpu().numpy()
+        assert np.abs(sc - Kq @ al).max() < 5e-4 * np.abs(al).sum(0).max()
+        assert np.abs(sc - Kx @ al).max() < 3e-2 * np.sqrt(M)
+    finally:
+        be.gauss, be.knm_storage = old, oldk
+
+
 def test_u24_stored_knm_is_the_rounded_f32_block(be):
     """The 24-bit fixed-point block is the f32 block the default build stores, entry by entry rounded to the nearest
     multiple of 2^-24 (saturating at 1 - 2^-24)."""

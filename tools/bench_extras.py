@@ -240,12 +240,14 @@ def falkon_config_extra(name, C, n, D, M, sigma, lam, classes_run, labels="one_v
             infos.extend(p.info for p in Ps)
             Mp = (M + 1) // 2 * 2
             b0s = torch.zeros((len(cls), Mp), dtype=torch.float64, device=dev)
-            Ks = [be.knm_rhs(F, Zfs[k], sigma, ys[k] * (1.0 / n), rhs_out=b0s[k, :Zfs[k].n])[0] for k in range(len(cls))]
-            alphas = be.cg_solve_batched(Ks, Ps, b0s, [n] * len(cls), lam, maxiter, opt)
-            if alphas is None:          # outside the batched pass configurations (M = 2e4): one CG loop per class
-                alphas = torch.stack([torch.nn.functional.pad(be.cg_solve(Ks[k], Ps[k], b0s[k, :Zfs[k].n], n, lam, maxiter, opt),
+            alphas = None
+            if be.knm_format(n, M) == "f32":      # small blocks: all K_nM builds, then the CG loops of the chain's classes in lock step
+                Ks = [be.knm_rhs(F, Zfs[k], sigma, ys[k] * (1.0 / n), rhs_out=b0s[k, :Zfs[k].n])[0] for k in range(len(cls))]
+                alphas = be.cg_solve_batched(Ks, Ps, b0s, [n] * len(cls), lam, maxiter, opt)
+                del Ks
+            if alphas is None:          # HBM-bound blocks (compact storage) or M outside the batched configurations: one fit per class
+                alphas = torch.stack([torch.nn.functional.pad(odx.falkon_fit(be, F, ys[k], Zfs[k], sigma, lam, maxiter, opt, precond=Ps[k]),
                                                               (0, Mp - Zfs[k].n)) for k in range(len(cls))])
-            del Ks
             for k, c in enumerate(cls):
                 be.mmv(F, Zfs[k], sigma, alphas[k, :Zfs[k].n], None, out=scores[:, g0 + k:g0 + k + 1])
         return scores, infos, (F, Zfs[-1], alphas[-1, :Zfs[-1].n])
@@ -258,7 +260,8 @@ def falkon_config_extra(name, C, n, D, M, sigma, lam, classes_run, labels="one_v
     out = {"workload": "%s: %d classes x (FALKON fit + score-all) on n=%d rows, D=%d, M=%d, sigma=%g, lambda=%g, %d CG iterations; "
                        "%d class(es) run on this GPU%s" % (name, C, n, D, M, sigma, lam, maxiter, len(run),
                                                           "" if len(run) == C else ", the config's time extrapolated linearly in the class count"),
-           "dtype": "f32 K_nM via two-term f16 split + f64 solver" if be.gauss == "h2" else "f32 K_nM (f32 MFMA) + f64 solver",
+           "dtype": {"h2": "f32-accurate K_nM entries via two-term f16 split", "f8": "K_nM entries from e4m3 operands (throughput only)",
+                     "f32": "f32 K_nM entries (f32 MFMA)"}[be.gauss] + ", stored as %s, f64 solver" % be.knm_format(n, M),
            "s_classes_run": round(dt, 4), "classes_run": len(run), "samples_per_s": round(n / s_all, 1),
            "samples_x_classes_per_s": round(n * C / s_all, 1), "failed_choleskys": failed, "scores_finite": finite}
     if labels != "pixels" and len(run) == C:
@@ -277,15 +280,15 @@ def falkon_config_extra(name, C, n, D, M, sigma, lam, classes_run, labels="one_v
     sc = torch.empty((n, 1), dtype=torch.float32, device=dev)
     ms_s = _events_ms(lambda: be.mmv(F, Zf, sigma, alpha, None, out=sc), 3)
     flop = 2.0 * n * Zf.n * D
-    kbytes = float(n) * K.ld * 4
-    peak = F16_MFMA_PEAK_TFLOPS if be.gauss == "h2" else 157.3
-    tile = be.lib.odx_gauss_h2_tile(n, Zf.n) if be.gauss == "h2" else 0
+    kbytes = float(be.knm_bytes(n, Zf.n))
+    peak = {"h2": F16_MFMA_PEAK_TFLOPS, "f8": F8_MFMA_PEAK_TFLOPS}.get(be.gauss, 157.3)
+    tile = 256 if be.gauss == "f8" else (be.lib.odx_gauss_h2_tile(n, Zf.n) if be.gauss == "h2" else 0)
     out["kernels"] = {
-        "build": {"kernel": ("gauss_knm_h2w256_kernel<RHS>" if tile == 256 else "gauss_knm_h2s16_kernel + pass") if be.gauss == "h2" else "gauss_knm_f32_kernel",
+        "build": {"kernel": ("gauss_knm_h2w256_kernel<RHS>" if tile == 256 else "gauss_knm_h2s16_kernel + pass") if be.gauss in ("h2", "f8") else "gauss_knm_f32_kernel",
                   "ms": round(ms_b, 3), "TFLOPs": round(flop / ms_b / 1e9, 1), "frac_mfma": round(flop / ms_b / 1e9 / peak, 4),
                   "K_write_GBps": round(kbytes / ms_b / 1e6, 1), "frac_hbm_write": round(kbytes / ms_b / 1e6 / HBM_PEAK_GBS, 4),
                   "bound": "mfma" if flop / (peak * 1e12) > kbytes / (HBM_PEAK_GBS * 1e9) else "hbm (K write)"},
-        "pass": {"kernel": "knm_pass_kernel", "ms": round(ms_p, 3), "GBps": round(kbytes / ms_p / 1e6, 1),
+        "pass": {"kernel": "knm_pass_kernel" if K.fmt == "f32" else "knm_passq_kernel", "storage": K.fmt, "ms": round(ms_p, 3), "GBps": round(kbytes / ms_p / 1e6, 1),
                  "frac_hbm": round(kbytes / ms_p / 1e6 / HBM_PEAK_GBS, 4), "bound": "hbm"},
         "score": {"kernel": "gauss_mmv_h2w256_kernel" if tile == 256 else "gauss_mmv_h2s16_kernel", "ms": round(ms_s, 3),
                   "TFLOPs": round(flop / ms_s / 1e9, 1), "frac_mfma": round(flop / ms_s / 1e9 / peak, 4), "bound": "mfma"}}
