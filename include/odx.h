@@ -368,6 +368,16 @@ int odx_gemm_h2_f32(const void* PA, int64_t ldpa, const float* metaa, int64_t m,
 int odx_roi_align_rows_f32(const float* feat, int N, int C, int H, int W, const float* rois, int R,
                            float spatial_scale, int PH, int PW, int sampling_ratio, int step, float* out_rows,
                            odx_stream_t stream);
+/* Multi-level RoIAlign over an FPN pyramid: maskrcnn_benchmark's Pooler as FPN2MLPFeatureExtractor uses it
+ * (mrcnn_modified/modeling/roi_heads/box_head/roi_box_feature_extractors.py:61-68,79; config/defaults.py:214-219 with the
+ * R-50-FPN values POOLER_SCALES (1/4 .. 1/32), POOLER_RESOLUTION 7, POOLER_SAMPLING_RATIO 2).  feats[l] (N, C, H[l], W[l]),
+ * scales[l] = 1 / stride of level l (halving from level to level; at most 4 levels); each RoI is pooled from the level
+ *   clamp(floor(4 + log2(sqrt((x2 - x1 + 1)(y2 - y1 + 1)) / 224 + 1e-6)), -log2 scales[0], -log2 scales[levels-1]) + log2 scales[0]
+ * with ONE launch for all RoIs (the reference: one RoIAlign per level over a boolean selection, then a scatter).
+ * out (R, C, PH, PW); level_out (R ints, may be NULL) receives each RoI's level.  feats / H / W / scales are HOST arrays. */
+int odx_roi_align_fpn_f32(const float* const* feats, const int* H, const int* W, const float* scales, int levels,
+                          int N, int C, const float* rois, int R, int PH, int PW, int sampling_ratio, float* out,
+                          int* level_out, odx_stream_t stream);
 /* Greedy NMS over boxes (R, 4) xyxy ALREADY SORTED by descending score, areas with the +1
  * pixel convention: keep[i] = 1 unless an earlier kept box overlaps i with IoU > threshold.  */
 int64_t odx_nms_workspace_bytes(int R);

@@ -6,9 +6,13 @@
 // Semantics restated from the published operators (Mask R-CNN RoIAlign in its legacy
 // "aligned = False" form with adaptive sampling when sampling_ratio == 0; greedy NMS with the
 // +1 pixel-area convention); parity unpinned by the reference (the extension is not vendored).
+#include <math.h>
+
 #include "odx_common.h"
 
 namespace odx {
+
+constexpr int ODX_MAX_FPN_LEVELS = 4;
 
 // ---------------------------------------------------------------- RoIAlign forward
 // feat (N, C, H, W) f32, rois (R, 5) = (batch index, x1, y1, x2, y2), out (R, C, PH, PW).
@@ -80,6 +84,86 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(const float* __restr
     for (int k = 0; k < ROI_CCH; ++k)
       if (k < nch) row[k] = acc[k] / count;
     return;
+  }
+#pragma unroll
+  for (int k = 0; k < ROI_CCH; ++k)
+    if (k < nch) out[(((int64_t)r * C + c0 + k) * PH + ph) * PW + pw] = acc[k] / count;
+}
+
+// ---------------------------------------------------------------- multi-level RoIAlign (FPN Pooler)
+// maskrcnn_benchmark's Pooler over an FPN pyramid (mrcnn_modified/modeling/roi_heads/box_head/roi_box_feature_extractors.py
+// :61-68,79 -> Pooler; levels by maskrcnn_benchmark.modeling.poolers.LevelMapper): every RoI is pooled from ONE level,
+//     level = clamp(floor(4 + log2(sqrt(area) / 224 + 1e-6)), k_min, k_max) - k_min,   area = (x2 - x1 + 1)(y2 - y1 + 1),
+// k_min / k_max = -log2 of the first / last level's scale, with that level's map and scale.  The reference runs one
+// RoIAlign per level over a boolean selection of the RoIs and scatters the results back; here ONE launch serves all RoIs —
+// the workgroup of a RoI picks its level's map from a table in the kernel arguments.  out (R, C, PH, PW): viewed as
+// (R, C PH PW) it is the row matrix the fc6 GEMM of FPN2MLPFeatureExtractor consumes (x.view(x.size(0), -1), :80).
+struct FpnLevels {
+  const float* feat[ODX_MAX_FPN_LEVELS];
+  int H[ODX_MAX_FPN_LEVELS], W[ODX_MAX_FPN_LEVELS];
+  float scale[ODX_MAX_FPN_LEVELS];
+  int levels, k_min, k_max;
+};
+
+__device__ __forceinline__ int fpn_level_of(const float* roi, const FpnLevels& L) {
+  const float area = (roi[3] - roi[1] + 1.f) * (roi[4] - roi[2] + 1.f);
+  const float s = sqrtf(area);
+  float lvl = floorf(4.f + log2f(s / 224.f + 1e-6f));
+  lvl = fminf(fmaxf(lvl, (float)L.k_min), (float)L.k_max);
+  return (int)lvl - L.k_min;
+}
+
+__global__ __launch_bounds__(256) void roi_align_fpn_kernel(FpnLevels L, int N, int C, const float* __restrict__ rois, int R,
+                                                            int PH, int PW, int sampling_ratio, float* __restrict__ out,
+                                                            int* __restrict__ level_out) {
+  const int r = blockIdx.x;
+  const int c0 = blockIdx.y * ROI_CCH;
+  const int t = threadIdx.x;
+  const float* roi = rois + (int64_t)r * 5;
+  const int lv = fpn_level_of(roi, L);
+  if (level_out != nullptr && blockIdx.y == 0 && t == 0) level_out[r] = lv;
+  if (t >= PH * PW) return;
+  const int ph = t / PW, pw = t % PW;
+  const float* feat = L.feat[0];
+  int H = L.H[0], W = L.W[0];
+  float scale = L.scale[0];
+#pragma unroll
+  for (int k = 1; k < ODX_MAX_FPN_LEVELS; ++k)
+    if (k == lv) { feat = L.feat[k]; H = L.H[k]; W = L.W[k]; scale = L.scale[k]; }
+  const int b = (int)roi[0];
+  const float x1 = roi[1] * scale, y1 = roi[2] * scale, x2 = roi[3] * scale, y2 = roi[4] * scale;
+  const float rw = fmaxf(x2 - x1, 1.f), rh = fmaxf(y2 - y1, 1.f);
+  const float bw = rw / (float)PW, bh = rh / (float)PH;
+  const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)PH);
+  const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)PW);
+  const float count = (float)(gh * gw);
+  float acc[ROI_CCH];
+#pragma unroll
+  for (int k = 0; k < ROI_CCH; ++k) acc[k] = 0.f;
+  const int nch = min(ROI_CCH, C - c0);
+  const float* base = feat + ((int64_t)b * C + c0) * H * W;
+  if (b >= 0 && b < N) {
+    for (int iy = 0; iy < gh; ++iy) {
+      const float y = y1 + ph * bh + (iy + 0.5f) * bh / (float)gh;
+      for (int ix = 0; ix < gw; ++ix) {
+        const float x = x1 + pw * bw + (ix + 0.5f) * bw / (float)gw;
+        if (y < -1.f || y > (float)H || x < -1.f || x > (float)W) continue;
+        float yy = fmaxf(y, 0.f), xx = fmaxf(x, 0.f);
+        int yl = (int)yy, xl = (int)xx, yh, xh;
+        if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else { yh = yl + 1; }
+        if (xl >= W - 1) { xh = xl = W - 1; xx = (float)xl; } else { xh = xl + 1; }
+        const float ly = yy - yl, lx = xx - xl, hy = 1.f - ly, hx = 1.f - lx;
+        const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+        const int i1 = yl * W + xl, i2 = yl * W + xh, i3 = yh * W + xl, i4 = yh * W + xh;
+#pragma unroll
+        for (int k = 0; k < ROI_CCH; ++k) {
+          if (k < nch) {
+            const float* p = base + (int64_t)k * H * W;
+            acc[k] += w1 * p[i1] + w2 * p[i2] + w3 * p[i3] + w4 * p[i4];
+          }
+        }
+      }
+    }
   }
 #pragma unroll
   for (int k = 0; k < ROI_CCH; ++k)
@@ -285,6 +369,36 @@ extern "C" int odx_roi_align_rows_f32(const float* feat, int N, int C, int H, in
   hipLaunchKernelGGL(roi_align_fwd_kernel, grid, dim3(256), 0, as_stream(stream), feat, N, C, H, W, rois, R,
                      spatial_scale, PH, PW, sampling_ratio, out_rows, step);
   ODX_CHECK_LAUNCH("odx_roi_align_rows_f32");
+  return ODX_OK;
+}
+
+extern "C" int odx_roi_align_fpn_f32(const float* const* feats, const int* H, const int* W, const float* scales, int levels,
+                                     int N, int C, const float* rois, int R, int PH, int PW, int sampling_ratio, float* out,
+                                     int* level_out, odx_stream_t stream) {
+  if (R <= 0 || C <= 0) return ODX_OK;
+  ODX_REQUIRE(feats && H && W && scales && rois && out && N > 0, "odx_roi_align_fpn_f32: null pointer");
+  ODX_REQUIRE(levels >= 1 && levels <= ODX_MAX_FPN_LEVELS, "odx_roi_align_fpn_f32: 1..%d pyramid levels", ODX_MAX_FPN_LEVELS);
+  ODX_REQUIRE(PH > 0 && PW > 0 && PH * PW <= 256, "odx_roi_align_fpn_f32: PH * PW must be in 1..256");
+  ODX_REQUIRE(ceil_div(C, ROI_CCH) < 65536, "odx_roi_align_fpn_f32: too many channels");
+  FpnLevels L;
+  for (int k = 0; k < ODX_MAX_FPN_LEVELS; ++k) {
+    const int j = k < levels ? k : levels - 1;
+    ODX_REQUIRE(feats[j] && H[j] > 0 && W[j] > 0 && scales[j] > 0.f && (int64_t)H[j] * W[j] < (1ll << 31),
+                "odx_roi_align_fpn_f32: bad level %d", j);
+    L.feat[k] = feats[j];
+    L.H[k] = H[j];
+    L.W[k] = W[j];
+    L.scale[k] = scales[j];
+  }
+  L.levels = levels;
+  // LevelMapper: k_min = -log2(scales[0]), k_max = -log2(scales[-1]) (scales are powers of two: 1/4 .. 1/32)
+  L.k_min = (int)lrintf(-log2f(scales[0]));
+  L.k_max = (int)lrintf(-log2f(scales[levels - 1]));
+  ODX_REQUIRE(L.k_max - L.k_min == levels - 1, "odx_roi_align_fpn_f32: the level scales must halve from level to level");
+  dim3 grid((unsigned)R, (unsigned)ceil_div(C, ROI_CCH));
+  hipLaunchKernelGGL(roi_align_fpn_kernel, grid, dim3(256), 0, as_stream(stream), L, N, C, rois, R, PH, PW, sampling_ratio, out,
+                     level_out);
+  ODX_CHECK_LAUNCH("odx_roi_align_fpn_f32");
   return ODX_OK;
 }
 

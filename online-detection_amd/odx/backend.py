@@ -592,6 +592,28 @@ class HipBackend:
                                                  int(sampling_ratio), _p(out), self._stream()), "odx_roi_align_fwd_f32")
         return out
 
+    def roi_align_fpn(self, feats, rois, scales, output_size, sampling_ratio=2, return_levels=False):
+        """maskrcnn_benchmark's Pooler over an FPN pyramid with one launch: feats = list of (N, C, H_l, W_l) f32 maps,
+        scales = their 1 / strides; every RoI (R, 5) is pooled from the level LevelMapper assigns it.  -> (R, C, PH, PW)."""
+        feats = [f.to(device=self.device, dtype=torch.float32).contiguous() for f in feats]
+        rois = rois.to(device=self.device, dtype=torch.float32).contiguous()
+        L = len(feats)
+        N, C = feats[0].shape[:2]
+        if any(f.shape[0] != N or f.shape[1] != C for f in feats):
+            raise ValueError("roi_align_fpn: every level needs the same batch size and channel count")
+        PH, PW = output_size
+        R = rois.shape[0]
+        out = torch.empty((R, C, PH, PW), dtype=torch.float32, device=self.device)
+        lv = torch.empty(R, dtype=torch.int32, device=self.device) if return_levels else None
+        if R:
+            fp = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats])
+            hs = (ctypes.c_int * L)(*[int(f.shape[2]) for f in feats])
+            ws = (ctypes.c_int * L)(*[int(f.shape[3]) for f in feats])
+            sc = (ctypes.c_float * L)(*[float(v) for v in scales])
+            hip.check(self.lib.odx_roi_align_fpn_f32(fp, hs, ws, sc, L, N, C, _p(rois), R, PH, PW, int(sampling_ratio), _p(out),
+                                                     _p(lv), self._stream()), "odx_roi_align_fpn_f32")
+        return (out, lv) if return_levels else out
+
     def packed(self, X):
         """X (rows, K) f32 as a GEMM operand of gemm_h2: its packed two-term f16 split (no row norms)."""
         X = X.to(device=self.device, dtype=torch.float32)

@@ -641,8 +641,9 @@ class OnlineFeatureExtractor:
                 else:
                     with torch.no_grad():
                         c4s = m.c4(torch.cat([_unpack(smp)[0].to(dev) for smp in group], dim=0))
+                    cut = getattr(m, "trunk_slice", None)          # (a pyramid is sliced level by level: odx/fpn.py)
                     for j, smp in enumerate(group):
-                        yield forward_one(smp, c4s[j:j + 1])
+                        yield forward_one(smp, cut(c4s, j) if cut is not None else c4s[j:j + 1])
                 i += len(group)
 
         def harvest_one(item):

@@ -1,0 +1,228 @@
+"""The R-50-FPN variant of the feature forward: ResNet-50 trunk with a feature pyramid, RPN over five levels, multi-level
+RoIAlign and the two-layer MLP head — the "ResNet50-FPN + RoIAlign" forward BASELINE.json's north star and config 2 name
+(D = 1024 RoI features).
+
+In the reference this variant exists only as selectable registry entries of maskrcnn_benchmark — none of its YAMLs picks
+it, all shipped configs run R-50-C4 (odx/extract.py):
+    FPN2MLPFeatureExtractor        mrcnn_modified/modeling/roi_heads/box_head/roi_box_feature_extractors.py:55-87
+    RPNPostProcessor over levels   mrcnn_modified/modeling/rpn/inference.py:76-175 (forward_for_single_feature_map,
+                                   select_over_all_levels)
+    the knobs                      mrcnn_modified/config/defaults.py:107-111 (FPN), :130-167 (RPN incl. FPN_POST_NMS_TOP_N_*),
+                                   :214-219 (POOLER_*, MLP_HEAD_DIM = 1024)
+with the trunk / pyramid / Pooler code living in maskrcnn_benchmark itself (not vendored).  PARITY UNPINNED (as the C4
+forward): restated from the published R-50-FPN definition — lateral 1 x 1 and output 3 x 3 convolutions of 256 channels on
+C2..C5, nearest-neighbour top-down pathway, P6 by a stride-2 subsampling of P5, one RPN head shared by the levels with one
+anchor size per level (32 .. 512) x three aspect ratios, strides 4 .. 64; LevelMapper + RoIAlign 7 x 7, sampling_ratio 2,
+scales 1/4 .. 1/32; fc6 (256 * 49 -> 1024) + ReLU, fc7 (1024 -> 1024) + ReLU.
+
+What runs where: the convolutions are PyTorch-ROCm library calls (frozen batch norm folded in); the pooling is ONE
+hand-written HIP launch for all RoIs and levels (odx_roi_align_fpn_f32); the proposals' suppression is odx_nms_first_f32
+per level; fc6 / fc7 run on the split-f16 tile cores with bias + ReLU in the GEMM epilogue (odx_gemm_h2_f32: f32 accuracy
+on the f16 matrix cores).  The model offers the interface of extract.OnlineDetectionModel (c4 / proposals / roi_head_maps /
+roi_features / forward / feat_dim / online_box / update_model), so the detector harvester, the on-line box head and
+detect() take it unchanged; the on-line RPN and mask heads of the reference are defined on the C4 network only.
+"""
+import contextlib
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import backend as _backend
+from .extract import (FrozenBatchNorm2d, _FoldedBN, _nms_takes_max_keep, _stage, cell_anchors, decode_deltas, grid_anchors)
+
+
+class ResNet50Stages(_FoldedBN):
+    """ResNet-50 stem + res2..res5, returning all four stage outputs (C2..C5: 256, 512, 1024, 2048 channels at width 64)."""
+
+    def __init__(self, width=64):
+        super().__init__()
+        w = width
+        self.conv1, self.bn1 = nn.Conv2d(3, w, 7, 2, 3, bias=False), FrozenBatchNorm2d(w)
+        self.layer1 = _stage(w, w, 4 * w, 3, 1)
+        self.layer2 = _stage(4 * w, 2 * w, 8 * w, 4, 2)
+        self.layer3 = _stage(8 * w, 4 * w, 16 * w, 6, 2)
+        self.layer4 = _stage(16 * w, 8 * w, 32 * w, 3, 2)
+        self.channels = (4 * w, 8 * w, 16 * w, 32 * w)
+
+    def forward(self, x):
+        x = F.max_pool2d(F.relu(self.conv_bn("conv1", "bn1", x)), 3, 2, 1)
+        c2 = self.layer1(x)
+        c3 = self.layer2(c2)
+        c4 = self.layer3(c3)
+        return c2, c3, c4, self.layer4(c4)
+
+
+class FeaturePyramid(nn.Module):
+    """FPN on C2..C5: inner (lateral 1 x 1) and layer (output 3 x 3) blocks of `out_channels`, top-down by nearest-neighbour
+    upsampling, plus P6 = the stride-2 subsampling of P5 (LastLevelMaxPool: max_pool2d(kernel 1, stride 2))."""
+
+    def __init__(self, in_channels, out_channels=256):
+        super().__init__()
+        self.inner = nn.ModuleList([nn.Conv2d(c, out_channels, 1) for c in in_channels])
+        self.layer = nn.ModuleList([nn.Conv2d(out_channels, out_channels, 3, 1, 1) for _ in in_channels])
+        for m in list(self.inner) + list(self.layer):
+            nn.init.kaiming_uniform_(m.weight, a=1)
+            nn.init.constant_(m.bias, 0)
+        self.out_channels = out_channels
+
+    def forward(self, cs):
+        last = self.inner[-1](cs[-1])
+        outs = [self.layer[-1](last)]
+        for k in range(len(cs) - 2, -1, -1):
+            lat = self.inner[k](cs[k])
+            last = lat + F.interpolate(last, size=lat.shape[-2:], mode="nearest")
+            outs.insert(0, self.layer[k](last))
+        outs.append(F.max_pool2d(outs[-1], 1, 2, 0))
+        return tuple(outs)                                   # P2, P3, P4, P5, P6
+
+
+class OnlineDetectionModelFPN(nn.Module):
+    """trunk + pyramid -> RPN over P2..P6 -> (gt boxes prepended) -> multi-level RoIAlign on P2..P5 -> fc6 / fc7 features."""
+
+    strides = (4, 8, 16, 32, 64)
+    anchor_sizes = (32, 64, 128, 256, 512)
+
+    def __init__(self, width=64, fpn_channels=256, mlp_dim=1024, pre_nms_top_n=1000, post_nms_top_n=1000, fpn_post_nms_top_n=1000,
+                 rpn_nms=0.7, resolution=7, sampling_ratio=2, seed=0, compute_dtype=None):
+        """Defaults = maskrcnn_benchmark's R-50-FPN test-time values (PRE / POST_NMS_TOP_N_TEST 1000 per level,
+        FPN_POST_NMS_TOP_N_TEST 1000 over the levels; the reference's defaults.py:155-167 carries 6000 / 1000 / 2000)."""
+        super().__init__()
+        self.compute_dtype = compute_dtype
+        g = torch.random.get_rng_state()
+        torch.manual_seed(seed)
+        self.backbone = ResNet50Stages(width)
+        self.fpn = FeaturePyramid(self.backbone.channels, fpn_channels)
+        C = fpn_channels
+        self.rpn_conv = nn.Conv2d(C, C, 3, 1, 1)
+        self.rpn_logits = nn.Conv2d(C, 3, 1)
+        self.rpn_deltas = nn.Conv2d(C, 12, 1)
+        for l in (self.rpn_conv, self.rpn_logits, self.rpn_deltas):
+            nn.init.normal_(l.weight, std=0.01)
+            nn.init.constant_(l.bias, 0)
+        self.fc6 = nn.Linear(C * resolution * resolution, mlp_dim)
+        self.fc7 = nn.Linear(mlp_dim, mlp_dim)
+        for l in (self.fc6, self.fc7):
+            nn.init.kaiming_uniform_(l.weight, a=1)
+            nn.init.constant_(l.bias, 0)
+        torch.random.set_rng_state(g)
+        self.cells = [cell_anchors(st, sizes=(sz,)) for st, sz in zip(self.strides, self.anchor_sizes)]     # 3 anchors per level
+        self.pre_nms_top_n, self.post_nms_top_n, self.fpn_post_nms_top_n = pre_nms_top_n, post_nms_top_n, fpn_post_nms_top_n
+        self.rpn_nms, self.resolution, self.sampling_ratio = rpn_nms, resolution, sampling_ratio
+        self.pool_scales = tuple(1.0 / s for s in self.strides[:4])
+        self.mlp_dim = mlp_dim
+        self.online_rpn = None
+        self.online_box = None
+        self.online_mask = None
+        self._packed = {}
+
+    def _apply(self, fn, *a, **kw):
+        self._packed.clear()                                  # packed fc weights are derived data
+        return super()._apply(fn, *a, **kw)
+
+    @property
+    def feat_dim(self):
+        return self.mlp_dim
+
+    def _amp(self):
+        if self.compute_dtype is None:
+            return contextlib.nullcontext()
+        return torch.autocast("cuda", dtype=self.compute_dtype)
+
+    # ------------------------------------------------------------------ trunk
+    @torch.no_grad()
+    def c4(self, image):
+        """The trunk features of an image — here the pyramid (P2 .. P6), f32 (the method keeps extract's name: the harvest
+        loops call model.c4 / proposals / roi_head_maps on whatever the trunk hands out)."""
+        with self._amp():
+            return tuple(p.float() for p in self.fpn(self.backbone(image)))
+
+    pyramid = c4
+
+    @staticmethod
+    def trunk_slice(trunk, j):
+        """Image j of a batched trunk output."""
+        return tuple(p[j:j + 1] for p in trunk)
+
+    def update_model(self, models_rpn=None, models_detection=None, models_segmentation=None):
+        from . import heads
+        if models_rpn or models_segmentation:
+            raise NotImplementedError("the reference defines its on-line RPN and mask heads on the R-50-C4 network only")
+        if models_detection:
+            if self.online_box is None:
+                self.online_box = heads.OnlineBoxPredictor()
+            self.online_box.set_models(models_detection["classifiers"], models_detection.get("regressors"), models_detection["stats"])
+
+    # ------------------------------------------------------------------ proposals
+    @torch.no_grad()
+    def proposals(self, trunk, img_size):
+        """RPNPostProcessor.forward at test time over the five levels (rpn/inference.py:76-175): per level the
+        pre_nms_top_n best anchors by objectness are decoded, clipped and suppressed (NMS 0.7, at most post_nms_top_n kept —
+        odx_nms_first_f32 on the top-k's own order), then the fpn_post_nms_top_n best of all levels are kept in descending
+        score order (select_over_all_levels, the per-image branch).  Returns (boxes, scores)."""
+        be = _backend.get_backend()
+        fast = _nms_takes_max_keep(be)
+        boxes_all, scores_all = [], []
+        for lvl, p in enumerate(trunk):
+            with self._amp():
+                t = F.relu(self.rpn_conv(p))
+                logits, deltas = self.rpn_logits(t).float(), self.rpn_deltas(t).float()
+            _, A, H, W = logits.shape
+            obj = logits.permute(0, 2, 3, 1).reshape(-1).sigmoid()
+            reg = deltas.view(1, A, 4, H, W).permute(0, 3, 4, 1, 2).reshape(-1, 4)
+            k = min(self.pre_nms_top_n, obj.numel())
+            score, idx = obj.topk(k, sorted=True)
+            anchors = grid_anchors(H, W, self.strides[lvl], self.cells[lvl].to(reg.device))
+            boxes = decode_deltas(reg[idx], anchors[idx])
+            boxes[:, 0].clamp_(0, img_size[0] - 1)
+            boxes[:, 2].clamp_(0, img_size[0] - 1)
+            boxes[:, 1].clamp_(0, img_size[1] - 1)
+            boxes[:, 3].clamp_(0, img_size[1] - 1)
+            if fast:
+                keep = be.nms(boxes, score, self.rpn_nms, max_keep=self.post_nms_top_n, sorted_desc=True)
+            else:
+                keep = be.nms(boxes, score, self.rpn_nms)[:self.post_nms_top_n]
+            boxes_all.append(boxes[keep])
+            scores_all.append(score[keep])
+        boxes, scores = torch.cat(boxes_all), torch.cat(scores_all)
+        k = min(self.fpn_post_nms_top_n, scores.numel())
+        top, order = scores.topk(k, sorted=True)
+        return boxes[order], top
+
+    # ------------------------------------------------------------------ RoI features
+    def _fc(self, be, name, x, layer):
+        """relu(x W' + b) on the split-f16 tile cores (f32 accuracy), the weight packed once."""
+        w = self._packed.get(name)
+        if w is None:
+            w = self._packed[name] = be.packed(layer.weight.detach().float().contiguous())
+        return be.gemm_h2(be.packed(x), w, bias=layer.bias.detach().float(), relu=True)
+
+    @torch.no_grad()
+    def roi_features(self, trunk, boxes):
+        """(R, mlp_dim): Pooler over P2..P5 (one HIP launch for all levels) -> flatten -> fc6 -> ReLU -> fc7 -> ReLU."""
+        be = _backend.get_backend()
+        rois = torch.cat((torch.zeros((boxes.shape[0], 1), device=boxes.device), boxes), dim=1)
+        crops = be.roi_align_fpn(list(trunk[:4]), rois, self.pool_scales, (self.resolution, self.resolution), self.sampling_ratio)
+        x = crops.reshape(crops.shape[0], -1)
+        if x.shape[0] == 0:
+            return x.new_zeros((0, self.mlp_dim))
+        if x.is_cuda and self.compute_dtype is None and hasattr(be, "gemm_h2"):
+            return self._fc(be, "fc7", self._fc(be, "fc6", x, self.fc6), self.fc7)
+        with self._amp():
+            return F.relu(self.fc7(F.relu(self.fc6(x)))).float()
+
+    @torch.no_grad()
+    def roi_head_maps(self, trunk, boxes):
+        """The features as (R, D, 1, 1) maps: what extract's harvest loop and detect() average over the last two axes."""
+        return self.roi_features(trunk, boxes)[:, :, None, None]
+
+    @torch.no_grad()
+    def forward(self, image, gt_boxes=None):
+        """image (1, 3, H, W) already normalised / resized; returns (boxes (R, 4), feats (R, 1024), pyramid) with the
+        ground-truth boxes prepended to the proposals (generalized_rcnn_getProposals.py:90-96)."""
+        trunk = self.c4(image)
+        img_size = (image.shape[3], image.shape[2])
+        boxes, _ = self.proposals(trunk, img_size)
+        if gt_boxes is not None and len(gt_boxes):
+            boxes = torch.cat((gt_boxes.to(boxes.device).float(), boxes), dim=0)
+        return boxes, self.roi_features(trunk, boxes), trunk

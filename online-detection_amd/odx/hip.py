@@ -99,6 +99,7 @@ SIGNATURES = {
     "odx_split_f16_taps3x3": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
     "odx_gemm_h2_f32": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
     "odx_roi_align_rows_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _f32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "odx_roi_align_fpn_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "odx_nms_workspace_bytes": (_i64, [_i32]),
     "odx_nms_f32": (_i32, [_vp, _i32, _f32, _vp, _vp, _i64, _vp]),
     "odx_nms_first_f32": (_i32, [_vp, _i32, _f32, _i32, _vp, _vp, _i64, _vp]),

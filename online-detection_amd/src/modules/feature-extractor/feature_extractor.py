@@ -7,7 +7,11 @@ and load Detectron weights; datasets, weights and that package are outside this 
 (SURVEY §2 rows 17-19), so the image stream and (optionally) the network are handed in through
 `cfg_options`:
     cfg_options['samples']  iterable of (image (1, 3, H, W) float tensor, gt_boxes (G, 4), gt_labels list[int])
-    cfg_options['model']    an odx.extract.OnlineDetectionModel (default: R-50-C4, seeded random weights)
+    cfg_options['model']    an odx.extract.OnlineDetectionModel (default: R-50-C4, seeded random weights) or an
+                            odx.fpn.OnlineDetectionModelFPN; cfg_options['conv_body'] = 'R-50-FPN' builds the latter
+                            (MODEL.BACKBONE.CONV_BODY of the reference's YAMLs, config/defaults.py:99).  The FPN network
+                            serves the detector's features / heads; the reference defines its on-line RPN and mask heads
+                            on R-50-C4 only
     cfg_options['shard_images']  True: under a multi-process launcher each rank harvests only its images (rank::world);
                                  default False — every rank sees every image, so the drop-in trainers downstream (which
                                  are not sharded) build identical models on all ranks
@@ -66,13 +70,20 @@ class FeatureExtractor(FeatureExtractorAbstract):
     def _model(self, cfg_options):
         model = cfg_options.get('model')
         if model is None:
-            model = OnlineDetectionModel()
+            if str(cfg_options.get('conv_body', 'R-50-C4')).upper() == 'R-50-FPN':
+                from odx.fpn import OnlineDetectionModelFPN
+                model = OnlineDetectionModelFPN()
+            else:
+                model = OnlineDetectionModel()
             if torch.cuda.is_available():
                 model = model.cuda()
         model.eval()
         if self.regions_post_nms is not None:
             model.post_nms_top_n = self.regions_post_nms
         if self.falkon_rpn_models is not None:      # on-line RPN injected (evaluate_accuracy_detector.py:131-150)
+            if not hasattr(model, "rpn_activation"):
+                raise NotImplementedError("on-line RPN models need the R-50-C4 network (the reference's on-line RPN has 15 "
+                                          "anchor types on one stride-16 map)")
             model.online_rpn = OnlineRPNHead(self.falkon_rpn_models, self.regressors_rpn_models, self.stats_rpn)
         if self.falkon_detector_models is not None:
             model.online_box = OnlineBoxPredictor(self.falkon_detector_models, self.regressors_detector_models,

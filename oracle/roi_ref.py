@@ -62,6 +62,36 @@ def roi_align(feat, rois, spatial_scale, output_size, sampling_ratio=0):
     return out
 
 
+def fpn_levels(boxes, scales, canonical_scale=224.0, canonical_level=4.0, eps=1e-6):
+    """maskrcnn_benchmark.modeling.poolers.LevelMapper (reached from FPN2MLPFeatureExtractor's Pooler,
+    mrcnn_modified/modeling/roi_heads/box_head/roi_box_feature_extractors.py:61-68; PARITY UNPINNED like roi_align): the
+    pyramid level (0-based) each box is pooled from,
+        floor(4 + log2(sqrt(area) / 224 + 1e-6)) clamped to [k_min, k_max], minus k_min,
+    area with the +1 pixel convention (BoxList.area, mode xyxy), k_min / k_max = -log2 of the first / last scale.
+    Evaluated in f32 like the torch ops it restates."""
+    b = np.asarray(boxes, dtype=np.float32).reshape(-1, 4)
+    f = np.float32
+    area = (b[:, 2] - b[:, 0] + f(1)) * (b[:, 3] - b[:, 1] + f(1))
+    s = np.sqrt(area).astype(np.float32)
+    k_min = -np.log2(np.float32(scales[0]))
+    k_max = -np.log2(np.float32(scales[-1]))
+    lv = np.floor(f(canonical_level) + np.log2(s / f(canonical_scale) + f(eps)))
+    return (np.clip(lv, k_min, k_max) - k_min).astype(np.int64)
+
+
+def roi_align_fpn(feats, rois, scales, output_size, sampling_ratio=2):
+    """Pooler.forward over several levels: every RoI through roi_align on the map / scale of its level."""
+    rois = np.asarray(rois, dtype=np.float64)
+    lv = fpn_levels(rois[:, 1:5], scales)
+    C = np.asarray(feats[0]).shape[1]
+    out = np.zeros((rois.shape[0], C, output_size[0], output_size[1]))
+    for l, (f, sc) in enumerate(zip(feats, scales)):
+        idx = np.flatnonzero(lv == l)
+        if len(idx):
+            out[idx] = roi_align(f, rois[idx], sc, output_size, sampling_ratio)
+    return out
+
+
 def iou_plus1(a, b):
     w = max(min(a[2], b[2]) - max(a[0], b[0]) + 1.0, 0.0)
     h = max(min(a[3], b[3]) - max(a[1], b[1]) + 1.0, 0.0)

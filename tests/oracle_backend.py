@@ -152,6 +152,14 @@ class OracleBackend:
         from oracle import roi_ref
         return torch.from_numpy(roi_ref.roi_align(feat.numpy(), rois.numpy(), spatial_scale, output_size, sampling_ratio)).float()
 
+    def roi_align_fpn(self, feats, rois, scales, output_size, sampling_ratio=2, return_levels=False):
+        from oracle import roi_ref
+        out = torch.from_numpy(roi_ref.roi_align_fpn([f.numpy() for f in feats], rois.numpy(), list(scales), output_size,
+                                                     sampling_ratio)).float()
+        if return_levels:
+            return out, torch.from_numpy(roi_ref.fpn_levels(rois.numpy()[:, 1:5], list(scales))).int()
+        return out
+
     def paste_masks(self, masks, boxes, im_h, im_w, thresh=0.5, padding=1):
         from oracle import roi_ref
         m, b = masks.numpy(), boxes.numpy()

@@ -83,6 +83,29 @@ def forward_extra(height=600, width=800, rois=300, reps=8):
     return out
 
 
+def forward_fpn_extra(height=600, width=800, reps=8):
+    """BASELINE config 2's forward as named — ResNet50-FPN + RoIAlign -> D = 1024 RoI features (odx/fpn.py): trunk + pyramid,
+    RPN over five levels (1000 candidates per level, NMS, 1000 kept over all levels), ONE multi-level RoIAlign launch, fc6 /
+    fc7 on the split-f16 tile cores; f32 and bf16 autocast, random weights."""
+    from odx.fpn import OnlineDetectionModelFPN
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(1)
+    img = torch.randn((1, 3, height, width), device=dev, generator=g)
+    out = {"workload": "R-50-FPN trunk + pyramid + RPN over 5 levels (HIP NMS) + multi-level RoIAlign (one HIP launch) + fc6 / fc7 on "
+                       "one synthetic %dx%d image, random weights" % (height, width)}
+    for name, dt in (("f32", None), ("bf16", torch.bfloat16)):
+        model = OnlineDetectionModelFPN(compute_dtype=dt).to(dev).eval()
+        with torch.no_grad():
+            for _ in range(3):
+                boxes, feats, _ = model(img)
+            dt_s, _ = _sync_time(lambda: [model(img) for _ in range(reps)])
+        out["images_per_s_" + name] = round(reps / dt_s, 1)
+        out["ms_per_image_" + name] = round(dt_s / reps * 1e3, 2)
+        out["rois"], out["feature_dim"] = int(boxes.shape[0]), int(feats.shape[1])
+        del model
+    return out
+
+
 def detect_extra(height=600, width=800, rois=300, C=30, M=1000, reps=10):
     """One test-time image end to end (odx.extract.detect: trunk, RPN proposals, RoIAlign, conv5 head, the on-line box
     head of C FALKON classifiers + C box regressors, decode / threshold / per-class NMS / top-k): ms per image, with the
@@ -202,7 +225,24 @@ def _events_ms(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-def falkon_config_extra(name, C, n, D, M, sigma, lam, classes_run, labels="one_vs_rest", seed=1234, maxiter=20):
+def falkon_config_extra(name, C, n, D, M, sigma, lam, classes_run, labels="one_vs_rest", seed=1234, maxiter=20, gauss=None,
+                        storage=None):
+    """`gauss` / `storage`: run with the backend's contraction (h2 / f8) and K_nM storage (f32 / u24 / bf16) set to these
+    for the duration of the call — the throughput-only variants BASELINE configs 2 and 5 name."""
+    import odx
+    be = odx.get_backend()
+    old = (be.gauss, be.knm_storage)
+    try:
+        if gauss is not None:
+            be.gauss = gauss
+        if storage is not None:
+            be.knm_storage = storage
+        return _falkon_config_extra(name, C, n, D, M, sigma, lam, classes_run, labels, seed, maxiter)
+    finally:
+        be.gauss, be.knm_storage = old
+
+
+def _falkon_config_extra(name, C, n, D, M, sigma, lam, classes_run, labels="one_vs_rest", seed=1234, maxiter=20):
     """One BASELINE config's FALKON leg on this GPU: `classes_run` of its C classes fitted (Nystroem centres by the
     reference rule, class-batched preconditioner chain, K_nM build with the fused right-hand side, the CG loops of the
     classes in lock step) and every row scored with each model.  Reports the config's metric (rows / seconds for ALL C
@@ -300,12 +340,16 @@ def config_extras():
     """BASELINE configs 2, 4 and 5 (FALKON legs) at the sizes BASELINE.json states, on one GPU: config 5 as the shard one
     of its 8 GPUs holds (625 000 x 20 000), three of its 100 classes."""
     out = {}
-    for key, kw in (("config2", dict(name="BASELINE config 2 (FALKON leg)", C=30, n=100_000, D=1024, M=2000, sigma=15.0, lam=1e-5,
-                                     classes_run=30, seed=1234 + 2)),
+    c2 = dict(C=30, n=100_000, D=1024, M=2000, sigma=15.0, lam=1e-5, classes_run=30, seed=1234 + 2)
+    c5 = dict(C=100, n=625_000, D=1024, M=20_000, sigma=15.0, lam=1e-5, classes_run=3, seed=1234 + 5)
+    for key, kw in (("config2", dict(name="BASELINE config 2 (FALKON leg)", **c2)),
+                    ("config2_bf16", dict(name="BASELINE config 2 (FALKON leg) with K_nM stored as bf16 — throughput only, alpha off by 1e-2..6e-1 "
+                                               "(tools/precision_storage_study.py)", storage="bf16", **c2)),
                     ("config4", dict(name="BASELINE config 4 (O-OS mask-pixel rows, one fit per class)", C=21, n=500_000, D=256, M=2000,
                                      sigma=10.0, lam=1e-5, classes_run=21, labels="pixels", seed=1234 + 4)),
-                    ("config5_shard", dict(name="BASELINE config 5, the 625 000-row shard of one of 8 GPUs", C=100, n=625_000, D=1024,
-                                           M=20_000, sigma=15.0, lam=1e-5, classes_run=3, seed=1234 + 5))):
+                    ("config5_shard", dict(name="BASELINE config 5, the 625 000-row shard of one of 8 GPUs, at f32 accuracy", **c5)),
+                    ("config5_shard_f8", dict(name="BASELINE config 5 as stated — fp8 (e4m3) inputs to the X Z' MFMA, f32 accumulate, "
+                                                   "throughput only —, the 625 000-row shard of one of 8 GPUs", gauss="f8", **c5))):
         try:
             out[key] = falkon_config_extra(**kw)
         except Exception as e:          # noqa: BLE001
@@ -319,7 +363,7 @@ def config_extras():
 def collect(args):
     """Everything above; a failing extra is reported as its error string, never as a missing headline."""
     out = {}
-    for key, fn in (("rls", lambda: rls_extra(cpu=not args.no_cpu_baseline)), ("forward", forward_extra), ("detect", detect_extra),
+    for key, fn in (("rls", lambda: rls_extra(cpu=not args.no_cpu_baseline)), ("forward", forward_extra), ("forward_fpn", forward_fpn_extra), ("detect", detect_extra),
                     ("minibootstrap", minibootstrap_extra)):
         try:
             out[key] = fn()
