@@ -316,7 +316,12 @@ def main():
         p2_ms, p2_n = ph["ktk2"].total_ms(), ph["ktk2"].count()
         pass_ms, pass_launches = p1_ms + p2_ms, p1_n + p2_n
         bytes_per_pass = float(be.knm_bytes(n_loc, M))      # the stored shard, read exactly once per launch (n M s_K)
-        pk = ("knm_pass_kernel", "knm_pass2_kernel") if kfmt == "f32" else ("knm_passq_kernel<NV=1>", "knm_passq_kernel<NV=2>")
+        if kfmt == "f32":
+            pk = ("knm_pass_kernel", "knm_pass2_kernel")
+        elif 8192 < M <= 10240 and not os.environ.get("ODX_PASSQ_NO_STAGGER") and not os.environ.get("ODX_PASSQ_CFG"):
+            pk = ("knm_passq_stag_kernel", "knm_passq_kernel<NV=2>")      # one vector: two free-running halves per workgroup
+        else:
+            pk = ("knm_passq_kernel<NV=1>", "knm_passq_kernel<NV=2>")
         gach = flops_per_launch * gauss_launches / max(gauss_ms * 1e-3, 1e-12) / 1e12
 
         def per_kernel(ms, cnt, unit_work, scale):

@@ -78,13 +78,15 @@ __global__ __launch_bounds__(NT, WPE) void knm_passq_kernel(const unsigned short
 #pragma unroll
       for (int e = 0; e < CW; ++e) acc[q][c][e] = 0.0;
 
-  // Addressing.  ONE buffer descriptor per plane and row block (base = the block's first row, length = its rows that
-  // exist), built from scalars once per block; a load takes the lane's place inside a chunk column as its vector offset and
-  // [row inside the block] x [row stride] + [chunk column] as its scalar offset.  (A descriptor per (row, chunk column) window — the first form of this
-  // kernel — cost ~8 scalar instructions per load: ~1000 per wave and block against ~700 vector ones, and the scalar unit
-  // is shared by the CU's four SIMDs.)  Rows past n are read as the block's last existing row and their row dots are
-  // set to zero before phase 2, so they add nothing.  A lane whose chunk lies past the row's end reads the start of the
-  // next row instead of zeros: its v entries are forced to zero in phase 1 and its column sums are never stored.
+  // Addressing.  ONE buffer descriptor per plane and row block, built from scalars once per block: base = the block's
+  // first row, length = the bytes of its rows that exist.  A load takes [the lane's place inside a chunk column] as its
+  // vector offset and [row inside the block] x [row stride] + [chunk column] as its scalar offset; the hardware checks
+  // their SUM against the length (measured: with a one-row length every row but the first read as zero), so nothing is
+  // read past the block's last row.  (A descriptor per (row, chunk column) window — the first form of this kernel — cost
+  // ~8 scalar instructions per load: ~1000 per wave and block against ~700 vector ones, and the scalar unit is shared by
+  // the CU's four SIMDs.)  Rows past n are read as the block's last existing row and their row dots are set to zero
+  // before phase 2, so they add nothing.  A lane whose chunk lies past the row's end reads the start of the next row
+  // instead of zeros: its v entries are forced to zero in phase 1 and its column sums are never stored.
   QChunk<FMT, CW> kr[R][CH];
   const int rowb_hi = (int)ldk * 2, rowb_lo = (int)ldlo;
   const int voff_hi = tid * (2 * CW), voff_lo = tid * CW;      // the only per-lane part of an address: the chunk inside a
@@ -223,8 +225,171 @@ __global__ __launch_bounds__(NT, WPE) void knm_passq_kernel(const unsigned short
     }
 }
 
+// ---------------------------------------------------------------- two free-running halves (one vector, 8192 < M <= 10240)
+// ONE 512-thread workgroup per CU whose two halves (waves 0-3, waves 4-7) each stream their own row blocks over ALL
+// columns (256 threads x CH chunks), share one copy of v in LDS and never wait for each other: a half's four waves meet
+// at a counter in LDS (one ds_add per wave and row block, a short spin), not at the workgroup's barrier.  The halves
+// drift apart, so one multiplies while the other waits on memory — what two independent 256-thread workgroups per CU
+// gain (5.7 against 5.2 TB/s alone for one 512-thread workgroup that waits and computes in step) without needing the
+// CU's whole LDS for two copies of v: beside the preconditioner stream of the headline job a CU that holds one foreign
+// workgroup still takes the pass's ONE workgroup, where it would take only one of two and push the other behind the
+// whole persistent grid (5.10 TB/s in bench.py).  (The same halves kept in step by workgroup barriers, half a block
+// apart, ran at 3.3 TB/s: only one half's loads are then in flight at a time.)  Every wave of a half makes the same
+// number of trips, all eight waves are resident by construction, and the spin is bounded.  Bitwise reproducible: a
+// half's column sums depend only on its own rows, the slab holds one vector per half, the fixed-order reduce adds
+// 2 x grid of them.
+template <int CH, int R, int FMT>
+__global__ __launch_bounds__(512, 2) void knm_passq_stag_kernel(const unsigned short* __restrict__ Khi, int64_t ldk,
+                                                                const unsigned char* __restrict__ Klo, int64_t ldlo, int64_t n,
+                                                                int64_t M, const double* __restrict__ v1,
+                                                                const double* __restrict__ w, double* __restrict__ slab,
+                                                                int64_t slab_ld) {
+  constexpr int NT = 256, CW = QCW;
+  extern __shared__ __attribute__((aligned(16))) double vsq[];
+  __shared__ double red[2][2][4][R];                 // [half][ping-pong][wave of the half][row]
+  const int tid = threadIdx.x, lane = tid & 63;
+  // (wave-uniform by construction; readfirstlane tells the compiler so — otherwise every load of a half's block is wrapped
+  // in a waterfall loop over "possibly different" descriptors and the loop drains all loads at its back edge)
+  const int h = __builtin_amdgcn_readfirstlane(tid >> 8), hw = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
+  const int ht = tid & 255;
+  const int nchunk = (int)((M + CW - 1) / CW);
+  const int vcap = nchunk * CW;
+  const int64_t nblk = (n + R - 1) / R;
+  const double vscale = FMT == QF_U24 ? 5.9604644775390625e-08 : 1.0;
+  for (int i = tid; i < vcap; i += 512) vsq[i] = (v1 != nullptr && i < M) ? v1[i] * vscale : 0.0;
+  const int voff_hi = ht * (2 * CW), voff_lo = ht * CW;
+  double acc[CH][CW];
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < CW; ++e) acc[c][e] = 0.0;
+  QChunk<FMT, CW> kr[R][CH];
+  const int rowb_hi = (int)ldk * 2, rowb_lo = (int)ldlo;
+  __amdgpu_buffer_rsrc_t rs_hi, rs_lo;
+  int rows_open = R;
+  auto open_block = [&](int64_t blk) {
+    const int64_t row0 = blk * R;
+    rows_open = (int)(n - row0 < R ? n - row0 : R);
+    rs_hi = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Khi + row0 * ldk), (short)0, rows_open * rowb_hi, 0x00020000);
+    if (FMT == QF_U24)
+      rs_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(Klo + row0 * ldlo), (short)0, rows_open * rowb_lo, 0x00020000);
+  };
+  auto load_block = [&](int c) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int rr = r < rows_open ? r : rows_open - 1;
+      const u32x2q th = __builtin_amdgcn_raw_buffer_load_b64(rs_hi, voff_hi, rr * rowb_hi + c * (NT * 2 * CW), 0);
+      kr[r][c].hi[0] = th[0], kr[r][c].hi[1] = th[1];
+      if (FMT == QF_U24) kr[r][c].lo[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_lo, voff_lo, rr * rowb_lo + c * (NT * CW), 0);
+    }
+  };
+  // half h walks blocks first, first + step, ...: the same trip count for every wave of the half
+  __shared__ unsigned int arrived[2];
+  if (tid < 2) arrived[tid] = 0u;
+  const int64_t first = 2 * (int64_t)blockIdx.x + h, step = 2 * (int64_t)gridDim.x;
+  const int64_t mine = first < nblk ? (nblk - first + step - 1) / step : 0;
+  if (mine > 0) {
+    open_block(first);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) load_block(c);
+  }
+  __syncthreads();  // vsq and the counters are complete; the only workgroup-wide barrier
+  int pp = 0;
+  for (int64_t k = 0; k < mine; ++k) {
+    const int64_t blk = first + k * step;
+    double t[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) t[r] = 0.0;
+    if (v1 != nullptr) {
+      // ---- phase 1: this half's row dots over all columns, one partial per wave
+      int zofs;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(zofs));
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int ch = ht + c * NT + zofs;
+        const bool cin = ch < nchunk;
+        const int vi = (cin ? ch : nchunk - 1) * CW;
+        const f64x2q a = *reinterpret_cast<const f64x2q*>(&vsq[vi]);
+        const f64x2q b = *reinterpret_cast<const f64x2q*>(&vsq[vi + 2]);
+        const double v0 = cin ? a[0] : 0.0, v1_ = cin ? a[1] : 0.0, v2_ = cin ? b[0] : 0.0, v3 = cin ? b[1] : 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          t[r] = fma(q_entry<FMT, CW>(kr[r][c], 0), v0, t[r]);
+          t[r] = fma(q_entry<FMT, CW>(kr[r][c], 1), v1_, t[r]);
+          t[r] = fma(q_entry<FMT, CW>(kr[r][c], 2), v2_, t[r]);
+          t[r] = fma(q_entry<FMT, CW>(kr[r][c], 3), v3, t[r]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        double sum = t[r];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+        if (lane == 0) red[h][pp][hw][r] = sum;
+      }
+      // the half's four waves meet here: arrive (release: the partial sums above are in LDS first), then wait until the
+      // counter shows all four arrivals of this trip (acquire).  red[] is double-buffered: a wave can be at most one trip
+      // ahead of the slowest wave of its half, which is then still reading the other buffer.
+      // (relaxed LDS atomics between compiler barriers: a wave's LDS operations execute in order, which is all the
+      // ordering needed here; release / acquire semantics would also wait for the wave's outstanding GLOBAL loads — the
+      // next block's prefetch — at every rendezvous: 4.2 TB/s)
+      asm volatile("" ::: "memory");
+      if (lane == 0) {
+        __hip_atomic_fetch_add(&arrived[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const unsigned int want = 4u * (unsigned int)(k + 1);
+        for (int spin = 0; spin < (1 << 22); ++spin) {
+          if (__hip_atomic_load(&arrived[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < R; ++r) t[r] = ((red[h][pp][0][r] + red[h][pp][1][r]) + red[h][pp][2][r]) + red[h][pp][3][r];
+      pp ^= 1;
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          asm volatile("" : "+v"(kr[r][c].hi[0]));
+          asm volatile("" : "+v"(kr[r][c].hi[1]));
+          if (FMT == QF_U24) asm volatile("" : "+v"(kr[r][c].lo[0]));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = blk * R + r;
+      if (row >= n) t[r] = 0.0;                      // a repeated row, not a zero one, was read for it
+      else if (w != nullptr) t[r] += w[row];
+    }
+    // ---- phase 2: the column sums, and the next block's loads chunk by chunk
+    const bool more = k + 1 < mine;
+    if (more) open_block(blk + step);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int e = 0; e < CW; ++e) acc[c][e] = fma(q_entry<FMT, CW>(kr[r][c], e), t[r], acc[c][e]);
+      if (more) load_block(c);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  double* my = slab + (2 * (int64_t)blockIdx.x + h) * slab_ld;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = ht + c * NT;
+    if (ch < nchunk) {
+#pragma unroll
+      for (int e = 0; e < CW; ++e)
+        if ((int64_t)ch * CW + e < slab_ld) my[(int64_t)ch * CW + e] = acc[c][e] * vscale;
+    }
+  }
+}
+
 struct QCfg {
-  int nt, ch, r, wg_per_cu;
+  int nt, ch, r, wg_per_cu;      // nt == 0: the two-halves kernel (512 threads, ch chunks per thread of a half)
 };
 
 // One-vector configurations.  Up to 8192 columns the pass runs as TWO 256-thread workgroups per CU, each with its own
@@ -240,7 +405,7 @@ static bool pick_qcfg(int64_t M, int nv, int fmt, QCfg* cfg) {
     // experiments: ODX_PASSQ_CFG="nt ch r" forces a configuration (must cover the row and be one of those built below)
     if (const char* e = getenv("ODX_PASSQ_CFG")) {
       int nt = 0, ch = 0, r = 0;
-      if (sscanf(e, "%d %d %d", &nt, &ch, &r) == 3 && (int64_t)nt * ch >= chunks) { *cfg = {nt, ch, r, nt <= 256 ? 2 : 1}; return true; }
+      if (sscanf(e, "%d %d %d", &nt, &ch, &r) == 3 && (int64_t)(nt ? nt : 256) * ch >= chunks) { *cfg = {nt, ch, r, (nt && nt <= 256) ? 2 : 1}; return true; }
     }
     if (chunks <= 256) { *cfg = {256, 1, 16, 2}; return true; }
     if (chunks <= 512) { *cfg = {256, 2, 8, 2}; return true; }
@@ -250,6 +415,7 @@ static bool pick_qcfg(int64_t M, int nv, int fmt, QCfg* cfg) {
     // the preconditioner stream of the headline job a CU holding one small workgroup of another kernel takes only ONE of
     // the two, the displaced workgroup of the persistent grid runs after the others, and the pass loses more than it won
     // — 5.10 against 5.30 TB/s inside bench.py.  ODX_PASSQ_CFG="256 10 2" selects it.)
+    if (chunks <= 2560 && !getenv("ODX_PASSQ_NO_STAGGER")) { *cfg = {0, 10, 2, 1}; return true; }      // two free-running halves
     if (chunks <= 2560) { *cfg = {512, 5, 6, 1}; return true; }
     if (chunks <= 3072) { *cfg = {512, 6, 4, 1}; return true; }
     if (chunks <= 5120) { *cfg = {1024, 5, 1, 1}; return true; }
@@ -266,7 +432,7 @@ static bool pick_qcfg(int64_t M, int nv, int fmt, QCfg* cfg) {
 static int qgrid_for(const QCfg& cfg, int64_t n) {
   int cus = odx_device_cus();
   if (cus <= 0) cus = 256;
-  const int64_t nblk = ceil_div(n, cfg.r);
+  const int64_t nblk = cfg.nt == 0 ? ceil_div(ceil_div(n, cfg.r), 2) : ceil_div(n, cfg.r);     // staggered: two blocks per tick pair
   int64_t g = (int64_t)cus * cfg.wg_per_cu;
   if (g > nblk) g = nblk;
   if (g < 1) g = 1;
@@ -289,6 +455,13 @@ static int dispatch_passq(const QCfg& cfg, int grid, size_t lds, hipStream_t s, 
                           int64_t slab_ld) {
 #define ODX_Q(NT_, CH_, R_) return launch_passq<NT_, CH_, R_, NV, FMT>(grid, lds, s, K, ldk, Klo, ldlo, n, M, v, v2, w, slab, slab_ld)
   if constexpr (NV == 1) {
+    if (cfg.nt == 0) {
+      ODX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knm_passq_stag_kernel<10, 2, FMT>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((knm_passq_stag_kernel<10, 2, FMT>), dim3(grid), dim3(512), lds, s, static_cast<const unsigned short*>(K), ldk,
+                         static_cast<const unsigned char*>(Klo), ldlo, n, M, v, w, slab, slab_ld);
+      return ODX_OK;
+    }
     if (cfg.nt == 256 && cfg.ch == 1) ODX_Q(256, 1, 16);
     if (cfg.nt == 256 && cfg.ch == 2) ODX_Q(256, 2, 8);
     if (cfg.nt == 256 && cfg.ch == 4) ODX_Q(256, 4, 8);
@@ -330,7 +503,7 @@ extern "C" int64_t odx_knm_fwd_bwd_q_workspace_bytes(int64_t n, int64_t M, int f
   if ((fmt != ODX_KNM_U24 && fmt != ODX_KNM_BF16) || !pick_qcfg(M, 1, fmt, &cfg)) return ODX_ERR_UNSUPPORTED;
   int cus = odx_device_cus();
   if (cus <= 0) cus = 256;
-  return (int64_t)cus * cfg.wg_per_cu * round_up(M, 4) * (int64_t)sizeof(double);
+  return (int64_t)cus * (cfg.nt == 0 ? 2 : cfg.wg_per_cu) * round_up(M, 4) * (int64_t)sizeof(double);
 }
 
 extern "C" int odx_knm_fwd_bwd_q(const void* K, int64_t ldk, const void* Klo, int64_t ldlo, int fmt, int64_t n, int64_t M,
@@ -351,7 +524,8 @@ extern "C" int odx_knm_fwd_bwd_q(const void* K, int64_t ldk, const void* Klo, in
   }
   const int grid = qgrid_for(cfg, n);
   const int64_t slab_ld = round_up(M, 4);
-  if (workspace == nullptr || workspace_bytes < (int64_t)grid * slab_ld * (int64_t)sizeof(double)) {
+  const int nslab = cfg.nt == 0 ? 2 * grid : grid;       // the staggered kernel leaves one vector per half
+  if (workspace == nullptr || workspace_bytes < (int64_t)nslab * slab_ld * (int64_t)sizeof(double)) {
     set_error("odx_knm_fwd_bwd_q: workspace too small");
     return ODX_ERR_WORKSPACE;
   }
@@ -360,7 +534,7 @@ extern "C" int odx_knm_fwd_bwd_q(const void* K, int64_t ldk, const void* Klo, in
   if (fmt == ODX_KNM_U24) ODX_PROPAGATE((dispatch_passq<1, QF_U24>(cfg, grid, lds, s, K, ldk, Klo, ldlo, n, M, v, nullptr, w, slab, slab_ld)));
   else ODX_PROPAGATE((dispatch_passq<1, QF_BF16>(cfg, grid, lds, s, K, ldk, nullptr, 0, n, M, v, nullptr, w, slab, slab_ld)));
   ODX_CHECK_LAUNCH("odx_knm_fwd_bwd_q");
-  return slab_reduce_f64(slab, slab_ld, grid, M, out, s);
+  return slab_reduce_f64(slab, slab_ld, nslab, M, out, s);
 }
 
 extern "C" int64_t odx_knm_fwd_bwd2_q_workspace_bytes(int64_t n, int64_t M, int fmt) {
