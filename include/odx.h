@@ -43,6 +43,9 @@ int odx_device_cus(void);
 
 /* out[i] = sum_d X[i,d]^2 (f32 fmaf chain).  ldx % 4 == 0. */
 int odx_row_sqnorm_f32(const float* X, int64_t ldx, int64_t n, int D, float* out, odx_stream_t stream);
+/* The same norms (bit for bit) and, from the same read, max |x| of the matrix into meta[1] (its IEEE bits; meta[1] must be 0
+ * on entry) — the value odx_split_f16 scales by; odx_split_f16_premax then packs without a maximum pass of its own. */
+int odx_row_sqnorm_absmax_f32(const float* X, int64_t ldx, int64_t n, int D, float* out, float* meta, odx_stream_t stream);
 
 /* K (n x M, ldk % 4 == 0) = gauss(X (n x D), Z (M x D)); xsq/zsq from odx_row_sqnorm_f32.
  * Columns [M, ldk) of K are written as 0.  ldx % 4 == 0, ldz % 4 == 0. */
@@ -79,6 +82,7 @@ int odx_gauss_mmv_f32(const float* X, int64_t ldx, const float* xsq, int64_t n,
  * keep the same meta.                                                                              */
 int odx_split_f16(const float* X, int64_t ldx, int64_t n, int D, void* P, int64_t ldp, float* meta,
                   odx_stream_t stream);
+int odx_split_f16_premax(const float* X, int64_t ldx, int64_t n, int D, void* P, int64_t ldp, float* meta, odx_stream_t stream);
 /* odx_set_h2_tile pins the tile core (128 or 256; 0 = automatic, the default): a process-wide setting for tests and
  * measurements.  odx_gauss_h2_tile: side of the square output tile odx_gauss_knm_h2 uses for an n x M block under the
  * current setting; 0 for an empty block. */
@@ -315,6 +319,11 @@ int odx_rls_solve_f64(double* G, int64_t ldg, int D, double lam, const double* X
  * of the apply  F W[:-1] + W[-1]  of predict_regions.py:45-46.                              */
 int odx_rls_predict_rows_f64(const float* X, int64_t ldx, int D, const int64_t* idx, int64_t nc,
                              const double* W, int64_t ldw, double* P, int64_t ldp, odx_stream_t stream);
+/* The same for the rows of up to 32 classes with one launch: idx holds the row ids class after class (class c's rows start at
+ * seg_start[c], a HOST array of C ascending entries beginning with 0), W (C, 4, ldw) w_stride apart; P (total, 4). */
+int odx_rls_predict_rows_batched_f64(const float* X, int64_t ldx, int D, const int64_t* idx, const int64_t* seg_start, int C,
+                                     int64_t total, const double* W, int64_t ldw, int64_t w_stride, double* P, int64_t ldp,
+                                     odx_stream_t stream);
 
 /* The regressors of C <= 32 classes at once (the reference trains them one after the other,
  * train_region_refiner.py:27-98; they are independent): every kernel takes the class as a grid dimension.

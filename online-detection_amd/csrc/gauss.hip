@@ -32,6 +32,47 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const T* __restrict__ X
   if (lane == 0) out[row] = s;
 }
 
+// The same row norms (the same per-row fmaf chain and reduction, bit for bit) and, from the same read of the rows, the
+// matrix's largest |entry| — what the f16 split scales by (odx_split_f16 otherwise makes a pass of its own over the matrix
+// for it: a Minibootstrap round spent more time in those 180 absmax launches than in the 180 splits they serve).  maxbits
+// holds the IEEE bits of max |x| (a non-negative float orders like its bits) and must be 0 on entry; one atomic per workgroup.
+__global__ __launch_bounds__(256) void row_sqnorm_absmax_kernel(const float* __restrict__ X, int64_t ldx, int64_t n, int D,
+                                                                float* __restrict__ out, unsigned int* __restrict__ maxbits) {
+  __shared__ unsigned int wm[4];
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  unsigned int m = 0u;
+  if (row < n) {
+    const float* x = X + row * ldx;
+    float s = 0.f;
+    const int nvec = D / 4;
+    for (int c = lane; c < nvec; c += 64) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + c * 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s = fmaf(v[q], v[q], s);
+        m = max(m, __float_as_uint(v[q]) & 0x7fffffffu);
+      }
+    }
+    for (int d = nvec * 4 + lane; d < D; d += 64) {
+      s = fmaf(x[d], x[d], s);
+      m = max(m, __float_as_uint(x[d]) & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      s += __shfl_xor(s, off);
+      m = max(m, (unsigned int)__shfl_xor((int)m, off));
+    }
+    if (lane == 0) out[row] = s;
+  }
+  if (lane == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+    if (m) atomicMax(maxbits, m);
+  }
+}
+
 // ---------------------------------------------------------------- K_nM (f32)
 __global__ __launch_bounds__(GEMM_THREADS, 3) void gauss_knm_f32_kernel(
     const float* __restrict__ X, int64_t ldx, const float* __restrict__ xsq, int64_t n,
@@ -226,6 +267,17 @@ extern "C" int odx_row_sqnorm_f32(const float* X, int64_t ldx, int64_t n, int D,
   hipLaunchKernelGGL((row_sqnorm_kernel<float, f32x4>), dim3((unsigned)ceil_div(n, 4)), dim3(256), 0,
                      as_stream(stream), X, ldx, n, D, out);
   ODX_CHECK_LAUNCH("odx_row_sqnorm_f32");
+  return ODX_OK;
+}
+
+extern "C" int odx_row_sqnorm_absmax_f32(const float* X, int64_t ldx, int64_t n, int D, float* out, float* meta,
+                                         odx_stream_t stream) {
+  if (n <= 0) return ODX_OK;
+  ODX_REQUIRE(X && out && meta && D > 0, "odx_row_sqnorm_absmax_f32: null pointer or D <= 0");
+  ODX_REQUIRE(ldx % 4 == 0 && ldx >= D && aligned16(X), "odx_row_sqnorm_absmax_f32: X must be 16-byte aligned, ldx %% 4 == 0, ldx >= D");
+  hipLaunchKernelGGL(row_sqnorm_absmax_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, as_stream(stream), X, ldx, n, D, out,
+                     reinterpret_cast<unsigned int*>(meta + 1));
+  ODX_CHECK_LAUNCH("odx_row_sqnorm_absmax_f32");
   return ODX_OK;
 }
 

@@ -942,6 +942,30 @@ extern "C" int odx_split_f16(const float* X, int64_t ldx, int64_t n, int D, void
   return ODX_OK;
 }
 
+// odx_split_f16 for a matrix whose largest |entry| is already in meta[1] (odx_row_sqnorm_absmax_f32 left it there with the
+// row norms): the packing only — no memset, no pass over the matrix for the maximum.
+extern "C" int odx_split_f16_premax(const float* X, int64_t ldx, int64_t n, int D, void* P, int64_t ldp, float* meta,
+                                    odx_stream_t stream) {
+  ODX_REQUIRE(meta, "odx_split_f16_premax: meta is null");
+  hipStream_t s = as_stream(stream);
+  if (n <= 0) {
+    hipLaunchKernelGGL(split_f16_kernel, dim3(1, 1), dim3(256), 0, s, X, ldx, 0, 0, (uint32_t*)P, ldp, meta);
+    ODX_CHECK_LAUNCH("odx_split_f16_premax");
+    return ODX_OK;
+  }
+  ODX_REQUIRE(X && P && D > 0 && ldx >= D && ldx % 4 == 0 && aligned16(X), "odx_split_f16_premax: X must be 16-byte aligned with ldx %% 4 == 0 and ldx >= D");
+  ODX_REQUIRE(ldp >= round_up(D, H2_KT) && ldp % 4 == 0 && aligned16(P), "odx_split_f16_premax: P must be 16-byte aligned, ldp %% 4 == 0, ldp >= roundup(D, 64)");
+  ODX_REQUIRE(n < 65536ll * 32768, "odx_split_f16_premax: too many rows");
+  const int groups = (int)ceil_div(D, H2_KT) * 8;
+  for (int64_t r0 = 0; r0 < n; r0 += 65535) {
+    const int64_t nr = n - r0 < 65535 ? n - r0 : 65535;
+    hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)ceil_div(groups, 256), (unsigned)nr), dim3(256), 0, s, X + r0 * ldx,
+                       ldx, nr, D, (uint32_t*)P + r0 * ldp, ldp, meta);
+    ODX_CHECK_LAUNCH("odx_split_f16_premax");
+  }
+  return ODX_OK;
+}
+
 template <bool RHS, int FMT, int CORE>
 static int launch_knm_w256_t(unsigned wt, hipStream_t s, const uint32_t* PX, int64_t ldpx, const float* metax, const float* xsq,
                              int64_t n, const uint32_t* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t M,

@@ -7,6 +7,8 @@
 
 namespace odx {
 
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
 // Xt[d][r] = X[idx[c0 + r]][d] (d < D), Xt[D][r] = 1, zero for r >= cn (pad up to ldt).
 __global__ __launch_bounds__(256) void rls_gather_transpose_kernel(const float* __restrict__ X, int64_t ldx, int D,
                                                                    const int64_t* __restrict__ idx, int64_t c0,
@@ -83,6 +85,71 @@ __global__ __launch_bounds__(256) void rls_gather_transpose_all_kernel(const flo
     const int64_t d = d0 + ty + q * 8, r = r0 + tx;
     if (d <= D && r < ldt) Xt[d * ldt + r] = tile[tx][ty + q * 8];
   }
+}
+
+// O5[c][j][d] = sum over class c's padded segment of Y5[j][r] * Xt[d][r], j = 0..4 (four whitened target rows and the ones
+// row): the skinny 5 x (D + 1) products X'Y and [X 1]'1 of every class.  One wave per (class, feature row d): the row
+// segment of Xt is contiguous (16-byte loads), the five Y5 segments are re-read from L2 by the D + 1 waves of the class.
+// As a GEMM on 128 x 64 tiles this product used 5 of a tile's 128 rows and took 2.06 ms for 30 classes of 1e4 rows at
+// D = 1024 (2.5 GB of Xt at 1.2 TB/s); here it is one HBM-bound sweep.
+struct RlsSegs {
+  int64_t off[ODX_MAX_ZBATCH];
+  int64_t len[ODX_MAX_ZBATCH];
+};
+
+__global__ __launch_bounds__(256) void rls_xty_kernel(const double* __restrict__ Xt, int64_t ldt, const double* __restrict__ Y5,
+                                                      RlsSegs sg, int D1, double* __restrict__ O5, int64_t ldo) {
+  const int c = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (d >= D1) return;
+  const int64_t off = sg.off[c], len = sg.len[c];              // off % 16 == 0: 16-byte aligned f64 pairs
+  const double* x = Xt + (int64_t)d * ldt + off;
+  double s[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int64_t r = 2 * lane; r < len; r += 128) {
+    const f64x2 xv = *reinterpret_cast<const f64x2*>(x + r);     // padded entries of Xt are zero: reading one past len is harmless
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const f64x2 yv = *reinterpret_cast<const f64x2*>(Y5 + (int64_t)j * ldt + off + r);
+      s[j] = fma(xv[0], yv[0], s[j]);
+      s[j] = fma(xv[1], yv[1], s[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s[j] += __shfl_xor(s[j], o);
+  }
+  if (lane < 5) O5[((int64_t)c * 5 + lane) * ldo + d] = s[lane];
+}
+
+// P[i][k] for the rows of ALL classes with one launch: row i belongs to the class whose [start, start + len) holds it.
+__global__ __launch_bounds__(256) void rls_predict_rows_batched_kernel(const float* __restrict__ X, int64_t ldx, int D,
+                                                                       const int64_t* __restrict__ idx, RlsSegs sg, int C,
+                                                                       const double* __restrict__ W, int64_t ldw,
+                                                                       int64_t w_stride, double* __restrict__ P, int64_t ldp,
+                                                                       int64_t total) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= total) return;
+  int c = 0;
+#pragma unroll 1
+  for (int k = 1; k < C; ++k)
+    if (i >= sg.off[k]) c = k;
+  const double* Wc = W + (int64_t)c * w_stride;
+  const float* x = X + idx[i] * ldx;
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int d = lane; d < D; d += 64) {
+    const double xv = (double)x[d];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = fma(xv, Wc[k * ldw + d], s[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off);
+  }
+  if (lane < 4) P[i * ldp + lane] = s[lane] + Wc[lane * ldw + D];
 }
 
 static int64_t rls_chunk(int64_t workspace_bytes, int D) {
@@ -184,6 +251,25 @@ extern "C" int odx_rls_predict_rows_f64(const float* X, int64_t ldx, int D, cons
   return ODX_OK;
 }
 
+extern "C" int odx_rls_predict_rows_batched_f64(const float* X, int64_t ldx, int D, const int64_t* idx, const int64_t* seg_start,
+                                                int C, int64_t total, const double* W, int64_t ldw, int64_t w_stride, double* P,
+                                                int64_t ldp, odx_stream_t stream) {
+  if (total <= 0 || C <= 0) return ODX_OK;
+  ODX_REQUIRE(C <= ODX_MAX_ZBATCH, "odx_rls_predict_rows_batched_f64: at most %d classes per call", ODX_MAX_ZBATCH);
+  ODX_REQUIRE(X && idx && seg_start && W && P && D > 0 && ldw >= D + 1 && ldp >= 4 && w_stride >= 4 * ldw, "odx_rls_predict_rows_batched_f64: bad argument");
+  RlsSegs sg;
+  for (int c = 0; c < ODX_MAX_ZBATCH; ++c) sg.off[c] = sg.len[c] = 0;
+  for (int c = 0; c < C; ++c) {
+    ODX_REQUIRE(seg_start[c] >= 0 && seg_start[c] <= total && (c == 0 ? seg_start[c] == 0 : seg_start[c] >= seg_start[c - 1]),
+                "odx_rls_predict_rows_batched_f64: class starts must be ascending from 0");
+    sg.off[c] = seg_start[c];
+  }
+  hipLaunchKernelGGL(rls_predict_rows_batched_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, as_stream(stream), X, ldx, D, idx,
+                     sg, C, W, ldw, w_stride, P, ldp, total);
+  ODX_CHECK_LAUNCH("odx_rls_predict_rows_batched_f64");
+  return ODX_OK;
+}
+
 // ---------------------------------------------------------------- the regressors of a class batch
 // RegionRefinerTrainer trains its classes one after the other (train_region_refiner.py:27-98); they are independent, and
 // at the reference's sizes (D + 1 = 1025 .. 2049, a few thousand rows per class) one class fills neither the f64 matrix
@@ -246,18 +332,19 @@ extern "C" int odx_rls_gram_batched_f64(const float* X, int64_t ldx, int D, cons
   g.A = Xt; g.lda = ldt; g.B = Xt; g.ldb = ldt; g.C = G; g.ldc = ldg;
   g.m = D; g.n = D; g.k = 0; g.alpha = 1.0; g.beta = 1.0; g.flags = ODX_GEMM_LOWER_ONLY;
   g.zbatches = C; g.zstrideC = g_stride; g.zk_on = 1;
-  GemmParams<double> h;
-  h.A = Y5; h.lda = ldt; h.B = Xt; h.ldb = ldt; h.C = O5; h.ldc = ldo;
-  h.m = 5; h.n = D1; h.k = 0; h.alpha = 1.0; h.beta = 0.0;
-  h.zbatches = C; h.zstrideC = 5 * ldo; h.zk_on = 1;
+  RlsSegs sg;
+  for (int c = 0; c < ODX_MAX_ZBATCH; ++c) sg.off[c] = sg.len[c] = 0;
   for (int c = 0; c < C; ++c) {
     ODX_REQUIRE(seg_off[c] % 16 == 0 && seg_len[c] >= 0 && seg_off[c] + seg_len[c] <= npad,
                 "odx_rls_gram_batched_f64: class %d: segment must start at a multiple of 16 inside the padded index array", c);
-    g.zkoff[c] = h.zkoff[c] = seg_off[c];
-    g.zklen[c] = h.zklen[c] = seg_len[c];
+    g.zkoff[c] = seg_off[c];
+    g.zklen[c] = seg_len[c];
+    sg.off[c] = seg_off[c];
+    sg.len[c] = seg_len[c];
   }
   ODX_PROPAGATE(launch_gemm_f64(g, s));
-  ODX_PROPAGATE(launch_gemm_f64(h, s));
+  hipLaunchKernelGGL(rls_xty_kernel, dim3((unsigned)ceil_div(D1, 4), (unsigned)C), dim3(256), 0, s, Xt, ldt, Y5, sg, (int)D1, O5, ldo);
+  ODX_CHECK_LAUNCH("rls_xty");
   hipLaunchKernelGGL(rls_fold_bias_kernel, dim3((unsigned)ceil_div(D1, 256), (unsigned)C), dim3(256), 0, s, O5, ldo, (int)D1, XtY, ldxy,
                      xy_stride, G, ldg, g_stride);
   ODX_CHECK_LAUNCH("rls_fold_bias");

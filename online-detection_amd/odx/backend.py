@@ -80,6 +80,7 @@ class HipBackend:
         self.lib = hip.require_gpu()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._ws = {}
+        self._meta_pools = {}
         # "h2": X Z' of the Gaussian kernels on the f16 matrix cores via the two-term split (f32 accuracy);
         # "f32": the all-f32 MFMA chain.  Both are HIP paths of libodx; there is no other.
         self.gauss = os.environ.get("ODX_GAUSS", "h2")
@@ -144,9 +145,30 @@ class HipBackend:
             buf[:, :D] = X
             X = buf[:, :D]
         sq = torch.empty(n, dtype=torch.float32, device=self.device)
+        if n and self.gauss == "h2":
+            # the norms and, from the same read of the rows, the maximum the f16 split scales by (pack() then only packs)
+            meta = self._meta_slot()
+            hip.check(self.lib.odx_row_sqnorm_absmax_f32(_p(X), X.stride(0), n, D, _p(sq), _p(meta), self._stream()),
+                      "odx_row_sqnorm_absmax_f32")
+            F = Features(X, sq, D)
+            F.meta = meta
+            return F
         if n:
             hip.check(self.lib.odx_row_sqnorm_f32(_p(X), X.stride(0), n, D, _p(sq), self._stream()), "odx_row_sqnorm_f32")
         return Features(X, sq, D)
+
+    def _meta_slot(self):
+        """Two zeroed floats (scale, max |x| bits) for one matrix, cut from a pool that is zeroed once per 4096 matrices —
+        a fill launch per matrix otherwise (a Minibootstrap round: ~250 of them).  A slot is handed out once; the slices
+        keep their pool alive."""
+        cur = torch.cuda.current_stream(self.device)
+        key = cur.cuda_stream
+        pool = self._meta_pools.get(key)
+        if pool is None or pool[1] + 2 > pool[0].numel():
+            pool = self._meta_pools[key] = [torch.zeros(8192, dtype=torch.float32, device=self.device), 0]
+        at = pool[1]
+        pool[1] = at + 4                      # 16-byte slots
+        return pool[0][at:at + 2]
 
     def rows(self, F, idx):
         """MyCenterSelector.select: gather rows (their norms, and their packed split if it exists) by index."""
@@ -176,9 +198,13 @@ class HipBackend:
         if F.P is None:
             ldp = (F.D + 63) // 64 * 64
             F.P = torch.empty((F.n, ldp), dtype=torch.int32, device=self.device)
-            F.meta = torch.zeros(2, dtype=torch.float32, device=self.device)
-            hip.check(self.lib.odx_split_f16(_p(F.X), F.ld, F.n, F.D, _p(F.P), ldp, _p(F.meta), self._stream()),
-                      "odx_split_f16")
+            if F.meta is not None and F.n:            # features() already left max |x| in meta[1]
+                hip.check(self.lib.odx_split_f16_premax(_p(F.X), F.ld, F.n, F.D, _p(F.P), ldp, _p(F.meta), self._stream()),
+                          "odx_split_f16_premax")
+            else:
+                F.meta = torch.zeros(2, dtype=torch.float32, device=self.device)
+                hip.check(self.lib.odx_split_f16(_p(F.X), F.ld, F.n, F.D, _p(F.P), ldp, _p(F.meta), self._stream()),
+                          "odx_split_f16")
         return F
 
     # ------------------------------------------------------------------ FALKON pieces
@@ -569,6 +595,18 @@ class HipBackend:
                                                         self._stream()), "odx_rls_predict_rows_f64")
         return Pm
 
+
+    def rls_predict_rows_batched(self, F, idx_all, starts, W, out):
+        """out (total, 4) f64 = [X 1] w for the rows of len(starts) <= 32 classes with one launch: idx_all holds the row ids
+        class after class, class c's first at starts[c]; W (C, 4, ldw)."""
+        total = int(idx_all.numel())
+        C = len(starts)
+        if total == 0:
+            return out
+        st = (ctypes.c_int64 * C)(*[int(v) for v in starts])
+        hip.check(self.lib.odx_rls_predict_rows_batched_f64(_p(F.X), F.ld, F.D, _p(idx_all), st, C, total, _p(W), W.stride(1),
+                                                            W.stride(0), _p(out), 4, self._stream()), "odx_rls_predict_rows_batched_f64")
+        return out
 
     # ------------------------------------------------------------------ dense f32 product (RLS apply)
     def gemm_nt(self, Fa, Fb):

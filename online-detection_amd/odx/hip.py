@@ -32,6 +32,8 @@ SIGNATURES = {
     "odx_version": (_i32, []),
     "odx_device_cus": (_i32, []),
     "odx_row_sqnorm_f32": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp]),
+    "odx_row_sqnorm_absmax_f32": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _vp]),
+    "odx_split_f16_premax": (_i32, [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp]),
     "odx_gauss_knm_f32": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _f64, _vp, _i64, _vp]),
     "odx_gauss_mmv_f32": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _f64, _vp, _i64, _vp, _i32, _vp, _i64, _vp]),
     "odx_split_f16": (_i32, [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp]),
@@ -95,6 +97,7 @@ SIGNATURES = {
     "odx_rls_solve_batched_workspace_bytes": (_i64, [_i32, _i32]),
     "odx_rls_solve_batched_f64": (_i32, [_vp, _i64, _i64, _i32, _i32, _f64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
     "odx_rls_predict_rows_f64": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "odx_rls_predict_rows_batched_f64": (_i32, [_vp, _i64, _i32, _vp, _vp, _i32, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "odx_roi_align_fwd_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _f32, _i32, _i32, _i32, _vp, _vp]),
     "odx_split_f16_taps3x3": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
     "odx_gemm_h2_f32": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),

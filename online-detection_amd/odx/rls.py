@@ -86,6 +86,7 @@ class RegionRefinerTrainer:
         n_tot = {c: (n_loc[c] if self.shard is None else self.shard.total(n_loc[c])) for c in ids}
         models = {}
         Wall, infos, rows_of, Yw_of, whit = {}, {}, {}, {}, {}
+        solved = []
         live = [c for c in ids if n_tot[c] > 0]
         for g0 in range(0, len(live), be.MAX_CLASS_BATCH):
             group = live[g0:g0 + be.MAX_CLASS_BATCH]
@@ -166,6 +167,7 @@ class RegionRefinerTrainer:
                 if bad[k] != 0:
                     raise RuntimeError('RLS Cholesky failed for class %s (pivot %d)' % (chosen_classes[c], bad[k] - 1))
                 Wall[c] = W[k]
+            solved.append((group, W))
         # the training losses of all classes: one prediction launch per class into ONE (rows, 4) array, the elementwise
         # part once over all of it (per class it was ~15 short launches: 5 ms of a 30-ms call); every class keeps its own
         # contiguous copies, as the class-by-class loop hands them out (a saved model must not drag the whole array along)
@@ -175,8 +177,14 @@ class RegionRefinerTrainer:
             span[i] = (at, at + n_loc[i])
             at += n_loc[i]
         P_all = torch.empty((at, 4), dtype=torch.float64, device=xdev)
-        for i in live:
-            be.rls_predict_rows(F, rows_of[i].contiguous(), Wall[i], out=P_all[span[i][0]:span[i][1]])
+        if hasattr(be, "rls_predict_rows_batched"):
+            for group, W in solved:           # one launch per solved group of classes (its weights are one (C, 4, ld) block)
+                rows = torch.cat([rows_of[c] for c in group]) if len(group) > 1 else rows_of[group[0]].contiguous()
+                a0 = span[group[0]][0]
+                be.rls_predict_rows_batched(F, rows, [span[c][0] - a0 for c in group], W, P_all[a0:span[group[-1]][1]])
+        else:
+            for i in live:
+                be.rls_predict_rows(F, rows_of[i].contiguous(), Wall[i], out=P_all[span[i][0]:span[i][1]])
         losses_all = (0.5 * (P_all - torch.cat([Yw_of[i] for i in live])) ** 2).type(torch.float32) if live else None
         W32 = torch.stack([Wall[i][:, :D1] for i in live]).to(dev).type(torch.float32) if live else None
         stats32 = torch.stack([torch.cat((whit[i][0].reshape(1, 4), whit[i][1], whit[i][2])) for i in live]).to(dev).type(torch.float32) if live else None

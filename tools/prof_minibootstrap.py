@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""The class-batched Minibootstrap of tools/bench_extras.py once (after a warm-up run), for rocprofv3 --kernel-trace;
-tools/round_timeline.py then shows where one round's time goes on the GPU."""
+"""The reference-regime Minibootstrap of tools/bench_extras.py in its default mode (after a warm-up repetition), for
+`rocprofv3 --kernel-trace --stats -- python tools/prof_minibootstrap.py`; tools/trace_window.py then shows where the time
+goes on the GPU."""
 import os
 import sys
 
@@ -12,4 +13,6 @@ import odx  # noqa: E402
 from bench_extras import minibootstrap_extra  # noqa: E402
 
 odx.get_backend()
-print(minibootstrap_extra(modes=(("class_batch4", {"class_batch": 4}),)))
+mode = sys.argv[1] if len(sys.argv) > 1 else "default"
+modes = {"default": (("default", None),), "class_batch4": (("class_batch4", {"class_batch": 4}),)}[mode]
+print(minibootstrap_extra(modes=modes))
