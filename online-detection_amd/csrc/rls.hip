@@ -8,6 +8,7 @@
 namespace odx {
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4r __attribute__((ext_vector_type(4)));
 
 // Xt[d][r] = X[idx[c0 + r]][d] (d < D), Xt[D][r] = 1, zero for r >= cn (pad up to ldt).
 __global__ __launch_bounds__(256) void rls_gather_transpose_kernel(const float* __restrict__ X, int64_t ldx, int D,
@@ -139,7 +140,28 @@ __global__ __launch_bounds__(256) void rls_predict_rows_batched_kernel(const flo
   const double* Wc = W + (int64_t)c * w_stride;
   const float* x = X + idx[i] * ldx;
   double s[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int d = lane; d < D; d += 64) {
+  const int nvec = D / 4;                                     // ldx % 4 == 0 and X 16-byte aligned: whole float4s
+  for (int c0 = lane; c0 < nvec; c0 += 128) {                 // two 16-byte loads of the row in flight per lane
+    f32x4r v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int cc = c0 + 64 * u;
+      v[u] = cc < nvec ? *reinterpret_cast<const f32x4r*>(x + cc * 4) : f32x4r{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int cc = c0 + 64 * u;
+      if (cc < nvec) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double xv = (double)v[u][q];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) s[k] = fma(xv, Wc[k * ldw + cc * 4 + q], s[k]);
+        }
+      }
+    }
+  }
+  for (int d = nvec * 4 + lane; d < D; d += 64) {
     const double xv = (double)x[d];
 #pragma unroll
     for (int k = 0; k < 4; ++k) s[k] = fma(xv, Wc[k * ldw + d], s[k]);
@@ -257,6 +279,7 @@ extern "C" int odx_rls_predict_rows_batched_f64(const float* X, int64_t ldx, int
   if (total <= 0 || C <= 0) return ODX_OK;
   ODX_REQUIRE(C <= ODX_MAX_ZBATCH, "odx_rls_predict_rows_batched_f64: at most %d classes per call", ODX_MAX_ZBATCH);
   ODX_REQUIRE(X && idx && seg_start && W && P && D > 0 && ldw >= D + 1 && ldp >= 4 && w_stride >= 4 * ldw, "odx_rls_predict_rows_batched_f64: bad argument");
+  ODX_REQUIRE(ldx % 4 == 0 && aligned16(X), "odx_rls_predict_rows_batched_f64: X must be 16-byte aligned with ldx %% 4 == 0");
   RlsSegs sg;
   for (int c = 0; c < ODX_MAX_ZBATCH; ++c) sg.off[c] = sg.len[c] = 0;
   for (int c = 0; c < C; ++c) {

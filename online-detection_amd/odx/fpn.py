@@ -115,9 +115,11 @@ class OnlineDetectionModelFPN(nn.Module):
         self.online_box = None
         self.online_mask = None
         self._packed = {}
+        self._anchor_cache = {}
 
     def _apply(self, fn, *a, **kw):
-        self._packed.clear()                                  # packed fc weights are derived data
+        self._packed.clear()
+        self._anchor_cache.clear()                                  # packed fc weights are derived data
         return super()._apply(fn, *a, **kw)
 
     @property
@@ -162,32 +164,53 @@ class OnlineDetectionModelFPN(nn.Module):
         score order (select_over_all_levels, the per-image branch).  Returns (boxes, scores)."""
         be = _backend.get_backend()
         fast = _nms_takes_max_keep(be)
-        boxes_all, scores_all = [], []
+        # per level: the RPN head and the top-k (their sizes differ); the decoding / clipping of the selected candidates of
+        # all five levels is then done ONCE on their concatenation (a level's ~20 small elementwise launches otherwise: the
+        # FPN forward was launch-bound at 600 launches per image), and the suppression runs per level again
+        sel_reg, sel_anc, sel_score, counts = [], [], [], []
         for lvl, p in enumerate(trunk):
             with self._amp():
                 t = F.relu(self.rpn_conv(p))
                 logits, deltas = self.rpn_logits(t).float(), self.rpn_deltas(t).float()
             _, A, H, W = logits.shape
-            obj = logits.permute(0, 2, 3, 1).reshape(-1).sigmoid()
+            obj = logits.permute(0, 2, 3, 1).reshape(-1)
             reg = deltas.view(1, A, 4, H, W).permute(0, 3, 4, 1, 2).reshape(-1, 4)
             k = min(self.pre_nms_top_n, obj.numel())
-            score, idx = obj.topk(k, sorted=True)
-            anchors = grid_anchors(H, W, self.strides[lvl], self.cells[lvl].to(reg.device))
-            boxes = decode_deltas(reg[idx], anchors[idx])
-            boxes[:, 0].clamp_(0, img_size[0] - 1)
-            boxes[:, 2].clamp_(0, img_size[0] - 1)
-            boxes[:, 1].clamp_(0, img_size[1] - 1)
-            boxes[:, 3].clamp_(0, img_size[1] - 1)
+            score, idx = obj.topk(k, sorted=True)              # (the sigmoid is monotonic: same order on the logits)
+            sel_reg.append(reg[idx])
+            sel_anc.append(self._anchors(lvl, H, W, reg.device)[idx])
+            sel_score.append(score)
+            counts.append(k)
+        scores_cat = torch.cat(sel_score).sigmoid()
+        boxes_cat = decode_deltas(torch.cat(sel_reg), torch.cat(sel_anc))
+        boxes_cat.clamp_(min=0)
+        boxes_cat[:, 0::2].clamp_(max=img_size[0] - 1)
+        boxes_cat[:, 1::2].clamp_(max=img_size[1] - 1)
+        kept = []
+        at = 0
+        for k in counts:
+            b, sc = boxes_cat[at:at + k], scores_cat[at:at + k]
             if fast:
-                keep = be.nms(boxes, score, self.rpn_nms, max_keep=self.post_nms_top_n, sorted_desc=True)
+                keep = be.nms(b, sc, self.rpn_nms, max_keep=self.post_nms_top_n, sorted_desc=True)
             else:
-                keep = be.nms(boxes, score, self.rpn_nms)[:self.post_nms_top_n]
-            boxes_all.append(boxes[keep])
-            scores_all.append(score[keep])
-        boxes, scores = torch.cat(boxes_all), torch.cat(scores_all)
+                keep = be.nms(b, sc, self.rpn_nms)[:self.post_nms_top_n]
+            kept.append(keep + at)
+            at += k
+        kept = torch.cat(kept)
+        boxes, scores = boxes_cat[kept], scores_cat[kept]
         k = min(self.fpn_post_nms_top_n, scores.numel())
         top, order = scores.topk(k, sorted=True)
         return boxes[order], top
+
+    def _anchors(self, lvl, H, W, device):
+        """The anchors of a level's H x W grid (cached per shape: a function of the image size only)."""
+        key = (lvl, H, W, str(device))
+        a = self._anchor_cache.get(key)
+        if a is None:
+            if len(self._anchor_cache) > 64:
+                self._anchor_cache.clear()
+            a = self._anchor_cache[key] = grid_anchors(H, W, self.strides[lvl], self.cells[lvl].to(device))
+        return a
 
     # ------------------------------------------------------------------ RoI features
     def _fc(self, be, name, x, layer):

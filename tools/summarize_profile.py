@@ -82,6 +82,31 @@ def pmc_lines(d, prefix, want):
     print()
 
 
+def marker_windows(path, marker="axpby"):
+    """Per-kernel totals of the launches between consecutive PAIRS of marker kernels of a kernel-trace CSV (tools/prof_forward.py
+    brackets one steady-state image of each network with them)."""
+    rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
+    marks = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
+    out = []
+    for a, b in zip(marks[0::2], marks[1::2]):
+        win = rows[a + 1:b]
+        if not win:
+            continue
+        tot = collections.defaultdict(lambda: [0, 0])
+        busy, cur = 0, int(win[0]["Start_Timestamp"])
+        for r in win:
+            s0, e0 = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            t = tot[short(r["Kernel_Name"])[-70:]]
+            t[0] += 1
+            t[1] += e0 - s0
+            if e0 > cur:
+                busy += e0 - max(s0, cur)
+                cur = e0
+        span = int(win[-1]["End_Timestamp"]) - int(win[0]["Start_Timestamp"])
+        out.append((len(win), span / 1e6, busy / 1e6, sorted(tot.items(), key=lambda kv: -kv[1][1])))
+    return out
+
+
 d = sys.argv[1]
 print("# rocprofv3 summary (%s)\n" % os.path.basename(d.rstrip("/")))
 try:
@@ -125,6 +150,23 @@ for tag, title, want in (("forward", "feature forward: R-50-C4 and R-50-FPN, 10 
                           ("gemm_nt_kernel", "rls_", "potrf", "trsm", "trtri", "trmv")),
                          ("minibootstrap", "Minibootstrap, reference regime, default mode, two repetitions (tools/prof_minibootstrap.py)", ())):
     sp = os.path.join(d, "x_%s_kernel_stats.csv" % tag)
+    tp = os.path.join(d, "x_%s_kernel_trace.csv" % tag)
+    if tag == "forward" and os.path.exists(tp):
+        print("## %s\n" % title)
+        print("(The whole-process stats of this script are dominated by the convolution library's solver search on the first image of "
+              "each network — every applicable solver, the naive reference one included, is run once per new shape; the tables below are "
+              "ONE steady-state image of each network, cut out of the kernel trace between two marker launches.)\n")
+        for (cnt, span, busy, tot), name in zip(marker_windows(tp), ("R-50-C4 (300 RoIs, conv5 head)", "R-50-FPN (1000 RoIs, fc6 / fc7)")):
+            print("### %s: %d launches, %.2f ms first to last under the profiler, GPU busy %.2f ms\n" % (name, cnt, span, busy))
+            print("| kernel | launches | total us | avg us |")
+            print("|---|---|---|---|")
+            for k, v in tot[:16]:
+                print("| `%s` | %d | %.1f | %.1f |" % (k, v[0], v[1] / 1e3, v[1] / 1e3 / v[0]))
+            print()
+        if glob.glob(os.path.join(d, "xpmc_%s_*counter_collection.csv" % tag)):
+            print("PMC (FETCH_SIZE / WRITE_SIZE / MFMA-busy passes of the same script; medians over all launches of a kernel):\n")
+            pmc_lines(d, "xpmc_%s_" % tag, ("gemm_h2", "split_f16", "roi_align", "nms_"))
+        continue
     if os.path.exists(sp):
         stats_table(sp, rows=18, title="## %s\n" % title)
         if want and glob.glob(os.path.join(d, "xpmc_%s_*counter_collection.csv" % tag)):
