@@ -330,14 +330,15 @@ print("RCCL-OK")
     assert "RCCL-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("ranks,classes,rows,centres", [(2, 4, 80000, 4200), (3, 4, 40000, 1024)])
-def test_bench_starts_its_own_ranks_and_matches_the_oracle(ranks, classes, rows, centres):
+@pytest.mark.parametrize("ranks,classes,rows,centres,storage", [(2, 4, 80000, 4200, "u24"), (3, 4, 40000, 1024, "auto")])
+def test_bench_starts_its_own_ranks_and_matches_the_oracle(ranks, classes, rows, centres, storage):
     """`python bench.py --gpus 2` (the driver's form, no launcher around it): the parent starts the two ranks itself, the
     ranks shard the rows and run the lock-step fit with its per-iteration exchange (gloo here: both ranks share this
     box's one GPU), and the result line reports the rank count the collective saw plus the oracle check."""
     import subprocess
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ODX_KNM"] = storage          # 2 ranks: the row shards stored as 24-bit fixed point, as the headline's are (compact passes, folded two-vector pass)
     # (3 ranks, 4 classes: lock-step batches of 3 and 1 — two ranks own nothing in the second batch; class-batched
     # preconditioner groups of different sizes per rank, identical collectives on all of them)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "1",
