@@ -35,6 +35,19 @@ const char* odx_last_error_string(void);
 int odx_version(void);
 /* number of compute units of the current device (grid sizing for persistent kernels) */
 int odx_device_cus(void);
+/* CU-partitioned execution.  odx_stream_create_cu_mask: a HIP stream whose kernels run only on the compute units whose
+ * bit is set in `mask` (`words` 32-bit words, bit i = logical CU i; hipExtStreamCreateWithCUMask) — the HBM-bound CG passes
+ * of one class and the MFMA-bound K_nM build / scoring of its neighbours then run beside each other on disjoint parts of
+ * the chip (odx/job.py; the reference has no counterpart: one class after the other,
+ * OnlineRegionClassifier_incore.py:96-155).  odx_set_pass_cus: the CU count the persistent grids of the compact pass
+ * kernels are sized for (0 = the device's; set it to the size of the partition their stream is confined to).
+ * odx_debug_placement: where `blocks` one-wave workgroups launched on `stream` ran — out[3 b] = XCC id, out[3 b + 1] =
+ * HW_ID register, out[3 b + 2] = arrival order (out: 3 * blocks + 1 int32 on the device; every workgroup holds its CU
+ * for `spin` ticks of the 100 MHz clock).                                                                                */
+int odx_stream_create_cu_mask(const uint32_t* mask, int words, odx_stream_t* stream);
+int odx_stream_destroy(odx_stream_t stream);
+int odx_set_pass_cus(int cus);
+int odx_debug_placement(int32_t* out, int blocks, int spin, odx_stream_t stream);
 
 /* ---------------------------------------------------------------- A3: Gaussian kernel
  * falkon.kernels.GaussianKernel(sigma) as built at

@@ -30,3 +30,47 @@ extern "C" int odx_device_cus(void) {
   }
   return cus;
 }
+
+// ---------------------------------------------------------------- CU-partitioned streams
+// A stream whose kernels run only on the compute units of a mask (hipExtStreamCreateWithCUMask): the HBM-bound CG passes
+// and the MFMA-bound Gaussian kernels of DIFFERENT classes then run beside each other on disjoint parts of the chip
+// instead of one after the other on all of it (odx/job.py).  `words` 32-bit mask words, bit i = logical CU i of the device.
+extern "C" int odx_stream_create_cu_mask(const uint32_t* mask, int words, odx_stream_t* stream) {
+  ODX_REQUIRE(mask && words > 0 && stream, "odx_stream_create_cu_mask: bad argument");
+  hipStream_t s = nullptr;
+  ODX_CHECK_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask));
+  *stream = reinterpret_cast<odx_stream_t>(s);
+  return ODX_OK;
+}
+
+extern "C" int odx_stream_destroy(odx_stream_t stream) {
+  if (stream) ODX_CHECK_HIP(hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)));
+  return ODX_OK;
+}
+
+namespace odx {
+// where a workgroup runs: out[3 b] = XCC_ID, out[3 b + 1] = HW_ID (CU_ID bits 8..11, SH_ID bit 12, SE_ID bits 13..15),
+// out[3 b + 2] = order of arrival.  Every workgroup holds its CU for `spin` clock ticks so that a grid of as many
+// workgroups as CUs lands on all of them.
+__global__ __launch_bounds__(64) void placement_kernel(int32_t* __restrict__ out, int32_t* __restrict__ counter, int spin) {
+  if (threadIdx.x == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);        // HW_REG_XCC_ID, 4 bits
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);         // HW_REG_HW_ID
+    out[3 * blockIdx.x] = (int32_t)xcc;
+    out[3 * blockIdx.x + 1] = (int32_t)hw;
+    out[3 * blockIdx.x + 2] = atomicAdd(counter, 1);
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < spin) __builtin_amdgcn_s_sleep(8);
+  }
+}
+}  // namespace odx
+
+// diagnostic: the placement of `blocks` one-wave workgroups launched on `stream` (out: 3 * blocks + 1 int32, zeroed here)
+extern "C" int odx_debug_placement(int32_t* out, int blocks, int spin, odx_stream_t stream) {
+  ODX_REQUIRE(out && blocks > 0 && spin >= 0, "odx_debug_placement: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  ODX_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)(3 * blocks + 1) * sizeof(int32_t), s));
+  hipLaunchKernelGGL(odx::placement_kernel, dim3((unsigned)blocks), dim3(64), 0, s, out, out + 3 * blocks, spin);
+  ODX_CHECK_LAUNCH("odx_debug_placement");
+  return ODX_OK;
+}

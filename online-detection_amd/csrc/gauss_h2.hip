@@ -606,6 +606,66 @@ __device__ __forceinline__ unsigned short bf16_of(float v) {          // round t
   return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
+// One lane's share of a tile's epilogue.  The exponent is formed already scaled, e = gamma log2(e) d^2 = fma(m2g, acc, xg) + zg
+// with the row / column norms pre-multiplied (xg in LDS, zg in registers; zg = -inf for the pad columns [M, mpad), which
+// are thereby stored as exp2(-inf) = 0 without a select): two operations per entry instead of three; the store addresses
+// advance by the row pitch (the 64-bit products row * ld per store were a quarter-rate multiply chain of six instructions
+// per row); the two planes of the 24-bit format are cut out of the four words by two + three v_perm_b32 / v_or_b32.
+// `interior`: the tile lies inside the block, every store happens.
+template <bool RHS, int FMT>
+__device__ __forceinline__ void knm_tile_epilogue(const f32x4 (&acc)[8][4], const float* xg_s, const double* ws_s, int rl0,
+                                                  float m2g, const float (&zg)[4], bool interior, bool cols_in,
+                                                  int64_t rows_left, char* phi, int64_t shi, char* plo, int64_t slo,
+                                                  double (&csum)[4]) {
+#pragma unroll
+  for (int tm = 0; tm < 8; ++tm) {
+    const f32x4 xg = *reinterpret_cast<const f32x4*>(&xg_s[rl0 + tm * 16]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double wq = RHS ? ws_s[rl0 + tm * 16 + q] : 0.0;
+      f32x4 v;
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)     // gamma < 0: d^2 >= 0 <=> e <= 0
+        v[tn] = __builtin_amdgcn_exp2f(fminf(fmaf(m2g, acc[tm][tn][q], xg[q]) + zg[tn], 0.f));
+      const bool store = interior || (tm * 16 + q < rows_left && cols_in);
+      if (FMT == KF_F32) {
+        if (RHS) {
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) csum[tn] = fma((double)v[tn], wq, csum[tn]);
+        }
+        if (store) *reinterpret_cast<f32x4*>(phi) = v;      // (non-temporal stores: no difference)
+      } else if (FMT == KF_U24) {
+        uint32_t qv[4];
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+          qv[tn] = u24_of(v[tn]);
+          if (RHS) csum[tn] = fma((double)qv[tn], wq, csum[tn]);                       // scaled by 2^-24 below
+        }
+        if (store) {
+          // bytes 1, 2 of each word -> the u16 plane; byte 0 of each -> the u8 plane
+          const uint32_t h01 = __builtin_amdgcn_perm(qv[1], qv[0], 0x06050201u), h23 = __builtin_amdgcn_perm(qv[3], qv[2], 0x06050201u);
+          *reinterpret_cast<uint2*>(phi) = make_uint2(h01, h23);
+          *reinterpret_cast<uint32_t*>(plo) =
+              __builtin_amdgcn_perm(qv[1], qv[0], 0x0c0c0400u) | __builtin_amdgcn_perm(qv[3], qv[2], 0x04000c0cu);
+        }
+      } else {
+        u16x4 b;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+          b[tn] = bf16_of(v[tn]);
+          if (RHS) csum[tn] = fma((double)__uint_as_float((uint32_t)b[tn] << 16), wq, csum[tn]);
+        }
+        if (store) *reinterpret_cast<u16x4*>(phi) = b;
+      }
+      phi += shi;
+      if (FMT == KF_U24) plo += slo;
+    }
+    phi += 12 * shi;
+    if (FMT == KF_U24) plo += 12 * slo;
+    if (RHS) __builtin_amdgcn_sched_barrier(0);      // keep the row weights of later blocks out of registers until needed
+  }
+}
+
 // accumulator element (tm, tn, q) of a wave's 128 x 64 share (B rows permuted, w_mainloop<true>):
 // row 16 tm + 4 (lane >> 4) + q, column 4 (lane & 15) + tn — a lane holds four adjacent columns of every one of its rows.
 // RHS: also leave wslab[row block][j] = sum over the tile's rows i of K_ij w_i (f64), K_ij being the value the block
@@ -625,81 +685,34 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_knm_h2w256_kernel(
   const int64_t i0 = (band * GR + within % GR) * W_BM, j0 = (within / GR) * W_BN;
   if (i0 >= n) return;
 
-  __shared__ __attribute__((aligned(16))) float xs_s[W_BM];
+  __shared__ __attribute__((aligned(16))) float xg_s[W_BM];
   __shared__ double ws_s[RHS ? W_BM : 1];
   if (threadIdx.x < W_BM) {
-    xs_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] : 0.f;
+    xg_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] * gamma_log2e : 0.f;
     if (RHS) ws_s[threadIdx.x] = (i0 + threadIdx.x < n) ? w[i0 + threadIdx.x] : 0.0;   // rows past the end weigh nothing
   }
 
   f32x4 acc[8][4];
   w_zero(acc);
-  w_mainloop<true, CORE>(acc, PX, ldpx, n, PZ, ldpz, M, i0, j0, stages, lds);      // its barriers also publish xs_s
+  w_mainloop<true, CORE>(acc, PX, ldpx, n, PZ, ldpz, M, i0, j0, stages, lds);      // its barriers also publish xg_s
 
-  const float m2 = -2.f / (metax[0] * metaz[0]);
+  const float m2g = -2.f / (metax[0] * metaz[0]) * gamma_log2e;    // the scales are powers of two: m2 is exact
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   const int cb = wc * 64 + 4 * (lane & 15);                 // first of this lane's four adjacent columns inside the tile
+  const int rl0 = wr * 128 + 4 * (lane >> 4);               // first of this lane's rows inside the tile
   const int64_t mpad = FMT == KF_F32 ? ((M + 3) & ~int64_t(3)) : ((M + 7) & ~int64_t(7));
   const bool interior = i0 + W_BM <= n && j0 + W_BN <= M;
   const bool cols_in = j0 + cb < mpad;                      // groups of four: entirely inside the padded row or not at all
   double csum[4] = {0.0, 0.0, 0.0, 0.0};
-  float zs[4];
-  bool cv[4];
+  float zg[4];
 #pragma unroll
-  for (int tn = 0; tn < 4; ++tn) {
-    cv[tn] = j0 + cb + tn < M;
-    zs[tn] = cv[tn] ? zsq[j0 + cb + tn] : 0.f;
-  }
-#pragma unroll
-  for (int tm = 0; tm < 8; ++tm) {
-    const int rl = wr * 128 + tm * 16 + 4 * (lane >> 4);
-    const f32x4 xs = *reinterpret_cast<const f32x4*>(&xs_s[rl]);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const double wq = RHS ? ws_s[rl + q] : 0.0;
-      f32x4 v;
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        float d2 = fmaf(m2, acc[tm][tn][q], xs[q]) + zs[tn];
-        d2 = fmaxf(d2, 0.f);
-        v[tn] = __builtin_amdgcn_exp2f(d2 * gamma_log2e);
-        if (!interior && !cv[tn]) v[tn] = 0.f;              // pad columns [M, mpad) are stored as zero
-      }
-      const bool store = interior || (i0 + rl + q < n && cols_in);
-      const int64_t off = (i0 + rl + q) * ldk + j0 + cb;
-      if (FMT == KF_F32) {
-        if (RHS) {
-#pragma unroll
-          for (int tn = 0; tn < 4; ++tn) csum[tn] = fma((double)v[tn], wq, csum[tn]);
-        }
-        if (store) *reinterpret_cast<f32x4*>(static_cast<float*>(Kp) + off) = v;      // (non-temporal stores: no difference)
-      } else if (FMT == KF_U24) {
-        uint32_t qv[4];
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-          qv[tn] = u24_of(v[tn]);
-          if (RHS) csum[tn] = fma((double)qv[tn], wq, csum[tn]);                       // scaled by 2^-24 below
-        }
-        if (store) {
-          const u16x4 hi = {(unsigned short)(qv[0] >> 8), (unsigned short)(qv[1] >> 8), (unsigned short)(qv[2] >> 8),
-                            (unsigned short)(qv[3] >> 8)};
-          *reinterpret_cast<u16x4*>(static_cast<unsigned short*>(Kp) + off) = hi;
-          *reinterpret_cast<uint32_t*>(Klo + (i0 + rl + q) * ldlo + j0 + cb) =
-              (qv[0] & 255u) | ((qv[1] & 255u) << 8) | ((qv[2] & 255u) << 16) | (qv[3] << 24);
-        }
-      } else {
-        u16x4 b;
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-          b[tn] = bf16_of(v[tn]);
-          if (RHS) csum[tn] = fma((double)__uint_as_float((uint32_t)b[tn] << 16), wq, csum[tn]);
-        }
-        if (store) *reinterpret_cast<u16x4*>(static_cast<unsigned short*>(Kp) + off) = b;
-      }
-    }
-    if (RHS) __builtin_amdgcn_sched_barrier(0);      // keep the row weights of later blocks out of registers until needed
-  }
+  for (int tn = 0; tn < 4; ++tn) zg[tn] = j0 + cb + tn < M ? zsq[j0 + cb + tn] * gamma_log2e : -__builtin_inff();
+  const int64_t e0 = (i0 + rl0) * ldk + j0 + cb;            // this lane's first entry
+  const int esz = FMT == KF_F32 ? 4 : 2;
+  char* phi = static_cast<char*>(Kp) + e0 * esz;
+  char* plo = FMT == KF_U24 ? reinterpret_cast<char*>(Klo) + (i0 + rl0) * ldlo + j0 + cb : nullptr;
+  knm_tile_epilogue<RHS, FMT>(acc, xg_s, ws_s, rl0, m2g, zg, interior, cols_in, n - i0 - rl0, phi, ldk * esz, plo, ldlo, csum);
   if (RHS) {
     // lanes l, l + 16, l + 32, l + 48 hold the same columns: add them, then the two row halves of the tile through LDS
     double* red2 = reinterpret_cast<double*>(lds);          // the stage buffers are free: the main loop ended on a barrier
@@ -802,7 +815,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_mmv_h2w256_kernel(
     double* __restrict__ slab, int64_t slab_ld) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   __shared__ double red[4][W_BM];
-  __shared__ __attribute__((aligned(16))) float xs_s[W_BM];
+  __shared__ __attribute__((aligned(16))) float xg_s[W_BM];   // row norms times gamma log2(e): the exponent comes out scaled
   constexpr int64_t GR = 8;
   const int c = blockIdx.y;
   const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -815,9 +828,9 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_mmv_h2w256_kernel(
   if (i0 >= n || s0 >= r1) return;       // mmv_reduce_kernel only visits the groups that exist
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 2, wc = wave & 3;
-  const float m2 = -2.f / (metax[0] * metaz[0]);
+  const float m2g = -2.f / (metax[0] * metaz[0]) * gamma_log2e;    // the scales are powers of two: -2 / (sx sz) is exact
 
-  if (threadIdx.x < W_BM) xs_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] : 0.f;
+  if (threadIdx.x < W_BM) xg_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] * gamma_log2e : 0.f;
   // Lane l ends every tile with two f64 sums over the tile's 64 columns of this wave: for half h of the wave's rows,
   // row slot (l & 15) of its lane quarter (slot = 4 tm' + q, row 64 h + 16 tm' + 4 (l >> 4) + q).
   double tot[2] = {0.0, 0.0};
@@ -833,7 +846,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_mmv_h2w256_kernel(
     for (int tn = 0; tn < 4; ++tn) {
       const int64_t col = j0 + wc * 64 + tn * 16 + (lane & 15);
       const bool cv = col < s1;
-      zs[tn] = cv ? zsq[col] : 0.f;
+      zs[tn] = cv ? zsq[col] * gamma_log2e : 0.f;
       al[tn] = cv ? V[col * ldv + c] : 0.0;     // weight 0 removes the columns past the group / range
     }
 #pragma unroll
@@ -845,13 +858,12 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_mmv_h2w256_kernel(
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int tm = 4 * h + 2 * u + (j >> 2), q = j & 3;
-          const float xs = xs_s[wr * 128 + tm * 16 + 4 * (lane >> 4) + q];
+          const float xs = xg_s[wr * 128 + tm * 16 + 4 * (lane >> 4) + q];
           v[u] = 0.0;
 #pragma unroll
           for (int tn = 0; tn < 4; ++tn) {
-            float d2 = fmaf(m2, acc[tm][tn][q], xs) + zs[tn];
-            d2 = fmaxf(d2, 0.f);
-            v[u] = fma((double)__builtin_amdgcn_exp2f(d2 * gamma_log2e), al[tn], v[u]);
+            const float e = fminf(fmaf(m2g, acc[tm][tn][q], xs) + zs[tn], 0.f);     // gamma < 0: d^2 >= 0 <=> e <= 0
+            v[u] = fma((double)__builtin_amdgcn_exp2f(e), al[tn], v[u]);
           }
         }
         w8[j] = (b8 ? v[1] : v[0]) + __shfl_xor(b8 ? v[0] : v[1], 8);

@@ -429,9 +429,18 @@ static bool pick_qcfg(int64_t M, int nv, int fmt, QCfg* cfg) {
   return lds <= 163840;
 }
 
+// compute units the persistent grids of this file are sized for: the device's, or what odx_set_pass_cus() says (the size
+// of the CU partition the passes' stream is confined to, odx_stream_create_cu_mask)
+static int g_pass_cus = 0;
+
+static int pass_cus() {
+  if (g_pass_cus > 0) return g_pass_cus;
+  const int cus = odx_device_cus();
+  return cus > 0 ? cus : 256;
+}
+
 static int qgrid_for(const QCfg& cfg, int64_t n) {
-  int cus = odx_device_cus();
-  if (cus <= 0) cus = 256;
+  const int cus = pass_cus();
   const int64_t nblk = cfg.nt == 0 ? ceil_div(ceil_div(n, cfg.r), 2) : ceil_div(n, cfg.r);     // staggered: two blocks per tick pair
   int64_t g = (int64_t)cus * cfg.wg_per_cu;
   if (g > nblk) g = nblk;
@@ -486,6 +495,12 @@ static int dispatch_passq(const QCfg& cfg, int grid, size_t lds, hipStream_t s, 
 
 using namespace odx;
 
+extern "C" int odx_set_pass_cus(int cus) {
+  ODX_REQUIRE(cus >= 0 && cus <= 4096, "odx_set_pass_cus: 0 (the device's) .. 4096");
+  g_pass_cus = cus;
+  return ODX_OK;
+}
+
 static int check_q(const char* who, const void* K, int64_t ldk, const void* Klo, int64_t ldlo, int fmt, int64_t M) {
   ODX_REQUIRE(fmt == ODX_KNM_U24 || fmt == ODX_KNM_BF16, "%s: storage format must be ODX_KNM_U24 or ODX_KNM_BF16 (got %d)", who, fmt);
   // (row sub-blocks of a stored shard are valid arguments: the planes need the alignment of one chunk load only)
@@ -501,7 +516,7 @@ extern "C" int64_t odx_knm_fwd_bwd_q_workspace_bytes(int64_t n, int64_t M, int f
   QCfg cfg;
   if (n <= 0 || M <= 0) return 0;
   if ((fmt != ODX_KNM_U24 && fmt != ODX_KNM_BF16) || !pick_qcfg(M, 1, fmt, &cfg)) return ODX_ERR_UNSUPPORTED;
-  int cus = odx_device_cus();
+  int cus = odx_device_cus();       // (never less than what a partitioned launch needs)
   if (cus <= 0) cus = 256;
   return (int64_t)cus * (cfg.nt == 0 ? 2 : cfg.wg_per_cu) * round_up(M, 4) * (int64_t)sizeof(double);
 }
