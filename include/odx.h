@@ -35,7 +35,8 @@ const char* odx_last_error_string(void);
 int odx_version(void);
 /* number of compute units of the current device (grid sizing for persistent kernels) */
 int odx_device_cus(void);
-/* CU-partitioned execution.  odx_stream_create_cu_mask: a HIP stream whose kernels run only on the compute units whose
+/* CU-partitioned execution (diagnostic: tools/cu_split_probe.py measured it and the job does NOT use it).
+ * odx_stream_create_cu_mask: a HIP stream whose kernels run only on the compute units whose
  * bit is set in `mask` (`words` 32-bit words, bit i = logical CU i; hipExtStreamCreateWithCUMask) — the HBM-bound CG passes
  * of one class and the MFMA-bound K_nM build / scoring of its neighbours then run beside each other on disjoint parts of
  * the chip (odx/job.py; the reference has no counterpart: one class after the other,

@@ -31,10 +31,10 @@ SIGNATURES = {
     "odx_last_error_string": (ctypes.c_char_p, []),
     "odx_version": (_i32, []),
     "odx_device_cus": (_i32, []),
-    "odx_stream_create_cu_mask": (_i32, [_ptr, _i32, _ptr]),
-    "odx_stream_destroy": (_i32, [_ptr]),
+    "odx_stream_create_cu_mask": (_i32, [_vp, _i32, _vp]),
+    "odx_stream_destroy": (_i32, [_vp]),
     "odx_set_pass_cus": (_i32, [_i32]),
-    "odx_debug_placement": (_i32, [_ptr, _i32, _i32, _ptr]),
+    "odx_debug_placement": (_i32, [_vp, _i32, _i32, _vp]),
     "odx_row_sqnorm_f32": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp]),
     "odx_row_sqnorm_absmax_f32": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "odx_split_f16_premax": (_i32, [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp]),
