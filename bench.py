@@ -308,7 +308,8 @@ def main():
         #   roofline_hbm   the CG passes over the stored K_nM: knm_pass_kernel (one vector) and knm_pass2_kernel (two vectors
         #                  from one read; one launch per class), each also reported on its own
         #   roofline_mfma  the Gaussian contraction: K_nM build + fused scoring (one tile core, two kernels)
-        # `roofline` is the family that took more device time in THIS run's timed region.
+        # `roofline` is the family of the DOMINANT KERNEL — the single kernel (one-vector pass, two-vector pass, build, scoring)
+        # with the most device time in THIS run's timed region; it names that kernel as `dominant_kernel`.
         gauss_ms = ph["knm"].total_ms() + ph["mmv"].total_ms()
         gauss_launches = ph["knm"].count() + ph["mmv"].count()
         flops_per_launch = 2.0 * n_loc * M * D
@@ -359,7 +360,11 @@ def main():
         if (n_loc, M, D) == (1_000_000, 10_000, 1024):
             for r in (roof_g, roof_p):
                 r["traffic"], r["traffic_unit"] = profiled_traffic_gb(r["kernel"])
-        roof = roof_g if gauss_ms >= pass_ms else roof_p          # the family with more device time in this run
+        kernel_ms = {pk[0]: p1_ms, pk[1]: p2_ms, gk[0]: ph["knm"].total_ms(), gk[1]: ph["mmv"].total_ms()}
+        dominant = max(kernel_ms, key=kernel_ms.get)
+        roof = dict(roof_p if dominant in pk else roof_g)         # the family the dominant kernel belongs to
+        roof["dominant_kernel"] = dominant
+        roof["dominant_kernel_ms_per_step"] = round(kernel_ms[dominant] / args.steps, 2)
         phases = {k: round(v.total_ms() / args.steps, 2) for k, v in ph.items()}
         # the preconditioners run on side streams beside everything else: this is first-to-last-kernel time, not GPU time
         phases["precond_side_stream_span"] = phases.pop("precond")
