@@ -135,7 +135,9 @@ __device__ __forceinline__ void knm_pass_body(const float* __restrict__ K, int64
       }
     }
     // phase 2: column sums, and the next block's loads re-issued chunk by chunk
-    const int64_t nxt = blk + nwg;
+    // (the loads are issued unconditionally — behind the last block they re-read it and nobody waits for them: a branch
+    // around them makes every register of the block a loop-carried select, two register copies per register and trip)
+    const int64_t nxt = blk + nwg < nblk ? blk + nwg : blk;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
 #pragma unroll
@@ -144,7 +146,7 @@ __device__ __forceinline__ void knm_pass_body(const float* __restrict__ K, int64
         for (int r = 0; r < R; ++r)
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[q][c][e] = fma((double)kr[r][c][e], t[q][r], acc[q][c][e]);
-      if (nxt < nblk) load_block(nxt, c);
+      load_block(nxt, c);
     }
   }
   double* my = slab + wg * slab_ld * NV;
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(NT) void knm_pass2_kernel(const float* __restrict__
 #pragma unroll
       for (int r = 0; r < R; ++r) asm volatile("" : "+v"(kr[r][c]));
     // phase 2: column sums, and the next block's loads re-issued chunk by chunk
-    const int64_t nxt = blk + gridDim.x;
+    const int64_t nxt = blk + gridDim.x < nblk ? blk + gridDim.x : blk;      // (unconditional loads, as in knm_pass_kernel)
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
 #pragma unroll
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(NT) void knm_pass2_kernel(const float* __restrict__
         for (int r = 0; r < R; ++r)
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[q][c][e] = fma((double)kr[r][c][e], t[q][r], acc[q][c][e]);
-      if (nxt < nblk) load_block(nxt, c);
+      load_block(nxt, c);
     }
   }
   double* my = slab + (int64_t)blockIdx.x * slab_ld * 2;

@@ -207,7 +207,9 @@ __global__ __launch_bounds__(NT, WPE) void knm_passq_kernel(const unsigned short
 #pragma unroll
           for (int q = 0; q < NV; ++q) acc[q][c][e] = fma(kd, t[q][r], acc[q][c][e]);
         }
-      if (nxt < nblk) load_block(c);
+      // (unconditional — behind the last block the loads re-read it and nobody waits for them: a branch around the loads
+      // turns every register of the block into a loop-carried select, ~2 register copies per register and trip)
+      load_block(c);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -253,7 +255,9 @@ __global__ __launch_bounds__(512, 2) void knm_passq_stag_kernel(const unsigned s
   const int h = __builtin_amdgcn_readfirstlane(tid >> 8), hw = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
   const int ht = tid & 255;
   const int nchunk = (int)((M + CW - 1) / CW);
-  const int vcap = nchunk * CW;
+  // v in LDS is zero-filled up to the CH * NT chunks the threads walk: a chunk past the row's end multiplies whatever the
+  // load returned (finite integers of the next row, or the range check's zeros) by 0 — no select, no index clamp per chunk
+  constexpr int vcap = CH * NT * CW;
   const int64_t nblk = (n + R - 1) / R;
   const double vscale = FMT == QF_U24 ? 5.9604644775390625e-08 : 1.0;
   for (int i = tid; i < vcap; i += 512) vsq[i] = (v1 != nullptr && i < M) ? v1[i] * vscale : 0.0;
@@ -306,12 +310,10 @@ __global__ __launch_bounds__(512, 2) void knm_passq_stag_kernel(const unsigned s
       asm volatile("v_mov_b32 %0, 0" : "=v"(zofs));
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
-        const int ch = ht + c * NT + zofs;
-        const bool cin = ch < nchunk;
-        const int vi = (cin ? ch : nchunk - 1) * CW;
+        const int vi = (ht + c * NT + zofs) * CW;
         const f64x2q a = *reinterpret_cast<const f64x2q*>(&vsq[vi]);
         const f64x2q b = *reinterpret_cast<const f64x2q*>(&vsq[vi + 2]);
-        const double v0 = cin ? a[0] : 0.0, v1_ = cin ? a[1] : 0.0, v2_ = cin ? b[0] : 0.0, v3 = cin ? b[1] : 0.0;
+        const double v0 = a[0], v1_ = a[1], v2_ = b[0], v3 = b[1];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           t[r] = fma(q_entry<FMT, CW>(kr[r][c], 0), v0, t[r]);
@@ -372,7 +374,9 @@ __global__ __launch_bounds__(512, 2) void knm_passq_stag_kernel(const unsigned s
       for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int e = 0; e < CW; ++e) acc[c][e] = fma(q_entry<FMT, CW>(kr[r][c], e), t[r], acc[c][e]);
-      if (more) load_block(c);
+      // (unconditional: a branch around the loads makes every register of the block a loop-carried select — 120 register
+      // copies per trip; after the last block the loads re-read it and nobody waits for them)
+      load_block(c);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -545,7 +549,8 @@ extern "C" int odx_knm_fwd_bwd_q(const void* K, int64_t ldk, const void* Klo, in
     return ODX_ERR_WORKSPACE;
   }
   double* slab = static_cast<double*>(workspace);
-  const size_t lds = (size_t)slab_ld * sizeof(double);
+  // (the halves kernel keeps v zero-filled up to the 10 x 256 chunks of four its threads walk)
+  const size_t lds = (cfg.nt == 0 ? (size_t)(10 * 256 * 4) : (size_t)slab_ld) * sizeof(double);
   if (fmt == ODX_KNM_U24) ODX_PROPAGATE((dispatch_passq<1, QF_U24>(cfg, grid, lds, s, K, ldk, Klo, ldlo, n, M, v, nullptr, w, slab, slab_ld)));
   else ODX_PROPAGATE((dispatch_passq<1, QF_BF16>(cfg, grid, lds, s, K, ldk, nullptr, 0, n, M, v, nullptr, w, slab, slab_ld)));
   ODX_CHECK_LAUNCH("odx_knm_fwd_bwd_q");
