@@ -157,7 +157,7 @@ int odx_knm_fwd_bwd2(const float* K, int64_t ldk, int64_t n, int64_t M, const do
  * Pad columns [M, ld) are written as zero.  odx_gauss_knm_h2_store builds a block in any of the three on the 256 x 256
  * tile core (16-byte stores per lane) and, when w is given, leaves ktw = K' w over the values it STORED (the fused
  * right-hand side; workspace as odx_gauss_knm_h2_rhs_workspace_bytes).  odx_knm_fwd_bwd_q / odx_knm_fwd_bwd2_q are
- * odx_knm_fwd_bwd / odx_knm_fwd_bwd2 on the two compact formats (M <= 20480; two vectors: 4096 < M <= ~10 000). */
+ * odx_knm_fwd_bwd / odx_knm_fwd_bwd2 on the two compact formats (M <= 20440; two vectors: 4096 < M <= ~10 000). */
 #define ODX_KNM_F32 0
 #define ODX_KNM_U24 1
 #define ODX_KNM_BF16 2

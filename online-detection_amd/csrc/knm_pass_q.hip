@@ -63,7 +63,7 @@ __global__ __launch_bounds__(NT, WPE) void knm_passq_kernel(const unsigned short
   __shared__ double red[2][NW][NV * R];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nchunk = (int)((M + CW - 1) / CW);
-  const int vcap = nchunk * CW;
+  const int vcap = (nchunk + 1) * CW;      // one chunk of zeros behind the row: where the chunks past the row's end point
   const int64_t nblk = (n + R - 1) / R;
   const double vscale = FMT == QF_U24 ? 5.9604644775390625e-08 : 1.0;      // 2^-24 (exact)
   for (int i = tid; i < vcap; i += NT) {
@@ -133,15 +133,16 @@ __global__ __launch_bounds__(NT, WPE) void knm_passq_kernel(const unsigned short
       for (int c = 0; c < CH; ++c) {
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
+          // a chunk past the row's end holds the next row's entries, not zeros: it is multiplied by the zero chunk behind v
+          // (one v_min per chunk; a select per loaded double of v cost 8 v_cndmask per chunk and vector)
           const int ch = tid + c * NT + zofs;
-          const bool cin = ch < nchunk;
-          const int vi = (cin ? ch : nchunk - 1) * CW;
+          const int vi = (ch < nchunk ? ch : nchunk) * CW;
           double vv[CW];
 #pragma unroll
           for (int u = 0; u < CW / 2; ++u) {
             const f64x2q a = *reinterpret_cast<const f64x2q*>(&vsq[q * vcap + vi + 2 * u]);
-            vv[2 * u] = cin ? a[0] : 0.0;          // a chunk past the row's end holds the next row's entries, not zeros
-            vv[2 * u + 1] = cin ? a[1] : 0.0;
+            vv[2 * u] = a[0];
+            vv[2 * u + 1] = a[1];
           }
 #pragma unroll
           for (int r = 0; r < R; ++r)
@@ -422,14 +423,14 @@ static bool pick_qcfg(int64_t M, int nv, int fmt, QCfg* cfg) {
     if (chunks <= 2560 && !getenv("ODX_PASSQ_NO_STAGGER")) { *cfg = {0, 10, 2, 1}; return true; }      // two free-running halves
     if (chunks <= 2560) { *cfg = {512, 5, 6, 1}; return true; }
     if (chunks <= 3072) { *cfg = {512, 6, 4, 1}; return true; }
-    if (chunks <= 5120) { *cfg = {1024, 5, 1, 1}; return true; }
+    if (chunks <= 5110) { *cfg = {1024, 5, 1, 1}; return true; }      // v + its zero chunk + the reduction scratch in 160 KB of LDS
     return false;
   }
   // two vectors: both in LDS (2 x roundup(M, 4) x 8 B beside the reduction scratch), a second set of column sums in registers
   if (chunks <= 1024 || chunks > 2560) return false;
   if (chunks <= 2048) *cfg = {512, 4, 2, 1};
   else *cfg = {512, 5, 2, 1};
-  const int64_t lds = 2 * chunks * 4 * 8 + 2 * (cfg->nt / 64) * cfg->r * 2 * 8 + 64;
+  const int64_t lds = 2 * (chunks + 1) * 4 * 8 + 2 * (cfg->nt / 64) * cfg->r * 2 * 8 + 64;
   return lds <= 163840;
 }
 
@@ -538,7 +539,7 @@ extern "C" int odx_knm_fwd_bwd_q(const void* K, int64_t ldk, const void* Klo, in
   ODX_PROPAGATE(check_q("odx_knm_fwd_bwd_q", K, ldk, Klo, ldlo, fmt, M));
   QCfg cfg;
   if (!pick_qcfg(M, 1, fmt, &cfg)) {
-    set_error("odx_knm_fwd_bwd_q: M = %lld exceeds the 20480 columns the compact-format pass kernels are built for", (long long)M);
+    set_error("odx_knm_fwd_bwd_q: M = %lld exceeds the 20440 columns the compact-format pass kernels are built for", (long long)M);
     return ODX_ERR_UNSUPPORTED;
   }
   const int grid = qgrid_for(cfg, n);
@@ -550,7 +551,7 @@ extern "C" int odx_knm_fwd_bwd_q(const void* K, int64_t ldk, const void* Klo, in
   }
   double* slab = static_cast<double*>(workspace);
   // (the halves kernel keeps v zero-filled up to the 10 x 256 chunks of four its threads walk)
-  const size_t lds = (cfg.nt == 0 ? (size_t)(10 * 256 * 4) : (size_t)slab_ld) * sizeof(double);
+  const size_t lds = (cfg.nt == 0 ? (size_t)(10 * 256 * 4) : (size_t)(slab_ld + 4)) * sizeof(double);      // + the zero chunk
   if (fmt == ODX_KNM_U24) ODX_PROPAGATE((dispatch_passq<1, QF_U24>(cfg, grid, lds, s, K, ldk, Klo, ldlo, n, M, v, nullptr, w, slab, slab_ld)));
   else ODX_PROPAGATE((dispatch_passq<1, QF_BF16>(cfg, grid, lds, s, K, ldk, nullptr, 0, n, M, v, nullptr, w, slab, slab_ld)));
   ODX_CHECK_LAUNCH("odx_knm_fwd_bwd_q");
@@ -590,7 +591,7 @@ extern "C" int odx_knm_fwd_bwd2_q(const void* K, int64_t ldk, const void* Klo, i
     return ODX_ERR_WORKSPACE;
   }
   double* slab = static_cast<double*>(workspace);
-  const size_t lds = (size_t)(2 * slab_ld * sizeof(double));
+  const size_t lds = (size_t)(2 * (slab_ld + 4) * sizeof(double));      // two vectors, each with its zero chunk
   if (fmt == ODX_KNM_U24) ODX_PROPAGATE((dispatch_passq<2, QF_U24>(cfg, grid, lds, s, K, ldk, Klo, ldlo, n, M, v, v2, nullptr, slab, slab_ld)));
   else ODX_PROPAGATE((dispatch_passq<2, QF_BF16>(cfg, grid, lds, s, K, ldk, nullptr, 0, n, M, v, v2, nullptr, slab, slab_ld)));
   ODX_CHECK_LAUNCH("odx_knm_fwd_bwd2_q");
