@@ -264,38 +264,38 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gauss_knm_h2s16_kernel(
   const int64_t i0 = (band * GR + within % GR) * GEMM_BM, j0 = (within / GR) * GEMM_BN;
   if (i0 >= n) return;
 
-  __shared__ __attribute__((aligned(16))) float xs_s[GEMM_BM];
-  if (threadIdx.x < GEMM_BM) xs_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] : 0.f;
+  // (epilogue as in gauss_knm_h2w256_kernel: exponent formed already scaled from norms pre-multiplied by gamma log2(e), pad
+  // columns through exp2(-inf) = 0, store addresses advanced by the row pitch instead of a 64-bit product per store)
+  __shared__ __attribute__((aligned(16))) float xg_s[GEMM_BM];
+  if (threadIdx.x < GEMM_BM) xg_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] * gamma_log2e : 0.f;
 
   f32x4 acc[4][4];
   s16_zero(acc);
   s16_mainloop(acc, PX, ldpx, n, PZ, ldpz, M, i0, j0, ktiles, lds);
 
-  const float m2 = -2.f / (metax[0] * metaz[0]);
+  const float m2g = -2.f / (metax[0] * metaz[0]) * gamma_log2e;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const bool interior = i0 + GEMM_BM <= n && j0 + GEMM_BN <= M;
   const int64_t mpad = (M + 3) & ~int64_t(3);
-  float* tile = K + i0 * ldk + j0;
+  const int rl0 = wr * 64 + 4 * (lane >> 4);                // first of this lane's rows inside the tile
+  const int64_t rows_left = n - i0 - rl0;
 #pragma unroll
   for (int tn = 0; tn < 4; ++tn) {
     const int cl = wc * 64 + tn * 16 + (lane & 15);
-    const float zs = (j0 + cl < M) ? zsq[j0 + cl] : 0.f;
+    const float zg = (j0 + cl < M) ? zsq[j0 + cl] * gamma_log2e : -__builtin_inff();
+    const bool col_in = j0 + cl < mpad;
+    float* pr = K + (i0 + rl0) * ldk + j0 + cl;
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) {
-      const int rl = wr * 64 + tm * 16 + 4 * (lane >> 4);
-      const f32x4 xs = *reinterpret_cast<const f32x4*>(&xs_s[rl]);
+      const f32x4 xg = *reinterpret_cast<const f32x4*>(&xg_s[rl0 + tm * 16]);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float d2 = fmaf(m2, acc[tm][tn][q], xs[q]) + zs;
-        d2 = fmaxf(d2, 0.f);
-        const float v = __builtin_amdgcn_exp2f(d2 * gamma_log2e);
-        if (interior) {
-          tile[(uint32_t)(rl + q) * (uint32_t)ldk + (uint32_t)cl] = v;
-        } else if (i0 + rl + q < n && j0 + cl < mpad) {
-          tile[(int64_t)(rl + q) * ldk + cl] = (j0 + cl < M) ? v : 0.f;
-        }
+        const float v = __builtin_amdgcn_exp2f(fminf(fmaf(m2g, acc[tm][tn][q], xg[q]) + zg, 0.f));     // gamma < 0: d^2 >= 0 <=> e <= 0
+        if (interior || (tm * 16 + q < rows_left && col_in)) *pr = v;
+        pr += ldk;
       }
+      pr += 12 * ldk;
     }
   }
 }
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gauss_mmv_h2s16_kernel(
     double* __restrict__ slab, int64_t slab_ld) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   __shared__ double red[2][2][64];
-  __shared__ __attribute__((aligned(16))) float xs_s[GEMM_BM];
+  __shared__ __attribute__((aligned(16))) float xg_s[GEMM_BM];      // row norms times gamma log2(e)
   constexpr int64_t GR = 8;
   const int c = blockIdx.y;
   const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -326,9 +326,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gauss_mmv_h2s16_kernel(
   if (i0 >= n || s0 >= r1) return;       // mmv_reduce_kernel only visits the groups that exist
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const float m2 = -2.f / (metax[0] * metaz[0]);
+  const float m2g = -2.f / (metax[0] * metaz[0]) * gamma_log2e;
 
-  if (threadIdx.x < GEMM_BM) xs_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] : 0.f;
+  if (threadIdx.x < GEMM_BM) xg_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] * gamma_log2e : 0.f;
   // Lane l ends every tile with the f64 sum over the tile's 64 columns of this wave of row slot (l & 15) of its lane
   // quarter (slot = 4 tm + q, row 16 tm + 4 (l >> 4) + q): a reduce-scatter butterfly over the 16 lanes of the quarter.
   double tot = 0.0;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gauss_mmv_h2s16_kernel(
     for (int tn = 0; tn < 4; ++tn) {
       const int64_t col = j0 + wc * 64 + tn * 16 + (lane & 15);
       const bool cv = col < s1;
-      zs[tn] = cv ? zsq[col] : 0.f;
+      zs[tn] = cv ? zsq[col] * gamma_log2e : 0.f;
       al[tn] = cv ? V[col * ldv + c] : 0.0;     // weight 0 removes the columns past the group / range
     }
     double w8[8];
@@ -354,13 +354,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gauss_mmv_h2s16_kernel(
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int tm = 2 * u + (j >> 2), q = j & 3;
-        const float xs = xs_s[wr * 64 + tm * 16 + 4 * (lane >> 4) + q];
+        const float xs = xg_s[wr * 64 + tm * 16 + 4 * (lane >> 4) + q];
         v[u] = 0.0;
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) {
-          float d2 = fmaf(m2, acc[tm][tn][q], xs) + zs[tn];
-          d2 = fmaxf(d2, 0.f);
-          v[u] = fma((double)__builtin_amdgcn_exp2f(d2 * gamma_log2e), al[tn], v[u]);
+          const float e = fminf(fmaf(m2g, acc[tm][tn][q], xs) + zs[tn], 0.f);     // gamma < 0: d^2 >= 0 <=> e <= 0
+          v[u] = fma((double)__builtin_amdgcn_exp2f(e), al[tn], v[u]);
         }
       }
       w8[j] = (b8 ? v[1] : v[0]) + __shfl_xor(b8 ? v[0] : v[1], 8);
@@ -734,10 +733,9 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_knm_h2w256_kernel(
 // product at f32 accuracy on the f16 matrix cores, 3 MFMAs per product — ~3 x the rate of the f32 MFMA path for the
 // GEMM-shaped layers of the feature forward (the conv5 head as row GEMMs).  Same tile order and main loops as the
 // Gaussian builds; the epilogue scales by 1 / (s_A s_B) (powers of two: exact) and adds bias / residual, optional ReLU.
-__device__ __forceinline__ float gemm_h2_finish(float acc, float inv, float b, const float* __restrict__ res, int64_t ldr,
-                                                int64_t row, int64_t col, int relu) {
+__device__ __forceinline__ float gemm_h2_finish(float acc, float inv, float b, const float* __restrict__ res_entry, int relu) {
   float v = fmaf(acc, inv, b);
-  if (res != nullptr) v += res[row * ldr + col];
+  if (res_entry != nullptr) v += *res_entry;
   return relu ? fmaxf(v, 0.f) : v;
 }
 
@@ -763,12 +761,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_h2s16_kernel(
     const int64_t col = j0 + wc * 64 + tn * 16 + (lane & 15);
     if (col >= n) continue;
     const float b = bias != nullptr ? bias[col] : 0.f;
+    // running addresses: a 64-bit row * ld product per store is a quarter-rate multiply chain
+    const int64_t rb = i0 + wr * 64 + 4 * (lane >> 4);
+    float* po = out + rb * ldo + col;
+    const float* pr = res != nullptr ? res + rb * ldr + col : nullptr;
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) {
-      const int64_t r0 = i0 + wr * 64 + tm * 16 + 4 * (lane >> 4);
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (r0 + q < m) out[(r0 + q) * ldo + col] = gemm_h2_finish(acc[tm][tn][q], inv, b, res, ldr, r0 + q, col, relu);
+      for (int q = 0; q < 4; ++q) {
+        if (rb + tm * 16 + q < m) *po = gemm_h2_finish(acc[tm][tn][q], inv, b, pr, relu);
+        po += ldo;
+        if (pr != nullptr) pr += ldr;
+      }
+      po += 12 * ldo;
+      if (pr != nullptr) pr += 12 * ldr;
     }
   }
 }
@@ -786,22 +792,48 @@ __global__ __launch_bounds__(W_THREADS, 1) void gemm_h2w256_kernel(
   if (i0 >= m) return;
   f32x4 acc[8][4];
   w_zero(acc);
-  w_mainloop(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds);
+  // B rows in the permuted order of the K_nM builds: a lane holds four ADJACENT output columns 64 wc + 4 (lane & 15) + tn
+  // of each of its rows, and stores them (loads bias / residual) 16 bytes at a time when the matrices allow it
+  w_mainloop<true>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds);
   const float inv = 1.f / (metaa[0] * metab[0]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 2, wc = wave & 3;
+  const int64_t col = j0 + wc * 64 + 4 * (lane & 15);
+  const int64_t rb = i0 + wr * 128 + 4 * (lane >> 4);
+  if (col >= n) return;
+  const bool vec = col + 4 <= n && ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0 &&
+                   (res == nullptr || (ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(res) & 15u) == 0));
+  float b[4];
 #pragma unroll
-  for (int tn = 0; tn < 4; ++tn) {
-    const int64_t col = j0 + wc * 64 + tn * 16 + (lane & 15);
-    if (col >= n) continue;
-    const float b = bias != nullptr ? bias[col] : 0.f;
+  for (int tn = 0; tn < 4; ++tn) b[tn] = (bias != nullptr && col + tn < n) ? bias[col + tn] : 0.f;
+  float* po = out + rb * ldo + col;
+  const float* pr = res != nullptr ? res + rb * ldr + col : nullptr;
 #pragma unroll
-    for (int tm = 0; tm < 8; ++tm) {
-      const int64_t r0 = i0 + wr * 128 + tm * 16 + 4 * (lane >> 4);
+  for (int tm = 0; tm < 8; ++tm) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (r0 + q < m) out[(r0 + q) * ldo + col] = gemm_h2_finish(acc[tm][tn][q], inv, b, res, ldr, r0 + q, col, relu);
+    for (int q = 0; q < 4; ++q) {
+      if (rb + tm * 16 + q < m) {
+        if (vec) {
+          f32x4 v;
+          f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
+          if (pr != nullptr) r4 = *reinterpret_cast<const f32x4*>(pr);
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) {
+            v[tn] = fmaf(acc[tm][tn][q], inv, b[tn]) + r4[tn];
+            if (relu) v[tn] = fmaxf(v[tn], 0.f);
+          }
+          *reinterpret_cast<f32x4*>(po) = v;
+        } else {
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn)
+            if (col + tn < n) po[tn] = gemm_h2_finish(acc[tm][tn][q], inv, b[tn], pr != nullptr ? pr + tn : nullptr, relu);
+        }
+      }
+      po += ldo;
+      if (pr != nullptr) pr += ldr;
     }
+    po += 12 * ldo;
+    if (pr != nullptr) pr += 12 * ldr;
   }
 }
 
