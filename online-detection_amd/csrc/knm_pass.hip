@@ -192,6 +192,22 @@ __global__ __launch_bounds__(NT) void knm_pass_batched_kernel(PassBatch pb, cons
                               slab + (int64_t)b * slab_stride, slab_ld, blockIdx.x, pb.grid[b]);
 }
 
+// Sum over the slabs g = wave, wave + 4, ... of one column (`stride` doubles from slab to slab): four loads in flight per
+// lane (a chain of one load + one add per slab was latency-bound: 77 us for 512 slabs of 1e4 columns).  ONE function for
+// every reducer: the order of the additions depends on (nslab, wave) alone, so the class-batched reducers give, bit for
+// bit, what the single-class ones give.
+__device__ __forceinline__ double slab_column_sum(const double* __restrict__ col, int64_t stride, int nslab, int wave) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int g = wave;
+  for (; g + 12 < nslab; g += 16) {
+    const double a0 = col[(int64_t)g * stride], a1 = col[(int64_t)(g + 4) * stride];
+    const double a2 = col[(int64_t)(g + 8) * stride], a3 = col[(int64_t)(g + 12) * stride];
+    s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+  }
+  for (; g < nslab; g += 4) s0 += col[(int64_t)g * stride];
+  return (s0 + s1) + (s2 + s3);
+}
+
 __global__ __launch_bounds__(256) void slab_reduce_batched_kernel(PassBatch pb, const double* __restrict__ slab,
                                                                   int64_t slab_ld, int64_t slab_stride,
                                                                   double* __restrict__ out, int64_t ostride) {
@@ -202,10 +218,7 @@ __global__ __launch_bounds__(256) void slab_reduce_batched_kernel(PassBatch pb, 
   const int64_t M = pb.M[b];
   const int nslab = pb.grid[b];
   const double* base = slab + (int64_t)b * slab_stride;
-  double s = 0.0;
-  if (j < M)
-    for (int g = wave; g < nslab; g += 4) s += base[(int64_t)g * slab_ld + j];
-  part[wave][lane] = s;
+  part[wave][lane] = j < M ? slab_column_sum(base + j, slab_ld, nslab, wave) : 0.0;
   __syncthreads();
   if (wave == 0 && j < M) out[(int64_t)b * ostride + j] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
@@ -356,20 +369,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const double* __restri
   __shared__ double part[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t j = (int64_t)blockIdx.x * 64 + lane;
-  // four loads in flight per lane (a chain of one load + one add per slab was latency-bound: 77 us for 512 slabs of 1e4);
-  // the order of the additions is fixed by (nslab, wave) alone
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  if (j < M) {
-    const double* col = slab + j;
-    int g = wave;
-    for (; g + 12 < nslab; g += 16) {
-      const double a0 = col[(int64_t)g * slab_ld], a1 = col[(int64_t)(g + 4) * slab_ld];
-      const double a2 = col[(int64_t)(g + 8) * slab_ld], a3 = col[(int64_t)(g + 12) * slab_ld];
-      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
-    }
-    for (; g < nslab; g += 4) s0 += col[(int64_t)g * slab_ld];
-  }
-  part[wave][lane] = (s0 + s1) + (s2 + s3);
+  part[wave][lane] = j < M ? slab_column_sum(slab + j, slab_ld, nslab, wave) : 0.0;
   __syncthreads();
   if (wave == 0 && j < M) out[j] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
@@ -381,19 +381,7 @@ __global__ __launch_bounds__(256) void slab_reduce2_kernel(const double* __restr
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t j = (int64_t)blockIdx.x * 64 + lane;
   const double* base = slab + (int64_t)blockIdx.y * slab_ld;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  if (j < M) {
-    const double* col = base + j;
-    const int64_t st = 2 * slab_ld;
-    int g = wave;
-    for (; g + 12 < nslab; g += 16) {
-      const double a0 = col[(int64_t)g * st], a1 = col[(int64_t)(g + 4) * st];
-      const double a2 = col[(int64_t)(g + 8) * st], a3 = col[(int64_t)(g + 12) * st];
-      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
-    }
-    for (; g < nslab; g += 4) s0 += col[(int64_t)g * st];
-  }
-  part[wave][lane] = (s0 + s1) + (s2 + s3);
+  part[wave][lane] = j < M ? slab_column_sum(base + j, 2 * slab_ld, nslab, wave) : 0.0;
   __syncthreads();
   if (wave == 0 && j < M) (blockIdx.y ? out2 : out)[j] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
