@@ -129,7 +129,12 @@ class HipBackend:
         torch.cuda.synchronize(self.device)
 
     # ------------------------------------------------------------------ features
-    def features(self, X):
+    def row_matrix(self, X):
+        """features() without the squared norms: the layout contract only, for the callers that never form a kernel block
+        of these rows (the RLS box regressors: a read of all rows saved)."""
+        return self.features(X, norms=False)
+
+    def features(self, X, norms=True):
         """Adopt (n, D) rows as kernel operands: f32, row stride a multiple of 4 elements,
         16-byte aligned (copied only when the caller's tensor is not already so)."""
         if not torch.is_tensor(X):
@@ -144,6 +149,8 @@ class HipBackend:
             buf = torch.zeros((n, ld), dtype=torch.float32, device=self.device)
             buf[:, :D] = X
             X = buf[:, :D]
+        if not norms:
+            return Features(X, None, D)
         sq = torch.empty(n, dtype=torch.float32, device=self.device)
         if n and self.gauss == "h2":
             # the norms and, from the same read of the rows, the maximum the f16 split scales by (pack() then only packs)

@@ -25,6 +25,12 @@ def _device():
     return 'cuda' if torch.cuda.is_available() else 'cpu'
 
 
+def _rows(be, X):
+    """The rows as the backend's operand container WITHOUT their squared norms (no Gaussian block is formed here: a read of
+    every row saved); backends without row_matrix() (the tests' oracle backend) hand out their features()."""
+    return be.row_matrix(X) if hasattr(be, "row_matrix") else be.features(X)
+
+
 def whiten_targets(Yi):
     """mu, T, T_inv (f64) of train_region_refiner.py:61-67 for targets Yi (n, 4) f64."""
     mu = torch.mean(Yi, dim=0)
@@ -68,7 +74,7 @@ class RegionRefinerTrainer:
         start_index = 0 if self.is_rpn else 1
         num_clss = len(chosen_classes)
         ids = list(range(start_index, num_clss))
-        F = be.features(self.COXY['X'])
+        F = _rows(be, self.COXY['X'])
         xdev = F.X.device
         Call = self.COXY['C'].to(xdev).reshape(-1)
         Yall = self.COXY['Y'].to(xdev)
@@ -224,7 +230,7 @@ class RegionRefinerTrainer:
         start_index = 0 if self.is_rpn else 1
         num_clss = len(chosen_classes)
         models = np.empty((0))
-        F = be.features(self.COXY['X'])
+        F = _rows(be, self.COXY['X'])
         Call = self.COXY['C'].to(F.X.device)
         Yall = self.COXY['Y'].to(F.X.device)
         D = F.D
@@ -286,7 +292,7 @@ class RegionRefinerTrainer:
                   and bool((feats.to(torch.float32).to(X.dtype) == feats).all()))
         out = {}
         if native:
-            F = be.features(feats.to(torch.float32))
+            F = _rows(be, feats.to(torch.float32))
             xdev = F.X.device
             W_all = None
             for k in range(4):
@@ -351,7 +357,7 @@ class RegionPredictor:
             feat = torch.tensor(features[i]['feat'][keep, :][0], device=dev)
             if normalize_features:
                 feat = (feat - stats['mean']) * (20 / stats['mean_norm'].item())
-            F = be.features(feat)
+            F = _rows(be, feat)
             ex_box = boxes[i].bbox.to(dev)
             num_boxes = ex_box.size()[0]
             if hasattr(be, "gemm_nt") and all(m['Beta'] is not None for m in self.models[:num_clss - 1]):
@@ -362,7 +368,7 @@ class RegionPredictor:
                 if fold is None or fold[0] is not self.models or fold[1] != F.D:
                     from .heads import _fold_regressors
                     Wt, bias = _fold_regressors(list(self.models[:num_clss - 1]), F.D, False)
-                    fold = self._fold = (self.models, F.D, be.features(Wt.to(F.X.device)), bias.to(F.X.device))
+                    fold = self._fold = (self.models, F.D, _rows(be, Wt.to(F.X.device)), bias.to(F.X.device))
                 Y = (be.gemm_nt(F, fold[2]) + fold[3]).view(num_boxes, num_clss - 1, 4)
                 dec = decode_boxes(ex_box.unsqueeze(1), Y, img_width, img_height, plus=float(np.spacing(1)))
                 boxes[i].bbox = torch.cat((ex_box.view(num_boxes, 1, 4), dec), dim=1)
