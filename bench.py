@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--precond-batch", type=int, default=0, help="classes whose preconditioners one batched launch chain builds "
                     "(odx_falkon_precond_batched_f64), one group ahead of the fits; 1 = one chain per class (--precond-depth applies); "
                     "default: min(6, classes this rank owns)")
+    ap.add_argument("--precond-cus", type=int, default=0, help="confine the preconditioner chains (their stream and the library's "
+                    "helper streams) to this many compute units, spread over the XCDs (0: the whole device; an experiment knob — "
+                    "measured slower at 48..128 CUs: the confined chains starve behind the main stream's grids, DESIGN.md 7)")
     ap.add_argument("--reserve-cus", type=int, default=0, help="CUs the persistent pass kernel leaves to the side streams")
     ap.add_argument("--precond-behind-cg", dest="precond_after_fit", action="store_true",
                     help="issue the look-ahead preconditioner behind the batch's CG instead of before its fit")
@@ -242,7 +245,7 @@ def main():
     be.reserve_cus_during_passes(args.reserve_cus)
     job = LockstepClassJob(be, X, N, M, lambda c: torch.where((row_ids % C) == c, 1.0, -1.0).to(torch.float64), cidx_dev,
                            args.sigma, args.lam, args.maxiter, opt, shard=shard, precond_batch=args.precond_batch,
-                           precond_depth=args.precond_depth, precond_after_fit=args.precond_after_fit)
+                           precond_depth=args.precond_depth, precond_after_fit=args.precond_after_fit, precond_cus=args.precond_cus)
     G, ldk, scores = job.G, job.ldk, job.scores
     kfmt = be.knm_format(n_loc, M)                 # storage of the K_nM shards ("u24" at the headline size, "f32" for small ones)
 
@@ -381,7 +384,7 @@ def main():
             "config": {"workload": "%d-class one-vs-rest FALKON fit + score-all, N=%d D=%d M=%d, %d CG iterations, "
                                    "rows sharded over %d GPU(s)" % (C, N, D, M, args.maxiter, world),
                        "N": N, "D": D, "M": M, "classes": C, "sigma": args.sigma, "lambda": args.lam,
-                       "rows_per_gpu": n_loc, "preconditioners_per_batched_chain": G},
+                       "rows_per_gpu": n_loc, "preconditioners_per_batched_chain": G, "preconditioner_cus": args.precond_cus or "all"},
             "roofline": roof,
             "roofline_hbm": roof_p,
             "roofline_mfma": roof_g,

@@ -48,6 +48,9 @@ int odx_device_cus(void);
 int odx_stream_create_cu_mask(const uint32_t* mask, int words, odx_stream_t* stream);
 int odx_stream_destroy(odx_stream_t stream);
 int odx_set_pass_cus(int cus);
+/* the CU mask the library's internal helper streams (look-ahead of the blocked Cholesky, the forked inverse) are created
+ * with from now on; words = 0: the whole device.  Streams that exist keep theirs.                                       */
+int odx_set_side_stream_cu_mask(const uint32_t* mask, int words);
 int odx_debug_placement(int32_t* out, int blocks, int spin, odx_stream_t stream);
 
 /* ---------------------------------------------------------------- A3: Gaussian kernel

@@ -548,6 +548,10 @@ struct SideStream {
 // preconditioner, slot 1 carries the look-ahead trailing updates of potrf_f64.  Keyed by the calling stream so that
 // factorisations issued on different streams (classes trained side by side) do not queue behind each other on one
 // helper.  Everything is ordered with events; the host never waits.
+// CU mask the helper streams are created with (odx_set_side_stream_cu_mask: a factorisation chain confined to a part of
+// the chip takes its look-ahead and fork streams along); empty = the whole device.  Streams that exist keep their mask.
+static std::vector<uint32_t> g_side_mask;
+
 static int side_stream(SideStream** out, int slot, hipStream_t caller) {
   struct Entry {
     int device;
@@ -569,7 +573,9 @@ static int side_stream(SideStream** out, int slot, hipStream_t caller) {
   }
   SideStream& s = e->ss[slot];
   if (s.stream == nullptr) {
-    if (slot == 1) {
+    if (!g_side_mask.empty()) {
+      ODX_CHECK_HIP(hipExtStreamCreateWithCUMask(&s.stream, (uint32_t)g_side_mask.size(), g_side_mask.data()));
+    } else if (slot == 1) {
       // The look-ahead updates are bulk work that must not starve the latency-bound chain they overlap with: lowest
       // priority, so freed CU slots go to the chain's small kernels first.
       int lo = 0, hi = 0;
@@ -989,4 +995,10 @@ extern "C" int odx_falkon_precond_batched_f64(const float* const* Z, const int64
   // join, then the inverses of L_A (scratch W1: T is no longer needed)
   ODX_CHECK_HIP(hipStreamWaitEvent(s, side->join, 0));
   return trtri_from_diag_f64(W2, wld, Mmax, DinvA, LAi, LAit, ld, W1, s, zt);
+}
+
+extern "C" int odx_set_side_stream_cu_mask(const uint32_t* mask, int words) {
+  ODX_REQUIRE(words >= 0 && words <= 64 && (words == 0 || mask != nullptr), "odx_set_side_stream_cu_mask: bad argument");
+  g_side_mask.assign(mask, mask + words);
+  return ODX_OK;
 }

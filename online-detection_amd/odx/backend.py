@@ -164,6 +164,23 @@ class HipBackend:
             hip.check(self.lib.odx_row_sqnorm_f32(_p(X), X.stride(0), n, D, _p(sq), self._stream()), "odx_row_sqnorm_f32")
         return Features(X, sq, D)
 
+    def masked_stream(self, cus):
+        """A stream confined to `cus` compute units, spread evenly over the XCDs (logical CU i sits on XCC i % 8, so the
+        first `cus` bits are cus / 8 per XCD); the library's internal helper streams created from now on get the same
+        mask.  Kept alive by the backend."""
+        total = int(self.lib.odx_device_cus())
+        cus = max(8, min(int(cus), total))
+        words = (total + 31) // 32
+        arr = (ctypes.c_uint32 * words)()
+        for b in range(cus):
+            arr[b // 32] |= 1 << (b % 32)
+        hip.check(self.lib.odx_set_side_stream_cu_mask(arr, words), "odx_set_side_stream_cu_mask")
+        raw = ctypes.c_void_p()
+        hip.check(self.lib.odx_stream_create_cu_mask(arr, words, ctypes.byref(raw)), "odx_stream_create_cu_mask")
+        st = torch.cuda.ExternalStream(raw.value, device=self.device)
+        self._masked_streams = getattr(self, "_masked_streams", []) + [(st, raw)]
+        return st
+
     def _meta_slot(self):
         """Two zeroed floats (scale, max |x| bits) for one matrix, cut from a pool that is zeroed once per 4096 matrices —
         a fill launch per matrix otherwise (a Minibootstrap round: ~250 of them).  A slot is handed out once; the slices

@@ -34,6 +34,7 @@ SIGNATURES = {
     "odx_stream_create_cu_mask": (_i32, [_vp, _i32, _vp]),
     "odx_stream_destroy": (_i32, [_vp]),
     "odx_set_pass_cus": (_i32, [_i32]),
+    "odx_set_side_stream_cu_mask": (_i32, [_vp, _i32]),
     "odx_debug_placement": (_i32, [_vp, _i32, _i32, _vp]),
     "odx_row_sqnorm_f32": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp]),
     "odx_row_sqnorm_absmax_f32": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _vp]),

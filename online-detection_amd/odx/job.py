@@ -21,9 +21,15 @@ from .dist import RowShard
 class _Side:
     """A side stream with an event, or (CPU tensors) nothing: work is then simply done in program order."""
 
-    def __init__(self, device):
+    def __init__(self, device, be=None, cus=0):
         self.cuda = torch.device(device).type == "cuda"
-        self.stream = torch.cuda.Stream(device=device) if self.cuda else None
+        self.stream = None
+        if self.cuda and cus > 0 and be is not None and hasattr(be, "masked_stream"):
+            # confined to `cus` compute units (spread over the XCDs): the factorisation chains then pack their workgroups on
+            # those instead of holding one slot on many CUs, each of which takes no Gaussian workgroup meanwhile
+            self.stream = be.masked_stream(cus)
+        elif self.cuda:
+            self.stream = torch.cuda.Stream(device=device)
 
     def after_current(self):
         if self.cuda:
@@ -70,7 +76,7 @@ class LockstepClassJob:
     row ids of class c's Nystroem centres (identical on every rank)."""
 
     def __init__(self, be, X, n_total, M, labels, centre_idx, sigma, lam, maxiter=20, opt=None, shard=None,
-                 precond_batch=0, precond_depth=2, precond_after_fit=False, classes=None):
+                 precond_batch=0, precond_depth=2, precond_after_fit=False, classes=None, precond_cus=0):
         self.be, self.X, self.N, self.M = be, X, int(n_total), int(M)
         self.labels, self.cidx = labels, centre_idx
         self.sigma, self.lam, self.maxiter = sigma, lam, maxiter
@@ -94,8 +100,8 @@ class LockstepClassJob:
         self.G = precond_batch if precond_batch > 0 else max(1, min(6, n_batches))
         self.ld_p = (self.M + 1) // 2 * 2
         self.nslot = self.depth + 1
-        self.sides = [_Side(dev) for _ in range(self.nslot)] if self.G == 1 else []
-        self.gside = _Side(dev) if self.G > 1 else None
+        self.sides = [_Side(dev, be, precond_cus) for _ in range(self.nslot)] if self.G == 1 else []
+        self.gside = _Side(dev, be, precond_cus) if self.G > 1 else None
         self.pbuf, self.pgroup = [], []
         self.trace = []          # (kind, payload) records of the schedule this rank executed (tests read it)
 
