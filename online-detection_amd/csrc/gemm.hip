@@ -6,6 +6,58 @@
 
 namespace odx {
 
+// One 32-row slab of a tile from LDS to its destination in whole 16-byte segments.  TR: the slab holds the tile transposed
+// (slab[c][r]) and goes to dst[col][row].  The orientation is a template parameter so that the segment index splits into
+// (slow, fast) by shifts — with a run-time orientation it was an integer division per segment — and the destination
+// address advances by a constant number of rows per trip instead of a 64-bit row * ld product per segment: at k = 128 (the
+// panel updates of the blocked Cholesky) the epilogue is as long as the main loop.
+template <typename T, int BN, bool TR>
+__device__ __forceinline__ void gemm_slab_out(const T* __restrict__ slab, T* __restrict__ dst, int64_t ldd, int64_t row0,
+                                              int64_t col0, int64_t m, int64_t n, T alpha, T beta, bool rmw) {
+  using Tr = GemmTraits<T>;
+  constexpr int EPV = Tr::EPV;
+  constexpr int SLAB = 32;
+  constexpr int NA = TR ? BN : SLAB, NB = TR ? SLAB : BN;           // out(a, b): a = slow index, b = fast (contiguous) index
+  constexpr int LDSLAB = (TR ? SLAB : BN) + EPV;
+  constexpr int SEGS = NB / EPV;                                     // a power of two
+  constexpr int STEP = GEMM_THREADS / SEGS;                          // slow-index rows per trip
+  static_assert((SEGS & (SEGS - 1)) == 0 && GEMM_THREADS % SEGS == 0 && NA % STEP == 0, "gemm_slab_out: segment geometry");
+  typedef T VecT __attribute__((ext_vector_type(EPV)));
+  const int64_t a0 = TR ? col0 : row0, b0 = TR ? row0 : col0;
+  const int64_t alim = TR ? n : m, blim = TR ? m : n;
+  const int tid = threadIdx.x;
+  const int b = (tid & (SEGS - 1)) * EPV;
+  const int64_t gb = b0 + b;
+  if (gb >= blim) return;
+  const bool whole = gb + EPV <= blim;
+  int a = tid / SEGS;
+  T* g = dst + (a0 + a) * ldd + gb;
+  const T* sp = slab + a * LDSLAB + b;
+#pragma unroll
+  for (int it = 0; it < NA / STEP; ++it, a += STEP, g += (int64_t)STEP * ldd, sp += STEP * LDSLAB) {
+    if (a0 + a >= alim) break;
+    const VecT v = *reinterpret_cast<const VecT*>(sp);
+    if (whole) {
+      VecT o;
+      if (rmw) {
+        const VecT c = *reinterpret_cast<const VecT*>(g);
+#pragma unroll
+        for (int q = 0; q < EPV; ++q) o[q] = alpha * v[q] + beta * c[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < EPV; ++q) o[q] = alpha * v[q];
+      }
+      *reinterpret_cast<VecT*>(g) = o;
+    } else {
+      for (int q = 0; q < EPV && gb + q < blim; ++q) {
+        T o = alpha * v[q];
+        if (rmw) o += beta * g[q];
+        g[q] = o;
+      }
+    }
+  }
+}
+
 template <typename T, int BN>
 __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 8 && BN == 64) ? 3 : 1) void gemm_nt_kernel(GemmParams<T> p) {
   using Tr = GemmTraits<T>;
@@ -79,8 +131,6 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 8 && BN == 64) ? 3 : 1)
     constexpr int LDT = SLAB + EPV;       // transposed:  slab[c][r], c < BN, r < 32
     static_assert(sizeof(T) * SLAB * LDN <= LDS_BYTES && sizeof(T) * BN * LDT <= LDS_BYTES, "slab");
     T* slab = reinterpret_cast<T*>(lds);
-    typedef T VecT __attribute__((ext_vector_type(Tr::EPV)));
-    const int tid = threadIdx.x;
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int r0 = pass * SLAB;                       // tile rows [r0, r0 + 32)
@@ -104,39 +154,11 @@ __global__ __launch_bounds__(GEMM_THREADS, (sizeof(T) == 8 && BN == 64) ? 3 : 1)
           }
         }
         __syncthreads();
-        // out(a, b): a = slow index, b = fast (contiguous) index of the destination
-        const int na = tr ? BN : SLAB, nb = tr ? SLAB : BN;
-        const int ldslab = tr ? LDT : LDN;
         T* dst = variant == 0 ? C : C2;
         const int64_t ldd = variant == 0 ? p.ldc : p.ldc2;
-        const int64_t a0 = tr ? j0 : i0 + r0, b0 = tr ? i0 + r0 : j0;
-        const int64_t alim = tr ? n : m, blim = tr ? m : n;
-        const int segs = nb / EPV;
-        for (int e = tid; e < na * segs; e += GEMM_THREADS) {
-          const int a = e / segs, b = (e % segs) * EPV;
-          const int64_t ga = a0 + a, gb = b0 + b;
-          if (ga >= alim || gb >= blim) continue;
-          VecT v = *reinterpret_cast<const VecT*>(slab + a * ldslab + b);
-          T* g = dst + ga * ldd + gb;
-          if (gb + EPV <= blim) {
-            VecT o;
-            if (variant == 0 && has_beta) {
-              const VecT c = *reinterpret_cast<const VecT*>(g);
-#pragma unroll
-              for (int q = 0; q < EPV; ++q) o[q] = alpha * v[q] + p.beta * c[q];
-            } else {
-#pragma unroll
-              for (int q = 0; q < EPV; ++q) o[q] = alpha * v[q];
-            }
-            *reinterpret_cast<VecT*>(g) = o;
-          } else {
-            for (int q = 0; q < EPV && gb + q < blim; ++q) {
-              T o = alpha * v[q];
-              if (variant == 0 && has_beta) o += p.beta * g[q];
-              g[q] = o;
-            }
-          }
-        }
+        const bool rmw = variant == 0 && has_beta;
+        if (tr) gemm_slab_out<T, BN, true>(slab, dst, ldd, i0 + r0, j0, m, n, alpha, p.beta, rmw);
+        else gemm_slab_out<T, BN, false>(slab, dst, ldd, i0 + r0, j0, m, n, alpha, p.beta, rmw);
       }
     }
     return;
