@@ -32,6 +32,7 @@ __device__ __forceinline__ void knm_pass_body(const float* __restrict__ K, int64
                                               const int64_t wg, const int64_t nwg) {
   constexpr int NW = NT / 64;
   constexpr int VCAP = (NT * CH * 4 < 20000) ? NT * CH * 4 : 20000;  // 160,000 B of the 163,840 B LDS at most
+  constexpr bool VFULL = NV == 1 && NT * CH * 4 <= VCAP;             // v zero-filled up to every chunk a thread walks
   __shared__ __attribute__((aligned(16))) double vs_static[NV == 1 ? VCAP : 2];
   extern __shared__ __attribute__((aligned(16))) double vs_dyn[];       // NV == 2: [2][vcap2]
   __shared__ double red[2][NW][R * NV];
@@ -58,15 +59,20 @@ __device__ __forceinline__ void knm_pass_body(const float* __restrict__ K, int64
       for (int e = 0; e < 4; ++e) acc[q][c][e] = 0.0;
   }
 
+  // Loads are unconditional (a load under a condition makes its registers selects: zero-fills and copies around every
+  // load of the streaming loop): a row past n is read as row n - 1 and its row dot is set to zero before phase 2; a chunk
+  // past the row's end is read as the thread's chunk 0 — it meets zeros of v in phase 1 (VFULL: v is zero-filled up to the
+  // chunks the threads walk; otherwise the guard on v stays) and its column sums are never stored.
   f32x4 kr[R][CH];
+  uint32_t kcol[CH];       // element offset of the thread's chunk inside a row (32 bits; the row base is wave-uniform)
+#pragma unroll
+  for (int c = 0; c < CH; ++c) kcol[c] = cvalid[c] ? (uint32_t)(tid + c * NT) * 4u : 0u;
   auto load_block = [&](int64_t blk, int c) {
-    const int64_t ch = tid + (int64_t)c * NT;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int64_t row = blk * R + r;
-      f32x4 x = {0.f, 0.f, 0.f, 0.f};
-      if (cvalid[c] && row < n) x = *reinterpret_cast<const f32x4*>(K + row * ldk + ch * 4);
-      kr[r][c] = x;
+      const int64_t row = blk * R + r < n ? blk * R + r : n - 1;
+      const float* rowp = K + row * ldk;
+      kr[r][c] = *reinterpret_cast<const f32x4*>(rowp + kcol[c]);
     }
   };
 
@@ -90,7 +96,7 @@ __device__ __forceinline__ void knm_pass_body(const float* __restrict__ K, int64
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
           double vv[4] = {0.0, 0.0, 0.0, 0.0};
-          if (cvalid[c]) {
+          if (VFULL || cvalid[c]) {
             const f64x2 a = *reinterpret_cast<const f64x2*>(&vs[q * vcap + (tid + c * NT) * 4]);
             const f64x2 b = *reinterpret_cast<const f64x2*>(&vs[q * vcap + (tid + c * NT) * 4 + 2]);
             vv[0] = a[0]; vv[1] = a[1]; vv[2] = b[0]; vv[3] = b[1];
@@ -127,13 +133,22 @@ __device__ __forceinline__ void knm_pass_body(const float* __restrict__ K, int64
 #pragma unroll
         for (int r = 0; r < R; ++r) t[q][r] = 0.0;
     }
-    if (NV == 1 && w != nullptr) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int64_t row = blk * R + r;
-        if (row < n) t[0][r] += w[row];
+    for (int r = 0; r < R; ++r) {
+      const int64_t row = blk * R + r;
+      if (row >= n) {                        // (the last block only) a repeated row, not a zero one, was read for it
+#pragma unroll
+        for (int q = 0; q < NV; ++q) t[q][r] = 0.0;
+      } else if (NV == 1 && w != nullptr) {
+        t[0][r] += w[row];
       }
     }
+    // the doubles phase 1 converted the block to must not stay live into phase 2 (R x CH x 4 of them: spills); an empty asm
+    // makes the f32 registers opaque here, phase 2 converts again
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int r = 0; r < R; ++r) asm volatile("" : "+v"(kr[r][c]));
     // phase 2: column sums, and the next block's loads re-issued chunk by chunk
     // (the loads are issued unconditionally — behind the last block they re-read it and nobody waits for them: a branch
     // around them makes every register of the block a loop-carried select, two register copies per register and trip)
@@ -147,6 +162,7 @@ __device__ __forceinline__ void knm_pass_body(const float* __restrict__ K, int64
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[q][c][e] = fma((double)kr[r][c][e], t[q][r], acc[q][c][e]);
       load_block(nxt, c);
+      __builtin_amdgcn_sched_barrier(0);      // the loads of chunk column c go into the registers just consumed, not ahead of them
     }
   }
   double* my = slab + wg * slab_ld * NV;
