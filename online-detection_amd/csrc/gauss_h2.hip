@@ -234,12 +234,11 @@ __device__ __forceinline__ void s16_mainloop(f32x4 (&acc)[4][4], const uint32_t*
     s16_store_operand(st.a, ldsA);
     s16_store_operand(st.b, ldsB);
     __syncthreads();
-    if (kt + 1 < ktiles) {
-      ta += H2_KT;
-      tb += H2_KT;
-      h2_load_operand(st.a, ta, offa);
-      h2_load_operand(st.b, tb, offb);
-    }
+    // (unconditional: behind the last k-tile the loads re-read it and nobody waits for them — a branch around the loads
+    // makes the 64 staging registers loop-carried selects)
+    const int64_t nk = (int64_t)(kt + 1 < ktiles ? kt + 1 : kt) * H2_KT;
+    h2_load_operand(st.a, ta + nk, offa);
+    h2_load_operand(st.b, tb + nk, offb);
     s16_compute_ktile(acc, ldsA, ldsB, wr, wc, lane);
   }
 }
