@@ -846,7 +846,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_mmv_h2w256_kernel(
     double* __restrict__ slab, int64_t slab_ld) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   __shared__ double red[4][W_BM];
-  __shared__ __attribute__((aligned(16))) float xg_s[W_BM];   // row norms times gamma log2(e): the exponent comes out scaled
+  __shared__ __attribute__((aligned(16))) float xs_s[W_BM];
   constexpr int64_t GR = 8;
   const int c = blockIdx.y;
   const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -859,9 +859,9 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_mmv_h2w256_kernel(
   if (i0 >= n || s0 >= r1) return;       // mmv_reduce_kernel only visits the groups that exist
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 2, wc = wave & 3;
-  const float m2g = -2.f / (metax[0] * metaz[0]) * gamma_log2e;    // the scales are powers of two: -2 / (sx sz) is exact
+  const float m2 = -2.f / (metax[0] * metaz[0]);
 
-  if (threadIdx.x < W_BM) xg_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] * gamma_log2e : 0.f;
+  if (threadIdx.x < W_BM) xs_s[threadIdx.x] = (i0 + threadIdx.x < n) ? xsq[i0 + threadIdx.x] : 0.f;
   // Lane l ends every tile with two f64 sums over the tile's 64 columns of this wave: for half h of the wave's rows,
   // row slot (l & 15) of its lane quarter (slot = 4 tm' + q, row 64 h + 16 tm' + 4 (l >> 4) + q).
   double tot[2] = {0.0, 0.0};
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_mmv_h2w256_kernel(
     for (int tn = 0; tn < 4; ++tn) {
       const int64_t col = j0 + wc * 64 + tn * 16 + (lane & 15);
       const bool cv = col < s1;
-      zs[tn] = cv ? zsq[col] * gamma_log2e : 0.f;
+      zs[tn] = cv ? zsq[col] : 0.f;
       al[tn] = cv ? V[col * ldv + c] : 0.0;     // weight 0 removes the columns past the group / range
     }
 #pragma unroll
@@ -889,12 +889,17 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_mmv_h2w256_kernel(
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const int tm = 4 * h + 2 * u + (j >> 2), q = j & 3;
-          const float xs = xg_s[wr * 128 + tm * 16 + 4 * (lane >> 4) + q];
+          const float xs = xs_s[wr * 128 + tm * 16 + 4 * (lane >> 4) + q];
           v[u] = 0.0;
 #pragma unroll
           for (int tn = 0; tn < 4; ++tn) {
-            const float e = fminf(fmaf(m2g, acc[tm][tn][q], xs) + zs[tn], 0.f);     // gamma < 0: d^2 >= 0 <=> e <= 0
-            v[u] = fma((double)__builtin_amdgcn_exp2f(e), al[tn], v[u]);
+            // (the build's shorter form — exponent from pre-scaled norms, fma + add + min — was measured here and is
+            // SLOWER: 50.3 against 49.5 ms, with 125 instead of 75 GB fetched from beyond L2 per launch; how far the
+            // workgroups of an XCD drift apart in k decides how often they share a fetched slice, and this form's timing
+            // keeps them closer)
+            float d2 = fmaf(m2, acc[tm][tn][q], xs) + zs[tn];
+            d2 = fmaxf(d2, 0.f);
+            v[u] = fma((double)__builtin_amdgcn_exp2f(d2 * gamma_log2e), al[tn], v[u]);
           }
         }
         w8[j] = (b8 ? v[1] : v[0]) + __shfl_xor(b8 ? v[0] : v[1], 8);
