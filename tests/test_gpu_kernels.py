@@ -861,3 +861,48 @@ def test_packed_3x3_taps_equal_the_split_of_the_gathered_matrix(R, H, W, C):
     a, b = be.packed_taps3x3(Y, R, H, W), be.packed(cols)
     assert a.n == b.n and a.D == b.D == 9 * C
     assert torch.equal(a.meta, b.meta) and torch.equal(a.P[:, : b.P.shape[1]], b.P)
+
+
+def test_cu_masked_stream_and_partition_sized_pass(be):
+    """The diagnostic entry points behind tools/cu_split_probe.py: a stream confined to 16 compute units runs its workgroups
+    on at most 16 distinct (XCC, SE, SH, CU) places, two per XCC; a compact pass launched there with its persistent grid sized
+    for the partition gives the whole-chip launch's result to f64 rounding (the slab order depends on the grid)."""
+    from odx import hip
+    lib = be.lib
+    total = int(lib.odx_device_cus())
+    words = (total + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for b in range(16):
+        mask[b // 32] |= 1 << (b % 32)
+    raw = ctypes.c_void_p()
+    hip.check(lib.odx_stream_create_cu_mask(mask, words, ctypes.byref(raw)), "odx_stream_create_cu_mask")
+    st = torch.cuda.ExternalStream(raw.value)
+    try:
+        blocks = 256
+        buf = torch.zeros(3 * blocks + 1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st):
+            hip.check(lib.odx_debug_placement(buf.data_ptr(), blocks, 500, be._stream()), "odx_debug_placement")
+        st.synchronize()
+        v = buf[:3 * blocks].view(blocks, 3).cpu().numpy()
+        places = {(int(x), (int(h) >> 13) & 7, (int(h) >> 12) & 1, (int(h) >> 8) & 15) for x, h, _ in v}
+        assert len(places) <= 16 and len({p[0] for p in places}) == 8
+        assert sorted(v[:, 2].tolist()) == list(range(blocks)) and int(buf[3 * blocks]) == blocks
+        rng = np.random.default_rng(5)
+        K, vals = _compact_block(rng, 3000, 10000, "u24")
+        vv = rng.standard_normal(10000)
+        whole = be.ktk(K, v=dev(vv))
+        hip.check(lib.odx_set_pass_cus(16), "odx_set_pass_cus")
+        try:
+            torch.cuda.synchronize()
+            with torch.cuda.stream(st):
+                part = be.ktk(K, v=dev(vv))
+            st.synchronize()
+        finally:
+            hip.check(lib.odx_set_pass_cus(0), "odx_set_pass_cus")
+        ref = vals.T @ (vals @ vv)
+        assert np.abs(part.cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+        assert float((part - whole).abs().max()) <= 1e-12 * float(whole.abs().max())
+    finally:
+        torch.cuda.synchronize()
+        hip.check(lib.odx_stream_destroy(raw), "odx_stream_destroy")
