@@ -322,7 +322,7 @@ def main():
         bytes_per_pass = float(be.knm_bytes(n_loc, M))      # the stored shard, read exactly once per launch (n M s_K)
         if kfmt == "f32":
             pk = ("knm_pass_kernel", "knm_pass2_kernel")
-        elif 8192 < M <= 10240 and not os.environ.get("ODX_PASSQ_NO_STAGGER") and not os.environ.get("ODX_PASSQ_CFG"):
+        elif (8192 < M <= 10240 or 1024 < M <= 4096) and not os.environ.get("ODX_PASSQ_NO_STAGGER") and not os.environ.get("ODX_PASSQ_CFG"):
             pk = ("knm_passq_stag_kernel", "knm_passq_kernel<NV=2>")      # one vector: two free-running halves per workgroup
         else:
             pk = ("knm_passq_kernel<NV=1>", "knm_passq_kernel<NV=2>")

@@ -413,6 +413,11 @@ static bool pick_qcfg(int64_t M, int nv, int fmt, QCfg* cfg) {
       if (sscanf(e, "%d %d %d", &nt, &ch, &r) == 3 && (int64_t)(nt ? nt : 256) * ch >= chunks) { *cfg = {nt, ch, r, (nt && nt <= 256) ? 2 : 1}; return true; }
     }
     if (chunks <= 256) { *cfg = {256, 1, 16, 2}; return true; }
+    // (the two-halves form, two workgroups per CU: 4.9 / 5.0 TB/s at M = 2000 / 3000 against 4.1 / 4.5 for the barrier form
+    // below; at 8 chunks per thread it needs the CU to itself and loses to it — 5.1 against 5.3 TB/s at M = 6000)
+    const bool halves = !getenv("ODX_PASSQ_NO_STAGGER");
+    if (halves && chunks <= 512) { *cfg = {0, 2, 8, 2}; return true; }
+    if (halves && chunks <= 1024) { *cfg = {0, 4, 4, 2}; return true; }
     if (chunks <= 512) { *cfg = {256, 2, 8, 2}; return true; }
     if (chunks <= 1024) { *cfg = {256, 4, 8, 2}; return true; }
     if (chunks <= 2048) { *cfg = {256, 8, 3, 2}; return true; }
@@ -470,11 +475,19 @@ static int dispatch_passq(const QCfg& cfg, int grid, size_t lds, hipStream_t s, 
 #define ODX_Q(NT_, CH_, R_) return launch_passq<NT_, CH_, R_, NV, FMT>(grid, lds, s, K, ldk, Klo, ldlo, n, M, v, v2, w, slab, slab_ld)
   if constexpr (NV == 1) {
     if (cfg.nt == 0) {
-      ODX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knm_passq_stag_kernel<10, 2, FMT>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((knm_passq_stag_kernel<10, 2, FMT>), dim3(grid), dim3(512), lds, s, static_cast<const unsigned short*>(K), ldk,
-                         static_cast<const unsigned char*>(Klo), ldlo, n, M, v, w, slab, slab_ld);
-      return ODX_OK;
+#define ODX_QH(CH_, R_)                                                                                                         \
+  do {                                                                                                                          \
+    ODX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knm_passq_stag_kernel<CH_, R_, FMT>),                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                   \
+    hipLaunchKernelGGL((knm_passq_stag_kernel<CH_, R_, FMT>), dim3(grid), dim3(512), lds, s,                                    \
+                       static_cast<const unsigned short*>(K), ldk, static_cast<const unsigned char*>(Klo), ldlo, n, M, v, w,    \
+                       slab, slab_ld);                                                                                          \
+    return ODX_OK;                                                                                                              \
+  } while (0)
+      if (cfg.ch == 2) ODX_QH(2, 8);
+      if (cfg.ch == 4) ODX_QH(4, 4);
+      ODX_QH(10, 2);
+#undef ODX_QH
     }
     if (cfg.nt == 256 && cfg.ch == 1) ODX_Q(256, 1, 16);
     if (cfg.nt == 256 && cfg.ch == 2) ODX_Q(256, 2, 8);
@@ -523,7 +536,7 @@ extern "C" int64_t odx_knm_fwd_bwd_q_workspace_bytes(int64_t n, int64_t M, int f
   if ((fmt != ODX_KNM_U24 && fmt != ODX_KNM_BF16) || !pick_qcfg(M, 1, fmt, &cfg)) return ODX_ERR_UNSUPPORTED;
   int cus = odx_device_cus();       // (never less than what a partitioned launch needs)
   if (cus <= 0) cus = 256;
-  return (int64_t)cus * (cfg.nt == 0 ? 2 : cfg.wg_per_cu) * round_up(M, 4) * (int64_t)sizeof(double);
+  return (int64_t)cus * (cfg.nt == 0 ? 2 * cfg.wg_per_cu : cfg.wg_per_cu) * round_up(M, 4) * (int64_t)sizeof(double);
 }
 
 extern "C" int odx_knm_fwd_bwd_q(const void* K, int64_t ldk, const void* Klo, int64_t ldlo, int fmt, int64_t n, int64_t M,
@@ -551,7 +564,7 @@ extern "C" int odx_knm_fwd_bwd_q(const void* K, int64_t ldk, const void* Klo, in
   }
   double* slab = static_cast<double*>(workspace);
   // (the halves kernel keeps v zero-filled up to the 10 x 256 chunks of four its threads walk)
-  const size_t lds = (cfg.nt == 0 ? (size_t)(10 * 256 * 4) : (size_t)(slab_ld + 4)) * sizeof(double);      // + the zero chunk
+  const size_t lds = (cfg.nt == 0 ? (size_t)(cfg.ch * 256 * 4) : (size_t)(slab_ld + 4)) * sizeof(double);      // + the zero chunk
   if (fmt == ODX_KNM_U24) ODX_PROPAGATE((dispatch_passq<1, QF_U24>(cfg, grid, lds, s, K, ldk, Klo, ldlo, n, M, v, nullptr, w, slab, slab_ld)));
   else ODX_PROPAGATE((dispatch_passq<1, QF_BF16>(cfg, grid, lds, s, K, ldk, nullptr, 0, n, M, v, nullptr, w, slab, slab_ld)));
   ODX_CHECK_LAUNCH("odx_knm_fwd_bwd_q");
