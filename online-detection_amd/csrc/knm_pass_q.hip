@@ -341,10 +341,15 @@ __global__ __launch_bounds__(512, 2) void knm_passq_stag_kernel(const unsigned s
       if (lane == 0) {
         __hip_atomic_fetch_add(&arrived[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const unsigned int want = 4u * (unsigned int)(k + 1);
-        for (int spin = 0; spin < (1 << 22); ++spin) {
-          if (__hip_atomic_load(&arrived[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) break;
+        // (all eight waves of the workgroup are co-resident by construction, so the wait ends; it is bounded only so that a
+        // broken build cannot hang the device — and a bound that is hit must not fall through to sums the other waves have
+        // not written yet: the wave traps, the launch fails, the host sees an error instead of a silently wrong K'(K v))
+        bool met = false;
+        for (int spin = 0; spin < (1 << 26); ++spin) {
+          if (__hip_atomic_load(&arrived[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) { met = true; break; }
           __builtin_amdgcn_s_sleep(1);
         }
+        if (!met) __builtin_trap();
       }
       __builtin_amdgcn_wave_barrier();
       asm volatile("" ::: "memory");
@@ -410,7 +415,15 @@ static bool pick_qcfg(int64_t M, int nv, int fmt, QCfg* cfg) {
     // experiments: ODX_PASSQ_CFG="nt ch r" forces a configuration (must cover the row and be one of those built below)
     if (const char* e = getenv("ODX_PASSQ_CFG")) {
       int nt = 0, ch = 0, r = 0;
-      if (sscanf(e, "%d %d %d", &nt, &ch, &r) == 3 && (int64_t)(nt ? nt : 256) * ch >= chunks) { *cfg = {nt, ch, r, (nt && nt <= 256) ? 2 : 1}; return true; }
+      // only tuples dispatch_passq() instantiates: an unlisted one would run another configuration's kernel on a grid and an
+      // LDS size computed for this one (out-of-bounds LDS reads); anything else in the variable is ignored
+      static const int built[][3] = {{0, 2, 8}, {0, 4, 4}, {0, 10, 2}, {256, 1, 16}, {256, 2, 8}, {256, 4, 8}, {256, 8, 3}, {256, 10, 2},
+                                     {512, 4, 8}, {512, 5, 6}, {512, 6, 4}, {1024, 5, 1}};
+      bool ok = false;
+      if (sscanf(e, "%d %d %d", &nt, &ch, &r) == 3)
+        for (const auto& b : built) ok = ok || (b[0] == nt && b[1] == ch && b[2] == r);
+      if (fmt == QF_BF16 && nt == 256 && ch == 10 && r == 3) ok = true;
+      if (ok && (int64_t)(nt ? nt : 256) * ch >= chunks) { *cfg = {nt, ch, r, (nt == 0) ? (ch == 10 ? 1 : 2) : (nt <= 256 ? 2 : 1)}; return true; }
     }
     if (chunks <= 256) { *cfg = {256, 1, 16, 2}; return true; }
     // (the two-halves form, two workgroups per CU: 4.9 / 5.0 TB/s at M = 2000 / 3000 against 4.1 / 4.5 for the barrier form

@@ -116,6 +116,14 @@ class OnlineDetectionModelFPN(nn.Module):
         self.online_mask = None
         self._packed = {}
         self._anchor_cache = {}
+        # load_state_dict copies the parameters in place and never goes through _apply: the packed fc weights are derived
+        # data of the OLD values then (the C4 network guards the same case in _FoldedBN)
+        self.register_load_state_dict_post_hook(OnlineDetectionModelFPN._drop_derived)
+
+    @staticmethod
+    def _drop_derived(module, incompatible_keys):
+        module._packed.clear()
+        module._anchor_cache.clear()
 
     def _apply(self, fn, *a, **kw):
         self._packed.clear()
@@ -215,10 +223,13 @@ class OnlineDetectionModelFPN(nn.Module):
     # ------------------------------------------------------------------ RoI features
     def _fc(self, be, name, x, layer):
         """relu(x W' + b) on the split-f16 tile cores (f32 accuracy), the weight packed once."""
-        w = self._packed.get(name)
-        if w is None:
-            w = self._packed[name] = be.packed(layer.weight.detach().float().contiguous())
-        return be.gemm_h2(be.packed(x), w, bias=layer.bias.detach().float(), relu=True)
+        # keyed on the parameter's storage and in-place version counter as well: an optimiser step, a copy_ into the weight
+        # or a re-assigned Parameter must not be multiplied with the packing of the old values
+        key = (layer.weight.data_ptr(), layer.weight._version)
+        hit = self._packed.get(name)
+        if hit is None or hit[0] != key:
+            hit = self._packed[name] = (key, be.packed(layer.weight.detach().float().contiguous()))
+        return be.gemm_h2(be.packed(x), hit[1], bias=layer.bias.detach().float(), relu=True)
 
     @torch.no_grad()
     def roi_features(self, trunk, boxes):

@@ -170,10 +170,10 @@ class LockstepClassJob:
         return [(Zs_all[k], Ps.get(k), ev) for k in range(len(group))]
 
     # ------------------------------------------------------------------ the schedule
-    def run(self, F, classes=None, phases=None, infos=None):
+    def run(self, F, classes=None, phases=None, infos=None, alphas_out=None):
         """Fit and score `classes` (default: all).  F: Features of this rank's rows.  phases: name -> context manager
-        (bench.py's HIP-event timers) or None; infos: list collecting the Cholesky status words.  Returns (alpha, Zf) of
-        the last class."""
+        (bench.py's HIP-event timers) or None; infos: list collecting the Cholesky status words; alphas_out: optional dict
+        that receives class -> alpha (M,) f64 of every fitted class.  Returns (alpha, Zf) of the last class."""
         be, world, rank = self.be, self.world, self.rank
         classes = list(range(self.C)) if classes is None else list(classes)
         ph = (lambda name: phases[name]) if phases is not None else (lambda name: contextlib.nullcontext())
@@ -205,6 +205,8 @@ class LockstepClassJob:
                 # issued behind this batch's CG in stream order: the factorisations then run beside the MFMA-bound scoring
                 # of this batch and K_nM build of the next, and the HBM-bound passes keep the chip to themselves
                 ready[bi + self.depth] = self._prepare(batches[bi + self.depth], (bi + self.depth) % self.nslot, ph, infos)
+            if alphas_out is not None:
+                alphas_out.update((c, alphas[pos]) for pos, c in enumerate(batch))
             for pos, c in enumerate(batch):
                 with ph("mmv"):
                     be.mmv(F, Zs[pos], self.sigma, alphas[pos], None, out=self.scores[:, c:c + 1])

@@ -28,6 +28,22 @@ def test_committed_bench_line_has_the_contracted_shape():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] < 1
     assert r["traffic"] is None or r["traffic"] > 0
+    if os.path.basename(_newest_bench_line()) >= "r04":
+        # `roofline` is the kernel family with MORE device time in the timed region (not the family of the single biggest kernel)
+        fam = {"mfma": d["roofline_mfma"], "hbm": d["roofline_hbm"]}
+        other = fam["hbm" if r["bound"] == "mfma" else "mfma"]
+        assert r["family_ms_per_step"] >= other["family_ms_per_step"]
+        assert r["kernel"] == fam[r["bound"]]["kernel"] and r["achieved"] == fam[r["bound"]]["achieved"]
+        # the whole step against SURVEY 8(d)'s roofline time: F_K / P_mfma + B_CG / BW_hbm + F_pc / P_mfma(f64)
+        st, cf = d["roofline_step"], d["config"]
+        N, D, M, C = cf["N"], cf["D"], cf["M"], cf["classes"]
+        assert abs(st["F_K_flop"] - 2 * 2.0 * N * M * D * C) <= 1e-9 * st["F_K_flop"]
+        assert abs(st["F_pc_flop"] - (2.0 * M * M * D + float(M) ** 3) * C) <= 1e-9 * st["F_pc_flop"]
+        assert abs(st["B_CG_bytes"] - 21.0 * N * M * st["s_K_bytes_per_entry"] * C) <= 2e-3 * st["B_CG_bytes"]
+        t = (st["F_K_flop"] / (st["peaks"]["mfma_TFLOPs"] * 1e12) + st["B_CG_bytes"] / (st["peaks"]["hbm_GBps"] * 1e9)
+             + st["F_pc_flop"] / (st["peaks"]["mfma_f64_TFLOPs"] * 1e12)) / d["n_gpus"]
+        assert abs(t - st["roofline_time_s"]) < 2e-3 * t
+        assert abs(st["achieved"] - st["roofline_time_s"] / (d["ms_per_step"] / 1e3)) < 2e-3 and 0 < st["achieved"] < 1
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
 

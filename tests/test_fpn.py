@@ -84,6 +84,42 @@ def test_fpn_harvest_loop_on_cpu_with_oracle_backend():
         odx.set_backend(None)
 
 
+def test_fpn_load_state_dict_drops_the_packed_weights():
+    """load_state_dict copies parameters in place without passing through _apply: the packed fc6 / fc7 operands (derived
+    data of the OLD weights) and the anchor cache must not survive it (advisor finding, round 3)."""
+    model = OnlineDetectionModelFPN(width=4, fpn_channels=8, mlp_dim=24, resolution=3).eval()
+    other = OnlineDetectionModelFPN(width=4, fpn_channels=8, mlp_dim=24, resolution=3, seed=5).eval()
+    model._packed["fc6"] = ("stale", object())
+    model._anchor_cache[(0, 1, 1, "cpu")] = object()
+    model.load_state_dict(other.state_dict())
+    assert not model._packed and not model._anchor_cache
+    assert torch.equal(model.fc6.weight, other.fc6.weight)
+
+
+@pytest.mark.gpu
+def test_fpn_features_follow_a_loaded_checkpoint():
+    """Forward, load another checkpoint, forward again: the RoI features are those of a fresh model holding the new weights
+    (the split-core fc6 / fc7 multiply by the weights of the checkpoint, not by a packing made before it was loaded); the
+    same after an in-place change of one weight (the cache is keyed on the parameter's version counter)."""
+    odx.set_backend(None)
+    kw = dict(width=8, fpn_channels=16, mlp_dim=64, pre_nms_top_n=100, post_nms_top_n=20, fpn_post_nms_top_n=40)
+    model = OnlineDetectionModelFPN(seed=1, **kw).eval().cuda()
+    donor = OnlineDetectionModelFPN(seed=2, **kw).eval()
+    fresh = OnlineDetectionModelFPN(seed=2, **kw).eval().cuda()
+    img = torch.randn(1, 3, 192, 256, generator=torch.Generator().manual_seed(0)).cuda()
+    with torch.no_grad():
+        model(img)                                              # fills the packed-weight cache with seed 1's weights
+        model.load_state_dict(donor.state_dict())
+        b1, f1, _ = model(img)
+        b2, f2, _ = fresh(img)
+        assert torch.equal(b1, b2) and torch.equal(f1, f2)
+        model.fc7.weight.mul_(0.5)
+        fresh.fc7.weight.mul_(0.5)
+        fresh._packed.clear()
+        assert torch.equal(model(img)[1], fresh(img)[1])
+        assert not torch.equal(model(img)[1], f1)
+
+
 @pytest.mark.gpu
 def test_fpn_forward_gpu_equals_plain_torch_cpu():
     """The FPN forward on the MI355X — folded batch norm, pyramid, per-level top-k / decode / early-stopping NMS, the

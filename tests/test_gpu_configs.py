@@ -59,6 +59,62 @@ def test_config2_thirty_classes_n1e5_m2000(be):
         assert np.abs(scores[rows, c].cpu().numpy() - pref[:, 0]).max() < 1e-4
 
 
+def test_headline_kernels_alpha_at_m1e4(be):
+    """alpha of the headline's OWN kernels at the headline's own width (round-3 review, item 1): bench.py's synthetic job
+    (same generator, centre rule, sigma = 15, lambda = 1e-5, 20 CG steps) at N = 1e5, D = 1024, **M = 1e4**, storage left on
+    `auto` — 24-bit fixed-point K_nM, gauss_knm_h2w256_kernel with the fused right-hand side, knm_passq_stag_kernel and the
+    folded two-vector pass, the class-batched M = 1e4 preconditioner chain (one chain of 1 class, one of 2), the lock-step
+    schedule of odx/job.py, gauss_mmv_h2w256_kernel — against oracle/falkon_ref.falkon_fit in f64 (8 GB of K_nM on the host):
+    alpha within 1e-4 relative, scores within 1e-4.  The same classes on f32-stored blocks give the price of the 24-bit
+    storage at this size as a number.  (tools/alpha_at_scale.py is this comparison at the full N = 1e6.)"""
+    import bench
+    from odx.job import LockstepClassJob
+    from odx.solver import SolverOptions
+    from oracle import falkon_ref as fr
+    N, D, M, C, sigma, lam = 100_000, 1024, 10_000, 30, 15.0, 1e-5
+    dev = be.device
+    seed = 1234 + 3
+    X = bench.synth_rows(0, N, D, C, seed, dev)
+    cidx = bench.centre_indices(N, C, M, seed)
+    row_ids = torch.arange(N, device=dev)
+    labels = lambda c: torch.where((row_ids % C) == c, 1.0, -1.0).to(torch.float64)            # noqa: E731
+    run = [0, 1, 2]
+    got = {}
+    for storage in ("auto", "f32"):
+        prev, be.knm_storage = be.knm_storage, storage
+        try:
+            assert be.knm_format(N, M) == {"auto": "u24", "f32": "f32"}[storage]
+            assert be.lib.odx_gauss_h2_tile(N, M) == 256
+            infos, alphas = [], {}
+            job = LockstepClassJob(be, X, N, M, labels, [torch.from_numpy(i).to(dev) for i in cidx], sigma, lam, 20,
+                                   SolverOptions(check_pivots=False), classes=len(run))
+            assert job.G == 3                                   # chains: [class 0], then [classes 1, 2] in one batched call
+            job.run(be.features(X), run, infos=infos, alphas_out=alphas)
+            torch.cuda.synchronize()
+            assert [t for t in job.trace if t[0] == "precond"] == [("precond", (0,)), ("precond", (1, 2))]
+            assert len(infos) == 3 and all(int(i.item()) == 0 for i in infos)
+            got[storage] = ({c: alphas[c].cpu().numpy() for c in run}, job.scores[:, :len(run)].cpu().numpy())
+            job.release()
+        finally:
+            be.knm_storage = prev
+        be.release_workspaces()
+        torch.cuda.empty_cache()
+    Xd = X.cpu().numpy().astype(np.float64)
+    srows = np.arange(0, N, 97)
+    report = {}
+    for c in (0, 2):                                            # one class of each chain
+        y = labels(c).cpu().numpy()
+        ref, Z = fr.falkon_fit(Xd, y, cidx[c], sigma, lam, maxiter=20, dtype=np.float64, pc_eps=1e-5, cg_epsilon=1e-7)
+        pref = fr.falkon_predict(Xd[srows], Z, ref, sigma)[:, 0]
+        for storage in ("auto", "f32"):
+            a, sc = got[storage][0][c], got[storage][1][srows, c]
+            report[(c, storage)] = (float(np.linalg.norm(a - ref[:, 0]) / np.linalg.norm(ref[:, 0])), float(np.abs(sc - pref).max()))
+        del ref, Z
+    print("alpha rel err / max score err at M = 1e4:", report)
+    for key, (rel, serr) in report.items():
+        assert rel < 1e-4 and serr < 1e-4, (key, rel, serr, report)
+
+
 def test_config4_mask_pixels_d256_m2000(be):
     """Config 4's shape: one class of the on-line segmentation head, 7 x 7 x 256 mask features as D = 256 pixel rows,
     M = 2000, sigma = 10, a single fit per class (no minibootstrap, run_experiment_online_rpn_ood_oos.py:254) — at
