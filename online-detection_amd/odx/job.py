@@ -7,6 +7,11 @@ the centres of a group's classes are assembled with collectives), which collecti
 runs under gloo on CPU ranks with the tests' oracle backend at world sizes no single-GPU box can host
 (tests/test_dist_gloo.py: 8 ranks, 30 classes -> batches of 8, 8, 8, 6 and preconditioner groups of 1 + 3).
 
+How many classes advance together (b, a divisor of the world size) and how many classes one chain builds per rank (g) come
+from a memory plan (odx/plan.py): b K_nM shards and 2 x g sets of factors per rank must fit the GPU's HBM beside the rows.
+With b < world the owners of consecutive batches rotate through the ranks (a ROUND of world / b batches gives every rank
+one class), and the chain groups are counted in rounds.
+
 The reference has no counterpart (single process, class-by-class loop: OnlineRegionClassifier_incore.py:96-155); the
 arithmetic per class is odx.solver.falkon_fit_lockstep's, i.e. falkon_fit's.
 """
@@ -14,6 +19,7 @@ import contextlib
 
 import torch
 
+from . import plan as _plan
 from . import solver
 from .dist import RowShard
 
@@ -56,19 +62,7 @@ def _wait(ev):
         torch.cuda.current_stream().wait_event(ev)
 
 
-def precond_groups(n_batches, G):
-    """The lock-step batches grouped for the class-batched preconditioner chains: sizes 1, 2, 3 (each only while smaller
-    than G), then G — nothing but the first class's preconditioner is waited for at the start of a job, every later group
-    is built while the group before it is being fitted.  Returns a list of lists of batch indices."""
-    groups, g0 = [], 0
-    for size in (1, 2, 3):
-        if g0 < n_batches and size < G:
-            groups.append(list(range(g0, min(g0 + size, n_batches))))
-            g0 += size
-    while g0 < n_batches:
-        groups.append(list(range(g0, min(g0 + G, n_batches))))
-        g0 += G
-    return groups
+precond_groups = _plan.precond_groups       # (kept under its old name: tests and tools import it from here)
 
 
 class LockstepClassJob:
@@ -76,7 +70,11 @@ class LockstepClassJob:
     row ids of class c's Nystroem centres (identical on every rank)."""
 
     def __init__(self, be, X, n_total, M, labels, centre_idx, sigma, lam, maxiter=20, opt=None, shard=None,
-                 precond_batch=0, precond_depth=2, precond_after_fit=False, classes=None, precond_cus=0):
+                 precond_batch=0, precond_depth=2, precond_after_fit=False, classes=None, precond_cus=0, batch=0,
+                 hbm_bytes=None):
+        """precond_batch: classes per rank and preconditioner chain (g; 0 = planned, 1 = one chain per class on `precond_depth`
+        side streams); batch: classes per lock-step batch (b, a divisor of the world size; 0 = planned); hbm_bytes: the
+        memory the plan may count on per rank (default: the device's, 288 GB without one)."""
         self.be, self.X, self.N, self.M = be, X, int(n_total), int(M)
         self.labels, self.cidx = labels, centre_idx
         self.sigma, self.lam, self.maxiter = sigma, lam, maxiter
@@ -88,16 +86,23 @@ class LockstepClassJob:
         dev = X.device
         self.C = len(centre_idx) if classes is None else int(classes)
         self.ldk = (self.M + 3) // 4 * 4
-        # N x M entries per rank in all: one K_nM shard per class of the batch in flight, in the backend's storage format
+        # The plan (the same on every rank: derived from N, D, M, C, world and the budget only): b K_nM shards — one per
+        # class of the batch in flight, in the backend's storage format — and 2 x g sets of factors per rank.
+        D = int(X.shape[1]) if X.dim() == 2 else 0
+        self.plan = _plan.plan_lockstep(
+            self.N, D, self.M, self.C, self.world, batch=batch, chain=precond_batch,
+            hbm_bytes=hbm_bytes if hbm_bytes is not None else (_plan.device_hbm_bytes(dev) if dev.type == "cuda" else _plan.HBM_BYTES_MI355X),
+            knm_format=(be.knm_format if hasattr(be, "knm_format") else None),
+            knm_bytes=(be.knm_bytes if hasattr(be, "knm_bytes") else None), gauss=getattr(be, "gauss", "h2"))
+        if not self.plan.feasible:
+            raise MemoryError("LockstepClassJob: this job does not fit %d rank(s): %s" % (self.world, self.plan.summary()))
+        self.b, self.G = self.plan.b, self.plan.g
+        self.R = self.world // self.b                   # batches per round (every rank owns one class per round)
         kbytes = be.knm_bytes(self.n_loc, self.M) if hasattr(be, "knm_bytes") else self.n_loc * self.ldk * 4
-        self.kbufs = [torch.empty(max(kbytes, 16), dtype=torch.uint8, device=dev) for _ in range(self.world)]
+        self.kbufs = [torch.empty(max(kbytes, 16), dtype=torch.uint8, device=dev) for _ in range(self.b)]
         self.scores = torch.empty((self.n_loc, self.C), dtype=torch.float32, device=dev)
         self.depth = precond_depth if precond_depth > 0 else 2
         self.after_fit = bool(precond_after_fit)
-        # the group size is derived from the number of lock-step batches (the same on every rank), never from how many
-        # classes this rank happens to own
-        n_batches = (self.C + self.world - 1) // self.world
-        self.G = precond_batch if precond_batch > 0 else max(1, min(6, n_batches))
         self.ld_p = (self.M + 1) // 2 * 2
         self.nslot = self.depth + 1
         self.sides = [_Side(dev, be, precond_cus) for _ in range(self.nslot)] if self.G == 1 else []
@@ -122,39 +127,41 @@ class LockstepClassJob:
         self.shard.allreduce(Z)
         return be.features(Z)
 
-    def _prepare(self, batch, slot, ph, infos):
+    def _prepare(self, batch, owners, slot, ph, infos):
         """Per-class mode (G == 1): centres of the batch's classes (one all-reduce each, main stream) and, on the slot's side
-        stream, the preconditioner of the class this rank owns in the batch (owner = position in the batch)."""
+        stream, the preconditioner of the class this rank owns in the batch."""
         be, dev = self.be, self.X.device
         while len(self.pbuf) < self.nslot:
             self.pbuf.append(torch.empty((4, self.M, self.ld_p), dtype=torch.float64, device=dev))
         Zs = [self.gather_centres(self.cidx[c]) for c in batch]
         P, ev = None, None
-        if self.rank < len(batch):
+        if self.rank in owners:
+            pos = owners.index(self.rank)
             side = self.sides[slot]
             side.after_current()          # the slot's last reader is done, the centres exist
             with side:
                 with ph("precond"):
                     kw = {"out": self.pbuf[slot], "ws_key": "precond%d" % slot} if hasattr(be, "precond_batched") else {}
-                    P = be.precond(Zs[self.rank], self.sigma, self.lam, self.opt.pc_epsilon, **kw)
+                    P = be.precond(Zs[pos], self.sigma, self.lam, self.opt.pc_epsilon, **kw)
                 ev = side.mark()
             if infos is not None and hasattr(P, "info"):
                 infos.append(P.info)
-            self.trace.append(("precond", (batch[self.rank],)))
+            self.trace.append(("precond", (batch[pos],)))
         return Zs, P, ev
 
     def _prepare_group(self, group, slot, ph, infos):
         """Class-batched mode: centres of every class of the group's batches (main stream) and, on the side stream, the
-        preconditioners of the classes this rank owns among them, all by one batched call.  One (Zs, P, event) per batch."""
+        preconditioners of the classes this rank owns among them (at most one per round, g per group), all by one batched
+        call.  group: [(classes, owners)] of the group's batches.  One (Zs, P, event) per batch."""
         be, dev = self.be, self.X.device
-        Zs_all = [[self.gather_centres(self.cidx[c]) for c in batch] for batch in group]
-        own = [k for k, batch in enumerate(group) if self.rank < len(batch)]
+        Zs_all = [[self.gather_centres(self.cidx[c]) for c in batch] for batch, _ in group]
+        own = [(k, owners.index(self.rank)) for k, (_, owners) in enumerate(group) if self.rank in owners]
         Ps, ev = {}, None
         if own:
             self.gside.after_current()    # the slot's last readers were issued, the centres exist
             with self.gside:
                 with ph("precond"):
-                    zf = [Zs_all[k][self.rank] for k in own]
+                    zf = [Zs_all[k][pos] for k, pos in own]
                     if hasattr(be, "precond_batched"):
                         while len(self.pgroup) < 2:
                             self.pgroup.append(torch.empty((self.G, 4, self.M, self.ld_p), dtype=torch.float64, device=dev))
@@ -163,10 +170,10 @@ class LockstepClassJob:
                     else:                 # a backend without the batched chain (tests' oracle backend): one after the other
                         plist = [be.precond(z, self.sigma, self.lam, self.opt.pc_epsilon) for z in zf]
                 ev = self.gside.mark()
-            Ps = dict(zip(own, plist))
+            Ps = dict(zip((k for k, _ in own), plist))
             if infos is not None:
                 infos.extend(p.info for p in plist if hasattr(p, "info"))
-            self.trace.append(("precond", tuple(group[k][self.rank] for k in own)))
+            self.trace.append(("precond", tuple(group[k][0][pos] for k, pos in own)))
         return [(Zs_all[k], Ps.get(k), ev) for k in range(len(group))]
 
     # ------------------------------------------------------------------ the schedule
@@ -177,34 +184,37 @@ class LockstepClassJob:
         be, world, rank = self.be, self.world, self.rank
         classes = list(range(self.C)) if classes is None else list(classes)
         ph = (lambda name: phases[name]) if phases is not None else (lambda name: contextlib.nullcontext())
-        batches = [classes[b0:b0 + world] for b0 in range(0, len(classes), world)]
+        sched = _plan.lockstep_batches(classes, world, self.b)          # [(classes of the batch, their owner ranks)]
         out = None
         if self.G > 1:
-            groups = precond_groups(len(batches), self.G)
+            # chain groups are counted in ROUNDS (R = world / b consecutive batches: one class per rank): sizes 1, 2, 3, then g
+            n_rounds = (len(sched) + self.R - 1) // self.R
+            groups = [[bi for r in grp for bi in range(r * self.R, min((r + 1) * self.R, len(sched)))]
+                      for grp in precond_groups(n_rounds, self.G)]
             first_of = {grp[0]: gi for gi, grp in enumerate(groups)}
-            ready = dict(zip(groups[0], self._prepare_group([batches[bi] for bi in groups[0]], 0, ph, infos)))
+            ready = dict(zip(groups[0], self._prepare_group([sched[bi] for bi in groups[0]], 0, ph, infos)))
         else:
-            ready = {bi: self._prepare(batches[bi], bi % self.nslot, ph, infos) for bi in range(min(self.depth, len(batches)))}
-        for bi, batch in enumerate(batches):
+            ready = {bi: self._prepare(*sched[bi], bi % self.nslot, ph, infos) for bi in range(min(self.depth, len(sched)))}
+        for bi, (batch, owners) in enumerate(sched):
             if self.G > 1:
                 gi = first_of.get(bi)
                 if gi is not None and gi + 1 < len(groups):          # one group ahead, on the side stream
-                    ready.update(zip(groups[gi + 1], self._prepare_group([batches[k] for k in groups[gi + 1]], (gi + 1) % 2, ph, infos)))
-            elif not self.after_fit and bi + self.depth < len(batches):
-                ready[bi + self.depth] = self._prepare(batches[bi + self.depth], (bi + self.depth) % self.nslot, ph, infos)
+                    ready.update(zip(groups[gi + 1], self._prepare_group([sched[k] for k in groups[gi + 1]], (gi + 1) % 2, ph, infos)))
+            elif not self.after_fit and bi + self.depth < len(sched):
+                ready[bi + self.depth] = self._prepare(*sched[bi + self.depth], (bi + self.depth) % self.nslot, ph, infos)
             Zs, P, ev = ready.pop(bi)
             ys = [self.labels(c) for c in batch]
-            mine = rank < len(batch)
+            mine = rank in owners
             self.trace.append(("fit", tuple(batch)))
             alphas = solver.falkon_fit_lockstep(be, F, ys, Zs, self.sigma, self.lam, self.maxiter, self.opt, n_total=self.N,
                                                 shard=self.shard, knm_outs=self.kbufs[:len(batch)],
                                                 phase=(lambda name: phases[name]) if phases is not None else None,
                                                 precond=P if mine else None,
-                                                precond_ready=(lambda: _wait(ev)) if mine else None)
-            if self.G == 1 and self.after_fit and bi + self.depth < len(batches):
+                                                precond_ready=(lambda: _wait(ev)) if mine else None, owners=owners)
+            if self.G == 1 and self.after_fit and bi + self.depth < len(sched):
                 # issued behind this batch's CG in stream order: the factorisations then run beside the MFMA-bound scoring
                 # of this batch and K_nM build of the next, and the HBM-bound passes keep the chip to themselves
-                ready[bi + self.depth] = self._prepare(batches[bi + self.depth], (bi + self.depth) % self.nslot, ph, infos)
+                ready[bi + self.depth] = self._prepare(*sched[bi + self.depth], (bi + self.depth) % self.nslot, ph, infos)
             if alphas_out is not None:
                 alphas_out.update((c, alphas[pos]) for pos, c in enumerate(batch))
             for pos, c in enumerate(batch):

@@ -223,11 +223,12 @@ def falkon_fit(be, F, y, Zf, sigma, lam, maxiter=20, opt=None, n_total=None, all
 
 
 def falkon_fit_lockstep(be, F, ys, Zfs, sigma, lam, maxiter=20, opt=None, n_total=None, shard=None, knm_outs=None,
-                        phase=None, precond=None, precond_ready=None):
+                        phase=None, precond=None, precond_ready=None, owners=None):
     """Fit up to `world` binary problems at once over row shards, one owner rank per problem.
 
-    Problem b (labels ys[b], centres Zfs[b]) is owned by rank b: only that rank holds its preconditioner and CG
-    state.  All problems advance through the same CG schedule in lock step, so one iteration costs every rank
+    Problem b (labels ys[b], centres Zfs[b]) is owned by rank owners[b] (default: rank b): only that rank holds its
+    preconditioner and CG state.  (`owners`: B distinct ranks, the same list on every rank — odx.plan rotates them over
+    the ranks when a batch is smaller than the world, so that the preconditioner work stays balanced.)  All problems advance through the same CG schedule in lock step, so one iteration costs every rank
         its own problem's triangular products                      (all ranks busy: no owner-only serial section)
         one all-gather of the B directions T^-1 A^-1 p             ((world, M) f64)
         B passes over its row shard of the B stored K_nM           (HBM-bound, the bulk)
@@ -237,7 +238,7 @@ def falkon_fit_lockstep(be, F, ys, Zfs, sigma, lam, maxiter=20, opt=None, n_tota
 
     ys, Zfs     lists of B <= world label vectors / centre Features (identical on every rank)
     knm_outs    optional list of B preallocated f32 buffers for the K_nM shards
-    precond     this rank's problem's preconditioner (rank < B), or None to build it here
+    precond     this rank's problem's preconditioner (when it owns one), or None to build it here
     returns     list of B alpha vectors (M,) f64, on every rank
     """
     from .dist import RowShard
@@ -252,26 +253,29 @@ def falkon_fit_lockstep(be, F, ys, Zfs, sigma, lam, maxiter=20, opt=None, n_tota
     if any(z.n != M for z in Zfs):
         raise ValueError("falkon_fit_lockstep: every problem needs the same number of centres")
     ph = phase if phase is not None else (lambda name: _NoPhase())
-    owned = rank < B
+    owners = list(range(B)) if owners is None else [int(o) for o in owners]
+    if len(owners) != B or len(set(owners)) != B or any(not 0 <= o < world for o in owners):
+        raise ValueError("falkon_fit_lockstep: owners must be %d distinct ranks below %d, got %r" % (B, world, owners))
+    owned = rank in owners
     P = precond
     if owned and P is None:
         with ph("precond"):
-            P = be.precond(Zfs[rank], sigma, lam, opt.pc_epsilon)
+            P = be.precond(Zfs[owners.index(rank)], sigma, lam, opt.pc_epsilon)
     Mp = (M + 1) // 2 * 2                             # rows of the exchanged matrices stay 16-byte aligned
-    Tall = be.zeros(world * Mp).view(world, Mp)       # gathered directions
-    CC = be.zeros(world * Mp).view(world, Mp)         # this rank's partials, one row per problem
+    Tall = be.zeros(world * Mp).view(world, Mp)       # gathered directions: row r = the direction of the problem rank r owns
+    CC = be.zeros(world * Mp).view(world, Mp)         # this rank's partials: row r = its partial of the problem rank r owns
     Ks = []
     for b in range(B):
         with ph("knm"):                               # K_nM shard and this shard's K' (y / n) of problem b in one launch
             Ks.append(be.knm_rhs(F, Zfs[b], sigma, ys[b] * (1.0 / n), out=None if knm_outs is None else knm_outs[b],
-                                 rhs_out=CC[b, :M])[0])
+                                 rhs_out=CC[owners[b], :M])[0])
     tbuf, ccbuf, v = be.zeros(Mp), be.zeros(Mp), be.zeros(M)
     t, cc = tbuf[:M], ccbuf[:M]
 
     def passes():
         for b in range(B):
             with ph("ktk"):
-                be.ktk(Ks[b], v=Tall[b, :M], out=CC[b, :M])
+                be.ktk(Ks[b], v=Tall[owners[b], :M], out=CC[owners[b], :M])
         return shard.reduce_scatter_rows(CC, ccbuf)
 
     def mmv(s, out):
@@ -301,7 +305,8 @@ def falkon_fit_lockstep(be, F, ys, Zfs, sigma, lam, maxiter=20, opt=None, n_tota
         shard.gather_rows(tbuf2, Tall2)
         for b in range(B):
             with ph("ktk2"):
-                be.ktk2(Ks[b], Tall2[b, :M], Tall2[b, Mp:Mp + M], out1=CC2[b, :M], out2=CC2[b, Mp:Mp + M])
+                o = owners[b]
+                be.ktk2(Ks[b], Tall2[o, :M], Tall2[o, Mp:Mp + M], out1=CC2[o, :M], out2=CC2[o, Mp:Mp + M])
         shard.reduce_scatter_rows(CC2, ccbuf2)
         if owned:
             u = be.trmv(P, "LTi", ccbuf2[:M], alpha=1.0 / n, beta=lam, z=v)
@@ -346,4 +351,4 @@ def falkon_fit_lockstep(be, F, ys, Zfs, sigma, lam, maxiter=20, opt=None, n_tota
         if opt.check_pivots:
             _check_pivots(be, P)
     shard.gather_rows(tbuf, Tall)
-    return [Tall[b, :M].clone() for b in range(B)]
+    return [Tall[owners[b], :M].clone() for b in range(B)]

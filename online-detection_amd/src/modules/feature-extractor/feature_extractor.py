@@ -13,8 +13,12 @@ and load Detectron weights; datasets, weights and that package are outside this 
                             serves the detector's features / heads; the reference defines its on-line RPN and mask heads
                             on R-50-C4 only
     cfg_options['shard_images']  True: under a multi-process launcher each rank harvests only its images (rank::world);
-                                 default False — every rank sees every image, so the drop-in trainers downstream (which
-                                 are not sharded) build identical models on all ranks
+                                 False — every rank sees every image, so the drop-in trainers downstream (which
+                                 are not sharded) build identical models on all ranks.  Default: True exactly when the
+                                 caller hands in the row shard it trains with (cfg_options['shard'], an odx.dist.RowShard
+                                 over more than one rank), False otherwise
+    cfg_options['shard']         the odx.dist.RowShard the caller's sharded trainers use (falkon_fit(shard=),
+                                 RegionRefinerTrainer(shard=)): images are then split over its ranks by default
     cfg_options['trunk_batch']   images of one size that share a trunk call in the harvest loop (default 2; 1 = one image
                                  per call).  With > 1 an image's features depend on its neighbour in the list in the
                                  last bits (the convolution library picks its algorithm per batch size) and so differ
@@ -112,9 +116,22 @@ class FeatureExtractor(FeatureExtractorAbstract):
         # given, so a silent split would train every rank's models on 1 / world of the data.  With the option every rank
         # returns the rows of its own images (rank::world) and the caller is responsible for training on shards
         # (odx.solver.falkon_fit(shard=...), RegionRefinerTrainer(shard=...)) — the multi-GPU route bench.py exercises.
+        # When the caller DOES shard its training — it hands in the odx.dist.RowShard it trains with as cfg_options['shard']
+        # (an initialised process group of more than one rank) — the split is the default: the rows a rank harvests are then
+        # its row shard of the fit, which is the design (north star: "the backbone forward shards over images the same way").
+        # An explicit cfg_options['shard_images'] = False / True always wins.
         rank, world = 0, 1
-        if cfg_options.get('shard_images'):
-            rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+        shard = cfg_options.get('shard')
+        want = cfg_options.get('shard_images')
+        if want is None:
+            want = shard is not None and getattr(shard, 'world', 1) > 1
+        if want:
+            if shard is not None and getattr(shard, 'world', 1) > 1:
+                rank, world = int(shard.rank), int(shard.world)
+            elif torch.distributed.is_available() and torch.distributed.is_initialized():
+                rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+            else:
+                rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
         num_classes = _mb(cfg, 'NUM_CLASSES', cfg_options.get('num_classes', 30))
         det_kw = self._kw(cfg, 'DETECTOR')
         det_kw['reg_min_overlap'] = (cfg.get('REGRESSORS') or {}).get('MIN_OVERLAP', 0.6)

@@ -234,7 +234,7 @@ def test_class_sharded_minibootstrap_equals_single_process(world, tmp_path):
             assert M == ref[c].M and sigma == 6.0
 
 
-def _job_worker(rank, world, port, N, D, M, C, ret):
+def _job_worker(rank, world, port, N, D, M, C, ret, batch=0, chain=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -250,10 +250,11 @@ def _job_worker(rank, world, port, N, D, M, C, ret):
         lo, hi = shard.bounds(N)
         row_ids = torch.arange(lo, hi)
         job = LockstepClassJob(be, torch.from_numpy(X[lo:hi]), N, M, lambda c: torch.where((row_ids % C) == c, 1.0, -1.0).double(),
-                               [torch.from_numpy(i) for i in cidx], 6.0, 1e-4, 20, shard=shard)
+                               [torch.from_numpy(i) for i in cidx], 6.0, 1e-4, 20, shard=shard, batch=batch, precond_batch=chain)
         F = be.features(job.X)
         alpha, _ = job.run(F)
-        ret[rank] = {"scores": job.scores.numpy().copy(), "trace": list(job.trace), "G": job.G, "alpha_last": alpha.numpy().copy()}
+        ret[rank] = {"scores": job.scores.numpy().copy(), "trace": list(job.trace), "G": job.G, "alpha_last": alpha.numpy().copy(),
+                     "b": job.b, "kbufs": len(job.kbufs)}
     finally:
         dist.destroy_process_group()
 
@@ -308,3 +309,41 @@ def test_headline_control_flow_on_eight_ranks():
         want = fr.falkon_predict(Xd, Z, a, 6.0)[:, 0]
         assert np.abs(scores[:, c] - want).max() < 1e-6 * max(1.0, np.abs(want).max()), c
     assert (scores.argmax(1) == np.arange(N) % C).mean() > 0.9
+
+
+@pytest.mark.parametrize("b,chain", [(2, 2), (4, 0)])
+def test_lockstep_batches_smaller_than_the_world(b, chain):
+    """The memory plan's other shape (odx/plan.py): lock-step batches of b < world classes — b K_nM shards per rank instead
+    of `world` — whose owners rotate through the ranks, so that every ROUND of world / b batches gives each rank one class;
+    the preconditioner chains are grouped in rounds.  8 gloo ranks, 30 classes, b = 2 (15 batches, rounds of 4) and b = 4 (8
+    batches, rounds of 2): every rank runs exactly that schedule, holds b shard buffers, builds only the preconditioners of
+    the classes it owns, and the scores of all classes equal a single process fitting them one after the other."""
+    from odx import plan
+    from oracle import falkon_ref as fr
+    N, D, M, C, world = 1600, 16, 40, 30, 8
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_job_worker, args=(world, port, N, D, M, C, ret, b, chain), nprocs=world, join=True)
+    sched = plan.lockstep_batches(range(C), world, b)
+    R = world // b
+    n_rounds = (len(sched) + R - 1) // R
+    owned_by = {r: [c for batch, owners in sched for c, o in zip(batch, owners) if o == r] for r in range(world)}
+    assert sorted(c for cs in owned_by.values() for c in cs) == list(range(C))          # every class has exactly one owner
+    assert max(len(v) for v in owned_by.values()) - min(len(v) for v in owned_by.values()) <= 1       # balanced
+    for r in range(world):
+        t = ret[r]["trace"]
+        assert ret[r]["b"] == b and ret[r]["kbufs"] == b
+        g = ret[r]["G"]
+        assert g == (chain or min(6, n_rounds))
+        assert [p for k, p in t if k == "fit"] == [tuple(batch) for batch, _ in sched]
+        built = [c for k, p in t if k == "precond" for c in p]
+        assert built == owned_by[r], (r, built, owned_by[r])
+        assert all(len(p) <= g for k, p in t if k == "precond")                         # at most g classes per chain
+    scores = np.concatenate([ret[r]["scores"] for r in range(world)], axis=0)
+    X, cidx = _job_problem(N, D, M, C)
+    Xd = X.astype(np.float64)
+    for c in (0, 1, 2, 7, 8, 15, 28, 29):
+        y = np.where(np.arange(N) % C == c, 1.0, -1.0)
+        a, Z = fr.falkon_fit(Xd, y, cidx[c], 6.0, 1e-4, maxiter=20, dtype=np.float64, pc_eps=1e-5, cg_epsilon=1e-7)
+        want = fr.falkon_predict(Xd, Z, a, 6.0)[:, 0]
+        assert np.abs(scores[:, c] - want).max() < 1e-6 * max(1.0, np.abs(want).max()), c

@@ -449,6 +449,24 @@ def test_dropin_feature_extractor_shards_images_only_on_request(monkeypatch):
             out[shard] = sum(len(p) for p in pos)
         assert out[False] == sum(len(s[2]) for s in samples)                # every ground-truth box of every image
         assert out[True] == sum(len(s[2]) for s in samples[1::2])           # rank 1 of 2: images 1 and 3
+        # a caller that shards its training hands in its RowShard: the images are then split by default (and an explicit
+        # False still gives every rank every image)
+        import types
+        monkeypatch.delenv("RANK")
+        monkeypatch.delenv("WORLD_SIZE")
+        shard3 = types.SimpleNamespace(rank=2, world=3)
+        for explicit, want in ((None, samples[2::3]), (False, samples)):
+            opts = {"samples": samples, "model": model, "num_classes": 2, "shard": shard3}
+            if explicit is not None:
+                opts["shard_images"] = explicit
+            torch.manual_seed(0)
+            with redirect_stdout(io.StringIO()):
+                neg, pos, COXY = fe_mod.FeatureExtractor().extractFeatures(True, cfg_options=opts)
+            assert sum(len(p) for p in pos) == sum(len(s[2]) for s in want)
+        one = types.SimpleNamespace(rank=0, world=1)                         # a one-rank "shard": nothing to split
+        with redirect_stdout(io.StringIO()):
+            neg, pos, COXY = fe_mod.FeatureExtractor().extractFeatures(True, cfg_options={"samples": samples, "model": model, "num_classes": 2, "shard": one})
+        assert sum(len(p) for p in pos) == sum(len(s[2]) for s in samples)
     finally:
         odx.set_backend(None)
 

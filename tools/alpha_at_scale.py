@@ -62,28 +62,14 @@ def gpu_fit(be, F, y, Zf, sigma, lam, maxiter, storage):
     return alpha, scores, fmt, dt
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--rows", dest="n", type=int, default=1_000_000)
-    ap.add_argument("--dim", dest="D", type=int, default=1024)
-    ap.add_argument("--centres", dest="M", type=int, default=10_000)
-    ap.add_argument("--classes", type=int, default=30, help="classes of the synthetic job (positives of class c: rows i % classes == c)")
-    ap.add_argument("--classes-run", type=int, nargs="*", default=[0], help="which classes to fit and compare")
-    ap.add_argument("--sigma", type=float, default=15.0)
-    ap.add_argument("--lam", type=float, default=1e-5)
-    ap.add_argument("--maxiter", type=int, default=20)
-    ap.add_argument("--storages", nargs="*", default=["auto", "f32"])
-    ap.add_argument("--oracle", choices=("auto", "stored", "blocked"), default="auto")
-    ap.add_argument("--out", default=None)
-    args = ap.parse_args()
-
+def compare(N, D=1024, M=10_000, C=30, classes_run=(0,), storages=("auto", "f32"), sigma=15.0, lam=1e-5, maxiter=20, oracle="auto",
+            log=None):
+    """The comparison as a function (tests/test_gpu_configs.py runs it at the full N): returns the result dict."""
     import bench
     import odx
     from oracle import falkon_ref as fr
-    torch.cuda.set_device(0)
     be = odx.get_backend()
-    dev = torch.device("cuda", 0)
-    N, D, M, C = args.n, args.D, args.M, args.classes
+    dev = be.device
     seed = 1234 + 3
     X = bench.synth_rows(0, N, D, C, seed, dev)
     cidx = bench.centre_indices(N, C, M, seed)
@@ -92,24 +78,24 @@ def main():
     Xh = X.cpu().numpy().astype(np.float64)
     need = 8.0 * N * M + 2.0 * 8 * M * M * 3
     free = host_free_bytes()
-    stored = args.oracle == "stored" or (args.oracle == "auto" and free > 1.15 * need + 8e9)
+    stored = oracle == "stored" or (oracle == "auto" and free > 1.15 * need + 8e9)
     res = {"workload": "one-vs-rest FALKON fit + score-all of bench.py's synthetic job, N=%d D=%d M=%d sigma=%g lambda=%g, %d CG steps"
-                       % (N, D, M, args.sigma, args.lam, args.maxiter),
+                       % (N, D, M, sigma, lam, maxiter),
            "oracle": "oracle/falkon_ref.falkon_fit, f64, %s" % ("stored K_nM (%.0f GB)" % (8.0 * N * M / 1e9) if stored else "row-blocked (K recomputed per product)"),
            "host": {"cores": os.cpu_count(), "mem_available_GB": round(free / 1e9, 1)}, "classes": {}}
     srows = np.unique(np.concatenate([np.arange(0, N, max(1, N // 4000)), np.arange(0, min(N, 300)), np.arange(max(0, N - 300), N)]))
-    for c in args.classes_run:
+    for c in classes_run:
         y = torch.where((row_ids % C) == c, 1.0, -1.0).to(torch.float64)
         Zf = be.features(X.index_select(0, torch.from_numpy(cidx[c]).to(dev)))
         t0 = time.perf_counter()
-        a_ref, Zh = fr.falkon_fit(Xh, y.cpu().numpy(), cidx[c], args.sigma, args.lam, maxiter=args.maxiter, dtype=np.float64,
+        a_ref, Zh = fr.falkon_fit(Xh, y.cpu().numpy(), cidx[c], sigma, lam, maxiter=maxiter, dtype=np.float64,
                                   pc_eps=1e-5, cg_epsilon=1e-7, store_knm=stored, row_block=16384)
         t_or = time.perf_counter() - t0
-        p_ref = fr.falkon_predict(Xh[srows], Zh, a_ref, args.sigma)[:, 0]
+        p_ref = fr.falkon_predict(Xh[srows], Zh, a_ref, sigma)[:, 0]
         entry = {"oracle_s": round(t_or, 1), "alpha_norm": float(np.linalg.norm(a_ref)), "score_scale": float(np.abs(p_ref).max())}
         got = {}
-        for st in args.storages:
-            alpha, scores, fmt, dt = gpu_fit(be, F, y, Zf, args.sigma, args.lam, args.maxiter, st)
+        for st in storages:
+            alpha, scores, fmt, dt = gpu_fit(be, F, y, Zf, sigma, lam, maxiter, st)
             a = got[st] = alpha.cpu().numpy()
             entry[st] = {"stored_as": fmt, "gpu_s": round(dt, 3),
                          "alpha_rel_err": float(np.linalg.norm(a - a_ref[:, 0]) / np.linalg.norm(a_ref[:, 0])),
@@ -120,7 +106,29 @@ def main():
         if "auto" in got and "f32" in got:
             entry["alpha_rel_diff_auto_vs_f32_storage"] = float(np.linalg.norm(got["auto"] - got["f32"]) / np.linalg.norm(got["f32"]))
         res["classes"][str(c)] = entry
-        print("class %d: %s" % (c, json.dumps(entry)), file=sys.stderr, flush=True)
+        if log is not None:
+            print("class %d: %s" % (c, json.dumps(entry)), file=log, flush=True)
+        del a_ref, Zh
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", dest="n", type=int, default=1_000_000)
+    ap.add_argument("--dim", dest="D", type=int, default=1024)
+    ap.add_argument("--centres", dest="M", type=int, default=10_000)
+    ap.add_argument("--classes", type=int, default=30, help="classes of the synthetic job (positives of class c: rows i %% classes == c)")
+    ap.add_argument("--classes-run", type=int, nargs="*", default=[0], help="which classes to fit and compare")
+    ap.add_argument("--sigma", type=float, default=15.0)
+    ap.add_argument("--lam", type=float, default=1e-5)
+    ap.add_argument("--maxiter", type=int, default=20)
+    ap.add_argument("--storages", nargs="*", default=["auto", "f32"])
+    ap.add_argument("--oracle", choices=("auto", "stored", "blocked"), default="auto")
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    torch.cuda.set_device(0)
+    res = compare(args.n, args.D, args.M, args.classes, args.classes_run, args.storages, args.sigma, args.lam, args.maxiter,
+                  args.oracle, log=sys.stderr)
     line = json.dumps(res)
     print(line, flush=True)
     if args.out:
