@@ -407,6 +407,9 @@ __global__ __launch_bounds__(256) void mmv_reduce_kernel(const double* __restric
 // of 8 lanes writes the 8 slots of one row.
 constexpr int W_BM = 256, W_BN = 256, W_THREADS = 512;
 constexpr int W_KS = 32;                                  // features per stage (one granule)
+#ifndef ODX_W_DMA
+#define ODX_W_DMA 1                                       // operand staging: 1 = LDS-DMA (w_mainloop_dma), 0 = through registers
+#endif
 constexpr int W_ROW = 128;                                // bytes per LDS row
 constexpr int W_OPND_BYTES = W_BM * W_ROW;                // 32,768
 constexpr int W_STAGE_BYTES = 2 * W_OPND_BYTES;           // 65,536
@@ -575,6 +578,130 @@ __device__ __forceinline__ void w_mainloop(f32x4 (&acc)[8][4], const uint32_t* _
   w_stage<false, false, CORE>(acc, st, lds + (s & 1) * W_STAGE_BYTES, lds, ta, tb, ad);
 }
 
+// ---- the same stage pipeline with the operands staged by LDS-DMA (buffer_load_dwordx4 ... lds) instead of through registers.
+// A wave-instruction of the DMA fills 1 KiB of LDS — 8 rows of the image — as wave-uniform base + lane * 16: lane l lands in
+// slot l & 7 of image row 8 P + (l >> 3), so the XOR swizzle of the image is applied on the SOURCE side (the lane fetches chunk
+// (l & 7) ^ ((row >> 1) & 7) of its row: the same 128-byte line, its 16-byte pieces permuted).  Wave w moves pieces w, w + 8,
+// w + 16, w + 24 of each operand: 8 DMAs per wave and stage, no staging registers (32 fewer VGPRs), no ds_write (a quarter
+// of the LDS instructions, none of the 13-cycle register -> LDS transfers).  The freed registers hold the NEXT part's A
+// fragments, read before the current part's MFMAs are issued, so that no MFMA waits for an LDS read inside a stage.
+// Stage s + 1 is fetched into the other buffer during stage s; every wave waits for its own DMAs (vmcnt(0)) before the
+// barrier that ends the stage — nothing else orders a ds_read behind an LDS-DMA.  Rows are addressed through one buffer
+// descriptor per operand (tile base, rows clamped to the operand's last row as in w_row_offsets), the stage on the scalar
+// offset: no vector address arithmetic in the loop.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <bool PERM>
+__device__ __forceinline__ void w_dma_offsets(uint32_t (&voff)[4], int64_t ld, int64_t row0, int64_t nrows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t l64 = nrows - 1 - row0;               // >= 0: the tile starts inside the operand
+  const int last = l64 < W_BM - 1 ? (int)l64 : W_BM - 1;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int ri = 8 * wave + 64 * p + (lane >> 3);    // image row this lane fills
+    const int r = PERM ? ((ri & ~63) | ((ri & 15) << 2) | ((ri >> 4) & 3)) : ri;
+    const int q = (lane & 7) ^ ((ri >> 1) & 7);        // chunk of the row that belongs in slot lane & 7
+    voff[p] = ((uint32_t)(r < last ? r : last) * (uint32_t)ld + (uint32_t)q * 4u) * 4u;      // bytes
+  }
+}
+
+struct WDma {
+  __amdgpu_buffer_rsrc_t ra, rb;
+  uint32_t va[4], vb[4];       // per-lane byte offsets of this wave's four 8-row pieces of each operand
+  int fa, fb, hi, lo;          // LDS: fragment rows of this lane in the A / B image, hi / lo chunk inside a row
+};
+
+// the two pieces `q0`, `q0 + 1` (0..7: A pieces 0..3, B pieces 0..3) of stage `koff` (bytes into the rows) -> image `dst`
+__device__ __forceinline__ void w_dma_pair(const WDma& ad, char* dst, int koff, int q0) {
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = q0; q < q0 + 2; ++q) {
+    char* d = dst + (q >> 2) * W_OPND_BYTES + wave * 1024 + (q & 3) * 8192;
+    if (q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(ad.ra, (lds_ptr_t)d, 16, ad.va[q & 3], koff, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(ad.rb, (lds_ptr_t)d, 16, ad.vb[q & 3], koff, 0, 0);
+  }
+}
+
+template <int CORE>
+__device__ __forceinline__ void w_mfma_part(f32x4 (&acc)[8][4], const f16x8 (&ah)[2], const f16x8 (&al)[2], const f16x8 (&bh)[4],
+                                            const f16x8 (&bl)[4], int tm0) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int tm = tm0 + u;
+    if (CORE == CORE_F8) {
+      const i32x8 a8 = f8_frag(ah[u], al[u]);
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, f8_frag(bh[tn], bl[tn]), acc[tm][tn], 0, 0, 0,
+                                                                        F8_SCALE_ONE, 0, F8_SCALE_ONE);
+    } else {
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u], bh[tn], acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], bl[tn], acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], bh[tn], acc[tm][tn], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// FETCH: stage s + 1 exists and is fetched into `nxt` (two DMAs per part, in front of the part's MFMAs)
+template <bool FETCH, int CORE>
+__device__ __forceinline__ void w_stage_dma(f32x4 (&acc)[8][4], const char* cur, char* nxt, int koff_next, const WDma& ad) {
+  f16x8 bh[4], bl[4], ah[2][2], al[2][2];
+  const char* pa = cur + ad.fa;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    ah[0][u] = *reinterpret_cast<const f16x8*>(pa + u * 16 * W_ROW + ad.hi);
+    al[0][u] = *reinterpret_cast<const f16x8*>(pa + u * 16 * W_ROW + ad.lo);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    bh[t] = *reinterpret_cast<const f16x8*>(cur + ad.fb + t * 16 * W_ROW + ad.hi);
+    bl[t] = *reinterpret_cast<const f16x8*>(cur + ad.fb + t * 16 * W_ROW + ad.lo);
+  }
+#pragma unroll
+  for (int part = 0; part < 4; ++part) {
+    if (part < 3) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        ah[(part + 1) & 1][u] = *reinterpret_cast<const f16x8*>(pa + (2 * part + 2 + u) * 16 * W_ROW + ad.hi);
+        al[(part + 1) & 1][u] = *reinterpret_cast<const f16x8*>(pa + (2 * part + 2 + u) * 16 * W_ROW + ad.lo);
+      }
+    }
+    if (FETCH) w_dma_pair(ad, nxt, koff_next, 2 * part);
+    w_mfma_part<CORE>(acc, ah[part & 1], al[part & 1], bh, bl, 2 * part);
+  }
+  __syncthreads();          // (with DMAs in flight the compiler puts s_waitcnt vmcnt(0) in front of the barrier: what is needed)
+}
+
+template <bool PERMB = false, int CORE = CORE_H2>
+__device__ __forceinline__ void w_mainloop_dma(f32x4 (&acc)[8][4], const uint32_t* __restrict__ A, int64_t lda, int64_t m,
+                                               const uint32_t* __restrict__ B, int64_t ldb, int64_t n, int64_t i0, int64_t j0,
+                                               int stages, char* lds) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  WDma ad;
+  w_dma_offsets<false>(ad.va, lda, i0, m);
+  w_dma_offsets<PERMB>(ad.vb, ldb, j0, n);
+  const int64_t la = m - i0 < W_BM ? m - i0 : W_BM, lb = n - j0 < W_BN ? n - j0 : W_BN;       // rows of the tile that exist
+  ad.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(A + i0 * lda), (short)0, (int)(la * lda * 4), 0x00020000);
+  ad.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(B + j0 * ldb), (short)0, (int)(lb * ldb * 4), 0x00020000);
+  const int r = lane & 15, g = lane >> 4;
+  ad.hi = ((g ^ ((r >> 1) & 7)) << 4);
+  ad.lo = ad.hi ^ 64;
+  ad.fa = (wr * 128 + r) * W_ROW;
+  ad.fb = W_OPND_BYTES + (wc * 64 + r) * W_ROW;
+  // (the caller's last use of the LDS ended on a barrier)
+#pragma unroll
+  for (int q0 = 0; q0 < 8; q0 += 2) w_dma_pair(ad, lds, 0, q0);
+  __syncthreads();
+  int s = 0;
+  for (; s + 1 < stages; ++s)
+    w_stage_dma<true, CORE>(acc, lds + (s & 1) * W_STAGE_BYTES, lds + ((s + 1) & 1) * W_STAGE_BYTES, (s + 1) * (W_KS * 4), ad);
+  w_stage_dma<false, CORE>(acc, lds + (s & 1) * W_STAGE_BYTES, lds, 0, ad);
+}
+
 __device__ __forceinline__ void w_zero(f32x4 (&acc)[8][4]) {
 #pragma unroll
   for (int tm = 0; tm < 8; ++tm)
@@ -692,7 +819,8 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_knm_h2w256_kernel(
 
   f32x4 acc[8][4];
   w_zero(acc);
-  w_mainloop<true, CORE>(acc, PX, ldpx, n, PZ, ldpz, M, i0, j0, stages, lds);      // its barriers also publish xg_s
+  if (ODX_W_DMA) w_mainloop_dma<true, CORE>(acc, PX, ldpx, n, PZ, ldpz, M, i0, j0, stages, lds);      // its barriers also publish xg_s
+  else w_mainloop<true, CORE>(acc, PX, ldpx, n, PZ, ldpz, M, i0, j0, stages, lds);
 
   const float m2g = -2.f / (metax[0] * metaz[0]) * gamma_log2e;    // the scales are powers of two: m2 is exact
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -793,7 +921,8 @@ __global__ __launch_bounds__(W_THREADS, 1) void gemm_h2w256_kernel(
   w_zero(acc);
   // B rows in the permuted order of the K_nM builds: a lane holds four ADJACENT output columns 64 wc + 4 (lane & 15) + tn
   // of each of its rows, and stores them (loads bias / residual) 16 bytes at a time when the matrices allow it
-  w_mainloop<true>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds);
+  if (ODX_W_DMA) w_mainloop_dma<true>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds);
+  else w_mainloop<true>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds);
   const float inv = 1.f / (metaa[0] * metab[0]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 2, wc = wave & 3;
@@ -870,7 +999,8 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_mmv_h2w256_kernel(
   for (int64_t j0 = s0; j0 < s1; j0 += W_BN) {
     f32x4 acc[8][4];
     w_zero(acc);
-    w_mainloop<false, CORE>(acc, PX, ldpx, n, PZ + j0 * ldpz, ldpz, r1 - j0, i0, 0, stages, lds);
+    if (ODX_W_DMA) w_mainloop_dma<false, CORE>(acc, PX, ldpx, n, PZ + j0 * ldpz, ldpz, r1 - j0, i0, 0, stages, lds);
+    else w_mainloop<false, CORE>(acc, PX, ldpx, n, PZ + j0 * ldpz, ldpz, r1 - j0, i0, 0, stages, lds);
     float zs[4];
     double al[4];
 #pragma unroll
