@@ -407,9 +407,7 @@ __global__ __launch_bounds__(256) void mmv_reduce_kernel(const double* __restric
 // of 8 lanes writes the 8 slots of one row.
 constexpr int W_BM = 256, W_BN = 256, W_THREADS = 512;
 constexpr int W_KS = 32;                                  // features per stage (one granule)
-#ifndef ODX_W_DMA
-#define ODX_W_DMA 1                                       // operand staging: 1 = LDS-DMA (w_mainloop_dma), 0 = through registers
-#endif
+enum { STG_REG = 0, STG_DMA = 1 };                        // operand staging: through registers (w_mainloop) or by LDS-DMA (w_mainloop_dma)
 constexpr int W_ROW = 128;                                // bytes per LDS row
 constexpr int W_OPND_BYTES = W_BM * W_ROW;                // 32,768
 constexpr int W_STAGE_BYTES = 2 * W_OPND_BYTES;           // 65,536
@@ -611,11 +609,12 @@ struct WDma {
   int fa, fb, hi, lo;          // LDS: fragment rows of this lane in the A / B image, hi / lo chunk inside a row
 };
 
-// the two pieces `q0`, `q0 + 1` (0..7: A pieces 0..3, B pieces 0..3) of stage `koff` (bytes into the rows) -> image `dst`
-__device__ __forceinline__ void w_dma_pair(const WDma& ad, char* dst, int koff, int q0) {
-  const int wave = threadIdx.x >> 6;
+// pieces q0 .. q1 - 1 (0..7: A pieces 0..3, B pieces 0..3) of stage `koff` (bytes into the rows) -> image `dst`
+template <int Q0, int Q1>
+__device__ __forceinline__ void w_dma_pieces(const WDma& ad, char* dst, int koff) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
-  for (int q = q0; q < q0 + 2; ++q) {
+  for (int q = Q0; q < Q1; ++q) {
     char* d = dst + (q >> 2) * W_OPND_BYTES + wave * 1024 + (q & 3) * 8192;
     if (q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(ad.ra, (lds_ptr_t)d, 16, ad.va[q & 3], koff, 0, 0);
     else __builtin_amdgcn_raw_ptr_buffer_load_lds(ad.rb, (lds_ptr_t)d, 16, ad.vb[q & 3], koff, 0, 0);
@@ -645,34 +644,108 @@ __device__ __forceinline__ void w_mfma_part(f32x4 (&acc)[8][4], const f16x8 (&ah
   }
 }
 
-// FETCH: stage s + 1 exists and is fetched into `nxt` (two DMAs per part, in front of the part's MFMAs)
-template <bool FETCH, int CORE>
-__device__ __forceinline__ void w_stage_dma(f32x4 (&acc)[8][4], const char* cur, char* nxt, int koff_next, const WDma& ad) {
-  f16x8 bh[4], bl[4], ah[2][2], al[2][2];
-  const char* pa = cur + ad.fa;
+struct WFrag {
+  f16x8 bh[4], bl[4];       // the stage's B fragments (4 column blocks)
+  f16x8 a0h[2], a0l[2];     // A fragments of parts 0 and 2 (2 row blocks each)
+  f16x8 a1h[2], a1l[2];     // A fragments of parts 1 and 3
+};
+
+__device__ __forceinline__ void w_read_b1(WFrag& f, const char* img, const WDma& ad, int t) {
+  f.bh[t] = *reinterpret_cast<const f16x8*>(img + ad.fb + t * 16 * W_ROW + ad.hi);
+  f.bl[t] = *reinterpret_cast<const f16x8*>(img + ad.fb + t * 16 * W_ROW + ad.lo);
+}
+
+__device__ __forceinline__ void w_read_a(f16x8 (&ah)[2], f16x8 (&al)[2], const char* img, const WDma& ad, int part) {
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    ah[0][u] = *reinterpret_cast<const f16x8*>(pa + u * 16 * W_ROW + ad.hi);
-    al[0][u] = *reinterpret_cast<const f16x8*>(pa + u * 16 * W_ROW + ad.lo);
+    ah[u] = *reinterpret_cast<const f16x8*>(img + ad.fa + (2 * part + u) * 16 * W_ROW + ad.hi);
+    al[u] = *reinterpret_cast<const f16x8*>(img + ad.fa + (2 * part + u) * 16 * W_ROW + ad.lo);
   }
+}
+
+// the MFMAs of row blocks tm0, tm0 + 1 against column block tn (every accumulator sees its products in the same order
+// whatever the order of the blocks: the sums do not depend on the schedule)
+template <int CORE>
+__device__ __forceinline__ void w_mfma_col(f32x4 (&acc)[8][4], const f16x8 (&ah)[2], const f16x8 (&al)[2], const f16x8& bh,
+                                           const f16x8& bl, int tm0, int tn) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    bh[t] = *reinterpret_cast<const f16x8*>(cur + ad.fb + t * 16 * W_ROW + ad.hi);
-    bl[t] = *reinterpret_cast<const f16x8*>(cur + ad.fb + t * 16 * W_ROW + ad.lo);
-  }
-#pragma unroll
-  for (int part = 0; part < 4; ++part) {
-    if (part < 3) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        ah[(part + 1) & 1][u] = *reinterpret_cast<const f16x8*>(pa + (2 * part + 2 + u) * 16 * W_ROW + ad.hi);
-        al[(part + 1) & 1][u] = *reinterpret_cast<const f16x8*>(pa + (2 * part + 2 + u) * 16 * W_ROW + ad.lo);
-      }
+  for (int u = 0; u < 2; ++u) {
+    if (CORE == CORE_F8) {
+      acc[tm0 + u][tn] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(f8_frag(ah[u], al[u]), f8_frag(bh, bl), acc[tm0 + u][tn], 0, 0,
+                                                                           0, F8_SCALE_ONE, 0, F8_SCALE_ONE);
+    } else {
+      acc[tm0 + u][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u], bh, acc[tm0 + u][tn], 0, 0, 0);
+      acc[tm0 + u][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], bl, acc[tm0 + u][tn], 0, 0, 0);
+      acc[tm0 + u][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], bh, acc[tm0 + u][tn], 0, 0, 0);
     }
-    if (FETCH) w_dma_pair(ad, nxt, koff_next, 2 * part);
-    w_mfma_part<CORE>(acc, ah[part & 1], al[part & 1], bh, bl, 2 * part);
   }
-  __syncthreads();          // (with DMAs in flight the compiler puts s_waitcnt vmcnt(0) in front of the barrier: what is needed)
+}
+
+// the order a part's instructions are to be issued in: 4 x (one LDS read, then PER MFMAs), NV x (one DMA, then PER MFMAs)
+template <int PER, int NV>
+__device__ __forceinline__ void w_sched_part() {
+#ifndef ODX_NO_SGB
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+    __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);    // MFMA
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read (the DMA)
+    __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+  }
+#endif
+}
+
+// One stage (s).  On entry `f` holds the stage's B fragments and the A fragments of part 0 (read behind the barrier of the
+// stage before), and pieces 0..2 of stage s + 1 are on their way into `nxt`.  Parts 0..2 read the next part's A fragments
+// under their own MFMAs; parts 0 and 1 also issue the other five DMAs of stage s + 1 (F1), one per few MFMAs — a DMA costs
+// its wave ~60 cycles of issue, and eight of them in one place, in both waves of a SIMD at once, are 500 cycles in which
+// the matrix pipe has nothing to do.  In front of part 3 every LDS read of the stage has been issued: the wave waits for
+// them and for its own DMAs of stage s + 1, meets the others at the barrier, then — the image of stage s is free, that of
+// stage s + 1 complete — starts the DMAs of stage s + 2 (pieces 0..2, F2) and reads the first A fragments and, column block
+// by column block as part 3 is done with them, the B fragments of stage s + 1 (F1), all UNDER the 24 MFMAs of part 3:
+// neither the barrier's skew nor the LDS latency of a stage's first fragments stops the matrix pipe, and the B fragments
+// need no second register set.
+template <bool F1, bool F2, int CORE>
+__device__ __forceinline__ void w_stage_dma(f32x4 (&acc)[8][4], WFrag& f, const char* cur, char* nxt, int koff1, const WDma& ad) {
+  constexpr int PER = CORE == CORE_F8 ? 1 : 3;
+  // part 0, reading part 1
+  w_read_a(f.a1h, f.a1l, cur, ad, 1);
+  if (F1) w_dma_pieces<3, 6>(ad, nxt, koff1);
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) w_mfma_col<CORE>(acc, f.a0h, f.a0l, f.bh[tn], f.bl[tn], 0, tn);
+  w_sched_part<PER, F1 ? 3 : 0>();
+  __builtin_amdgcn_sched_barrier(0);
+  // part 1, reading part 2
+  w_read_a(f.a0h, f.a0l, cur, ad, 2);
+  if (F1) w_dma_pieces<6, 8>(ad, nxt, koff1);
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) w_mfma_col<CORE>(acc, f.a1h, f.a1l, f.bh[tn], f.bl[tn], 2, tn);
+  w_sched_part<PER, F1 ? 2 : 0>();
+  __builtin_amdgcn_sched_barrier(0);
+  // part 2, reading part 3
+  w_read_a(f.a1h, f.a1l, cur, ad, 3);
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) w_mfma_col<CORE>(acc, f.a0h, f.a0l, f.bh[tn], f.bl[tn], 4, tn);
+  w_sched_part<PER, 0>();
+  __builtin_amdgcn_sched_barrier(0);
+  if (F1) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (F2) w_dma_pieces<0, 3>(ad, const_cast<char*>(cur), koff1 + W_KS * 4);
+    w_read_a(f.a0h, f.a0l, nxt, ad, 0);
+  }
+  // part 3, column block by column block; each block's B registers take the next stage's fragments as soon as it is done
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) {
+    w_mfma_col<CORE>(acc, f.a1h, f.a1l, f.bh[tn], f.bl[tn], 6, tn);
+    __builtin_amdgcn_sched_barrier(0);
+    if (F1) w_read_b1(f, nxt, ad, tn);
+  }
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 template <bool PERMB = false, int CORE = CORE_H2>
@@ -693,13 +766,23 @@ __device__ __forceinline__ void w_mainloop_dma(f32x4 (&acc)[8][4], const uint32_
   ad.fa = (wr * 128 + r) * W_ROW;
   ad.fb = W_OPND_BYTES + (wc * 64 + r) * W_ROW;
   // (the caller's last use of the LDS ended on a barrier)
-#pragma unroll
-  for (int q0 = 0; q0 < 8; q0 += 2) w_dma_pair(ad, lds, 0, q0);
+  w_dma_pieces<0, 8>(ad, lds, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (stages > 1) w_dma_pieces<0, 3>(ad, lds + W_STAGE_BYTES, W_KS * 4);
+  WFrag f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) w_read_b1(f, lds, ad, t);
+  w_read_a(f.a0h, f.a0l, lds, ad, 0);
   int s = 0;
-  for (; s + 1 < stages; ++s)
-    w_stage_dma<true, CORE>(acc, lds + (s & 1) * W_STAGE_BYTES, lds + ((s + 1) & 1) * W_STAGE_BYTES, (s + 1) * (W_KS * 4), ad);
-  w_stage_dma<false, CORE>(acc, lds + (s & 1) * W_STAGE_BYTES, lds, 0, ad);
+  for (; s + 2 < stages; ++s)
+    w_stage_dma<true, true, CORE>(acc, f, lds + (s & 1) * W_STAGE_BYTES, lds + ((s + 1) & 1) * W_STAGE_BYTES, (s + 1) * (W_KS * 4), ad);
+  if (s + 1 < stages) {
+    w_stage_dma<true, false, CORE>(acc, f, lds + (s & 1) * W_STAGE_BYTES, lds + ((s + 1) & 1) * W_STAGE_BYTES, (s + 1) * (W_KS * 4), ad);
+    ++s;
+  }
+  w_stage_dma<false, false, CORE>(acc, f, lds + (s & 1) * W_STAGE_BYTES, lds, 0, ad);
+  __syncthreads();          // every wave has read its last fragments: the LDS is the caller's again
 }
 
 __device__ __forceinline__ void w_zero(f32x4 (&acc)[8][4]) {
@@ -796,7 +879,7 @@ __device__ __forceinline__ void knm_tile_epilogue(const f32x4 (&acc)[8][4], cons
 // RHS: also leave wslab[row block][j] = sum over the tile's rows i of K_ij w_i (f64), K_ij being the value the block
 // STORES (the dequantised one for KF_U24 / KF_BF16): the column sums K' w of the right-hand side of the fit come out of
 // the build, and the first pass over the stored K_nM is not needed.
-template <bool RHS, int FMT, int CORE>
+template <bool RHS, int FMT, int CORE, int STG>
 __global__ __launch_bounds__(W_THREADS, 1) void gauss_knm_h2w256_kernel(
     const uint32_t* __restrict__ PX, int64_t ldpx, const float* __restrict__ metax, const float* __restrict__ xsq, int64_t n,
     const uint32_t* __restrict__ PZ, int64_t ldpz, const float* __restrict__ metaz, const float* __restrict__ zsq, int64_t M,
@@ -819,7 +902,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_knm_h2w256_kernel(
 
   f32x4 acc[8][4];
   w_zero(acc);
-  if (ODX_W_DMA) w_mainloop_dma<true, CORE>(acc, PX, ldpx, n, PZ, ldpz, M, i0, j0, stages, lds);      // its barriers also publish xg_s
+  if (STG == STG_DMA) w_mainloop_dma<true, CORE>(acc, PX, ldpx, n, PZ, ldpz, M, i0, j0, stages, lds);      // its barriers also publish xg_s
   else w_mainloop<true, CORE>(acc, PX, ldpx, n, PZ, ldpz, M, i0, j0, stages, lds);
 
   const float m2g = -2.f / (metax[0] * metaz[0]) * gamma_log2e;    // the scales are powers of two: m2 is exact
@@ -906,6 +989,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_h2s16_kernel(
   }
 }
 
+template <int STG>
 __global__ __launch_bounds__(W_THREADS, 1) void gemm_h2w256_kernel(
     const uint32_t* __restrict__ PA, int64_t ldpa, const float* __restrict__ metaa, int64_t m, const uint32_t* __restrict__ PB,
     int64_t ldpb, const float* __restrict__ metab, int64_t n, int stages, const float* __restrict__ bias,
@@ -921,7 +1005,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void gemm_h2w256_kernel(
   w_zero(acc);
   // B rows in the permuted order of the K_nM builds: a lane holds four ADJACENT output columns 64 wc + 4 (lane & 15) + tn
   // of each of its rows, and stores them (loads bias / residual) 16 bytes at a time when the matrices allow it
-  if (ODX_W_DMA) w_mainloop_dma<true>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds);
+  if (STG == STG_DMA) w_mainloop_dma<true>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds);
   else w_mainloop<true>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds);
   const float inv = 1.f / (metaa[0] * metab[0]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -967,7 +1051,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void gemm_h2w256_kernel(
 
 // Fused scoring on the 256 x 256 core: same decomposition as gauss_mmv_h2s16_kernel (row block x group of `tg` column
 // tiles, f64 partial row sums per group in the slab, mmv_reduce_kernel adds the groups), 256-row blocks, 256-column tiles.
-template <int CORE>
+template <int CORE, int STG>
 __global__ __launch_bounds__(W_THREADS, 1) void gauss_mmv_h2w256_kernel(
     const uint32_t* __restrict__ PX, int64_t ldpx, const float* __restrict__ metax, const float* __restrict__ xsq, int64_t n,
     const uint32_t* __restrict__ PZ, int64_t ldpz, const float* __restrict__ metaz, const float* __restrict__ zsq, int stages,
@@ -999,7 +1083,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_mmv_h2w256_kernel(
   for (int64_t j0 = s0; j0 < s1; j0 += W_BN) {
     f32x4 acc[8][4];
     w_zero(acc);
-    if (ODX_W_DMA) w_mainloop_dma<false, CORE>(acc, PX, ldpx, n, PZ + j0 * ldpz, ldpz, r1 - j0, i0, 0, stages, lds);
+    if (STG == STG_DMA) w_mainloop_dma<false, CORE>(acc, PX, ldpx, n, PZ + j0 * ldpz, ldpz, r1 - j0, i0, 0, stages, lds);
     else w_mainloop<false, CORE>(acc, PX, ldpx, n, PZ + j0 * ldpz, ldpz, r1 - j0, i0, 0, stages, lds);
     float zs[4];
     double al[4];
@@ -1070,6 +1154,13 @@ static int h2_enable_lds(const void* fn, int bytes = S16_LDS_BYTES) {   // > 64 
 // core (4 x as many, smaller workgroups) below that.  odx_set_h2_tile(128 | 256) pins one (tests, measurements); the
 // environment variable ODX_H2_TILE gives the initial setting.
 static int g_h2_tile = -1;
+
+// ODX_H2_STAGING=reg keeps the register-staged main loop of the 256 x 256 core (A/B runs in one process: the variable is read
+// at every launch); default: LDS-DMA
+static int w_staging() {
+  const char* e = getenv("ODX_H2_STAGING");
+  return (e && e[0] == 'r') ? STG_REG : STG_DMA;
+}
 
 static bool h2_use_w256(int64_t tiles256) {
   if (g_h2_tile < 0) {
@@ -1149,9 +1240,15 @@ static int launch_knm_w256_t(unsigned wt, hipStream_t s, const uint32_t* PX, int
                              int64_t n, const uint32_t* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t M,
                              int stages, float g2, void* K, int64_t ldk, unsigned char* Klo, int64_t ldlo, int wgr,
                              const double* w, double* wslab, int64_t wslab_ld) {
-  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2w256_kernel<RHS, FMT, CORE>), W_LDS_BYTES));
-  hipLaunchKernelGGL((gauss_knm_h2w256_kernel<RHS, FMT, CORE>), dim3(wt), dim3(W_THREADS), W_LDS_BYTES, s, PX, ldpx, metax, xsq, n,
-                     PZ, ldpz, metaz, zsq, M, stages, g2, K, ldk, Klo, ldlo, wgr, w, wslab, wslab_ld);
+  if (w_staging() == STG_DMA) {
+    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2w256_kernel<RHS, FMT, CORE, STG_DMA>), W_LDS_BYTES));
+    hipLaunchKernelGGL((gauss_knm_h2w256_kernel<RHS, FMT, CORE, STG_DMA>), dim3(wt), dim3(W_THREADS), W_LDS_BYTES, s, PX, ldpx, metax,
+                       xsq, n, PZ, ldpz, metaz, zsq, M, stages, g2, K, ldk, Klo, ldlo, wgr, w, wslab, wslab_ld);
+  } else {
+    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2w256_kernel<RHS, FMT, CORE, STG_REG>), W_LDS_BYTES));
+    hipLaunchKernelGGL((gauss_knm_h2w256_kernel<RHS, FMT, CORE, STG_REG>), dim3(wt), dim3(W_THREADS), W_LDS_BYTES, s, PX, ldpx, metax,
+                       xsq, n, PZ, ldpz, metaz, zsq, M, stages, g2, K, ldk, Klo, ldlo, wgr, w, wslab, wslab_ld);
+  }
   return ODX_OK;
 }
 
@@ -1233,10 +1330,17 @@ extern "C" int odx_gemm_h2_f32(const void* PA, int64_t ldpa, const float* metaa,
   if (t256 >= 256) {           // the 256 x 256 core once it fills the chip (one workgroup per CU), else 128 x 128 tiles
     const int64_t wt = round_up(ceil_div(m, W_BM), gr) * ceil_div(n, W_BN);
     ODX_REQUIRE(wt < (1ll << 31), "odx_gemm_h2_f32: grid too large");
-    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2w256_kernel), W_LDS_BYTES));
-    hipLaunchKernelGGL(gemm_h2w256_kernel, dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
-                       (const uint32_t*)PA, ldpa, metaa, m, (const uint32_t*)PB, ldpb, metab, n, (int)(dp / W_KS), bias, residual,
-                       ldr, relu, out, ldo, gr);
+    if (w_staging() == STG_DMA) {
+      ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2w256_kernel<STG_DMA>), W_LDS_BYTES));
+      hipLaunchKernelGGL(gemm_h2w256_kernel<STG_DMA>, dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
+                         (const uint32_t*)PA, ldpa, metaa, m, (const uint32_t*)PB, ldpb, metab, n, (int)(dp / W_KS), bias, residual,
+                         ldr, relu, out, ldo, gr);
+    } else {
+      ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2w256_kernel<STG_REG>), W_LDS_BYTES));
+      hipLaunchKernelGGL(gemm_h2w256_kernel<STG_REG>, dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
+                         (const uint32_t*)PA, ldpa, metaa, m, (const uint32_t*)PB, ldpb, metab, n, (int)(dp / W_KS), bias, residual,
+                         ldr, relu, out, ldo, gr);
+    }
     ODX_CHECK_LAUNCH("odx_gemm_h2_f32(w256)");
     return ODX_OK;
   }
@@ -1488,10 +1592,17 @@ static int launch_mmv_w256(const void* PX, int64_t ldpx, const float* metax, con
   const int64_t Gw = ceil_div(ceil_div(max_range, W_BN), W_MMV_TG);      // <= mmv_groups(max_range): the slab is large enough
   const int64_t wgs = round_up(ceil_div(n, W_BM), 8) * Gw;
   ODX_REQUIRE(wgs < (1ll << 31), "odx_gauss_mmv: grid too large");
-  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_mmv_h2w256_kernel<CORE>), W_LDS_BYTES));
-  hipLaunchKernelGGL(gauss_mmv_h2w256_kernel<CORE>, dim3((unsigned)wgs, (unsigned)C), dim3(W_THREADS), W_LDS_BYTES,
-                     as_stream(stream), (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq, stages,
-                     (float)(-0.5 / (sigma * sigma)) * LOG2E, V, ldv, ranges, W_MMV_TG, (int)Gw, slab, slab_ld);
+  if (w_staging() == STG_DMA) {
+    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_mmv_h2w256_kernel<CORE, STG_DMA>), W_LDS_BYTES));
+    hipLaunchKernelGGL((gauss_mmv_h2w256_kernel<CORE, STG_DMA>), dim3((unsigned)wgs, (unsigned)C), dim3(W_THREADS), W_LDS_BYTES,
+                       as_stream(stream), (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq, stages,
+                       (float)(-0.5 / (sigma * sigma)) * LOG2E, V, ldv, ranges, W_MMV_TG, (int)Gw, slab, slab_ld);
+  } else {
+    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_mmv_h2w256_kernel<CORE, STG_REG>), W_LDS_BYTES));
+    hipLaunchKernelGGL((gauss_mmv_h2w256_kernel<CORE, STG_REG>), dim3((unsigned)wgs, (unsigned)C), dim3(W_THREADS), W_LDS_BYTES,
+                       as_stream(stream), (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq, stages,
+                       (float)(-0.5 / (sigma * sigma)) * LOG2E, V, ldv, ranges, W_MMV_TG, (int)Gw, slab, slab_ld);
+  }
   ODX_CHECK_LAUNCH("odx_gauss_mmv(w256)");
   hipLaunchKernelGGL(mmv_reduce_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)C), dim3(256), 0, as_stream(stream), slab,
                      slab_ld, (int)Gw, W_MMV_TG, W_BN, ranges, n, out, ldo);
