@@ -603,7 +603,11 @@ static int side_stream(SideStream** out, int slot, hipStream_t caller) {
 //                                           per 512 columns instead of per 128, MFMA-bound)
 constexpr int POTRF_NBO = 512;
 
-int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hipStream_t stream, const ZBatch& zb) {
+// pk != nullptr: the rank-512 trailing updates (the bulk of the flops) run on the split-f16 tile core (gemm_h2_f64:
+// f32-accurate products added into the f64 trailing matrix) — for a factor that only preconditions.  pk: two packed panel
+// buffers per matrix, pk_buf 4-byte units apart, matrices pk_z apart; pk_scale: power of two with |L_ij| pk_scale << 65504.
+int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hipStream_t stream, const ZBatch& zb, uint32_t* pk,
+              int64_t pk_buf, int64_t pk_z, float pk_scale) {
   constexpr int NB = POTRF_NB;
   ODX_REQUIRE(lda % 2 == 0 && aligned16(A) && aligned16(Dinv), "potrf_f64: A/Dinv must be 16-byte aligned, lda even");
   const int Z = zb.count;
@@ -652,21 +656,36 @@ int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hi
         ODX_CHECK_HIP(hipStreamWaitEvent(stream, look->join, 0));
         pending = false;
       }
-      GemmParams<double> u;
-      u.A = P; u.lda = lda; u.B = P; u.ldb = lda; u.C = A + (K0 + kbo) * (lda + 1); u.ldc = lda;
-      u.m = mt; u.n = nw; u.k = kbo; u.alpha = -1.0; u.beta = 1.0; u.flags = ODX_GEMM_LOWER_ONLY;
-      zgemm(u);
-      ODX_PROPAGATE(launch_gemm_f64(u, stream));
       const int64_t mr = mt - nw;
+      double minus1[ODX_MAX_ZBATCH];
+      for (int z = 0; z < Z; ++z) minus1[z] = -1.0;
+      uint32_t* Pk = pk ? pk + ((K0 / POTRF_NBO) & 1) * pk_buf : nullptr;      // (its last reader, two panels back, has been joined)
+      if (Pk) {
+        ODX_PROPAGATE(split_f64(P, lda, zb.strideA, mt, kbo, pk_scale, Pk, POTRF_NBO, pk_z, Z, stream));
+        ODX_PROPAGATE(gemm_h2_f64(Pk, POTRF_NBO, pk_z, pk_scale, Pk, POTRF_NBO, pk_z, pk_scale, A + (K0 + kbo) * (lda + 1), lda,
+                                  zb.strideA, mt, nw, kbo, minus1, 1.0, ODX_GEMM_LOWER_ONLY, Z, stream));
+      } else {
+        GemmParams<double> u;
+        u.A = P; u.lda = lda; u.B = P; u.ldb = lda; u.C = A + (K0 + kbo) * (lda + 1); u.ldc = lda;
+        u.m = mt; u.n = nw; u.k = kbo; u.alpha = -1.0; u.beta = 1.0; u.flags = ODX_GEMM_LOWER_ONLY;
+        zgemm(u);
+        ODX_PROPAGATE(launch_gemm_f64(u, stream));
+      }
       if (mr > 0) {
         ODX_CHECK_HIP(hipEventRecord(look->fork, stream));
         ODX_CHECK_HIP(hipStreamWaitEvent(look->stream, look->fork, 0));
-        double* P2 = P + nw * lda;
-        GemmParams<double> r;
-        r.A = P2; r.lda = lda; r.B = P2; r.ldb = lda; r.C = A + (K0 + kbo + nw) * (lda + 1); r.ldc = lda;
-        r.m = mr; r.n = mr; r.k = kbo; r.alpha = -1.0; r.beta = 1.0; r.flags = ODX_GEMM_LOWER_ONLY;
-        zgemm(r);
-        ODX_PROPAGATE(launch_gemm_f64(r, look->stream));
+        if (Pk) {
+          ODX_PROPAGATE(gemm_h2_f64(Pk + nw * POTRF_NBO, POTRF_NBO, pk_z, pk_scale, Pk + nw * POTRF_NBO, POTRF_NBO, pk_z, pk_scale,
+                                    A + (K0 + kbo + nw) * (lda + 1), lda, zb.strideA, mr, mr, kbo, minus1, 1.0, ODX_GEMM_LOWER_ONLY, Z,
+                                    look->stream));
+        } else {
+          double* P2 = P + nw * lda;
+          GemmParams<double> r;
+          r.A = P2; r.lda = lda; r.B = P2; r.ldb = lda; r.C = A + (K0 + kbo + nw) * (lda + 1); r.ldc = lda;
+          r.m = mr; r.n = mr; r.k = kbo; r.alpha = -1.0; r.beta = 1.0; r.flags = ODX_GEMM_LOWER_ONLY;
+          zgemm(r);
+          ODX_PROPAGATE(launch_gemm_f64(r, look->stream));
+        }
         ODX_CHECK_HIP(hipEventRecord(look->join, look->stream));
         pending = true;
       }
@@ -831,10 +850,30 @@ extern "C" int odx_trtri_f64(const double* L, int64_t ldl, int64_t M, double* Li
 // asynchronous with respect to the host.
 static int64_t precond_ld(int64_t M) { return round_up(M, 2); }
 
+// The GEMM-shaped work of the A factor (T T' / M, the rank-512 updates of its Cholesky) on the split-f16 tile core: A only
+// preconditions the system (the solution the CG converges to does not depend on it, and the reference's all-f32 falkon gives it
+// f32 accuracy at best), so its products are formed at f32 accuracy at ~6 x the f64 MFMA rate; T, whose products define the
+// regulariser, stays f64 throughout.  ODX_PRECOND = "f64": never; "split": always; default: from 4096 centres on (below that
+// the chain is latency-bound and nothing is gained).  Read at every call.
+static bool precond_split(int64_t M) {
+  const char* e = getenv("ODX_PRECOND");
+  if (e && e[0] == 'f') return false;
+  if (e && e[0] == 's') return true;
+  return M >= 4096;
+}
+// scratch of the split path per matrix, in doubles: packed T (M x roundup(M, 64) 4-byte units) + two packed 512-column panels
+static int64_t precond_split_doubles(int64_t M) { return (M * h2_f64_packed_ld(M) + 2 * M * POTRF_NBO) / 2 + 2; }
+// power of two s with bound * s in [2^11, 2^12]: the entries' two f16 terms stay far from overflow (65504)
+static float split_scale_for(double bound) {
+  int e = 0;
+  frexp(bound > 1e-300 ? bound : 1.0, &e);      // bound = f 2^e, f in [0.5, 1)
+  return ldexpf(1.f, 12 - e);
+}
+
 extern "C" int64_t odx_falkon_precond_workspace_bytes(int64_t M, int D) {
   if (M <= 0 || D <= 0) return 0;
   const int64_t ld = precond_ld(M), ldzd = round_up(D, 2);
-  int64_t dbl = M * ldzd + round_up(M, 2) + 4 * M * ld + 2 * ceil_div(M, POTRF_NB) * POTRF_NB * POTRF_NB;
+  int64_t dbl = M * ldzd + round_up(M, 2) + 4 * M * ld + 2 * ceil_div(M, POTRF_NB) * POTRF_NB * POTRF_NB + precond_split_doubles(M);
   return dbl * (int64_t)sizeof(double);
 }
 
@@ -864,6 +903,10 @@ extern "C" int odx_falkon_precond_f64(const float* Z, int64_t ldz, int64_t M, in
   double* W3 = W2 + M * wld;
   double* DinvT = W3 + M * wld;
   double* DinvA = DinvT + dsz;
+  const bool split = precond_split(M);
+  const int64_t ldpt = h2_f64_packed_ld(M);
+  uint32_t* Tk = reinterpret_cast<uint32_t*>(DinvA + dsz);             // packed T, then the two packed panels
+  uint32_t* Pk = Tk + M * ldpt;
 
   ODX_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), s));
   ODX_CHECK_HIP(hipMemsetAsync(Zd, 0, (size_t)(M * ldzd) * sizeof(double), s));
@@ -883,15 +926,26 @@ extern "C" int odx_falkon_precond_f64(const float* Z, int64_t ldz, int64_t M, in
   ODX_CHECK_HIP(hipMemsetAsync(W1, 0, (size_t)(M * wld) * sizeof(double), s));
   ODX_PROPAGATE(transpose_f64(W0, wld, W1, wld, M, M, s));
   ODX_CHECK_HIP(hipMemsetAsync(W2, 0, (size_t)(M * wld) * sizeof(double), s));
-  {
+  if (split) {
+    // |T_ij| <= sqrt(max diagonal of T'T) = sqrt(1 + eps M);  |L_A ij| <= sqrt(max diagonal of T T' / M + lam) <= sqrt(1 + eps + lam)
+    // (M < 65536 everywhere in this file: one bound for every call, so that the class-batched chain packs with the very
+    // scales of the single-class one and stays bit-identical to it)
+    const float st = split_scale_for(sqrt(1.0 + eps * 65536.0)), sa = split_scale_for(sqrt(1.0 + eps + lam));
+    const double a1 = 1.0 / (double)M;
+    ODX_PROPAGATE(split_f64(W1, wld, 0, M, M, st, Tk, ldpt, 0, 1, s));
+    ODX_PROPAGATE(gemm_h2_f64(Tk, ldpt, 0, st, Tk, ldpt, 0, st, W2, wld, 0, M, M, M, &a1, 0.0,
+                              ODX_GEMM_LOWER_ONLY | ODX_GEMM_A_UPPER | ODX_GEMM_B_UPPER, 1, s));
+    ODX_PROPAGATE(add_diag_f64(W2, wld, M, lam, s));
+    ODX_PROPAGATE(potrf_f64(W2, wld, M, DinvA, info, s, ZBatch(), Pk, M * POTRF_NBO, 0, sa));
+  } else {
     GemmParams<double> g;
     g.A = W1; g.lda = wld; g.B = W1; g.ldb = wld; g.C = W2; g.ldc = wld;
     g.m = M; g.n = M; g.k = M; g.alpha = 1.0 / (double)M; g.beta = 0.0;
     g.flags = ODX_GEMM_LOWER_ONLY | ODX_GEMM_A_UPPER | ODX_GEMM_B_UPPER;
     ODX_PROPAGATE(launch_gemm_f64(g, s));
+    ODX_PROPAGATE(add_diag_f64(W2, wld, M, lam, s));
+    ODX_PROPAGATE(potrf_f64(W2, wld, M, DinvA, info, s));
   }
-  ODX_PROPAGATE(add_diag_f64(W2, wld, M, lam, s));
-  ODX_PROPAGATE(potrf_f64(W2, wld, M, DinvA, info, s));
   // join, then the inverses of L_A (scratch W1: T is no longer needed)
   ODX_CHECK_HIP(hipStreamWaitEvent(s, side->join, 0));
   ODX_PROPAGATE(fill_f64(LAi, ld, M, M, 0.0, s));
@@ -913,7 +967,8 @@ extern "C" int odx_falkon_precond_f64(const float* Z, int64_t ldz, int64_t M, in
 extern "C" int64_t odx_falkon_precond_batched_workspace_bytes(int64_t Mmax, int D, int B) {
   if (Mmax <= 0 || D <= 0 || B <= 0) return 0;
   const int64_t ld = precond_ld(Mmax), ldzd = round_up(D, 2);
-  const int64_t per = Mmax * ldzd + round_up(Mmax, 2) + 4 * Mmax * ld + 2 * ceil_div(Mmax, POTRF_NB) * POTRF_NB * POTRF_NB;
+  const int64_t per = Mmax * ldzd + round_up(Mmax, 2) + 4 * Mmax * ld + 2 * ceil_div(Mmax, POTRF_NB) * POTRF_NB * POTRF_NB +
+                      precond_split_doubles(Mmax);
   return per * B * (int64_t)sizeof(double);
 }
 
@@ -948,6 +1003,10 @@ extern "C" int odx_falkon_precond_batched_f64(const float* const* Z, const int64
   double* DinvT = W3 + (int64_t)B * wsz;
   double* DinvA = DinvT + (int64_t)B * dsz;
   double* LTi = out, *LTit = out + Mmax * ld, *LAi = out + 2 * Mmax * ld, *LAit = out + 3 * Mmax * ld;
+  const bool split = precond_split(Mmax);
+  const int64_t ldpt = h2_f64_packed_ld(Mmax);
+  uint32_t* Tk = reinterpret_cast<uint32_t*>(DinvA + (int64_t)B * dsz);   // packed T of every class, then the packed panels
+  uint32_t* Pk = Tk + (int64_t)B * Mmax * ldpt;
 
   ODX_CHECK_HIP(hipMemsetAsync(info, 0, (size_t)B * sizeof(int32_t), s));
   ODX_CHECK_HIP(hipMemsetAsync(Zd0, 0, (size_t)((int64_t)B * zper) * sizeof(double), s));
@@ -980,7 +1039,17 @@ extern "C" int odx_falkon_precond_batched_f64(const float* const* Z, const int64
   ODX_CHECK_HIP(hipEventRecord(side->join, s2));
   // main: W1 = L_T' = T; W2 = T T' / M_b + lam I; L_A in place in W2
   ODX_PROPAGATE(transpose_f64(W0, wld, W1, wld, Mmax, Mmax, s, B, wsz, wsz));
-  {
+  if (split) {
+    // (bounds as in the single-class call; the identity border of a class with fewer centres is inside them)
+    const float st = split_scale_for(sqrt(1.0 + eps * 65536.0)), sa = split_scale_for(sqrt(1.0 + eps + lam));
+    double a1[ODX_MAX_ZBATCH];
+    for (int b = 0; b < B; ++b) a1[b] = 1.0 / (double)M[b];
+    ODX_PROPAGATE(split_f64(W1, wld, wsz, Mmax, Mmax, st, Tk, ldpt, Mmax * ldpt, B, s));
+    ODX_PROPAGATE(gemm_h2_f64(Tk, ldpt, Mmax * ldpt, st, Tk, ldpt, Mmax * ldpt, st, W2, wld, wsz, Mmax, Mmax, Mmax, a1, 0.0,
+                              ODX_GEMM_LOWER_ONLY | ODX_GEMM_A_UPPER | ODX_GEMM_B_UPPER, B, s));
+    ODX_PROPAGATE(add_diag_f64(W2, wld, Mmax, lam, s, B, wsz));
+    ODX_PROPAGATE(potrf_f64(W2, wld, Mmax, DinvA, info, s, zt, Pk, (int64_t)B * Mmax * POTRF_NBO, Mmax * POTRF_NBO, sa));
+  } else {
     GemmParams<double> g;
     g.A = W1; g.lda = wld; g.B = W1; g.ldb = wld; g.C = W2; g.ldc = wld;
     g.m = Mmax; g.n = Mmax; g.k = Mmax; g.beta = 0.0;
@@ -989,9 +1058,9 @@ extern "C" int odx_falkon_precond_batched_f64(const float* const* Z, const int64
     g.zalpha_on = 1;
     for (int b = 0; b < B; ++b) g.zalpha[b] = 1.0 / (double)M[b];
     ODX_PROPAGATE(launch_gemm_f64(g, s));
+    ODX_PROPAGATE(add_diag_f64(W2, wld, Mmax, lam, s, B, wsz));
+    ODX_PROPAGATE(potrf_f64(W2, wld, Mmax, DinvA, info, s, zt));
   }
-  ODX_PROPAGATE(add_diag_f64(W2, wld, Mmax, lam, s, B, wsz));
-  ODX_PROPAGATE(potrf_f64(W2, wld, Mmax, DinvA, info, s, zt));
   // join, then the inverses of L_A (scratch W1: T is no longer needed)
   ODX_CHECK_HIP(hipStreamWaitEvent(s, side->join, 0));
   return trtri_from_diag_f64(W2, wld, Mmax, DinvA, LAi, LAit, ld, W1, s, zt);

@@ -1049,6 +1049,116 @@ __global__ __launch_bounds__(W_THREADS, 1) void gemm_h2w256_kernel(
   }
 }
 
+// ---------------------------------------------------------------- f64 matrices through the split core
+// C (f64) = alpha (A B') + beta C for f64 operands packed as two-term f16 splits (split_f64_kernel): the products carry ~22
+// bits per factor relative to the operand's largest entry, the sum is formed in f32 and scaled / added into C in f64.  Used
+// for the GEMM-shaped work of the A factor of the FALKON preconditioner (T T' / M and the rank-512 updates of its Cholesky,
+// dense_f64.hip) — A only PRECONDITIONS the system, so f32-accurate products are what the reference's all-f32 falkon gives
+// it too — at ~6 x the rate of the f64 MFMA.  The operands' scales are powers of two chosen by the caller from a bound of
+// the entries.
+__global__ __launch_bounds__(256) void split_f64_kernel(const double* __restrict__ X, int64_t ldx, int64_t zsx, int64_t rows, int cols,
+                                                        float s, uint32_t* __restrict__ P, int64_t ldp, int64_t zsp) {
+  const int groups = (int)((cols + H2_KT - 1) / H2_KT) * 8;  // 8-column groups per row, zero padded to whole k-tiles
+  const int64_t row = blockIdx.y;
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= groups || row >= rows) return;
+  const double* x = X + (int64_t)blockIdx.z * zsx + row * ldx + (int64_t)g * 8;
+  double v[8];
+  if (g * 8 + 8 <= cols) {
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+      const f64x2 a = *reinterpret_cast<const f64x2*>(x + q);
+      v[q] = a[0];
+      v[q + 1] = a[1];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (g * 8 + q < cols) ? x[q] : 0.0;
+  }
+  f16x8 hi, lo;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float t = (float)(v[q] * (double)s);       // (the f32 rounding is below the second term's last bit)
+    const _Float16 h = (_Float16)t;
+    hi[q] = h;
+    lo[q] = (_Float16)(t - (float)h);
+  }
+  uint32_t* dst = P + (int64_t)blockIdx.z * zsp + row * ldp + (int64_t)(g >> 2) * 32 + (g & 3) * 4;
+  *reinterpret_cast<f16x8*>(dst) = hi;
+  *reinterpret_cast<f16x8*>(dst + 16) = lo;
+}
+
+struct H2F64Params {
+  const uint32_t* PA; int64_t ldpa, zsa;      // packed A (m x k), class stride in 4-byte units
+  const uint32_t* PB; int64_t ldpb, zsb;      // packed B (n x k)
+  double* C; int64_t ldc, zsc;
+  int64_t m, n;
+  int stages;                                  // 32-column stages of the packed rows
+  int flags;                                   // ODX_GEMM_LOWER_ONLY | ODX_GEMM_A_UPPER | ODX_GEMM_B_UPPER
+  double beta;
+  double alpha[ODX_MAX_ZBATCH];                // per class, 1 / (s_A s_B) folded in
+};
+
+__global__ __launch_bounds__(W_THREADS, 1) void gemm_h2w256_f64_kernel(H2F64Params p) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int64_t GR = 4;
+  const int64_t tiles_n = (p.n + W_BN - 1) / W_BN;
+  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t band = wg / (GR * tiles_n), within = wg % (GR * tiles_n);
+  const int64_t i0 = (band * GR + within % GR) * W_BM, j0 = (within / GR) * W_BN;
+  if (i0 >= p.m) return;
+  const bool lower = (p.flags & ODX_GEMM_LOWER_ONLY) != 0;
+  if (lower && j0 > i0 + W_BM - 1) return;
+  const int z = blockIdx.y;
+  int64_t kb = 0;                                                     // operands known to be zero left of column kb
+  if (p.flags & ODX_GEMM_A_UPPER) kb = i0;
+  if ((p.flags & ODX_GEMM_B_UPPER) && j0 > kb) kb = j0;
+  const int s0 = (int)(kb / W_KS);                                    // i0, j0 are multiples of 256
+  const int stages = p.stages - s0;
+  f32x4 acc[8][4];
+  w_zero(acc);
+  if (stages > 0)
+    w_mainloop_dma<true>(acc, p.PA + (int64_t)z * p.zsa + (int64_t)s0 * W_KS, p.ldpa, p.m, p.PB + (int64_t)z * p.zsb + (int64_t)s0 * W_KS,
+                         p.ldpb, p.n, i0, j0, stages, lds);
+  const double alpha = p.alpha[z], beta = p.beta;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int64_t col = j0 + wc * 64 + 4 * (lane & 15);                 // four adjacent columns per lane (permuted B rows)
+  const int64_t rb = i0 + wr * 128 + 4 * (lane >> 4);
+  if (col >= p.n) return;
+  double* pc = p.C + (int64_t)z * p.zsc + rb * p.ldc + col;
+#pragma unroll
+  for (int tm = 0; tm < 8; ++tm) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t row = rb + tm * 16 + q;
+      if (row < p.m) {
+        // lower-only: what the f64 kernel's 128-row tiles write — every column up to the end of the row's 128-block
+        const int64_t lim = lower ? (((row | 127) + 1 < p.n) ? (row | 127) + 1 : p.n) : p.n;
+        if (col + 4 <= lim) {
+          f64x2 c0 = {0.0, 0.0}, c1 = {0.0, 0.0};
+          if (beta != 0.0) {
+            c0 = *reinterpret_cast<const f64x2*>(pc);
+            c1 = *reinterpret_cast<const f64x2*>(pc + 2);
+          }
+          c0[0] = fma(alpha, (double)acc[tm][0][q], beta * c0[0]);
+          c0[1] = fma(alpha, (double)acc[tm][1][q], beta * c0[1]);
+          c1[0] = fma(alpha, (double)acc[tm][2][q], beta * c1[0]);
+          c1[1] = fma(alpha, (double)acc[tm][3][q], beta * c1[1]);
+          *reinterpret_cast<f64x2*>(pc) = c0;
+          *reinterpret_cast<f64x2*>(pc + 2) = c1;
+        } else {
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn)
+            if (col + tn < lim) pc[tn] = fma(alpha, (double)acc[tm][tn][q], beta != 0.0 ? beta * pc[tn] : 0.0);
+        }
+      }
+      pc += p.ldc;
+    }
+    pc += 12 * p.ldc;
+  }
+}
+
 // Fused scoring on the 256 x 256 core: same decomposition as gauss_mmv_h2s16_kernel (row block x group of `tg` column
 // tiles, f64 partial row sums per group in the slab, mmv_reduce_kernel adds the groups), 256-row blocks, 256-column tiles.
 template <int CORE, int STG>
@@ -1171,6 +1281,41 @@ static bool h2_use_w256(int64_t tiles256) {
   if (g_h2_tile == 128) return false;
   if (g_h2_tile == 256) return true;
   return tiles256 >= 512;
+}
+
+// (internal, odx_internal.h) packed bytes of a (rows x cols) f64 operand of gemm_h2_f64
+int64_t h2_f64_packed_ld(int64_t cols) { return round_up(cols, H2_KT); }
+
+int split_f64(const double* X, int64_t ldx, int64_t zsx, int64_t rows, int64_t cols, float scale, uint32_t* P, int64_t ldp,
+              int64_t zsp, int z, hipStream_t stream) {
+  if (rows <= 0 || cols <= 0 || z <= 0) return ODX_OK;
+  ODX_REQUIRE(ldx % 2 == 0 && aligned16(X) && zsx % 2 == 0, "split_f64: X must be 16-byte aligned with even ld / class stride");
+  ODX_REQUIRE(ldp % 4 == 0 && ldp >= round_up(cols, H2_KT) && aligned16(P) && zsp % 4 == 0, "split_f64: packed rows cover roundup(cols, 64)");
+  ODX_REQUIRE(rows < 65536 && z < 65536, "split_f64: too many rows");
+  const int groups = (int)(round_up(cols, H2_KT) / 8);
+  hipLaunchKernelGGL(split_f64_kernel, dim3((unsigned)ceil_div(groups, 256), (unsigned)rows, (unsigned)z), dim3(256), 0, stream, X, ldx, zsx,
+                     rows, (int)cols, scale, P, ldp, zsp);
+  ODX_CHECK_LAUNCH("split_f64");
+  return ODX_OK;
+}
+
+// C_z = alpha_z (A_z B_z') / (sa sb) + beta C_z for z = 0 .. zcount - 1; k = columns of the operands
+int gemm_h2_f64(const uint32_t* PA, int64_t ldpa, int64_t zsa, float sa, const uint32_t* PB, int64_t ldpb, int64_t zsb, float sb,
+                double* C, int64_t ldc, int64_t zsc, int64_t m, int64_t n, int64_t k, const double* alpha, double beta, int flags,
+                int zcount, hipStream_t stream) {
+  if (m <= 0 || n <= 0 || zcount <= 0) return ODX_OK;
+  ODX_REQUIRE(zcount <= ODX_MAX_ZBATCH && ldc % 2 == 0 && zsc % 2 == 0 && aligned16(C), "gemm_h2_f64: C must be 16-byte aligned, even ld");
+  ODX_REQUIRE(ldpa < (1 << 24) && ldpb < (1 << 24) && ldpa >= round_up(k, H2_KT) && ldpb >= round_up(k, H2_KT), "gemm_h2_f64: packed leading dimensions");
+  H2F64Params p;
+  p.PA = PA; p.ldpa = ldpa; p.zsa = zsa; p.PB = PB; p.ldpb = ldpb; p.zsb = zsb; p.C = C; p.ldc = ldc; p.zsc = zsc;
+  p.m = m; p.n = n; p.stages = (int)(round_up(k, H2_KT) / W_KS); p.flags = flags; p.beta = beta;
+  for (int z = 0; z < zcount; ++z) p.alpha[z] = alpha[z] / ((double)sa * (double)sb);
+  const int64_t wt = round_up(ceil_div(m, W_BM), 4) * ceil_div(n, W_BN);
+  ODX_REQUIRE(wt < (1ll << 31), "gemm_h2_f64: grid too large");
+  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2w256_f64_kernel), W_LDS_BYTES));
+  hipLaunchKernelGGL(gemm_h2w256_f64_kernel, dim3((unsigned)wt, (unsigned)zcount), dim3(W_THREADS), W_LDS_BYTES, stream, p);
+  ODX_CHECK_LAUNCH("gemm_h2_f64");
+  return ODX_OK;
 }
 
 }  // namespace odx

@@ -50,7 +50,8 @@ struct ZBatch {
   int64_t strideW = 0;      // between their scratch (WT)
 };
 int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv /* nblk x NB x NB */, int32_t* info /* one per matrix */,
-              hipStream_t stream, const ZBatch& zb = ZBatch());
+              hipStream_t stream, const ZBatch& zb = ZBatch(), uint32_t* pk = nullptr, int64_t pk_buf = 0, int64_t pk_z = 0,
+              float pk_scale = 1.f);
 int trtri_from_diag_f64(const double* L, int64_t ldl, int64_t M, const double* Dinv, double* Li, double* Lit,
                         int64_t ld, double* WT, hipStream_t stream, const ZBatch& zb = ZBatch());
 int transpose_f64(const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols,
@@ -87,6 +88,14 @@ int cg_finish_batched(const VecBatch& vb, const double* R, double* P, double* st
                       int64_t vstride, hipStream_t stream);
 int cg_full_residual_batched(const VecBatch& vb, const double* Bv, const double* AX, double* R, int64_t vstride,
                              hipStream_t stream);
+
+// gauss_h2.hip: f64 matrices through the split-f16 tile core (f32-accurate products, f64 scale / accumulate into C)
+int64_t h2_f64_packed_ld(int64_t cols);            // 4-byte units per packed row
+int split_f64(const double* X, int64_t ldx, int64_t zsx, int64_t rows, int64_t cols, float scale, uint32_t* P, int64_t ldp,
+              int64_t zsp, int z, hipStream_t stream);
+int gemm_h2_f64(const uint32_t* PA, int64_t ldpa, int64_t zsa, float sa, const uint32_t* PB, int64_t ldpb, int64_t zsb, float sb,
+                double* C, int64_t ldc, int64_t zsc, int64_t m, int64_t n, int64_t k, const double* alpha, double beta, int flags,
+                int zcount, hipStream_t stream);
 
 // gauss.hip
 int gauss_kmm_f64(const double* Zd, int64_t ldz, int64_t M, int D, double sigma, double diag_add, double* Kmm,

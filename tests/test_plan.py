@@ -32,7 +32,7 @@ def test_planned_bytes_fit_the_gpu(cfg, world):
         # round 3's fixed shape (world shards + 2 x 6 sets of factors per rank) at 8 ranks: 300 + 154 GB — what the plan avoids
         old = world * plan.knm_bytes_rule(p.n_loc, M, p.knm_format) + 2 * 6 * plan.factor_bytes(M)
         assert old > 288 * GB or world < 4
-        assert {2: (1, 2), 4: (2, 2), 8: (4, 2)}[world] == (p.b, p.g)
+        assert {2: (1, 1), 4: (2, 2), 8: (4, 2)}[world] == (p.b, p.g)
 
 
 def test_pinned_batch_and_chain_are_respected_or_refused():
@@ -45,6 +45,17 @@ def test_pinned_batch_and_chain_are_respected_or_refused():
         plan.plan_lockstep(N, D, M, C, 8, batch=3)
     small = plan.plan_lockstep(*CONFIGS[3], 8, hbm_bytes=40 * GB)
     assert small.feasible and small.b < 8               # a smaller GPU: fewer shards in flight, not a failure
+
+
+def test_chain_workspace_formula_is_the_one_of_the_library():
+    """The planner's bytes for the preconditioner chain's scratch are what libodx asks for (host arithmetic on both sides:
+    the library loads without a GPU)."""
+    import odx
+    lib = odx.hip.load()
+    for M, D in ((10_000, 1024), (2_000, 2048), (20_000, 1024), (700, 36), (129, 7)):
+        assert lib.odx_falkon_precond_workspace_bytes(M, D) == plan.chain_workspace_bytes(M, D)
+        for B in (1, 6, 32):
+            assert lib.odx_falkon_precond_batched_workspace_bytes(M, D, B) == B * plan.chain_workspace_bytes(M, D)
 
 
 def test_storage_rule_matches_the_documented_thresholds():
