@@ -603,6 +603,29 @@ static int side_stream(SideStream** out, int slot, hipStream_t caller) {
 //                                           per 512 columns instead of per 128, MFMA-bound)
 constexpr int POTRF_NBO = 512;
 
+// The GEMM-shaped work of the A factor (T T' / M, the rank-512 updates of its Cholesky) on the split-f16 tile core: A only
+// preconditions the system (the solution the CG converges to does not depend on it, and the reference's all-f32 falkon gives it
+// f32 accuracy at best), so its products are formed at f32 accuracy at ~6 x the f64 MFMA rate; T, whose products define the
+// regulariser, stays f64 throughout.  ODX_PRECOND = "f64": never; "split": always; default: from 4096 centres on (below that
+// the chain is latency-bound and nothing is gained).  Read at every call.
+static bool precond_split(int64_t M) {
+  const char* e = getenv("ODX_PRECOND");
+  if (e && e[0] == 'f') return false;
+  if (e && e[0] == 's') return true;
+  return M >= 4096;
+}
+// scratch of the split path per matrix, in doubles: 2 M roundup(M, 64) 4-byte units for the packed T and, later, the four
+// packed operands of a triangular-inverse merge level + two packed 512-column panels
+static int64_t precond_pack_units(int64_t M) { return 2 * M * h2_f64_packed_ld(M); }     // packed T, later the packs of a merge level
+static int64_t precond_split_doubles(int64_t M) { return (precond_pack_units(M) + 2 * M * POTRF_NBO) / 2 + 2; }
+// power of two s with bound * s in [2^11, 2^12]: the entries' two f16 terms stay far from overflow (65504)
+static float split_scale_for(double bound) {
+  int e = 0;
+  frexp(bound > 1e-300 ? bound : 1.0, &e);      // bound = f 2^e, f in [0.5, 1)
+  return ldexpf(1.f, 12 - e);
+}
+
+
 // pk != nullptr: the rank-512 trailing updates (the bulk of the flops) run on the split-f16 tile core (gemm_h2_f64:
 // f32-accurate products added into the f64 trailing matrix) — for a factor that only preconditions.  pk: two packed panel
 // buffers per matrix, pk_buf 4-byte units apart, matrices pk_z apart; pk_scale: power of two with |L_ij| pk_scale << 65504.
@@ -716,8 +739,12 @@ int trmv_batched_f64(const double* Tri, int64_t ld, int64_t tri_stride, int uplo
 //   GEMM 1:  WT = (L21 X11)'        A = L21 (m2 x s), B = X11' = Lit block (upper), stored transposed
 //   GEMM 2:  X21 = -X22 WT'         A = X22 (lower), B = WT;  X21 -> Li, X21' -> Lit
 // Li and Lit must be zero on entry outside what is written here.  WT: >= M*M doubles.
+// pk != nullptr: the merge levels of 512 rows and more run on the split-f16 tile core (the inverse of a factor that only
+// preconditions): pk holds pk_cap 4-byte units per matrix (matrices pk_z apart; a level needs at most 2 M roundup(M, 64));
+// bound_l / bound_inv: bounds of |L_ij| and of |(L^-1)_ij| the operand scales are taken from.
 int trtri_from_diag_f64(const double* L, int64_t ldl, int64_t M, const double* Dinv, double* Li, double* Lit,
-                        int64_t ld, double* WT, hipStream_t stream, const ZBatch& zb) {
+                        int64_t ld, double* WT, hipStream_t stream, const ZBatch& zb, uint32_t* pk, int64_t pk_cap, int64_t pk_z,
+                        double bound_l, double bound_inv) {
   constexpr int NB = POTRF_NB;
   ODX_REQUIRE(ld % 2 == 0 && ldl % 2 == 0, "trtri_f64: leading dimensions must be even");
   const int Z = zb.count;
@@ -729,6 +756,52 @@ int trtri_from_diag_f64(const double* L, int64_t ldl, int64_t M, const double* D
   ODX_CHECK_LAUNCH("place_diag_inverses");
   for (int64_t s = NB; s < M; s *= 2) {
     const int nb = (int)ceil_div(M, 2 * s);  // pairs; the last may be ragged or empty
+    const int nbe = (int)ceil_div(M - s, 2 * s);                       // pairs with rows below their first block
+    const int64_t m2l = M - s - (int64_t)(nbe - 1) * 2 * s;            // rows of the last pair's second block (<= s)
+    const int64_t szr = (int64_t)(nbe - 1) * s * s + (m2l < s ? m2l : s) * s;     // packs whose rows are ragged (ld = s)
+    if (pk != nullptr && s >= 512 && 2 * szr + 2 * (int64_t)nbe * s * s <= pk_cap) {
+      const float sl = split_scale_for(bound_l), si = split_scale_for(bound_inv), sw = split_scale_for(bound_l * bound_inv);
+      uint32_t *pL21 = pk, *pX11 = pL21 + szr, *pX22 = pX11 + (int64_t)nbe * s * s, *pWT = pX22 + szr;
+      double one[ODX_MAX_ZBATCH], mone[ODX_MAX_ZBATCH];
+      for (int z = 0; z < Z; ++z) { one[z] = 1.0; mone[z] = -1.0; }
+      SplitBlocksArgs k1;                    // L21 of every pair: rows ragged
+      k1.X = L + s * ldl; k1.ldx = ldl; k1.bsx = 2 * s * (ldl + 1); k1.zsx = zb.strideA;
+      k1.P = pL21; k1.ldp = s; k1.bsp = s * s; k1.zsp = pk_z; k1.rows = s; k1.cols = s;
+      k1.rg_total = M; k1.rg_off = s; k1.rg_step = 2 * s; k1.rows_ragged = 1; k1.nb = nbe; k1.Z = Z; k1.scale = sl;
+      ODX_PROPAGATE(split_f64_blocks(k1, stream));
+      SplitBlocksArgs k2;                    // X11' of every pair (the Lit block: upper)
+      k2.X = Lit; k2.ldx = ld; k2.bsx = 2 * s * (ld + 1); k2.zsx = zb.strideO;
+      k2.P = pX11; k2.ldp = s; k2.bsp = s * s; k2.zsp = pk_z; k2.rows = s; k2.cols = s; k2.nb = nbe; k2.Z = Z; k2.scale = si;
+      ODX_PROPAGATE(split_f64_blocks(k2, stream));
+      H2F64Args a1;                          // WT = (L21 X11)'
+      a1.PA = pL21; a1.ldpa = s; a1.zsa = pk_z; a1.bsa = s * s; a1.sa = sl;
+      a1.PB = pX11; a1.ldpb = s; a1.zsb = pk_z; a1.bsb = s * s; a1.sb = si;
+      a1.C = WT; a1.ldc = s; a1.zsc = zb.strideW; a1.bsc = s * s;
+      a1.m = s; a1.n = s; a1.k = s; a1.rg_total = M; a1.rg_off = s; a1.rg_step = 2 * s;
+      a1.flags = ODX_GEMM_B_UPPER | ODX_GEMM_STORE_T; a1.zcount = Z; a1.nb = nbe; a1.beta = 0.0;
+      for (int z = 0; z < Z; ++z) a1.alpha[z] = one[z];
+      ODX_PROPAGATE(gemm_h2_f64_ex(a1, stream));
+      SplitBlocksArgs k3;                    // X22 of every pair: rows and columns ragged
+      k3.X = Li + s * (ld + 1); k3.ldx = ld; k3.bsx = 2 * s * (ld + 1); k3.zsx = zb.strideO;
+      k3.P = pX22; k3.ldp = s; k3.bsp = s * s; k3.zsp = pk_z; k3.rows = s; k3.cols = s;
+      k3.rg_total = M; k3.rg_off = s; k3.rg_step = 2 * s; k3.rows_ragged = 1; k3.cols_ragged = 1; k3.nb = nbe; k3.Z = Z; k3.scale = si;
+      ODX_PROPAGATE(split_f64_blocks(k3, stream));
+      SplitBlocksArgs k4;                    // WT of every pair: s rows, columns ragged
+      k4.X = WT; k4.ldx = s; k4.bsx = s * s; k4.zsx = zb.strideW;
+      k4.P = pWT; k4.ldp = s; k4.bsp = s * s; k4.zsp = pk_z; k4.rows = s; k4.cols = s;
+      k4.rg_total = M; k4.rg_off = s; k4.rg_step = 2 * s; k4.cols_ragged = 1; k4.nb = nbe; k4.Z = Z; k4.scale = sw;
+      ODX_PROPAGATE(split_f64_blocks(k4, stream));
+      H2F64Args a2;                          // X21 = -X22 WT'  -> Li, and transposed -> Lit
+      a2.PA = pX22; a2.ldpa = s; a2.zsa = pk_z; a2.bsa = s * s; a2.sa = si;
+      a2.PB = pWT; a2.ldpb = s; a2.zsb = pk_z; a2.bsb = s * s; a2.sb = sw;
+      a2.C = Li + s * ld; a2.ldc = ld; a2.zsc = zb.strideO; a2.bsc = 2 * s * (ld + 1);
+      a2.C2 = Lit + s; a2.ldc2 = ld; a2.zsc2 = zb.strideO; a2.bsc2 = 2 * s * (ld + 1);
+      a2.m = s; a2.n = s; a2.k = s; a2.rg_total = M; a2.rg_off = s; a2.rg_step = 2 * s; a2.k_is_m = 1;
+      a2.flags = ODX_GEMM_A_LOWER; a2.zcount = Z; a2.nb = nbe; a2.beta = 0.0;
+      for (int z = 0; z < Z; ++z) a2.alpha[z] = mone[z];
+      ODX_PROPAGATE(gemm_h2_f64_ex(a2, stream));
+      continue;
+    }
     GemmParams<double> g1;
     g1.A = L + s * ldl; g1.lda = ldl;                  // L21 of pair 0: rows s.., cols 0..
     g1.B = Lit; g1.ldb = ld;                           // X11' of pair 0
@@ -850,26 +923,6 @@ extern "C" int odx_trtri_f64(const double* L, int64_t ldl, int64_t M, double* Li
 // asynchronous with respect to the host.
 static int64_t precond_ld(int64_t M) { return round_up(M, 2); }
 
-// The GEMM-shaped work of the A factor (T T' / M, the rank-512 updates of its Cholesky) on the split-f16 tile core: A only
-// preconditions the system (the solution the CG converges to does not depend on it, and the reference's all-f32 falkon gives it
-// f32 accuracy at best), so its products are formed at f32 accuracy at ~6 x the f64 MFMA rate; T, whose products define the
-// regulariser, stays f64 throughout.  ODX_PRECOND = "f64": never; "split": always; default: from 4096 centres on (below that
-// the chain is latency-bound and nothing is gained).  Read at every call.
-static bool precond_split(int64_t M) {
-  const char* e = getenv("ODX_PRECOND");
-  if (e && e[0] == 'f') return false;
-  if (e && e[0] == 's') return true;
-  return M >= 4096;
-}
-// scratch of the split path per matrix, in doubles: packed T (M x roundup(M, 64) 4-byte units) + two packed 512-column panels
-static int64_t precond_split_doubles(int64_t M) { return (M * h2_f64_packed_ld(M) + 2 * M * POTRF_NBO) / 2 + 2; }
-// power of two s with bound * s in [2^11, 2^12]: the entries' two f16 terms stay far from overflow (65504)
-static float split_scale_for(double bound) {
-  int e = 0;
-  frexp(bound > 1e-300 ? bound : 1.0, &e);      // bound = f 2^e, f in [0.5, 1)
-  return ldexpf(1.f, 12 - e);
-}
-
 extern "C" int64_t odx_falkon_precond_workspace_bytes(int64_t M, int D) {
   if (M <= 0 || D <= 0) return 0;
   const int64_t ld = precond_ld(M), ldzd = round_up(D, 2);
@@ -905,8 +958,8 @@ extern "C" int odx_falkon_precond_f64(const float* Z, int64_t ldz, int64_t M, in
   double* DinvA = DinvT + dsz;
   const bool split = precond_split(M);
   const int64_t ldpt = h2_f64_packed_ld(M);
-  uint32_t* Tk = reinterpret_cast<uint32_t*>(DinvA + dsz);             // packed T, then the two packed panels
-  uint32_t* Pk = Tk + M * ldpt;
+  uint32_t* Tk = reinterpret_cast<uint32_t*>(DinvA + dsz);             // packed T (later: merge-level packs), then the two packed panels
+  uint32_t* Pk = Tk + precond_pack_units(M);
 
   ODX_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), s));
   ODX_CHECK_HIP(hipMemsetAsync(Zd, 0, (size_t)(M * ldzd) * sizeof(double), s));
@@ -950,6 +1003,9 @@ extern "C" int odx_falkon_precond_f64(const float* Z, int64_t ldz, int64_t M, in
   ODX_CHECK_HIP(hipStreamWaitEvent(s, side->join, 0));
   ODX_PROPAGATE(fill_f64(LAi, ld, M, M, 0.0, s));
   ODX_PROPAGATE(fill_f64(LAit, ld, M, M, 0.0, s));
+  if (split && eps + lam > 0.0)
+    return trtri_from_diag_f64(W2, wld, M, DinvA, LAi, LAit, ld, W1, s, ZBatch(), Tk, precond_pack_units(M), 0, sqrt(1.0 + eps + lam),
+                               1.0 / sqrt(eps + lam));
   ODX_PROPAGATE(trtri_from_diag_f64(W2, wld, M, DinvA, LAi, LAit, ld, W1, s));
   return ODX_OK;
 }
@@ -1005,8 +1061,8 @@ extern "C" int odx_falkon_precond_batched_f64(const float* const* Z, const int64
   double* LTi = out, *LTit = out + Mmax * ld, *LAi = out + 2 * Mmax * ld, *LAit = out + 3 * Mmax * ld;
   const bool split = precond_split(Mmax);
   const int64_t ldpt = h2_f64_packed_ld(Mmax);
-  uint32_t* Tk = reinterpret_cast<uint32_t*>(DinvA + (int64_t)B * dsz);   // packed T of every class, then the packed panels
-  uint32_t* Pk = Tk + (int64_t)B * Mmax * ldpt;
+  uint32_t* Tk = reinterpret_cast<uint32_t*>(DinvA + (int64_t)B * dsz);   // packed T of every class (later: merge-level packs), then the packed panels
+  uint32_t* Pk = Tk + (int64_t)B * precond_pack_units(Mmax);
 
   ODX_CHECK_HIP(hipMemsetAsync(info, 0, (size_t)B * sizeof(int32_t), s));
   ODX_CHECK_HIP(hipMemsetAsync(Zd0, 0, (size_t)((int64_t)B * zper) * sizeof(double), s));
@@ -1044,8 +1100,8 @@ extern "C" int odx_falkon_precond_batched_f64(const float* const* Z, const int64
     const float st = split_scale_for(sqrt(1.0 + eps * 65536.0)), sa = split_scale_for(sqrt(1.0 + eps + lam));
     double a1[ODX_MAX_ZBATCH];
     for (int b = 0; b < B; ++b) a1[b] = 1.0 / (double)M[b];
-    ODX_PROPAGATE(split_f64(W1, wld, wsz, Mmax, Mmax, st, Tk, ldpt, Mmax * ldpt, B, s));
-    ODX_PROPAGATE(gemm_h2_f64(Tk, ldpt, Mmax * ldpt, st, Tk, ldpt, Mmax * ldpt, st, W2, wld, wsz, Mmax, Mmax, Mmax, a1, 0.0,
+    ODX_PROPAGATE(split_f64(W1, wld, wsz, Mmax, Mmax, st, Tk, ldpt, precond_pack_units(Mmax), B, s));
+    ODX_PROPAGATE(gemm_h2_f64(Tk, ldpt, precond_pack_units(Mmax), st, Tk, ldpt, precond_pack_units(Mmax), st, W2, wld, wsz, Mmax, Mmax, Mmax, a1, 0.0,
                               ODX_GEMM_LOWER_ONLY | ODX_GEMM_A_UPPER | ODX_GEMM_B_UPPER, B, s));
     ODX_PROPAGATE(add_diag_f64(W2, wld, Mmax, lam, s, B, wsz));
     ODX_PROPAGATE(potrf_f64(W2, wld, Mmax, DinvA, info, s, zt, Pk, (int64_t)B * Mmax * POTRF_NBO, Mmax * POTRF_NBO, sa));
@@ -1063,6 +1119,10 @@ extern "C" int odx_falkon_precond_batched_f64(const float* const* Z, const int64
   }
   // join, then the inverses of L_A (scratch W1: T is no longer needed)
   ODX_CHECK_HIP(hipStreamWaitEvent(s, side->join, 0));
+  // (every eigenvalue of T T' / M_b + lam I is at least eps + lam: |(L_A^-1)_ij| <= 1 / sqrt(eps + lam))
+  if (split && eps + lam > 0.0)
+    return trtri_from_diag_f64(W2, wld, Mmax, DinvA, LAi, LAit, ld, W1, s, zt, Tk, precond_pack_units(Mmax), precond_pack_units(Mmax),
+                               sqrt(1.0 + eps + lam), 1.0 / sqrt(eps + lam));
   return trtri_from_diag_f64(W2, wld, Mmax, DinvA, LAi, LAit, ld, W1, s, zt);
 }
 

@@ -1089,73 +1089,165 @@ __global__ __launch_bounds__(256) void split_f64_kernel(const double* __restrict
 }
 
 struct H2F64Params {
-  const uint32_t* PA; int64_t ldpa, zsa;      // packed A (m x k), class stride in 4-byte units
-  const uint32_t* PB; int64_t ldpb, zsb;      // packed B (n x k)
-  double* C; int64_t ldc, zsc;
-  int64_t m, n;
-  int stages;                                  // 32-column stages of the packed rows
-  int flags;                                   // ODX_GEMM_LOWER_ONLY | ODX_GEMM_A_UPPER | ODX_GEMM_B_UPPER
+  const uint32_t* PA; int64_t ldpa, zsa, bsa;  // packed A (m x k); class / block strides in 4-byte units
+  const uint32_t* PB; int64_t ldpb, zsb, bsb;  // packed B (n x k)
+  double* C; int64_t ldc, zsc, bsc;
+  double* C2; int64_t ldc2, zsc2, bsc2;        // optional transposed copy C2[j, i]
+  int64_t m, n, k;
+  int64_t rg_total, rg_off, rg_step;           // ragged blocks: m_b = clamp(total - off - b step, 0, m)
+  int k_is_m;                                  // k_b = m_b
+  int flags;                                   // ODX_GEMM_LOWER_ONLY | A_UPPER | B_UPPER | A_LOWER | B_LOWER | STORE_T
   double beta;
   double alpha[ODX_MAX_ZBATCH];                // per class, 1 / (s_A s_B) folded in
 };
 
+// The same packing for a batch of blocks of f64 matrices (the pairs of a triangular-inverse merge level, for every class):
+// block (b, z) starts bsx * b + zsx * z doubles into X and has rows_b x cols_b entries, rows_b / cols_b = the ragged extent
+// clamp(total - off - b step, 0, rows / cols) where asked for (the last pair of a level may be short).  Rows past rows_b are
+// not written (the products clamp their row reads), columns past cols_b are written as zeros up to a whole k-tile.
+struct SplitBlocks {
+  const double* X; int64_t ldx, bsx, zsx;
+  uint32_t* P; int64_t ldp, bsp, zsp;
+  int64_t rows, cols;                         // extent of a full block
+  int64_t rg_total, rg_off, rg_step;          // ragged extent: total - off - b * step
+  int rows_ragged, cols_ragged, Z;
+  float s;
+};
+
+__global__ __launch_bounds__(256) void split_f64_blocks_kernel(SplitBlocks p) {
+  const int b = blockIdx.z / p.Z, z = blockIdx.z % p.Z;
+  int64_t rg = p.rg_total - p.rg_off - (int64_t)b * p.rg_step;
+  const int64_t rows = p.rows_ragged ? (rg < p.rows ? (rg > 0 ? rg : 0) : p.rows) : p.rows;
+  const int64_t cols = p.cols_ragged ? (rg < p.cols ? (rg > 0 ? rg : 0) : p.cols) : p.cols;
+  const int64_t row = blockIdx.y;
+  const int groups = (int)((cols + H2_KT - 1) / H2_KT) * 8;
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= groups || row >= rows) return;
+  const double* x = p.X + (int64_t)b * p.bsx + (int64_t)z * p.zsx + row * p.ldx + (int64_t)g * 8;
+  double v[8];
+  if (g * 8 + 8 <= cols) {
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+      const f64x2 a = *reinterpret_cast<const f64x2*>(x + q);
+      v[q] = a[0];
+      v[q + 1] = a[1];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = (g * 8 + q < cols) ? x[q] : 0.0;
+  }
+  f16x8 hi, lo;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float t = (float)(v[q] * (double)p.s);
+    const _Float16 h = (_Float16)t;
+    hi[q] = h;
+    lo[q] = (_Float16)(t - (float)h);
+  }
+  uint32_t* dst = p.P + (int64_t)b * p.bsp + (int64_t)z * p.zsp + row * p.ldp + (int64_t)(g >> 2) * 32 + (g & 3) * 4;
+  *reinterpret_cast<f16x8*>(dst) = hi;
+  *reinterpret_cast<f16x8*>(dst + 16) = lo;
+}
+
 __global__ __launch_bounds__(W_THREADS, 1) void gemm_h2w256_f64_kernel(H2F64Params p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int64_t GR = 4;
+  const int z = blockIdx.y, b = blockIdx.z;
+  int64_t m = p.m, k = p.k;
+  if (p.rg_total > 0) {                                               // ragged batch: the last pair of a merge level may be short
+    int64_t mb = p.rg_total - p.rg_off - (int64_t)b * p.rg_step;
+    if (mb > p.m) mb = p.m;
+    if (mb <= 0) return;
+    m = mb;
+    if (p.k_is_m) k = mb;
+  }
   const int64_t tiles_n = (p.n + W_BN - 1) / W_BN;
   const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
   const int64_t band = wg / (GR * tiles_n), within = wg % (GR * tiles_n);
   const int64_t i0 = (band * GR + within % GR) * W_BM, j0 = (within / GR) * W_BN;
-  if (i0 >= p.m) return;
+  if (i0 >= m) return;
   const bool lower = (p.flags & ODX_GEMM_LOWER_ONLY) != 0;
   if (lower && j0 > i0 + W_BM - 1) return;
-  const int z = blockIdx.y;
-  int64_t kb = 0;                                                     // operands known to be zero left of column kb
+  int64_t kb = 0, ke = k;                                             // operands known to be zero left of kb / right of ke
   if (p.flags & ODX_GEMM_A_UPPER) kb = i0;
   if ((p.flags & ODX_GEMM_B_UPPER) && j0 > kb) kb = j0;
+  if ((p.flags & ODX_GEMM_A_LOWER) && i0 + W_BM < ke) ke = i0 + W_BM;
+  if ((p.flags & ODX_GEMM_B_LOWER) && j0 + W_BN < ke) ke = j0 + W_BN;
   const int s0 = (int)(kb / W_KS);                                    // i0, j0 are multiples of 256
-  const int stages = p.stages - s0;
+  const int stages = (int)((((ke + H2_KT - 1) / H2_KT) * H2_KT) / W_KS) - s0;
   f32x4 acc[8][4];
   w_zero(acc);
   if (stages > 0)
-    w_mainloop_dma<true>(acc, p.PA + (int64_t)z * p.zsa + (int64_t)s0 * W_KS, p.ldpa, p.m, p.PB + (int64_t)z * p.zsb + (int64_t)s0 * W_KS,
-                         p.ldpb, p.n, i0, j0, stages, lds);
+    w_mainloop_dma<true>(acc, p.PA + (int64_t)b * p.bsa + (int64_t)z * p.zsa + (int64_t)s0 * W_KS, p.ldpa, m,
+                         p.PB + (int64_t)b * p.bsb + (int64_t)z * p.zsb + (int64_t)s0 * W_KS, p.ldpb, p.n, i0, j0, stages, lds);
   const double alpha = p.alpha[z], beta = p.beta;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   const int64_t col = j0 + wc * 64 + 4 * (lane & 15);                 // four adjacent columns per lane (permuted B rows)
   const int64_t rb = i0 + wr * 128 + 4 * (lane >> 4);
   if (col >= p.n) return;
-  double* pc = p.C + (int64_t)z * p.zsc + rb * p.ldc + col;
+  double* C = p.C + (int64_t)b * p.bsc + (int64_t)z * p.zsc;
+  double* C2 = p.C2 ? p.C2 + (int64_t)b * p.bsc2 + (int64_t)z * p.zsc2 : nullptr;
+  const bool st = (p.flags & ODX_GEMM_STORE_T) != 0;
+  if (!st) {
+    double* pc = C + rb * p.ldc + col;
 #pragma unroll
-  for (int tm = 0; tm < 8; ++tm) {
+    for (int tm = 0; tm < 8; ++tm) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int64_t row = rb + tm * 16 + q;
-      if (row < p.m) {
-        // lower-only: what the f64 kernel's 128-row tiles write — every column up to the end of the row's 128-block
-        const int64_t lim = lower ? (((row | 127) + 1 < p.n) ? (row | 127) + 1 : p.n) : p.n;
-        if (col + 4 <= lim) {
-          f64x2 c0 = {0.0, 0.0}, c1 = {0.0, 0.0};
-          if (beta != 0.0) {
-            c0 = *reinterpret_cast<const f64x2*>(pc);
-            c1 = *reinterpret_cast<const f64x2*>(pc + 2);
+      for (int q = 0; q < 4; ++q) {
+        const int64_t row = rb + tm * 16 + q;
+        if (row < m) {
+          // lower-only: what the f64 kernel's 128-row tiles write — every column up to the end of the row's 128-block
+          const int64_t lim = lower ? (((row | 127) + 1 < p.n) ? (row | 127) + 1 : p.n) : p.n;
+          if (col + 4 <= lim) {
+            f64x2 c0 = {0.0, 0.0}, c1 = {0.0, 0.0};
+            if (beta != 0.0) {
+              c0 = *reinterpret_cast<const f64x2*>(pc);
+              c1 = *reinterpret_cast<const f64x2*>(pc + 2);
+            }
+            c0[0] = fma(alpha, (double)acc[tm][0][q], beta * c0[0]);
+            c0[1] = fma(alpha, (double)acc[tm][1][q], beta * c0[1]);
+            c1[0] = fma(alpha, (double)acc[tm][2][q], beta * c1[0]);
+            c1[1] = fma(alpha, (double)acc[tm][3][q], beta * c1[1]);
+            *reinterpret_cast<f64x2*>(pc) = c0;
+            *reinterpret_cast<f64x2*>(pc + 2) = c1;
+          } else {
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+              if (col + tn < lim) pc[tn] = fma(alpha, (double)acc[tm][tn][q], beta != 0.0 ? beta * pc[tn] : 0.0);
           }
-          c0[0] = fma(alpha, (double)acc[tm][0][q], beta * c0[0]);
-          c0[1] = fma(alpha, (double)acc[tm][1][q], beta * c0[1]);
-          c1[0] = fma(alpha, (double)acc[tm][2][q], beta * c1[0]);
-          c1[1] = fma(alpha, (double)acc[tm][3][q], beta * c1[1]);
-          *reinterpret_cast<f64x2*>(pc) = c0;
-          *reinterpret_cast<f64x2*>(pc + 2) = c1;
+        }
+        pc += p.ldc;
+      }
+      pc += 12 * p.ldc;
+    }
+  }
+  if (st || C2 != nullptr) {
+    // transposed store(s): for a column, the lane's rows q = 0..3 of a row block are four adjacent doubles (beta = 0 forms only)
+    double* ct = st ? C : C2;
+    const int64_t ldt = st ? p.ldc : p.ldc2;
+#pragma unroll
+    for (int tm = 0; tm < 8; ++tm) {
+      const int64_t row = rb + tm * 16;
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        if (col + tn >= p.n) continue;
+        double* pt = ct + (col + tn) * ldt + row;
+        if (row + 4 <= m) {
+          f64x2 c0, c1;
+          c0[0] = alpha * (double)acc[tm][tn][0];
+          c0[1] = alpha * (double)acc[tm][tn][1];
+          c1[0] = alpha * (double)acc[tm][tn][2];
+          c1[1] = alpha * (double)acc[tm][tn][3];
+          *reinterpret_cast<f64x2*>(pt) = c0;
+          *reinterpret_cast<f64x2*>(pt + 2) = c1;
         } else {
 #pragma unroll
-          for (int tn = 0; tn < 4; ++tn)
-            if (col + tn < lim) pc[tn] = fma(alpha, (double)acc[tm][tn][q], beta != 0.0 ? beta * pc[tn] : 0.0);
+          for (int q = 0; q < 4; ++q)
+            if (row + q < m) pt[q] = alpha * (double)acc[tm][tn][q];
         }
       }
-      pc += p.ldc;
     }
-    pc += 12 * p.ldc;
   }
 }
 
@@ -1299,23 +1391,54 @@ int split_f64(const double* X, int64_t ldx, int64_t zsx, int64_t rows, int64_t c
   return ODX_OK;
 }
 
+int split_f64_blocks(const SplitBlocksArgs& a, hipStream_t stream) {
+  if (a.rows <= 0 || a.cols <= 0 || a.nb <= 0 || a.Z <= 0) return ODX_OK;
+  ODX_REQUIRE(a.ldx % 2 == 0 && aligned16(a.X) && a.zsx % 2 == 0 && a.bsx % 2 == 0, "split_f64_blocks: X blocks must be 16-byte aligned");
+  ODX_REQUIRE(a.ldp % 4 == 0 && a.ldp >= round_up(a.cols, H2_KT) && aligned16(a.P) && a.zsp % 4 == 0 && a.bsp % 4 == 0,
+              "split_f64_blocks: packed rows cover roundup(cols, 64)");
+  ODX_REQUIRE(a.rows < 65536 && (int64_t)a.nb * a.Z < 65536, "split_f64_blocks: too many rows / blocks");
+  SplitBlocks p;
+  p.X = a.X; p.ldx = a.ldx; p.bsx = a.bsx; p.zsx = a.zsx; p.P = a.P; p.ldp = a.ldp; p.bsp = a.bsp; p.zsp = a.zsp;
+  p.rows = a.rows; p.cols = a.cols; p.rg_total = a.rg_total; p.rg_off = a.rg_off; p.rg_step = a.rg_step;
+  p.rows_ragged = a.rows_ragged; p.cols_ragged = a.cols_ragged; p.Z = a.Z; p.s = a.scale;
+  const int groups = (int)(round_up(a.cols, H2_KT) / 8);
+  hipLaunchKernelGGL(split_f64_blocks_kernel, dim3((unsigned)ceil_div(groups, 256), (unsigned)a.rows, (unsigned)(a.nb * a.Z)), dim3(256), 0,
+                     stream, p);
+  ODX_CHECK_LAUNCH("split_f64_blocks");
+  return ODX_OK;
+}
+
+int gemm_h2_f64_ex(const H2F64Args& a, hipStream_t stream) {
+  if (a.m <= 0 || a.n <= 0 || a.zcount <= 0 || a.nb <= 0) return ODX_OK;
+  ODX_REQUIRE(a.zcount <= ODX_MAX_ZBATCH && a.nb < 65536 && a.ldc % 2 == 0 && a.zsc % 2 == 0 && a.bsc % 2 == 0 && aligned16(a.C),
+              "gemm_h2_f64: C must be 16-byte aligned, even ld / strides");
+  ODX_REQUIRE(a.C2 == nullptr || (a.ldc2 % 2 == 0 && a.zsc2 % 2 == 0 && a.bsc2 % 2 == 0 && aligned16(a.C2)), "gemm_h2_f64: C2 alignment");
+  ODX_REQUIRE(!(a.flags & ODX_GEMM_STORE_T) || a.beta == 0.0, "gemm_h2_f64: a transposed store cannot accumulate");
+  ODX_REQUIRE(a.ldpa < (1 << 24) && a.ldpb < (1 << 24) && a.ldpa >= round_up(a.k, H2_KT) && a.ldpb >= round_up(a.k, H2_KT),
+              "gemm_h2_f64: packed leading dimensions");
+  H2F64Params p;
+  p.PA = a.PA; p.ldpa = a.ldpa; p.zsa = a.zsa; p.bsa = a.bsa; p.PB = a.PB; p.ldpb = a.ldpb; p.zsb = a.zsb; p.bsb = a.bsb;
+  p.C = a.C; p.ldc = a.ldc; p.zsc = a.zsc; p.bsc = a.bsc; p.C2 = a.C2; p.ldc2 = a.ldc2; p.zsc2 = a.zsc2; p.bsc2 = a.bsc2;
+  p.m = a.m; p.n = a.n; p.k = a.k; p.rg_total = a.rg_total; p.rg_off = a.rg_off; p.rg_step = a.rg_step; p.k_is_m = a.k_is_m;
+  p.flags = a.flags; p.beta = a.beta;
+  for (int z = 0; z < a.zcount; ++z) p.alpha[z] = a.alpha[z] / ((double)a.sa * (double)a.sb);
+  const int64_t wt = round_up(ceil_div(a.m, W_BM), 4) * ceil_div(a.n, W_BN);
+  ODX_REQUIRE(wt < (1ll << 31), "gemm_h2_f64: grid too large");
+  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2w256_f64_kernel), W_LDS_BYTES));
+  hipLaunchKernelGGL(gemm_h2w256_f64_kernel, dim3((unsigned)wt, (unsigned)a.zcount, (unsigned)a.nb), dim3(W_THREADS), W_LDS_BYTES, stream, p);
+  ODX_CHECK_LAUNCH("gemm_h2_f64");
+  return ODX_OK;
+}
+
 // C_z = alpha_z (A_z B_z') / (sa sb) + beta C_z for z = 0 .. zcount - 1; k = columns of the operands
 int gemm_h2_f64(const uint32_t* PA, int64_t ldpa, int64_t zsa, float sa, const uint32_t* PB, int64_t ldpb, int64_t zsb, float sb,
                 double* C, int64_t ldc, int64_t zsc, int64_t m, int64_t n, int64_t k, const double* alpha, double beta, int flags,
                 int zcount, hipStream_t stream) {
-  if (m <= 0 || n <= 0 || zcount <= 0) return ODX_OK;
-  ODX_REQUIRE(zcount <= ODX_MAX_ZBATCH && ldc % 2 == 0 && zsc % 2 == 0 && aligned16(C), "gemm_h2_f64: C must be 16-byte aligned, even ld");
-  ODX_REQUIRE(ldpa < (1 << 24) && ldpb < (1 << 24) && ldpa >= round_up(k, H2_KT) && ldpb >= round_up(k, H2_KT), "gemm_h2_f64: packed leading dimensions");
-  H2F64Params p;
-  p.PA = PA; p.ldpa = ldpa; p.zsa = zsa; p.PB = PB; p.ldpb = ldpb; p.zsb = zsb; p.C = C; p.ldc = ldc; p.zsc = zsc;
-  p.m = m; p.n = n; p.stages = (int)(round_up(k, H2_KT) / W_KS); p.flags = flags; p.beta = beta;
-  for (int z = 0; z < zcount; ++z) p.alpha[z] = alpha[z] / ((double)sa * (double)sb);
-  const int64_t wt = round_up(ceil_div(m, W_BM), 4) * ceil_div(n, W_BN);
-  ODX_REQUIRE(wt < (1ll << 31), "gemm_h2_f64: grid too large");
-  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2w256_f64_kernel), W_LDS_BYTES));
-  hipLaunchKernelGGL(gemm_h2w256_f64_kernel, dim3((unsigned)wt, (unsigned)zcount), dim3(W_THREADS), W_LDS_BYTES, stream, p);
-  ODX_CHECK_LAUNCH("gemm_h2_f64");
-  return ODX_OK;
+  H2F64Args a;
+  a.PA = PA; a.ldpa = ldpa; a.zsa = zsa; a.sa = sa; a.PB = PB; a.ldpb = ldpb; a.zsb = zsb; a.sb = sb;
+  a.C = C; a.ldc = ldc; a.zsc = zsc; a.m = m; a.n = n; a.k = k; a.beta = beta; a.flags = flags; a.zcount = zcount;
+  for (int z = 0; z < zcount && z < ODX_MAX_ZBATCH; ++z) a.alpha[z] = alpha[z];
+  return gemm_h2_f64_ex(a, stream);
 }
 
 }  // namespace odx

@@ -53,7 +53,8 @@ int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv /* nblk x NB x NB 
               hipStream_t stream, const ZBatch& zb = ZBatch(), uint32_t* pk = nullptr, int64_t pk_buf = 0, int64_t pk_z = 0,
               float pk_scale = 1.f);
 int trtri_from_diag_f64(const double* L, int64_t ldl, int64_t M, const double* Dinv, double* Li, double* Lit,
-                        int64_t ld, double* WT, hipStream_t stream, const ZBatch& zb = ZBatch());
+                        int64_t ld, double* WT, hipStream_t stream, const ZBatch& zb = ZBatch(), uint32_t* pk = nullptr,
+                        int64_t pk_cap = 0, int64_t pk_z = 0, double bound_l = 1.0, double bound_inv = 1.0);
 int transpose_f64(const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols,
                   hipStream_t stream, int zcount = 1, int64_t zstride_src = 0, int64_t zstride_dst = 0);
 int add_diag_f64(double* A, int64_t lda, int64_t M, double value, hipStream_t stream, int zcount = 1, int64_t zstride = 0);
@@ -93,6 +94,27 @@ int cg_full_residual_batched(const VecBatch& vb, const double* Bv, const double*
 int64_t h2_f64_packed_ld(int64_t cols);            // 4-byte units per packed row
 int split_f64(const double* X, int64_t ldx, int64_t zsx, int64_t rows, int64_t cols, float scale, uint32_t* P, int64_t ldp,
               int64_t zsp, int z, hipStream_t stream);
+struct SplitBlocksArgs {          // a batch of nb x Z blocks of f64 matrices -> packed splits (split_f64_blocks_kernel)
+  const double* X = nullptr; int64_t ldx = 0, bsx = 0, zsx = 0;
+  uint32_t* P = nullptr; int64_t ldp = 0, bsp = 0, zsp = 0;
+  int64_t rows = 0, cols = 0;
+  int64_t rg_total = 0, rg_off = 0, rg_step = 0;
+  int rows_ragged = 0, cols_ragged = 0, nb = 1, Z = 1;
+  float scale = 1.f;
+};
+int split_f64_blocks(const SplitBlocksArgs& a, hipStream_t stream);
+struct H2F64Args {                // C = alpha (A B') / (sa sb) + beta C over nb blocks x zcount classes (gemm_h2w256_f64_kernel)
+  const uint32_t* PA = nullptr; int64_t ldpa = 0, zsa = 0, bsa = 0; float sa = 1.f;
+  const uint32_t* PB = nullptr; int64_t ldpb = 0, zsb = 0, bsb = 0; float sb = 1.f;
+  double* C = nullptr; int64_t ldc = 0, zsc = 0, bsc = 0;
+  double* C2 = nullptr; int64_t ldc2 = 0, zsc2 = 0, bsc2 = 0;
+  int64_t m = 0, n = 0, k = 0;
+  int64_t rg_total = 0, rg_off = 0, rg_step = 0;
+  int k_is_m = 0, flags = 0, zcount = 1, nb = 1;
+  double beta = 0.0;
+  double alpha[ODX_MAX_ZBATCH] = {};
+};
+int gemm_h2_f64_ex(const H2F64Args& a, hipStream_t stream);
 int gemm_h2_f64(const uint32_t* PA, int64_t ldpa, int64_t zsa, float sa, const uint32_t* PB, int64_t ldpb, int64_t zsb, float sb,
                 double* C, int64_t ldc, int64_t zsc, int64_t m, int64_t n, int64_t k, const double* alpha, double beta, int flags,
                 int zcount, hipStream_t stream);

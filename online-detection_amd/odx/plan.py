@@ -48,10 +48,10 @@ def knm_bytes_rule(n, M, fmt):
 
 def chain_workspace_bytes(M, D):
     """odx_falkon_precond_batched_workspace_bytes per class: the f64 centres, four M x ld work matrices, the diagonal
-    blocks' inverses, and the packed f16 splits of T and of two 512-column panels (the A factor's products run on the
-    split tile core from 4096 centres on; the scratch is sized for every M)."""
+    blocks' inverses, and the packed f16 splits the A factor's products run on from 4096 centres on (2 M roundup(M, 64) units for
+    T and, later, a merge level's four operands; two 512-column panels) — the scratch is sized for every M."""
     ld = _round_up(M, 2)
-    split = (M * _round_up(M, 64) + 2 * M * 512) // 2 + 2
+    split = (2 * M * _round_up(M, 64) + 2 * M * 512) // 2 + 2
     return (M * _round_up(D, 2) + ld + 4 * M * ld + 2 * ((M + 127) // 128) * 128 * 128 + split) * 8
 
 
