@@ -170,6 +170,55 @@ def test_config5_shard_shape_one_class(be):
     torch.cuda.empty_cache()
 
 
+def test_config5_shard_shape_fp8_contraction(be):
+    """Config 5 AS STATED (fp8 e4m3 inputs to the X Z' MFMA, f32 accumulate; throughput only) at the shard one of its 8 GPUs
+    holds: 625 000 x 20 000, D = 1024.  The 37.5 GB block the fp8 build stores and the fp8 fused scoring are compared on
+    sampled rows with the numpy restatement of that arithmetic (operands scaled by the matrix's power of two and rounded once
+    to e4m3, exact products, norms of the ROUNDED rows), plus the size-independent pass properties on the stored block."""
+    from tests.test_gpu_kernels import _e4m3
+    n, D, M, sigma = 625_000, 1024, 20_000, 15.0
+    g = torch.Generator(device="cuda").manual_seed(11)
+    X = torch.randn((n, D), generator=g, device="cuda") * (20.0 / D ** 0.5)
+    idx = torch.arange(0, n, n // M, device="cuda")[:M]
+    F = be.features(X)
+    Zf = be.features(X.index_select(0, idx) + 0.05 * torch.randn((M, D), generator=g, device="cuda"))
+    old, oldk = be.gauss, be.knm_storage
+    try:
+        be.gauss = "f8"
+        assert be.knm_format(n, M) == "u24"
+        w = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+        K, ktw = be.knm_rhs(F, Zf, sigma, w)
+        sx, sz = float(F.meta8[0]), float(Zf.meta8[0])
+        rows = np.array([0, 1, 255, 256, 4097, n // 2, n - 257, n - 1])
+        cols = np.unique(np.concatenate([np.arange(0, 600), np.arange(M // 2 - 130, M // 2 + 130), np.arange(M - 300, M)]))
+        Xq = _e4m3(X[rows].cpu().numpy().astype(np.float64) * sx)
+        Zq = _e4m3(Zf.X.cpu().numpy().astype(np.float64) * sz)
+        sqx = ((Xq / sx) ** 2).sum(1)[:, None]
+        sqz = ((Zq / sz) ** 2).sum(1)[None, :]
+        Kq = np.exp(-np.maximum(sqx + sqz - 2.0 * (Xq @ Zq.T) / (sx * sz), 0.0) / (2 * sigma ** 2))
+        got = torch.stack([K.rows(int(r), int(r) + 1).dense()[0] for r in rows]).cpu().numpy().astype(np.float64)
+        assert np.abs(got[:, cols] - Kq[:, cols]).max() < 5e-4, np.abs(got[:, cols] - Kq[:, cols]).max()
+        assert np.abs(got - Kq).max() < 5e-4
+        # the fused right-hand side = one pass over the block the build stored; the pass: halves add up, repeatable
+        b0 = be.ktk(K, w=w)
+        assert float((ktw - b0).abs().max()) <= 1e-9 * max(1.0, float(b0.abs().max()))
+        v = torch.randn(M, dtype=torch.float64, device="cuda", generator=g)
+        full = be.ktk(K, v=v)
+        assert torch.equal(full, be.ktk(K, v=v))
+        parts = be.ktk(K.rows(0, n // 2 - 3), v=v) + be.ktk(K.rows(n // 2 - 3, n), v=v)
+        assert float((parts - full).abs().max()) <= 1e-11 * float(full.abs().max())
+        # fused scoring on the fp8 core, sampled rows against the restatement
+        al = torch.randn(M, dtype=torch.float64, device="cuda", generator=g) * 0.05
+        sc = be.mmv(F, Zf, sigma, al)
+        want = Kq @ al.cpu().numpy()
+        assert np.abs(sc[torch.from_numpy(rows).cuda(), 0].cpu().numpy() - want).max() < 5e-4 * float(al.abs().sum())
+        del K
+    finally:
+        be.gauss, be.knm_storage = old, oldk
+        be.release_workspaces()
+        torch.cuda.empty_cache()
+
+
 def test_config3_rls_thirty_regressors_n3e5(be):
     """Config 3's RLS half: COXY with n = 3e5 rows, D = 1024, 30 classes, lambda = 1000 through the drop-in
     RegionRefinerTrainer on the GPU; three classes (first, middle, last) against oracle/rls_ref.py, which is pinned to the

@@ -429,6 +429,53 @@ def test_fp8_contraction(be, n, M, D, sigma):
         be.gauss, be.knm_storage = old, oldk
 
 
+@pytest.mark.parametrize("n,M,D,sigma,amp", [(513, 1025, 200, 3.0, 8), (300, 257, 1024, 4.0, 4)])
+def test_fp8_contraction_is_exact_on_integer_operands(be, n, M, D, sigma, amp):
+    """The scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales) on operands it must multiply EXACTLY: integer
+    entries in [-amp, amp] (amp = 8 or 4) are e4m3 values after the power-of-two scaling, every product and every partial sum is an integer
+    below 2^24, so x . z and the row norms are exact whatever the order of summation — the stored entries must then equal
+    exp(-d^2 / 2 sigma^2) to the f32 accuracy of the exponent's three terms (a few 1e-5; round 3 asserted 5e-4 on random operands,
+    which a partial lane -> feature error on a few features could have hidden: one wrong product here moves an entry by >= 5 %)."""
+    rng = np.random.default_rng(n + D)
+    protos = rng.integers(-amp, amp + 1, (8, D)).astype(np.float32)            # eight integer prototypes; rows / centres = a prototype a few
+                                                                       # integer steps away: d^2 = 0 .. ~100 inside a prototype's family
+
+    def family(count):
+        A = protos[np.arange(count) % 8].copy()
+        for j in range(count):
+            c = rng.integers(0, D, int(rng.integers(0, 7)))
+            A[j, c] = np.clip(A[j, c] + rng.integers(-3, 4, c.size), -amp, amp)
+        A[0, 0] = float(amp)                                           # max |a| = amp: scale 128 / amp, values multiples of it <= 128
+        return A
+    X, Z = family(n), family(M)
+    Xd, Zd = X.astype(np.float64), Z.astype(np.float64)
+    d2 = (Xd * Xd).sum(1)[:, None] + (Zd * Zd).sum(1)[None, :] - 2.0 * Xd @ Zd.T
+    Kx = np.exp(-d2 / (2 * sigma ** 2))
+    assert (Kx > 1e-3).sum() > n * M // 32                             # plenty of entries that are not simply 0
+    F, Zf = be.features(torch.from_numpy(X)), be.features(torch.from_numpy(Z))
+    w = rng.standard_normal(n)
+    al = rng.standard_normal((M, 2))
+    old, oldk = be.gauss, be.knm_storage
+    try:
+        be.gauss = "f8"
+        be.knm_storage = "f32"
+        K, ktw = be.knm_rhs(F, Zf, sigma, torch.from_numpy(w).cuda())
+        assert float(F.meta8[0]) == 128.0 / amp and float(Zf.meta8[0]) == 128.0 / amp
+        assert np.array_equal(F.sq8.cpu().numpy().astype(np.float64), (Xd * Xd).sum(1))       # integer norms: exact
+        got = kdense(K).astype(np.float64)
+        # x . z and the norms are exact; what remains is the f32 evaluation of gamma (|x|^2 + |z|^2 - 2 x . z): three terms of
+        # size |x|^2 / (2 sigma^2), each rounded to f32, then exp2 — a wrong product would move d^2 by >= 2, i.e. K by >= 10 %
+        tol = 2e-6 + 8e-8 * ((Xd * Xd).sum(1).max() + (Zd * Zd).sum(1).max()) / (2 * sigma ** 2)
+        assert tol < 1e-4 and np.abs(got - Kx).max() < tol, (np.abs(got - Kx).max(), tol)
+        sc = be.mmv(F, Zf, sigma, torch.from_numpy(al)).cpu().numpy()
+        assert np.abs(sc - Kx @ al).max() < tol * np.abs(al).sum(0).max()
+        be.knm_storage = "u24"
+        K24 = be.knm(F, Zf, sigma)
+        assert np.array_equal(kdense(K24).astype(np.float64), np.minimum(np.rint(got * 2.0 ** 24), 2.0 ** 24 - 1) * 2.0 ** -24)
+    finally:
+        be.gauss, be.knm_storage = old, oldk
+
+
 def test_u24_stored_knm_is_the_rounded_f32_block(be):
     """The 24-bit fixed-point block is the f32 block the default build stores, entry by entry rounded to the nearest
     multiple of 2^-24 (saturating at 1 - 2^-24)."""
