@@ -283,6 +283,16 @@ int odx_falkon_cg_batched_f64(int B, const float* const* K, const int64_t* ldk, 
                               const double* b0, int64_t vstride, const double* n_total, double lam,
                               int maxiter, int full_gradient_every, double cg_epsilon, double cg_tolerance,
                               double* alpha, void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+/* The same lock-step loops over blocks stored in a compact format (odx_gauss_knm_h2_store; fmt = ODX_KNM_U24: Khi / Klo are the
+ * u16 / u8 planes, ODX_KNM_BF16: Khi the bf16 words, Klo / ldlo ignored): class b's passes are odx_knm_fwd_bwd_q's bit for bit.
+ * Replaces, for a class batch, the per-class CG loops the reference's falkon runs one fit at a time
+ * (FALKONWrapper_with_centers_selection_incore.py:56-68) when the stored blocks are not floats. */
+int64_t odx_falkon_cg_batched_q_workspace_bytes(int B, const int64_t* n, const int64_t* M, int fmt);
+int odx_falkon_cg_batched_q_f64(int B, const void* const* Khi, const int64_t* ldk, const void* const* Klo, const int64_t* ldlo,
+                                int fmt, const int64_t* n, const int64_t* M, const double* P, int64_t ldp, int64_t p_rows,
+                                int64_t p_stride, const double* b0, int64_t vstride, const double* n_total, double lam,
+                                int maxiter, int full_gradient_every, double cg_epsilon, double cg_tolerance, double* alpha,
+                                void* workspace, int64_t workspace_bytes, odx_stream_t stream);
 
 /* ---------------------------------------------------------------- dense f64 building blocks
  * (exported for the parity tests and for the RLS path)                                   */

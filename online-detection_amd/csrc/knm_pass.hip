@@ -522,6 +522,23 @@ int knm_pass_batched(int B, const float* const* K, const int64_t* ldk, const int
 
 using namespace odx;
 
+// out[b][j] = sum over class b's nslab[b] slabs (slab_stride doubles from class to class), in the single-class reducer's order
+int odx::slab_reduce_batched_f64(int B, const int64_t* M, const int* nslab, const double* slab, int64_t slab_ld, int64_t slab_stride,
+                                 double* out, int64_t ostride, hipStream_t s) {
+  PassBatch pb;
+  int64_t mm = 1;
+  for (int b = 0; b < ODX_MAX_ZBATCH; ++b) {
+    pb.K[b] = nullptr; pb.ldk[b] = 0; pb.n[b] = 0;
+    pb.M[b] = b < B ? (int)M[b] : 0;
+    pb.grid[b] = b < B ? nslab[b] : 0;
+    if (b < B && M[b] > mm) mm = M[b];
+  }
+  hipLaunchKernelGGL(slab_reduce_batched_kernel, dim3((unsigned)ceil_div(mm, 64), B), dim3(256), 0, s, pb, slab, slab_ld, slab_stride, out,
+                     ostride);
+  ODX_CHECK_LAUNCH("slab_reduce_batched_f64");
+  return ODX_OK;
+}
+
 int odx::slab_reduce_f64(const double* slab, int64_t slab_ld, int nslab, int64_t M, double* out, hipStream_t s) {
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(M, 64)), dim3(256), 0, s, slab, slab_ld, nslab, M, out);
   ODX_CHECK_LAUNCH("slab_reduce_f64");

@@ -53,10 +53,11 @@ __device__ __forceinline__ double q_entry(const QChunk<FMT, CW>& k, int e) {
 }
 
 template <int NT, int CH, int R, int NV, int FMT, int WPE>
-__global__ __launch_bounds__(NT, WPE) void knm_passq_kernel(const unsigned short* __restrict__ Khi, int64_t ldk,
-                                                       const unsigned char* __restrict__ Klo, int64_t ldlo, int64_t n,
-                                                       int64_t M, const double* __restrict__ v1, const double* __restrict__ v2,
-                                                       const double* __restrict__ w, double* __restrict__ slab, int64_t slab_ld) {
+__device__ __forceinline__ void knm_passq_body(const unsigned short* __restrict__ Khi, int64_t ldk,
+                                               const unsigned char* __restrict__ Klo, int64_t ldlo, int64_t n,
+                                               int64_t M, const double* __restrict__ v1, const double* __restrict__ v2,
+                                               const double* __restrict__ w, double* __restrict__ slab, int64_t slab_ld,
+                                               int wg, int nwg) {
   constexpr int NW = NT / 64;
   constexpr int CW = QCW;
   extern __shared__ __attribute__((aligned(16))) double vsq[];       // [NV][vcap]
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(NT, WPE) void knm_passq_kernel(const unsigned short
     }
   };
 
-  int64_t blk = blockIdx.x;
+  int64_t blk = wg;
   if (blk < nblk) {
     open_block(blk);
 #pragma unroll
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(NT, WPE) void knm_passq_kernel(const unsigned short
   }
   __syncthreads();  // vsq is complete
   int pp = 0;
-  for (; blk < nblk; blk += gridDim.x) {
+  for (; blk < nblk; blk += nwg) {
     double t[NV][R];
 #pragma unroll
     for (int q = 0; q < NV; ++q)
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(NT, WPE) void knm_passq_kernel(const unsigned short
         }
       }
     // phase 2: column sums, and the next block's loads re-issued chunk by chunk
-    const int64_t nxt = blk + gridDim.x;
+    const int64_t nxt = blk + nwg;
     if (nxt < nblk) open_block(nxt);
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(NT, WPE) void knm_passq_kernel(const unsigned short
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  double* my = slab + (int64_t)blockIdx.x * slab_ld * NV;
+  double* my = slab + (int64_t)wg * slab_ld * NV;
 #pragma unroll
   for (int q = 0; q < NV; ++q)
 #pragma unroll
@@ -226,6 +227,36 @@ __global__ __launch_bounds__(NT, WPE) void knm_passq_kernel(const unsigned short
           if ((int64_t)ch * CW + e < slab_ld) my[q * slab_ld + (int64_t)ch * CW + e] = acc[q][c][e] * vscale;
       }
     }
+}
+
+template <int NT, int CH, int R, int NV, int FMT, int WPE>
+__global__ __launch_bounds__(NT, WPE) void knm_passq_kernel(const unsigned short* __restrict__ Khi, int64_t ldk,
+                                                       const unsigned char* __restrict__ Klo, int64_t ldlo, int64_t n,
+                                                       int64_t M, const double* __restrict__ v1, const double* __restrict__ v2,
+                                                       const double* __restrict__ w, double* __restrict__ slab, int64_t slab_ld) {
+  knm_passq_body<NT, CH, R, NV, FMT, WPE>(Khi, ldk, Klo, ldlo, n, M, v1, v2, w, slab, slab_ld, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The classes of a batch by one launch (blockIdx.y = class): class b's block is walked by grid[b] workgroups exactly as its
+// own odx_knm_fwd_bwd_q launch would walk it (same workgroup -> rows assignment, same slab order): its sums are the
+// single-class call's bit for bit.  Vectors lie vstride apart, a class's slabs slab_stride apart.
+struct PassBatchQ {
+  const unsigned short* Khi[ODX_MAX_ZBATCH];
+  const unsigned char* Klo[ODX_MAX_ZBATCH];
+  int64_t ldk[ODX_MAX_ZBATCH];
+  int64_t ldlo[ODX_MAX_ZBATCH];
+  int64_t n[ODX_MAX_ZBATCH];
+  int M[ODX_MAX_ZBATCH];
+  int grid[ODX_MAX_ZBATCH];
+};
+
+template <int NT, int CH, int R, int FMT, int WPE = (NT >= 1024 ? 4 : 2)>
+__global__ __launch_bounds__(NT, WPE) void knm_passq_batched_kernel(PassBatchQ pb, const double* __restrict__ v, int64_t vstride,
+                                                                    double* __restrict__ slab, int64_t slab_ld, int64_t slab_stride) {
+  const int b = blockIdx.y;
+  if ((int)blockIdx.x >= pb.grid[b]) return;
+  knm_passq_body<NT, CH, R, 1, FMT, WPE>(pb.Khi[b], pb.ldk[b], pb.Klo[b], pb.ldlo[b], pb.n[b], pb.M[b], v + (int64_t)b * vstride, nullptr,
+                                         nullptr, slab + (int64_t)b * slab_stride, slab_ld, (int)blockIdx.x, pb.grid[b]);
 }
 
 // ---------------------------------------------------------------- two free-running halves (one vector, 8192 < M <= 10240)
@@ -242,11 +273,11 @@ __global__ __launch_bounds__(NT, WPE) void knm_passq_kernel(const unsigned short
 // half's column sums depend only on its own rows, the slab holds one vector per half, the fixed-order reduce adds
 // 2 x grid of them.
 template <int CH, int R, int FMT>
-__global__ __launch_bounds__(512, 2) void knm_passq_stag_kernel(const unsigned short* __restrict__ Khi, int64_t ldk,
-                                                                const unsigned char* __restrict__ Klo, int64_t ldlo, int64_t n,
-                                                                int64_t M, const double* __restrict__ v1,
-                                                                const double* __restrict__ w, double* __restrict__ slab,
-                                                                int64_t slab_ld) {
+__device__ __forceinline__ void knm_passq_stag_body(const unsigned short* __restrict__ Khi, int64_t ldk,
+                                                    const unsigned char* __restrict__ Klo, int64_t ldlo, int64_t n,
+                                                    int64_t M, const double* __restrict__ v1,
+                                                    const double* __restrict__ w, double* __restrict__ slab,
+                                                    int64_t slab_ld, int wg, int nwg) {
   constexpr int NT = 256, CW = QCW;
   extern __shared__ __attribute__((aligned(16))) double vsq[];
   __shared__ double red[2][2][4][R];                 // [half][ping-pong][wave of the half][row]
@@ -291,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void knm_passq_stag_kernel(const unsigned s
   // half h walks blocks first, first + step, ...: the same trip count for every wave of the half
   __shared__ unsigned int arrived[2];
   if (tid < 2) arrived[tid] = 0u;
-  const int64_t first = 2 * (int64_t)blockIdx.x + h, step = 2 * (int64_t)gridDim.x;
+  const int64_t first = 2 * (int64_t)wg + h, step = 2 * (int64_t)nwg;
   const int64_t mine = first < nblk ? (nblk - first + step - 1) / step : 0;
   if (mine > 0) {
     open_block(first);
@@ -386,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void knm_passq_stag_kernel(const unsigned s
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  double* my = slab + (2 * (int64_t)blockIdx.x + h) * slab_ld;
+  double* my = slab + (2 * (int64_t)wg + h) * slab_ld;
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const int ch = ht + c * NT;
@@ -396,6 +427,25 @@ __global__ __launch_bounds__(512, 2) void knm_passq_stag_kernel(const unsigned s
         if ((int64_t)ch * CW + e < slab_ld) my[(int64_t)ch * CW + e] = acc[c][e] * vscale;
     }
   }
+}
+
+template <int CH, int R, int FMT>
+__global__ __launch_bounds__(512, 2) void knm_passq_stag_kernel(const unsigned short* __restrict__ Khi, int64_t ldk,
+                                                                const unsigned char* __restrict__ Klo, int64_t ldlo, int64_t n,
+                                                                int64_t M, const double* __restrict__ v1,
+                                                                const double* __restrict__ w, double* __restrict__ slab,
+                                                                int64_t slab_ld) {
+  knm_passq_stag_body<CH, R, FMT>(Khi, ldk, Klo, ldlo, n, M, v1, w, slab, slab_ld, (int)blockIdx.x, (int)gridDim.x);
+}
+
+template <int CH, int R, int FMT>
+__global__ __launch_bounds__(512, 2) void knm_passq_stag_batched_kernel(PassBatchQ pb, const double* __restrict__ v, int64_t vstride,
+                                                                        double* __restrict__ slab, int64_t slab_ld,
+                                                                        int64_t slab_stride) {
+  const int b = blockIdx.y;
+  if ((int)blockIdx.x >= pb.grid[b]) return;
+  knm_passq_stag_body<CH, R, FMT>(pb.Khi[b], pb.ldk[b], pb.Klo[b], pb.ldlo[b], pb.n[b], pb.M[b], v + (int64_t)b * vstride, nullptr,
+                                  slab + (int64_t)b * slab_stride, slab_ld, (int)blockIdx.x, pb.grid[b]);
 }
 
 struct QCfg {
@@ -522,6 +572,127 @@ static int dispatch_passq(const QCfg& cfg, int grid, size_t lds, hipStream_t s, 
 #undef ODX_Q
 }
 
+static int check_q_block(const char* who, const void* K, int64_t ldk, const void* Klo, int64_t ldlo, int fmt, int64_t M) {
+  ODX_REQUIRE(fmt == ODX_KNM_U24 || fmt == ODX_KNM_BF16, "%s: storage format must be ODX_KNM_U24 or ODX_KNM_BF16 (got %d)", who, fmt);
+  // (row sub-blocks of a stored shard are valid arguments: the planes need the alignment of one chunk load only)
+  ODX_REQUIRE(K && ldk % 8 == 0 && ldk >= round_up(M, 8) && (reinterpret_cast<uintptr_t>(K) & 7u) == 0,
+              "%s: K must be 8-byte aligned with ldk %% 8 == 0, ldk >= roundup(M, 8)", who);
+  if (fmt == ODX_KNM_U24)
+    ODX_REQUIRE(Klo && ldlo % 8 == 0 && ldlo >= round_up(M, 8) && (reinterpret_cast<uintptr_t>(Klo) & 3u) == 0,
+                "%s: the low-byte plane must be 4-byte aligned with ldlo %% 8 == 0, ldlo >= roundup(M, 8)", who);
+  return ODX_OK;
+}
+
+// ---- class-batched pass over compact blocks (internal; the batched CG of solve.cpp drives it)
+static bool passq_batch_cfg(int B, const int64_t* M, int fmt, QCfg* out) {
+  QCfg c0 = {0, 0, 0, 0};
+  for (int b = 0; b < B; ++b) {
+    QCfg c;
+    if (M[b] <= 0 || !pick_qcfg(M[b], 1, fmt, &c)) return false;
+    if (b == 0) c0 = c;
+    else if (c.nt != c0.nt || c.ch != c0.ch || c.r != c0.r) return false;
+  }
+  // (the configurations launch_passq_batched instantiates)
+  const bool built = (c0.nt == 0 && (c0.ch == 2 || c0.ch == 4 || c0.ch == 10)) ||
+                     (c0.nt == 256 && (c0.ch == 1 || c0.ch == 2 || c0.ch == 4 || c0.ch == 8)) || (c0.nt == 512 && (c0.ch == 5 || c0.ch == 6));
+  if (out) *out = c0;
+  return B > 0 && built;
+}
+
+static void passq_batch_geometry(int B, const int64_t* n, const int64_t* M, const QCfg& cfg, int* gmax, int64_t* slab_ld) {
+  int g = 1;
+  int64_t mm = 1;
+  for (int b = 0; b < B; ++b) {
+    if (n[b] > 0) g = std::max(g, qgrid_for(cfg, n[b]));
+    mm = std::max(mm, M[b]);
+  }
+  *gmax = g;
+  *slab_ld = round_up(mm, 4);
+}
+
+int64_t knm_passq_batched_workspace_bytes(int B, const int64_t* n, const int64_t* M, int fmt) {
+  QCfg cfg;
+  if ((fmt != ODX_KNM_U24 && fmt != ODX_KNM_BF16) || !passq_batch_cfg(B, M, fmt, &cfg)) return ODX_ERR_UNSUPPORTED;
+  int gmax;
+  int64_t slab_ld;
+  passq_batch_geometry(B, n, M, cfg, &gmax, &slab_ld);
+  return (int64_t)B * (cfg.nt == 0 ? 2 : 1) * gmax * slab_ld * (int64_t)sizeof(double);
+}
+
+template <int FMT>
+static int launch_passq_batched(const QCfg& cfg, const PassBatchQ& pb, int gmax, int B, size_t lds, hipStream_t s, const double* v,
+                                int64_t vstride, double* slab, int64_t slab_ld, int64_t slab_stride) {
+#define ODX_QB(NT_, CH_, R_)                                                                                                        \
+  do {                                                                                                                              \
+    ODX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knm_passq_batched_kernel<NT_, CH_, R_, FMT>),                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                        \
+    hipLaunchKernelGGL((knm_passq_batched_kernel<NT_, CH_, R_, FMT>), dim3(gmax, B), dim3(NT_), lds, s, pb, v, vstride, slab, slab_ld, \
+                       slab_stride);                                                                                                \
+    return ODX_OK;                                                                                                                  \
+  } while (0)
+#define ODX_QBH(CH_, R_)                                                                                                            \
+  do {                                                                                                                              \
+    ODX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knm_passq_stag_batched_kernel<CH_, R_, FMT>),                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                        \
+    hipLaunchKernelGGL((knm_passq_stag_batched_kernel<CH_, R_, FMT>), dim3(gmax, B), dim3(512), lds, s, pb, v, vstride, slab, slab_ld, \
+                       slab_stride);                                                                                                \
+    return ODX_OK;                                                                                                                  \
+  } while (0)
+  if (cfg.nt == 0 && cfg.ch == 2) ODX_QBH(2, 8);
+  if (cfg.nt == 0 && cfg.ch == 4) ODX_QBH(4, 4);
+  if (cfg.nt == 0 && cfg.ch == 10) ODX_QBH(10, 2);
+  if (cfg.nt == 256 && cfg.ch == 1) ODX_QB(256, 1, 16);
+  if (cfg.nt == 256 && cfg.ch == 2) ODX_QB(256, 2, 8);
+  if (cfg.nt == 256 && cfg.ch == 4) ODX_QB(256, 4, 8);
+  if (cfg.nt == 256 && cfg.ch == 8) ODX_QB(256, 8, 3);
+  if (cfg.nt == 512 && cfg.ch == 5) ODX_QB(512, 5, 6);
+  if (cfg.nt == 512 && cfg.ch == 6) ODX_QB(512, 6, 4);
+#undef ODX_QB
+#undef ODX_QBH
+  set_error("knm_passq_batched: no class-batched kernel for this pass configuration");
+  return ODX_ERR_UNSUPPORTED;
+}
+
+// out[b] = K_b' (K_b v[b]) for the B classes of a batch (compact-format blocks) with ONE pass launch and ONE reduce launch;
+// class b is handled exactly as odx_knm_fwd_bwd_q(K_b, ..) would handle it (same configuration, workgroup count, slab order)
+int knm_passq_batched(int B, const void* const* Khi, const int64_t* ldk, const void* const* Klo, const int64_t* ldlo, int fmt,
+                      const int64_t* n, const int64_t* M, const double* v, int64_t vstride, double* out, int64_t ostride,
+                      void* workspace, int64_t workspace_bytes, hipStream_t s) {
+  ODX_REQUIRE(B >= 1 && B <= ODX_MAX_ZBATCH, "knm_passq_batched: 1..%d classes", ODX_MAX_ZBATCH);
+  QCfg cfg;
+  ODX_REQUIRE((fmt == ODX_KNM_U24 || fmt == ODX_KNM_BF16) && passq_batch_cfg(B, M, fmt, &cfg),
+              "knm_passq_batched: the classes of a batch must share one pass configuration");
+  int gmax;
+  int64_t slab_ld;
+  passq_batch_geometry(B, n, M, cfg, &gmax, &slab_ld);
+  const int per = cfg.nt == 0 ? 2 : 1;                            // the halves kernel leaves one vector per half
+  const int64_t slab_stride = (int64_t)per * gmax * slab_ld;
+  if (workspace == nullptr || workspace_bytes < (int64_t)B * slab_stride * (int64_t)sizeof(double)) {
+    set_error("knm_passq_batched: workspace too small");
+    return ODX_ERR_WORKSPACE;
+  }
+  PassBatchQ pb;
+  int nslab[ODX_MAX_ZBATCH];
+  for (int b = 0; b < ODX_MAX_ZBATCH; ++b) {
+    const bool on = b < B;
+    pb.Khi[b] = on ? static_cast<const unsigned short*>(Khi[b]) : nullptr;
+    pb.Klo[b] = (on && fmt == ODX_KNM_U24) ? static_cast<const unsigned char*>(Klo[b]) : nullptr;
+    pb.ldk[b] = on ? ldk[b] : 0;
+    pb.ldlo[b] = (on && fmt == ODX_KNM_U24) ? ldlo[b] : 0;
+    pb.n[b] = on ? n[b] : 0;
+    pb.M[b] = on ? (int)M[b] : 0;
+    pb.grid[b] = (on && n[b] > 0) ? qgrid_for(cfg, n[b]) : 0;
+    nslab[b] = per * pb.grid[b];
+    if (on && n[b] > 0) ODX_PROPAGATE(check_q_block("knm_passq_batched", Khi[b], ldk[b], Klo ? Klo[b] : nullptr, ldlo ? ldlo[b] : 0, fmt, M[b]));
+  }
+  double* slab = static_cast<double*>(workspace);
+  const size_t lds = (cfg.nt == 0 ? (size_t)(cfg.ch * 256 * 4) : (size_t)(slab_ld + 4)) * sizeof(double);
+  if (fmt == ODX_KNM_U24) ODX_PROPAGATE((launch_passq_batched<QF_U24>(cfg, pb, gmax, B, lds, s, v, vstride, slab, slab_ld, slab_stride)));
+  else ODX_PROPAGATE((launch_passq_batched<QF_BF16>(cfg, pb, gmax, B, lds, s, v, vstride, slab, slab_ld, slab_stride)));
+  ODX_CHECK_LAUNCH("knm_passq_batched");
+  return slab_reduce_batched_f64(B, M, nslab, slab, slab_ld, slab_stride, out, ostride, s);
+}
+
 }  // namespace odx
 
 using namespace odx;
@@ -533,14 +704,7 @@ extern "C" int odx_set_pass_cus(int cus) {
 }
 
 static int check_q(const char* who, const void* K, int64_t ldk, const void* Klo, int64_t ldlo, int fmt, int64_t M) {
-  ODX_REQUIRE(fmt == ODX_KNM_U24 || fmt == ODX_KNM_BF16, "%s: storage format must be ODX_KNM_U24 or ODX_KNM_BF16 (got %d)", who, fmt);
-  // (row sub-blocks of a stored shard are valid arguments: the planes need the alignment of one chunk load only)
-  ODX_REQUIRE(K && ldk % 8 == 0 && ldk >= round_up(M, 8) && (reinterpret_cast<uintptr_t>(K) & 7u) == 0,
-              "%s: K must be 8-byte aligned with ldk %% 8 == 0, ldk >= roundup(M, 8)", who);
-  if (fmt == ODX_KNM_U24)
-    ODX_REQUIRE(Klo && ldlo % 8 == 0 && ldlo >= round_up(M, 8) && (reinterpret_cast<uintptr_t>(Klo) & 3u) == 0,
-                "%s: the low-byte plane must be 4-byte aligned with ldlo %% 8 == 0, ldlo >= roundup(M, 8)", who);
-  return ODX_OK;
+  return check_q_block(who, K, ldk, Klo, ldlo, fmt, M);
 }
 
 extern "C" int64_t odx_knm_fwd_bwd_q_workspace_bytes(int64_t n, int64_t M, int fmt) {

@@ -65,6 +65,14 @@ int slab_reduce_f64(const double* slab, int64_t slab_ld, int nslab, int64_t M, d
 // the same for the two vectors a two-product pass leaves per workgroup (slab g = [sums of v | sums of v2], 2 slab_ld apart)
 int slab_reduce2_f64(const double* slab, int64_t slab_ld, int nslab, int64_t M, double* out, double* out2, hipStream_t stream);
 
+int slab_reduce_batched_f64(int B, const int64_t* M, const int* nslab, const double* slab, int64_t slab_ld, int64_t slab_stride,
+                            double* out, int64_t ostride, hipStream_t stream);
+// knm_pass_q.hip: the CG pass over compact-format blocks (24-bit fixed point / bf16) for a batch of classes
+int64_t knm_passq_batched_workspace_bytes(int B, const int64_t* n, const int64_t* M, int fmt);
+int knm_passq_batched(int B, const void* const* Khi, const int64_t* ldk, const void* const* Klo, const int64_t* ldlo, int fmt,
+                      const int64_t* n, const int64_t* M, const double* v, int64_t vstride, double* out, int64_t ostride,
+                      void* workspace, int64_t workspace_bytes, hipStream_t stream);
+
 // knm_pass.hip: the CG pass for a batch of classes (one launch; per class the arithmetic of odx_knm_fwd_bwd)
 bool knm_pass_batch_cfg(int B, const int64_t* M, int* nt, int* ch, int* r);
 int64_t knm_pass_batched_workspace_bytes(int B, const int64_t* n, const int64_t* M);

@@ -99,9 +99,20 @@ extern "C" int odx_falkon_cg_f64(const float* K, int64_t ldk, int64_t n, int64_t
 // same pass configuration and workgroup count, same slab order): alpha comes out bit-identical to the one-class call.
 // The classes must share one pass configuration (odx_falkon_cg_batched_workspace_bytes < 0 otherwise).  A class whose
 // residual meets the tolerance raises its own stop flag and coasts.
-extern "C" int64_t odx_falkon_cg_batched_workspace_bytes(int B, const int64_t* n, const int64_t* M) {
+// The blocks a class-batched CG streams: f32 rows (K) or one of the compact formats (Khi / Klo planes, fmt).
+struct BatchBlocks {
+  int fmt = ODX_KNM_F32;
+  const float* const* K = nullptr; const int64_t* ldk = nullptr;
+  const void* const* Khi = nullptr; const void* const* Klo = nullptr; const int64_t* ldlo = nullptr;
+};
+
+static int64_t batched_pass_bytes(const BatchBlocks& kb, int B, const int64_t* n, const int64_t* M) {
+  return kb.fmt == ODX_KNM_F32 ? knm_pass_batched_workspace_bytes(B, n, M) : knm_passq_batched_workspace_bytes(B, n, M, kb.fmt);
+}
+
+static int64_t cg_batched_bytes(const BatchBlocks& kb, int B, const int64_t* n, const int64_t* M) {
   if (B < 1 || B > ODX_MAX_ZBATCH || !n || !M) return ODX_ERR_INVALID;
-  const int64_t pass = knm_pass_batched_workspace_bytes(B, n, M);
+  const int64_t pass = batched_pass_bytes(kb, B, n, M);
   if (pass < 0) return pass;
   int64_t mm = 1;
   for (int b = 0; b < B; ++b) mm = M[b] > mm ? M[b] : mm;
@@ -109,31 +120,40 @@ extern "C" int64_t odx_falkon_cg_batched_workspace_bytes(int B, const int64_t* n
   return ((int64_t)B * (9 * Mp + 4)) * (int64_t)sizeof(double) + round_up(pass, 16);
 }
 
-extern "C" int odx_falkon_cg_batched_f64(int B, const float* const* K, const int64_t* ldk, const int64_t* n, const int64_t* M,
-                                         const double* P, int64_t ldp, int64_t p_rows, int64_t p_stride, const double* b0,
-                                         int64_t vstride, const double* n_total, double lam, int maxiter,
-                                         int full_gradient_every, double cg_epsilon, double cg_tolerance, double* alpha,
-                                         void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
-  ODX_REQUIRE(B >= 1 && B <= ODX_MAX_ZBATCH && K && ldk && n && M && P && b0 && n_total && alpha && maxiter >= 0 &&
-                  full_gradient_every > 0,
-              "odx_falkon_cg_batched_f64: bad argument");
-  const int64_t need = odx_falkon_cg_batched_workspace_bytes(B, n, M);
-  ODX_REQUIRE(need >= 0, "odx_falkon_cg_batched_f64: the classes of a batch must share one pass configuration");
+extern "C" int64_t odx_falkon_cg_batched_workspace_bytes(int B, const int64_t* n, const int64_t* M) {
+  return cg_batched_bytes(BatchBlocks(), B, n, M);
+}
+
+extern "C" int64_t odx_falkon_cg_batched_q_workspace_bytes(int B, const int64_t* n, const int64_t* M, int fmt) {
+  BatchBlocks kb;
+  kb.fmt = fmt;
+  if (fmt != ODX_KNM_U24 && fmt != ODX_KNM_BF16) return ODX_ERR_UNSUPPORTED;
+  return cg_batched_bytes(kb, B, n, M);
+}
+
+static int falkon_cg_batched(const char* who, const BatchBlocks& kb, int B, const int64_t* n, const int64_t* M, const double* P,
+                             int64_t ldp, int64_t p_rows, int64_t p_stride, const double* b0, int64_t vstride, const double* n_total,
+                             double lam, int maxiter, int full_gradient_every, double cg_epsilon, double cg_tolerance, double* alpha,
+                             void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
+  ODX_REQUIRE(B >= 1 && B <= ODX_MAX_ZBATCH && n && M && P && b0 && n_total && alpha && maxiter >= 0 && full_gradient_every > 0,
+              "%s: bad argument", who);
+  const int64_t need = cg_batched_bytes(kb, B, n, M);
+  ODX_REQUIRE(need >= 0, "%s: the classes of a batch must share one pass configuration", who);
   if (workspace == nullptr || workspace_bytes < need || !aligned16(workspace)) {
-    set_error("odx_falkon_cg_batched_f64: workspace too small or not 16-byte aligned");
+    set_error("%s: workspace too small or not 16-byte aligned", who);
     return ODX_ERR_WORKSPACE;
   }
   VecBatch vb;
   vb.B = B;
   int64_t mm = 1;
   for (int b = 0; b < B; ++b) {
-    ODX_REQUIRE(M[b] > 0 && M[b] <= p_rows && n[b] >= 0 && n_total[b] > 0, "odx_falkon_cg_batched_f64: class %d: bad sizes", b);
+    ODX_REQUIRE(M[b] > 0 && M[b] <= p_rows && n[b] >= 0 && n_total[b] > 0, "%s: class %d: bad sizes", who, b);
     vb.M[b] = (int)M[b];
     vb.scale[b] = 1.0 / n_total[b];
     mm = M[b] > mm ? M[b] : mm;
   }
   ODX_REQUIRE(vstride >= mm && vstride % 2 == 0 && ldp % 2 == 0 && p_stride >= 4 * p_rows * ldp,
-              "odx_falkon_cg_batched_f64: vstride even >= max M, ldp even, p_stride >= 4 p_rows ldp");
+              "%s: vstride even >= max M, ldp even, p_stride >= 4 p_rows ldp", who);
   const int64_t Mp = round_up(mm, 2);
   double* w = static_cast<double*>(workspace);
   const int64_t V = (int64_t)B * Mp;            // one vector per class, Mp apart
@@ -144,10 +164,14 @@ extern "C" int odx_falkon_cg_batched_f64(int B, const float* const* K, const int
   hipStream_t s = as_stream(stream);
   const double *LTi = P, *LTit = P + p_rows * ldp, *LAi = P + 2 * p_rows * ldp, *LAit = P + 3 * p_rows * ldp;
 
+  auto pass = [&](const double* src, double* dst) -> int {
+    if (kb.fmt == ODX_KNM_F32) return knm_pass_batched(B, kb.K, kb.ldk, n, M, src, Mp, dst, Mp, pass_ws, pass_bytes, s);
+    return knm_passq_batched(B, kb.Khi, kb.ldk, kb.Klo, kb.ldlo, kb.fmt, n, M, src, Mp, dst, Mp, pass_ws, pass_bytes, s);
+  };
   auto mmv = [&](const double* src, double* out) -> int {
     ODX_PROPAGATE(trmv_batched_f64(LAit, ldp, p_stride, 1, vb, src, Mp, false, 0.0, nullptr, 0, v, Mp, s));
     ODX_PROPAGATE(trmv_batched_f64(LTit, ldp, p_stride, 1, vb, v, Mp, false, 0.0, nullptr, 0, t, Mp, s));
-    ODX_PROPAGATE(knm_pass_batched(B, K, ldk, n, M, t, Mp, cc, Mp, pass_ws, pass_bytes, s));
+    ODX_PROPAGATE(pass(t, cc));
     ODX_PROPAGATE(trmv_batched_f64(LTi, ldp, p_stride, 0, vb, cc, Mp, true, lam, v, Mp, u, Mp, s));
     return trmv_batched_f64(LAi, ldp, p_stride, 0, vb, u, Mp, false, 0.0, nullptr, 0, out, Mp, s);
   };
@@ -171,4 +195,31 @@ extern "C" int odx_falkon_cg_batched_f64(int B, const float* const* K, const int
   }
   ODX_PROPAGATE(trmv_batched_f64(LAit, ldp, p_stride, 1, vb, X, Mp, false, 0.0, nullptr, 0, v, Mp, s));
   return trmv_batched_f64(LTit, ldp, p_stride, 1, vb, v, Mp, false, 0.0, nullptr, 0, alpha, vstride, s);
+}
+
+extern "C" int odx_falkon_cg_batched_f64(int B, const float* const* K, const int64_t* ldk, const int64_t* n, const int64_t* M,
+                                         const double* P, int64_t ldp, int64_t p_rows, int64_t p_stride, const double* b0,
+                                         int64_t vstride, const double* n_total, double lam, int maxiter,
+                                         int full_gradient_every, double cg_epsilon, double cg_tolerance, double* alpha,
+                                         void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
+  ODX_REQUIRE(K && ldk, "odx_falkon_cg_batched_f64: bad argument");
+  BatchBlocks kb;
+  kb.K = K; kb.ldk = ldk;
+  return falkon_cg_batched("odx_falkon_cg_batched_f64", kb, B, n, M, P, ldp, p_rows, p_stride, b0, vstride, n_total, lam, maxiter,
+                           full_gradient_every, cg_epsilon, cg_tolerance, alpha, workspace, workspace_bytes, stream);
+}
+
+// The same lock-step loops over blocks stored in a compact format (ODX_KNM_U24: Khi = the u16 plane, Klo = the u8 plane;
+// ODX_KNM_BF16: Khi = the bf16 words, Klo ignored): class b's passes are odx_knm_fwd_bwd_q's, bit for bit.
+extern "C" int odx_falkon_cg_batched_q_f64(int B, const void* const* Khi, const int64_t* ldk, const void* const* Klo,
+                                           const int64_t* ldlo, int fmt, const int64_t* n, const int64_t* M, const double* P,
+                                           int64_t ldp, int64_t p_rows, int64_t p_stride, const double* b0, int64_t vstride,
+                                           const double* n_total, double lam, int maxiter, int full_gradient_every,
+                                           double cg_epsilon, double cg_tolerance, double* alpha, void* workspace,
+                                           int64_t workspace_bytes, odx_stream_t stream) {
+  ODX_REQUIRE(Khi && ldk && (fmt == ODX_KNM_BF16 || (fmt == ODX_KNM_U24 && Klo && ldlo)), "odx_falkon_cg_batched_q_f64: bad argument");
+  BatchBlocks kb;
+  kb.fmt = fmt; kb.Khi = Khi; kb.ldk = ldk; kb.Klo = Klo; kb.ldlo = ldlo;
+  return falkon_cg_batched("odx_falkon_cg_batched_q_f64", kb, B, n, M, P, ldp, p_rows, p_stride, b0, vstride, n_total, lam, maxiter,
+                           full_gradient_every, cg_epsilon, cg_tolerance, alpha, workspace, workspace_bytes, stream);
 }

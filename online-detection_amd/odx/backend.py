@@ -89,9 +89,9 @@ class HipBackend:
             raise ValueError("ODX_GAUSS must be 'h2', 'f32' or 'f8', got %r" % self.gauss)
         # Storage of the K_nM block the CG passes stream (include/odx.h): "f32" always f32; "u24" / "bf16" always that compact
         # format (f16-split kernels only); "auto" (default): 24-bit fixed point for the blocks whose passes are HBM-bound
-        # (>= 2^28 entries and more than 4096 centres on the wide tile core: the headline, config 5's shards), f32 below —
-        # narrow blocks (M = 2000: 0.75 ms per pass in either format) and small fits gain nothing and keep the one-call /
-        # class-batched CG loops, which stream f32.  tools/precision_storage_study.py: alpha against the f64 evaluation is the same
+        # (>= 2^27 entries and at least 1024 centres on the wide tile core: the headline, config 5's shards, configs 2 and
+        # 4), f32 below — the fits of a Minibootstrap round (<= 22 000 x 2000) gain nothing.  The one-call / class-batched CG
+        # loops stream either (odx_falkon_cg_batched_f64 / _q_f64).  tools/precision_storage_study.py: alpha against the f64 evaluation is the same
         # with u24 as with f32 storage; bf16 is BASELINE config 2's throughput-only storage (alpha off by 1e-2..6e-1).
         self.knm_storage = os.environ.get("ODX_KNM", "auto")
         if self.knm_storage not in ("auto", "f32", "u24", "bf16"):
@@ -241,6 +241,7 @@ class HipBackend:
         P.M, P.ld = M, ld
         mats = out if out is not None else torch.empty((4, M, ld), dtype=torch.float64, device=self.device)
         P.LTi, P.LTit, P.LAi, P.LAit = mats[0], mats[1], mats[2], mats[3]
+        P.block_rows = M                     # the four factors are one (4, M, ld) block: a class batch of one (cg_solve_batched)
         P.info = torch.zeros(1, dtype=torch.int32, device=self.device)
         nbytes = self.lib.odx_falkon_precond_workspace_bytes(M, D)
         ws = self._workspace(ws_key, nbytes)
@@ -301,7 +302,7 @@ class HipBackend:
             return "f32"
         if self.knm_storage in ("u24", "bf16"):
             return self.knm_storage if self.lib.odx_knm_fwd_bwd_q_workspace_bytes(n, M, _KNM_CODE[self.knm_storage]) >= 0 else "f32"
-        if self.knm_storage == "auto" and n * M >= (1 << 28) and M > 4096 and (self.gauss == "f8" or self.lib.odx_gauss_h2_tile(n, M) == 256) \
+        if self.knm_storage == "auto" and n * M >= (1 << 27) and M >= 1024 and (self.gauss == "f8" or self.lib.odx_gauss_h2_tile(n, M) == 256) \
                 and self.lib.odx_knm_fwd_bwd_q_workspace_bytes(n, M, hip.KNM_U24) >= 0:
             return "u24"
         return "f32"
@@ -459,17 +460,34 @@ class HipBackend:
                                              self._stream()), "odx_falkon_cg_f64")
         return alpha
 
+    def cg_batched_supported(self, ns, Ms, fmt="f32"):
+        """Whether cg_solve_batched has a lock-step loop for blocks of these shapes stored as `fmt` (one pass configuration
+        for all of them) — asked BEFORE the blocks are built."""
+        B = len(ns)
+        if not 1 <= B <= self.MAX_CLASS_BATCH:
+            return False
+        n = (ctypes.c_int64 * B)(*[int(v) for v in ns])
+        M = (ctypes.c_int64 * B)(*[int(v) for v in Ms])
+        if fmt == "f32":
+            return self.lib.odx_falkon_cg_batched_workspace_bytes(B, n, M) >= 0
+        return self.lib.odx_falkon_cg_batched_q_workspace_bytes(B, n, M, _KNM_CODE[fmt]) >= 0
+
     def cg_solve_batched(self, Ks, Ps, b0s, n_totals, lam, maxiter, opt):
         """The CG loops of len(Ks) <= 32 independent fits in lock step, one launch sequence for all of them
         (odx_falkon_cg_batched_f64).  Ps: the Preconds of ONE precond_batched call, in order (they share a block);
         b0s: (B, vstride) f64.  Returns alpha (B, vstride) f64 — row b's first M_b entries are class b's alpha, bit for
-        bit what cg_solve gives — or None when the classes do not share a pass configuration."""
+        bit what cg_solve gives — or None when the classes do not share a pass configuration / storage format.  Blocks in
+        a compact format (24-bit fixed point, bf16) go through odx_falkon_cg_batched_q_f64."""
         B = len(Ks)
-        if any(k.fmt != "f32" for k in Ks):         # the batched library loop streams f32 blocks only
+        fmt = Ks[0].fmt
+        if any(k.fmt != fmt for k in Ks):           # one storage format per batch
             return None
         n = (ctypes.c_int64 * B)(*[int(k.n) for k in Ks])
         M = (ctypes.c_int64 * B)(*[int(k.M) for k in Ks])
-        nbytes = self.lib.odx_falkon_cg_batched_workspace_bytes(B, n, M)
+        if fmt == "f32":
+            nbytes = self.lib.odx_falkon_cg_batched_workspace_bytes(B, n, M)
+        else:
+            nbytes = self.lib.odx_falkon_cg_batched_q_workspace_bytes(B, n, M, _KNM_CODE[fmt])
         if nbytes < 0:
             return None
         base = Ps[0].LTi
@@ -483,6 +501,13 @@ class HipBackend:
         nt = (ctypes.c_double * B)(*[float(x) for x in n_totals])
         alpha = torch.zeros_like(b0s)
         ws = self._workspace("cg_solve_batched", nbytes)
+        if fmt != "f32":
+            lp = (ctypes.c_void_p * B)(*[(k.lo.data_ptr() if k.lo is not None else 0) for k in Ks])
+            hip.check(self.lib.odx_falkon_cg_batched_q_f64(B, kp, kl, lp, kl, _KNM_CODE[fmt], n, M, _p(base), ldp, p_rows, p_stride, _p(b0s),
+                                                           b0s.stride(0), nt, float(lam), int(maxiter), int(opt.cg_full_gradient_every),
+                                                           float(opt.cg_epsilon), float(opt.cg_tolerance), _p(alpha), _p(ws), ws.numel(),
+                                                           self._stream()), "odx_falkon_cg_batched_q_f64")
+            return alpha
         hip.check(self.lib.odx_falkon_cg_batched_f64(B, kp, kl, n, M, _p(base), ldp, p_rows, p_stride, _p(b0s), b0s.stride(0), nt,
                                                      float(lam), int(maxiter), int(opt.cg_full_gradient_every), float(opt.cg_epsilon),
                                                      float(opt.cg_tolerance), _p(alpha), _p(ws), ws.numel(), self._stream()),

@@ -203,9 +203,11 @@ def fit_batch(estimators, Xs, Ys, streams=None):
             iters = {int(estimators[i].maxiter) for i in chunk}
             same = len(iters) == 1 and all(o == opts[0] for o in opts) and hasattr(be, "cg_solve_batched")
             if same and hasattr(be, "knm_format"):
-                # the lock-step library loop streams f32 blocks: decided BEFORE anything is built (a chunk in a compact
-                # storage format would otherwise build every K_nM block here, hold them all, and build them again below)
-                same = all(be.knm_format(Fs[i].n, Zfs[i].n) == "f32" for i in chunk)
+                # the lock-step library loop needs one storage format and one pass configuration for the chunk: decided BEFORE
+                # anything is built (otherwise every K_nM block would be built here, held, and built again below)
+                fmts = {be.knm_format(Fs[i].n, Zfs[i].n) for i in chunk}
+                same = len(fmts) == 1 and (not hasattr(be, "cg_batched_supported") or
+                                           be.cg_batched_supported([Fs[i].n for i in chunk], [Zfs[i].n for i in chunk], fmts.pop()))
             if same:
                 Mmax = max(Zfs[i].n for i in chunk)
                 b0s = torch.zeros((len(chunk), (Mmax + 1) // 2 * 2), dtype=torch.float64, device=be.device)

@@ -57,6 +57,9 @@ SIGNATURES = {
     "odx_falkon_cg_batched_workspace_bytes": (_i64, [_i32, _vp, _vp]),
     "odx_falkon_cg_batched_f64": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _f64, _i32, _i32, _f64, _f64,
                                          _vp, _vp, _i64, _vp]),
+    "odx_falkon_cg_batched_q_workspace_bytes": (_i64, [_i32, _vp, _vp, _i32]),
+    "odx_falkon_cg_batched_q_f64": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _f64, _i32, _i32,
+                                           _f64, _f64, _vp, _vp, _i64, _vp]),
     "odx_knm_fwd_bwd_workspace_bytes": (_i64, [_i64, _i64]),
     "odx_set_pass_reserved_cus": (_i32, [_i32]),
     "odx_knm_fwd_bwd": (_i32, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),

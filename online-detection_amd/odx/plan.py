@@ -30,10 +30,10 @@ def _round_up(x, m):
 
 def knm_format_rule(n, M, storage="auto", wide_tile=True):
     """The storage format HipBackend.knm_format gives an (n, M) block (tests/test_gpu_modules.py compares the two): 24-bit
-    fixed point where the passes are HBM-bound (>= 2^28 entries, more than 4096 centres, the wide tile core), f32 below."""
+    fixed point where the passes are HBM-bound (>= 2^27 entries, at least 1024 centres, the wide tile core), f32 below."""
     if storage in ("f32", "u24", "bf16"):
         return storage
-    if n * M >= (1 << 28) and M > 4096 and wide_tile:
+    if n * M >= (1 << 27) and M >= 1024 and wide_tile:
         return "u24"
     return "f32"
 

@@ -171,11 +171,24 @@ def falkon_fit(be, F, y, Zf, sigma, lam, maxiter=20, opt=None, n_total=None, all
             be.trmv(P, "LAi", u, out=out2)
 
     b0 = ar(b0)                                        # K' (y / n), summed over shards
-    if shard is None and allreduce is None and phase is None and hasattr(be, "cg_solve") and getattr(K, "fmt", "f32") == "f32":
+    one_call = shard is None and allreduce is None and phase is None and hasattr(be, "cg_solve")
+    if one_call and getattr(K, "fmt", "f32") != "f32":
+        # compact-format block: the class-batched library loop with a batch of one (odx_falkon_cg_batched_q_f64), where the
+        # block's pass configuration has one and the factors are one contiguous block
+        one_call = bool(hasattr(be, "cg_batched_supported") and getattr(P, "block_rows", None) is not None
+                        and be.cg_batched_supported([K.n], [K.M], K.fmt))
+    if one_call:
         # one shard, nothing to time per kernel family: the loop below as one library call (odx_falkon_cg_f64)
         if precond_ready is not None:
             precond_ready()
-        alpha = be.cg_solve(K, P, b0, n, lam, maxiter, opt)
+        if K.fmt != "f32":
+            b0s = be.zeros((M + 1) // 2 * 2).view(1, -1)
+            b0s[0, :M].copy_(b0)
+            got = be.cg_solve_batched([K], [P], b0s, [n], lam, maxiter, opt)
+            alpha = None if got is None else got[0, :M].clone()
+        else:
+            alpha = be.cg_solve(K, P, b0, n, lam, maxiter, opt)
+    if one_call and alpha is not None:
         if opt.check_pivots:
             _check_pivots(be, P)
         if return_knm:

@@ -912,6 +912,54 @@ def test_lockstep_cg_of_a_class_batch_equals_the_single_class_loops(be):
     assert be.cg_solve_batched([K0, K1], Pb, b2, [Fs[0].n, 3000], lam, 20, opt) is None
 
 
+@pytest.mark.parametrize("fmt", ["u24", "bf16"])
+@pytest.mark.parametrize("specs", [[(900, 300), (50, 257), (1500, 1000), (777, 333), (2000, 640)],          # <= 256 chunks of four per row
+                                   [(3000, 1100), (2500, 2000), (1800, 1537)]])                               # the two-halves pass of 257..512 chunks
+def test_lockstep_cg_over_compact_blocks_equals_the_single_class_loops(be, fmt, specs):
+    """odx_falkon_cg_batched_q_f64: the lock-step CG loops of a class batch over K_nM blocks stored as 24-bit fixed point or
+    bf16 (what config 2 'as stated' and every HBM-bound fit of a Minibootstrap-sized batch stream).  Per class the alpha
+    must be the very bits the statement-by-statement loop of odx/solver.py gives on the same stored block (its passes are
+    odx_knm_fwd_bwd_q launches: same workgroup -> rows assignment, same slab order)."""
+    import odx
+    from odx.solver import SolverOptions
+    rng = np.random.default_rng(5 + len(specs))
+    D, sigma, lam, opt = 48, 7.0, 1e-4, SolverOptions(check_pivots=False)
+    Fs, Zfs, ys = [], [], []
+    for n, M in specs:
+        X = (rng.standard_normal((n, D)) * (20.0 / np.sqrt(D))).astype(np.float32)
+        F = be.features(torch.from_numpy(X))
+        Fs.append(F)
+        Zfs.append(be.rows(F, np.sort(rng.choice(n, size=M, replace=False))) if M <= n else be.features(torch.from_numpy(
+            (rng.standard_normal((M, D)) * (20.0 / np.sqrt(D))).astype(np.float32))))
+        ys.append(be.vec(np.where(rng.random(n) < 0.2, 1.0, -1.0)))
+    old = be.knm_storage
+    try:
+        be.knm_storage = fmt
+        be.pin_gauss_tile(256)                            # the compact formats are written by the wide tile core's epilogue
+        assert be.cg_batched_supported([F.n for F in Fs], [z.n for z in Zfs], fmt)
+        Ps = be.precond_batched(Zfs, sigma, lam, opt.pc_epsilon)
+        Mmax = max(z.n for z in Zfs)
+        b0s = torch.zeros((len(specs), (Mmax + 1) // 2 * 2), dtype=torch.float64, device="cuda")
+        Ks = []
+        for i, (F, Zf, y) in enumerate(zip(Fs, Zfs, ys)):
+            K, _ = be.knm_rhs(F, Zf, sigma, y * (1.0 / F.n), rhs_out=b0s[i, :Zf.n])
+            assert K.fmt == fmt
+            Ks.append(K)
+        alphas = be.cg_solve_batched(Ks, Ps, b0s, [F.n for F in Fs], lam, 20, opt)
+        assert alphas is not None
+        for i, (F, Zf, y, P) in enumerate(zip(Fs, Zfs, ys, Ps)):
+            single = odx.falkon_fit(be, F, y, Zf, sigma, lam, 20, opt, precond=P)
+            assert torch.equal(alphas[i, :Zf.n], single), (fmt, specs[i], float((alphas[i, :Zf.n] - single).abs().max()))
+            assert torch.isfinite(single).all() and float(single.abs().max()) > 0
+        # mixed storage formats cannot share a launch
+        be.knm_storage = "f32"
+        Kf, _ = be.knm_rhs(Fs[0], Zfs[0], sigma, ys[0] * (1.0 / Fs[0].n))
+        assert be.cg_solve_batched([Kf] + Ks[1:], Ps, b0s, [F.n for F in Fs], lam, 20, opt) is None
+    finally:
+        be.knm_storage = old
+        be.pin_gauss_tile(0)
+
+
 @pytest.mark.parametrize("n,M,D,maxiter", [(3000, 300, 256, 20), (700, 129, 36, 7), (5000, 1000, 64, 25)])
 def test_cg_loop_in_one_call_equals_the_loop_issued_from_python(be, n, M, D, maxiter):
     """odx_falkon_cg_f64 (what an unsharded fit runs) against the statement-by-statement loop of odx/solver.py (what

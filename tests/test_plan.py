@@ -60,8 +60,9 @@ def test_chain_workspace_formula_is_the_one_of_the_library():
 
 def test_storage_rule_matches_the_documented_thresholds():
     assert plan.knm_format_rule(1_000_000, 10_000) == "u24" and plan.knm_format_rule(125_000, 10_000) == "u24"
-    assert plan.knm_format_rule(100_000, 2_000) == "f32" and plan.knm_format_rule(20_000, 10_000) == "f32"
-    assert plan.knm_format_rule(1_000_000, 4096) == "f32" and plan.knm_format_rule(1_000_000, 10_000, "f32") == "f32"
+    assert plan.knm_format_rule(100_000, 2_000) == "u24" and plan.knm_format_rule(20_000, 10_000) == "u24"      # configs 2 / small shards
+    assert plan.knm_format_rule(22_000, 2_000) == "f32" and plan.knm_format_rule(10_000_000, 1_000) == "f32"    # Minibootstrap fits; narrow blocks
+    assert plan.knm_format_rule(1_000_000, 4096) == "u24" and plan.knm_format_rule(1_000_000, 10_000, "f32") == "f32"
     assert plan.knm_bytes_rule(1_000_000, 10_000, "u24") == 30_000_000_000 and plan.knm_bytes_rule(10, 10, "f32") == 10 * 12 * 4
 
 

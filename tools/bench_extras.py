@@ -281,7 +281,8 @@ def _falkon_config_extra(name, C, n, D, M, sigma, lam, classes_run, labels="one_
             Mp = (M + 1) // 2 * 2
             b0s = torch.zeros((len(cls), Mp), dtype=torch.float64, device=dev)
             alphas = None
-            if be.knm_format(n, M) == "f32":      # small blocks: all K_nM builds, then the CG loops of the chain's classes in lock step
+            if be.cg_batched_supported([n] * len(cls), [M] * len(cls), be.knm_format(n, M)) and len(cls) * be.knm_bytes(n, M) <= 60e9:
+                # all K_nM builds, then the CG loops of the chain's classes in lock step (f32 or compact blocks alike)
                 Ks = [be.knm_rhs(F, Zfs[k], sigma, ys[k] * (1.0 / n), rhs_out=b0s[k, :Zfs[k].n])[0] for k in range(len(cls))]
                 alphas = be.cg_solve_batched(Ks, Ps, b0s, [n] * len(cls), lam, maxiter, opt)
                 del Ks
