@@ -215,7 +215,12 @@ class _FoldedBN(nn.Module):
         """(weight, bias) of conv followed by the frozen batch norm, in the dtype the convolution will run in: under
         autocast the folded tensors are kept in the autocast dtype too — autocast's own cast of an f32 weight is redone
         on every call (53 weight tensors per image; the bf16 trunk was slower than the f32 one for it)."""
-        dt = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled("cuda")) else conv.weight.dtype
+        if x.is_cuda and torch.is_autocast_enabled("cuda"):
+            dt = torch.get_autocast_dtype("cuda")
+        elif x.dtype in (torch.bfloat16, torch.float16):
+            dt = x.dtype            # a trunk run natively in a 16-bit dtype (no autocast context: its per-op dispatch is host time)
+        else:
+            dt = conv.weight.dtype
         wb = self._folded.get((key, dt))
         if wb is None:
             with torch.no_grad():

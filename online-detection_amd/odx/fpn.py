@@ -66,13 +66,34 @@ class FeaturePyramid(nn.Module):
             nn.init.constant_(m.bias, 0)
         self.out_channels = out_channels
 
+    def _apply(self, fn, *a, **kw):
+        self._cast = {}
+        return super()._apply(fn, *a, **kw)
+
+    def _wb(self, conv, dtype):
+        """conv's weight / bias in `dtype` (cached per parameter version: a 16-bit trunk does not cast them per call)."""
+        if dtype == conv.weight.dtype:
+            return conv.weight, conv.bias
+        cache = self.__dict__.setdefault("_cast", {})
+        key = (id(conv), dtype, conv.weight.data_ptr(), conv.weight._version, conv.bias._version)
+        hit = cache.get(id(conv))
+        if hit is None or hit[0] != key:
+            hit = cache[id(conv)] = (key, conv.weight.detach().to(dtype), conv.bias.detach().to(dtype))
+        return hit[1], hit[2]
+
+    def _conv(self, conv, x):
+        if torch.is_autocast_enabled("cuda") and x.is_cuda:
+            return conv(x)
+        w, b = self._wb(conv, x.dtype)
+        return F.conv2d(x, w, b, conv.stride, conv.padding)
+
     def forward(self, cs):
-        last = self.inner[-1](cs[-1])
-        outs = [self.layer[-1](last)]
+        last = self._conv(self.inner[-1], cs[-1])
+        outs = [self._conv(self.layer[-1], last)]
         for k in range(len(cs) - 2, -1, -1):
-            lat = self.inner[k](cs[k])
+            lat = self._conv(self.inner[k], cs[k])
             last = lat + F.interpolate(last, size=lat.shape[-2:], mode="nearest")
-            outs.insert(0, self.layer[k](last))
+            outs.insert(0, self._conv(self.layer[k], last))
         outs.append(F.max_pool2d(outs[-1], 1, 2, 0))
         return tuple(outs)                                   # P2, P3, P4, P5, P6
 
@@ -142,10 +163,17 @@ class OnlineDetectionModelFPN(nn.Module):
     # ------------------------------------------------------------------ trunk
     @torch.no_grad()
     def c4(self, image):
-        """The trunk features of an image — here the pyramid (P2 .. P6), f32 (the method keeps extract's name: the harvest
-        loops call model.c4 / proposals / roi_head_maps on whatever the trunk hands out)."""
+        """The trunk features of an image — here the pyramid (P2 .. P6) (the method keeps extract's name: the harvest loops
+        call model.c4 / proposals / roi_head_maps on whatever the trunk hands out).  f32 maps; under a bf16 trunk the maps stay
+        in bf16: the RPN head convolves them in bf16 anyway and the RoIAlign launch converts the four levels it pools from —
+        five casts to f32 here plus five casts back in the proposal stage were most of what made the bf16 forward SLOWER
+        than the f32 one (6.6 against 5.5 ms in round 3's bench line)."""
+        if self.compute_dtype is not None and image.is_cuda:
+            # natively in the 16-bit dtype: the folded / cached weights are already in it, and an autocast context costs host
+            # time per operation — the bf16 trunk's kernels are shorter than the f32 one's and the forward became host-bound
+            return tuple(self.fpn(self.backbone(image.to(self.compute_dtype))))
         with self._amp():
-            return tuple(p.float() for p in self.fpn(self.backbone(image)))
+            return tuple(self.fpn(self.backbone(image)))
 
     pyramid = c4
 
@@ -177,9 +205,12 @@ class OnlineDetectionModelFPN(nn.Module):
         # FPN forward was launch-bound at 600 launches per image), and the suppression runs per level again
         sel_reg, sel_anc, sel_score, counts = [], [], [], []
         for lvl, p in enumerate(trunk):
-            with self._amp():
-                t = F.relu(self.rpn_conv(p))
-                logits, deltas = self.rpn_logits(t).float(), self.rpn_deltas(t).float()
+            with (contextlib.nullcontext() if p.dtype in (torch.bfloat16, torch.float16) else self._amp()):
+                # (weights / biases held in the compute dtype: autocast casts an f32 parameter again on every call — 15 casts
+                # per image over the five levels)
+                w = self._rpn_weights(p.dtype)
+                t = F.relu(F.conv2d(p, w[0], w[1], 1, 1))
+                logits, deltas = F.conv2d(t, w[2], w[3]).float(), F.conv2d(t, w[4], w[5]).float()
             _, A, H, W = logits.shape
             obj = logits.permute(0, 2, 3, 1).reshape(-1)
             reg = deltas.view(1, A, 4, H, W).permute(0, 3, 4, 1, 2).reshape(-1, 4)
@@ -209,6 +240,16 @@ class OnlineDetectionModelFPN(nn.Module):
         k = min(self.fpn_post_nms_top_n, scores.numel())
         top, order = scores.topk(k, sorted=True)
         return boxes[order], top
+
+    def _rpn_weights(self, dtype):
+        """The RPN head's three convolutions' weights and biases in `dtype` (cached; dropped with the packed fc weights when
+        the parameters change)."""
+        ps = (self.rpn_conv.weight, self.rpn_conv.bias, self.rpn_logits.weight, self.rpn_logits.bias, self.rpn_deltas.weight, self.rpn_deltas.bias)
+        key = (dtype,) + tuple((q.data_ptr(), q._version) for q in ps)
+        hit = self._packed.get("rpn")
+        if hit is None or hit[0] != key:
+            hit = self._packed["rpn"] = (key, tuple(q.detach().to(dtype) for q in ps))
+        return hit[1]
 
     def _anchors(self, lvl, H, W, device):
         """The anchors of a level's H x W grid (cached per shape: a function of the image size only)."""
