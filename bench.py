@@ -401,8 +401,10 @@ def main():
             "metric": "FALKON fit+infer samples/sec (N=1e6 D=1024 M=1e4)",
             "value": round(value, 1), "unit": "samples/s", "n_gpus": ranks_seen, "ranks": ranks_seen, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": (("f32-accurate K_nM (X Z' as a two-term f16 split on the f16 MFMA, f32 accumulate) stored as %s + f64 solver"
-                                                 % {"f32": "f32", "u24": "24-bit fixed point (step 2^-24)", "bf16": "bf16 (throughput only)"}[kfmt])
+            "scaling": "strong", "vs_baseline": None, "dtype": (("f32-accurate K_nM (X Z' as a two-term f16 split on the f16 MFMA, f32 accumulate) stored as %s + f64 solver%s"
+                                                 % ({"f32": "f32", "u24": "24-bit fixed point (step 2^-24)", "bf16": "bf16 (throughput only)"}[kfmt],
+                                                    "" if os.environ.get("ODX_PRECOND", "")[:1] == "f" or (M < 4096 and os.environ.get("ODX_PRECOND", "")[:1] != "s") else
+                                                    " (preconditioner: K_MM, T and T^-1 in f64; the products of the A factor, which only preconditions, at f32 accuracy on the f16 MFMA)"))
                                                 if be.gauss == "h2" else "f32 K_nM (f32-input MFMA) + f64 solver"),
             "data": "synthetic",
             "config": {"workload": "%d-class one-vs-rest FALKON fit + score-all, N=%d D=%d M=%d, %d CG iterations, "
