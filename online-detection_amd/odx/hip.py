@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _LIB = None
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libodx.so")
+# (ODX_LIB_PATH: a development knob — experimental builds of the library side by side, tools/ab_gauss.py)
+_LIB_PATH = os.environ.get("ODX_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libodx.so")
 
 ODX_OK = 0
 KNM_F32, KNM_U24, KNM_BF16 = 0, 1, 2
