@@ -621,29 +621,6 @@ __device__ __forceinline__ void w_dma_pieces(const WDma& ad, char* dst, int koff
   }
 }
 
-template <int CORE>
-__device__ __forceinline__ void w_mfma_part(f32x4 (&acc)[8][4], const f16x8 (&ah)[2], const f16x8 (&al)[2], const f16x8 (&bh)[4],
-                                            const f16x8 (&bl)[4], int tm0) {
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int tm = tm0 + u;
-    if (CORE == CORE_F8) {
-      const i32x8 a8 = f8_frag(ah[u], al[u]);
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn)
-        acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, f8_frag(bh[tn], bl[tn]), acc[tm][tn], 0, 0, 0,
-                                                                        F8_SCALE_ONE, 0, F8_SCALE_ONE);
-    } else {
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u], bh[tn], acc[tm][tn], 0, 0, 0);
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], bl[tn], acc[tm][tn], 0, 0, 0);
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], bh[tn], acc[tm][tn], 0, 0, 0);
-      }
-    }
-  }
-}
-
 struct WFrag {
   f16x8 bh[4], bl[4];       // the stage's B fragments (4 column blocks)
   f16x8 a0h[2], a0l[2];     // A fragments of parts 0 and 2 (2 row blocks each)
@@ -684,7 +661,6 @@ __device__ __forceinline__ void w_mfma_col(f32x4 (&acc)[8][4], const f16x8 (&ah)
 // the order a part's instructions are to be issued in: 4 x (one LDS read, then PER MFMAs), NV x (one DMA, then PER MFMAs)
 template <int PER, int NV>
 __device__ __forceinline__ void w_sched_part() {
-#ifndef ODX_NO_SGB
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
@@ -695,7 +671,6 @@ __device__ __forceinline__ void w_sched_part() {
     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read (the DMA)
     __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
   }
-#endif
 }
 
 // One stage (s).  On entry `f` holds the stage's B fragments and the A fragments of part 0 (read behind the barrier of the
