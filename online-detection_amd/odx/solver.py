@@ -181,6 +181,7 @@ def falkon_fit(be, F, y, Zf, sigma, lam, maxiter=20, opt=None, n_total=None, all
         # one shard, nothing to time per kernel family: the loop below as one library call (odx_falkon_cg_f64)
         if precond_ready is not None:
             precond_ready()
+            precond_ready = None           # (waited for: the statement-by-statement loop below must not wait again)
         if K.fmt != "f32":
             b0s = be.zeros((M + 1) // 2 * 2).view(1, -1)
             b0s[0, :M].copy_(b0)
