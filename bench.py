@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--precond-batch", type=int, default=0, help="classes whose preconditioners one batched launch chain builds "
                     "(odx_falkon_precond_batched_f64), one group ahead of the fits; 1 = one chain per class (--precond-depth applies); "
                     "default: min(6, classes this rank owns)")
+    ap.add_argument("--lockstep-batch", type=int, default=0, help="classes per lock-step batch (a divisor of the rank count; default: "
+                    "planned from the HBM budget, odx/plan.py — the rank count when it fits); smaller batches rotate their owners "
+                    "through the ranks")
     ap.add_argument("--precond-cus", type=int, default=0, help="confine the preconditioner chains (their stream and the library's "
                     "helper streams) to this many compute units, spread over the XCDs (0: the whole device; an experiment knob — "
                     "measured slower at 48..128 CUs: the confined chains starve behind the main stream's grids, DESIGN.md 7)")
@@ -246,8 +249,10 @@ def main():
     be.reserve_cus_during_passes(args.reserve_cus)
     job = LockstepClassJob(be, X, N, M, lambda c: torch.where((row_ids % C) == c, 1.0, -1.0).to(torch.float64), cidx_dev,
                            args.sigma, args.lam, args.maxiter, opt, shard=shard, precond_batch=args.precond_batch,
-                           precond_depth=args.precond_depth, precond_after_fit=args.precond_after_fit, precond_cus=args.precond_cus)
+                           precond_depth=args.precond_depth, precond_after_fit=args.precond_after_fit, precond_cus=args.precond_cus,
+                           batch=args.lockstep_batch)
     G, ldk, scores = job.G, job.ldk, job.scores
+    job_b, plan_gb = job.b, round(job.plan.total_bytes / 1e9, 1)
     kfmt = be.knm_format(n_loc, M)                 # storage of the K_nM shards ("u24" at the headline size, "f32" for small ones)
 
     def run_classes(classes, timed):
@@ -410,7 +415,8 @@ def main():
             "config": {"workload": "%d-class one-vs-rest FALKON fit + score-all, N=%d D=%d M=%d, %d CG iterations, "
                                    "rows sharded over %d GPU(s)" % (C, N, D, M, args.maxiter, world),
                        "N": N, "D": D, "M": M, "classes": C, "sigma": args.sigma, "lambda": args.lam,
-                       "rows_per_gpu": n_loc, "preconditioners_per_batched_chain": G, "preconditioner_cus": args.precond_cus or "all"},
+                       "rows_per_gpu": n_loc, "preconditioners_per_batched_chain": G, "preconditioner_cus": args.precond_cus or "all",
+                       "lockstep_batch": job_b, "planned_GB_per_rank": plan_gb},
             "roofline": roof,
             "roofline_hbm": roof_p,
             "roofline_mfma": roof_g,
