@@ -52,7 +52,9 @@ def chain_workspace_bytes(M, D):
     T and, later, a merge level's four operands; two 512-column panels) — the scratch is sized for every M."""
     ld = _round_up(M, 2)
     split = (2 * M * _round_up(M, 64) + 2 * M * 512) // 2 + 2
-    return (M * _round_up(D, 2) + ld + 4 * M * ld + 2 * ((M + 127) // 128) * 128 * 128 + split) * 8
+    ldz = _round_up(D, 2)
+    ldz += 64 if ldz % 128 == 0 else 0           # (rows of the f64 centres are kept off a power-of-two stride)
+    return (M * ldz + ld + 4 * M * ld + 2 * ((M + 127) // 128) * 128 * 128 + split) * 8
 
 
 def factor_bytes(M):
