@@ -109,6 +109,14 @@ class LockstepClassJob:
         self.gside = _Side(dev, be, precond_cus) if self.G > 1 else None
         self.pbuf, self.pgroup = [], []
         self.trace = []          # (kind, payload) records of the schedule this rank executed (tests read it)
+        if self.G > 1 and hasattr(be, "precond_batched") and hasattr(be, "lib") and dev.type == "cuda":
+            # the two factor blocks and the chain's scratch at their final size now, not inside the first step that needs them
+            # (a warm-up on a few classes runs smaller chains: the 22 GB scratch of a 6-class chain was first allocated in the
+            # timed region)
+            while len(self.pgroup) < 2:
+                self.pgroup.append(torch.empty((self.G, 4, self.M, self.ld_p), dtype=torch.float64, device=dev))
+            with self.gside:
+                be._workspace("precond_group", be.lib.odx_falkon_precond_batched_workspace_bytes(self.M, D, self.G))
 
     def release(self):
         self.kbufs, self.pbuf, self.pgroup, self.scores = [], [], [], None
