@@ -3,11 +3,13 @@
 // following RegionRefinerTrainer.solve (train_region_refiner.py:100-119).  The Gram is an
 // NT GEMM on the f64 MFMA core over a gathered, transposed, bias-augmented f64 copy of the
 // class's rows, formed chunk by chunk so that row shards / chunks simply accumulate.
+#include <stdlib.h>
 #include "odx_internal.h"
 
 namespace odx {
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4r __attribute__((ext_vector_type(4)));
 
 // Xt[d][r] = X[idx[c0 + r]][d] (d < D), Xt[D][r] = 1, zero for r >= cn (pad up to ldt).
@@ -122,6 +124,145 @@ __global__ __launch_bounds__(256) void rls_xty_kernel(const double* __restrict__
     for (int o = 32; o > 0; o >>= 1) s[j] += __shfl_xor(s[j], o);
   }
   if (lane < 5) O5[((int64_t)c * 5 + lane) * ldo + d] = s[lane];
+}
+
+// ---------------------------------------------------------------- the Grams of a class batch straight from the f32 rows
+// G_c (D x D, lower 128 x 64 tiles) += X_c' X_c for the rows listed in class c's padded segment of idx (-1 = no row), on the
+// f64 MFMA (v_mfma_f64_16x16x4_f64) WITHOUT the transposed f64 copy of the rows the NT GEMM needs (round 3: a 2.46 GB write
+// and read-back at config 3's size): a k-tile is 16 ROWS of X — 128 (A side) + 64 (B side) consecutive floats of each,
+// gathered by row id, converted to f64 on the way into LDS as [k][column] rows of 144 / 80 doubles (the four k-rows a 32-lane
+// group of ds_read_b64 touches lie 128 bytes apart modulo the 256-byte bank window: conflict-free), the next k-tile's floats
+// prefetched into registers under the MFMAs.  One workgroup owns a tile and walks all of the class's rows: the sum over k is
+// in one fixed order (bitwise reproducible; row shards add their Grams by all-reduce afterwards).
+constexpr int RG_BM = 128, RG_BN = 64, RG_BK = 16;
+constexpr int RG_LDA = RG_BM + 16, RG_LDB = RG_BN + 16;      // doubles per LDS row
+
+__global__ __launch_bounds__(256, 3) void rls_gram_rows_kernel(const float* __restrict__ X, int64_t ldx, int D,
+                                                               const int64_t* __restrict__ idx, RlsSegs sg, double* __restrict__ G,
+                                                               int64_t ldg, int64_t g_stride) {
+  __shared__ __attribute__((aligned(16))) double lds_a[RG_BK * RG_LDA];
+  __shared__ __attribute__((aligned(16))) double lds_b[RG_BK * RG_LDB];
+  const int c = blockIdx.z;
+  const int tiles_n = (D + RG_BN - 1) / RG_BN;
+  // gridDim.x = 8 x ceil(tile rows / 8) x tiles_n: workgroup x runs on XCD x & 7 (round-robin dispatch), and that XCD walks
+  // the tile rows xcd, xcd + 8, ... left to right, so the tiles sharing an A panel (and the rows' B pieces next to each
+  // other) share one L2; the class index rotates which rows an XCD gets (row r carries r + 1 tiles)
+  const int xcd = (blockIdx.x + c) & 7, local = blockIdx.x >> 3;
+  const int bi = 8 * (local / tiles_n) + xcd, bj = local % tiles_n;
+  const int i0 = bi * RG_BM, j0 = bj * RG_BN;
+  if (i0 >= D || j0 > i0 + RG_BM - 1) return;                  // lower tiles only
+  const int64_t off = sg.off[c], len = sg.len[c];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int krow = tid >> 4, seg = tid & 15;
+  const int ca = i0 + seg * 8, cb = j0 + seg * 4;              // this thread's columns of the A / B side
+  // D % 8 == 0 (the host's condition for this kernel): a column group is whole or absent; an absent one reads the row's
+  // first floats and is zeroed on the way into LDS, like a padded row (id -1 -> row 0).  No branch around a load: with one
+  // the compiler waits for every load at the join, i.e. in front of the MFMAs the loads are meant to hide under.
+  const bool aok = ca < D, bok = cb < D;
+  const int cae = aok ? ca : 0, cbe = bok ? cb : 0;
+  f64x4 acc[4][2];
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = f64x4{0.0, 0.0, 0.0, 0.0};
+  const int64_t nk = (len + RG_BK - 1) / RG_BK;
+  if (nk == 0) return;
+  // the row id of a k-tile is fetched one k-tile before its row is: the row's loads never wait for a dependent load
+  // (the segment is padded with -1 to a multiple of 16 rows; past the last k-tile the last one is read again and dropped)
+  auto row_of = [&](int64_t kt) -> int64_t { return idx[off + (kt < nk ? kt : nk - 1) * RG_BK + krow]; };
+  f32x4r ra0, ra1, rb;
+  bool valid;
+  auto load = [&](int64_t row) {
+    valid = row >= 0;
+    const float* x = X + (valid ? row : 0) * ldx;
+    ra0 = *reinterpret_cast<const f32x4r*>(x + cae);
+    ra1 = *reinterpret_cast<const f32x4r*>(x + cae + 4);
+    rb = *reinterpret_cast<const f32x4r*>(x + cbe);
+  };
+  int64_t row_next = row_of(1);
+  load(row_of(0));
+  const int r16 = lane & 15, kq = lane >> 4;
+  for (int64_t kt = 0; kt < nk; ++kt) {
+    __syncthreads();                                           // everyone finished reading the previous k-tile
+    double* da = lds_a + krow * RG_LDA + seg * 8;
+    double* db = lds_b + krow * RG_LDB + seg * 4;
+    const float ma = valid && aok ? 1.f : 0.f, mb = valid && bok ? 1.f : 0.f;
+    *reinterpret_cast<f64x2*>(da) = f64x2{(double)(ma * ra0[0]), (double)(ma * ra0[1])};
+    *reinterpret_cast<f64x2*>(da + 2) = f64x2{(double)(ma * ra0[2]), (double)(ma * ra0[3])};
+    *reinterpret_cast<f64x2*>(da + 4) = f64x2{(double)(ma * ra1[0]), (double)(ma * ra1[1])};
+    *reinterpret_cast<f64x2*>(da + 6) = f64x2{(double)(ma * ra1[2]), (double)(ma * ra1[3])};
+    *reinterpret_cast<f64x2*>(db) = f64x2{(double)(mb * rb[0]), (double)(mb * rb[1])};
+    *reinterpret_cast<f64x2*>(db + 2) = f64x2{(double)(mb * rb[2]), (double)(mb * rb[3])};
+    __syncthreads();
+    load(row_next);
+    row_next = row_of(kt + 2);
+    __builtin_amdgcn_sched_barrier(0);                         // (the loads stay in front of the MFMAs they hide under)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      double a[4], b[2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = lds_a[(ks * 4 + kq) * RG_LDA + wr * 64 + t * 16 + r16];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) b[t] = lds_b[(ks * 4 + kq) * RG_LDB + wc * 32 + t * 16 + r16];
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+    }
+  }
+  // accumulator (tm, tn, reg): row 16 tm + (lane >> 4) + 4 reg, column 16 tn + (lane & 15) of the wave's 64 x 32 share
+  double* g = G + (int64_t)c * g_stride;
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = i0 + wr * 64 + tm * 16 + kq + 4 * reg;
+      if (row >= D) continue;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int col = j0 + wc * 32 + tn * 16 + r16;
+        if (col < D) g[(int64_t)row * ldg + col] += acc[tm][tn][reg];
+      }
+    }
+}
+
+// The skinny products of the same rows: P[c][chunk][j][d] = sum over the chunk's rows of Y5[j][r] [X 1][r][d], j = 0..4 (the four
+// whitened target rows and the ones row), d = 0..D (d = D: the bias column).  A thread owns a column and walks the chunk's
+// rows (coalesced 1-KB row pieces per workgroup, the Y5 values broadcast); RX_CH chunks per class give the launch its
+// parallelism, rls_xty_reduce_kernel adds them in a fixed order.
+constexpr int RX_CH = 32;
+
+__global__ __launch_bounds__(256) void rls_xty_rows_kernel(const float* __restrict__ X, int64_t ldx, int D, const int64_t* __restrict__ idx,
+                                                           RlsSegs sg, const double* __restrict__ Y4, int64_t ldy, double* __restrict__ P,
+                                                           int64_t ldo) {
+  const int c = blockIdx.z, chunk = blockIdx.y;
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  const int64_t off = sg.off[c], len = sg.len[c];
+  const int64_t per = ((len + RX_CH - 1) / RX_CH + 15) / 16 * 16;
+  const int64_t r0 = (int64_t)chunk * per, r1 = r0 + per < len ? r0 + per : len;
+  double s[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  if (d <= D) {
+    for (int64_t r = r0; r < r1; ++r) {
+      const int64_t row = idx[off + r];
+      if (row < 0) continue;
+      const double x = d < D ? (double)X[row * ldx + d] : 1.0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] = fma(Y4[(int64_t)j * ldy + off + r], x, s[j]);
+      s[4] += x;
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) P[(((int64_t)c * RX_CH + chunk) * 5 + j) * ldo + d] = s[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void rls_xty_reduce_kernel(const double* __restrict__ P, int64_t ldo, int D1, double* __restrict__ O5) {
+  const int c = blockIdx.y, j = blockIdx.z;
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D1) return;
+  double s = 0.0;
+  for (int chunk = 0; chunk < RX_CH; ++chunk) s += P[(((int64_t)c * RX_CH + chunk) * 5 + j) * ldo + d];
+  O5[((int64_t)c * 5 + j) * ldo + d] = s;
 }
 
 // P[i][k] for the rows of ALL classes with one launch: row i belongs to the class whose [start, start + len) holds it.
@@ -307,7 +448,9 @@ extern "C" int odx_rls_predict_rows_batched_f64(const float* X, int64_t ldx, int
 extern "C" int64_t odx_rls_gram_batched_workspace_bytes(int64_t npad, int D) {
   if (npad <= 0 || D <= 0) return 0;
   const int64_t ldt = round_up(npad, 16), ldo = round_up((int64_t)D + 1, 2);
-  return (ldt * (int64_t)(D + 1) + 5 * ldt + (int64_t)ODX_MAX_ZBATCH * 5 * ldo) * (int64_t)sizeof(double);
+  const int64_t nt = ldt * (int64_t)(D + 1) + 5 * ldt + (int64_t)ODX_MAX_ZBATCH * 5 * ldo;          // the NT form's copy of the rows
+  const int64_t rows = (int64_t)ODX_MAX_ZBATCH * (32 + 1) * 5 * ldo;                               // the rows form's partial sums
+  return (nt > rows ? nt : rows) * (int64_t)sizeof(double);
 }
 
 // XtY[c] (4 x D1) += O5[c] rows 0..3;  G[c] row D (the bias row of the lower triangle) += O5[c] row 4
@@ -338,6 +481,36 @@ extern "C" int odx_rls_gram_batched_f64(const float* X, int64_t ldx, int D, cons
     return ODX_ERR_WORKSPACE;
   }
   hipStream_t s = as_stream(stream);
+  {
+    // default: the Grams and the skinny products straight from the f32 rows (rls_gram_rows_kernel, rls_xty_rows_kernel);
+    // ODX_RLS_GRAM=nt keeps round 3's form (a transposed f64 copy of all rows + the generic NT GEMM) for A/B runs
+    const char* e = getenv("ODX_RLS_GRAM");
+    if (!(e && e[0] == 'n') && D % 8 == 0 && ldx % 4 == 0 && aligned16(X)) {
+      RlsSegs sg;
+      for (int c = 0; c < ODX_MAX_ZBATCH; ++c) sg.off[c] = sg.len[c] = 0;
+      for (int c = 0; c < C; ++c) {
+        ODX_REQUIRE(seg_off[c] % 16 == 0 && seg_len[c] >= 0 && seg_off[c] + seg_len[c] <= npad,
+                    "odx_rls_gram_batched_f64: class %d: segment must start at a multiple of 16 inside the padded index array", c);
+        sg.off[c] = seg_off[c];
+        sg.len[c] = seg_len[c];
+      }
+      const int tiles = (int)(8 * ceil_div(ceil_div(D, RG_BM), 8) * ceil_div(D, RG_BN));
+      hipLaunchKernelGGL(rls_gram_rows_kernel, dim3((unsigned)tiles, 1, (unsigned)C), dim3(256), 0, s, X, ldx, D, idx_pad, sg, G, ldg, g_stride);
+      ODX_CHECK_LAUNCH("rls_gram_rows");
+      const int64_t ldo = round_up(D1, 2);
+      double* P = static_cast<double*>(workspace);                       // C x RX_CH x 5 x ldo partial sums, then O5
+      double* O5 = P + (int64_t)C * RX_CH * 5 * ldo;
+      hipLaunchKernelGGL(rls_xty_rows_kernel, dim3((unsigned)ceil_div(D1, 256), RX_CH, (unsigned)C), dim3(256), 0, s, X, ldx, D, idx_pad, sg, Yt,
+                         ldy, P, ldo);
+      ODX_CHECK_LAUNCH("rls_xty_rows");
+      hipLaunchKernelGGL(rls_xty_reduce_kernel, dim3((unsigned)ceil_div(D1, 256), (unsigned)C, 5), dim3(256), 0, s, P, ldo, (int)D1, O5);
+      ODX_CHECK_LAUNCH("rls_xty_reduce");
+      hipLaunchKernelGGL(rls_fold_bias_kernel, dim3((unsigned)ceil_div(D1, 256), (unsigned)C), dim3(256), 0, s, O5, ldo, (int)D1, XtY, ldxy,
+                         xy_stride, G, ldg, g_stride);
+      ODX_CHECK_LAUNCH("rls_fold_bias");
+      return ODX_OK;
+    }
+  }
   double* Xt = static_cast<double*>(workspace);
   dim3 grid((unsigned)ceil_div(ldt, 32), (unsigned)ceil_div(D1, 32));
   hipLaunchKernelGGL(rls_gather_transpose_all_kernel, grid, dim3(256), 0, s, X, ldx, D, idx_pad, npad, Xt, ldt);
