@@ -252,10 +252,11 @@ class HipBackend:
 
     MAX_CLASS_BATCH = 32        # ODX_MAX_ZBATCH of libodx
 
-    def precond_batched(self, Zfs, sigma, lam, eps, out=None, ws_key="precond_batched"):
+    def precond_batched(self, Zfs, sigma, lam, eps, out=None, ws_key="precond_batched", Mmax=None):
         """The preconditioners of len(Zfs) <= 32 independent classes with ONE chain of launches
         (odx_falkon_precond_batched_f64): returns one Precond per class, views into a shared (B, 4, Mmax, ld) f64 block
-        (`out` when given) whose leading M_b x M_b blocks equal, bit for bit, what precond() makes for that class."""
+        (`out` when given) whose leading M_b x M_b blocks equal, bit for bit, what precond() makes for that class.  Mmax: rows
+        of a class's slot when that is more than this call's largest class (two calls filling halves of one block)."""
         B = len(Zfs)
         if not 1 <= B <= self.MAX_CLASS_BATCH:
             raise ValueError("precond_batched: 1..%d classes per call, got %d" % (self.MAX_CLASS_BATCH, B))
@@ -263,7 +264,9 @@ class HipBackend:
         if any(z.D != D for z in Zfs):
             raise ValueError("precond_batched: every class needs the same feature dimension")
         Ms = [int(z.n) for z in Zfs]
-        Mmax = max(Ms)
+        if Mmax is not None and int(Mmax) < max(Ms):
+            raise ValueError("precond_batched: Mmax (%d) below the largest class (%d)" % (int(Mmax), max(Ms)))
+        Mmax = max(Ms) if Mmax is None else int(Mmax)
         ld = (Mmax + 1) // 2 * 2
         if out is None:
             out = torch.empty((B, 4, Mmax, ld), dtype=torch.float64, device=self.device)

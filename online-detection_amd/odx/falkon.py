@@ -13,6 +13,7 @@ the drop-in wrappers in ``src/modules/region-classifier`` stay as thin as the re
 and so that ``sys.modules['falkon'] = odx.falkon`` is a valid binding for the reference's
 own wrapper files.
 """
+import os
 import types
 
 import torch
@@ -214,7 +215,25 @@ def fit_batch(estimators, Xs, Ys, streams=None):
                 if streams:
                     for s in streams:           # before the chain is queued: the builds below start beside it, not after it
                         s.wait_stream(cur)
-            Ps = be.precond_batched([Zfs[i] for i in chunk], sigma, lam, eps, ws_key="precond_batched_fit")
+            if streams and len(chunk) >= 2 * _CHAIN_SPLIT_MIN:
+                # two half chains side by side: a chain is a dependent sequence of short launches, a third of them one
+                # workgroup per class (the 128 x 128 diagonal factorisations), and a half's products fill what the other
+                # half's diagonal steps leave idle.  Both write their classes' slots of ONE factor block (the lock-step CG
+                # wants a uniform stride); per class the factors are those of any other grouping, bit for bit.
+                Mmax_c = max(Zfs[i].n for i in chunk)
+                block = torch.empty((len(chunk), 4, Mmax_c, (Mmax_c + 1) // 2 * 2), dtype=torch.float64, device=be.device)
+                h = (len(chunk) + 1) // 2
+                side = _chain_stream()
+                side.wait_stream(cur)
+                Ps = be.precond_batched([Zfs[i] for i in chunk[:h]], sigma, lam, eps, out=block[:h], ws_key="precond_batched_fit", Mmax=Mmax_c)
+                with torch.cuda.stream(side):
+                    Pb = be.precond_batched([Zfs[i] for i in chunk[h:]], sigma, lam, eps, out=block[h:], ws_key="precond_batched_fit_b", Mmax=Mmax_c)
+                for P in Pb:
+                    P.info.record_stream(cur)
+                Ps = Ps + Pb
+            else:
+                side = None
+                Ps = be.precond_batched([Zfs[i] for i in chunk], sigma, lam, eps, ws_key="precond_batched_fit")
             alphas = None
             if same:
                 # K_nM builds (f16 split of the rows, one Gaussian launch, the right-hand side: ~10 short kernels per
@@ -229,7 +248,13 @@ def fit_batch(estimators, Xs, Ys, streams=None):
                 if streams:
                     for s in streams:
                         cur.wait_stream(s)
+                # (ONE lock-step CG over both halves: a CG per half, the first started beside the tail of the second chain,
+                # measured slower — twice the launches, each half the width the triangular products stream best at)
+                if side is not None:
+                    cur.wait_stream(side)
                 alphas = be.cg_solve_batched(Ks, Ps, b0s, [Fs[i].n for i in chunk], lam, iters.pop(), opts[0])
+            if side is not None:
+                cur.wait_stream(side)
             for row, (i, P) in enumerate(zip(chunk, Ps)):
                 est = estimators[i]
                 if alphas is not None:
@@ -252,6 +277,18 @@ def fit_batch(estimators, Xs, Ys, streams=None):
         for s in streams:
             cur.wait_stream(s)
     return estimators
+
+
+_CHAIN_SPLIT_MIN = int(os.environ.get('ODX_CHAIN_SPLIT_MIN', '4'))
+_chain_streams = {}
+
+
+def _chain_stream():
+    """The side stream of the current device the second half chain of fit_batch runs on."""
+    dev = torch.cuda.current_device()
+    if dev not in _chain_streams:
+        _chain_streams[dev] = torch.cuda.Stream()
+    return _chain_streams[dev]
 
 
 class _nullcontext:
