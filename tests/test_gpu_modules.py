@@ -102,13 +102,16 @@ def test_rls_large_d_against_oracle(hip_backend):
     assert np.abs(W - ref["W"]).max() < 1e-6 * max(1.0, np.abs(ref["W"]).max())
 
 
-def test_batched_rls_equals_the_class_by_class_loop(hip_backend):
-    """RegionRefinerTrainer trains all classes with one launch chain (one gather, one Gram GEMM over per-class column
-    windows, batched Cholesky / inverses / triangular products); per class the result must be the class-by-class
-    loop's (the reference's order of work) — ragged class sizes, a class without rows, more classes than one batch."""
+@pytest.mark.parametrize("D", [70, 72, 328])
+def test_batched_rls_equals_the_class_by_class_loop(hip_backend, D):
+    """RegionRefinerTrainer trains all classes with one launch chain (one Gram launch over the classes' row segments,
+    batched Cholesky / inverses / triangular products); per class the result must be the class-by-class loop's (the
+    reference's order of work) — ragged class sizes, a class without rows, more classes than one batch.  D = 70: the Grams
+    through the transposed f64 copy and the NT GEMM (D % 8 != 0); 72 and 328: straight from the f32 rows
+    (rls_gram_rows_kernel), one ragged tile / three tile rows with ragged last tiles on both sides."""
     from odx.rls import RegionRefinerTrainer
     rng = np.random.default_rng(5)
-    D, C = 70, 35                                         # 35 classes: two batches (32 + 3)
+    C = 35                                                # 35 classes: two batches (32 + 3)
     sizes = [int(v) for v in rng.integers(1, 400, C)]
     sizes[3], sizes[20] = 0, 17
     X = torch.from_numpy(rng.standard_normal((sum(sizes), D)).astype(np.float32) * 0.5 + 0.1).cuda()
@@ -132,6 +135,32 @@ def test_batched_rls_equals_the_class_by_class_loop(hip_backend):
             wa, wb = a["Beta"][str(k)]["weights"], b["Beta"][str(k)]["weights"]
             assert float((wa - wb).abs().max()) <= 1e-6 * max(1.0, float(wb.abs().max())), (c, k)
             assert torch.allclose(a["Beta"][str(k)]["losses"], b["Beta"][str(k)]["losses"], atol=1e-6), (c, k)
+
+
+def test_rls_grams_from_rows_equal_the_transposed_copy_form(hip_backend, monkeypatch):
+    """The two forms of the batched Gram step (ODX_RLS_GRAM=nt: transposed f64 copy + NT GEMM; default: straight from the f32
+    rows) sum the same f64 products in different orders: the regressors agree to rounding, for class sizes that are not
+    multiples of the 16-row k-tile and feature counts that leave ragged tiles."""
+    from odx.rls import RegionRefinerTrainer
+    rng = np.random.default_rng(11)
+    D, C = 456, 5
+    sizes = [1, 15, 16, 17, 1000]
+    X = torch.from_numpy(rng.standard_normal((sum(sizes), D)).astype(np.float32) * 0.5 + 0.1).cuda()
+    Y = torch.from_numpy(rng.standard_normal((sum(sizes), 4)).astype(np.float32) * 0.2).cuda()
+    Cl = torch.from_numpy(np.repeat(np.arange(1, C + 1), sizes).astype(np.float32)).cuda()
+    perm = torch.from_numpy(rng.permutation(sum(sizes))).cuda()
+    COXY = {"C": Cl[perm].view(-1, 1), "O": None, "X": X[perm], "Y": Y[perm]}
+    cfg = {"CHOSEN_CLASSES": {i: "c%d" % i for i in range(C + 1)}, "REGION_REFINER": {"opts": {"lambda": 10.0}}}
+    out = {}
+    for mode in ("nt", "rows"):
+        monkeypatch.setenv("ODX_RLS_GRAM", mode)
+        tr = RegionRefinerTrainer(cfg, 10.0, False)
+        tr.COXY = COXY
+        out[mode] = quiet(tr._train_batched, hip_backend)
+    for c in range(C):
+        for k in range(4):
+            wa, wb = out["nt"][c]["Beta"][str(k)]["weights"], out["rows"][c]["Beta"][str(k)]["weights"]
+            assert float((wa - wb).abs().max()) <= 1e-6 * max(1.0, float(wb.abs().max())), (c, k)
 
 
 class OracleFalkonClassifier:
