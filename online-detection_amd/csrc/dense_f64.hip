@@ -209,13 +209,24 @@ __device__ __forceinline__ void lds_trinv_128(double* s, double* xi, double* rd,
   __syncthreads();
 }
 
+// (eight loads in flight per thread, none behind a branch: an absent element reads A[0] and is replaced afterwards — a load
+// under a condition is waited for at the join, one memory latency per element, 32 of them in a row: a quarter of the kernel)
 __device__ __forceinline__ void lds_load_lower_128(double* s, const double* __restrict__ A, int64_t lda, int jb) {
-  for (int e = threadIdx.x; e < DB_NB * DB_NB; e += DB_NT) {
-    const int i = e >> 7, j = e & 127;
-    double v = 0.0;
-    if (i < jb && j <= i) v = A[(int64_t)i * lda + j];
-    else if (i == j) v = 1.0;
-    s[i * DB_LD + j] = v;
+#pragma unroll 1
+  for (int e0 = threadIdx.x; e0 < DB_NB * DB_NB; e0 += 8 * DB_NT) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = e0 + q * DB_NT, i = e >> 7, j = e & 127;
+      const bool ok = i < jb && j <= i;
+      v[q] = A[ok ? (int64_t)i * lda + j : 0];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = e0 + q * DB_NT, i = e >> 7, j = e & 127;
+      const bool ok = i < jb && j <= i;
+      s[i * DB_LD + j] = ok ? v[q] : (i == j ? 1.0 : 0.0);
+    }
   }
   __syncthreads();
 }
@@ -246,9 +257,17 @@ __global__ __launch_bounds__(DB_NT) void potrf_diag_kernel(double* __restrict__ 
   double* gx = Dinv + DB_NB * DB_NB - 4096;
   lds_load_lower_128(s, A, lda, jb);
   lds_chol_128(s, xi, rd, gx, jb, info, info_base);
-  for (int e = threadIdx.x; e < jb * jb; e += DB_NT) {
-    const int i = e / jb, j = e % jb;
-    A[(int64_t)i * lda + j] = (j <= i) ? s[i * DB_LD + j] : 0.0;
+  if (jb == DB_NB) {
+#pragma unroll 4
+    for (int e = threadIdx.x; e < DB_NB * DB_NB; e += DB_NT) {
+      const int i = e >> 7, j = e & 127;
+      A[(int64_t)i * lda + j] = (j <= i) ? s[i * DB_LD + j] : 0.0;
+    }
+  } else {
+    for (int e = threadIdx.x; e < jb * jb; e += DB_NT) {
+      const int i = e / jb, j = e % jb;
+      A[(int64_t)i * lda + j] = (j <= i) ? s[i * DB_LD + j] : 0.0;
+    }
   }
   if (!WITH_INV) return;
   __threadfence_block();
