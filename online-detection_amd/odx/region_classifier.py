@@ -43,6 +43,19 @@ def _randint_advances_one_draw_per_value(g, shape):
     return bool(torch.equal(a.get_state(), b.get_state()))
 
 
+_STREAMS = {}
+
+
+def _work_streams(k, tag="class"):
+    """k side streams of the current device, created once (a call used to create its own: the stream pool hands out 32
+    streams in turn and the caching allocator keeps a pool of blocks per stream)."""
+    key = (torch.cuda.current_device(), tag)
+    have = _STREAMS.setdefault(key, [])
+    while len(have) < k:
+        have.append(torch.cuda.Stream())
+    return have[:k]
+
+
 class OnlineRegionClassifierBase:
     incore = True
 
@@ -276,7 +289,7 @@ class OnlineRegionClassifierBase:
         C = self.num_classes - 1
         k = max(1, int(self.class_streams))
         main = torch.cuda.current_stream()
-        streams = [torch.cuda.Stream() for _ in range(k)]
+        streams = _work_streams(k)
         for s in streams:
             s.wait_stream(main)
         seed0 = self._class_seed()
@@ -410,7 +423,7 @@ class OnlineRegionClassifierBase:
         C = self.num_classes - 1
         k = max(1, int(self.class_batch)) if self.class_batch > 0 else 4
         main = torch.cuda.current_stream()
-        streams = [torch.cuda.Stream() for _ in range(k)]
+        streams = _work_streams(k)
         active = [i for i in range(C) if len(positives[i]) != 0 and len(negatives[i]) != 0 and self._owned(i)]
         if reference_rng is None:
             seed0 = self._class_seed()
