@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void rls_xty_kernel(const double* __restrict__
 // group of ds_read_b64 touches lie 128 bytes apart modulo the 256-byte bank window: conflict-free), the next k-tile's floats
 // prefetched into registers under the MFMAs.  One workgroup owns a tile and walks all of the class's rows: the sum over k is
 // in one fixed order (bitwise reproducible; row shards add their Grams by all-reduce afterwards).
+typedef float f32x2r __attribute__((ext_vector_type(2)));
 constexpr int RG_BM = 128, RG_BN = 64, RG_BK = 16;
 constexpr int RG_LDA = RG_BM + 16, RG_LDB = RG_BN + 16;      // doubles per LDS row
 
@@ -155,12 +156,26 @@ __global__ __launch_bounds__(256, 3) void rls_gram_rows_kernel(const float* __re
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int krow = tid >> 4, seg = tid & 15;
-  const int ca = i0 + seg * 8, cb = j0 + seg * 4;              // this thread's columns of the A / B side
-  // D % 8 == 0 (the host's condition for this kernel): a column group is whole or absent; an absent one reads the row's
-  // first floats and is zeroed on the way into LDS, like a padded row (id -1 -> row 0).  No branch around a load: with one
-  // the compiler waits for every load at the join, i.e. in front of the MFMAs the loads are meant to hide under.
-  const bool aok = ca < D, bok = cb < D;
-  const int cae = aok ? ca : 0, cbe = bok ? cb : 0;
+  // this thread's columns: pairs (2 seg, 2 seg + 1) of the four 32-column groups of the A side and the two of the B side —
+  // the 16 lanes of a k-row write 16 consecutive 16-byte pairs of an LDS row (conflict-free; eight consecutive columns per
+  // lane put lanes 0, 4, 8, 12 on the same banks: four-way conflicts on every store)
+  // D % 8 == 0 (the host's condition for this kernel): a pair is whole or absent; an absent one reads the row's first floats
+  // and is zeroed on the way into LDS, like a padded row (id -1 -> row 0).  No branch around a load: with one the compiler
+  // waits for every load at the join, i.e. in front of the MFMAs the loads are meant to hide under.
+  int cae[4], cbe[2];
+  bool aok[4], bok[2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int col = i0 + q * 32 + seg * 2;
+    aok[q] = col < D;
+    cae[q] = aok[q] ? col : 0;
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int col = j0 + q * 32 + seg * 2;
+    bok[q] = col < D;
+    cbe[q] = bok[q] ? col : 0;
+  }
   f64x4 acc[4][2];
 #pragma unroll
   for (int tm = 0; tm < 4; ++tm)
@@ -171,29 +186,33 @@ __global__ __launch_bounds__(256, 3) void rls_gram_rows_kernel(const float* __re
   // the row id of a k-tile is fetched one k-tile before its row is: the row's loads never wait for a dependent load
   // (the segment is padded with -1 to a multiple of 16 rows; past the last k-tile the last one is read again and dropped)
   auto row_of = [&](int64_t kt) -> int64_t { return idx[off + (kt < nk ? kt : nk - 1) * RG_BK + krow]; };
-  f32x4r ra0, ra1, rb;
+  f32x2r ra[4], rb[2];
   bool valid;
   auto load = [&](int64_t row) {
     valid = row >= 0;
     const float* x = X + (valid ? row : 0) * ldx;
-    ra0 = *reinterpret_cast<const f32x4r*>(x + cae);
-    ra1 = *reinterpret_cast<const f32x4r*>(x + cae + 4);
-    rb = *reinterpret_cast<const f32x4r*>(x + cbe);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ra[q] = *reinterpret_cast<const f32x2r*>(x + cae[q]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) rb[q] = *reinterpret_cast<const f32x2r*>(x + cbe[q]);
   };
   int64_t row_next = row_of(1);
   load(row_of(0));
   const int r16 = lane & 15, kq = lane >> 4;
   for (int64_t kt = 0; kt < nk; ++kt) {
     __syncthreads();                                           // everyone finished reading the previous k-tile
-    double* da = lds_a + krow * RG_LDA + seg * 8;
-    double* db = lds_b + krow * RG_LDB + seg * 4;
-    const float ma = valid && aok ? 1.f : 0.f, mb = valid && bok ? 1.f : 0.f;
-    *reinterpret_cast<f64x2*>(da) = f64x2{(double)(ma * ra0[0]), (double)(ma * ra0[1])};
-    *reinterpret_cast<f64x2*>(da + 2) = f64x2{(double)(ma * ra0[2]), (double)(ma * ra0[3])};
-    *reinterpret_cast<f64x2*>(da + 4) = f64x2{(double)(ma * ra1[0]), (double)(ma * ra1[1])};
-    *reinterpret_cast<f64x2*>(da + 6) = f64x2{(double)(ma * ra1[2]), (double)(ma * ra1[3])};
-    *reinterpret_cast<f64x2*>(db) = f64x2{(double)(mb * rb[0]), (double)(mb * rb[1])};
-    *reinterpret_cast<f64x2*>(db + 2) = f64x2{(double)(mb * rb[2]), (double)(mb * rb[3])};
+    double* da = lds_a + krow * RG_LDA + seg * 2;
+    double* db = lds_b + krow * RG_LDB + seg * 2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float m = valid && aok[q] ? 1.f : 0.f;
+      *reinterpret_cast<f64x2*>(da + q * 32) = f64x2{(double)(m * ra[q][0]), (double)(m * ra[q][1])};
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float m = valid && bok[q] ? 1.f : 0.f;
+      *reinterpret_cast<f64x2*>(db + q * 32) = f64x2{(double)(m * rb[q][0]), (double)(m * rb[q][1])};
+    }
     __syncthreads();
     load(row_next);
     row_next = row_of(kt + 2);
