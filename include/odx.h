@@ -357,7 +357,9 @@ int odx_rls_predict_rows_batched_f64(const float* X, int64_t ldx, int D, const i
  *   gram:  idx_pad (DEVICE, npad entries): the row ids class after class, each class's segment starting at a multiple of
  *          16 and padded with -1; seg_off / seg_len (HOST, C entries): start and true length of the segments; Yt (4 x ldy):
  *          the whitened targets in the same padded order.  G (C blocks g_stride apart, (D+1) x ldg lower) += Gram,
- *          XtY (C blocks xy_stride apart, 4 x ldxy) += Yt [X 1] — one gather, one Gram GEMM, one X'Y GEMM.
+ *          XtY (C blocks xy_stride apart, 4 x ldxy) += Yt [X 1] — straight from the f32 rows when D % 8 == 0, ldx % 4 == 0
+ *          and X is 16-byte aligned (one TN Gram launch on the f64 matrix cores + one sweep for X'Y); otherwise, or with
+ *          ODX_RLS_GRAM=nt in the environment, through a transposed f64 copy of the rows and the NT GEMM.
  *   solve: per class as odx_rls_solve_f64; W: C blocks w_stride apart, 4 x ldw; info: C words.
  * Two calls so that a row-sharded caller can all-reduce G and XtY in between. */
 int64_t odx_rls_gram_batched_workspace_bytes(int64_t npad, int D);
