@@ -441,6 +441,17 @@ int odx_nms_batched_f32(const float* boxes_sorted, const int32_t* counts, int Rm
 int odx_paste_masks_u8(const float* masks, const float* boxes, int R, int S, int im_h, int im_w, float thresh,
                        int padding, unsigned char* out, odx_stream_t stream);
 
+/* What follows every convolution of the frozen-batch-norm ResNet trunk (mrcnn_modified/modeling/backbone/resnet.py
+ * Bottleneck.forward: conv -> FrozenBatchNorm2d -> (+ identity) -> relu_; the norm folded into the weights and `bias`), in
+ * place over a contiguous NCHW f32 map and in ONE pass:  y = act(y + bias[c] (+ residual)),  act = ReLU when relu != 0.
+ * residual: same shape as y, or NULL.  The additions are made in the reference's order ((conv + bias) + identity).      */
+int odx_bias_act_nchw_f32(float* y, const float* bias, const float* residual, int64_t N, int C, int64_t HW, int relu,
+                          odx_stream_t stream);
+/* The same over a 16-bit map (a trunk run natively in bf16 / f16): is_bf16 != 0: bfloat16, else IEEE half; every addition is
+ * rounded to the map's type, as the separate operators round.                                                            */
+int odx_bias_act_nchw_16(void* y, const void* bias, const void* residual, int is_bf16, int64_t N, int C, int64_t HW, int relu,
+                         odx_stream_t stream);
+
 
 #ifdef __cplusplus
 }

@@ -508,8 +508,9 @@ extern "C" int odx_rls_gram_batched_f64(const float* X, int64_t ldx, int D, cons
       RlsSegs sg;
       for (int c = 0; c < ODX_MAX_ZBATCH; ++c) sg.off[c] = sg.len[c] = 0;
       for (int c = 0; c < C; ++c) {
-        ODX_REQUIRE(seg_off[c] % 16 == 0 && seg_len[c] >= 0 && seg_off[c] + seg_len[c] <= npad,
-                    "odx_rls_gram_batched_f64: class %d: segment must start at a multiple of 16 inside the padded index array", c);
+        // (the kernel reads whole 16-row k-tiles: the -1 padding behind a segment must lie inside the array too)
+        ODX_REQUIRE(seg_off[c] % 16 == 0 && seg_len[c] >= 0 && round_up(seg_off[c] + seg_len[c], 16) <= npad,
+                    "odx_rls_gram_batched_f64: class %d: segment must start at a multiple of 16 and end, padded to one, inside the index array", c);
         sg.off[c] = seg_off[c];
         sg.len[c] = seg_len[c];
       }

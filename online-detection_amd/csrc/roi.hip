@@ -494,3 +494,96 @@ extern "C" int odx_paste_masks_u8(const float* masks, const float* boxes, int R,
   ODX_CHECK_LAUNCH("odx_paste_masks_u8");
   return ODX_OK;
 }
+
+// ---------------------------------------------------------------- epilogue of a trunk convolution
+// y[n][c][p] = act(y[n][c][p] + bias[c] (+ residual[n][c][p])) in place over an NCHW map: what follows every convolution of
+// the frozen-batch-norm ResNet trunk (the norm is folded into the weights and this bias) as ONE pass instead of the library's
+// bias kernel + an addition + a ReLU.  blockIdx.y = (n, c) plane; 16-byte accesses when the plane allows.  f32, or a 16-bit
+// type rounded after every addition as the separate ops round (bit-identical to them); NaN passes through the ReLU.
+struct EpiF32 {
+  typedef float T;
+  static constexpr int V = 4;
+  static __device__ __forceinline__ float load(const T* p) { return *p; }
+  static __device__ __forceinline__ void store(T* p, float v) { *p = v; }
+  static __device__ __forceinline__ float round(float v) { return v; }
+};
+struct EpiBF16 {
+  typedef unsigned short T;
+  static constexpr int V = 8;
+  static __device__ __forceinline__ float load(const T* p) { return __uint_as_float((unsigned)*p << 16); }
+  static __device__ __forceinline__ unsigned short bits(float v) {
+    unsigned u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);     // NaN stays NaN
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);                     // round to nearest even
+  }
+  static __device__ __forceinline__ void store(T* p, float v) { *p = bits(v); }
+  static __device__ __forceinline__ float round(float v) { return __uint_as_float((unsigned)bits(v) << 16); }
+};
+struct EpiF16 {
+  typedef _Float16 T;
+  static constexpr int V = 8;
+  static __device__ __forceinline__ float load(const T* p) { return (float)*p; }
+  static __device__ __forceinline__ void store(T* p, float v) { *p = (_Float16)v; }
+  static __device__ __forceinline__ float round(float v) { return (float)(_Float16)v; }
+};
+
+template <typename E>
+__global__ __launch_bounds__(256) void bias_act_nchw_kernel(typename E::T* __restrict__ y, const typename E::T* __restrict__ bias,
+                                                            const typename E::T* __restrict__ res, int C, int64_t HW, int relu, int vec) {
+  typedef typename E::T T;
+  constexpr int V = E::V;                 // elements per 16 bytes
+  typedef T VecT __attribute__((ext_vector_type(V)));
+  const int64_t plane = blockIdx.y;
+  const float b = E::load(bias + plane % C);
+  T* yp = y + plane * HW;
+  const T* rp = res ? res + plane * HW : nullptr;
+  auto one = [&](T* dst, const T* r) {
+    float v = E::round(E::load(dst) + b);
+    if (r) v = E::round(v + E::load(r));
+    if (relu) v = v < 0.f ? 0.f : v;
+    E::store(dst, v);
+  };
+  if (vec) {
+    const int64_t nv = HW / V;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+      VecT v = reinterpret_cast<const VecT*>(yp)[i];
+      VecT r;
+      if (rp) r = reinterpret_cast<const VecT*>(rp)[i];
+      T* e = reinterpret_cast<T*>(&v);
+      const T* re = reinterpret_cast<const T*>(&r);
+#pragma unroll
+      for (int q = 0; q < V; ++q) one(e + q, rp ? re + q : nullptr);
+      reinterpret_cast<VecT*>(yp)[i] = v;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.x * 256) one(yp + i, rp ? rp + i : nullptr);
+  }
+}
+
+template <typename E>
+static int bias_act_nchw(void* y, const void* bias, const void* residual, int64_t N, int C, int64_t HW, int relu, odx_stream_t stream,
+                         const char* who) {
+  if (N <= 0 || C <= 0 || HW <= 0) return ODX_OK;
+  ODX_REQUIRE(y && bias, "%s: null pointer", who);
+  ODX_REQUIRE(N * C < 65536, "%s: too many planes (N C must stay below 65536)", who);
+  const int vec = (HW * (int64_t)sizeof(typename E::T)) % 16 == 0 && aligned16(y) && (!residual || aligned16(residual));
+  const int64_t per = vec ? HW / E::V : HW;
+  int64_t gx = ceil_div(per, 256);
+  if (gx > 64) gx = 64;
+  typedef typename E::T T;
+  hipLaunchKernelGGL((bias_act_nchw_kernel<E>), dim3((unsigned)gx, (unsigned)(N * C)), dim3(256), 0, as_stream(stream), static_cast<T*>(y),
+                     static_cast<const T*>(bias), static_cast<const T*>(residual), C, HW, relu, vec);
+  ODX_CHECK_LAUNCH(who);
+  return ODX_OK;
+}
+
+extern "C" int odx_bias_act_nchw_f32(float* y, const float* bias, const float* residual, int64_t N, int C, int64_t HW, int relu,
+                                     odx_stream_t stream) {
+  return bias_act_nchw<EpiF32>(y, bias, residual, N, C, HW, relu, stream, "odx_bias_act_nchw_f32");
+}
+
+extern "C" int odx_bias_act_nchw_16(void* y, const void* bias, const void* residual, int is_bf16, int64_t N, int C, int64_t HW, int relu,
+                                    odx_stream_t stream) {
+  return is_bf16 ? bias_act_nchw<EpiBF16>(y, bias, residual, N, C, HW, relu, stream, "odx_bias_act_nchw_16")
+                 : bias_act_nchw<EpiF16>(y, bias, residual, N, C, HW, relu, stream, "odx_bias_act_nchw_16");
+}

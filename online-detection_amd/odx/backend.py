@@ -765,6 +765,28 @@ class HipBackend:
                                                   int(sampling_ratio), int(step), _p(out), self._stream()), "odx_roi_align_rows_f32")
         return out, (R, OH, OW)
 
+    BIAS_ACT_DTYPES = (torch.float32, torch.bfloat16, torch.float16)
+
+    def bias_act_(self, y, bias, residual=None, relu=True):
+        """y = act(y + bias[c] (+ residual)) in place over a contiguous NCHW map, f32 / bf16 / f16 (odx_bias_act_nchw_f32 /
+        _16): the epilogue of a trunk convolution as one pass.  Returns y."""
+        dt = y.dtype
+        if dt not in self.BIAS_ACT_DTYPES or not y.is_contiguous() or y.dim() != 4 or bias.dtype != dt or not bias.is_contiguous():
+            raise ValueError("bias_act_: contiguous f32 / bf16 / f16 NCHW map and a bias of its dtype expected")
+        if residual is not None and (residual.shape != y.shape or residual.dtype != dt or not residual.is_contiguous()):
+            raise ValueError("bias_act_: the residual must be a contiguous tensor of the map's shape and dtype")
+        N, C, H, W = y.shape
+        if bias.numel() != C:
+            raise ValueError("bias_act_: %d bias values for %d channels" % (bias.numel(), C))
+        rp = _p(residual) if residual is not None else None
+        if dt == torch.float32:
+            hip.check(self.lib.odx_bias_act_nchw_f32(_p(y), _p(bias), rp, N, C, H * W, 1 if relu else 0, self._stream()),
+                      "odx_bias_act_nchw_f32")
+        else:
+            hip.check(self.lib.odx_bias_act_nchw_16(_p(y), _p(bias), rp, 1 if dt == torch.bfloat16 else 0, N, C, H * W,
+                                                    1 if relu else 0, self._stream()), "odx_bias_act_nchw_16")
+        return y
+
     def paste_masks(self, masks, boxes, im_h, im_w, thresh=0.5, padding=1):
         """Masker: masks (R, S, S) f32, boxes (R, 4) -> (R, im_h, im_w) bool."""
         masks = masks.to(device=self.device, dtype=torch.float32).contiguous()

@@ -46,7 +46,7 @@ class ResNet50Stages(_FoldedBN):
         self.channels = (4 * w, 8 * w, 16 * w, 32 * w)
 
     def forward(self, x):
-        x = F.max_pool2d(F.relu(self.conv_bn("conv1", "bn1", x)), 3, 2, 1)
+        x = F.max_pool2d(self.conv_bn_act("conv1", "bn1", x), 3, 2, 1)
         c2 = self.layer1(x)
         c3 = self.layer2(c2)
         c4 = self.layer3(c3)

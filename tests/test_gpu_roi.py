@@ -85,3 +85,27 @@ def test_roi_align_rows_is_the_strided_subset_of_the_grid():
         ref = full[:, :, ::step, ::step]
         assert (r, OH, OW) == (R, ref.shape[2], ref.shape[3])
         assert torch.equal(rows.view(R, OH, OW, -1).permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("N,C,H,W", [(1, 64, 150, 200), (2, 7, 19, 25), (1, 3, 1, 1), (1, 256, 38, 50)])
+@pytest.mark.parametrize("with_res", [False, True])
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
+def test_trunk_epilogue_equals_the_three_torch_ops_bit_for_bit(be, N, C, H, W, with_res, relu, dtype):
+    """odx_bias_act_nchw_f32 / _16 = (y + bias) (+ residual), ReLU: one addition per term in the reference's order, rounded
+    to the map's type each time, so the result is the separate torch ops' bit for bit — planes whose size is and is not a
+    multiple of the 16-byte vector (vector / scalar path), NaN passed through as torch.relu does."""
+    g = torch.Generator(device="cuda").manual_seed(N * 1000 + C + H)
+    dt = getattr(torch, dtype)
+    y = torch.randn((N, C, H, W), generator=g, device="cuda").to(dt)
+    bias = torch.randn(C, generator=g, device="cuda").to(dt)
+    res = torch.randn((N, C, H, W), generator=g, device="cuda").to(dt) if with_res else None
+    y.view(-1)[0] = float("nan")
+    ref = y + bias.view(1, -1, 1, 1)
+    if with_res:
+        ref = ref + res
+    if relu:
+        ref = torch.relu(ref)
+    got = be.bias_act_(y.clone(), bias, res, relu=relu)
+    assert torch.equal(torch.nan_to_num(got, nan=123.0), torch.nan_to_num(ref, nan=123.0))
+    assert bool(torch.isnan(got.view(-1)[0])) == bool(torch.isnan(ref.view(-1)[0]))
