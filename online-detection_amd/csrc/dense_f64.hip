@@ -571,7 +571,21 @@ struct SideStream {
 // the chip takes its look-ahead and fork streams along); empty = the whole device.  Streams that exist keep their mask.
 static std::vector<uint32_t> g_side_mask;
 
-static int side_stream(SideStream** out, int slot, hipStream_t caller) {
+// Helper streams pay where the chain is GEMM-bound (the headline's M = 1e4: the look-ahead update beside the next panel, the
+// inverse of L_T beside T T').  Below CHAIN_HELPER_MIN_M centres a chain is latency-bound and is run several at a time by its
+// callers (fit_batch's half chains, the classes of a Minibootstrap round): every extra stream then competes for the runtime's
+// few hardware queues (4 by default) with the streams of the other chains — measured on a Minibootstrap round: 0.48 s with
+// the small chains in order on their caller's stream, 0.52-0.57 s with helpers, depending on which streams collided.
+// ODX_CHAIN_HELPERS=1 / 0 in the environment forces them on / off (read at every call).
+constexpr int64_t CHAIN_HELPER_MIN_M = 4096;
+
+static bool chain_helpers(int64_t M) {
+  const char* e = getenv("ODX_CHAIN_HELPERS");
+  if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+  return M >= CHAIN_HELPER_MIN_M;
+}
+
+static int side_stream(SideStream** out, int slot, hipStream_t caller, int64_t M) {
   struct Entry {
     int device;
     hipStream_t caller;
@@ -581,6 +595,19 @@ static int side_stream(SideStream** out, int slot, hipStream_t caller) {
   int dev = 0;
   ODX_CHECK_HIP(hipGetDevice(&dev));
   ODX_REQUIRE(slot >= 0 && slot < 2, "side_stream: bad slot");
+  if (!chain_helpers(M)) {
+    // no helper: the "side" work goes on the caller's stream, in order (the fork / join events become no-ops there)
+    static thread_local SideStream inl[2];
+    SideStream& s = inl[slot];
+    if (s.fork == nullptr || s.device != dev) {
+      ODX_CHECK_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
+      ODX_CHECK_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+      s.device = dev;
+    }
+    s.stream = caller;
+    *out = &s;
+    return ODX_OK;
+  }
   Entry* e = nullptr;
   for (Entry* c : pool)
     if (c->device == dev && c->caller == caller) e = c;
@@ -661,7 +688,7 @@ int potrf_f64(double* A, int64_t lda, int64_t M, double* Dinv, int32_t* info, hi
   ODX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(trsm128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     TS_LDS_BYTES));
   SideStream* look = nullptr;
-  ODX_PROPAGATE(side_stream(&look, 1, stream));
+  ODX_PROPAGATE(side_stream(&look, 1, stream, M));
   bool pending = false;      // a trailing update is in flight on the helper stream
   for (int64_t K0 = 0; K0 < M; K0 += POTRF_NBO) {
     const int64_t kbo = M - K0 < POTRF_NBO ? M - K0 : POTRF_NBO;
@@ -966,7 +993,7 @@ extern "C" int odx_falkon_precond_f64(const float* Z, int64_t ldz, int64_t M, in
   }
   hipStream_t s = as_stream(stream);
   SideStream* side = nullptr;
-  ODX_PROPAGATE(side_stream(&side, 0, s));
+  ODX_PROPAGATE(side_stream(&side, 0, s, M));
   hipStream_t s2 = side->stream;
   const int64_t wld = precond_ld(M), ldzd = precond_ldz(D);
   const int64_t dsz = ceil_div(M, POTRF_NB) * POTRF_NB * POTRF_NB;
@@ -1068,7 +1095,7 @@ extern "C" int odx_falkon_precond_batched_f64(const float* const* Z, const int64
   }
   hipStream_t s = as_stream(stream);
   SideStream* side = nullptr;
-  ODX_PROPAGATE(side_stream(&side, 0, s));
+  ODX_PROPAGATE(side_stream(&side, 0, s, Mmax));
   hipStream_t s2 = side->stream;
   const int64_t wld = precond_ld(Mmax), ldzd = precond_ldz(D);
   const int64_t dsz = ceil_div(Mmax, POTRF_NB) * POTRF_NB * POTRF_NB;

@@ -292,8 +292,13 @@ _chain_streams = {}
 
 
 def _chain_stream(k=0):
-    """Side stream k of the calling stream: the half chains of fit_batch run on two of them (callers on different streams —
-    the two lanes of a pipelined Minibootstrap — get different ones)."""
+    """Side stream k (0, 1) of the calling stream for the half chains of fit_batch: the first two of the streams measured to
+    sit on hardware queues of their own (odx/streams.py; the callers' class streams are taken from the ones behind them), a
+    plain stream when the device has none to spare."""
+    from . import streams as _streams
+    own = _streams.distinct(2)
+    if len(own) > k:
+        return own[k]
     dev = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, k)
     if dev not in _chain_streams:
         _chain_streams[dev] = torch.cuda.Stream()

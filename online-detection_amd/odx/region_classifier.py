@@ -47,9 +47,15 @@ _STREAMS = {}
 
 
 def _work_streams(k, tag="class"):
-    """k side streams of the current device, created once (a call used to create its own: the stream pool hands out 32
-    streams in turn and the caching allocator keeps a pool of blocks per stream)."""
-    key = (torch.cuda.current_device(), tag)
+    """k side streams for the classes of a round, chosen once per (device, calling stream) among streams that share a
+    hardware queue neither with the calling stream nor with each other (odx/streams.py) — the first two of those are left to
+    fit_batch's half chains; with the runtime's 4 queues that leaves ONE for the classes' builds and predictions (their
+    kernels are wide enough to fill the chip one after the other), more with GPU_MAX_HW_QUEUES raised."""
+    from . import streams as _streams
+    own = _streams.distinct(2 + k)
+    if len(own) > 2:
+        return _streams.spread(own[2:], k)
+    key = (torch.cuda.current_device(), tag)          # (no queue to spare: plain streams, as before)
     have = _STREAMS.setdefault(key, [])
     while len(have) < k:
         have.append(torch.cuda.Stream())

@@ -31,6 +31,16 @@ def _sync_time(fn):
     return time.perf_counter() - t0, out
 
 
+def _best_time(fn, batches=3):
+    """Shortest of `batches` timed calls: the steady state (one slow batch — an allocator refill after the cache was emptied
+    between extras, a clock ramp — is not what these keys report)."""
+    best, out = None, None
+    for _ in range(batches):
+        dt, out = _sync_time(fn)
+        best = dt if best is None else min(best, dt)
+    return best, out
+
+
 def rls_extra(n=300_000, D=1024, C=30, lam=1000.0, cpu=True):
     from odx.rls import RegionRefinerTrainer
     g = torch.Generator(device="cuda").manual_seed(1234 + 3)
@@ -77,7 +87,7 @@ def forward_extra(height=600, width=800, rois=300, reps=8):
         with torch.no_grad(), ctx:
             for _ in range(3):
                 model(img)
-            dt, _ = _sync_time(lambda: [model(img) for _ in range(reps)])
+            dt, _ = _best_time(lambda: [model(img) for _ in range(reps)])
         out["images_per_s_" + name] = round(reps / dt, 1)
         out["ms_per_image_" + name] = round(dt / reps * 1e3, 2)
     return out
@@ -98,7 +108,7 @@ def forward_fpn_extra(height=600, width=800, reps=8):
         with torch.no_grad():
             for _ in range(3):
                 boxes, feats, _ = model(img)
-            dt_s, _ = _sync_time(lambda: [model(img) for _ in range(reps)])
+            dt_s, _ = _best_time(lambda: [model(img) for _ in range(reps)])
         out["images_per_s_" + name] = round(reps / dt_s, 1)
         out["ms_per_image_" + name] = round(dt_s / reps * 1e3, 2)
         out["rois"], out["feature_dim"] = int(boxes.shape[0]), int(feats.shape[1])
@@ -135,10 +145,10 @@ def detect_extra(height=600, width=800, rois=300, C=30, M=1000, reps=10):
     with torch.no_grad():
         for _ in range(3):
             res, boxes = detect(model, img, (width, height), -2.0, 0.3, 100)
-        dt, _ = _sync_time(lambda: [detect(model, img, (width, height), -2.0, 0.3, 100) for _ in range(reps)])
+        dt, _ = _best_time(lambda: [detect(model, img, (width, height), -2.0, 0.3, 100) for _ in range(reps)])
         maps = model.roi_head_maps(model.c4(img), boxes)
         scores, deltas = model.online_box(maps.mean(dim=(2, 3)))
-        dtp, _ = _sync_time(lambda: [postprocess_detections(scores, deltas, boxes, (width, height), -2.0, 0.3, 100) for _ in range(reps)])
+        dtp, _ = _best_time(lambda: [postprocess_detections(scores, deltas, boxes, (width, height), -2.0, 0.3, 100) for _ in range(reps)])
     return {"workload": "detect(): %dx%d image, %d proposals, %d FALKON classifiers (M=%d, D=%d) + %d box regressors, decode + "
                         "per-class NMS + top-100, f32" % (height, width, boxes.shape[0], C, M, D, C),
             "ms_per_image": round(dt / reps * 1e3, 2), "images_per_s": round(reps / dt, 1),
