@@ -27,7 +27,7 @@ from .dist import RowShard
 class _Side:
     """A side stream with an event, or (CPU tensors) nothing: work is then simply done in program order."""
 
-    def __init__(self, device, be=None, cus=0):
+    def __init__(self, device, be=None, cus=0, index=0):
         self.cuda = torch.device(device).type == "cuda"
         self.stream = None
         if self.cuda and cus > 0 and be is not None and hasattr(be, "masked_stream"):
@@ -35,7 +35,11 @@ class _Side:
             # those instead of holding one slot on many CUs, each of which takes no Gaussian workgroup meanwhile
             self.stream = be.masked_stream(cus)
         elif self.cuda:
-            self.stream = torch.cuda.Stream(device=device)
+            # a stream measured to sit on a hardware queue of its own (odx/streams.py): the chain must not queue behind the
+            # builds and passes of the main stream
+            from . import streams as _streams
+            own = _streams.distinct(index + 1, device)
+            self.stream = own[index] if len(own) > index else torch.cuda.Stream(device=device)
 
     def after_current(self):
         if self.cuda:
@@ -105,7 +109,7 @@ class LockstepClassJob:
         self.after_fit = bool(precond_after_fit)
         self.ld_p = (self.M + 1) // 2 * 2
         self.nslot = self.depth + 1
-        self.sides = [_Side(dev, be, precond_cus) for _ in range(self.nslot)] if self.G == 1 else []
+        self.sides = [_Side(dev, be, precond_cus, index=k) for k in range(self.nslot)] if self.G == 1 else []
         self.gside = _Side(dev, be, precond_cus) if self.G > 1 else None
         self.pbuf, self.pgroup = [], []
         self.trace = []          # (kind, payload) records of the schedule this rank executed (tests read it)
