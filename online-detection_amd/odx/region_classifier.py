@@ -46,15 +46,15 @@ def _randint_advances_one_draw_per_value(g, shape):
 _STREAMS = {}
 
 
-def _work_streams(k, tag="class"):
+def _work_streams(k, tag="class", reserve=2):
     """k side streams for the classes of a round, chosen once per (device, calling stream) among streams that share a
-    hardware queue neither with the calling stream nor with each other (odx/streams.py) — the first two of those are left to
-    fit_batch's half chains; with the runtime's 4 queues that leaves ONE for the classes' builds and predictions (their
+    hardware queue neither with the calling stream nor with each other (odx/streams.py) — the first `reserve` of those are
+    left to fit_batch's half chains (none in the streams mode, whose fits run whole on their class's stream); with the runtime's 4 queues that leaves ONE for the classes' builds and predictions (their
     kernels are wide enough to fill the chip one after the other), more with GPU_MAX_HW_QUEUES raised."""
     from . import streams as _streams
-    own = _streams.distinct(2 + k)
-    if len(own) > 2:
-        return _streams.spread(own[2:], k)
+    own = _streams.distinct(reserve + k)
+    if len(own) > reserve:
+        return _streams.spread(own[reserve:], k)
     key = (torch.cuda.current_device(), tag)          # (no queue to spare: plain streams, as before)
     have = _STREAMS.setdefault(key, [])
     while len(have) < k:
@@ -295,7 +295,7 @@ class OnlineRegionClassifierBase:
         C = self.num_classes - 1
         k = max(1, int(self.class_streams))
         main = torch.cuda.current_stream()
-        streams = _work_streams(k)
+        streams = _work_streams(k, reserve=0)
         for s in streams:
             s.wait_stream(main)
         seed0 = self._class_seed()
