@@ -177,19 +177,29 @@ def fit_batch(estimators, Xs, Ys, streams=None):
         for est, X, Y in zip(estimators, Xs, Ys):
             est.fit(X, Y)
         return estimators
+    # First only what the factorisation chains need — the centres — so that the GPU starts on K_MM while the host is still
+    # preparing the rest: the row norms of the training sets and the uploads of the labels (a launch / a copy per class, ~2 ms
+    # of host time for the 30 classes of a round) are issued behind the chains (`finish` below), for the K_nM builds.
     Fs, Zfs, yvs = [], [], []
     for est, X, Y in zip(estimators, Xs, Ys):
-        F = be.features(X)
         if isinstance(est.center_selection, str):
+            F = be.features(X)                           # (the uniform selection gathers norms and packed rows along)
             Zf = be.rows(F, torch.randperm(F.n)[: est.M])
         else:
+            F = be.features(X, norms=False) if hasattr(be, "row_matrix") else be.features(X)
             sel = est.center_selection.select(F.X, None)
             Zf = be.features(sel[0] if isinstance(sel, tuple) else sel)
         est.M = Zf.n
         y = torch.as_tensor(Y).reshape(F.n, -1)
         if y.shape[1] != 1:
             raise ValueError("odx FALKON fits one right-hand side per model; got Y with %d columns" % y.shape[1])
-        Fs.append(F), Zfs.append(Zf), yvs.append(be.vec(y[:, 0]))
+        Fs.append(F), Zfs.append(Zf), yvs.append(y)
+
+    def finish(i):
+        if getattr(Fs[i], "sq", 0) is None:
+            Fs[i] = be.features(Fs[i].X)
+        if yvs[i].dim() == 2:
+            yvs[i] = be.vec(yvs[i][:, 0])
     # classes that share (sigma, penalty, jitter) share a chain; the reference's classes always do
     groups = {}
     for i, est in enumerate(estimators):
@@ -233,15 +243,19 @@ def fit_batch(estimators, Xs, Ys, streams=None):
                     Ps = be.precond_batched([Zfs[i] for i in chunk[:h]], sigma, lam, eps, out=block[:h], ws_key="precond_batched_fit", Mmax=Mmax_c)
                 for P in Ps:
                     P.info.record_stream(cur)
-                cur.wait_stream(side_a)
                 with torch.cuda.stream(side):
                     Pb = be.precond_batched([Zfs[i] for i in chunk[h:]], sigma, lam, eps, out=block[h:], ws_key="precond_batched_fit_b", Mmax=Mmax_c)
                 for P in Pb:
                     P.info.record_stream(cur)
                 Ps = Ps + Pb
             else:
-                side = None
+                side = side_a = None
                 Ps = be.precond_batched([Zfs[i] for i in chunk], sigma, lam, eps, ws_key="precond_batched_fit")
+            for i in chunk:
+                finish(i)
+            if same and streams:
+                for s in streams:               # the builds read the norms and labels just queued on the caller's stream
+                    s.wait_stream(cur)
             alphas = None
             if same:
                 # K_nM builds (f16 split of the rows, one Gaussian launch, the right-hand side: ~10 short kernels per
@@ -259,9 +273,11 @@ def fit_batch(estimators, Xs, Ys, streams=None):
                 # (ONE lock-step CG over both halves: a CG per half, the first started beside the tail of the second chain,
                 # measured slower — twice the launches, each half the width the triangular products stream best at)
                 if side is not None:
+                    cur.wait_stream(side_a)
                     cur.wait_stream(side)
                 alphas = be.cg_solve_batched(Ks, Ps, b0s, [Fs[i].n for i in chunk], lam, iters.pop(), opts[0])
             if side is not None:
+                cur.wait_stream(side_a)
                 cur.wait_stream(side)
             for row, (i, P) in enumerate(zip(chunk, Ps)):
                 est = estimators[i]
