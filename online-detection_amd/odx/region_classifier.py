@@ -539,12 +539,16 @@ class OnlineRegionClassifierBase:
         mask = torch.empty(flat.shape, dtype=torch.bool, device=flat.device)
         torch.ge(flat[:split], self.easy_tresh, out=mask[:split])
         torch.gt(flat[split:], self.hard_tresh, out=mask[split:])
-        nz = mask.nonzero().reshape(-1)
-        cuts = np.searchsorted(nz.cpu().numpy(), ends, side='left')
-        out, a, off = [], 0, 0
-        for b, e in zip(cuts, ends):
-            out.append(nz[a:b] - off)
-            a, off = int(b), int(e)
+        nz_host = mask.nonzero().reshape(-1).cpu().numpy()
+        cuts = np.searchsorted(nz_host, ends, side='left')
+        # positions inside each vector, made on the host from the one array that was read back and uploaded once (a
+        # subtraction per vector on the GPU was 60 launches per round)
+        counts = np.diff(np.concatenate(([0], cuts)))
+        local = torch.from_numpy(nz_host - np.repeat(ends - np.asarray(lens), counts)).to(flat.device)
+        out, a = [], 0
+        for b in cuts:
+            out.append(local[a:int(b)])
+            a = int(b)
         return out[:len(easy_scores)], out[len(easy_scores):]
 
     def trainRegionClassifier(self, opts=None, output_dir=None):
