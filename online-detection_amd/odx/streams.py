@@ -8,7 +8,7 @@ share one depends on the order in which all streams of the process were first us
 
 `distinct(n)` picks side streams by MEASURING: a candidate is kept if a marker recorded on it completes while a busy kernel is
 still running on the current stream and on every stream kept so far.  At most (hardware queues - 1) streams can qualify; the
-callers spread their work over what they get.  The result is cached per (device, current stream): ~20 ms once.
+callers spread their work over what they get.  The result is cached per (device, current stream): ~50 ms once.
 """
 import time
 
@@ -16,8 +16,8 @@ import torch
 
 _CACHE = {}
 CANDIDATES = 12
-BUSY_CYCLES = 1_500_000      # ~0.7 ms of torch.cuda._sleep
-WAIT_S = 2.5e-4
+BUSY_CYCLES = 4_000_000      # ~2 ms of torch.cuda._sleep: the marker is looked at after 0.3 ms, a host hiccup of 1.5 ms changes nothing
+WAIT_S = 3e-4
 
 
 def _collide(a, b, scratch):
