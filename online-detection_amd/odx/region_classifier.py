@@ -49,8 +49,9 @@ _STREAMS = {}
 def _work_streams(k, tag="class", reserve=2):
     """k side streams for the classes of a round, chosen once per (device, calling stream) among streams that share a
     hardware queue neither with the calling stream nor with each other (odx/streams.py) — the first `reserve` of those are
-    left to fit_batch's half chains (none in the streams mode, whose fits run whole on their class's stream); with the runtime's 4 queues that leaves ONE for the classes' builds and predictions (their
-    kernels are wide enough to fill the chip one after the other), more with GPU_MAX_HW_QUEUES raised."""
+    left to fit_batch's half chains (none in the streams mode, whose fits run whole on their class's stream).  With the
+    runtime's 4 queues that leaves ONE for the classes' builds and predictions in the batched mode (their kernels are wide
+    enough to fill the chip one after the other), more with GPU_MAX_HW_QUEUES raised."""
     from . import streams as _streams
     own = _streams.distinct(reserve + k)
     if len(own) > reserve:
