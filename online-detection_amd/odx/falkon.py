@@ -303,6 +303,138 @@ def fit_batch(estimators, Xs, Ys, streams=None):
     return estimators
 
 
+class BatchFit:
+    """fit_batch in two phases, for callers that can hand over the classes of a round in groups: ``add`` prepares a group's
+    centres and queues its factorisation chain at once (on a side stream of its own), ``finish`` queues everything that
+    needs all groups — row norms, K_nM builds, ONE lock-step CG over all classes — and leaves every estimator as its own
+    ``fit`` would (same bits).  Between two ``add`` calls the caller is free to synchronise with the host and prepare the
+    next group while the first group's chain already runs (the Minibootstrap reads a group's selections, gathers its rows
+    and draws its centres: ~2.5 ms of host work per half round that used to pass with the GPU idle).
+    The fast path needs what a Minibootstrap round has: a GPU backend with the batched chain and CG, side streams, at most
+    32 classes with one (sigma, penalty, jitter, iterations, options) and pre-chosen centres; anything else is collected and
+    goes through fit_batch in ``finish``."""
+
+    def __init__(self, streams=None):
+        self.be = _backend.get_backend()
+        self.streams = list(streams) if streams else None
+        self.est, self.Xs, self.Ys = [], [], []
+        self.Fs, self.Zfs, self.ys = [], [], []
+        self.segments = []            # (first class, count, Preconds of the group, its chain's stream)
+        self.block = None
+        self.key = None
+        self.fast = bool(self.streams) and hasattr(self.be, "precond_batched") and hasattr(self.be, "cg_solve_batched") \
+            and hasattr(self.be, "row_matrix") and torch.cuda.is_available()
+        self.cur = torch.cuda.current_stream() if self.fast else None
+
+    def _key(self, est):
+        o = est.options.solver_options()
+        return (float(est.kernel.sigma), float(est.penalty), o.pc_epsilon, int(est.maxiter),
+                (o.cg_epsilon, o.cg_tolerance, o.cg_full_gradient_every, o.check_pivots))
+
+    def add(self, estimators, Xs, Ys, expect_total=None):
+        be = self.be
+        first = len(self.est)
+        self.est += list(estimators)
+        self.Xs += list(Xs)
+        self.Ys += list(Ys)
+        if not self.fast or not estimators:
+            return
+        if any(isinstance(e.center_selection, str) or e.center_selection is None for e in estimators):
+            self.fast = False
+            return
+        keys = {self._key(e) for e in estimators}
+        if len(keys) != 1 or (self.key is not None and keys != {self.key}):
+            self.fast = False
+            return
+        self.key = next(iter(keys))
+        self.opt = estimators[0].options.solver_options()
+        total = max(int(expect_total or 0), len(self.est))
+        if total > be.MAX_CLASS_BATCH:
+            self.fast = False
+            return
+        Fs, Zfs, ys = [], [], []
+        for est, X, Y in zip(estimators, Xs, Ys):
+            F = be.features(X, norms=False)
+            sel = est.center_selection.select(F.X, None)
+            Zf = be.features(sel[0] if isinstance(sel, tuple) else sel)
+            est.M = Zf.n
+            y = torch.as_tensor(Y).reshape(F.n, -1)
+            if y.shape[1] != 1:
+                raise ValueError("odx FALKON fits one right-hand side per model; got Y with %d columns" % y.shape[1])
+            Fs.append(F), Zfs.append(Zf), ys.append(y)
+        Mmax = max(z.n for z in Zfs)
+        sigma, lam, eps = self.key[0], self.key[1], self.key[2]
+        if self.block is None:
+            self.block = torch.empty((total, 4, Mmax, (Mmax + 1) // 2 * 2), dtype=torch.float64, device=be.device)
+        if Mmax > self.block.shape[2] or first + len(estimators) > self.block.shape[0]:
+            self.fast = False          # (a later group with more centres than the block was cut for: everything through fit_batch)
+            return
+        g = len(self.segments)
+        side = _chain_stream(g % 2)
+        side.wait_stream(self.cur)
+        with torch.cuda.stream(side):
+            Ps = be.precond_batched(Zfs, sigma, lam, eps, out=self.block[first:first + len(estimators)],
+                                    ws_key="precond_batched_fit" + ("_b" if g % 2 else ""), Mmax=int(self.block.shape[2]))
+        for P in Ps:
+            P.info.record_stream(self.cur)
+        self.Fs += Fs
+        self.Zfs += Zfs
+        self.ys += ys
+        self.segments.append((first, len(estimators), Ps, side))
+
+    def finish(self):
+        be, cur, streams = self.be, self.cur, self.streams
+        done = sum(c for _, c, _, _ in self.segments)
+        if not self.fast or done != len(self.est):
+            if self.segments:                 # chains already queued for some groups: let them drain, then the general path
+                for _, _, _, side in self.segments:
+                    cur.wait_stream(side)
+            return fit_batch(self.est, self.Xs, self.Ys, streams=self.streams)
+        from . import solver as _solver
+        sigma, lam, eps, maxiter, opt = self.key[0], self.key[1], self.key[2], self.key[3], self.opt
+        n_cls = len(self.est)
+        Fs, Zfs = self.Fs, self.Zfs
+        fmts = {be.knm_format(Fs[i].n, Zfs[i].n) for i in range(n_cls)}
+        if len(fmts) != 1 or (hasattr(be, "cg_batched_supported")
+                              and not be.cg_batched_supported([f.n for f in Fs], [z.n for z in Zfs], next(iter(fmts)))):
+            for _, _, _, side in self.segments:
+                cur.wait_stream(side)
+            return fit_batch(self.est, self.Xs, self.Ys, streams=self.streams)
+        for i in range(n_cls):                # behind the chains: row norms of the training sets, label uploads
+            Fs[i] = be.features(Fs[i].X)
+        yvs = [be.vec(y[:, 0]) for y in self.ys]
+        Mmax = int(self.block.shape[2])
+        b0s = torch.zeros((n_cls, (Mmax + 1) // 2 * 2), dtype=torch.float64, device=be.device)
+        for s in streams:
+            s.wait_stream(cur)
+        Ks = []
+        for i in range(n_cls):
+            with torch.cuda.stream(streams[i % len(streams)]):
+                K, _ = be.knm_rhs(Fs[i], Zfs[i], sigma, yvs[i] * (1.0 / Fs[i].n), rhs_out=b0s[i, :Zfs[i].n])
+                K.K.record_stream(cur)
+            Ks.append(K)
+        for s in streams:
+            cur.wait_stream(s)
+        Ps = []
+        for _, _, P, side in self.segments:
+            cur.wait_stream(side)
+            Ps += P
+        alphas = be.cg_solve_batched(Ks, Ps, b0s, [f.n for f in Fs], lam, maxiter, opt)
+        if alphas is None:
+            return fit_batch(self.est, self.Xs, self.Ys, streams=self.streams)
+        for i, (est, P) in enumerate(zip(self.est, Ps)):
+            alpha = alphas[i, :Zfs[i].n].clone()
+            if opt.check_pivots:
+                _solver._check_pivots(be, P)
+            ny = Zfs[i].X.contiguous() if Zfs[i].X.stride(0) != Zfs[i].D else Zfs[i].X
+            est.alpha_, est.ny_points_ = alpha.reshape(-1, 1), ny
+            if est._cpu_model:
+                est.alpha_, est.ny_points_ = est.alpha_.cpu(), est.ny_points_.cpu()
+            else:
+                est._centres(Zfs[i])
+        return self.est
+
+
 _CHAIN_SPLIT_MIN = int(os.environ.get('ODX_CHAIN_SPLIT_MIN', '4'))
 _chain_streams = {}
 

@@ -415,6 +415,8 @@ class OnlineRegionClassifierBase:
                 torch.randint(2, (count,), generator=g)
         return states, rooms, g.get_state()
 
+    GROUP_MIN_CLASSES = 4          # classes per group from which a round is handed to the classifier in two groups
+
     def trainWithMinibootstrapBatched(self, negatives, positives, output_dir=None, reference_rng=None):
         """The per-class state machine with the classes advancing together one negative batch at a time (as in
         trainWithMinibootstrapStreams) and ALL fits of a round made by one `classifier.train_batch` call: their
@@ -445,65 +447,28 @@ class OnlineRegionClassifierBase:
         t_start = time.time()
         nb = max([len(negatives[i]) for i in active] or [0])
 
-        def on_streams(items, fn):
-            """fn(i) for every class on its stream; the streams start after what the caller's stream has queued and
-            the caller's stream continues after them."""
-            for s in streams:
-                s.wait_stream(main)
-            out = {}
-            for i in items:
-                with torch.cuda.stream(streams[i % k]):
-                    out[i] = fn(i)
-            for s in streams:
-                main.wait_stream(s)
-            return out
-
         next_hard = {}          # class -> hard-negative rows of its NEXT batch under its current model (scored with the pruning predicts)
-        for j in range(nb):
-            todo = [i for i in active if j < len(negatives[i])]
-            if j == 0:
-                for i in todo:
-                    caches[i] = {'pos': positives[i], 'neg': negatives[i][0]}
-            else:
-                for i in todo:
-                    hard_idx = next_hard.pop(i)
-                    caches[i]['neg'] = torch.cat((caches[i]['neg'], negatives[i][j][hard_idx]), 0)
-                    print('Class {}: chosen {} hard negatives from the {}th batch'.format(i, len(hard_idx), j))
-            if rooms is not None and any(len(caches[i]['neg']) <= rooms[i] for i in todo):
-                return None      # a fit that draws fewer values than predicted: the later classes' positions in the stream are off
-            Xs, ys = [], []
-            for i in todo:
-                X_pos, X_neg = caches[i]['pos'], caches[i]['neg']
-                print('Class {}: traning with {} positives and {} negatives'.format(i, len(X_pos), len(X_neg)))
-                Xs.append(torch.cat((X_pos, X_neg), 0))
-                # labels on the host: the Nystroem index rule reads them (two nonzero() per class — host synchronisations
-                # when the labels live on the GPU); the fit uploads its own f64 copy
-                ys.append(torch.cat((torch.ones(len(X_pos)), -torch.ones(len(X_neg))), 0))
+        # The classes advance in TWO groups through a round when the classifier can take them group by group
+        # (FALKONWrapper.train_batch_begin): the host's part of a round — read the selections (a synchronisation), gather every
+        # class's rows, draw its centres: ~5 ms for 30 classes — is done for the first group while the second group's
+        # predictions of the previous round still run, and for the second group while the first group's factorisation chain
+        # already does; as ONE group those 5 ms passed with the GPU idle, a tenth of a round.  The group of a class is fixed
+        # (it owns the events its selections wait for); per class nothing changes.
+        two = hasattr(self.classifier, 'train_batch_begin') and len(active) >= 2 * self.GROUP_MIN_CLASSES
+        cut = (len(active) + 1) // 2 if two else len(active)
+        parts = [active[:cut], active[cut:]] if two else [active]
+        pending = {}            # group -> (prune, ahead, scores, events) of its last queued predictions, selections not read yet
 
-            def with_class_rng(pos, fn):
-                i = todo[pos]
-                with torch.random.fork_rng(devices=[]):
-                    torch.set_rng_state(rng[i])
-                    out = fn()
-                    rng[i] = torch.get_rng_state()
-                return out
-
-            with solver.deferred_pivot_checks():       # every Cholesky status of the round is read once, after the round's fits are queued
-                fitted = self.classifier.train_batch(Xs, ys, sigma=self.sigma, lam=self.lam, index_rng=with_class_rng, streams=streams)
-            for i, m in zip(todo, fitted):
-                model[i] = m
-            prune = [i for i in todo if len(caches[i]['neg']) != 0 and j != len(negatives[i]) - 1]
-            ahead = [i for i in todo if j + 1 < len(negatives[i])]
-            # the two predicts a class's fresh model is used for — pruning its cache now, mining its next batch at the start
-            # of the next round — in ONE phase on the streams (the next batch is known; the reference scores it first thing
-            # in the next iteration with this same model, OnlineRegionClassifier_incore.py:112-116)
-            both = on_streams(sorted(set(prune) | set(ahead)),
-                              lambda i: (self.classifier.predict(model[i], caches[i]['neg']) if i in prune else None,
-                                         self.classifier.predict(model[i], negatives[i][j + 1]) if i in ahead else None))
-            # every selection of the phase — the rows a class keeps (score >= easy threshold) and the hard negatives of
-            # its next batch (score > hard threshold) — from ONE nonzero() over the concatenated scores, i.e. one host
-            # synchronisation per round instead of one per torch.where; each class's indices are its slice of the
-            # result, in the same (ascending) order torch.where gives
+        def settle(g):
+            """The host's part of group g's previous round: every selection of the phase — the rows a class keeps (score >= easy
+            threshold) and the hard negatives of its next batch (score > hard threshold) — from ONE nonzero() over the
+            concatenated scores, i.e. one host synchronisation per group and round instead of one per torch.where; each
+            class's indices are its slice of the result, in the same (ascending) order torch.where gives."""
+            if g not in pending:
+                return
+            prune, ahead, both, events = pending.pop(g)
+            for ev in events:
+                main.wait_event(ev)
             keep, hard = self._select_rows([both[i][0] for i in prune], [both[i][1] for i in ahead])
             for i, hard_idx in zip(ahead, hard):
                 next_hard[i] = hard_idx
@@ -511,6 +476,89 @@ class OnlineRegionClassifierBase:
                 removed = len(caches[i]['neg']) - len(keep_idx)
                 caches[i]['neg'] = caches[i]['neg'][keep_idx]
                 print('Class {}: removed {} easy negatives. {} Remaining'.format(i, removed, len(caches[i]['neg'])))
+
+        for j in range(nb):
+            todo = [i for i in active if j < len(negatives[i])]
+            order = []              # the round's classes in the order they are handed to the classifier
+
+            def with_class_rng(pos, fn):
+                i = order[pos]
+                with torch.random.fork_rng(devices=[]):
+                    torch.set_rng_state(rng[i])
+                    out = fn()
+                    rng[i] = torch.get_rng_state()
+                return out
+
+            def training_sets(members):
+                if j == 0:
+                    for i in members:
+                        caches[i] = {'pos': positives[i], 'neg': negatives[i][0]}
+                else:
+                    for i in members:
+                        hard_idx = next_hard.pop(i)
+                        caches[i]['neg'] = torch.cat((caches[i]['neg'], negatives[i][j][hard_idx]), 0)
+                        print('Class {}: chosen {} hard negatives from the {}th batch'.format(i, len(hard_idx), j))
+                if rooms is not None and any(len(caches[i]['neg']) <= rooms[i] for i in members):
+                    return None      # a fit that draws fewer values than predicted: the later classes' positions in the stream are off
+                Xs, ys = [], []
+                for i in members:
+                    X_pos, X_neg = caches[i]['pos'], caches[i]['neg']
+                    print('Class {}: traning with {} positives and {} negatives'.format(i, len(X_pos), len(X_neg)))
+                    Xs.append(torch.cat((X_pos, X_neg), 0))
+                    # labels on the host: the Nystroem index rule reads them (two nonzero() per class — host synchronisations
+                    # when the labels live on the GPU); the fit uploads its own f64 copy
+                    ys.append(torch.cat((torch.ones(len(X_pos)), -torch.ones(len(X_neg))), 0))
+                return Xs, ys
+
+            # every Cholesky status of the round is read once (a host synchronisation), when the block closes: after the round's
+            # fits AND the predictions that use them are queued — read right behind the fits, the host would start queueing the
+            # 60 predictions of a round only when the GPU has gone idle
+            with solver.deferred_pivot_checks():
+                groups = [[i for i in part if i in todo] for part in parts]
+                if two:
+                    rnd = self.classifier.train_batch_begin(sigma=self.sigma, lam=self.lam, streams=streams, expect_total=len(todo))
+                    for g, members in enumerate(groups):
+                        settle(g)
+                        sets = training_sets(members)
+                        if sets is None:
+                            return None
+                        order += members
+                        rnd.add(sets[0], sets[1], index_rng=with_class_rng)
+                    fitted = rnd.finish()
+                else:
+                    settle(0)
+                    sets = training_sets(todo)
+                    if sets is None:
+                        return None
+                    order += todo
+                    fitted = self.classifier.train_batch(sets[0], sets[1], sigma=self.sigma, lam=self.lam, index_rng=with_class_rng,
+                                                         streams=streams)
+                for i, m in zip(order, fitted):
+                    model[i] = m
+                # the two predicts a class's fresh model is used for — pruning its cache now, mining its next batch at the
+                # start of the next round — in ONE phase on the streams (the next batch is known; the reference scores it first
+                # thing in the next iteration with this same model, OnlineRegionClassifier_incore.py:112-116), group by group:
+                # a group's selections wait for ITS predictions only (an event per stream behind them)
+                for s in streams:
+                    s.wait_stream(main)
+                for g, members in enumerate(groups):
+                    prune = [i for i in members if len(caches[i]['neg']) != 0 and j != len(negatives[i]) - 1]
+                    ahead = [i for i in members if j + 1 < len(negatives[i])]
+                    both = {}
+                    for i in sorted(set(prune) | set(ahead)):
+                        with torch.cuda.stream(streams[i % k]):
+                            both[i] = (self.classifier.predict(model[i], caches[i]['neg']) if i in prune else None,
+                                       self.classifier.predict(model[i], negatives[i][j + 1]) if i in ahead else None)
+                    events = []
+                    for s in {id(s): s for s in streams}.values():
+                        ev = torch.cuda.Event()
+                        ev.record(s)
+                        events.append(ev)
+                    pending[g] = (prune, ahead, both, events)
+        for g in range(len(parts)):
+            settle(g)
+        for s in streams:
+            main.wait_stream(s)
         for i in active:
             if not self.return_caches:
                 caches[i] = None

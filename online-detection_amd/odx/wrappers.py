@@ -28,6 +28,34 @@ class CenterSelector:
         return picked, Y[self.center_indices, :]
 
 
+class _BatchRound:
+    """See FALKONWrapperBase.train_batch_begin."""
+
+    def __init__(self, wrapper, sigma, lam, streams, expect_total):
+        self.w, self.sigma, self.lam, self.expect_total = wrapper, sigma, lam, expect_total
+        self.fit = _falkon.BatchFit(streams=streams)
+        self.count = 0
+        w = wrapper
+        w.kernel = w.kernel_cls(sigma=sigma)
+        own_rule = (type(w).compute_indices_selection is FALKONWrapperBase.compute_indices_selection
+                    and "compute_indices_selection" not in w.__dict__)
+        self.rule = w._indices_tensor if own_rule else w.compute_indices_selection
+
+    def add(self, Xs, ys, index_rng=None):
+        models = []
+        for k, y in enumerate(ys):
+            pos = self.count + k
+            indices = index_rng(pos, lambda y=y: self.rule(y)) if index_rng else self.rule(y)
+            models.append(self.w._estimator_for(indices, self.sigma, self.lam))
+        self.count += len(models)
+        self.fit.add(models, Xs, ys, expect_total=self.expect_total)
+
+    def finish(self):
+        models = self.fit.finish()
+        self.w.model = models[-1] if models else None
+        return models
+
+
 class FALKONWrapperBase:
     incore = True
 
@@ -116,6 +144,24 @@ class FALKONWrapperBase:
         _falkon.fit_batch(models, Xs, ys, streams=streams)
         self.model = models[-1] if models else None
         return models       # fresh objects per call: nothing of the wrapper aliases them, so no deep copy is needed
+
+    def train_batch_begin(self, sigma=None, lam=None, streams=None, expect_total=None):
+        """train_batch in two phases (odx.falkon.BatchFit): the returned object takes the classes of a round in groups —
+        ``add(Xs, ys, index_rng)`` applies the index rule, builds the estimators and queues the group's preconditioner chain
+        at once; ``finish()`` fits everything and returns the estimators in the order they were added.  index_rng's first
+        argument is the class's position among ALL classes added so far."""
+        return _BatchRound(self, self.sigma if sigma is None else sigma, self.lam if lam is None else lam, streams, expect_total)
+
+    def _estimator_for(self, indices, sigma, lam):
+        if isinstance(indices, int):
+            indices = [indices]
+        opt = self.options_cls(min_cuda_iter_size_32=0, min_cuda_iter_size_64=0, keops_active="no",
+                               min_cuda_pc_size_32=0, min_cuda_pc_size_64=0, store_kernel_d_threshold=250)
+        cls = self.estimator_incore if self.incore else self.estimator_cpu
+        kw = {"maxiter": self.maxiter} if self.incore else {}
+        # the indices as one tensor (same rows selected; a model with a 2000-entry python list costs ~1 ms to copy or pickle)
+        return cls(kernel=self.kernel_cls(sigma=sigma), penalty=lam, M=len(indices),
+                   center_selection=self.selector_cls(torch.as_tensor(indices, dtype=torch.int64)), options=opt, **kw)
 
     def model_from_tensors(self, ny_points, alpha, sigma=None, lam=None):
         """An estimator as `train` returns it, around centres and coefficients that were trained elsewhere (another rank
