@@ -455,8 +455,9 @@ class OnlineRegionClassifierBase:
         # already does; as ONE group those 5 ms passed with the GPU idle, a tenth of a round.  The group of a class is fixed
         # (it owns the events its selections wait for); per class nothing changes.
         two = hasattr(self.classifier, 'train_batch_begin') and len(active) >= 2 * self.GROUP_MIN_CLASSES
-        cut = (len(active) + 1) // 2 if two else len(active)
-        parts = [active[:cut], active[cut:]] if two else [active]
+        ng = 2 if two else 1            # (three groups: 0.455-0.46 s, four: 0.445 s, two: 0.44 s on the same box)
+        cut = (len(active) + ng - 1) // ng
+        parts = [active[g * cut:(g + 1) * cut] for g in range(ng)]
         pending = {}            # group -> (prune, ahead, scores, events) of its last queued predictions, selections not read yet
 
         def settle(g):
