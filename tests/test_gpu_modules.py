@@ -391,13 +391,17 @@ def test_bench_starts_its_own_ranks_and_matches_the_oracle(ranks, classes, rows,
     assert out["health"]["failed_choleskys"] == 0 and out["health"]["ranks_with_nonfinite_scores"] == 0
 
 
-def test_batched_minibootstrap_equals_the_sequential_one_bit_for_bit(tmp_path):
+def test_batched_minibootstrap_equals_the_sequential_one_bit_for_bit(tmp_path, monkeypatch):
     """opts['class_batch'] = k fits all classes of a Minibootstrap round with one batched preconditioner launch chain and
     runs their K_nM builds / CG loops on k streams.  Fed the same Nystroem indices (the wrapper's index rule replaced by a
     deterministic one, so that the order in which classes consume the RNG does not matter) it must reproduce the
     reference-order sequential training bit for bit: same models, same caches — for k = 1 and k = 3, with a class without
-    positives, a class with fewer negative batches and classes whose fits have different numbers of centres."""
+    positives, a class with fewer negative batches and classes whose fits have different numbers of centres.  "b3g": the
+    rounds in two groups (falkon.BatchFit: a chain per group, queued while the other group is prepared); "b3h": one group
+    whose chain fit_batch splits into two half chains — both forced onto this small problem."""
     import yaml
+    import odx.falkon as odx_falkon
+    from odx.region_classifier import OnlineRegionClassifierBase
     D, C, ITER, M = 64, 5, 4, 120
     classes = ["_background_", "a", "b", "c", "d", "e"]
     cfg = {"NUM_CLASSES": 6, "ONLINE_REGION_CLASSIFIER": {"MINIBOOTSTRAP": {"EASY_THRESH": -0.9, "HARD_THRESH": -0.7},
@@ -432,17 +436,30 @@ def test_batched_minibootstrap_equals_the_sequential_one_bit_for_bit(tmp_path):
         return pos + neg
 
     out = {}
+    two_phase = []          # (mode, fast path kept, chains queued) of every BatchFit.finish
+    plain_finish = odx_falkon.BatchFit.finish
+
+    def recording_finish(self):
+        two_phase.append((mode, self.fast, len(self.segments)))
+        return plain_finish(self)
+    monkeypatch.setattr(odx_falkon.BatchFit, "finish", recording_finish)
     for mode, opts in (("seq", {"return_caches": True}), ("b1", {"class_batch": 1, "return_caches": True}),
-                       ("b3", {"class_batch": 3, "return_caches": True}), ("s3", {"class_streams": 3, "return_caches": True})):
+                       ("b3", {"class_batch": 3, "return_caches": True}), ("s3", {"class_streams": 3, "return_caches": True}),
+                       ("b3g", {"class_batch": 3, "return_caches": True}), ("b3h", {"class_batch": 3, "return_caches": True})):
+        monkeypatch.setattr(OnlineRegionClassifierBase, "GROUP_MIN_CLASSES", {"b3g": 1, "b3h": 99}.get(mode, 4))
+        monkeypatch.setattr(odx_falkon, "_CHAIN_SPLIT_MIN", 1 if mode == "b3h" else 4)
         pos, neg = data()
         w = wrap_mod.FALKONWrapper(cfg_path=path)
         w.compute_indices_selection = injected
         torch.manual_seed(5)
         out[mode] = quiet(orc_mod.OnlineRegionClassifier(w, pos, neg, stats, cfg_path=path).trainRegionClassifier, opts=opts)
+    # the two-group rounds went through the two-phase fit and kept its fast path (a chain per group), nobody else used it
+    assert two_phase and {m for m, _, _ in two_phase} == {"b3g"} and all(fast and 1 <= n <= 2 for _, fast, n in two_phase)
+    assert any(n == 2 for _, _, n in two_phase)
     (ms, cs) = out["seq"]
     assert [m is None for m in ms] == [False, True, False, False, False]
     assert ms[4].M < M                                                   # the ragged member of the batch
-    for mode in ("b1", "b3", "s3"):                # the class-streams mode too: same per-class draws => same bits
+    for mode in ("b1", "b3", "s3", "b3g", "b3h"):  # the class-streams mode too: same per-class draws => same bits
         mb, cb = out[mode]
         for c in range(C):
             assert (ms[c] is None) == (mb[c] is None)

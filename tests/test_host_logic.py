@@ -139,6 +139,31 @@ def test_train_batch_on_a_backend_without_batched_kernels_equals_train():
         assert tuple(a.predict(Xs[0][:5]).shape) == (5, 1)
 
 
+def test_two_phase_train_batch_equals_train_batch():
+    """train_batch_begin / add (group by group) / finish: the same models as one train_batch call over all classes with the
+    same index draws — here on the backend without batched kernels (everything through the general path in finish)."""
+    mod = dropin.load("FALKONWrapper_with_centers_selection_incore")
+    w = mod.FALKONWrapper(cfg_path=os.path.join(GOLD, "cfg_bootstrap.yaml"))
+    Xs, ys = [], []
+    for seed in (1, 2, 3, 4):
+        X, y, _ = blob_problem(240 + 20 * seed, 16, seed=seed)
+        Xs.append(torch.from_numpy(X)), ys.append(torch.from_numpy(y))
+    torch.manual_seed(9)
+    whole = quiet(w.train_batch, Xs, ys, sigma=7.0, lam=0.01)
+    torch.manual_seed(9)
+    seen = []
+
+    def run():
+        rnd = w.train_batch_begin(sigma=7.0, lam=0.01, expect_total=4)
+        rnd.add(Xs[:3], ys[:3], index_rng=lambda pos, fn: (seen.append(pos), fn())[1])
+        rnd.add(Xs[3:], ys[3:], index_rng=lambda pos, fn: (seen.append(pos), fn())[1])
+        return rnd.finish()
+    parts = quiet(run)
+    assert seen == [0, 1, 2, 3] and len(parts) == 4
+    for a, b in zip(parts, whole):
+        assert a.M == b.M and torch.equal(a.ny_points_, b.ny_points_) and torch.equal(a.alpha_, b.alpha_)
+
+
 def test_multi_output_fit_is_rejected_loudly():
     m = odx.InCoreFalkon(kernel=odx.GaussianKernel(5.0), penalty=1e-3, M=10)
     with pytest.raises(ValueError):
