@@ -561,13 +561,16 @@ def test_class_sharded_minibootstrap_on_gpu(tmp_path):
                 assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (rank, c)
 
 
+@pytest.mark.parametrize("group_min", [4, 1])
 @pytest.mark.parametrize("neg_rows,expect", [(200, "reference order, classes together"), (60, "reference order, class by class")])
-def test_default_mode_keeps_the_reference_order_of_draws(tmp_path, neg_rows, expect):
-    """Without options the classes advance together AND every class draws its Nystroem centres from the global torch RNG
+def test_default_mode_keeps_the_reference_order_of_draws(tmp_path, monkeypatch, neg_rows, expect, group_min):
+    """(group_min = 1: the rounds in two groups, as 8 classes and more run them.)  Without options the classes advance together AND every class draws its Nystroem centres from the global torch RNG
     exactly where the reference's class-by-class loop would: models, caches and the RNG state afterwards equal the forced
     class-by-class loop bit for bit (real index rule).  With 60-row negative batches class 4 has fewer negatives than room
     for negative centres, draws nothing, the prediction of the stream positions fails and the plain loop runs instead."""
     import yaml
+    from odx.region_classifier import OnlineRegionClassifierBase
+    monkeypatch.setattr(OnlineRegionClassifierBase, "GROUP_MIN_CLASSES", group_min)
     D, C, ITER, M = 64, 5, 4, 120
     cfg = {"NUM_CLASSES": 6, "ONLINE_REGION_CLASSIFIER": {"MINIBOOTSTRAP": {"EASY_THRESH": -0.9, "HARD_THRESH": -0.7},
                                                           "CLASSIFIER": {"lambda": 0.001, "sigma": 8, "M": M, "kernel_type": "gauss"}},
