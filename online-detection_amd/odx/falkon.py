@@ -331,7 +331,10 @@ class BatchFit:
         return (float(est.kernel.sigma), float(est.penalty), o.pc_epsilon, int(est.maxiter),
                 (o.cg_epsilon, o.cg_tolerance, o.cg_full_gradient_every, o.check_pivots))
 
-    def add(self, estimators, Xs, Ys, expect_total=None):
+    def add(self, estimators, Xs, Ys, expect_total=None, centres_cap=None):
+        """expect_total: classes the caller will add in all (sizes the shared factor block at the first group); centres_cap:
+        the most centres any class can have (the block's slot size: a later group with more centres than the first group's
+        largest class would otherwise force everything through the general path)."""
         be = self.be
         first = len(self.est)
         self.est += list(estimators)
@@ -365,7 +368,8 @@ class BatchFit:
         Mmax = max(z.n for z in Zfs)
         sigma, lam, eps = self.key[0], self.key[1], self.key[2]
         if self.block is None:
-            self.block = torch.empty((total, 4, Mmax, (Mmax + 1) // 2 * 2), dtype=torch.float64, device=be.device)
+            slot = max(Mmax, int(centres_cap or 0))
+            self.block = torch.empty((total, 4, slot, (slot + 1) // 2 * 2), dtype=torch.float64, device=be.device)
         if Mmax > self.block.shape[2] or first + len(estimators) > self.block.shape[0]:
             self.fast = False          # (a later group with more centres than the block was cut for: everything through fit_batch)
             return

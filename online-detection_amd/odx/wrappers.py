@@ -48,7 +48,7 @@ class _BatchRound:
             indices = index_rng(pos, lambda y=y: self.rule(y)) if index_rng else self.rule(y)
             models.append(self.w._estimator_for(indices, self.sigma, self.lam))
         self.count += len(models)
-        self.fit.add(models, Xs, ys, expect_total=self.expect_total)
+        self.fit.add(models, Xs, ys, expect_total=self.expect_total, centres_cap=getattr(self.w, "nyst_centers", None))
 
     def finish(self):
         models = self.fit.finish()
