@@ -363,6 +363,16 @@ int odx_rls_predict_rows_batched_f64(const float* X, int64_t ldx, int D, const i
  *   solve: per class as odx_rls_solve_f64; W: C blocks w_stride apart, 4 x ldw; info: C words.
  * Two calls so that a row-sharded caller can all-reduce G and XtY in between. */
 int64_t odx_rls_gram_batched_workspace_bytes(int64_t npad, int D);
+/* The gram step in two calls, so that the Grams (which need the rows only) can run while the caller is still deriving the
+ * targets (train_region_refiner.py:58-68: mean, covariance, its eigen-decomposition, the whitening): odx_rls_gram_batched_f64
+ * with Yt == NULL and XtY == NULL forms the Grams alone, odx_rls_xty_batched_f64 (same workspace size) then adds Yt [X 1] and
+ * the bias row / column of G.  Both need the rows form (odx_rls_rows_form(X, ldx, D) != 0: D % 8 == 0, ldx % 4 == 0, X 16-byte
+ * aligned, ODX_RLS_GRAM != nt) and return ODX_ERR_UNSUPPORTED without it — the single call with Yt always works. */
+int odx_rls_rows_form(const float* X, int64_t ldx, int D);
+int odx_rls_xty_batched_f64(const float* X, int64_t ldx, int D, const int64_t* idx_pad, int64_t npad,
+                            const int64_t* seg_off, const int64_t* seg_len, int C, const double* Yt, int64_t ldy,
+                            double* G, int64_t ldg, int64_t g_stride, double* XtY, int64_t ldxy, int64_t xy_stride,
+                            void* workspace, int64_t workspace_bytes, odx_stream_t stream);
 int odx_rls_gram_batched_f64(const float* X, int64_t ldx, int D, const int64_t* idx_pad, int64_t npad,
                              const int64_t* seg_off, const int64_t* seg_len, int C,
                              const double* Yt, int64_t ldy, double* G, int64_t ldg, int64_t g_stride,

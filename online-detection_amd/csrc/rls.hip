@@ -484,6 +484,56 @@ __global__ __launch_bounds__(256) void rls_fold_bias_kernel(const double* __rest
   G[(int64_t)c * g_stride + (int64_t)(D1 - 1) * ldg + j] += o[4 * ldo + j];
 }
 
+// The Grams come straight from the f32 rows (rls_gram_rows_kernel) when the rows allow 16-byte column groups; ODX_RLS_GRAM=nt
+// keeps round 3's form (a transposed f64 copy of all rows + the generic NT GEMM) for A/B runs.
+static bool rls_rows_form(const float* X, int64_t ldx, int D) {
+  const char* e = getenv("ODX_RLS_GRAM");
+  return !(e && e[0] == 'n') && D % 8 == 0 && ldx % 4 == 0 && aligned16(X);
+}
+
+extern "C" int odx_rls_rows_form(const float* X, int64_t ldx, int D) { return rls_rows_form(X, ldx, D) ? 1 : 0; }
+
+extern "C" int odx_rls_xty_batched_f64(const float* X, int64_t ldx, int D, const int64_t* idx_pad, int64_t npad,
+                                       const int64_t* seg_off, const int64_t* seg_len, int C, const double* Yt, int64_t ldy,
+                                       double* G, int64_t ldg, int64_t g_stride, double* XtY, int64_t ldxy, int64_t xy_stride,
+                                       void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
+  ODX_REQUIRE(C >= 1 && C <= ODX_MAX_ZBATCH, "odx_rls_xty_batched_f64: 1..%d classes per call", ODX_MAX_ZBATCH);
+  if (npad <= 0) return ODX_OK;
+  ODX_REQUIRE(X && idx_pad && seg_off && seg_len && Yt && G && XtY && workspace && D > 0, "odx_rls_xty_batched_f64: bad argument");
+  const int64_t D1 = D + 1, ldt = round_up(npad, 16);
+  ODX_REQUIRE(ldy % 2 == 0 && ldy >= ldt && aligned16(Yt) && aligned16(workspace), "odx_rls_xty_batched_f64: Yt/workspace 16-byte aligned, ldy even >= padded rows");
+  ODX_REQUIRE(ldg >= D1 && ldxy >= D1 && g_stride >= D1 * ldg && xy_stride >= 4 * ldxy, "odx_rls_xty_batched_f64: output strides too small");
+  if (!rls_rows_form(X, ldx, D)) {
+    set_error("odx_rls_xty_batched_f64: needs the rows form (D %% 8 == 0, ldx %% 4 == 0, X 16-byte aligned): odx_rls_rows_form");
+    return ODX_ERR_UNSUPPORTED;
+  }
+  if (workspace_bytes < odx_rls_gram_batched_workspace_bytes(npad, D)) {
+    set_error("odx_rls_xty_batched_f64: workspace too small");
+    return ODX_ERR_WORKSPACE;
+  }
+  hipStream_t s = as_stream(stream);
+  RlsSegs sg;
+  for (int c = 0; c < ODX_MAX_ZBATCH; ++c) sg.off[c] = sg.len[c] = 0;
+  for (int c = 0; c < C; ++c) {
+    ODX_REQUIRE(seg_off[c] % 16 == 0 && seg_len[c] >= 0 && round_up(seg_off[c] + seg_len[c], 16) <= npad,
+                "odx_rls_xty_batched_f64: class %d: segment must start at a multiple of 16 and end, padded to one, inside the index array", c);
+    sg.off[c] = seg_off[c];
+    sg.len[c] = seg_len[c];
+  }
+  const int64_t ldo = round_up(D1, 2);
+  double* P = static_cast<double*>(workspace);                       // C x RX_CH x 5 x ldo partial sums, then O5
+  double* O5 = P + (int64_t)C * RX_CH * 5 * ldo;
+  hipLaunchKernelGGL(rls_xty_rows_kernel, dim3((unsigned)ceil_div(D1, 256), RX_CH, (unsigned)C), dim3(256), 0, s, X, ldx, D, idx_pad, sg, Yt,
+                     ldy, P, ldo);
+  ODX_CHECK_LAUNCH("rls_xty_rows");
+  hipLaunchKernelGGL(rls_xty_reduce_kernel, dim3((unsigned)ceil_div(D1, 256), (unsigned)C, 5), dim3(256), 0, s, P, ldo, (int)D1, O5);
+  ODX_CHECK_LAUNCH("rls_xty_reduce");
+  hipLaunchKernelGGL(rls_fold_bias_kernel, dim3((unsigned)ceil_div(D1, 256), (unsigned)C), dim3(256), 0, s, O5, ldo, (int)D1, XtY, ldxy,
+                     xy_stride, G, ldg, g_stride);
+  ODX_CHECK_LAUNCH("rls_fold_bias");
+  return ODX_OK;
+}
+
 extern "C" int odx_rls_gram_batched_f64(const float* X, int64_t ldx, int D, const int64_t* idx_pad, int64_t npad,
                                         const int64_t* seg_off, const int64_t* seg_len, int C, const double* Yt,
                                         int64_t ldy, double* G, int64_t ldg, int64_t g_stride, double* XtY,
@@ -491,20 +541,22 @@ extern "C" int odx_rls_gram_batched_f64(const float* X, int64_t ldx, int D, cons
                                         odx_stream_t stream) {
   ODX_REQUIRE(C >= 1 && C <= ODX_MAX_ZBATCH, "odx_rls_gram_batched_f64: 1..%d classes per call", ODX_MAX_ZBATCH);
   if (npad <= 0) return ODX_OK;
-  ODX_REQUIRE(X && idx_pad && seg_off && seg_len && Yt && G && XtY && workspace && D > 0, "odx_rls_gram_batched_f64: bad argument");
+  const bool gram_only = Yt == nullptr && XtY == nullptr;          // (the targets follow with odx_rls_xty_batched_f64)
+  ODX_REQUIRE(X && idx_pad && seg_off && seg_len && G && workspace && D > 0 && (gram_only || (Yt && XtY)),
+              "odx_rls_gram_batched_f64: bad argument");
   const int64_t D1 = D + 1, ldt = round_up(npad, 16);
-  ODX_REQUIRE(ldy % 2 == 0 && ldy >= ldt && aligned16(Yt) && aligned16(workspace), "odx_rls_gram_batched_f64: Yt/workspace 16-byte aligned, ldy even >= padded rows");
-  ODX_REQUIRE(ldg >= D1 && ldxy >= D1 && g_stride >= D1 * ldg && xy_stride >= 4 * ldxy, "odx_rls_gram_batched_f64: output strides too small");
+  ODX_REQUIRE(aligned16(workspace) && (gram_only || (ldy % 2 == 0 && ldy >= ldt && aligned16(Yt))),
+              "odx_rls_gram_batched_f64: Yt/workspace 16-byte aligned, ldy even >= padded rows");
+  ODX_REQUIRE(ldg >= D1 && g_stride >= D1 * ldg && (gram_only || (ldxy >= D1 && xy_stride >= 4 * ldxy)),
+              "odx_rls_gram_batched_f64: output strides too small");
   if (workspace_bytes < odx_rls_gram_batched_workspace_bytes(npad, D)) {
     set_error("odx_rls_gram_batched_f64: workspace too small");
     return ODX_ERR_WORKSPACE;
   }
   hipStream_t s = as_stream(stream);
   {
-    // default: the Grams and the skinny products straight from the f32 rows (rls_gram_rows_kernel, rls_xty_rows_kernel);
-    // ODX_RLS_GRAM=nt keeps round 3's form (a transposed f64 copy of all rows + the generic NT GEMM) for A/B runs
-    const char* e = getenv("ODX_RLS_GRAM");
-    if (!(e && e[0] == 'n') && D % 8 == 0 && ldx % 4 == 0 && aligned16(X)) {
+    // default: the Grams and the skinny products straight from the f32 rows (rls_gram_rows_kernel, rls_xty_rows_kernel)
+    if (rls_rows_form(X, ldx, D)) {
       RlsSegs sg;
       for (int c = 0; c < ODX_MAX_ZBATCH; ++c) sg.off[c] = sg.len[c] = 0;
       for (int c = 0; c < C; ++c) {
@@ -517,6 +569,7 @@ extern "C" int odx_rls_gram_batched_f64(const float* X, int64_t ldx, int D, cons
       const int tiles = (int)(8 * ceil_div(ceil_div(D, RG_BM), 8) * ceil_div(D, RG_BN));
       hipLaunchKernelGGL(rls_gram_rows_kernel, dim3((unsigned)tiles, 1, (unsigned)C), dim3(256), 0, s, X, ldx, D, idx_pad, sg, G, ldg, g_stride);
       ODX_CHECK_LAUNCH("rls_gram_rows");
+      if (gram_only) return ODX_OK;
       const int64_t ldo = round_up(D1, 2);
       double* P = static_cast<double*>(workspace);                       // C x RX_CH x 5 x ldo partial sums, then O5
       double* O5 = P + (int64_t)C * RX_CH * 5 * ldo;
@@ -530,6 +583,10 @@ extern "C" int odx_rls_gram_batched_f64(const float* X, int64_t ldx, int D, cons
       ODX_CHECK_LAUNCH("rls_fold_bias");
       return ODX_OK;
     }
+  }
+  if (gram_only) {
+    set_error("odx_rls_gram_batched_f64: the Gram-only call needs the rows form (D %% 8 == 0, ldx %% 4 == 0, X 16-byte aligned): odx_rls_rows_form");
+    return ODX_ERR_UNSUPPORTED;
   }
   double* Xt = static_cast<double*>(workspace);
   dim3 grid((unsigned)ceil_div(ldt, 32), (unsigned)ceil_div(D1, 32));

@@ -608,17 +608,43 @@ class HipBackend:
                   "odx_rls_solve_f64")
         return W, info
 
-    def rls_train_batched(self, F, idx_pad, seg_off, seg_len, Yt, lam, allreduce=None):
+    def rls_rows_form(self, F):
+        """Whether the Grams of F's rows can be formed on their own (rls_gram_begin): see odx_rls_rows_form."""
+        return bool(F.n) and bool(self.lib.odx_rls_rows_form(_p(F.X), F.ld, F.D))
+
+    def rls_gram_zeros(self, F, C):
+        D1 = F.D + 1
+        return torch.zeros((C, D1, (D1 + 1) // 2 * 2), dtype=torch.float64, device=self.device)
+
+    def rls_gram_begin(self, F, idx_pad, seg_off, seg_len, G):
+        """Queue the Grams of the classes alone (they need the rows, not the targets) into G = rls_gram_zeros(F, C), which
+        rls_train_batched(begun=G) completes.  Needs rls_rows_form(F)."""
+        C, D = len(seg_len), F.D
+        npad = int(idx_pad.numel())
+        if not npad:
+            return G
+        D1 = D + 1
+        ld = (D1 + 1) // 2 * 2
+        so = (ctypes.c_int64 * C)(*[int(v) for v in seg_off])
+        sl = (ctypes.c_int64 * C)(*[int(v) for v in seg_len])
+        ws = self._workspace("rls_gram_batched", self.lib.odx_rls_gram_batched_workspace_bytes(npad, D))
+        hip.check(self.lib.odx_rls_gram_batched_f64(_p(F.X), F.ld, D, _p(idx_pad), npad, so, sl, C, None, 0, _p(G), ld, D1 * ld, None, 0, 0,
+                                                    _p(ws), ws.numel(), self._stream()), "odx_rls_gram_batched_f64")
+        return G
+
+    def rls_train_batched(self, F, idx_pad, seg_off, seg_len, Yt, lam, allreduce=None, begun=None, after=None):
         """The RLS solves of len(seg_len) <= 32 classes with one launch chain (odx_rls_gram_batched_f64 +
         odx_rls_solve_batched_f64).  idx_pad: device int64 row ids class after class, every segment starting at a multiple
         of 16 and padded with -1; seg_off / seg_len: python lists; Yt (4, ldy) f64 whitened targets in the same padded
-        order.  allreduce: optional callable summing a tensor over row shards (applied to the Grams and X'Y).  Returns
-        W (C, 4, ldw) f64 and info (C,) int32."""
+        order.  allreduce: optional callable summing a tensor over row shards (applied to the Grams and X'Y).  begun: the G
+        block of rls_gram_begin for the same rows, queued on stream `after`: only Yt [X 1] is formed here (beside the Grams —
+        it writes other entries of G than they do), and the solves wait for `after`.  Returns W (C, 4, ldw) f64 and info
+        (C,) int32."""
         C, D = len(seg_len), F.D
         D1 = D + 1
         ld = (D1 + 1) // 2 * 2
         npad = int(idx_pad.numel())
-        G = torch.zeros((C, D1, ld), dtype=torch.float64, device=self.device)
+        G = begun if begun is not None else torch.zeros((C, D1, ld), dtype=torch.float64, device=self.device)
         XtY = torch.zeros((C, 4, ld), dtype=torch.float64, device=self.device)
         W = torch.empty((C, 4, ld), dtype=torch.float64, device=self.device)
         info = torch.zeros(C, dtype=torch.int32, device=self.device)
@@ -626,9 +652,12 @@ class HipBackend:
         sl = (ctypes.c_int64 * C)(*[int(v) for v in seg_len])
         if npad:
             ws = self._workspace("rls_gram_batched", self.lib.odx_rls_gram_batched_workspace_bytes(npad, D))
-            hip.check(self.lib.odx_rls_gram_batched_f64(_p(F.X), F.ld, D, _p(idx_pad), npad, so, sl, C, _p(Yt), Yt.stride(0), _p(G), ld,
-                                                        D1 * ld, _p(XtY), ld, 4 * ld, _p(ws), ws.numel(), self._stream()),
-                      "odx_rls_gram_batched_f64")
+            fn, name = ((self.lib.odx_rls_xty_batched_f64, "odx_rls_xty_batched_f64") if begun is not None
+                        else (self.lib.odx_rls_gram_batched_f64, "odx_rls_gram_batched_f64"))
+            hip.check(fn(_p(F.X), F.ld, D, _p(idx_pad), npad, so, sl, C, _p(Yt), Yt.stride(0), _p(G), ld, D1 * ld, _p(XtY), ld, 4 * ld,
+                         _p(ws), ws.numel(), self._stream()), name)
+        if after is not None:
+            torch.cuda.current_stream(self.device).wait_stream(after)
         if allreduce is not None:
             allreduce(G)
             allreduce(XtY)

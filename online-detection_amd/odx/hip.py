@@ -103,6 +103,8 @@ SIGNATURES = {
     "odx_rls_solve_f64": (_i32, [_vp, _i64, _i32, _f64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
     "odx_rls_gram_batched_workspace_bytes": (_i64, [_i64, _i32]),
     "odx_rls_gram_batched_f64": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
+    "odx_rls_xty_batched_f64": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
+    "odx_rls_rows_form": (_i32, [_vp, _i64, _i32]),
     "odx_rls_solve_batched_workspace_bytes": (_i64, [_i32, _i32]),
     "odx_rls_solve_batched_f64": (_i32, [_vp, _i64, _i64, _i32, _i32, _f64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _vp]),
     "odx_rls_predict_rows_f64": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),

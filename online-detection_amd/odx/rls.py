@@ -92,6 +92,7 @@ class RegionRefinerTrainer:
         n_tot = {c: (n_loc[c] if self.shard is None else self.shard.total(n_loc[c])) for c in ids}
         models = {}
         Wall, infos, rows_of, Yw_of, whit = {}, {}, {}, {}, {}
+        stat_blocks = []          # per solved group: (its classes, (G, 9, 4) f64 = [mu; T; T_inv] of each)
         solved = []
         live = [c for c in ids if n_tot[c] > 0]
         for g0 in range(0, len(live), be.MAX_CLASS_BATCH):
@@ -122,6 +123,23 @@ class RegionRefinerTrainer:
                 gid = torch.repeat_interleave(torch.arange(G_, device=xdev), lens_d, output_size=total)      # class slot of every row
                 starts = torch.tensor(np.concatenate(([0], np.cumsum(seg_len)[:-1])), dtype=torch.int64).to(xdev)
                 pos = torch.arange(total, device=xdev) - starts[gid]                                         # row's rank inside its class
+                dest = torch.tensor(seg_off, dtype=torch.int64).to(xdev)[gid] + pos
+                idx_pad[dest] = run
+                # The Grams need the rows only: queued NOW, on a side stream (odx/streams.py: a hardware queue of its own), they
+                # run — 7 of the call's 12 ms at config 3 — while this stream derives the targets (statistics, the host's
+                # eigen-decomposition with its synchronisation, whitening) and forms Yt [X 1] beside them.
+                begun = side = None
+                if hasattr(be, "rls_gram_begin") and xdev.type == "cuda" and be.rls_rows_form(F):
+                    from . import streams as _streams
+                    own = _streams.distinct(1)
+                    if own:
+                        side, cur = own[0], torch.cuda.current_stream()
+                        begun = be.rls_gram_zeros(F, G_)          # (zeroed on THIS stream: Yt [X 1] adds to its bias row later)
+                        side.wait_stream(cur)
+                        with torch.cuda.stream(side):
+                            be.rls_gram_begin(F, idx_pad, seg_off, seg_len, begun)
+                        begun.record_stream(side)
+                        idx_pad.record_stream(side)
                 Ypad = torch.zeros((G_, nmax, 4), dtype=torch.float64, device=xdev)
                 Ypad[gid, pos] = Yall[run].type(torch.float64)
                 cnt = lens_d.type(torch.float64).clamp(min=1).view(G_, 1)
@@ -153,8 +171,6 @@ class RegionRefinerTrainer:
             Tis = Wv @ torch.diag_embed(root) @ Wv.transpose(1, 2)
             if not sharded:
                 Yw_all = torch.bmm(Yc_all, Ts)[gid, pos]                                   # (rows of the group, 4), class-sorted
-                dest = torch.tensor(seg_off, dtype=torch.int64).to(xdev)[gid] + pos
-                idx_pad[dest] = run
                 Yt[:, dest] = Yw_all.t()
                 a = 0
                 for k, c in enumerate(group):
@@ -168,8 +184,15 @@ class RegionRefinerTrainer:
                     whit[c], Yw_of[c] = (mus[k], Ts[k], Tis[k]), Yw
                     idx_pad[off:off + n_loc[c]] = rows_of[c]
                     Yt[:, off:off + n_loc[c]] = Yw.t()
-            W, info = be.rls_train_batched(F, idx_pad, seg_off, seg_len, Yt, self.lambd,
-                                           allreduce=self.shard.allreduce if self.shard is not None else None)
+            if not sharded and begun is not None:
+                # Yt [X 1] (an HBM sweep) beside the Grams' last tiles, then the solves behind both
+                W, info = be.rls_train_batched(F, idx_pad, seg_off, seg_len, Yt, self.lambd, begun=begun,
+                                               allreduce=None, after=side)
+            else:
+                W, info = be.rls_train_batched(F, idx_pad, seg_off, seg_len, Yt, self.lambd,
+                                               allreduce=self.shard.allreduce if self.shard is not None else None)
+            stat_blocks.append((group, torch.cat((torch.stack([whit[c][0] for c in group]).view(len(group), 1, 4) if sharded
+                                                  else mu_all.view(len(group), 1, 4), Ts, Tis), dim=1)))
             bad = info.tolist()
             for k, c in enumerate(group):
                 if bad[k] != 0:
@@ -195,12 +218,16 @@ class RegionRefinerTrainer:
                 be.rls_predict_rows(F, rows_of[i].contiguous(), Wall[i], out=P_all[span[i][0]:span[i][1]])
         losses_all = (0.5 * (P_all - torch.cat([Yw_of[i] for i in live])) ** 2).type(torch.float32) if live else None
         W32 = torch.stack([Wall[i][:, :D1] for i in live]).to(dev).type(torch.float32) if live else None
-        stats32 = torch.stack([torch.cat((whit[i][0].reshape(1, 4), whit[i][1], whit[i][2])) for i in live]).to(dev).type(torch.float32) if live else None
-        # (three copies per class — its losses, its four weight rows, its nine statistics rows — and views into them: a class's
-        # entry keeps 16 KB + its own losses alive, not the arrays of all classes)
+        stats32 = torch.cat([b for _, b in stat_blocks]).to(dev).type(torch.float32) if live else None      # (live classes in order)
+        # Three tensors of its own per class — its losses, its four weight rows, its nine statistics rows — and views into
+        # them: a class's entry keeps 16 KB + its own losses alive, not the arrays of all classes.  All 3 x classes copies in
+        # ONE multi-tensor launch (was a launch per copy: 90 at config 3, the tail of the call).
+        srcs = [t for j, i in enumerate(live) for t in (losses_all[span[i][0]:span[i][1]], W32[j], stats32[j])]
+        own = [torch.empty_like(t) for t in srcs]
+        if srcs:
+            torch._foreach_copy_(own, srcs)
         for j, i in enumerate(live):
-            losses = losses_all[span[i][0]:span[i][1]].clone()
-            Wc, sc = W32[j].clone(), stats32[j].clone()
+            losses, Wc, sc = own[3 * j], own[3 * j + 1], own[3 * j + 2]
             Beta = {str(k): {'weights': Wc[k], 'losses': losses[:, k]} for k in range(4)}
             entries[i] = {'mu': sc[0], 'T': sc[1:5], 'T_inv': sc[5:9], 'Beta': Beta}
         if live:
