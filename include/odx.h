@@ -360,7 +360,9 @@ int odx_rls_predict_rows_batched_f64(const float* X, int64_t ldx, int D, const i
  *          XtY (C blocks xy_stride apart, 4 x ldxy) += Yt [X 1] — straight from the f32 rows when D % 8 == 0, ldx % 4 == 0
  *          and X is 16-byte aligned (one TN Gram launch on the f64 matrix cores + one sweep for X'Y); otherwise, or with
  *          ODX_RLS_GRAM=nt in the environment, through a transposed f64 copy of the rows and the NT GEMM.
- *   solve: per class as odx_rls_solve_f64; W: C blocks w_stride apart, 4 x ldw; info: C words.
+ *   solve: per class the result of odx_rls_solve_f64 (to rounding: Cholesky, then block substitution with the factor — one
+ *          workgroup per class — instead of the explicit inverse; ODX_RLS_SOLVE=inverse keeps that form); W: C blocks w_stride
+ *          apart, 4 x ldw; info: C words.
  * Two calls so that a row-sharded caller can all-reduce G and XtY in between. */
 int64_t odx_rls_gram_batched_workspace_bytes(int64_t npad, int D);
 /* The gram step in two calls, so that the Grams (which need the rows only) can run while the caller is still deriving the

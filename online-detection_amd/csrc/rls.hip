@@ -632,6 +632,159 @@ extern "C" int64_t odx_rls_solve_batched_workspace_bytes(int D, int C) {
   return per * C * (int64_t)sizeof(double);
 }
 
+// ---------------------------------------------------------------- the four solves of a class by block substitution
+// W_q = (L L')^-1 b_q, q = 0..3, from the Cholesky factor L (lower, in G) and the inverses of its 128 x 128 diagonal blocks
+// (Dinv, what potrf_f64 leaves): forward L y = b block row by block row, then back L' w = y — ONE workgroup per class, the
+// vectors in LDS.  Replaces the explicit inverse of L (six merge levels of small GEMMs + two zeroed D1 x D1 matrices per
+// class: 0.7 ms of a dependent chain at D = 1024) and eight triangular products per class (0.2 ms); L is read twice (once by
+// rows, once by columns of its block columns: 16-lane-coalesced either way), 8.4 MB per class by one CU.
+constexpr int RS_NT = 512, RS_NB = 128, RS_MAXB = 24;          // up to 24 x 128 = 3072 unknowns (D + 1 <= 3072)
+
+__global__ __launch_bounds__(RS_NT) void rls_substitute_kernel(const double* __restrict__ Lall, int64_t ldl, int64_t l_stride,
+                                                               const double* __restrict__ Dall, int64_t d_stride, int D1,
+                                                               const double* __restrict__ Ball, int64_t ldb, int64_t b_stride,
+                                                               double* __restrict__ Wall, int64_t ldw, int64_t w_stride) {
+  extern __shared__ __attribute__((aligned(16))) double rs_lds[];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = (D1 + RS_NB - 1) / RS_NB, npad = nb * RS_NB;
+  const double* L = Lall + (int64_t)c * l_stride;
+  const double* Dv = Dall + (int64_t)c * d_stride;
+  const double* B = Ball + (int64_t)c * b_stride;
+  double* W = Wall + (int64_t)c * w_stride;
+  double* y = rs_lds;                       // [npad][4]
+  double* t = y + (int64_t)npad * 4;        // [128][4]
+  double* part = t + RS_NB * 4;             // [8 waves][128][4]
+  for (int e = tid; e < npad * 4; e += RS_NT) {
+    const int j = e >> 2, q = e & 3;
+    y[e] = j < D1 ? B[(int64_t)q * ldb + j] : 0.0;
+  }
+  __syncthreads();
+  // ---- forward: y_k = Dinv_k (b_k - L[k, < k] y[< k])
+  for (int k = 0; k < nb; ++k) {
+    const int r0 = k * RS_NB;
+    {                                       // wave w: rows 16 w .. 16 w + 15 of the block row, all sixteen at once — sixteen loads
+      const int r = wave * 16;              // in flight per step of the walk along the rows (a row at a time: one memory latency
+      double a[16][4] = {};                 // per row and step, 128 rows x 16 steps of them in a row)
+      const double* lr[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) lr[u] = L + (int64_t)(r0 + r + u < D1 ? r0 + r + u : 0) * ldl;
+      for (int j = lane; j < r0; j += 64) {
+        double l[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) l[u] = lr[u][j];
+        const double y0 = y[j * 4 + 0], y1 = y[j * 4 + 1], y2 = y[j * 4 + 2], y3 = y[j * 4 + 3];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          a[u][0] = fma(l[u], y0, a[u][0]); a[u][1] = fma(l[u], y1, a[u][1]); a[u][2] = fma(l[u], y2, a[u][2]); a[u][3] = fma(l[u], y3, a[u][3]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const bool ok = r0 + r + u < D1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          double v = ok ? a[u][q] : 0.0;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+          if (lane == q) t[(r + u) * 4 + q] = y[(r0 + r + u) * 4 + q] - v;
+        }
+      }
+    }
+    __syncthreads();
+    // y_k = Dinv_k t: the block's rows pass through LDS 32 at a time (every thread loads 8 of the chunk's 4096 doubles at once:
+    // one memory latency per chunk; a row or a column per thread straight from memory is 128 latencies in a row)
+    const double* Dk = Dv + (int64_t)k * RS_NB * RS_NB;
+    double dreg[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dreg[u] = Dk[u * RS_NT + tid];
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) part[u * RS_NT + tid] = dreg[u];
+      __syncthreads();
+      if (m < 3) {                          // the next chunk's loads fly under this chunk's products
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dreg[u] = Dk[(m + 1) * 4096 + u * RS_NT + tid];
+      }
+      {
+        const int rl = tid >> 4, q = (tid >> 2) & 3, sp = tid & 3;       // 32 rows x 4 right-hand sides x 4 column phases
+        const int r = m * 32 + rl;
+        double a = 0.0;
+        for (int j = sp; j <= r; j += 4) a = fma(part[rl * RS_NB + j], t[j * 4 + q], a);
+        a += __shfl_xor(a, 1);
+        a += __shfl_xor(a, 2);
+        if (sp == 0) y[(r0 + r) * 4 + q] = a;
+      }
+      __syncthreads();
+    }
+  }
+  // ---- back: w_k = Dinv_k' (y_k - L[> k, k]' w[> k]); w overwrites y block by block from the bottom
+  for (int k = nb - 1; k >= 0; --k) {
+    const int c0 = k * RS_NB;
+    double p[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};      // this lane's two columns c0 + lane, c0 + lane + 64
+    for (int row = c0 + RS_NB + wave; row < D1; row += 64) {          // eight rows of this wave per step: sixteen loads in flight
+      double l0[8], l1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int rr = row + 8 * u;
+        const double* lr = L + (int64_t)(rr < D1 ? rr : row) * ldl + c0;
+        l0[u] = lr[lane];
+        l1[u] = lr[lane + 64];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int rr = row + 8 * u;
+        if (rr < D1) {
+          const double w0 = y[rr * 4 + 0], w1 = y[rr * 4 + 1], w2 = y[rr * 4 + 2], w3 = y[rr * 4 + 3];
+          p[0][0] = fma(l0[u], w0, p[0][0]); p[0][1] = fma(l0[u], w1, p[0][1]); p[0][2] = fma(l0[u], w2, p[0][2]); p[0][3] = fma(l0[u], w3, p[0][3]);
+          p[1][0] = fma(l1[u], w0, p[1][0]); p[1][1] = fma(l1[u], w1, p[1][1]); p[1][2] = fma(l1[u], w2, p[1][2]); p[1][3] = fma(l1[u], w3, p[1][3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part[(wave * RS_NB + lane + 64 * h) * 4 + q] = p[h][q];
+    __syncthreads();
+    {
+      const int j = tid >> 2, q = tid & 3;            // 128 columns x 4 right-hand sides = 512 threads
+      double sum = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) sum += part[(w * RS_NB + j) * 4 + q];
+      t[j * 4 + q] = y[(c0 + j) * 4 + q] - sum;
+    }
+    __syncthreads();
+    {
+      // w_k = Dinv_k' t: thread (column j, right-hand side q) walks the rows of the block, 32 at a time through LDS
+      const double* Dk = Dv + (int64_t)k * RS_NB * RS_NB;
+      const int j = tid >> 2, q = tid & 3;
+      double sum = 0.0;
+      double dreg[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dreg[u] = Dk[u * RS_NT + tid];
+      for (int m = 0; m < 4; ++m) {
+        __syncthreads();                                // (the partial sums / the previous chunk have been read)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) part[u * RS_NT + tid] = dreg[u];
+        __syncthreads();
+        if (m < 3) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) dreg[u] = Dk[(m + 1) * 4096 + u * RS_NT + tid];
+        }
+        for (int rl = 0; rl < 32; ++rl) {
+          const int r = m * 32 + rl;
+          if (r >= j) sum = fma(part[rl * RS_NB + j], t[r * 4 + q], sum);
+        }
+      }
+      y[(c0 + j) * 4 + q] = sum;
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < D1 * 4; e += RS_NT) {
+    const int j = e >> 2, q = e & 3;
+    W[(int64_t)q * ldw + j] = y[e];
+  }
+}
+
 extern "C" int odx_rls_solve_batched_f64(double* G, int64_t ldg, int64_t g_stride, int D, int C, double lam, const double* XtY,
                                          int64_t ldxy, int64_t xy_stride, double* W, int64_t ldw, int64_t w_stride,
                                          int32_t* info, void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
@@ -655,11 +808,22 @@ extern "C" int odx_rls_solve_batched_f64(double* G, int64_t ldg, int64_t g_strid
   double* Lit = Li + (int64_t)C * lsz;
   double* z = Lit + (int64_t)C * lsz;
   ODX_CHECK_HIP(hipMemsetAsync(info, 0, (size_t)C * sizeof(int32_t), s));
-  ODX_CHECK_HIP(hipMemsetAsync(Li, 0, (size_t)(2 * (int64_t)C * lsz) * sizeof(double), s));       // Li and Lit
   ODX_PROPAGATE(add_diag_f64(G, ldg, D1, lam, s, C, g_stride));
   ZBatch zb;
   zb.count = C; zb.strideA = g_stride; zb.strideD = dsz; zb.strideO = lsz; zb.strideW = wtsz;
   ODX_PROPAGATE(potrf_f64(G, ldg, D1, Dinv, info, s, zb));
+  const char* sub = getenv("ODX_RLS_SOLVE");
+  if (!(sub && sub[0] == 'i') && ceil_div(D1, RS_NB) <= RS_MAXB) {
+    // block substitution with the factor (rls_substitute_kernel); ODX_RLS_SOLVE=inverse keeps the explicit inverse + products
+    const int64_t npad = ceil_div(D1, RS_NB) * RS_NB;
+    const size_t lds = (size_t)(npad * 4 + RS_NB * 4 + 8 * RS_NB * 4) * sizeof(double);
+    ODX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rls_substitute_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(rls_substitute_kernel, dim3((unsigned)C), dim3(RS_NT), lds, s, G, ldg, g_stride, Dinv, dsz, (int)D1, XtY, ldxy, xy_stride, W,
+                       ldw, w_stride);
+    ODX_CHECK_LAUNCH("rls_substitute");
+    return ODX_OK;
+  }
+  ODX_CHECK_HIP(hipMemsetAsync(Li, 0, (size_t)(2 * (int64_t)C * lsz) * sizeof(double), s));       // Li and Lit
   ODX_PROPAGATE(trtri_from_diag_f64(G, ldg, D1, Dinv, Li, Lit, ld, WT, s, zb));
   VecBatch vb;
   vb.B = C;

@@ -139,8 +139,9 @@ def test_batched_rls_equals_the_class_by_class_loop(hip_backend, D):
 
 def test_rls_grams_from_rows_equal_the_transposed_copy_form(hip_backend, monkeypatch):
     """The two forms of the batched Gram step (ODX_RLS_GRAM=nt: transposed f64 copy + NT GEMM; default: straight from the f32
-    rows) sum the same f64 products in different orders: the regressors agree to rounding, for class sizes that are not
-    multiples of the 16-row k-tile and feature counts that leave ragged tiles."""
+    rows) sum the same f64 products in different orders, and so do the two forms of the solves (block substitution with the
+    Cholesky factor; its explicit inverse): the regressors agree to rounding, for class sizes that are not multiples of the
+    16-row k-tile and feature counts that leave ragged tiles (D + 1 = 457: four 128-blocks, the last one 73 rows)."""
     from odx.rls import RegionRefinerTrainer
     rng = np.random.default_rng(11)
     D, C = 456, 5
@@ -152,15 +153,19 @@ def test_rls_grams_from_rows_equal_the_transposed_copy_form(hip_backend, monkeyp
     COXY = {"C": Cl[perm].view(-1, 1), "O": None, "X": X[perm], "Y": Y[perm]}
     cfg = {"CHOSEN_CLASSES": {i: "c%d" % i for i in range(C + 1)}, "REGION_REFINER": {"opts": {"lambda": 10.0}}}
     out = {}
-    for mode in ("nt", "rows"):
-        monkeypatch.setenv("ODX_RLS_GRAM", mode)
+    for mode in ("nt", "rows", "rows+inverse"):
+        monkeypatch.setenv("ODX_RLS_GRAM", mode.split("+")[0])
+        # the solves: block substitution with the factor (default) / the explicit inverse and triangular products
+        monkeypatch.setenv("ODX_RLS_SOLVE", "inverse" if mode.endswith("inverse") else "")
         tr = RegionRefinerTrainer(cfg, 10.0, False)
         tr.COXY = COXY
         out[mode] = quiet(tr._train_batched, hip_backend)
     for c in range(C):
         for k in range(4):
-            wa, wb = out["nt"][c]["Beta"][str(k)]["weights"], out["rows"][c]["Beta"][str(k)]["weights"]
-            assert float((wa - wb).abs().max()) <= 1e-6 * max(1.0, float(wb.abs().max())), (c, k)
+            wb = out["rows"][c]["Beta"][str(k)]["weights"]
+            for other in ("nt", "rows+inverse"):
+                wa = out[other][c]["Beta"][str(k)]["weights"]
+                assert float((wa - wb).abs().max()) <= 1e-6 * max(1.0, float(wb.abs().max())), (other, c, k)
 
 
 class OracleFalkonClassifier:
