@@ -183,7 +183,7 @@ def minibootstrap_extra(C=30, D=2048, IT=10, positives=800, sigma=15.0, modes=((
                        "batch) through OnlineRegionClassifier_incore.trainRegionClassifier" % (C, IT, positives, D)}
     for name, opts in modes:
         best = None
-        for rep in range(2):                      # the first repetition warms every kernel and allocation
+        for rep in range(3 if name in ("default", "class_batch4") else 2):     # the first repetition warms every kernel and allocation
             pos, neg = data()
             with redirect_stdout(io.StringIO()):
                 torch.manual_seed(7)
