@@ -17,6 +17,8 @@ No pretrained weights or datasets exist in this environment: weights are random 
 a state dict is given, and images come from the caller.  PARITY UNPINNED (structure only).
 """
 import contextlib
+import os
+import sys
 import math
 
 import torch
@@ -413,6 +415,83 @@ class Conv5Head(nn.Module):
         return self.forward_rows(xs.permute(0, 2, 3, 1).reshape(R * H * W, C), R, H, W)
 
 
+class GraphedCall:
+    """fn(x) replayed from a captured HIP graph, one graph per input (shape, dtype).
+
+    At batch 1 the frozen trunk is 120-170 dependent launches of 5-60 us: the host queues them barely faster than the GPU runs
+    them, and every gap is idle chip (R-50-C4 at 600 x 800: 2.06 ms launch by launch, 1.26 ms replayed; same kernels, same
+    order).  The graph owns its input and output buffers: the caller's tensor is copied in, the results are handed out as
+    copies, so nothing the caller holds is overwritten by the next replay.  Shapes are data here (aspect ratios differ between
+    images): at most `max_graphs` are kept, least recently used first out.  Whoever changes the weights behind fn calls
+    clear().  A capture that fails (an operation the runtime cannot capture) turns the wrapper into a plain call for good;
+    ODX_TRUNK_GRAPH=0 does the same from the environment."""
+
+    def __init__(self, fn, max_graphs=6):
+        import threading
+        self.fn, self.max_graphs = fn, max_graphs
+        self.graphs = {}
+        self.seen = {}                         # shape -> calls so far: a shape is captured at its SECOND call (a stream of images
+        # that all differ in size — capture costs three forwards — then simply runs launch by launch)
+        self.enabled = os.environ.get("ODX_TRUNK_GRAPH", "1") != "0"
+        self.lock = threading.Lock()           # the extractor's forward thread and the caller's may both come through here
+
+    def clear(self):
+        with self.lock:
+            self.graphs.clear()                 # (the shapes seen so far stay seen: the next call of one captures again)
+
+    def __getstate__(self):                     # a copied / pickled model starts without graphs (they are tied to this process's buffers)
+        return {"fn": self.fn, "max_graphs": self.max_graphs, "enabled": self.enabled}
+
+    def __setstate__(self, d):
+        import threading
+        self.fn, self.max_graphs, self.enabled = d["fn"], d["max_graphs"], d["enabled"]
+        self.graphs, self.seen, self.lock = {}, {}, threading.Lock()
+
+    def _capture(self, x):
+        static_in = x.clone()
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):           # the library picks its algorithms and the caches fill outside the capture
+            for _ in range(2):
+                self.fn(static_in)
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):     # (the extractor's other thread keeps allocating)
+            static_out = self.fn(static_in)
+        return graph, static_in, static_out
+
+    def __call__(self, x):
+        if not (self.enabled and x.is_cuda and not torch.is_grad_enabled()):
+            return self.fn(x)
+        key = (tuple(x.shape), x.dtype, x.device.index, torch.is_autocast_enabled("cuda"),
+               torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None)
+        with self.lock:
+            entry = self.graphs.pop(key, None)
+            if entry is None:
+                n = self.seen.get(key, 0)
+                if n < 1:
+                    if len(self.seen) > 256:
+                        self.seen.clear()
+                    self.seen[key] = n + 1
+                    return self.fn(x)
+                try:
+                    entry = self._capture(x)
+                except Exception as e:          # noqa: BLE001 — whatever the runtime refuses: the plain call is always right
+                    self.enabled = False
+                    print("odx: HIP graph capture of the trunk failed (%s: %s); running it launch by launch" % (type(e).__name__, e),
+                          file=sys.stderr)
+                    return self.fn(x)
+                while len(self.graphs) >= self.max_graphs:
+                    self.graphs.pop(next(iter(self.graphs)))
+            self.graphs[key] = entry             # (re-inserted last: most recently used)
+            graph, static_in, static_out = entry
+            static_in.copy_(x)
+            graph.replay()
+            return static_out.clone() if torch.is_tensor(static_out) else tuple(t.clone() for t in static_out)
+
+
 class OnlineDetectionModel(nn.Module):
     """backbone -> RPN -> (gt boxes prepended) -> RoIAlign -> conv5 head -> avg-pooled features."""
 
@@ -446,6 +525,17 @@ class OnlineDetectionModel(nn.Module):
         self.online_box = None          # odx.heads.OnlineBoxPredictor
         self.online_mask = None         # odx.heads.OnlineMaskPredictor
         self.mask_dim = mask_dim
+        self._trunk_graphs = GraphedCall(self._c4_eager)
+        self.register_load_state_dict_post_hook(OnlineDetectionModel._drop_graphs)
+
+    @staticmethod
+    def _drop_graphs(module, incompatible):
+        module._trunk_graphs.clear()
+
+    def _apply(self, fn, *a, **kw):
+        if "_trunk_graphs" in self.__dict__:
+            self._trunk_graphs.clear()          # (.to / .cuda / .half: the captured graphs point at the old tensors)
+        return super()._apply(fn, *a, **kw)
 
     @property
     def feat_dim(self):
@@ -456,11 +546,14 @@ class OnlineDetectionModel(nn.Module):
             return contextlib.nullcontext()
         return torch.autocast("cuda", dtype=self.compute_dtype)
 
-    @torch.no_grad()
-    def c4(self, image):
-        """(1, C, H/16, W/16) f32 trunk features."""
+    def _c4_eager(self, image):
         with self._amp():
             return self.backbone(image).float()
+
+    @torch.no_grad()
+    def c4(self, image):
+        """(1, C, H/16, W/16) f32 trunk features; on the GPU replayed from a HIP graph per image size (GraphedCall)."""
+        return self._trunk_graphs(image)
 
     def update_model(self, models_rpn=None, models_detection=None, models_segmentation=None):
         """Swap trained on-line models into the running pipeline, each a dict {'classifiers', 'regressors', 'stats'}

@@ -137,6 +137,8 @@ class OnlineDetectionModelFPN(nn.Module):
         self.online_mask = None
         self._packed = {}
         self._anchor_cache = {}
+        from .extract import GraphedCall
+        self._trunk_graphs = GraphedCall(self._c4_eager)
         # load_state_dict copies the parameters in place and never goes through _apply: the packed fc weights are derived
         # data of the OLD values then (the C4 network guards the same case in _FoldedBN)
         self.register_load_state_dict_post_hook(OnlineDetectionModelFPN._drop_derived)
@@ -145,10 +147,13 @@ class OnlineDetectionModelFPN(nn.Module):
     def _drop_derived(module, incompatible_keys):
         module._packed.clear()
         module._anchor_cache.clear()
+        module._trunk_graphs.clear()
 
     def _apply(self, fn, *a, **kw):
         self._packed.clear()
         self._anchor_cache.clear()                                  # packed fc weights are derived data
+        if "_trunk_graphs" in self.__dict__:
+            self._trunk_graphs.clear()                              # (the captured graphs point at the old tensors)
         return super()._apply(fn, *a, **kw)
 
     @property
@@ -163,6 +168,12 @@ class OnlineDetectionModelFPN(nn.Module):
     # ------------------------------------------------------------------ trunk
     @torch.no_grad()
     def c4(self, image):
+        """The pyramid of an image, on the GPU replayed from a HIP graph per image size (extract.GraphedCall: this forward is
+        host-bound at batch 1 — trunk + pyramid are ~170 launches and the proposal stage behind them synchronises with the
+        host per level, so the host never runs ahead)."""
+        return self._trunk_graphs(image)
+
+    def _c4_eager(self, image):
         """The trunk features of an image — here the pyramid (P2 .. P6) (the method keeps extract's name: the harvest loops
         call model.c4 / proposals / roi_head_maps on whatever the trunk hands out).  f32 maps; under a bf16 trunk the maps stay
         in bf16: the RPN head convolves them in bf16 anyway and the RoIAlign launch converts the four levels it pools from —

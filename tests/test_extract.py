@@ -620,3 +620,43 @@ def test_forward_gpu_equals_plain_torch_cpu():
     rel = float((feats.cpu() - feats_ref).norm(dim=1).max() / feats_ref.norm(dim=1).max())
     assert feats.shape == feats_ref.shape and rel < 1e-4, rel
     assert float((feats.cpu() - feats_ref).abs().max()) < 1e-4 * float(feats_ref.abs().max())
+
+
+@pytest.mark.gpu
+def test_trunk_replayed_from_a_graph_equals_the_launch_by_launch_trunk():
+    """OnlineDetectionModel.c4 replays the frozen trunk from a HIP graph per image size, captured at a size's second call: the
+    C4 map is the launch-by-launch one (to the convolution library's own run-to-run rounding); a second size gets its own graph,
+    the first is still right afterwards; the result is a copy (the next replay does not overwrite it); loading a checkpoint
+    drops the graphs; and the FPN model's pyramid goes the same way."""
+    import odx
+    from odx.extract import OnlineDetectionModel
+    from odx.fpn import OnlineDetectionModelFPN
+    odx.set_backend(None)
+    odx.get_backend()
+    dev = torch.device("cuda")
+    m = OnlineDetectionModel(width=16).to(dev).eval()
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.randn((1, 3, 160, 224), generator=g).to(dev), torch.randn((1, 3, 192, 160), generator=g).to(dev)
+
+    def close(x, y):
+        return float((x - y).abs().max()) <= 1e-4 * float(y.abs().max())
+    with torch.no_grad():
+        ref_a, ref_b = m._c4_eager(a), m._c4_eager(b)
+        first = m.c4(a)
+        assert len(m._trunk_graphs.graphs) == 0 and close(first, ref_a)          # a size's first call runs launch by launch
+        got_a, _, got_b = m.c4(a), m.c4(b), m.c4(b)
+        again_a = m.c4(a)
+        assert m._trunk_graphs.enabled and len(m._trunk_graphs.graphs) == 2
+        assert close(got_a, ref_a) and close(got_b, ref_b) and close(again_a, ref_a)
+        assert got_a.data_ptr() != again_a.data_ptr()                  # copies: got_a survived two more replays
+        other = OnlineDetectionModel(width=16, seed=5).to(dev).eval()
+        m.load_state_dict(other.state_dict())
+        assert len(m._trunk_graphs.graphs) == 0
+        new_a, want = m.c4(a), other._c4_eager(a)
+        assert close(new_a, want) and float((new_a - got_a).abs().max()) > 1e-3 * float(want.abs().max())     # NOT the old weights' map
+        f = OnlineDetectionModelFPN(width=16, fpn_channels=32, mlp_dim=64).to(dev).eval()
+        want = f._c4_eager(a)
+        f.c4(a)
+        got = f.c4(a)
+        assert len(f._trunk_graphs.graphs) == 1 and len(got) == len(want) == 5
+        assert all(close(x, y) for x, y in zip(got, want))

@@ -114,9 +114,9 @@ def forward_fpn_extra(height=600, width=800, reps=8):
         out["ms_per_image_" + name] = round(dt_s / reps * 1e3, 2)
         out["rois"], out["feature_dim"] = int(boxes.shape[0]), int(feats.shape[1])
         del model
-    out["note"] = ("f32 is the default and the faster form at batch 1: a 16-bit trunk (run natively, pyramid and RPN head kept in it, no "
-                   "casts around the split-core fc6 / fc7) shortens no stage of this forward — the convolution library's bf16 kernels "
-                   "for these shapes; no bf16 speed-up is claimed for the FPN forward")
+    out["note"] = ("trunk + pyramid replayed from a HIP graph per image size (extract.GraphedCall): launch by launch this forward was "
+                   "host-bound at batch 1 and a 16-bit trunk, whose kernels are shorter, gained nothing (5.1-6.4 ms against 5.0-5.3 in "
+                   "f32); replayed, the 16-bit trunk's device time is what counts")
     return out
 
 
