@@ -24,6 +24,7 @@ detect() take it unchanged; the on-line RPN and mask heads of the reference are 
 """
 import contextlib
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -236,17 +237,38 @@ class OnlineDetectionModelFPN(nn.Module):
         boxes_cat.clamp_(min=0)
         boxes_cat[:, 0::2].clamp_(max=img_size[0] - 1)
         boxes_cat[:, 1::2].clamp_(max=img_size[1] - 1)
-        kept = []
-        at = 0
-        for k in counts:
-            b, sc = boxes_cat[at:at + k], scores_cat[at:at + k]
-            if fast:
-                keep = be.nms(b, sc, self.rpn_nms, max_keep=self.post_nms_top_n, sorted_desc=True)
-            else:
-                keep = be.nms(b, sc, self.rpn_nms)[:self.post_nms_top_n]
-            kept.append(keep + at)
-            at += k
-        kept = torch.cat(kept)
+        if hasattr(be, "nms_batched") and boxes_cat.is_cuda and len(counts) > 1:
+            # the suppression of all levels with ONE launch pair and ONE host synchronisation (odx_nms_batched_f32: independent
+            # sorted box sets, sizes on the device) instead of a launch pair and a synchronisation per level — this stage is
+            # what kept the host from running ahead of the GPU; "the first post_nms_top_n survivors" of a level are the same
+            # boxes whether the greedy pass stops there or runs to the end
+            B, Rmax = len(counts), max(counts)
+            padded = torch.zeros((B, Rmax, 4), dtype=torch.float32, device=boxes_cat.device)
+            at = 0
+            for lvl, k in enumerate(counts):
+                padded[lvl, :k] = boxes_cat[at:at + k]
+                at += k
+            meta = self._anchor_cache.get(("nms_meta", tuple(counts), boxes_cat.device))
+            if meta is None:
+                offs = np.concatenate(([0], np.cumsum(counts)[:-1]))
+                meta = self._anchor_cache[("nms_meta", tuple(counts), boxes_cat.device)] = (
+                    torch.tensor(counts, dtype=torch.int32, device=boxes_cat.device),
+                    torch.from_numpy(offs).to(boxes_cat.device).view(B, 1) + torch.arange(Rmax, device=boxes_cat.device).view(1, Rmax))
+            keep = be.nms_batched(padded, meta[0], self.rpn_nms)
+            keep &= keep.cumsum(1) <= self.post_nms_top_n
+            kept = meta[1].masked_select(keep)                  # level after level, descending score inside a level
+        else:
+            kept = []
+            at = 0
+            for k in counts:
+                b, sc = boxes_cat[at:at + k], scores_cat[at:at + k]
+                if fast:
+                    keep = be.nms(b, sc, self.rpn_nms, max_keep=self.post_nms_top_n, sorted_desc=True)
+                else:
+                    keep = be.nms(b, sc, self.rpn_nms)[:self.post_nms_top_n]
+                kept.append(keep + at)
+                at += k
+            kept = torch.cat(kept)
         boxes, scores = boxes_cat[kept], scores_cat[kept]
         k = min(self.fpn_post_nms_top_n, scores.numel())
         top, order = scores.topk(k, sorted=True)
