@@ -529,11 +529,13 @@ struct EpiF16 {
 
 template <typename E>
 __global__ __launch_bounds__(256) void bias_act_nchw_kernel(typename E::T* __restrict__ y, const typename E::T* __restrict__ bias,
-                                                            const typename E::T* __restrict__ res, int C, int64_t HW, int relu, int vec) {
+                                                            const typename E::T* __restrict__ res, int64_t planes, int C, int64_t HW, int relu,
+                                                            int vec) {
   typedef typename E::T T;
   constexpr int V = E::V;                 // elements per 16 bytes
   typedef T VecT __attribute__((ext_vector_type(V)));
-  const int64_t plane = blockIdx.y;
+  // (a grid's y extent stops at 65535: 300 RoIs x 512 channels of the conv5 head are 153 600 planes — a workgroup row walks them)
+  for (int64_t plane = blockIdx.y; plane < planes; plane += gridDim.y) {
   const float b = E::load(bias + plane % C);
   T* yp = y + plane * HW;
   const T* rp = res ? res + plane * HW : nullptr;
@@ -558,6 +560,7 @@ __global__ __launch_bounds__(256) void bias_act_nchw_kernel(typename E::T* __res
   } else {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.x * 256) one(yp + i, rp ? rp + i : nullptr);
   }
+  }
 }
 
 template <typename E>
@@ -565,14 +568,14 @@ static int bias_act_nchw(void* y, const void* bias, const void* residual, int64_
                          const char* who) {
   if (N <= 0 || C <= 0 || HW <= 0) return ODX_OK;
   ODX_REQUIRE(y && bias, "%s: null pointer", who);
-  ODX_REQUIRE(N * C < 65536, "%s: too many planes (N C must stay below 65536)", who);
+  const int64_t planes = N * C;
   const int vec = (HW * (int64_t)sizeof(typename E::T)) % 16 == 0 && aligned16(y) && (!residual || aligned16(residual));
   const int64_t per = vec ? HW / E::V : HW;
   int64_t gx = ceil_div(per, 256);
   if (gx > 64) gx = 64;
   typedef typename E::T T;
-  hipLaunchKernelGGL((bias_act_nchw_kernel<E>), dim3((unsigned)gx, (unsigned)(N * C)), dim3(256), 0, as_stream(stream), static_cast<T*>(y),
-                     static_cast<const T*>(bias), static_cast<const T*>(residual), C, HW, relu, vec);
+  hipLaunchKernelGGL((bias_act_nchw_kernel<E>), dim3((unsigned)gx, (unsigned)(planes < 65535 ? planes : 65535)), dim3(256), 0, as_stream(stream),
+                     static_cast<T*>(y), static_cast<const T*>(bias), static_cast<const T*>(residual), planes, C, HW, relu, vec);
   ODX_CHECK_LAUNCH(who);
   return ODX_OK;
 }

@@ -698,6 +698,28 @@ class HipBackend:
                                                1.0, 0.0, 0, self._stream()), "odx_gemm_nt_f32")
         return out
 
+    def gemm_nt_f64(self, A, B):
+        """(m, n) f64 = A (m, k) @ B (n, k)' on the f64 matrix cores (odx_gemm_nt_f64); the result's rows are an even number
+        of doubles apart (what the RLS solve asks of its operands): returns the (m, n) view of an (m, ldn) block."""
+        A, B = (t.to(device=self.device, dtype=torch.float64) for t in (A, B))
+        m, k = A.shape
+        n = B.shape[0]
+        if B.shape[1] != k:
+            raise ValueError("gemm_nt_f64: inner dimensions differ (%d, %d)" % (k, B.shape[1]))
+
+        def even(t):
+            if t.stride(1) == 1 and t.stride(0) % 2 == 0 and t.data_ptr() % 16 == 0:
+                return t
+            buf = torch.zeros((t.shape[0], (t.shape[1] + 1) // 2 * 2), dtype=torch.float64, device=self.device)
+            buf[:, :t.shape[1]] = t
+            return buf[:, :t.shape[1]]
+        A, B = even(A), even(B)
+        out = torch.zeros((m, (n + 1) // 2 * 2), dtype=torch.float64, device=self.device)
+        if m and n and k:
+            hip.check(self.lib.odx_gemm_nt_f64(_p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), m, n, k, 1.0, 0.0, 0,
+                                               self._stream()), "odx_gemm_nt_f64")
+        return out[:, :n]
+
     # ------------------------------------------------------------------ feature-forward ops (A11)
     def roi_align(self, feat, rois, spatial_scale, output_size, sampling_ratio=0):
         """maskrcnn_benchmark.layers.ROIAlign forward: feat (N, C, H, W) f32, rois (R, 5)."""

@@ -31,12 +31,50 @@ def _rows(be, X):
     return be.row_matrix(X) if hasattr(be, "row_matrix") else be.features(X)
 
 
+def sym_eig_small(S):
+    """Eigen-decomposition of a batch of small symmetric matrices S (B, k, k) — the 4 x 4 target covariances of
+    train_region_refiner.py:63 — by cyclic Jacobi rotations in f64 on the host: (evals (B, k), V (B, k, k)) with
+    S = V diag(evals) V', eigenvalues in no particular order (T = V diag(.) V' does not depend on it, nor on the vectors'
+    signs).  k (k - 1) / 2 rotations per sweep, quadratic convergence: a 4 x 4 matrix is diagonal to rounding after 4-6
+    sweeps; written out here because a solver library's launch + synchronisation per batch costs more than the arithmetic."""
+    A = np.array(S.detach().cpu().numpy(), dtype=np.float64, copy=True)
+    single = A.ndim == 2
+    if single:
+        A = A[None]
+    B, k, _ = A.shape
+    V = np.broadcast_to(np.eye(k), (B, k, k)).copy()
+    scale = np.maximum(np.abs(A).max(axis=(1, 2)), np.finfo(np.float64).tiny)
+    for _ in range(30):
+        off = np.abs(A - np.einsum("bii->bi", A)[:, :, None] * np.eye(k)).max(axis=(1, 2))
+        if not np.any(off > 1e-300 + 1e-17 * scale):
+            break
+        for p in range(k - 1):
+            for q in range(p + 1, k):
+                apq = A[:, p, q]
+                live = np.abs(apq) > 1e-300
+                safe = np.where(live, apq, 1.0)
+                theta = (A[:, q, q] - A[:, p, p]) / (2.0 * safe)
+                t = np.where(theta >= 0, 1.0, -1.0) / (np.abs(theta) + np.hypot(theta, 1.0))
+                t = np.where(live, t, 0.0)
+                c = 1.0 / np.sqrt(t * t + 1.0)
+                sn = t * c
+                Ap, Aq = A[:, :, p].copy(), A[:, :, q].copy()                    # columns
+                A[:, :, p], A[:, :, q] = c[:, None] * Ap - sn[:, None] * Aq, sn[:, None] * Ap + c[:, None] * Aq
+                Ap, Aq = A[:, p, :].copy(), A[:, q, :].copy()                    # rows
+                A[:, p, :], A[:, q, :] = c[:, None] * Ap - sn[:, None] * Aq, sn[:, None] * Ap + c[:, None] * Aq
+                Vp, Vq = V[:, :, p].copy(), V[:, :, q].copy()
+                V[:, :, p], V[:, :, q] = c[:, None] * Vp - sn[:, None] * Vq, sn[:, None] * Vp + c[:, None] * Vq
+    evals = np.einsum("bii->bi", A).copy()
+    ev, Vt = torch.from_numpy(evals).to(S.device), torch.from_numpy(V).to(S.device)
+    return (ev[0], Vt[0]) if single else (ev, Vt)
+
+
 def whiten_targets(Yi):
     """mu, T, T_inv (f64) of train_region_refiner.py:61-67 for targets Yi (n, 4) f64."""
     mu = torch.mean(Yi, dim=0)
     Yc = Yi - mu
     S = torch.matmul(Yc.t(), Yc) / Yc.size()[0]
-    evals, W = torch.linalg.eigh(S)     # S is symmetric: same T as the reference's general eig
+    evals, W = sym_eig_small(S)         # S is symmetric: same T as the reference's general eig
     root = torch.sqrt(evals + 0.001)
     T = W @ torch.diag(1.0 / root) @ W.t()
     T_inv = W @ torch.diag(root) @ W.t()
@@ -164,8 +202,7 @@ class RegionRefinerTrainer:
                     mus.append(mu), Ycs.append(Yc), Ss.append(S)
                 S_all = torch.stack(Ss)
             # (on the host: 4 x 4 matrices — the GPU solver costs ~8 ms for the batch, mostly launch + synchronisation)
-            evals, Wv = torch.linalg.eigh(S_all.cpu())
-            evals, Wv = evals.to(S_all.device), Wv.to(S_all.device)
+            evals, Wv = sym_eig_small(S_all)
             root = torch.sqrt(evals + 0.001)
             Ts = Wv @ torch.diag_embed(1.0 / root) @ Wv.transpose(1, 2)
             Tis = Wv @ torch.diag_embed(root) @ Wv.transpose(1, 2)
@@ -357,13 +394,30 @@ class RegionRefinerTrainer:
                 out[str(k)] = {'weights': W_all[k, :D1].to(dev).type(torch.float32),
                                'losses': (0.5 * (P[:, k] - Ysub[:, k]) ** 2).type(torch.float32)}
             return out
-        X64, y64 = X.to(torch.float64), y.to(torch.float64)
+        # any other matrix (rows that are not f32-exact, no column of ones): the same normal equations through the library's
+        # f64 kernels — Gram and X'y on the f64 matrix cores (odx_gemm_nt_f64), Cholesky + the four solves (odx_rls_solve_f64),
+        # the predictions by one more product.  No vendor BLAS / solver on this path either.
+        if not hasattr(be, "gemm_nt_f64"):
+            raise RuntimeError("RegionRefinerTrainer.solve: the backend offers no f64 solve for a general design matrix")
+        xdev = be.device
+        X64, y64 = X.to(xdev, torch.float64), y.to(xdev, torch.float64)
+        W, P, Ysub = None, None, None
         for k in range(4):
-            Xs, ys = (X64, y64) if indices is None else (X64[indices[k]], y64[indices[k]])
-            R = torch.linalg.cholesky(Xs.t() @ Xs + lmbd * torch.eye(D1, device=Xs.device, dtype=torch.float64))
-            z = torch.linalg.solve_triangular(R, (Xs.t() @ ys[:, k]).view(D1, 1), upper=False)
-            w = torch.linalg.solve_triangular(R.t(), z, upper=True).view(D1)
-            out[str(k)] = {'weights': w.to(dev).type(torch.float32), 'losses': (0.5 * (Xs @ w - ys[:, k]) ** 2).type(torch.float32)}
+            if indices is not None or W is None:
+                if indices is None:
+                    Xs, Ysub = X64, y64
+                else:
+                    I = torch.as_tensor(indices[k]).to(xdev)
+                    Xs, Ysub = X64[I], y64[I]
+                Xt = Xs.t().contiguous()                                              # (D1, n_k)
+                G = be.gemm_nt_f64(Xt, Xt)                                            # X'X  (D1, D1)
+                XtY = be.gemm_nt_f64(Ysub.t().contiguous(), Xt)                       # (4, D1)
+                W, info = be.rls_solve(G, D1 - 1, lmbd, XtY)                          # (views of even-stride blocks)
+                if int(info.item()) != 0:
+                    raise RuntimeError('RLS Cholesky failed (pivot %d)' % (int(info.item()) - 1))
+                P = be.gemm_nt_f64(Xs, W[:, :D1])                                     # (n_k, 4)
+            out[str(k)] = {'weights': W[k, :D1].to(dev).type(torch.float32),
+                           'losses': (0.5 * (P[:, k] - Ysub[:, k]) ** 2).type(torch.float32)}
         return out
 
     def _whiten_sharded(self, Yi, n_tot):
@@ -375,7 +429,7 @@ class RegionRefinerTrainer:
         S = torch.matmul(Yc.t(), Yc)
         self.shard.allreduce(S)
         S = S / n_tot
-        evals, W = torch.linalg.eigh(S)
+        evals, W = sym_eig_small(S)
         root = torch.sqrt(evals + 0.001)
         return mu, Yc, W @ torch.diag(1.0 / root) @ W.t(), W @ torch.diag(root) @ W.t()
 

@@ -128,7 +128,7 @@ def conjugate_gradient(B, mmv, max_iter, dtype, cg_epsilon=None, cg_tolerance=CG
 def falkon_fit(X, y, center_idx, sigma, lam, maxiter=20, dtype=None, pc_eps=None,
                cg_epsilon=None, cg_tolerance=CG_TOLERANCE,
                full_gradient_every=CG_FULL_GRADIENT_EVERY, store_knm=True,
-               row_block=8192, trace=None, allreduce=None):
+               row_block=8192, trace=None, allreduce=None, knm=None):
     """InCoreFalkon(kernel=GaussianKernel(sigma), penalty=lam, M=len(center_idx),
     maxiter=maxiter, center_selection=MyCenterSelector(center_idx)).fit(X, y)
     (FALKONWrapper_with_centers_selection_incore.py:58-68).
@@ -137,6 +137,8 @@ def falkon_fit(X, y, center_idx, sigma, lam, maxiter=20, dtype=None, pc_eps=None
     ``allreduce`` (optional) sums an (M, T) array over row shards: with it, X/y are one
     shard and ``n_total`` rows is obtained by all-reducing the local count (used by the
     world_size>1 tests; the reference itself is single-process).
+    ``knm`` (optional): the stored K_nM block to iterate on instead of gaussian_kernel(X, Z) — for storage formats that
+    round the entries (bf16 / fp8 throughput variants): the oracle then states what the SOLVER must produce on that block.
     """
     dtype = np.dtype(dtype or X.dtype)
     X = np.asarray(X, dtype=dtype)
@@ -147,12 +149,12 @@ def falkon_fit(X, y, center_idx, sigma, lam, maxiter=20, dtype=None, pc_eps=None
     n = n_local if allreduce is None else int(allreduce(np.array([[float(n_local)]]))[0, 0])
     Z = np.ascontiguousarray(X[np.asarray(center_idx, dtype=np.int64)]) if center_idx is not None else None
     return falkon_fit_centers(X, Y, Z, sigma, lam, n, maxiter, dtype, pc_eps, cg_epsilon, cg_tolerance,
-                              full_gradient_every, store_knm, row_block, trace, allreduce)
+                              full_gradient_every, store_knm, row_block, trace, allreduce, knm)
 
 
 def falkon_fit_centers(X, Y, Z, sigma, lam, n, maxiter=20, dtype=None, pc_eps=None, cg_epsilon=None,
                        cg_tolerance=CG_TOLERANCE, full_gradient_every=CG_FULL_GRADIENT_EVERY,
-                       store_knm=True, row_block=8192, trace=None, allreduce=None):
+                       store_knm=True, row_block=8192, trace=None, allreduce=None, knm=None):
     dtype = np.dtype(dtype or X.dtype)
     X = np.asarray(X, dtype=dtype)
     Y = np.asarray(Y, dtype=dtype)
@@ -164,7 +166,11 @@ def falkon_fit_centers(X, Y, Z, sigma, lam, n, maxiter=20, dtype=None, pc_eps=No
     nn = dtype.type(n)
     lam_t = dtype.type(lam)
 
-    Knm = gaussian_kernel(X, Z, sigma, dtype) if store_knm else None
+    if knm is not None:
+        Knm = np.asarray(knm, dtype=dtype)
+        assert Knm.shape == (X.shape[0], Z.shape[0])
+    else:
+        Knm = gaussian_kernel(X, Z, sigma, dtype) if store_knm else None
 
     def ktk(v, w=None):
         """K_nM' (K_nM v + w) summed over row shards."""

@@ -187,6 +187,9 @@ class OracleBackend:
                       for k in range(4)])
         return torch.from_numpy(W), torch.zeros(1, dtype=torch.int32)
 
+    def gemm_nt_f64(self, A, B):
+        return A.double() @ B.double().t()
+
     def rls_predict_rows(self, F, idx, W):
         X = (F.X if idx is None else F.X[idx]).double()
         return X @ W[:, :-1].t() + W[:, -1]

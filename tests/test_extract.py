@@ -37,6 +37,29 @@ def test_conv5_head_as_row_gemms_equals_the_convolutions(device):
     assert head(torch.empty((0, 64, 14, 14), device=device)).shape[0] == 0
 
 
+@pytest.mark.gpu
+def test_conv5_head_convolution_form_at_300_rois():
+    """The stage as convolutions on the reference's 300 RoIs per image: 300 x 256 mid channels = 76 800 (n, c) planes go
+    through the trunk's bias / ReLU epilogue, more than a grid's y extent holds (advisor, round 4: the kernel refused
+    N C >= 65536 and the 7-RoI test never saw it) — same numbers as the row-GEMM form."""
+    from odx.extract import Conv5Head
+    odx.set_backend(None)
+    torch.manual_seed(1)
+    head = Conv5Head(512).eval()
+    for m in head.modules():
+        if hasattr(m, "running_var"):
+            m.running_var.uniform_(0.5, 1.5)
+            m.running_mean.normal_()
+            m.weight.data.normal_(1, 0.1)
+            m.bias.data.normal_()
+    head = head.cuda()
+    x = torch.randn((300, 512, 14, 14), device="cuda")
+    with torch.no_grad():
+        a, b = head.forward_conv(x), head(x)
+    assert a.shape == b.shape == (300, 1024, 7, 7)
+    assert float((a - b).abs().max()) < 5e-5 * max(1.0, float(a.abs().max()))
+
+
 def test_cell_anchors_follow_the_detectron_enumeration():
     a = cell_anchors(16)
     assert a.shape == (15, 4)

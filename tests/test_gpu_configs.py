@@ -59,6 +59,61 @@ def test_config2_thirty_classes_n1e5_m2000(be):
         assert np.abs(scores[rows, c].cpu().numpy() - pref[:, 0]).max() < 1e-4
 
 
+def test_config2_as_stated_bf16_stored_knm(be):
+    """Config 2 AS STATED (K_nM stored as bf16; throughput only — bf16 entries move alpha by 1e-2 .. 6e-1 against the
+    f32-accurate fit, tools/precision_storage_study.py) at its own size, N = 1e5, D = 1024, M = 2000: (i) the stored block is,
+    entry for entry, the round-to-nearest-even bf16 of the f32 block the default build stores; (ii) the fit on it — fused
+    right-hand side, the compact-format pass kernels, the class-batched chain and lock-step CG — gives the alpha the f64
+    oracle gives when it iterates on that SAME rounded block (oracle/falkon_ref.falkon_fit(knm=...)): 1e-4 relative;
+    (iii) scores of those alphas against the oracle's (the fused scoring kernel recomputes K at f32 accuracy, as
+    FALKONWrapper.predict does whatever the fit stored)."""
+    import odx
+    from odx.solver import SolverOptions
+    from oracle import falkon_ref as fr
+    n, D, M, C, sigma, lam = 100_000, 1024, 2000, 30, 15.0, 1e-5
+    X, rng = _blobs(n, D, C, seed=1234 + 2)
+    F = be.features(torch.from_numpy(X))
+    cls = np.arange(n) % C
+    run = (0, 17)
+    ys = [np.where(cls == c, 1.0, -1.0) for c in run]
+    idx = [fr.compute_indices_selection(y, M, lambda high, size: rng.integers(0, high, size)) for y in ys]
+    Zfs = [be.rows(F, i) for i in idx]
+    old = be.knm_storage
+    try:
+        be.knm_storage = "f32"
+        K32 = be.knm(F, Zfs[0], sigma).dense()
+        want0 = K32.to(torch.bfloat16)
+        del K32
+        be.knm_storage = "bf16"
+        assert be.knm_format(n, M) == "bf16"
+        opt = SolverOptions(check_pivots=False)
+        Ps = be.precond_batched(Zfs, sigma, lam, opt.pc_epsilon)
+        b0s = torch.zeros((len(run), M), dtype=torch.float64, device="cuda")
+        Ks = [be.knm_rhs(F, Zfs[k], sigma, torch.from_numpy(ys[k]).cuda() * (1.0 / n), rhs_out=b0s[k])[0] for k in range(len(run))]
+        assert all(K.fmt == "bf16" for K in Ks)
+        stored = [K.dense().cpu().numpy().astype(np.float64) for K in Ks]
+        assert torch.equal(Ks[0].dense().to(torch.bfloat16), want0)                         # (i)
+        assert be.cg_batched_supported([n] * len(run), [M] * len(run), "bf16")
+        alphas = be.cg_solve_batched(Ks, Ps, b0s, [n] * len(run), lam, 20, opt).cpu().numpy()
+        one = odx.falkon_fit(be, F, be.vec(ys[1].astype(np.float32)), Zfs[1], sigma, lam, 20, opt).cpu().numpy()     # a batch of one
+    finally:
+        be.knm_storage = old
+    Xd = X.astype(np.float64)
+    rows = np.arange(0, n, 997)
+    for k in range(len(run)):
+        ref, Z = fr.falkon_fit(Xd, ys[k], idx[k], sigma, lam, maxiter=20, dtype=np.float64, pc_eps=1e-5, cg_epsilon=1e-7, knm=stored[k])
+        rel = np.linalg.norm(alphas[k, :M] - ref[:, 0]) / np.linalg.norm(ref[:, 0])
+        print("config 2, bf16-stored K_nM, class %d: alpha rel err vs the oracle on the same block %.2e" % (run[k], rel))
+        assert rel < 1e-4, (run[k], rel)                                                    # (ii)
+        if k == 1:
+            assert np.linalg.norm(one - ref[:, 0]) / np.linalg.norm(ref[:, 0]) < 1e-4
+        got = be.mmv(be.features(torch.from_numpy(X[rows])), Zfs[k], sigma, torch.from_numpy(alphas[k, :M])).cpu().numpy()
+        pref = fr.falkon_predict(Xd[rows], Z, ref, sigma)
+        assert np.abs(got - pref).max() < 1e-4 * max(1.0, float(np.abs(pref).max()))       # (iii)
+    be.release_workspaces()
+    torch.cuda.empty_cache()
+
+
 def test_headline_kernels_alpha_at_m1e4(be):
     """alpha of the headline's OWN kernels at the headline's own width (round-3 review, item 1): bench.py's synthetic job
     (same generator, centre rule, sigma = 15, lambda = 1e-5, 20 CG steps) at N = 1e5, D = 1024, **M = 1e4**, storage left on

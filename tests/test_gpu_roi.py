@@ -87,7 +87,8 @@ def test_roi_align_rows_is_the_strided_subset_of_the_grid():
         assert torch.equal(rows.view(R, OH, OW, -1).permute(0, 3, 1, 2), ref)
 
 
-@pytest.mark.parametrize("N,C,H,W", [(1, 64, 150, 200), (2, 7, 19, 25), (1, 3, 1, 1), (1, 256, 38, 50)])
+@pytest.mark.parametrize("N,C,H,W", [(1, 64, 150, 200), (2, 7, 19, 25), (1, 3, 1, 1), (1, 256, 38, 50),
+                                     (300, 512, 7, 7), (70001, 1, 2, 3), (64, 1024, 4, 4)])     # > 65535 planes (advisor, round 4)
 @pytest.mark.parametrize("with_res", [False, True])
 @pytest.mark.parametrize("relu", [False, True])
 @pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
