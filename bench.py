@@ -326,12 +326,10 @@ def main():
         p2_ms, p2_n = ph["ktk2"].total_ms(), ph["ktk2"].count()
         pass_ms, pass_launches = p1_ms + p2_ms, p1_n + p2_n
         bytes_per_pass = float(be.knm_bytes(n_loc, M))      # the stored shard, read exactly once per launch (n M s_K)
-        if kfmt == "f32":
-            pk = ("knm_pass_kernel", "knm_pass2_kernel")
-        elif (8192 < M <= 10240 or 1024 < M <= 4096) and not os.environ.get("ODX_PASSQ_NO_STAGGER") and not os.environ.get("ODX_PASSQ_CFG"):
-            pk = ("knm_passq_stag_kernel", "knm_passq_kernel<NV=2>")      # one vector: two free-running halves per workgroup
-        else:
-            pk = ("knm_passq_kernel<NV=1>", "knm_passq_kernel<NV=2>")
+        # the pass kernels' names as rocprofv3 lists them: asked of the library (its own dispatch rule), not restated here
+        from odx import hip as _hip
+        kcode = {"f32": _hip.KNM_F32, "u24": _hip.KNM_U24, "bf16": _hip.KNM_BF16}[kfmt]
+        pk = tuple((be.lib.odx_knm_pass_kernel_name(M, kcode, nv) or b"").decode() or "knm_pass(no configuration, nv=%d)" % nv for nv in (1, 2))
         gach = flops_per_launch * gauss_launches / max(gauss_ms * 1e-3, 1e-12) / 1e12
 
         def per_kernel(ms, cnt, unit_work, scale):
@@ -367,8 +365,18 @@ def main():
                               "launch counts its ONE read of K_nM), where %d CUs are left to the preconditioner stream; "
                               "achieved_alone: the one-vector kernel, same buffer, idle GPU, before the timed region" % args.reserve_cus)
         if (n_loc, M, D) == (1_000_000, 10_000, 1024):
+            # HBM traffic per launch, PER KERNEL (round-4 review: a median over both members of a family describes neither): each
+            # kernel's own figure sits beside its launches; the family's `traffic` is that of its member with more device time
             for r in (roof_g, roof_p):
-                r["traffic"], r["traffic_unit"] = profiled_traffic_gb(r["kernel"])
+                best = None
+                for kname, pkd in r["per_kernel"].items():
+                    if pkd is None:
+                        continue
+                    pkd["traffic_GB_per_launch"], unit = profiled_traffic_gb(kname)
+                    if pkd["traffic_GB_per_launch"] is not None and (best is None or pkd["launches"] * pkd["avg_launch_ms"] > best[0]):
+                        best = (pkd["launches"] * pkd["avg_launch_ms"], kname, pkd["traffic_GB_per_launch"], unit)
+                if best is not None:
+                    r["traffic"], r["traffic_unit"] = best[2], "%s of %s" % (best[3], best[1])
         kernel_ms = {pk[0]: p1_ms, pk[1]: p2_ms, gk[0]: ph["knm"].total_ms(), gk[1]: ph["mmv"].total_ms()}
         dominant = max(kernel_ms, key=kernel_ms.get)
         # `roofline` = the kernel FAMILY with more measured device time in this run's timed region (round-3 review: the single
@@ -446,8 +454,20 @@ def main():
         sys.exit(4)
 
 
+def _same_kernel(name, profiled):
+    """Whether the profiler's kernel name (namespace, `void`, spaces after commas, argument list) is the kernel `name`
+    (`knm_passq_stag_kernel<10,2,1>`; a name without template arguments matches every instantiation)."""
+    import re
+    m = re.search(r"(?:\w+::)*(\w+)(<[^(]*>)?", profiled.replace("void ", "").strip())
+    if not m:
+        return False
+    base, targs = m.group(1), (m.group(2) or "").replace(" ", "")
+    want = name.replace(" ", "")
+    return want == base + targs or ("<" not in want and want == base)
+
+
 def profiled_traffic_gb(kernel_names):
-    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC passes
+    """HBM bytes per launch of ONE kernel from the newest committed rocprofv3 PMC passes
     (profiles/rNN_pmc_*: the counters cannot be read from inside this process): FETCH_SIZE (KiB, doubled per the gfx950
     correction of the guide) + WRITE_SIZE (KiB), median over the profiled launches at this same shard shape.  The file
     stem the number came from is named in the unit string.  None if absent."""
@@ -465,7 +485,7 @@ def profiled_traffic_gb(kernel_names):
             if not os.path.exists(path):
                 break
             vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
-                    if r["Counter_Name"] == counter and any(k.split("<")[0] in r["Kernel_Name"] for k in kernel_names.split("+"))]
+                    if r["Counter_Name"] == counter and _same_kernel(kernel_names, r["Kernel_Name"])]
             if vals:
                 found += 1
                 tot += mult * 1024.0 * statistics.median(vals)

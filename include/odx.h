@@ -149,6 +149,10 @@ int64_t odx_knm_fwd_bwd2_workspace_bytes(int64_t n, int64_t M);
 int odx_knm_fwd_bwd2(const float* K, int64_t ldk, int64_t n, int64_t M, const double* v, const double* v2,
                      double* out, double* out2, void* workspace, int64_t workspace_bytes, odx_stream_t stream);
 
+/* Name of the kernel (as rocprofv3 lists it) a pass over a block of M columns stored as `fmt` launches, nv = 1 (one vector)
+ * or 2 (two vectors from one read): the library's own dispatch rule, for tools that label measurements.  "" if no
+ * configuration covers the shape.  The string lives in thread-local storage until the thread's next call.  */
+const char* odx_knm_pass_kernel_name(int64_t M, int fmt, int nv);
 /* ---------------------------------------------------------------- A4: compact storage of the stored K_nM
  * The CG passes above are HBM-bound at the chip's copy rate, so their time is the bytes per entry of the stored block
  * (falkon keeps it in the data's dtype: f32, FALKONWrapper_with_centers_selection_incore.py:56-68; config/defaults.py:466).
@@ -412,6 +416,17 @@ int odx_split_f16_taps3x3(const float* Y, int64_t ldy, int64_t R, int H, int W, 
 int odx_gemm_h2_f32(const void* PA, int64_t ldpa, const float* metaa, int64_t m, const void* PB, int64_t ldpb,
                     const float* metab, int64_t n, int K, const float* bias, const float* residual, int64_t ldr,
                     int relu, float* out, int64_t ldo, odx_stream_t stream);
+/* The same layers for a forward run in a 16-bit type (BASELINE config 2's bf16; the reference's own dtype is f32,
+ * config/defaults.py:466): out (m x n) = act(A B' + bias[col] + residual) for plain row-major bf16 (is_bf16 = 1) or f16
+ * operands A (m x K), B (n x K) — lda / ldb in ELEMENTS, multiples of 8, >= roundup(K, 128), the elements beyond K zero;
+ * 16-byte aligned.  One MFMA term per product (v_mfma_f32_16x16x32_bf16 / _f16), sums in f32; bias f32; out / residual are
+ * f32 (out_16 = 0) or the operands' type (out_16 = 1: bias and residual are added in f32, ONE rounding).  */
+int odx_gemm_b16(const void* A, int64_t lda, int64_t m, const void* B, int64_t ldb, int64_t n, int K, int is_bf16,
+                 const float* bias, const void* residual, int64_t ldr, int relu, void* out, int64_t ldo, int out_16,
+                 odx_stream_t stream);
+/* odx_split_f16_taps3x3 for 16-bit rows: P ((R H W) x ldp elements, ldp % 8 == 0, ldp >= 9 C) = the 3 x 3 neighbourhood
+ * matrix of Y ((R H W) x C, C % 8 == 0, ldy % 8 == 0), zeros outside the map and beyond 9 C: the operand of odx_gemm_b16.  */
+int odx_taps3x3_16(const void* Y, int64_t ldy, int64_t R, int H, int W, int C, void* P, int64_t ldp, odx_stream_t stream);
 /* The same bins for a consumer that starts with a stride-`step` 1 x 1 convolution (ResNet50Conv5ROIFeatureExtractor's
  * head, roi_box_feature_extractors.py:26-52 with STRIDE_IN_1X1): only the bins (ph, pw) with ph % step == pw % step == 0,
  * as rows of an (R * ceil(PH / step) * ceil(PW / step), C) matrix (NHWC) — a quarter of the grid at 14 x 14, step 2.  */
@@ -445,6 +460,11 @@ int odx_nms_first_f32(const float* boxes_sorted, int R, float iou_threshold, int
 int64_t odx_nms_batched_workspace_bytes(int Rmax, int B);
 int odx_nms_batched_f32(const float* boxes_sorted, const int32_t* counts, int Rmax, int B, float iou_threshold,
                         unsigned char* keep, void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+/* odx_nms_batched_f32 with at most max_keep (> 0) survivors per set, the first ones in score order: the RPN proposals of a
+ * batch of images (one set per image) with one launch pair (rpn/inference.py:116-121 per image).  */
+int odx_nms_batched_first_f32(const float* boxes_sorted, const int32_t* counts, int Rmax, int B, float iou_threshold,
+                              int max_keep, unsigned char* keep, void* workspace, int64_t workspace_bytes,
+                              odx_stream_t stream);
 
 /* Masker / paste_mask_in_image (mrcnn_modified/modeling/roi_heads/mask_head/inference.py:119-191), all detections
  * of one image at once: masks (R, S, S) f32 probabilities, boxes (R, 4) xyxy f32 -> out (R, im_h, im_w) u8 0/1:

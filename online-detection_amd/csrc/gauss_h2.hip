@@ -187,6 +187,13 @@ __device__ __forceinline__ void s16_store_operand(const u32x4 (&r)[8], char* lds
   for (int p = 0; p < 8; ++p) *reinterpret_cast<u32x4*>(d + 16 * p * S16_ROW) = r[p];
 }
 
+// CORE (declared with the wide core below): S16_H2 = two-term f16 splits, three MFMAs per product block; S16_BF16 / S16_F16 =
+// plain 16-bit operands (a 256-byte LDS row is 128 features: the "hi" and "lo" chunks of a lane are simply two 8-feature
+// pieces of its row, the same ones for A and B), two MFMAs per product block and k-group.
+enum { S16_H2 = 0, S16_BF16 = 2, S16_F16 = 3 };
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int CORE = S16_H2>
 __device__ __forceinline__ void s16_compute_ktile(f32x4 (&acc)[4][4], const char* ldsA, const char* ldsB, int wr, int wc,
                                                   int lane) {
   const int r = lane & 15, g = lane >> 4;
@@ -207,13 +214,24 @@ __device__ __forceinline__ void s16_compute_ktile(f32x4 (&acc)[4][4], const char
     for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) {
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+        if (CORE == S16_BF16) {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[tm]), __builtin_bit_cast(bf16x8, bh[tn]),
+                                                                acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[tm]), __builtin_bit_cast(bf16x8, bl[tn]),
+                                                                acc[tm][tn], 0, 0, 0);
+        } else if (CORE == S16_F16) {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+        } else {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+        }
       }
   }
 }
 
+template <int CORE = S16_H2>
 __device__ __forceinline__ void s16_mainloop(f32x4 (&acc)[4][4], const uint32_t* __restrict__ A, int64_t lda, int64_t m,
                                              const uint32_t* __restrict__ B, int64_t ldb, int64_t n, int64_t i0, int64_t j0,
                                              int ktiles, char* lds) {
@@ -239,7 +257,7 @@ __device__ __forceinline__ void s16_mainloop(f32x4 (&acc)[4][4], const uint32_t*
     const int64_t nk = (int64_t)(kt + 1 < ktiles ? kt + 1 : kt) * H2_KT;
     h2_load_operand(st.a, ta + nk, offa);
     h2_load_operand(st.b, tb + nk, offb);
-    s16_compute_ktile(acc, ldsA, ldsB, wr, wc, lane);
+    s16_compute_ktile<CORE>(acc, ldsA, ldsB, wr, wc, lane);
   }
 }
 
@@ -458,7 +476,7 @@ __device__ __forceinline__ void w_store_operand(const u32x4 (&r)[4], char* lds) 
 // v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales, 2^0) per product block.  Both operands split the row the same way,
 // so the order in which a lane group's 32 features enter the sum is the same permutation for A and B — a dot product does
 // not care.  Same loads, same LDS image, same stores: 4 x the features per stage in 1/3 of the MFMA issue slots.
-enum { CORE_H2 = 0, CORE_F8 = 1 };
+enum { CORE_H2 = 0, CORE_F8 = 1, CORE_BF16 = S16_BF16, CORE_F16 = S16_F16 };   // the 16-bit cores: see s16_compute_ktile
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 constexpr int F8_SCALE_ONE = 0x7f7f7f7f;      // E8M0 exponent 127 = 2^0 in every byte (op_sel picks byte 0)
 
@@ -480,6 +498,18 @@ __device__ __forceinline__ void w_compute_part(f32x4 (&acc)[8][4], const char* p
       for (int tn = 0; tn < 4; ++tn)
         acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, f8_frag(bh[tn], bl[tn]), acc[tm][tn], 0, 0, 0,
                                                                         F8_SCALE_ONE, 0, F8_SCALE_ONE);
+    } else if (CORE == CORE_BF16) {
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh[tn]), acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bl[tn]), acc[tm][tn], 0, 0, 0);
+      }
+    } else if (CORE == CORE_F16) {
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[tn], acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bl[tn], acc[tm][tn], 0, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) {
@@ -650,6 +680,12 @@ __device__ __forceinline__ void w_mfma_col(f32x4 (&acc)[8][4], const f16x8 (&ah)
     if (CORE == CORE_F8) {
       acc[tm0 + u][tn] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(f8_frag(ah[u], al[u]), f8_frag(bh, bl), acc[tm0 + u][tn], 0, 0,
                                                                            0, F8_SCALE_ONE, 0, F8_SCALE_ONE);
+    } else if (CORE == CORE_BF16) {
+      acc[tm0 + u][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah[u]), __builtin_bit_cast(bf16x8, bh), acc[tm0 + u][tn], 0, 0, 0);
+      acc[tm0 + u][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al[u]), __builtin_bit_cast(bf16x8, bl), acc[tm0 + u][tn], 0, 0, 0);
+    } else if (CORE == CORE_F16) {
+      acc[tm0 + u][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], bh, acc[tm0 + u][tn], 0, 0, 0);
+      acc[tm0 + u][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u], bl, acc[tm0 + u][tn], 0, 0, 0);
     } else {
       acc[tm0 + u][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u], bh, acc[tm0 + u][tn], 0, 0, 0);
       acc[tm0 + u][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], bl, acc[tm0 + u][tn], 0, 0, 0);
@@ -685,7 +721,7 @@ __device__ __forceinline__ void w_sched_part() {
 // need no second register set.
 template <bool F1, bool F2, int CORE>
 __device__ __forceinline__ void w_stage_dma(f32x4 (&acc)[8][4], WFrag& f, const char* cur, char* nxt, int koff1, const WDma& ad) {
-  constexpr int PER = CORE == CORE_F8 ? 1 : 3;
+  constexpr int PER = CORE == CORE_F8 ? 1 : (CORE == CORE_H2 ? 3 : 2);
   // part 0, reading part 1
   w_read_a(f.a1h, f.a1l, cur, ad, 1);
   if (F1) w_dma_pieces<3, 6>(ad, nxt, koff1);
@@ -1022,6 +1058,156 @@ __global__ __launch_bounds__(W_THREADS, 1) void gemm_h2w256_kernel(
     po += 12 * ldo;
     if (pr != nullptr) pr += 12 * ldr;
   }
+}
+
+// ---------------------------------------------------------------- 16-bit operands (bf16 / f16), one term
+// out = act(A B' + bias (+ residual)) for plain 16-bit row-major operands — the layers of a forward run in bf16 / f16 (BASELINE
+// config 2's stated dtype): no split, no scale, TWO MFMAs per product block and 64 features where the f32-accurate form needs
+// three per 32.  An operand row is its features back to back, zero beyond K up to a multiple of 128 (the 128 x 128 core's
+// k-tile; the wide core consumes 64 per stage), 16-byte aligned: a row-major bf16 matrix with K % 128 == 0 IS the operand.
+// Sums in f32; the result is rounded ONCE (bias and residual are added in f32 before it) to the operands' type, or left f32.
+template <int CORE>
+__device__ __forceinline__ float b16_load(const unsigned short* p) {
+  if (CORE == CORE_BF16) return __uint_as_float((uint32_t)*p << 16);
+  return (float)__builtin_bit_cast(_Float16, *p);
+}
+
+template <int CORE>
+__device__ __forceinline__ unsigned short b16_round(float v) {
+  if (CORE == CORE_BF16) {
+    const uint32_t u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);     // NaN stays NaN
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);                     // round to nearest even
+  }
+  return __builtin_bit_cast(unsigned short, (_Float16)v);
+}
+
+template <int CORE, bool OUT16>
+__device__ __forceinline__ void b16_finish(float acc, float b, const void* __restrict__ res, int64_t ri, int relu, void* __restrict__ out,
+                                           int64_t oi) {
+  float v = acc + b;
+  if (res != nullptr) v += OUT16 ? b16_load<CORE>(static_cast<const unsigned short*>(res) + ri) : static_cast<const float*>(res)[ri];
+  if (relu) v = fmaxf(v, 0.f);
+  if (OUT16) static_cast<unsigned short*>(out)[oi] = b16_round<CORE>(v);
+  else static_cast<float*>(out)[oi] = v;
+}
+
+template <int CORE, bool OUT16>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_b16s16_kernel(
+    const uint32_t* __restrict__ PA, int64_t ldpa, int64_t m, const uint32_t* __restrict__ PB, int64_t ldpb, int64_t n, int ktiles,
+    const float* __restrict__ bias, const void* __restrict__ res, int64_t ldr, int relu, void* __restrict__ out, int64_t ldo, int gr) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int64_t GR = gr;
+  const int64_t tiles_n = (n + GEMM_BN - 1) / GEMM_BN;
+  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t band = wg / (GR * tiles_n), within = wg % (GR * tiles_n);
+  const int64_t i0 = (band * GR + within % GR) * GEMM_BM, j0 = (within / GR) * GEMM_BN;
+  if (i0 >= m) return;
+  f32x4 acc[4][4];
+  s16_zero(acc);
+  s16_mainloop<CORE>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, ktiles, lds);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) {
+    const int64_t col = j0 + wc * 64 + tn * 16 + (lane & 15);
+    if (col >= n) continue;
+    const float b = bias != nullptr ? bias[col] : 0.f;
+    const int64_t rb = i0 + wr * 64 + 4 * (lane >> 4);
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t row = rb + tm * 16 + q;
+        if (row < m) b16_finish<CORE, OUT16>(acc[tm][tn][q], b, res, row * ldr + col, relu, out, row * ldo + col);
+      }
+  }
+}
+
+template <int CORE, bool OUT16>
+__global__ __launch_bounds__(W_THREADS, 1) void gemm_b16w256_kernel(
+    const uint32_t* __restrict__ PA, int64_t ldpa, int64_t m, const uint32_t* __restrict__ PB, int64_t ldpb, int64_t n, int stages,
+    const float* __restrict__ bias, const void* __restrict__ res, int64_t ldr, int relu, void* __restrict__ out, int64_t ldo, int gr) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int64_t GR = gr;
+  const int64_t tiles_n = (n + W_BN - 1) / W_BN;
+  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t band = wg / (GR * tiles_n), within = wg % (GR * tiles_n);
+  const int64_t i0 = (band * GR + within % GR) * W_BM, j0 = (within / GR) * W_BN;
+  if (i0 >= m) return;
+  f32x4 acc[8][4];
+  w_zero(acc);
+  w_mainloop_dma<true, CORE>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds);     // (a lane holds four ADJACENT columns per row)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int64_t col = j0 + wc * 64 + 4 * (lane & 15);
+  const int64_t rb = i0 + wr * 128 + 4 * (lane >> 4);
+  if (col >= n) return;
+  constexpr int ESZ = OUT16 ? 2 : 4;
+  const bool vec = col + 4 <= n && (ldo * ESZ) % (4 * ESZ) == 0 && (reinterpret_cast<uintptr_t>(out) & (4 * ESZ - 1)) == 0 &&
+                   (res == nullptr || ((ldr * ESZ) % (4 * ESZ) == 0 && (reinterpret_cast<uintptr_t>(res) & (4 * ESZ - 1)) == 0));
+  float b[4];
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) b[tn] = (bias != nullptr && col + tn < n) ? bias[col + tn] : 0.f;
+#pragma unroll
+  for (int tm = 0; tm < 8; ++tm) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t row = rb + tm * 16 + q;
+      if (row >= m) continue;
+      if (vec) {
+        float v[4];
+        if (OUT16) {
+          u16x4 r4 = {0, 0, 0, 0};
+          if (res != nullptr) r4 = *reinterpret_cast<const u16x4*>(static_cast<const unsigned short*>(res) + row * ldr + col);
+          u16x4 o;
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) {
+            v[tn] = acc[tm][tn][q] + b[tn];
+            if (res != nullptr) { const unsigned short h = r4[tn]; v[tn] += b16_load<CORE>(&h); }
+            if (relu) v[tn] = fmaxf(v[tn], 0.f);
+            o[tn] = b16_round<CORE>(v[tn]);
+          }
+          *reinterpret_cast<u16x4*>(static_cast<unsigned short*>(out) + row * ldo + col) = o;
+        } else {
+          f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
+          if (res != nullptr) r4 = *reinterpret_cast<const f32x4*>(static_cast<const float*>(res) + row * ldr + col);
+          f32x4 o;
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) {
+            o[tn] = acc[tm][tn][q] + b[tn] + r4[tn];
+            if (relu) o[tn] = fmaxf(o[tn], 0.f);
+          }
+          *reinterpret_cast<f32x4*>(static_cast<float*>(out) + row * ldo + col) = o;
+        }
+      } else {
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+          if (col + tn < n) b16_finish<CORE, OUT16>(acc[tm][tn][q], b[tn], res, row * ldr + col + tn, relu, out, row * ldo + col + tn);
+      }
+    }
+  }
+}
+
+// The operand of a 3 x 3 convolution (padding 1) run as a GEMM over 16-bit NHWC rows Y (R * H * W rows of C channels): row
+// (r, h, w) of P holds, tap after tap, the C channels of Y's row (r, h + ky - 1, w + kx - 1), zeros outside the map and beyond
+// 9 C up to ldp.  One thread per 16 bytes (8 channels).
+__global__ __launch_bounds__(256) void taps3x3_b16_kernel(const unsigned short* __restrict__ Y, int64_t ldy, int H, int W, int C,
+                                                          unsigned short* __restrict__ P, int64_t ldp, int64_t row0) {
+  const int D = 9 * C;
+  const int groups = (int)(ldp / 8);
+  const int64_t row = row0 + blockIdx.y;
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= groups) return;
+  u32x4 v = {0u, 0u, 0u, 0u};
+  const int f = g * 8;
+  if (f < D) {
+    const int tap = f / C, c = f - tap * C;
+    const int w = (int)(row % W), h = (int)((row / W) % H);
+    const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
+    if (hh >= 0 && hh < H && ww >= 0 && ww < W) v = *reinterpret_cast<const u32x4*>(Y + (row + (int64_t)(hh - h) * W + (ww - w)) * ldy + c);
+  }
+  *reinterpret_cast<u32x4*>(P + row * ldp + f) = v;
 }
 
 // ---------------------------------------------------------------- f64 matrices through the split core
@@ -1595,6 +1781,66 @@ extern "C" int odx_gemm_h2_f32(const void* PA, int64_t ldpa, const float* metaa,
                      ldr, relu, out, ldo, gr);
   ODX_CHECK_LAUNCH("odx_gemm_h2_f32");
   return ODX_OK;
+}
+
+extern "C" int odx_taps3x3_16(const void* Y, int64_t ldy, int64_t R, int H, int W, int C, void* P, int64_t ldp, odx_stream_t stream) {
+  const int64_t n = R * H * W;
+  if (n <= 0) return ODX_OK;
+  ODX_REQUIRE(Y && P && H > 0 && W > 0 && C > 0 && C % 8 == 0 && ldy >= C && ldy % 8 == 0 && aligned16(Y),
+              "odx_taps3x3_16: Y must be 16-byte aligned with ldy %% 8 == 0, ldy >= C, C %% 8 == 0");
+  ODX_REQUIRE(ldp >= 9 * (int64_t)C && ldp % 8 == 0 && aligned16(P), "odx_taps3x3_16: P must be 16-byte aligned with ldp %% 8 == 0, ldp >= 9 C");
+  hipStream_t s = as_stream(stream);
+  const int groups = (int)(ldp / 8);
+  for (int64_t r0 = 0; r0 < n; r0 += 65535) {
+    const int64_t nr = n - r0 < 65535 ? n - r0 : 65535;
+    hipLaunchKernelGGL(taps3x3_b16_kernel, dim3((unsigned)ceil_div(groups, 256), (unsigned)nr), dim3(256), 0, s,
+                       static_cast<const unsigned short*>(Y), ldy, H, W, C, static_cast<unsigned short*>(P), ldp, r0);
+    ODX_CHECK_LAUNCH("odx_taps3x3_16");
+  }
+  return ODX_OK;
+}
+
+template <int CORE, bool OUT16>
+static int launch_gemm_b16(const void* A, int64_t lda, int64_t m, const void* B, int64_t ldb, int64_t n, int K, const float* bias,
+                           const void* residual, int64_t ldr, int relu, void* out, int64_t ldo, hipStream_t s) {
+  const int gr = 8;
+  const int64_t t256 = ceil_div(m, W_BM) * ceil_div(n, W_BN);
+  const bool wide = g_h2_tile == 256 || (g_h2_tile != 128 && t256 >= 256);
+  if (wide) {                  // the 256 x 256 core once it fills the chip (one workgroup per CU), else 128 x 128 tiles
+    const int64_t wt = round_up(ceil_div(m, W_BM), gr) * ceil_div(n, W_BN);
+    ODX_REQUIRE(wt < (1ll << 31), "odx_gemm_b16: grid too large");
+    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_b16w256_kernel<CORE, OUT16>), W_LDS_BYTES));
+    hipLaunchKernelGGL((gemm_b16w256_kernel<CORE, OUT16>), dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, s, (const uint32_t*)A, lda / 2, m,
+                       (const uint32_t*)B, ldb / 2, n, (int)(round_up(K, 64) / 64), bias, residual, ldr, relu, out, ldo, gr);
+    ODX_CHECK_LAUNCH("odx_gemm_b16(w256)");
+    return ODX_OK;
+  }
+  const int64_t tiles = round_up(ceil_div(m, GEMM_BM), gr) * ceil_div(n, GEMM_BN);
+  ODX_REQUIRE(tiles < (1ll << 31), "odx_gemm_b16: grid too large");
+  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_b16s16_kernel<CORE, OUT16>)));
+  hipLaunchKernelGGL((gemm_b16s16_kernel<CORE, OUT16>), dim3((unsigned)tiles), dim3(GEMM_THREADS), S16_LDS_BYTES, s, (const uint32_t*)A, lda / 2,
+                     m, (const uint32_t*)B, ldb / 2, n, (int)(round_up(K, 128) / 128), bias, residual, ldr, relu, out, ldo, gr);
+  ODX_CHECK_LAUNCH("odx_gemm_b16");
+  return ODX_OK;
+}
+
+extern "C" int odx_gemm_b16(const void* A, int64_t lda, int64_t m, const void* B, int64_t ldb, int64_t n, int K, int is_bf16,
+                            const float* bias, const void* residual, int64_t ldr, int relu, void* out, int64_t ldo, int out_16,
+                            odx_stream_t stream) {
+  if (m <= 0 || n <= 0) return ODX_OK;
+  ODX_REQUIRE(A && B && out && K > 0, "odx_gemm_b16: bad argument");
+  const int64_t kp = round_up(K, 128);
+  ODX_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= kp && ldb >= kp && aligned16(A) && aligned16(B),
+              "odx_gemm_b16: operands must be 16-byte aligned with ld %% 8 == 0 and ld >= roundup(K, 128) elements (zero beyond K)");
+  ODX_REQUIRE(ldo >= n && (residual == nullptr || ldr >= n), "odx_gemm_b16: ldo / ldr < n");
+  ODX_REQUIRE(lda < (1 << 25) && ldb < (1 << 25), "odx_gemm_b16: leading dimensions must stay below 2^25 (32-bit tile offsets)");
+  hipStream_t s = as_stream(stream);
+  if (is_bf16) {
+    return out_16 ? launch_gemm_b16<CORE_BF16, true>(A, lda, m, B, ldb, n, K, bias, residual, ldr, relu, out, ldo, s)
+                  : launch_gemm_b16<CORE_BF16, false>(A, lda, m, B, ldb, n, K, bias, residual, ldr, relu, out, ldo, s);
+  }
+  return out_16 ? launch_gemm_b16<CORE_F16, true>(A, lda, m, B, ldb, n, K, bias, residual, ldr, relu, out, ldo, s)
+                : launch_gemm_b16<CORE_F16, false>(A, lda, m, B, ldb, n, K, bias, residual, ldr, relu, out, ldo, s);
 }
 
 extern "C" int odx_gauss_h2_tile(int64_t n, int64_t M) {

@@ -697,6 +697,23 @@ int knm_passq_batched(int B, const void* const* Khi, const int64_t* ldk, const v
 
 using namespace odx;
 
+// The kernel a pass over a block of M columns stored as `fmt` runs as (nv = 1: one vector, 2: two vectors from one read): the
+// name rocprofv3 lists it under, from the SAME rule the launches use (pick_qcfg) — for tools that label measurements
+// (bench.py's result line) without restating that rule.  "" when the shape has no configuration.
+extern "C" const char* odx_knm_pass_kernel_name(int64_t M, int fmt, int nv) {
+  static thread_local char name[96];
+  name[0] = 0;
+  if (fmt == 0) {                        // ODX_KNM_F32: knm_pass.hip's kernels (not templates)
+    snprintf(name, sizeof(name), nv == 2 ? "knm_pass2_kernel" : "knm_pass_kernel");
+    return name;
+  }
+  QCfg cfg;
+  if ((fmt != QF_U24 && fmt != QF_BF16) || (nv != 1 && nv != 2) || M <= 0 || !pick_qcfg(M, nv, fmt, &cfg)) return name;
+  if (cfg.nt == 0) snprintf(name, sizeof(name), "knm_passq_stag_kernel<%d,%d,%d>", cfg.ch, cfg.r, fmt);
+  else snprintf(name, sizeof(name), "knm_passq_kernel<%d,%d,%d,%d,%d,%d>", cfg.nt, cfg.ch, cfg.r, nv, fmt, cfg.nt >= 1024 ? 4 : 2);
+  return name;
+}
+
 extern "C" int odx_set_pass_cus(int cus) {
   ODX_REQUIRE(cus >= 0 && cus <= 4096, "odx_set_pass_cus: 0 (the device's) .. 4096");
   g_pass_cus = cus;

@@ -462,8 +462,26 @@ extern "C" int64_t odx_nms_batched_workspace_bytes(int Rmax, int B) {
   return (int64_t)B * odx_nms_workspace_bytes(Rmax);
 }
 
+static int nms_batched(const float* boxes_sorted, const int32_t* counts, int Rmax, int B, float iou_threshold, int max_keep,
+                       unsigned char* keep, void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+
 extern "C" int odx_nms_batched_f32(const float* boxes_sorted, const int32_t* counts, int Rmax, int B, float iou_threshold,
                                    unsigned char* keep, void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
+  return nms_batched(boxes_sorted, counts, Rmax, B, iou_threshold, 0, keep, workspace, workspace_bytes, stream);
+}
+
+// The same with an upper bound on each set's survivors (odx_nms_first_f32 per set): the proposals of a BATCH of images — B
+// sets of up to 6000 candidates of which the first post_nms_top_n survivors are used (rpn/inference.py:116-121) — with one
+// launch pair and no walk behind the last survivor needed.
+extern "C" int odx_nms_batched_first_f32(const float* boxes_sorted, const int32_t* counts, int Rmax, int B, float iou_threshold,
+                                         int max_keep, unsigned char* keep, void* workspace, int64_t workspace_bytes,
+                                         odx_stream_t stream) {
+  ODX_REQUIRE(max_keep > 0, "odx_nms_batched_first_f32: max_keep <= 0");
+  return nms_batched(boxes_sorted, counts, Rmax, B, iou_threshold, max_keep, keep, workspace, workspace_bytes, stream);
+}
+
+static int nms_batched(const float* boxes_sorted, const int32_t* counts, int Rmax, int B, float iou_threshold, int max_keep,
+                       unsigned char* keep, void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
   if (Rmax <= 0 || B <= 0) return ODX_OK;
   ODX_REQUIRE(boxes_sorted && counts && keep && workspace, "odx_nms_batched_f32: null pointer");
   ODX_REQUIRE(Rmax <= 64 * 64 * 4 && B < 65536, "odx_nms_batched_f32: at most 16384 boxes per set, 65535 sets");
@@ -479,7 +497,7 @@ extern "C" int odx_nms_batched_f32(const float* boxes_sorted, const int32_t* cou
   hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)words, (unsigned)words, (unsigned)B), dim3(64), 0, s, boxes_sorted, Rmax,
                      iou_threshold, mask, words, counts);
   ODX_CHECK_LAUNCH("odx_nms_batched_f32(mask)");
-  hipLaunchKernelGGL(nms_reduce_kernel, dim3((unsigned)B), dim3(64), 0, s, mask, Rmax, words, keep, counts, 0);
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3((unsigned)B), dim3(64), 0, s, mask, Rmax, words, keep, counts, max_keep);
   ODX_CHECK_LAUNCH("odx_nms_batched_f32(reduce)");
   return ODX_OK;
 }

@@ -38,6 +38,19 @@ class Features:
         self.P8 = self.meta8 = self.sq8 = None     # e4m3 packing (odx_split_f8), made on demand by the throughput-only fp8 kernels
 
 
+class Rows16:
+    """A 16-bit (bf16 / f16) row matrix as odx_gemm_b16 takes it: buf (n, ld), ld a multiple of 128 elements, columns K .. ld
+    zero.  `dense` is the (n, K) view."""
+    __slots__ = ("buf", "n", "K")
+
+    def __init__(self, buf, K):
+        self.buf, self.n, self.K = buf, buf.shape[0], K
+
+    @property
+    def dense(self):
+        return self.buf[:, :self.K]
+
+
 class Precond:
     """Inverse Cholesky factors of the FALKON preconditioner, f64, row-major (M x ld)."""
     __slots__ = ("LTi", "LTit", "LAi", "LAit", "M", "ld", "info", "block_rows")
@@ -802,6 +815,68 @@ class HipBackend:
                                            _p(bias), _p(residual), ldr, int(bool(relu)), _p(out), n, self._stream()), "odx_gemm_h2_f32")
         return out
 
+    # ------------------------------------------------------------------ 16-bit layers (a forward run in bf16 / f16)
+    def rows16(self, X, dtype=None):
+        """X (rows, K) as the operand of gemm_b16: a bf16 / f16 row-major block whose rows are a multiple of 128 elements
+        long, zero beyond K (Rows16).  A matrix that already is one (right dtype, contiguous, K % 128 == 0) is taken as it is."""
+        if isinstance(X, Rows16):
+            return X
+        dtype = dtype or (X.dtype if X.dtype in (torch.bfloat16, torch.float16) else torch.bfloat16)
+        n, K = X.shape
+        ld = (K + 127) // 128 * 128
+        if X.is_cuda and X.dtype == dtype and K == ld and X.stride(1) == 1 and X.stride(0) == ld and X.data_ptr() % 16 == 0:
+            return Rows16(X, K)
+        buf = torch.empty((n, ld), dtype=dtype, device=self.device)
+        if ld > K:
+            buf[:, K:].zero_()
+        buf[:, :K].copy_(X)
+        return Rows16(buf, K)
+
+    def gemm_b16(self, A, B, bias=None, residual=None, relu=False, out_f32=False):
+        """act(A B' + bias (+ residual)) for Rows16 operands A (m, K), B (n, K) of one 16-bit type (odx_gemm_b16: one MFMA term
+        per product, f32 sums, one rounding).  Returns a Rows16 of the operands' type — ready to be the next layer's operand,
+        its pad columns zero — or, with out_f32, an (m, n) f32 tensor.  residual: Rows16 of the operands' type (f32 tensor
+        with out_f32) of the result's shape."""
+        m, n, K = A.n, B.n, A.K
+        dt = A.buf.dtype
+        if B.K != K or B.buf.dtype != dt:
+            raise ValueError("gemm_b16: operands differ in inner dimension (%d, %d) or type" % (K, B.K))
+        if out_f32:
+            out = torch.empty((m, n), dtype=torch.float32, device=self.device)
+            ldo, res, ldr = n, None, 0
+            if residual is not None:
+                res = residual.to(device=self.device, dtype=torch.float32)
+                res = res if res.stride(1) == 1 else res.contiguous()
+                ldr = res.stride(0)
+        else:
+            ldo = (n + 127) // 128 * 128
+            out = torch.empty((m, ldo), dtype=dt, device=self.device)
+            if ldo > n:
+                out[:, n:].zero_()
+            res, ldr = None, 0
+            if residual is not None:
+                if not isinstance(residual, Rows16) or residual.buf.dtype != dt or residual.n != m or residual.K != n:
+                    raise ValueError("gemm_b16: the residual must be a Rows16 of the result's shape and type")
+                res, ldr = residual.buf, residual.buf.stride(0)
+        if bias is not None:
+            bias = bias.to(device=self.device, dtype=torch.float32).contiguous()
+        if m and n:
+            hip.check(self.lib.odx_gemm_b16(_p(A.buf), A.buf.stride(0), m, _p(B.buf), B.buf.stride(0), n, K, 1 if dt == torch.bfloat16 else 0,
+                                            _p(bias), _p(res), ldr, int(bool(relu)), _p(out), ldo, 0 if out_f32 else 1, self._stream()),
+                      "odx_gemm_b16")
+        return out if out_f32 else Rows16(out, n)
+
+    def taps3x3_16(self, Y, R, H, W):
+        """The operand of a 3 x 3 convolution (padding 1) as a GEMM over the 16-bit NHWC rows Y (Rows16, R * H * W rows of C
+        channels, C % 8 == 0): K = 9 C, tap after tap (odx_taps3x3_16)."""
+        C = Y.K
+        if Y.n != R * H * W or C % 8 != 0:
+            raise ValueError("taps3x3_16: %d rows of %d channels for R, H, W = %d, %d, %d (C %% 8 == 0 required)" % (Y.n, C, R, H, W))
+        ld = (9 * C + 127) // 128 * 128
+        P = torch.empty((Y.n, ld), dtype=Y.buf.dtype, device=self.device)
+        hip.check(self.lib.odx_taps3x3_16(_p(Y.buf), Y.buf.stride(0), R, H, W, C, _p(P), ld, self._stream()), "odx_taps3x3_16")
+        return Rows16(P, 9 * C)
+
     def roi_align_rows(self, feat, rois, spatial_scale, output_size, sampling_ratio=0, step=2):
         """RoIAlign for a head that starts with a stride-`step` 1 x 1 convolution: the bins that convolution reads only,
         as an (R * OH * OW, C) row matrix (NHWC).  Returns (rows, (R, OH, OW))."""
@@ -874,9 +949,10 @@ class HipBackend:
         kept = keep.bool().nonzero().reshape(-1)
         return kept if order is None else order[kept]
 
-    def nms_batched(self, boxes_sorted, counts, iou_threshold):
+    def nms_batched(self, boxes_sorted, counts, iou_threshold, max_keep=0):
         """Greedy NMS of B independent box sets with one launch pair: boxes_sorted (B, Rmax, 4) f32, set b's counts[b]
-        boxes first in its slot, sorted by descending score; counts (B,) int32 ON THE DEVICE.  Returns keep (B, Rmax) bool."""
+        boxes first in its slot, sorted by descending score; counts (B,) int32 ON THE DEVICE.  Returns keep (B, Rmax) bool.
+        max_keep > 0: at most that many survivors per set, the first ones (the walk of a set stops there)."""
         B, Rmax = int(boxes_sorted.shape[0]), int(boxes_sorted.shape[1])
         keep = torch.empty((B, Rmax), dtype=torch.uint8, device=self.device)
         if B == 0 or Rmax == 0:
@@ -884,8 +960,12 @@ class HipBackend:
         boxes_sorted = boxes_sorted.to(device=self.device, dtype=torch.float32).contiguous()
         counts = counts.to(device=self.device, dtype=torch.int32).contiguous()
         ws = self._workspace("nms_batched", self.lib.odx_nms_batched_workspace_bytes(Rmax, B))
-        hip.check(self.lib.odx_nms_batched_f32(_p(boxes_sorted), _p(counts), Rmax, B, float(iou_threshold), _p(keep), _p(ws),
-                                               ws.numel(), self._stream()), "odx_nms_batched_f32")
+        if max_keep > 0:
+            hip.check(self.lib.odx_nms_batched_first_f32(_p(boxes_sorted), _p(counts), Rmax, B, float(iou_threshold), int(max_keep),
+                                                         _p(keep), _p(ws), ws.numel(), self._stream()), "odx_nms_batched_first_f32")
+        else:
+            hip.check(self.lib.odx_nms_batched_f32(_p(boxes_sorted), _p(counts), Rmax, B, float(iou_threshold), _p(keep), _p(ws),
+                                                   ws.numel(), self._stream()), "odx_nms_batched_f32")
         return keep.bool()
 
 

@@ -108,6 +108,31 @@ def rpn_proposals(objectness, box_regression, anchors, img_size, pre_nms_top_n=6
     return boxes[keep], score[keep]
 
 
+def rpn_proposals_batch(objectness, box_regression, anchors, img_size, pre_nms_top_n=6000, post_nms_top_n=300, nms_thresh=0.7):
+    """rpn_proposals for B images of ONE size at once (the per-image rule of rpn/inference.py:76-123 applied to every image of
+    the batch): one top-k over (B, H W A), one decode / clip over all selected candidates, ONE suppression launch pair for the
+    B candidate sets (odx_nms_batched_first_f32: a set's walk stops at its post_nms_top_n-th survivor) and ONE host
+    synchronisation for the B survivor counts.  Returns [(boxes_b, scores_b)] — per image what rpn_proposals returns."""
+    be = _backend.get_backend()
+    B, A, H, W = objectness.shape
+    obj = objectness.permute(0, 2, 3, 1).reshape(B, -1).sigmoid()
+    reg = box_regression.view(B, A, 4, H, W).permute(0, 3, 4, 1, 2).reshape(B, -1, 4)
+    k = min(pre_nms_top_n, obj.shape[1])
+    score, idx = obj.topk(k, dim=1, sorted=True)
+    sel = reg.gather(1, idx.unsqueeze(2).expand(B, k, 4)).reshape(B * k, 4)
+    boxes = decode_deltas(sel, anchors.to(reg.device)[idx.reshape(-1)])
+    boxes[:, 0].clamp_(0, img_size[0] - 1)
+    boxes[:, 2].clamp_(0, img_size[0] - 1)
+    boxes[:, 1].clamp_(0, img_size[1] - 1)
+    boxes[:, 3].clamp_(0, img_size[1] - 1)
+    boxes = boxes.view(B, k, 4)
+    counts = torch.full((B,), k, dtype=torch.int32, device=boxes.device)
+    keep = be.nms_batched(boxes, counts, nms_thresh, max_keep=post_nms_top_n)
+    n = keep.sum(dim=1).tolist()                          # the batch's one host synchronisation
+    kb, ks = boxes[keep].split(n), score[keep].split(n)   # image after image, descending score inside an image
+    return list(zip(kb, ks))
+
+
 # ---------------------------------------------------------------------------- image pre-processing
 PIXEL_MEAN_BGR255 = (102.9801, 115.9465, 122.7717)     # cfg.INPUT.PIXEL_MEAN of the shipped configs (Detectron BGR-255)
 
@@ -287,13 +312,30 @@ class Bottleneck(_FoldedBN):
         return self.conv_bn_act("conv3", "bn3", y, residual=idn)
 
 
-def _addmm_relu(bias, x, w):
-    """relu(x @ w + bias) with the ReLU in the GEMM's epilogue where the library offers it (hipBLASLt through
-    torch._addmm_activation), as a second pass over the output otherwise."""
-    fused = getattr(torch, "_addmm_activation", None)
-    if fused is not None and x.is_cuda:
-        return fused(bias, x, w, use_gelu=False)
-    return torch.addmm(bias, x, w).relu_()
+def _bottleneck_rows_b16(be, blk, x, R, H, W):
+    """_bottleneck_rows for a forward run in bf16 / f16 (compute_dtype): x is a backend.Rows16; the folded weights rounded once
+    to the 16-bit type, every product on the matrix cores with ONE MFMA term (odx_gemm_b16), sums, bias and identity in f32,
+    one rounding per layer output; the 9-tap gather in the 16-bit type (odx_taps3x3_16).  No vendor GEMM."""
+    dt = x.buf.dtype
+
+    def wrows(key, conv, bn, taps=False):
+        c = blk._folded.get((key + "/b16", dt))
+        if c is None:
+            w, b = blk._fold(key, conv, bn, x.buf)
+            w = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1) if taps else w.reshape(w.shape[0], -1)     # (out, ky kx in)
+            c = blk._folded[(key + "/b16", dt)] = (be.rows16(w.to(dt).contiguous(), dt), b.float().contiguous())
+        return c
+    if blk.down is None:
+        idn = x
+    else:
+        wd, bd = wrows("down", blk.down[0], blk.down[1])
+        idn = be.gemm_b16(x, wd, bias=bd)
+    w1, b1 = wrows("conv1", blk.conv1, blk.bn1)
+    y = be.gemm_b16(x, w1, bias=b1, relu=True)
+    w2, b2 = wrows("conv2", blk.conv2, blk.bn2, taps=True)
+    y = be.gemm_b16(be.taps3x3_16(y, R, H, W), w2, bias=b2, relu=True)
+    w3, b3 = wrows("conv3", blk.conv3, blk.bn3)
+    return be.gemm_b16(y, w3, bias=b3, residual=idn, relu=True)
 
 
 def _bottleneck_rows_h2(be, blk, x, R, H, W):
@@ -325,14 +367,21 @@ def _bottleneck_rows_h2(be, blk, x, R, H, W):
 def _bottleneck_rows(blk, x, R, H, W):
     """One Bottleneck on activations kept as a (R * H * W, C) row matrix (NHWC): the 1 x 1 convolutions ARE matrix products
     over those rows and the 3 x 3 one is a product over a 9-tap gather of them, so the block is three (four with the
-    projection) library GEMMs with the folded batch-norm bias added by the GEMM, instead of MIOpen convolutions on 7 x 7
-    maps (74 TF in f32 for the whole head; the same products as GEMMs run at 95-117 TF).  A stride (always in the 1 x 1
-    convolutions here, STRIDE_IN_1X1) is applied by the caller: x holds the rows of the positions that survive it."""
-    dt = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled("cuda")) else blk.conv1.weight.dtype
-    if x.is_cuda and dt == torch.float32 and x.dtype == torch.float32:
+    projection) GEMMs with the folded batch-norm bias added by the GEMM, instead of library convolutions on 7 x 7 maps.  A
+    stride (always in the 1 x 1 convolutions here, STRIDE_IN_1X1) is applied by the caller: x holds the rows of the
+    positions that survive it.  On the GPU the products run on this library's tile cores (f32: _bottleneck_rows_h2; a 16-bit
+    forward: _bottleneck_rows_b16 through Conv5Head.forward_rows); the plain-torch form below is the CPU statement of the
+    same block (tests' oracle backend)."""
+    if x.is_cuda:
         be = _backend.get_backend()
-        if hasattr(be, "gemm_h2"):
+        if x.dtype == torch.float32 and not torch.is_autocast_enabled("cuda") and hasattr(be, "gemm_h2"):
             return _bottleneck_rows_h2(be, blk, x, R, H, W)
+        if hasattr(be, "gemm_b16"):
+            dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+            if dt in (torch.bfloat16, torch.float16):
+                return _bottleneck_rows_b16(be, blk, be.rows16(x, dt), R, H, W).dense
+        raise RuntimeError("conv5 head: no tile core for rows of type %s on this backend" % x.dtype)
+    dt = x.dtype
 
     def mat(key, conv, bn, taps=False):
         c = blk._folded.get((key + "/rows", dt))
@@ -345,16 +394,16 @@ def _bottleneck_rows(blk, x, R, H, W):
         idn = x
     else:
         wd, bd = mat("down", blk.down[0], blk.down[1])
-        idn = torch.addmm(bd, x, wd)
+        idn = x @ wd + bd
     w1, b1 = mat("conv1", blk.conv1, blk.bn1)
-    y = _addmm_relu(b1, x, w1)
+    y = F.relu(x @ w1 + b1)
     mid = y.shape[1]
     yp = F.pad(y.view(R, H, W, mid), (0, 0, 1, 1, 1, 1))
     cols = torch.cat([yp[:, ky:ky + H, kx:kx + W, :] for ky in range(3) for kx in range(3)], dim=3).view(R * H * W, 9 * mid)
     w2, b2 = mat("conv2", blk.conv2, blk.bn2, taps=True)
-    y = _addmm_relu(b2, cols, w2)
+    y = F.relu(cols @ w2 + b2)
     w3, b3 = mat("conv3", blk.conv3, blk.bn3)
-    return torch.addmm(b3, y, w3).add_(idn).relu_()
+    return F.relu(y @ w3 + b3 + idn)
 
 
 def _stage(cin, mid, cout, blocks, stride):
@@ -400,8 +449,14 @@ class Conv5Head(nn.Module):
 
     def forward_rows(self, rows, R, H, W):
         """rows (R * H * W, C): the input at the positions the first block's strided 1 x 1 convolutions read (NHWC)."""
-        if torch.is_autocast_enabled("cuda") and rows.is_cuda:
-            rows = rows.to(torch.get_autocast_dtype("cuda"))
+        if rows.is_cuda:
+            dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else rows.dtype
+            be = _backend.get_backend()
+            if dt in (torch.bfloat16, torch.float16) and hasattr(be, "gemm_b16"):
+                x = be.rows16(rows, dt)                              # the one cast of the stage's input
+                for blk in self.layer4:
+                    x = _bottleneck_rows_b16(be, blk, x, R, H, W)    # 16-bit activations from block to block, pad columns zero
+                return x.dense.reshape(R, H, W, -1).permute(0, 3, 1, 2)
         for blk in self.layer4:
             rows = _bottleneck_rows(blk, rows, R, H, W)
         return rows.view(R, H, W, -1).permute(0, 3, 1, 2)          # (R, 2048, H, W) as a view of the NHWC rows
@@ -575,8 +630,10 @@ class OnlineDetectionModel(nn.Module):
             return F.relu(self.rpn_conv(c4)).float()
 
     @torch.no_grad()
-    def proposals(self, c4, img_size):
-        t = self.rpn_activation(c4)
+    def proposals(self, c4, img_size, t=None):
+        """t: rpn_activation(c4) when the caller already has it (the on-line RPN harvest reads the same map)."""
+        if t is None:
+            t = self.rpn_activation(c4)
         if self.online_rpn is not None:
             logits, deltas = self.online_rpn(t)
         else:
@@ -586,10 +643,29 @@ class OnlineDetectionModel(nn.Module):
         return rpn_proposals(logits, deltas, anchors, img_size, self.pre_nms_top_n, self.post_nms_top_n, self.rpn_nms)
 
     @torch.no_grad()
-    def roi_head_maps(self, c4, boxes):
-        """(R, D, r/2, r/2): RoIAlign r x r @ 1/stride (HIP kernel) -> conv5 head."""
+    def proposals_batch(self, c4, img_size, t=None):
+        """proposals() for the trunk features of B images of one size: [(boxes_b, scores_b)].  One RPN-head pass, one top-k,
+        one suppression launch pair and one host synchronisation for the batch (rpn_proposals_batch); with an on-line RPN head
+        (its scoring is written for one image) or a backend without the batched suppression: image after image."""
         be = _backend.get_backend()
-        rois = torch.cat((torch.zeros((boxes.shape[0], 1), device=boxes.device), boxes), dim=1)
+        B = c4.shape[0]
+        if B == 1 or self.online_rpn is not None or not (c4.is_cuda and hasattr(be, "nms_batched") and _nms_takes_max_keep(be)):
+            return [self.proposals(c4[b:b + 1], img_size, None if t is None else t[b:b + 1]) for b in range(B)]
+        if t is None:
+            t = self.rpn_activation(c4)
+        with self._amp():
+            logits, deltas = self.rpn_logits(t).float(), self.rpn_deltas(t).float()
+        anchors = grid_anchors(c4.shape[2], c4.shape[3], self.stride, self.cells.to(c4.device))
+        return rpn_proposals_batch(logits, deltas, anchors, img_size, self.pre_nms_top_n, self.post_nms_top_n, self.rpn_nms)
+
+    @torch.no_grad()
+    def roi_head_maps(self, c4, boxes, batch_idx=None):
+        """(R, D, r/2, r/2): RoIAlign r x r @ 1/stride (HIP kernel) -> conv5 head.  batch_idx (R,): the image of c4 (N > 1)
+        each box is pooled from — the RoIs of a batch of images go through the head as ONE row matrix."""
+        be = _backend.get_backend()
+        first = (torch.zeros((boxes.shape[0], 1), device=boxes.device) if batch_idx is None
+                 else batch_idx.to(device=boxes.device, dtype=boxes.dtype).view(-1, 1))
+        rois = torch.cat((first, boxes), dim=1)
         st = self.head.rows_form() if hasattr(self.head, "rows_form") else 0
         if st > 0 and hasattr(be, "roi_align_rows") and boxes.shape[0] > 0:
             # the head's first 1 x 1 convolutions read every st-th position of the crop: RoIAlign forms those bins only,
@@ -622,6 +698,43 @@ class OnlineDetectionModel(nn.Module):
         if gt_boxes is not None and len(gt_boxes):
             boxes = torch.cat((gt_boxes.to(boxes.device).float(), boxes), dim=0)
         return boxes, self.roi_features(c4, boxes), c4
+
+
+def forward_batch(model, images, gt_boxes_list=None, want_rpn_activation=False):
+    """OnlineDetectionModel.forward for B pre-processed images of ONE size, images (B, 3, H, W): one trunk call (replayed from
+    a HIP graph per shape), one proposal stage (proposals_batch) and ONE pass of the RoI head over all images' RoIs — at batch
+    1 the trunk is ~120 latency-bound launches and the head's GEMMs see 300 x 49 rows where the 256 x 256 tile core wants
+    tens of thousands (feature_proposal_extractor.py:228-281 walks one image per iteration; SURVEY 2.1 leaves batching to the
+    build).  Returns ([(boxes_b, feats_b)], trunk, maps, offsets): per image what forward() returns, the trunk features, the
+    head maps of all RoIs (image after image) and the row offset of each image in them; with want_rpn_activation also the
+    (B, C, h, w) RPN activation the proposal stage computed."""
+    B = images.shape[0]
+    trunk = model.c4(images)
+    img_size = (images.shape[3], images.shape[2])
+    tr0 = trunk if torch.is_tensor(trunk) else trunk[0]
+    act = None
+    if hasattr(model, "proposals_batch"):
+        if want_rpn_activation:              # computed once: the proposal stage and the caller's on-line RPN harvest read the same map
+            act = model.rpn_activation(trunk)
+        props = model.proposals_batch(trunk, img_size, t=act)
+    else:
+        props = [model.proposals(model.trunk_slice(trunk, b) if hasattr(model, "trunk_slice") else trunk[b:b + 1], img_size) for b in range(B)]
+    boxes_list = []
+    for b in range(B):
+        bx = props[b][0]
+        gt = None if gt_boxes_list is None else gt_boxes_list[b]
+        if gt is not None and len(gt):
+            bx = torch.cat((gt.to(bx.device).float(), bx), dim=0)
+        boxes_list.append(bx)
+    counts = [int(bx.shape[0]) for bx in boxes_list]
+    bidx = torch.repeat_interleave(torch.arange(B, device=tr0.device), torch.tensor(counts, device=tr0.device))
+    maps = model.roi_head_maps(trunk, torch.cat(boxes_list, dim=0), batch_idx=bidx)
+    feats = maps.mean(dim=(2, 3))
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    out = [(boxes_list[b], feats[offs[b]:offs[b + 1]]) for b in range(B)], trunk, maps, offs
+    return out + (act,) if want_rpn_activation else out
 
 
 def detect(model, image, orig_size=None, score_thresh=-2.0, nms_thresh=0.3, detections_per_img=100, with_masks=False):
@@ -697,13 +810,14 @@ class OnlineFeatureExtractor:
     `parts` selects what is harvested: any of "rpn", "detector", "mask"."""
 
     def __init__(self, model, num_classes, parts=("rpn", "detector"), det=None, rpn=None, mask=None, rank=0, world=1,
-                 pipeline=True, trunk_batch=2):
+                 pipeline=True, trunk_batch=4):
         self.model, self.C, self.parts, self.rank, self.world = model, num_classes, tuple(parts), rank, world
         self.pipeline = pipeline        # on a GPU: forward of the next image on a second thread / stream while this one is harvested
-        # on a GPU: consecutive images of one size share a trunk call (1 = one image per call).  With > 1 a harvested row
-        # depends, in its last bits, on the image's neighbour in the list and on the rank sharding (the convolution library
-        # picks its algorithm per batch size) and differs in rounding from detect() / forward(), which see one image:
-        # trunk_batch = 1 (cfg_options['trunk_batch'] of the facade) is the per-image bit-reproducible setting
+        # on a GPU: consecutive images of one size share ONE forward — trunk, proposal stage and RoI head each run once for the
+        # group (forward_batch; 1 = one image per call).  With > 1 a harvested row depends, in its last bits, on the image's
+        # neighbours in the list and on the rank sharding (the convolution library picks its algorithm per batch size) and
+        # differs in rounding from detect() / forward(), which see one image: trunk_batch = 1 (cfg_options['trunk_batch'] of
+        # the facade) is the per-image bit-reproducible setting
         self.trunk_batch = trunk_batch
         self.det_kw = dict(iterations=10, batch_size=2000, neg_iou_thresh=0.3, reg_min_overlap=0.6, shuffle_negatives=False)
         self.rpn_kw = dict(iterations=10, batch_size=2000, neg_iou_thresh=0.3, pos_iou_thresh=0.7, shuffle_negatives=False)
@@ -734,12 +848,15 @@ class OnlineFeatureExtractor:
             with torch.no_grad():
                 if c4 is None:
                     c4 = m.c4(image)
+                t_act = None
                 if hv_rpn is not None and len(gt_boxes):
                     item["anchors"] = grid_anchors(c4.shape[2], c4.shape[3], m.stride, m.cells.to(dev))
-                    item["t"] = m.rpn_activation(c4)[0]
+                    t_act = m.rpn_activation(c4)
+                    item["t"] = t_act[0]
                 if hv_det is None and hv_mask is None:
                     return item
-                boxes, _ = m.proposals(c4, img_size)
+                # (the RPN activation is computed once: the harvest and the proposal stage read the same map)
+                boxes, _ = m.proposals(c4, img_size, t_act) if (t_act is not None and not hasattr(m, "trunk_slice")) else m.proposals(c4, img_size)
                 if len(gt_boxes):
                     boxes = torch.cat((gt_boxes, boxes), dim=0)
                 maps = m.roi_head_maps(c4, boxes)
@@ -751,11 +868,48 @@ class OnlineFeatureExtractor:
                     item["mg"] = project_masks_on_boxes(masks.to(dev), gt_boxes, item["act"].shape[2])
             return item
 
+        def forward_group(group):
+            """forward_one for `len(group)` > 1 images of one size through ONE forward (forward_batch: trunk, proposal stage
+            and RoI head each once for the group); the per-image items come out in the group's order."""
+            unp = [_unpack(smp) for smp in group]
+            images = torch.cat([u[0].to(dev) for u in unp], dim=0)
+            gts = [u[1].to(dev).float() for u in unp]
+            img_size = (images.shape[3], images.shape[2])
+            items = [{"gt_boxes": gts[j], "gt_labels": list(unp[j][2]), "img_size": img_size} for j in range(len(group))]
+            with torch.no_grad():
+                need_heads = hv_det is not None or hv_mask is not None
+                want_t = hv_rpn is not None and any(len(g) for g in gts)
+                ts = None
+                if need_heads:
+                    res = forward_batch(m, images, gts, want_rpn_activation=want_t)
+                    per, c4s, maps, offs = res[:4]
+                    ts = res[4] if want_t else None
+                else:
+                    c4s = m.c4(images)
+                if want_t:
+                    if ts is None:
+                        ts = m.rpn_activation(c4s)
+                    anchors = grid_anchors(c4s.shape[2], c4s.shape[3], m.stride, m.cells.to(dev))
+                    for j, it in enumerate(items):
+                        if len(gts[j]):
+                            it["anchors"], it["t"] = anchors, ts[j]
+                if need_heads:
+                    for j, it in enumerate(items):
+                        it["boxes"] = per[j][0]
+                        if hv_det is not None:
+                            it["feats"] = per[j][1]
+                        masks = unp[j][3]
+                        if hv_mask is not None and masks is not None and len(it["gt_labels"]):
+                            it["act"] = m.mask_activation(maps[offs[j]:offs[j] + len(it["gt_labels"])])
+                            it["mg"] = project_masks_on_boxes(masks.to(dev), gts[j], it["act"].shape[2])
+            return items
+
         def forward_items(seq):
-            """forward_one for every sample, in order; consecutive images of one size go through the trunk together
-            (`trunk_batch` at a time): at batch 1 the trunk is 53 latency-bound library calls (1.6-1.9 ms for 64 GFLOP),
-            two images cost 2.4 ms.  Everything behind the trunk stays per image."""
+            """forward_one for every sample, in order; consecutive images of one size go through the forward together,
+            `trunk_batch` at a time (forward_group).  A network whose trunk hands out several maps (the pyramid of odx/fpn.py)
+            shares the trunk call only and runs everything behind it per image."""
             k = max(1, int(self.trunk_batch)) if dev.type == "cuda" else 1
+            whole = hasattr(m, "proposals_batch")
             i = 0
             while i < len(seq):
                 group = [seq[i]]
@@ -765,6 +919,9 @@ class OnlineFeatureExtractor:
                         group.append(seq[i + len(group)])
                 if len(group) == 1:
                     yield forward_one(group[0])
+                elif whole:
+                    for item in forward_group(group):
+                        yield item
                 else:
                     with torch.no_grad():
                         c4s = m.c4(torch.cat([_unpack(smp)[0].to(dev) for smp in group], dim=0))
@@ -792,7 +949,8 @@ class OnlineFeatureExtractor:
             main = torch.cuda.current_stream()
             fwd = torch.cuda.Stream()
             fwd.wait_stream(main)
-            q = queue.Queue(maxsize=2)
+            q = queue.Queue(maxsize=2 * max(1, int(self.trunk_batch)) + 2)      # two groups ahead: the next group's forward starts
+            # while the current group's items are still being harvested
             stop = threading.Event()
 
             def put(x):

@@ -30,6 +30,7 @@ _vp, _i64, _i32, _f64, _f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, cty
 # name -> (restype, argtypes): exactly the declarations of include/odx.h
 SIGNATURES = {
     "odx_last_error_string": (ctypes.c_char_p, []),
+    "odx_knm_pass_kernel_name": (ctypes.c_char_p, [_i64, _i32, _i32]),
     "odx_version": (_i32, []),
     "odx_device_cus": (_i32, []),
     "odx_stream_create_cu_mask": (_i32, [_vp, _i32, _vp]),
@@ -111,6 +112,8 @@ SIGNATURES = {
     "odx_rls_predict_rows_batched_f64": (_i32, [_vp, _i64, _i32, _vp, _vp, _i32, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "odx_roi_align_fwd_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _f32, _i32, _i32, _i32, _vp, _vp]),
     "odx_split_f16_taps3x3": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "odx_gemm_b16": (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp]),
+    "odx_taps3x3_16": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "odx_gemm_h2_f32": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
     "odx_roi_align_rows_f32": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _f32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "odx_roi_align_fpn_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
@@ -119,6 +122,7 @@ SIGNATURES = {
     "odx_nms_first_f32": (_i32, [_vp, _i32, _f32, _i32, _vp, _vp, _i64, _vp]),
     "odx_nms_batched_workspace_bytes": (_i64, [_i32, _i32]),
     "odx_nms_batched_f32": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _i64, _vp]),
+    "odx_nms_batched_first_f32": (_i32, [_vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp, _i64, _vp]),
     "odx_paste_masks_u8": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
     "odx_bias_act_nchw_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp]),
     "odx_bias_act_nchw_16": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _i64, _i32, _vp]),

@@ -496,13 +496,19 @@ def test_dropin_feature_extractor_shards_images_only_on_request(monkeypatch):
 
 @pytest.mark.gpu
 def test_pipelined_harvest_equals_the_sequential_loop():
-    """OnlineFeatureExtractor runs the forward of image k + 1 on a second thread / stream while image k is harvested.
-    Harvesting stays in image order on the caller's thread, so every buffer must be what the plain loop gives (same row
-    counts and batch structure; values equal up to the run-to-run noise MIOpen convolutions are allowed)."""
+    """OnlineFeatureExtractor runs the forward of the next images on a second thread / stream while image k is harvested,
+    FOUR images of one size per forward (trunk, proposal stage and RoI head once per group: forward_batch).  Harvesting stays
+    in image order on the caller's thread, so every buffer must be what the plain one-image-at-a-time loop gives (same row
+    counts and batch structure — i.e. the same proposals, labels and random draws; values equal up to the noise the
+    convolution library is allowed between batch sizes)."""
     from odx.extract import OnlineFeatureExtractor
     odx.set_backend(None)
     C = 4
-    model = OnlineDetectionModel(width=16, post_nms_top_n=60, pre_nms_top_n=600).cuda().eval()
+    model = OnlineDetectionModel(width=16, post_nms_top_n=60, pre_nms_top_n=600).eval()
+    torch.manual_seed(2)
+    model.rpn_logits.weight.data.normal_(0, 0.3)          # well separated scores: the comparison is of the pipeline, not of how
+    model.rpn_deltas.weight.data.normal_(0, 0.05)         # the convolution library rounds a tie at two batch sizes
+    model = model.cuda()
     samples = []
     for (img, gt, labels) in _samples(7, 192, 256, C, seed=9):
         masks = torch.zeros((len(labels), 192, 256), dtype=torch.uint8)
@@ -511,12 +517,16 @@ def test_pipelined_harvest_equals_the_sequential_loop():
             masks[j, y1:y2, x1:x2] = 1
         samples.append((img, gt, labels, masks))
     out = {}
-    for pipe in (False, True):
+    for pipe, tb in ((False, 1), (True, 4), (False, 4)):
         torch.manual_seed(11)
         ex = OnlineFeatureExtractor(model, C, parts=("rpn", "detector", "mask"), det={"iterations": 2, "batch_size": 30},
-                                    rpn={"iterations": 2, "batch_size": 30}, mask={"batch_size": 200}, pipeline=pipe)
-        out[pipe] = ex.train(samples)
-    a, b = out[False], out[True]
+                                    rpn={"iterations": 2, "batch_size": 30}, mask={"batch_size": 200}, pipeline=pipe, trunk_batch=tb)
+        out[(pipe, tb)] = ex.train(samples)
+    _same_harvest(out[(False, 1)], out[(True, 4)], samples)        # four images per forward, pipelined = one image at a time, plain loop
+    _same_harvest(out[(False, 1)], out[(False, 4)], samples)
+
+
+def _same_harvest(a, b, samples):
 
     def same(x, y):
         assert tuple(x.shape) == tuple(y.shape)
@@ -570,8 +580,12 @@ def _plain_roi_align(feat, boxes, scale, P):
 
 
 @pytest.mark.gpu
-def test_forward_gpu_equals_plain_torch_cpu():
-    """The COMPOSITION of the forward — trunk with folded batch norm, the top-k's own order feeding the early-stopping NMS
+@pytest.mark.parametrize("batch", [1, 3])
+def test_forward_gpu_equals_plain_torch_cpu(batch):
+    """batch = 3: the image sits in the middle of a batch of three of its size that goes through forward_batch — one trunk
+    call, one proposal stage (rpn_proposals_batch + odx_nms_batched_first_f32), one pass of the RoI head over all three images'
+    RoIs (round-4 review, item 2) — and must come out as it does alone.
+    The COMPOSITION of the forward — trunk with folded batch norm, the top-k's own order feeding the early-stopping NMS
     (odx_nms_first_f32), RoIAlign of only the bins the head's stride-2 convolutions read written as NHWC rows
     (odx_roi_align_rows_f32), the conv5 head as row GEMMs on the split-f16 tile cores, average pooling — on the MI355X
     against an independent plain-f32 torch restatement of the same network on the CPU: convolution -> frozen batch norm ->
@@ -600,7 +614,16 @@ def test_forward_gpu_equals_plain_torch_cpu():
     img = torch.randn(1, 3, 320, 416)
     gt = torch.tensor([[30.0, 40.0, 200.0, 260.0]])
     with torch.no_grad():
-        boxes, feats, c4 = model(img.cuda(), gt)
+        if batch == 1:
+            boxes, feats, c4 = model(img.cuda(), gt)
+        else:
+            from odx.extract import forward_batch
+            others = torch.randn(2, 3, 320, 416)
+            images = torch.cat((others[:1], img, others[1:]), dim=0).cuda()
+            per, c4s, _, offs = forward_batch(model, images, [None, gt, torch.tensor([[10.0, 10.0, 100.0, 90.0]])])
+            assert offs[0] == 0 and offs[-1] == sum(len(p[0]) for p in per)
+            (boxes, feats), c4 = per[1], c4s[1:2]
+            assert torch.equal(per[2][0][:1].cpu(), torch.tensor([[10.0, 10.0, 100.0, 90.0]]))      # every image keeps its own boxes
 
         # ---- the same network in plain torch on the CPU
         def block(b, x):

@@ -73,6 +73,10 @@ def assert_k_close(got, ref, sigma, variant="h2", note=None):
     assert err[near].max(initial=0.0) < max(ktol(sigma, variant), 8e-4 / sigma ** 2), (note, float(err[near].max(initial=0.0)))
 
 
+def _absmax(t):
+    return float(t.float().abs().max()) if t.numel() else 0.0
+
+
 def dev(a, dtype=None):
     return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
 
@@ -1119,6 +1123,112 @@ def test_split_f16_gemm_with_bias_residual_relu(m, n, K):
             want = want.clamp(min=0)
         got = be.gemm_h2(Ap, Bp, **kw)
         assert float((got.double() - want).abs().max()) < 3e-6 * scale + 1e-6, (kw.keys(), float((got.double() - want).abs().max()), scale)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("m,n,K", [(300, 70, 96), (1000, 512, 1024), (513, 257, 200), (4100, 2048, 512), (1, 1, 64), (3000, 640, 4608)])
+def test_b16_gemm_with_bias_residual_relu(be, dtype, tile, m, n, K):
+    """odx_gemm_b16: act(A B' + bias + residual) for plain bf16 / f16 operands, one MFMA term per product, f32 sums — both
+    tile cores, ragged shapes (K not a multiple of the 128-element row pad, m and n not multiples of the tiles), f32 output
+    against the f64 product of the SAME 16-bit values, 16-bit output = that result rounded once; the pad columns of a result
+    that becomes the next layer's operand are zero."""
+    dt = getattr(torch, dtype)
+    g = torch.Generator(device="cuda").manual_seed(m + n + K)
+    A = (torch.randn((m, K), generator=g, device="cuda") * 0.5).to(dt)
+    B = (torch.randn((n, K), generator=g, device="cuda") * 0.5).to(dt)
+    bias = torch.randn(n, generator=g, device="cuda")
+    res32 = torch.randn((m, n), generator=g, device="cuda")
+    res16 = res32.to(dt)
+    be.pin_gauss_tile(tile)
+    try:
+        Ar, Br = be.rows16(A), be.rows16(B)
+        assert Ar.buf.shape[1] % 128 == 0 and _absmax(Ar.buf[:, K:]) == 0.0
+        ref = A.double() @ B.double().t()
+        scale = float((A.double().abs() @ B.double().abs().t()).max())
+        got = be.gemm_b16(Ar, Br, out_f32=True)
+        assert float((got.double() - ref).abs().max()) <= 2e-6 * scale
+        full = torch.relu(ref + bias.double() + res32.double())
+        got = be.gemm_b16(Ar, Br, bias=bias, residual=res32, relu=True, out_f32=True)
+        assert float((got.double() - full).abs().max()) <= 2e-6 * (scale + 8.0)
+        full16 = torch.relu(ref + bias.double() + res16.double())
+        out = be.gemm_b16(Ar, Br, bias=bias, residual=be.rows16(res16), relu=True)
+        assert out.buf.dtype == dt and out.K == n and out.buf.shape[1] % 128 == 0
+        assert _absmax(out.buf[:, n:]) == 0.0
+        ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11        # half a unit in the last place is at most this times |x|
+        err = (out.dense.double() - full16).abs()
+        assert bool((err <= ulp * full16.abs() * 1.01 + 4e-6 * (scale + 8.0) + 1e-7).all())     # ONE rounding of the f32 result
+        plain = be.gemm_b16(Ar, Br)                                                   # no epilogue terms at all
+        assert bool(((plain.dense.double() - ref).abs() <= ulp * ref.abs() * 1.01 + 4e-6 * scale + 1e-7).all())
+    finally:
+        be.pin_gauss_tile(0)
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("R,H,W,C", [(5, 7, 7, 64), (3, 4, 9, 8), (1, 1, 1, 16), (2200, 6, 5, 8), (300, 7, 7, 512)])
+def test_16bit_3x3_taps_equal_the_gathered_matrix(be, dtype, R, H, W, C):
+    """odx_taps3x3_16: the 9-tap neighbourhood matrix of 16-bit NHWC rows, bit for bit the padded gather, zeros beyond 9 C."""
+    dt = getattr(torch, dtype)
+    g = torch.Generator(device="cuda").manual_seed(R + C)
+    Y = torch.randn((R * H * W, C), generator=g, device="cuda").to(dt)
+    P = be.taps3x3_16(be.rows16(Y), R, H, W)
+    yp = torch.nn.functional.pad(Y.view(R, H, W, C), (0, 0, 1, 1, 1, 1))
+    want = torch.cat([yp[:, ky:ky + H, kx:kx + W, :] for ky in range(3) for kx in range(3)], dim=3).reshape(R * H * W, 9 * C)
+    assert P.K == 9 * C and torch.equal(P.dense, want)
+    assert _absmax(P.buf[:, 9 * C:]) == 0.0
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_conv5_head_in_16_bit_equals_its_layer_by_layer_statement(be, dtype):
+    """Conv5Head on 16-bit rows (what a compute_dtype = bf16 forward runs: odx_gemm_b16 + odx_taps3x3_16, no vendor GEMM)
+    against the layer-by-layer statement of that arithmetic in f64 on the host — folded weights rounded once to the 16-bit
+    type, exact products of 16-bit values, bias and identity added before the ONE rounding of each layer's output — and
+    within the type's rounding of the f32 head."""
+    from odx.extract import Conv5Head
+    dt = getattr(torch, dtype)
+    torch.manual_seed(0)
+    head = Conv5Head(64).eval()
+    for mod in head.modules():
+        if hasattr(mod, "running_var"):
+            mod.running_var.uniform_(0.5, 1.5)
+            mod.running_mean.normal_(0, 0.3)
+            mod.weight.data.normal_(1, 0.1)
+            mod.bias.data.normal_(0, 0.3)
+    R, H, W = 37, 7, 7
+    x = torch.randn((R * H * W, 64))
+    head = head.cuda()
+    with torch.no_grad():
+        got = head.forward_rows(x.cuda().to(dt), R, H, W)                     # (R, 128, H, W) view of 16-bit rows
+        f32 = head.forward_rows(x.cuda(), R, H, W)
+    assert got.dtype == dt
+    rnd = lambda t: t.to(dt).double()                                           # noqa: E731
+    cur = rnd(x)
+    hc = head.cpu()
+    for blk in hc.layer4:
+        def wb(conv, bn, taps=False):
+            scale = bn.weight * bn.running_var.rsqrt()
+            w = conv.weight * scale.view(-1, 1, 1, 1)
+            w = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1) if taps else w.reshape(w.shape[0], -1)
+            return rnd(w), rnd(bn.bias - bn.running_mean * scale)
+        idn = cur
+        if blk.down is not None:
+            w, b = wb(blk.down[0], blk.down[1])
+            idn = rnd(cur @ w.t() + b)
+        w, b = wb(blk.conv1, blk.bn1)
+        y = rnd(torch.relu(cur @ w.t() + b))
+        mid = y.shape[1]
+        yp = torch.nn.functional.pad(y.view(R, H, W, mid), (0, 0, 1, 1, 1, 1))
+        cols = torch.cat([yp[:, ky:ky + H, kx:kx + W, :] for ky in range(3) for kx in range(3)], dim=3).reshape(R * H * W, 9 * mid)
+        w, b = wb(blk.conv2, blk.bn2, taps=True)
+        y = rnd(torch.relu(cols @ w.t() + b))
+        w, b = wb(blk.conv3, blk.bn3)
+        cur = rnd(torch.relu(y @ w.t() + b + idn))
+    want = cur.view(R, H, W, -1).permute(0, 3, 1, 2)
+    # (an f32 sum in another order can land on the other side of a rounding boundary: single elements may differ by one unit
+    # of the 16-bit type, and that difference travels through the next layers)
+    rel = float((got.double().cpu() - want).norm() / want.norm())
+    assert rel < (2e-3 if dt == torch.bfloat16 else 3e-4), rel
+    assert float((got.float() - f32).norm() / f32.norm()) < (3e-2 if dt == torch.bfloat16 else 4e-3)
 
 
 @pytest.mark.parametrize("R,H,W,C", [(5, 7, 7, 64), (3, 4, 9, 8), (1, 1, 1, 16), (2200, 6, 5, 8)])
