@@ -72,6 +72,10 @@ def parse():
     ap.add_argument("--check", action="store_true", help="verify one class against the oracle on a row sample")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only for the "
                     "single-device debugging mode below")
+    ap.add_argument("--emulate-world", type=int, default=0, help="run ONE rank's share of a job of this many ranks alone on this GPU "
+                    "(its 1 / W of the rows for all classes, the chains of the classes it owns, collectives replaced by local copies "
+                    "of the right size): the rank's compute-only step time — a prediction, not a measurement of W GPUs")
+    ap.add_argument("--emulate-rank", type=int, default=0, help="which rank of --emulate-world to run")
     ap.add_argument("--single-device", action="store_true",
                     help="debugging: every rank uses cuda:0 (exercises the sharded path on a 1-GPU box)")
     return ap.parse_args()
@@ -222,6 +226,13 @@ def main():
 
     be = odx.get_backend()
     shard = RowShard()
+    emulated = args.emulate_world > 1
+    if emulated:
+        if world > 1:
+            print("bench.py: --emulate-world runs in one process", file=sys.stderr)
+            sys.exit(2)
+        from odx.dist import EmulatedShard
+        shard = EmulatedShard(args.emulate_world, args.emulate_rank)
     N, D, M, C = args.n, args.D, args.M, args.classes
     lo, hi = shard.bounds(N)
     n_loc = hi - lo
@@ -230,6 +241,17 @@ def main():
     F = None                                       # kernel operands of X (row norms, packed f16 split): derived inside every step
     row_ids = torch.arange(lo, hi, device=device)
     cidx = centre_indices(N, C, M, seed)
+    if emulated:
+        # the centres' rows live on all ranks; this process holds one rank's: every centre index is folded onto a row of THIS
+        # shard with the same class id (row i is of class i % C), so that a class's centres keep their positives / negatives
+        # make-up and the Gaussian blocks their statistics
+        def fold(idx):
+            cls = idx % C
+            first = lo + ((cls - lo) % C)                          # first row of that class in [lo, hi)
+            cnt = np.maximum((hi - first + C - 1) // C, 1)
+            return first + C * ((idx // C) % cnt)
+        cidx = [fold(i) for i in cidx]
+        assert all(int(i.min()) >= lo and int(i.max()) < hi for i in cidx)
     cidx_dev = [torch.from_numpy(i).to(device) for i in cidx]     # inputs of the job: resident before the timed region
     opt = SolverOptions(check_pivots=False)       # no host sync inside the timed region: every status is read after it
     infos = []                                    # Cholesky status words of every preconditioner built in the timed region
@@ -397,7 +419,8 @@ def main():
         F_K = 2.0 * (2.0 * N * M * D) * C
         B_CG = (args.maxiter + 1.0) * float(N) * M * s_K * C
         F_pc = (2.0 * M * M * D + float(M) ** 3) * C
-        t_K, t_CG, t_pc = F_K / (gpeak * 1e12) / world, B_CG / (HBM_PEAK_GBS * 1e9) / world, F_pc / (pk_f64 * 1e12) / world
+        wshare = args.emulate_world if emulated else world      # GPUs the job's work is spread over
+        t_K, t_CG, t_pc = F_K / (gpeak * 1e12) / wshare, B_CG / (HBM_PEAK_GBS * 1e9) / wshare, F_pc / (pk_f64 * 1e12) / wshare
         roof_step = {"F_K_flop": F_K, "B_CG_bytes": B_CG, "F_pc_flop": F_pc, "s_K_bytes_per_entry": round(s_K, 3),
                      "peaks": {"mfma_TFLOPs": gpeak, "hbm_GBps": HBM_PEAK_GBS, "mfma_f64_TFLOPs": pk_f64},
                      "t_K_s": round(t_K, 4), "t_CG_s": round(t_CG, 4), "t_pc_s": round(t_pc, 4),
@@ -421,7 +444,7 @@ def main():
                                                 if be.gauss == "h2" else "f32 K_nM (f32-input MFMA) + f64 solver"),
             "data": "synthetic",
             "config": {"workload": "%d-class one-vs-rest FALKON fit + score-all, N=%d D=%d M=%d, %d CG iterations, "
-                                   "rows sharded over %d GPU(s)" % (C, N, D, M, args.maxiter, world),
+                                   "rows sharded over %d GPU(s)" % (C, N, D, M, args.maxiter, args.emulate_world if emulated else world),
                        "N": N, "D": D, "M": M, "classes": C, "sigma": args.sigma, "lambda": args.lam,
                        "rows_per_gpu": n_loc, "preconditioners_per_batched_chain": G, "preconditioner_cus": args.precond_cus or "all",
                        "lockstep_batch": job_b, "planned_GB_per_rank": plan_gb},
@@ -432,11 +455,17 @@ def main():
             "phases_ms_per_step_rank0": phases,
             "health": health,
         }
-        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only
+        if emulated:
+            out["metric"] += " — ONE RANK'S COMPUTE of a %d-rank job, emulated on one GPU (a prediction)" % args.emulate_world
+            out["emulated"] = {"world": args.emulate_world, "rank": args.emulate_rank, "rows_of_this_rank": n_loc,
+                               "collectives_replaced_by_local_copies_warmup_included": {k: {"calls": v[0], "bytes": v[1]} for k, v in shard.calls.items()},
+                               "note": "value = N / this rank's compute-only step time: what the %d-rank job would reach if every rank took "
+                                       "this long and the collectives were free; unmeasured on hardware" % args.emulate_world}
+        if not args.no_cpu_baseline and world == 1 and not emulated:      # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args)
         if args.check:
             out["check"] = check_against_oracle(be, F, last, X, row_ids, args, C - 1)
-        if not args.no_extras and world == 1:
+        if not args.no_extras and world == 1 and not emulated:
             # the other halves of BASELINE configs 2 and 3 (RLS regressors, feature forward) and the reference-regime
             # minibootstrap: measured after and outside the timed headline region, with its buffers released first
             job.release()

@@ -73,3 +73,46 @@ class RowShard:
             dist.all_reduce(partials, op=dist.ReduceOp.SUM, group=self.group)
             out.copy_(partials[self.rank])
         return out
+
+
+class EmulatedShard(RowShard):
+    """ONE rank's share of a `world`-rank job, run alone in a single process: the rank's row bounds, its place among the
+    owners, the collectives replaced by local copies of the right size (their calls and bytes are counted).  What comes out is
+    the rank's COMPUTE — every kernel it would launch on its 1 / world of the rows, the preconditioner chains of the classes
+    it owns — not the job's numbers: partial sums of the other ranks are missing, directions of the classes other ranks own
+    are stand-ins (this rank's own).  For measuring the per-rank step time of a multi-GPU job on a one-GPU box
+    (bench.py --emulate-world); the row indices handed to the job must lie in this rank's range (the caller folds them)."""
+
+    def __init__(self, world, rank):
+        self.group = None
+        self.enabled = False
+        self.world, self.rank = int(world), int(rank)
+        if not 0 <= self.rank < self.world:
+            raise ValueError("EmulatedShard: rank %d outside a world of %d" % (self.rank, self.world))
+        self.emulated = True
+        self.calls = {"all_reduce": [0, 0], "all_gather": [0, 0], "reduce_scatter": [0, 0], "broadcast": [0, 0]}   # [calls, bytes]
+
+    def _count(self, kind, t):
+        self.calls[kind][0] += 1
+        self.calls[kind][1] += int(t.numel()) * int(t.element_size())
+
+    def allreduce(self, v):
+        self._count("all_reduce", v)
+        return v
+
+    def total(self, n_local):
+        return int(n_local) * self.world
+
+    def broadcast(self, t, src=0):
+        self._count("broadcast", t)
+        return t
+
+    def gather_rows(self, mine, out):
+        self._count("all_gather", out)
+        out.copy_(mine.unsqueeze(0).expand_as(out))       # every owner's direction stands in as this rank's
+        return out
+
+    def reduce_scatter_rows(self, partials, out):
+        self._count("reduce_scatter", partials)
+        out.copy_(partials[self.rank])                    # this rank's partial of its own problem only
+        return out

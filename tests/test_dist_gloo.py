@@ -347,3 +347,51 @@ def test_lockstep_batches_smaller_than_the_world(b, chain):
         a, Z = fr.falkon_fit(Xd, y, cidx[c], 6.0, 1e-4, maxiter=20, dtype=np.float64, pc_eps=1e-5, cg_epsilon=1e-7)
         want = fr.falkon_predict(Xd, Z, a, 6.0)[:, 0]
         assert np.abs(scores[:, c] - want).max() < 1e-6 * max(1.0, np.abs(want).max()), c
+
+
+@pytest.mark.parametrize("world,rank", [(8, 0), (8, 7), (4, 2)])
+def test_emulated_rank_runs_the_schedule_of_the_real_rank(world, rank):
+    """odx.dist.EmulatedShard (bench.py --emulate-world): ONE rank's share of a `world`-rank job in a single process — the
+    schedule it executes (every lock-step batch fitted, the preconditioners of exactly the classes that rank owns, chain by
+    chain), the rows it holds and the collectives it would have issued (one all-gather + one reduce-scatter of a (world, M)
+    f64 matrix per exchange, one all-reduce of the centres per class) are those of the real rank of the gloo runs above; its
+    numbers are finite (they are a rank's partial sums, not the job's)."""
+    import odx
+    from odx import plan
+    from odx.dist import EmulatedShard, shard_bounds
+    from odx.job import LockstepClassJob
+    from tests.oracle_backend import OracleBackend
+    N, D, M, C = 2400, 16, 40, 30
+    odx.set_backend(OracleBackend(np.float64))
+    try:
+        be = odx.get_backend()
+        X, cidx = _job_problem(N, D, M, C)
+        shard = EmulatedShard(world, rank)
+        lo, hi = shard.bounds(N)
+        assert (lo, hi) == shard_bounds(N, world, rank)
+        # centre indices folded onto this rank's rows, class ids kept (what bench.py does under --emulate-world)
+        folded = []
+        for i in cidx:
+            cls = i % C
+            first = lo + ((cls - lo) % C)
+            cnt = np.maximum((hi - first + C - 1) // C, 1)
+            folded.append(first + C * ((i // C) % cnt))
+            assert folded[-1].min() >= lo and folded[-1].max() < hi and ((folded[-1] % C) == cls).all()
+        row_ids = torch.arange(lo, hi)
+        job = LockstepClassJob(be, torch.from_numpy(X[lo:hi]), N, M, lambda c: torch.where((row_ids % C) == c, 1.0, -1.0).double(),
+                               [torch.from_numpy(i) for i in folded], 6.0, 1e-4, 20, shard=shard)
+        job.run(be.features(job.X))
+        sched = plan.lockstep_batches(range(C), world, job.b)
+        assert [p for k, p in job.trace if k == "fit"] == [tuple(b) for b, _ in sched]
+        owned = [c for b, owners in sched for c, o in zip(b, owners) if o == rank]
+        assert [c for k, p in job.trace if k == "precond" for c in p] == owned
+        assert torch.isfinite(job.scores).all() and tuple(job.scores.shape) == (hi - lo, C)
+        calls = shard.calls
+        assert calls["all_reduce"][0] == C and calls["all_reduce"][1] == C * M * D * 4          # the centres of every class, f32 rows
+        assert calls["all_gather"][0] == calls["reduce_scatter"][0]     # paired: per exchange, + the right-hand side's scatter / alpha's gather ...
+        Mp = (M + 1) // 2 * 2
+        per = world * Mp * 8
+        assert calls["all_gather"][1] % per == 0 and calls["reduce_scatter"][1] % per == 0      # ... of (world, M) f64 matrices (or two vectors wide)
+        assert calls["all_gather"][0] >= len(sched) * 21 and calls["reduce_scatter"][0] >= len(sched) * 21
+    finally:
+        odx.set_backend(None)
