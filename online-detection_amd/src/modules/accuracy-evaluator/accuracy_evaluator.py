@@ -16,6 +16,7 @@ As for the FeatureExtractor drop-in, dataset classes, images and pretrained weig
                             reads it (then odx.extract.preprocess_image applies the reference transform)
     cfg_options['model']    an odx.extract.OnlineDetectionModel (default: R-50-C4 with seeded random weights; load a
                             reference checkpoint with odx.extract.load_reference_checkpoint)
+    (neither given, as in the reference's unchanged drivers: ODX_SAMPLES / ODX_MODEL = "module:callable", odx/providers.py)
     cfg_options['class_names']  names for the per-class lines (default: the YAML's CHOSEN_CLASSES, else "class_i")
 """
 import os
@@ -77,6 +78,8 @@ class AccuracyEvaluator(AccuracyEvaluatorAbstract):
     def evaluateAccuracyDetection(self, is_train, output_dir=None, save_features=False, evaluate_segmentation=True,
                                   eval_segm_with_gt_bboxes=False, normalize_features_regressors=False,
                                   evaluate_segmentation_icwt=False, cfg_options={}):
+        from odx import providers
+        cfg_options = providers.fill(cfg_options, 'train' if is_train else 'test', self.cfg_path_target_task)      # ODX_SAMPLES / ODX_MODEL
         if 'samples' not in cfg_options:
             raise NotImplementedError("dataset loading (iCWT / YCB-V / HO-3D through maskrcnn_benchmark) is outside this "
                                       "repository: pass the test images as cfg_options['samples']")

@@ -24,6 +24,8 @@ and load Detectron weights; datasets, weights and that package are outside this 
                                  last bits (the convolution library picks its algorithm per batch size) and so differ
                                  in rounding from the one-image detect() / forward() path used at test time: pass 1 for
                                  runs whose harvested rows must be bit-reproducible per image
+A driver that passes neither (the reference's own, unchanged) gets both through the environment: ODX_SAMPLES /
+ODX_MODEL = "module:callable" (odx/providers.py).
 The MINIBOOTSTRAP / REGRESSORS values are read from the feature-extraction YAML when present.
 """
 import os
@@ -107,6 +109,8 @@ class FeatureExtractor(FeatureExtractorAbstract):
         return kw
 
     def _harvest(self, cfg_path, parts, is_train, use_only_gt_positives, cfg_options, output_dir, label, save_features=False):
+        from odx import providers
+        cfg_options = providers.fill(cfg_options, 'train' if is_train else 'test', cfg_path)     # ODX_SAMPLES / ODX_MODEL
         if 'samples' not in cfg_options:
             raise NotImplementedError(self._NEED_SAMPLES)
         cfg = self._cfg(cfg_path)

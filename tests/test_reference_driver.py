@@ -1,0 +1,133 @@
+"""The reference's experiment driver, UNCHANGED, on the drop-in modules (round-4 review, item 6; north star: "experiments/
+run_experiment_* call it unchanged").
+
+tests/golden/driver_run.{npz,json} (made by tests/golden/make_driver_golden.py, container-only) hold the feature caches a tiny
+seeded network harvested and a summary of what experiments/run_experiment_online_rpn_ood_oos.py — its source text compiled
+and run as __main__, not a line changed — left in its output directory when run on them with
+`--load_RPN_detector_segmentation_features --save_RPN_detector_segmentation_models --CPU`: the three classifier / regressor /
+stats model files (structure, shapes, norms, leading values) and the mAP lines of result.txt.
+
+  * where /root/reference exists (this container): the driver is executed again and must leave exactly that;
+  * everywhere: the same call sequence restated on the drop-in modules (tests/driver_fixture.replay) leaves exactly that on
+    the CPU (f64 oracle backend) — the restatement IS the driver's sequence —, and
+  * on the MI355X (libodx): the same models to the north star's tolerances — alphas 1e-4 relative, mAP within 0.1."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+import odx
+from tests import driver_fixture as df
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _fixture():
+    arrays = dict(np.load(os.path.join(HERE, "golden", "driver_run.npz")))
+    want = json.load(open(os.path.join(HERE, "golden", "driver_run.json")))
+    return arrays, want
+
+
+def _setup(tmp_path, device):
+    arrays, want = _fixture()
+    out = str(tmp_path)
+    df.unpack_cache(arrays, out, device)
+    cfg_path = os.path.join(out, "cfg.yaml")
+    yaml.safe_dump(df.config(), open(cfg_path, "w"))
+    return out, cfg_path, want
+
+
+def _close(got, want, rtol, path=""):
+    if isinstance(want, dict):
+        assert isinstance(got, dict) and sorted(got) == sorted(want), path
+        for k in want:
+            _close(got[k], want[k], rtol, path + "/" + str(k))
+    elif isinstance(want, list):
+        assert isinstance(got, list) and len(got) == len(want), path
+        for i, (g, w) in enumerate(zip(got, want)):
+            _close(g, w, rtol, path + "[%d]" % i)
+    elif isinstance(want, float):
+        assert abs(got - want) <= rtol * max(1.0, abs(want)), (path, got, want)
+    else:
+        assert got == want, (path, got, want)
+
+
+def _maps(lines):
+    return {m.group(1): float(m.group(2)) for l in lines for m in [re.match(r"(\w+) mAP50: ([0-9.]+|nan)", l)] if m}
+
+
+@pytest.mark.skipif(not os.path.exists(df.REF_DRIVER), reason="the reference is only present in the build container")
+def test_reference_driver_runs_unchanged_on_the_dropins(tmp_path, monkeypatch):
+    from tests.golden.make_driver_golden import run_reference_driver
+    from tests.oracle_backend import OracleBackend
+    odx.set_backend(OracleBackend(np.float64))
+    try:
+        out, cfg_path, want = _setup(tmp_path, "cpu")
+        run_reference_driver(out, cfg_path)                     # experiments/run_experiment_online_rpn_ood_oos.py, unmodified
+        got = df.summarize(out)
+        _close(got, want, 1e-9)
+        assert got["files"] == ["cfg.yaml", "classifier_detector", "classifier_rpn", "classifier_segmentation", "regressor_detector",
+                                "regressor_rpn", "result.txt", "stats_detector", "stats_rpn", "stats_segmentation"]
+        assert set(_maps(got["result_lines"])) == {"Detection", "Segmentation"}
+    finally:
+        odx.set_backend(None)
+
+
+def test_restated_call_sequence_leaves_what_the_driver_left_cpu(tmp_path):
+    from tests.oracle_backend import OracleBackend
+    odx.set_backend(OracleBackend(np.float64))
+    try:
+        out, cfg_path, want = _setup(tmp_path, "cpu")
+        torch.manual_seed(df.SEED)
+        os.environ["ODX_SAMPLES"], os.environ["ODX_MODEL"] = "tests.driver_fixture:samples", "tests.driver_fixture:model"
+        try:
+            res = df.replay(out, cfg_path, cpu=True)
+        finally:
+            del os.environ["ODX_SAMPLES"], os.environ["ODX_MODEL"]
+        assert set(res) == {"ap", "map"}
+        _close(df.summarize(out), want, 1e-9)
+    finally:
+        odx.set_backend(None)
+
+
+@pytest.mark.gpu
+def test_driver_call_sequence_on_the_gpu_matches_the_reference_run(tmp_path):
+    """The GPU route of the same driver (no --CPU: the `_incore` classes, caches as a GPU harvest leaves them) through libodx:
+    same files, same structure and shapes, every FALKON alpha within 1e-4 relative and every regressor within 1e-5 of what the
+    reference driver's run produced with the f64 oracle backend, mAP within 0.1."""
+    odx.set_backend(None)
+    assert odx.get_backend().name == "hip-gfx950"
+    out, cfg_path, want = _setup(tmp_path, "cuda")
+    torch.manual_seed(df.SEED)
+    os.environ["ODX_SAMPLES"], os.environ["ODX_MODEL"] = "tests.driver_fixture:samples", "tests.driver_fixture:model"
+    try:
+        df.replay(out, cfg_path, cpu=False)
+    finally:
+        del os.environ["ODX_SAMPLES"], os.environ["ODX_MODEL"]
+    got = df.summarize(out)
+    assert got["files"] == want["files"]
+    for tag in ("rpn", "detector", "segmentation"):
+        assert len(got[tag]["classifiers"]) == len(want[tag]["classifiers"])
+        for g, w in zip(got[tag]["classifiers"], want[tag]["classifiers"]):
+            assert (g is None) == (w is None), tag
+            if w is None:
+                continue
+            assert (g["M"], g["D"], g["alpha_shape"]) == (w["M"], w["D"], w["alpha_shape"]), tag
+            assert abs(g["centres_sum"] - w["centres_sum"]) <= 1e-4 * max(1.0, abs(w["centres_sum"])), tag     # the same centres were drawn
+            assert abs(g["alpha_norm"] - w["alpha_norm"]) <= 1e-4 * w["alpha_norm"], (tag, g["alpha_norm"], w["alpha_norm"])
+            assert max(abs(a - b) for a, b in zip(g["alpha_head"], w["alpha_head"])) <= 1e-4 * w["alpha_norm"], tag
+        for g, w in zip(got[tag].get("regressors", []), want[tag].get("regressors", [])):
+            assert (g is None) == (w is None), tag
+            if w is not None:
+                assert g["weights_shape"] == w["weights_shape"] and g["losses_rows"] == w["losses_rows"]
+                assert abs(g["weights_norm"] - w["weights_norm"]) <= 1e-5 * max(1.0, w["weights_norm"]), tag
+        _close(got[tag]["stats"], want[tag]["stats"], 1e-5, tag + "/stats")
+    gm, wm = _maps(got["result_lines"]), _maps(want["result_lines"])
+    assert set(gm) == set(wm)
+    for k in wm:
+        assert abs(gm[k] - wm[k]) <= 0.1, (k, gm[k], wm[k])
+    print("driver on the GPU:", gm, "reference run:", wm)
