@@ -118,6 +118,11 @@ class HipBackend:
         """Scratch buffer of a call site, one per stream it has been used on (fits issued on different streams must not
         share scratch; the main stream keeps the bare key)."""
         nbytes = max(int(nbytes), 16)
+        if torch.cuda.is_current_stream_capturing():
+            # inside a HIP-graph capture (extract.GraphedCall): the kernels being recorded keep this address for as long as the graph
+            # is replayed, so the buffer must belong to the GRAPH — a fresh allocation from the capture's private pool — and never
+            # to the shared table, whose entries are replaced when a later call asks for more (use after free on the next replay)
+            return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         cur = torch.cuda.current_stream(self.device)
         if cur != torch.cuda.default_stream(self.device):
             key = (key, cur.cuda_stream)
@@ -198,6 +203,8 @@ class HipBackend:
         """Two zeroed floats (scale, max |x| bits) for one matrix, cut from a pool that is zeroed once per 4096 matrices —
         a fill launch per matrix otherwise (a Minibootstrap round: ~250 of them).  A slot is handed out once; the slices
         keep their pool alive."""
+        if torch.cuda.is_current_stream_capturing():          # (see _workspace: memory a captured graph refers to is the graph's own)
+            return torch.zeros(2, dtype=torch.float32, device=self.device)
         cur = torch.cuda.current_stream(self.device)
         key = cur.cuda_stream
         pool = self._meta_pools.get(key)

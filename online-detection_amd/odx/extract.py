@@ -485,6 +485,7 @@ class GraphedCall:
         import threading
         self.fn, self.max_graphs = fn, max_graphs
         self.graphs = {}
+        self.captures = {}                     # key -> times captured (see __call__)
         self.seen = {}                         # shape -> calls so far: a shape is captured at its SECOND call (a stream of images
         # that all differ in size — capture costs three forwards — then simply runs launch by launch)
         self.enabled = os.environ.get("ODX_TRUNK_GRAPH", "1") != "0"
@@ -493,6 +494,7 @@ class GraphedCall:
     def clear(self):
         with self.lock:
             self.graphs.clear()                 # (the shapes seen so far stay seen: the next call of one captures again)
+            self.captures.clear()
 
     def __getstate__(self):                     # a copied / pickled model starts without graphs (they are tied to this process's buffers)
         return {"fn": self.fn, "max_graphs": self.max_graphs, "enabled": self.enabled}
@@ -500,51 +502,61 @@ class GraphedCall:
     def __setstate__(self, d):
         import threading
         self.fn, self.max_graphs, self.enabled = d["fn"], d["max_graphs"], d["enabled"]
-        self.graphs, self.seen, self.lock = {}, {}, threading.Lock()
+        self.graphs, self.seen, self.captures, self.lock = {}, {}, {}, threading.Lock()
 
-    def _capture(self, x):
-        static_in = x.clone()
+    def _capture(self, xs):
+        static_in = tuple(x.clone() for x in xs)
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):           # the library picks its algorithms and the caches fill outside the capture
             for _ in range(2):
-                self.fn(static_in)
+                self.fn(*static_in)
         cur.wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):     # (the extractor's other thread keeps allocating)
-            static_out = self.fn(static_in)
+            static_out = self.fn(*static_in)
         return graph, static_in, static_out
 
-    def __call__(self, x):
+    def __call__(self, x, *more, key_extra=None, capture=True):
+        """fn(x, *more): every argument a tensor of fixed shape per key (copied into the graph's own inputs); key_extra:
+        whatever else the captured work depends on (hashable); capture=False: replay a graph that exists, never make one in
+        this call (a thread that shares the device with another thread's launches: a capture is made where nothing else runs)."""
+        xs = (x,) + tuple(more)
         if not (self.enabled and x.is_cuda and not torch.is_grad_enabled()):
-            return self.fn(x)
-        key = (tuple(x.shape), x.dtype, x.device.index, torch.is_autocast_enabled("cuda"),
-               torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None)
+            return self.fn(*xs)
+        key = (tuple((tuple(t.shape), t.dtype) for t in xs), x.device.index, torch.is_autocast_enabled("cuda"),
+               torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None, key_extra)
         with self.lock:
             entry = self.graphs.pop(key, None)
             if entry is None:
                 n = self.seen.get(key, 0)
+                if not capture:
+                    return self.fn(*xs)
                 if n < 1:
                     if len(self.seen) > 256:
                         self.seen.clear()
                     self.seen[key] = n + 1
-                    return self.fn(x)
+                    return self.fn(*xs)
+                if self.captures.get(key, 0) >= 2:    # captured, evicted, captured, evicted: this stream of shapes cycles through
+                    return self.fn(*xs)               # more of them than are kept — a capture costs ~4 plain calls, stop paying it
+                self.captures[key] = self.captures.get(key, 0) + 1
                 try:
-                    entry = self._capture(x)
+                    entry = self._capture(xs)
                 except Exception as e:          # noqa: BLE001 — whatever the runtime refuses: the plain call is always right
                     self.enabled = False
-                    print("odx: HIP graph capture of the trunk failed (%s: %s); running it launch by launch" % (type(e).__name__, e),
-                          file=sys.stderr)
-                    return self.fn(x)
+                    print("odx: HIP graph capture of %s failed (%s: %s); running it launch by launch" % (
+                        getattr(self.fn, "__name__", "the forward"), type(e).__name__, e), file=sys.stderr)
+                    return self.fn(*xs)
                 while len(self.graphs) >= self.max_graphs:
                     self.graphs.pop(next(iter(self.graphs)))
             self.graphs[key] = entry             # (re-inserted last: most recently used)
             graph, static_in, static_out = entry
-            static_in.copy_(x)
+            for dst, src in zip(static_in, xs):
+                dst.copy_(src)
             graph.replay()
-            return static_out.clone() if torch.is_tensor(static_out) else tuple(t.clone() for t in static_out)
+            return static_out.clone() if torch.is_tensor(static_out) else tuple(None if t is None else t.clone() for t in static_out)
 
 
 class OnlineDetectionModel(nn.Module):
@@ -581,15 +593,29 @@ class OnlineDetectionModel(nn.Module):
         self.online_mask = None         # odx.heads.OnlineMaskPredictor
         self.mask_dim = mask_dim
         self._trunk_graphs = GraphedCall(self._c4_eager)
+        # The whole group forward from ONE HIP graph (forward_group): OFF unless ODX_GROUP_GRAPH=1.  Forward-only loops replay it
+        # fine (3.0 ms per image at 8 images per group, f32) and so does a 16-channel-wide network inside the harvest loop, but
+        # at 600 x 800 with ground-truth slots the SECOND replay — the first one after other launches have run in between —
+        # ends in a GPU memory fault (tools/group_graph_probe.py localises it: the capture's own replay and that group's harvest
+        # are fine, the next group's replay faults); with graph-owned workspaces, blocking index copies, no second thread and
+        # no library transposed convolution in the graph alike.  Cause not found this round: the harvest loop therefore queues
+        # a group's forward launch by launch (forward_batch) and the code below stays as the opt-in it is.
+        self._group_graphs = GraphedCall(self._group_static, max_graphs=4)
+        if os.environ.get("ODX_GROUP_GRAPH", "0") != "1":
+            self._group_graphs.enabled = False
         self.register_load_state_dict_post_hook(OnlineDetectionModel._drop_graphs)
 
     @staticmethod
     def _drop_graphs(module, incompatible):
         module._trunk_graphs.clear()
+        module._group_graphs.clear()
+        module.__dict__.pop("_mask_pack", None)
 
     def _apply(self, fn, *a, **kw):
         if "_trunk_graphs" in self.__dict__:
             self._trunk_graphs.clear()          # (.to / .cuda / .half: the captured graphs point at the old tensors)
+            self._group_graphs.clear()
+            self.__dict__.pop("_mask_pack", None)
         return super()._apply(fn, *a, **kw)
 
     @property
@@ -608,7 +634,7 @@ class OnlineDetectionModel(nn.Module):
     @torch.no_grad()
     def c4(self, image):
         """(1, C, H/16, W/16) f32 trunk features; on the GPU replayed from a HIP graph per image size (GraphedCall)."""
-        return self._trunk_graphs(image)
+        return self._trunk_graphs(image, key_extra=self.compute_dtype)
 
     def update_model(self, models_rpn=None, models_detection=None, models_segmentation=None):
         """Swap trained on-line models into the running pipeline, each a dict {'classifiers', 'regressors', 'stats'}
@@ -658,6 +684,97 @@ class OnlineDetectionModel(nn.Module):
         anchors = grid_anchors(c4.shape[2], c4.shape[3], self.stride, self.cells.to(c4.device))
         return rpn_proposals_batch(logits, deltas, anchors, img_size, self.pre_nms_top_n, self.post_nms_top_n, self.rpn_nms)
 
+    def _group_static(self, images, gt_slots, anchors):
+        """The forward of B images of one size with NOTHING data-dependent in its shapes, so that it can be replayed from ONE HIP
+        graph (forward_group): every image has `gpad` ground-truth slots (gt_slots (B, gpad, 4); unused ones hold a dummy box)
+        followed by post_nms_top_n proposal slots — the first survivors of the suppression in score order, found with a top-k over
+        the keep flags' positions instead of a masked select; when fewer survive, the tail slots hold suppressed candidates and
+        the count n[b] says where they start.  Returns (slots (B, gpad + P, 4), n (B,), features (B (gpad + P), D), RPN activation
+        (B, C, h, w), mask activation of the ground-truth slots (B gpad, mask_dim, r, r))."""
+        be = _backend.get_backend()
+        B, gpad = gt_slots.shape[0], gt_slots.shape[1]
+        img_size = (images.shape[3], images.shape[2])
+        c4 = self._c4_eager(images)
+        t = self.rpn_activation(c4)
+        with self._amp():
+            logits, deltas = self.rpn_logits(t).float(), self.rpn_deltas(t).float()
+        _, A, H, W = logits.shape            # (anchors: an argument — made from host constants, a copy a capture does not allow)
+        if anchors.shape[0] != H * W * A:
+            raise ValueError("forward_group: %d anchors for a %d x %d map of %d types" % (anchors.shape[0], H, W, A))
+        obj = logits.permute(0, 2, 3, 1).reshape(B, -1).sigmoid()
+        reg = deltas.view(B, A, 4, H, W).permute(0, 3, 4, 1, 2).reshape(B, -1, 4)
+        k = min(self.pre_nms_top_n, obj.shape[1])
+        score, idx = obj.topk(k, dim=1, sorted=True)
+        cand = decode_deltas(reg.gather(1, idx.unsqueeze(2).expand(B, k, 4)).reshape(B * k, 4), anchors[idx.reshape(-1)])
+        cand[:, 0].clamp_(0, img_size[0] - 1)
+        cand[:, 2].clamp_(0, img_size[0] - 1)
+        cand[:, 1].clamp_(0, img_size[1] - 1)
+        cand[:, 3].clamp_(0, img_size[1] - 1)
+        cand = cand.view(B, k, 4)
+        keep = be.nms_batched(cand, torch.full((B,), k, dtype=torch.int32, device=cand.device), self.rpn_nms, max_keep=self.post_nms_top_n)
+        P = min(self.post_nms_top_n, k)
+        pos = torch.arange(k, device=cand.device).unsqueeze(0)
+        order = torch.where(keep, pos, pos + k).topk(P, dim=1, largest=False, sorted=True)[1]       # survivors first, in score order
+        props = cand.gather(1, order.unsqueeze(2).expand(B, P, 4))
+        slots = torch.cat((gt_slots, props), dim=1)
+        bidx = torch.arange(B, device=cand.device).repeat_interleave(gpad + P)
+        maps = self.roi_head_maps(c4, slots.reshape(-1, 4), batch_idx=bidx)
+        feats = maps.mean(dim=(2, 3))
+        act = self.mask_activation(maps.view(B, gpad + P, *maps.shape[1:])[:, :gpad].reshape(B * gpad, *maps.shape[1:])) if gpad else None
+        return slots, keep.sum(dim=1), feats, t, act
+
+    @torch.no_grad()
+    def forward_group(self, images, gt_boxes_list, capture=True):
+        """forward_batch for a group of B images, replayed from ONE HIP graph per (shape, ground-truth slots): trunk, RPN head,
+        top-k, decoding, suppression, RoIAlign, conv5 head, mask activation — ~300 launches per image launch by launch, one
+        graph launch once captured.  Returns a list of per-image dicts: boxes (ground truth first), feats, t (RPN activation),
+        act (mask activation of the ground-truth rows).  One host synchronisation (the survivor counts).  begin / finish: the
+        same in two halves — begin queues the group's forward and returns at once, finish waits for it —, so that ONE host
+        thread can harvest group k while the GPU runs group k + 1 (OnlineFeatureExtractor.train)."""
+        return self.forward_group_finish(self.forward_group_begin(images, gt_boxes_list, capture))
+
+    @torch.no_grad()
+    def forward_group_begin(self, images, gt_boxes_list, capture=True):
+        B = images.shape[0]
+        dev = images.device
+        G = [0 if g is None else int(len(g)) for g in gt_boxes_list]
+        gpad = (max(G) + 3) // 4 * 4
+        gt_slots = torch.zeros((B, gpad, 4), dtype=torch.float32, device=dev)
+        if gpad:
+            gt_slots[:, :, 2:] = 15.0                       # unused slots: a harmless 16 x 16 box
+            for b, g in enumerate(gt_boxes_list):
+                if G[b]:
+                    gt_slots[b, :G[b]] = g.to(dev).float()
+        h, w = -(-images.shape[2] // self.stride), -(-images.shape[3] // self.stride)          # the C4 map: ceil(size / 16)
+        akey = (h, w, str(dev))
+        anchors = self.__dict__.setdefault("_anchor_cache", {}).get(akey)
+        if anchors is None:
+            if len(self._anchor_cache) > 16:
+                self._anchor_cache.clear()
+            anchors = self._anchor_cache[akey] = grid_anchors(h, w, self.stride, self.cells.to(dev))
+        out = self._group_graphs(images, gt_slots, anchors, key_extra=(self.pre_nms_top_n, self.post_nms_top_n, self.rpn_nms,
+                                                                       self.compute_dtype, self.resolution), capture=capture)
+        return (out, G, gpad)
+
+    @torch.no_grad()
+    def forward_group_finish(self, handle):
+        """The per-image results of a forward_group_begin: waits for that group's forward (the survivor counts are read on the
+        host — the group's one synchronisation; call it on the stream the group was begun on)."""
+        (slots, n, feats, t, act), G, gpad = handle
+        B, dev = slots.shape[0], slots.device
+        n = n.tolist()
+        P = slots.shape[1] - gpad
+        sel = torch.tensor([b * (gpad + P) + j for b in range(B) for j in list(range(G[b])) + list(range(gpad, gpad + n[b]))],
+                           dtype=torch.int64).to(dev)       # (a blocking copy: the host list is a temporary)
+        boxes_all, feats_all = slots.view(-1, 4).index_select(0, sel), feats.index_select(0, sel)
+        out, at = [], 0
+        for b in range(B):
+            r = G[b] + n[b]
+            out.append({"boxes": boxes_all[at:at + r], "feats": feats_all[at:at + r], "t": t[b],
+                        "act": None if act is None or not G[b] else act[b * gpad:b * gpad + G[b]]})
+            at += r
+        return out
+
     @torch.no_grad()
     def roi_head_maps(self, c4, boxes, batch_idx=None):
         """(R, D, r/2, r/2): RoIAlign r x r @ 1/stride (HIP kernel) -> conv5 head.  batch_idx (R,): the image of c4 (N > 1)
@@ -684,7 +801,26 @@ class OnlineDetectionModel(nn.Module):
 
     @torch.no_grad()
     def mask_activation(self, head_maps):
-        """(R, mask_dim, r, r) = relu(conv5_mask(head maps))  (roi_mask_predictors.py:38)."""
+        """(R, mask_dim, r, r) = relu(conv5_mask(head maps))  (roi_mask_predictors.py:38).  conv5_mask is a 2 x 2, stride-2
+        transposed convolution: every input position feeds its own 2 x 2 output block, i.e. out[(r, i, j), (oc, di, dj)] =
+        in[(r, i, j), :] . W[:, oc, di, dj] — ONE product over the head's NHWC rows.  On the GPU in f32 it runs on the split-f16
+        tile core with bias + ReLU in the GEMM's epilogue (f32 accuracy; also what keeps this step inside a captured forward:
+        the library's transposed convolution brought a workspace of its own into the graph)."""
+        be = _backend.get_backend() if head_maps.is_cuda else None
+        cm = self.conv5_mask
+        if (be is not None and hasattr(be, "gemm_h2") and self.compute_dtype is None and head_maps.dtype == torch.float32
+                and head_maps.shape[0] > 0 and tuple(cm.kernel_size) == (2, 2) and tuple(cm.stride) == (2, 2) and tuple(cm.padding) == (0, 0)
+                and tuple(cm.output_padding) == (0, 0) and cm.groups == 1):
+            R, Cin, H, W = head_maps.shape
+            rows = head_maps.permute(0, 2, 3, 1).reshape(R * H * W, Cin)          # a view when the maps are the head's NHWC rows
+            key = (cm.weight.data_ptr(), cm.weight._version, cm.bias._version)
+            hit = self.__dict__.get("_mask_pack")
+            if hit is None or hit[0] != key:
+                wt = cm.weight.detach().float().reshape(Cin, -1).t().contiguous()                 # (Cout * 4, Cin): column (oc, di, dj)
+                hit = self.__dict__["_mask_pack"] = (key, be.packed(wt), cm.bias.detach().float().repeat_interleave(4).contiguous())
+            out = be.gemm_h2(be.packed(rows), hit[1], bias=hit[2], relu=True)               # (R H W, Cout * 4)
+            Cout = cm.out_channels
+            return out.view(R, H, W, Cout, 2, 2).permute(0, 3, 1, 4, 2, 5).reshape(R, Cout, 2 * H, 2 * W)
         with self._amp():
             return F.relu(self.conv5_mask(head_maps.contiguous())).float()      # (the head hands out an NHWC-strided view)
 
@@ -868,17 +1004,47 @@ class OnlineFeatureExtractor:
                     item["mg"] = project_masks_on_boxes(masks.to(dev), gt_boxes, item["act"].shape[2])
             return item
 
-        def forward_group(group):
+        def group_graph_ok(group):
+            return (dev.type == "cuda" and (hv_det is not None or hv_mask is not None) and len(group) > 1
+                    and len(group) == max(1, int(self.trunk_batch)) and hasattr(m, "forward_group_begin") and m.online_rpn is None
+                    and getattr(m._group_graphs, "enabled", False))
+
+        def group_begin(group):
+            """Queue the forward of a full group as ONE HIP-graph launch (OnlineDetectionModel.forward_group_begin) and return
+            at once; None for a group that goes launch by launch (forward_group does all of it then)."""
+            if not group_graph_ok(group):
+                return None
+            unp = [_unpack(smp) for smp in group]
+            with torch.no_grad():
+                return m.forward_group_begin(torch.cat([u[0].to(dev) for u in unp], dim=0), [u[1].to(dev).float() for u in unp])
+
+        def forward_group(group, graphed=None):
             """forward_one for `len(group)` > 1 images of one size through ONE forward (forward_batch: trunk, proposal stage
-            and RoI head each once for the group); the per-image items come out in the group's order."""
+            and RoI head each once for the group; `graphed`: the group's group_begin, whose results are collected here); the
+            per-image items come out in the group's order."""
             unp = [_unpack(smp) for smp in group]
             images = torch.cat([u[0].to(dev) for u in unp], dim=0)
             gts = [u[1].to(dev).float() for u in unp]
             img_size = (images.shape[3], images.shape[2])
             items = [{"gt_boxes": gts[j], "gt_labels": list(unp[j][2]), "img_size": img_size} for j in range(len(group))]
+            need_heads = hv_det is not None or hv_mask is not None
+            want_t = hv_rpn is not None and any(len(g) for g in gts)
+            if graphed is not None:
+                # a full group: the whole forward replayed from one HIP graph (no host work but the copies in and out)
+                res = m.forward_group_finish(graphed)
+                anchors = grid_anchors(res[0]["t"].shape[1], res[0]["t"].shape[2], m.stride, m.cells.to(dev)) if want_t else None
+                for j, (it, r) in enumerate(zip(items, res)):
+                    it["boxes"] = r["boxes"]
+                    if hv_det is not None:
+                        it["feats"] = r["feats"]
+                    if want_t and len(gts[j]):
+                        it["anchors"], it["t"] = anchors, r["t"]
+                    masks = unp[j][3]
+                    if hv_mask is not None and masks is not None and len(it["gt_labels"]) and r["act"] is not None:
+                        it["act"] = r["act"]
+                        it["mg"] = project_masks_on_boxes(masks.to(dev), gts[j], it["act"].shape[2])
+                return items
             with torch.no_grad():
-                need_heads = hv_det is not None or hv_mask is not None
-                want_t = hv_rpn is not None and any(len(g) for g in gts)
                 ts = None
                 if need_heads:
                     res = forward_batch(m, images, gts, want_rpn_activation=want_t)
@@ -920,7 +1086,9 @@ class OnlineFeatureExtractor:
                 if len(group) == 1:
                     yield forward_one(group[0])
                 elif whole:
-                    for item in forward_group(group):
+                    # (a full group from one HIP graph — but only on the caller's own thread: the two-thread loop below keeps to
+                    # plain launches, a capture or replay beside another thread's launches faulted on this runtime)
+                    for item in forward_group(group, None if in_thread[0] else group_begin(group)):
                         yield item
                 else:
                     with torch.no_grad():
@@ -939,13 +1107,60 @@ class OnlineFeatureExtractor:
             if "act" in item:
                 hv_mask.add_image(item["act"], item["mg"], item["gt_labels"])
 
-        if dev.type == "cuda" and self.pipeline and len(samples) > 1:
-            # Two host threads, two streams: the forward of image k + 1 (57 convolutions to enqueue, two host <-> GPU
-            # round trips in the proposal stage) runs while image k is harvested (its own host <-> GPU round trips for the
-            # data-dependent sizes).  Harvesting stays strictly in image order on the caller's thread and stream, so the
-            # RNG draws and every buffer are what the sequential loop produces.
+        def split_groups(seq):
+            k = max(1, int(self.trunk_batch)) if dev.type == "cuda" else 1
+            out, i = [], 0
+            while i < len(seq):
+                group = [seq[i]]
+                if k > 1:
+                    shape = tuple(_unpack(seq[i])[0].shape)
+                    while len(group) < k and i + len(group) < len(seq) and tuple(_unpack(seq[i + len(group)])[0].shape) == shape:
+                        group.append(seq[i + len(group)])
+                out.append(group)
+                i += len(group)
+            return out
+
+        groups = split_groups(samples)
+        in_thread = [False]
+        if dev.type == "cuda" and self.pipeline and len(groups) > 1 and any(group_graph_ok(g) for g in groups):
+            # ONE host thread, two streams: the forward of group k + 1 is queued (a single HIP-graph launch for a full group:
+            # no host work to speak of) on the forward stream BEFORE group k is harvested on the caller's stream, so the GPU
+            # runs it under the harvest's host work; the host waits for a group only when it needs its survivor counts.  (Two
+            # threads — below, for networks without a graphed group forward — share the interpreter: with ~300 launches per
+            # image to queue, the forward thread and the harvesting thread took turns and the loop was bound by their sum.)
+            main = torch.cuda.current_stream()
+            fwd = torch.cuda.Stream()
+            fwd.wait_stream(main)
+
+            def begin(group):
+                with torch.cuda.stream(fwd):
+                    return (group, group_begin(group))
+
+            def finish(state):
+                group, graphed = state
+                with torch.cuda.stream(fwd):
+                    items = (forward_group(group, graphed) if graphed is not None else
+                             ([forward_one(group[0])] if len(group) == 1 else forward_group(group)))
+                    ev = torch.cuda.Event()
+                    ev.record(fwd)
+                return items, ev
+
+            state = begin(groups[0])
+            for gi in range(len(groups)):
+                items, ev = finish(state)                               # waits for group gi (its survivor counts)
+                if gi + 1 < len(groups):
+                    state = begin(groups[gi + 1])                       # group gi + 1 runs on the GPU ...
+                main.wait_event(ev)
+                for item in items:                                      # ... while group gi is harvested here
+                    for v in item.values():
+                        if torch.is_tensor(v) and v.is_cuda:
+                            v.record_stream(main)
+                    harvest_one(item)
+            fwd.synchronize()
+        elif dev.type == "cuda" and self.pipeline and len(samples) > 1:
             import queue
             import threading
+            in_thread[0] = True
             main = torch.cuda.current_stream()
             fwd = torch.cuda.Stream()
             fwd.wait_stream(main)

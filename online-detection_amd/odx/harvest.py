@@ -146,7 +146,7 @@ class _SlotGrid:
         dst = np.repeat(runs[:, 0], ks) + ramp
         src = np.repeat(np.asarray(self.src, dtype=np.int64), ks) + ramp
         self.dst, self.src = [], []
-        idx = torch.from_numpy(np.stack((dst, src))).to(rows.device, non_blocking=True)     # one host -> device copy
+        idx = torch.from_numpy(np.stack((dst, src))).to(rows.device)      # one host -> device copy (blocking: the array is a temporary)
         # the rows take the store's dtype / device here (f64 or f16 features, features of another device): index_copy_
         # itself accepts neither, and by now `plan` has already counted the rows
         picked = rows.index_select(0, idx[1]).to(device=self.store.device, dtype=self.store.dtype)
@@ -564,8 +564,8 @@ def project_masks_on_boxes(masks, boxes, M):
 
     xa, xb, wxa, wxb = taps(wn[:, 0], wn[:, 2] - wn[:, 0])       # (G, M) each
     ya, yb, wya, wyb = taps(wn[:, 1], wn[:, 3] - wn[:, 1])
-    idx = torch.from_numpy(np.stack((xa, xb, ya, yb))).to(dev, non_blocking=True)
-    wts = torch.from_numpy(np.stack((wxa, wxb, wya, wyb))).to(dev, non_blocking=True)
+    idx = torch.from_numpy(np.stack((xa, xb, ya, yb))).to(dev)
+    wts = torch.from_numpy(np.stack((wxa, wxb, wya, wyb))).to(dev)
     xa, xb, ya, yb = idx[0], idx[1], idx[2], idx[3]
     wxa, wxb, wya, wyb = wts[0], wts[1], wts[2], wts[3]
     g = torch.arange(G, device=dev)[:, None, None]
@@ -628,7 +628,7 @@ class MaskHarvester:
         for (c, kind), lst in picks.items():
             loc = torch.cat([p for _, p in lst])
             obj = torch.cat([torch.full((len(p),), i, dtype=torch.int64) for i, p in lst])
-            idx = torch.stack((obj, loc)).to(dev, non_blocking=True)
+            idx = torch.stack((obj, loc)).to(dev)
             sel = order[idx[0], idx[1]] + idx[0] * S2
             (self._pos if kind == 0 else self._neg)[c].append(rows.index_select(0, sel), seg_lens=[len(p) for _, p in lst])
 

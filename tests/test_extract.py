@@ -547,6 +547,85 @@ def _same_harvest(a, b, samples):
     assert sum(len(p) for p in a["detector"][1]) == sum(len(s[2]) for s in samples)
 
 
+@pytest.mark.gpu
+def test_mask_activation_as_a_product_over_the_rows_equals_the_transposed_convolution():
+    """relu(conv5_mask(x)) — a 2 x 2, stride-2 transposed convolution — as ONE product over the head's NHWC rows on the
+    split-f16 tile core (OnlineDetectionModel.mask_activation on the GPU) against the library's transposed convolution and an
+    f64 evaluation on the host: NHWC-strided maps as the head hands them out and plain NCHW ones, one RoI and many."""
+    odx.set_backend(None)
+    model = OnlineDetectionModel(width=16, mask_dim=24, seed=2).cuda().eval()
+    model.conv5_mask.bias.data.normal_(0, 0.5)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for R in (1, 7, 40):
+        rows = torch.randn((R * 7 * 7, 512), generator=g, device="cuda")
+        nhwc = rows.view(R, 7, 7, 512).permute(0, 3, 1, 2)
+        for x in (nhwc, nhwc.contiguous()):
+            with torch.no_grad():
+                got = model.mask_activation(x)
+                lib = torch.relu(model.conv5_mask(x.contiguous()))
+                ref = torch.relu(torch.nn.functional.conv_transpose2d(x.double().cpu(), model.conv5_mask.weight.double().cpu(),
+                                                                      model.conv5_mask.bias.double().cpu(), stride=2))
+            assert got.shape == lib.shape == (R, 24, 14, 14)
+            scale = float(ref.abs().max())
+            assert float((got.double().cpu() - ref).abs().max()) < 3e-6 * scale
+            assert float((got - lib).abs().max()) < 1e-4 * scale
+    assert model.mask_activation(torch.empty((0, 512, 7, 7), device="cuda")).shape == (0, 24, 14, 14)
+
+
+@pytest.mark.gpu
+def test_group_forward_from_one_graph_equals_the_eager_batched_forward():
+    """OnlineDetectionModel.forward_group — the whole forward of a group of images (trunk, RPN head, top-k, decoding,
+    suppression, RoIAlign, conv5 head, mask activation) replayed from ONE HIP graph with static shapes (ground-truth and
+    proposal SLOTS per image) — against forward_batch launched piece by piece: same boxes in the same order, features, RPN
+    activation and mask activation to the convolution library's noise; images without ground truth, different ground-truth
+    counts under one slot count reuse the graph; a changed post_nms_top_n gets a graph of its own."""
+    from odx.extract import forward_batch
+    odx.set_backend(None)
+    torch.manual_seed(4)
+    model = OnlineDetectionModel(width=16, pre_nms_top_n=500, post_nms_top_n=40, mask_dim=16, seed=8).eval()
+    model.rpn_logits.weight.data.normal_(0, 0.3)
+    model.rpn_deltas.weight.data.normal_(0, 0.05)
+    model = model.cuda()
+    model._group_graphs.enabled = True            # (opt-in: ODX_GROUP_GRAPH=1 — see OnlineDetectionModel.__init__ for why it is off by default)
+    g = torch.Generator().manual_seed(1)
+    images = torch.randn(4, 3, 192, 256, generator=g).cuda()
+
+    def gts(counts):
+        out = []
+        for c in counts:
+            xy = torch.rand(c, 2, generator=g) * torch.tensor([120.0, 90.0])
+            out.append(torch.cat((xy, xy + 30 + torch.rand(c, 2, generator=g) * 80), dim=1).cuda())
+        return out
+
+    def check(gt_list):
+        per, c4s, maps, offs, t = forward_batch(model, images, gt_list, want_rpn_activation=True)
+        res = model.forward_group(images, gt_list)
+        for b in range(4):
+            assert res[b]["boxes"].shape == per[b][0].shape
+            assert float((res[b]["boxes"] - per[b][0]).abs().max()) < 1e-3
+            assert float((res[b]["feats"] - per[b][1]).norm() / per[b][1].norm()) < 1e-4
+            assert float((res[b]["t"] - t[b]).abs().max()) <= 1e-4 * float(t[b].abs().max())
+            G = len(gt_list[b])
+            if G:
+                want = model.mask_activation(maps[offs[b]:offs[b] + G])
+                assert res[b]["act"].shape == want.shape and float((res[b]["act"] - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+            else:
+                assert res[b]["act"] is None
+    with torch.no_grad():
+        a = gts([2, 0, 1, 3])
+        check(a)                                              # first call of the shape: launch by launch
+        assert len(model._group_graphs.graphs) == 0
+        check(a)                                              # captured
+        assert model._group_graphs.enabled and len(model._group_graphs.graphs) == 1
+        check(gts([1, 4, 0, 2]))                              # other boxes, same slots: replayed
+        assert len(model._group_graphs.graphs) == 1
+        model.post_nms_top_n = 25
+        check(a)
+        check(a)
+        assert len(model._group_graphs.graphs) == 2
+        assert all(r["boxes"].shape[0] <= 25 + 3 for r in model.forward_group(images, a))
+
+
 def _plain_roi_align(feat, boxes, scale, P):
     """RoIAlign (maskrcnn_benchmark legacy form: no half-pixel shift, RoI sides clamped to >= 1, adaptive sampling grid
     ceil(side / P), samples outside [-1, size] contribute 0) in plain f32 torch, one RoI at a time, every bin / sample /

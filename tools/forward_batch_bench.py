@@ -34,12 +34,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--images", type=int, default=24)
     ap.add_argument("--phases", action="store_true", help="device time of trunk / proposals / head per group size")
+    ap.add_argument("--harvest-only", action="store_true")
+    ap.add_argument("--groups", default="1,2,4,8")
+    ap.add_argument("--pipe", default="1,0", help="harvest loop variants to time: 1 = forward of the next group under the harvest, 0 = plain loop")
+    ap.add_argument("--parts", default="rpn,detector,mask")
     args = ap.parse_args()
     odx.get_backend()
     dev = torch.device("cuda")
     g = torch.Generator().manual_seed(3)
     imgs = torch.randn((args.images, 3, 600, 800), generator=g).to(dev)
-    for name, dt in (("f32", None), ("bf16", torch.bfloat16)):
+    for name, dt in (() if args.harvest_only else (("f32", None), ("bf16", torch.bfloat16))):
         model = OnlineDetectionModel(compute_dtype=dt).to(dev).eval()
         for B in (1, 2, 4, 8):
             def run():
@@ -74,6 +78,21 @@ def main():
                     line += " | alone, per image: trunk %.2f, proposals %.2f, RoIAlign + head %.2f ms" % tuple(
                         ev[k].elapsed_time(ev[k + 1]) / 5 / B for k in range(3))
             print(line, flush=True)
+            if B > 1:
+                model._group_graphs.enabled = True          # (opt-in path: forward-only replays are fine, see extract.py)
+
+                def run_g():
+                    for i in range(0, args.images, B):
+                        model.forward_group(imgs[i:i + B], [None] * B)
+                with torch.no_grad():
+                    run_g()
+                    run_g()
+                    tg = best(run_g)
+                    t0 = time.perf_counter()
+                    run_g()
+                    th = time.perf_counter() - t0          # (includes the one synchronisation per group)
+                print("[%s] %d image(s) per forward, ONE HIP graph per group: %.2f ms per image (graphs kept: %d)" % (
+                    name, B, tg / args.images * 1e3, len(model._group_graphs.graphs)), flush=True)
     # the harvest loop
     C = 30
     model = OnlineDetectionModel().to(dev).eval()
@@ -89,14 +108,14 @@ def main():
             x1, y1, x2, y2 = [int(v) for v in boxes[j]]
             masks[j, y1 + 10:y2 - 10, x1 + 10:x2 - 10] = 1
         samples.append((imgs[i:i + 1], boxes.to(dev), labels, masks.to(dev)))
-    for tb in (1, 2, 4, 8):
-        for pipe in (True, False):
-            ex = OnlineFeatureExtractor(model, C, parts=("rpn", "detector", "mask"), pipeline=pipe, trunk_batch=tb)
+    for tb in [int(v) for v in args.groups.split(",")]:
+        for pipe in [v == "1" for v in args.pipe.split(",")]:
+            ex = OnlineFeatureExtractor(model, C, parts=tuple(args.parts.split(",")), pipeline=pipe, trunk_batch=tb)
             torch.manual_seed(0)
             ex.train(samples[:8])
             t = best(lambda: ex.train(samples))
-            print("harvest rpn+detector+mask, %d image(s) per forward, %s: %.2f ms per image" % (
-                tb, "pipelined" if pipe else "plain loop", t / args.images * 1e3), flush=True)
+            print("harvest %s, %d image(s) per forward, %s: %.2f ms per image" % (
+                args.parts, tb, "pipelined" if pipe else "plain loop", t / args.images * 1e3), flush=True)
 
 
 if __name__ == "__main__":
