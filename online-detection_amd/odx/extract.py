@@ -552,11 +552,18 @@ class GraphedCall:
                 while len(self.graphs) >= self.max_graphs:
                     self.graphs.pop(next(iter(self.graphs)))
             self.graphs[key] = entry             # (re-inserted last: most recently used)
-            graph, static_in, static_out = entry
+            graph, static_in, static_out = entry[:3]
+            cur = torch.cuda.current_stream()
+            if len(entry) > 3 and entry[3] is not None:
+                cur.wait_event(entry[3])         # the previous user's copies out of the graph's buffers — possibly on another stream
             for dst, src in zip(static_in, xs):
                 dst.copy_(src)
             graph.replay()
-            return static_out.clone() if torch.is_tensor(static_out) else tuple(None if t is None else t.clone() for t in static_out)
+            out = static_out.clone() if torch.is_tensor(static_out) else tuple(None if t is None else t.clone() for t in static_out)
+            done = torch.cuda.Event()
+            done.record(cur)
+            self.graphs[key] = (graph, static_in, static_out, done)
+            return out
 
 
 class OnlineDetectionModel(nn.Module):
@@ -634,7 +641,10 @@ class OnlineDetectionModel(nn.Module):
     @torch.no_grad()
     def c4(self, image):
         """(1, C, H/16, W/16) f32 trunk features; on the GPU replayed from a HIP graph per image size (GraphedCall)."""
-        return self._trunk_graphs(image, key_extra=self.compute_dtype)
+        w0, w1 = self.backbone.conv1.weight, self.backbone.layer3[-1].conv3.weight
+        # (the weights' storage and in-place version counters are part of the key: a graph replays the tensors it was captured
+        # with — an optimiser step or a copy_ into a weight must not be answered from the old capture)
+        return self._trunk_graphs(image, key_extra=(self.compute_dtype, w0.data_ptr(), w0._version, w1.data_ptr(), w1._version))
 
     def update_model(self, models_rpn=None, models_detection=None, models_segmentation=None):
         """Swap trained on-line models into the running pipeline, each a dict {'classifiers', 'regressors', 'stats'}
@@ -1075,7 +1085,9 @@ class OnlineFeatureExtractor:
             `trunk_batch` at a time (forward_group).  A network whose trunk hands out several maps (the pyramid of odx/fpn.py)
             shares the trunk call only and runs everything behind it per image."""
             k = max(1, int(self.trunk_batch)) if dev.type == "cuda" else 1
-            whole = hasattr(m, "proposals_batch")
+            # (forward_batch: one trunk call and ONE pass of the RoI head for the group; the proposal stage in one go for the C4
+            # network, image after image on the pyramid of odx/fpn.py, whose levels it already suppresses with one launch pair)
+            whole = hasattr(m, "proposals_batch") or (hasattr(m, "trunk_slice") and hv_rpn is None and hv_mask is None)
             i = 0
             while i < len(seq):
                 group = [seq[i]]

@@ -386,6 +386,14 @@ class BatchFit:
         self.ys += ys
         self.segments.append((first, len(estimators), Ps, side))
 
+    def abort(self):
+        """Give up the round: the caller's stream waits for every chain queued so far (they read rows and caches the caller
+        may free or rewrite next), nothing is fitted."""
+        for _, _, _, side in self.segments:
+            if side is not None and self.cur is not None:
+                self.cur.wait_stream(side)
+        self.segments = []
+
     def finish(self):
         be, cur, streams = self.be, self.cur, self.streams
         done = sum(c for _, c, _, _ in self.segments)

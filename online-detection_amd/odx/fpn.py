@@ -172,7 +172,8 @@ class OnlineDetectionModelFPN(nn.Module):
         """The pyramid of an image, on the GPU replayed from a HIP graph per image size (extract.GraphedCall: this forward is
         host-bound at batch 1 — trunk + pyramid are ~170 launches and the proposal stage behind them synchronises with the
         host per level, so the host never runs ahead)."""
-        return self._trunk_graphs(image)
+        w0 = self.backbone.conv1.weight
+        return self._trunk_graphs(image, key_extra=(self.compute_dtype, w0.data_ptr(), w0._version))
 
     def _c4_eager(self, image):
         """The trunk features of an image — here the pyramid (P2 .. P6) (the method keeps extract's name: the harvest loops
@@ -306,10 +307,14 @@ class OnlineDetectionModelFPN(nn.Module):
         return be.gemm_h2(be.packed(x), hit[1], bias=layer.bias.detach().float(), relu=True)
 
     @torch.no_grad()
-    def roi_features(self, trunk, boxes):
-        """(R, mlp_dim): Pooler over P2..P5 (one HIP launch for all levels) -> flatten -> fc6 -> ReLU -> fc7 -> ReLU."""
+    def roi_features(self, trunk, boxes, batch_idx=None):
+        """(R, mlp_dim): Pooler over P2..P5 (one HIP launch for all levels) -> flatten -> fc6 -> ReLU -> fc7 -> ReLU.
+        batch_idx (R,): the image of a batched pyramid each box is pooled from (extract.forward_batch: the RoIs of a group of
+        images go through fc6 / fc7 as ONE row matrix)."""
         be = _backend.get_backend()
-        rois = torch.cat((torch.zeros((boxes.shape[0], 1), device=boxes.device), boxes), dim=1)
+        first = (torch.zeros((boxes.shape[0], 1), device=boxes.device) if batch_idx is None
+                 else batch_idx.to(device=boxes.device, dtype=boxes.dtype).view(-1, 1))
+        rois = torch.cat((first, boxes), dim=1)
         crops = be.roi_align_fpn(list(trunk[:4]), rois, self.pool_scales, (self.resolution, self.resolution), self.sampling_ratio)
         x = crops.reshape(crops.shape[0], -1)
         if x.shape[0] == 0:
@@ -322,9 +327,9 @@ class OnlineDetectionModelFPN(nn.Module):
             return F.relu(self.fc7(F.relu(self.fc6(x)))).float()
 
     @torch.no_grad()
-    def roi_head_maps(self, trunk, boxes):
+    def roi_head_maps(self, trunk, boxes, batch_idx=None):
         """The features as (R, D, 1, 1) maps: what extract's harvest loop and detect() average over the last two axes."""
-        return self.roi_features(trunk, boxes)[:, :, None, None]
+        return self.roi_features(trunk, boxes, batch_idx)[:, :, None, None]
 
     @torch.no_grad()
     def forward(self, image, gt_boxes=None):

@@ -522,6 +522,15 @@ class OnlineRegionClassifierBase:
                         settle(g)
                         sets = training_sets(members)
                         if sets is None:
+                            # (advisor, round 4) an earlier group's chain may already be queued on the side streams and the other
+                            # group's predictions of the previous round may still be pending: join all of it before the
+                            # caller's fallback reuses the rows and caches on the main stream
+                            rnd.abort()
+                            for s in streams:
+                                main.wait_stream(s)
+                            for gg in list(pending):
+                                for ev in pending.pop(gg)[3]:
+                                    main.wait_event(ev)
                             return None
                         order += members
                         rnd.add(sets[0], sets[1], index_rng=with_class_rng)

@@ -262,7 +262,12 @@ class RegionRefinerTrainer:
         srcs = [t for j, i in enumerate(live) for t in (losses_all[span[i][0]:span[i][1]], W32[j], stats32[j])]
         own = [torch.empty_like(t) for t in srcs]
         if srcs:
-            torch._foreach_copy_(own, srcs)
+            fc = getattr(torch, "_foreach_copy_", None)       # one multi-tensor copy where this torch has it (a private entry point)
+            if fc is not None:
+                fc(own, srcs)
+            else:
+                for d_, s_ in zip(own, srcs):
+                    d_.copy_(s_)
         for j, i in enumerate(live):
             losses, Wc, sc = own[3 * j], own[3 * j + 1], own[3 * j + 2]
             Beta = {str(k): {'weights': Wc[k], 'losses': losses[:, k]} for k in range(4)}

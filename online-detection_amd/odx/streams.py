@@ -8,31 +8,36 @@ share one depends on the order in which all streams of the process were first us
 
 `distinct(n)` picks side streams by MEASURING: a candidate is kept if a marker recorded on it completes while a busy kernel is
 still running on the current stream and on every stream kept so far.  At most (hardware queues - 1) streams can qualify; the
-callers spread their work over what they get.  The result is cached per (device, current stream): ~50 ms once.
+callers spread their work over what they get.  The result is cached per (device, current stream): ~50 ms once; a heuristic —
+it changes how work overlaps, never what is computed.
 """
-import time
-
 import torch
 
 _CACHE = {}
 CANDIDATES = 12
-BUSY_CYCLES = 4_000_000      # ~2 ms of torch.cuda._sleep: the marker is looked at after 0.3 ms, a host hiccup of 1.5 ms changes nothing
-WAIT_S = 3e-4
+BUSY_CYCLES = 2_000_000      # ~1 ms of torch.cuda._sleep per reading
 
 
 def _collide(a, b, scratch):
-    """True when a marker on stream b does not complete while stream a is busy."""
-    torch.cuda.synchronize()
-    with torch.cuda.stream(a):
-        torch.cuda._sleep(BUSY_CYCLES)
-    done = torch.cuda.Event()
-    with torch.cuda.stream(b):
-        scratch.add_(1)
-        done.record()
-    time.sleep(WAIT_S)
-    hit = not done.query()
-    torch.cuda.synchronize()
-    return hit
+    """True when a marker on stream b does not complete while stream a is busy.  Decided from EVENT TIMES on the device — the
+    marker's completion against the start and the end of the busy kernel —, not from a host sleep: a stalled host (a loaded
+    box, a profiler attached) cannot make a colliding stream look independent (advisor, round 4).  Two readings must agree;
+    when they do not, the stream counts as colliding (the safe side: it is simply not picked)."""
+    verdicts = []
+    for _ in range(2):
+        torch.cuda.synchronize()
+        start, end, done = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        with torch.cuda.stream(a):
+            start.record()
+            torch.cuda._sleep(BUSY_CYCLES)
+            end.record()
+        with torch.cuda.stream(b):
+            scratch.add_(1)
+            done.record()
+        torch.cuda.synchronize()
+        busy = start.elapsed_time(end)
+        verdicts.append(start.elapsed_time(done) >= 0.5 * busy)     # independent: the marker is done microseconds after the start
+    return verdicts[0] or verdicts[1]
 
 
 def distinct(n, device=None):

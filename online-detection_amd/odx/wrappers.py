@@ -55,6 +55,10 @@ class _BatchRound:
         self.w.model = models[-1] if models else None
         return models
 
+    def abort(self):
+        """Drop the round (odx.falkon.BatchFit.abort): what was queued for the groups added so far is joined, nothing is fitted."""
+        self.fit.abort()
+
 
 class FALKONWrapperBase:
     incore = True
