@@ -465,6 +465,18 @@ int odx_nms_batched_f32(const float* boxes_sorted, const int32_t* counts, int Rm
 int odx_nms_batched_first_f32(const float* boxes_sorted, const int32_t* counts, int Rmax, int B, float iou_threshold,
                               int max_keep, unsigned char* keep, void* workspace, int64_t workspace_bytes,
                               odx_stream_t stream);
+/* RPNPostProcessor.forward_for_single_feature_map up to the suppression (rpn/inference.py:76-115) for B images of one size,
+ * one launch: logits (B, A, H, W), deltas (B, 4 A, H, W), anchors (H W A, 4) in grid order (location-major, anchor type minor)
+ * -> the k <= min(8192, A H W) best candidates of every image by objectness in descending order (ties: lower flat index
+ * (h W + w) A + a first): boxes (B, k, 4) decoded (BoxCoder weights 1, +1 widths, dw / dh clamped at delta_clamp) and clipped to
+ * [0, img_w - 1] x [0, img_h - 1], scores (B, k) = sigmoid(logit), index (B, k) flat indices (may be NULL).  */
+int odx_rpn_topk_decode_f32(const float* logits, const float* deltas, const float* anchors, int B, int A, int H, int W, int k,
+                            float img_w, float img_h, float delta_clamp, float* boxes, float* scores, int32_t* index,
+                            odx_stream_t stream);
+/* The first P kept boxes of each of B sorted sets (keep flags from odx_nms_*), in order, as a dense (B, P, 4) block; nkept[b]
+ * = how many (<= P); slots behind them hold the box (0, 0, 15, 15).  counts (DEVICE, may be NULL = Rmax each).  */
+int odx_nms_compact_f32(const float* boxes, const unsigned char* keep, const int32_t* counts, int Rmax, int B, int P, float* out,
+                        int32_t* nkept, odx_stream_t stream);
 
 /* Masker / paste_mask_in_image (mrcnn_modified/modeling/roi_heads/mask_head/inference.py:119-191), all detections
  * of one image at once: masks (R, S, S) f32 probabilities, boxes (R, 4) xyxy f32 -> out (R, im_h, im_w) u8 0/1:

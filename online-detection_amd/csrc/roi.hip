@@ -297,6 +297,171 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const unsigned long long
   }
 }
 
+// ---------------------------------------------------------------- RPN candidates: top-k, decode, clip — one kernel
+// RPNPostProcessor.forward_for_single_feature_map up to the suppression (rpn/inference.py:76-115) for a batch of images of one
+// size: the pre_nms_top_n best anchors of an image by objectness, in descending order (ties: the lower anchor index first),
+// their deltas decoded against the anchors (BoxCoder weights 1, +1 widths, dw / dh clamped) and clipped to the image.
+// One 1024-thread workgroup per image: a radix select over the 56-bit keys (ordered logit bits, inverted anchor index) finds the
+// k-th key in seven 8-bit passes over the image's logits (L2-resident: 28 500 floats at 600 x 800), the k keys at or above it
+// are compacted into LDS and sorted there (bitonic, <= 8192 entries), and each thread then decodes its ranks.  Replaces a
+// sigmoid, a top-k, a gather, an advanced-index gather and ~25 elementwise launches — and the library top-k whose replay from
+// a captured HIP graph faulted.  logits (B, A, H, W), deltas (B, 4 A, H, W), anchors (H W A, 4) in the
+// (location, anchor type) order of grid_anchors; flat candidate index i = (h W + w) A + a.
+constexpr int TOPK_NT = 1024, TOPK_MAX = 8192;
+
+__device__ __forceinline__ unsigned ordered_bits(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);          // ascending as unsigned
+}
+
+__device__ __forceinline__ float from_ordered_bits(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__global__ __launch_bounds__(TOPK_NT) void rpn_topk_decode_kernel(const float* __restrict__ logits, const float* __restrict__ deltas,
+                                                                  const float* __restrict__ anchors, int A, int HW, int k, int kpad,
+                                                                  float xmax, float ymax, float dclamp, float* __restrict__ boxes,
+                                                                  float* __restrict__ scores, int32_t* __restrict__ index) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long buf[];      // kpad entries (<= 64 KiB, asked for at launch)
+  __shared__ unsigned hist[256];
+  __shared__ unsigned long long s_prefix, s_mask;
+  __shared__ unsigned s_need, s_cnt;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int N = A * HW;
+  const float* lg = logits + (int64_t)b * N;
+  auto key_of = [&](int j) -> unsigned long long {           // j walks memory order (a, hw); the candidate index is (hw, a)
+    const int a = j / HW, hw = j - a * HW;
+    const unsigned i = (unsigned)(hw * A + a);
+    return ((unsigned long long)ordered_bits(lg[j]) << 24) | (unsigned long long)(0xffffffu - i);
+  };
+  if (tid == 0) { s_prefix = 0ull; s_mask = 0ull; s_need = (unsigned)k; s_cnt = 0u; }
+  __syncthreads();
+  for (int pass = 6; pass >= 0; --pass) {
+    if (tid < 256) hist[tid] = 0u;
+    __syncthreads();
+    const unsigned long long prefix = s_prefix, mask = s_mask;
+    for (int j = tid; j < N; j += TOPK_NT) {
+      const unsigned long long key = key_of(j);
+      if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> (8 * pass)) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned need = s_need, acc = 0u;
+      int d = 255;
+      for (; d > 0; --d) {
+        if (acc + hist[d] >= need) break;
+        acc += hist[d];
+      }
+      s_need = need - acc;                                     // how many of digit d's keys are still wanted
+      s_prefix = prefix | ((unsigned long long)d << (8 * pass));
+      s_mask = mask | (255ull << (8 * pass));
+    }
+    __syncthreads();
+  }
+  const unsigned long long thresh = s_prefix;                  // the k-th largest key (keys are unique: they carry the index)
+  for (int j = tid; j < kpad; j += TOPK_NT) buf[j] = 0ull;      // pads sort to the end
+  __syncthreads();
+  for (int j = tid; j < N; j += TOPK_NT) {
+    const unsigned long long key = key_of(j);
+    if (key >= thresh) {
+      const unsigned pos = atomicAdd(&s_cnt, 1u);
+      if (pos < (unsigned)kpad) buf[pos] = key;
+    }
+  }
+  __syncthreads();
+  // bitonic sort, descending, kpad = a power of two
+  for (int size = 2; size <= kpad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < (kpad >> 1); t += TOPK_NT) {
+        const int lo = ((t / stride) * stride * 2) + (t % stride), hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long x = buf[lo], y = buf[hi];
+        if ((x < y) == desc) { buf[lo] = y; buf[hi] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int r = tid; r < k; r += TOPK_NT) {                     // (separate multiplies and adds, as the reference's tensor ops round)
+#pragma clang fp contract(off)
+    const unsigned long long key = buf[r];
+    const int i = (int)(0xffffffu - (unsigned)(key & 0xffffffull));
+    const float v = from_ordered_bits((unsigned)(key >> 24));
+    const int a = i % A, hw = i / A;
+    const float* dl = deltas + ((int64_t)b * 4 * A + 4 * a) * HW + hw;
+    const float dx = dl[0], dy = dl[HW];
+    const float dw = fminf(dl[2 * (int64_t)HW], dclamp), dh = fminf(dl[3 * (int64_t)HW], dclamp);
+    const float* an = anchors + (int64_t)i * 4;
+    const float w = an[2] - an[0] + 1.f, h = an[3] - an[1] + 1.f;
+    const float cx = an[0] + 0.5f * w, cy = an[1] + 0.5f * h;
+    const float pcx = dx * w + cx, pcy = dy * h + cy;
+    const float pw = expf(dw) * w, ph = expf(dh) * h;
+    float* o = boxes + ((int64_t)b * k + r) * 4;
+    o[0] = fminf(fmaxf(pcx - 0.5f * pw, 0.f), xmax);
+    o[1] = fminf(fmaxf(pcy - 0.5f * ph, 0.f), ymax);
+    o[2] = fminf(fmaxf(pcx + 0.5f * pw - 1.f, 0.f), xmax);
+    o[3] = fminf(fmaxf(pcy + 0.5f * ph - 1.f, 0.f), ymax);
+    scores[(int64_t)b * k + r] = 1.f / (1.f + expf(-v));
+    if (index != nullptr) index[(int64_t)b * k + r] = i;
+  }
+}
+
+extern "C" int odx_rpn_topk_decode_f32(const float* logits, const float* deltas, const float* anchors, int B, int A, int H, int W, int k,
+                                       float img_w, float img_h, float delta_clamp, float* boxes, float* scores, int32_t* index,
+                                       odx_stream_t stream) {
+  if (B <= 0 || k <= 0) return ODX_OK;
+  ODX_REQUIRE(logits && deltas && anchors && boxes && scores && A > 0 && H > 0 && W > 0, "odx_rpn_topk_decode_f32: bad argument");
+  const int64_t N = (int64_t)A * H * W;
+  ODX_REQUIRE(k <= TOPK_MAX && k <= N && N < (1 << 24), "odx_rpn_topk_decode_f32: k <= min(8192, A H W) and A H W < 2^24 required");
+  int kpad = 2;
+  while (kpad < k) kpad <<= 1;
+  const size_t lds = (size_t)kpad * sizeof(unsigned long long);
+  ODX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rpn_topk_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(TOPK_MAX * sizeof(unsigned long long))));
+  hipLaunchKernelGGL(rpn_topk_decode_kernel, dim3((unsigned)B), dim3(TOPK_NT), lds, as_stream(stream), logits, deltas, anchors, A, H * W, k,
+                     kpad, img_w - 1.f, img_h - 1.f, delta_clamp, boxes, scores, index);
+  ODX_CHECK_LAUNCH("odx_rpn_topk_decode_f32");
+  return ODX_OK;
+}
+
+// The first `P` survivors of each set's suppression, in order, as a dense (B, P, 4) block + their count: one wave per set walks
+// the keep flags 64 at a time (ballot + prefix count); slots past the count get a harmless 16 x 16 box.  With the kernel above
+// and odx_nms_batched_first_f32 the proposal stage of a batch has no data-dependent shape and no library sort left.
+__global__ __launch_bounds__(64) void nms_compact_kernel(const float* __restrict__ boxes, const unsigned char* __restrict__ keep,
+                                                         const int* __restrict__ counts, int Rmax, int P, float* __restrict__ out,
+                                                         int32_t* __restrict__ nkept) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int R = counts != nullptr ? counts[b] : Rmax;
+  const float* bx = boxes + (int64_t)b * Rmax * 4;
+  const unsigned char* kp = keep + (int64_t)b * Rmax;
+  float* o = out + (int64_t)b * P * 4;
+  int n = 0;
+  for (int r0 = 0; r0 < R && n < P; r0 += 64) {
+    const int r = r0 + lane;
+    const bool k1 = r < R && kp[r] != 0;
+    const unsigned long long m = __ballot(k1);
+    const int at = n + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+    if (k1 && at < P) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[(int64_t)at * 4 + q] = bx[(int64_t)r * 4 + q];
+    }
+    n += __builtin_popcountll(m);
+  }
+  n = n < P ? n : P;
+  for (int s = n + lane; s < P; s += 64) {
+    o[(int64_t)s * 4 + 0] = 0.f; o[(int64_t)s * 4 + 1] = 0.f; o[(int64_t)s * 4 + 2] = 15.f; o[(int64_t)s * 4 + 3] = 15.f;
+  }
+  if (lane == 0) nkept[b] = n;
+}
+
+extern "C" int odx_nms_compact_f32(const float* boxes, const unsigned char* keep, const int32_t* counts, int Rmax, int B, int P,
+                                   float* out, int32_t* nkept, odx_stream_t stream) {
+  if (B <= 0 || P <= 0) return ODX_OK;
+  ODX_REQUIRE(boxes && keep && out && nkept && Rmax > 0, "odx_nms_compact_f32: bad argument");
+  hipLaunchKernelGGL(nms_compact_kernel, dim3((unsigned)B), dim3(64), 0, as_stream(stream), boxes, keep, counts, Rmax, P, out, nkept);
+  ODX_CHECK_LAUNCH("odx_nms_compact_f32");
+  return ODX_OK;
+}
+
 // ---------------------------------------------------------------- mask pasting (Masker / paste_mask_in_image)
 // One thread per image pixel and detection: zero-pad the S x S mask by `padding`, grow the box by the same ratio,
 // truncate it to integers, resize the padded mask to the box bilinearly (align_corners = False) and threshold.

@@ -956,10 +956,45 @@ class HipBackend:
         kept = keep.bool().nonzero().reshape(-1)
         return kept if order is None else order[kept]
 
-    def nms_batched(self, boxes_sorted, counts, iou_threshold, max_keep=0):
+    def rpn_topk_decode(self, logits, deltas, anchors, k, img_size, delta_clamp):
+        """The k best RPN candidates of every image of a batch by objectness, sorted, decoded and clipped — one launch
+        (odx_rpn_topk_decode_f32): logits (B, A, H, W), deltas (B, 4 A, H, W), anchors (H W A, 4); img_size = (width, height).
+        Returns boxes (B, k, 4), scores (B, k) = sigmoid(logit), index (B, k) int32 (flat (h W + w) A + a)."""
+        logits = logits.to(device=self.device, dtype=torch.float32).contiguous()
+        deltas = deltas.to(device=self.device, dtype=torch.float32).contiguous()
+        anchors = anchors.to(device=self.device, dtype=torch.float32).contiguous()
+        B, A, H, W = logits.shape
+        if tuple(deltas.shape) != (B, 4 * A, H, W) or tuple(anchors.shape) != (H * W * A, 4):
+            raise ValueError("rpn_topk_decode: deltas %s / anchors %s do not belong to logits %s" % (tuple(deltas.shape), tuple(anchors.shape), tuple(logits.shape)))
+        k = int(k)
+        if not 0 < k <= min(8192, A * H * W):
+            raise ValueError("rpn_topk_decode: k = %d outside 1 .. min(8192, A H W = %d)" % (k, A * H * W))
+        boxes = torch.empty((B, k, 4), dtype=torch.float32, device=self.device)
+        scores = torch.empty((B, k), dtype=torch.float32, device=self.device)
+        index = torch.empty((B, k), dtype=torch.int32, device=self.device)
+        hip.check(self.lib.odx_rpn_topk_decode_f32(_p(logits), _p(deltas), _p(anchors), B, A, H, W, k, float(img_size[0]), float(img_size[1]),
+                                                   float(delta_clamp), _p(boxes), _p(scores), _p(index), self._stream()), "odx_rpn_topk_decode_f32")
+        return boxes, scores, index
+
+    def nms_compact(self, boxes_sorted, keep, P, counts=None):
+        """The first P kept boxes of each set as a dense (B, P, 4) block and their counts (B,) int32 (odx_nms_compact_f32)."""
+        B, Rmax = int(boxes_sorted.shape[0]), int(boxes_sorted.shape[1])
+        boxes_sorted = boxes_sorted.to(device=self.device, dtype=torch.float32).contiguous()
+        keep8 = keep.to(device=self.device).to(torch.uint8).contiguous()
+        out = torch.empty((B, int(P), 4), dtype=torch.float32, device=self.device)
+        n = torch.zeros(B, dtype=torch.int32, device=self.device)
+        if counts is not None:
+            counts = counts.to(device=self.device, dtype=torch.int32).contiguous()
+        if B and P and Rmax:
+            hip.check(self.lib.odx_nms_compact_f32(_p(boxes_sorted), _p(keep8), _p(counts), Rmax, B, int(P), _p(out), _p(n), self._stream()),
+                      "odx_nms_compact_f32")
+        return out, n
+
+    def nms_batched(self, boxes_sorted, counts, iou_threshold, max_keep=0, as_bool=True):
         """Greedy NMS of B independent box sets with one launch pair: boxes_sorted (B, Rmax, 4) f32, set b's counts[b]
-        boxes first in its slot, sorted by descending score; counts (B,) int32 ON THE DEVICE.  Returns keep (B, Rmax) bool.
-        max_keep > 0: at most that many survivors per set, the first ones (the walk of a set stops there)."""
+        boxes first in its slot, sorted by descending score; counts (B,) int32 ON THE DEVICE.  Returns keep (B, Rmax) bool
+        (as_bool=False: the kernel's own uint8 flags).  max_keep > 0: at most that many survivors per set, the first ones (the
+        walk of a set stops there)."""
         B, Rmax = int(boxes_sorted.shape[0]), int(boxes_sorted.shape[1])
         keep = torch.empty((B, Rmax), dtype=torch.uint8, device=self.device)
         if B == 0 or Rmax == 0:
@@ -973,7 +1008,7 @@ class HipBackend:
         else:
             hip.check(self.lib.odx_nms_batched_f32(_p(boxes_sorted), _p(counts), Rmax, B, float(iou_threshold), _p(keep), _p(ws),
                                                    ws.numel(), self._stream()), "odx_nms_batched_f32")
-        return keep.bool()
+        return keep.bool() if as_bool else keep
 
 
 _BACKEND = None

@@ -56,7 +56,10 @@ def grid_anchors(H, W, stride, cells):
     return (shifts.view(-1, 1, 4) + cells.view(1, -1, 4)).reshape(-1, 4)
 
 
-def decode_deltas(deltas, boxes, clamp=math.log(1000.0 / 16)):
+DELTA_CLAMP = math.log(1000.0 / 16)          # BoxCoder's bbox_xform_clip
+
+
+def decode_deltas(deltas, boxes, clamp=DELTA_CLAMP):
     """BoxCoder(weights=(1, 1, 1, 1)).decode with the +1 width convention."""
     w = boxes[:, 2] - boxes[:, 0] + 1
     h = boxes[:, 3] - boxes[:, 1] + 1
@@ -115,9 +118,16 @@ def rpn_proposals_batch(objectness, box_regression, anchors, img_size, pre_nms_t
     synchronisation for the B survivor counts.  Returns [(boxes_b, scores_b)] — per image what rpn_proposals returns."""
     be = _backend.get_backend()
     B, A, H, W = objectness.shape
+    k = min(pre_nms_top_n, A * H * W)
+    if hasattr(be, "rpn_topk_decode") and objectness.is_cuda and k <= 8192:
+        # top-k, sorting, delta gather, decoding and clipping of the whole batch as ONE launch (odx_rpn_topk_decode_f32)
+        boxes, score, _ = be.rpn_topk_decode(objectness, box_regression, anchors, k, img_size, DELTA_CLAMP)
+        counts = torch.full((B,), k, dtype=torch.int32, device=boxes.device)
+        keep = be.nms_batched(boxes, counts, nms_thresh, max_keep=post_nms_top_n)
+        n = keep.sum(dim=1).tolist()                      # the batch's one host synchronisation
+        return list(zip(boxes[keep].split(n), score[keep].split(n)))
     obj = objectness.permute(0, 2, 3, 1).reshape(B, -1).sigmoid()
     reg = box_regression.view(B, A, 4, H, W).permute(0, 3, 4, 1, 2).reshape(B, -1, 4)
-    k = min(pre_nms_top_n, obj.shape[1])
     score, idx = obj.topk(k, dim=1, sorted=True)
     sel = reg.gather(1, idx.unsqueeze(2).expand(B, k, 4)).reshape(B * k, 4)
     boxes = decode_deltas(sel, anchors.to(reg.device)[idx.reshape(-1)])
@@ -600,15 +610,13 @@ class OnlineDetectionModel(nn.Module):
         self.online_mask = None         # odx.heads.OnlineMaskPredictor
         self.mask_dim = mask_dim
         self._trunk_graphs = GraphedCall(self._c4_eager)
-        # The whole group forward from ONE HIP graph (forward_group): OFF unless ODX_GROUP_GRAPH=1.  Forward-only loops replay it
-        # fine (3.0 ms per image at 8 images per group, f32) and so does a 16-channel-wide network inside the harvest loop, but
-        # at 600 x 800 with ground-truth slots the SECOND replay — the first one after other launches have run in between —
-        # ends in a GPU memory fault (tools/group_graph_probe.py localises it: the capture's own replay and that group's harvest
-        # are fine, the next group's replay faults); with graph-owned workspaces, blocking index copies, no second thread and
-        # no library transposed convolution in the graph alike.  Cause not found this round: the harvest loop therefore queues
-        # a group's forward launch by launch (forward_batch) and the code below stays as the opt-in it is.
+        # The whole group forward from ONE HIP graph (forward_group; ODX_GROUP_GRAPH=0 turns it off).  Its first form kept the
+        # proposal stage as tensor operations (top-k, gather, advanced indexing) and ended in a GPU memory fault at the graph's
+        # second or third replay whenever other work had run in between — tools/group_graph_bisect.py captures growing prefixes of
+        # the forward and localised it to exactly that stage (trunk and RPN head replay fine); with the stage as three kernels of
+        # this library (odx_rpn_topk_decode_f32, odx_nms_batched_first_f32, odx_nms_compact_f32) every prefix replays.
         self._group_graphs = GraphedCall(self._group_static, max_graphs=4)
-        if os.environ.get("ODX_GROUP_GRAPH", "0") != "1":
+        if os.environ.get("ODX_GROUP_GRAPH", "1") == "0":
             self._group_graphs.enabled = False
         self.register_load_state_dict_post_hook(OnlineDetectionModel._drop_graphs)
 
@@ -697,9 +705,8 @@ class OnlineDetectionModel(nn.Module):
     def _group_static(self, images, gt_slots, anchors):
         """The forward of B images of one size with NOTHING data-dependent in its shapes, so that it can be replayed from ONE HIP
         graph (forward_group): every image has `gpad` ground-truth slots (gt_slots (B, gpad, 4); unused ones hold a dummy box)
-        followed by post_nms_top_n proposal slots — the first survivors of the suppression in score order, found with a top-k over
-        the keep flags' positions instead of a masked select; when fewer survive, the tail slots hold suppressed candidates and
-        the count n[b] says where they start.  Returns (slots (B, gpad + P, 4), n (B,), features (B (gpad + P), D), RPN activation
+        followed by post_nms_top_n proposal slots — the first survivors of the suppression in score order, compacted by a kernel
+        instead of a masked select; when fewer survive, the tail slots hold a dummy box and the count n[b] says where they start.  Returns (slots (B, gpad + P, 4), n (B,), features (B (gpad + P), D), RPN activation
         (B, C, h, w), mask activation of the ground-truth slots (B gpad, mask_dim, r, r))."""
         be = _backend.get_backend()
         B, gpad = gt_slots.shape[0], gt_slots.shape[1]
@@ -711,27 +718,21 @@ class OnlineDetectionModel(nn.Module):
         _, A, H, W = logits.shape            # (anchors: an argument — made from host constants, a copy a capture does not allow)
         if anchors.shape[0] != H * W * A:
             raise ValueError("forward_group: %d anchors for a %d x %d map of %d types" % (anchors.shape[0], H, W, A))
-        obj = logits.permute(0, 2, 3, 1).reshape(B, -1).sigmoid()
-        reg = deltas.view(B, A, 4, H, W).permute(0, 3, 4, 1, 2).reshape(B, -1, 4)
-        k = min(self.pre_nms_top_n, obj.shape[1])
-        score, idx = obj.topk(k, dim=1, sorted=True)
-        cand = decode_deltas(reg.gather(1, idx.unsqueeze(2).expand(B, k, 4)).reshape(B * k, 4), anchors[idx.reshape(-1)])
-        cand[:, 0].clamp_(0, img_size[0] - 1)
-        cand[:, 2].clamp_(0, img_size[0] - 1)
-        cand[:, 1].clamp_(0, img_size[1] - 1)
-        cand[:, 3].clamp_(0, img_size[1] - 1)
-        cand = cand.view(B, k, 4)
-        keep = be.nms_batched(cand, torch.full((B,), k, dtype=torch.int32, device=cand.device), self.rpn_nms, max_keep=self.post_nms_top_n)
+        # the proposal stage with no library sort / top-k in it (their replay from a captured graph faulted: tools/
+        # group_graph_bisect.py) and no data-dependent shape: the k best candidates sorted, decoded and clipped by one launch,
+        # the suppression of all images by one launch pair, the first P survivors compacted into their slots by one more
+        k = min(self.pre_nms_top_n, H * W * A)
+        cand, _, _ = be.rpn_topk_decode(logits, deltas, anchors, k, img_size, DELTA_CLAMP)
+        keep = be.nms_batched(cand, torch.full((B,), k, dtype=torch.int32, device=cand.device), self.rpn_nms, max_keep=self.post_nms_top_n,
+                              as_bool=False)
         P = min(self.post_nms_top_n, k)
-        pos = torch.arange(k, device=cand.device).unsqueeze(0)
-        order = torch.where(keep, pos, pos + k).topk(P, dim=1, largest=False, sorted=True)[1]       # survivors first, in score order
-        props = cand.gather(1, order.unsqueeze(2).expand(B, P, 4))
+        props, nkept = be.nms_compact(cand, keep, P)
         slots = torch.cat((gt_slots, props), dim=1)
         bidx = torch.arange(B, device=cand.device).repeat_interleave(gpad + P)
         maps = self.roi_head_maps(c4, slots.reshape(-1, 4), batch_idx=bidx)
         feats = maps.mean(dim=(2, 3))
         act = self.mask_activation(maps.view(B, gpad + P, *maps.shape[1:])[:, :gpad].reshape(B * gpad, *maps.shape[1:])) if gpad else None
-        return slots, keep.sum(dim=1), feats, t, act
+        return slots, nkept, feats, t, act
 
     @torch.no_grad()
     def forward_group(self, images, gt_boxes_list, capture=True):
@@ -1143,6 +1144,9 @@ class OnlineFeatureExtractor:
             main = torch.cuda.current_stream()
             fwd = torch.cuda.Stream()
             fwd.wait_stream(main)
+            # (the harvest's own kernels — hundreds of tiny launches with a host read every few of them — on a high-priority stream
+            # of their own: measured, no gain: 5.4 against 5.2 ms per image)
+            harv = main
 
             def begin(group):
                 with torch.cuda.stream(fwd):
@@ -1162,12 +1166,13 @@ class OnlineFeatureExtractor:
                 items, ev = finish(state)                               # waits for group gi (its survivor counts)
                 if gi + 1 < len(groups):
                     state = begin(groups[gi + 1])                       # group gi + 1 runs on the GPU ...
-                main.wait_event(ev)
-                for item in items:                                      # ... while group gi is harvested here
-                    for v in item.values():
-                        if torch.is_tensor(v) and v.is_cuda:
-                            v.record_stream(main)
-                    harvest_one(item)
+                harv.wait_event(ev)
+                with torch.cuda.stream(harv):
+                    for item in items:                                  # ... while group gi is harvested here
+                        for v in item.values():
+                            if torch.is_tensor(v) and v.is_cuda:
+                                v.record_stream(harv)
+                        harvest_one(item)
             fwd.synchronize()
         elif dev.type == "cuda" and self.pipeline and len(samples) > 1:
             import queue

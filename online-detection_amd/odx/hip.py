@@ -122,6 +122,8 @@ SIGNATURES = {
     "odx_nms_first_f32": (_i32, [_vp, _i32, _f32, _i32, _vp, _vp, _i64, _vp]),
     "odx_nms_batched_workspace_bytes": (_i64, [_i32, _i32]),
     "odx_nms_batched_f32": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp, _vp, _i64, _vp]),
+    "odx_rpn_topk_decode_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "odx_nms_compact_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "odx_nms_batched_first_f32": (_i32, [_vp, _vp, _i32, _i32, _f32, _i32, _vp, _vp, _i64, _vp]),
     "odx_paste_masks_u8": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
     "odx_bias_act_nchw_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp]),

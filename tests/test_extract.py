@@ -586,7 +586,6 @@ def test_group_forward_from_one_graph_equals_the_eager_batched_forward():
     model.rpn_logits.weight.data.normal_(0, 0.3)
     model.rpn_deltas.weight.data.normal_(0, 0.05)
     model = model.cuda()
-    model._group_graphs.enabled = True            # (opt-in: ODX_GROUP_GRAPH=1 — see OnlineDetectionModel.__init__ for why it is off by default)
     g = torch.Generator().manual_seed(1)
     images = torch.randn(4, 3, 192, 256, generator=g).cuda()
 
@@ -624,6 +623,44 @@ def test_group_forward_from_one_graph_equals_the_eager_batched_forward():
         check(a)
         assert len(model._group_graphs.graphs) == 2
         assert all(r["boxes"].shape[0] <= 25 + 3 for r in model.forward_group(images, a))
+
+
+@pytest.mark.gpu
+def test_group_graph_at_full_size_with_other_work_between_replays():
+    """The graphed group forward at the reference's size — the full-width R-50-C4 network, four 600 x 800 images, 6000
+    candidates, 300 proposals, ground-truth slots — replayed four times with harvest-like work (large allocations, index
+    operations, a host read) between the replays: every replay equals the launch-by-launch forward_batch of the same images.
+    This is the configuration whose first form — the proposal stage as tensor operations: a library top-k, gather, advanced
+    indexing — faulted at the second or third replay (tools/group_graph_bisect.py); the stage is three kernels of this library now."""
+    from odx.extract import forward_batch
+    odx.set_backend(None)
+    torch.manual_seed(5)
+    model = OnlineDetectionModel(seed=6).eval()
+    model.rpn_logits.weight.data.normal_(0, 0.3)          # well separated objectness (see test_forward_gpu_equals_plain_torch_cpu)
+    model.rpn_deltas.weight.data.normal_(0, 0.05)
+    model = model.cuda()
+    g = torch.Generator().manual_seed(2)
+    images = torch.randn(4, 3, 600, 800, generator=g).cuda()
+    gts = []
+    for c in (2, 1, 3, 1):
+        xy = torch.rand(c, 2, generator=g) * torch.tensor([500.0, 300.0])
+        gts.append(torch.cat((xy, xy + 60 + torch.rand(c, 2, generator=g) * 200), dim=1).cuda())
+    with torch.no_grad():
+        for _ in range(2):                                   # (the library settles on its convolution algorithms)
+            per, c4s, maps, offs, t = forward_batch(model, images, gts, want_rpn_activation=True)
+        model.forward_group(images, gts)
+        for rep in range(4):
+            x = torch.randn((40000, 2048), device="cuda")
+            y = x.index_select(0, torch.randint(0, 40000, (50000,), device="cuda"))
+            assert int((y[:, 0] > 0).nonzero().numel()) > 0
+            del x, y
+            res = model.forward_group(images, gts)
+            assert len(model._group_graphs.graphs) == 1
+            for b in range(4):
+                assert res[b]["boxes"].shape == per[b][0].shape == (len(gts[b]) + 300, 4)
+                assert float((res[b]["boxes"] - per[b][0]).abs().max()) < 1e-3, (rep, b)
+                assert float((res[b]["feats"] - per[b][1]).norm() / per[b][1].norm()) < 1e-4, (rep, b)
+                assert float((res[b]["t"] - t[b]).abs().max()) <= 1e-4 * float(t[b].abs().max())
 
 
 def _plain_roi_align(feat, boxes, scale, P):

@@ -110,3 +110,56 @@ def test_trunk_epilogue_equals_the_three_torch_ops_bit_for_bit(be, N, C, H, W, w
     got = be.bias_act_(y.clone(), bias, res, relu=relu)
     assert torch.equal(torch.nan_to_num(got, nan=123.0), torch.nan_to_num(ref, nan=123.0))
     assert bool(torch.isnan(got.view(-1)[0])) == bool(torch.isnan(ref.view(-1)[0]))
+
+
+@pytest.mark.parametrize("B,A,H,W,k", [(3, 15, 20, 26, 700), (1, 15, 38, 50, 6000), (2, 3, 5, 7, 105), (4, 15, 12, 16, 1), (2, 15, 24, 32, 8192)])
+def test_rpn_topk_decode_equals_the_tensor_op_sequence(be, B, A, H, W, k):
+    """odx_rpn_topk_decode_f32 — objectness top-k, sorting, delta gather, decoding, clipping in one launch — against the
+    sequence of tensor operations it replaces (extract.rpn_proposals: permute, top-k, gather, decode_deltas, clamp): the same
+    candidates in the same order (ties — duplicated logits are planted — by the lower flat index, what a stable sort gives),
+    boxes to 1e-4 px, scores = sigmoid(logit)."""
+    from odx.extract import DELTA_CLAMP, decode_deltas, grid_anchors, cell_anchors
+    g = torch.Generator().manual_seed(B * 1000 + k)
+    logits = torch.randn((B, A, H, W), generator=g) * 3
+    lv = logits.view(-1)
+    dup = lv[3::7].clone()
+    lv[0:7 * len(dup):7] = dup                                                          # ties
+    logits.view(-1)[5] = 0.0
+    logits.view(-1)[6] = -0.0
+    deltas = torch.randn((B, 4 * A, H, W), generator=g) * 0.3
+    deltas[:, 2::4] *= 10                                                              # some dw past the clamp
+    cells = cell_anchors(16)[:A] if A <= 15 else None
+    anchors = grid_anchors(H, W, 16, cells)
+    img = (W * 16.0, H * 16.0)
+    boxes, scores, index = be.rpn_topk_decode(logits.cuda(), deltas.cuda(), anchors.cuda(), k, img, DELTA_CLAMP)
+    obj = logits.permute(0, 2, 3, 1).reshape(B, -1)
+    reg = deltas.view(B, A, 4, H, W).permute(0, 3, 4, 1, 2).reshape(B, -1, 4)
+    for b in range(B):
+        order = torch.from_numpy(np.argsort(-obj[b].numpy().astype(np.float64), kind="stable"))[:k]
+        assert torch.equal(index[b].cpu().long(), order), b
+        want = decode_deltas(reg[b][order], anchors[order])
+        want[:, 0::2] = want[:, 0::2].clamp(0, img[0] - 1)
+        want[:, 1::2] = want[:, 1::2].clamp(0, img[1] - 1)
+        assert float((boxes[b].cpu() - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()) / 1e3)
+        assert float((scores[b].cpu() - obj[b][order].sigmoid()).abs().max()) < 1e-6
+        assert bool((scores[b][:-1] >= scores[b][1:]).all())
+
+
+@pytest.mark.parametrize("B,R,P", [(3, 500, 40), (1, 6000, 300), (4, 64, 64), (2, 130, 1000)])
+def test_nms_compact_packs_the_first_survivors(be, B, R, P):
+    g = torch.Generator().manual_seed(R + P)
+    boxes = torch.rand((B, R, 4), generator=g).cuda() * 100
+    keep = (torch.rand((B, R), generator=g) < 0.3).cuda()
+    keep[0] = False if B > 1 else keep[0]
+    counts = torch.tensor([R - 7 * b for b in range(B)], dtype=torch.int32).cuda()
+    out, n = be.nms_compact(boxes, keep, P, counts=counts)
+    assert tuple(out.shape) == (B, P, 4) and n.dtype == torch.int32
+    for b in range(B):
+        kb = keep[b].clone()
+        kb[int(counts[b]):] = False
+        want = boxes[b][kb][:P]
+        assert int(n[b]) == len(want)
+        assert torch.equal(out[b, :len(want)], want)
+        assert bool((out[b, len(want):] == torch.tensor([0.0, 0.0, 15.0, 15.0], device="cuda")).all())
+    out2, n2 = be.nms_compact(boxes, keep.to(torch.uint8), P)                       # no counts: every set holds R boxes
+    assert [int(v) for v in n2] == [min(P, int(keep[b].sum())) for b in range(B)]

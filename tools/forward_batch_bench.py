@@ -79,8 +79,6 @@ def main():
                         ev[k].elapsed_time(ev[k + 1]) / 5 / B for k in range(3))
             print(line, flush=True)
             if B > 1:
-                model._group_graphs.enabled = True          # (opt-in path: forward-only replays are fine, see extract.py)
-
                 def run_g():
                     for i in range(0, args.images, B):
                         model.forward_group(imgs[i:i + B], [None] * B)
