@@ -231,9 +231,17 @@ class DetectorHarvester:
                     rows_c = [i for i, l in enumerate(gt_labels_list) if l == c]
                     self._pos[c - 1].append(x[rows_c].view(-1, self.D), seg_lens=[1] * len(rows_c))
             sel = (overlap[:, cls].t() > self.reg_min_overlap) & (assoc[None, :] == torch.arange(G, device=x.device)[:, None])
-            pairs = sel.nonzero()
-            seg = torch.bincount(pairs[:, 0], minlength=G).tolist()
-            j_idx, r_idx = pairs[:, 0], pairs[:, 1]
+            # ONE host read per image for this harvester: the rows per ground-truth box (here) and the negatives' candidate counts
+            # of the classes present (_sample_all) come over together; the pairs themselves are listed on the device by a stable
+            # sort of the flags (box-major, row-minor: the order nonzero() gives, without its synchronisation)
+            classes_neg = list(range(self.num_classes)) if self.shuffle_negatives else list(self.still_to_complete)
+            present = [i for i in classes_neg if i + 1 in gt_labels_list]
+            cmask = (overlap[:, present] < self.neg_iou_thresh) if present else None                     # (R, len(present))
+            both = torch.cat((sel.sum(1), cmask.sum(0))) if present else sel.sum(1)
+            both = both.tolist()
+            seg, ccounts = both[:G], both[G:]
+            flat = torch.argsort((~sel).reshape(-1).to(torch.int8), stable=True)[:sum(seg)]
+            j_idx, r_idx = flat // R, flat % R
             ex, tgt = prop_d[r_idx], prop_d[j_idx]                          # tgt: the prepended ground-truth rows
             sw, sh = ex[:, 2] - ex[:, 0] + 1, ex[:, 3] - ex[:, 1] + 1
             sx, sy = ex[:, 0] + 0.5 * sw, ex[:, 1] + 0.5 * sh
@@ -243,11 +251,13 @@ class DetectorHarvester:
             self._Y.append(target, seg_lens=seg)
             self._C.append((cls[j_idx] + 1).to(torch.float32).view(-1, 1), seg_lens=seg)
             self._X.append(x[r_idx].view(-1, self.D), seg_lens=seg)
+        else:
+            present, cmask, ccounts = [], None, []
         if not self.shuffle_negatives:
-            self._fill_batches(x, overlap, gt_labels_list)
+            self._fill_batches(x, overlap, gt_labels_list, (present, cmask, ccounts))
         else:
             classes = list(range(self.num_classes))
-            feats_all, lens = self._sample_all(x, overlap, classes, gt_labels_list)
+            feats_all, lens = self._sample_all(x, overlap, classes, gt_labels_list, (present, cmask, ccounts))
             at = 0
             for i, n_i in zip(classes, lens):
                 last = self._neg[i][-1]
@@ -256,45 +266,48 @@ class DetectorHarvester:
                 if last.n >= self.batch_size:
                     self._neg[i].append(_Growing(self.D, self.device, cap=self.batch_size))
 
-    def _sample_all(self, x, overlap, classes, gt_labels_list):
+    def _sample_all(self, x, overlap, classes, gt_labels_list, known=None):
         """The negatives of one image for every class of `classes`, in that order, with one gather
         (box_head_getProposals.py:213-222 per class): returns the sampled rows of
         all classes back to back and the number of rows of each.  The draws come from the global RNG class by class as
         in the reference (one randint per class: over all R rows for a class that is not in the image, over its
         candidates — rows overlapping its boxes by less than NEG_IOU_THRESH — for a class that is, none when it has no
-        candidate); only the classes present in the image need anything read back from the device (their counts)."""
+        candidate).  known = (present classes, their candidate flags (R, n), their counts) when add_image has already brought
+        the counts to the host with its own read; the candidates of a class are listed by a stable sort of its flags (ascending
+        row index: what nonzero() gives, without a synchronisation per class), and every draw goes to the device in ONE copy."""
         k = self.negatives_to_pick
         present = [i for i in classes if i + 1 in gt_labels_list]
-        cand, counts = {}, {}
-        if present:
-            masks = overlap[:, present] < self.neg_iou_thresh                               # (R, len(present))
-            for i, c in zip(present, masks.sum(0).tolist()):
-                counts[i] = c
-            for j, i in enumerate(present):
-                cand[i] = torch.nonzero(masks[:, j]).reshape(-1)
-        host_picks, plan, lens = [], [], []
+        if known is not None and known[0] == present:
+            masks, clist = known[1], known[2]
+        else:
+            masks = overlap[:, present] < self.neg_iou_thresh if present else None               # (R, len(present))
+            clist = masks.sum(0).tolist() if present else []
+        counts = dict(zip(present, (int(c) for c in clist)))
+        col = {i: j for j, i in enumerate(present)}
+        cand_order = torch.argsort((~masks).to(torch.int8), dim=0, stable=True) if present else None    # column j: class present[j]'s candidates first
+        draws, plan, lens = [], [], []
         for i in classes:
             if i in counts:
                 if counts[i] > 0:
-                    plan.append(("dev", i, torch.randint(counts[i], (k,))))
+                    plan.append(("dev", i, len(draws)))
+                    draws.append(torch.randint(counts[i], (k,)))
                     lens.append(k)
                 else:
                     lens.append(0)
             else:
-                p = torch.randint(x.size(0), (k,))
-                plan.append(("host", len(host_picks), None))
-                host_picks.append(p)
+                plan.append(("host", i, len(draws)))
+                draws.append(torch.randint(x.size(0), (k,)))
                 lens.append(k)
         if not plan:
             return torch.empty((0, self.D), dtype=x.dtype, device=x.device), lens
-        hp = torch.stack(host_picks).to(x.device) if host_picks else None                  # one copy for all absent classes
-        parts = [hp[j] if kind == "host" else cand[j][p.to(x.device)] for kind, j, p in plan]
+        up = torch.stack(draws).to(x.device)                                                   # one copy for all classes' draws
+        parts = [up[d] if kind == "host" else cand_order[:, col[i]][up[d]] for kind, i, d in plan]
         return x[torch.cat(parts)].view(-1, self.D), lens
 
-    def _fill_batches(self, x, overlap, gt_labels_list):
+    def _fill_batches(self, x, overlap, gt_labels_list, known=None):
         done = []
         classes = list(self.still_to_complete)
-        feats_all, lens = self._sample_all(x, overlap, classes, gt_labels_list)
+        feats_all, lens = self._sample_all(x, overlap, classes, gt_labels_list, known)
         at = 0
         per_batch = math.ceil(self.negatives_to_pick / self.iterations)
         for i, n_i in zip(classes, lens):
@@ -411,27 +424,57 @@ class RPNHarvester:
 
     def add_image(self, t, anchors_all, img_size, gt_bbox):
         """t (D, H, W) RPN activation of the image; anchors_all (H*W*A, 4) from grid_anchors;
-        img_size (width, height); gt_bbox (G >= 1, 4) in the same pixel frame."""
+        img_size (width, height); gt_bbox (G >= 1, 4) in the same pixel frame.
+
+        ONE host read per image: everything the host decides — how many candidates each anchor type has, which ground-truth
+        boxes get their best anchor added as a positive (the reference's `elem in tensor` walk, rpn_getProposals.py:383-400),
+        how many positives each type ends up with — is decided from one small block of counts brought over together; the
+        reference (and this class until round 4) read them piece by piece, a synchronisation for the candidates, one for the
+        positives and two per ground-truth box, each of which waits for the harvest's kernels to get their turn beside the
+        next images' forward."""
         if self.negatives_to_pick is None:
             self.negatives_to_pick = math.ceil((self.batch_size * self.iterations) / self.num_images)
         if self.anchors is None:
             self._setup(anchors_all.to(t.device), img_size, t.shape[2])
-        gt = gt_bbox.to(t.device).float()
-        ious = torch.squeeze(box_iou_plus1(gt, self.anchors))
-        if gt.shape[0] > 1:
-            ious, idx = torch.max(ious, dim=0)
+        dev = t.device
+        A = self.A
+        gt = gt_bbox.to(dev).float()
+        G = gt.shape[0]
+        iou_all = box_iou_plus1(gt, self.anchors)                                   # (G, n_vis)
+        if G > 1:
+            ious, idx = torch.max(iou_all, dim=0)
             assoc = gt[idx]
         else:
-            ious = ious.reshape(-1)
+            ious = iou_all.reshape(-1)
             assoc = gt[0].expand(self.anchors.shape[0], 4)
         neg_mask = ious < self.neg_iou_thresh
-        types = list(self.still_to_complete if not self.shuffle_negatives else range(self.A))
-        # All anchor types at once on the device: candidates per type counted in one reduction (one host read), the
-        # candidates ordered by type with a stable sort (ascending anchor index inside a type, as torch.nonzero gives
-        # them), one gather of the sampled anchors' features.  What stays on the host is what the reference fixes there:
-        # the with-replacement draws, type by type from the global RNG, and the bookkeeping of the open batches.
-        counts = (neg_mask[:, None] & (self.cls[:, None] == torch.arange(self.A, device=t.device)[None, :])).sum(0).tolist()
-        order = torch.argsort(torch.where(neg_mask, self.cls, torch.full_like(self.cls, self.A)), stable=True)
+        over = ious > self.pos_iou_thresh
+        types = list(self.still_to_complete if not self.shuffle_negatives else range(A))
+        onehot = self.cls[:, None] == torch.arange(A, device=dev)[None, :]           # (n_vis, A)
+        # per ground-truth box j (the reference walks them in order):
+        #   mine_j   anchors associated with a box equal to box j in all four coordinates
+        #   extra_j  those of them at their best IoU — what is appended when box j has no positive yet
+        #   hit_j    how many anchors over the threshold are associated with a box sharing ANY coordinate with box j, position by
+        #            position (the reference's `g in positive_gts` on tensors: any equal element)
+        mine = (assoc[None, :, :] == gt[:, None, :]).all(dim=2)                       # (G, n_vis)
+        best = torch.where(mine, ious[None, :], torch.full_like(ious, -1.0)[None, :]).max(dim=1)[0]
+        extra = mine & (ious[None, :] == best[:, None])
+        share = (assoc[None, :, :] == gt[:, None, :]).any(dim=2)                      # (G, n_vis)
+        f64 = torch.float64
+        block = torch.cat(((neg_mask[:, None] & onehot).sum(0).to(f64),                # A      candidates per type
+                           (share & over[None, :]).sum(1).to(f64),                    # G      hit_j
+                           mine.any(dim=1).to(f64),                                   # G      box j has anchors at all
+                           (over[:, None] & onehot).sum(0).to(f64),                   # A      positives over the threshold per type
+                           (extra[:, :, None] & onehot[None, :, :]).sum(1).reshape(-1).to(f64),     # G A    extras of box j per type
+                           gt.reshape(-1).to(f64))).tolist()                          # 4 G    the boxes (for the coordinate test)
+        counts = [int(v) for v in block[:A]]
+        hit = block[A:A + G]
+        has_mine = block[A + G:A + 2 * G]
+        over_type = [int(v) for v in block[A + 2 * G:2 * A + 2 * G]]
+        extra_type = [[int(v) for v in block[2 * A + 2 * G + j * A:2 * A + 2 * G + (j + 1) * A]] for j in range(G)]
+        gth = [block[2 * A + 2 * G + G * A + 4 * j:2 * A + 2 * G + G * A + 4 * j + 4] for j in range(G)]
+        # ---- negatives: the with-replacement draws type by type from the global RNG, the bookkeeping of the open batches
+        order = torch.argsort(torch.where(neg_mask, self.cls, torch.full_like(self.cls, A)), stable=True)
         starts, acc = [], 0
         for c in counts:
             starts.append(acc)
@@ -442,10 +485,22 @@ class RPNHarvester:
             p = torch.randint(c, (self.negatives_to_pick,)) if c > self.negatives_to_pick else torch.arange(c)
             picks.append(p + starts[i])
             lens.append(p.numel())
-        if picks and sum(lens):
-            feats_all = self._gather(t, order[torch.cat(picks).to(t.device)])
-        else:
-            feats_all = torch.empty((0, self.D), dtype=t.dtype, device=t.device)
+        # ---- positives: which boxes get their best anchors added (on the host, from the counts), in the reference's order
+        rank_of = [0] * G                      # 0: not selected; k >= 1: its extras come k-th behind the over-threshold anchors
+        chosen = []
+        for j in range(G):
+            if hit[j] > 0 or any(any(a == b for a, b in zip(gth[j], gth[j2])) for j2 in chosen):
+                continue
+            if has_mine[j] > 0:
+                chosen.append(j)
+                rank_of[j] = len(chosen)
+        per_type = [over_type[a] + sum(extra_type[j][a] for j in chosen) for a in range(A)]
+        n_pos = sum(per_type)
+        n_neg = sum(lens)
+        # one host -> device copy for everything the device needs back: the sampled candidates' positions, the boxes' ranks
+        up = torch.cat(picks + [torch.tensor(rank_of, dtype=torch.int64)]).to(dev) if (picks or G) else None
+        pick_idx, rank_dev = up[:n_neg], up[n_neg:]
+        feats_all = self._gather(t, order[pick_idx]) if n_neg else torch.empty((0, self.D), dtype=t.dtype, device=dev)
         done = []
         at = 0
         for i, n_i in zip(types, lens):
@@ -475,25 +530,20 @@ class RPNHarvester:
             self._grid.commit(feats_all)
         for i in done:
             self.still_to_complete.remove(i)
-        # positives
-        pos = torch.nonzero(ious > self.pos_iou_thresh).reshape(-1)
-        pos_gt = assoc[pos]
-        for g in gt:
-            if bool((g[None, :] == pos_gt).any()):       # the reference's `elem in tensor`: ANY coordinate match
-                continue
-            mine = (assoc == g[None, :]).all(dim=1)
-            if bool(mine.any()):
-                best = ious[mine].max()
-                extra = torch.nonzero(mine & (ious == best)).reshape(-1)
-                pos = torch.cat((pos, extra))
-                pos_gt = assoc[pos]
         # The reference walks the anchor types that have positives in ascending order and, per type, appends its rows
-        # (rpn_getProposals.py:383-449).  Here: a stable sort by type gives that order for all types at once, one gather
-        # fetches every positive's features, and each buffer receives one copy; one host read (the per-type counts).
-        pcls = self.cls[pos]
-        order_p = torch.argsort(pcls, stable=True)
-        sel = pos[order_p]
-        per_type = torch.bincount(pcls, minlength=self.A).tolist()
+        # (rpn_getProposals.py:383-449): over-threshold anchors first (ascending anchor index), then the added best anchors box
+        # by box.  Here: ONE stable sort by (type, group) gives that order for all types at once, one gather fetches every
+        # positive's features, and each buffer receives one copy.
+        if G > 1:
+            sel_extra = extra & (rank_dev > 0)[:, None]
+            grp = (sel_extra.to(torch.int64) * rank_dev[:, None]).max(dim=0)[0]       # the rank of the box whose extra this anchor is
+        else:
+            grp = extra[0].to(torch.int64) * rank_dev[0]
+        is_pos = over | (grp > 0)
+        grp = torch.where(over, torch.zeros_like(grp), grp)
+        key = torch.where(is_pos, self.cls * (G + 1) + grp, torch.full_like(self.cls, A * (G + 1)))
+        sel = torch.argsort(key, stable=True)[:n_pos]
+        pcls_sorted = self.cls[sel]
         feat = self._gather(t, sel)
         ex, tg = self.anchors[sel], assoc[sel]
         sw, sh = ex[:, 2] - ex[:, 0] + 1, ex[:, 3] - ex[:, 1] + 1
@@ -507,7 +557,7 @@ class RPNHarvester:
                 self._pos[i].append(feat[at:at + k])
                 at += k
         self._Y.append(torch.stack(((gx - sx) / sw, (gy - sy) / sh, torch.log(gw / sw), torch.log(gh / sh)), dim=1), seg_lens=seg)
-        self._C.append(pcls[order_p].to(torch.float32).view(-1, 1), seg_lens=seg)
+        self._C.append(pcls_sorted.to(torch.float32).view(-1, 1), seg_lens=seg)
         self._X.append(feat, seg_lens=seg)
 
     def finalize(self):

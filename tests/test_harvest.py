@@ -202,3 +202,69 @@ def test_batched_mask_projection_equals_the_per_object_resize(device):
         got = project_masks_on_boxes(masks.to(device), boxes.to(device), M).cpu()
         ref = _project_one_by_one(masks, boxes, M)
         assert got.shape == ref.shape and torch.equal(got, ref), (M, int((got != ref).sum()))
+
+
+@pytest.mark.parametrize("device", DEVICES)
+def test_rpn_positives_with_one_host_read_equal_the_box_by_box_walk(device):
+    """RPNHarvester.add_image decides the positives from ONE block of counts read from the device (round 5); the reference
+    walks the ground-truth boxes one by one with `g in positive_gts` tests on tensors (rpn_getProposals.py:383-400), which is
+    what this class did until round 4.  Random scenes — several boxes, boxes sharing a coordinate with another box (the
+    reference's any-element-equal test then skips them), duplicated boxes, boxes without any anchor over the threshold —
+    through both: the same positives in the same order (regressor rows X / Y / C and the per-type positives)."""
+    from odx.extract import cell_anchors, grid_anchors
+    from odx.harvest import RPNHarvester, box_iou_plus1
+    D, A, H, W = 6, 15, 12, 16
+    anchors = grid_anchors(H, W, 16, cell_anchors(16)).to(device)
+    g = torch.Generator().manual_seed(5)
+    scenes = []
+    for s in range(12):
+        G = 1 + s % 4
+        xy = torch.rand(G, 2, generator=g) * torch.tensor([W * 16 * 0.6, H * 16 * 0.6])
+        wh = 12 + torch.rand(G, 2, generator=g) * torch.tensor([W * 16 * 0.5, H * 16 * 0.5])
+        gt = torch.cat((xy, xy + wh), dim=1)
+        if s % 3 == 1 and G > 1:
+            gt[1, 0] = gt[0, 0]                       # shares x1 with box 0
+        if s % 5 == 2 and G > 2:
+            gt[2] = gt[0]                             # a duplicate
+        if s % 4 == 3:
+            gt[0] = torch.tensor([3.0, 3.0, 9.0, 8.0])    # too small for any anchor to pass 0.7
+        scenes.append((torch.randn(D, H, W, generator=g), gt))
+
+    def walk(h, t, gt):
+        """The box-by-box form (round 4's code): returns the positives' anchor indices in append order, type-sorted."""
+        ious = torch.squeeze(box_iou_plus1(gt, h.anchors))
+        if gt.shape[0] > 1:
+            ious, idx = torch.max(ious, dim=0)
+            assoc = gt[idx]
+        else:
+            ious = ious.reshape(-1)
+            assoc = gt[0].expand(h.anchors.shape[0], 4)
+        pos = torch.nonzero(ious > h.pos_iou_thresh).reshape(-1)
+        pos_gt = assoc[pos]
+        for gb in gt:
+            if bool((gb[None, :] == pos_gt).any()):
+                continue
+            mine = (assoc == gb[None, :]).all(dim=1)
+            if bool(mine.any()):
+                best = ious[mine].max()
+                pos = torch.cat((pos, torch.nonzero(mine & (ious == best)).reshape(-1)))
+                pos_gt = assoc[pos]
+        pcls = h.cls[pos]
+        return pos[torch.argsort(pcls, stable=True)]
+
+    h = RPNHarvester(D, A, 2, 40, len(scenes), device=device)
+    torch.manual_seed(1)
+    want_rows, n_extra = [], 0
+    for t, gt in scenes:
+        t, gt = t.to(device), gt.to(device)
+        before = h._X.n
+        h.add_image(t, anchors, (W * 16, H * 16), gt)
+        sel = walk(h, t, gt)
+        n_extra += int((box_iou_plus1(gt, h.anchors).max(dim=0)[0][sel] <= h.pos_iou_thresh).sum())
+        want = t[:, h.rows[sel], h.cols[sel]].t().reshape(-1, D)
+        got = h._X.view()[before:]
+        assert got.shape == want.shape and torch.equal(got, want)
+        want_rows.append(h.cls[sel])
+    assert n_extra > 0                                  # the scenes do exercise the added best anchors
+    assert torch.equal(h._C.view().reshape(-1), torch.cat(want_rows).to(torch.float32))
+    assert sum(p.n for p in h._pos) == h._X.n
