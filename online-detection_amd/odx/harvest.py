@@ -29,6 +29,14 @@ import numpy as np
 import torch
 
 
+def to_device(host, device):
+    """A small host tensor (index lists, draws) on `device`: a plain blocking copy.  (Tried in round 5 and dropped: the same
+    through page-locked memory as an asynchronous copy, so that the host does not wait for the stream at every index list —
+    a freshly pinned block per list cost 12 ms per image, a ring of pinned buffers allocated once 24 ms against 1.4 ms for
+    the detector harvester with plain copies; tools/harvest_split_probe.py.)"""
+    return host.to(device)
+
+
 def box_iou_plus1(gt, prop):
     """(G, R) IoU, +1 pixel convention, 0 where boxes do not touch (utils/evaluations.py:4-18)."""
     xmin = torch.max(gt[:, None, 0], prop[None, :, 0])
@@ -146,7 +154,7 @@ class _SlotGrid:
         dst = np.repeat(runs[:, 0], ks) + ramp
         src = np.repeat(np.asarray(self.src, dtype=np.int64), ks) + ramp
         self.dst, self.src = [], []
-        idx = torch.from_numpy(np.stack((dst, src))).to(rows.device)      # one host -> device copy (blocking: the array is a temporary)
+        idx = to_device(torch.from_numpy(np.stack((dst, src))), rows.device)      # one host -> device copy
         # the rows take the store's dtype / device here (f64 or f16 features, features of another device): index_copy_
         # itself accepts neither, and by now `plan` has already counted the rows
         picked = rows.index_select(0, idx[1]).to(device=self.store.device, dtype=self.store.dtype)
@@ -225,7 +233,7 @@ class DetectorHarvester:
             # All ground-truth boxes at once (the reference walks them one by one, box_head_getProposals.py:151-226):
             # sel[j, r] = proposal r regresses onto box j; nonzero() lists the pairs box-major, row-minor — the order of
             # the reference's appends — with one host synchronisation per image instead of several per box.
-            cls = torch.tensor([l - 1 for l in gt_labels_list], dtype=torch.int64, device=x.device)
+            cls = to_device(torch.tensor([l - 1 for l in gt_labels_list], dtype=torch.int64), x.device)
             if self.compute_gt_positives:
                 for c in sorted(set(gt_labels_list)):                      # rows of a class in ground-truth order
                     rows_c = [i for i, l in enumerate(gt_labels_list) if l == c]
@@ -300,7 +308,7 @@ class DetectorHarvester:
                 lens.append(k)
         if not plan:
             return torch.empty((0, self.D), dtype=x.dtype, device=x.device), lens
-        up = torch.stack(draws).to(x.device)                                                   # one copy for all classes' draws
+        up = to_device(torch.stack(draws), x.device)                                           # one copy for all classes' draws
         parts = [up[d] if kind == "host" else cand_order[:, col[i]][up[d]] for kind, i, d in plan]
         return x[torch.cat(parts)].view(-1, self.D), lens
 
@@ -498,7 +506,7 @@ class RPNHarvester:
         n_pos = sum(per_type)
         n_neg = sum(lens)
         # one host -> device copy for everything the device needs back: the sampled candidates' positions, the boxes' ranks
-        up = torch.cat(picks + [torch.tensor(rank_of, dtype=torch.int64)]).to(dev) if (picks or G) else None
+        up = to_device(torch.cat(picks + [torch.tensor(rank_of, dtype=torch.int64)]), dev) if (picks or G) else None
         pick_idx, rank_dev = up[:n_neg], up[n_neg:]
         feats_all = self._gather(t, order[pick_idx]) if n_neg else torch.empty((0, self.D), dtype=t.dtype, device=dev)
         done = []
@@ -614,8 +622,8 @@ def project_masks_on_boxes(masks, boxes, M):
 
     xa, xb, wxa, wxb = taps(wn[:, 0], wn[:, 2] - wn[:, 0])       # (G, M) each
     ya, yb, wya, wyb = taps(wn[:, 1], wn[:, 3] - wn[:, 1])
-    idx = torch.from_numpy(np.stack((xa, xb, ya, yb))).to(dev)
-    wts = torch.from_numpy(np.stack((wxa, wxb, wya, wyb))).to(dev)
+    idx = to_device(torch.from_numpy(np.stack((xa, xb, ya, yb))), dev)
+    wts = to_device(torch.from_numpy(np.stack((wxa, wxb, wya, wyb))), dev)
     xa, xb, ya, yb = idx[0], idx[1], idx[2], idx[3]
     wxa, wxb, wya, wyb = wts[0], wts[1], wts[2], wts[3]
     g = torch.arange(G, device=dev)[:, None, None]
@@ -678,7 +686,7 @@ class MaskHarvester:
         for (c, kind), lst in picks.items():
             loc = torch.cat([p for _, p in lst])
             obj = torch.cat([torch.full((len(p),), i, dtype=torch.int64) for i, p in lst])
-            idx = torch.stack((obj, loc)).to(dev)
+            idx = to_device(torch.stack((obj, loc)), dev)
             sel = order[idx[0], idx[1]] + idx[0] * S2
             (self._pos if kind == 0 else self._neg)[c].append(rows.index_select(0, sel), seg_lens=[len(p) for _, p in lst])
 
