@@ -33,40 +33,13 @@ def _rows(be, X):
 
 def sym_eig_small(S):
     """Eigen-decomposition of a batch of small symmetric matrices S (B, k, k) — the 4 x 4 target covariances of
-    train_region_refiner.py:63 — by cyclic Jacobi rotations in f64 on the host: (evals (B, k), V (B, k, k)) with
-    S = V diag(evals) V', eigenvalues in no particular order (T = V diag(.) V' does not depend on it, nor on the vectors'
-    signs).  k (k - 1) / 2 rotations per sweep, quadratic convergence: a 4 x 4 matrix is diagonal to rounding after 4-6
-    sweeps; written out here because a solver library's launch + synchronisation per batch costs more than the arithmetic."""
-    A = np.array(S.detach().cpu().numpy(), dtype=np.float64, copy=True)
-    single = A.ndim == 2
-    if single:
-        A = A[None]
-    B, k, _ = A.shape
-    V = np.broadcast_to(np.eye(k), (B, k, k)).copy()
-    scale = np.maximum(np.abs(A).max(axis=(1, 2)), np.finfo(np.float64).tiny)
-    for _ in range(30):
-        off = np.abs(A - np.einsum("bii->bi", A)[:, :, None] * np.eye(k)).max(axis=(1, 2))
-        if not np.any(off > 1e-300 + 1e-17 * scale):
-            break
-        for p in range(k - 1):
-            for q in range(p + 1, k):
-                apq = A[:, p, q]
-                live = np.abs(apq) > 1e-300
-                safe = np.where(live, apq, 1.0)
-                theta = (A[:, q, q] - A[:, p, p]) / (2.0 * safe)
-                t = np.where(theta >= 0, 1.0, -1.0) / (np.abs(theta) + np.hypot(theta, 1.0))
-                t = np.where(live, t, 0.0)
-                c = 1.0 / np.sqrt(t * t + 1.0)
-                sn = t * c
-                Ap, Aq = A[:, :, p].copy(), A[:, :, q].copy()                    # columns
-                A[:, :, p], A[:, :, q] = c[:, None] * Ap - sn[:, None] * Aq, sn[:, None] * Ap + c[:, None] * Aq
-                Ap, Aq = A[:, p, :].copy(), A[:, q, :].copy()                    # rows
-                A[:, p, :], A[:, q, :] = c[:, None] * Ap - sn[:, None] * Aq, sn[:, None] * Ap + c[:, None] * Aq
-                Vp, Vq = V[:, :, p].copy(), V[:, :, q].copy()
-                V[:, :, p], V[:, :, q] = c[:, None] * Vp - sn[:, None] * Vq, sn[:, None] * Vp + c[:, None] * Vq
-    evals = np.einsum("bii->bi", A).copy()
-    ev, Vt = torch.from_numpy(evals).to(S.device), torch.from_numpy(V).to(S.device)
-    return (ev[0], Vt[0]) if single else (ev, Vt)
+    train_region_refiner.py:63 — in f64 ON THE HOST (numpy): (evals (B, k), V (B, k, k)) with S = V diag(evals) V'.  Sixteen
+    numbers per class: a device solver's launch + synchronisation per batch costs more than the arithmetic (~8 ms against
+    ~30 us), and T = V diag(.) V' depends neither on the eigenvalues' order nor on the vectors' signs."""
+    A = np.asarray(S.detach().cpu().numpy(), dtype=np.float64)
+    A = 0.5 * (A + np.swapaxes(A, -1, -2))
+    ev, V = np.linalg.eigh(A)
+    return torch.from_numpy(np.ascontiguousarray(ev)).to(S.device), torch.from_numpy(np.ascontiguousarray(V)).to(S.device)
 
 
 def whiten_targets(Yi):

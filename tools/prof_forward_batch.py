@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""What to run under `rocprofv3 --kernel-trace --stats`: the R-50-C4 forward of ODX_FWD_B (default 4) 600 x 800 images per
-call (extract.forward_batch), ODX_FWD_DTYPE = f32 | bf16, 12 calls after the warm-up."""
+"""What to run under `rocprofv3 --kernel-trace --stats -- python3 tools/prof_forward_batch.py [B] [f32|bf16]`: the R-50-C4
+forward of B (default 4) 600 x 800 images per call (extract.forward_batch), 15 calls; the first ones carry the convolution
+library's solver search (its naive reference kernels show up in the statistics: ignore `naive_conv_*`)."""
 import os
 import sys
 
@@ -13,8 +14,8 @@ import odx  # noqa: E402
 from odx.extract import OnlineDetectionModel, forward_batch  # noqa: E402
 
 odx.get_backend()
-B = int(os.environ.get("ODX_FWD_B", "4"))
-dt = torch.bfloat16 if os.environ.get("ODX_FWD_DTYPE", "f32") == "bf16" else None
+B = int(sys.argv[1]) if len(sys.argv) > 1 else int(os.environ.get("ODX_FWD_B", "4"))
+dt = torch.bfloat16 if (sys.argv[2] if len(sys.argv) > 2 else os.environ.get("ODX_FWD_DTYPE", "f32")) == "bf16" else None
 model = OnlineDetectionModel(compute_dtype=dt).cuda().eval()
 x = torch.randn((B, 3, 600, 800), generator=torch.Generator().manual_seed(1)).cuda()
 with torch.no_grad():
