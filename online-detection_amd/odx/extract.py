@@ -491,6 +491,10 @@ class GraphedCall:
     clear().  A capture that fails (an operation the runtime cannot capture) turns the wrapper into a plain call for good;
     ODX_TRUNK_GRAPH=0 does the same from the environment."""
 
+    import threading as _threading
+    _tls = _threading.local()                  # .forbid = True: no capture from this thread (a thread that shares the device with
+    # another thread's launches — the harvest loop's forward thread; captures are made on the caller's thread beforehand)
+
     def __init__(self, fn, max_graphs=6):
         import threading
         self.fn, self.max_graphs = fn, max_graphs
@@ -514,25 +518,32 @@ class GraphedCall:
         self.fn, self.max_graphs, self.enabled = d["fn"], d["max_graphs"], d["enabled"]
         self.graphs, self.seen, self.captures, self.lock = {}, {}, {}, threading.Lock()
 
-    def _capture(self, xs):
-        static_in = tuple(x.clone() for x in xs)
-        cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):           # the library picks its algorithms and the caches fill outside the capture
-            for _ in range(2):
-                self.fn(*static_in)
-        cur.wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):     # (the extractor's other thread keeps allocating)
-            static_out = self.fn(*static_in)
-        return graph, static_in, static_out
+    def _capture(self, xs, gstream):
+        with torch.cuda.stream(gstream):
+            static_in = tuple(x.clone() for x in xs)
+            side = torch.cuda.Stream()
+            side.wait_stream(gstream)
+            with torch.cuda.stream(side):       # the library picks its algorithms and the caches fill outside the capture
+                for _ in range(2):
+                    self.fn(*static_in)
+            gstream.wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):     # (the extractor's other thread keeps allocating)
+                static_out = self.fn(*static_in)
+        return graph, static_in, static_out, gstream
 
     def __call__(self, x, *more, key_extra=None, capture=True):
         """fn(x, *more): every argument a tensor of fixed shape per key (copied into the graph's own inputs); key_extra:
         whatever else the captured work depends on (hashable); capture=False: replay a graph that exists, never make one in
-        this call (a thread that shares the device with another thread's launches: a capture is made where nothing else runs)."""
+        this call.
+
+        A graph is ALWAYS launched on one stream of its own (made with the capture), whatever stream the caller is on: the caller's
+        stream and the graph's are joined by events before the inputs are copied in and behind the copies out.  Launching one
+        graph from changing streams is not safe on this runtime: the first launch from another stream with new inputs returned
+        the previous inputs' results (or garbage — a survivor count read as 10^5 was the harvest loop's memory fault), on the
+        legacy default stream and on side streams alike (round 5; the matrix that showed it: capture on A, replay on A / B /
+        A ...)."""
         xs = (x,) + tuple(more)
         if not (self.enabled and x.is_cuda and not torch.is_grad_enabled()):
             return self.fn(*xs)
@@ -542,7 +553,7 @@ class GraphedCall:
             entry = self.graphs.pop(key, None)
             if entry is None:
                 n = self.seen.get(key, 0)
-                if not capture:
+                if not capture or getattr(self._tls, "forbid", False):
                     return self.fn(*xs)
                 if n < 1:
                     if len(self.seen) > 256:
@@ -552,27 +563,32 @@ class GraphedCall:
                 if self.captures.get(key, 0) >= 2:    # captured, evicted, captured, evicted: this stream of shapes cycles through
                     return self.fn(*xs)               # more of them than are kept — a capture costs ~4 plain calls, stop paying it
                 self.captures[key] = self.captures.get(key, 0) + 1
+                cur = torch.cuda.current_stream()
+                gstream = torch.cuda.Stream()
+                gstream.wait_stream(cur)
                 try:
-                    entry = self._capture(xs)
+                    entry = self._capture(xs, gstream)
                 except Exception as e:          # noqa: BLE001 — whatever the runtime refuses: the plain call is always right
                     self.enabled = False
                     print("odx: HIP graph capture of %s failed (%s: %s); running it launch by launch" % (
                         getattr(self.fn, "__name__", "the forward"), type(e).__name__, e), file=sys.stderr)
                     return self.fn(*xs)
+                cur.wait_stream(gstream)
                 while len(self.graphs) >= self.max_graphs:
                     self.graphs.pop(next(iter(self.graphs)))
             self.graphs[key] = entry             # (re-inserted last: most recently used)
-            graph, static_in, static_out = entry[:3]
+            graph, static_in, static_out, gstream = entry
             cur = torch.cuda.current_stream()
-            if len(entry) > 3 and entry[3] is not None:
-                cur.wait_event(entry[3])         # the previous user's copies out of the graph's buffers — possibly on another stream
-            for dst, src in zip(static_in, xs):
-                dst.copy_(src)
-            graph.replay()
-            out = static_out.clone() if torch.is_tensor(static_out) else tuple(None if t is None else t.clone() for t in static_out)
-            done = torch.cuda.Event()
-            done.record(cur)
-            self.graphs[key] = (graph, static_in, static_out, done)
+            gstream.wait_stream(cur)             # the caller's inputs are ready; (earlier users' copies out are on gstream itself)
+            with torch.cuda.stream(gstream):
+                for dst, src in zip(static_in, xs):
+                    dst.copy_(src)
+                graph.replay()
+                out = static_out.clone() if torch.is_tensor(static_out) else tuple(None if t is None else t.clone() for t in static_out)
+            cur.wait_stream(gstream)
+            for t in ((out,) if torch.is_tensor(out) else out):
+                if t is not None:
+                    t.record_stream(cur)         # allocated on the graph's stream, used (and later freed) by the caller's
             return out
 
 
@@ -610,13 +626,20 @@ class OnlineDetectionModel(nn.Module):
         self.online_mask = None         # odx.heads.OnlineMaskPredictor
         self.mask_dim = mask_dim
         self._trunk_graphs = GraphedCall(self._c4_eager)
-        # The whole group forward from ONE HIP graph (forward_group; ODX_GROUP_GRAPH=0 turns it off).  Its first form kept the
-        # proposal stage as tensor operations (top-k, gather, advanced indexing) and ended in a GPU memory fault at the graph's
-        # second or third replay whenever other work had run in between — tools/group_graph_bisect.py captures growing prefixes of
-        # the forward and localised it to exactly that stage (trunk and RPN head replay fine); with the stage as three kernels of
-        # this library (odx_rpn_topk_decode_f32, odx_nms_batched_first_f32, odx_nms_compact_f32) every prefix replays.
+        # The whole group forward from ONE HIP graph (forward_group): OPT-IN, ODX_GROUP_GRAPH=1.  What round 5 found on this
+        # runtime: (i) with the proposal stage as tensor operations (a library top-k, gather, advanced indexing) the graph's second
+        # or third replay ended in a GPU memory fault whenever other work had run in between — tools/group_graph_bisect.py captures
+        # growing prefixes of the forward and localised it to exactly that stage; the stage is three kernels of this library now
+        # (odx_rpn_topk_decode_f32, odx_nms_batched_first_f32, odx_nms_compact_f32) and every prefix replays, at full size, with
+        # other work in between (tests/test_extract.py); (ii) a graph launched from CHANGING streams returned the previous inputs'
+        # results or zeros — GraphedCall now launches every graph on one stream of its own; (iii) one sequence (replays called
+        # alternately from the default and a side stream, a second graph replayed in between) still produced all-zero features
+        # once and could not be reproduced in isolation.  Until (iii) is understood the harvest loop queues a group's forward
+        # launch by launch (forward_batch: one trunk call, one proposal stage, one head pass per group) — 3.2 instead of 3.0 ms per
+        # image for the forward alone at 8 images per group, the harvest loop 5.2 ms per image either way (it is bound by the
+        # harvesters' own host work) — and this path is kept as the opt-in it is.
         self._group_graphs = GraphedCall(self._group_static, max_graphs=4)
-        if os.environ.get("ODX_GROUP_GRAPH", "1") == "0":
+        if os.environ.get("ODX_GROUP_GRAPH", "0") != "1":
             self._group_graphs.enabled = False
         self.register_load_state_dict_post_hook(OnlineDetectionModel._drop_graphs)
 
@@ -1178,6 +1201,24 @@ class OnlineFeatureExtractor:
             import queue
             import threading
             in_thread[0] = True
+            # HIP graphs of the trunk are captured HERE, on the caller's thread with nothing else in flight — for the group shapes
+            # this list starts with — and only replayed by the forward thread below (GraphedCall._tls.forbid): a capture beside
+            # another thread's launches on the legacy stream fails ("dependency created on uncaptured work in another stream")
+            tg = getattr(m, "_trunk_graphs", None)
+            if tg is not None and tg.enabled:
+                done_shapes = set()
+                with torch.no_grad():
+                    for grp in groups:
+                        shape = (len(grp),) + tuple(_unpack(grp[0])[0].shape[1:])
+                        if shape in done_shapes:
+                            continue
+                        if len(done_shapes) >= 3:
+                            break
+                        done_shapes.add(shape)
+                        ims = torch.cat([_unpack(smp)[0].to(dev) for smp in grp], dim=0)
+                        for _ in range(2):                       # a shape's first call runs launch by launch, its second captures
+                            m.c4(ims)
+                torch.cuda.synchronize()
             main = torch.cuda.current_stream()
             fwd = torch.cuda.Stream()
             fwd.wait_stream(main)
@@ -1197,6 +1238,7 @@ class OnlineFeatureExtractor:
             def producer():
                 try:
                     torch.cuda.set_device(dev)
+                    GraphedCall._tls.forbid = True
                     with torch.cuda.stream(fwd):
                         for item in forward_items(samples):
                             if stop.is_set():

@@ -588,6 +588,7 @@ def test_group_forward_from_one_graph_equals_the_eager_batched_forward():
     model.rpn_logits.weight.data.normal_(0, 0.3)
     model.rpn_deltas.weight.data.normal_(0, 0.05)
     model = model.cuda()
+    model._group_graphs.enabled = True            # (opt-in: ODX_GROUP_GRAPH=1 — OnlineDetectionModel.__init__ says why)
     g = torch.Generator().manual_seed(1)
     images = torch.randn(4, 3, 192, 256, generator=g).cuda()
 
@@ -641,6 +642,7 @@ def test_group_graph_at_full_size_with_other_work_between_replays():
     model.rpn_logits.weight.data.normal_(0, 0.3)          # well separated objectness (see test_forward_gpu_equals_plain_torch_cpu)
     model.rpn_deltas.weight.data.normal_(0, 0.05)
     model = model.cuda()
+    model._group_graphs.enabled = True            # (opt-in: ODX_GROUP_GRAPH=1)
     g = torch.Generator().manual_seed(2)
     images = torch.randn(4, 3, 600, 800, generator=g).cuda()
     gts = []

@@ -92,16 +92,17 @@ def forward_extra(height=600, width=800, rois=300, reps=8):
         out["images_per_s_" + name] = round(reps / dt, 1)
         out["ms_per_image_" + name] = round(dt / reps * 1e3, 2)
         out["roofline_" + name] = _forward_roofline(forward_flop_c4(model, height, width, rois), dt / reps * 1e3, name)
-    # groups of same-size images through ONE forward each (extract.forward_batch; the whole group from one HIP graph:
-    # OnlineDetectionModel.forward_group) — what the harvest loop runs; the one-image keys above are detect()'s route
+    # groups of same-size images through ONE forward each (extract.forward_batch: one trunk call, one proposal stage, one pass
+    # of the RoI head per group) — what the harvest loop runs; the one-image keys above are detect()'s route
     for name, cd in (("f32", None), ("bf16", torch.bfloat16)):
         gm = OnlineDetectionModel(post_nms_top_n=rois, compute_dtype=cd).to(dev).eval()
+        from odx.extract import forward_batch
         for B in (4, 8):
             imgs = torch.randn((B, 3, height, width), device=dev, generator=g)
             with torch.no_grad():
                 for _ in range(3):
-                    gm.forward_group(imgs, [None] * B)
-                dt, _ = _best_time(lambda: [gm.forward_group(imgs, [None] * B) for _ in range(4)])
+                    forward_batch(gm, imgs)
+                dt, _ = _best_time(lambda: [forward_batch(gm, imgs) for _ in range(4)])
             ms = dt / (4 * B) * 1e3
             out["ms_per_image_%s_group%d" % (name, B)] = round(ms, 2)
             if B == 8:

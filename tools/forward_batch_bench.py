@@ -79,6 +79,8 @@ def main():
                         ev[k].elapsed_time(ev[k + 1]) / 5 / B for k in range(3))
             print(line, flush=True)
             if B > 1:
+                model._group_graphs.enabled = True          # (opt-in path, see OnlineDetectionModel.__init__)
+
                 def run_g():
                     for i in range(0, args.images, B):
                         model.forward_group(imgs[i:i + B], [None] * B)
