@@ -30,7 +30,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import backend as _backend
-from .extract import (FrozenBatchNorm2d, _FoldedBN, _nms_takes_max_keep, _stage, cell_anchors, decode_deltas, grid_anchors)
+from .extract import (DELTA_CLAMP, FrozenBatchNorm2d, _FoldedBN, _nms_takes_max_keep, _stage, cell_anchors, decode_deltas, grid_anchors)
 
 
 class ResNet50Stages(_FoldedBN):
@@ -216,7 +216,9 @@ class OnlineDetectionModelFPN(nn.Module):
         # per level: the RPN head and the top-k (their sizes differ); the decoding / clipping of the selected candidates of
         # all five levels is then done ONCE on their concatenation (a level's ~20 small elementwise launches otherwise: the
         # FPN forward was launch-bound at 600 launches per image), and the suppression runs per level again
+        fused = hasattr(be, "rpn_topk_decode") and trunk[0].is_cuda and self.online_rpn is None
         sel_reg, sel_anc, sel_score, counts = [], [], [], []
+        lvl_boxes = []
         for lvl, p in enumerate(trunk):
             with (contextlib.nullcontext() if p.dtype in (torch.bfloat16, torch.float16) else self._amp()):
                 # (weights / biases held in the compute dtype: autocast casts an f32 parameter again on every call — 15 casts
@@ -225,19 +227,32 @@ class OnlineDetectionModelFPN(nn.Module):
                 t = F.relu(F.conv2d(p, w[0], w[1], 1, 1))
                 logits, deltas = F.conv2d(t, w[2], w[3]).float(), F.conv2d(t, w[4], w[5]).float()
             _, A, H, W = logits.shape
+            k = min(self.pre_nms_top_n, A * H * W)
+            if fused and k <= 8192:
+                # a level's top-k, sorting, delta gather, decoding and clipping as ONE launch (odx_rpn_topk_decode_f32) instead of
+                # ~25 tensor operations: the five levels were 125 of this forward's launches
+                b, sc, _ = be.rpn_topk_decode(logits, deltas, self._anchors(lvl, H, W, logits.device), k, img_size, DELTA_CLAMP)
+                lvl_boxes.append(b[0])
+                sel_score.append(sc[0])
+                counts.append(k)
+                continue
             obj = logits.permute(0, 2, 3, 1).reshape(-1)
             reg = deltas.view(1, A, 4, H, W).permute(0, 3, 4, 1, 2).reshape(-1, 4)
-            k = min(self.pre_nms_top_n, obj.numel())
             score, idx = obj.topk(k, sorted=True)              # (the sigmoid is monotonic: same order on the logits)
             sel_reg.append(reg[idx])
             sel_anc.append(self._anchors(lvl, H, W, reg.device)[idx])
             sel_score.append(score)
             counts.append(k)
-        scores_cat = torch.cat(sel_score).sigmoid()
-        boxes_cat = decode_deltas(torch.cat(sel_reg), torch.cat(sel_anc))
-        boxes_cat.clamp_(min=0)
-        boxes_cat[:, 0::2].clamp_(max=img_size[0] - 1)
-        boxes_cat[:, 1::2].clamp_(max=img_size[1] - 1)
+        if lvl_boxes and len(lvl_boxes) == len(counts):
+            scores_cat, boxes_cat = torch.cat(sel_score), torch.cat(lvl_boxes)          # (already sigmoid, decoded, clipped)
+        else:
+            if lvl_boxes:
+                raise RuntimeError("FPN proposals: levels took different routes")      # (k > 8192 on some level only: not a shipped setting)
+            scores_cat = torch.cat(sel_score).sigmoid()
+            boxes_cat = decode_deltas(torch.cat(sel_reg), torch.cat(sel_anc))
+            boxes_cat.clamp_(min=0)
+            boxes_cat[:, 0::2].clamp_(max=img_size[0] - 1)
+            boxes_cat[:, 1::2].clamp_(max=img_size[1] - 1)
         if hasattr(be, "nms_batched") and boxes_cat.is_cuda and len(counts) > 1:
             # the suppression of all levels with ONE launch pair and ONE host synchronisation (odx_nms_batched_f32: independent
             # sorted box sets, sizes on the device) instead of a launch pair and a synchronisation per level — this stage is

@@ -22,14 +22,14 @@ def short(name):
     return name.split("(")[0].replace("void ", "").replace("odx::", "")
 
 
-def stats_table(path, rows=16, title=None):
+def stats_table(path, rows=16, title=None, skip=()):
     if not os.path.exists(path):
         return
     if title:
         print(title)
     print("| kernel | calls | total ms | avg us | % |")
     print("|---|---|---|---|---|")
-    for r in list(csv.DictReader(open(path)))[:rows]:
+    for r in [r for r in csv.DictReader(open(path)) if not any(w in r["Name"] for w in skip)][:rows]:
         print("| `%s` | %s | %.1f | %.1f | %s |" % (short(r["Name"])[-70:], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                   float(r["AverageNs"]) / 1e3, r["Percentage"]))
     print()
@@ -172,3 +172,11 @@ for tag, title, want in (("forward", "feature forward: R-50-C4 and R-50-FPN, 10 
         if want and glob.glob(os.path.join(d, "xpmc_%s_*counter_collection.csv" % tag)):
             print("PMC (FETCH_SIZE / WRITE_SIZE / MFMA-busy passes of the same script):\n")
             pmc_lines(d, "xpmc_%s_" % tag, want)
+
+for tag, title in (("forward_b4", "R-50-C4 forward, FOUR 600 x 800 images per call (extract.forward_batch), f32, 15 calls (tools/prof_forward_batch.py 4 f32)"),
+                   ("forward_b4_bf16", "the same in bf16 (compute_dtype = bfloat16: trunk by the library in bf16, head on odx_gemm_b16)")):
+    sp = os.path.join(d, "x_%s_kernel_stats.csv" % tag)
+    if os.path.exists(sp):
+        stats_table(sp, rows=16, skip=("naive_conv",), title="## %s\n\n(whole-process statistics, 15 calls = 60 images; the convolution library's "
+                    "solver search on the first calls runs its naive reference kernels once per shape — left out of the table; the percentages "
+                    "are of the process's total including them)\n" % title)
