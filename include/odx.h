@@ -416,6 +416,29 @@ int odx_split_f16_taps3x3(const float* Y, int64_t ldy, int64_t R, int H, int W, 
 int odx_gemm_h2_f32(const void* PA, int64_t ldpa, const float* metaa, int64_t m, const void* PB, int64_t ldpb,
                     const float* metab, int64_t n, int K, const float* bias, const float* residual, int64_t ldr,
                     int relu, float* out, int64_t ldo, odx_stream_t stream);
+/* The same product for a CHAIN of layers — the ResNet trunk (mrcnn_modified/modeling/detector/generalized_rcnn_getProposals.py:60
+ * -> self.backbone; maskrcnn_benchmark's ResNet stages, STRIDE_IN_1X1) and the RPN head's 3 x 3 convolution
+ * (mrcnn_modified/modeling/rpn/rpn.py:164-170) run as GEMMs over NHWC rows, as the conv5 head is: the launch also leaves
+ * max |out| in out_meta[1] (IEEE bits of a non-negative float; must be 0 on entry, out_meta[0] is not touched), which is what
+ * odx_split_f16_premax / odx_split_f16_taps3x3_premax scale the next layer's operand by, so no layer reads its input once
+ * more for a maximum. */
+int odx_gemm_h2_max_f32(const void* PA, int64_t ldpa, const float* metaa, int64_t m, const void* PB, int64_t ldpb,
+                        const float* metab, int64_t n, int K, const float* bias, const float* residual, int64_t ldr,
+                        int relu, float* out, int64_t ldo, float* out_meta, odx_stream_t stream);
+int odx_split_f16_taps3x3_premax(const float* Y, int64_t ldy, int64_t R, int H, int W, int C, void* P, int64_t ldp,
+                                 float* meta, odx_stream_t stream);
+/* The 3 x 3 convolution of such a chain WITHOUT the 9 x neighbourhood matrix: out (R H W x n) = act(taps3x3(Y) B' + bias +
+ * residual) with the gather done inside the product's operand loads (LDS-DMA from the neighbour's row, or from a zero row
+ * outside the map).  PY: the packed rows of Y (R H W rows of C channels, odx_split_f16's form, row stride ldpy 4-byte units,
+ * meta words metay) FOLLOWED BY ONE ALL-ZERO ROW; B (n x 9 C, K index (ky kx c)) packed as for odx_gemm_h2_f32; out_meta
+ * as in odx_gemm_h2_max_f32, or NULL.  Served where odx_gemm_h2_taps_supported(m = R H W, n, C, ldpy) returns 1 (the
+ * 256 x 256 tile core fills the chip, C % 32 == 0, the packed rows span < 2^31 bytes); elsewhere: odx_split_f16_taps3x3 +
+ * odx_gemm_h2_f32.  Same sums in the same order as that pair (bit-identical results). */
+int odx_gemm_h2_taps_supported(int64_t m, int64_t n, int C, int64_t ldpy);
+int odx_gemm_h2_taps_f32(const void* PY, int64_t ldpy, const float* metay, int64_t R, int H, int W, int C,
+                         const void* PB, int64_t ldpb, const float* metab, int64_t n, const float* bias,
+                         const float* residual, int64_t ldr, int relu, float* out, int64_t ldo, float* out_meta,
+                         odx_stream_t stream);
 /* The same layers for a forward run in a 16-bit type (BASELINE config 2's bf16; the reference's own dtype is f32,
  * config/defaults.py:466): out (m x n) = act(A B' + bias[col] + residual) for plain row-major bf16 (is_bf16 = 1) or f16
  * operands A (m x K), B (n x K) — lda / ldb in ELEMENTS, multiples of 8, >= roundup(K, 128), the elements beyond K zero;
@@ -433,6 +456,11 @@ int odx_taps3x3_16(const void* Y, int64_t ldy, int64_t R, int H, int W, int C, v
 int odx_roi_align_rows_f32(const float* feat, int N, int C, int H, int W, const float* rois, int R,
                            float spatial_scale, int PH, int PW, int sampling_ratio, int step, float* out_rows,
                            odx_stream_t stream);
+/* odx_roi_align_rows_f32 reading the map as the NHWC row matrix the trunk's GEMMs write (N * H * W rows of C channels, row
+ * stride ldf floats; C % 4 == 0, ldf % 4 == 0, 16-byte aligned) — same bins, sample positions and sums per channel. */
+int odx_roi_align_rows_nhwc_f32(const float* feat_rows, int64_t ldf, int N, int C, int H, int W, const float* rois, int R,
+                                float spatial_scale, int PH, int PW, int sampling_ratio, int step, float* out_rows,
+                                odx_stream_t stream);
 /* Multi-level RoIAlign over an FPN pyramid: maskrcnn_benchmark's Pooler as FPN2MLPFeatureExtractor uses it
  * (mrcnn_modified/modeling/roi_heads/box_head/roi_box_feature_extractors.py:61-68,79; config/defaults.py:214-219 with the
  * R-50-FPN values POOLER_SCALES (1/4 .. 1/32), POOLER_RESOLUTION 7, POOLER_SAMPLING_RATIO 2).  feats[l] (N, C, H[l], W[l]),

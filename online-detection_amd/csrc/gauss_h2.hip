@@ -76,11 +76,14 @@ __device__ __forceinline__ float h2_scale_from_absmax(unsigned int bits) {
 __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ X, int64_t ldx, int64_t n, int D,
                                                         uint32_t* __restrict__ P, int64_t ldp, float* __restrict__ meta) {
   const float s = h2_scale_from_absmax(__float_as_uint(meta[1]));
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) meta[0] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) meta[0] = s;
+  if (n <= 0) return;
   const int groups = (int)((D + H2_KT - 1) / H2_KT) * 8;  // 8-feature groups per row, zero padded to whole k-tiles
-  const int64_t row = blockIdx.y;
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= groups) return;
+  // a flat index over (row, group): with one workgroup per row a 64-channel activation kept 8 of its 256 lanes busy
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = idx / groups;
+  const int g = (int)(idx - row * groups);
+  if (row >= n) return;
   const float* x = X + row * ldx + (int64_t)g * 8;
   float v[8];
   if (g * 8 + 8 <= D) {
@@ -110,14 +113,17 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
 // never as floats (9 x the bytes of Y).  C % 8 == 0; the scale comes from Y's own absmax (the zeros add nothing).
 __global__ __launch_bounds__(256) void split_f16_taps3x3_kernel(const float* __restrict__ Y, int64_t ldy, int H, int W, int C,
                                                                 uint32_t* __restrict__ P, int64_t ldp, float* __restrict__ meta,
-                                                                int64_t row0) {
+                                                                int64_t nrows) {
   const float s = h2_scale_from_absmax(__float_as_uint(meta[1]));
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) meta[0] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) meta[0] = s;
   const int D = 9 * C;
   const int groups = (int)((D + H2_KT - 1) / H2_KT) * 8;
-  const int64_t row = row0 + blockIdx.y;
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= groups) return;
+  // a flat index over (row, 8-feature group): with the rows on grid.y a 64-channel layer (72 groups) kept 72 of a workgroup's
+  // 256 lanes busy and a trunk stage of 120 000 rows needed two launches
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = idx / groups;
+  const int g = (int)(idx - row * groups);
+  if (row >= nrows) return;
   float v[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) v[q] = 0.f;
@@ -637,17 +643,48 @@ struct WDma {
   __amdgpu_buffer_rsrc_t ra, rb;
   uint32_t va[4], vb[4];       // per-lane byte offsets of this wave's four 8-row pieces of each operand
   int fa, fb, hi, lo;          // LDS: fragment rows of this lane in the A / B image, hi / lo chunk inside a row
+  // TAPS (A = the 3 x 3 neighbourhood matrix of packed NHWC rows, never materialised: see w_mainloop_dma):
+  int th[4], tw[4];            // map position (h, w) of the lane's four rows (h = -4 for a row past the operand's end)
+  int tH, tW, tld, tkb;        // map size, row stride in bytes, bytes of one tap inside a packed row (4 C)
+  uint32_t tzero;              // this lane's chunk of the all-zero row behind the operand's last row
 };
 
+// Stage -> (tap, channel offset) for the TAPS operand, kept as a cursor: stage s covers the 32 channels at byte `kin` of tap
+// (dy, dx) = (ky - 1, kx - 1), taps in the order ky kx of the weight matrix's K axis.
+struct WTapCur {
+  int kin, dy, dx;
+};
+__device__ __forceinline__ WTapCur w_tap_next(WTapCur c, int kbytes) {
+  c.kin += W_KS * 4;
+  if (c.kin == kbytes) {
+    c.kin = 0;
+    if (++c.dx == 2) {
+      c.dx = -1;
+      ++c.dy;
+    }
+  }
+  return c;
+}
+
 // pieces q0 .. q1 - 1 (0..7: A pieces 0..3, B pieces 0..3) of stage `koff` (bytes into the rows) -> image `dst`
-template <int Q0, int Q1>
-__device__ __forceinline__ void w_dma_pieces(const WDma& ad, char* dst, int koff) {
+template <int Q0, int Q1, bool TAPS = false>
+__device__ __forceinline__ void w_dma_pieces(const WDma& ad, char* dst, int koff, const WTapCur tc = WTapCur{0, 0, 0}) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
   for (int q = Q0; q < Q1; ++q) {
     char* d = dst + (q >> 2) * W_OPND_BYTES + wave * 1024 + (q & 3) * 8192;
-    if (q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(ad.ra, (lds_ptr_t)d, 16, ad.va[q & 3], koff, 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(ad.rb, (lds_ptr_t)d, 16, ad.vb[q & 3], koff, 0, 0);
+    if (q < 4) {
+      if (TAPS) {
+        // the row of the neighbour (h + dy, w + dx) of this lane's row, or the zero row when that is outside the map
+        const bool in = (unsigned)(ad.th[q & 3] + tc.dy) < (unsigned)ad.tH && (unsigned)(ad.tw[q & 3] + tc.dx) < (unsigned)ad.tW;
+        const uint32_t v = in ? ad.va[q & 3] + (uint32_t)((tc.dy * ad.tW + tc.dx) * ad.tld) : ad.tzero;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ad.ra, (lds_ptr_t)d, 16, v, tc.kin, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ad.ra, (lds_ptr_t)d, 16, ad.va[q & 3], koff, 0, 0);
+      }
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ad.rb, (lds_ptr_t)d, 16, ad.vb[q & 3], koff, 0, 0);
+    }
   }
 }
 
@@ -719,12 +756,13 @@ __device__ __forceinline__ void w_sched_part() {
 // by column block as part 3 is done with them, the B fragments of stage s + 1 (F1), all UNDER the 24 MFMAs of part 3:
 // neither the barrier's skew nor the LDS latency of a stage's first fragments stops the matrix pipe, and the B fragments
 // need no second register set.
-template <bool F1, bool F2, int CORE>
-__device__ __forceinline__ void w_stage_dma(f32x4 (&acc)[8][4], WFrag& f, const char* cur, char* nxt, int koff1, const WDma& ad) {
+template <bool F1, bool F2, int CORE, bool TAPS = false>
+__device__ __forceinline__ void w_stage_dma(f32x4 (&acc)[8][4], WFrag& f, const char* cur, char* nxt, int koff1, const WDma& ad,
+                                            const WTapCur tc1 = WTapCur{0, 0, 0}) {
   constexpr int PER = CORE == CORE_F8 ? 1 : (CORE == CORE_H2 ? 3 : 2);
   // part 0, reading part 1
   w_read_a(f.a1h, f.a1l, cur, ad, 1);
-  if (F1) w_dma_pieces<3, 6>(ad, nxt, koff1);
+  if (F1) w_dma_pieces<3, 6, TAPS>(ad, nxt, koff1, tc1);
 #pragma unroll
   for (int tn = 0; tn < 4; ++tn) w_mfma_col<CORE>(acc, f.a0h, f.a0l, f.bh[tn], f.bl[tn], 0, tn);
   w_sched_part<PER, F1 ? 3 : 0>();
@@ -746,7 +784,7 @@ __device__ __forceinline__ void w_stage_dma(f32x4 (&acc)[8][4], WFrag& f, const 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (F2) w_dma_pieces<0, 3>(ad, const_cast<char*>(cur), koff1 + W_KS * 4);
+    if (F2) w_dma_pieces<0, 3, TAPS>(ad, const_cast<char*>(cur), koff1 + W_KS * 4, TAPS ? w_tap_next(tc1, ad.tkb) : tc1);
     w_read_a(f.a0h, f.a0l, nxt, ad, 0);
   }
   // part 3, column block by column block; each block's B registers take the next stage's fragments as soon as it is done
@@ -759,17 +797,40 @@ __device__ __forceinline__ void w_stage_dma(f32x4 (&acc)[8][4], WFrag& f, const 
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool PERMB = false, int CORE = CORE_H2>
+// TAPS: A is not an (m x K) matrix in memory but the 3 x 3 neighbourhood matrix (K = 9 C, tap after tap) of the packed NHWC
+// rows Y (m = R H W rows of C channels, C % 32 == 0, followed by ONE all-zero row; (m + 1) ld 4 < 2^31 bytes): row r of
+// stage s is read from Y's row of the neighbour (h + dy, w + dx) at the stage's channels, or from the zero row outside the
+// map.  The gather costs two compares and a select per DMA; the 9 x copy of the activation that odx_split_f16_taps3x3 writes
+// (2.2 GB per conv5-head layer at 2400 RoIs) and this loop would read back is never made.
+template <bool PERMB = false, int CORE = CORE_H2, bool TAPS = false>
 __device__ __forceinline__ void w_mainloop_dma(f32x4 (&acc)[8][4], const uint32_t* __restrict__ A, int64_t lda, int64_t m,
                                                const uint32_t* __restrict__ B, int64_t ldb, int64_t n, int64_t i0, int64_t j0,
-                                               int stages, char* lds) {
+                                               int stages, char* lds, int tapH = 0, int tapW = 0, int tapC = 0) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   WDma ad;
-  w_dma_offsets<false>(ad.va, lda, i0, m);
   w_dma_offsets<PERMB>(ad.vb, ldb, j0, n);
   const int64_t la = m - i0 < W_BM ? m - i0 : W_BM, lb = n - j0 < W_BN ? n - j0 : W_BN;       // rows of the tile that exist
-  ad.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(A + i0 * lda), (short)0, (int)(la * lda * 4), 0x00020000);
+  if (TAPS) {
+    ad.tH = tapH;
+    ad.tW = tapW;
+    ad.tld = (int)(lda * 4);
+    ad.tkb = tapC * 4;
+    const uint32_t chunk = (uint32_t)(((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 16);   // (ri >> 1) & 7 is the same for the four pieces
+    ad.tzero = (uint32_t)(m * lda * 4) + chunk;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t r = i0 + 8 * wave + 64 * p + (lane >> 3);
+      const bool real = r < m;
+      ad.th[p] = real ? (int)((r / tapW) % tapH) : -4;
+      ad.tw[p] = real ? (int)(r % tapW) : -4;
+      ad.va[p] = (uint32_t)(r * lda * 4) + chunk;
+    }
+    ad.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(A), (short)0, (int)((m + 1) * lda * 4), 0x00020000);
+  } else {
+    w_dma_offsets<false>(ad.va, lda, i0, m);
+    ad.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(A + i0 * lda), (short)0, (int)(la * lda * 4), 0x00020000);
+  }
   ad.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(B + j0 * ldb), (short)0, (int)(lb * ldb * 4), 0x00020000);
   const int r = lane & 15, g = lane >> 4;
   ad.hi = ((g ^ ((r >> 1) & 7)) << 4);
@@ -777,22 +838,26 @@ __device__ __forceinline__ void w_mainloop_dma(f32x4 (&acc)[8][4], const uint32_
   ad.fa = (wr * 128 + r) * W_ROW;
   ad.fb = W_OPND_BYTES + (wc * 64 + r) * W_ROW;
   // (the caller's last use of the LDS ended on a barrier)
-  w_dma_pieces<0, 8>(ad, lds, 0);
+  WTapCur tc{0, -1, -1};                 // stage 0: tap (ky, kx) = (0, 0), first channels
+  w_dma_pieces<0, 8, TAPS>(ad, lds, 0, tc);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (stages > 1) w_dma_pieces<0, 3>(ad, lds + W_STAGE_BYTES, W_KS * 4);
+  if (TAPS) tc = w_tap_next(tc, ad.tkb);                // from here on: the cursor of stage s + 1
+  if (stages > 1) w_dma_pieces<0, 3, TAPS>(ad, lds + W_STAGE_BYTES, W_KS * 4, tc);
   WFrag f;
 #pragma unroll
   for (int t = 0; t < 4; ++t) w_read_b1(f, lds, ad, t);
   w_read_a(f.a0h, f.a0l, lds, ad, 0);
   int s = 0;
-  for (; s + 2 < stages; ++s)
-    w_stage_dma<true, true, CORE>(acc, f, lds + (s & 1) * W_STAGE_BYTES, lds + ((s + 1) & 1) * W_STAGE_BYTES, (s + 1) * (W_KS * 4), ad);
+  for (; s + 2 < stages; ++s) {
+    w_stage_dma<true, true, CORE, TAPS>(acc, f, lds + (s & 1) * W_STAGE_BYTES, lds + ((s + 1) & 1) * W_STAGE_BYTES, (s + 1) * (W_KS * 4), ad, tc);
+    if (TAPS) tc = w_tap_next(tc, ad.tkb);
+  }
   if (s + 1 < stages) {
-    w_stage_dma<true, false, CORE>(acc, f, lds + (s & 1) * W_STAGE_BYTES, lds + ((s + 1) & 1) * W_STAGE_BYTES, (s + 1) * (W_KS * 4), ad);
+    w_stage_dma<true, false, CORE, TAPS>(acc, f, lds + (s & 1) * W_STAGE_BYTES, lds + ((s + 1) & 1) * W_STAGE_BYTES, (s + 1) * (W_KS * 4), ad, tc);
     ++s;
   }
-  w_stage_dma<false, false, CORE>(acc, f, lds + (s & 1) * W_STAGE_BYTES, lds, 0, ad);
+  w_stage_dma<false, false, CORE, TAPS>(acc, f, lds + (s & 1) * W_STAGE_BYTES, lds, 0, ad);
   __syncthreads();          // every wave has read its last fragments: the LDS is the caller's again
 }
 
@@ -960,10 +1025,20 @@ __device__ __forceinline__ float gemm_h2_finish(float acc, float inv, float b, c
   return relu ? fmaxf(v, 0.f) : v;
 }
 
+// max |out| of a launch for the NEXT layer's packing (odx_split_f16_premax scales by it): every lane keeps the largest
+// magnitude it stored, a wave adds ONE atomic — the absmax pass over the activation (a read of the whole matrix per layer)
+// is not made.  amax: the IEEE bits of a non-negative float, 0 on entry.
+__device__ __forceinline__ void gemm_h2_publish_max(unsigned int mx, unsigned int* __restrict__ amax) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned int)__shfl_xor((int)mx, off));
+  if ((threadIdx.x & 63) == 0 && mx) atomicMax(amax, mx);
+}
+
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_h2s16_kernel(
     const uint32_t* __restrict__ PA, int64_t ldpa, const float* __restrict__ metaa, int64_t m, const uint32_t* __restrict__ PB,
     int64_t ldpb, const float* __restrict__ metab, int64_t n, int ktiles, const float* __restrict__ bias,
-    const float* __restrict__ res, int64_t ldr, int relu, float* __restrict__ out, int64_t ldo, int gr) {
+    const float* __restrict__ res, int64_t ldr, int relu, float* __restrict__ out, int64_t ldo, int gr,
+    unsigned int* __restrict__ amax) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int64_t GR = gr;
   const int64_t tiles_n = (n + GEMM_BN - 1) / GEMM_BN;
@@ -977,6 +1052,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_h2s16_kernel(
   const float inv = 1.f / (metaa[0] * metab[0]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
+  unsigned int mx = 0;
 #pragma unroll
   for (int tn = 0; tn < 4; ++tn) {
     const int64_t col = j0 + wc * 64 + tn * 16 + (lane & 15);
@@ -990,7 +1066,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_h2s16_kernel(
     for (int tm = 0; tm < 4; ++tm) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if (rb + tm * 16 + q < m) *po = gemm_h2_finish(acc[tm][tn][q], inv, b, pr, relu);
+        if (rb + tm * 16 + q < m) {
+          const float v = gemm_h2_finish(acc[tm][tn][q], inv, b, pr, relu);
+          *po = v;
+          mx = max(mx, __float_as_uint(v) & 0x7fffffffu);
+        }
         po += ldo;
         if (pr != nullptr) pr += ldr;
       }
@@ -998,13 +1078,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_h2s16_kernel(
       if (pr != nullptr) pr += 12 * ldr;
     }
   }
+  if (amax != nullptr) gemm_h2_publish_max(mx, amax);
 }
 
-template <int STG>
+template <int STG, bool TAPS = false>
 __global__ __launch_bounds__(W_THREADS, 1) void gemm_h2w256_kernel(
     const uint32_t* __restrict__ PA, int64_t ldpa, const float* __restrict__ metaa, int64_t m, const uint32_t* __restrict__ PB,
     int64_t ldpb, const float* __restrict__ metab, int64_t n, int stages, const float* __restrict__ bias,
-    const float* __restrict__ res, int64_t ldr, int relu, float* __restrict__ out, int64_t ldo, int gr) {
+    const float* __restrict__ res, int64_t ldr, int relu, float* __restrict__ out, int64_t ldo, int gr,
+    unsigned int* __restrict__ amax, int tapH, int tapW, int tapC) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int64_t GR = gr;
   const int64_t tiles_n = (n + W_BN - 1) / W_BN;
@@ -1016,48 +1098,56 @@ __global__ __launch_bounds__(W_THREADS, 1) void gemm_h2w256_kernel(
   w_zero(acc);
   // B rows in the permuted order of the K_nM builds: a lane holds four ADJACENT output columns 64 wc + 4 (lane & 15) + tn
   // of each of its rows, and stores them (loads bias / residual) 16 bytes at a time when the matrices allow it
-  if (STG == STG_DMA) w_mainloop_dma<true>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds);
+  if (STG == STG_DMA) w_mainloop_dma<true, CORE_H2, TAPS>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds, tapH, tapW, tapC);
   else w_mainloop<true>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds);
   const float inv = 1.f / (metaa[0] * metab[0]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   const int64_t col = j0 + wc * 64 + 4 * (lane & 15);
   const int64_t rb = i0 + wr * 128 + 4 * (lane >> 4);
-  if (col >= n) return;
-  const bool vec = col + 4 <= n && ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0 &&
-                   (res == nullptr || (ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(res) & 15u) == 0));
-  float b[4];
+  unsigned int mx = 0;
+  if (col < n) {
+    const bool vec = col + 4 <= n && ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0 &&
+                     (res == nullptr || (ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(res) & 15u) == 0));
+    float b[4];
 #pragma unroll
-  for (int tn = 0; tn < 4; ++tn) b[tn] = (bias != nullptr && col + tn < n) ? bias[col + tn] : 0.f;
-  float* po = out + rb * ldo + col;
-  const float* pr = res != nullptr ? res + rb * ldr + col : nullptr;
+    for (int tn = 0; tn < 4; ++tn) b[tn] = (bias != nullptr && col + tn < n) ? bias[col + tn] : 0.f;
+    float* po = out + rb * ldo + col;
+    const float* pr = res != nullptr ? res + rb * ldr + col : nullptr;
 #pragma unroll
-  for (int tm = 0; tm < 8; ++tm) {
+    for (int tm = 0; tm < 8; ++tm) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (rb + tm * 16 + q < m) {
-        if (vec) {
-          f32x4 v;
-          f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
-          if (pr != nullptr) r4 = *reinterpret_cast<const f32x4*>(pr);
+      for (int q = 0; q < 4; ++q) {
+        if (rb + tm * 16 + q < m) {
+          if (vec) {
+            f32x4 v;
+            f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
+            if (pr != nullptr) r4 = *reinterpret_cast<const f32x4*>(pr);
 #pragma unroll
-          for (int tn = 0; tn < 4; ++tn) {
-            v[tn] = fmaf(acc[tm][tn][q], inv, b[tn]) + r4[tn];
-            if (relu) v[tn] = fmaxf(v[tn], 0.f);
+            for (int tn = 0; tn < 4; ++tn) {
+              v[tn] = fmaf(acc[tm][tn][q], inv, b[tn]) + r4[tn];
+              if (relu) v[tn] = fmaxf(v[tn], 0.f);
+              mx = max(mx, __float_as_uint(v[tn]) & 0x7fffffffu);
+            }
+            *reinterpret_cast<f32x4*>(po) = v;
+          } else {
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+              if (col + tn < n) {
+                const float v = gemm_h2_finish(acc[tm][tn][q], inv, b[tn], pr != nullptr ? pr + tn : nullptr, relu);
+                po[tn] = v;
+                mx = max(mx, __float_as_uint(v) & 0x7fffffffu);
+              }
           }
-          *reinterpret_cast<f32x4*>(po) = v;
-        } else {
-#pragma unroll
-          for (int tn = 0; tn < 4; ++tn)
-            if (col + tn < n) po[tn] = gemm_h2_finish(acc[tm][tn][q], inv, b[tn], pr != nullptr ? pr + tn : nullptr, relu);
         }
+        po += ldo;
+        if (pr != nullptr) pr += ldr;
       }
-      po += ldo;
-      if (pr != nullptr) pr += ldr;
+      po += 12 * ldo;
+      if (pr != nullptr) pr += 12 * ldr;
     }
-    po += 12 * ldo;
-    if (pr != nullptr) pr += 12 * ldr;
   }
+  if (amax != nullptr) gemm_h2_publish_max(mx, amax);
 }
 
 // ---------------------------------------------------------------- 16-bit operands (bf16 / f16), one term
@@ -1625,18 +1715,13 @@ extern "C" int odx_split_f16(const float* X, int64_t ldx, int64_t n, int D, void
   }
   ODX_REQUIRE(X && P && D > 0 && ldx >= D && ldx % 4 == 0 && aligned16(X), "odx_split_f16: X must be 16-byte aligned with ldx %% 4 == 0 and ldx >= D");
   ODX_REQUIRE(ldp >= round_up(D, H2_KT) && ldp % 4 == 0 && aligned16(P), "odx_split_f16: P must be 16-byte aligned, ldp %% 4 == 0, ldp >= roundup(D, 64)");
-  ODX_REQUIRE(n < 65536ll * 32768, "odx_split_f16: too many rows");
   const unsigned blocks = (unsigned)(ceil_div(n, 4) > 1024 ? 1024 : ceil_div(n, 4));
   hipLaunchKernelGGL(absmax_f32_kernel, dim3(blocks), dim3(256), 0, s, X, ldx, n, D, reinterpret_cast<unsigned int*>(meta + 1));
   ODX_CHECK_LAUNCH("odx_split_f16(absmax)");
   const int groups = (int)ceil_div(D, H2_KT) * 8;
-  // rows ride on grid.y (<= 65535 per launch)
-  for (int64_t r0 = 0; r0 < n; r0 += 65535) {
-    const int64_t nr = n - r0 < 65535 ? n - r0 : 65535;
-    hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)ceil_div(groups, 256), (unsigned)nr), dim3(256), 0, s, X + r0 * ldx,
-                       ldx, nr, D, (uint32_t*)P + r0 * ldp, ldp, meta);
-    ODX_CHECK_LAUNCH("odx_split_f16");
-  }
+  ODX_REQUIRE(ceil_div(n * groups, 256) < (1ll << 31), "odx_split_f16: too many rows");
+  hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)ceil_div(n * groups, 256)), dim3(256), 0, s, X, ldx, n, D, (uint32_t*)P, ldp, meta);
+  ODX_CHECK_LAUNCH("odx_split_f16");
   return ODX_OK;
 }
 
@@ -1653,14 +1738,10 @@ extern "C" int odx_split_f16_premax(const float* X, int64_t ldx, int64_t n, int 
   }
   ODX_REQUIRE(X && P && D > 0 && ldx >= D && ldx % 4 == 0 && aligned16(X), "odx_split_f16_premax: X must be 16-byte aligned with ldx %% 4 == 0 and ldx >= D");
   ODX_REQUIRE(ldp >= round_up(D, H2_KT) && ldp % 4 == 0 && aligned16(P), "odx_split_f16_premax: P must be 16-byte aligned, ldp %% 4 == 0, ldp >= roundup(D, 64)");
-  ODX_REQUIRE(n < 65536ll * 32768, "odx_split_f16_premax: too many rows");
   const int groups = (int)ceil_div(D, H2_KT) * 8;
-  for (int64_t r0 = 0; r0 < n; r0 += 65535) {
-    const int64_t nr = n - r0 < 65535 ? n - r0 : 65535;
-    hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)ceil_div(groups, 256), (unsigned)nr), dim3(256), 0, s, X + r0 * ldx,
-                       ldx, nr, D, (uint32_t*)P + r0 * ldp, ldp, meta);
-    ODX_CHECK_LAUNCH("odx_split_f16_premax");
-  }
+  ODX_REQUIRE(ceil_div(n * groups, 256) < (1ll << 31), "odx_split_f16_premax: too many rows");
+  hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)ceil_div(n * groups, 256)), dim3(256), 0, s, X, ldx, n, D, (uint32_t*)P, ldp, meta);
+  ODX_CHECK_LAUNCH("odx_split_f16_premax");
   return ODX_OK;
 }
 
@@ -1719,34 +1800,44 @@ static int launch_knm_w256(const void* PX, int64_t ldpx, const float* metax, con
   return ODX_OK;
 }
 
-extern "C" int odx_split_f16_taps3x3(const float* Y, int64_t ldy, int64_t R, int H, int W, int C, void* P, int64_t ldp,
-                                     float* meta, odx_stream_t stream) {
+static int split_taps3x3_launch(const float* Y, int64_t ldy, int64_t R, int H, int W, int C, void* P, int64_t ldp, float* meta,
+                                bool premax, odx_stream_t stream, const char* who) {
   ODX_REQUIRE(meta, "odx_split_f16_taps3x3: meta is null");
   hipStream_t s = as_stream(stream);
-  ODX_CHECK_HIP(hipMemsetAsync(meta, 0, 2 * sizeof(float), s));
+  if (!premax) ODX_CHECK_HIP(hipMemsetAsync(meta, 0, 2 * sizeof(float), s));
   const int64_t n = R * H * W;
   if (n <= 0) return ODX_OK;
   ODX_REQUIRE(Y && P && H > 0 && W > 0 && C > 0 && C % 8 == 0 && ldy >= C && ldy % 4 == 0 && aligned16(Y),
               "odx_split_f16_taps3x3: Y must be 16-byte aligned with ldy %% 4 == 0, ldy >= C, C %% 8 == 0");
   const int D = 9 * C;
   ODX_REQUIRE(ldp >= round_up(D, H2_KT) && ldp % 4 == 0 && aligned16(P), "odx_split_f16_taps3x3: P must be 16-byte aligned, ldp %% 4 == 0, ldp >= roundup(9 C, 64)");
-  ODX_REQUIRE(n < 65536ll * 32768, "odx_split_f16_taps3x3: too many rows");
-  const unsigned blocks = (unsigned)(ceil_div(n, 4) > 1024 ? 1024 : ceil_div(n, 4));
-  hipLaunchKernelGGL(absmax_f32_kernel, dim3(blocks), dim3(256), 0, s, Y, ldy, n, C, reinterpret_cast<unsigned int*>(meta + 1));
-  ODX_CHECK_LAUNCH("odx_split_f16_taps3x3(absmax)");
   const int groups = (int)ceil_div(D, H2_KT) * 8;
-  for (int64_t r0 = 0; r0 < n; r0 += 65535) {            // rows ride on grid.y (<= 65535 per launch); the kernel takes
-    const int64_t nr = n - r0 < 65535 ? n - r0 : 65535;  // (h, w) from the global row index r0 + blockIdx.y
-    hipLaunchKernelGGL(split_f16_taps3x3_kernel, dim3((unsigned)ceil_div(groups, 256), (unsigned)nr), dim3(256), 0, s,
-                       Y, ldy, H, W, C, (uint32_t*)P, ldp, meta, r0);
-    ODX_CHECK_LAUNCH("odx_split_f16_taps3x3");
+  ODX_REQUIRE(ceil_div(n * groups, 256) < (1ll << 31), "odx_split_f16_taps3x3: too many rows");
+  if (!premax) {
+    const unsigned blocks = (unsigned)(ceil_div(n, 4) > 1024 ? 1024 : ceil_div(n, 4));
+    hipLaunchKernelGGL(absmax_f32_kernel, dim3(blocks), dim3(256), 0, s, Y, ldy, n, C, reinterpret_cast<unsigned int*>(meta + 1));
+    ODX_CHECK_LAUNCH("odx_split_f16_taps3x3(absmax)");
   }
+  hipLaunchKernelGGL(split_f16_taps3x3_kernel, dim3((unsigned)ceil_div(n * groups, 256)), dim3(256), 0, s, Y, ldy, H, W, C,
+                     (uint32_t*)P, ldp, meta, n);
+  ODX_CHECK_LAUNCH(who);
   return ODX_OK;
 }
 
-extern "C" int odx_gemm_h2_f32(const void* PA, int64_t ldpa, const float* metaa, int64_t m, const void* PB, int64_t ldpb,
-                               const float* metab, int64_t n, int K, const float* bias, const float* residual, int64_t ldr,
-                               int relu, float* out, int64_t ldo, odx_stream_t stream) {
+extern "C" int odx_split_f16_taps3x3(const float* Y, int64_t ldy, int64_t R, int H, int W, int C, void* P, int64_t ldp,
+                                     float* meta, odx_stream_t stream) {
+  return split_taps3x3_launch(Y, ldy, R, H, W, C, P, ldp, meta, false, stream, "odx_split_f16_taps3x3");
+}
+
+// The same with max |Y| already in meta[1] (odx_gemm_h2_max_f32 left it there): no maximum pass.
+extern "C" int odx_split_f16_taps3x3_premax(const float* Y, int64_t ldy, int64_t R, int H, int W, int C, void* P, int64_t ldp,
+                                            float* meta, odx_stream_t stream) {
+  return split_taps3x3_launch(Y, ldy, R, H, W, C, P, ldp, meta, true, stream, "odx_split_f16_taps3x3_premax");
+}
+
+static int gemm_h2_launch(const void* PA, int64_t ldpa, const float* metaa, int64_t m, const void* PB, int64_t ldpb,
+                          const float* metab, int64_t n, int K, const float* bias, const float* residual, int64_t ldr,
+                          int relu, float* out, int64_t ldo, float* out_meta, odx_stream_t stream) {
   if (m <= 0 || n <= 0) return ODX_OK;
   ODX_REQUIRE(PA && PB && metaa && metab && out && K > 0, "odx_gemm_h2_f32: bad argument");
   const int64_t dp = round_up(K, H2_KT);
@@ -1755,20 +1846,22 @@ extern "C" int odx_gemm_h2_f32(const void* PA, int64_t ldpa, const float* metaa,
   ODX_REQUIRE(ldo >= n && (residual == nullptr || ldr >= n), "odx_gemm_h2_f32: ldo / ldr < n");
   ODX_REQUIRE(ldpa < (1 << 24) && ldpb < (1 << 24), "odx_gemm_h2_f32: leading dimensions must stay below 2^24 (32-bit tile offsets)");
   const int gr = 8;
+  unsigned int* amax = out_meta ? reinterpret_cast<unsigned int*>(out_meta + 1) : nullptr;
   const int64_t t256 = ceil_div(m, W_BM) * ceil_div(n, W_BN);
-  if (t256 >= 256) {           // the 256 x 256 core once it fills the chip (one workgroup per CU), else 128 x 128 tiles
+  // (a product of at most 128 columns leaves at least half of a 256-wide tile idle: the 128 x 128 core takes it)
+  if (t256 >= 256 && n > GEMM_BN) {           // the 256 x 256 core once it fills the chip (one workgroup per CU), else 128 x 128 tiles
     const int64_t wt = round_up(ceil_div(m, W_BM), gr) * ceil_div(n, W_BN);
     ODX_REQUIRE(wt < (1ll << 31), "odx_gemm_h2_f32: grid too large");
     if (w_staging() == STG_DMA) {
       ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2w256_kernel<STG_DMA>), W_LDS_BYTES));
       hipLaunchKernelGGL(gemm_h2w256_kernel<STG_DMA>, dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
                          (const uint32_t*)PA, ldpa, metaa, m, (const uint32_t*)PB, ldpb, metab, n, (int)(dp / W_KS), bias, residual,
-                         ldr, relu, out, ldo, gr);
+                         ldr, relu, out, ldo, gr, amax, 0, 0, 0);
     } else {
       ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2w256_kernel<STG_REG>), W_LDS_BYTES));
       hipLaunchKernelGGL(gemm_h2w256_kernel<STG_REG>, dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
                          (const uint32_t*)PA, ldpa, metaa, m, (const uint32_t*)PB, ldpb, metab, n, (int)(dp / W_KS), bias, residual,
-                         ldr, relu, out, ldo, gr);
+                         ldr, relu, out, ldo, gr, amax, 0, 0, 0);
     }
     ODX_CHECK_LAUNCH("odx_gemm_h2_f32(w256)");
     return ODX_OK;
@@ -1778,8 +1871,62 @@ extern "C" int odx_gemm_h2_f32(const void* PA, int64_t ldpa, const float* metaa,
   ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2s16_kernel)));
   hipLaunchKernelGGL(gemm_h2s16_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), S16_LDS_BYTES, as_stream(stream),
                      (const uint32_t*)PA, ldpa, metaa, m, (const uint32_t*)PB, ldpb, metab, n, (int)(dp / H2_KT), bias, residual,
-                     ldr, relu, out, ldo, gr);
+                     ldr, relu, out, ldo, gr, amax);
   ODX_CHECK_LAUNCH("odx_gemm_h2_f32");
+  return ODX_OK;
+}
+
+extern "C" int odx_gemm_h2_f32(const void* PA, int64_t ldpa, const float* metaa, int64_t m, const void* PB, int64_t ldpb,
+                               const float* metab, int64_t n, int K, const float* bias, const float* residual, int64_t ldr,
+                               int relu, float* out, int64_t ldo, odx_stream_t stream) {
+  return gemm_h2_launch(PA, ldpa, metaa, m, PB, ldpb, metab, n, K, bias, residual, ldr, relu, out, ldo, nullptr, stream);
+}
+
+// odx_gemm_h2_f32 that also leaves max |out| in out_meta[1] (IEEE bits; out_meta[1] must be 0 on entry, out_meta[0] is not
+// touched): the meta words odx_split_f16_premax / odx_split_f16_taps3x3_premax pack `out` with, so a chain of layers makes no
+// maximum pass over its activations.
+extern "C" int odx_gemm_h2_max_f32(const void* PA, int64_t ldpa, const float* metaa, int64_t m, const void* PB, int64_t ldpb,
+                                   const float* metab, int64_t n, int K, const float* bias, const float* residual, int64_t ldr,
+                                   int relu, float* out, int64_t ldo, float* out_meta, odx_stream_t stream) {
+  ODX_REQUIRE(out_meta, "odx_gemm_h2_max_f32: out_meta is null");
+  return gemm_h2_launch(PA, ldpa, metaa, m, PB, ldpb, metab, n, K, bias, residual, ldr, relu, out, ldo, out_meta, stream);
+}
+
+// 1 when odx_gemm_h2_taps_f32 serves this layer: the 256 x 256 LDS-DMA core (it fills the chip: >= 256 tiles, more than 128
+// output columns), whole 32-channel stages per tap, 32-bit byte offsets over the packed rows.
+extern "C" int odx_gemm_h2_taps_supported(int64_t m, int64_t n, int C, int64_t ldpy) {
+  if (m <= 0 || n <= GEMM_BN || C <= 0 || C % W_KS != 0) return 0;
+  if (w_staging() != STG_DMA || ceil_div(m, W_BM) * ceil_div(n, W_BN) < 256) return 0;
+  return (m + 1) * ldpy * 4 < (1ll << 31) ? 1 : 0;
+}
+
+// out (R H W x n) = act(taps3x3(Y) B' + bias + residual): odx_gemm_h2_max_f32 whose A operand is the 3 x 3 neighbourhood matrix of
+// the packed NHWC rows PY (R H W rows of C channels in odx_split_f16's form, row stride ldpy 4-byte units, metay) gathered
+// INSIDE the product's operand loads — odx_split_f16_taps3x3's matrix is never written.  PY must be followed by one all-zero
+// row (row R H W: what a position outside the map reads).  B (n x 9 C, tap after tap: K index (ky kx c)) packed as for
+// odx_gemm_h2_f32.  out_meta may be NULL.  Only where odx_gemm_h2_taps_supported says so.
+extern "C" int odx_gemm_h2_taps_f32(const void* PY, int64_t ldpy, const float* metay, int64_t R, int H, int W, int C,
+                                    const void* PB, int64_t ldpb, const float* metab, int64_t n, const float* bias,
+                                    const float* residual, int64_t ldr, int relu, float* out, int64_t ldo, float* out_meta,
+                                    odx_stream_t stream) {
+  const int64_t m = R * H * W;
+  if (m <= 0 || n <= 0) return ODX_OK;
+  ODX_REQUIRE(PY && PB && metay && metab && out && H > 0 && W > 0, "odx_gemm_h2_taps_f32: bad argument");
+  ODX_REQUIRE(odx_gemm_h2_taps_supported(m, n, C, ldpy), "odx_gemm_h2_taps_f32: layer not served (odx_gemm_h2_taps_supported)");
+  const int64_t K = 9 * (int64_t)C;
+  ODX_REQUIRE(ldpy % 4 == 0 && ldpb % 4 == 0 && ldpy >= C && ldpb >= round_up(K, H2_KT) && aligned16(PY) && aligned16(PB),
+              "odx_gemm_h2_taps_f32: packed operands must be 16-byte aligned with ld %% 4 == 0, ldpy >= C, ldpb >= roundup(9 C, 64)");
+  ODX_REQUIRE(ldo >= n && (residual == nullptr || ldr >= n), "odx_gemm_h2_taps_f32: ldo / ldr < n");
+  ODX_REQUIRE(ldpb < (1 << 24), "odx_gemm_h2_taps_f32: leading dimensions must stay below 2^24 (32-bit tile offsets)");
+  const int gr = 8;
+  const int64_t wt = round_up(ceil_div(m, W_BM), gr) * ceil_div(n, W_BN);
+  ODX_REQUIRE(wt < (1ll << 31), "odx_gemm_h2_taps_f32: grid too large");
+  unsigned int* amax = out_meta ? reinterpret_cast<unsigned int*>(out_meta + 1) : nullptr;
+  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2w256_kernel<STG_DMA, true>), W_LDS_BYTES));
+  hipLaunchKernelGGL((gemm_h2w256_kernel<STG_DMA, true>), dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
+                     (const uint32_t*)PY, ldpy, metay, m, (const uint32_t*)PB, ldpb, metab, n, (int)(K / W_KS), bias, residual, ldr,
+                     relu, out, ldo, gr, amax, H, W, C);
+  ODX_CHECK_LAUNCH("odx_gemm_h2_taps_f32");
   return ODX_OK;
 }
 

@@ -13,6 +13,7 @@
 namespace odx {
 
 constexpr int ODX_MAX_FPN_LEVELS = 4;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------- RoIAlign forward
 // feat (N, C, H, W) f32, rois (R, 5) = (batch index, x1, y1, x2, y2), out (R, C, PH, PW).
@@ -20,6 +21,12 @@ constexpr int ODX_MAX_FPN_LEVELS = 4;
 // PH x PW grid (PH * PW <= 256); the sample positions and bilinear weights of a bin are the same
 // for every channel, so they are formed once per sample and reused across the chunk's channels.
 constexpr int ROI_CCH = 16;
+
+// One sample's bilinear value with the fusing of multiplies into adds written out (what the compiler chose for the sum
+// w1 p1 + w2 p2 + w3 p3 + w4 p4 differed between the kernels below; stated once, every layout of the map gives the same bits).
+__device__ __forceinline__ float roi_bilinear(float w1, float p1, float w2, float p2, float w3, float p3, float w4, float p4) {
+  return fmaf(w4, p4, fmaf(w3, p3, fmaf(w2, p2, w1 * p1)));
+}
 
 // step > 0 ("rows" form): only the bins (ph, pw) with ph % step == 0 and pw % step == 0 are formed — the positions a
 // stride-`step` 1 x 1 convolution reads, a quarter of the 14 x 14 grid for the conv5 head — and written as rows of an
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(const float* __restr
         for (int k = 0; k < ROI_CCH; ++k) {
           if (k < nch) {
             const float* p = base + (int64_t)k * H * W;
-            acc[k] += w1 * p[i1] + w2 * p[i2] + w3 * p[i3] + w4 * p[i4];
+            acc[k] += roi_bilinear(w1, p[i1], w2, p[i2], w3, p[i3], w4, p[i4]);
           }
         }
       }
@@ -88,6 +95,57 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(const float* __restr
 #pragma unroll
   for (int k = 0; k < ROI_CCH; ++k)
     if (k < nch) out[(((int64_t)r * C + c0 + k) * PH + ph) * PW + pw] = acc[k] / count;
+}
+
+// The rows form of RoIAlign over an NHWC map: feat is the (N * H * W, C) row matrix the trunk's GEMMs write (row stride ldf),
+// out the (R * OH * OW, C) row matrix the head's GEMMs read.  One workgroup per (RoI, bin the head reads); a thread owns four
+// adjacent channels, so every sample is four 16-byte-per-lane reads of contiguous rows (the NCHW kernel above strides by
+// H * W between channels) and the output row is written 16 bytes per lane.  Same sample positions, weights and order of
+// additions per channel as roi_align_fwd_kernel.
+__global__ __launch_bounds__(256) void roi_align_rows_nhwc_kernel(const float* __restrict__ feat, int64_t ldf, int N, int C, int H, int W,
+                                                                  const float* __restrict__ rois, float scale, int PH, int PW,
+                                                                  int sampling_ratio, int step, float* __restrict__ out) {
+  const int r = blockIdx.x;
+  const int OW = (PW + step - 1) / step;
+  const int ph = ((int)blockIdx.y / OW) * step, pw = ((int)blockIdx.y % OW) * step;
+  const float* roi = rois + (int64_t)r * 5;
+  const int b = (int)roi[0];
+  const float x1 = roi[1] * scale, y1 = roi[2] * scale, x2 = roi[3] * scale, y2 = roi[4] * scale;
+  const float rw = fmaxf(x2 - x1, 1.f), rh = fmaxf(y2 - y1, 1.f);
+  const float bw = rw / (float)PW, bh = rh / (float)PH;
+  const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)PH);
+  const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)PW);
+  const float count = (float)(gh * gw);
+  const float* base = feat + (int64_t)b * H * W * ldf;
+  float* row = out + ((int64_t)r * gridDim.y + blockIdx.y) * C;
+  for (int c = threadIdx.x * 4; c < C; c += 1024) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (b >= 0 && b < N) {
+      for (int iy = 0; iy < gh; ++iy) {
+        float y = y1 + ph * bh + (iy + 0.5f) * bh / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+          float x = x1 + pw * bw + (ix + 0.5f) * bw / (float)gw;
+          if (y < -1.f || y > (float)H || x < -1.f || x > (float)W) continue;
+          float yy = fmaxf(y, 0.f), xx = fmaxf(x, 0.f);
+          int yl = (int)yy, xl = (int)xx, yh, xh;
+          if (yl >= H - 1) { yh = yl = H - 1; yy = (float)yl; } else { yh = yl + 1; }
+          if (xl >= W - 1) { xh = xl = W - 1; xx = (float)xl; } else { xh = xl + 1; }
+          const float ly = yy - yl, lx = xx - xl, hy = 1.f - ly, hx = 1.f - lx;
+          const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+          const f32x4 p1 = *reinterpret_cast<const f32x4*>(base + (int64_t)(yl * W + xl) * ldf + c);
+          const f32x4 p2 = *reinterpret_cast<const f32x4*>(base + (int64_t)(yl * W + xh) * ldf + c);
+          const f32x4 p3 = *reinterpret_cast<const f32x4*>(base + (int64_t)(yh * W + xl) * ldf + c);
+          const f32x4 p4 = *reinterpret_cast<const f32x4*>(base + (int64_t)(yh * W + xh) * ldf + c);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[k] += roi_bilinear(w1, p1[k], w2, p2[k], w3, p3[k], w4, p4[k]);
+        }
+      }
+    }
+    f32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = acc[k] / count;
+    *reinterpret_cast<f32x4*>(row + c) = v;
+  }
 }
 
 // ---------------------------------------------------------------- multi-level RoIAlign (FPN Pooler)
@@ -159,7 +217,7 @@ __global__ __launch_bounds__(256) void roi_align_fpn_kernel(FpnLevels L, int N, 
         for (int k = 0; k < ROI_CCH; ++k) {
           if (k < nch) {
             const float* p = base + (int64_t)k * H * W;
-            acc[k] += w1 * p[i1] + w2 * p[i2] + w3 * p[i3] + w4 * p[i4];
+            acc[k] += roi_bilinear(w1, p[i1], w2, p[i2], w3, p[i3], w4, p[i4]);
           }
         }
       }
@@ -534,6 +592,25 @@ extern "C" int odx_roi_align_rows_f32(const float* feat, int N, int C, int H, in
   hipLaunchKernelGGL(roi_align_fwd_kernel, grid, dim3(256), 0, as_stream(stream), feat, N, C, H, W, rois, R,
                      spatial_scale, PH, PW, sampling_ratio, out_rows, step);
   ODX_CHECK_LAUNCH("odx_roi_align_rows_f32");
+  return ODX_OK;
+}
+
+// The same bins from an NHWC map handed over as its row matrix (N * H * W rows of C channels, row stride ldf floats) — what the
+// trunk run as row GEMMs writes: no NCHW copy of the map between the two.  C % 4 == 0, ldf % 4 == 0, 16-byte aligned.
+extern "C" int odx_roi_align_rows_nhwc_f32(const float* feat_rows, int64_t ldf, int N, int C, int H, int W, const float* rois, int R,
+                                           float spatial_scale, int PH, int PW, int sampling_ratio, int step, float* out_rows,
+                                           odx_stream_t stream) {
+  if (R <= 0 || C <= 0) return ODX_OK;
+  ODX_REQUIRE(feat_rows && rois && out_rows && N > 0 && H > 0 && W > 0 && step > 0, "odx_roi_align_rows_nhwc_f32: bad argument");
+  ODX_REQUIRE(PH > 0 && PW > 0 && PH * PW <= 65535, "odx_roi_align_rows_nhwc_f32: PH * PW must be in 1..65535");
+  ODX_REQUIRE(C % 4 == 0 && ldf % 4 == 0 && ldf >= C && (reinterpret_cast<uintptr_t>(feat_rows) & 15u) == 0 &&
+              (reinterpret_cast<uintptr_t>(out_rows) & 15u) == 0, "odx_roi_align_rows_nhwc_f32: C %% 4, ldf %% 4 == 0 and 16-byte aligned rows expected");
+  ODX_REQUIRE((int64_t)H * W < (1ll << 31), "odx_roi_align_rows_nhwc_f32: map too large");
+  const int OH = (PH + step - 1) / step, OW = (PW + step - 1) / step;
+  dim3 grid((unsigned)R, (unsigned)(OH * OW));
+  hipLaunchKernelGGL(roi_align_rows_nhwc_kernel, grid, dim3(256), 0, as_stream(stream), feat_rows, ldf, N, C, H, W, rois,
+                     spatial_scale, PH, PW, sampling_ratio, step, out_rows);
+  ODX_CHECK_LAUNCH("odx_roi_align_rows_nhwc_f32");
   return ODX_OK;
 }
 

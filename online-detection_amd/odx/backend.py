@@ -94,6 +94,7 @@ class HipBackend:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._ws = {}
         self._meta_pools = {}
+        self._capture_meta_pool = None
         # "h2": X Z' of the Gaussian kernels on the f16 matrix cores via the two-term split (f32 accuracy);
         # "f32": the all-f32 MFMA chain.  Both are HIP paths of libodx; there is no other.
         self.gauss = os.environ.get("ODX_GAUSS", "h2")
@@ -204,7 +205,14 @@ class HipBackend:
         a fill launch per matrix otherwise (a Minibootstrap round: ~250 of them).  A slot is handed out once; the slices
         keep their pool alive."""
         if torch.cuda.is_current_stream_capturing():          # (see _workspace: memory a captured graph refers to is the graph's own)
-            return torch.zeros(2, dtype=torch.float32, device=self.device)
+            # one zero fill per 256 matrices of the capture (a trunk run as row GEMMs asks for ~60 slots per forward); the pool
+            # is the graph's own memory and its fill a node of that graph: extract.GraphedCall drops it around every capture
+            pool = self._capture_meta_pool
+            if pool is None or pool[1] + 2 > pool[0].numel():
+                pool = self._capture_meta_pool = [torch.zeros(1024, dtype=torch.float32, device=self.device), 0]
+            at = pool[1]
+            pool[1] = at + 4
+            return pool[0][at:at + 2]
         cur = torch.cuda.current_stream(self.device)
         key = cur.cuda_stream
         pool = self._meta_pools.get(key)
@@ -213,6 +221,11 @@ class HipBackend:
         at = pool[1]
         pool[1] = at + 4                      # 16-byte slots
         return pool[0][at:at + 2]
+
+    def reset_capture_pools(self):
+        """Called by whoever captures a HIP graph, before and after the capture: pooled memory handed out during one capture
+        must not serve the next one (it belongs to the first graph, and so does the launch that zeroes it)."""
+        self._capture_meta_pool = None
 
     def rows(self, F, idx):
         """MyCenterSelector.select: gather rows (their norms, and their packed split if it exists) by index."""
@@ -237,11 +250,17 @@ class HipBackend:
                       "odx_split_f8")
         return F
 
-    def pack(self, F):
-        """Make sure F carries its packed f16 split (odx_split_f16); returns F."""
+    def pack(self, F, zero_row=False):
+        """Make sure F carries its packed f16 split (odx_split_f16); returns F.  zero_row: the packed rows are followed by
+        one all-zero row in memory (what gemm_h2_taps reads for a position outside the map)."""
         if F.P is None:
             ldp = (F.D + 63) // 64 * 64
-            F.P = torch.empty((F.n, ldp), dtype=torch.int32, device=self.device)
+            if zero_row:
+                buf = torch.empty((F.n + 1, ldp), dtype=torch.int32, device=self.device)
+                buf[F.n].zero_()
+                F.P = buf[:F.n]
+            else:
+                F.P = torch.empty((F.n, ldp), dtype=torch.int32, device=self.device)
             if F.meta is not None and F.n:            # features() already left max |x| in meta[1]
                 hip.check(self.lib.odx_split_f16_premax(_p(F.X), F.ld, F.n, F.D, _p(F.P), ldp, _p(F.meta), self._stream()),
                           "odx_split_f16_premax")
@@ -775,19 +794,42 @@ class HipBackend:
                                                      _p(lv), self._stream()), "odx_roi_align_fpn_f32")
         return (out, lv) if return_levels else out
 
-    def packed(self, X):
-        """X (rows, K) f32 as a GEMM operand of gemm_h2: its packed two-term f16 split (no row norms)."""
+    def packed(self, X, meta=None, zero_row=False):
+        """X (rows, K) f32 as a GEMM operand of gemm_h2: its packed two-term f16 split (no row norms).  meta: the two meta
+        words a producer already left for X (gemm_h2(..., with_max=True): max |X| in meta[1]) — no maximum pass then; a bound
+        on max |X| (the maximum of a matrix X's rows were cut from) serves as well."""
         X = X.to(device=self.device, dtype=torch.float32)
         if X.stride(1) != 1 or X.stride(0) % 4 != 0 or X.data_ptr() % 16 != 0:
             ld = (X.shape[1] + 3) // 4 * 4
             buf = torch.zeros((X.shape[0], ld), dtype=torch.float32, device=self.device)
             buf[:, :X.shape[1]] = X
             X = buf[:, :X.shape[1]]
-        return self.pack(Features(X, None, X.shape[1]))
+        return self.pack(Features(X, None, X.shape[1], meta=meta), zero_row=zero_row)
 
-    def packed_taps3x3(self, Y, R, H, W):
+    def conv3x3_rows(self, Y, R, H, W, B, bias=None, relu=False, meta=None, with_max=False):
+        """act(3 x 3 convolution, padding 1) of the NHWC rows Y (R H W, C) f32 with the packed weights B (n, 9 C: ky kx c) as
+        ONE product: where the library gathers the taps inside the product's operand loads (odx_gemm_h2_taps_f32: wide
+        layers on the 256 x 256 core) Y is packed once and its 9 x neighbourhood matrix never written; elsewhere that matrix
+        is written in packed form (packed_taps3x3) and multiplied (gemm_h2).  Same sums either way.  meta / with_max as for
+        `packed` / `gemm_h2`."""
+        C, n, m = Y.shape[1], B.n, R * H * W
+        ok = (Y.dtype == torch.float32 and Y.stride(1) == 1 and Y.stride(0) % 4 == 0 and Y.data_ptr() % 16 == 0 and B.D == 9 * C
+              and self.lib.odx_gemm_h2_taps_supported(m, n, C, (C + 63) // 64 * 64))
+        if not ok:
+            return self.gemm_h2(self.packed_taps3x3(Y, R, H, W, meta=meta), B, bias=bias, relu=relu, with_max=with_max)
+        Fy = self.packed(Y, meta=meta, zero_row=True)
+        out = torch.empty((m, n), dtype=torch.float32, device=self.device)
+        if bias is not None:
+            bias = bias.to(device=self.device, dtype=torch.float32).contiguous()
+        om = self._meta_slot() if with_max else None
+        hip.check(self.lib.odx_gemm_h2_taps_f32(_p(Fy.P), Fy.P.stride(0), _p(Fy.meta), R, H, W, C, _p(B.P), B.P.stride(0), _p(B.meta), n,
+                                                _p(bias), None, 0, int(bool(relu)), _p(out), n, _p(om), self._stream()), "odx_gemm_h2_taps_f32")
+        return (out, om) if with_max else out
+
+    def packed_taps3x3(self, Y, R, H, W, meta=None):
         """The packed operand of a 3 x 3 convolution (padding 1) as a GEMM over the NHWC rows Y (R * H * W, C): K = 9 C,
-        tap after tap; written in the packed form directly (odx_split_f16_taps3x3)."""
+        tap after tap; written in the packed form directly (odx_split_f16_taps3x3; with the meta words of Y's producer,
+        as for `packed`: odx_split_f16_taps3x3_premax)."""
         C = Y.shape[1]
         if C % 8 != 0 or Y.stride(1) != 1 or Y.stride(0) % 4 != 0 or Y.data_ptr() % 16 != 0 or Y.dtype != torch.float32:
             yp = torch.nn.functional.pad(Y.reshape(R, H, W, C), (0, 0, 1, 1, 1, 1))
@@ -796,20 +838,26 @@ class HipBackend:
         Fp = Features(Y, None, C)
         Fp.n, Fp.D = n, D                              # the operand the GEMM sees; X stays the (n, C) source
         Fp.P = torch.empty((n, (D + 63) // 64 * 64), dtype=torch.int32, device=self.device)
+        if meta is not None:
+            Fp.meta = meta
+            hip.check(self.lib.odx_split_f16_taps3x3_premax(_p(Y), Y.stride(0), R, H, W, C, _p(Fp.P), Fp.P.stride(0), _p(meta), self._stream()),
+                      "odx_split_f16_taps3x3_premax")
+            return Fp
         Fp.meta = torch.empty(2, dtype=torch.float32, device=self.device)
         hip.check(self.lib.odx_split_f16_taps3x3(_p(Y), Y.stride(0), R, H, W, C, _p(Fp.P), Fp.P.stride(0), _p(Fp.meta), self._stream()),
                   "odx_split_f16_taps3x3")
         return Fp
 
-    def gemm_h2(self, A, B, bias=None, residual=None, relu=False):
+    def gemm_h2(self, A, B, bias=None, residual=None, relu=False, with_max=False):
         """(m, n) f32 = act(A.X B.X' + bias + residual) for packed operands (`packed`): the f32 product at f32 accuracy on
-        the f16 matrix cores (odx_gemm_h2_f32)."""
+        the f16 matrix cores (odx_gemm_h2_f32).  with_max: returns (out, meta) — the launch leaves max |out| in meta[1]
+        (odx_gemm_h2_max_f32), the words `packed` / `packed_taps3x3` take for the next layer."""
         m, n, K = A.n, B.n, A.D
         if B.D != K:
             raise ValueError("gemm_h2: inner dimensions differ (%d, %d)" % (K, B.D))
         out = torch.empty((m, n), dtype=torch.float32, device=self.device)
         if m == 0 or n == 0:
-            return out
+            return (out, self._meta_slot()) if with_max else out
         if bias is not None:
             bias = bias.to(device=self.device, dtype=torch.float32).contiguous()
         ldr = 0
@@ -818,6 +866,12 @@ class HipBackend:
             if residual.stride(1) != 1:
                 residual = residual.contiguous()
             ldr = residual.stride(0)
+        if with_max:
+            meta = self._meta_slot()
+            hip.check(self.lib.odx_gemm_h2_max_f32(_p(A.P), A.P.stride(0), _p(A.meta), m, _p(B.P), B.P.stride(0), _p(B.meta), n, K,
+                                                   _p(bias), _p(residual), ldr, int(bool(relu)), _p(out), n, _p(meta), self._stream()),
+                      "odx_gemm_h2_max_f32")
+            return out, meta
         hip.check(self.lib.odx_gemm_h2_f32(_p(A.P), A.P.stride(0), _p(A.meta), m, _p(B.P), B.P.stride(0), _p(B.meta), n, K,
                                            _p(bias), _p(residual), ldr, int(bool(relu)), _p(out), n, self._stream()), "odx_gemm_h2_f32")
         return out
@@ -887,13 +941,19 @@ class HipBackend:
     def roi_align_rows(self, feat, rois, spatial_scale, output_size, sampling_ratio=0, step=2):
         """RoIAlign for a head that starts with a stride-`step` 1 x 1 convolution: the bins that convolution reads only,
         as an (R * OH * OW, C) row matrix (NHWC).  Returns (rows, (R, OH, OW))."""
-        feat = feat.to(device=self.device, dtype=torch.float32).contiguous()
         rois = rois.to(device=self.device, dtype=torch.float32).contiguous()
         N, C, H, W = feat.shape
         PH, PW = output_size
         R = rois.shape[0]
         OH, OW = (PH + step - 1) // step, (PW + step - 1) // step
         out = torch.empty((R * OH * OW, C), dtype=torch.float32, device=self.device)
+        feat = feat.to(device=self.device, dtype=torch.float32)
+        if (C % 4 == 0 and not feat.is_contiguous() and feat.is_contiguous(memory_format=torch.channels_last) and feat.data_ptr() % 16 == 0):
+            # the map is the NHWC row matrix of a trunk run as row GEMMs (a channels-last view): pooled straight from it
+            hip.check(self.lib.odx_roi_align_rows_nhwc_f32(_p(feat), C, N, C, H, W, _p(rois), R, float(spatial_scale), PH, PW,
+                                                           int(sampling_ratio), int(step), _p(out), self._stream()), "odx_roi_align_rows_nhwc_f32")
+            return out, (R, OH, OW)
+        feat = feat.contiguous()
         hip.check(self.lib.odx_roi_align_rows_f32(_p(feat), N, C, H, W, _p(rois), R, float(spatial_scale), PH, PW,
                                                   int(sampling_ratio), int(step), _p(out), self._stream()), "odx_roi_align_rows_f32")
         return out, (R, OH, OW)

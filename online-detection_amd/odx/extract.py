@@ -348,11 +348,13 @@ def _bottleneck_rows_b16(be, blk, x, R, H, W):
     return be.gemm_b16(y, w3, bias=b3, residual=idn, relu=True)
 
 
-def _bottleneck_rows_h2(be, blk, x, R, H, W):
+def _bottleneck_rows_h2(be, blk, x, R, H, W, x_meta=None, want_max=False):
     """The f32 form of _bottleneck_rows on the split-f16 tile cores (odx_gemm_h2_f32: f32 accuracy on the f16 matrix cores,
     243-317 TF on these shapes against 95-117 TF for the f32 MFMA GEMMs): folded weights packed once per layer, every
     activation matrix packed once (the block's input serves conv1 and the projection), bias / identity / ReLU in the
-    GEMM's epilogue."""
+    GEMM's epilogue.  Every GEMM also leaves the maximum of what it wrote (odx_gemm_h2_max_f32), which is what the next
+    layer's packing scales by: no layer reads its input a second time for that.  x_meta: those words for x, when x came out of
+    such a GEMM (or was cut from a matrix that did); want_max: return (out, meta) for the next block."""
     def wpack(key, conv, bn, taps=False):
         c = blk._folded.get((key + "/h2", torch.float32))
         if c is None:
@@ -360,18 +362,18 @@ def _bottleneck_rows_h2(be, blk, x, R, H, W):
             w = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1) if taps else w.reshape(w.shape[0], -1)     # (out, ky kx in)
             c = blk._folded[(key + "/h2", torch.float32)] = (be.packed(w.float().contiguous()), b.float().contiguous())
         return c
-    xp = be.packed(x)
+    xp = be.packed(x, meta=x_meta)
     if blk.down is None:
         idn = x
     else:
         wd, bd = wpack("down", blk.down[0], blk.down[1])
         idn = be.gemm_h2(xp, wd, bias=bd)
     w1, b1 = wpack("conv1", blk.conv1, blk.bn1)
-    y = be.gemm_h2(xp, w1, bias=b1, relu=True)
+    y, my = be.gemm_h2(xp, w1, bias=b1, relu=True, with_max=True)
     w2, b2 = wpack("conv2", blk.conv2, blk.bn2, taps=True)
-    y = be.gemm_h2(be.packed_taps3x3(y, R, H, W), w2, bias=b2, relu=True)       # the 9-tap gather exists in packed form only
+    y, my = be.conv3x3_rows(y, R, H, W, w2, bias=b2, relu=True, meta=my, with_max=True)     # (taps gathered inside the product where it can)
     w3, b3 = wpack("conv3", blk.conv3, blk.bn3)
-    return be.gemm_h2(be.packed(y), w3, bias=b3, residual=idn, relu=True)
+    return be.gemm_h2(be.packed(y, meta=my), w3, bias=b3, residual=idn, relu=True, with_max=want_max)
 
 
 def _bottleneck_rows(blk, x, R, H, W):
@@ -437,6 +439,41 @@ class ResNet50C4(_FoldedBN):
         x = F.max_pool2d(self.conv_bn_act("conv1", "bn1", x), 3, 2, 1)
         return self.layer3(self.layer2(self.layer1(x)))
 
+    def rows_form(self):
+        """True when the stages can run as row GEMMs: strides only in the 1 x 1 convolutions that open a block (STRIDE_IN_1X1,
+        the projection beside them with the same stride), 3 x 3 convolutions of stride 1 / padding 1, channels in eights."""
+        for blk in self.stages():
+            st = blk.conv1.stride[0]
+            if (blk.conv2.stride[0] != 1 or tuple(blk.conv2.padding) != (1, 1) or blk.conv3.stride[0] != 1
+                    or (blk.down is not None and blk.down[0].stride[0] != st) or (blk.down is None and st != 1)
+                    or blk.conv1.in_channels % 8 or blk.conv2.in_channels % 8 or blk.conv3.out_channels % 8):
+                return False
+        return True
+
+    def stages(self):
+        return [blk for stage in (self.layer1, self.layer2, self.layer3) for blk in stage]
+
+    def forward_rows(self, x):
+        """The trunk on this library's tile cores (f32 on the GPU): the stem (7 x 7 convolution, max pooling) by the convolution
+        library, its output turned ONCE into NHWC rows, and every bottleneck of the three stages as row GEMMs on the split-f16
+        matrix-core path (_bottleneck_rows_h2: f32 accuracy, bias / identity / ReLU in the GEMM epilogues, the 3 x 3
+        convolutions over a 9-tap gather written in packed form) — 60 GFLOP per 600 x 800 image that the library ran as f32
+        Winograd / GEMM convolutions on the vector units plus an epilogue pass per layer.  A block's stride is applied to its
+        input rows (the positions a strided 1 x 1 convolution reads).  Returns (rows (B h w, C) f32, (B, h, w)); the map as
+        the callers know it is rows.view(B, h, w, C).permute(0, 3, 1, 2) — a channels-last view, no copy."""
+        be = _backend.get_backend()
+        y = F.max_pool2d(self.conv_bn_act("conv1", "bn1", x), 3, 2, 1)
+        B, C, H, W = y.shape
+        rows, meta = y.permute(0, 2, 3, 1).reshape(B * H * W, C), None
+        for blk in self.stages():
+            st = blk.conv1.stride[0]
+            if st > 1:
+                cut = rows.view(B, H, W, -1)[:, ::st, ::st]
+                H, W = cut.shape[1], cut.shape[2]
+                rows = cut.reshape(B * H * W, -1)                   # (the maximum of the whole matrix bounds that of the cut rows)
+            rows, meta = _bottleneck_rows_h2(be, blk, rows, B, H, W, x_meta=meta, want_max=True)
+        return rows, (B, H, W)
+
 
 class Conv5Head(nn.Module):
     """ResNet stage 5 on 14 x 14 RoI crops -> 7 x 7 x 2048 (ResNet50Conv5ROIFeatureExtractor.head)."""
@@ -467,6 +504,11 @@ class Conv5Head(nn.Module):
                 for blk in self.layer4:
                     x = _bottleneck_rows_b16(be, blk, x, R, H, W)    # 16-bit activations from block to block, pad columns zero
                 return x.dense.reshape(R, H, W, -1).permute(0, 3, 1, 2)
+            if dt == torch.float32 and hasattr(be, "gemm_h2"):
+                meta = None
+                for blk in self.layer4:                              # (each block's output maximum is the next one's packing scale)
+                    rows, meta = _bottleneck_rows_h2(be, blk, rows, R, H, W, x_meta=meta, want_max=True)
+                return rows.view(R, H, W, -1).permute(0, 3, 1, 2)
         for blk in self.layer4:
             rows = _bottleneck_rows(blk, rows, R, H, W)
         return rows.view(R, H, W, -1).permute(0, 3, 1, 2)          # (R, 2048, H, W) as a view of the NHWC rows
@@ -529,8 +571,16 @@ class GraphedCall:
             gstream.wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):     # (the extractor's other thread keeps allocating)
-                static_out = self.fn(*static_in)
+            be = _backend.get_backend()
+            reset = getattr(be, "reset_capture_pools", None)          # memory pooled during a capture belongs to that graph alone
+            if reset is not None:
+                reset()
+            try:
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):     # (the extractor's other thread keeps allocating)
+                    static_out = self.fn(*static_in)
+            finally:
+                if reset is not None:
+                    reset()
         return graph, static_in, static_out, gstream
 
     def __call__(self, x, *more, key_extra=None, capture=True):
@@ -625,6 +675,8 @@ class OnlineDetectionModel(nn.Module):
         self.online_box = None          # odx.heads.OnlineBoxPredictor
         self.online_mask = None         # odx.heads.OnlineMaskPredictor
         self.mask_dim = mask_dim
+        # stride-16 positions (images x h x w) from which the f32 trunk and RPN head run as row GEMMs (_rows_path)
+        self.rows_min_positions = int(os.environ.get("ODX_ROWS_MIN_POSITIONS", 4800))
         self._trunk_graphs = GraphedCall(self._c4_eager)
         # The whole group forward from ONE HIP graph (forward_group): OPT-IN, ODX_GROUP_GRAPH=1.  What round 5 found on this
         # runtime: (i) with the proposal stage as tensor operations (a library top-k, gather, advanced indexing) the graph's second
@@ -648,12 +700,14 @@ class OnlineDetectionModel(nn.Module):
         module._trunk_graphs.clear()
         module._group_graphs.clear()
         module.__dict__.pop("_mask_pack", None)
+        module.__dict__.pop("_wpacks", None)
 
     def _apply(self, fn, *a, **kw):
         if "_trunk_graphs" in self.__dict__:
             self._trunk_graphs.clear()          # (.to / .cuda / .half: the captured graphs point at the old tensors)
             self._group_graphs.clear()
             self.__dict__.pop("_mask_pack", None)
+            self.__dict__.pop("_wpacks", None)
         return super()._apply(fn, *a, **kw)
 
     @property
@@ -665,7 +719,33 @@ class OnlineDetectionModel(nn.Module):
             return contextlib.nullcontext()
         return torch.autocast("cuda", dtype=self.compute_dtype)
 
+    def _rows_path(self, x):
+        """The f32 forward on the GPU runs as row GEMMs on this library's tile cores from the stem's output on (trunk stages,
+        RPN head; the conv5 head always did): ODX_TRUNK=conv keeps the convolution library for the trunk and the RPN head."""
+        if not (x.is_cuda and self.compute_dtype is None and x.dtype == torch.float32 and not torch.is_grad_enabled()
+                and not torch.is_autocast_enabled("cuda") and os.environ.get("ODX_TRUNK", "rows") != "conv"):
+            return False
+        # below three images of 600 x 800 the stage-3 / RPN products (1900 rows per image) leave most of the chip idle on
+        # 128 x 128 tiles and the convolution library's kernels are faster (trunk 1.37 against 2.31 ms at one image, 0.87
+        # against 0.86 ms per image at eight; the RPN head 0.33 against 0.52 ms per image at four)
+        positions = x.shape[0] * x.shape[2] * x.shape[3] if x.shape[1] != 3 else x.shape[0] * (-(-x.shape[2] // self.stride)) * (-(-x.shape[3] // self.stride))
+        if positions < self.rows_min_positions:
+            return False
+        return hasattr(_backend.get_backend(), "gemm_h2") and self.backbone.rows_form()
+
+    def _wpack(self, name, params, make):
+        """A packed GEMM operand made from weights, remade when one of them is replaced or written in place."""
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        cache = self.__dict__.setdefault("_wpacks", {})
+        hit = cache.get(name)
+        if hit is None or hit[0] != key:
+            hit = cache[name] = (key, make())
+        return hit[1]
+
     def _c4_eager(self, image):
+        if self._rows_path(image):
+            rows, (B, h, w) = self.backbone.forward_rows(image)
+            return rows.view(B, h, w, -1).permute(0, 3, 1, 2)          # (B, C, h, w) as a channels-last view of the NHWC rows
         with self._amp():
             return self.backbone(image).float()
 
@@ -693,8 +773,36 @@ class OnlineDetectionModel(nn.Module):
             getattr(self, attr).set_models(models["classifiers"], models.get("regressors"), models["stats"])
 
     def rpn_activation(self, c4):
+        cv = self.rpn_conv
+        if (self._rows_path(c4) and c4.shape[1] % 8 == 0 and tuple(cv.kernel_size) == (3, 3) and tuple(cv.stride) == (1, 1)
+                and tuple(cv.padding) == (1, 1)):
+            # RPNHead.conv (rpn.py:164-170) as ONE product over the 9-tap gather of the map's NHWC rows (a view when the trunk
+            # ran as row GEMMs), bias + ReLU in its epilogue: 36 of the forward's 96 trunk-side GFLOP at 600 x 800
+            be = _backend.get_backend()
+            B, C, h, w = c4.shape
+            rows = c4.permute(0, 2, 3, 1).reshape(B * h * w, C)
+            wp, b = self._wpack("rpn_conv", (cv.weight, cv.bias), lambda: (
+                be.packed(cv.weight.detach().float().permute(0, 2, 3, 1).reshape(cv.out_channels, -1).contiguous()),
+                cv.bias.detach().float().contiguous()))
+            t = be.conv3x3_rows(rows, B, h, w, wp, bias=b, relu=True)
+            return t.view(B, h, w, -1).permute(0, 3, 1, 2)
         with self._amp():
             return F.relu(self.rpn_conv(c4)).float()
+
+    def rpn_outputs(self, t):
+        """(objectness logits (B, A, h, w), box deltas (B, 4 A, h, w)) of the RPN's two 1 x 1 convolutions, f32 contiguous."""
+        lg, dl = self.rpn_logits, self.rpn_deltas
+        if self._rows_path(t) and tuple(lg.kernel_size) == (1, 1) and tuple(dl.kernel_size) == (1, 1):
+            be = _backend.get_backend()                 # both as ONE product over the rows (A + 4 A output columns)
+            B, C, h, w = t.shape
+            wp, b = self._wpack("rpn_out", (lg.weight, lg.bias, dl.weight, dl.bias), lambda: (
+                be.packed(torch.cat((lg.weight.detach().float().reshape(lg.out_channels, -1), dl.weight.detach().float().reshape(dl.out_channels, -1)), dim=0).contiguous()),
+                torch.cat((lg.bias.detach().float(), dl.bias.detach().float())).contiguous()))
+            o = be.gemm_h2(be.packed(t.permute(0, 2, 3, 1).reshape(B * h * w, C)), wp, bias=b).view(B, h, w, -1)
+            A = lg.out_channels
+            return o[..., :A].permute(0, 3, 1, 2).contiguous(), o[..., A:].permute(0, 3, 1, 2).contiguous()
+        with self._amp():
+            return self.rpn_logits(t).float(), self.rpn_deltas(t).float()
 
     @torch.no_grad()
     def proposals(self, c4, img_size, t=None):
@@ -704,8 +812,7 @@ class OnlineDetectionModel(nn.Module):
         if self.online_rpn is not None:
             logits, deltas = self.online_rpn(t)
         else:
-            with self._amp():
-                logits, deltas = self.rpn_logits(t).float(), self.rpn_deltas(t).float()
+            logits, deltas = self.rpn_outputs(t)
         anchors = grid_anchors(c4.shape[2], c4.shape[3], self.stride, self.cells.to(c4.device))
         return rpn_proposals(logits, deltas, anchors, img_size, self.pre_nms_top_n, self.post_nms_top_n, self.rpn_nms)
 
@@ -720,8 +827,7 @@ class OnlineDetectionModel(nn.Module):
             return [self.proposals(c4[b:b + 1], img_size, None if t is None else t[b:b + 1]) for b in range(B)]
         if t is None:
             t = self.rpn_activation(c4)
-        with self._amp():
-            logits, deltas = self.rpn_logits(t).float(), self.rpn_deltas(t).float()
+        logits, deltas = self.rpn_outputs(t)
         anchors = grid_anchors(c4.shape[2], c4.shape[3], self.stride, self.cells.to(c4.device))
         return rpn_proposals_batch(logits, deltas, anchors, img_size, self.pre_nms_top_n, self.post_nms_top_n, self.rpn_nms)
 
@@ -736,8 +842,7 @@ class OnlineDetectionModel(nn.Module):
         img_size = (images.shape[3], images.shape[2])
         c4 = self._c4_eager(images)
         t = self.rpn_activation(c4)
-        with self._amp():
-            logits, deltas = self.rpn_logits(t).float(), self.rpn_deltas(t).float()
+        logits, deltas = self.rpn_outputs(t)
         _, A, H, W = logits.shape            # (anchors: an argument — made from host constants, a copy a capture does not allow)
         if anchors.shape[0] != H * W * A:
             raise ValueError("forward_group: %d anchors for a %d x %d map of %d types" % (anchors.shape[0], H, W, A))

@@ -10,6 +10,13 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 
+# The f32 trunk / RPN head run as row GEMMs on the library's tile cores from three 600 x 800 images per call on (the
+# convolution library is faster below that: OnlineDetectionModel.rows_min_positions).  The tests' reduced models and small
+# images would never get there: they take that route at every size; the convolution route is asked for by name
+# (test_forward_gpu_equals_plain_torch_cpu[conv]).
+os.environ.setdefault("ODX_ROWS_MIN_POSITIONS", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 

@@ -700,9 +700,11 @@ def _plain_roi_align(feat, boxes, scale, P):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batch", [1, 3])
-def test_forward_gpu_equals_plain_torch_cpu(batch):
-    """batch = 3: the image sits in the middle of a batch of three of its size that goes through forward_batch — one trunk
+@pytest.mark.parametrize("batch,route", [(1, "rows"), (3, "rows"), (1, "conv"), (3, "conv")])
+def test_forward_gpu_equals_plain_torch_cpu(batch, route):
+    """route: "rows" = trunk stages and RPN head as row GEMMs on the split-f16 tile cores (ResNet50C4.forward_rows, the map
+    handed on as a channels-last view, RoIAlign from the NHWC rows: what three or more 600 x 800 images per call get), "conv" =
+    the convolution library for both (smaller calls).  batch = 3: the image sits in the middle of a batch of three of its size that goes through forward_batch — one trunk
     call, one proposal stage (rpn_proposals_batch + odx_nms_batched_first_f32), one pass of the RoI head over all three images'
     RoIs (round-4 review, item 2) — and must come out as it does alone.
     The COMPOSITION of the forward — trunk with folded batch norm, the top-k's own order feeding the early-stopping NMS
@@ -731,11 +733,13 @@ def test_forward_gpu_equals_plain_torch_cpu(batch):
     model.rpn_deltas.weight.data.normal_(0, 0.05)
     ref = copy.deepcopy(model)                                    # stays on the CPU
     model = model.cuda()
+    model.rows_min_positions = 0 if route == "rows" else 1 << 40
     img = torch.randn(1, 3, 320, 416)
     gt = torch.tensor([[30.0, 40.0, 200.0, 260.0]])
     with torch.no_grad():
         if batch == 1:
             boxes, feats, c4 = model(img.cuda(), gt)
+            assert c4.is_contiguous() == (route == "conv")          # rows: a channels-last view of the trunk's row matrix
         else:
             from odx.extract import forward_batch
             others = torch.randn(2, 3, 320, 416)

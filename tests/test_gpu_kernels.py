@@ -1247,6 +1247,59 @@ def test_packed_3x3_taps_equal_the_split_of_the_gathered_matrix(R, H, W, C):
     assert torch.equal(a.meta, b.meta) and torch.equal(a.P[:, : b.P.shape[1]], b.P)
 
 
+@pytest.mark.parametrize("m,n,K", [(300, 64, 64), (1000, 256, 576), (70000, 64, 576), (66000, 512, 128), (5, 75, 1024)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_gemm_h2_leaves_the_maximum_of_its_output_for_the_next_layers_packing(m, n, K, relu):
+    """odx_gemm_h2_max_f32 = odx_gemm_h2_f32 bit for bit, plus max |out| in meta[1] (exactly, on both tile cores and with
+    ragged edges); packing the output with those words (odx_split_f16_premax, odx_split_f16_taps3x3_premax) gives the words
+    and the scale of a packing that finds the maximum itself — what a chain of layers run as GEMMs relies on."""
+    import odx
+    be = odx.get_backend()
+    g = torch.Generator().manual_seed(m + n + K)
+    A, B = torch.randn((m, K), generator=g).cuda(), (torch.randn((n, K), generator=g) / K ** 0.5).cuda()
+    bias, res = torch.randn(n, generator=g).cuda(), torch.randn((m, n), generator=g).cuda()
+    pa, pb = be.packed(A), be.packed(B)
+    plain = be.gemm_h2(pa, pb, bias=bias, residual=res, relu=relu)
+    out, meta = be.gemm_h2(pa, pb, bias=bias, residual=res, relu=relu, with_max=True)
+    assert torch.equal(out, plain)
+    assert float(meta[1]) == float(out.abs().max())
+    a, b = be.packed(out, meta=meta), be.packed(out.clone())
+    assert torch.equal(a.meta, b.meta) and torch.equal(a.P, b.P)
+    if n % 8 == 0 and m % 20 == 0:
+        R, H, W = m // 20, 4, 5
+        out2, meta2 = be.gemm_h2(pa, pb, bias=bias, relu=relu, with_max=True)
+        a, b = be.packed_taps3x3(out2, R, H, W, meta=meta2), be.packed_taps3x3(out2.clone(), R, H, W)
+        assert torch.equal(a.meta, b.meta) and torch.equal(a.P, b.P)
+
+
+@pytest.mark.parametrize("R,H,W,C,n", [(1400, 7, 7, 64, 256), (2400, 7, 7, 512, 512), (9, 150, 200, 32, 160), (1400, 7, 7, 64, 128),
+                                       (37, 7, 7, 64, 256), (1400, 7, 7, 48, 256)])
+def test_3x3_convolution_with_the_taps_gathered_in_the_operand_loads(R, H, W, C, n):
+    """odx_gemm_h2_taps_f32 (the 3 x 3 neighbourhood gathered by the product's own LDS-DMA loads from the packed rows, a zero
+    row outside the map) = odx_split_f16_taps3x3 + odx_gemm_h2_max_f32 bit for bit, output maximum included, and both = the
+    convolution in f64 to f32 rounding; maps whose rows straddle tile boundaries (7 x 7 RoI crops, a 150 x 200 trunk map), a
+    ragged last tile; the last three shapes are ones the library does not serve that way (narrow output, too few tiles,
+    C % 32 != 0): HipBackend.conv3x3_rows takes the written-out matrix for them."""
+    import odx
+    be = odx.get_backend()
+    g = torch.Generator().manual_seed(R + C + n)
+    m = R * H * W
+    Y = torch.randn((m, C), generator=g).cuda()
+    Wt = (torch.randn((n, 9 * C), generator=g) / (9 * C) ** 0.5).cuda()
+    bias = torch.randn(n, generator=g).cuda()
+    wp = be.packed(Wt)
+    want, wmeta = be.gemm_h2(be.packed_taps3x3(Y, R, H, W), wp, bias=bias, relu=True, with_max=True)
+    served = bool(be.lib.odx_gemm_h2_taps_supported(m, n, C, (C + 63) // 64 * 64))
+    assert served == ((R, n, C) in ((1400, 256, 64), (2400, 512, 512), (9, 160, 32)))
+    got, gmeta = be.conv3x3_rows(Y, R, H, W, wp, bias=bias, relu=True, with_max=True)
+    assert torch.equal(got, want) and torch.equal(gmeta[1], wmeta[1])
+    if m * C * n < 3e10:
+        ref = torch.nn.functional.conv2d(Y.view(R, H, W, C).permute(0, 3, 1, 2).double(),
+                                         Wt.view(n, 3, 3, C).permute(0, 3, 1, 2).double(), bias.double(), padding=1).relu()
+        ref = ref.permute(0, 2, 3, 1).reshape(m, n)
+        assert float((got.double() - ref).abs().max()) < 2e-6 * float(ref.abs().max())
+
+
 def test_cu_masked_stream_and_partition_sized_pass(be):
     """The diagnostic entry points behind tools/cu_split_probe.py: a stream confined to 16 compute units runs its workgroups
     on at most 16 distinct (XCC, SE, SH, CU) places, two per XCC; a compact pass launched there with its persistent grid sized

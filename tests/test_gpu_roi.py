@@ -87,6 +87,34 @@ def test_roi_align_rows_is_the_strided_subset_of_the_grid():
         assert torch.equal(rows.view(R, OH, OW, -1).permute(0, 3, 1, 2), ref)
 
 
+def test_roi_align_rows_from_an_nhwc_map_equals_the_nchw_kernel():
+    """odx_roi_align_rows_nhwc_f32 (the map handed over as the NHWC row matrix the trunk's GEMMs write — here a channels-last
+    view, whole and sliced by image) = odx_roi_align_rows_f32 on the NCHW copy of the same map, bit for bit; channel counts
+    below / above one pass of the workgroup (1024), steps 1 / 2 / 3, an odd grid."""
+    import odx
+    be = odx.get_backend()
+    g = torch.Generator().manual_seed(4)
+    for C in (16, 1024, 1500):
+        nchw = torch.randn((3, C, 20, 27), generator=g).cuda()
+        rows = nchw.permute(0, 2, 3, 1).contiguous()                          # (N, H, W, C): the row matrix
+        nhwc = rows.permute(0, 3, 1, 2)                                       # the map as callers see it: a channels-last view
+        assert not nhwc.is_contiguous() and nhwc.is_contiguous(memory_format=torch.channels_last)
+        R = 23
+        xy = torch.rand((R, 2), generator=g) * torch.tensor([300.0, 200.0])
+        wh = 10 + torch.rand((R, 2), generator=g) * 150
+        rois = torch.cat((torch.randint(0, 3, (R, 1), generator=g).float(), xy, xy + wh), dim=1).cuda()
+        rois[0, 1:] = torch.tensor([-40.0, -30.0, 700.0, 500.0])               # samples outside the map on every side
+        for (PH, PW), step in (((14, 14), 2), ((7, 9), 2), ((14, 14), 1), ((13, 14), 3)):
+            want, shape = be.roi_align_rows(nchw, rois, 1.0 / 16, (PH, PW), 0, step=step)
+            got, shape2 = be.roi_align_rows(nhwc, rois, 1.0 / 16, (PH, PW), 0, step=step)
+            assert shape == shape2 and torch.equal(got, want), (C, PH, PW, step)
+        one = rois[rois[:, 0] == 1].clone()
+        one[:, 0] = 0
+        want, _ = be.roi_align_rows(nchw[1:2], one, 1.0 / 16, (14, 14), 0, step=2)
+        got, _ = be.roi_align_rows(nhwc[1:2], one, 1.0 / 16, (14, 14), 0, step=2)         # one image of the batch: still a view
+        assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("N,C,H,W", [(1, 64, 150, 200), (2, 7, 19, 25), (1, 3, 1, 1), (1, 256, 38, 50),
                                      (300, 512, 7, 7), (70001, 1, 2, 3), (64, 1024, 4, 4)])     # > 65535 planes (advisor, round 4)
 @pytest.mark.parametrize("with_res", [False, True])
