@@ -438,7 +438,26 @@ int odx_gemm_h2_taps_supported(int64_t m, int64_t n, int C, int64_t ldpy);
 int odx_gemm_h2_taps_f32(const void* PY, int64_t ldpy, const float* metay, int64_t R, int H, int W, int C,
                          const void* PB, int64_t ldpb, const float* metab, int64_t n, const float* bias,
                          const float* residual, int64_t ldr, int relu, float* out, int64_t ldo, float* out_meta,
+                         void* out_packed, int64_t ldop, float bound_w, float bound_add, const float* residual_meta,
                          odx_stream_t stream);
+/* A layer of such a chain that writes its output AS the next layer's operand: odx_gemm_h2_max_f32 which also
+ * (out_packed != NULL) stores the packed two-term split of its output straight from the accumulators — rows of ldop 4-byte
+ * units (ldop % 4 == 0, ldop >= roundup(n, 64), columns n .. roundup(n, 64) zero), out_meta[0] = the scale, out_meta[1] =
+ * max |out| — so no split pass is made over the activation; `out` may then be NULL (an activation only products read gets no
+ * f32 copy).  The scale has to be fixed before the maximum is known; it comes from the caller's bound
+ *     max |out| <= metaa[1] * bound_w + bound_add + residual_meta[1]
+ * (metaa[1] = max |A|; bound_w >= sqrt(K) max_j |B_j|_2 by Cauchy-Schwarz, bound_add >= max |bias|; residual_meta: the meta
+ * words of the residual's own packing / producer, NULL without a residual).  A bound 2^b above the true maximum costs b of
+ * the ~17 binades below the maximum in which the split carries its full 22 bits; the absolute error of an entry stays below
+ * 2^(b-39) of the maximum.  odx_gemm_h2_taps_f32 takes the same trailing arguments (out_packed NULL: as before).
+ * odx_taps3x3_packed: odx_split_f16_taps3x3 for rows that are already packed (a gather of 16-byte pieces, same meta words)
+ * — for the layers odx_gemm_h2_taps_supported does not serve. */
+int odx_gemm_h2_chain_f32(const void* PA, int64_t ldpa, const float* metaa, int64_t m, const void* PB, int64_t ldpb,
+                          const float* metab, int64_t n, int K, const float* bias, const float* residual, int64_t ldr,
+                          int relu, float* out, int64_t ldo, float* out_meta, void* out_packed, int64_t ldop,
+                          float bound_w, float bound_add, const float* residual_meta, odx_stream_t stream);
+int odx_taps3x3_packed(const void* PY, int64_t ldpy, int64_t R, int H, int W, int C, void* P, int64_t ldp,
+                       odx_stream_t stream);
 /* The same layers for a forward run in a 16-bit type (BASELINE config 2's bf16; the reference's own dtype is f32,
  * config/defaults.py:466): out (m x n) = act(A B' + bias[col] + residual) for plain row-major bf16 (is_bf16 = 1) or f16
  * operands A (m x K), B (n x K) — lda / ldb in ELEMENTS, multiples of 8, >= roundup(K, 128), the elements beyond K zero;

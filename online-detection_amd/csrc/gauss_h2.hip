@@ -64,6 +64,14 @@ __global__ __launch_bounds__(256) void absmax_f32_kernel(const float* __restrict
   }
 }
 
+// The two meta words of a matrix are cleared by a KERNEL, not by hipMemsetAsync: these calls are captured into HIP graphs (the
+// feature forward), and a graph's memset nodes were not reliably ordered against the kernel nodes around them on this runtime —
+// a forward replayed from the harvest loop's second thread now and then cleared the words AFTER the packing kernel had left its
+// scale there (scale 0 -> 1 / 0 in the next product -> NaN -> an all-zero map behind the ReLU, for as long as the timing held).
+__global__ void meta_zero_kernel(float* __restrict__ meta) {
+  if (threadIdx.x < 2) meta[threadIdx.x] = 0.f;
+}
+
 // scale = 2^(13 - e) for absmax = 1.m x 2^e  (1 for an all-zero, denormal or non-finite matrix)
 __device__ __forceinline__ float h2_scale_from_absmax(unsigned int bits) {
   const int ef = (int)((bits >> 23) & 0xffu);
@@ -152,6 +160,34 @@ __global__ __launch_bounds__(256) void split_f16_taps3x3_kernel(const float* __r
   *reinterpret_cast<f16x8*>(dst + 16) = lo;
 }
 
+// The same neighbourhood matrix from rows that are ALREADY packed (a chain layer's output, H2PackOut): a gather of 16-byte
+// pieces — feature group g of tap t comes from group (g's channels) of the neighbour's row, hi and lo pieces alike; same scale.
+__global__ __launch_bounds__(256) void taps3x3_packed_kernel(const uint32_t* __restrict__ PY, int64_t ldpy, int H, int W, int C,
+                                                             uint32_t* __restrict__ P, int64_t ldp, int64_t nrows) {
+  const int D = 9 * C;
+  const int groups = (int)((D + H2_KT - 1) / H2_KT) * 8;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = idx / groups;
+  const int g = (int)(idx - row * groups);
+  if (row >= nrows) return;
+  u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
+  const int f = g * 8;
+  if (f < D) {
+    const int tap = f / C, c = f - tap * C;
+    const int w = (int)(row % W), h = (int)((row / W) % H);
+    const int hh = h + tap / 3 - 1, ww = w + tap % 3 - 1;
+    if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+      const int gs = c >> 3;
+      const uint32_t* src = PY + (row + (int64_t)(hh - h) * W + (ww - w)) * ldpy + (int64_t)(gs >> 2) * 32 + (gs & 3) * 4;
+      hi = *reinterpret_cast<const u32x4*>(src);
+      lo = *reinterpret_cast<const u32x4*>(src + 16);
+    }
+  }
+  uint32_t* dst = P + row * ldp + (int64_t)(g >> 2) * 32 + (g & 3) * 4;
+  *reinterpret_cast<u32x4*>(dst) = hi;
+  *reinterpret_cast<u32x4*>(dst + 16) = lo;
+}
+
 // ---------------------------------------------------------------- tile mainloop
 struct H2Stage {
   u32x4 a[8], b[8];
@@ -160,12 +196,17 @@ struct H2Stage {
 // Rows past the operand's end are read as its last row (never branch around a load: the eight loads of an operand
 // issue back to back); whatever they produce is masked in the epilogues.  voff: per-thread 32-bit offsets (4-byte
 // units) from the uniform tile base, so the loads take the scalar-base + vector-offset form.
+// PERM (the B operand of the plain products): LDS row 64 b + 16 t + i of the image holds operand row 64 b + 4 i + t, so that the
+// four accumulator blocks tn = 0..3 of a lane are four ADJACENT output columns 64 wc + 4 (lane & 15) + tn (as on the wide
+// core, w_row_offsets): the epilogue moves 16 bytes per lane instead of four scattered floats.
+template <bool PERM = false>
 __device__ __forceinline__ void h2_row_offsets(uint32_t (&voff)[8], int64_t ld, int64_t row0, int64_t nrows) {
   const int tid = threadIdx.x;
   const int last = (int)(nrows - 1 - row0);          // >= 0: the tile starts inside the operand
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
-    const int r = (tid >> 4) + 16 * p;
+    const int ri = (tid >> 4) + 16 * p;
+    const int r = PERM ? ((ri & ~63) | ((ri & 15) << 2) | ((ri >> 4) & 3)) : ri;
     voff[p] = (uint32_t)(r < last ? r : last) * (uint32_t)ld + (uint32_t)(tid & 15) * 4u;
   }
 }
@@ -237,7 +278,7 @@ __device__ __forceinline__ void s16_compute_ktile(f32x4 (&acc)[4][4], const char
   }
 }
 
-template <int CORE = S16_H2>
+template <int CORE = S16_H2, bool PERMB = false>
 __device__ __forceinline__ void s16_mainloop(f32x4 (&acc)[4][4], const uint32_t* __restrict__ A, int64_t lda, int64_t m,
                                              const uint32_t* __restrict__ B, int64_t ldb, int64_t n, int64_t i0, int64_t j0,
                                              int ktiles, char* lds) {
@@ -246,8 +287,8 @@ __device__ __forceinline__ void s16_mainloop(f32x4 (&acc)[4][4], const uint32_t*
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   uint32_t offa[8], offb[8];
-  h2_row_offsets(offa, lda, i0, m);
-  h2_row_offsets(offb, ldb, j0, n);
+  h2_row_offsets<false>(offa, lda, i0, m);
+  h2_row_offsets<PERMB>(offb, ldb, j0, n);
   const uint32_t* ta = A + i0 * lda;
   const uint32_t* tb = B + j0 * ldb;
   H2Stage st;
@@ -1034,11 +1075,110 @@ __device__ __forceinline__ void gemm_h2_publish_max(unsigned int mx, unsigned in
   if ((threadIdx.x & 63) == 0 && mx) atomicMax(amax, mx);
 }
 
+// A layer of a CHAIN writes its output as the next layer's operand: the packed two-term split (odx_split_f16's form) straight
+// from the accumulators, beside or instead of the f32 matrix — no split pass (a read and a write of the whole activation per
+// layer) and, for an activation only GEMMs consume, no f32 copy at all.  The packing scale must be known BEFORE the maximum
+// of the output is: it comes from a bound, max |out| <= amax(A) bound_w + bound_add + amax(residual) with bound_w >= sqrt(K)
+// max_j |B_j|_2 (Cauchy-Schwarz) and bound_add >= max |bias| — the caller's promise.  A bound that is 2^b too generous costs
+// b of the ~17 binades below the maximum in which the split keeps its full 22 bits; the absolute error stays below 2^-39+b of
+// the maximum (f32's own rounding of the maximum: 2^-24).  meta[0] = the scale, meta[1] = the TRUE maximum (for the next
+// layer's bound), as odx_split_f16 leaves them.
+struct H2PackOut {
+  uint32_t* P;             // nullptr: no packed output
+  int64_t ldp;             // row stride, 4-byte units
+  float* meta;             // (scale, max bits); meta[1] is what `amax` points at
+  float bound_w, bound_add;
+  const float* rmeta;      // the residual's meta words (its maximum in [1]) or nullptr
+};
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float h2_chain_scale(const H2PackOut& po, const float* __restrict__ metaa) {
+  float bound = metaa[1] * po.bound_w + po.bound_add;
+  if (po.rmeta != nullptr) bound += po.rmeta[1];
+  bound *= 1.001f;                                   // (the f32 sums round: a hair of slack; the scale has 4 x headroom anyway)
+  return h2_scale_from_absmax(__float_as_uint(bound));
+}
+
+// The epilogue of both plain-product kernels.  A lane holds, for each of its TM row blocks (rows rb + 16 tm + q, q = 0..3), the
+// four ADJACENT columns col .. col + 3 (B rows fetched in the permuted order): bias / residual / f32 output move 16 bytes per
+// lane, the packed output 8 + 8.
+template <int TM>
+__device__ __forceinline__ void gemm_h2_store(const f32x4 (&acc)[TM][4], float inv, int64_t m, int64_t n, int64_t rb, int64_t col,
+                                              const float* __restrict__ metaa, const float* __restrict__ bias,
+                                              const float* __restrict__ res, int64_t ldr, int relu, float* __restrict__ out,
+                                              int64_t ldo, unsigned int* __restrict__ amax, const H2PackOut& pk) {
+  unsigned int mx = 0;
+  float so = 1.f;
+  if (pk.P != nullptr) {
+    so = h2_chain_scale(pk, metaa);
+    if (blockIdx.x == 0 && threadIdx.x == 0) pk.meta[0] = so;
+  }
+  const int64_t ncols = pk.P != nullptr ? ((n + H2_KT - 1) / H2_KT) * H2_KT : n;     // the packed rows are zero up to a whole k-tile
+  if (col < ncols) {
+    const bool full = col + 4 <= n;
+    const bool vec = full && (out == nullptr || (ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0)) &&
+                     (res == nullptr || (ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(res) & 15u) == 0));
+    float b[4];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) b[tn] = (bias != nullptr && col + tn < n) ? bias[col + tn] : 0.f;
+    // running addresses: a 64-bit row * ld product per store is a quarter-rate multiply chain
+    float* po = out != nullptr ? out + rb * ldo + col : nullptr;
+    const float* pr = res != nullptr ? res + rb * ldr + col : nullptr;
+    // packed form: granule col / 32 of the row = 32 f16 "hi" then 32 f16 "lo"; this lane's four columns are 8 + 8 bytes
+    uint32_t* pp = pk.P != nullptr ? pk.P + rb * pk.ldp + (col >> 5) * 32 + ((col & 31) >> 1) : nullptr;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (rb + tm * 16 + q < m) {
+          f32x4 v;
+          if (vec) {
+            f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
+            if (pr != nullptr) r4 = *reinterpret_cast<const f32x4*>(pr);
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+              v[tn] = fmaf(acc[tm][tn][q], inv, b[tn]) + r4[tn];
+              if (relu) v[tn] = fmaxf(v[tn], 0.f);
+            }
+            if (po != nullptr) *reinterpret_cast<f32x4*>(po) = v;
+          } else {
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+              v[tn] = col + tn < n ? gemm_h2_finish(acc[tm][tn][q], inv, b[tn], pr != nullptr ? pr + tn : nullptr, relu) : 0.f;
+              if (po != nullptr && col + tn < n) po[tn] = v[tn];
+            }
+          }
+          f16x4 hi, lo;
+#pragma unroll
+          for (int tn = 0; tn < 4; ++tn) {
+            mx = max(mx, __float_as_uint(v[tn]) & 0x7fffffffu);
+            const float t = v[tn] * so;
+            hi[tn] = (_Float16)t;
+            lo[tn] = (_Float16)(t - (float)hi[tn]);
+          }
+          if (pp != nullptr) {
+            *reinterpret_cast<f16x4*>(pp) = hi;
+            *reinterpret_cast<f16x4*>(pp + 16) = lo;
+          }
+        }
+        if (po != nullptr) po += ldo;
+        if (pr != nullptr) pr += ldr;
+        if (pp != nullptr) pp += pk.ldp;
+      }
+      if (po != nullptr) po += 12 * ldo;
+      if (pr != nullptr) pr += 12 * ldr;
+      if (pp != nullptr) pp += 12 * pk.ldp;
+    }
+  }
+  if (amax != nullptr) gemm_h2_publish_max(mx, amax);
+}
+
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_h2s16_kernel(
     const uint32_t* __restrict__ PA, int64_t ldpa, const float* __restrict__ metaa, int64_t m, const uint32_t* __restrict__ PB,
     int64_t ldpb, const float* __restrict__ metab, int64_t n, int ktiles, const float* __restrict__ bias,
     const float* __restrict__ res, int64_t ldr, int relu, float* __restrict__ out, int64_t ldo, int gr,
-    unsigned int* __restrict__ amax) {
+    unsigned int* __restrict__ amax, H2PackOut pk) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int64_t GR = gr;
   const int64_t tiles_n = (n + GEMM_BN - 1) / GEMM_BN;
@@ -1048,37 +1188,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_h2s16_kernel(
   if (i0 >= m) return;
   f32x4 acc[4][4];
   s16_zero(acc);
-  s16_mainloop(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, ktiles, lds);
+  s16_mainloop<S16_H2, true>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, ktiles, lds);
   const float inv = 1.f / (metaa[0] * metab[0]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  unsigned int mx = 0;
-#pragma unroll
-  for (int tn = 0; tn < 4; ++tn) {
-    const int64_t col = j0 + wc * 64 + tn * 16 + (lane & 15);
-    if (col >= n) continue;
-    const float b = bias != nullptr ? bias[col] : 0.f;
-    // running addresses: a 64-bit row * ld product per store is a quarter-rate multiply chain
-    const int64_t rb = i0 + wr * 64 + 4 * (lane >> 4);
-    float* po = out + rb * ldo + col;
-    const float* pr = res != nullptr ? res + rb * ldr + col : nullptr;
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (rb + tm * 16 + q < m) {
-          const float v = gemm_h2_finish(acc[tm][tn][q], inv, b, pr, relu);
-          *po = v;
-          mx = max(mx, __float_as_uint(v) & 0x7fffffffu);
-        }
-        po += ldo;
-        if (pr != nullptr) pr += ldr;
-      }
-      po += 12 * ldo;
-      if (pr != nullptr) pr += 12 * ldr;
-    }
-  }
-  if (amax != nullptr) gemm_h2_publish_max(mx, amax);
+  gemm_h2_store<4>(acc, inv, m, n, i0 + wr * 64 + 4 * (lane >> 4), j0 + wc * 64 + 4 * (lane & 15), metaa, bias, res, ldr, relu, out, ldo,
+                   amax, pk);
 }
 
 template <int STG, bool TAPS = false>
@@ -1086,7 +1201,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void gemm_h2w256_kernel(
     const uint32_t* __restrict__ PA, int64_t ldpa, const float* __restrict__ metaa, int64_t m, const uint32_t* __restrict__ PB,
     int64_t ldpb, const float* __restrict__ metab, int64_t n, int stages, const float* __restrict__ bias,
     const float* __restrict__ res, int64_t ldr, int relu, float* __restrict__ out, int64_t ldo, int gr,
-    unsigned int* __restrict__ amax, int tapH, int tapW, int tapC) {
+    unsigned int* __restrict__ amax, int tapH, int tapW, int tapC, H2PackOut pk) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int64_t GR = gr;
   const int64_t tiles_n = (n + W_BN - 1) / W_BN;
@@ -1103,51 +1218,8 @@ __global__ __launch_bounds__(W_THREADS, 1) void gemm_h2w256_kernel(
   const float inv = 1.f / (metaa[0] * metab[0]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 2, wc = wave & 3;
-  const int64_t col = j0 + wc * 64 + 4 * (lane & 15);
-  const int64_t rb = i0 + wr * 128 + 4 * (lane >> 4);
-  unsigned int mx = 0;
-  if (col < n) {
-    const bool vec = col + 4 <= n && ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0 &&
-                     (res == nullptr || (ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(res) & 15u) == 0));
-    float b[4];
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn) b[tn] = (bias != nullptr && col + tn < n) ? bias[col + tn] : 0.f;
-    float* po = out + rb * ldo + col;
-    const float* pr = res != nullptr ? res + rb * ldr + col : nullptr;
-#pragma unroll
-    for (int tm = 0; tm < 8; ++tm) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (rb + tm * 16 + q < m) {
-          if (vec) {
-            f32x4 v;
-            f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
-            if (pr != nullptr) r4 = *reinterpret_cast<const f32x4*>(pr);
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) {
-              v[tn] = fmaf(acc[tm][tn][q], inv, b[tn]) + r4[tn];
-              if (relu) v[tn] = fmaxf(v[tn], 0.f);
-              mx = max(mx, __float_as_uint(v[tn]) & 0x7fffffffu);
-            }
-            *reinterpret_cast<f32x4*>(po) = v;
-          } else {
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn)
-              if (col + tn < n) {
-                const float v = gemm_h2_finish(acc[tm][tn][q], inv, b[tn], pr != nullptr ? pr + tn : nullptr, relu);
-                po[tn] = v;
-                mx = max(mx, __float_as_uint(v) & 0x7fffffffu);
-              }
-          }
-        }
-        po += ldo;
-        if (pr != nullptr) pr += ldr;
-      }
-      po += 12 * ldo;
-      if (pr != nullptr) pr += 12 * ldr;
-    }
-  }
-  if (amax != nullptr) gemm_h2_publish_max(mx, amax);
+  gemm_h2_store<8>(acc, inv, m, n, i0 + wr * 128 + 4 * (lane >> 4), j0 + wc * 64 + 4 * (lane & 15), metaa, bias, res, ldr, relu, out, ldo,
+                   amax, pk);
 }
 
 // ---------------------------------------------------------------- 16-bit operands (bf16 / f16), one term
@@ -1706,7 +1778,7 @@ extern "C" int odx_split_f16(const float* X, int64_t ldx, int64_t n, int D, void
                              odx_stream_t stream) {
   ODX_REQUIRE(meta, "odx_split_f16: meta is null");
   hipStream_t s = as_stream(stream);
-  ODX_CHECK_HIP(hipMemsetAsync(meta, 0, 2 * sizeof(float), s));
+  hipLaunchKernelGGL(meta_zero_kernel, dim3(1), dim3(64), 0, s, meta);
   if (n <= 0) {
     // scale of an empty matrix: 1
     hipLaunchKernelGGL(split_f16_kernel, dim3(1, 1), dim3(256), 0, s, X, ldx, 0, 0, (uint32_t*)P, ldp, meta);
@@ -1804,7 +1876,7 @@ static int split_taps3x3_launch(const float* Y, int64_t ldy, int64_t R, int H, i
                                 bool premax, odx_stream_t stream, const char* who) {
   ODX_REQUIRE(meta, "odx_split_f16_taps3x3: meta is null");
   hipStream_t s = as_stream(stream);
-  if (!premax) ODX_CHECK_HIP(hipMemsetAsync(meta, 0, 2 * sizeof(float), s));
+  if (!premax) hipLaunchKernelGGL(meta_zero_kernel, dim3(1), dim3(64), 0, s, meta);
   const int64_t n = R * H * W;
   if (n <= 0) return ODX_OK;
   ODX_REQUIRE(Y && P && H > 0 && W > 0 && C > 0 && C % 8 == 0 && ldy >= C && ldy % 4 == 0 && aligned16(Y),
@@ -1835,15 +1907,29 @@ extern "C" int odx_split_f16_taps3x3_premax(const float* Y, int64_t ldy, int64_t
   return split_taps3x3_launch(Y, ldy, R, H, W, C, P, ldp, meta, true, stream, "odx_split_f16_taps3x3_premax");
 }
 
+static int h2_pack_out(H2PackOut& pk, const char* who, float* out, int64_t n, float* out_meta, void* out_packed, int64_t ldop,
+                       float bound_w, float bound_add, const float* residual_meta) {
+  pk = H2PackOut{nullptr, 0, nullptr, 0.f, 0.f, nullptr};
+  if (out_packed == nullptr) {
+    ODX_REQUIRE(out != nullptr, "%s: neither an f32 nor a packed output", who);
+    return ODX_OK;
+  }
+  ODX_REQUIRE(out_meta != nullptr, "%s: a packed output needs out_meta", who);
+  ODX_REQUIRE(ldop % 4 == 0 && ldop >= round_up(n, H2_KT) && aligned16(out_packed), "%s: out_packed must be 16-byte aligned, ldop %% 4 == 0, ldop >= roundup(n, 64)", who);
+  ODX_REQUIRE(bound_w >= 0.f && bound_add >= 0.f && bound_w == bound_w && bound_add == bound_add, "%s: bounds must be non-negative numbers", who);
+  pk = H2PackOut{static_cast<uint32_t*>(out_packed), ldop, out_meta, bound_w, bound_add, residual_meta};
+  return ODX_OK;
+}
+
 static int gemm_h2_launch(const void* PA, int64_t ldpa, const float* metaa, int64_t m, const void* PB, int64_t ldpb,
                           const float* metab, int64_t n, int K, const float* bias, const float* residual, int64_t ldr,
-                          int relu, float* out, int64_t ldo, float* out_meta, odx_stream_t stream) {
+                          int relu, float* out, int64_t ldo, float* out_meta, const H2PackOut& pk, odx_stream_t stream) {
   if (m <= 0 || n <= 0) return ODX_OK;
-  ODX_REQUIRE(PA && PB && metaa && metab && out && K > 0, "odx_gemm_h2_f32: bad argument");
+  ODX_REQUIRE(PA && PB && metaa && metab && (out || pk.P) && K > 0, "odx_gemm_h2_f32: bad argument");
   const int64_t dp = round_up(K, H2_KT);
   ODX_REQUIRE(ldpa % 4 == 0 && ldpb % 4 == 0 && ldpa >= dp && ldpb >= dp && aligned16(PA) && aligned16(PB),
               "odx_gemm_h2_f32: packed operands must be 16-byte aligned with ld %% 4 == 0 and ld >= roundup(K, 64)");
-  ODX_REQUIRE(ldo >= n && (residual == nullptr || ldr >= n), "odx_gemm_h2_f32: ldo / ldr < n");
+  ODX_REQUIRE((out == nullptr || ldo >= n) && (residual == nullptr || ldr >= n), "odx_gemm_h2_f32: ldo / ldr < n");
   ODX_REQUIRE(ldpa < (1 << 24) && ldpb < (1 << 24), "odx_gemm_h2_f32: leading dimensions must stay below 2^24 (32-bit tile offsets)");
   const int gr = 8;
   unsigned int* amax = out_meta ? reinterpret_cast<unsigned int*>(out_meta + 1) : nullptr;
@@ -1856,12 +1942,12 @@ static int gemm_h2_launch(const void* PA, int64_t ldpa, const float* metaa, int6
       ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2w256_kernel<STG_DMA>), W_LDS_BYTES));
       hipLaunchKernelGGL(gemm_h2w256_kernel<STG_DMA>, dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
                          (const uint32_t*)PA, ldpa, metaa, m, (const uint32_t*)PB, ldpb, metab, n, (int)(dp / W_KS), bias, residual,
-                         ldr, relu, out, ldo, gr, amax, 0, 0, 0);
+                         ldr, relu, out, ldo, gr, amax, 0, 0, 0, pk);
     } else {
       ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2w256_kernel<STG_REG>), W_LDS_BYTES));
       hipLaunchKernelGGL(gemm_h2w256_kernel<STG_REG>, dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
                          (const uint32_t*)PA, ldpa, metaa, m, (const uint32_t*)PB, ldpb, metab, n, (int)(dp / W_KS), bias, residual,
-                         ldr, relu, out, ldo, gr, amax, 0, 0, 0);
+                         ldr, relu, out, ldo, gr, amax, 0, 0, 0, pk);
     }
     ODX_CHECK_LAUNCH("odx_gemm_h2_f32(w256)");
     return ODX_OK;
@@ -1871,7 +1957,7 @@ static int gemm_h2_launch(const void* PA, int64_t ldpa, const float* metaa, int6
   ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2s16_kernel)));
   hipLaunchKernelGGL(gemm_h2s16_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), S16_LDS_BYTES, as_stream(stream),
                      (const uint32_t*)PA, ldpa, metaa, m, (const uint32_t*)PB, ldpb, metab, n, (int)(dp / H2_KT), bias, residual,
-                     ldr, relu, out, ldo, gr, amax);
+                     ldr, relu, out, ldo, gr, amax, pk);
   ODX_CHECK_LAUNCH("odx_gemm_h2_f32");
   return ODX_OK;
 }
@@ -1879,7 +1965,9 @@ static int gemm_h2_launch(const void* PA, int64_t ldpa, const float* metaa, int6
 extern "C" int odx_gemm_h2_f32(const void* PA, int64_t ldpa, const float* metaa, int64_t m, const void* PB, int64_t ldpb,
                                const float* metab, int64_t n, int K, const float* bias, const float* residual, int64_t ldr,
                                int relu, float* out, int64_t ldo, odx_stream_t stream) {
-  return gemm_h2_launch(PA, ldpa, metaa, m, PB, ldpb, metab, n, K, bias, residual, ldr, relu, out, ldo, nullptr, stream);
+  ODX_REQUIRE(out, "odx_gemm_h2_f32: out is null");
+  return gemm_h2_launch(PA, ldpa, metaa, m, PB, ldpb, metab, n, K, bias, residual, ldr, relu, out, ldo, nullptr,
+                        H2PackOut{nullptr, 0, nullptr, 0.f, 0.f, nullptr}, stream);
 }
 
 // odx_gemm_h2_f32 that also leaves max |out| in out_meta[1] (IEEE bits; out_meta[1] must be 0 on entry, out_meta[0] is not
@@ -1888,8 +1976,43 @@ extern "C" int odx_gemm_h2_f32(const void* PA, int64_t ldpa, const float* metaa,
 extern "C" int odx_gemm_h2_max_f32(const void* PA, int64_t ldpa, const float* metaa, int64_t m, const void* PB, int64_t ldpb,
                                    const float* metab, int64_t n, int K, const float* bias, const float* residual, int64_t ldr,
                                    int relu, float* out, int64_t ldo, float* out_meta, odx_stream_t stream) {
-  ODX_REQUIRE(out_meta, "odx_gemm_h2_max_f32: out_meta is null");
-  return gemm_h2_launch(PA, ldpa, metaa, m, PB, ldpb, metab, n, K, bias, residual, ldr, relu, out, ldo, out_meta, stream);
+  ODX_REQUIRE(out_meta && out, "odx_gemm_h2_max_f32: out / out_meta is null");
+  return gemm_h2_launch(PA, ldpa, metaa, m, PB, ldpb, metab, n, K, bias, residual, ldr, relu, out, ldo, out_meta,
+                        H2PackOut{nullptr, 0, nullptr, 0.f, 0.f, nullptr}, stream);
+}
+
+// A layer of a chain (H2PackOut above): odx_gemm_h2_max_f32 that ALSO (out_packed != NULL) writes its output as the next
+// layer's packed operand — rows of ldop 4-byte units, ldop %% 4 == 0, ldop >= roundup(n, 64), columns n .. roundup(n, 64) zero
+// — with out_meta[0] = the scale it packed with, out_meta[1] = max |out|; `out` may then be NULL (an activation only GEMMs
+// read).  The caller promises  max |out| <= amax(A) bound_w + bound_add + amax(residual)  (amax(A) = metaa[1],
+// amax(residual) = residual_meta[1]; residual_meta may be NULL when there is no residual): bound_w >= sqrt(K) max_j |B_j|_2,
+// bound_add >= max |bias|.
+extern "C" int odx_gemm_h2_chain_f32(const void* PA, int64_t ldpa, const float* metaa, int64_t m, const void* PB, int64_t ldpb,
+                                     const float* metab, int64_t n, int K, const float* bias, const float* residual, int64_t ldr,
+                                     int relu, float* out, int64_t ldo, float* out_meta, void* out_packed, int64_t ldop,
+                                     float bound_w, float bound_add, const float* residual_meta, odx_stream_t stream) {
+  H2PackOut pk;
+  ODX_PROPAGATE(h2_pack_out(pk, "odx_gemm_h2_chain_f32", out, n, out_meta, out_packed, ldop, bound_w, bound_add, residual_meta));
+  ODX_REQUIRE(residual == nullptr || out_packed == nullptr || residual_meta != nullptr, "odx_gemm_h2_chain_f32: a packed output with a residual needs residual_meta");
+  return gemm_h2_launch(PA, ldpa, metaa, m, PB, ldpb, metab, n, K, bias, residual, ldr, relu, out, ldo, out_meta, pk, stream);
+}
+
+// odx_split_f16_taps3x3 of rows that are already packed (a chain layer's output): P ((R H W) x ldp, ldp >= roundup(9 C, 64)) =
+// the 3 x 3 neighbourhood matrix of PY ((R H W) x C channels, C % 8 == 0) in packed form, same meta words as PY.
+extern "C" int odx_taps3x3_packed(const void* PY, int64_t ldpy, int64_t R, int H, int W, int C, void* P, int64_t ldp,
+                                  odx_stream_t stream) {
+  const int64_t n = R * H * W;
+  if (n <= 0) return ODX_OK;
+  ODX_REQUIRE(PY && P && H > 0 && W > 0 && C > 0 && C % 8 == 0 && ldpy % 4 == 0 && ldpy >= round_up(C, 32) && aligned16(PY),
+              "odx_taps3x3_packed: PY must be 16-byte aligned with ldpy %% 4 == 0, ldpy >= roundup(C, 32), C %% 8 == 0");
+  const int D = 9 * C;
+  ODX_REQUIRE(ldp >= round_up(D, H2_KT) && ldp % 4 == 0 && aligned16(P), "odx_taps3x3_packed: P must be 16-byte aligned, ldp %% 4 == 0, ldp >= roundup(9 C, 64)");
+  const int groups = (int)ceil_div(D, H2_KT) * 8;
+  ODX_REQUIRE(ceil_div(n * groups, 256) < (1ll << 31), "odx_taps3x3_packed: too many rows");
+  hipLaunchKernelGGL(taps3x3_packed_kernel, dim3((unsigned)ceil_div(n * groups, 256)), dim3(256), 0, as_stream(stream),
+                     static_cast<const uint32_t*>(PY), ldpy, H, W, C, static_cast<uint32_t*>(P), ldp, n);
+  ODX_CHECK_LAUNCH("odx_taps3x3_packed");
+  return ODX_OK;
 }
 
 // 1 when odx_gemm_h2_taps_f32 serves this layer: the 256 x 256 LDS-DMA core (it fills the chip: >= 256 tiles, more than 128
@@ -1908,15 +2031,19 @@ extern "C" int odx_gemm_h2_taps_supported(int64_t m, int64_t n, int C, int64_t l
 extern "C" int odx_gemm_h2_taps_f32(const void* PY, int64_t ldpy, const float* metay, int64_t R, int H, int W, int C,
                                     const void* PB, int64_t ldpb, const float* metab, int64_t n, const float* bias,
                                     const float* residual, int64_t ldr, int relu, float* out, int64_t ldo, float* out_meta,
+                                    void* out_packed, int64_t ldop, float bound_w, float bound_add, const float* residual_meta,
                                     odx_stream_t stream) {
   const int64_t m = R * H * W;
   if (m <= 0 || n <= 0) return ODX_OK;
-  ODX_REQUIRE(PY && PB && metay && metab && out && H > 0 && W > 0, "odx_gemm_h2_taps_f32: bad argument");
+  H2PackOut pk;
+  ODX_PROPAGATE(h2_pack_out(pk, "odx_gemm_h2_taps_f32", out, n, out_meta, out_packed, ldop, bound_w, bound_add, residual_meta));
+  ODX_REQUIRE(residual == nullptr || out_packed == nullptr || residual_meta != nullptr, "odx_gemm_h2_taps_f32: a packed output with a residual needs residual_meta");
+  ODX_REQUIRE(PY && PB && metay && metab && H > 0 && W > 0, "odx_gemm_h2_taps_f32: bad argument");
   ODX_REQUIRE(odx_gemm_h2_taps_supported(m, n, C, ldpy), "odx_gemm_h2_taps_f32: layer not served (odx_gemm_h2_taps_supported)");
   const int64_t K = 9 * (int64_t)C;
   ODX_REQUIRE(ldpy % 4 == 0 && ldpb % 4 == 0 && ldpy >= C && ldpb >= round_up(K, H2_KT) && aligned16(PY) && aligned16(PB),
               "odx_gemm_h2_taps_f32: packed operands must be 16-byte aligned with ld %% 4 == 0, ldpy >= C, ldpb >= roundup(9 C, 64)");
-  ODX_REQUIRE(ldo >= n && (residual == nullptr || ldr >= n), "odx_gemm_h2_taps_f32: ldo / ldr < n");
+  ODX_REQUIRE((out == nullptr || ldo >= n) && (residual == nullptr || ldr >= n), "odx_gemm_h2_taps_f32: ldo / ldr < n");
   ODX_REQUIRE(ldpb < (1 << 24), "odx_gemm_h2_taps_f32: leading dimensions must stay below 2^24 (32-bit tile offsets)");
   const int gr = 8;
   const int64_t wt = round_up(ceil_div(m, W_BM), gr) * ceil_div(n, W_BN);
@@ -1925,7 +2052,7 @@ extern "C" int odx_gemm_h2_taps_f32(const void* PY, int64_t ldpy, const float* m
   ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2w256_kernel<STG_DMA, true>), W_LDS_BYTES));
   hipLaunchKernelGGL((gemm_h2w256_kernel<STG_DMA, true>), dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
                      (const uint32_t*)PY, ldpy, metay, m, (const uint32_t*)PB, ldpb, metab, n, (int)(K / W_KS), bias, residual, ldr,
-                     relu, out, ldo, gr, amax, H, W, C);
+                     relu, out, ldo, gr, amax, H, W, C, pk);
   ODX_CHECK_LAUNCH("odx_gemm_h2_taps_f32");
   return ODX_OK;
 }
@@ -2166,7 +2293,7 @@ extern "C" int odx_split_f8(const float* X, int64_t ldx, int64_t n, int D, void*
                             odx_stream_t stream) {
   ODX_REQUIRE(meta, "odx_split_f8: meta is null");
   hipStream_t s = as_stream(stream);
-  ODX_CHECK_HIP(hipMemsetAsync(meta, 0, 2 * sizeof(float), s));
+  hipLaunchKernelGGL(meta_zero_kernel, dim3(1), dim3(64), 0, s, meta);
   if (n <= 0) {
     hipLaunchKernelGGL(split_f8_kernel, dim3(1, 1), dim3(256), 0, s, X, ldx, 0, 0, (uint32_t*)P, 0, meta);
     ODX_CHECK_LAUNCH("odx_split_f8");

@@ -15,6 +15,28 @@ namespace odx {
 constexpr int ODX_MAX_FPN_LEVELS = 4;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Buffers of these calls are cleared by a KERNEL, not by hipMemsetAsync: the calls are captured into HIP graphs (the group
+// forward), and a graph's memset nodes were not reliably ordered against the kernel nodes around them on this runtime (see
+// meta_zero_kernel in gauss_h2.hip; the all-zero RoI features of round 5's group-graph probe).  Any address, any byte count.
+__global__ __launch_bounds__(256) void zero_bytes_kernel(unsigned char* __restrict__ p, size_t nbytes) {
+  const size_t stride = (size_t)gridDim.x * 256 * 16;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16; i < nbytes; i += stride) {
+    if (i + 16 <= nbytes && ((reinterpret_cast<uintptr_t>(p) + i) & 15u) == 0) {
+      *reinterpret_cast<uint4*>(p + i) = uint4{0u, 0u, 0u, 0u};
+    } else {
+      for (size_t j = i; j < nbytes && j < i + 16; ++j) p[j] = 0;
+    }
+  }
+}
+
+static int zero_bytes(void* p, size_t nbytes, hipStream_t s) {
+  if (nbytes == 0) return ODX_OK;
+  const size_t blocks = (nbytes + 4095) / 4096;
+  hipLaunchKernelGGL(zero_bytes_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, static_cast<unsigned char*>(p), nbytes);
+  ODX_CHECK_LAUNCH("zero_bytes");
+  return ODX_OK;
+}
+
 // ---------------------------------------------------------------- RoIAlign forward
 // feat (N, C, H, W) f32, rois (R, 5) = (batch index, x1, y1, x2, y2), out (R, C, PH, PW).
 // One 256-thread workgroup per (roi, chunk of CCH channels): thread t owns output bin t of the
@@ -661,7 +683,7 @@ extern "C" int odx_nms_f32(const float* boxes_sorted, int R, float iou_threshold
   }
   const int words = (int)ceil_div(R, 64);
   hipStream_t s = as_stream(stream);
-  ODX_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)odx_nms_workspace_bytes(R), s));
+  ODX_PROPAGATE(zero_bytes(workspace, (size_t)odx_nms_workspace_bytes(R), s));
   auto* mask = static_cast<unsigned long long*>(workspace);
   hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)words, (unsigned)words), dim3(64), 0, s, boxes_sorted, R,
                      iou_threshold, mask, words, (const int*)nullptr);
@@ -684,8 +706,8 @@ extern "C" int odx_nms_first_f32(const float* boxes_sorted, int R, float iou_thr
   }
   const int words = (int)ceil_div(R, 64);
   hipStream_t s = as_stream(stream);
-  ODX_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)odx_nms_workspace_bytes(R), s));
-  ODX_CHECK_HIP(hipMemsetAsync(keep, 0, (size_t)R, s));
+  ODX_PROPAGATE(zero_bytes(workspace, (size_t)odx_nms_workspace_bytes(R), s));
+  ODX_PROPAGATE(zero_bytes(keep, (size_t)R, s));
   auto* mask = static_cast<unsigned long long*>(workspace);
   hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)words, (unsigned)words), dim3(64), 0, s, boxes_sorted, R,
                      iou_threshold, mask, words, (const int*)nullptr);
@@ -733,8 +755,8 @@ static int nms_batched(const float* boxes_sorted, const int32_t* counts, int Rma
   }
   const int words = (int)ceil_div(Rmax, 64);
   hipStream_t s = as_stream(stream);
-  ODX_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)odx_nms_batched_workspace_bytes(Rmax, B), s));
-  ODX_CHECK_HIP(hipMemsetAsync(keep, 0, (size_t)B * Rmax, s));
+  ODX_PROPAGATE(zero_bytes(workspace, (size_t)odx_nms_batched_workspace_bytes(Rmax, B), s));
+  ODX_PROPAGATE(zero_bytes(keep, (size_t)B * Rmax, s));
   auto* mask = static_cast<unsigned long long*>(workspace);
   hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)words, (unsigned)words, (unsigned)B), dim3(64), 0, s, boxes_sorted, Rmax,
                      iou_threshold, mask, words, counts);

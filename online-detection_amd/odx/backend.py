@@ -51,6 +51,16 @@ class Rows16:
         return self.buf[:, :self.K]
 
 
+class PackedRows:
+    """An activation matrix (n, D) of a chain of GEMM layers: P / meta = its packed two-term f16 split as a layer's epilogue
+    wrote it (odx_gemm_h2_chain_f32; meta[0] the scale, meta[1] max |x|), X = the f32 matrix when the layer wrote one (a block's
+    output: the next block's identity branch), zero_row = P is followed by one all-zero row in memory (odx_gemm_h2_taps_f32)."""
+    __slots__ = ("X", "n", "D", "P", "meta", "zero_row")
+
+    def __init__(self, X, n, D, P, meta, zero_row=False):
+        self.X, self.n, self.D, self.P, self.meta, self.zero_row = X, n, D, P, meta, zero_row
+
+
 class Precond:
     """Inverse Cholesky factors of the FALKON preconditioner, f64, row-major (M x ld)."""
     __slots__ = ("LTi", "LTit", "LAi", "LAit", "M", "ld", "info", "block_rows")
@@ -806,6 +816,68 @@ class HipBackend:
             X = buf[:, :X.shape[1]]
         return self.pack(Features(X, None, X.shape[1], meta=meta), zero_row=zero_row)
 
+    @staticmethod
+    def weight_bounds(w, bias=None):
+        """(bound_w, bound_add) of odx_gemm_h2_chain_f32 for the weight matrix w (n, K) and bias: sqrt(K) max_j |w_j|_2 and
+        max |bias|, rounded up (host numbers, computed once per layer when its weights are packed)."""
+        w = w.detach().double()
+        bw = float(w.norm(dim=1).max()) * (w.shape[1] ** 0.5) * (1 + 1e-6) if w.numel() else 0.0
+        ba = float(bias.detach().abs().max()) * (1 + 1e-6) if bias is not None and bias.numel() else 0.0
+        return bw, ba
+
+    def _chain_out(self, m, n, f32_out, zero_row):
+        ldop = (n + 63) // 64 * 64
+        buf = torch.empty((m + 1 if zero_row else m, ldop), dtype=torch.int32, device=self.device)
+        if zero_row:
+            buf[m].zero_()
+        out = torch.empty((m, n), dtype=torch.float32, device=self.device) if f32_out else None
+        return out, buf[:m], self._meta_slot()
+
+    def chain_gemm(self, A, B, bias=None, residual=None, residual_meta=None, relu=False, bounds=(0.0, 0.0), f32_out=True, zero_row=False):
+        """A layer of a chain: act(A B' + bias + residual) written AS the next layer's packed operand by the product's own
+        epilogue (odx_gemm_h2_chain_f32) — PackedRows with P / meta, and X when f32_out.  A: Features / PackedRows; bounds =
+        weight_bounds(B's matrix, bias); residual_meta: the meta words of the residual (its maximum in [1])."""
+        m, n, K = A.n, B.n, A.D
+        if B.D != K:
+            raise ValueError("chain_gemm: inner dimensions differ (%d, %d)" % (K, B.D))
+        if residual is not None and residual_meta is None:
+            raise ValueError("chain_gemm: a residual needs its meta words")
+        out, P, meta = self._chain_out(m, n, f32_out, zero_row)
+        if m and n:
+            if bias is not None:
+                bias = bias.to(device=self.device, dtype=torch.float32).contiguous()
+            ldr = 0
+            if residual is not None:
+                residual = residual.to(device=self.device, dtype=torch.float32)
+                if residual.stride(1) != 1:
+                    residual = residual.contiguous()
+                ldr = residual.stride(0)
+            hip.check(self.lib.odx_gemm_h2_chain_f32(_p(A.P), A.P.stride(0), _p(A.meta), m, _p(B.P), B.P.stride(0), _p(B.meta), n, K,
+                                                     _p(bias), _p(residual), ldr, int(bool(relu)), _p(out), n, _p(meta), _p(P), P.stride(0),
+                                                     float(bounds[0]), float(bounds[1]), _p(residual_meta), self._stream()), "odx_gemm_h2_chain_f32")
+        return PackedRows(out, m, n, P, meta, zero_row)
+
+    def chain_conv3x3(self, A, R, H, W, B, bias=None, relu=False, bounds=(0.0, 0.0), f32_out=False, zero_row=False):
+        """chain_gemm for a 3 x 3 convolution (padding 1) over the packed NHWC rows A (R H W, C): the taps gathered inside the
+        product's operand loads where the library does that (A.zero_row required), else gathered from the packed rows into the
+        packed neighbourhood matrix (odx_taps3x3_packed) and multiplied."""
+        C, n, m = A.D, B.n, R * H * W
+        if A.n != m or B.D != 9 * C:
+            raise ValueError("chain_conv3x3: %d rows of %d channels against R H W = %d, K = %d" % (A.n, C, m, B.D))
+        if A.zero_row and self.lib.odx_gemm_h2_taps_supported(m, n, C, A.P.stride(0)):
+            out, P, meta = self._chain_out(m, n, f32_out, zero_row)
+            if bias is not None:
+                bias = bias.to(device=self.device, dtype=torch.float32).contiguous()
+            hip.check(self.lib.odx_gemm_h2_taps_f32(_p(A.P), A.P.stride(0), _p(A.meta), R, H, W, C, _p(B.P), B.P.stride(0), _p(B.meta), n,
+                                                    _p(bias), None, 0, int(bool(relu)), _p(out), n, _p(meta), _p(P), P.stride(0),
+                                                    float(bounds[0]), float(bounds[1]), None, self._stream()), "odx_gemm_h2_taps_f32")
+            return PackedRows(out, m, n, P, meta, zero_row)
+        D = 9 * C
+        T = PackedRows(None, m, D, torch.empty((m, (D + 63) // 64 * 64), dtype=torch.int32, device=self.device), A.meta)
+        if m:
+            hip.check(self.lib.odx_taps3x3_packed(_p(A.P), A.P.stride(0), R, H, W, C, _p(T.P), T.P.stride(0), self._stream()), "odx_taps3x3_packed")
+        return self.chain_gemm(T, B, bias=bias, relu=relu, bounds=bounds, f32_out=f32_out, zero_row=zero_row)
+
     def conv3x3_rows(self, Y, R, H, W, B, bias=None, relu=False, meta=None, with_max=False):
         """act(3 x 3 convolution, padding 1) of the NHWC rows Y (R H W, C) f32 with the packed weights B (n, 9 C: ky kx c) as
         ONE product: where the library gathers the taps inside the product's operand loads (odx_gemm_h2_taps_f32: wide
@@ -823,7 +895,8 @@ class HipBackend:
             bias = bias.to(device=self.device, dtype=torch.float32).contiguous()
         om = self._meta_slot() if with_max else None
         hip.check(self.lib.odx_gemm_h2_taps_f32(_p(Fy.P), Fy.P.stride(0), _p(Fy.meta), R, H, W, C, _p(B.P), B.P.stride(0), _p(B.meta), n,
-                                                _p(bias), None, 0, int(bool(relu)), _p(out), n, _p(om), self._stream()), "odx_gemm_h2_taps_f32")
+                                                _p(bias), None, 0, int(bool(relu)), _p(out), n, _p(om), None, 0, 0.0, 0.0, None,
+                                                self._stream()), "odx_gemm_h2_taps_f32")
         return (out, om) if with_max else out
 
     def packed_taps3x3(self, Y, R, H, W, meta=None):

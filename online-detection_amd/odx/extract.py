@@ -348,32 +348,52 @@ def _bottleneck_rows_b16(be, blk, x, R, H, W):
     return be.gemm_b16(y, w3, bias=b3, residual=idn, relu=True)
 
 
-def _bottleneck_rows_h2(be, blk, x, R, H, W, x_meta=None, want_max=False):
+def _bottleneck_rows_h2(be, blk, x, R, H, W, x_meta=None, want_max=False, pack_out=False):
     """The f32 form of _bottleneck_rows on the split-f16 tile cores (odx_gemm_h2_f32: f32 accuracy on the f16 matrix cores,
-    243-317 TF on these shapes against 95-117 TF for the f32 MFMA GEMMs): folded weights packed once per layer, every
-    activation matrix packed once (the block's input serves conv1 and the projection), bias / identity / ReLU in the
-    GEMM's epilogue.  Every GEMM also leaves the maximum of what it wrote (odx_gemm_h2_max_f32), which is what the next
-    layer's packing scales by: no layer reads its input a second time for that.  x_meta: those words for x, when x came out of
-    such a GEMM (or was cut from a matrix that did); want_max: return (out, meta) for the next block."""
+    243-317 TF on these shapes against 95-117 TF for the f32 MFMA GEMMs) as a CHAIN of layers: folded weights packed once per
+    layer; bias / identity / ReLU in the GEMM epilogues; and every layer writes its output as the next layer's packed operand
+    straight from its accumulators (odx_gemm_h2_chain_f32) — the two inner activations exist in packed form only, the 3 x 3
+    convolution gathers its taps inside its operand loads where the library can (odx_gemm_h2_taps_f32) or from the packed rows,
+    and only the block's input is ever packed by a pass of its own (when it did not come out of such a layer).
+    x: the block's input — f32 rows (x_meta: the meta words its producer left, its maximum in [1]) or the backend.PackedRows a
+    previous block returned with pack_out (its f32 rows serve the identity branch).  Returns the output rows; with want_max
+    (out, meta); with pack_out a PackedRows holding both forms, for the next block."""
+    from .backend import PackedRows
+
     def wpack(key, conv, bn, taps=False):
         c = blk._folded.get((key + "/h2", torch.float32))
         if c is None:
-            w, b = blk._fold(key, conv, bn, x)
-            w = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1) if taps else w.reshape(w.shape[0], -1)     # (out, ky kx in)
-            c = blk._folded[(key + "/h2", torch.float32)] = (be.packed(w.float().contiguous()), b.float().contiguous())
+            w, b = blk._fold(key, conv, bn, x.X if isinstance(x, PackedRows) else x)
+            w = (w.permute(0, 2, 3, 1).reshape(w.shape[0], -1) if taps else w.reshape(w.shape[0], -1)).float().contiguous()   # (out, ky kx in)
+            c = blk._folded[(key + "/h2", torch.float32)] = (be.packed(w), b.float().contiguous(), be.weight_bounds(w, b))
         return c
-    xp = be.packed(x, meta=x_meta)
-    if blk.down is None:
-        idn = x
+    if isinstance(x, PackedRows):
+        xp, xf, xm = x, x.X, x.meta
     else:
-        wd, bd = wpack("down", blk.down[0], blk.down[1])
-        idn = be.gemm_h2(xp, wd, bias=bd)
-    w1, b1 = wpack("conv1", blk.conv1, blk.bn1)
-    y, my = be.gemm_h2(xp, w1, bias=b1, relu=True, with_max=True)
-    w2, b2 = wpack("conv2", blk.conv2, blk.bn2, taps=True)
-    y, my = be.conv3x3_rows(y, R, H, W, w2, bias=b2, relu=True, meta=my, with_max=True)     # (taps gathered inside the product where it can)
-    w3, b3 = wpack("conv3", blk.conv3, blk.bn3)
-    return be.gemm_h2(be.packed(y, meta=my), w3, bias=b3, residual=idn, relu=True, with_max=want_max)
+        xp = be.packed(x, meta=x_meta)
+        xf, xm = x, xp.meta
+    if os.environ.get("ODX_DBG_NOCHAIN") == "1":        # (debug: every layer's output packed by a pass of its own)
+        idn = xf if blk.down is None else be.gemm_h2(xp, wpack("down", blk.down[0], blk.down[1])[0], bias=wpack("down", blk.down[0], blk.down[1])[1])
+        w1, b1, _ = wpack("conv1", blk.conv1, blk.bn1)
+        y, my = be.gemm_h2(xp, w1, bias=b1, relu=True, with_max=True)
+        w2, b2, _ = wpack("conv2", blk.conv2, blk.bn2, taps=True)
+        y, my = be.conv3x3_rows(y, R, H, W, w2, bias=b2, relu=True, meta=my, with_max=True)
+        w3, b3, _ = wpack("conv3", blk.conv3, blk.bn3)
+        o, mo = be.gemm_h2(be.packed(y, meta=my), w3, bias=b3, residual=idn, relu=True, with_max=True)
+        return PackedRows(o, o.shape[0], o.shape[1], be.packed(o, meta=mo).P, mo) if pack_out else ((o, mo) if want_max else o)
+    if blk.down is None:
+        idn, im = xf, xm
+    else:
+        wd, bd, _ = wpack("down", blk.down[0], blk.down[1])
+        idn, im = be.gemm_h2(xp, wd, bias=bd, with_max=True)
+    w1, b1, g1 = wpack("conv1", blk.conv1, blk.bn1)
+    y = be.chain_gemm(xp, w1, bias=b1, relu=True, bounds=g1, f32_out=False, zero_row=True)
+    w2, b2, g2 = wpack("conv2", blk.conv2, blk.bn2, taps=True)
+    y = be.chain_conv3x3(y, R, H, W, w2, bias=b2, relu=True, bounds=g2, f32_out=False)
+    w3, b3, g3 = wpack("conv3", blk.conv3, blk.bn3)
+    if pack_out:
+        return be.chain_gemm(y, w3, bias=b3, residual=idn, residual_meta=im, relu=True, bounds=g3, f32_out=True)
+    return be.gemm_h2(y, w3, bias=b3, residual=idn, relu=True, with_max=want_max)
 
 
 def _bottleneck_rows(blk, x, R, H, W):
@@ -464,15 +484,20 @@ class ResNet50C4(_FoldedBN):
         be = _backend.get_backend()
         y = F.max_pool2d(self.conv_bn_act("conv1", "bn1", x), 3, 2, 1)
         B, C, H, W = y.shape
-        rows, meta = y.permute(0, 2, 3, 1).reshape(B * H * W, C), None
-        for blk in self.stages():
+        x, meta = y.permute(0, 2, 3, 1).reshape(B * H * W, C), None
+        blocks = self.stages()
+        for k, blk in enumerate(blocks):
             st = blk.conv1.stride[0]
-            if st > 1:
+            if st > 1:                                              # the rows a strided 1 x 1 convolution reads, packed anew
+                rows, meta = (x.X, x.meta) if hasattr(x, "P") else (x, meta)
                 cut = rows.view(B, H, W, -1)[:, ::st, ::st]
                 H, W = cut.shape[1], cut.shape[2]
-                rows = cut.reshape(B * H * W, -1)                   # (the maximum of the whole matrix bounds that of the cut rows)
-            rows, meta = _bottleneck_rows_h2(be, blk, rows, B, H, W, x_meta=meta, want_max=True)
-        return rows, (B, H, W)
+                x = cut.reshape(B * H * W, -1)                      # (the maximum of the whole matrix bounds that of the cut rows)
+            if k + 1 < len(blocks):
+                x = _bottleneck_rows_h2(be, blk, x, B, H, W, x_meta=meta, pack_out=True)
+            else:
+                x = _bottleneck_rows_h2(be, blk, x, B, H, W, x_meta=meta)
+        return x, (B, H, W)
 
 
 class Conv5Head(nn.Module):
@@ -505,9 +530,9 @@ class Conv5Head(nn.Module):
                     x = _bottleneck_rows_b16(be, blk, x, R, H, W)    # 16-bit activations from block to block, pad columns zero
                 return x.dense.reshape(R, H, W, -1).permute(0, 3, 1, 2)
             if dt == torch.float32 and hasattr(be, "gemm_h2"):
-                meta = None
-                for blk in self.layer4:                              # (each block's output maximum is the next one's packing scale)
-                    rows, meta = _bottleneck_rows_h2(be, blk, rows, R, H, W, x_meta=meta, want_max=True)
+                blocks = list(self.layer4)                           # (a chain: each block hands the next one its packed output)
+                for k, blk in enumerate(blocks):
+                    rows = _bottleneck_rows_h2(be, blk, rows, R, H, W, pack_out=k + 1 < len(blocks))
                 return rows.view(R, H, W, -1).permute(0, 3, 1, 2)
         for blk in self.layer4:
             rows = _bottleneck_rows(blk, rows, R, H, W)

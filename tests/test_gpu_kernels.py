@@ -1300,6 +1300,73 @@ def test_3x3_convolution_with_the_taps_gathered_in_the_operand_loads(R, H, W, C,
         assert float((got.double() - ref).abs().max()) < 2e-6 * float(ref.abs().max())
 
 
+def _unpack_rows(P, meta, n):
+    """The f32 values a packed matrix stands for: (hi + lo) / scale, columns 0 .. n - 1."""
+    raw = P.contiguous().view(torch.float16).view(P.shape[0], -1, 2, 32).float()          # (rows, granules, hi | lo, 32)
+    return ((raw[:, :, 0] + raw[:, :, 1]).reshape(P.shape[0], -1) / meta[0])[:, :n]
+
+
+@pytest.mark.parametrize("m,n,K", [(300, 64, 64), (1000, 250, 576), (70000, 64, 576), (66000, 512, 128), (5, 75, 1024)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_chain_layer_writes_its_output_as_the_next_layers_operand(m, n, K, relu):
+    """odx_gemm_h2_chain_f32: the f32 output = odx_gemm_h2_f32's bit for bit; the packed output stands for the same numbers to
+    the split's 22 bits (relative to the entry down to 2^-11 of the maximum, 2^-30 of the maximum below), its scale keeps the
+    bound inside f16's range, meta[1] is the exact maximum, pad columns are zero, a zero row follows when asked; and a product
+    that takes the packed output as its operand agrees with one that packs the f32 output itself.  Both tile cores, ragged
+    edges, with and without an f32 copy."""
+    import odx
+    be = odx.get_backend()
+    g = torch.Generator().manual_seed(m + n + K)
+    A, B = torch.randn((m, K), generator=g).cuda(), (torch.randn((n, K), generator=g) / K ** 0.5).cuda()
+    bias, res = torch.randn(n, generator=g).cuda(), torch.randn((m, n), generator=g).cuda()
+    pa, pb = be.packed(A), be.packed(B)
+    rp = be.packed(res)                                                       # (its meta words: the residual's maximum)
+    plain = be.gemm_h2(pa, pb, bias=bias, residual=res, relu=relu)
+    bounds = be.weight_bounds(B, bias)
+    for f32_out in (True, False):
+        y = be.chain_gemm(pa, pb, bias=bias, residual=res, residual_meta=rp.meta, relu=relu, bounds=bounds, f32_out=f32_out, zero_row=True)
+        assert (y.X is None) == (not f32_out) and (y.X is None or torch.equal(y.X, plain))
+        assert float(y.meta[1]) == float(plain.abs().max())
+        scale = float(y.meta[0])
+        assert scale * float(plain.abs().max()) < 32768 and scale == 2.0 ** round(np.log2(scale))
+        full = torch.as_strided(y.P, (m + 1, y.P.shape[1]), y.P.stride())       # the rows and the zero row behind them
+        assert int(full[m].abs().max()) == 0
+        val = _unpack_rows(y.P, y.meta, (n + 63) // 64 * 64)
+        assert float(val[:, n:].abs().max()) == 0 if val.shape[1] > n else True
+        err = (val[:, :n].double() - plain.double()).abs()
+        top = float(plain.abs().max())
+        assert bool((err <= 2.0 ** -21 * plain.abs().double() + 2.0 ** -30 * top).all())
+        nxt = (torch.randn((96, n), generator=g) / n ** 0.5).cuda()
+        pn = be.packed(nxt)
+        a, b = be.gemm_h2(y, pn), be.gemm_h2(be.packed(plain), pn)
+        assert float((a - b).abs().max()) < 2e-6 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("R,H,W,C,n", [(1400, 7, 7, 64, 256), (9, 150, 200, 32, 160), (1400, 7, 7, 64, 128), (37, 7, 7, 64, 256),
+                                       (1400, 7, 7, 48, 256)])
+def test_chain_3x3_convolution_from_packed_rows(R, H, W, C, n):
+    """HipBackend.chain_conv3x3 on a chain layer's packed output (taps gathered in the operand loads where the library serves the
+    shape — the first two —, else from the packed rows by odx_taps3x3_packed) against the convolution of the f32 activation
+    in f64; packed and f32 outputs agree."""
+    import odx
+    be = odx.get_backend()
+    g = torch.Generator().manual_seed(R + C + n)
+    m = R * H * W
+    X = torch.randn((m, 64), generator=g).cuda()
+    W1 = (torch.randn((C, 64), generator=g) / 8).cuda()
+    W2 = (torch.randn((n, 9 * C), generator=g) / (9 * C) ** 0.5).cuda()
+    b2 = torch.randn(n, generator=g).cuda()
+    y = be.chain_gemm(be.packed(X), be.packed(W1), relu=True, bounds=be.weight_bounds(W1), f32_out=True, zero_row=True)
+    z = be.chain_conv3x3(y, R, H, W, be.packed(W2), bias=b2, relu=True, bounds=be.weight_bounds(W2, b2), f32_out=True)
+    ref = torch.nn.functional.conv2d(y.X.view(R, H, W, C).permute(0, 3, 1, 2).double(), W2.view(n, 3, 3, C).permute(0, 3, 1, 2).double(),
+                                     b2.double(), padding=1).relu().permute(0, 2, 3, 1).reshape(m, n)
+    top = float(ref.abs().max())
+    assert float((z.X.double() - ref).abs().max()) < 3e-6 * top
+    assert float(z.meta[1]) == float(z.X.abs().max())
+    val = _unpack_rows(z.P, z.meta, n)
+    assert bool(((val.double() - z.X.double()).abs() <= 2.0 ** -21 * z.X.abs().double() + 2.0 ** -30 * top).all())
+
+
 def test_cu_masked_stream_and_partition_sized_pass(be):
     """The diagnostic entry points behind tools/cu_split_probe.py: a stream confined to 16 compute units runs its workgroups
     on at most 16 distinct (XCC, SE, SH, CU) places, two per XCC; a compact pass launched there with its persistent grid sized
