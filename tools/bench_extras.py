@@ -93,7 +93,8 @@ def forward_extra(height=600, width=800, rois=300, reps=8):
         out["ms_per_image_" + name] = round(dt / reps * 1e3, 2)
         out["roofline_" + name] = _forward_roofline(forward_flop_c4(model, height, width, rois), dt / reps * 1e3, name)
     # groups of same-size images through ONE forward each (extract.forward_batch: one trunk call, one proposal stage, one pass
-    # of the RoI head per group) — what the harvest loop runs; the one-image keys above are detect()'s route
+    # of the RoI head per group; in f32 from three images on the trunk stages, the RPN head and the conv5 head are one chain of
+    # row GEMMs on the split-f16 tile cores) — what the harvest loop runs; the one-image keys above are detect()'s route
     for name, cd in (("f32", None), ("bf16", torch.bfloat16)):
         gm = OnlineDetectionModel(post_nms_top_n=rois, compute_dtype=cd).to(dev).eval()
         from odx.extract import forward_batch
