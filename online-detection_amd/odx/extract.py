@@ -438,6 +438,44 @@ def _bottleneck_rows(blk, x, R, H, W):
     return F.relu(y @ w3 + b3 + idn)
 
 
+def _stages_rows_form(stages):
+    """True when these ResNet stages can run as row GEMMs: strides only in the 1 x 1 convolutions that open a block
+    (STRIDE_IN_1X1, the projection beside them with the same stride), 3 x 3 convolutions of stride 1 / padding 1, channels in
+    eights."""
+    for stage in stages:
+        for blk in stage:
+            st = blk.conv1.stride[0]
+            if (blk.conv2.stride[0] != 1 or tuple(blk.conv2.padding) != (1, 1) or blk.conv3.stride[0] != 1
+                    or (blk.down is not None and blk.down[0].stride[0] != st) or (blk.down is None and st != 1)
+                    or blk.conv1.in_channels % 8 or blk.conv2.in_channels % 8 or blk.conv3.out_channels % 8):
+                return False
+    return True
+
+
+def _stages_rows(be, y, stages, pack_last=False):
+    """The stages of a ResNet trunk as one chain of row GEMMs (_bottleneck_rows_h2) behind the stem's output y (B, C, H, W):
+    y becomes NHWC rows once; a block's stride is applied to its input rows (the positions a strided 1 x 1 convolution
+    reads).  Returns, per stage, (out, (B, H, W)): out = the stage's last block's output — backend.PackedRows (f32 rows .X and
+    the packed operand) for every stage but the last, whose output is plain f32 rows unless pack_last."""
+    B, C, H, W = y.shape
+    x, meta, outs = y.permute(0, 2, 3, 1).reshape(B * H * W, C), None, []
+    blocks = [(si, blk) for si, stage in enumerate(stages) for blk in stage]
+    for k, (si, blk) in enumerate(blocks):
+        st = blk.conv1.stride[0]
+        if st > 1:                                              # the rows a strided 1 x 1 convolution reads, packed anew
+            # (a COPY of the producer's meta words: packing the cut rows writes its own scale into them, and the stage's packed
+            # output — the pyramid's lateral convolution reads it — keeps the scale it was written with)
+            rows, meta = (x.X, x.meta.clone()) if hasattr(x, "P") else (x, meta)
+            cut = rows.view(B, H, W, -1)[:, ::st, ::st]
+            H, W = cut.shape[1], cut.shape[2]
+            x = cut.reshape(B * H * W, -1)                      # (the maximum of the whole matrix bounds that of the cut rows)
+        last = k + 1 == len(blocks)
+        x = _bottleneck_rows_h2(be, blk, x, B, H, W, x_meta=meta, pack_out=pack_last or not last)
+        if last or blocks[k + 1][0] != si:
+            outs.append((x, (B, H, W)))
+    return outs
+
+
 def _stage(cin, mid, cout, blocks, stride):
     layers = [Bottleneck(cin, mid, cout, stride)] + [Bottleneck(cout, mid, cout, 1) for _ in range(blocks - 1)]
     return nn.Sequential(*layers)
@@ -460,44 +498,19 @@ class ResNet50C4(_FoldedBN):
         return self.layer3(self.layer2(self.layer1(x)))
 
     def rows_form(self):
-        """True when the stages can run as row GEMMs: strides only in the 1 x 1 convolutions that open a block (STRIDE_IN_1X1,
-        the projection beside them with the same stride), 3 x 3 convolutions of stride 1 / padding 1, channels in eights."""
-        for blk in self.stages():
-            st = blk.conv1.stride[0]
-            if (blk.conv2.stride[0] != 1 or tuple(blk.conv2.padding) != (1, 1) or blk.conv3.stride[0] != 1
-                    or (blk.down is not None and blk.down[0].stride[0] != st) or (blk.down is None and st != 1)
-                    or blk.conv1.in_channels % 8 or blk.conv2.in_channels % 8 or blk.conv3.out_channels % 8):
-                return False
-        return True
-
-    def stages(self):
-        return [blk for stage in (self.layer1, self.layer2, self.layer3) for blk in stage]
+        return _stages_rows_form((self.layer1, self.layer2, self.layer3))
 
     def forward_rows(self, x):
         """The trunk on this library's tile cores (f32 on the GPU): the stem (7 x 7 convolution, max pooling) by the convolution
         library, its output turned ONCE into NHWC rows, and every bottleneck of the three stages as row GEMMs on the split-f16
-        matrix-core path (_bottleneck_rows_h2: f32 accuracy, bias / identity / ReLU in the GEMM epilogues, the 3 x 3
-        convolutions over a 9-tap gather written in packed form) — 60 GFLOP per 600 x 800 image that the library ran as f32
-        Winograd / GEMM convolutions on the vector units plus an epilogue pass per layer.  A block's stride is applied to its
-        input rows (the positions a strided 1 x 1 convolution reads).  Returns (rows (B h w, C) f32, (B, h, w)); the map as
-        the callers know it is rows.view(B, h, w, C).permute(0, 3, 1, 2) — a channels-last view, no copy."""
+        matrix-core path (_stages_rows / _bottleneck_rows_h2: f32 accuracy, bias / identity / ReLU in the GEMM epilogues, the
+        3 x 3 convolutions over a 9-tap gather, every layer writing the next one's packed operand) — 60 GFLOP per 600 x 800
+        image that the library ran as f32 Winograd / GEMM convolutions plus an epilogue pass per layer.  Returns (rows
+        (B h w, C) f32, (B, h, w)); the map as the callers know it is rows.view(B, h, w, C).permute(0, 3, 1, 2) — a
+        channels-last view, no copy."""
         be = _backend.get_backend()
         y = F.max_pool2d(self.conv_bn_act("conv1", "bn1", x), 3, 2, 1)
-        B, C, H, W = y.shape
-        x, meta = y.permute(0, 2, 3, 1).reshape(B * H * W, C), None
-        blocks = self.stages()
-        for k, blk in enumerate(blocks):
-            st = blk.conv1.stride[0]
-            if st > 1:                                              # the rows a strided 1 x 1 convolution reads, packed anew
-                rows, meta = (x.X, x.meta) if hasattr(x, "P") else (x, meta)
-                cut = rows.view(B, H, W, -1)[:, ::st, ::st]
-                H, W = cut.shape[1], cut.shape[2]
-                x = cut.reshape(B * H * W, -1)                      # (the maximum of the whole matrix bounds that of the cut rows)
-            if k + 1 < len(blocks):
-                x = _bottleneck_rows_h2(be, blk, x, B, H, W, x_meta=meta, pack_out=True)
-            else:
-                x = _bottleneck_rows_h2(be, blk, x, B, H, W, x_meta=meta)
-        return x, (B, H, W)
+        return _stages_rows(be, y, (self.layer1, self.layer2, self.layer3))[-1]
 
 
 class Conv5Head(nn.Module):

@@ -30,7 +30,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import backend as _backend
-from .extract import (DELTA_CLAMP, FrozenBatchNorm2d, _FoldedBN, _nms_takes_max_keep, _stage, cell_anchors, decode_deltas, grid_anchors)
+from .extract import (DELTA_CLAMP, FrozenBatchNorm2d, _FoldedBN, _nms_takes_max_keep, _stage, _stages_rows, _stages_rows_form,
+                      cell_anchors, decode_deltas, grid_anchors)
 
 
 class ResNet50Stages(_FoldedBN):
@@ -53,6 +54,15 @@ class ResNet50Stages(_FoldedBN):
         c4 = self.layer3(c3)
         return c2, c3, c4, self.layer4(c4)
 
+    def rows_form(self):
+        return _stages_rows_form((self.layer1, self.layer2, self.layer3, self.layer4))
+
+    def forward_rows(self, x):
+        """The four stages as one chain of row GEMMs on the split-f16 tile cores behind the library's stem (extract._stages_rows):
+        [(backend.PackedRows of C2 .. C5 — f32 rows and packed operand —, (B, h, w))]."""
+        y = F.max_pool2d(self.conv_bn_act("conv1", "bn1", x), 3, 2, 1)
+        return _stages_rows(_backend.get_backend(), y, (self.layer1, self.layer2, self.layer3, self.layer4), pack_last=True)
+
 
 class FeaturePyramid(nn.Module):
     """FPN on C2..C5: inner (lateral 1 x 1) and layer (output 3 x 3) blocks of `out_channels`, top-down by nearest-neighbour
@@ -69,6 +79,7 @@ class FeaturePyramid(nn.Module):
 
     def _apply(self, fn, *a, **kw):
         self._cast = {}
+        self.__dict__.pop("_rows_pack", None)
         return super()._apply(fn, *a, **kw)
 
     def _wb(self, conv, dtype):
@@ -97,6 +108,44 @@ class FeaturePyramid(nn.Module):
             outs.insert(0, self._conv(self.layer[k], last))
         outs.append(F.max_pool2d(outs[-1], 1, 2, 0))
         return tuple(outs)                                   # P2, P3, P4, P5, P6
+
+    def _rows_weights(self, be):
+        """Packed operands of the eight convolutions (lateral 1 x 1: (out, in); output 3 x 3: (out, ky kx in)), remade when a
+        weight is replaced or written in place."""
+        key = tuple((c.weight.data_ptr(), c.weight._version, c.bias._version) for c in list(self.inner) + list(self.layer))
+        hit = self.__dict__.get("_rows_pack")
+        if hit is None or hit[0] != key:
+            inner = [(be.packed(c.weight.detach().float().reshape(c.out_channels, -1).contiguous()), c.bias.detach().float().contiguous())
+                     for c in self.inner]
+            layer = [(be.packed(c.weight.detach().float().permute(0, 2, 3, 1).reshape(c.out_channels, -1).contiguous()),
+                      c.bias.detach().float().contiguous()) for c in self.layer]
+            hit = self.__dict__["_rows_pack"] = (key, inner, layer)
+        return hit[1], hit[2]
+
+    def forward_rows(self, cs):
+        """forward() on the stage outputs of ResNet50Stages.forward_rows — every convolution of the pyramid a product of the
+        split-f16 tile cores over NHWC rows: the lateral 1 x 1 convolutions read the stages' packed operands as the trunk's last
+        products wrote them, the nearest-neighbour upsampling of the top-down path is a row gather, the 3 x 3 output convolutions
+        gather their taps inside the product's operand loads where the library serves the shape (HipBackend.conv3x3_rows).
+        Returns the five levels as contiguous (B, C, h, w) maps — what the RPN head, the proposal stage and the multi-level
+        RoIAlign take (a copy of 1.3 x the bytes of P2 per image)."""
+        be = _backend.get_backend()
+        inner, layer = self._rows_weights(be)
+        outs, last, dims = [], None, None
+        for k in range(len(cs) - 1, -1, -1):
+            x, (B, H, W) = cs[k]
+            lat = be.gemm_h2(x, inner[k][0], bias=inner[k][1])                        # (B H W, C) f32
+            if last is not None:
+                _, Hp, Wp = dims                                                      # F.interpolate(..., mode="nearest") to (H, W)
+                hi = (torch.arange(H, device=lat.device) * Hp) // H
+                wi = (torch.arange(W, device=lat.device) * Wp) // W
+                up = last.view(B, Hp, Wp, -1)[:, hi][:, :, wi]
+                lat = (lat.view(B, H, W, -1) + up).reshape(B * H * W, -1)
+            last, dims = lat, (B, H, W)
+            o = be.conv3x3_rows(lat, B, H, W, layer[k][0], bias=layer[k][1])
+            outs.insert(0, o.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous())
+        outs.append(outs[-1][:, :, ::2, ::2].contiguous())                            # max pooling, kernel 1, stride 2
+        return tuple(outs)
 
 
 class OnlineDetectionModelFPN(nn.Module):
@@ -138,6 +187,8 @@ class OnlineDetectionModelFPN(nn.Module):
         self.online_mask = None
         self._packed = {}
         self._anchor_cache = {}
+        import os
+        self.rows_min_positions = int(os.environ.get("ODX_ROWS_MIN_POSITIONS", 4800))
         from .extract import GraphedCall
         self._trunk_graphs = GraphedCall(self._c4_eager)
         # load_state_dict copies the parameters in place and never goes through _apply: the packed fc weights are derived
@@ -181,6 +232,8 @@ class OnlineDetectionModelFPN(nn.Module):
         in bf16: the RPN head convolves them in bf16 anyway and the RoIAlign launch converts the four levels it pools from —
         five casts to f32 here plus five casts back in the proposal stage were most of what made the bf16 forward SLOWER
         than the f32 one (6.6 against 5.5 ms in round 3's bench line)."""
+        if self._rows_path(image):
+            return self.fpn.forward_rows(self.backbone.forward_rows(image))
         if self.compute_dtype is not None and image.is_cuda:
             # natively in the 16-bit dtype: the folded / cached weights are already in it, and an autocast context costs host
             # time per operation — the bf16 trunk's kernels are shorter than the f32 one's and the forward became host-bound
@@ -189,6 +242,17 @@ class OnlineDetectionModelFPN(nn.Module):
             return tuple(self.fpn(self.backbone(image)))
 
     pyramid = c4
+
+    def _rows_path(self, x):
+        """The f32 trunk and pyramid on the GPU as row GEMMs on the library's tile cores (as OnlineDetectionModel._rows_path: from
+        rows_min_positions stride-16 positions per call on; ODX_TRUNK=conv keeps the convolution library)."""
+        import os
+        if not (x.is_cuda and self.compute_dtype is None and x.dtype == torch.float32 and not torch.is_grad_enabled()
+                and not torch.is_autocast_enabled("cuda") and os.environ.get("ODX_TRUNK", "rows") != "conv"):
+            return False
+        if x.shape[0] * (-(-x.shape[2] // 16)) * (-(-x.shape[3] // 16)) < self.rows_min_positions:
+            return False
+        return hasattr(_backend.get_backend(), "gemm_h2") and self.backbone.rows_form() and self.fpn.out_channels % 8 == 0
 
     @staticmethod
     def trunk_slice(trunk, j):
