@@ -1254,7 +1254,8 @@ class OnlineFeatureExtractor:
             k = max(1, int(self.trunk_batch)) if dev.type == "cuda" else 1
             # (forward_batch: one trunk call and ONE pass of the RoI head for the group; the proposal stage in one go for the C4
             # network, image after image on the pyramid of odx/fpn.py, whose levels it already suppresses with one launch pair)
-            whole = hasattr(m, "proposals_batch") or (hasattr(m, "trunk_slice") and hv_rpn is None and hv_mask is None)
+            whole = ((hasattr(m, "proposals_batch") and not hasattr(m, "trunk_slice"))
+                     or (hasattr(m, "trunk_slice") and hv_rpn is None and hv_mask is None))
             i = 0
             while i < len(seq):
                 group = [seq[i]]

@@ -375,3 +375,32 @@ def test_fpn_features_through_the_online_pipeline(tmp_path):
     model.update_model(models_detection={"classifiers": models, "regressors": regs, "stats": stats})
     res, boxes = detect(model, samples[0][0].cuda(), (256, 192), -2.0, 0.3, 50)
     assert boxes.shape[1] == 4 and (res is None or (len(res["boxes"]) <= 50 and bool(torch.isfinite(res["scores"]).all())))
+
+
+@pytest.mark.gpu
+def test_fpn_proposals_of_a_group_equal_the_per_image_stage():
+    """OnlineDetectionModelFPN.proposals_batch (per level one RPN-head pass and one odx_rpn_topk_decode_f32 launch for the B
+    images, one suppression launch pair over the B x 5 candidate sets, the selection over all levels as one top-k over a padded
+    score matrix) = proposals() image after image: same boxes, same scores, same order; and forward_batch on the pyramid model
+    hands every image what forward() gives it alone."""
+    import odx
+    from odx.extract import forward_batch
+    odx.set_backend(None)
+    odx.get_backend()
+    torch.manual_seed(3)
+    model = OnlineDetectionModelFPN(width=16, fpn_channels=32, mlp_dim=64, pre_nms_top_n=300, post_nms_top_n=100, fpn_post_nms_top_n=150).cuda().eval()
+    model.rpn_logits.weight.data.normal_(0, 0.3)          # well separated objectness, candidates that move and overlap
+    model.rpn_deltas.weight.data.normal_(0, 0.05)
+    x = torch.randn(3, 3, 192, 256).cuda()
+    with torch.no_grad():
+        trunk = model.c4(x)
+        one = [model.proposals(model.trunk_slice(trunk, b), (256, 192)) for b in range(3)]
+        grp = model.proposals_batch(trunk, (256, 192))
+        for (b1, s1), (b2, s2) in zip(one, grp):
+            # (the convolution library may run the head's convolutions of three maps by another algorithm than those of one)
+            assert b1.shape == b2.shape, (b1.shape, b2.shape)
+            assert float((b1 - b2).abs().max()) < 1e-3 and float((s1 - s2).abs().max()) < 1e-6, (float((b1 - b2).abs().max()), float((s1 - s2).abs().max()))
+        per, _, _, _ = forward_batch(model, x, [None, torch.tensor([[10.0, 20.0, 120.0, 150.0]]), None])
+        boxes, feats, _ = model(x[1:2], torch.tensor([[10.0, 20.0, 120.0, 150.0]]))
+        assert per[1][0].shape == boxes.shape and float((per[1][0] - boxes).abs().max()) < 1e-3
+        assert float((per[1][1] - feats).abs().max()) <= 1e-4 * float(feats.abs().max())

@@ -198,6 +198,19 @@ def forward_fpn_extra(height=600, width=800, reps=8):
         out["ms_per_image_" + name] = round(dt_s / reps * 1e3, 2)
         out["rois"], out["feature_dim"] = int(boxes.shape[0]), int(feats.shape[1])
         out["roofline_" + name] = _forward_roofline(forward_flop_fpn(model, height, width, int(boxes.shape[0])), dt_s / reps * 1e3, name)
+        # groups of images of one size through extract.forward_batch: one trunk + pyramid call (f32, three images or more: the
+        # stages and the pyramid as row GEMMs on the split-f16 tile cores), the proposal stage per image, ONE fc6 / fc7 pass
+        from odx.extract import forward_batch
+        for B in (4, 8):
+            imgs = torch.randn((B, 3, height, width), device=dev, generator=g)
+            with torch.no_grad():
+                for _ in range(3):
+                    forward_batch(model, imgs)
+                dt_g, _ = _best_time(lambda: [forward_batch(model, imgs) for _ in range(3)])
+            ms = dt_g / (3 * B) * 1e3
+            out["ms_per_image_%s_group%d" % (name, B)] = round(ms, 2)
+            if B == 8:
+                out["roofline_%s_group8" % name] = _forward_roofline(forward_flop_fpn(model, height, width, int(boxes.shape[0])), ms, name)
         del model
     out["note"] = ("trunk + pyramid replayed from a HIP graph per image size (extract.GraphedCall): launch by launch this forward was "
                    "host-bound at batch 1 and a 16-bit trunk, whose kernels are shorter, gained nothing (5.1-6.4 ms against 5.0-5.3 in "
