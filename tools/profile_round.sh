@@ -22,7 +22,7 @@ if [ "$PART" = "1" ]; then
   done
   rm -f $OUT/bench_kernel_trace.csv
 else
-  for job in "rls tools/prof_rls.py" "forward tools/prof_forward.py both 10" "forward_b4 tools/prof_forward_batch.py 4 f32" "forward_b4_bf16 tools/prof_forward_batch.py 4 bf16" "minibootstrap tools/prof_minibootstrap.py"; do
+  for job in "rls tools/prof_rls.py" "forward tools/prof_forward.py both 10" "forward_b4 tools/prof_forward_batch.py 4 f32" "forward_b4_bf16 tools/prof_forward_batch.py 4 bf16" "forward_b8 tools/prof_forward_batch.py 8 f32" "forward_fpn_b8 tools/prof_forward_batch.py 8 f32 fpn" "minibootstrap tools/prof_minibootstrap.py"; do
     set -- $job
     tag=$1; shift
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o x_$tag -- python "$@" > $OUT/x_$tag.out 2> $OUT/x_$tag.err

@@ -174,9 +174,33 @@ for tag, title, want in (("forward", "feature forward: R-50-C4 and R-50-FPN, 10 
             pmc_lines(d, "xpmc_%s_" % tag, want)
 
 for tag, title in (("forward_b4", "R-50-C4 forward, FOUR 600 x 800 images per call (extract.forward_batch), f32, 15 calls (tools/prof_forward_batch.py 4 f32)"),
-                   ("forward_b4_bf16", "the same in bf16 (compute_dtype = bfloat16: trunk by the library in bf16, head on odx_gemm_b16)")):
+                   ("forward_b4_bf16", "the same in bf16 (compute_dtype = bfloat16: trunk by the library in bf16, head on odx_gemm_b16)"),
+                   ("forward_b8", "R-50-C4 forward, EIGHT images per call, f32: trunk stages, RPN head and conv5 head as one chain of row GEMMs "
+                                  "(tools/prof_forward_batch.py 8 f32)"),
+                   ("forward_fpn_b8", "R-50-FPN forward, EIGHT images per call, f32: trunk stages and pyramid as row GEMMs, the proposal stage per "
+                                      "level for the group (tools/prof_forward_batch.py 8 f32 fpn)")):
     sp = os.path.join(d, "x_%s_kernel_stats.csv" % tag)
     if os.path.exists(sp):
-        stats_table(sp, rows=16, skip=("naive_conv",), title="## %s\n\n(whole-process statistics, 15 calls = 60 images; the convolution library's "
+        stats_table(sp, rows=16, skip=("naive_conv",), title="## %s\n\n(whole-process statistics, 15 calls; the convolution library's "
                     "solver search on the first calls runs its naive reference kernels once per shape — left out of the table; the percentages "
                     "are of the process's total including them)\n" % title)
+
+for tag, anchor in (("forward_b8", "max_pool"), ("forward_fpn_b8", "max_pool")):
+    tp = os.path.join(d, "x_%s_kernel_trace.csv" % tag)
+    if os.path.exists(tp):
+        import csv as _csv
+        rows = sorted(_csv.DictReader(open(tp)), key=lambda r: int(r["Start_Timestamp"]))
+        idx = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
+        if idx:
+            i0 = idx[-1]
+            t0 = int(rows[i0]["Start_Timestamp"])
+            print("\n### kernel timeline of the last call of %s (us from its max pooling; launches of 20 us and more)\n" % tag)
+            print("| start | us | kernel | grid |\n|---|---|---|---|")
+            busy = 0.0
+            for r in rows[max(i0 - 3, 0):]:
+                dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+                busy += dur
+                if dur >= 20:
+                    print("| %.0f | %.1f | `%s` | %s |" % ((int(r["Start_Timestamp"]) - t0) / 1e3, dur,
+                                                         r["Kernel_Name"].replace("odx::", "").replace("void ", "")[:60], r["Grid_Size_X"]))
+            print("\nGPU busy from the stem on: %.2f ms for the call's 8 images\n" % (busy / 1e3))
