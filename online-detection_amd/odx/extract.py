@@ -26,7 +26,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import backend as _backend
-from .harvest import DetectorHarvester, MaskHarvester, RPNHarvester, project_masks_on_boxes
+from .harvest import DetectorHarvester, MaskHarvester, RPNHarvester, project_masks_on_boxes, to_device
 from .heads import OnlineBoxPredictor, OnlineMaskPredictor, OnlineRPNHead  # noqa: F401
 
 
@@ -810,6 +810,18 @@ class OnlineDetectionModel(nn.Module):
                 setattr(self, attr, cls())
             getattr(self, attr).set_models(models["classifiers"], models.get("regressors"), models["stats"])
 
+    def grid_anchors(self, h, w, device):
+        """grid_anchors(h, w, stride, cells) on `device`, kept per map size: the cell anchors are a host tensor, and a host ->
+        device copy per image waits for whatever the GPU is running (harvest.to_device)."""
+        cache = self.__dict__.setdefault("_anchor_cache", {})
+        key = (int(h), int(w), str(device))
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) > 16:
+                cache.clear()
+            hit = cache[key] = grid_anchors(h, w, self.stride, self.cells.to(device))
+        return hit
+
     def rpn_activation(self, c4):
         cv = self.rpn_conv
         if (self._rows_path(c4) and c4.shape[1] % 8 == 0 and tuple(cv.kernel_size) == (3, 3) and tuple(cv.stride) == (1, 1)
@@ -851,7 +863,7 @@ class OnlineDetectionModel(nn.Module):
             logits, deltas = self.online_rpn(t)
         else:
             logits, deltas = self.rpn_outputs(t)
-        anchors = grid_anchors(c4.shape[2], c4.shape[3], self.stride, self.cells.to(c4.device))
+        anchors = self.grid_anchors(c4.shape[2], c4.shape[3], c4.device)
         return rpn_proposals(logits, deltas, anchors, img_size, self.pre_nms_top_n, self.post_nms_top_n, self.rpn_nms)
 
     @torch.no_grad()
@@ -866,7 +878,7 @@ class OnlineDetectionModel(nn.Module):
         if t is None:
             t = self.rpn_activation(c4)
         logits, deltas = self.rpn_outputs(t)
-        anchors = grid_anchors(c4.shape[2], c4.shape[3], self.stride, self.cells.to(c4.device))
+        anchors = self.grid_anchors(c4.shape[2], c4.shape[3], c4.device)
         return rpn_proposals_batch(logits, deltas, anchors, img_size, self.pre_nms_top_n, self.post_nms_top_n, self.rpn_nms)
 
     def _group_static(self, images, gt_slots, anchors):
@@ -923,12 +935,7 @@ class OnlineDetectionModel(nn.Module):
                 if G[b]:
                     gt_slots[b, :G[b]] = g.to(dev).float()
         h, w = -(-images.shape[2] // self.stride), -(-images.shape[3] // self.stride)          # the C4 map: ceil(size / 16)
-        akey = (h, w, str(dev))
-        anchors = self.__dict__.setdefault("_anchor_cache", {}).get(akey)
-        if anchors is None:
-            if len(self._anchor_cache) > 16:
-                self._anchor_cache.clear()
-            anchors = self._anchor_cache[akey] = grid_anchors(h, w, self.stride, self.cells.to(dev))
+        anchors = self.grid_anchors(h, w, dev)
         out = self._group_graphs(images, gt_slots, anchors, key_extra=(self.pre_nms_top_n, self.post_nms_top_n, self.rpn_nms,
                                                                        self.compute_dtype, self.resolution), capture=capture)
         return (out, G, gpad)
@@ -942,7 +949,8 @@ class OnlineDetectionModel(nn.Module):
         n = n.tolist()
         P = slots.shape[1] - gpad
         sel = torch.tensor([b * (gpad + P) + j for b in range(B) for j in list(range(G[b])) + list(range(gpad, gpad + n[b]))],
-                           dtype=torch.int64).to(dev)       # (a blocking copy: the host list is a temporary)
+                           dtype=torch.int64)
+        sel = to_device(sel, dev)                           # (staged through page-locked memory: the host list is a temporary)
         boxes_all, feats_all = slots.view(-1, 4).index_select(0, sel), feats.index_select(0, sel)
         out, at = [], 0
         for b in range(B):
@@ -1013,6 +1021,13 @@ class OnlineDetectionModel(nn.Module):
         return boxes, self.roi_features(c4, boxes), c4
 
 
+def _model_anchors(m, h, w, dev):
+    """The anchors of an (h, w) map of model m on dev: the model's cached ones when it keeps them (OnlineDetectionModel.grid_anchors)."""
+    if hasattr(m, "grid_anchors"):
+        return m.grid_anchors(h, w, dev)
+    return grid_anchors(h, w, m.stride, m.cells.to(dev))
+
+
 def forward_batch(model, images, gt_boxes_list=None, want_rpn_activation=False):
     """OnlineDetectionModel.forward for B pre-processed images of ONE size, images (B, 3, H, W): one trunk call (replayed from
     a HIP graph per shape), one proposal stage (proposals_batch) and ONE pass of the RoI head over all images' RoIs — at batch
@@ -1040,7 +1055,8 @@ def forward_batch(model, images, gt_boxes_list=None, want_rpn_activation=False):
             bx = torch.cat((gt.to(bx.device).float(), bx), dim=0)
         boxes_list.append(bx)
     counts = [int(bx.shape[0]) for bx in boxes_list]
-    bidx = torch.repeat_interleave(torch.arange(B, device=tr0.device), torch.tensor(counts, device=tr0.device))
+    # (host lists go up through harvest.to_device: a plain copy of pageable memory waits for whatever the GPU is running)
+    bidx = torch.repeat_interleave(torch.arange(B, device=tr0.device), to_device(torch.tensor(counts, dtype=torch.int64), tr0.device))
     maps = model.roi_head_maps(trunk, torch.cat(boxes_list, dim=0), batch_idx=bidx)
     feats = maps.mean(dim=(2, 3))
     offs = [0]
@@ -1163,7 +1179,7 @@ class OnlineFeatureExtractor:
                     c4 = m.c4(image)
                 t_act = None
                 if hv_rpn is not None and len(gt_boxes):
-                    item["anchors"] = grid_anchors(c4.shape[2], c4.shape[3], m.stride, m.cells.to(dev))
+                    item["anchors"] = _model_anchors(m, c4.shape[2], c4.shape[3], dev)
                     t_act = m.rpn_activation(c4)
                     item["t"] = t_act[0]
                 if hv_det is None and hv_mask is None:
@@ -1204,12 +1220,23 @@ class OnlineFeatureExtractor:
             gts = [u[1].to(dev).float() for u in unp]
             img_size = (images.shape[3], images.shape[2])
             items = [{"gt_boxes": gts[j], "gt_labels": list(unp[j][2]), "img_size": img_size} for j in range(len(group))]
+            gts_host = None
+            if hv_mask is not None and any(u[3] is not None and len(u[2]) for u in unp):
+                # the crop windows of the mask projection are decided on the host: the group's boxes in ONE read (none at all
+                # for boxes handed in on the host), not one per image
+                if all(not torch.as_tensor(u[1]).is_cuda for u in unp):
+                    gts_host = [torch.as_tensor(u[1]).float().reshape(-1, 4).tolist() for u in unp]
+                else:
+                    flat, at, gts_host = torch.cat([g.reshape(-1, 4) for g in gts]).tolist(), 0, []
+                    for g in gts:
+                        gts_host.append(flat[at:at + len(g)])
+                        at += len(g)
             need_heads = hv_det is not None or hv_mask is not None
             want_t = hv_rpn is not None and any(len(g) for g in gts)
             if graphed is not None:
                 # a full group: the whole forward replayed from one HIP graph (no host work but the copies in and out)
                 res = m.forward_group_finish(graphed)
-                anchors = grid_anchors(res[0]["t"].shape[1], res[0]["t"].shape[2], m.stride, m.cells.to(dev)) if want_t else None
+                anchors = _model_anchors(m, res[0]["t"].shape[1], res[0]["t"].shape[2], dev) if want_t else None
                 for j, (it, r) in enumerate(zip(items, res)):
                     it["boxes"] = r["boxes"]
                     if hv_det is not None:
@@ -1219,7 +1246,7 @@ class OnlineFeatureExtractor:
                     masks = unp[j][3]
                     if hv_mask is not None and masks is not None and len(it["gt_labels"]) and r["act"] is not None:
                         it["act"] = r["act"]
-                        it["mg"] = project_masks_on_boxes(masks.to(dev), gts[j], it["act"].shape[2])
+                        it["mg"] = project_masks_on_boxes(masks.to(dev), gts[j], it["act"].shape[2], boxes_host=None if gts_host is None else gts_host[j])
                 return items
             with torch.no_grad():
                 ts = None
@@ -1232,7 +1259,7 @@ class OnlineFeatureExtractor:
                 if want_t:
                     if ts is None:
                         ts = m.rpn_activation(c4s)
-                    anchors = grid_anchors(c4s.shape[2], c4s.shape[3], m.stride, m.cells.to(dev))
+                    anchors = _model_anchors(m, c4s.shape[2], c4s.shape[3], dev)
                     for j, it in enumerate(items):
                         if len(gts[j]):
                             it["anchors"], it["t"] = anchors, ts[j]
@@ -1244,7 +1271,7 @@ class OnlineFeatureExtractor:
                         masks = unp[j][3]
                         if hv_mask is not None and masks is not None and len(it["gt_labels"]):
                             it["act"] = m.mask_activation(maps[offs[j]:offs[j] + len(it["gt_labels"])])
-                            it["mg"] = project_masks_on_boxes(masks.to(dev), gts[j], it["act"].shape[2])
+                            it["mg"] = project_masks_on_boxes(masks.to(dev), gts[j], it["act"].shape[2], boxes_host=None if gts_host is None else gts_host[j])
             return items
 
         def forward_items(seq):
@@ -1263,19 +1290,26 @@ class OnlineFeatureExtractor:
                     shape = tuple(_unpack(seq[i])[0].shape)
                     while len(group) < k and i + len(group) < len(seq) and tuple(_unpack(seq[i + len(group)])[0].shape) == shape:
                         group.append(seq[i + len(group)])
+                # ("_end": the last image of its group — the consumer harvests a group's images together, harvest_group)
                 if len(group) == 1:
-                    yield forward_one(group[0])
+                    item = forward_one(group[0])
+                    item["_end"] = True
+                    yield item
                 elif whole:
                     # (a full group from one HIP graph — but only on the caller's own thread: the two-thread loop below keeps to
                     # plain launches, a capture or replay beside another thread's launches faulted on this runtime)
-                    for item in forward_group(group, None if in_thread[0] else group_begin(group)):
+                    items = forward_group(group, None if in_thread[0] else group_begin(group))
+                    items[-1]["_end"] = True
+                    for item in items:
                         yield item
                 else:
                     with torch.no_grad():
                         c4s = m.c4(torch.cat([_unpack(smp)[0].to(dev) for smp in group], dim=0))
                     cut = getattr(m, "trunk_slice", None)          # (a pyramid is sliced level by level: odx/fpn.py)
                     for j, smp in enumerate(group):
-                        yield forward_one(smp, cut(c4s, j) if cut is not None else c4s[j:j + 1])
+                        item = forward_one(smp, cut(c4s, j) if cut is not None else c4s[j:j + 1])
+                        item["_end"] = j + 1 == len(group)
+                        yield item
                 i += len(group)
 
         def harvest_one(item):
@@ -1286,6 +1320,46 @@ class OnlineFeatureExtractor:
                 hv_det.add_image(item["feats"], item["boxes"], item["gt_boxes"], item["gt_labels"], list(item["img_size"]))
             if "act" in item:
                 hv_mask.add_image(item["act"], item["mg"], item["gt_labels"])
+
+        def harvest_group(items):
+            """harvest_one for the images of a group with ONE host read: every harvester's device work in front of its host
+            decisions for all images (prepare: stateless), the counts of all of them in one copy, then the stateful parts image
+            by image in the order harvest_one has (commit: RNG draws, batch bookkeeping, rows into the buffers) — same rows,
+            same draws.  Image by image each of the three harvesters reads its own counts, and every such read waits for its
+            few small kernels to get their turn beside the next group's forward (~0.5 ms each, four per image)."""
+            if len(items) < 2 or dev.type != "cuda":
+                for item in items:
+                    harvest_one(item)
+                return
+            ctxs, blocks = [], []
+            for item in items:
+                c = {}
+                if "t" in item:
+                    c["rpn"] = hv_rpn.prepare(item["t"], item["anchors"], item["img_size"], item["gt_boxes"])
+                if "feats" in item:
+                    c["det"] = hv_det.prepare(item["feats"], item["boxes"], item["gt_boxes"], item["gt_labels"], list(item["img_size"]))
+                if "act" in item:
+                    c["mask"] = hv_mask.prepare(item["act"], item["mg"], item["gt_labels"])
+                ctxs.append(c)
+                blocks.extend(x["block"] for x in c.values() if x is not None and x["block"] is not None)
+            host = torch.cat([b.reshape(-1).to(torch.float64) for b in blocks]).tolist() if blocks else []     # counts: exact in f64
+            at = [0]
+
+            def take(x, as_int):
+                if x is None or x["block"] is None:
+                    return []
+                n = x["block"].numel()
+                vals = host[at[0]:at[0] + n]
+                at[0] += n
+                return [int(v) for v in vals] if as_int else vals
+            got = [{k: take(c[k], k != "rpn") for k in ("rpn", "det", "mask") if k in c} for c in ctxs]      # (the order blocks were listed in)
+            for c, g in zip(ctxs, got):
+                if "rpn" in c:
+                    hv_rpn.commit(c["rpn"], g["rpn"])
+                if "det" in c:
+                    hv_det.commit(c["det"], g["det"])
+                if c.get("mask") is not None:
+                    hv_mask.commit(c["mask"], g["mask"])
 
         def split_groups(seq):
             k = max(1, int(self.trunk_batch)) if dev.type == "cuda" else 1
@@ -1339,7 +1413,7 @@ class OnlineFeatureExtractor:
                         for v in item.values():
                             if torch.is_tensor(v) and v.is_cuda:
                                 v.record_stream(harv)
-                        harvest_one(item)
+                    harvest_group(items)
             fwd.synchronize()
         elif dev.type == "cuda" and self.pipeline and len(samples) > 1:
             import queue
@@ -1398,6 +1472,7 @@ class OnlineFeatureExtractor:
             th = threading.Thread(target=producer, daemon=True)
             th.start()
             try:
+                pending = []
                 while True:
                     item, ev = q.get()
                     if item is None:
@@ -1408,7 +1483,11 @@ class OnlineFeatureExtractor:
                     for v in item.values():
                         if torch.is_tensor(v) and v.is_cuda:
                             v.record_stream(main)
-                    harvest_one(item)
+                    pending.append(item)
+                    if item.get("_end", True):                       # the group is complete: one host read for its images
+                        harvest_group(pending)
+                        pending = []
+                harvest_group(pending)
             finally:
                 stop.set()                      # a failed harvest must not leave the forward thread blocked on the queue
                 th.join()

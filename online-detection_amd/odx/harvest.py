@@ -24,17 +24,69 @@ of all ground-truth boxes come from one nonzero() and one copy per buffer.  The 
 reference fixes there: the order of the global RNG draws and the integer bookkeeping of open batches.
 """
 import math
+import os
+import threading
 
 import numpy as np
 import torch
 
 
+class _Staging:
+    """One page-locked block per host thread, split in two halves that are filled in turn: a small host tensor is copied into the
+    next free bytes and goes to the device from there with an ASYNCHRONOUS copy.  A half is entered again only after the copies
+    issued from it the last time have completed (one event per stream that used it, recorded when the half was left; by then
+    the other half — a megabyte of index lists, tens of images — has gone by, so the wait is never a wait)."""
+    HALF = 1 << 20
+
+    def __init__(self):
+        self.buf = torch.empty(2 * self.HALF, dtype=torch.uint8).pin_memory()
+        self.half, self.off = 0, 0
+        self.used = [set(), set()]          # streams that copied out of each half since it was entered
+        self.fence = [[], []]               # events behind the last copies out of each half
+
+    def put(self, host, device):
+        n = host.numel() * host.element_size()
+        if self.off + n > self.HALF:
+            self.fence[self.half] = []
+            for st in self.used[self.half]:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self.fence[self.half].append(ev)
+            self.half, self.off = 1 - self.half, 0
+            for ev in self.fence[self.half]:
+                ev.synchronize()
+            self.used[self.half] = set()
+        base = self.half * self.HALF + self.off
+        slot = self.buf[base:base + n].view(host.dtype).view(host.shape)
+        slot.copy_(host)
+        self.off += (n + 63) // 64 * 64
+        out = torch.empty(host.shape, dtype=host.dtype, device=device)
+        out.copy_(slot, non_blocking=True)
+        self.used[self.half].add(torch.cuda.current_stream(out.device))
+        return out
+
+
+_staging = threading.local()
+
+
 def to_device(host, device):
-    """A small host tensor (index lists, draws) on `device`: a plain blocking copy.  (Tried in round 5 and dropped: the same
-    through page-locked memory as an asynchronous copy, so that the host does not wait for the stream at every index list —
-    a freshly pinned block per list cost 12 ms per image, a ring of pinned buffers allocated once 24 ms against 1.4 ms for
-    the detector harvester with plain copies; tools/harvest_split_probe.py.)"""
-    return host.to(device)
+    """A small host tensor (index lists, draws, labels) on `device`: a plain copy.  ODX_STAGED_UPLOADS=1: through a persistent
+    page-locked staging block and an asynchronous copy (_Staging) — in isolation the difference is large (a `.to(device)` of
+    pageable memory waits, on the host, for whatever the GPU is running: 1.5 ms per copy beside a busy stream against 15-20 us
+    staged, tools/h2d_probe.py; the harvesters make ~11 such copies per image beside the next group's forward), but the harvest
+    loop as a whole did not move with it (4.4-6.3 ms per image run to run either way: the wait only moves to the group's one
+    host read — what the loop waits for is the harvesters' ~100 small dependent kernels per image getting their turn beside the
+    forward's chip-filling products).  Opt-in until that is understood.  (Round 5 had also tried a freshly pinned block per
+    list: 12 ms per image, the allocation.)"""
+    device = torch.device(device)
+    nbytes = host.numel() * host.element_size()
+    if (device.type != "cuda" or host.is_cuda or nbytes == 0 or nbytes > _Staging.HALF // 4 or not host.is_contiguous()
+            or os.environ.get("ODX_STAGED_UPLOADS", "0") != "1"):
+        return host.to(device)
+    st = getattr(_staging, "block", None)
+    if st is None:
+        st = _staging.block = _Staging()
+    return st.put(host, device)
 
 
 def box_iou_plus1(gt, prop):
@@ -210,7 +262,16 @@ class DetectorHarvester:
     # ------------------------------------------------------------------ train time
     def add_image(self, x, proposals, gt_bbox, gt_labels_list, img_size):
         """x (R, D) pooled features of `proposals` (R, 4) whose first len(gt) rows are the ground
-        truth boxes; gt_bbox (G, 4); gt_labels_list: class ids 1..C of the G boxes."""
+        truth boxes; gt_bbox (G, 4); gt_labels_list: class ids 1..C of the G boxes.
+        = commit(prepare(...)) with the image's own host read; a caller that harvests several images at a time (the feature
+        extractor's group loop) prepares them all, reads every harvester's counts in ONE copy and commits image by image."""
+        ctx = self.prepare(x, proposals, gt_bbox, gt_labels_list, img_size)
+        self.commit(ctx, ctx["block"].tolist() if ctx["block"] is not None else [])
+
+    def prepare(self, x, proposals, gt_bbox, gt_labels_list, img_size):
+        """Everything of add_image that runs on the device BEFORE the host has to decide anything, and nothing that reads or
+        changes this object's state: overlaps, associations, the regression pairs' flags, the negatives' candidate flags of
+        every class present in the image.  ctx["block"]: the counts the host needs (device, int64) or None."""
         if self.negatives_to_pick is None:
             self.negatives_to_pick = math.ceil((self.batch_size * self.iterations) / self.num_images)
         x = x.reshape(x.size(0), -1)
@@ -228,26 +289,39 @@ class DetectorHarvester:
             best, arg = iou.max(dim=0)
             first = (iou == best[None, :]).float().argmax(dim=0)
             assoc = torch.where(best > 0, first, assoc)
-        prop_d = prop.to(x.device)
+        ctx = {"x": x, "overlap": overlap, "labels": list(gt_labels_list), "R": R, "G": G, "block": None}
         if G:
             # All ground-truth boxes at once (the reference walks them one by one, box_head_getProposals.py:151-226):
-            # sel[j, r] = proposal r regresses onto box j; nonzero() lists the pairs box-major, row-minor — the order of
-            # the reference's appends — with one host synchronisation per image instead of several per box.
+            # sel[j, r] = proposal r regresses onto box j; the pairs are listed box-major, row-minor — the order of the
+            # reference's appends — by a stable sort of the flags (commit), without nonzero()'s synchronisation.
             cls = to_device(torch.tensor([l - 1 for l in gt_labels_list], dtype=torch.int64), x.device)
+            sel = (overlap[:, cls].t() > self.reg_min_overlap) & (assoc[None, :] == torch.arange(G, device=x.device)[:, None])
+            # ONE host read per image for this harvester: the rows per ground-truth box and the negatives' candidate counts of
+            # the classes in the image (which of them still collect negatives is this object's state: commit picks the columns)
+            in_image = sorted({l - 1 for l in gt_labels_list if 0 <= l - 1 < self.num_classes})
+            cmask = (overlap[:, in_image] < self.neg_iou_thresh) if in_image else None                   # (R, len(in_image))
+            ctx.update(prop_d=prop.to(x.device), cls=cls, sel=sel, in_image=in_image, cmask=cmask,
+                       block=torch.cat((sel.sum(1), cmask.sum(0))) if in_image else sel.sum(1))
+        return ctx
+
+    def commit(self, ctx, both):
+        """The stateful rest of add_image: `both` = ctx["block"] on the host."""
+        x, overlap, gt_labels_list, R, G = ctx["x"], ctx["overlap"], ctx["labels"], ctx["R"], ctx["G"]
+        if G:
+            prop_d, cls, sel = ctx["prop_d"], ctx["cls"], ctx["sel"]
             if self.compute_gt_positives:
                 for c in sorted(set(gt_labels_list)):                      # rows of a class in ground-truth order
                     rows_c = [i for i, l in enumerate(gt_labels_list) if l == c]
                     self._pos[c - 1].append(x[rows_c].view(-1, self.D), seg_lens=[1] * len(rows_c))
-            sel = (overlap[:, cls].t() > self.reg_min_overlap) & (assoc[None, :] == torch.arange(G, device=x.device)[:, None])
-            # ONE host read per image for this harvester: the rows per ground-truth box (here) and the negatives' candidate counts
-            # of the classes present (_sample_all) come over together; the pairs themselves are listed on the device by a stable
-            # sort of the flags (box-major, row-minor: the order nonzero() gives, without its synchronisation)
             classes_neg = list(range(self.num_classes)) if self.shuffle_negatives else list(self.still_to_complete)
             present = [i for i in classes_neg if i + 1 in gt_labels_list]
-            cmask = (overlap[:, present] < self.neg_iou_thresh) if present else None                     # (R, len(present))
-            both = torch.cat((sel.sum(1), cmask.sum(0))) if present else sel.sum(1)
-            both = both.tolist()
-            seg, ccounts = both[:G], both[G:]
+            seg, call = both[:G], both[G:]
+            cols = [ctx["in_image"].index(i) for i in present]
+            if cols == list(range(len(ctx["in_image"]))):
+                cmask, ccounts = ctx["cmask"], call
+            else:
+                cmask = ctx["cmask"][:, cols] if cols else None
+                ccounts = [call[c] for c in cols]
             flat = torch.argsort((~sel).reshape(-1).to(torch.int8), stable=True)[:sum(seg)]
             j_idx, r_idx = flat // R, flat % R
             ex, tgt = prop_d[r_idx], prop_d[j_idx]                          # tgt: the prepended ground-truth rows
@@ -440,6 +514,13 @@ class RPNHarvester:
         reference (and this class until round 4) read them piece by piece, a synchronisation for the candidates, one for the
         positives and two per ground-truth box, each of which waits for the harvest's kernels to get their turn beside the
         next images' forward."""
+        ctx = self.prepare(t, anchors_all, img_size, gt_bbox)
+        self.commit(ctx, ctx["block"].tolist())
+
+    def prepare(self, t, anchors_all, img_size, gt_bbox):
+        """The device work of add_image in front of its host read, independent of this object's batch state; ctx["block"]: what
+        the host needs (device, f64).  A caller harvesting several images at a time reads the blocks of all of them — and of the
+        other harvesters — in one copy and commits image by image (OnlineFeatureExtractor's group loop)."""
         if self.negatives_to_pick is None:
             self.negatives_to_pick = math.ceil((self.batch_size * self.iterations) / self.num_images)
         if self.anchors is None:
@@ -457,7 +538,6 @@ class RPNHarvester:
             assoc = gt[0].expand(self.anchors.shape[0], 4)
         neg_mask = ious < self.neg_iou_thresh
         over = ious > self.pos_iou_thresh
-        types = list(self.still_to_complete if not self.shuffle_negatives else range(A))
         onehot = self.cls[:, None] == torch.arange(A, device=dev)[None, :]           # (n_vis, A)
         # per ground-truth box j (the reference walks them in order):
         #   mine_j   anchors associated with a box equal to box j in all four coordinates
@@ -474,7 +554,14 @@ class RPNHarvester:
                            mine.any(dim=1).to(f64),                                   # G      box j has anchors at all
                            (over[:, None] & onehot).sum(0).to(f64),                   # A      positives over the threshold per type
                            (extra[:, :, None] & onehot[None, :, :]).sum(1).reshape(-1).to(f64),     # G A    extras of box j per type
-                           gt.reshape(-1).to(f64))).tolist()                          # 4 G    the boxes (for the coordinate test)
+                           gt.reshape(-1).to(f64)))                                   # 4 G    the boxes (for the coordinate test)
+        return {"t": t, "G": G, "block": block, "neg_mask": neg_mask, "over": over, "extra": extra, "assoc": assoc}
+
+    def commit(self, ctx, block):
+        """The stateful rest of add_image: `block` = ctx["block"] on the host."""
+        t, G, neg_mask, over, extra, assoc = ctx["t"], ctx["G"], ctx["neg_mask"], ctx["over"], ctx["extra"], ctx["assoc"]
+        dev, A = t.device, self.A
+        types = list(self.still_to_complete if not self.shuffle_negatives else range(A))
         counts = [int(v) for v in block[:A]]
         hit = block[A:A + G]
         has_mine = block[A + G:A + 2 * G]
@@ -585,7 +672,7 @@ class RPNHarvester:
         return negatives, positives, COXY
 
 
-def project_masks_on_boxes(masks, boxes, M):
+def project_masks_on_boxes(masks, boxes, M, boxes_host=None):
     """Crop each object's full-image binary mask to its box and resize to M x M
     (mask_head_getProposals.py:15-46 -> SegmentationMask.crop / resize of maskrcnn_benchmark's binary-mask
     representation: integer-rounded crop window, bilinear resize without corner alignment, truncated
@@ -600,7 +687,7 @@ def project_masks_on_boxes(masks, boxes, M):
         return torch.empty(0, dtype=torch.float32, device=masks.device)
     H, W = masks.shape[1], masks.shape[2]
     win = []
-    for bx in boxes.tolist():                                   # one host read for all objects
+    for bx in (boxes.tolist() if boxes_host is None else boxes_host):    # one host read for all objects (none when the caller has them)
         x1, y1, x2, y2 = [int(round(float(v))) for v in bx]
         x1, y1 = min(max(x1, 0), W - 1), min(max(y1, 0), H - 1)
         x2, y2 = min(max(x2, 0), W - 1), min(max(y2, 0), H - 1)
@@ -665,15 +752,27 @@ class MaskHarvester:
         pixel index inside each group, as torch.where lists them), the sizes come to the host in one read, the random
         sub-sampling draws are made object by object, positives then negatives, from the global RNG as in the reference,
         and every class buffer receives one copy."""
+        ctx = self.prepare(mask_features, masks_gt, gt_labels_list)
+        if ctx is not None:
+            self.commit(ctx, ctx["block"].tolist())                               # the one host read
+
+    def prepare(self, mask_features, masks_gt, gt_labels_list):
+        """The device work in front of add_image's host read (stateless); None for an image without objects."""
         G = len(mask_features)
         if G == 0:
-            return
+            return None
         D, S2 = mask_features.size(1), mask_features.size(2) * mask_features.size(3)
         dev = mask_features.device
         rows = mask_features.permute(0, 2, 3, 1).reshape(G * S2, D)
         is_pos = masks_gt.reshape(G, S2).to(dev) >= 0.5
         order = torch.argsort((~is_pos).to(torch.int8), dim=1, stable=True)        # positives first, each group ascending
-        npos = is_pos.sum(1).tolist()                                             # the one host read
+        return {"G": G, "S2": S2, "rows": rows, "order": order, "labels": list(gt_labels_list), "block": is_pos.sum(1)}
+
+    def commit(self, ctx, npos):
+        """The draws and the copies of add_image: npos = ctx["block"] on the host."""
+        G, S2, rows, order, gt_labels_list = ctx["G"], ctx["S2"], ctx["rows"], ctx["order"], ctx["labels"]
+        dev = rows.device
+        npos = [int(v) for v in npos]
         picks = {}                                                                # (class, kind) -> [(object, tensor of local picks)]
         for i in range(G):
             c = gt_labels_list[i] - 1
