@@ -268,3 +268,31 @@ def test_rpn_positives_with_one_host_read_equal_the_box_by_box_walk(device):
     assert n_extra > 0                                  # the scenes do exercise the added best anchors
     assert torch.equal(h._C.view().reshape(-1), torch.cat(want_rows).to(torch.float32))
     assert sum(p.n for p in h._pos) == h._X.n
+
+
+@pytest.mark.gpu
+def test_staged_uploads_deliver_the_same_tensors(monkeypatch):
+    """harvest.to_device through the page-locked staging block (ODX_STAGED_UPLOADS=1): every tensor arrives as a plain copy
+    would deliver it — dtypes, shapes, more bytes than both halves of the block hold (the halves are re-entered behind their
+    fences), copies issued from two streams."""
+    from odx import harvest
+    monkeypatch.setenv("ODX_STAGED_UPLOADS", "1")
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(0)
+    side = torch.cuda.Stream()
+    kept = []
+    for i in range(900):
+        n = int(torch.randint(1, 3000, (1,), generator=g))
+        host = [torch.randint(0, 1 << 40, (n,), generator=g), torch.randn((n // 7 + 1, 7), generator=g),
+                torch.randint(0, 2, (n,), generator=g).bool()][i % 3]
+        if i % 5 == 0:
+            with torch.cuda.stream(side):
+                d = harvest.to_device(host, dev)
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            d = harvest.to_device(host, dev)
+        kept.append((host, d))
+    torch.cuda.synchronize()
+    assert sum(h.numel() * h.element_size() for h, _ in kept) > 4 * harvest._Staging.HALF
+    for h, d in kept:
+        assert d.is_cuda and d.dtype == h.dtype and d.shape == h.shape and torch.equal(d.cpu(), h)
