@@ -469,6 +469,14 @@ int odx_gemm_b16(const void* A, int64_t lda, int64_t m, const void* B, int64_t l
 /* odx_split_f16_taps3x3 for 16-bit rows: P ((R H W) x ldp elements, ldp % 8 == 0, ldp >= 9 C) = the 3 x 3 neighbourhood
  * matrix of Y ((R H W) x C, C % 8 == 0, ldy % 8 == 0), zeros outside the map and beyond 9 C: the operand of odx_gemm_b16.  */
 int odx_taps3x3_16(const void* Y, int64_t ldy, int64_t R, int H, int W, int C, void* P, int64_t ldp, odx_stream_t stream);
+/* The 3 x 3 layer of a 16-bit forward WITHOUT the neighbourhood matrix (as odx_gemm_h2_taps_f32 for f32): out = act(taps3x3(Y) B' +
+ * bias + residual), the taps of the 16-bit NHWC rows Y (R H W rows of C channels, C % 64 == 0, row stride ldy elements, FOLLOWED
+ * BY ONE ALL-ZERO ROW) gathered inside the product's operand loads; B (n x 9 C) and the rest as for odx_gemm_b16.  Served where
+ * odx_gemm_b16_taps_supported(m = R H W, n, C, ldy) returns 1; elsewhere odx_taps3x3_16 + odx_gemm_b16. */
+int odx_gemm_b16_taps_supported(int64_t m, int64_t n, int C, int64_t ldy);
+int odx_gemm_b16_taps(const void* Y, int64_t ldy, int64_t R, int H, int W, int C, const void* B, int64_t ldb, int64_t n,
+                      int is_bf16, const float* bias, const void* residual, int64_t ldr, int relu, void* out, int64_t ldo,
+                      int out_16, odx_stream_t stream);
 /* The same bins for a consumer that starts with a stride-`step` 1 x 1 convolution (ResNet50Conv5ROIFeatureExtractor's
  * head, roi_box_feature_extractors.py:26-52 with STRIDE_IN_1X1): only the bins (ph, pw) with ph % step == pw % step == 0,
  * as rows of an (R * ceil(PH / step) * ceil(PW / step), C) matrix (NHWC) — a quarter of the grid at 14 x 14, step 2.  */

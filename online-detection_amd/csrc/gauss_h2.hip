@@ -856,7 +856,7 @@ __device__ __forceinline__ void w_mainloop_dma(f32x4 (&acc)[8][4], const uint32_
     ad.tH = tapH;
     ad.tW = tapW;
     ad.tld = (int)(lda * 4);
-    ad.tkb = tapC * 4;
+    ad.tkb = tapC;                       // bytes of one tap inside a row: 4 C (packed two-term rows), 2 C (16-bit rows)
     const uint32_t chunk = (uint32_t)(((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 16);   // (ri >> 1) & 7 is the same for the four pieces
     ad.tzero = (uint32_t)(m * lda * 4) + chunk;
 #pragma unroll
@@ -1213,7 +1213,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void gemm_h2w256_kernel(
   w_zero(acc);
   // B rows in the permuted order of the K_nM builds: a lane holds four ADJACENT output columns 64 wc + 4 (lane & 15) + tn
   // of each of its rows, and stores them (loads bias / residual) 16 bytes at a time when the matrices allow it
-  if (STG == STG_DMA) w_mainloop_dma<true, CORE_H2, TAPS>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds, tapH, tapW, tapC);
+  if (STG == STG_DMA) w_mainloop_dma<true, CORE_H2, TAPS>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds, tapH, tapW, tapC * 4);
   else w_mainloop<true>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds);
   const float inv = 1.f / (metaa[0] * metab[0]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1254,56 +1254,12 @@ __device__ __forceinline__ void b16_finish(float acc, float b, const void* __res
   else static_cast<float*>(out)[oi] = v;
 }
 
-template <int CORE, bool OUT16>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_b16s16_kernel(
-    const uint32_t* __restrict__ PA, int64_t ldpa, int64_t m, const uint32_t* __restrict__ PB, int64_t ldpb, int64_t n, int ktiles,
-    const float* __restrict__ bias, const void* __restrict__ res, int64_t ldr, int relu, void* __restrict__ out, int64_t ldo, int gr) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int64_t GR = gr;
-  const int64_t tiles_n = (n + GEMM_BN - 1) / GEMM_BN;
-  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t band = wg / (GR * tiles_n), within = wg % (GR * tiles_n);
-  const int64_t i0 = (band * GR + within % GR) * GEMM_BM, j0 = (within / GR) * GEMM_BN;
-  if (i0 >= m) return;
-  f32x4 acc[4][4];
-  s16_zero(acc);
-  s16_mainloop<CORE>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, ktiles, lds);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-#pragma unroll
-  for (int tn = 0; tn < 4; ++tn) {
-    const int64_t col = j0 + wc * 64 + tn * 16 + (lane & 15);
-    if (col >= n) continue;
-    const float b = bias != nullptr ? bias[col] : 0.f;
-    const int64_t rb = i0 + wr * 64 + 4 * (lane >> 4);
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int64_t row = rb + tm * 16 + q;
-        if (row < m) b16_finish<CORE, OUT16>(acc[tm][tn][q], b, res, row * ldr + col, relu, out, row * ldo + col);
-      }
-  }
-}
-
-template <int CORE, bool OUT16>
-__global__ __launch_bounds__(W_THREADS, 1) void gemm_b16w256_kernel(
-    const uint32_t* __restrict__ PA, int64_t ldpa, int64_t m, const uint32_t* __restrict__ PB, int64_t ldpb, int64_t n, int stages,
-    const float* __restrict__ bias, const void* __restrict__ res, int64_t ldr, int relu, void* __restrict__ out, int64_t ldo, int gr) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int64_t GR = gr;
-  const int64_t tiles_n = (n + W_BN - 1) / W_BN;
-  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t band = wg / (GR * tiles_n), within = wg % (GR * tiles_n);
-  const int64_t i0 = (band * GR + within % GR) * W_BM, j0 = (within / GR) * W_BN;
-  if (i0 >= m) return;
-  f32x4 acc[8][4];
-  w_zero(acc);
-  w_mainloop_dma<true, CORE>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds);     // (a lane holds four ADJACENT columns per row)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 2, wc = wave & 3;
-  const int64_t col = j0 + wc * 64 + 4 * (lane & 15);
-  const int64_t rb = i0 + wr * 128 + 4 * (lane >> 4);
+// The epilogue of both 16-bit product kernels: a lane holds, for each of its TM row blocks, four ADJACENT columns (B rows fetched
+// in the permuted order): 8 (16-bit output / residual) or 16 bytes per lane and row.
+template <int TM, int CORE, bool OUT16>
+__device__ __forceinline__ void gemm_b16_store(const f32x4 (&acc)[TM][4], int64_t m, int64_t n, int64_t rb, int64_t col,
+                                               const float* __restrict__ bias, const void* __restrict__ res, int64_t ldr, int relu,
+                                               void* __restrict__ out, int64_t ldo) {
   if (col >= n) return;
   constexpr int ESZ = OUT16 ? 2 : 4;
   const bool vec = col + 4 <= n && (ldo * ESZ) % (4 * ESZ) == 0 && (reinterpret_cast<uintptr_t>(out) & (4 * ESZ - 1)) == 0 &&
@@ -1312,7 +1268,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void gemm_b16w256_kernel(
 #pragma unroll
   for (int tn = 0; tn < 4; ++tn) b[tn] = (bias != nullptr && col + tn < n) ? bias[col + tn] : 0.f;
 #pragma unroll
-  for (int tm = 0; tm < 8; ++tm) {
+  for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int64_t row = rb + tm * 16 + q;
@@ -1349,6 +1305,47 @@ __global__ __launch_bounds__(W_THREADS, 1) void gemm_b16w256_kernel(
       }
     }
   }
+}
+
+template <int CORE, bool OUT16>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_b16s16_kernel(
+    const uint32_t* __restrict__ PA, int64_t ldpa, int64_t m, const uint32_t* __restrict__ PB, int64_t ldpb, int64_t n, int ktiles,
+    const float* __restrict__ bias, const void* __restrict__ res, int64_t ldr, int relu, void* __restrict__ out, int64_t ldo, int gr) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int64_t GR = gr;
+  const int64_t tiles_n = (n + GEMM_BN - 1) / GEMM_BN;
+  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t band = wg / (GR * tiles_n), within = wg % (GR * tiles_n);
+  const int64_t i0 = (band * GR + within % GR) * GEMM_BM, j0 = (within / GR) * GEMM_BN;
+  if (i0 >= m) return;
+  f32x4 acc[4][4];
+  s16_zero(acc);
+  s16_mainloop<CORE, true>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, ktiles, lds);      // (a lane holds four ADJACENT columns per row)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  gemm_b16_store<4, CORE, OUT16>(acc, m, n, i0 + wr * 64 + 4 * (lane >> 4), j0 + wc * 64 + 4 * (lane & 15), bias, res, ldr, relu, out, ldo);
+}
+
+// TAPS: A = the 3 x 3 neighbourhood matrix of 16-bit NHWC rows (C % 64 == 0: a stage is 64 channels of one tap), gathered inside
+// the operand loads as in gemm_h2w256_kernel<.., true>; A's rows are followed by one all-zero row.
+template <int CORE, bool OUT16, bool TAPS = false>
+__global__ __launch_bounds__(W_THREADS, 1) void gemm_b16w256_kernel(
+    const uint32_t* __restrict__ PA, int64_t ldpa, int64_t m, const uint32_t* __restrict__ PB, int64_t ldpb, int64_t n, int stages,
+    const float* __restrict__ bias, const void* __restrict__ res, int64_t ldr, int relu, void* __restrict__ out, int64_t ldo, int gr,
+    int tapH, int tapW, int tapC) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int64_t GR = gr;
+  const int64_t tiles_n = (n + W_BN - 1) / W_BN;
+  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t band = wg / (GR * tiles_n), within = wg % (GR * tiles_n);
+  const int64_t i0 = (band * GR + within % GR) * W_BM, j0 = (within / GR) * W_BN;
+  if (i0 >= m) return;
+  f32x4 acc[8][4];
+  w_zero(acc);
+  w_mainloop_dma<true, CORE, TAPS>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds, tapH, tapW, tapC * 2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  gemm_b16_store<8, CORE, OUT16>(acc, m, n, i0 + wr * 128 + 4 * (lane >> 4), j0 + wc * 64 + 4 * (lane & 15), bias, res, ldr, relu, out, ldo);
 }
 
 // The operand of a 3 x 3 convolution (padding 1) run as a GEMM over 16-bit NHWC rows Y (R * H * W rows of C channels): row
@@ -2079,13 +2076,13 @@ static int launch_gemm_b16(const void* A, int64_t lda, int64_t m, const void* B,
                            const void* residual, int64_t ldr, int relu, void* out, int64_t ldo, hipStream_t s) {
   const int gr = 8;
   const int64_t t256 = ceil_div(m, W_BM) * ceil_div(n, W_BN);
-  const bool wide = g_h2_tile == 256 || (g_h2_tile != 128 && t256 >= 256);
+  const bool wide = g_h2_tile == 256 || (g_h2_tile != 128 && t256 >= 256 && n > GEMM_BN);     // (<= 128 columns: half a wide tile idle)
   if (wide) {                  // the 256 x 256 core once it fills the chip (one workgroup per CU), else 128 x 128 tiles
     const int64_t wt = round_up(ceil_div(m, W_BM), gr) * ceil_div(n, W_BN);
     ODX_REQUIRE(wt < (1ll << 31), "odx_gemm_b16: grid too large");
     ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_b16w256_kernel<CORE, OUT16>), W_LDS_BYTES));
     hipLaunchKernelGGL((gemm_b16w256_kernel<CORE, OUT16>), dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, s, (const uint32_t*)A, lda / 2, m,
-                       (const uint32_t*)B, ldb / 2, n, (int)(round_up(K, 64) / 64), bias, residual, ldr, relu, out, ldo, gr);
+                       (const uint32_t*)B, ldb / 2, n, (int)(round_up(K, 64) / 64), bias, residual, ldr, relu, out, ldo, gr, 0, 0, 0);
     ODX_CHECK_LAUNCH("odx_gemm_b16(w256)");
     return ODX_OK;
   }
@@ -2115,6 +2112,48 @@ extern "C" int odx_gemm_b16(const void* A, int64_t lda, int64_t m, const void* B
   }
   return out_16 ? launch_gemm_b16<CORE_F16, true>(A, lda, m, B, ldb, n, K, bias, residual, ldr, relu, out, ldo, s)
                 : launch_gemm_b16<CORE_F16, false>(A, lda, m, B, ldb, n, K, bias, residual, ldr, relu, out, ldo, s);
+}
+
+// odx_gemm_h2_taps_supported / odx_gemm_h2_taps_f32 for 16-bit rows: out = act(taps3x3(Y) B' + bias + residual) with the taps of the
+// 16-bit NHWC rows Y (R H W rows of C channels, C % 64 == 0, row stride ldy elements, FOLLOWED BY ONE ALL-ZERO ROW) gathered
+// inside the product's operand loads — odx_taps3x3_16's matrix is never written.  B (n x 9 C) as for odx_gemm_b16.
+extern "C" int odx_gemm_b16_taps_supported(int64_t m, int64_t n, int C, int64_t ldy) {
+  if (m <= 0 || n <= GEMM_BN || C <= 0 || C % 64 != 0) return 0;
+  if (g_h2_tile == 128 || ceil_div(m, W_BM) * ceil_div(n, W_BN) < 256) return 0;
+  return (m + 1) * ldy * 2 < (1ll << 31) ? 1 : 0;
+}
+
+template <int CORE, bool OUT16>
+static int launch_gemm_b16_taps(const void* Y, int64_t ldy, int64_t m, int H, int W, int C, const void* B, int64_t ldb, int64_t n,
+                                const float* bias, const void* residual, int64_t ldr, int relu, void* out, int64_t ldo, hipStream_t s) {
+  const int gr = 8;
+  const int64_t wt = round_up(ceil_div(m, W_BM), gr) * ceil_div(n, W_BN);
+  ODX_REQUIRE(wt < (1ll << 31), "odx_gemm_b16_taps: grid too large");
+  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_b16w256_kernel<CORE, OUT16, true>), W_LDS_BYTES));
+  hipLaunchKernelGGL((gemm_b16w256_kernel<CORE, OUT16, true>), dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, s, (const uint32_t*)Y, ldy / 2, m,
+                     (const uint32_t*)B, ldb / 2, n, (int)(9 * (int64_t)C / 64), bias, residual, ldr, relu, out, ldo, gr, H, W, C);
+  ODX_CHECK_LAUNCH("odx_gemm_b16_taps");
+  return ODX_OK;
+}
+
+extern "C" int odx_gemm_b16_taps(const void* Y, int64_t ldy, int64_t R, int H, int W, int C, const void* B, int64_t ldb, int64_t n,
+                                 int is_bf16, const float* bias, const void* residual, int64_t ldr, int relu, void* out, int64_t ldo,
+                                 int out_16, odx_stream_t stream) {
+  const int64_t m = R * H * W;
+  if (m <= 0 || n <= 0) return ODX_OK;
+  ODX_REQUIRE(Y && B && out && H > 0 && W > 0, "odx_gemm_b16_taps: bad argument");
+  ODX_REQUIRE(odx_gemm_b16_taps_supported(m, n, C, ldy), "odx_gemm_b16_taps: layer not served (odx_gemm_b16_taps_supported)");
+  ODX_REQUIRE(ldy % 8 == 0 && ldb % 8 == 0 && ldy >= C && ldb >= round_up(9 * (int64_t)C, 128) && aligned16(Y) && aligned16(B),
+              "odx_gemm_b16_taps: operands must be 16-byte aligned with ld %% 8 == 0, ldy >= C, ldb >= roundup(9 C, 128)");
+  ODX_REQUIRE(ldo >= n && (residual == nullptr || ldr >= n), "odx_gemm_b16_taps: ldo / ldr < n");
+  ODX_REQUIRE(ldb < (1 << 25), "odx_gemm_b16_taps: leading dimensions must stay below 2^25 (32-bit tile offsets)");
+  hipStream_t s = as_stream(stream);
+  if (is_bf16) {
+    return out_16 ? launch_gemm_b16_taps<CORE_BF16, true>(Y, ldy, m, H, W, C, B, ldb, n, bias, residual, ldr, relu, out, ldo, s)
+                  : launch_gemm_b16_taps<CORE_BF16, false>(Y, ldy, m, H, W, C, B, ldb, n, bias, residual, ldr, relu, out, ldo, s);
+  }
+  return out_16 ? launch_gemm_b16_taps<CORE_F16, true>(Y, ldy, m, H, W, C, B, ldb, n, bias, residual, ldr, relu, out, ldo, s)
+                : launch_gemm_b16_taps<CORE_F16, false>(Y, ldy, m, H, W, C, B, ldb, n, bias, residual, ldr, relu, out, ldo, s);
 }
 
 extern "C" int odx_gauss_h2_tile(int64_t n, int64_t M) {

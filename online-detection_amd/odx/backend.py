@@ -41,10 +41,11 @@ class Features:
 class Rows16:
     """A 16-bit (bf16 / f16) row matrix as odx_gemm_b16 takes it: buf (n, ld), ld a multiple of 128 elements, columns K .. ld
     zero.  `dense` is the (n, K) view."""
-    __slots__ = ("buf", "n", "K")
+    __slots__ = ("buf", "n", "K", "zero_row")
 
-    def __init__(self, buf, K):
+    def __init__(self, buf, K, zero_row=False):
         self.buf, self.n, self.K = buf, buf.shape[0], K
+        self.zero_row = zero_row            # buf is followed by one all-zero row in memory (odx_gemm_b16_taps reads it outside the map)
 
     @property
     def dense(self):
@@ -950,23 +951,24 @@ class HipBackend:
         return out
 
     # ------------------------------------------------------------------ 16-bit layers (a forward run in bf16 / f16)
-    def rows16(self, X, dtype=None):
+    def rows16(self, X, dtype=None, zero_row=False):
         """X (rows, K) as the operand of gemm_b16: a bf16 / f16 row-major block whose rows are a multiple of 128 elements
-        long, zero beyond K (Rows16).  A matrix that already is one (right dtype, contiguous, K % 128 == 0) is taken as it is."""
-        if isinstance(X, Rows16):
+        long, zero beyond K (Rows16).  A matrix that already is one (right dtype, contiguous, K % 128 == 0) is taken as it is.
+        zero_row: the block is followed by one all-zero row in memory (conv3x3_rows16 gathers its taps in the product then)."""
+        if isinstance(X, Rows16) and (X.zero_row or not zero_row):
             return X
+        if isinstance(X, Rows16):
+            X = X.dense
         dtype = dtype or (X.dtype if X.dtype in (torch.bfloat16, torch.float16) else torch.bfloat16)
         n, K = X.shape
         ld = (K + 127) // 128 * 128
-        if X.is_cuda and X.dtype == dtype and K == ld and X.stride(1) == 1 and X.stride(0) == ld and X.data_ptr() % 16 == 0:
+        if not zero_row and X.is_cuda and X.dtype == dtype and K == ld and X.stride(1) == 1 and X.stride(0) == ld and X.data_ptr() % 16 == 0:
             return Rows16(X, K)
-        buf = torch.empty((n, ld), dtype=dtype, device=self.device)
-        if ld > K:
-            buf[:, K:].zero_()
+        buf, _ = self._rows16_out(n, K, dtype, zero_row)
         buf[:, :K].copy_(X)
-        return Rows16(buf, K)
+        return Rows16(buf, K, zero_row)
 
-    def gemm_b16(self, A, B, bias=None, residual=None, relu=False, out_f32=False):
+    def gemm_b16(self, A, B, bias=None, residual=None, relu=False, out_f32=False, zero_row=False):
         """act(A B' + bias (+ residual)) for Rows16 operands A (m, K), B (n, K) of one 16-bit type (odx_gemm_b16: one MFMA term
         per product, f32 sums, one rounding).  Returns a Rows16 of the operands' type — ready to be the next layer's operand,
         its pad columns zero — or, with out_f32, an (m, n) f32 tensor.  residual: Rows16 of the operands' type (f32 tensor
@@ -983,10 +985,7 @@ class HipBackend:
                 res = res if res.stride(1) == 1 else res.contiguous()
                 ldr = res.stride(0)
         else:
-            ldo = (n + 127) // 128 * 128
-            out = torch.empty((m, ldo), dtype=dt, device=self.device)
-            if ldo > n:
-                out[:, n:].zero_()
+            out, ldo = self._rows16_out(m, n, dt, zero_row)
             res, ldr = None, 0
             if residual is not None:
                 if not isinstance(residual, Rows16) or residual.buf.dtype != dt or residual.n != m or residual.K != n:
@@ -998,7 +997,36 @@ class HipBackend:
             hip.check(self.lib.odx_gemm_b16(_p(A.buf), A.buf.stride(0), m, _p(B.buf), B.buf.stride(0), n, K, 1 if dt == torch.bfloat16 else 0,
                                             _p(bias), _p(res), ldr, int(bool(relu)), _p(out), ldo, 0 if out_f32 else 1, self._stream()),
                       "odx_gemm_b16")
-        return out if out_f32 else Rows16(out, n)
+        return out if out_f32 else Rows16(out, n, zero_row)
+
+    def _rows16_out(self, m, n, dt, zero_row):
+        """(m, roundup(n, 128)) 16-bit output block with zero pad columns, followed by an all-zero row when asked."""
+        ldo = (n + 127) // 128 * 128
+        buf = torch.empty((m + 1 if zero_row else m, ldo), dtype=dt, device=self.device)
+        if zero_row:
+            buf[m].zero_()
+        out = buf[:m]
+        if ldo > n:
+            out[:, n:].zero_()
+        return out, ldo
+
+    def conv3x3_rows16(self, Y, R, H, W, B, bias=None, relu=False, zero_row=False):
+        """act(3 x 3 convolution, padding 1) of the 16-bit NHWC rows Y (Rows16, R H W rows of C channels) with the weights B
+        (Rows16 (n, 9 C): ky kx c) as one product: the taps gathered inside the product's operand loads where the library serves
+        the shape (odx_gemm_b16_taps: Y.zero_row, C % 64 == 0, a wide layer), else from the written-out neighbourhood matrix
+        (taps3x3_16 + gemm_b16).  Returns a Rows16."""
+        C, n, m = Y.K, B.n, R * H * W
+        dt = Y.buf.dtype
+        if Y.n != m or B.K != 9 * C or B.buf.dtype != dt:
+            raise ValueError("conv3x3_rows16: %d rows of %d channels against R H W = %d, K = %d" % (Y.n, C, m, B.K))
+        if not (Y.zero_row and m and self.lib.odx_gemm_b16_taps_supported(m, n, C, Y.buf.stride(0))):
+            return self.gemm_b16(self.taps3x3_16(Y, R, H, W), B, bias=bias, relu=relu, zero_row=zero_row)
+        out, ldo = self._rows16_out(m, n, dt, zero_row)
+        if bias is not None:
+            bias = bias.to(device=self.device, dtype=torch.float32).contiguous()
+        hip.check(self.lib.odx_gemm_b16_taps(_p(Y.buf), Y.buf.stride(0), R, H, W, C, _p(B.buf), B.buf.stride(0), n, 1 if dt == torch.bfloat16 else 0,
+                                             _p(bias), None, 0, int(bool(relu)), _p(out), ldo, 1, self._stream()), "odx_gemm_b16_taps")
+        return Rows16(out, n, zero_row)
 
     def taps3x3_16(self, Y, R, H, W):
         """The operand of a 3 x 3 convolution (padding 1) as a GEMM over the 16-bit NHWC rows Y (Rows16, R * H * W rows of C

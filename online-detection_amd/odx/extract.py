@@ -341,9 +341,9 @@ def _bottleneck_rows_b16(be, blk, x, R, H, W):
         wd, bd = wrows("down", blk.down[0], blk.down[1])
         idn = be.gemm_b16(x, wd, bias=bd)
     w1, b1 = wrows("conv1", blk.conv1, blk.bn1)
-    y = be.gemm_b16(x, w1, bias=b1, relu=True)
+    y = be.gemm_b16(x, w1, bias=b1, relu=True, zero_row=True)
     w2, b2 = wrows("conv2", blk.conv2, blk.bn2, taps=True)
-    y = be.gemm_b16(be.taps3x3_16(y, R, H, W), w2, bias=b2, relu=True)
+    y = be.conv3x3_rows16(y, R, H, W, w2, bias=b2, relu=True)             # (taps gathered inside the product where it can)
     w3, b3 = wrows("conv3", blk.conv3, blk.bn3)
     return be.gemm_b16(y, w3, bias=b3, residual=idn, relu=True)
 
@@ -476,6 +476,26 @@ def _stages_rows(be, y, stages, pack_last=False):
     return outs
 
 
+def _stages_rows16(be, y, stages):
+    """_stages_rows for a forward run in bf16 / f16: y (B, C, H, W) the stem's output in the 16-bit type; every bottleneck on
+    16-bit rows (_bottleneck_rows_b16: one MFMA term per product, f32 sums, one rounding per layer — no packing, no scales).
+    Returns, per stage, (backend.Rows16, (B, H, W))."""
+    B, C, H, W = y.shape
+    x = be.rows16(y.permute(0, 2, 3, 1).reshape(B * H * W, C), y.dtype)
+    outs = []
+    blocks = [(si, blk) for si, stage in enumerate(stages) for blk in stage]
+    for k, (si, blk) in enumerate(blocks):
+        st = blk.conv1.stride[0]
+        if st > 1:
+            cut = x.buf.view(B, H, W, -1)[:, ::st, ::st]
+            H, W = cut.shape[1], cut.shape[2]
+            x = type(x)(cut.reshape(B * H * W, -1), x.K)
+        x = _bottleneck_rows_b16(be, blk, x, B, H, W)
+        if k + 1 == len(blocks) or blocks[k + 1][0] != si:
+            outs.append((x, (B, H, W)))
+    return outs
+
+
 def _stage(cin, mid, cout, blocks, stride):
     layers = [Bottleneck(cin, mid, cout, stride)] + [Bottleneck(cout, mid, cout, 1) for _ in range(blocks - 1)]
     return nn.Sequential(*layers)
@@ -499,6 +519,13 @@ class ResNet50C4(_FoldedBN):
 
     def rows_form(self):
         return _stages_rows_form((self.layer1, self.layer2, self.layer3))
+
+    def forward_rows16(self, x):
+        """forward_rows for a forward run in bf16 / f16 (x: the image, under the caller's autocast): the stem by the convolution
+        library in the 16-bit type, the three stages on 16-bit rows (_stages_rows16).  Returns (backend.Rows16, (B, h, w))."""
+        be = _backend.get_backend()
+        y = F.max_pool2d(self.conv_bn_act("conv1", "bn1", x), 3, 2, 1)
+        return _stages_rows16(be, y, (self.layer1, self.layer2, self.layer3))[-1]
 
     def forward_rows(self, x):
         """The trunk on this library's tile cores (f32 on the GPU): the stem (7 x 7 convolution, max pooling) by the convolution
@@ -780,10 +807,24 @@ class OnlineDetectionModel(nn.Module):
             hit = cache[name] = (key, make())
         return hit[1]
 
+    def _rows16_path(self, x):
+        """_rows_path for a forward run in bf16 / f16 (compute_dtype): trunk stages and RPN head on 16-bit rows (odx_gemm_b16)."""
+        if not (x.is_cuda and self.compute_dtype in (torch.bfloat16, torch.float16) and not torch.is_grad_enabled()
+                and os.environ.get("ODX_TRUNK", "rows") != "conv"):
+            return False
+        positions = x.shape[0] * x.shape[2] * x.shape[3] if x.shape[1] != 3 else x.shape[0] * (-(-x.shape[2] // self.stride)) * (-(-x.shape[3] // self.stride))
+        if positions < self.rows_min_positions:
+            return False
+        return hasattr(_backend.get_backend(), "conv3x3_rows16") and self.backbone.rows_form()
+
     def _c4_eager(self, image):
         if self._rows_path(image):
             rows, (B, h, w) = self.backbone.forward_rows(image)
             return rows.view(B, h, w, -1).permute(0, 3, 1, 2)          # (B, C, h, w) as a channels-last view of the NHWC rows
+        if self._rows16_path(image):
+            with self._amp():
+                x16, (B, h, w) = self.backbone.forward_rows16(image)
+            return x16.dense.float().view(B, h, w, -1).permute(0, 3, 1, 2)      # handed on in f32, as every map of this model
         with self._amp():
             return self.backbone(image).float()
 
@@ -836,6 +877,16 @@ class OnlineDetectionModel(nn.Module):
                 cv.bias.detach().float().contiguous()))
             t = be.conv3x3_rows(rows, B, h, w, wp, bias=b, relu=True)
             return t.view(B, h, w, -1).permute(0, 3, 1, 2)
+        if (self._rows16_path(c4) and c4.shape[1] % 8 == 0 and tuple(cv.kernel_size) == (3, 3) and tuple(cv.stride) == (1, 1)
+                and tuple(cv.padding) == (1, 1)):
+            be, dt = _backend.get_backend(), self.compute_dtype
+            B, C, h, w = c4.shape
+            x16 = be.rows16(c4.permute(0, 2, 3, 1).reshape(B * h * w, C), dt, zero_row=True)
+            wp, b = self._wpack(("rpn_conv", dt), (cv.weight, cv.bias), lambda: (
+                be.rows16(cv.weight.detach().permute(0, 2, 3, 1).reshape(cv.out_channels, -1).to(dt).contiguous(), dt),
+                cv.bias.detach().float().contiguous()))
+            t16 = be.conv3x3_rows16(x16, B, h, w, wp, bias=b, relu=True)
+            return t16.dense.float().view(B, h, w, -1).permute(0, 3, 1, 2)
         with self._amp():
             return F.relu(self.rpn_conv(c4)).float()
 
@@ -849,6 +900,15 @@ class OnlineDetectionModel(nn.Module):
                 be.packed(torch.cat((lg.weight.detach().float().reshape(lg.out_channels, -1), dl.weight.detach().float().reshape(dl.out_channels, -1)), dim=0).contiguous()),
                 torch.cat((lg.bias.detach().float(), dl.bias.detach().float())).contiguous()))
             o = be.gemm_h2(be.packed(t.permute(0, 2, 3, 1).reshape(B * h * w, C)), wp, bias=b).view(B, h, w, -1)
+            A = lg.out_channels
+            return o[..., :A].permute(0, 3, 1, 2).contiguous(), o[..., A:].permute(0, 3, 1, 2).contiguous()
+        if self._rows16_path(t) and tuple(lg.kernel_size) == (1, 1) and tuple(dl.kernel_size) == (1, 1):
+            be, dt = _backend.get_backend(), self.compute_dtype
+            B, C, h, w = t.shape
+            wp, b = self._wpack(("rpn_out", dt), (lg.weight, lg.bias, dl.weight, dl.bias), lambda: (
+                be.rows16(torch.cat((lg.weight.detach().reshape(lg.out_channels, -1), dl.weight.detach().reshape(dl.out_channels, -1)), dim=0).to(dt).contiguous(), dt),
+                torch.cat((lg.bias.detach().float(), dl.bias.detach().float())).contiguous()))
+            o = be.gemm_b16(be.rows16(t.permute(0, 2, 3, 1).reshape(B * h * w, C), dt), wp, bias=b, out_f32=True).view(B, h, w, -1)
             A = lg.out_channels
             return o[..., :A].permute(0, 3, 1, 2).contiguous(), o[..., A:].permute(0, 3, 1, 2).contiguous()
         with self._amp():

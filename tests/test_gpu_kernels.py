@@ -1367,6 +1367,36 @@ def test_chain_3x3_convolution_from_packed_rows(R, H, W, C, n):
     assert bool(((val.double() - z.X.double()).abs() <= 2.0 ** -21 * z.X.abs().double() + 2.0 ** -30 * top).all())
 
 
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("R,H,W,C,n", [(1400, 7, 7, 64, 256), (9, 150, 200, 64, 160), (1400, 7, 7, 64, 128), (37, 7, 7, 64, 256),
+                                       (1400, 7, 7, 32, 256)])
+def test_16bit_3x3_convolution_with_the_taps_gathered_in_the_operand_loads(dtype, R, H, W, C, n):
+    """HipBackend.conv3x3_rows16: odx_gemm_b16_taps (first two shapes: the taps of the 16-bit rows gathered by the product's own
+    LDS-DMA loads, a zero row outside the map) = odx_taps3x3_16 + odx_gemm_b16 bit for bit (the same products in the same
+    order), and = the convolution of the rounded operands in f64 to the output's rounding; the other shapes take the written-out
+    matrix (narrow output, too few tiles, C % 64 != 0)."""
+    import odx
+    be = odx.get_backend()
+    dt = getattr(torch, dtype)
+    g = torch.Generator().manual_seed(R + C + n)
+    m = R * H * W
+    Y = torch.randn((m, C), generator=g).cuda().to(dt)
+    Wt = (torch.randn((n, 9 * C), generator=g) / (9 * C) ** 0.5).cuda().to(dt)
+    bias = torch.randn(n, generator=g).cuda()
+    y0, y1, wp = be.rows16(Y, dt), be.rows16(Y, dt, zero_row=True), be.rows16(Wt, dt)
+    want = be.gemm_b16(be.taps3x3_16(y0, R, H, W), wp, bias=bias, relu=True)
+    served = bool(be.lib.odx_gemm_b16_taps_supported(m, n, C, y1.buf.stride(0)))
+    assert served == ((R, n, C) in ((1400, 256, 64), (9, 160, 64)))
+    got = be.conv3x3_rows16(y1, R, H, W, wp, bias=bias, relu=True, zero_row=True)
+    assert got.zero_row and torch.equal(got.dense, want.dense)
+    assert int(torch.as_strided(got.buf, (m + 1, got.buf.shape[1]), got.buf.stride())[m].abs().max()) == 0
+    if m * C * n < 3e10:
+        ref = torch.nn.functional.conv2d(Y.double().view(R, H, W, C).permute(0, 3, 1, 2), Wt.double().view(n, 3, 3, C).permute(0, 3, 1, 2),
+                                         bias.double(), padding=1).relu().permute(0, 2, 3, 1).reshape(m, n)
+        ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+        assert bool(((got.dense.double() - ref).abs() <= ulp * ref.abs() + 1e-5 * float(ref.abs().max())).all())
+
+
 def test_cu_masked_stream_and_partition_sized_pass(be):
     """The diagnostic entry points behind tools/cu_split_probe.py: a stream confined to 16 compute units runs its workgroups
     on at most 16 distinct (XCC, SE, SH, CU) places, two per XCC; a compact pass launched there with its persistent grid sized
