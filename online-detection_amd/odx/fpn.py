@@ -30,8 +30,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import backend as _backend
-from .extract import (DELTA_CLAMP, FrozenBatchNorm2d, _FoldedBN, _nms_takes_max_keep, _stage, _stages_rows, _stages_rows_form,
-                      cell_anchors, decode_deltas, grid_anchors)
+from .extract import (DELTA_CLAMP, FrozenBatchNorm2d, _FoldedBN, _nms_takes_max_keep, _stage, _stages_rows, _stages_rows16,
+                      _stages_rows_form, cell_anchors, decode_deltas, grid_anchors)
 
 
 class ResNet50Stages(_FoldedBN):
@@ -57,6 +57,11 @@ class ResNet50Stages(_FoldedBN):
     def rows_form(self):
         return _stages_rows_form((self.layer1, self.layer2, self.layer3, self.layer4))
 
+    def forward_rows16(self, x):
+        """forward_rows for a trunk run natively in bf16 / f16 (x in that type): [(backend.Rows16 of C2 .. C5, (B, h, w))]."""
+        y = F.max_pool2d(self.conv_bn_act("conv1", "bn1", x), 3, 2, 1)
+        return _stages_rows16(_backend.get_backend(), y, (self.layer1, self.layer2, self.layer3, self.layer4))
+
     def forward_rows(self, x):
         """The four stages as one chain of row GEMMs on the split-f16 tile cores behind the library's stem (extract._stages_rows):
         [(backend.PackedRows of C2 .. C5 — f32 rows and packed operand —, (B, h, w))]."""
@@ -80,6 +85,7 @@ class FeaturePyramid(nn.Module):
     def _apply(self, fn, *a, **kw):
         self._cast = {}
         self.__dict__.pop("_rows_pack", None)
+        self.__dict__.pop("_rows16_pack", None)
         return super()._apply(fn, *a, **kw)
 
     def _wb(self, conv, dtype):
@@ -121,6 +127,40 @@ class FeaturePyramid(nn.Module):
                       c.bias.detach().float().contiguous()) for c in self.layer]
             hit = self.__dict__["_rows_pack"] = (key, inner, layer)
         return hit[1], hit[2]
+
+    def _rows16_weights(self, be, dt):
+        key = (dt,) + tuple((c.weight.data_ptr(), c.weight._version, c.bias._version) for c in list(self.inner) + list(self.layer))
+        hit = self.__dict__.get("_rows16_pack")
+        if hit is None or hit[0] != key:
+            inner = [(be.rows16(c.weight.detach().reshape(c.out_channels, -1).to(dt).contiguous(), dt), c.bias.detach().float().contiguous())
+                     for c in self.inner]
+            layer = [(be.rows16(c.weight.detach().permute(0, 2, 3, 1).reshape(c.out_channels, -1).to(dt).contiguous(), dt),
+                      c.bias.detach().float().contiguous()) for c in self.layer]
+            hit = self.__dict__["_rows16_pack"] = (key, inner, layer)
+        return hit[1], hit[2]
+
+    def forward_rows16(self, cs):
+        """forward_rows for a pyramid in bf16 / f16: the stages' 16-bit rows (ResNet50Stages.forward_rows16) through odx_gemm_b16 /
+        conv3x3_rows16, the top-down sum in the 16-bit type (as the library's 16-bit pyramid adds two 16-bit maps); the five
+        levels as contiguous 16-bit (B, C, h, w) maps."""
+        be = _backend.get_backend()
+        dt = cs[0][0].buf.dtype
+        inner, layer = self._rows16_weights(be, dt)
+        outs, last, dims = [], None, None
+        for k in range(len(cs) - 1, -1, -1):
+            x, (B, H, W) = cs[k]
+            lat = be.gemm_b16(x, inner[k][0], bias=inner[k][1], zero_row=last is None)
+            if last is not None:
+                _, Hp, Wp = dims
+                hi = (torch.arange(H, device=lat.buf.device) * Hp) // H
+                wi = (torch.arange(W, device=lat.buf.device) * Wp) // W
+                up = last.dense.reshape(B, Hp, Wp, -1)[:, hi][:, :, wi]
+                lat = be.rows16((lat.dense.reshape(B, H, W, -1) + up).reshape(B * H * W, -1), dt, zero_row=True)
+            last, dims = lat, (B, H, W)
+            o = be.conv3x3_rows16(lat, B, H, W, layer[k][0], bias=layer[k][1])
+            outs.insert(0, o.dense.reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous())
+        outs.append(outs[-1][:, :, ::2, ::2].contiguous())
+        return tuple(outs)
 
     def forward_rows(self, cs):
         """forward() on the stage outputs of ResNet50Stages.forward_rows — every convolution of the pyramid a product of the
@@ -234,6 +274,8 @@ class OnlineDetectionModelFPN(nn.Module):
         than the f32 one (6.6 against 5.5 ms in round 3's bench line)."""
         if self._rows_path(image):
             return self.fpn.forward_rows(self.backbone.forward_rows(image))
+        if self._rows16_path(image):
+            return self.fpn.forward_rows16(self.backbone.forward_rows16(image.to(self.compute_dtype)))
         if self.compute_dtype is not None and image.is_cuda:
             # natively in the 16-bit dtype: the folded / cached weights are already in it, and an autocast context costs host
             # time per operation — the bf16 trunk's kernels are shorter than the f32 one's and the forward became host-bound
@@ -242,6 +284,16 @@ class OnlineDetectionModelFPN(nn.Module):
             return tuple(self.fpn(self.backbone(image)))
 
     pyramid = c4
+
+    def _rows16_path(self, x):
+        """_rows_path for compute_dtype = bf16 / f16: trunk and pyramid on 16-bit rows (odx_gemm_b16 / odx_gemm_b16_taps)."""
+        import os
+        if not (x.is_cuda and self.compute_dtype in (torch.bfloat16, torch.float16) and not torch.is_grad_enabled()
+                and os.environ.get("ODX_TRUNK", "rows") != "conv"):
+            return False
+        if x.shape[0] * (-(-x.shape[2] // 16)) * (-(-x.shape[3] // 16)) < self.rows_min_positions:
+            return False
+        return hasattr(_backend.get_backend(), "conv3x3_rows16") and self.backbone.rows_form() and self.fpn.out_channels % 8 == 0
 
     def _rows_path(self, x):
         """The f32 trunk and pyramid on the GPU as row GEMMs on the library's tile cores (as OnlineDetectionModel._rows_path: from
