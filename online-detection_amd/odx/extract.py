@@ -1150,6 +1150,37 @@ def detect(model, image, orig_size=None, score_thresh=-2.0, nms_thresh=0.3, dete
     return res, boxes
 
 
+def detect_batch(model, images, orig_sizes=None, score_thresh=-2.0, nms_thresh=0.3, detections_per_img=100, with_masks=False):
+    """detect() for B pre-processed images of ONE size, images (B, 3, H, W): [(result, proposals)] per image.  One forward for the
+    group (forward_batch: trunk, proposal stage and RoI head once — from three 600 x 800 images on the f32 trunk and heads are
+    one chain of row GEMMs), ONE pass of the on-line box predictor over all images' RoI features (the FALKON scoring and the RLS
+    regressors act row by row), then the reference's post-processing per image in its own original frame
+    (OnlineDetectionPostProcessor.py:12-79).  The reference's test loop walks one image per iteration
+    (engine/inference.py:268-357); the evaluator drop-in groups consecutive images of one size."""
+    from .postprocess import paste_masks, postprocess_detections, select_class_masks
+    if model.online_box is None:
+        raise RuntimeError("detect_batch: the model has no on-line box predictor (update_model(models_detection=...))")
+    B = images.shape[0]
+    img_size = (images.shape[3], images.shape[2])
+    sizes = [tuple(s) if s is not None else img_size for s in (orig_sizes if orig_sizes is not None else [None] * B)]
+    if B == 1:
+        return [detect(model, images, sizes[0], score_thresh, nms_thresh, detections_per_img, with_masks)]
+    per, trunk, _, offs = forward_batch(model, images)
+    scores, deltas = model.online_box(torch.cat([p[1] for p in per], dim=0))
+    out = []
+    for b in range(B):
+        boxes = per[b][0]
+        res = postprocess_detections(scores[offs[b]:offs[b + 1]], deltas[offs[b]:offs[b + 1]], boxes, sizes[b], score_thresh, nms_thresh,
+                                     detections_per_img, proposals_size=img_size)
+        if res is not None and with_masks and model.online_mask is not None and len(res["boxes"]):
+            tb = model.trunk_slice(trunk, b) if hasattr(model, "trunk_slice") else trunk[b:b + 1]
+            back = res["boxes"] * res["boxes"].new_tensor([img_size[0] / sizes[b][0], img_size[1] / sizes[b][1]] * 2)
+            pix = model.online_mask(model.mask_activation(model.roi_head_maps(tb, back)))
+            res["masks"] = paste_masks(select_class_masks(pix, res["labels"]), res["boxes"], sizes[b])
+        out.append((res, boxes))
+    return out
+
+
 class DetectorFeatureExtractor:
     """The per-image harvest loop of FeatureExtractorDetector.train
     (feature_extractor_detector/extract_features_detector.py:96-292 with

@@ -28,7 +28,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import yaml  # noqa: E402
 from odx.contracts import AccuracyEvaluatorAbstract  # noqa: E402
-from odx.extract import OnlineDetectionModel, detect, preprocess_image  # noqa: E402
+from odx.extract import OnlineDetectionModel, detect_batch, preprocess_image  # noqa: E402
 from odx.postprocess import eval_detection  # noqa: E402
 
 
@@ -92,6 +92,28 @@ class AccuracyEvaluator(AccuracyEvaluatorAbstract):
         dev = next(model.parameters()).device
         do_masks = bool(evaluate_segmentation or evaluate_segmentation_icwt) and model.online_mask is not None
         preds, gts = [], []
+        # the reference's test loop walks one image per iteration (engine/inference.py:268-357); consecutive images of one
+        # pre-processed size go through the network together here (extract.detect_batch, cfg_options['trunk_batch'] at a time,
+        # default 4): one forward and one pass of the on-line heads per group, the post-processing per image
+        k = max(1, int(cfg_options.get('trunk_batch', 4))) if dev.type == "cuda" else 1
+        pending = []                                               # (image (1, 3, H, W), original size, wants masks)
+
+        def flush():
+            if not pending:
+                return
+            images = torch.cat([p[0] for p in pending], dim=0)
+            want = any(p[2] for p in pending)
+            for (res, _), (_, orig, want_masks) in zip(detect_batch(model, images, [p[1] for p in pending], score_thresh, nms, per_img,
+                                                                    with_masks=want), pending):
+                if res is None:
+                    res = {"boxes": torch.zeros((0, 4)), "scores": torch.zeros(0), "labels": torch.zeros(0, dtype=torch.int64)}
+                if not want_masks:
+                    res.pop("masks", None)
+                elif "masks" not in res:                           # an image without detections still counts its ground truth
+                    res["masks"] = torch.zeros((0, orig[1], orig[0]), dtype=torch.uint8)
+                preds.append({k2: v.cpu().numpy() for k2, v in res.items()})
+            del pending[:]
+
         for sample in cfg_options['samples']:
             image, gt_boxes, gt_labels = sample[0], torch.as_tensor(sample[1]).float().reshape(-1, 4), list(sample[2])
             gt_masks = sample[3] if len(sample) > 3 else None
@@ -102,19 +124,16 @@ class AccuracyEvaluator(AccuracyEvaluatorAbstract):
                 image, _ = preprocess_image(image, min_size=(cfg.get('INPUT') or {}).get('MIN_SIZE_TEST', 600))
             else:
                 orig = (int(image.shape[3]), int(image.shape[2]))
-            want_masks = do_masks and gt_masks is not None
-            res, _ = detect(model, image, orig, score_thresh, nms, per_img, with_masks=want_masks)
-            if res is None:
-                res = {"boxes": torch.zeros((0, 4)), "scores": torch.zeros(0), "labels": torch.zeros(0, dtype=torch.int64)}
-            if want_masks and "masks" not in res:                  # an image without detections still counts its ground truth
-                res["masks"] = torch.zeros((0, orig[1], orig[0]), dtype=torch.uint8)
-            preds.append({k: v.cpu().numpy() for k, v in res.items()})
+            if pending and (len(pending) >= k or tuple(pending[0][0].shape) != tuple(image.shape)):
+                flush()
+            pending.append((image, orig, do_masks and gt_masks is not None))
             g = {"boxes": gt_boxes.numpy(), "labels": np.asarray(gt_labels, dtype=np.int64)}
             if difficult is not None:
                 g["difficult"] = np.asarray(difficult, dtype=bool)
             if gt_masks is not None:
                 g["masks"] = torch.as_tensor(gt_masks).cpu().numpy()
             gts.append(g)
+        flush()
         names = cfg_options.get('class_names') or cfg.get('CHOSEN_CLASSES') or {}
         result = None
         for thr in thresholds:

@@ -163,6 +163,18 @@ def test_end_to_end_pipeline_on_gpu(tmp_path):
     assert torch.isfinite(scores).all() and torch.isfinite(deltas).all()
     assert "Detector's feature extraction time" in open(os.path.join(str(tmp_path), "result.txt")).read()
     _check_accuracy_evaluator(path, str(tmp_path), model, samples[:4], models, regs, stats, C)
+    # a group of images through ONE forward and one pass of the on-line heads (detect_batch: what the evaluator drop-in runs)
+    # gives every image the detections it gets alone
+    from odx.extract import detect, detect_batch
+    grp = detect_batch(model, torch.cat([smp[0] for smp in samples[:3]]).cuda(), [(256, 192)] * 3, -2.0, 0.3, 50)
+    for j in range(3):
+        one, props = detect(model, samples[j][0].cuda(), (256, 192), -2.0, 0.3, 50)
+        res, pb = grp[j]
+        assert props.shape == pb.shape and float((props - pb).abs().max()) < 1e-3
+        assert (one is None) == (res is None)
+        if one is not None:
+            assert one["labels"].shape == res["labels"].shape and torch.equal(one["labels"], res["labels"])
+            assert float((one["boxes"] - res["boxes"]).abs().max()) < 1e-2 and float((one["scores"] - res["scores"]).abs().max()) < 1e-4
     # save_features=True: nothing is returned, the reference's cache files appear and replay to the same rows
     torch.manual_seed(1)
     assert fe.extractFeatures(True, output_dir=str(tmp_path), save_features=True, cfg_options={"samples": samples, "model": model}) is None

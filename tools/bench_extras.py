@@ -287,10 +287,21 @@ def detect_extra(height=600, width=800, rois=300, C=30, M=1000, reps=10):
         maps = model.roi_head_maps(model.c4(img), boxes)
         scores, deltas = model.online_box(maps.mean(dim=(2, 3)))
         dtp, _ = _best_time(lambda: [postprocess_detections(scores, deltas, boxes, (width, height), -2.0, 0.3, 100) for _ in range(reps)])
-    return {"workload": "detect(): %dx%d image, %d proposals, %d FALKON classifiers (M=%d, D=%d) + %d box regressors, decode + "
-                        "per-class NMS + top-100, f32" % (height, width, boxes.shape[0], C, M, D, C),
-            "ms_per_image": round(dt / reps * 1e3, 2), "images_per_s": round(reps / dt, 1),
-            "postprocessing_ms": round(dtp / reps * 1e3, 2), "detections": 0 if res is None else int(len(res["scores"]))}
+        # groups of images through one forward and one pass of the heads (extract.detect_batch: what the evaluator drop-in runs)
+        from odx.extract import detect_batch
+        grp = {}
+        for B in (4, 8):
+            imgs = torch.randn((B, 3, height, width), generator=g).to(dev)
+            for _ in range(3):
+                detect_batch(model, imgs, [(width, height)] * B, -2.0, 0.3, 100)
+            dtg, _ = _best_time(lambda: [detect_batch(model, imgs, [(width, height)] * B, -2.0, 0.3, 100) for _ in range(3)])
+            grp["ms_per_image_group%d" % B] = round(dtg / (3 * B) * 1e3, 2)
+    out = {"workload": "detect(): %dx%d image, %d proposals, %d FALKON classifiers (M=%d, D=%d) + %d box regressors, decode + "
+                       "per-class NMS + top-100, f32" % (height, width, boxes.shape[0], C, M, D, C),
+           "ms_per_image": round(dt / reps * 1e3, 2), "images_per_s": round(reps / dt, 1),
+           "postprocessing_ms": round(dtp / reps * 1e3, 2), "detections": 0 if res is None else int(len(res["scores"]))}
+    out.update(grp)
+    return out
 
 
 def minibootstrap_extra(C=30, D=2048, IT=10, positives=800, sigma=15.0, modes=(("default", None), ("class_by_class_loop", {"reference_order": "sequential"}), ("class_streams4", {"class_streams": 4}),
