@@ -473,6 +473,10 @@ int odx_taps3x3_16(const void* Y, int64_t ldy, int64_t R, int H, int W, int C, v
  * bias + residual), the taps of the 16-bit NHWC rows Y (R H W rows of C channels, C % 64 == 0, row stride ldy elements, FOLLOWED
  * BY ONE ALL-ZERO ROW) gathered inside the product's operand loads; B (n x 9 C) and the rest as for odx_gemm_b16.  Served where
  * odx_gemm_b16_taps_supported(m = R H W, n, C, ldy) returns 1; elsewhere odx_taps3x3_16 + odx_gemm_b16. */
+/* Measurement only (tools/ab_mfma_shape.py): odx_gemm_h2_f32 without bias / residual on the same 256 x 256 LDS-DMA loop built from
+ * v_mfma_f32_32x32x16_f16 instead of v_mfma_f32_16x16x32_f16 — the A/B of the MFMA shape the round-4 review asked for. */
+int odx_debug_gemm_h2_mf32(const void* PA, int64_t ldpa, const float* metaa, int64_t m, const void* PB, int64_t ldpb,
+                           const float* metab, int64_t n, int K, float* out, int64_t ldo, odx_stream_t stream);
 int odx_gemm_b16_taps_supported(int64_t m, int64_t n, int C, int64_t ldy);
 int odx_gemm_b16_taps(const void* Y, int64_t ldy, int64_t R, int H, int W, int C, const void* B, int64_t ldb, int64_t n,
                       int is_bf16, const float* bias, const void* residual, int64_t ldr, int relu, void* out, int64_t ldo,

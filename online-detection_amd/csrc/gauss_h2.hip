@@ -902,6 +902,165 @@ __device__ __forceinline__ void w_mainloop_dma(f32x4 (&acc)[8][4], const uint32_
   __syncthreads();          // every wave has read its last fragments: the LDS is the caller's again
 }
 
+// ---- A/B of the MFMA shape (round-4 review, item 3 iii): the SAME stage pipeline — LDS-DMA staging, the LDS image, the DMA
+// issue spread over the parts, the barrier in front of the last part — with v_mfma_f32_32x32x16_f16 instead of
+// v_mfma_f32_16x16x32_f16: half the MFMA instructions for the same products (12 instead of 24 per part, each twice as long), the
+// same number of fragment reads (a 32-row block of one 16-feature step is 16 bytes per lane: row lane & 31, k-chunk lane >> 5
+// + 2 step), the same registers (4 x 2 accumulator blocks of 16 instead of 8 x 4 of 4; 8 B and 2 x 4 A fragment registers).
+// A wave's share is still 128 x 64.  Used by the debug entry odx_debug_gemm_h2_mf32 only (tools/ab_mfma_shape.py).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WFrag32 {
+  f16x8 bh[2][2], bl[2][2];   // [column block of 32][k-step]
+  f16x8 a0h[2], a0l[2];       // A fragments of parts 0 and 2 (one 32-row block, two k-steps)
+  f16x8 a1h[2], a1l[2];       // parts 1 and 3
+};
+
+struct WOff32 {
+  int fa, fb;                 // LDS row of this lane in the A / B image (row lane & 31 of block 0)
+  int hi[2];                  // byte offset of the hi chunk of k-step 0 / 1 inside the lane's row; lo = hi ^ 64
+};
+
+__device__ __forceinline__ void w32_read_a(f16x8 (&ah)[2], f16x8 (&al)[2], const char* img, const WOff32& o, int part) {
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    ah[st] = *reinterpret_cast<const f16x8*>(img + o.fa + part * 32 * W_ROW + o.hi[st]);
+    al[st] = *reinterpret_cast<const f16x8*>(img + o.fa + part * 32 * W_ROW + (o.hi[st] ^ 64));
+  }
+}
+
+__device__ __forceinline__ void w32_read_b1(WFrag32& f, const char* img, const WOff32& o, int c, int st) {
+  f.bh[c][st] = *reinterpret_cast<const f16x8*>(img + o.fb + c * 32 * W_ROW + o.hi[st]);
+  f.bl[c][st] = *reinterpret_cast<const f16x8*>(img + o.fb + c * 32 * W_ROW + (o.hi[st] ^ 64));
+}
+
+__device__ __forceinline__ void w32_mfma(f32x16& acc, const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+}
+
+template <bool F1, bool F2>
+__device__ __forceinline__ void w32_stage(f32x16 (&acc)[4][2], WFrag32& f, const char* cur, char* nxt, int koff1, const WDma& ad, const WOff32& o) {
+  // part 0, reading part 1
+  w32_read_a(f.a1h, f.a1l, cur, o, 1);
+  if (F1) w_dma_pieces<3, 6>(ad, nxt, koff1);
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) w32_mfma(acc[0][c], f.a0h[st], f.a0l[st], f.bh[c][st], f.bl[c][st]);
+  w_sched_part<3, F1 ? 3 : 0>();
+  __builtin_amdgcn_sched_barrier(0);
+  // part 1, reading part 2
+  w32_read_a(f.a0h, f.a0l, cur, o, 2);
+  if (F1) w_dma_pieces<6, 8>(ad, nxt, koff1);
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) w32_mfma(acc[1][c], f.a1h[st], f.a1l[st], f.bh[c][st], f.bl[c][st]);
+  w_sched_part<3, F1 ? 2 : 0>();
+  __builtin_amdgcn_sched_barrier(0);
+  // part 2, reading part 3
+  w32_read_a(f.a1h, f.a1l, cur, o, 3);
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) w32_mfma(acc[2][c], f.a0h[st], f.a0l[st], f.bh[c][st], f.bl[c][st]);
+  w_sched_part<3, 0>();
+  __builtin_amdgcn_sched_barrier(0);
+  if (F1) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (F2) w_dma_pieces<0, 3>(ad, const_cast<char*>(cur), koff1 + W_KS * 4);
+    w32_read_a(f.a0h, f.a0l, nxt, o, 0);
+  }
+  // part 3; each (column block, k-step) pair's B registers take the next stage's fragments as soon as it is done
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      w32_mfma(acc[3][c], f.a1h[st], f.a1l[st], f.bh[c][st], f.bl[c][st]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (F1) w32_read_b1(f, nxt, o, c, st);
+    }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ void w32_mainloop_dma(f32x16 (&acc)[4][2], const uint32_t* __restrict__ A, int64_t lda, int64_t m,
+                                                 const uint32_t* __restrict__ B, int64_t ldb, int64_t n, int64_t i0, int64_t j0, int stages,
+                                                 char* lds) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  WDma ad;
+  w_dma_offsets<false>(ad.va, lda, i0, m);
+  w_dma_offsets<false>(ad.vb, ldb, j0, n);
+  const int64_t la = m - i0 < W_BM ? m - i0 : W_BM, lb = n - j0 < W_BN ? n - j0 : W_BN;
+  ad.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(A + i0 * lda), (short)0, (int)(la * lda * 4), 0x00020000);
+  ad.rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(B + j0 * ldb), (short)0, (int)(lb * ldb * 4), 0x00020000);
+  const int r = lane & 31, kh = lane >> 5;
+  WOff32 o;
+  o.fa = (wr * 128 + r) * W_ROW;
+  o.fb = W_OPND_BYTES + (wc * 64 + r) * W_ROW;
+#pragma unroll
+  for (int st = 0; st < 2; ++st) o.hi[st] = (((kh + 2 * st) ^ ((r >> 1) & 7)) << 4);
+  w_dma_pieces<0, 8>(ad, lds, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (stages > 1) w_dma_pieces<0, 3>(ad, lds + W_STAGE_BYTES, W_KS * 4);
+  WFrag32 f;
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) w32_read_b1(f, lds, o, c, st);
+  w32_read_a(f.a0h, f.a0l, lds, o, 0);
+  int s = 0;
+  for (; s + 2 < stages; ++s)
+    w32_stage<true, true>(acc, f, lds + (s & 1) * W_STAGE_BYTES, lds + ((s + 1) & 1) * W_STAGE_BYTES, (s + 1) * (W_KS * 4), ad, o);
+  if (s + 1 < stages) {
+    w32_stage<true, false>(acc, f, lds + (s & 1) * W_STAGE_BYTES, lds + ((s + 1) & 1) * W_STAGE_BYTES, (s + 1) * (W_KS * 4), ad, o);
+    ++s;
+  }
+  w32_stage<false, false>(acc, f, lds + (s & 1) * W_STAGE_BYTES, lds, 0, ad, o);
+  __syncthreads();
+}
+
+// out = A B' / (s_A s_B) with the 32 x 32 x 16 loop above: plain f32 stores, no bias / residual (a measurement and its check)
+__global__ __launch_bounds__(W_THREADS, 1) void gemm_h2w256_mf32_kernel(
+    const uint32_t* __restrict__ PA, int64_t ldpa, const float* __restrict__ metaa, int64_t m, const uint32_t* __restrict__ PB,
+    int64_t ldpb, const float* __restrict__ metab, int64_t n, int stages, float* __restrict__ out, int64_t ldo, int gr) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int64_t GR = gr;
+  const int64_t tiles_n = (n + W_BN - 1) / W_BN;
+  const int64_t wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t band = wg / (GR * tiles_n), within = wg % (GR * tiles_n);
+  const int64_t i0 = (band * GR + within % GR) * W_BM, j0 = (within / GR) * W_BN;
+  if (i0 >= m) return;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[p][c][j] = 0.f;
+  w32_mainloop_dma(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds);
+  const float inv = 1.f / (metaa[0] * metab[0]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int r = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int64_t col = j0 + wc * 64 + c * 32 + r;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int64_t row = i0 + wr * 128 + p * 32 + (j >> 2) * 8 + kh * 4 + (j & 3);
+        if (row < m && col < n) out[row * ldo + col] = acc[p][c][j] * inv;
+      }
+    }
+}
+
 __device__ __forceinline__ void w_zero(f32x4 (&acc)[8][4]) {
 #pragma unroll
   for (int tm = 0; tm < 8; ++tm)
@@ -2051,6 +2210,26 @@ extern "C" int odx_gemm_h2_taps_f32(const void* PY, int64_t ldpy, const float* m
                      (const uint32_t*)PY, ldpy, metay, m, (const uint32_t*)PB, ldpb, metab, n, (int)(K / W_KS), bias, residual, ldr,
                      relu, out, ldo, gr, amax, H, W, C, pk);
   ODX_CHECK_LAUNCH("odx_gemm_h2_taps_f32");
+  return ODX_OK;
+}
+
+// Measurement only (tools/ab_mfma_shape.py): out (m x n) f32 = A B' for packed operands on the 256 x 256 LDS-DMA loop built from
+// v_mfma_f32_32x32x16_f16 — the A/B partner of odx_gemm_h2_f32 (v_mfma_f32_16x16x32_f16) on the same operands.
+extern "C" int odx_debug_gemm_h2_mf32(const void* PA, int64_t ldpa, const float* metaa, int64_t m, const void* PB, int64_t ldpb,
+                                      const float* metab, int64_t n, int K, float* out, int64_t ldo, odx_stream_t stream) {
+  if (m <= 0 || n <= 0) return ODX_OK;
+  ODX_REQUIRE(PA && PB && metaa && metab && out && K > 0, "odx_debug_gemm_h2_mf32: bad argument");
+  const int64_t dp = round_up(K, H2_KT);
+  ODX_REQUIRE(ldpa % 4 == 0 && ldpb % 4 == 0 && ldpa >= dp && ldpb >= dp && aligned16(PA) && aligned16(PB) && ldo >= n,
+              "odx_debug_gemm_h2_mf32: packed operands as for odx_gemm_h2_f32");
+  ODX_REQUIRE(ldpa < (1 << 24) && ldpb < (1 << 24), "odx_debug_gemm_h2_mf32: leading dimensions must stay below 2^24");
+  const int gr = 8;
+  const int64_t wt = round_up(ceil_div(m, W_BM), gr) * ceil_div(n, W_BN);
+  ODX_REQUIRE(wt < (1ll << 31), "odx_debug_gemm_h2_mf32: grid too large");
+  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2w256_mf32_kernel), W_LDS_BYTES));
+  hipLaunchKernelGGL(gemm_h2w256_mf32_kernel, dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream), (const uint32_t*)PA, ldpa,
+                     metaa, m, (const uint32_t*)PB, ldpb, metab, n, (int)(dp / W_KS), out, ldo, gr);
+  ODX_CHECK_LAUNCH("odx_debug_gemm_h2_mf32");
   return ODX_OK;
 }
 

@@ -1397,6 +1397,22 @@ def test_16bit_3x3_convolution_with_the_taps_gathered_in_the_operand_loads(dtype
         assert bool(((got.dense.double() - ref).abs() <= ulp * ref.abs() + 1e-5 * float(ref.abs().max())).all())
 
 
+def test_the_32x32x16_loop_of_the_mfma_shape_ab_gives_the_product(be):
+    """odx_debug_gemm_h2_mf32 (tools/ab_mfma_shape.py's partner of odx_gemm_h2_f32: the 256 x 256 LDS-DMA loop built from
+    v_mfma_f32_32x32x16_f16) computes the same f32-accurate product — ragged edges, several tiles either way."""
+    from odx import hip
+    g = torch.Generator().manual_seed(5)
+    A, B = torch.randn((70000, 200), generator=g).cuda(), torch.randn((300, 200), generator=g).cuda()
+    pa, pb = be.packed(A), be.packed(B)
+    out = torch.empty((pa.n, pb.n), dtype=torch.float32, device="cuda")
+    hip.check(be.lib.odx_debug_gemm_h2_mf32(ctypes.c_void_p(pa.P.data_ptr()), pa.P.stride(0), ctypes.c_void_p(pa.meta.data_ptr()), pa.n,
+                                            ctypes.c_void_p(pb.P.data_ptr()), pb.P.stride(0), ctypes.c_void_p(pb.meta.data_ptr()), pb.n, pa.D,
+                                            ctypes.c_void_p(out.data_ptr()), pb.n, be._stream()), "odx_debug_gemm_h2_mf32")
+    ref = A.double() @ B.double().t()
+    assert float((out.double() - ref).abs().max()) < 2e-6 * float(ref.abs().max())
+    assert float((out - be.gemm_h2(pa, pb)).abs().max()) < 2e-6 * float(ref.abs().max())
+
+
 def test_cu_masked_stream_and_partition_sized_pass(be):
     """The diagnostic entry points behind tools/cu_split_probe.py: a stream confined to 16 compute units runs its workgroups
     on at most 16 distinct (XCC, SE, SH, CU) places, two per XCC; a compact pass launched there with its persistent grid sized
