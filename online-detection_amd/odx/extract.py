@@ -743,20 +743,19 @@ class OnlineDetectionModel(nn.Module):
         # stride-16 positions (images x h x w) from which the f32 trunk and RPN head run as row GEMMs (_rows_path)
         self.rows_min_positions = int(os.environ.get("ODX_ROWS_MIN_POSITIONS", 4800))
         self._trunk_graphs = GraphedCall(self._c4_eager)
-        # The whole group forward from ONE HIP graph (forward_group): OPT-IN, ODX_GROUP_GRAPH=1.  What round 5 found on this
-        # runtime: (i) with the proposal stage as tensor operations (a library top-k, gather, advanced indexing) the graph's second
-        # or third replay ended in a GPU memory fault whenever other work had run in between — tools/group_graph_bisect.py captures
-        # growing prefixes of the forward and localised it to exactly that stage; the stage is three kernels of this library now
-        # (odx_rpn_topk_decode_f32, odx_nms_batched_first_f32, odx_nms_compact_f32) and every prefix replays, at full size, with
-        # other work in between (tests/test_extract.py); (ii) a graph launched from CHANGING streams returned the previous inputs'
-        # results or zeros — GraphedCall now launches every graph on one stream of its own; (iii) one sequence (replays called
-        # alternately from the default and a side stream, a second graph replayed in between) still produced all-zero features
-        # once and could not be reproduced in isolation.  Until (iii) is understood the harvest loop queues a group's forward
-        # launch by launch (forward_batch: one trunk call, one proposal stage, one head pass per group) — 3.2 instead of 3.0 ms per
-        # image for the forward alone at 8 images per group, the harvest loop 5.2 ms per image either way (it is bound by the
-        # harvesters' own host work) — and this path is kept as the opt-in it is.
+        # The whole group forward from ONE HIP graph (forward_group); ODX_GROUP_GRAPH=0 turns it off.  What it took on this
+        # runtime (round 5): (i) with the proposal stage as tensor operations (a library top-k, gather, advanced indexing) the
+        # graph's second or third replay ended in a GPU memory fault — tools/group_graph_bisect.py localised it to that stage,
+        # which is three kernels of this library now (odx_rpn_topk_decode_f32, odx_nms_batched_first_f32, odx_nms_compact_f32);
+        # (ii) a graph launched from CHANGING streams returned the previous inputs' results or zeros — GraphedCall launches
+        # every graph on one stream of its own; (iii) one sequence still produced all-zero features once — explained later in
+        # the round: hipMemsetAsync captured into a graph is not reliably ordered against the kernel nodes around it (the same
+        # fault showed as all-zero trunk maps under the threaded harvest loop), and the suppression's two
+        # clears were memsets.  Every clear that can be captured is a kernel now; tools/group_graph_soak.py (1500 group
+        # forwards on changing images and calling streams with another graph and other work in between, 40 harvest passes,
+        # every result checked against the launch-by-launch forward: no difference) is what the default rests on.
         self._group_graphs = GraphedCall(self._group_static, max_graphs=4)
-        if os.environ.get("ODX_GROUP_GRAPH", "0") != "1":
+        if os.environ.get("ODX_GROUP_GRAPH", "1") == "0":
             self._group_graphs.enabled = False
         self.register_load_state_dict_post_hook(OnlineDetectionModel._drop_graphs)
 
