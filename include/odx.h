@@ -556,6 +556,31 @@ int odx_bias_act_nchw_16(void* y, const void* bias, const void* residual, int is
                          odx_stream_t stream);
 
 
+/* ---------------------------------------------------------------- A11 / A12: harvest labelling
+ * The device work in front of a harvester's host read (odx/harvest.py RPNHarvester.prepare / DetectorHarvester.prepare; the
+ * reference's rpn_getProposals.py:265-449 and box_head_getProposals.py:117-226 label anchors / proposals against the ground-truth
+ * boxes with ~45 tensor operations per image): one or two launches, the tensor form's arithmetic operation by operation in f32
+ * (no fused multiply-add: the flags compare overlaps with thresholds), maxima keep the FIRST maximum.  G <= 64 boxes per image.
+ *
+ * odx_rpn_label_f32: n visible anchors (anchors (n, 4), cls (n) int64 anchor types 0..A-1) against gt (G, 4): ious (n) best overlap,
+ * assoc (n, 4) the box of best overlap, neg_mask / over (n) bytes (overlap < neg_thr, > pos_thr), extra (G, n) bytes (anchor i is
+ * associated with a box equal to box j and has the best overlap of all such anchors); counters (int32): [A candidates per type]
+ * [G over-threshold anchors whose box shares a coordinate with box j][G box j has anchors][A over-threshold anchors per type]
+ * [G x A extras of box j per type].  workspace: G uint32.
+ * odx_det_label_f32: R proposals against gt (G, 4) with classes labels0 (G) int32 (0-based): both clamped to the image (prop (R, 4)
+ * out), overlap (R, C) per-class maximum overlap, sel (G, R) bytes (proposal r regresses onto box j: its class's overlap > reg_min
+ * and j the first box of largest, positive overlap), cmask (R, n_in) bytes (overlap of listed class in_image[k] < neg_thr);
+ * counters (int32): [G pairs per box][n_in candidates per listed class].
+ * odx_box_targets_f32: the regression targets of n (example, target) box pairs, ((gx - sx) / sw, (gy - sy) / sh, log(gw / sw),
+ * log(gh / sh)) with widths x2 - x1 + 1. */
+int odx_rpn_label_f32(const float* gt, int G, const float* anchors, const int64_t* cls, int n, int A, float neg_thr,
+                      float pos_thr, float* ious, float* assoc, unsigned char* neg_mask, unsigned char* over,
+                      unsigned char* extra, int32_t* counters, void* workspace, odx_stream_t stream);
+int odx_det_label_f32(const float* gt, const int32_t* labels0, int G, const float* proposals, int R, int C, float img_w,
+                      float img_h, float reg_min, float neg_thr, const int32_t* in_image, int n_in, float* prop, float* overlap,
+                      unsigned char* sel, unsigned char* cmask, int32_t* counters, odx_stream_t stream);
+int odx_box_targets_f32(const float* examples, const float* targets, int64_t n, float* out, odx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -583,6 +583,155 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restric
   out[((int64_t)r * im_h + y) * im_w + x] = v;
 }
 
+
+// ---------------------------------------------------------------- harvest labelling (the device work in front of a harvester's host read)
+// The on-line RPN and detector harvesters (odx/harvest.py: RPNHarvester.prepare, DetectorHarvester.prepare; the reference's
+// rpn_getProposals.py:265-449 and box_head_getProposals.py:117-226) label every anchor / proposal of an image against its
+// ground-truth boxes before the host decides what to sample: overlaps, the associated box, the flags and their counts.  As tensor
+// operations that is ~45 launches per image and harvester; here it is one launch (two for the anchors: the best overlap per box
+// is a reduction over all of them).  The arithmetic is the tensor form's, operation by operation in f32 with no fused
+// multiply-add (the flags compare overlaps with thresholds: they have to be the same bits), maxima keep the FIRST maximum.
+__device__ __forceinline__ float iou_plus1(const float* g, const float* p) {
+#pragma clang fp contract(off)
+  const float xmin = fmaxf(g[0], p[0]), ymin = fmaxf(g[1], p[1]), xmax = fminf(g[2], p[2]), ymax = fminf(g[3], p[3]);
+  const float w = xmax - xmin + 1.f, h = ymax - ymin + 1.f;
+  const float inter = w * h;
+  const float ga = (g[2] - g[0] + 1.f) * (g[3] - g[1] + 1.f);
+  const float pa = (p[2] - p[0] + 1.f) * (p[3] - p[1] + 1.f);
+  const float ov = inter / (ga + pa - inter);
+  return (w > 0.f && h > 0.f) ? ov : 0.f;
+}
+
+constexpr int LABEL_MAX_GT = 64;
+
+// counters (int32, zero on entry): [A candidates per type][G hit][G has_mine][A over per type][G A extras per (box, type)]
+__global__ __launch_bounds__(256) void rpn_label_kernel(const float* __restrict__ gt, int G, const float* __restrict__ anchors,
+                                                        const int64_t* __restrict__ cls, int n, int A, float neg_thr, float pos_thr,
+                                                        float* __restrict__ ious, float* __restrict__ assoc, unsigned char* __restrict__ neg_mask,
+                                                        unsigned char* __restrict__ over, unsigned int* __restrict__ best_bits,
+                                                        int* __restrict__ counters) {
+  __shared__ float gs[LABEL_MAX_GT * 4];
+  for (int k = threadIdx.x; k < G * 4; k += 256) gs[k] = gt[k];
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) a[q] = anchors[(int64_t)i * 4 + q];
+  float best = iou_plus1(gs, a);
+  int arg = 0;
+  for (int j = 1; j < G; ++j) {
+    const float v = iou_plus1(gs + 4 * j, a);
+    if (v > best) { best = v; arg = j; }
+  }
+  float as[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { as[q] = gs[4 * arg + q]; assoc[(int64_t)i * 4 + q] = as[q]; }
+  ious[i] = best;
+  const bool ng = best < neg_thr, ov = best > pos_thr;
+  neg_mask[i] = ng;
+  over[i] = ov;
+  const int t = (int)cls[i];
+  if (ng) atomicAdd(counters + t, 1);
+  if (ov) atomicAdd(counters + A + 2 * G + t, 1);
+  for (int j = 0; j < G; ++j) {
+    const bool e0 = as[0] == gs[4 * j], e1 = as[1] == gs[4 * j + 1], e2 = as[2] == gs[4 * j + 2], e3 = as[3] == gs[4 * j + 3];
+    if (e0 && e1 && e2 && e3) {
+      atomicMax(best_bits + j, __float_as_uint(best));       // overlaps are >= 0: their bits order like the numbers
+      counters[A + G + j] = 1;                                // (every writer stores the same value)
+    }
+    if ((e0 || e1 || e2 || e3) && ov) atomicAdd(counters + A + j, 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void rpn_label_extra_kernel(const float* __restrict__ gt, int G, const int64_t* __restrict__ cls, int n, int A,
+                                                              const float* __restrict__ ious, const float* __restrict__ assoc,
+                                                              const unsigned int* __restrict__ best_bits, unsigned char* __restrict__ extra,
+                                                              int* __restrict__ counters) {
+  __shared__ float gs[LABEL_MAX_GT * 4];
+  for (int k = threadIdx.x; k < G * 4; k += 256) gs[k] = gt[k];
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = ious[i];
+  float as[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) as[q] = assoc[(int64_t)i * 4 + q];
+  const int t = (int)cls[i];
+  for (int j = 0; j < G; ++j) {
+    const bool mine = as[0] == gs[4 * j] && as[1] == gs[4 * j + 1] && as[2] == gs[4 * j + 2] && as[3] == gs[4 * j + 3];
+    const bool ex = mine && v == __uint_as_float(best_bits[j]);
+    extra[(int64_t)j * n + i] = ex;
+    if (ex) atomicAdd(counters + 2 * A + 2 * G + j * A + t, 1);
+  }
+}
+
+// counters (int32, zero on entry): [G pairs per box][n_in candidates per listed class]
+__global__ __launch_bounds__(256) void det_label_kernel(const float* __restrict__ gt_raw, const int* __restrict__ labels0, int G,
+                                                        const float* __restrict__ prop_raw, int R, int C, float img_w, float img_h,
+                                                        float reg_min, float neg_thr, const int* __restrict__ in_image, int n_in,
+                                                        float* __restrict__ prop, float* __restrict__ overlap, unsigned char* __restrict__ sel,
+                                                        unsigned char* __restrict__ cmask, int* __restrict__ counters) {
+  __shared__ float gs[LABEL_MAX_GT * 4];
+  __shared__ int ls[LABEL_MAX_GT];
+  for (int k = threadIdx.x; k < G * 4; k += 256) {
+    const float hi = (k & 1) ? img_h - 1.f : img_w - 1.f;         // clamp_boxes_: x to [0, w - 1], y to [0, h - 1]
+    gs[k] = fminf(fmaxf(gt_raw[k], 0.f), hi);
+  }
+  for (int k = threadIdx.x; k < G; k += 256) ls[k] = labels0[k];
+  __syncthreads();
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  float p[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float hi = (q & 1) ? img_h - 1.f : img_w - 1.f;
+    p[q] = fminf(fmaxf(prop_raw[(int64_t)r * 4 + q], 0.f), hi);
+    prop[(int64_t)r * 4 + q] = p[q];
+  }
+  float* orow = overlap + (int64_t)r * C;
+  for (int c = 0; c < C; ++c) orow[c] = 0.f;
+  float best = -1.f;
+  int first = -1;
+  for (int j = 0; j < G; ++j) {
+    const float v = iou_plus1(gs + 4 * j, p);
+    const int c = ls[j];
+    if (c >= 0 && c < C) orow[c] = fmaxf(orow[c], v);
+    if (v > best) { best = v; first = j; }                      // the FIRST maximum
+  }
+  const int assoc = best > 0.f ? first : -1;
+  for (int j = 0; j < G; ++j) {
+    const int c = ls[j];
+    const bool s = c >= 0 && c < C && orow[c] > reg_min && assoc == j;
+    sel[(int64_t)j * R + r] = s;
+    if (s) atomicAdd(counters + j, 1);
+  }
+  for (int k = 0; k < n_in; ++k) {
+    const bool m = orow[in_image[k]] < neg_thr;
+    cmask[(int64_t)r * n_in + k] = m;
+    if (m) atomicAdd(counters + G + k, 1);
+  }
+}
+
+// regression targets of n (example, target) box pairs, the reference's formula operation by operation
+// (box_head_getProposals.py:170-182, rpn_getProposals.py:420-432): ((gx - sx) / sw, (gy - sy) / sh, log(gw / sw), log(gh / sh))
+__global__ __launch_bounds__(256) void box_targets_kernel(const float* __restrict__ ex, const float* __restrict__ tg, int64_t n,
+                                                          float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* e = ex + i * 4;
+  const float* g = tg + i * 4;
+  const float sw = e[2] - e[0] + 1.f, sh = e[3] - e[1] + 1.f;
+  const float sx = e[0] + 0.5f * sw, sy = e[1] + 0.5f * sh;
+  const float gw = g[2] - g[0] + 1.f, gh = g[3] - g[1] + 1.f;
+  const float gx = g[0] + 0.5f * gw, gy = g[1] + 0.5f * gh;
+  out[i * 4 + 0] = (gx - sx) / sw;
+  out[i * 4 + 1] = (gy - sy) / sh;
+  out[i * 4 + 2] = logf(gw / sw);
+  out[i * 4 + 3] = logf(gh / sh);
+}
+
 }  // namespace odx
 
 using namespace odx;
@@ -871,4 +1020,58 @@ extern "C" int odx_bias_act_nchw_16(void* y, const void* bias, const void* resid
                                     odx_stream_t stream) {
   return is_bf16 ? bias_act_nchw<EpiBF16>(y, bias, residual, N, C, HW, relu, stream, "odx_bias_act_nchw_16")
                  : bias_act_nchw<EpiF16>(y, bias, residual, N, C, HW, relu, stream, "odx_bias_act_nchw_16");
+}
+
+// Labels of the n visible anchors of an image against its G ground-truth boxes (RPNHarvester.prepare): per anchor the best overlap
+// (ious), the box it is associated with (assoc (n, 4)), overlap below neg_thr / above pos_thr (neg_mask, over: bytes), per box the
+// anchors that are its best among those associated with it (extra (G, n) bytes), and the counts the host decides from —
+// counters (int32): [A: candidates per anchor type][G: over-threshold anchors sharing a coordinate with box j][G: box j has
+// anchors][A: over-threshold anchors per type][G x A: extras of box j per type].  cls (n) int64: anchor types.  G <= 64.
+// workspace: G uint32 (scratch).
+extern "C" int odx_rpn_label_f32(const float* gt, int G, const float* anchors, const int64_t* cls, int n, int A, float neg_thr,
+                                 float pos_thr, float* ious, float* assoc, unsigned char* neg_mask, unsigned char* over,
+                                 unsigned char* extra, int32_t* counters, void* workspace, odx_stream_t stream) {
+  ODX_REQUIRE(G >= 1 && G <= LABEL_MAX_GT && A >= 1, "odx_rpn_label_f32: 1..%d ground-truth boxes per image", LABEL_MAX_GT);
+  hipStream_t s = as_stream(stream);
+  const size_t nc = (size_t)(2 * A + 2 * G + G * A);
+  ODX_PROPAGATE(zero_bytes(counters, nc * sizeof(int32_t), s));
+  if (n <= 0) return ODX_OK;
+  ODX_REQUIRE(gt && anchors && cls && ious && assoc && neg_mask && over && extra && counters && workspace, "odx_rpn_label_f32: null pointer");
+  ODX_PROPAGATE(zero_bytes(workspace, (size_t)G * sizeof(unsigned int), s));
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(rpn_label_kernel, dim3(blocks), dim3(256), 0, s, gt, G, anchors, cls, n, A, neg_thr, pos_thr, ious, assoc, neg_mask, over,
+                     static_cast<unsigned int*>(workspace), counters);
+  ODX_CHECK_LAUNCH("odx_rpn_label_f32");
+  hipLaunchKernelGGL(rpn_label_extra_kernel, dim3(blocks), dim3(256), 0, s, gt, G, cls, n, A, ious, assoc,
+                     static_cast<const unsigned int*>(workspace), extra, counters);
+  ODX_CHECK_LAUNCH("odx_rpn_label_f32(extra)");
+  return ODX_OK;
+}
+
+// Labels of the R proposals of an image against its G ground-truth boxes (DetectorHarvester.prepare): boxes clamped to the image
+// (prop (R, 4) out), per-class maximum overlap (overlap (R, C)), the regression pairs (sel (G, R) bytes: proposal r regresses onto
+// box j — its class's overlap above reg_min and box j the FIRST box of largest overlap, if that is positive), the negatives'
+// candidate flags of the n_in listed classes (cmask (R, n_in) bytes: overlap below neg_thr) and counters (int32): [G: pairs per
+// box][n_in: candidates per listed class].  labels0 (G) int32: class of box j, 0-based; in_image (n_in) int32.  G <= 64.
+extern "C" int odx_det_label_f32(const float* gt, const int32_t* labels0, int G, const float* proposals, int R, int C, float img_w,
+                                 float img_h, float reg_min, float neg_thr, const int32_t* in_image, int n_in, float* prop, float* overlap,
+                                 unsigned char* sel, unsigned char* cmask, int32_t* counters, odx_stream_t stream) {
+  ODX_REQUIRE(G >= 1 && G <= LABEL_MAX_GT && C >= 1 && n_in >= 0, "odx_det_label_f32: 1..%d ground-truth boxes per image", LABEL_MAX_GT);
+  hipStream_t s = as_stream(stream);
+  ODX_PROPAGATE(zero_bytes(counters, (size_t)(G + n_in) * sizeof(int32_t), s));
+  if (R <= 0) return ODX_OK;
+  ODX_REQUIRE(gt && labels0 && proposals && prop && overlap && sel && counters && (n_in == 0 || (in_image && cmask)), "odx_det_label_f32: null pointer");
+  hipLaunchKernelGGL(det_label_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, gt, labels0, G, proposals, R, C, img_w, img_h, reg_min,
+                     neg_thr, in_image, n_in, prop, overlap, sel, cmask, counters);
+  ODX_CHECK_LAUNCH("odx_det_label_f32");
+  return ODX_OK;
+}
+
+// out (n, 4) = the box-regression targets of n (example, target) pairs (x1, y1, x2, y2 rows).
+extern "C" int odx_box_targets_f32(const float* examples, const float* targets, int64_t n, float* out, odx_stream_t stream) {
+  if (n <= 0) return ODX_OK;
+  ODX_REQUIRE(examples && targets && out, "odx_box_targets_f32: null pointer");
+  hipLaunchKernelGGL(box_targets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), examples, targets, n, out);
+  ODX_CHECK_LAUNCH("odx_box_targets_f32");
+  return ODX_OK;
 }

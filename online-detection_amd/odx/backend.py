@@ -1059,6 +1059,53 @@ class HipBackend:
                                                   int(sampling_ratio), int(step), _p(out), self._stream()), "odx_roi_align_rows_f32")
         return out, (R, OH, OW)
 
+    # ------------------------------------------------------------------ harvest labelling (odx/harvest.py)
+    LABEL_MAX_GT = 64
+
+    def rpn_label(self, gt, anchors, cls, A, neg_thr, pos_thr):
+        """Labels of the visible anchors of an image against its ground-truth boxes in two launches (odx_rpn_label_f32): returns
+        (ious (n,), assoc (n, 4), neg_mask (n,) bool, over (n,) bool, extra (G, n) bool, counters (2 A + 2 G + G A,) int32 in
+        the order RPNHarvester reads them)."""
+        gt = gt.to(device=self.device, dtype=torch.float32).contiguous()
+        anchors = anchors.to(device=self.device, dtype=torch.float32).contiguous()
+        cls = cls.to(device=self.device, dtype=torch.int64).contiguous()
+        G, n = int(gt.shape[0]), int(anchors.shape[0])
+        ious = torch.empty(n, dtype=torch.float32, device=self.device)
+        assoc = torch.empty((n, 4), dtype=torch.float32, device=self.device)
+        flags = torch.empty((2 + G, n), dtype=torch.uint8, device=self.device)
+        counters = torch.empty(2 * A + 2 * G + G * A + G, dtype=torch.int32, device=self.device)       # (+ G words of scratch)
+        nc = 2 * A + 2 * G + G * A
+        hip.check(self.lib.odx_rpn_label_f32(_p(gt), G, _p(anchors), _p(cls), n, int(A), float(neg_thr), float(pos_thr), _p(ious), _p(assoc),
+                                             _p(flags[0]), _p(flags[1]), _p(flags[2:]), _p(counters), _p(counters[nc:]), self._stream()),
+                  "odx_rpn_label_f32")
+        fb = flags.view(torch.bool)
+        return ious, assoc, fb[0], fb[1], fb[2:], counters[:nc]
+
+    def det_label(self, gt, labels0, proposals, C, img_size, reg_min, neg_thr, in_image):
+        """Labels of the proposals of an image against its ground-truth boxes in one launch (odx_det_label_f32): returns (prop
+        (R, 4) clamped to the image, overlap (R, C), sel (G, R) bool, cmask (R, n_in) bool or None, counters (G + n_in,) int32).
+        labels0 / in_image: DEVICE int32 tensors (the boxes' 0-based classes; the classes whose candidates are wanted)."""
+        gt = gt.to(device=self.device, dtype=torch.float32).contiguous()
+        proposals = proposals.to(device=self.device, dtype=torch.float32).contiguous()
+        G, R, n_in = int(gt.shape[0]), int(proposals.shape[0]), int(in_image.numel())
+        prop = torch.empty((R, 4), dtype=torch.float32, device=self.device)
+        overlap = torch.empty((R, int(C)), dtype=torch.float32, device=self.device)
+        sel = torch.empty((G, R), dtype=torch.uint8, device=self.device)
+        cmask = torch.empty((R, n_in), dtype=torch.uint8, device=self.device) if n_in else None
+        counters = torch.empty(G + n_in, dtype=torch.int32, device=self.device)
+        hip.check(self.lib.odx_det_label_f32(_p(gt), _p(labels0), G, _p(proposals), R, int(C), float(img_size[0]), float(img_size[1]),
+                                             float(reg_min), float(neg_thr), _p(in_image) if n_in else None, n_in, _p(prop), _p(overlap), _p(sel),
+                                             _p(cmask), _p(counters), self._stream()), "odx_det_label_f32")
+        return prop, overlap, sel.view(torch.bool), None if cmask is None else cmask.view(torch.bool), counters
+
+    def box_targets(self, examples, targets):
+        """(n, 4) box-regression targets of n (example, target) pairs in one launch (odx_box_targets_f32)."""
+        examples = examples.to(device=self.device, dtype=torch.float32).contiguous()
+        targets = targets.to(device=self.device, dtype=torch.float32).contiguous()
+        out = torch.empty_like(examples)
+        hip.check(self.lib.odx_box_targets_f32(_p(examples), _p(targets), int(examples.shape[0]), _p(out), self._stream()), "odx_box_targets_f32")
+        return out
+
     BIAS_ACT_DTYPES = (torch.float32, torch.bfloat16, torch.float16)
 
     def bias_act_(self, y, bias, residual=None, relu=True):

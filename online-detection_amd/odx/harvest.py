@@ -89,6 +89,28 @@ def to_device(host, device):
     return st.put(host, device)
 
 
+def _label_backend(t):
+    """The backend whose labelling kernels serve tensors on t's device (HipBackend on the GPU: odx_rpn_label_f32, odx_det_label_f32,
+    odx_box_targets_f32), or None — the tensor statements below are then what runs (the CPU, the tests' oracle backend)."""
+    if not t.is_cuda:
+        return None
+    from . import backend as _backend
+    be = _backend.get_backend()
+    return be if hasattr(be, "det_label") and hasattr(be, "rpn_label") else None
+
+
+def _box_targets(ex, tg):
+    """((gx - sx) / sw, (gy - sy) / sh, log(gw / sw), log(gh / sh)) of (example, target) box rows — one launch on the GPU."""
+    be = _label_backend(ex)
+    if be is not None:
+        return be.box_targets(ex, tg)
+    sw, sh = ex[:, 2] - ex[:, 0] + 1, ex[:, 3] - ex[:, 1] + 1
+    sx, sy = ex[:, 0] + 0.5 * sw, ex[:, 1] + 0.5 * sh
+    gw, gh = tg[:, 2] - tg[:, 0] + 1, tg[:, 3] - tg[:, 1] + 1
+    gx, gy = tg[:, 0] + 0.5 * gw, tg[:, 1] + 0.5 * gh
+    return torch.stack(((gx - sx) / sw, (gy - sy) / sh, torch.log(gw / sw), torch.log(gh / sh)), dim=1)
+
+
 def box_iou_plus1(gt, prop):
     """(G, R) IoU, +1 pixel convention, 0 where boxes do not touch (utils/evaluations.py:4-18)."""
     xmin = torch.max(gt[:, None, 0], prop[None, :, 0])
@@ -275,6 +297,17 @@ class DetectorHarvester:
         if self.negatives_to_pick is None:
             self.negatives_to_pick = math.ceil((self.batch_size * self.iterations) / self.num_images)
         x = x.reshape(x.size(0), -1)
+        be = _label_backend(x)
+        if be is not None and 0 < gt_bbox.shape[0] <= be.LABEL_MAX_GT and all(1 <= l <= self.num_classes for l in gt_labels_list):
+            # the same labels from ONE launch (odx_det_label_f32: clamping, overlaps, per-class maxima, first-maximum association,
+            # the pairs' and the candidates' flags and their counts) instead of ~45 tensor operations; one small upload
+            G, R = int(gt_bbox.shape[0]), int(proposals.shape[0])
+            in_image = sorted({l - 1 for l in gt_labels_list})
+            up = to_device(torch.tensor([l - 1 for l in gt_labels_list] + in_image, dtype=torch.int32), x.device)
+            prop_d, overlap, sel, cmask, counters = be.det_label(gt_bbox, up[:G], proposals, self.num_classes, img_size, self.reg_min_overlap,
+                                                                 self.neg_iou_thresh, up[G:])
+            return {"x": x, "overlap": overlap, "labels": list(gt_labels_list), "R": R, "G": G, "block": counters, "prop_d": prop_d,
+                    "cls": up[:G].to(torch.int64), "sel": sel, "in_image": in_image, "cmask": cmask}
         prop = clamp_boxes_(proposals.clone().float(), img_size)
         gt = clamp_boxes_(gt_bbox.clone().float(), img_size)
         R, G = prop.shape[0], gt.shape[0]
@@ -325,12 +358,7 @@ class DetectorHarvester:
             flat = torch.argsort((~sel).reshape(-1).to(torch.int8), stable=True)[:sum(seg)]
             j_idx, r_idx = flat // R, flat % R
             ex, tgt = prop_d[r_idx], prop_d[j_idx]                          # tgt: the prepended ground-truth rows
-            sw, sh = ex[:, 2] - ex[:, 0] + 1, ex[:, 3] - ex[:, 1] + 1
-            sx, sy = ex[:, 0] + 0.5 * sw, ex[:, 1] + 0.5 * sh
-            gw, gh = tgt[:, 2] - tgt[:, 0] + 1, tgt[:, 3] - tgt[:, 1] + 1
-            gx, gy = tgt[:, 0] + 0.5 * gw, tgt[:, 1] + 0.5 * gh
-            target = torch.stack(((gx - sx) / sw, (gy - sy) / sh, torch.log(gw / sw), torch.log(gh / sh)), dim=1)
-            self._Y.append(target, seg_lens=seg)
+            self._Y.append(_box_targets(ex, tgt), seg_lens=seg)
             self._C.append((cls[j_idx] + 1).to(torch.float32).view(-1, 1), seg_lens=seg)
             self._X.append(x[r_idx].view(-1, self.D), seg_lens=seg)
         else:
@@ -529,6 +557,12 @@ class RPNHarvester:
         A = self.A
         gt = gt_bbox.to(dev).float()
         G = gt.shape[0]
+        be = _label_backend(t)
+        if be is not None and 0 < G <= be.LABEL_MAX_GT:
+            # the labels below from two launches (odx_rpn_label_f32) instead of ~45 tensor operations
+            _, assoc, neg_mask, over, extra, cnt = be.rpn_label(gt, self.anchors, self.cls, A, self.neg_iou_thresh, self.pos_iou_thresh)
+            block = torch.cat((cnt.to(torch.float64), gt.reshape(-1).to(torch.float64)))
+            return {"t": t, "G": G, "block": block, "neg_mask": neg_mask, "over": over, "extra": extra, "assoc": assoc}
         iou_all = box_iou_plus1(gt, self.anchors)                                   # (G, n_vis)
         if G > 1:
             ious, idx = torch.max(iou_all, dim=0)
@@ -641,17 +675,13 @@ class RPNHarvester:
         pcls_sorted = self.cls[sel]
         feat = self._gather(t, sel)
         ex, tg = self.anchors[sel], assoc[sel]
-        sw, sh = ex[:, 2] - ex[:, 0] + 1, ex[:, 3] - ex[:, 1] + 1
-        sx, sy = ex[:, 0] + 0.5 * sw, ex[:, 1] + 0.5 * sh
-        gw, gh = tg[:, 2] - tg[:, 0] + 1, tg[:, 3] - tg[:, 1] + 1
-        gx, gy = tg[:, 0] + 0.5 * gw, tg[:, 1] + 0.5 * gh
         seg = [k for k in per_type if k]
         at = 0
         for i, k in enumerate(per_type):
             if k:
                 self._pos[i].append(feat[at:at + k])
                 at += k
-        self._Y.append(torch.stack(((gx - sx) / sw, (gy - sy) / sh, torch.log(gw / sw), torch.log(gh / sh)), dim=1), seg_lens=seg)
+        self._Y.append(_box_targets(ex, tg), seg_lens=seg)
         self._C.append(pcls_sorted.to(torch.float32).view(-1, 1), seg_lens=seg)
         self._X.append(feat, seg_lens=seg)
 

@@ -125,6 +125,9 @@ SIGNATURES = {
     "odx_gemm_h2_chain_f32": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp,
                                      _vp, _i64, _f32, _f32, _vp, _vp]),
     "odx_taps3x3_packed": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
+    "odx_rpn_label_f32": (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "odx_det_label_f32": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _f32, _f32, _f32, _f32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "odx_box_targets_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "odx_debug_gemm_h2_mf32": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
     "odx_gemm_b16_taps_supported": (_i32, [_i64, _i64, _i32, _i64]),
     "odx_gemm_b16_taps": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp]),

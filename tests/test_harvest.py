@@ -296,3 +296,83 @@ def test_staged_uploads_deliver_the_same_tensors(monkeypatch):
     assert sum(h.numel() * h.element_size() for h, _ in kept) > 4 * harvest._Staging.HALF
     for h, d in kept:
         assert d.is_cuda and d.dtype == h.dtype and d.shape == h.shape and torch.equal(d.cpu(), h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G", [1, 2, 5, 17])
+def test_labelling_kernels_equal_the_tensor_statements(G):
+    """odx_rpn_label_f32 / odx_det_label_f32 / odx_box_targets_f32 against the tensor statements they replace in the harvesters'
+    prepare / commit (the CPU path: box_iou_plus1, maxima, associations, flags, counts), bit for bit — overlaps are compared with
+    thresholds, so the overlaps have to be the same bits; duplicate ground-truth boxes, boxes sharing single coordinates, boxes
+    partly outside the image, thresholds hit exactly."""
+    import odx
+    from odx import harvest
+    be = odx.get_backend()
+    g = torch.Generator().manual_seed(G)
+    W, H, A, C = 800.0, 600.0, 15, 30
+    xy = torch.rand((G, 2), generator=g) * torch.tensor([W * 0.7, H * 0.7])
+    gt = torch.cat((xy, xy + 30 + torch.rand((G, 2), generator=g) * 250), dim=1).round()
+    if G >= 2:
+        gt[1] = gt[0]                                        # a duplicate box
+    if G >= 5:
+        gt[3, 0] = gt[2, 0]                                  # boxes sharing one coordinate
+        gt[4, 2:] += 400                                     # partly outside the image
+    n = 5000
+    axy = torch.rand((n, 2), generator=g) * torch.tensor([W, H]) - 40
+    anchors = torch.cat((axy, axy + 16 + torch.rand((n, 2), generator=g) * 300), dim=1).round()
+    anchors[:G] = gt                                          # overlap exactly 1
+    cls = torch.randint(0, A, (n,), generator=g)
+    gt_d, an_d, cls_d = gt.cuda(), anchors.cuda(), cls.cuda()
+    # ---- RPN
+    iou_all = harvest.box_iou_plus1(gt_d, an_d)
+    ious, idx = torch.max(iou_all, dim=0)
+    assoc = gt_d[idx]
+    thr_n, thr_p = float(ious[n // 2]), float(ious[n // 3])       # thresholds that some overlap equals exactly
+    neg_mask, over = ious < thr_n, ious > thr_p
+    onehot = cls_d[:, None] == torch.arange(A, device="cuda")[None, :]
+    mine = (assoc[None, :, :] == gt_d[:, None, :]).all(dim=2)
+    best = torch.where(mine, ious[None, :], torch.full_like(ious, -1.0)[None, :]).max(dim=1)[0]
+    extra = mine & (ious[None, :] == best[:, None])
+    share = (assoc[None, :, :] == gt_d[:, None, :]).any(dim=2)
+    want = torch.cat(((neg_mask[:, None] & onehot).sum(0), (share & over[None, :]).sum(1), mine.any(dim=1).long(), (over[:, None] & onehot).sum(0),
+                      (extra[:, :, None] & onehot[None, :, :]).sum(1).reshape(-1)))
+    k_ious, k_assoc, k_neg, k_over, k_extra, k_cnt = be.rpn_label(gt_d, an_d, cls_d, A, thr_n, thr_p)
+    assert torch.equal(k_ious, ious) and torch.equal(k_assoc, assoc) and torch.equal(k_neg, neg_mask) and torch.equal(k_over, over)
+    assert torch.equal(k_extra, extra) and torch.equal(k_cnt.long(), want)
+    # ---- detector
+    labels = [1 + int(v) for v in torch.randint(0, C, (G,), generator=g)]
+    R = 700
+    pxy = torch.rand((R, 2), generator=g) * torch.tensor([W, H]) - 30
+    props = torch.cat((pxy, pxy + 10 + torch.rand((R, 2), generator=g) * 300), dim=1)
+    props[:G] = gt
+    prop = harvest.clamp_boxes_(props.clone().cuda(), (W, H))
+    gtc = harvest.clamp_boxes_(gt_d.clone(), (W, H))
+    iou = harvest.box_iou_plus1(gtc, prop)
+    overlap = torch.zeros((R, C), device="cuda")
+    for j in range(G):
+        overlap[:, labels[j] - 1] = torch.max(overlap[:, labels[j] - 1], iou[j])
+    bestv, _ = iou.max(dim=0)
+    first = (iou == bestv[None, :]).float().argmax(dim=0)
+    asc = torch.where(bestv > 0, first, torch.full((R,), -1, dtype=torch.int64, device="cuda"))
+    lab = torch.tensor([l - 1 for l in labels], device="cuda")
+    reg_min, thr = float(overlap[:, labels[0] - 1][R // 2]), 0.3
+    sel = (overlap[:, lab].t() > reg_min) & (asc[None, :] == torch.arange(G, device="cuda")[:, None])
+    in_image = sorted({l - 1 for l in labels})
+    cmask = overlap[:, in_image] < thr
+    up = torch.tensor([l - 1 for l in labels] + in_image, dtype=torch.int32, device="cuda")
+    k_prop, k_ov, k_sel, k_cm, k_cnt = be.det_label(gt_d, up[:G], props.cuda(), C, (W, H), reg_min, thr, up[G:])
+    assert torch.equal(k_prop, prop) and torch.equal(k_ov, overlap) and torch.equal(k_sel, sel) and torch.equal(k_cm, cmask)
+    assert torch.equal(k_cnt.long(), torch.cat((sel.sum(1), cmask.sum(0))))
+    # ---- targets
+    ex, tg = prop[G:G + 300], prop[:G][torch.randint(0, G, (300,), generator=g).cuda()]
+    sw, sh = ex[:, 2] - ex[:, 0] + 1, ex[:, 3] - ex[:, 1] + 1
+    sx, sy = ex[:, 0] + 0.5 * sw, ex[:, 1] + 0.5 * sh
+    gw, gh = tg[:, 2] - tg[:, 0] + 1, tg[:, 3] - tg[:, 1] + 1
+    gx, gy = tg[:, 0] + 0.5 * gw, tg[:, 1] + 0.5 * gh
+    wantt = torch.stack(((gx - sx) / sw, (gy - sy) / sh, torch.log(gw / sw), torch.log(gh / sh)), dim=1)
+    gott = be.box_targets(ex, tg)
+    # (the logarithm is the device library's logf here and torch's own kernel there: a unit in the last place apart)
+    # (a box pushed out of the image clamps to zero width: log of 0 / of a negative ratio — the same non-numbers on both sides)
+    fin = torch.isfinite(wantt[:, 2:])
+    assert torch.equal(gott[:, :2], wantt[:, :2]) and torch.equal(torch.isfinite(gott[:, 2:]), fin)
+    assert float((gott[:, 2:][fin] - wantt[:, 2:][fin]).abs().max()) <= 1e-6
