@@ -372,15 +372,6 @@ def _bottleneck_rows_h2(be, blk, x, R, H, W, x_meta=None, want_max=False, pack_o
     else:
         xp = be.packed(x, meta=x_meta)
         xf, xm = x, xp.meta
-    if os.environ.get("ODX_DBG_NOCHAIN") == "1":        # (debug: every layer's output packed by a pass of its own)
-        idn = xf if blk.down is None else be.gemm_h2(xp, wpack("down", blk.down[0], blk.down[1])[0], bias=wpack("down", blk.down[0], blk.down[1])[1])
-        w1, b1, _ = wpack("conv1", blk.conv1, blk.bn1)
-        y, my = be.gemm_h2(xp, w1, bias=b1, relu=True, with_max=True)
-        w2, b2, _ = wpack("conv2", blk.conv2, blk.bn2, taps=True)
-        y, my = be.conv3x3_rows(y, R, H, W, w2, bias=b2, relu=True, meta=my, with_max=True)
-        w3, b3, _ = wpack("conv3", blk.conv3, blk.bn3)
-        o, mo = be.gemm_h2(be.packed(y, meta=my), w3, bias=b3, residual=idn, relu=True, with_max=True)
-        return PackedRows(o, o.shape[0], o.shape[1], be.packed(o, meta=mo).P, mo) if pack_out else ((o, mo) if want_max else o)
     if blk.down is None:
         idn, im = xf, xm
     else:

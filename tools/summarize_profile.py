@@ -174,7 +174,7 @@ for tag, title, want in (("forward", "feature forward: R-50-C4 and R-50-FPN, 10 
             pmc_lines(d, "xpmc_%s_" % tag, want)
 
 for tag, title in (("forward_b4", "R-50-C4 forward, FOUR 600 x 800 images per call (extract.forward_batch), f32, 15 calls (tools/prof_forward_batch.py 4 f32)"),
-                   ("forward_b4_bf16", "the same in bf16 (compute_dtype = bfloat16: trunk by the library in bf16, head on odx_gemm_b16)"),
+                   ("forward_b4_bf16", "the same in bf16 (compute_dtype = bfloat16: trunk stages, RPN head and conv5 head on 16-bit rows, odx_gemm_b16 / odx_gemm_b16_taps)"),
                    ("forward_b8", "R-50-C4 forward, EIGHT images per call, f32: trunk stages, RPN head and conv5 head as one chain of row GEMMs "
                                   "(tools/prof_forward_batch.py 8 f32)"),
                    ("forward_fpn_b8", "R-50-FPN forward, EIGHT images per call, f32: trunk stages and pyramid as row GEMMs, the proposal stage per "
