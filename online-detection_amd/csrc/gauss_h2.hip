@@ -1288,13 +1288,20 @@ __device__ __forceinline__ void gemm_h2_store(const f32x4 (&acc)[TM][4], float i
     uint32_t* pp = pk.P != nullptr ? pk.P + rb * pk.ldp + (col >> 5) * 32 + ((col & 31) >> 1) : nullptr;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
+      // the four identity rows of this block are requested before the first of them is used: one load at a time in front of
+      // its three stores left the epilogue of the K = 512 products of the conv5 head waiting on HBM latency row by row
+      f32x4 rq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        rq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (vec && pr != nullptr && rb + tm * 16 + q < m) rq[q] = *reinterpret_cast<const f32x4*>(pr + (int64_t)q * ldr);
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (rb + tm * 16 + q < m) {
           f32x4 v;
           if (vec) {
-            f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
-            if (pr != nullptr) r4 = *reinterpret_cast<const f32x4*>(pr);
+            const f32x4 r4 = rq[q];
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn) {
               v[tn] = fmaf(acc[tm][tn][q], inv, b[tn]) + r4[tn];
