@@ -1435,6 +1435,19 @@ __device__ __forceinline__ void gemm_b16_store(const f32x4 (&acc)[TM][4], int64_
   for (int tn = 0; tn < 4; ++tn) b[tn] = (bias != nullptr && col + tn < n) ? bias[col + tn] : 0.f;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
+    // (the four identity rows of a block are requested before the first is used, as in gemm_h2_store)
+    u16x4 rq16[4];
+    f32x4 rq32[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t row = rb + tm * 16 + q;
+      rq16[q] = u16x4{0, 0, 0, 0};
+      rq32[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (vec && res != nullptr && row < m) {
+        if (OUT16) rq16[q] = *reinterpret_cast<const u16x4*>(static_cast<const unsigned short*>(res) + row * ldr + col);
+        else rq32[q] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(res) + row * ldr + col);
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int64_t row = rb + tm * 16 + q;
@@ -1442,8 +1455,7 @@ __device__ __forceinline__ void gemm_b16_store(const f32x4 (&acc)[TM][4], int64_
       if (vec) {
         float v[4];
         if (OUT16) {
-          u16x4 r4 = {0, 0, 0, 0};
-          if (res != nullptr) r4 = *reinterpret_cast<const u16x4*>(static_cast<const unsigned short*>(res) + row * ldr + col);
+          const u16x4 r4 = rq16[q];
           u16x4 o;
 #pragma unroll
           for (int tn = 0; tn < 4; ++tn) {
@@ -1454,8 +1466,7 @@ __device__ __forceinline__ void gemm_b16_store(const f32x4 (&acc)[TM][4], int64_
           }
           *reinterpret_cast<u16x4*>(static_cast<unsigned short*>(out) + row * ldo + col) = o;
         } else {
-          f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
-          if (res != nullptr) r4 = *reinterpret_cast<const f32x4*>(static_cast<const float*>(res) + row * ldr + col);
+          const f32x4 r4 = rq32[q];
           f32x4 o;
 #pragma unroll
           for (int tn = 0; tn < 4; ++tn) {
