@@ -278,21 +278,73 @@ __device__ __forceinline__ void s16_compute_ktile(f32x4 (&acc)[4][4], const char
   }
 }
 
-template <int CORE = S16_H2, bool PERMB = false>
+// The k-tile -> (tap, channel offset) cursor of a TAPS operand on this core: a k-tile is 64 channels of one tap (C % 64 == 0).
+struct S16Tap {
+  int kin, dy, dx;           // 4-byte units into the tap's channels; tap offset (ky - 1, kx - 1)
+};
+__device__ __forceinline__ S16Tap s16_tap_next(S16Tap c, int C) {
+  c.kin += H2_KT;
+  if (c.kin == C) {
+    c.kin = 0;
+    if (++c.dx == 2) {
+      c.dx = -1;
+      ++c.dy;
+    }
+  }
+  return c;
+}
+
+// the eight row offsets (4-byte units from A) of this lane for one tap: the neighbour (h + dy, w + dx) of each of its rows, or
+// the all-zero row behind the operand for a neighbour outside the map (hw: h << 16 | w, negative for a row past the end)
+__device__ __forceinline__ void s16_tap_offsets(uint32_t (&off)[8], const uint32_t (&rowoff)[8], const int (&hw)[8], uint32_t zoff, int lda,
+                                                int H, int W, const S16Tap& c) {
+  const int shift = (c.dy * W + c.dx) * lda;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int h = hw[p] >> 16, w = hw[p] & 0xffff;
+    const bool in = hw[p] >= 0 && (unsigned)(h + c.dy) < (unsigned)H && (unsigned)(w + c.dx) < (unsigned)W;
+    off[p] = (in ? rowoff[p] + (uint32_t)shift : zoff) + (uint32_t)c.kin;
+  }
+}
+
+// TAPS: A is the 3 x 3 neighbourhood matrix of the packed NHWC rows at A (m rows of tapC channels + one all-zero row), gathered in
+// the operand loads as on the wide core (w_mainloop_dma): the eight row offsets of a lane are recomputed per k-tile.
+template <int CORE = S16_H2, bool PERMB = false, bool TAPS = false>
 __device__ __forceinline__ void s16_mainloop(f32x4 (&acc)[4][4], const uint32_t* __restrict__ A, int64_t lda, int64_t m,
                                              const uint32_t* __restrict__ B, int64_t ldb, int64_t n, int64_t i0, int64_t j0,
-                                             int ktiles, char* lds) {
+                                             int ktiles, char* lds, int tapH = 0, int tapW = 0, int tapC = 0) {
   char* ldsA = lds;
   char* ldsB = lds + GEMM_BM * S16_ROW;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   uint32_t offa[8], offb[8];
-  h2_row_offsets<false>(offa, lda, i0, m);
   h2_row_offsets<PERMB>(offb, ldb, j0, n);
   const uint32_t* ta = A + i0 * lda;
   const uint32_t* tb = B + j0 * ldb;
+  int hw[8];
+  uint32_t zoff = 0;
+  S16Tap tc{0, -1, -1};
+  if (TAPS) {
+    const int tid = threadIdx.x;
+    ta = A;                                               // offsets are absolute: a neighbour's row may lie in front of the tile
+    zoff = (uint32_t)(m * lda) + (uint32_t)(tid & 15) * 4u;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int64_t r = i0 + (tid >> 4) + 16 * p;
+      hw[p] = r < m ? (int)((((r / tapW) % tapH) << 16) | (r % tapW)) : -1;
+      offa[p] = (uint32_t)(r * lda) + (uint32_t)(tid & 15) * 4u;
+    }
+  } else {
+    h2_row_offsets<false>(offa, lda, i0, m);
+  }
   H2Stage st;
-  h2_load_operand(st.a, ta, offa);
+  if (TAPS) {
+    uint32_t off[8];
+    s16_tap_offsets(off, offa, hw, zoff, (int)lda, tapH, tapW, tc);
+    h2_load_operand(st.a, ta, off);
+  } else {
+    h2_load_operand(st.a, ta, offa);
+  }
   h2_load_operand(st.b, tb, offb);
   for (int kt = 0; kt < ktiles; ++kt) {
     __syncthreads();
@@ -302,7 +354,14 @@ __device__ __forceinline__ void s16_mainloop(f32x4 (&acc)[4][4], const uint32_t*
     // (unconditional: behind the last k-tile the loads re-read it and nobody waits for them — a branch around the loads
     // makes the 64 staging registers loop-carried selects)
     const int64_t nk = (int64_t)(kt + 1 < ktiles ? kt + 1 : kt) * H2_KT;
-    h2_load_operand(st.a, ta + nk, offa);
+    if (TAPS) {
+      if (kt + 1 < ktiles) tc = s16_tap_next(tc, tapC);
+      uint32_t off[8];
+      s16_tap_offsets(off, offa, hw, zoff, (int)lda, tapH, tapW, tc);
+      h2_load_operand(st.a, ta, off);
+    } else {
+      h2_load_operand(st.a, ta + nk, offa);
+    }
     h2_load_operand(st.b, tb + nk, offb);
     s16_compute_ktile<CORE>(acc, ldsA, ldsB, wr, wc, lane);
   }
@@ -1340,11 +1399,12 @@ __device__ __forceinline__ void gemm_h2_store(const f32x4 (&acc)[TM][4], float i
   if (amax != nullptr) gemm_h2_publish_max(mx, amax);
 }
 
+template <bool TAPS = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_h2s16_kernel(
     const uint32_t* __restrict__ PA, int64_t ldpa, const float* __restrict__ metaa, int64_t m, const uint32_t* __restrict__ PB,
     int64_t ldpb, const float* __restrict__ metab, int64_t n, int ktiles, const float* __restrict__ bias,
     const float* __restrict__ res, int64_t ldr, int relu, float* __restrict__ out, int64_t ldo, int gr,
-    unsigned int* __restrict__ amax, H2PackOut pk) {
+    unsigned int* __restrict__ amax, H2PackOut pk, int tapH, int tapW, int tapC) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int64_t GR = gr;
   const int64_t tiles_n = (n + GEMM_BN - 1) / GEMM_BN;
@@ -1354,7 +1414,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_h2s16_kernel(
   if (i0 >= m) return;
   f32x4 acc[4][4];
   s16_zero(acc);
-  s16_mainloop<S16_H2, true>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, ktiles, lds);
+  s16_mainloop<S16_H2, true, TAPS>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, ktiles, lds, tapH, tapW, tapC);
   const float inv = 1.f / (metaa[0] * metab[0]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -1484,10 +1544,11 @@ __device__ __forceinline__ void gemm_b16_store(const f32x4 (&acc)[TM][4], int64_
   }
 }
 
-template <int CORE, bool OUT16>
+template <int CORE, bool OUT16, bool TAPS = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_b16s16_kernel(
     const uint32_t* __restrict__ PA, int64_t ldpa, int64_t m, const uint32_t* __restrict__ PB, int64_t ldpb, int64_t n, int ktiles,
-    const float* __restrict__ bias, const void* __restrict__ res, int64_t ldr, int relu, void* __restrict__ out, int64_t ldo, int gr) {
+    const float* __restrict__ bias, const void* __restrict__ res, int64_t ldr, int relu, void* __restrict__ out, int64_t ldo, int gr,
+    int tapH, int tapW, int tapC) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int64_t GR = gr;
   const int64_t tiles_n = (n + GEMM_BN - 1) / GEMM_BN;
@@ -1497,7 +1558,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_b16s16_kernel(
   if (i0 >= m) return;
   f32x4 acc[4][4];
   s16_zero(acc);
-  s16_mainloop<CORE, true>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, ktiles, lds);      // (a lane holds four ADJACENT columns per row)
+  // (a lane holds four ADJACENT columns per row; TAPS: a k-tile is 128 channels of one tap, tapC / 2 four-byte units per tap)
+  s16_mainloop<CORE, true, TAPS>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, ktiles, lds, tapH, tapW, tapC / 2);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   gemm_b16_store<4, CORE, OUT16>(acc, m, n, i0 + wr * 64 + 4 * (lane >> 4), j0 + wc * 64 + 4 * (lane & 15), bias, res, ldr, relu, out, ldo);
@@ -2128,10 +2190,10 @@ static int gemm_h2_launch(const void* PA, int64_t ldpa, const float* metaa, int6
   }
   const int64_t tiles = round_up(ceil_div(m, GEMM_BM), gr) * ceil_div(n, GEMM_BN);
   ODX_REQUIRE(tiles < (1ll << 31), "odx_gemm_h2_f32: grid too large");
-  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2s16_kernel)));
-  hipLaunchKernelGGL(gemm_h2s16_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), S16_LDS_BYTES, as_stream(stream),
+  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2s16_kernel<false>)));
+  hipLaunchKernelGGL(gemm_h2s16_kernel<false>, dim3((unsigned)tiles), dim3(GEMM_THREADS), S16_LDS_BYTES, as_stream(stream),
                      (const uint32_t*)PA, ldpa, metaa, m, (const uint32_t*)PB, ldpb, metab, n, (int)(dp / H2_KT), bias, residual,
-                     ldr, relu, out, ldo, gr, amax, pk);
+                     ldr, relu, out, ldo, gr, amax, pk, 0, 0, 0);
   ODX_CHECK_LAUNCH("odx_gemm_h2_f32");
   return ODX_OK;
 }
@@ -2191,9 +2253,13 @@ extern "C" int odx_taps3x3_packed(const void* PY, int64_t ldpy, int64_t R, int H
 
 // 1 when odx_gemm_h2_taps_f32 serves this layer: the 256 x 256 LDS-DMA core (it fills the chip: >= 256 tiles, more than 128
 // output columns), whole 32-channel stages per tap, 32-bit byte offsets over the packed rows.
+static bool h2_taps_wide(int64_t m, int64_t n, int C) {        // the layer goes to the 256 x 256 LDS-DMA core (gemm_h2_launch's rule)
+  return n > GEMM_BN && C % W_KS == 0 && w_staging() == STG_DMA && ceil_div(m, W_BM) * ceil_div(n, W_BN) >= 256;
+}
+
 extern "C" int odx_gemm_h2_taps_supported(int64_t m, int64_t n, int C, int64_t ldpy) {
-  if (m <= 0 || n <= GEMM_BN || C <= 0 || C % W_KS != 0) return 0;
-  if (w_staging() != STG_DMA || ceil_div(m, W_BM) * ceil_div(n, W_BN) < 256) return 0;
+  if (m <= 0 || n <= 0 || C <= 0) return 0;
+  if (!h2_taps_wide(m, n, C) && C % H2_KT != 0) return 0;       // (the 128 x 128 core: a k-tile is 64 channels of one tap)
   return (m + 1) * ldpy * 4 < (1ll << 31) ? 1 : 0;
 }
 
@@ -2220,9 +2286,19 @@ extern "C" int odx_gemm_h2_taps_f32(const void* PY, int64_t ldpy, const float* m
   ODX_REQUIRE((out == nullptr || ldo >= n) && (residual == nullptr || ldr >= n), "odx_gemm_h2_taps_f32: ldo / ldr < n");
   ODX_REQUIRE(ldpb < (1 << 24), "odx_gemm_h2_taps_f32: leading dimensions must stay below 2^24 (32-bit tile offsets)");
   const int gr = 8;
+  unsigned int* amax = out_meta ? reinterpret_cast<unsigned int*>(out_meta + 1) : nullptr;
+  if (!h2_taps_wide(m, n, C)) {          // narrow or small layers: the 128 x 128 core, the taps gathered in its register-staged loads
+    const int64_t tiles = round_up(ceil_div(m, GEMM_BM), gr) * ceil_div(n, GEMM_BN);
+    ODX_REQUIRE(tiles < (1ll << 31), "odx_gemm_h2_taps_f32: grid too large");
+    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2s16_kernel<true>)));
+    hipLaunchKernelGGL(gemm_h2s16_kernel<true>, dim3((unsigned)tiles), dim3(GEMM_THREADS), S16_LDS_BYTES, as_stream(stream), (const uint32_t*)PY,
+                       ldpy, metay, m, (const uint32_t*)PB, ldpb, metab, n, (int)(K / H2_KT), bias, residual, ldr, relu, out, ldo, gr, amax,
+                       pk, H, W, C);
+    ODX_CHECK_LAUNCH("odx_gemm_h2_taps_f32(s16)");
+    return ODX_OK;
+  }
   const int64_t wt = round_up(ceil_div(m, W_BM), gr) * ceil_div(n, W_BN);
   ODX_REQUIRE(wt < (1ll << 31), "odx_gemm_h2_taps_f32: grid too large");
-  unsigned int* amax = out_meta ? reinterpret_cast<unsigned int*>(out_meta + 1) : nullptr;
   ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2w256_kernel<STG_DMA, true>), W_LDS_BYTES));
   hipLaunchKernelGGL((gemm_h2w256_kernel<STG_DMA, true>), dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
                      (const uint32_t*)PY, ldpy, metay, m, (const uint32_t*)PB, ldpb, metab, n, (int)(K / W_KS), bias, residual, ldr,
@@ -2287,7 +2363,7 @@ static int launch_gemm_b16(const void* A, int64_t lda, int64_t m, const void* B,
   ODX_REQUIRE(tiles < (1ll << 31), "odx_gemm_b16: grid too large");
   ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_b16s16_kernel<CORE, OUT16>)));
   hipLaunchKernelGGL((gemm_b16s16_kernel<CORE, OUT16>), dim3((unsigned)tiles), dim3(GEMM_THREADS), S16_LDS_BYTES, s, (const uint32_t*)A, lda / 2,
-                     m, (const uint32_t*)B, ldb / 2, n, (int)(round_up(K, 128) / 128), bias, residual, ldr, relu, out, ldo, gr);
+                     m, (const uint32_t*)B, ldb / 2, n, (int)(round_up(K, 128) / 128), bias, residual, ldr, relu, out, ldo, gr, 0, 0, 0);
   ODX_CHECK_LAUNCH("odx_gemm_b16");
   return ODX_OK;
 }
@@ -2314,9 +2390,13 @@ extern "C" int odx_gemm_b16(const void* A, int64_t lda, int64_t m, const void* B
 // odx_gemm_h2_taps_supported / odx_gemm_h2_taps_f32 for 16-bit rows: out = act(taps3x3(Y) B' + bias + residual) with the taps of the
 // 16-bit NHWC rows Y (R H W rows of C channels, C % 64 == 0, row stride ldy elements, FOLLOWED BY ONE ALL-ZERO ROW) gathered
 // inside the product's operand loads — odx_taps3x3_16's matrix is never written.  B (n x 9 C) as for odx_gemm_b16.
+static bool b16_taps_wide(int64_t m, int64_t n, int C) {       // launch_gemm_b16's rule for the 256 x 256 core
+  return C % 64 == 0 && (g_h2_tile == 256 || (g_h2_tile != 128 && ceil_div(m, W_BM) * ceil_div(n, W_BN) >= 256 && n > GEMM_BN));
+}
+
 extern "C" int odx_gemm_b16_taps_supported(int64_t m, int64_t n, int C, int64_t ldy) {
-  if (m <= 0 || n <= GEMM_BN || C <= 0 || C % 64 != 0) return 0;
-  if (g_h2_tile == 128 || ceil_div(m, W_BM) * ceil_div(n, W_BN) < 256) return 0;
+  if (m <= 0 || n <= 0 || C <= 0) return 0;
+  if (!b16_taps_wide(m, n, C) && C % 128 != 0) return 0;        // (the 128 x 128 core: a k-tile is 128 channels of one tap)
   return (m + 1) * ldy * 2 < (1ll << 31) ? 1 : 0;
 }
 
@@ -2324,6 +2404,15 @@ template <int CORE, bool OUT16>
 static int launch_gemm_b16_taps(const void* Y, int64_t ldy, int64_t m, int H, int W, int C, const void* B, int64_t ldb, int64_t n,
                                 const float* bias, const void* residual, int64_t ldr, int relu, void* out, int64_t ldo, hipStream_t s) {
   const int gr = 8;
+  if (!b16_taps_wide(m, n, C)) {
+    const int64_t tiles = round_up(ceil_div(m, GEMM_BM), gr) * ceil_div(n, GEMM_BN);
+    ODX_REQUIRE(tiles < (1ll << 31), "odx_gemm_b16_taps: grid too large");
+    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_b16s16_kernel<CORE, OUT16, true>)));
+    hipLaunchKernelGGL((gemm_b16s16_kernel<CORE, OUT16, true>), dim3((unsigned)tiles), dim3(GEMM_THREADS), S16_LDS_BYTES, s, (const uint32_t*)Y,
+                       ldy / 2, m, (const uint32_t*)B, ldb / 2, n, (int)(9 * (int64_t)C / 128), bias, residual, ldr, relu, out, ldo, gr, H, W, C);
+    ODX_CHECK_LAUNCH("odx_gemm_b16_taps(s16)");
+    return ODX_OK;
+  }
   const int64_t wt = round_up(ceil_div(m, W_BM), gr) * ceil_div(n, W_BN);
   ODX_REQUIRE(wt < (1ll << 31), "odx_gemm_b16_taps: grid too large");
   ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_b16w256_kernel<CORE, OUT16, true>), W_LDS_BYTES));

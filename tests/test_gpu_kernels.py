@@ -1278,8 +1278,9 @@ def test_3x3_convolution_with_the_taps_gathered_in_the_operand_loads(R, H, W, C,
     """odx_gemm_h2_taps_f32 (the 3 x 3 neighbourhood gathered by the product's own LDS-DMA loads from the packed rows, a zero
     row outside the map) = odx_split_f16_taps3x3 + odx_gemm_h2_max_f32 bit for bit, output maximum included, and both = the
     convolution in f64 to f32 rounding; maps whose rows straddle tile boundaries (7 x 7 RoI crops, a 150 x 200 trunk map), a
-    ragged last tile; the last three shapes are ones the library does not serve that way (narrow output, too few tiles,
-    C % 32 != 0): HipBackend.conv3x3_rows takes the written-out matrix for them."""
+    ragged last tile; both tile cores (a narrow output and a launch of few tiles go to the 128 x 128 core, which gathers the taps
+    in its register-staged loads); the last shape is one the library does not serve that way (C % 32 != 0):
+    HipBackend.conv3x3_rows takes the written-out matrix for it."""
     import odx
     be = odx.get_backend()
     g = torch.Generator().manual_seed(R + C + n)
@@ -1290,7 +1291,7 @@ def test_3x3_convolution_with_the_taps_gathered_in_the_operand_loads(R, H, W, C,
     wp = be.packed(Wt)
     want, wmeta = be.gemm_h2(be.packed_taps3x3(Y, R, H, W), wp, bias=bias, relu=True, with_max=True)
     served = bool(be.lib.odx_gemm_h2_taps_supported(m, n, C, (C + 63) // 64 * 64))
-    assert served == ((R, n, C) in ((1400, 256, 64), (2400, 512, 512), (9, 160, 32)))
+    assert served == (C % 64 == 0 or (R, n, C) == (9, 160, 32))       # (the 128 x 128 core serves whole 64-channel k-tiles per tap)
     got, gmeta = be.conv3x3_rows(Y, R, H, W, wp, bias=bias, relu=True, with_max=True)
     assert torch.equal(got, want) and torch.equal(gmeta[1], wmeta[1])
     if m * C * n < 3e10:
@@ -1368,8 +1369,8 @@ def test_chain_3x3_convolution_from_packed_rows(R, H, W, C, n):
 
 
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
-@pytest.mark.parametrize("R,H,W,C,n", [(1400, 7, 7, 64, 256), (9, 150, 200, 64, 160), (1400, 7, 7, 64, 128), (37, 7, 7, 64, 256),
-                                       (1400, 7, 7, 32, 256)])
+@pytest.mark.parametrize("R,H,W,C,n", [(1400, 7, 7, 64, 256), (9, 150, 200, 64, 160), (1400, 7, 7, 128, 128), (37, 7, 7, 256, 256),
+                                       (1400, 7, 7, 64, 128), (1400, 7, 7, 32, 256)])
 def test_16bit_3x3_convolution_with_the_taps_gathered_in_the_operand_loads(dtype, R, H, W, C, n):
     """HipBackend.conv3x3_rows16: odx_gemm_b16_taps (first two shapes: the taps of the 16-bit rows gathered by the product's own
     LDS-DMA loads, a zero row outside the map) = odx_taps3x3_16 + odx_gemm_b16 bit for bit (the same products in the same
@@ -1386,7 +1387,8 @@ def test_16bit_3x3_convolution_with_the_taps_gathered_in_the_operand_loads(dtype
     y0, y1, wp = be.rows16(Y, dt), be.rows16(Y, dt, zero_row=True), be.rows16(Wt, dt)
     want = be.gemm_b16(be.taps3x3_16(y0, R, H, W), wp, bias=bias, relu=True)
     served = bool(be.lib.odx_gemm_b16_taps_supported(m, n, C, y1.buf.stride(0)))
-    assert served == ((R, n, C) in ((1400, 256, 64), (9, 160, 64)))
+    # (the wide core takes whole 64-channel stages per tap, the 128 x 128 core — narrow outputs, few tiles — 128-channel k-tiles)
+    assert served == ((R, n, C) in ((1400, 256, 64), (9, 160, 64), (1400, 128, 128), (37, 256, 256)))
     got = be.conv3x3_rows16(y1, R, H, W, wp, bias=bias, relu=True, zero_row=True)
     assert got.zero_row and torch.equal(got.dense, want.dense)
     assert int(torch.as_strided(got.buf, (m + 1, got.buf.shape[1]), got.buf.stride())[m].abs().max()) == 0
