@@ -732,7 +732,7 @@ class OnlineDetectionModel(nn.Module):
         self.online_mask = None         # odx.heads.OnlineMaskPredictor
         self.mask_dim = mask_dim
         # stride-16 positions (images x h x w) from which the f32 trunk and RPN head run as row GEMMs (_rows_path)
-        self.rows_min_positions = int(os.environ.get("ODX_ROWS_MIN_POSITIONS", 4800))
+        self.rows_min_positions = int(os.environ.get("ODX_ROWS_MIN_POSITIONS", 3600))
         self._trunk_graphs = GraphedCall(self._c4_eager)
         # The whole group forward from ONE HIP graph (forward_group); ODX_GROUP_GRAPH=0 turns it off.  What it took on this
         # runtime (round 5): (i) with the proposal stage as tensor operations (a library top-k, gather, advanced indexing) the
@@ -780,9 +780,9 @@ class OnlineDetectionModel(nn.Module):
         if not (x.is_cuda and self.compute_dtype is None and x.dtype == torch.float32 and not torch.is_grad_enabled()
                 and not torch.is_autocast_enabled("cuda") and os.environ.get("ODX_TRUNK", "rows") != "conv"):
             return False
-        # below three images of 600 x 800 the stage-3 / RPN products (1900 rows per image) leave most of the chip idle on
-        # 128 x 128 tiles and the convolution library's kernels are faster (trunk 1.37 against 2.31 ms at one image, 0.87
-        # against 0.86 ms per image at eight; the RPN head 0.33 against 0.52 ms per image at four)
+        # below two images of 600 x 800 the stage-3 / RPN products (1900 rows per image) leave most of the chip idle on
+        # 128 x 128 tiles and the convolution library's kernels are faster (forward 3.85 against 4.34 ms at one image; 3.30
+        # against 3.20 ms per image at two, 2.97 against 2.06 at eight)
         positions = x.shape[0] * x.shape[2] * x.shape[3] if x.shape[1] != 3 else x.shape[0] * (-(-x.shape[2] // self.stride)) * (-(-x.shape[3] // self.stride))
         if positions < self.rows_min_positions:
             return False
@@ -1142,7 +1142,7 @@ def detect(model, image, orig_size=None, score_thresh=-2.0, nms_thresh=0.3, dete
 
 def detect_batch(model, images, orig_sizes=None, score_thresh=-2.0, nms_thresh=0.3, detections_per_img=100, with_masks=False):
     """detect() for B pre-processed images of ONE size, images (B, 3, H, W): [(result, proposals)] per image.  One forward for the
-    group (forward_batch: trunk, proposal stage and RoI head once — from three 600 x 800 images on the f32 trunk and heads are
+    group (forward_batch: trunk, proposal stage and RoI head once — from two 600 x 800 images on the f32 trunk and heads are
     one chain of row GEMMs), ONE pass of the on-line box predictor over all images' RoI features (the FALKON scoring and the RLS
     regressors act row by row), then the reference's post-processing per image in its own original frame
     (OnlineDetectionPostProcessor.py:12-79).  The reference's test loop walks one image per iteration

@@ -228,7 +228,7 @@ class OnlineDetectionModelFPN(nn.Module):
         self._packed = {}
         self._anchor_cache = {}
         import os
-        self.rows_min_positions = int(os.environ.get("ODX_ROWS_MIN_POSITIONS", 4800))
+        self.rows_min_positions = int(os.environ.get("ODX_ROWS_MIN_POSITIONS", 3600))
         from .extract import GraphedCall
         self._trunk_graphs = GraphedCall(self._c4_eager)
         # load_state_dict copies the parameters in place and never goes through _apply: the packed fc weights are derived
