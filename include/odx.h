@@ -35,6 +35,12 @@ const char* odx_last_error_string(void);
 int odx_version(void);
 /* number of compute units of the current device (grid sizing for persistent kernels) */
 int odx_device_cus(void);
+/* Destroys the calling thread's internal helper streams of the factorisation chains (odx_falkon_precond_*, odx_potrf_f64 from 4096
+ * rows on: look-ahead updates, the inverse beside T T'); they are made again on demand.  Does not wait: the runtime keeps a
+ * destroyed stream until the work queued on it has completed.  Call it when a fit / a training step is queued: on this runtime
+ * the helpers of a class-batched chain, idle but alive, slow every later small launch of the process (a one-image forward behind
+ * the headline job: 4.7 -> 7.6 ms).  ODX_CHAIN_RELEASE_HELPERS=1 makes every chain do it by itself. */
+int odx_release_helper_streams(void);
 /* CU-partitioned execution (diagnostic: tools/cu_split_probe.py measured it and the job does NOT use it).
  * odx_stream_create_cu_mask: a HIP stream whose kernels run only on the compute units whose
  * bit is set in `mask` (`words` 32-bit words, bit i = logical CU i; hipExtStreamCreateWithCUMask) — the HBM-bound CG passes

@@ -585,13 +585,45 @@ static bool chain_helpers(int64_t M) {
   return M >= CHAIN_HELPER_MIN_M;
 }
 
+// ODX_CHAIN_RELEASE_HELPERS=1: every chain releases its helper streams when its last launch is queued (two stream creations per
+// chain: +7 % on a 0.2 s training step of six classes, nothing at the headline's size).  Default: they stay until the caller
+// releases them (odx_release_helper_streams: the Python host side does at the end of a fit / a training step).
+static bool chain_release_helpers() {
+  const char* e = getenv("ODX_CHAIN_RELEASE_HELPERS");
+  return e && e[0] == '1';
+}
+
+struct SideEntry {
+  int device;
+  hipStream_t caller;
+  SideStream ss[2];
+};
+static thread_local std::vector<SideEntry*> g_side_pool;
+
+// Destroys the calling thread's helper streams (they come back on demand).  A process that goes on to latency-bound work after
+// its factorisations should call this: on this runtime the helper streams of a class-batched chain, idle but alive, cost every
+// later small launch of the process (the bench line's one-image forwards ran 4.7 -> 7.6 ms behind the headline job until its
+// extras released them; idle streams that never carried a chain do not have that effect — tools/stream_footprint_probe.py).
+static int release_side_streams(bool wait = true) {
+  for (SideEntry* e : g_side_pool) {
+    for (SideStream& s : e->ss) {
+      if (s.stream != nullptr) {
+        // (without the wait: the runtime keeps a destroyed stream and its events until the work queued on them has completed)
+        if (wait) ODX_CHECK_HIP(hipStreamSynchronize(s.stream));
+        ODX_CHECK_HIP(hipStreamDestroy(s.stream));
+      }
+      if (s.fork != nullptr) ODX_CHECK_HIP(hipEventDestroy(s.fork));
+      if (s.join != nullptr) ODX_CHECK_HIP(hipEventDestroy(s.join));
+    }
+    delete e;
+  }
+  g_side_pool.clear();
+  return ODX_OK;
+}
+
 static int side_stream(SideStream** out, int slot, hipStream_t caller, int64_t M) {
-  struct Entry {
-    int device;
-    hipStream_t caller;
-    SideStream ss[2];
-  };
-  static thread_local std::vector<Entry*> pool;
+  typedef SideEntry Entry;
+  std::vector<Entry*>& pool = g_side_pool;
   int dev = 0;
   ODX_CHECK_HIP(hipGetDevice(&dev));
   ODX_REQUIRE(slot >= 0 && slot < 2, "side_stream: bad slot");
@@ -931,7 +963,12 @@ extern "C" int odx_potrf_f64(double* A, int64_t lda, int64_t M, int32_t* info, v
     return ODX_ERR_WORKSPACE;
   }
   ODX_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), as_stream(stream)));
-  return potrf_f64(A, lda, M, static_cast<double*>(workspace), info, as_stream(stream));
+  const int rc = potrf_f64(A, lda, M, static_cast<double*>(workspace), info, as_stream(stream));
+  if (chain_helpers(M) && chain_release_helpers()) {
+    const int rr = release_side_streams(false);
+    return rc != ODX_OK ? rc : rr;
+  }
+  return rc;
 }
 
 // workspace: Dinv | WT (M*M)
@@ -979,9 +1016,27 @@ extern "C" int64_t odx_falkon_precond_workspace_bytes(int64_t M, int D) {
   return dbl * (int64_t)sizeof(double);
 }
 
+static int falkon_precond_f64_impl(const float* Z, int64_t ldz, int64_t M, int D, double sigma, double lam,
+                                   double eps, double* LTi, double* LTit, double* LAi, double* LAit, int64_t ld,
+                                   int32_t* info, void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+
+// (ODX_CHAIN_RELEASE_HELPERS=1: the helper streams of a chain are released when its last launch is queued — the joins are already
+// in the caller's stream, the runtime keeps the streams until their work is done.  Left alive, the idle helpers of a
+// class-batched chain slow every later small launch of the process: odx_release_helper_streams.)
 extern "C" int odx_falkon_precond_f64(const float* Z, int64_t ldz, int64_t M, int D, double sigma, double lam,
                                       double eps, double* LTi, double* LTit, double* LAi, double* LAit, int64_t ld,
                                       int32_t* info, void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
+  const int rc = falkon_precond_f64_impl(Z, ldz, M, D, sigma, lam, eps, LTi, LTit, LAi, LAit, ld, info, workspace, workspace_bytes, stream);
+  if (chain_helpers(M) && chain_release_helpers()) {
+    const int rr = release_side_streams(false);
+    return rc != ODX_OK ? rc : rr;
+  }
+  return rc;
+}
+
+static int falkon_precond_f64_impl(const float* Z, int64_t ldz, int64_t M, int D, double sigma, double lam,
+                                   double eps, double* LTi, double* LTit, double* LAi, double* LAit, int64_t ld,
+                                   int32_t* info, void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
   ODX_REQUIRE(M > 0 && D > 0 && sigma > 0, "odx_falkon_precond_f64: bad sizes");
   ODX_REQUIRE(Z && LTi && LTit && LAi && LAit && info && workspace, "odx_falkon_precond_f64: null pointer");
   ODX_REQUIRE(ld % 2 == 0 && ld >= M && aligned16(LTi) && aligned16(LTit) && aligned16(LAi) && aligned16(LAit),
@@ -1077,10 +1132,27 @@ extern "C" int64_t odx_falkon_precond_batched_workspace_bytes(int64_t Mmax, int 
   return per * B * (int64_t)sizeof(double);
 }
 
+static int falkon_precond_batched_f64_impl(const float* const* Z, const int64_t* ldz, const int64_t* M, int B,
+                                           int64_t Mmax, int D, double sigma, double lam, double eps, double* out,
+                                           int64_t ld, int64_t out_stride, int32_t* info, void* workspace,
+                                           int64_t workspace_bytes, odx_stream_t stream);
+
 extern "C" int odx_falkon_precond_batched_f64(const float* const* Z, const int64_t* ldz, const int64_t* M, int B,
                                               int64_t Mmax, int D, double sigma, double lam, double eps, double* out,
                                               int64_t ld, int64_t out_stride, int32_t* info, void* workspace,
                                               int64_t workspace_bytes, odx_stream_t stream) {
+  const int rc = falkon_precond_batched_f64_impl(Z, ldz, M, B, Mmax, D, sigma, lam, eps, out, ld, out_stride, info, workspace, workspace_bytes, stream);
+  if (Mmax > 0 && chain_helpers(Mmax) && chain_release_helpers()) {
+    const int rr = release_side_streams(false);
+    return rc != ODX_OK ? rc : rr;
+  }
+  return rc;
+}
+
+static int falkon_precond_batched_f64_impl(const float* const* Z, const int64_t* ldz, const int64_t* M, int B,
+                                           int64_t Mmax, int D, double sigma, double lam, double eps, double* out,
+                                           int64_t ld, int64_t out_stride, int32_t* info, void* workspace,
+                                           int64_t workspace_bytes, odx_stream_t stream) {
   ODX_REQUIRE(B >= 1 && B <= ODX_MAX_ZBATCH, "odx_falkon_precond_batched_f64: 1 <= B <= %d classes per call", ODX_MAX_ZBATCH);
   ODX_REQUIRE(Z && ldz && M && out && info && workspace && Mmax > 0 && D > 0 && sigma > 0,
               "odx_falkon_precond_batched_f64: null pointer or bad size");
@@ -1179,4 +1251,8 @@ extern "C" int odx_set_side_stream_cu_mask(const uint32_t* mask, int words) {
   ODX_REQUIRE(words >= 0 && words <= 64 && (words == 0 || mask != nullptr), "odx_set_side_stream_cu_mask: bad argument");
   g_side_mask.assign(mask, mask + words);
   return ODX_OK;
+}
+
+extern "C" int odx_release_helper_streams(void) {
+  return odx::release_side_streams(false);
 }

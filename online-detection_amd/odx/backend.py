@@ -147,7 +147,16 @@ class HipBackend:
         return buf
 
     def release_workspaces(self):
+        """Drops the scratch buffers and the library's internal helper streams of this thread (both come back on demand): what
+        a process calls between its fits and latency-bound work (odx_release_helper_streams says why)."""
         self._ws.clear()
+        self.release_helper_streams()
+
+    def release_helper_streams(self):
+        """The library's internal helper streams of this thread's factorisation chains are destroyed (no wait; remade on demand):
+        called when a fit / a training step has been queued — left alive they slow every later small launch of the process
+        (odx_release_helper_streams)."""
+        hip.check(self.lib.odx_release_helper_streams(), "odx_release_helper_streams")
 
     def vec(self, x):
         return torch.as_tensor(x, dtype=torch.float64, device=self.device).contiguous()

@@ -116,6 +116,8 @@ class _FalkonBase:
         yv = be.vec(y[:, 0])
         alpha = falkon_fit(be, F, yv, Zf, self.kernel.sigma, float(self.penalty), int(self.maxiter),
                            self.options.solver_options())
+        if hasattr(be, "release_helper_streams"):
+            be.release_helper_streams()          # (a chain of 4096 centres or more made helper streams: not left behind idle)
         ny = Zf.X.contiguous() if Zf.X.stride(0) != Zf.D else Zf.X
         self.alpha_ = alpha.reshape(-1, 1)
         self.ny_points_ = ny
@@ -300,6 +302,8 @@ def fit_batch(estimators, Xs, Ys, streams=None):
     if streams:
         for s in streams:
             cur.wait_stream(s)
+    if hasattr(be, "release_helper_streams"):
+        be.release_helper_streams()              # (see InCoreFalkon.fit)
     return estimators
 
 
@@ -444,6 +448,8 @@ class BatchFit:
                 est.alpha_, est.ny_points_ = est.alpha_.cpu(), est.ny_points_.cpu()
             else:
                 est._centres(Zfs[i])
+        if hasattr(be, "release_helper_streams"):
+            be.release_helper_streams()          # (see InCoreFalkon.fit)
         return self.est
 
 

@@ -33,6 +33,7 @@ SIGNATURES = {
     "odx_knm_pass_kernel_name": (ctypes.c_char_p, [_i64, _i32, _i32]),
     "odx_version": (_i32, []),
     "odx_device_cus": (_i32, []),
+    "odx_release_helper_streams": (_i32, []),
     "odx_stream_create_cu_mask": (_i32, [_vp, _i32, _vp]),
     "odx_stream_destroy": (_i32, [_vp]),
     "odx_set_pass_cus": (_i32, [_i32]),

@@ -233,4 +233,8 @@ class LockstepClassJob:
                 with ph("mmv"):
                     be.mmv(F, Zs[pos], self.sigma, alphas[pos], None, out=self.scores[:, c:c + 1])
             out = (alphas[-1], Zs[-1])
+        if hasattr(be, "release_helper_streams"):
+            # the chains' internal helper streams go when the step is queued (their work completes first; the next step's first
+            # chain makes them again): left alive and idle they slow every later small launch of the process
+            be.release_helper_streams()
         return out
