@@ -557,5 +557,7 @@ if __name__ == "__main__":
     import json
 
     class _A:
-        no_cpu_baseline = False
-    print(json.dumps(collect(_A()), indent=1))
+        no_cpu_baseline = "--no-cpu-baseline" in sys.argv
+    import odx
+    odx.get_backend()
+    print(json.dumps(collect(_A())))
