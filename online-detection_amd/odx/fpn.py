@@ -428,11 +428,37 @@ class OnlineDetectionModelFPN(nn.Module):
         L, Rmax = len(trunk), max(ks)
         cand = torch.zeros((B, L, Rmax, 4), dtype=torch.float32, device=dev)
         score = torch.full((B, L, Rmax), -1.0, dtype=torch.float32, device=dev)           # (sigmoid scores are > 0: pads sort last)
+        rows_head = (self.compute_dtype is None and trunk[0].dtype == torch.float32 and not torch.is_autocast_enabled("cuda")
+                     and not torch.is_grad_enabled() and hasattr(be, "conv3x3_rows") and self.rpn_conv.in_channels % 8 == 0
+                     and __import__("os").environ.get("ODX_TRUNK", "rows") != "conv")
+        dt16 = self.compute_dtype if self.compute_dtype in (torch.bfloat16, torch.float16) else None
+        rows16_head = (dt16 is not None and trunk[0].dtype == dt16 and not torch.is_grad_enabled() and hasattr(be, "conv3x3_rows16")
+                       and self.rpn_conv.in_channels % 8 == 0 and __import__("os").environ.get("ODX_TRUNK", "rows") != "conv")
         for lvl, p in enumerate(trunk):
-            with (contextlib.nullcontext() if p.dtype in (torch.bfloat16, torch.float16) else self._amp()):
-                w = self._rpn_weights(p.dtype)
-                a = F.relu(F.conv2d(p, w[0], w[1], 1, 1))
-                logits, deltas = F.conv2d(a, w[2], w[3]).float(), F.conv2d(a, w[4], w[5]).float()
+            if rows16_head:
+                # (the same on 16-bit rows: odx_gemm_b16_taps / odx_gemm_b16, the outputs in f32)
+                Bn, C, H, W = p.shape
+                wp = self._rpn_rows16_weights(be, dt16)
+                x16 = be.rows16(p.permute(0, 2, 3, 1).reshape(Bn * H * W, C), dt16, zero_row=True)
+                a = be.conv3x3_rows16(x16, Bn, H, W, wp[0], bias=wp[1], relu=True)
+                o = be.gemm_b16(a, wp[2], bias=wp[3], out_f32=True).view(Bn, H, W, -1)
+                A = self.rpn_logits.out_channels
+                logits, deltas = o[..., :A].permute(0, 3, 1, 2).contiguous(), o[..., A:].permute(0, 3, 1, 2).contiguous()
+            elif rows_head:
+                # the RPN head of a level for the whole group as two products over the level's NHWC rows (the 3 x 3 convolution with
+                # its taps gathered in the operand loads, the two 1 x 1 outputs as one product of 15 columns): the convolution
+                # library's five 3 x 3 convolutions were a fifth of the group forward's device time
+                Bn, C, H, W = p.shape
+                wp = self._rpn_rows_weights(be)
+                a = be.conv3x3_rows(p.permute(0, 2, 3, 1).reshape(Bn * H * W, C), Bn, H, W, wp[0], bias=wp[1], relu=True)
+                o = be.gemm_h2(be.packed(a), wp[2], bias=wp[3]).view(Bn, H, W, -1)
+                A = self.rpn_logits.out_channels
+                logits, deltas = o[..., :A].permute(0, 3, 1, 2).contiguous(), o[..., A:].permute(0, 3, 1, 2).contiguous()
+            else:
+                with (contextlib.nullcontext() if p.dtype in (torch.bfloat16, torch.float16) else self._amp()):
+                    w = self._rpn_weights(p.dtype)
+                    a = F.relu(F.conv2d(p, w[0], w[1], 1, 1))
+                    logits, deltas = F.conv2d(a, w[2], w[3]).float(), F.conv2d(a, w[4], w[5]).float()
             _, A, H, W = logits.shape
             b, sc, _ = be.rpn_topk_decode(logits, deltas, self._anchors(lvl, H, W, dev), ks[lvl], img_size, DELTA_CLAMP)
             cand[:, lvl, :ks[lvl]] = b
@@ -446,6 +472,33 @@ class OnlineDetectionModelFPN(nn.Module):
         boxes = cand.view(B, L * Rmax, 4).gather(1, order.unsqueeze(2).expand(B, k, 4))
         n = (top > 0).sum(dim=1).tolist()                          # survivors per image (the group's one synchronisation)
         return [(boxes[b, :n[b]], top[b, :n[b]]) for b in range(B)]
+
+    def _rpn_rows_weights(self, be):
+        """The RPN head's weights as packed GEMM operands: (3 x 3 convolution (out, ky kx in), its bias, the two 1 x 1 outputs stacked
+        (A + 4 A, C), their biases); remade when a parameter is replaced or written in place."""
+        ps = (self.rpn_conv.weight, self.rpn_conv.bias, self.rpn_logits.weight, self.rpn_logits.bias, self.rpn_deltas.weight, self.rpn_deltas.bias)
+        key = ("rows",) + tuple((q.data_ptr(), q._version) for q in ps)
+        hit = self._packed.get("rpn_rows")
+        if hit is None or hit[0] != key:
+            cv, lg, dl = self.rpn_conv, self.rpn_logits, self.rpn_deltas
+            hit = self._packed["rpn_rows"] = (key, (
+                be.packed(cv.weight.detach().float().permute(0, 2, 3, 1).reshape(cv.out_channels, -1).contiguous()), cv.bias.detach().float().contiguous(),
+                be.packed(torch.cat((lg.weight.detach().float().reshape(lg.out_channels, -1), dl.weight.detach().float().reshape(dl.out_channels, -1)), dim=0).contiguous()),
+                torch.cat((lg.bias.detach().float(), dl.bias.detach().float())).contiguous()))
+        return hit[1]
+
+    def _rpn_rows16_weights(self, be, dt):
+        """_rpn_rows_weights for a 16-bit forward: Rows16 operands of type dt."""
+        ps = (self.rpn_conv.weight, self.rpn_conv.bias, self.rpn_logits.weight, self.rpn_logits.bias, self.rpn_deltas.weight, self.rpn_deltas.bias)
+        key = ("rows16", dt) + tuple((q.data_ptr(), q._version) for q in ps)
+        hit = self._packed.get("rpn_rows16")
+        if hit is None or hit[0] != key:
+            cv, lg, dl = self.rpn_conv, self.rpn_logits, self.rpn_deltas
+            hit = self._packed["rpn_rows16"] = (key, (
+                be.rows16(cv.weight.detach().permute(0, 2, 3, 1).reshape(cv.out_channels, -1).to(dt).contiguous(), dt), cv.bias.detach().float().contiguous(),
+                be.rows16(torch.cat((lg.weight.detach().reshape(lg.out_channels, -1), dl.weight.detach().reshape(dl.out_channels, -1)), dim=0).to(dt).contiguous(), dt),
+                torch.cat((lg.bias.detach().float(), dl.bias.detach().float())).contiguous()))
+        return hit[1]
 
     def _rpn_weights(self, dtype):
         """The RPN head's three convolutions' weights and biases in `dtype` (cached; dropped with the packed fc weights when
