@@ -508,6 +508,12 @@ int odx_roi_align_rows_nhwc_f32(const float* feat_rows, int64_t ldf, int N, int 
 int odx_roi_align_fpn_f32(const float* const* feats, const int* H, const int* W, const float* scales, int levels,
                           int N, int C, const float* rois, int R, int PH, int PW, int sampling_ratio, float* out,
                           int* level_out, odx_stream_t stream);
+/* odx_roi_align_fpn_f32 reading the levels as the NHWC row matrices the pyramid's row GEMMs write (level l: N H_l W_l rows of C
+ * channels, C % 4 == 0) and writing out (R, PH PW C): the rows fc6 multiplies when its weight's columns are ordered (ph, pw, c).
+ * Same level rule, sample positions and sums per channel. */
+int odx_roi_align_fpn_nhwc_f32(const float* const* feats, const int* H, const int* W, const float* scales, int levels,
+                               int N, int C, const float* rois, int R, int PH, int PW, int sampling_ratio, float* out_rows,
+                               int* level_out, odx_stream_t stream);
 /* Greedy NMS over boxes (R, 4) xyxy ALREADY SORTED by descending score, areas with the +1
  * pixel convention: keep[i] = 1 unless an earlier kept box overlaps i with IoU > threshold.  */
 int64_t odx_nms_workspace_bytes(int R);

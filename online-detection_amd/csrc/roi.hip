@@ -124,13 +124,11 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(const float* __restr
 // adjacent channels, so every sample is four 16-byte-per-lane reads of contiguous rows (the NCHW kernel above strides by
 // H * W between channels) and the output row is written 16 bytes per lane.  Same sample positions, weights and order of
 // additions per channel as roi_align_fwd_kernel.
-__global__ __launch_bounds__(256) void roi_align_rows_nhwc_kernel(const float* __restrict__ feat, int64_t ldf, int N, int C, int H, int W,
-                                                                  const float* __restrict__ rois, float scale, int PH, int PW,
-                                                                  int sampling_ratio, int step, float* __restrict__ out) {
-  const int r = blockIdx.x;
-  const int OW = (PW + step - 1) / step;
-  const int ph = ((int)blockIdx.y / OW) * step, pw = ((int)blockIdx.y % OW) * step;
-  const float* roi = rois + (int64_t)r * 5;
+// one output bin (ph, pw) of one RoI from an NHWC map (rows of ldf floats), all channels: the lanes of the workgroup own four
+// adjacent channels each
+__device__ __forceinline__ void roi_align_bin_nhwc(const float* __restrict__ feat, int64_t ldf, int N, int C, int H, int W,
+                                                   const float* __restrict__ roi, float scale, int PH, int PW, int sampling_ratio,
+                                                   int ph, int pw, float* __restrict__ row) {
   const int b = (int)roi[0];
   const float x1 = roi[1] * scale, y1 = roi[2] * scale, x2 = roi[3] * scale, y2 = roi[4] * scale;
   const float rw = fmaxf(x2 - x1, 1.f), rh = fmaxf(y2 - y1, 1.f);
@@ -139,8 +137,7 @@ __global__ __launch_bounds__(256) void roi_align_rows_nhwc_kernel(const float* _
   const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)PW);
   const float count = (float)(gh * gw);
   const float* base = feat + (int64_t)b * H * W * ldf;
-  float* row = out + ((int64_t)r * gridDim.y + blockIdx.y) * C;
-  for (int c = threadIdx.x * 4; c < C; c += 1024) {
+  for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (b >= 0 && b < N) {
       for (int iy = 0; iy < gh; ++iy) {
@@ -168,6 +165,16 @@ __global__ __launch_bounds__(256) void roi_align_rows_nhwc_kernel(const float* _
     for (int k = 0; k < 4; ++k) v[k] = acc[k] / count;
     *reinterpret_cast<f32x4*>(row + c) = v;
   }
+}
+
+__global__ __launch_bounds__(256) void roi_align_rows_nhwc_kernel(const float* __restrict__ feat, int64_t ldf, int N, int C, int H, int W,
+                                                                  const float* __restrict__ rois, float scale, int PH, int PW,
+                                                                  int sampling_ratio, int step, float* __restrict__ out) {
+  const int r = blockIdx.x;
+  const int OW = (PW + step - 1) / step;
+  const int ph = ((int)blockIdx.y / OW) * step, pw = ((int)blockIdx.y % OW) * step;
+  roi_align_bin_nhwc(feat, ldf, N, C, H, W, rois + (int64_t)r * 5, scale, PH, PW, sampling_ratio, ph, pw,
+                     out + ((int64_t)r * gridDim.y + blockIdx.y) * C);
 }
 
 // ---------------------------------------------------------------- multi-level RoIAlign (FPN Pooler)
@@ -248,6 +255,26 @@ __global__ __launch_bounds__(256) void roi_align_fpn_kernel(FpnLevels L, int N, 
 #pragma unroll
   for (int k = 0; k < ROI_CCH; ++k)
     if (k < nch) out[(((int64_t)r * C + c0 + k) * PH + ph) * PW + pw] = acc[k] / count;
+}
+
+// The multi-level RoIAlign from NHWC maps (the pyramid as the row GEMMs write it: level l = N H_l W_l rows of C channels), written
+// as the rows fc6 reads with its weight's columns in (ph, pw, c) order: out (R, PH PW C).  One workgroup per (RoI, bin), a lane
+// owns four adjacent channels (roi_align_bin_nhwc); same level choice, sample positions and sums per channel as
+// roi_align_fpn_kernel.
+__global__ __launch_bounds__(256) void roi_align_fpn_nhwc_kernel(FpnLevels L, int N, int C, const float* __restrict__ rois, int PH, int PW,
+                                                                 int sampling_ratio, float* __restrict__ out, int* __restrict__ level_out) {
+  const int r = blockIdx.x;
+  const float* roi = rois + (int64_t)r * 5;
+  const int lv = fpn_level_of(roi, L);
+  if (level_out != nullptr && blockIdx.y == 0 && threadIdx.x == 0) level_out[r] = lv;
+  const float* feat = L.feat[0];
+  int H = L.H[0], W = L.W[0];
+  float scale = L.scale[0];
+#pragma unroll
+  for (int k = 1; k < ODX_MAX_FPN_LEVELS; ++k)
+    if (k == lv) { feat = L.feat[k]; H = L.H[k]; W = L.W[k]; scale = L.scale[k]; }
+  const int ph = (int)blockIdx.y / PW, pw = (int)blockIdx.y % PW;
+  roi_align_bin_nhwc(feat, C, N, C, H, W, roi, scale, PH, PW, sampling_ratio, ph, pw, out + ((int64_t)r * gridDim.y + blockIdx.y) * C);
 }
 
 // ---------------------------------------------------------------- NMS
@@ -812,6 +839,37 @@ extern "C" int odx_roi_align_fpn_f32(const float* const* feats, const int* H, co
   hipLaunchKernelGGL(roi_align_fpn_kernel, grid, dim3(256), 0, as_stream(stream), L, N, C, rois, R, PH, PW, sampling_ratio, out,
                      level_out);
   ODX_CHECK_LAUNCH("odx_roi_align_fpn_f32");
+  return ODX_OK;
+}
+
+// odx_roi_align_fpn_f32 from NHWC maps (level l: N H_l W_l rows of C channels, C % 4 == 0, 16-byte aligned): out (R, PH PW C) —
+// the rows fc6 reads when its weight's columns are ordered (ph, pw, c).
+extern "C" int odx_roi_align_fpn_nhwc_f32(const float* const* feats, const int* H, const int* W, const float* scales, int levels,
+                                          int N, int C, const float* rois, int R, int PH, int PW, int sampling_ratio, float* out_rows,
+                                          int* level_out, odx_stream_t stream) {
+  if (R <= 0 || C <= 0) return ODX_OK;
+  ODX_REQUIRE(feats && H && W && scales && rois && out_rows && N > 0, "odx_roi_align_fpn_nhwc_f32: null pointer");
+  ODX_REQUIRE(levels >= 1 && levels <= ODX_MAX_FPN_LEVELS, "odx_roi_align_fpn_nhwc_f32: 1..%d pyramid levels", ODX_MAX_FPN_LEVELS);
+  ODX_REQUIRE(PH > 0 && PW > 0 && PH * PW <= 65535 && C % 4 == 0 && (reinterpret_cast<uintptr_t>(out_rows) & 15u) == 0,
+              "odx_roi_align_fpn_nhwc_f32: PH * PW in 1..65535, C %% 4 == 0, 16-byte aligned rows expected");
+  FpnLevels L;
+  for (int k = 0; k < ODX_MAX_FPN_LEVELS; ++k) {
+    const int j = k < levels ? k : levels - 1;
+    ODX_REQUIRE(feats[j] && H[j] > 0 && W[j] > 0 && scales[j] > 0.f && (int64_t)H[j] * W[j] < (1ll << 31) &&
+                (reinterpret_cast<uintptr_t>(feats[j]) & 15u) == 0, "odx_roi_align_fpn_nhwc_f32: bad level %d", j);
+    L.feat[k] = feats[j];
+    L.H[k] = H[j];
+    L.W[k] = W[j];
+    L.scale[k] = scales[j];
+  }
+  L.levels = levels;
+  L.k_min = (int)lrintf(-log2f(scales[0]));
+  L.k_max = (int)lrintf(-log2f(scales[levels - 1]));
+  ODX_REQUIRE(L.k_max - L.k_min == levels - 1, "odx_roi_align_fpn_nhwc_f32: the level scales must halve from level to level");
+  const int threads = C >= 1024 ? 256 : (C >= 512 ? 128 : 64);
+  hipLaunchKernelGGL(roi_align_fpn_nhwc_kernel, dim3((unsigned)R, (unsigned)(PH * PW)), dim3(threads), 0, as_stream(stream), L, N, C, rois,
+                     PH, PW, sampling_ratio, out_rows, level_out);
+  ODX_CHECK_LAUNCH("odx_roi_align_fpn_nhwc_f32");
   return ODX_OK;
 }
 

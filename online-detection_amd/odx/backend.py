@@ -814,6 +814,33 @@ class HipBackend:
                                                      _p(lv), self._stream()), "odx_roi_align_fpn_f32")
         return (out, lv) if return_levels else out
 
+    def roi_align_fpn_rows(self, feats, rois, scales, output_size, sampling_ratio=2):
+        """roi_align_fpn for a pyramid handed over as channels-last views of NHWC row matrices (what the pyramid's row GEMMs
+        write): -> (R, PH PW C) f32, the crops flattened in (ph, pw, c) order (odx_roi_align_fpn_nhwc_f32: no NCHW copy of the
+        levels).  Levels that are not such views are taken through a channels-last copy."""
+        fs = []
+        for f in feats:
+            f = f.to(device=self.device, dtype=torch.float32)
+            if f.is_contiguous() or not f.is_contiguous(memory_format=torch.channels_last) or f.data_ptr() % 16 != 0:
+                f = f.contiguous(memory_format=torch.channels_last)
+            fs.append(f)
+        rois = rois.to(device=self.device, dtype=torch.float32).contiguous()
+        L = len(fs)
+        N, C = fs[0].shape[:2]
+        if any(f.shape[0] != N or f.shape[1] != C for f in fs) or C % 4 != 0:
+            raise ValueError("roi_align_fpn_rows: every level needs the same batch size and a channel count in fours")
+        PH, PW = output_size
+        R = rois.shape[0]
+        out = torch.empty((R, PH * PW * C), dtype=torch.float32, device=self.device)
+        if R:
+            fp = (ctypes.c_void_p * L)(*[f.data_ptr() for f in fs])
+            hs = (ctypes.c_int * L)(*[int(f.shape[2]) for f in fs])
+            ws = (ctypes.c_int * L)(*[int(f.shape[3]) for f in fs])
+            sc = (ctypes.c_float * L)(*[float(v) for v in scales])
+            hip.check(self.lib.odx_roi_align_fpn_nhwc_f32(fp, hs, ws, sc, L, N, C, _p(rois), R, PH, PW, int(sampling_ratio), _p(out), None,
+                                                          self._stream()), "odx_roi_align_fpn_nhwc_f32")
+        return out
+
     def packed(self, X, meta=None, zero_row=False):
         """X (rows, K) f32 as a GEMM operand of gemm_h2: its packed two-term f16 split (no row norms).  meta: the two meta
         words a producer already left for X (gemm_h2(..., with_max=True): max |X| in meta[1]) — no maximum pass then; a bound

@@ -167,8 +167,9 @@ class FeaturePyramid(nn.Module):
         split-f16 tile cores over NHWC rows: the lateral 1 x 1 convolutions read the stages' packed operands as the trunk's last
         products wrote them, the nearest-neighbour upsampling of the top-down path is a row gather, the 3 x 3 output convolutions
         gather their taps inside the product's operand loads where the library serves the shape (HipBackend.conv3x3_rows).
-        Returns the five levels as contiguous (B, C, h, w) maps — what the RPN head, the proposal stage and the multi-level
-        RoIAlign take (a copy of 1.3 x the bytes of P2 per image)."""
+        Returns the five levels as (B, C, h, w) channels-last VIEWS of the products' rows: the RPN head of a group
+        (proposals_batch) and the multi-level RoIAlign (odx_roi_align_fpn_nhwc_f32) read the rows as they are; whoever needs an
+        NCHW map (the one-image proposal stage on the convolution library) copies."""
         be = _backend.get_backend()
         inner, layer = self._rows_weights(be)
         outs, last, dims = [], None, None
@@ -183,8 +184,9 @@ class FeaturePyramid(nn.Module):
                 lat = (lat.view(B, H, W, -1) + up).reshape(B * H * W, -1)
             last, dims = lat, (B, H, W)
             o = be.conv3x3_rows(lat, B, H, W, layer[k][0], bias=layer[k][1])
-            outs.insert(0, o.view(B, H, W, -1).permute(0, 3, 1, 2).contiguous())
-        outs.append(outs[-1][:, :, ::2, ::2].contiguous())                            # max pooling, kernel 1, stride 2
+            outs.insert(0, o.view(B, H, W, -1).permute(0, 3, 1, 2))                   # (B, C, h, w) as a channels-last VIEW of the rows
+        # (max pooling, kernel 1, stride 2; as rows of its own: a view of every second position is not a row matrix)
+        outs.append(outs[-1][:, :, ::2, ::2].contiguous(memory_format=torch.channels_last))
         return tuple(outs)
 
 
@@ -336,6 +338,7 @@ class OnlineDetectionModelFPN(nn.Module):
         sel_reg, sel_anc, sel_score, counts = [], [], [], []
         lvl_boxes = []
         for lvl, p in enumerate(trunk):
+            p = p.contiguous()                   # (a level of the row-GEMM pyramid is a channels-last view: the library's route copies)
             with (contextlib.nullcontext() if p.dtype in (torch.bfloat16, torch.float16) else self._amp()):
                 # (weights / biases held in the compute dtype: autocast casts an f32 parameter again on every call — 15 casts
                 # per image over the five levels)
@@ -455,6 +458,7 @@ class OnlineDetectionModelFPN(nn.Module):
                 A = self.rpn_logits.out_channels
                 logits, deltas = o[..., :A].permute(0, 3, 1, 2).contiguous(), o[..., A:].permute(0, 3, 1, 2).contiguous()
             else:
+                p = p.contiguous()
                 with (contextlib.nullcontext() if p.dtype in (torch.bfloat16, torch.float16) else self._amp()):
                     w = self._rpn_weights(p.dtype)
                     a = F.relu(F.conv2d(p, w[0], w[1], 1, 1))
@@ -521,14 +525,19 @@ class OnlineDetectionModelFPN(nn.Module):
         return a
 
     # ------------------------------------------------------------------ RoI features
-    def _fc(self, be, name, x, layer):
-        """relu(x W' + b) on the split-f16 tile cores (f32 accuracy), the weight packed once."""
+    def _fc(self, be, name, x, layer, nhwc=None):
+        """relu(x W' + b) on the split-f16 tile cores (f32 accuracy), the weight packed once.  nhwc = (C, r): x's columns are
+        ordered (ph, pw, c) instead of the layer's (c, ph, pw) — the weight's columns are permuted to match when it is packed."""
         # keyed on the parameter's storage and in-place version counter as well: an optimiser step, a copy_ into the weight
         # or a re-assigned Parameter must not be multiplied with the packing of the old values
         key = (layer.weight.data_ptr(), layer.weight._version)
         hit = self._packed.get(name)
         if hit is None or hit[0] != key:
-            hit = self._packed[name] = (key, be.packed(layer.weight.detach().float().contiguous()))
+            w = layer.weight.detach().float()
+            if nhwc is not None:
+                C, r = nhwc
+                w = w.view(w.shape[0], C, r, r).permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+            hit = self._packed[name] = (key, be.packed(w.contiguous()))
         return be.gemm_h2(be.packed(x), hit[1], bias=layer.bias.detach().float(), relu=True)
 
     @torch.no_grad()
@@ -540,7 +549,14 @@ class OnlineDetectionModelFPN(nn.Module):
         first = (torch.zeros((boxes.shape[0], 1), device=boxes.device) if batch_idx is None
                  else batch_idx.to(device=boxes.device, dtype=boxes.dtype).view(-1, 1))
         rois = torch.cat((first, boxes), dim=1)
-        crops = be.roi_align_fpn(list(trunk[:4]), rois, self.pool_scales, (self.resolution, self.resolution), self.sampling_ratio)
+        t0 = trunk[0]
+        if (t0.is_cuda and t0.dtype == torch.float32 and not t0.is_contiguous() and t0.is_contiguous(memory_format=torch.channels_last)
+                and hasattr(be, "roi_align_fpn_rows") and hasattr(be, "gemm_h2") and boxes.shape[0] > 0 and t0.shape[1] % 4 == 0):
+            # the pyramid is the row GEMMs' NHWC rows: pooled from them as they are, the crops flattened in (ph, pw, c) order and
+            # fc6's weight columns permuted to match (once) — no NCHW copy of the levels, 16-byte reads of contiguous channels
+            x = be.roi_align_fpn_rows(list(trunk[:4]), rois, self.pool_scales, (self.resolution, self.resolution), self.sampling_ratio)
+            return self._fc(be, "fc7", self._fc(be, "fc6_nhwc", x, self.fc6, nhwc=(t0.shape[1], self.resolution)), self.fc7)
+        crops = be.roi_align_fpn([p.contiguous() for p in trunk[:4]], rois, self.pool_scales, (self.resolution, self.resolution), self.sampling_ratio)
         x = crops.reshape(crops.shape[0], -1)
         if x.shape[0] == 0:
             return x.new_zeros((0, self.mlp_dim))

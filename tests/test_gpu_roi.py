@@ -115,6 +115,34 @@ def test_roi_align_rows_from_an_nhwc_map_equals_the_nchw_kernel():
         assert torch.equal(got, want)
 
 
+def test_roi_align_fpn_from_nhwc_levels_equals_the_nchw_kernel():
+    """odx_roi_align_fpn_nhwc_f32 (the pyramid's levels as channels-last views of the row GEMMs' outputs; crops flattened in
+    (ph, pw, c) order) = odx_roi_align_fpn_f32 on NCHW copies of the same levels, permuted, bit for bit: RoIs over all four
+    levels, both images of a batch, boxes hanging over the border, channel counts on every thread-count branch."""
+    import odx
+    be = odx.get_backend()
+    g = torch.Generator().manual_seed(9)
+    for C in (8, 64, 256, 300):
+        sizes = [(56, 72), (28, 36), (14, 18), (7, 9)]
+        nchw = [torch.randn((2, C, h, w), generator=g).cuda() for h, w in sizes]
+        views = [f.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2) for f in nchw]
+        R = 61
+        xy = torch.rand((R, 2), generator=g) * torch.tensor([220.0, 160.0])
+        wh = 4 + torch.rand((R, 2), generator=g) ** 2 * 900                    # sides from 4 to 904: every level of LevelMapper
+        rois = torch.cat((torch.randint(0, 2, (R, 1), generator=g).float(), xy, xy + wh), dim=1).cuda()
+        rois[0, 1:] = torch.tensor([-30.0, -20.0, 400.0, 300.0])
+        scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+        for (PH, PW), sr in (((7, 7), 2), ((14, 14), 2), ((7, 5), 0)):
+            want, lv = be.roi_align_fpn(nchw, rois, scales, (PH, PW), sr, return_levels=True)
+            got = be.roi_align_fpn_rows(views, rois, scales, (PH, PW), sr)
+            assert got.shape == (R, PH * PW * C)
+            assert torch.equal(got.view(R, PH, PW, C).permute(0, 3, 1, 2), want), (C, PH, PW, sr)
+            got2 = be.roi_align_fpn_rows(nchw, rois, scales, (PH, PW), sr)     # NCHW levels: through a channels-last copy
+            assert torch.equal(got2, got)
+        assert len(set(lv.tolist())) == 4
+    assert be.roi_align_fpn_rows(views, rois[:0], scales, (7, 7), 2).shape == (0, 49 * C)
+
+
 @pytest.mark.parametrize("N,C,H,W", [(1, 64, 150, 200), (2, 7, 19, 25), (1, 3, 1, 1), (1, 256, 38, 50),
                                      (300, 512, 7, 7), (70001, 1, 2, 3), (64, 1024, 4, 4)])     # > 65535 planes (advisor, round 4)
 @pytest.mark.parametrize("with_res", [False, True])
