@@ -390,6 +390,18 @@ int odx_rls_gram_batched_f64(const float* X, int64_t ldx, int D, const int64_t* 
                              const double* Yt, int64_t ldy, double* G, int64_t ldg, int64_t g_stride,
                              double* XtY, int64_t ldxy, int64_t xy_stride,
                              void* workspace, int64_t workspace_bytes, odx_stream_t stream);
+/* The same without waiting for the statistics at all (train_region_refiner.py:58-68 derives them from the targets only): the
+ * whitening is linear, Yw = (Y - 1 mu') T, so X' Yw = (X' Y - (X' 1) mu') T and 1' Yw = 0.  odx_rls_gram_raw_batched_f64 forms the
+ * Grams AND the raw products O5 (C, 5, ldo) f64 = [Y 1]' X (rows 0 .. 3: the un-whitened targets Yraw (n, ldyr >= 4) f32 by row
+ * id; row 4: the column sums; columns 0 .. D - 1) in ONE sweep over the rows — the targets' products ride on the vector ALU under
+ * the Gram's matrix instructions; odx_rls_fold_whitened_f64 then writes XtY (4 x (D + 1) per class) and adds the Gram's bias row
+ * from O5, stats (C, 9, 4) f64 = [mu; T; T_inv] per class and cnt (C) f64 = rows per class.  Rows form only. */
+int odx_rls_gram_raw_batched_f64(const float* X, int64_t ldx, int D, const int64_t* idx_pad, int64_t npad,
+                                 const int64_t* seg_off, const int64_t* seg_len, int C, const float* Yraw, int64_t ldyr,
+                                 double* G, int64_t ldg, int64_t g_stride, double* O5, int64_t ldo, odx_stream_t stream);
+int odx_rls_fold_whitened_f64(const double* O5, int64_t ldo, int D, int C, const double* stats, const double* cnt,
+                              double* G, int64_t ldg, int64_t g_stride, double* XtY, int64_t ldxy, int64_t xy_stride,
+                              odx_stream_t stream);
 int64_t odx_rls_solve_batched_workspace_bytes(int D, int C);
 int odx_rls_solve_batched_f64(double* G, int64_t ldg, int64_t g_stride, int D, int C, double lam,
                               const double* XtY, int64_t ldxy, int64_t xy_stride,

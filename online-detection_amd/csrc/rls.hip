@@ -140,16 +140,41 @@ constexpr int RG_LDA = RG_BM + 16, RG_LDB = RG_BN + 16;      // doubles per LDS 
 
 __global__ __launch_bounds__(256, 3) void rls_gram_rows_kernel(const float* __restrict__ X, int64_t ldx, int D,
                                                                const int64_t* __restrict__ idx, RlsSegs sg, double* __restrict__ G,
-                                                               int64_t ldg, int64_t g_stride) {
+                                                               int64_t ldg, int64_t g_stride, const float* __restrict__ Yraw,
+                                                               int64_t ldyr, double* __restrict__ O5, int64_t ldo) {
   __shared__ __attribute__((aligned(16))) double lds_a[RG_BK * RG_LDA];
   __shared__ __attribute__((aligned(16))) double lds_b[RG_BK * RG_LDB];
-  const int c = blockIdx.z;
+  __shared__ __attribute__((aligned(16))) double lds_y[RG_BK * 4];
+  int c = blockIdx.z;
   const int tiles_n = (D + RG_BN - 1) / RG_BN;
   // gridDim.x = 8 x ceil(tile rows / 8) x tiles_n: workgroup x runs on XCD x & 7 (round-robin dispatch), and that XCD walks
   // the tile rows xcd, xcd + 8, ... left to right, so the tiles sharing an A panel (and the rows' B pieces next to each
   // other) share one L2; the class index rotates which rows an XCD gets (row r carries r + 1 tiles)
-  const int xcd = (blockIdx.x + c) & 7, local = blockIdx.x >> 3;
-  const int bi = 8 * (local / tiles_n) + xcd, bj = local % tiles_n;
+  int bi, bj;
+  if (Yraw == nullptr) {
+    const int xcd = (blockIdx.x + c) & 7, local = blockIdx.x >> 3;
+    bi = 8 * (local / tiles_n) + xcd;
+    bj = local % tiles_n;
+  } else {
+    // with the targets' products the tiles of the first column carry ~ 15 % more work: they go FIRST in dispatch order (all
+    // classes'), so that none of them starts in the launch's last round and stretches its tail (measured: + 0.7 ms with the
+    // tiles in their usual places).  L = the linear dispatch index; both regions are multiples of 8 long, so L & 7 still
+    // names the XCD.
+    const int64_t L = (int64_t)blockIdx.z * gridDim.x + blockIdx.x;
+    const int nC = gridDim.z, nH = gridDim.x / tiles_n, nL = gridDim.x - nH;
+    if (L < (int64_t)nC * nH) {
+      c = (int)(L / nH);
+      const int h = (int)(L % nH);
+      bi = 8 * (h >> 3) + ((h + c) & 7);
+      bj = 0;
+    } else {
+      const int64_t L2 = L - (int64_t)nC * nH;
+      c = (int)(L2 / nL);
+      const int t = (int)(L2 % nL), local = t >> 3;
+      bi = 8 * (local / (tiles_n - 1)) + ((t + c) & 7);
+      bj = 1 + local % (tiles_n - 1);
+    }
+  }
   const int i0 = bi * RG_BM, j0 = bj * RG_BN;
   if (i0 >= D || j0 > i0 + RG_BM - 1) return;                  // lower tiles only
   const int64_t off = sg.off[c], len = sg.len[c];
@@ -182,11 +207,20 @@ __global__ __launch_bounds__(256, 3) void rls_gram_rows_kernel(const float* __re
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = f64x4{0.0, 0.0, 0.0, 0.0};
   const int64_t nk = (len + RG_BK - 1) / RG_BK;
-  if (nk == 0) return;
+  if (nk == 0) {
+    if (Yraw != nullptr && j0 == 0 && tid < 128 && i0 + tid < D)
+      for (int j = 0; j < 5; ++j) O5[((int64_t)c * 5 + j) * ldo + i0 + tid] = 0.0;
+    return;
+  }
   // the row id of a k-tile is fetched one k-tile before its row is: the row's loads never wait for a dependent load
   // (the segment is padded with -1 to a multiple of 16 rows; past the last k-tile the last one is read again and dropped)
   auto row_of = [&](int64_t kt) -> int64_t { return idx[off + (kt < nk ? kt : nk - 1) * RG_BK + krow]; };
+  // Yraw != nullptr: the workgroups of the first tile column also form [Y 1]' X for their 128 columns — the RAW targets' products
+  // and the column sums, on the vector ALU under the MFMAs (O5[c][0..3] = Y' X, O5[c][4] = 1' X): with them the whitened targets'
+  // X' Yw = (X' Y - X' 1 mu') T needs no second sweep over the rows once the statistics are known (odx_rls_fold_whitened_f64)
+  const bool xty = Yraw != nullptr && j0 == 0;
   f32x2r ra[4], rb[2];
+  f32x4r ry = {0.f, 0.f, 0.f, 0.f};
   bool valid;
   auto load = [&](int64_t row) {
     valid = row >= 0;
@@ -195,7 +229,10 @@ __global__ __launch_bounds__(256, 3) void rls_gram_rows_kernel(const float* __re
     for (int q = 0; q < 4; ++q) ra[q] = *reinterpret_cast<const f32x2r*>(x + cae[q]);
 #pragma unroll
     for (int q = 0; q < 2; ++q) rb[q] = *reinterpret_cast<const f32x2r*>(x + cbe[q]);
+    if (xty && seg == 0) ry = *reinterpret_cast<const f32x4r*>(Yraw + (valid ? row : 0) * ldyr);
   };
+  double ysum[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  const int ycol = tid & 127, yhalf = tid >> 7;               // the targets' products: column ycol of the A side, two k-rows of every step
   int64_t row_next = row_of(1);
   load(row_of(0));
   const int r16 = lane & 15, kq = lane >> 4;
@@ -213,6 +250,10 @@ __global__ __launch_bounds__(256, 3) void rls_gram_rows_kernel(const float* __re
       const float m = valid && bok[q] ? 1.f : 0.f;
       *reinterpret_cast<f64x2*>(db + q * 32) = f64x2{(double)(m * rb[q][0]), (double)(m * rb[q][1])};
     }
+    if (xty && seg == 0) {                                     // (a padded row's A entries are zero: its targets only have to be finite)
+      *reinterpret_cast<f64x2*>(lds_y + krow * 4) = f64x2{(double)ry[0], (double)ry[1]};
+      *reinterpret_cast<f64x2*>(lds_y + krow * 4 + 2) = f64x2{(double)ry[2], (double)ry[3]};
+    }
     __syncthreads();
     load(row_next);
     row_next = row_of(kt + 2);
@@ -228,6 +269,33 @@ __global__ __launch_bounds__(256, 3) void rls_gram_rows_kernel(const float* __re
       for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+      if (xty) {
+        // two of this step's four k-rows per thread: ten vector FMAs issued while the matrix pipe works off the eight above
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int kr = ks * 4 + yhalf * 2 + r;
+          const double av = lds_a[kr * RG_LDA + ycol];
+          const f64x2 y01 = *reinterpret_cast<const f64x2*>(lds_y + kr * 4), y23 = *reinterpret_cast<const f64x2*>(lds_y + kr * 4 + 2);
+          ysum[0] = fma(av, y01[0], ysum[0]);
+          ysum[1] = fma(av, y01[1], ysum[1]);
+          ysum[2] = fma(av, y23[0], ysum[2]);
+          ysum[3] = fma(av, y23[1], ysum[3]);
+          ysum[4] += av;
+        }
+      }
+    }
+  }
+  if (xty) {
+    // the two halves of the k-rows: the upper one through LDS, one fixed order of additions
+    __syncthreads();
+    if (yhalf == 1) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) lds_a[j * 128 + ycol] = ysum[j];
+    }
+    __syncthreads();
+    if (yhalf == 0 && i0 + ycol < D) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) O5[((int64_t)c * 5 + j) * ldo + i0 + ycol] = ysum[j] + lds_a[j * 128 + ycol];
     }
   }
   // accumulator (tm, tn, reg): row 16 tm + (lane >> 4) + 4 reg, column 16 tn + (lane & 15) of the wave's 64 x 32 share
@@ -484,6 +552,39 @@ __global__ __launch_bounds__(256) void rls_fold_bias_kernel(const double* __rest
   G[(int64_t)c * g_stride + (int64_t)(D1 - 1) * ldg + j] += o[4 * ldo + j];
 }
 
+// The whitened targets' products from the raw ones (rls_gram_rows_kernel's O5 = [Y 1]' X per class, columns 0 .. D - 1): with
+// Yw = (Y - 1 mu') T,   X' Yw = (X' Y - (X' 1) mu') T,   1' Yw = 0,   and the Gram's bias row [X 1]' 1 = (X' 1, n).
+// stats (C, 9, 4) f64 = [mu; T; T_inv] per class (the block the trainer keeps anyway), cnt (C) f64 = rows per class.
+__global__ __launch_bounds__(256) void rls_fold_whitened_kernel(const double* __restrict__ O5, int64_t ldo, int D1,
+                                                                const double* __restrict__ stats, const double* __restrict__ cnt,
+                                                                double* __restrict__ XtY, int64_t ldxy, int64_t xy_stride,
+                                                                double* __restrict__ G, int64_t ldg, int64_t g_stride) {
+  const int c = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D1) return;
+  const double* st = stats + (int64_t)c * 36;
+  double* xy = XtY + (int64_t)c * xy_stride;
+  double* gb = G + (int64_t)c * g_stride + (int64_t)(D1 - 1) * ldg;
+  if (d == D1 - 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xy[j * ldxy + d] = 0.0;
+    gb[d] += cnt[c];
+    return;
+  }
+  const double* o = O5 + (int64_t)c * 5 * ldo;
+  const double ones = o[4 * ldo + d];
+  double v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = o[i * ldo + d] - st[i] * ones;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t = fma(v[i], st[4 + i * 4 + j], t);
+    xy[j * ldxy + d] = t;
+  }
+  gb[d] += ones;
+}
+
 // The Grams come straight from the f32 rows (rls_gram_rows_kernel) when the rows allow 16-byte column groups; ODX_RLS_GRAM=nt
 // keeps round 3's form (a transposed f64 copy of all rows + the generic NT GEMM) for A/B runs.
 static bool rls_rows_form(const float* X, int64_t ldx, int D) {
@@ -492,6 +593,49 @@ static bool rls_rows_form(const float* X, int64_t ldx, int D) {
 }
 
 extern "C" int odx_rls_rows_form(const float* X, int64_t ldx, int D) { return rls_rows_form(X, ldx, D) ? 1 : 0; }
+
+// The Grams of a class batch AND the raw targets' products [Y 1]' X in one sweep over the rows (rls_gram_rows_kernel, rows form
+// only): Yraw (n, >= 4) f32 holds the UN-whitened targets by row id, O5 (C, 5, ldo) f64 receives Y' X (rows 0 .. 3) and 1' X (row 4)
+// for columns 0 .. D - 1.  odx_rls_fold_whitened_f64 turns them into the whitened targets' X' Yw and the Gram's bias row once the
+// statistics are known — the sweep does not wait for them.
+extern "C" int odx_rls_gram_raw_batched_f64(const float* X, int64_t ldx, int D, const int64_t* idx_pad, int64_t npad,
+                                            const int64_t* seg_off, const int64_t* seg_len, int C, const float* Yraw, int64_t ldyr,
+                                            double* G, int64_t ldg, int64_t g_stride, double* O5, int64_t ldo, odx_stream_t stream) {
+  ODX_REQUIRE(C >= 1 && C <= ODX_MAX_ZBATCH, "odx_rls_gram_raw_batched_f64: 1..%d classes per call", ODX_MAX_ZBATCH);
+  ODX_REQUIRE(X && idx_pad && seg_off && seg_len && Yraw && G && O5 && D > 0 && npad > 0, "odx_rls_gram_raw_batched_f64: bad argument");
+  ODX_REQUIRE(rls_rows_form(X, ldx, D), "odx_rls_gram_raw_batched_f64: needs the rows form (odx_rls_rows_form)");
+  const int64_t D1 = D + 1;
+  ODX_REQUIRE(ldyr >= 4 && ldyr % 4 == 0 && aligned16(Yraw), "odx_rls_gram_raw_batched_f64: Yraw rows of 4 floats, 16-byte aligned");
+  ODX_REQUIRE(ldg >= D1 && g_stride >= D1 * ldg && ldo >= D, "odx_rls_gram_raw_batched_f64: output strides too small");
+  RlsSegs sg;
+  for (int c = 0; c < ODX_MAX_ZBATCH; ++c) sg.off[c] = sg.len[c] = 0;
+  for (int c = 0; c < C; ++c) {
+    ODX_REQUIRE(seg_off[c] % 16 == 0 && seg_len[c] >= 0 && round_up(seg_off[c] + seg_len[c], 16) <= npad,
+                "odx_rls_gram_raw_batched_f64: class %d: segment must start at a multiple of 16 and end, padded to one, inside the index array", c);
+    sg.off[c] = seg_off[c];
+    sg.len[c] = seg_len[c];
+  }
+  const int tiles = (int)(8 * ceil_div(ceil_div(D, RG_BM), 8) * ceil_div(D, RG_BN));
+  hipLaunchKernelGGL(rls_gram_rows_kernel, dim3((unsigned)tiles, 1, (unsigned)C), dim3(256), 0, as_stream(stream), X, ldx, D, idx_pad, sg, G, ldg,
+                     g_stride, Yraw, ldyr, O5, ldo);
+  ODX_CHECK_LAUNCH("rls_gram_rows (raw targets)");
+  return ODX_OK;
+}
+
+// XtY[c] (4 x (D + 1)) = the whitened targets' [X 1]' Yw and G[c]'s bias row += [X 1]' 1, from odx_rls_gram_raw_batched_f64's O5,
+// the classes' statistics stats (C, 9, 4) f64 = [mu; T; T_inv] and row counts cnt (C) f64.
+extern "C" int odx_rls_fold_whitened_f64(const double* O5, int64_t ldo, int D, int C, const double* stats, const double* cnt,
+                                         double* G, int64_t ldg, int64_t g_stride, double* XtY, int64_t ldxy, int64_t xy_stride,
+                                         odx_stream_t stream) {
+  ODX_REQUIRE(C >= 1 && C <= ODX_MAX_ZBATCH, "odx_rls_fold_whitened_f64: 1..%d classes per call", ODX_MAX_ZBATCH);
+  ODX_REQUIRE(O5 && stats && cnt && G && XtY && D > 0, "odx_rls_fold_whitened_f64: bad argument");
+  const int64_t D1 = D + 1;
+  ODX_REQUIRE(ldo >= D && ldg >= D1 && g_stride >= D1 * ldg && ldxy >= D1 && xy_stride >= 4 * ldxy, "odx_rls_fold_whitened_f64: strides too small");
+  hipLaunchKernelGGL(rls_fold_whitened_kernel, dim3((unsigned)ceil_div(D1, 256), (unsigned)C), dim3(256), 0, as_stream(stream), O5, ldo, (int)D1,
+                     stats, cnt, XtY, ldxy, xy_stride, G, ldg, g_stride);
+  ODX_CHECK_LAUNCH("rls_fold_whitened");
+  return ODX_OK;
+}
 
 extern "C" int odx_rls_xty_batched_f64(const float* X, int64_t ldx, int D, const int64_t* idx_pad, int64_t npad,
                                        const int64_t* seg_off, const int64_t* seg_len, int C, const double* Yt, int64_t ldy,
@@ -567,7 +711,8 @@ extern "C" int odx_rls_gram_batched_f64(const float* X, int64_t ldx, int D, cons
         sg.len[c] = seg_len[c];
       }
       const int tiles = (int)(8 * ceil_div(ceil_div(D, RG_BM), 8) * ceil_div(D, RG_BN));
-      hipLaunchKernelGGL(rls_gram_rows_kernel, dim3((unsigned)tiles, 1, (unsigned)C), dim3(256), 0, s, X, ldx, D, idx_pad, sg, G, ldg, g_stride);
+      hipLaunchKernelGGL(rls_gram_rows_kernel, dim3((unsigned)tiles, 1, (unsigned)C), dim3(256), 0, s, X, ldx, D, idx_pad, sg, G, ldg, g_stride,
+                         (const float*)nullptr, (int64_t)0, (double*)nullptr, (int64_t)0);
       ODX_CHECK_LAUNCH("rls_gram_rows");
       if (gram_only) return ODX_OK;
       const int64_t ldo = round_up(D1, 2);

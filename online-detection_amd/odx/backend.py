@@ -691,7 +691,21 @@ class HipBackend:
                                                     _p(ws), ws.numel(), self._stream()), "odx_rls_gram_batched_f64")
         return G
 
-    def rls_train_batched(self, F, idx_pad, seg_off, seg_len, Yt, lam, allreduce=None, begun=None, after=None):
+    def rls_gram_raw_begin(self, F, idx_pad, seg_off, seg_len, G, Yraw):
+        """rls_gram_begin that also forms the RAW targets' products in the same sweep (odx_rls_gram_raw_batched_f64): Yraw (n, 4)
+        f32 by row id -> O5 (C, 5, ld) f64 = [Y 1]' X, which rls_train_batched(raw=(O5, stats, cnt)) turns into the whitened
+        targets' X' Yw once the statistics exist — no second sweep over the rows behind the Grams."""
+        C, D = len(seg_len), F.D
+        D1 = D + 1
+        ld = (D1 + 1) // 2 * 2
+        O5 = torch.empty((C, 5, ld), dtype=torch.float64, device=self.device)
+        so = (ctypes.c_int64 * C)(*[int(v) for v in seg_off])
+        sl = (ctypes.c_int64 * C)(*[int(v) for v in seg_len])
+        hip.check(self.lib.odx_rls_gram_raw_batched_f64(_p(F.X), F.ld, D, _p(idx_pad), int(idx_pad.numel()), so, sl, C, _p(Yraw), Yraw.stride(0),
+                                                        _p(G), ld, D1 * ld, _p(O5), ld, self._stream()), "odx_rls_gram_raw_batched_f64")
+        return O5
+
+    def rls_train_batched(self, F, idx_pad, seg_off, seg_len, Yt, lam, allreduce=None, begun=None, after=None, raw=None):
         """The RLS solves of len(seg_len) <= 32 classes with one launch chain (odx_rls_gram_batched_f64 +
         odx_rls_solve_batched_f64).  idx_pad: device int64 row ids class after class, every segment starting at a multiple
         of 16 and padded with -1; seg_off / seg_len: python lists; Yt (4, ldy) f64 whitened targets in the same padded
@@ -709,7 +723,14 @@ class HipBackend:
         info = torch.zeros(C, dtype=torch.int32, device=self.device)
         so = (ctypes.c_int64 * C)(*[int(v) for v in seg_off])
         sl = (ctypes.c_int64 * C)(*[int(v) for v in seg_len])
-        if npad:
+        if raw is not None:
+            # (the Grams and [Y 1]' X are on stream `after`: the fold needs both, and writes the Gram's bias row)
+            O5, stats, cnt = raw
+            torch.cuda.current_stream(self.device).wait_stream(after)
+            hip.check(self.lib.odx_rls_fold_whitened_f64(_p(O5), O5.stride(1), D, C, _p(stats), _p(cnt), _p(G), ld, D1 * ld, _p(XtY), ld, 4 * ld,
+                                                         self._stream()), "odx_rls_fold_whitened_f64")
+            after = None
+        elif npad:
             ws = self._workspace("rls_gram_batched", self.lib.odx_rls_gram_batched_workspace_bytes(npad, D))
             fn, name = ((self.lib.odx_rls_xty_batched_f64, "odx_rls_xty_batched_f64") if begun is not None
                         else (self.lib.odx_rls_gram_batched_f64, "odx_rls_gram_batched_f64"))

@@ -139,16 +139,29 @@ class RegionRefinerTrainer:
                 # The Grams need the rows only: queued NOW, on a side stream (odx/streams.py: a hardware queue of its own), they
                 # run — 7 of the call's 12 ms at config 3 — while this stream derives the targets (statistics, the host's
                 # eigen-decomposition with its synchronisation, whitening) and forms Yt [X 1] beside them.
-                begun = side = None
+                # With f32 targets the same sweep forms the RAW targets' products [Y 1]' X too (on the vector ALU under the Gram's
+                # matrix instructions): the whitening is linear, so X' Yw follows from them and the statistics in a launch of a few
+                # microseconds (rls_fold_whitened) — the 0.6-ms sweep for Yt [X 1] that used to land BEHIND the Grams (this
+                # stream's small kernels starve beside them) is gone.  ODX_RLS_RAW_TARGETS=0 keeps the two-sweep form.
+                begun = side = raw5 = None
                 if hasattr(be, "rls_gram_begin") and xdev.type == "cuda" and be.rls_rows_form(F):
                     from . import streams as _streams
                     own = _streams.distinct(1)
                     if own:
                         side, cur = own[0], torch.cuda.current_stream()
                         begun = be.rls_gram_zeros(F, G_)          # (zeroed on THIS stream: Yt [X 1] adds to its bias row later)
+                        use_raw = (hasattr(be, "rls_gram_raw_begin") and Yall.dtype == torch.float32 and Yall.dim() == 2
+                                   and Yall.shape[1] == 4 and os.environ.get("ODX_RLS_RAW_TARGETS", "1") != "0")
+                        Yraw = Yall.contiguous() if use_raw else None
+                        use_raw = use_raw and Yraw.data_ptr() % 16 == 0
                         side.wait_stream(cur)
                         with torch.cuda.stream(side):
-                            be.rls_gram_begin(F, idx_pad, seg_off, seg_len, begun)
+                            if use_raw:
+                                raw5 = be.rls_gram_raw_begin(F, idx_pad, seg_off, seg_len, begun, Yraw)
+                                raw5.record_stream(cur)
+                                Yraw.record_stream(side)
+                            else:
+                                be.rls_gram_begin(F, idx_pad, seg_off, seg_len, begun)
                         begun.record_stream(side)
                         idx_pad.record_stream(side)
                 Ypad = torch.zeros((G_, nmax, 4), dtype=torch.float64, device=xdev)
@@ -181,7 +194,8 @@ class RegionRefinerTrainer:
             Tis = Wv @ torch.diag_embed(root) @ Wv.transpose(1, 2)
             if not sharded:
                 Yw_all = torch.bmm(Yc_all, Ts)[gid, pos]                                   # (rows of the group, 4), class-sorted
-                Yt[:, dest] = Yw_all.t()
+                if raw5 is None:
+                    Yt[:, dest] = Yw_all.t()
                 a = 0
                 for k, c in enumerate(group):
                     rows_of[c] = run[a:a + n_loc[c]]
@@ -194,15 +208,21 @@ class RegionRefinerTrainer:
                     whit[c], Yw_of[c] = (mus[k], Ts[k], Tis[k]), Yw
                     idx_pad[off:off + n_loc[c]] = rows_of[c]
                     Yt[:, off:off + n_loc[c]] = Yw.t()
-            if not sharded and begun is not None:
+            stats_blk = None
+            if not sharded and raw5 is not None:
+                stats_blk = torch.cat((mu_all.view(G_, 1, 4), Ts, Tis), dim=1).contiguous()
+                W, info = be.rls_train_batched(F, idx_pad, seg_off, seg_len, None, self.lambd, begun=begun, allreduce=None, after=side,
+                                               raw=(raw5, stats_blk, lens_d.type(torch.float64)))
+            elif not sharded and begun is not None:
                 # Yt [X 1] (an HBM sweep) beside the Grams' last tiles, then the solves behind both
                 W, info = be.rls_train_batched(F, idx_pad, seg_off, seg_len, Yt, self.lambd, begun=begun,
                                                allreduce=None, after=side)
             else:
                 W, info = be.rls_train_batched(F, idx_pad, seg_off, seg_len, Yt, self.lambd,
                                                allreduce=self.shard.allreduce if self.shard is not None else None)
-            stat_blocks.append((group, torch.cat((torch.stack([whit[c][0] for c in group]).view(len(group), 1, 4) if sharded
-                                                  else mu_all.view(len(group), 1, 4), Ts, Tis), dim=1)))
+            stat_blocks.append((group, stats_blk if stats_blk is not None else
+                                torch.cat((torch.stack([whit[c][0] for c in group]).view(len(group), 1, 4) if sharded
+                                           else mu_all.view(len(group), 1, 4), Ts, Tis), dim=1)))
             bad = info.tolist()
             for k, c in enumerate(group):
                 if bad[k] != 0:

@@ -168,6 +168,45 @@ def test_rls_grams_from_rows_equal_the_transposed_copy_form(hip_backend, monkeyp
                 assert float((wa - wb).abs().max()) <= 1e-6 * max(1.0, float(wb.abs().max())), (other, c, k)
 
 
+def test_rls_raw_target_products_equal_the_second_sweep(hip_backend, monkeypatch):
+    """The whitened targets' X' Yw from the RAW targets' products formed inside the Gram sweep, (X' Y - X' 1 mu') T
+    (odx_rls_gram_raw_batched_f64 + odx_rls_fold_whitened_f64: the default with f32 targets), against the second sweep over the
+    rows with the whitened targets (ODX_RLS_RAW_TARGETS=0): the same f64 sums in another order.  Targets with means far above
+    their spread (the subtraction cancels four digits), ragged class sizes, a ragged last tile; f64 targets keep the two-sweep
+    form (nothing may be rounded to f32 on the way)."""
+    from odx.rls import RegionRefinerTrainer
+    rng = np.random.default_rng(12)
+    D, C = 328, 6
+    sizes = [1, 15, 16, 17, 700, 1300]
+    X = torch.from_numpy(rng.standard_normal((sum(sizes), D)).astype(np.float32) * 0.5 + 0.1).cuda()
+    Y = torch.from_numpy((rng.standard_normal((sum(sizes), 4)) * 0.05 + np.array([40.0, -25.0, 3.0, 0.0])).astype(np.float32)).cuda()
+    Cl = torch.from_numpy(np.repeat(np.arange(1, C + 1), sizes).astype(np.float32)).cuda()
+    perm = torch.from_numpy(rng.permutation(sum(sizes))).cuda()
+    cfg = {"CHOSEN_CLASSES": {i: "c%d" % i for i in range(C + 1)}, "REGION_REFINER": {"opts": {"lambda": 10.0}}}
+    calls = []
+    real = hip_backend.rls_gram_raw_begin
+
+    def spy(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+    monkeypatch.setattr(hip_backend, "rls_gram_raw_begin", spy)
+    out = {}
+    for mode, ydt in (("raw", torch.float32), ("sweep", torch.float32), ("f64", torch.float64)):
+        monkeypatch.setenv("ODX_RLS_RAW_TARGETS", "0" if mode == "sweep" else "1")
+        tr = RegionRefinerTrainer(cfg, 10.0, False)
+        tr.COXY = {"C": Cl[perm].view(-1, 1), "O": None, "X": X[perm], "Y": Y[perm].to(ydt)}
+        n0 = len(calls)
+        out[mode] = quiet(tr._train_batched, hip_backend)
+        assert (len(calls) - n0 == 1) == (mode == "raw"), mode
+    for c in range(C):
+        for k in range(4):
+            wb = out["sweep"][c]["Beta"][str(k)]["weights"]
+            for other in ("raw", "f64"):
+                wa = out[other][c]["Beta"][str(k)]["weights"]
+                assert float((wa - wb).abs().max()) <= 1e-6 * max(1.0, float(wb.abs().max())), (other, c, k)
+                assert torch.allclose(out[other][c]["Beta"][str(k)]["losses"], out["sweep"][c]["Beta"][str(k)]["losses"], atol=1e-6), (other, c, k)
+
+
 class OracleFalkonClassifier:
     """Test-side classifier plug-in: the reference wrapper's index rule + the f64 oracle fit."""
 
