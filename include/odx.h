@@ -396,6 +396,11 @@ int odx_rls_gram_batched_f64(const float* X, int64_t ldx, int D, const int64_t* 
  * id; row 4: the column sums; columns 0 .. D - 1) in ONE sweep over the rows — the targets' products ride on the vector ALU under
  * the Gram's matrix instructions; odx_rls_fold_whitened_f64 then writes XtY (4 x (D + 1) per class) and adds the Gram's bias row
  * from O5, stats (C, 9, 4) f64 = [mu; T; T_inv] per class and cnt (C) f64 = rows per class.  Rows form only. */
+/* The padded row-id array the batched calls take, and its inverse maps, in one launch: run (total) = the row ids class after class
+ * (seg_len[k] of class k); idx_pad (npad) gets class k's ids from seg_off[k] on and -1 elsewhere; for the i-th id of run gid[i] =
+ * its class slot, pos[i] = its rank inside the class, dest[i] = its position in idx_pad; lens (C) = seg_len (all int64, device). */
+int odx_rls_pad_index(const int64_t* run, int64_t total, const int64_t* seg_off, const int64_t* seg_len, int C, int64_t npad,
+                      int64_t* idx_pad, int64_t* gid, int64_t* pos, int64_t* dest, int64_t* lens, odx_stream_t stream);
 int odx_rls_gram_raw_batched_f64(const float* X, int64_t ldx, int D, const int64_t* idx_pad, int64_t npad,
                                  const int64_t* seg_off, const int64_t* seg_len, int C, const float* Yraw, int64_t ldyr,
                                  double* G, int64_t ldg, int64_t g_stride, double* O5, int64_t ldo, odx_stream_t stream);

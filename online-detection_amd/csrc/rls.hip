@@ -594,6 +594,58 @@ static bool rls_rows_form(const float* X, int64_t ldx, int D) {
 
 extern "C" int odx_rls_rows_form(const float* X, int64_t ldx, int D) { return rls_rows_form(X, ldx, D) ? 1 : 0; }
 
+// The padded row-id array of a class batch and its inverse maps, in one launch: run (total) holds the row ids class after class
+// (class k: len[k] of them), the padded array gives class k the positions seg_off[k] .. (a multiple of 16, -1 behind its rows).
+//   idx_pad[p] = row id or -1;   for the i-th id of run: gid[i] = its class slot, pos[i] = its rank in the class, dest[i] = p;
+//   lens[k] = len[k].
+// (the trainer built these with a dozen tensor statements and three small host-to-device copies: 0.3 ms of launch latency in
+// front of the Grams)
+__global__ __launch_bounds__(256) void rls_pad_index_kernel(const int64_t* __restrict__ run, RlsSegs sg, RlsSegs st, int C, int64_t npad,
+                                                            int64_t* __restrict__ idx_pad, int64_t* __restrict__ gid,
+                                                            int64_t* __restrict__ pos, int64_t* __restrict__ dest,
+                                                            int64_t* __restrict__ lens) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p < C) lens[p] = sg.len[p];                              // (the class sizes as a device array: no copy of the host's list)
+  if (p >= npad) return;
+  int k = 0;
+#pragma unroll 1
+  for (int q = 1; q < C; ++q)
+    if (p >= sg.off[q]) k = q;
+  const int64_t r = p - sg.off[k];
+  if (r < sg.len[k]) {
+    const int64_t i = st.off[k] + r;
+    idx_pad[p] = run[i];
+    gid[i] = k;
+    pos[i] = r;
+    dest[i] = p;
+  } else {
+    idx_pad[p] = -1;
+  }
+}
+
+extern "C" int odx_rls_pad_index(const int64_t* run, int64_t total, const int64_t* seg_off, const int64_t* seg_len, int C, int64_t npad,
+                                 int64_t* idx_pad, int64_t* gid, int64_t* pos, int64_t* dest, int64_t* lens, odx_stream_t stream) {
+  ODX_REQUIRE(C >= 1 && C <= ODX_MAX_ZBATCH, "odx_rls_pad_index: 1..%d classes per call", ODX_MAX_ZBATCH);
+  if (npad <= 0) return ODX_OK;
+  ODX_REQUIRE(run && seg_off && seg_len && idx_pad && gid && pos && dest && lens, "odx_rls_pad_index: bad argument");
+  RlsSegs sg, st;
+  for (int c = 0; c < ODX_MAX_ZBATCH; ++c) sg.off[c] = sg.len[c] = st.off[c] = st.len[c] = 0;
+  int64_t at = 0;
+  for (int c = 0; c < C; ++c) {
+    ODX_REQUIRE(seg_len[c] >= 0 && seg_off[c] >= (c ? seg_off[c - 1] + seg_len[c - 1] : 0) && seg_off[c] + seg_len[c] <= npad,
+                "odx_rls_pad_index: class %d: segments must ascend without overlap inside the padded array", c);
+    sg.off[c] = seg_off[c];
+    sg.len[c] = seg_len[c];
+    st.off[c] = at;
+    at += seg_len[c];
+  }
+  ODX_REQUIRE(at == total, "odx_rls_pad_index: the segment lengths must add up to the number of row ids");
+  hipLaunchKernelGGL(rls_pad_index_kernel, dim3((unsigned)ceil_div(npad > C ? npad : C, 256)), dim3(256), 0, as_stream(stream), run, sg, st,
+                     C, npad, idx_pad, gid, pos, dest, lens);
+  ODX_CHECK_LAUNCH("rls_pad_index");
+  return ODX_OK;
+}
+
 // The Grams of a class batch AND the raw targets' products [Y 1]' X in one sweep over the rows (rls_gram_rows_kernel, rows form
 // only): Yraw (n, >= 4) f32 holds the UN-whitened targets by row id, O5 (C, 5, ldo) f64 receives Y' X (rows 0 .. 3) and 1' X (row 4)
 // for columns 0 .. D - 1.  odx_rls_fold_whitened_f64 turns them into the whitened targets' X' Yw and the Gram's bias row once the

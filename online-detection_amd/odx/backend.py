@@ -691,6 +691,21 @@ class HipBackend:
                                                     _p(ws), ws.numel(), self._stream()), "odx_rls_gram_batched_f64")
         return G
 
+    def rls_pad_index(self, run, seg_off, seg_len, npad):
+        """(idx_pad (npad), gid, pos, dest (total each), lens (C)) for the row ids `run` of a class batch, one launch
+        (odx_rls_pad_index)."""
+        C, total = len(seg_len), int(run.numel())
+        run = run.contiguous()
+        idx_pad = torch.empty(npad, dtype=torch.int64, device=self.device)
+        maps = torch.empty(3 * max(total, 1) + C, dtype=torch.int64, device=self.device)
+        m = maps[:3 * max(total, 1)].view(3, -1)
+        lens = maps[3 * max(total, 1):]
+        so = (ctypes.c_int64 * C)(*[int(v) for v in seg_off])
+        sl = (ctypes.c_int64 * C)(*[int(v) for v in seg_len])
+        hip.check(self.lib.odx_rls_pad_index(_p(run), total, so, sl, C, int(npad), _p(idx_pad), _p(m[0]), _p(m[1]), _p(m[2]), _p(lens),
+                                             self._stream()), "odx_rls_pad_index")
+        return idx_pad, m[0, :total], m[1, :total], m[2, :total], lens
+
     def rls_gram_raw_begin(self, F, idx_pad, seg_off, seg_len, G, Yraw):
         """rls_gram_begin that also forms the RAW targets' products in the same sweep (odx_rls_gram_raw_batched_f64): Yraw (n, 4)
         f32 by row id -> O5 (C, 5, ld) f64 = [Y 1]' X, which rls_train_batched(raw=(O5, stats, cnt)) turns into the whitened

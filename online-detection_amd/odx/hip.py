@@ -105,6 +105,7 @@ SIGNATURES = {
     "odx_rls_solve_f64": (_i32, [_vp, _i64, _i32, _f64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
     "odx_rls_gram_batched_workspace_bytes": (_i64, [_i64, _i32]),
     "odx_rls_gram_batched_f64": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
+    "odx_rls_pad_index": (_i32, [_vp, _i64, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "odx_rls_gram_raw_batched_f64": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "odx_rls_fold_whitened_f64": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp]),
     "odx_rls_xty_batched_f64": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),

@@ -91,14 +91,22 @@ class RegionRefinerTrainer:
         Yall = self.COXY['Y'].to(xdev)
         D, D1 = F.D, F.D + 1
         start_time = time.time()
+        # (the first class batch's Gram block is cleared NOW: the 0.25-GB fill runs while the host is still busy with the sort and
+        # the one read of the class sizes, instead of between the index kernel and the Grams)
+        sharded_ = self.shard is not None and self.shard.enabled
+        pre_zero = (be.rls_gram_zeros(F, min(len(ids), be.MAX_CLASS_BATCH)) if len(ids) and not sharded_ and hasattr(be, "rls_gram_begin")
+                    and xdev.type == "cuda" and be.rls_rows_form(F) else None)
         Cl = Call.to(torch.int64)
-        order = torch.argsort(Cl, stable=True)
-        counts_all = torch.bincount(Cl[Cl >= 0], minlength=num_clss)[:num_clss].tolist()     # the one host read of the sizes (negative labels belong to no class)
-        first = {}
-        acc = int((Cl < 0).sum().item()) if Cl.numel() and bool((Cl < 0).any()) else 0
-        for c in range(num_clss):
-            first[c] = acc
-            acc += counts_all[c]
+        # rows sorted by class (stable), and the classes' runs in that order from the sorted labels: bounds[c] = the number of
+        # labels below c (negative labels belong to no class, labels past the last class neither) — ONE host read; the counting
+        # statements this replaces (a boolean selection, bincount, any / sum) each ended in a read of their own: 0.4 ms
+        # (the sort's keys in the narrowest type that holds -1 .. num_clss: the radix sort makes one pass per key byte — eight for
+        # int64 labels, 0.25 ms)
+        narrow = torch.int8 if num_clss < 127 else (torch.int16 if num_clss < 32767 else torch.int64)
+        sorted_labels, order = torch.sort(Cl.clamp(-1, num_clss).to(narrow), stable=True)
+        bounds = torch.searchsorted(sorted_labels, torch.arange(num_clss + 1, device=xdev, dtype=narrow)).tolist()
+        first = {c: bounds[c] for c in range(num_clss)}
+        counts_all = [bounds[c + 1] - bounds[c] for c in range(num_clss)]
         n_loc = {c: counts_all[c] for c in ids}
         n_tot = {c: (n_loc[c] if self.shard is None else self.shard.total(n_loc[c])) for c in ids}
         models = {}
@@ -114,9 +122,10 @@ class RegionRefinerTrainer:
                 seg_len.append(n_loc[c])
                 at += (n_loc[c] + 15) // 16 * 16
             npad = at
-            idx_pad = torch.full((max(npad, 1),), -1, dtype=torch.int64, device=xdev)[:npad]
-            Yt = torch.zeros((4, max(npad, 16)), dtype=torch.float64, device=xdev)
             sharded = self.shard is not None and self.shard.enabled
+            one_launch = not sharded and hasattr(be, "rls_pad_index") and xdev.type == "cuda"
+            idx_pad = None if one_launch else torch.full((max(npad, 1),), -1, dtype=torch.int64, device=xdev)[:npad]
+            Yt = None
             if not sharded:
                 # target statistics, whitening and the padded (index, target) arrays of the whole group in ~20 launches:
                 # the rows of the group's classes are one contiguous run of `order`; they are laid out as a zero-padded
@@ -130,12 +139,15 @@ class RegionRefinerTrainer:
                 run = order[lo:lo + sum(seg_len)] if all(first[group[k + 1]] == first[group[k]] + seg_len[k] for k in range(G_ - 1)) \
                     else torch.cat([order[first[c]:first[c] + n_loc[c]] for c in group])
                 total = int(sum(seg_len))
-                lens_d = lens.to(xdev)
-                gid = torch.repeat_interleave(torch.arange(G_, device=xdev), lens_d, output_size=total)      # class slot of every row
-                starts = torch.tensor(np.concatenate(([0], np.cumsum(seg_len)[:-1])), dtype=torch.int64).to(xdev)
-                pos = torch.arange(total, device=xdev) - starts[gid]                                         # row's rank inside its class
-                dest = torch.tensor(seg_off, dtype=torch.int64).to(xdev)[gid] + pos
-                idx_pad[dest] = run
+                if one_launch:
+                    idx_pad, gid, pos, dest, lens_d = be.rls_pad_index(run, seg_off, seg_len, npad)
+                else:
+                    lens_d = lens.to(xdev)
+                    gid = torch.repeat_interleave(torch.arange(G_, device=xdev), lens_d, output_size=total)      # class slot of every row
+                    starts = torch.tensor(np.concatenate(([0], np.cumsum(seg_len)[:-1])), dtype=torch.int64).to(xdev)
+                    pos = torch.arange(total, device=xdev) - starts[gid]                                         # row's rank inside its class
+                    dest = torch.tensor(seg_off, dtype=torch.int64).to(xdev)[gid] + pos
+                    idx_pad[dest] = run
                 # The Grams need the rows only: queued NOW, on a side stream (odx/streams.py: a hardware queue of its own), they
                 # run — 7 of the call's 12 ms at config 3 — while this stream derives the targets (statistics, the host's
                 # eigen-decomposition with its synchronisation, whitening) and forms Yt [X 1] beside them.
@@ -149,7 +161,8 @@ class RegionRefinerTrainer:
                     own = _streams.distinct(1)
                     if own:
                         side, cur = own[0], torch.cuda.current_stream()
-                        begun = be.rls_gram_zeros(F, G_)          # (zeroed on THIS stream: Yt [X 1] adds to its bias row later)
+                        # (zeroed on THIS stream: the fold / Yt [X 1] adds to its bias row later)
+                        begun = pre_zero[:G_] if pre_zero is not None and g0 == 0 else be.rls_gram_zeros(F, G_)
                         use_raw = (hasattr(be, "rls_gram_raw_begin") and Yall.dtype == torch.float32 and Yall.dim() == 2
                                    and Yall.shape[1] == 4 and os.environ.get("ODX_RLS_RAW_TARGETS", "1") != "0")
                         Yraw = Yall.contiguous() if use_raw else None
@@ -195,6 +208,7 @@ class RegionRefinerTrainer:
             if not sharded:
                 Yw_all = torch.bmm(Yc_all, Ts)[gid, pos]                                   # (rows of the group, 4), class-sorted
                 if raw5 is None:
+                    Yt = torch.zeros((4, max(npad, 16)), dtype=torch.float64, device=xdev)
                     Yt[:, dest] = Yw_all.t()
                 a = 0
                 for k, c in enumerate(group):
@@ -202,6 +216,7 @@ class RegionRefinerTrainer:
                     whit[c], Yw_of[c] = (mu_all[k], Ts[k], Tis[k]), Yw_all[a:a + n_loc[c]]
                     a += n_loc[c]
             else:
+                Yt = torch.zeros((4, max(npad, 16)), dtype=torch.float64, device=xdev)
                 for k, (c, off) in enumerate(zip(group, seg_off)):
                     rows_of[c] = order[first[c]:first[c] + n_loc[c]]
                     Yw = torch.matmul(Ycs[k], Ts[k])
@@ -269,10 +284,13 @@ class RegionRefinerTrainer:
             # the printed per-class means from ONE padded (class, row, 4) block and one reduction, instead of a reduction per
             # class (a running sum over all rows is no substitute: torch's scan of 3e5 x 4 doubles takes 0.7 ms here)
             lens_h = [n_loc[i] for i in live]
-            lens = torch.tensor(lens_h, dtype=torch.int64, device=losses_all.device)
-            slot = torch.repeat_interleave(torch.arange(len(live), device=lens.device), lens, output_size=at)
-            first_row = torch.tensor(np.concatenate(([0], np.cumsum(lens_h)[:-1])), dtype=torch.int64).to(lens.device)
-            rank = torch.arange(at, device=lens.device) - first_row[slot]
+            if len(solved) == 1 and not sharded_ and gid.numel() == at:
+                lens, slot, rank = lens_d, gid, pos           # (one class batch: its index maps are these)
+            else:
+                lens = torch.tensor(lens_h, dtype=torch.int64, device=losses_all.device)
+                slot = torch.repeat_interleave(torch.arange(len(live), device=lens.device), lens, output_size=at)
+                first_row = torch.tensor(np.concatenate(([0], np.cumsum(lens_h)[:-1])), dtype=torch.int64).to(lens.device)
+                rank = torch.arange(at, device=lens.device) - first_row[slot]
             padded = torch.zeros((len(live), max(max(lens_h), 1), 4), dtype=torch.float32, device=lens.device)
             padded[slot, rank] = losses_all
             means = (padded.sum(1, dtype=torch.float64) / lens.view(-1, 1)).type(torch.float32)     # 0 / 0 = nan: no local rows
