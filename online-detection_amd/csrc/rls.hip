@@ -352,54 +352,82 @@ __global__ __launch_bounds__(256) void rls_xty_reduce_kernel(const double* __res
   O5[((int64_t)c * 5 + j) * ldo + d] = s;
 }
 
-// P[i][k] for the rows of ALL classes with one launch: row i belongs to the class whose [start, start + len) holds it.
+// P[i][k] for the rows of ALL classes with one launch: row i belongs to the class whose [start, start + len) holds it.  A wave
+// takes RP_R consecutive rows of ONE class: the class's four weight rows are read once per column chunk for all of them (a row
+// of its own per wave read 32 KB of weights from the caches for every 4 KB row from memory — the kernel ran at 2.2 TB/s).
+// sg.off[c] = first row of class c, sg.len[c] = first row GROUP of class c.  Per row the sums run in the order of the one-row
+// kernel above (lane's chunks ascending, then the butterfly): the same bits.
+constexpr int RP_R = 4;
+
 __global__ __launch_bounds__(256) void rls_predict_rows_batched_kernel(const float* __restrict__ X, int64_t ldx, int D,
                                                                        const int64_t* __restrict__ idx, RlsSegs sg, int C,
                                                                        const double* __restrict__ W, int64_t ldw,
                                                                        int64_t w_stride, double* __restrict__ P, int64_t ldp,
-                                                                       int64_t total) {
+                                                                       int64_t total, int64_t groups) {
   const int lane = threadIdx.x & 63;
-  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= total) return;
+  const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= groups) return;
   int c = 0;
 #pragma unroll 1
   for (int k = 1; k < C; ++k)
-    if (i >= sg.off[k]) c = k;
+    if (g >= sg.len[k]) c = k;
+  const int64_t r0 = sg.off[c] + (g - sg.len[c]) * RP_R;
+  const int64_t rend = c + 1 < C ? sg.off[c + 1] : total;
+  const int nr = (int)(rend - r0 < RP_R ? rend - r0 : RP_R);
   const double* Wc = W + (int64_t)c * w_stride;
-  const float* x = X + idx[i] * ldx;
-  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  const float* x[RP_R];
+#pragma unroll
+  for (int u = 0; u < RP_R; ++u) x[u] = X + idx[r0 + (u < nr ? u : nr - 1)] * ldx;       // (a short group repeats its last row)
+  double s[RP_R][4];
+#pragma unroll
+  for (int u = 0; u < RP_R; ++u)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[u][k] = 0.0;
   const int nvec = D / 4;                                     // ldx % 4 == 0 and X 16-byte aligned: whole float4s
-  for (int c0 = lane; c0 < nvec; c0 += 128) {                 // two 16-byte loads of the row in flight per lane
-    f32x4r v[2];
+#pragma unroll 2
+  for (int cc = lane; cc < nvec; cc += 64) {
+    f32x4r v[RP_R];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int cc = c0 + 64 * u;
-      v[u] = cc < nvec ? *reinterpret_cast<const f32x4r*>(x + cc * 4) : f32x4r{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int u = 0; u < RP_R; ++u) v[u] = *reinterpret_cast<const f32x4r*>(x[u] + cc * 4);
+    double w[4][4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int cc = c0 + 64 * u;
-      if (cc < nvec) {
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const double xv = (double)v[u][q];
+      for (int q = 0; q < 4; ++q) w[k][q] = Wc[k * ldw + cc * 4 + q];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) s[k] = fma(xv, Wc[k * ldw + cc * 4 + q], s[k]);
-        }
+    for (int u = 0; u < RP_R; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double xv = (double)v[u][q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[u][k] = fma(xv, w[k][q], s[u][k]);
       }
-    }
   }
   for (int d = nvec * 4 + lane; d < D; d += 64) {
-    const double xv = (double)x[d];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) s[k] = fma(xv, Wc[k * ldw + d], s[k]);
+    for (int u = 0; u < RP_R; ++u) {
+      const double xv = (double)x[u][d];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s[u][k] = fma(xv, Wc[k * ldw + d], s[u][k]);
+    }
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int u = 0; u < RP_R; ++u)
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off);
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s[u][k] += __shfl_xor(s[u][k], off);
+    }
+  if (lane < 4 * RP_R) {
+    const int u = lane >> 2, k = lane & 3;
+    double v = 0.0;
+#pragma unroll
+    for (int uu = 0; uu < RP_R; ++uu)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        if (uu == u && kk == k) v = s[uu][kk];
+    if (u < nr) P[(r0 + u) * ldp + k] = v + Wc[k * ldw + D];
   }
-  if (lane < 4) P[i * ldp + lane] = s[lane] + Wc[lane * ldw + D];
 }
 
 static int64_t rls_chunk(int64_t workspace_bytes, int D) {
@@ -515,8 +543,13 @@ extern "C" int odx_rls_predict_rows_batched_f64(const float* X, int64_t ldx, int
                 "odx_rls_predict_rows_batched_f64: class starts must be ascending from 0");
     sg.off[c] = seg_start[c];
   }
-  hipLaunchKernelGGL(rls_predict_rows_batched_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, as_stream(stream), X, ldx, D, idx,
-                     sg, C, W, ldw, w_stride, P, ldp, total);
+  int64_t groups = 0;
+  for (int c = 0; c < C; ++c) {
+    sg.len[c] = groups;                                       // (the class's first row group)
+    groups += ceil_div((c + 1 < C ? seg_start[c + 1] : total) - seg_start[c], (int64_t)RP_R);
+  }
+  hipLaunchKernelGGL(rls_predict_rows_batched_kernel, dim3((unsigned)ceil_div(groups, 4)), dim3(256), 0, as_stream(stream), X, ldx, D, idx,
+                     sg, C, W, ldw, w_stride, P, ldp, total, groups);
   ODX_CHECK_LAUNCH("odx_rls_predict_rows_batched_f64");
   return ODX_OK;
 }

@@ -238,12 +238,11 @@ class RegionRefinerTrainer:
             stat_blocks.append((group, stats_blk if stats_blk is not None else
                                 torch.cat((torch.stack([whit[c][0] for c in group]).view(len(group), 1, 4) if sharded
                                            else mu_all.view(len(group), 1, 4), Ts, Tis), dim=1)))
-            bad = info.tolist()
+            # (the factorisations' status words are read at the END, after the predictions and the loss statements have been queued: a read here stalls
+            # the host until the whole solve chain has run, and the predictions then start 0.2 ms of host work late)
             for k, c in enumerate(group):
-                if bad[k] != 0:
-                    raise RuntimeError('RLS Cholesky failed for class %s (pivot %d)' % (chosen_classes[c], bad[k] - 1))
                 Wall[c] = W[k]
-            solved.append((group, W))
+            solved.append((group, W, info))
         # the training losses of all classes: one prediction launch per class into ONE (rows, 4) array, the elementwise
         # part once over all of it (per class it was ~15 short launches: 5 ms of a 30-ms call); every class keeps its own
         # contiguous copies, as the class-by-class loop hands them out (a saved model must not drag the whole array along)
@@ -254,7 +253,7 @@ class RegionRefinerTrainer:
             at += n_loc[i]
         P_all = torch.empty((at, 4), dtype=torch.float64, device=xdev)
         if hasattr(be, "rls_predict_rows_batched"):
-            for group, W in solved:           # one launch per solved group of classes (its weights are one (C, 4, ld) block)
+            for group, W, _ in solved:        # one launch per solved group of classes (its weights are one (C, 4, ld) block)
                 rows = torch.cat([rows_of[c] for c in group]) if len(group) > 1 else rows_of[group[0]].contiguous()
                 a0 = span[group[0]][0]
                 be.rls_predict_rows_batched(F, rows, [span[c][0] - a0 for c in group], W, P_all[a0:span[group[-1]][1]])
@@ -294,6 +293,11 @@ class RegionRefinerTrainer:
             padded = torch.zeros((len(live), max(max(lens_h), 1), 4), dtype=torch.float32, device=lens.device)
             padded[slot, rank] = losses_all
             means = (padded.sum(1, dtype=torch.float64) / lens.view(-1, 1)).type(torch.float32)     # 0 / 0 = nan: no local rows
+        for group, _, info in solved:
+            bad = info.tolist()
+            for k, c in enumerate(group):
+                if bad[k] != 0:
+                    raise RuntimeError('RLS Cholesky failed for class %s (pivot %d)' % (chosen_classes[c], bad[k] - 1))
         mean_host = dict(zip(live, means.tolist())) if live else {}      # one host read for the printed lines
         out = np.empty((0))
         for i in ids:
