@@ -258,17 +258,27 @@ __global__ __launch_bounds__(256, 3) void rls_gram_rows_kernel(const float* __re
     load(row_next);
     row_next = row_of(kt + 2);
     __builtin_amdgcn_sched_barrier(0);                         // (the loads stay in front of the MFMAs they hide under)
+    // (the next step's operands are read from LDS BEFORE this step's eight matrix instructions are issued: written as read-then-
+    // multiply per step, every step began with an LDS round trip nothing else of the wave covered)
+    double a[2][4], b[2][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[0][t] = lds_a[kq * RG_LDA + wr * 64 + t * 16 + r16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) b[0][t] = lds_b[kq * RG_LDB + wc * 32 + t * 16 + r16];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      double a[4], b[2];
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks < 3) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) a[t] = lds_a[(ks * 4 + kq) * RG_LDA + wr * 64 + t * 16 + r16];
+        for (int t = 0; t < 4; ++t) a[nxt][t] = lds_a[((ks + 1) * 4 + kq) * RG_LDA + wr * 64 + t * 16 + r16];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) b[t] = lds_b[(ks * 4 + kq) * RG_LDB + wc * 32 + t * 16 + r16];
+        for (int t = 0; t < 2; ++t) b[nxt][t] = lds_b[((ks + 1) * 4 + kq) * RG_LDB + wc * 32 + t * 16 + r16];
+        __builtin_amdgcn_sched_barrier(0);                     // (reads first: the scheduler sinks them below the multiplies otherwise)
+      }
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][tm], b[cur][tn], acc[tm][tn], 0, 0, 0);
       if (xty) {
         // two of this step's four k-rows per thread: ten vector FMAs issued while the matrix pipe works off the eight above
 #pragma unroll
