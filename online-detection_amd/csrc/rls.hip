@@ -138,20 +138,14 @@ typedef float f32x2r __attribute__((ext_vector_type(2)));
 constexpr int RG_BM = 128, RG_BN = 64, RG_BK = 16;
 constexpr int RG_LDA = RG_BM + 16, RG_LDB = RG_BN + 16;      // doubles per LDS row
 
-__global__ __launch_bounds__(256, 3) void rls_gram_rows_kernel(const float* __restrict__ X, int64_t ldx, int D,
-                                                               const int64_t* __restrict__ idx, RlsSegs sg, double* __restrict__ G,
-                                                               int64_t ldg, int64_t g_stride, const float* __restrict__ Yraw,
-                                                               int64_t ldyr, double* __restrict__ O5, int64_t ldo) {
-  __shared__ __attribute__((aligned(16))) double lds_a[RG_BK * RG_LDA];
-  __shared__ __attribute__((aligned(16))) double lds_b[RG_BK * RG_LDB];
-  __shared__ __attribute__((aligned(16))) double lds_y[RG_BK * 4];
-  int c = blockIdx.z;
+// The tile (class c, tile row bi, tile column bj) of a workgroup of the Gram launches (grid: tiles x 1 x classes).
+__device__ __forceinline__ void rls_gram_tile_of(int D, bool heavy_first, int& c, int& bi, int& bj) {
+  c = blockIdx.z;
   const int tiles_n = (D + RG_BN - 1) / RG_BN;
   // gridDim.x = 8 x ceil(tile rows / 8) x tiles_n: workgroup x runs on XCD x & 7 (round-robin dispatch), and that XCD walks
   // the tile rows xcd, xcd + 8, ... left to right, so the tiles sharing an A panel (and the rows' B pieces next to each
   // other) share one L2; the class index rotates which rows an XCD gets (row r carries r + 1 tiles)
-  int bi, bj;
-  if (Yraw == nullptr) {
+  if (!heavy_first) {
     const int xcd = (blockIdx.x + c) & 7, local = blockIdx.x >> 3;
     bi = 8 * (local / tiles_n) + xcd;
     bj = local % tiles_n;
@@ -175,6 +169,17 @@ __global__ __launch_bounds__(256, 3) void rls_gram_rows_kernel(const float* __re
       bj = 1 + local % (tiles_n - 1);
     }
   }
+}
+
+__global__ __launch_bounds__(256, 3) void rls_gram_rows_kernel(const float* __restrict__ X, int64_t ldx, int D,
+                                                               const int64_t* __restrict__ idx, RlsSegs sg, double* __restrict__ G,
+                                                               int64_t ldg, int64_t g_stride, const float* __restrict__ Yraw,
+                                                               int64_t ldyr, double* __restrict__ O5, int64_t ldo) {
+  __shared__ __attribute__((aligned(16))) double lds_a[RG_BK * RG_LDA];
+  __shared__ __attribute__((aligned(16))) double lds_b[RG_BK * RG_LDB];
+  __shared__ __attribute__((aligned(16))) double lds_y[RG_BK * 4];
+  int c, bi, bj;
+  rls_gram_tile_of(D, Yraw != nullptr, c, bi, bj);
   const int i0 = bi * RG_BM, j0 = bj * RG_BN;
   if (i0 >= D || j0 > i0 + RG_BM - 1) return;                  // lower tiles only
   const int64_t off = sg.off[c], len = sg.len[c];
@@ -316,6 +321,182 @@ __global__ __launch_bounds__(256, 3) void rls_gram_rows_kernel(const float* __re
     for (int reg = 0; reg < 4; ++reg) {
       const int row = i0 + wr * 64 + tm * 16 + kq + 4 * reg;
       if (row >= D) continue;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int col = j0 + wc * 32 + tn * 16 + r16;
+        if (col < D) g[(int64_t)row * ldg + col] += acc[tm][tn][reg];
+      }
+    }
+}
+
+// The same Grams with a k-tile of 32 rows held in LDS as the rows' own FLOATS (converted to f64 on the way from LDS into the
+// matrix instructions' operands — six conversions per eight MFMAs, on the vector ALU beside them): the LDS footprint of the
+// 16-row f64 form, HALF the barriers per matrix instruction (two per 64 instead of two per 32: the waves of a workgroup sit on
+// four SIMDs whose other residents differ, and every barrier makes the fastest wait for the slowest), half the LDS bytes
+// written and read.  Same order of the sum over k per output, same outputs (the conversion is exact either way).
+constexpr int RG32_BK = 32;
+constexpr int RG32_LDA = RG_BM + 16, RG32_LDB = RG_BN + 16;   // floats per LDS row: 16 banks further per k-row (the four k-rows a
+                                                               // 64-lane ds_read_b32 touches fall on four different bank quarters)
+
+__global__ __launch_bounds__(256, 3) void rls_gram_rows32_kernel(const float* __restrict__ X, int64_t ldx, int D,
+                                                                 const int64_t* __restrict__ idx, RlsSegs sg, double* __restrict__ G,
+                                                                 int64_t ldg, int64_t g_stride, const float* __restrict__ Yraw,
+                                                                 int64_t ldyr, double* __restrict__ O5, int64_t ldo) {
+  __shared__ __attribute__((aligned(16))) float lds_a[RG32_BK * RG32_LDA];
+  __shared__ __attribute__((aligned(16))) float lds_b[RG32_BK * RG32_LDB];
+  __shared__ __attribute__((aligned(16))) float lds_y[RG32_BK * 4];
+  int c, bi, bj;
+  rls_gram_tile_of(D, Yraw != nullptr, c, bi, bj);
+  const int i0 = bi * RG_BM, j0 = bj * RG_BN;
+  if (i0 >= D || j0 > i0 + RG_BM - 1) return;                  // lower tiles only
+  const int64_t off = sg.off[c], len = sg.len[c];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  // a tile's four waves own 64 x 32 outputs each — except in the tile right of the diagonal's first half (columns i0 + 64 ..
+  // against rows i0 ..): its upper 64 rows lie strictly above the diagonal, so the four waves share the LOWER 64 x 64 block,
+  // 32 x 32 each, and issue half the matrix instructions (8 of a tile row's 2 bi + 2 tiles: 5 % of the launch's)
+  const bool half = j0 == i0 + 64;
+  const int arow = half ? 64 + wr * 32 : wr * 64;
+  const int krow = tid >> 4, seg = tid & 15;                   // this thread stages k-rows krow and krow + 16 of a k-tile
+  int cae[4], cbe[2];
+  bool aok[4], bok[2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int col = i0 + q * 32 + seg * 2;
+    aok[q] = col < D;
+    cae[q] = aok[q] ? col : 0;
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int col = j0 + q * 32 + seg * 2;
+    bok[q] = col < D;
+    cbe[q] = bok[q] ? col : 0;
+  }
+  f64x4 acc[4][2];
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = f64x4{0.0, 0.0, 0.0, 0.0};
+  const int64_t nk = (len + RG32_BK - 1) / RG32_BK;
+  const bool xty = Yraw != nullptr && j0 == 0;
+  if (nk == 0) {
+    if (xty && tid < 128 && i0 + tid < D)
+      for (int j = 0; j < 5; ++j) O5[((int64_t)c * 5 + j) * ldo + i0 + tid] = 0.0;
+    return;
+  }
+  // row ids one k-tile ahead of the rows (positions past the class's rows — its -1 padding, another class's segment, the end
+  // of the array — count as no row and are not read)
+  auto row_of = [&](int64_t kt, int h) -> int64_t {
+    const int64_t q = kt * RG32_BK + krow + 16 * h;
+    return q < len ? idx[off + q] : -1;
+  };
+  f32x2r ra[2][4], rb[2][2];
+  f32x4r ry[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  bool valid[2];
+  auto load = [&](int64_t row, int h) {
+    valid[h] = row >= 0;
+    const float* x = X + (valid[h] ? row : 0) * ldx;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ra[h][q] = *reinterpret_cast<const f32x2r*>(x + cae[q]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) rb[h][q] = *reinterpret_cast<const f32x2r*>(x + cbe[q]);
+    if (xty && seg == 0) ry[h] = *reinterpret_cast<const f32x4r*>(Yraw + (valid[h] ? row : 0) * ldyr);
+  };
+  double ysum[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  const int ycol = tid & 127, yhalf = tid >> 7;               // the targets' products: column ycol of the A side, two k-rows of every step
+  int64_t row_next[2] = {row_of(1, 0), row_of(1, 1)};
+  load(row_of(0, 0), 0);
+  load(row_of(0, 1), 1);
+  const int r16 = lane & 15, kq = lane >> 4;
+  for (int64_t kt = 0; kt < nk; ++kt) {
+    __syncthreads();                                           // everyone finished reading the previous k-tile
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float* da = lds_a + (krow + 16 * h) * RG32_LDA + seg * 2;
+      float* db = lds_b + (krow + 16 * h) * RG32_LDB + seg * 2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float m = valid[h] && aok[q] ? 1.f : 0.f;
+        *reinterpret_cast<f32x2r*>(da + q * 32) = f32x2r{m * ra[h][q][0], m * ra[h][q][1]};
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float m = valid[h] && bok[q] ? 1.f : 0.f;
+        *reinterpret_cast<f32x2r*>(db + q * 32) = f32x2r{m * rb[h][q][0], m * rb[h][q][1]};
+      }
+      if (xty && seg == 0) *reinterpret_cast<f32x4r*>(lds_y + (krow + 16 * h) * 4) = ry[h];   // (a padded row's A entries are zero)
+    }
+    __syncthreads();
+    load(row_next[0], 0);
+    load(row_next[1], 1);
+    row_next[0] = row_of(kt + 2, 0);
+    row_next[1] = row_of(kt + 2, 1);
+    __builtin_amdgcn_sched_barrier(0);                         // (the loads stay in front of the MFMAs they hide under)
+    float a[2][4], b[2][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[0][t] = lds_a[kq * RG32_LDA + arow + t * 16 + r16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) b[0][t] = lds_b[kq * RG32_LDB + wc * 32 + t * 16 + r16];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks < 7) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[nxt][t] = lds_a[((ks + 1) * 4 + kq) * RG32_LDA + arow + t * 16 + r16];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) b[nxt][t] = lds_b[((ks + 1) * 4 + kq) * RG32_LDB + wc * 32 + t * 16 + r16];
+        __builtin_amdgcn_sched_barrier(0);                     // (reads first: the scheduler sinks them below the multiplies otherwise)
+      }
+      double ad[4], bd[2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ad[t] = (double)a[cur][t];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) bd[t] = (double)b[cur][t];
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[tm], bd[tn], acc[tm][tn], 0, 0, 0);
+      if (!half) {
+#pragma unroll
+        for (int tm = 2; tm < 4; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[tm], bd[tn], acc[tm][tn], 0, 0, 0);
+      }
+      if (xty) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int kr = ks * 4 + yhalf * 2 + r;
+          const double av = (double)lds_a[kr * RG32_LDA + ycol];
+          const f32x4r y = *reinterpret_cast<const f32x4r*>(lds_y + kr * 4);
+          ysum[0] = fma(av, (double)y[0], ysum[0]);
+          ysum[1] = fma(av, (double)y[1], ysum[1]);
+          ysum[2] = fma(av, (double)y[2], ysum[2]);
+          ysum[3] = fma(av, (double)y[3], ysum[3]);
+          ysum[4] += av;
+        }
+      }
+    }
+  }
+  if (xty) {
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(lds_a);            // (5 x 128 doubles of the 32 x 144 floats)
+    if (yhalf == 1) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) red[j * 128 + ycol] = ysum[j];
+    }
+    __syncthreads();
+    if (yhalf == 0 && i0 + ycol < D) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) O5[((int64_t)c * 5 + j) * ldo + i0 + ycol] = ysum[j] + red[j * 128 + ycol];
+    }
+  }
+  double* g = G + (int64_t)c * g_stride;
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = i0 + arow + tm * 16 + kq + 4 * reg;
+      if (row >= D || (half && tm >= 2)) continue;
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) {
         const int col = j0 + wc * 32 + tn * 16 + r16;
@@ -630,6 +811,12 @@ __global__ __launch_bounds__(256) void rls_fold_whitened_kernel(const double* __
 
 // The Grams come straight from the f32 rows (rls_gram_rows_kernel) when the rows allow 16-byte column groups; ODX_RLS_GRAM=nt
 // keeps round 3's form (a transposed f64 copy of all rows + the generic NT GEMM) for A/B runs.
+// ODX_RLS_GRAM_BK=16: the 16-row k-tile held as f64 in LDS (round 4's form, kept for A/B runs); default 32 rows held as floats
+static int rls_gram_bk() {
+  static const int bk = [] { const char* e = getenv("ODX_RLS_GRAM_BK"); return e && atoi(e) == 16 ? 16 : 32; }();
+  return bk;
+}
+
 static bool rls_rows_form(const float* X, int64_t ldx, int D) {
   const char* e = getenv("ODX_RLS_GRAM");
   return !(e && e[0] == 'n') && D % 8 == 0 && ldx % 4 == 0 && aligned16(X);
@@ -711,8 +898,8 @@ extern "C" int odx_rls_gram_raw_batched_f64(const float* X, int64_t ldx, int D, 
     sg.len[c] = seg_len[c];
   }
   const int tiles = (int)(8 * ceil_div(ceil_div(D, RG_BM), 8) * ceil_div(D, RG_BN));
-  hipLaunchKernelGGL(rls_gram_rows_kernel, dim3((unsigned)tiles, 1, (unsigned)C), dim3(256), 0, as_stream(stream), X, ldx, D, idx_pad, sg, G, ldg,
-                     g_stride, Yraw, ldyr, O5, ldo);
+  hipLaunchKernelGGL(rls_gram_bk() == 16 ? rls_gram_rows_kernel : rls_gram_rows32_kernel, dim3((unsigned)tiles, 1, (unsigned)C), dim3(256), 0,
+                     as_stream(stream), X, ldx, D, idx_pad, sg, G, ldg, g_stride, Yraw, ldyr, O5, ldo);
   ODX_CHECK_LAUNCH("rls_gram_rows (raw targets)");
   return ODX_OK;
 }
@@ -806,8 +993,8 @@ extern "C" int odx_rls_gram_batched_f64(const float* X, int64_t ldx, int D, cons
         sg.len[c] = seg_len[c];
       }
       const int tiles = (int)(8 * ceil_div(ceil_div(D, RG_BM), 8) * ceil_div(D, RG_BN));
-      hipLaunchKernelGGL(rls_gram_rows_kernel, dim3((unsigned)tiles, 1, (unsigned)C), dim3(256), 0, s, X, ldx, D, idx_pad, sg, G, ldg, g_stride,
-                         (const float*)nullptr, (int64_t)0, (double*)nullptr, (int64_t)0);
+      hipLaunchKernelGGL(rls_gram_bk() == 16 ? rls_gram_rows_kernel : rls_gram_rows32_kernel, dim3((unsigned)tiles, 1, (unsigned)C), dim3(256), 0, s,
+                         X, ldx, D, idx_pad, sg, G, ldg, g_stride, (const float*)nullptr, (int64_t)0, (double*)nullptr, (int64_t)0);
       ODX_CHECK_LAUNCH("rls_gram_rows");
       if (gram_only) return ODX_OK;
       const int64_t ldo = round_up(D1, 2);
