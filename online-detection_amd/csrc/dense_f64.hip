@@ -87,6 +87,12 @@ __device__ __forceinline__ void lds_chol_128(double* s, double* xi, double* rd, 
                                              int32_t* info, int info_base) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int J = 0; J < DB_NB; J += 32) {
+    if (J >= jb) {
+      // a 32-block of the identity padding behind a ragged last block (jb < 128; the RLS systems' 1025 = 8 x 128 + 1 rows end in
+      // a block of ONE row): its factor and its inverse are the identity already — nothing to compute, 16 us per block saved
+      for (int e = tid; e < 1024; e += DB_NT) gx[(J >> 5) * 1024 + e] = (e >> 5) == (e & 31) ? 1.0 : 0.0;
+      continue;
+    }
     if (wave == 0) {
       chol32_wave(s, rd, J, jb, info, info_base, lane);
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the block's LDS writes before its reads
@@ -96,7 +102,7 @@ __device__ __forceinline__ void lds_chol_128(double* s, double* xi, double* rd, 
     // the inverse phase needs X_JJ again: park it in global scratch (L2) instead of re-deriving it
     for (int e = tid; e < 1024; e += DB_NT) gx[(J >> 5) * 1024 + e] = xi[(e >> 5) * DB_XLD + (e & 31)];
     const int nrem = DB_NB - J - 32;  // rows below the panel
-    if (nrem > 0) {
+    if (nrem > 0 && J + 32 < jb) {   // (rows of the identity padding below: their panel is zero and stays zero)
       // Both products run on v_mfma_f64_16x16x4_f64 (16 x 16 tiles dealt round-robin to the 8 waves); operands come
       // straight from LDS: lane l feeds row / column (l & 15), k = 4 ks + (l >> 4).
       const int tr = lane & 15, kq = lane >> 4, nt16 = nrem >> 4;
