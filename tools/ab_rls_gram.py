@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""A/B of the RLS Gram launch (development aid): k-split (ODX_RLS_GRAM_SPLIT) x LDS padding (ODX_RLS_GRAM_LDS_PAD_KB: fewer
-resident workgroups per CU, room for the target kernels beside the Grams).  Each combination in a child process (the knobs are
-read once per process): the bench extras' RLS figure, best of 8."""
+"""A/B of the RLS call's forms (development aid): the Gram kernel's k-tile (ODX_RLS_GRAM_BK = 32: floats in LDS, the default;
+16: round 4's f64 form) x the targets' products (ODX_RLS_RAW_TARGETS = 1: inside the Gram sweep; 0: a second sweep).  Each
+combination runs in a child process (the knobs are read once per process) and prints the bench extras' RLS figure (best of 2 x 8).
+python tools/ab_rls_gram.py [BK:RAW ...]     default: 32:1 16:1 32:0"""
 import json
 import os
 import subprocess
@@ -18,9 +19,9 @@ r2 = b.rls_extra(cpu=False)
 print(json.dumps({"ms": min(r["ms"], r2["ms"])}))
 """ % (ROOT, os.path.join(ROOT, "online-detection_amd"), os.path.join(ROOT, "tools"))
 
-combos = [tuple(c.split(":")) for c in sys.argv[1:]] or [("1", "0"), ("2", "0"), ("1", "20"), ("2", "20")]
-for split, pad in combos:
-    env = dict(os.environ, ODX_RLS_GRAM_SPLIT=split, ODX_RLS_GRAM_LDS_PAD_KB=pad)
+combos = [tuple(c.split(":")) for c in sys.argv[1:]] or [("32", "1"), ("16", "1"), ("32", "0")]
+for bk, raw in combos:
+    env = dict(os.environ, ODX_RLS_GRAM_BK=bk, ODX_RLS_RAW_TARGETS=raw)
     out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    print("split", split, "pad_kb", pad, line[-1] if line else out.stderr[-400:], flush=True)
+    print("k-tile", bk, "raw targets", raw, line[-1] if line else out.stderr[-400:], flush=True)
