@@ -547,6 +547,41 @@ def test_heads_match_reference():
     check_heads_against_reference()
 
 
+@pytest.mark.parametrize("device", DEVICES)
+def test_region_refiner_class_runs_with_stray_labels(device):
+    """The trainer finds the classes' rows from ONE sort of the labels and the positions of the class boundaries in it
+    (rls.py::_train_batched: one host read).  Labels that belong to no regressor — negative ones, the background's 0, labels past
+    the last class — must neither be trained on nor shift a class's run; a class without rows gets the reference's empty
+    entry (train_region_refiner.py:38-44).  Checked against the same call on the strays-free rows, class by class."""
+    from odx.rls import RegionRefinerTrainer
+    rng = np.random.default_rng(21)
+    D, sizes = 24, {1: 37, 2: 0, 3: 16, 4: 5}
+    labels = np.concatenate([np.full(n, c) for c, n in sizes.items()] + [np.full(9, -1), np.full(7, 0), np.full(4, 9), np.full(3, -5)])
+    X = rng.standard_normal((len(labels), D)).astype(np.float32)
+    Y = (rng.standard_normal((len(labels), 4)) * 0.3).astype(np.float32)
+    perm = rng.permutation(len(labels))
+    labels, X, Y = labels[perm], X[perm], Y[perm]
+    cfg = {"CHOSEN_CLASSES": {i: "c%d" % i for i in range(5)}, "REGION_REFINER": {"opts": {"lambda": 2.0}}}
+
+    def train(keep):
+        coxy = {"C": torch.from_numpy(labels[keep].astype(np.float32)).view(-1, 1).to(device), "O": None,
+                "X": torch.from_numpy(X[keep]).to(device), "Y": torch.from_numpy(Y[keep]).to(device)}
+        return list(quiet(RegionRefinerTrainer(cfg, 2.0, False), coxy))
+
+    got = train(np.ones(len(labels), dtype=bool))
+    want = train((labels >= 1) & (labels <= 4))
+    assert len(got) == len(want) == 4
+    for c, (a, b) in enumerate(zip(got, want), start=1):
+        assert (a["Beta"] is None) == (b["Beta"] is None) == (sizes[c] == 0), c
+        if a["Beta"] is None:
+            continue
+        for k in range(4):
+            wa, wb = a["Beta"][str(k)]["weights"], b["Beta"][str(k)]["weights"]
+            assert float((wa - wb).abs().max()) <= 1e-6 * max(1.0, float(wb.abs().max())), (c, k)
+            assert a["Beta"][str(k)]["losses"].shape == (sizes[c],)
+            assert torch.allclose(a["Beta"][str(k)]["losses"], b["Beta"][str(k)]["losses"], atol=1e-6), (c, k)
+
+
 # ------------------------------------------------------------------ f4: adding a class to a running pipeline
 @pytest.mark.parametrize("device", DEVICES)
 def test_add_a_class_without_touching_the_others(device):
