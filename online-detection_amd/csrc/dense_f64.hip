@@ -459,8 +459,9 @@ __device__ __forceinline__ void trmv_row(const double* __restrict__ Tri, int64_t
                                          const double* __restrict__ x, double alpha, double beta,
                                          const double* __restrict__ z, double* __restrict__ y) {
   const int lane = threadIdx.x & 63;
-  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= M) return;
+  if (!uplo) i = M - 1 - i;      // longest rows first: a lower factor's long rows, dispatched last, were the launch's tail
   const int64_t jlo = uplo ? i : 0, jhi = uplo ? M : i + 1;  // [jlo, jhi)
   const double* row = Tri + i * ld;
   const int64_t q0 = (jlo + 1) >> 1, q1 = jhi >> 1;           // whole pairs [2 q0, 2 q1); ld is even so pairs are 16-B aligned

@@ -42,6 +42,20 @@ def sym_eig_small(S):
     return torch.from_numpy(np.ascontiguousarray(ev)).to(S.device), torch.from_numpy(np.ascontiguousarray(V)).to(S.device)
 
 
+def whitening_transforms(S, eps=0.001):
+    """(T, T_inv) (B, 4, 4) f64 on S's device for a batch of target covariances S (B, 4, 4): T = V diag(1 / sqrt(ev + eps)) V',
+    T_inv = V diag(sqrt(ev + eps)) V' (train_region_refiner.py:63-67) — eigen-decomposition AND the two small products on the
+    host, one upload (on the device the products were five library GEMM launches for 30 x 16 numbers)."""
+    A = np.asarray(S.detach().cpu().numpy(), dtype=np.float64)
+    A = 0.5 * (A + np.swapaxes(A, -1, -2))
+    ev, V = np.linalg.eigh(A)
+    root = np.sqrt(ev + eps)
+    Vt = np.swapaxes(V, -1, -2)
+    both = np.stack(((V / root[..., None, :]) @ Vt, (V * root[..., None, :]) @ Vt))
+    both = torch.from_numpy(np.ascontiguousarray(both)).to(S.device)
+    return both[0], both[1]
+
+
 def whiten_targets(Yi):
     """mu, T, T_inv (f64) of train_region_refiner.py:61-67 for targets Yi (n, 4) f64."""
     mu = torch.mean(Yi, dim=0)
@@ -201,12 +215,10 @@ class RegionRefinerTrainer:
                     mus.append(mu), Ycs.append(Yc), Ss.append(S)
                 S_all = torch.stack(Ss)
             # (on the host: 4 x 4 matrices — the GPU solver costs ~8 ms for the batch, mostly launch + synchronisation)
-            evals, Wv = sym_eig_small(S_all)
-            root = torch.sqrt(evals + 0.001)
-            Ts = Wv @ torch.diag_embed(1.0 / root) @ Wv.transpose(1, 2)
-            Tis = Wv @ torch.diag_embed(root) @ Wv.transpose(1, 2)
+            Ts, Tis = whitening_transforms(S_all)
             if not sharded:
-                Yw_all = torch.bmm(Yc_all, Ts)[gid, pos]                                   # (rows of the group, 4), class-sorted
+                # (rows of the group, 4), class-sorted: Yw[g, r, j] = sum_i Yc[g, r, i] T[g, i, j] as a product + a reduction
+                Yw_all = (Yc_all.unsqueeze(3) * Ts.unsqueeze(1)).sum(2)[gid, pos]
                 if raw5 is None:
                     Yt = torch.zeros((4, max(npad, 16)), dtype=torch.float64, device=xdev)
                     Yt[:, dest] = Yw_all.t()
