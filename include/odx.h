@@ -531,6 +531,11 @@ int odx_roi_align_fpn_f32(const float* const* feats, const int* H, const int* W,
 int odx_roi_align_fpn_nhwc_f32(const float* const* feats, const int* H, const int* W, const float* scales, int levels,
                                int N, int C, const float* rois, int R, int PH, int PW, int sampling_ratio, float* out_rows,
                                int* level_out, odx_stream_t stream);
+/* The same over a pyramid run natively in 16 bits (is_bf16 != 0: bfloat16, else IEEE half; levels 8-byte aligned, C % 4 == 0): the
+ * samples are decoded to f32, everything after is the f32 entry's arithmetic, the crops leave as f32 rows. */
+int odx_roi_align_fpn_nhwc_16(const void* const* feats, int is_bf16, const int* H, const int* W, const float* scales, int levels,
+                              int N, int C, const float* rois, int R, int PH, int PW, int sampling_ratio, float* out_rows,
+                              int* level_out, odx_stream_t stream);
 /* Greedy NMS over boxes (R, 4) xyxy ALREADY SORTED by descending score, areas with the +1
  * pixel convention: keep[i] = 1 unless an earlier kept box overlaps i with IoU > threshold.  */
 int64_t odx_nms_workspace_bytes(int R);

@@ -126,7 +126,33 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(const float* __restr
 // additions per channel as roi_align_fwd_kernel.
 // one output bin (ph, pw) of one RoI from an NHWC map (rows of ldf floats), all channels: the lanes of the workgroup own four
 // adjacent channels each
-__device__ __forceinline__ void roi_align_bin_nhwc(const float* __restrict__ feat, int64_t ldf, int N, int C, int H, int W,
+// four adjacent channels of an NHWC map as floats: f32 (16 bytes), bfloat16 / IEEE half (8 bytes; IS_BF16 picks the decoding)
+struct RoiF32 {};
+struct RoiBf16 {};
+struct RoiF16 {};
+template <typename TAG> struct RoiElem;
+template <> struct RoiElem<RoiF32> {
+  typedef float T;
+  static __device__ __forceinline__ f32x4 load4(const T* p) { return *reinterpret_cast<const f32x4*>(p); }
+};
+template <> struct RoiElem<RoiBf16> {
+  typedef unsigned short T;
+  static __device__ __forceinline__ f32x4 load4(const T* p) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    return f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
+  }
+};
+template <> struct RoiElem<RoiF16> {
+  typedef _Float16 T;
+  static __device__ __forceinline__ f32x4 load4(const T* p) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const h4 v = *reinterpret_cast<const h4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  }
+};
+
+template <typename TAG = RoiF32>
+__device__ __forceinline__ void roi_align_bin_nhwc(const typename RoiElem<TAG>::T* __restrict__ feat, int64_t ldf, int N, int C, int H, int W,
                                                    const float* __restrict__ roi, float scale, int PH, int PW, int sampling_ratio,
                                                    int ph, int pw, float* __restrict__ row) {
   const int b = (int)roi[0];
@@ -136,7 +162,7 @@ __device__ __forceinline__ void roi_align_bin_nhwc(const float* __restrict__ fea
   const int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)PH);
   const int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)PW);
   const float count = (float)(gh * gw);
-  const float* base = feat + (int64_t)b * H * W * ldf;
+  const typename RoiElem<TAG>::T* base = feat + (int64_t)b * H * W * ldf;
   for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (b >= 0 && b < N) {
@@ -151,10 +177,10 @@ __device__ __forceinline__ void roi_align_bin_nhwc(const float* __restrict__ fea
           if (xl >= W - 1) { xh = xl = W - 1; xx = (float)xl; } else { xh = xl + 1; }
           const float ly = yy - yl, lx = xx - xl, hy = 1.f - ly, hx = 1.f - lx;
           const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-          const f32x4 p1 = *reinterpret_cast<const f32x4*>(base + (int64_t)(yl * W + xl) * ldf + c);
-          const f32x4 p2 = *reinterpret_cast<const f32x4*>(base + (int64_t)(yl * W + xh) * ldf + c);
-          const f32x4 p3 = *reinterpret_cast<const f32x4*>(base + (int64_t)(yh * W + xl) * ldf + c);
-          const f32x4 p4 = *reinterpret_cast<const f32x4*>(base + (int64_t)(yh * W + xh) * ldf + c);
+          const f32x4 p1 = RoiElem<TAG>::load4(base + (int64_t)(yl * W + xl) * ldf + c);
+          const f32x4 p2 = RoiElem<TAG>::load4(base + (int64_t)(yl * W + xh) * ldf + c);
+          const f32x4 p3 = RoiElem<TAG>::load4(base + (int64_t)(yh * W + xl) * ldf + c);
+          const f32x4 p4 = RoiElem<TAG>::load4(base + (int64_t)(yh * W + xh) * ldf + c);
 #pragma unroll
           for (int k = 0; k < 4; ++k) acc[k] += roi_bilinear(w1, p1[k], w2, p2[k], w3, p3[k], w4, p4[k]);
         }
@@ -275,6 +301,26 @@ __global__ __launch_bounds__(256) void roi_align_fpn_nhwc_kernel(FpnLevels L, in
     if (k == lv) { feat = L.feat[k]; H = L.H[k]; W = L.W[k]; scale = L.scale[k]; }
   const int ph = (int)blockIdx.y / PW, pw = (int)blockIdx.y % PW;
   roi_align_bin_nhwc(feat, C, N, C, H, W, roi, scale, PH, PW, sampling_ratio, ph, pw, out + ((int64_t)r * gridDim.y + blockIdx.y) * C);
+}
+
+// The same from 16-bit NHWC maps (a pyramid run natively in bf16 / f16): the samples are decoded to f32 and everything after is
+// the f32 kernel's arithmetic — the crops leave as f32 rows.
+template <typename TAG>
+__global__ __launch_bounds__(256) void roi_align_fpn_nhwc16_kernel(FpnLevels L, int N, int C, const float* __restrict__ rois, int PH, int PW,
+                                                                   int sampling_ratio, float* __restrict__ out, int* __restrict__ level_out) {
+  const int r = blockIdx.x;
+  const float* roi = rois + (int64_t)r * 5;
+  const int lv = fpn_level_of(roi, L);
+  if (level_out != nullptr && blockIdx.y == 0 && threadIdx.x == 0) level_out[r] = lv;
+  const float* feat = L.feat[0];
+  int H = L.H[0], W = L.W[0];
+  float scale = L.scale[0];
+#pragma unroll
+  for (int k = 1; k < ODX_MAX_FPN_LEVELS; ++k)
+    if (k == lv) { feat = L.feat[k]; H = L.H[k]; W = L.W[k]; scale = L.scale[k]; }
+  const int ph = (int)blockIdx.y / PW, pw = (int)blockIdx.y % PW;
+  roi_align_bin_nhwc<TAG>(reinterpret_cast<const typename RoiElem<TAG>::T*>(feat), C, N, C, H, W, roi, scale, PH, PW, sampling_ratio, ph, pw,
+                          out + ((int64_t)r * gridDim.y + blockIdx.y) * C);
 }
 
 // ---------------------------------------------------------------- NMS
@@ -870,6 +916,42 @@ extern "C" int odx_roi_align_fpn_nhwc_f32(const float* const* feats, const int* 
   hipLaunchKernelGGL(roi_align_fpn_nhwc_kernel, dim3((unsigned)R, (unsigned)(PH * PW)), dim3(threads), 0, as_stream(stream), L, N, C, rois,
                      PH, PW, sampling_ratio, out_rows, level_out);
   ODX_CHECK_LAUNCH("odx_roi_align_fpn_nhwc_f32");
+  return ODX_OK;
+}
+
+// odx_roi_align_fpn_nhwc_f32 over 16-bit maps (is_bf16 != 0: bfloat16, else IEEE half; 8-byte aligned rows, C % 4 == 0): the
+// crops as f32 rows (R, PH PW C).
+extern "C" int odx_roi_align_fpn_nhwc_16(const void* const* feats, int is_bf16, const int* H, const int* W, const float* scales, int levels,
+                                         int N, int C, const float* rois, int R, int PH, int PW, int sampling_ratio, float* out_rows,
+                                         int* level_out, odx_stream_t stream) {
+  if (R <= 0 || C <= 0) return ODX_OK;
+  ODX_REQUIRE(feats && H && W && scales && rois && out_rows && N > 0, "odx_roi_align_fpn_nhwc_16: null pointer");
+  ODX_REQUIRE(levels >= 1 && levels <= ODX_MAX_FPN_LEVELS, "odx_roi_align_fpn_nhwc_16: 1..%d pyramid levels", ODX_MAX_FPN_LEVELS);
+  ODX_REQUIRE(PH > 0 && PW > 0 && PH * PW <= 65535 && C % 4 == 0 && (reinterpret_cast<uintptr_t>(out_rows) & 15u) == 0,
+              "odx_roi_align_fpn_nhwc_16: PH * PW in 1..65535, C %% 4 == 0, 16-byte aligned output rows expected");
+  FpnLevels L;
+  for (int k = 0; k < ODX_MAX_FPN_LEVELS; ++k) {
+    const int j = k < levels ? k : levels - 1;
+    ODX_REQUIRE(feats[j] && H[j] > 0 && W[j] > 0 && scales[j] > 0.f && (int64_t)H[j] * W[j] < (1ll << 31) &&
+                (reinterpret_cast<uintptr_t>(feats[j]) & 7u) == 0, "odx_roi_align_fpn_nhwc_16: bad level %d", j);
+    L.feat[k] = static_cast<const float*>(feats[j]);          // (the table's pointer type; the kernel reads 16-bit elements)
+    L.H[k] = H[j];
+    L.W[k] = W[j];
+    L.scale[k] = scales[j];
+  }
+  L.levels = levels;
+  L.k_min = (int)lrintf(-log2f(scales[0]));
+  L.k_max = (int)lrintf(-log2f(scales[levels - 1]));
+  ODX_REQUIRE(L.k_max - L.k_min == levels - 1, "odx_roi_align_fpn_nhwc_16: the level scales must halve from level to level");
+  const int threads = C >= 1024 ? 256 : (C >= 512 ? 128 : 64);
+  const dim3 grid((unsigned)R, (unsigned)(PH * PW));
+  if (is_bf16)
+    hipLaunchKernelGGL(roi_align_fpn_nhwc16_kernel<RoiBf16>, grid, dim3(threads), 0, as_stream(stream), L, N, C, rois, PH, PW, sampling_ratio,
+                       out_rows, level_out);
+  else
+    hipLaunchKernelGGL(roi_align_fpn_nhwc16_kernel<RoiF16>, grid, dim3(threads), 0, as_stream(stream), L, N, C, rois, PH, PW, sampling_ratio,
+                       out_rows, level_out);
+  ODX_CHECK_LAUNCH("odx_roi_align_fpn_nhwc_16");
   return ODX_OK;
 }
 

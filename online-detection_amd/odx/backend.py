@@ -854,9 +854,11 @@ class HipBackend:
         """roi_align_fpn for a pyramid handed over as channels-last views of NHWC row matrices (what the pyramid's row GEMMs
         write): -> (R, PH PW C) f32, the crops flattened in (ph, pw, c) order (odx_roi_align_fpn_nhwc_f32: no NCHW copy of the
         levels).  Levels that are not such views are taken through a channels-last copy."""
+        # (16-bit levels — a pyramid run natively in bf16 / f16 — are read as they are: odx_roi_align_fpn_nhwc_16 decodes the samples)
+        dt = feats[0].dtype if feats[0].dtype in (torch.bfloat16, torch.float16) and all(f.dtype == feats[0].dtype for f in feats) else torch.float32
         fs = []
         for f in feats:
-            f = f.to(device=self.device, dtype=torch.float32)
+            f = f.to(device=self.device, dtype=dt)
             if f.is_contiguous() or not f.is_contiguous(memory_format=torch.channels_last) or f.data_ptr() % 16 != 0:
                 f = f.contiguous(memory_format=torch.channels_last)
             fs.append(f)
@@ -873,8 +875,12 @@ class HipBackend:
             hs = (ctypes.c_int * L)(*[int(f.shape[2]) for f in fs])
             ws = (ctypes.c_int * L)(*[int(f.shape[3]) for f in fs])
             sc = (ctypes.c_float * L)(*[float(v) for v in scales])
-            hip.check(self.lib.odx_roi_align_fpn_nhwc_f32(fp, hs, ws, sc, L, N, C, _p(rois), R, PH, PW, int(sampling_ratio), _p(out), None,
-                                                          self._stream()), "odx_roi_align_fpn_nhwc_f32")
+            if dt == torch.float32:
+                hip.check(self.lib.odx_roi_align_fpn_nhwc_f32(fp, hs, ws, sc, L, N, C, _p(rois), R, PH, PW, int(sampling_ratio), _p(out), None,
+                                                              self._stream()), "odx_roi_align_fpn_nhwc_f32")
+            else:
+                hip.check(self.lib.odx_roi_align_fpn_nhwc_16(fp, int(dt == torch.bfloat16), hs, ws, sc, L, N, C, _p(rois), R, PH, PW,
+                                                             int(sampling_ratio), _p(out), None, self._stream()), "odx_roi_align_fpn_nhwc_16")
         return out
 
     def packed(self, X, meta=None, zero_row=False):

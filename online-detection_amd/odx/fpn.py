@@ -142,7 +142,7 @@ class FeaturePyramid(nn.Module):
     def forward_rows16(self, cs):
         """forward_rows for a pyramid in bf16 / f16: the stages' 16-bit rows (ResNet50Stages.forward_rows16) through odx_gemm_b16 /
         conv3x3_rows16, the top-down sum in the 16-bit type (as the library's 16-bit pyramid adds two 16-bit maps); the five
-        levels as contiguous 16-bit (B, C, h, w) maps."""
+        levels as 16-bit (B, C, h, w) channels-last views of the products' rows."""
         be = _backend.get_backend()
         dt = cs[0][0].buf.dtype
         inner, layer = self._rows16_weights(be, dt)
@@ -158,8 +158,8 @@ class FeaturePyramid(nn.Module):
                 lat = be.rows16((lat.dense.reshape(B, H, W, -1) + up).reshape(B * H * W, -1), dt, zero_row=True)
             last, dims = lat, (B, H, W)
             o = be.conv3x3_rows16(lat, B, H, W, layer[k][0], bias=layer[k][1])
-            outs.insert(0, o.dense.reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous())
-        outs.append(outs[-1][:, :, ::2, ::2].contiguous())
+            outs.insert(0, o.dense.reshape(B, H, W, -1).permute(0, 3, 1, 2))          # channels-last VIEWS of the rows, as forward_rows
+        outs.append(outs[-1][:, :, ::2, ::2].contiguous(memory_format=torch.channels_last))
         return tuple(outs)
 
     def forward_rows(self, cs):
@@ -550,7 +550,8 @@ class OnlineDetectionModelFPN(nn.Module):
                  else batch_idx.to(device=boxes.device, dtype=boxes.dtype).view(-1, 1))
         rois = torch.cat((first, boxes), dim=1)
         t0 = trunk[0]
-        if (t0.is_cuda and t0.dtype == torch.float32 and not t0.is_contiguous() and t0.is_contiguous(memory_format=torch.channels_last)
+        if (t0.is_cuda and t0.dtype in (torch.float32, torch.bfloat16, torch.float16) and not t0.is_contiguous()
+                and t0.is_contiguous(memory_format=torch.channels_last)
                 and hasattr(be, "roi_align_fpn_rows") and hasattr(be, "gemm_h2") and boxes.shape[0] > 0 and t0.shape[1] % 4 == 0):
             # the pyramid is the row GEMMs' NHWC rows: pooled from them as they are, the crops flattened in (ph, pw, c) order and
             # fc6's weight columns permuted to match (once) — no NCHW copy of the levels, 16-byte reads of contiguous channels

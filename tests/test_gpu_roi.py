@@ -141,6 +141,13 @@ def test_roi_align_fpn_from_nhwc_levels_equals_the_nchw_kernel():
             assert torch.equal(got2, got)
         assert len(set(lv.tolist())) == 4
     assert be.roi_align_fpn_rows(views, rois[:0], scales, (7, 7), 2).shape == (0, 49 * C)
+    # a pyramid held in 16 bits (odx_roi_align_fpn_nhwc_16): the samples decode exactly, the rest is the f32 kernel's arithmetic
+    for dt in (torch.bfloat16, torch.float16):
+        v16 = [f.to(dt) for f in views]
+        assert all(not f.is_contiguous() and f.is_contiguous(memory_format=torch.channels_last) for f in v16)
+        got16 = be.roi_align_fpn_rows(v16, rois, scales, (7, 7), 2)
+        want16 = be.roi_align_fpn_rows([f.float() for f in v16], rois, scales, (7, 7), 2)
+        assert got16.dtype == torch.float32 and torch.equal(got16, want16), dt
 
 
 @pytest.mark.parametrize("N,C,H,W", [(1, 64, 150, 200), (2, 7, 19, 25), (1, 3, 1, 1), (1, 256, 38, 50),
