@@ -168,6 +168,31 @@ def test_rls_grams_from_rows_equal_the_transposed_copy_form(hip_backend, monkeyp
                 assert float((wa - wb).abs().max()) <= 1e-6 * max(1.0, float(wb.abs().max())), (other, c, k)
 
 
+def test_rls_pad_index_equals_the_tensor_statements(hip_backend):
+    """odx_rls_pad_index (the padded row-id array of a class batch and its inverse maps, one launch) against the tensor
+    statements it replaced in rls.py: ragged classes, an empty one in the middle and at the end, segments padded to 16."""
+    seg_len = [5, 0, 16, 33, 1, 0]
+    seg_off, at = [], 0
+    for n in seg_len:
+        seg_off.append(at)
+        at += (n + 15) // 16 * 16
+    npad, total = at, sum(seg_len)
+    g = torch.Generator().manual_seed(2)
+    run = torch.randperm(1000, generator=g)[:total].cuda()
+    idx_pad, gid, pos, dest, lens = hip_backend.rls_pad_index(run, seg_off, seg_len, npad)
+    lens_h = torch.tensor(seg_len)
+    gid_w = torch.repeat_interleave(torch.arange(len(seg_len)), lens_h)
+    starts = torch.tensor(np.concatenate(([0], np.cumsum(seg_len)[:-1])))
+    pos_w = torch.arange(total) - starts[gid_w]
+    dest_w = torch.tensor(seg_off)[gid_w] + pos_w
+    idx_w = torch.full((npad,), -1, dtype=torch.int64)
+    idx_w[dest_w] = run.cpu()
+    assert torch.equal(idx_pad.cpu(), idx_w) and torch.equal(gid.cpu(), gid_w) and torch.equal(pos.cpu(), pos_w)
+    assert torch.equal(dest.cpu(), dest_w) and lens.cpu().tolist() == seg_len
+    with pytest.raises(RuntimeError):                     # lengths that do not add up to the ids handed over
+        hip_backend.rls_pad_index(run[:-1], seg_off, seg_len, npad)
+
+
 def test_rls_raw_target_products_equal_the_second_sweep(hip_backend, monkeypatch):
     """The whitened targets' X' Yw from the RAW targets' products formed inside the Gram sweep, (X' Y - X' 1 mu') T
     (odx_rls_gram_raw_batched_f64 + odx_rls_fold_whitened_f64: the default with f32 targets), against the second sweep over the

@@ -547,6 +547,25 @@ def test_heads_match_reference():
     check_heads_against_reference()
 
 
+def test_whitening_transforms_are_the_reference_formula():
+    """rls.whitening_transforms (eigen-decomposition and the two 4 x 4 products on the host, one upload) against
+    train_region_refiner.py:63-67 written out with torch: T = V diag(1 / sqrt(ev + 0.001)) V', T_inv = V diag(sqrt(ev + 0.001)) V',
+    T T_inv = I, T' = T — for a batch of covariances including a rank-deficient one (a class with a single row: S = 0)."""
+    from odx.rls import whitening_transforms
+    rng = np.random.default_rng(3)
+    Y = rng.standard_normal((5, 40, 4)) * np.array([0.3, 0.2, 0.1, 0.05])
+    S = np.einsum("bni,bnj->bij", Y, Y) / 40
+    S[4] = 0.0
+    T, Ti = whitening_transforms(torch.from_numpy(S))
+    assert T.dtype == torch.float64 and tuple(T.shape) == (5, 4, 4)
+    for b in range(5):
+        ev, V = torch.linalg.eigh(torch.from_numpy(S[b]))
+        root = torch.sqrt(ev + 0.001)
+        assert torch.allclose(T[b], V @ torch.diag(1.0 / root) @ V.t(), atol=1e-12)
+        assert torch.allclose(Ti[b], V @ torch.diag(root) @ V.t(), atol=1e-12)
+        assert torch.allclose(T[b] @ Ti[b], torch.eye(4, dtype=torch.float64), atol=1e-10) and torch.allclose(T[b], T[b].t(), atol=1e-14)
+
+
 @pytest.mark.parametrize("device", DEVICES)
 def test_region_refiner_class_runs_with_stray_labels(device):
     """The trainer finds the classes' rows from ONE sort of the labels and the positions of the class boundaries in it
