@@ -467,7 +467,13 @@ class OnlineDetectionModelFPN(nn.Module):
             b, sc, _ = be.rpn_topk_decode(logits, deltas, self._anchors(lvl, H, W, dev), ks[lvl], img_size, DELTA_CLAMP)
             cand[:, lvl, :ks[lvl]] = b
             score[:, lvl, :ks[lvl]] = sc
-        counts = torch.tensor(ks * B, dtype=torch.int32, device=dev)
+        # (the candidate counts of the B x 5 sets depend on the image size only: uploaded once — a host-to-device copy of pageable
+        # memory waits for the stream, here in the middle of the forward)
+        ckey = (B, tuple(ks), str(dev))
+        hit = self._packed.get("nms_counts")
+        if hit is None or hit[0] != ckey:
+            hit = self._packed["nms_counts"] = (ckey, torch.tensor(ks * B, dtype=torch.int32, device=dev))
+        counts = hit[1]
         keep = be.nms_batched(cand.view(B * L, Rmax, 4), counts, self.rpn_nms).view(B, L, Rmax)
         keep &= keep.cumsum(2) <= self.post_nms_top_n
         flat = torch.where(keep, score, torch.full_like(score, -1.0)).view(B, L * Rmax)
