@@ -463,6 +463,15 @@ int odx_gemm_h2_taps_f32(const void* PY, int64_t ldpy, const float* metay, int64
                          const float* residual, int64_t ldr, int relu, float* out, int64_t ldo, float* out_meta,
                          void* out_packed, int64_t ldop, float bound_w, float bound_add, const float* residual_meta,
                          odx_stream_t stream);
+/* The top-down step of a feature pyramid (maskrcnn_benchmark/modeling/backbone/fpn.py:57-63: last_inner = inner_lateral +
+ * F.interpolate(last_inner, scale_factor=2, mode="nearest")) on NHWC rows, in place and in one pass: lat (B H W rows of C, row
+ * stride ldl) += top (B Hp Wp rows) at row (h Hp / H, w Wp / W).  f32: meta != NULL receives max |sum| in meta[1] (bits of a
+ * non-negative float; zero on entry), what odx_split_f16_premax needs to pack the 3 x 3 output convolution's operand without a
+ * pass for the maximum.  16 bits (is_bf16 != 0: bfloat16, else IEEE half): added in f32, rounded once. */
+int odx_upsample_add_rows_f32(float* lat, int64_t ldl, const float* top, int64_t ldt, int B, int H, int W, int Hp, int Wp, int C,
+                              float* meta, odx_stream_t stream);
+int odx_upsample_add_rows_16(void* lat, int64_t ldl, const void* top, int64_t ldt, int is_bf16, int B, int H, int W, int Hp, int Wp,
+                             int C, odx_stream_t stream);
 /* A layer of such a chain that writes its output AS the next layer's operand: odx_gemm_h2_max_f32 which also
  * (out_packed != NULL) stores the packed two-term split of its output straight from the accumulators — rows of ldop 4-byte
  * units (ldop % 4 == 0, ldop >= roundup(n, 64), columns n .. roundup(n, 64) zero), out_meta[0] = the scale, out_meta[1] =

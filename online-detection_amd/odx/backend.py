@@ -957,6 +957,28 @@ class HipBackend:
             hip.check(self.lib.odx_taps3x3_packed(_p(A.P), A.P.stride(0), R, H, W, C, _p(T.P), T.P.stride(0), self._stream()), "odx_taps3x3_packed")
         return self.chain_gemm(T, B, bias=bias, relu=relu, bounds=bounds, f32_out=f32_out, zero_row=zero_row)
 
+    def upsample_add_rows(self, lat, top, B, H, W, Hp, Wp):
+        """The top-down step of a feature pyramid on NHWC rows, in place: lat (B H W, C) f32 += top (B Hp Wp, C) at the nearest-
+        neighbour source row (odx_upsample_add_rows_f32).  Returns the meta words holding max |sum| — what `packed` / `conv3x3_rows`
+        take as `meta`."""
+        C = lat.shape[1]
+        if (lat.dtype != torch.float32 or top.dtype != torch.float32 or lat.shape[0] != B * H * W or top.shape != (B * Hp * Wp, C)
+                or lat.stride(1) != 1 or top.stride(1) != 1):
+            raise ValueError("upsample_add_rows: (B H W, C) and (B Hp Wp, C) f32 row matrices expected")
+        om = self._meta_slot()
+        hip.check(self.lib.odx_upsample_add_rows_f32(_p(lat), lat.stride(0), _p(top), top.stride(0), B, H, W, Hp, Wp, C, _p(om), self._stream()),
+                  "odx_upsample_add_rows_f32")
+        return om
+
+    def upsample_add_rows16(self, lat, top, B, H, W, Hp, Wp):
+        """upsample_add_rows for 16-bit rows (Rows16, in place in lat's buffer): added in f32, rounded once."""
+        C, dt = lat.K, lat.buf.dtype
+        if top.buf.dtype != dt or top.K != C or lat.n != B * H * W or top.n != B * Hp * Wp:
+            raise ValueError("upsample_add_rows16: Rows16 of one type, (B H W) and (B Hp Wp) rows of the same channels expected")
+        hip.check(self.lib.odx_upsample_add_rows_16(_p(lat.buf), lat.buf.stride(0), _p(top.buf), top.buf.stride(0), int(dt == torch.bfloat16),
+                                                    B, H, W, Hp, Wp, C, self._stream()), "odx_upsample_add_rows_16")
+        return lat
+
     def conv3x3_rows(self, Y, R, H, W, B, bias=None, relu=False, meta=None, with_max=False):
         """act(3 x 3 convolution, padding 1) of the NHWC rows Y (R H W, C) f32 with the packed weights B (n, 9 C: ky kx c) as
         ONE product: where the library gathers the taps inside the product's operand loads (odx_gemm_h2_taps_f32: wide

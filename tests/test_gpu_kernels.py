@@ -1458,3 +1458,27 @@ def test_cu_masked_stream_and_partition_sized_pass(be):
     finally:
         torch.cuda.synchronize()
         hip.check(lib.odx_stream_destroy(raw), "odx_stream_destroy")
+
+
+def test_upsample_add_rows_equals_the_tensor_statements(be):
+    """odx_upsample_add_rows_f32 / _16 (the top-down step of the pyramid on NHWC rows, in place, one pass) = the row gathers and the
+    addition they replace, bit for bit — even and odd target sizes (75 x 100 from 38 x 50: the index rule h Hp / H), f32 with the
+    maximum of the sum left in the meta words, bf16 / f16 added in f32 and rounded once."""
+    from odx.backend import Rows16
+    g = torch.Generator().manual_seed(8)
+    for (B, H, W, Hp, Wp, C) in ((2, 8, 12, 4, 6, 16), (3, 75, 100, 38, 50, 256), (1, 5, 7, 3, 4, 8)):
+        lat = torch.randn((B * H * W, C), generator=g).cuda()
+        top = torch.randn((B * Hp * Wp, C), generator=g).cuda()
+        hi = (torch.arange(H, device="cuda") * Hp) // H
+        wi = (torch.arange(W, device="cuda") * Wp) // W
+        want = (lat.view(B, H, W, C) + top.view(B, Hp, Wp, C)[:, hi][:, :, wi]).reshape(B * H * W, C)
+        got = lat.clone()
+        meta = be.upsample_add_rows(got, top, B, H, W, Hp, Wp)
+        assert torch.equal(got, want)
+        assert meta.view(torch.int32)[1].item() == want.abs().max().view(torch.int32).item()
+        for dt in (torch.bfloat16, torch.float16):
+            l16 = be.rows16(lat.to(dt), dt, zero_row=True)
+            t16 = be.rows16(top.to(dt), dt)
+            want16 = (l16.dense.reshape(B, H, W, C) + t16.dense.reshape(B, Hp, Wp, C)[:, hi][:, :, wi]).reshape(B * H * W, C)
+            be.upsample_add_rows16(l16, t16, B, H, W, Hp, Wp)
+            assert torch.equal(l16.dense, want16), dt
