@@ -597,6 +597,15 @@ int odx_bias_act_nchw_f32(float* y, const float* bias, const float* residual, in
  * rounded to the map's type, as the separate operators round.                                                            */
 int odx_bias_act_nchw_16(void* y, const void* bias, const void* residual, int is_bf16, int64_t N, int C, int64_t HW, int relu,
                          odx_stream_t stream);
+/* The stem's tail in one pass (ResNet stem, maskrcnn_benchmark/modeling/backbone/resnet.py: relu(bn1(conv1(x))) -> max_pool2d(3, 2,
+ * 1)): relu(x + bias) of the convolution's NCHW output x (B, C, H, W) with the frozen batch norm folded into weights and bias,
+ * pooled 3 x 3 / stride 2 / padding 1, written as the NHWC rows (B Ho Wo, C) the stages' row GEMMs read (row stride ldr; Ho =
+ * (H - 1) / 2 + 1).  f32: meta != NULL receives max |out| in meta[1] (zero on entry) for odx_split_f16_premax.  16 bits: bias in
+ * the map's type, every sum rounded once (odx_bias_act_nchw_16's arithmetic). */
+int odx_stem_pool_rows_f32(const float* x, const float* bias, int B, int C, int H, int W, float* rows, int64_t ldr, float* meta,
+                           odx_stream_t stream);
+int odx_stem_pool_rows_16(const void* x, const void* bias, int is_bf16, int B, int C, int H, int W, void* rows, int64_t ldr,
+                          odx_stream_t stream);
 
 
 /* ---------------------------------------------------------------- A11 / A12: harvest labelling

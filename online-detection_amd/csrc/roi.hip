@@ -1151,6 +1151,96 @@ static int bias_act_nchw(void* y, const void* bias, const void* residual, int64_
   return ODX_OK;
 }
 
+// The stem's tail in one pass: relu(x + bias) of the 7 x 7 convolution's NCHW output, the 3 x 3 / stride 2 / padding 1 max pooling
+// of it, written as the NHWC ROWS the stages' row GEMMs read (rows (B Ho Wo, C), row stride ldr), with max |out| left for the first
+// packing (amax: bits of a non-negative float, zero on entry; nullptr: not wanted).  Before: the epilogue pass in place (read +
+// write of the 245-MB map of eight 600 x 800 images), the library's pooling (read it again, 177 us), a permuting copy of the pooled
+// map and a pass for its maximum.  Per element the arithmetic of bias_act_nchw_kernel (16-bit types: the sum rounded once), and
+// a maximum of rounded values is exact: the same numbers.  A workgroup owns 64 output columns of one output row of one image, 64
+// channels at a time; the transposition runs through LDS (reads coalesced along w, writes along c).
+template <typename E>
+__global__ __launch_bounds__(256) void stem_pool_rows_kernel(const typename E::T* __restrict__ x, const typename E::T* __restrict__ bias, int C,
+                                                             int H, int W, int Ho, int Wo, typename E::T* __restrict__ rows, int64_t ldr,
+                                                             unsigned int* __restrict__ amax) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z, oh = blockIdx.y, ow0 = blockIdx.x * 64, tid = threadIdx.x;
+  const int owl = tid & 63, cb = tid >> 6;
+  unsigned int mx = 0;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int ow = ow0 + owl;
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+      const int cl = cb + 4 * j, c = c0 + cl;
+      float m = 0.f;                                            // (every window holds its centre, and relu(.) >= 0)
+      if (ow < Wo && c < C) {
+        const float bv = E::load(bias + c);
+        const typename E::T* plane = x + ((int64_t)b * C + c) * H * W;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int ih = 2 * oh - 1 + dy;
+          if (ih < 0 || ih >= H) continue;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const int iw = 2 * ow - 1 + dx;
+            if (iw < 0 || iw >= W) continue;
+            const float v = E::round(E::load(plane + (int64_t)ih * W + iw) + bv);
+            m = fmaxf(m, v);                                    // (fmaxf(0, v) is the ReLU; a NaN input is not kept — nor by max_pool2d's >)
+          }
+        }
+      }
+      tile[owl][cl] = m;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+      const int ol = cb + 4 * j, ow2 = ow0 + ol, c = c0 + owl;
+      if (ow2 < Wo && c < C) {
+        const float v = tile[ol][owl];
+        E::store(rows + (((int64_t)b * Ho + oh) * Wo + ow2) * ldr + c, v);
+        mx = max(mx, __float_as_uint(v));
+      }
+    }
+    __syncthreads();
+  }
+  if (amax != nullptr) {
+    __shared__ unsigned int wmx[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned int)__shfl_xor((int)mx, off));
+    if ((tid & 63) == 0) wmx[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) {
+      mx = max(max(wmx[0], wmx[1]), max(wmx[2], wmx[3]));
+      if (mx) atomicMax(amax, mx);
+    }
+  }
+}
+
+template <typename E>
+static int stem_pool_rows(const void* x, const void* bias, int B, int C, int H, int W, void* rows, int64_t ldr, float* meta,
+                          odx_stream_t stream, const char* who) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return ODX_OK;
+  ODX_REQUIRE(x && bias && rows && ldr >= C, "%s: null pointer or row stride below the channel count", who);
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  ODX_REQUIRE(Ho <= 65535 && B <= 65535, "%s: at most 65535 output rows / images per call", who);
+  typedef typename E::T T;
+  hipLaunchKernelGGL((stem_pool_rows_kernel<E>), dim3((unsigned)ceil_div(Wo, 64), (unsigned)Ho, (unsigned)B), dim3(256), 0, as_stream(stream),
+                     static_cast<const T*>(x), static_cast<const T*>(bias), C, H, W, Ho, Wo, static_cast<T*>(rows), ldr,
+                     meta ? reinterpret_cast<unsigned int*>(meta + 1) : nullptr);
+  ODX_CHECK_LAUNCH(who);
+  return ODX_OK;
+}
+
+extern "C" int odx_stem_pool_rows_f32(const float* x, const float* bias, int B, int C, int H, int W, float* rows, int64_t ldr, float* meta,
+                                      odx_stream_t stream) {
+  return stem_pool_rows<EpiF32>(x, bias, B, C, H, W, rows, ldr, meta, stream, "odx_stem_pool_rows_f32");
+}
+
+extern "C" int odx_stem_pool_rows_16(const void* x, const void* bias, int is_bf16, int B, int C, int H, int W, void* rows, int64_t ldr,
+                                     odx_stream_t stream) {
+  return is_bf16 ? stem_pool_rows<EpiBF16>(x, bias, B, C, H, W, rows, ldr, nullptr, stream, "odx_stem_pool_rows_16")
+                 : stem_pool_rows<EpiF16>(x, bias, B, C, H, W, rows, ldr, nullptr, stream, "odx_stem_pool_rows_16");
+}
+
 extern "C" int odx_bias_act_nchw_f32(float* y, const float* bias, const float* residual, int64_t N, int C, int64_t HW, int relu,
                                      odx_stream_t stream) {
   return bias_act_nchw<EpiF32>(y, bias, residual, N, C, HW, relu, stream, "odx_bias_act_nchw_f32");

@@ -957,6 +957,26 @@ class HipBackend:
             hip.check(self.lib.odx_taps3x3_packed(_p(A.P), A.P.stride(0), R, H, W, C, _p(T.P), T.P.stride(0), self._stream()), "odx_taps3x3_packed")
         return self.chain_gemm(T, B, bias=bias, relu=relu, bounds=bounds, f32_out=f32_out, zero_row=zero_row)
 
+    def stem_pool_rows(self, y, bias):
+        """The stem's tail in one pass (odx_stem_pool_rows_f32 / _16): y (B, C, H, W) the 7 x 7 convolution's output WITHOUT its
+        bias, contiguous, f32 / bf16 / f16 -> relu(y + bias), max-pooled 3 x 3 / 2 / 1, as NHWC rows.  f32: (rows (B Ho Wo, C),
+        (B, Ho, Wo), meta words with max |rows|); 16 bits: (Rows16 with a zero row, (B, Ho, Wo), None)."""
+        B, C, H, W = y.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        if not y.is_contiguous():
+            raise ValueError("stem_pool_rows: a contiguous (B, C, H, W) map expected")
+        bias = bias.to(device=self.device, dtype=y.dtype).contiguous()
+        if y.dtype == torch.float32:
+            rows = torch.empty((B * Ho * Wo, C), dtype=torch.float32, device=self.device)
+            om = self._meta_slot()
+            hip.check(self.lib.odx_stem_pool_rows_f32(_p(y), _p(bias), B, C, H, W, _p(rows), C, _p(om), self._stream()), "odx_stem_pool_rows_f32")
+            return rows, (B, Ho, Wo), om
+        ld = (C + 127) // 128 * 128
+        buf = torch.zeros((B * Ho * Wo + 1, ld), dtype=y.dtype, device=self.device)         # (pad columns and the zero row)
+        hip.check(self.lib.odx_stem_pool_rows_16(_p(y), _p(bias), int(y.dtype == torch.bfloat16), B, C, H, W, _p(buf), ld, self._stream()),
+                  "odx_stem_pool_rows_16")
+        return Rows16(buf[:B * Ho * Wo], C, True), (B, Ho, Wo), None
+
     def upsample_add_rows(self, lat, top, B, H, W, Hp, Wp):
         """The top-down step of a feature pyramid on NHWC rows, in place: lat (B H W, C) f32 += top (B Hp Wp, C) at the nearest-
         neighbour source row (odx_upsample_add_rows_f32).  Returns the meta words holding max |sum| — what `packed` / `conv3x3_rows`

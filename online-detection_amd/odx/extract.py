@@ -288,6 +288,24 @@ class _FoldedBN(nn.Module):
         return F.relu(y if residual is None else y + residual)
 
 
+def _stem_rows(net, x):
+    """The stem of a ResNet trunk (net.conv1 / net.bn1, 3 x 3 / 2 max pooling) for the row-GEMM stages: the 7 x 7 convolution by the
+    convolution library WITHOUT its bias, then bias + ReLU + pooling + the change to NHWC rows + the maximum the first packing
+    needs as ONE pass (HipBackend.stem_pool_rows) -> what _stages_rows / _stages_rows16 take for `y`: (rows, (B, h, w), meta).
+    Where that pass does not apply (the CPU, gradients, operand types that differ): the pooled (B, C, h, w) map as before."""
+    be = _backend.get_backend()
+    dt = torch.get_autocast_dtype("cuda") if (x.is_cuda and torch.is_autocast_enabled("cuda")) else x.dtype
+    if dt in (torch.bfloat16, torch.float16) and x.dtype != dt and x.is_cuda and not torch.is_grad_enabled():
+        x = x.to(dt)                                     # (autocast's own cast of the image, made once here)
+    conv, bn = net.conv1, net.bn1
+    wb = net._fold("conv1", conv, bn, x)
+    if (_fused_epilogue(x, wb[0]) and hasattr(be, "stem_pool_rows") and os.environ.get("ODX_STEM", "fused") != "library"):
+        y = F.conv2d(x, wb[0], None, conv.stride, conv.padding)
+        if y.is_contiguous():
+            return be.stem_pool_rows(y, wb[1])
+    return F.max_pool2d(net.conv_bn_act("conv1", "bn1", x), 3, 2, 1)
+
+
 def _fused_epilogue(x, w):
     """The trunk's bias / residual / ReLU epilogue runs as one HIP pass (HipBackend.bias_act_): GPU maps in the dtype the
     convolution computes in (f32, or a trunk run natively in bf16 / f16; under autocast the operands differ and the library
@@ -448,8 +466,12 @@ def _stages_rows(be, y, stages, pack_last=False):
     y becomes NHWC rows once; a block's stride is applied to its input rows (the positions a strided 1 x 1 convolution
     reads).  Returns, per stage, (out, (B, H, W)): out = the stage's last block's output — backend.PackedRows (f32 rows .X and
     the packed operand) for every stage but the last, whose output is plain f32 rows unless pack_last."""
-    B, C, H, W = y.shape
-    x, meta, outs = y.permute(0, 2, 3, 1).reshape(B * H * W, C), None, []
+    if isinstance(y, tuple):                                    # (_stem_rows: already rows, with the maximum of the matrix)
+        x, (B, H, W), meta = y
+        outs = []
+    else:
+        B, C, H, W = y.shape
+        x, meta, outs = y.permute(0, 2, 3, 1).reshape(B * H * W, C), None, []
     blocks = [(si, blk) for si, stage in enumerate(stages) for blk in stage]
     for k, (si, blk) in enumerate(blocks):
         st = blk.conv1.stride[0]
@@ -471,8 +493,11 @@ def _stages_rows16(be, y, stages):
     """_stages_rows for a forward run in bf16 / f16: y (B, C, H, W) the stem's output in the 16-bit type; every bottleneck on
     16-bit rows (_bottleneck_rows_b16: one MFMA term per product, f32 sums, one rounding per layer — no packing, no scales).
     Returns, per stage, (backend.Rows16, (B, H, W))."""
-    B, C, H, W = y.shape
-    x = be.rows16(y.permute(0, 2, 3, 1).reshape(B * H * W, C), y.dtype)
+    if isinstance(y, tuple):                                    # (_stem_rows: Rows16 already)
+        x, (B, H, W), _ = y
+    else:
+        B, C, H, W = y.shape
+        x = be.rows16(y.permute(0, 2, 3, 1).reshape(B * H * W, C), y.dtype)
     outs = []
     blocks = [(si, blk) for si, stage in enumerate(stages) for blk in stage]
     for k, (si, blk) in enumerate(blocks):
@@ -515,8 +540,7 @@ class ResNet50C4(_FoldedBN):
         """forward_rows for a forward run in bf16 / f16 (x: the image, under the caller's autocast): the stem by the convolution
         library in the 16-bit type, the three stages on 16-bit rows (_stages_rows16).  Returns (backend.Rows16, (B, h, w))."""
         be = _backend.get_backend()
-        y = F.max_pool2d(self.conv_bn_act("conv1", "bn1", x), 3, 2, 1)
-        return _stages_rows16(be, y, (self.layer1, self.layer2, self.layer3))[-1]
+        return _stages_rows16(be, _stem_rows(self, x), (self.layer1, self.layer2, self.layer3))[-1]
 
     def forward_rows(self, x):
         """The trunk on this library's tile cores (f32 on the GPU): the stem (7 x 7 convolution, max pooling) by the convolution
@@ -527,8 +551,7 @@ class ResNet50C4(_FoldedBN):
         (B h w, C) f32, (B, h, w)); the map as the callers know it is rows.view(B, h, w, C).permute(0, 3, 1, 2) — a
         channels-last view, no copy."""
         be = _backend.get_backend()
-        y = F.max_pool2d(self.conv_bn_act("conv1", "bn1", x), 3, 2, 1)
-        return _stages_rows(be, y, (self.layer1, self.layer2, self.layer3))[-1]
+        return _stages_rows(be, _stem_rows(self, x), (self.layer1, self.layer2, self.layer3))[-1]
 
 
 class Conv5Head(nn.Module):

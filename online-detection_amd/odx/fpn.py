@@ -30,7 +30,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import backend as _backend
-from .extract import (DELTA_CLAMP, FrozenBatchNorm2d, _FoldedBN, _nms_takes_max_keep, _stage, _stages_rows, _stages_rows16,
+from .extract import (DELTA_CLAMP, FrozenBatchNorm2d, _FoldedBN, _nms_takes_max_keep, _stage, _stages_rows, _stages_rows16, _stem_rows,
                       _stages_rows_form, cell_anchors, decode_deltas, grid_anchors)
 
 
@@ -59,14 +59,12 @@ class ResNet50Stages(_FoldedBN):
 
     def forward_rows16(self, x):
         """forward_rows for a trunk run natively in bf16 / f16 (x in that type): [(backend.Rows16 of C2 .. C5, (B, h, w))]."""
-        y = F.max_pool2d(self.conv_bn_act("conv1", "bn1", x), 3, 2, 1)
-        return _stages_rows16(_backend.get_backend(), y, (self.layer1, self.layer2, self.layer3, self.layer4))
+        return _stages_rows16(_backend.get_backend(), _stem_rows(self, x), (self.layer1, self.layer2, self.layer3, self.layer4))
 
     def forward_rows(self, x):
         """The four stages as one chain of row GEMMs on the split-f16 tile cores behind the library's stem (extract._stages_rows):
         [(backend.PackedRows of C2 .. C5 — f32 rows and packed operand —, (B, h, w))]."""
-        y = F.max_pool2d(self.conv_bn_act("conv1", "bn1", x), 3, 2, 1)
-        return _stages_rows(_backend.get_backend(), y, (self.layer1, self.layer2, self.layer3, self.layer4), pack_last=True)
+        return _stages_rows(_backend.get_backend(), _stem_rows(self, x), (self.layer1, self.layer2, self.layer3, self.layer4), pack_last=True)
 
 
 class FeaturePyramid(nn.Module):

@@ -137,6 +137,8 @@ SIGNATURES = {
     "odx_gemm_b16_taps": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _vp]),
     "odx_roi_align_fpn_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "odx_roi_align_fpn_nhwc_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "odx_stem_pool_rows_f32": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "odx_stem_pool_rows_16": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp]),
     "odx_upsample_add_rows_f32": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "odx_upsample_add_rows_16": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "odx_roi_align_fpn_nhwc_16": (_i32, [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),

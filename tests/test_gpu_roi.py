@@ -226,3 +226,29 @@ def test_nms_compact_packs_the_first_survivors(be, B, R, P):
         assert bool((out[b, len(want):] == torch.tensor([0.0, 0.0, 15.0, 15.0], device="cuda")).all())
     out2, n2 = be.nms_compact(boxes, keep.to(torch.uint8), P)                       # no counts: every set holds R boxes
     assert [int(v) for v in n2] == [min(P, int(keep[b].sum())) for b in range(B)]
+
+
+def test_stem_pool_rows_equals_epilogue_pooling_and_transposition():
+    """odx_stem_pool_rows_f32 / _16 (bias + ReLU + 3 x 3 / 2 / 1 max pooling + NCHW -> NHWC rows + the maximum, one pass) = the
+    in-place epilogue (bias_act_), the library's max_pool2d and the permuting copy it replaces, bit for bit: even and odd map
+    sizes (a last window hanging over the border), channel counts below / at / above one 64-channel pass, f32 and both 16-bit
+    types (whose sums are rounded once, as odx_bias_act_nchw_16 does)."""
+    import torch.nn.functional as F
+    import odx
+    be = odx.get_backend()
+    g = torch.Generator().manual_seed(12)
+    for (B, C, H, W) in ((2, 64, 30, 40), (1, 16, 7, 9), (3, 72, 33, 130), (1, 64, 300, 400)):
+        x = torch.randn((B, C, H, W), generator=g).cuda()
+        bias = torch.randn(C, generator=g).cuda()
+        want = F.max_pool2d(be.bias_act_(x.clone(), bias, None, relu=True), 3, 2, 1)
+        rows, (b2, Ho, Wo), meta = be.stem_pool_rows(x, bias)
+        assert (b2, Ho, Wo) == (B, want.shape[2], want.shape[3]) and rows.shape == (B * Ho * Wo, C)
+        assert torch.equal(rows.view(B, Ho, Wo, C).permute(0, 3, 1, 2), want)
+        assert meta.view(torch.int32)[1].item() == want.abs().max().view(torch.int32).item()
+        for dt in (torch.bfloat16, torch.float16):
+            x16, b16 = x.to(dt), bias.to(dt)
+            want16 = F.max_pool2d(be.bias_act_(x16.clone(), b16, None, relu=True), 3, 2, 1)
+            r16, dims, none = be.stem_pool_rows(x16, b16)
+            assert none is None and dims == (B, Ho, Wo) and r16.zero_row and r16.K == C
+            assert torch.equal(r16.dense.reshape(B, Ho, Wo, C).permute(0, 3, 1, 2), want16), dt
+            assert float(r16.buf[:, C:].abs().max()) == 0.0 if r16.buf.shape[1] > C else True
