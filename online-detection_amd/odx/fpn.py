@@ -444,6 +444,15 @@ class OnlineDetectionModelFPN(nn.Module):
         dt16 = self.compute_dtype if self.compute_dtype in (torch.bfloat16, torch.float16) else None
         rows16_head = (dt16 is not None and trunk[0].dtype == dt16 and not torch.is_grad_enabled() and hasattr(be, "conv3x3_rows16")
                        and self.rpn_conv.in_channels % 8 == 0 and __import__("os").environ.get("ODX_TRUNK", "rows") != "conv")
+        side = cur = None
+        if (rows_head or rows16_head) and __import__("os").environ.get("ODX_RPN_SELECT_STREAM", "1") != "0" and not torch.cuda.is_current_stream_capturing():
+            from . import streams as _streams
+            own = _streams.distinct(1)
+            if own:
+                side, cur = own[0], torch.cuda.current_stream()
+                side.wait_stream(cur)                         # (cand / score were filled on this stream)
+                cand.record_stream(side)
+                score.record_stream(side)
         for lvl, p in enumerate(trunk):
             if rows16_head:
                 # (the same on 16-bit rows: odx_gemm_b16_taps / odx_gemm_b16, the outputs in f32)
@@ -471,9 +480,24 @@ class OnlineDetectionModelFPN(nn.Module):
                     a = F.relu(F.conv2d(p, w[0], w[1], 1, 1))
                     logits, deltas = F.conv2d(a, w[2], w[3]).float(), F.conv2d(a, w[4], w[5]).float()
             _, A, H, W = logits.shape
-            b, sc, _ = be.rpn_topk_decode(logits, deltas, self._anchors(lvl, H, W, dev), ks[lvl], img_size, DELTA_CLAMP)
+            anchors = self._anchors(lvl, H, W, dev)
+            if side is not None:
+                # a level's selection kernel is ONE workgroup per image (a sort of its candidates: 50 .. 280 us on eight of the
+                # chip's 256 CUs): on a stream of its own it runs under the NEXT level's head products instead of between them
+                # (0.6 ms of the five selections of a group of 8 were serial)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    b, sc, _ = be.rpn_topk_decode(logits, deltas, anchors, ks[lvl], img_size, DELTA_CLAMP)
+                    cand[:, lvl, :ks[lvl]] = b
+                    score[:, lvl, :ks[lvl]] = sc
+                for t_ in (logits, deltas):
+                    t_.record_stream(side)
+                continue
+            b, sc, _ = be.rpn_topk_decode(logits, deltas, anchors, ks[lvl], img_size, DELTA_CLAMP)
             cand[:, lvl, :ks[lvl]] = b
             score[:, lvl, :ks[lvl]] = sc
+        if side is not None:
+            cur.wait_stream(side)
         # (the candidate counts of the B x 5 sets depend on the image size only: uploaded once — a host-to-device copy of pageable
         # memory waits for the stream, here in the middle of the forward)
         ckey = (B, tuple(ks), str(dev))
