@@ -1128,8 +1128,10 @@ def forward_batch(model, images, gt_boxes_list=None, want_rpn_activation=False):
             bx = torch.cat((gt.to(bx.device).float(), bx), dim=0)
         boxes_list.append(bx)
     counts = [int(bx.shape[0]) for bx in boxes_list]
-    # (host lists go up through harvest.to_device: a plain copy of pageable memory waits for whatever the GPU is running)
-    bidx = torch.repeat_interleave(torch.arange(B, device=tr0.device), to_device(torch.tensor(counts, dtype=torch.int64), tr0.device))
+    # (the image index of every RoI from B fills: an upload of the counts waits for whatever the GPU is running, and
+    # repeat_interleave with a tensor of repeats reads their sum back — two more stalls of the host right behind the proposal
+    # stage's own read, while the GPU has nothing queued)
+    bidx = torch.cat([torch.full((c,), b, dtype=torch.int64, device=tr0.device) for b, c in enumerate(counts)])
     maps = model.roi_head_maps(trunk, torch.cat(boxes_list, dim=0), batch_idx=bidx)
     feats = maps.mean(dim=(2, 3))
     offs = [0]
