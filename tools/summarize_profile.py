@@ -185,16 +185,20 @@ for tag, title in (("forward_b4", "R-50-C4 forward, FOUR 600 x 800 images per ca
                     "solver search on the first calls runs its naive reference kernels once per shape — left out of the table; the percentages "
                     "are of the process's total including them)\n" % title)
 
-for tag, anchor in (("forward_b8", "max_pool"), ("forward_fpn_b8", "max_pool")):
+for tag, anchors in (("forward_b8", ("stem_pool_rows", "max_pool")), ("forward_fpn_b8", ("stem_pool_rows", "max_pool"))):
     tp = os.path.join(d, "x_%s_kernel_trace.csv" % tag)
     if os.path.exists(tp):
         import csv as _csv
         rows = sorted(_csv.DictReader(open(tp)), key=lambda r: int(r["Start_Timestamp"]))
-        idx = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
+        idx = []
+        for anchor in anchors:                   # (the stem's fused tail; the library's pooling in profiles made before it)
+            idx = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
+            if idx:
+                break
         if idx:
             i0 = idx[-1]
             t0 = int(rows[i0]["Start_Timestamp"])
-            print("\n### kernel timeline of the last call of %s (us from its max pooling; launches of 20 us and more)\n" % tag)
+            print("\n### kernel timeline of the last call of %s (us from the stem's pooling; launches of 20 us and more)\n" % tag)
             print("| start | us | kernel | grid |\n|---|---|---|---|")
             busy = 0.0
             for r in rows[max(i0 - 3, 0):]:
