@@ -1158,7 +1158,7 @@ static int bias_act_nchw(void* y, const void* bias, const void* residual, int64_
 // map and a pass for its maximum.  Per element the arithmetic of bias_act_nchw_kernel (16-bit types: the sum rounded once), and
 // a maximum of rounded values is exact: the same numbers.  A workgroup owns 64 output columns of one output row of one image, 64
 // channels at a time; the transposition runs through LDS (reads coalesced along w, writes along c).
-template <typename E>
+template <typename E, bool PAIRS>
 __global__ __launch_bounds__(256) void stem_pool_rows_kernel(const typename E::T* __restrict__ x, const typename E::T* __restrict__ bias, int C,
                                                              int H, int W, int Ho, int Wo, typename E::T* __restrict__ rows, int64_t ldr,
                                                              unsigned int* __restrict__ amax) {
@@ -1172,7 +1172,26 @@ __global__ __launch_bounds__(256) void stem_pool_rows_kernel(const typename E::T
     for (int j = 0; j < 16; ++j) {
       const int cl = cb + 4 * j, c = c0 + cl;
       float m = 0.f;                                            // (every window holds its centre, and relu(.) >= 0)
-      if (ow < Wo && c < C) {
+      if (PAIRS) {
+        // even W, f32: a lane reads the aligned PAIR (2 ow, 2 ow + 1) of each of the three rows — whole lines per wave instead of
+        // three stride-2 reads — and takes 2 ow - 1 from its left neighbour (the wave's first lane reads it itself)
+        const bool ok = ow < Wo && c < C;
+        const float bv = ok ? E::load(bias + c) : 0.f;
+        const typename E::T* plane = x + ((int64_t)b * C + (c < C ? c : 0)) * H * W;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int ih = 2 * oh - 1 + dy;
+          const bool rok = ok && ih >= 0 && ih < H;
+          float2 pr = {0.f, 0.f};
+          if (rok) pr = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(plane) + (int64_t)ih * W + 2 * ow);
+          float left = __shfl_up(pr.y, 1);
+          if (owl == 0 && rok && ow > 0) left = reinterpret_cast<const float*>(plane)[(int64_t)ih * W + 2 * ow - 1];
+          if (rok) {
+            m = fmaxf(m, fmaxf(pr.x + bv, pr.y + bv));
+            if (ow > 0) m = fmaxf(m, left + bv);
+          }
+        }
+      } else if (ow < Wo && c < C) {
         const float bv = E::load(bias + c);
         const typename E::T* plane = x + ((int64_t)b * C + c) * H * W;
 #pragma unroll
@@ -1223,9 +1242,14 @@ static int stem_pool_rows(const void* x, const void* bias, int B, int C, int H, 
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   ODX_REQUIRE(Ho <= 65535 && B <= 65535, "%s: at most 65535 output rows / images per call", who);
   typedef typename E::T T;
-  hipLaunchKernelGGL((stem_pool_rows_kernel<E>), dim3((unsigned)ceil_div(Wo, 64), (unsigned)Ho, (unsigned)B), dim3(256), 0, as_stream(stream),
-                     static_cast<const T*>(x), static_cast<const T*>(bias), C, H, W, Ho, Wo, static_cast<T*>(rows), ldr,
-                     meta ? reinterpret_cast<unsigned int*>(meta + 1) : nullptr);
+  const dim3 grid((unsigned)ceil_div(Wo, 64), (unsigned)Ho, (unsigned)B);
+  unsigned int* amax = meta ? reinterpret_cast<unsigned int*>(meta + 1) : nullptr;
+  if (sizeof(T) == 4 && W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7u) == 0)
+    hipLaunchKernelGGL((stem_pool_rows_kernel<E, true>), grid, dim3(256), 0, as_stream(stream), static_cast<const T*>(x),
+                       static_cast<const T*>(bias), C, H, W, Ho, Wo, static_cast<T*>(rows), ldr, amax);
+  else
+    hipLaunchKernelGGL((stem_pool_rows_kernel<E, false>), grid, dim3(256), 0, as_stream(stream), static_cast<const T*>(x),
+                       static_cast<const T*>(bias), C, H, W, Ho, Wo, static_cast<T*>(rows), ldr, amax);
   ODX_CHECK_LAUNCH(who);
   return ODX_OK;
 }
