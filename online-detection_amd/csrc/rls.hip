@@ -546,8 +546,8 @@ __global__ __launch_bounds__(256) void rls_xty_reduce_kernel(const double* __res
 // P[i][k] for the rows of ALL classes with one launch: row i belongs to the class whose [start, start + len) holds it.  A wave
 // takes RP_R consecutive rows of ONE class: the class's four weight rows are read once per column chunk for all of them (a row
 // of its own per wave read 32 KB of weights from the caches for every 4 KB row from memory — the kernel ran at 2.2 TB/s).
-// sg.off[c] = first row of class c, sg.len[c] = first row GROUP of class c.  Per row the sums run in the order of the one-row
-// kernel above (lane's chunks ascending, then the butterfly): the same bits.
+// sg.off[c] = first row of class c, sg.len[c] = first row GROUP of class c.  Per row the sums run in the order of the one-row-per-wave
+// form of this kernel (lane's chunks ascending, then the butterfly).
 constexpr int RP_R = 4;
 
 __global__ __launch_bounds__(256) void rls_predict_rows_batched_kernel(const float* __restrict__ X, int64_t ldx, int D,

@@ -168,6 +168,30 @@ def test_rls_grams_from_rows_equal_the_transposed_copy_form(hip_backend, monkeyp
                 assert float((wa - wb).abs().max()) <= 1e-6 * max(1.0, float(wb.abs().max())), (other, c, k)
 
 
+def test_rls_batched_predictions_equal_the_one_class_kernel(hip_backend):
+    """odx_rls_predict_rows_batched_f64 (a wave takes four consecutive rows of ONE class and reads the class's weight rows once per
+    column chunk for all of them) = odx_rls_predict_rows_f64 class by class to f64 rounding (the two kernels add a row's products
+    in different orders: 1e-14 at D = 1024): class sizes that are not multiples of four, an empty class in the middle and at the
+    end, a feature count with a ragged last float4 (D = 70)."""
+    from odx.backend import Features
+    rng = np.random.default_rng(17)
+    for D in (70, 72, 1024):
+        sizes = [5, 0, 16, 33, 1, 7, 0]
+        n = sum(sizes)
+        X = torch.from_numpy(rng.standard_normal((n + 11, D)).astype(np.float32)).cuda()
+        F = hip_backend.features(X)
+        ld = (D + 2) // 2 * 2
+        W = torch.from_numpy(rng.standard_normal((len(sizes), 4, ld))).cuda()
+        rows = torch.from_numpy(rng.permutation(n + 11)[:n]).cuda()
+        starts = [int(v) for v in np.concatenate(([0], np.cumsum(sizes)[:-1]))]
+        got = torch.empty((n, 4), dtype=torch.float64, device="cuda")
+        hip_backend.rls_predict_rows_batched(F, rows, starts, W, got)
+        for c, (s0, k) in enumerate(zip(starts, sizes)):
+            if k:
+                want = hip_backend.rls_predict_rows(F, rows[s0:s0 + k].contiguous(), W[c])
+                assert float((got[s0:s0 + k] - want).abs().max()) <= 1e-13 * max(1.0, float(want.abs().max())), (D, c)
+
+
 def test_rls_pad_index_equals_the_tensor_statements(hip_backend):
     """odx_rls_pad_index (the padded row-id array of a class batch and its inverse maps, one launch) against the tensor
     statements it replaced in rls.py: ragged classes, an empty one in the middle and at the end, segments padded to 16."""
