@@ -333,7 +333,8 @@ __global__ __launch_bounds__(256, 3) void rls_gram_rows_kernel(const float* __re
 // matrix instructions' operands — six conversions per eight MFMAs, on the vector ALU beside them): the LDS footprint of the
 // 16-row f64 form, HALF the barriers per matrix instruction (two per 64 instead of two per 32: the waves of a workgroup sit on
 // four SIMDs whose other residents differ, and every barrier makes the fastest wait for the slowest), half the LDS bytes
-// written and read.  Same order of the sum over k per output, same outputs (the conversion is exact either way).
+// written and read.  Same order of the sum over k per output: the lower triangle comes out bit for bit as from the 16-row form (the
+// conversion is exact either way; checked by hashing both); above the diagonal the half tiles leave their unused block unwritten.
 constexpr int RG32_BK = 32;
 constexpr int RG32_LDA = RG_BM + 16, RG32_LDB = RG_BN + 16;   // floats per LDS row: 16 banks further per k-row (the four k-rows a
                                                                // 64-lane ds_read_b32 touches fall on four different bank quarters)
