@@ -1,7 +1,8 @@
 // What the f64 matrix pipe sustains (gfx950): v_mfma_f64_16x16x4_f64 from registers only — eight independent accumulators per wave,
 // the same operands every time — with 1, 2, 3, 4 waves per SIMD on every CU.  TFLOP/s against the 78.6 of the data sheet, and the
 // cycles per instruction per SIMD it implies at the clock the run held.  The RLS Gram kernel (rls_gram_rows32_kernel) issues
-// exactly this instruction mix plus LDS reads: its 67 % of the data-sheet rate is judged against THIS number.
+// exactly this instruction mix plus LDS reads: its rate is judged against THIS number (32 instructions per loop trip: with eight,
+// the loop's own instructions and its taken branch cost a quarter).
 // Build: hipcc -O3 --offload-arch=gfx950 tools/micro/mfma_f64_rate.hip -o gpurun_out/mfma_f64_rate ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -12,9 +13,11 @@ __global__ __launch_bounds__(256) void k_mfma_f64(double* out, int iters) {
   f64x4 acc[8];
   for (int k = 0; k < 8; ++k) acc[k] = f64x4{0.0, 0.0, 0.0, 0.0};
   const double a = 1.0 + threadIdx.x * 1e-3, b = 0.5 - threadIdx.x * 1e-3;
-  for (int i = 0; i < iters; ++i) {
+  for (int i = 0; i < iters; i += 4) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[k], 0, 0, 0);
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[k], 0, 0, 0);
   }
   double s = 0.0;
   for (int k = 0; k < 8; ++k) s += acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3];
@@ -25,9 +28,11 @@ __global__ __launch_bounds__(256) void k_mfma_f64(double* out, int iters) {
 __global__ __launch_bounds__(256) void k_mfma_f64_4x4(double* out, int iters) {
   double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const double a = 1.0 + threadIdx.x * 1e-3, b = 0.5 - threadIdx.x * 1e-3;
-  for (int i = 0; i < iters; ++i) {
+  for (int i = 0; i < iters; i += 4) {            // (32 instructions per trip: the loop's own instructions must not count)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[k], 0, 0, 0);
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc[k], 0, 0, 0);
   }
   double s = 0.0;
   for (int k = 0; k < 8; ++k) s += acc[k];
