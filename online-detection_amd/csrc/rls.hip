@@ -3,7 +3,6 @@
 // following RegionRefinerTrainer.solve (train_region_refiner.py:100-119).  The Gram is an
 // NT GEMM on the f64 MFMA core over a gathered, transposed, bias-augmented f64 copy of the
 // class's rows, formed chunk by chunk so that row shards / chunks simply accumulate.
-#include <type_traits>
 #include <stdlib.h>
 #include "odx_internal.h"
 
@@ -340,7 +339,7 @@ constexpr int RG32_BK = 32;
 constexpr int RG32_LDA = RG_BM + 16, RG32_LDB = RG_BN + 16;   // floats per LDS row: 16 banks further per k-row (the four k-rows a
                                                                // 64-lane ds_read_b32 touches fall on four different bank quarters)
 
-__global__ __launch_bounds__(256, 2) void rls_gram_rows32_kernel(const float* __restrict__ X, int64_t ldx, int D,
+__global__ __launch_bounds__(256, 3) void rls_gram_rows32_kernel(const float* __restrict__ X, int64_t ldx, int D,
                                                                  const int64_t* __restrict__ idx, RlsSegs sg, double* __restrict__ G,
                                                                  int64_t ldg, int64_t g_stride, const float* __restrict__ Yraw,
                                                                  int64_t ldyr, double* __restrict__ O5, int64_t ldo) {
@@ -410,13 +409,6 @@ __global__ __launch_bounds__(256, 2) void rls_gram_rows32_kernel(const float* __
   load(row_of(0, 0), 0);
   load(row_of(0, 1), 1);
   const int r16 = lane & 15, kq = lane >> 4;
-  // The walk over the k-tiles, instantiated for (targets' products, half tile) as COMPILE-TIME cases: with the two conditions
-  // tested inside the eight k-steps, every step of a plain tile ended in a taken branch — from registers alone a taken branch per
-  // eight 64-cycle matrix instructions costs the stream a quarter of its rate (tools/micro/mfma_f64_rate.hip: 47 against 66
-  // TFLOP/s); here it was worth 2.6 % (6.87 -> 6.69 ms).  The case is picked once per workgroup; 208 VGPRs, two workgroups per CU
-  // (three made no difference before).
-  auto walk = [&](auto xty_c, auto half_c) {
-  constexpr bool XTY = decltype(xty_c)::value, HALF = decltype(half_c)::value;
   for (int64_t kt = 0; kt < nk; ++kt) {
     __syncthreads();                                           // everyone finished reading the previous k-tile
 #pragma unroll
@@ -433,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void rls_gram_rows32_kernel(const float* __
         const float m = valid[h] && bok[q] ? 1.f : 0.f;
         *reinterpret_cast<f32x2r*>(db + q * 32) = f32x2r{m * rb[h][q][0], m * rb[h][q][1]};
       }
-      if (XTY && seg == 0) *reinterpret_cast<f32x4r*>(lds_y + (krow + 16 * h) * 4) = ry[h];   // (a padded row's A entries are zero)
+      if (xty && seg == 0) *reinterpret_cast<f32x4r*>(lds_y + (krow + 16 * h) * 4) = ry[h];   // (a padded row's A entries are zero)
     }
     __syncthreads();
     load(row_next[0], 0);
@@ -465,13 +457,13 @@ __global__ __launch_bounds__(256, 2) void rls_gram_rows32_kernel(const float* __
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[tm], bd[tn], acc[tm][tn], 0, 0, 0);
-      if (!HALF) {
+      if (!half) {
 #pragma unroll
         for (int tm = 2; tm < 4; ++tm)
 #pragma unroll
           for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[tm], bd[tn], acc[tm][tn], 0, 0, 0);
       }
-      if (XTY) {
+      if (xty) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           const int kr = ks * 4 + yhalf * 2 + r;
@@ -486,12 +478,6 @@ __global__ __launch_bounds__(256, 2) void rls_gram_rows32_kernel(const float* __
       }
     }
   }
-  };
-  typedef std::integral_constant<bool, true> yes_t;
-  typedef std::integral_constant<bool, false> no_t;
-  if (xty) walk(yes_t{}, no_t{});                              // (the first tile column is never the tile right of the diagonal)
-  else if (half) walk(no_t{}, yes_t{});
-  else walk(no_t{}, no_t{});
   if (xty) {
     __syncthreads();
     double* red = reinterpret_cast<double*>(lds_a);            // (5 x 128 doubles of the 32 x 144 floats)

@@ -9,9 +9,9 @@
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <bool G, bool S, bool D2>
+template <bool G, bool S, bool D2, bool DB>
 __global__ __launch_bounds__(256) void stage(const float* __restrict__ X, int64_t ldx, int64_t rows, double* out, int tiles) {
-  __shared__ float lds[32 * 208];
+  __shared__ float lds[(DB ? 2 : 1) * 32 * 208];              // DB: two tile buffers, ONE barrier per tile (stores go to the other one)
   const int t = threadIdx.x, krow = t >> 4, seg = t & 15;
   for (int e = t; e < 32 * 208; e += 256) lds[e] = 0.001f * (e & 63);
   __syncthreads();
@@ -25,11 +25,16 @@ __global__ __launch_bounds__(256) void stage(const float* __restrict__ X, int64_
 #pragma unroll
       for (int q = 0; q < 12; ++q) { const f32x2 tmp = r[q]; r[q] = r2[q]; r2[q] = tmp; }      // (r: the older set; unrolled by two in a kernel)
     }
-    if (S) {
+    const int cur = DB ? (kt & 1) * 32 * 208 : 0, nxt = DB ? ((kt + 1) & 1) * 32 * 208 : 0;
+    if (S && !DB) {
       __syncthreads();
 #pragma unroll
       for (int q = 0; q < 12; ++q) *reinterpret_cast<f32x2*>(lds + ((krow + 16 * (q / 6)) * 208 + (q % 6) * 32 + seg * 2)) = r[q];
       __syncthreads();
+    }
+    if (S && DB) {
+#pragma unroll
+      for (int q = 0; q < 12; ++q) *reinterpret_cast<f32x2*>(lds + nxt + ((krow + 16 * (q / 6)) * 208 + (q % 6) * 32 + seg * 2)) = r[q];
     }
     if (G) {
       const float* x0 = X + row * ldx + seg * 2;
@@ -45,34 +50,35 @@ __global__ __launch_bounds__(256) void stage(const float* __restrict__ X, int64_
     for (int ks = 0; ks < 8; ++ks) {
       float f[6];
 #pragma unroll
-      for (int q = 0; q < 6; ++q) f[q] = lds[(ks * 4 + (t >> 4 & 3)) * 208 + q * 16 + (t & 15)];
+      for (int q = 0; q < 6; ++q) f[q] = lds[cur + (ks * 4 + (t >> 4 & 3)) * 208 + q * 16 + (t & 15)];
       double d[6];
 #pragma unroll
       for (int q = 0; q < 6; ++q) d[q] = (double)f[q];
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(d[k & 3], d[4 + (k & 1)], acc[k], 0, 0, 0);
     }
+    if (S && DB) __syncthreads();
   }
   double s = 0.0;
   for (int k = 0; k < 8; ++k) s += acc[k][0] + acc[k][3];
   out[blockIdx.x * 256 + t] = s + r[0][0] + r[11][1];
 }
 
-template <bool G, bool S, bool D2>
+template <bool G, bool S, bool D2, bool DB>
 static void run(int cus, const float* X, int64_t rows, double* out) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   const int tiles = 2000, w = 3;
-  hipLaunchKernelGGL((stage<G, S, D2>), dim3(cus * w), dim3(256), 0, 0, X, (int64_t)1024, rows, out, 10);
+  hipLaunchKernelGGL((stage<G, S, D2, DB>), dim3(cus * w), dim3(256), 0, 0, X, (int64_t)1024, rows, out, 10);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  hipLaunchKernelGGL((stage<G, S, D2>), dim3(cus * w), dim3(256), 0, 0, X, (int64_t)1024, rows, out, tiles);
+  hipLaunchKernelGGL((stage<G, S, D2, DB>), dim3(cus * w), dim3(256), 0, 0, X, (int64_t)1024, rows, out, tiles);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0.f;
   hipEventElapsedTime(&ms, e0, e1);
-  printf("global loads %s, LDS stores between barriers %s, stored %s later: %.1f TFLOP/s\n", G ? "yes" : "no", S ? "yes" : "no", D2 ? "two tiles" : "one tile",
+  printf("global loads %s, LDS stores between barriers %s, stored %s later%s: %.1f TFLOP/s\n", G ? "yes" : "no", S ? "yes" : "no", D2 ? "two tiles" : "one tile", DB ? ", two LDS buffers and one barrier per tile" : "",
          (double)w * tiles * 64 * 4.0 * cus * 2048.0 / ms / 1e9);
 }
 
@@ -86,10 +92,12 @@ int main() {
   hipDeviceProp_t p;
   hipGetDeviceProperties(&p, 0);
   const int cus = p.multiProcessorCount;
-  run<false, false, false>(cus, X, rows, out);
-  run<false, true, false>(cus, X, rows, out);
-  run<true, false, false>(cus, X, rows, out);
-  run<true, true, false>(cus, X, rows, out);
-  run<true, true, true>(cus, X, rows, out);
+  run<false, false, false, false>(cus, X, rows, out);
+  run<false, true, false, false>(cus, X, rows, out);
+  run<true, false, false, false>(cus, X, rows, out);
+  run<true, true, false, false>(cus, X, rows, out);
+  run<true, true, true, false>(cus, X, rows, out);
+  run<true, true, false, true>(cus, X, rows, out);
+  run<false, true, false, true>(cus, X, rows, out);
   return 0;
 }
