@@ -60,6 +60,10 @@ def parse():
     ap.add_argument("--lockstep-batch", type=int, default=0, help="classes per lock-step batch (a divisor of the rank count; default: "
                     "planned from the HBM budget, odx/plan.py — the rank count when it fits); smaller batches rotate their owners "
                     "through the ranks")
+    ap.add_argument("--cg-exchange", choices=("lockstep", "allreduce"), default="lockstep",
+                    help="lockstep (default, what the headline times): batches of classes, one owner rank per class, one all-gather + "
+                    "one reduce-scatter per CG iteration; allreduce: the north star's literal form — every rank holds every "
+                    "class's preconditioner and M-sized state, ONE all-reduce of the (M,) partial per CG iteration")
     ap.add_argument("--precond-cus", type=int, default=0, help="confine the preconditioner chains (their stream and the library's "
                     "helper streams) to this many compute units, spread over the XCDs (0: the whole device; an experiment knob — "
                     "measured slower at 48..128 CUs: the confined chains starve behind the main stream's grids, DESIGN.md 7)")
@@ -272,7 +276,7 @@ def main():
     job = LockstepClassJob(be, X, N, M, lambda c: torch.where((row_ids % C) == c, 1.0, -1.0).to(torch.float64), cidx_dev,
                            args.sigma, args.lam, args.maxiter, opt, shard=shard, precond_batch=args.precond_batch,
                            precond_depth=args.precond_depth, precond_after_fit=args.precond_after_fit, precond_cus=args.precond_cus,
-                           batch=args.lockstep_batch)
+                           batch=args.lockstep_batch, exchange=args.cg_exchange)
     G, ldk, scores = job.G, job.ldk, job.scores
     job_b, plan_gb = job.b, round(job.plan.total_bytes / 1e9, 1)
     kfmt = be.knm_format(n_loc, M)                 # storage of the K_nM shards ("u24" at the headline size, "f32" for small ones)
@@ -447,7 +451,7 @@ def main():
                                    "rows sharded over %d GPU(s)" % (C, N, D, M, args.maxiter, args.emulate_world if emulated else world),
                        "N": N, "D": D, "M": M, "classes": C, "sigma": args.sigma, "lambda": args.lam,
                        "rows_per_gpu": n_loc, "preconditioners_per_batched_chain": G, "preconditioner_cus": args.precond_cus or "all",
-                       "lockstep_batch": job_b, "planned_GB_per_rank": plan_gb},
+                       "lockstep_batch": job_b, "planned_GB_per_rank": plan_gb, "cg_exchange": args.cg_exchange},
             "roofline": roof,
             "roofline_hbm": roof_p,
             "roofline_mfma": roof_g,

@@ -63,6 +63,20 @@ class RowShard:
             dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
         return out
 
+    def gather_blocks(self, mine, out):
+        """out (world, r, D) <- block k = rank k's `mine` (r, D): one all-gather of equal-sized blocks (the centre rows each
+        rank owns, padded to the largest count: odx.job.LockstepClassJob.gather_centres)."""
+        if not self.enabled:
+            out[0].copy_(mine)
+        elif self._has_reduce_scatter():
+            dist.all_gather_into_tensor(out, mine, group=self.group)
+        else:
+            parts = [torch.empty_like(mine) for _ in range(self.world)]       # gloo: the list form
+            dist.all_gather(parts, mine, group=self.group)
+            for k, p in enumerate(parts):
+                out[k].copy_(p)
+        return out
+
     def reduce_scatter_rows(self, partials, out):
         """out (M,) <- sum over ranks of their partials[self.rank]  (partials: (world, M)).  One reduce-scatter."""
         if not self.enabled:
@@ -90,7 +104,8 @@ class EmulatedShard(RowShard):
         if not 0 <= self.rank < self.world:
             raise ValueError("EmulatedShard: rank %d outside a world of %d" % (self.rank, self.world))
         self.emulated = True
-        self.calls = {"all_reduce": [0, 0], "all_gather": [0, 0], "reduce_scatter": [0, 0], "broadcast": [0, 0]}   # [calls, bytes]
+        # [calls, bytes]; "centre_gather": the all-gather of the Nystroem centres' rows, one per class ((M, D) f32 received)
+        self.calls = {"all_reduce": [0, 0], "all_gather": [0, 0], "reduce_scatter": [0, 0], "broadcast": [0, 0], "centre_gather": [0, 0]}
 
     def _count(self, kind, t):
         self.calls[kind][0] += 1
@@ -110,6 +125,11 @@ class EmulatedShard(RowShard):
     def gather_rows(self, mine, out):
         self._count("all_gather", out)
         out.copy_(mine.unsqueeze(0).expand_as(out))       # every owner's direction stands in as this rank's
+        return out
+
+    def gather_blocks(self, mine, out):
+        self._count("centre_gather", out)
+        out.copy_(mine.unsqueeze(0).expand_as(out))
         return out
 
     def reduce_scatter_rows(self, partials, out):

@@ -75,10 +75,19 @@ class LockstepClassJob:
 
     def __init__(self, be, X, n_total, M, labels, centre_idx, sigma, lam, maxiter=20, opt=None, shard=None,
                  precond_batch=0, precond_depth=2, precond_after_fit=False, classes=None, precond_cus=0, batch=0,
-                 hbm_bytes=None):
+                 hbm_bytes=None, exchange="lockstep"):
         """precond_batch: classes per rank and preconditioner chain (g; 0 = planned, 1 = one chain per class on `precond_depth`
         side streams); batch: classes per lock-step batch (b, a divisor of the world size; 0 = planned); hbm_bytes: the
-        memory the plan may count on per rank (default: the device's, 288 GB without one)."""
+        memory the plan may count on per rank (default: the device's, 288 GB without one).
+        exchange: "lockstep" — batches of b classes, one owner rank per class, per CG iteration one all-gather of the
+        directions and one reduce-scatter of the partials (what bench.py times); "allreduce" — the north star's literal form:
+        classes one at a time, EVERY rank builds every class's preconditioner and runs every M-sized product, per CG iteration
+        ONE all-reduce of the (M,) partial (solver.falkon_fit's replicated mode).  Same arithmetic per class either way."""
+        if exchange not in ("lockstep", "allreduce"):
+            raise ValueError("LockstepClassJob: exchange must be 'lockstep' or 'allreduce', got %r" % (exchange,))
+        self.exchange = exchange
+        if exchange == "allreduce":
+            batch = 1                             # one stored K_nM shard in flight; the plan's b = 1 line is this mode's memory
         self.be, self.X, self.N, self.M = be, X, int(n_total), int(M)
         self.labels, self.cidx = labels, centre_idx
         self.sigma, self.lam, self.maxiter = sigma, lam, maxiter
@@ -110,7 +119,8 @@ class LockstepClassJob:
         self.ld_p = (self.M + 1) // 2 * 2
         self.nslot = self.depth + 1
         self.sides = [_Side(dev, be, precond_cus, index=k) for k in range(self.nslot)] if self.G == 1 else []
-        self.gside = _Side(dev, be, precond_cus) if self.G > 1 else None
+        self.gside = _Side(dev, be, precond_cus) if (self.G > 1 or exchange == "allreduce") else None
+        self._cplans = {}        # class -> the centre-assembly plan of gather_centres (world > 1)
         self.pbuf, self.pgroup = [], []
         self.trace = []          # (kind, payload) records of the schedule this rank executed (tests read it)
         if self.G > 1 and hasattr(be, "precond_batched") and hasattr(be, "lib") and dev.type == "cuda":
@@ -126,18 +136,53 @@ class LockstepClassJob:
         self.kbufs, self.pbuf, self.pgroup, self.scores = [], [], [], None
 
     # ------------------------------------------------------------------ pieces
+    def _centre_plan(self, idx):
+        """Who owns which centre row (every row of X has exactly one owner rank): per class, once, from the job's inputs —
+        `mine` = local row ids of the centres this rank owns (in idx order), `cmax` = the largest count any rank owns (every
+        rank contributes a block of that many rows), `slot` = for centre p its row in the gathered (world x cmax) block."""
+        key = (idx.data_ptr(), int(idx.numel()))
+        plan = self._cplans.get(key)
+        if plan is None:
+            from .dist import shard_bounds
+            ih = idx.detach().cpu().to(torch.int64)
+            los = torch.tensor([shard_bounds(self.N, self.world, r)[0] for r in range(self.world)], dtype=torch.int64)
+            owner = torch.bucketize(ih, los, right=True) - 1
+            counts = torch.bincount(owner, minlength=self.world)
+            cmax = max(int(counts.max()), 1)
+            order = torch.argsort(owner, stable=True)                       # positions grouped by owner, idx order inside
+            starts = torch.cumsum(counts, 0) - counts
+            within = torch.empty_like(ih)
+            within[order] = torch.arange(ih.numel(), dtype=torch.int64) - starts[owner[order]]
+            mine = ih[owner == self.rank] - self.lo
+            dev = self.X.device
+            plan = (mine.to(dev), cmax, (owner * cmax + within).to(dev), int(counts[self.rank]))
+            self._cplans[key] = plan
+        return plan
+
     def gather_centres(self, idx):
-        """Z = X_global[idx]: every rank contributes the rows it owns, one all-reduce sums them."""
-        # no boolean-mask indexing here: it would make the host wait for the GPU (nonzero), and the ~1500 launches of the
-        # next preconditioner are then enqueued while the main stream has nothing to run (33 ms per class, measured)
+        """Z = X_global[idx].  Every centre row lives on exactly one rank: each rank contributes the rows it owns (padded to
+        the largest count over the ranks), ONE all-gather assembles them, a row gather puts them in idx order — (W - 1) / W
+        of the (M x D) block per rank on a ring, where the zero-padded all-reduce this replaces moved twice that and had
+        every rank write and sum a full block (round-5 review, weak 10)."""
+        # no boolean-mask indexing on device tensors here: it would make the host wait for the GPU (nonzero), and the ~1500
+        # launches of the next preconditioner are then enqueued while the main stream has nothing to run (33 ms per class,
+        # measured); the ownership plan is host arithmetic on the job's inputs, made once per class
         be, X = self.be, self.X
         if self.world == 1:
             return be.features(X.index_select(0, idx))
-        mine = (idx >= self.lo) & (idx < self.hi)
-        Z = X.index_select(0, (idx - self.lo).clamp_(0, max(self.n_loc - 1, 0)))
-        Z *= mine.unsqueeze(1)
-        self.shard.allreduce(Z)
-        return be.features(Z)
+        if getattr(self.shard, "emulated", False):
+            # one rank of an emulated world: the (folded) indices all point at this rank's rows; the real rank would own M / W
+            # of them and receive the rest — the gather runs locally, the collective is counted at its real size
+            Z = X.index_select(0, idx - self.lo)
+            self.shard._count("centre_gather", Z)
+            return be.features(Z)
+        mine, cmax, slot, n_mine = self._centre_plan(idx)
+        blk = torch.zeros((cmax, X.shape[1]), dtype=X.dtype, device=X.device)
+        if n_mine:
+            torch.index_select(X, 0, mine, out=blk[:n_mine])
+        allb = torch.empty((self.world, cmax, X.shape[1]), dtype=X.dtype, device=X.device)
+        self.shard.gather_blocks(blk, allb)
+        return be.features(allb.view(self.world * cmax, X.shape[1]).index_select(0, slot))
 
     def _prepare(self, batch, owners, slot, ph, infos):
         """Per-class mode (G == 1): centres of the batch's classes (one all-reduce each, main stream) and, on the slot's side
@@ -188,6 +233,55 @@ class LockstepClassJob:
             self.trace.append(("precond", tuple(group[k][0][pos] for k, pos in own)))
         return [(Zs_all[k], Ps.get(k), ev) for k in range(len(group))]
 
+    def _run_replicated(self, F, classes, ph, phases, infos, alphas_out):
+        """exchange = "allreduce": the classes one after the other; every rank builds every preconditioner (class-batched
+        chains over groups of 1, 2, 3, g classes, one group ahead on the side stream) and runs the whole M-sized algebra of
+        every class; per CG iteration one all-reduce of the (M,) partial of its K_nM pass (two vectors on the folded one)."""
+        be, dev = self.be, self.X.device
+        groups = precond_groups(len(classes), max(self.G, 1))
+
+        def prepare(gi):
+            cls = [classes[k] for k in groups[gi]]
+            Zs = [self.gather_centres(self.cidx[c]) for c in cls]
+            self.gside.after_current()
+            with self.gside:
+                with ph("precond"):
+                    if hasattr(be, "precond_batched") and len(cls) > 1:
+                        g = max(self.G, len(cls))
+                        while len(self.pgroup) < 2:
+                            self.pgroup.append(torch.empty((g, 4, self.M, self.ld_p), dtype=torch.float64, device=dev))
+                        plist = be.precond_batched(Zs, self.sigma, self.lam, self.opt.pc_epsilon,
+                                                   out=self.pgroup[gi % 2][:len(cls)], ws_key="precond_group")
+                    else:
+                        plist = [be.precond(z, self.sigma, self.lam, self.opt.pc_epsilon) for z in Zs]
+                ev = self.gside.mark()
+            if infos is not None:
+                infos.extend(p.info for p in plist if hasattr(p, "info"))
+            self.trace.append(("precond", tuple(cls)))
+            return {c: (z, p, ev) for c, z, p in zip(cls, Zs, plist)}
+
+        ready = prepare(0) if groups else {}
+        first_of = {grp[0]: gi for gi, grp in enumerate(groups)}
+        out = None
+        for k, c in enumerate(classes):
+            gi = first_of.get(k)
+            if gi is not None and gi + 1 < len(groups):
+                ready.update(prepare(gi + 1))
+            Z, P, ev = ready.pop(c)
+            self.trace.append(("fit", (c,)))
+            alpha = solver.falkon_fit(be, F, self.labels(c), Z, self.sigma, self.lam, self.maxiter, self.opt, n_total=self.N,
+                                      shard=self.shard, owner=None, knm_out=self.kbufs[0],
+                                      phase=(lambda name: phases[name]) if phases is not None else None,
+                                      precond=P, precond_ready=(lambda ev=ev: _wait(ev)))
+            if alphas_out is not None:
+                alphas_out[c] = alpha
+            with ph("mmv"):
+                be.mmv(F, Z, self.sigma, alpha, None, out=self.scores[:, c:c + 1])
+            out = (alpha, Z)
+        if hasattr(be, "release_helper_streams"):
+            be.release_helper_streams()
+        return out
+
     # ------------------------------------------------------------------ the schedule
     def run(self, F, classes=None, phases=None, infos=None, alphas_out=None):
         """Fit and score `classes` (default: all).  F: Features of this rank's rows.  phases: name -> context manager
@@ -196,6 +290,8 @@ class LockstepClassJob:
         be, world, rank = self.be, self.world, self.rank
         classes = list(range(self.C)) if classes is None else list(classes)
         ph = (lambda name: phases[name]) if phases is not None else (lambda name: contextlib.nullcontext())
+        if self.exchange == "allreduce":
+            return self._run_replicated(F, classes, ph, phases, infos, alphas_out)
         sched = _plan.lockstep_batches(classes, world, self.b)          # [(classes of the batch, their owner ranks)]
         out = None
         if self.G > 1:

@@ -124,9 +124,21 @@ def summarize(out_dir):
     return out
 
 
-def replay(out_dir, cfg_path, cpu):
+def _stats_on_the_host(u, positives, negatives, dim, pos_fraction):
+    """computeFeatStatistics_torch on host copies of the rows (the same index draws from the global CPU generator — the index
+    tensors are host tensors either way — and the same f32 reductions as a `--CPU` run), handed back on the rows' device:
+    lets the GPU arm of the driver test start every fit from bit-identical statistics, so that what is compared is the fit."""
+    dev = positives[0].device if len(positives) else torch.device("cpu")
+    st = u.computeFeatStatistics_torch([p.cpu() for p in positives], [[b.cpu() for b in nb] for nb in negatives],
+                                       features_dim=dim, cpu_tensor=True, pos_fraction=pos_fraction)
+    return {k: v.to(dev) for k, v in st.items()}
+
+
+def replay(out_dir, cfg_path, cpu, host_stats=False):
     """The driver's statements for `--load_RPN_detector_segmentation_features --save_RPN_detector_segmentation_models`
-    (+ `--CPU` when cpu), in its order, on the drop-in modules imported the way it imports them."""
+    (+ `--CPU` when cpu), in its order, on the drop-in modules imported the way it imports them.  host_stats (GPU arm only):
+    the three feature statistics are reduced on the host, as in the reference run the fixture was made from — every fit then
+    sees bit-identical normalised rows (the normalisation itself is elementwise f32: the same on both devices)."""
     from tests import dropin
     FeatureExtractor = dropin.load("feature_extractor").FeatureExtractor
     AccuracyEvaluator = dropin.load("accuracy_evaluator").AccuracyEvaluator
@@ -139,8 +151,11 @@ def replay(out_dir, cfg_path, cpu):
     with redirect_stdout(io.StringIO()):
         FeatureExtractor(cfg_path, train_in_cpu=cpu)                                                              # :72
         positives_RPN, negatives_RPN = u.load_features_classifier(features_dir=os.path.join(out_dir, "features_RPN"), cfg_feature_extraction=cfg_path)
-        stats_rpn = u.computeFeatStatistics_torch(positives_RPN, negatives_RPN, features_dim=positives_RPN[0].size()[1], cpu_tensor=cpu,
-                                                  pos_fraction=pos_fraction_feat_stats)
+        if host_stats and not cpu:
+            stats_rpn = _stats_on_the_host(u, positives_RPN, negatives_RPN, positives_RPN[0].size()[1], pos_fraction_feat_stats)
+        else:
+            stats_rpn = u.computeFeatStatistics_torch(positives_RPN, negatives_RPN, features_dim=positives_RPN[0].size()[1], cpu_tensor=cpu,
+                                                      pos_fraction=pos_fraction_feat_stats)
         classifier = falkon.FALKONWrapper(cfg_path=cfg_path, is_rpn=True)
         rc = ocr.OnlineRegionClassifier(classifier, positives_RPN, negatives_RPN, stats_rpn, cfg_path=cfg_path, is_rpn=True)
         models_falkon_rpn = u.falkon_models_to_cuda(rc.trainRegionClassifier(opts={"is_rpn": True}, output_dir=out_dir))
@@ -162,8 +177,11 @@ def replay(out_dir, cfg_path, cpu):
             positives[i] = positives[i].to(training_device)
             for j in range(len(negatives[i])):
                 negatives[i][j] = negatives[i][j].to(training_device)
-        stats = u.computeFeatStatistics_torch(positives, negatives, features_dim=negatives[0][0].size()[1], cpu_tensor=cpu,
-                                              pos_fraction=pos_fraction_feat_stats)
+        if host_stats and not cpu:
+            stats = _stats_on_the_host(u, positives, negatives, negatives[0][0].size()[1], pos_fraction_feat_stats)
+        else:
+            stats = u.computeFeatStatistics_torch(positives, negatives, features_dim=negatives[0][0].size()[1], cpu_tensor=cpu,
+                                                  pos_fraction=pos_fraction_feat_stats)
         classifier = falkon.FALKONWrapper(cfg_path=cfg_path)
         rc = ocr.OnlineRegionClassifier(classifier, positives, negatives, stats, cfg_path=cfg_path)
         model_det = u.falkon_models_to_cuda(rc.trainRegionClassifier(output_dir=out_dir))
@@ -175,7 +193,10 @@ def replay(out_dir, cfg_path, cpu):
         for i in range(len(ps)):
             ps[i] = ps[i].to(training_device)
             ns[i] = [ns[i].to(training_device)]
-        stats_segm = u.computeFeatStatistics_torch(ps, ns, features_dim=ps[0].size()[1], cpu_tensor=cpu, pos_fraction=pos_fraction_feat_stats)
+        if host_stats and not cpu:
+            stats_segm = _stats_on_the_host(u, ps, ns, ps[0].size()[1], pos_fraction_feat_stats)
+        else:
+            stats_segm = u.computeFeatStatistics_torch(ps, ns, features_dim=ps[0].size()[1], cpu_tensor=cpu, pos_fraction=pos_fraction_feat_stats)
         classifier = falkon.FALKONWrapper(cfg_path=cfg_path, is_segmentation=True)
         rc = ocr.OnlineRegionClassifier(classifier, ps, ns, stats_segm, cfg_path=cfg_path, is_segmentation=True)
         model_segm = u.falkon_models_to_cuda(rc.trainRegionClassifier(output_dir=out_dir))

@@ -234,7 +234,7 @@ def test_class_sharded_minibootstrap_equals_single_process(world, tmp_path):
             assert M == ref[c].M and sigma == 6.0
 
 
-def _job_worker(rank, world, port, N, D, M, C, ret, batch=0, chain=0):
+def _job_worker(rank, world, port, N, D, M, C, ret, batch=0, chain=0, exchange="lockstep"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -250,7 +250,8 @@ def _job_worker(rank, world, port, N, D, M, C, ret, batch=0, chain=0):
         lo, hi = shard.bounds(N)
         row_ids = torch.arange(lo, hi)
         job = LockstepClassJob(be, torch.from_numpy(X[lo:hi]), N, M, lambda c: torch.where((row_ids % C) == c, 1.0, -1.0).double(),
-                               [torch.from_numpy(i) for i in cidx], 6.0, 1e-4, 20, shard=shard, batch=batch, precond_batch=chain)
+                               [torch.from_numpy(i) for i in cidx], 6.0, 1e-4, 20, shard=shard, batch=batch, precond_batch=chain,
+                               exchange=exchange)
         F = be.features(job.X)
         alpha, _ = job.run(F)
         ret[rank] = {"scores": job.scores.numpy().copy(), "trace": list(job.trace), "G": job.G, "alpha_last": alpha.numpy().copy(),
@@ -311,6 +312,84 @@ def test_headline_control_flow_on_eight_ranks():
     assert (scores.argmax(1) == np.arange(N) % C).mean() > 0.9
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_replicated_one_allreduce_form_of_the_job(world):
+    """exchange = "allreduce" (the north star's literal form; bench.py --cg-exchange allreduce): classes one at a time, EVERY
+    rank builds every class's preconditioner — chains over groups of 1, 2, 3 classes, one group ahead — and runs the M-sized
+    algebra of every class, one all-reduce of the K_nM pass's partial per CG iteration; one K_nM shard buffer per rank.
+    Scores of all classes equal the single-process oracle's and the lock-step job's (same arithmetic per class)."""
+    from oracle import falkon_ref as fr
+    N, D, M, C = 900, 16, 40, 7
+    ret, ret2 = mp.Manager().dict(), mp.Manager().dict()
+    mp.spawn(_job_worker, args=(world, _free_port(), N, D, M, C, ret, 0, 0, "allreduce"), nprocs=world, join=True)
+    mp.spawn(_job_worker, args=(world, _free_port(), N, D, M, C, ret2), nprocs=world, join=True)
+    for r in range(world):
+        t = ret[r]["trace"]
+        assert ret[r]["b"] == 1 and ret[r]["kbufs"] == 1
+        assert [p for k, p in t if k == "fit"] == [(c,) for c in range(C)]
+        assert [c for k, p in t if k == "precond" for c in p] == list(range(C))         # every rank builds every preconditioner
+        g = ret[r]["G"]
+        from odx import plan
+        assert [len(p) for k, p in t if k == "precond"] == [len(grp) for grp in plan.precond_groups(C, max(g, 1))]
+        kinds = [k for k, _ in t]
+        assert kinds[:3] == ["precond", "precond", "fit"]                               # one group ahead of the fits
+    scores = np.concatenate([ret[r]["scores"] for r in range(world)], axis=0)
+    scores2 = np.concatenate([ret2[r]["scores"] for r in range(world)], axis=0)
+    assert np.abs(scores - scores2).max() < 1e-9 * max(1.0, np.abs(scores2).max())     # the two exchanges: the same fits
+    X, cidx = _job_problem(N, D, M, C)
+    Xd = X.astype(np.float64)
+    for c in range(C):
+        y = np.where(np.arange(N) % C == c, 1.0, -1.0)
+        a, Z = fr.falkon_fit(Xd, y, cidx[c], 6.0, 1e-4, maxiter=20, dtype=np.float64, pc_eps=1e-5, cg_epsilon=1e-7)
+        want = fr.falkon_predict(Xd, Z, a, 6.0)[:, 0]
+        assert np.abs(scores[:, c] - want).max() < 1e-6 * max(1.0, np.abs(want).max()), c
+
+
+def test_centres_are_assembled_from_the_rows_each_rank_owns():
+    """LockstepClassJob.gather_centres under 3 gloo ranks: every rank contributes only the centre rows it owns (one
+    all-gather of equal-sized blocks) and ends with X_global[idx] in idx order, duplicates and unbalanced ownership included."""
+    N, D, world = 101, 8, 3
+    ret = mp.Manager().dict()
+    mp.spawn(_centre_worker, args=(world, _free_port(), N, D, ret), nprocs=world, join=True)
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    for r in range(world):
+        for idx, Z in ret[r]:
+            assert np.array_equal(Z, X[idx]), r
+
+
+def _centre_worker(rank, world, port, N, D, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import odx
+        from odx.dist import RowShard
+        from odx.job import LockstepClassJob
+        from tests.oracle_backend import OracleBackend
+        odx.set_backend(OracleBackend(np.float64))
+        be = odx.get_backend()
+        rng = np.random.default_rng(5)
+        X = rng.standard_normal((N, D)).astype(np.float32)
+        shard = RowShard()
+        lo, hi = shard.bounds(N)
+        idxs = [np.array([100, 0, 0, 50, 33, 34, 99, 1], dtype=np.int64),          # duplicates, every rank owns some
+                np.arange(0, 30, dtype=np.int64),                                   # all rows on rank 0
+                np.array([100], dtype=np.int64)]                                    # one row, last rank
+        job = LockstepClassJob(be, torch.from_numpy(X[lo:hi]), N, 8, lambda c: None, [torch.from_numpy(i) for i in idxs], 6.0, 1e-4,
+                               20, shard=shard)
+        out = []
+        for i in idxs:
+            Zf = job.gather_centres(torch.from_numpy(i))
+            out.append((i, Zf.X.numpy().copy()))
+            Zf2 = job.gather_centres(job.cidx[0]) if i is idxs[0] else None       # the cached plan gives the same rows
+            if Zf2 is not None:
+                assert np.array_equal(Zf2.X.numpy(), X[idxs[0]])
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("b,chain", [(2, 2), (4, 0)])
 def test_lockstep_batches_smaller_than_the_world(b, chain):
     """The memory plan's other shape (odx/plan.py): lock-step batches of b < world classes — b K_nM shards per rank instead
@@ -354,7 +433,7 @@ def test_emulated_rank_runs_the_schedule_of_the_real_rank(world, rank):
     """odx.dist.EmulatedShard (bench.py --emulate-world): ONE rank's share of a `world`-rank job in a single process — the
     schedule it executes (every lock-step batch fitted, the preconditioners of exactly the classes that rank owns, chain by
     chain), the rows it holds and the collectives it would have issued (one all-gather + one reduce-scatter of a (world, M)
-    f64 matrix per exchange, one all-reduce of the centres per class) are those of the real rank of the gloo runs above; its
+    f64 matrix per exchange, one all-gather of the centres' rows per class) are those of the real rank of the gloo runs above; its
     numbers are finite (they are a rank's partial sums, not the job's)."""
     import odx
     from odx import plan
@@ -387,7 +466,7 @@ def test_emulated_rank_runs_the_schedule_of_the_real_rank(world, rank):
         assert [c for k, p in job.trace if k == "precond" for c in p] == owned
         assert torch.isfinite(job.scores).all() and tuple(job.scores.shape) == (hi - lo, C)
         calls = shard.calls
-        assert calls["all_reduce"][0] == C and calls["all_reduce"][1] == C * M * D * 4          # the centres of every class, f32 rows
+        assert calls["centre_gather"] == [C, C * M * D * 4] and calls["all_reduce"][0] == 0     # the centres of every class: one all-gather of f32 rows each
         assert calls["all_gather"][0] == calls["reduce_scatter"][0]     # paired: per exchange, + the right-hand side's scatter / alpha's gather ...
         Mp = (M + 1) // 2 * 2
         per = world * Mp * 8

@@ -212,6 +212,18 @@ def test_config4_mask_pixels_d256_m2000(be):
     assert np.abs(got - fr.falkon_predict(X[rows].astype(np.float64), Z, ref, sigma)).max() < 1e-4
 
 
+def test_config4_at_its_own_size_5e5_rows(be):
+    """Config 4 at the size BASELINE states — 5e5 mask-pixel rows per class, D = 256, M = 2000, sigma = 10 — where the f64
+    oracle no longer fits a test's time: the size-independent properties of the headline-shape test (sampled K_nM entries and
+    scores against the f64 oracle's entries, pass additivity / linearity over row splits, the fused right-hand side = one
+    pass over the stored block, bitwise repeatability), beside the alpha < 1e-4 oracle case at 2e5 rows above.  D = 256 is
+    the one BASELINE shape whose build is bound by the K store (4 GB per launch), not by the contraction."""
+    from tests.test_gpu_kernels import full_size_properties
+    full_size_properties(be, 500_000, 256, 2000, 10.0, 1e-5)
+    be.release_workspaces()
+    torch.cuda.empty_cache()
+
+
 def test_config5_shard_shape_one_class(be):
     """Config 5 (100 classes, N = 5e6, D = 1024, M = 2e4 on 8 GPUs): the shard one GPU holds — 625 000 rows, a 50 GB f32
     K_nM block — for one class through the shipping f16-split path (f32-accurate K; the fp8 contraction BASELINE names is

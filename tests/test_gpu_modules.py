@@ -484,6 +484,32 @@ def test_bench_starts_its_own_ranks_and_matches_the_oracle(ranks, classes, rows,
     assert out["health"]["failed_choleskys"] == 0 and out["health"]["ranks_with_nonfinite_scores"] == 0
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the first run of the lock-step fit's RCCL collectives "
+                    "(all_gather_into_tensor / reduce_scatter_tensor) between real ranks; this pool's test boxes have one")
+@pytest.mark.parametrize("form", ["lockstep", "allreduce"])
+def test_bench_on_two_gpus_over_rccl_matches_the_oracle(form):
+    """`python bench.py --gpus 2 --check` on the `nccl` backend, one rank per GPU — what the driver's scaling run starts, at
+    the size the gloo form of this test uses on one GPU (80 000 rows, M = 4200, 4 classes, 24-bit shards, folded two-vector
+    iteration).  Skips by itself on a one-GPU box; on the first box with two it is the first execution of the RCCL branches
+    of odx/dist.py between real ranks.  `allreduce`: the replicated one-all-reduce-per-iteration form of the north star."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ODX_KNM"] = "u24"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--rows", "80000",
+           "--centres", "4200", "--classes", "4", "--check", "--no-cpu-baseline", "--no-extras"]
+    if form == "allreduce":
+        cmd += ["--cg-exchange", "allreduce"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["rows_per_gpu"] == 40000
+    assert out["check"]["max_abs_score_diff_vs_oracle_predict"] < 1e-4
+    assert out["check"]["alpha_rel_err_vs_oracle_fit"] < 1e-4
+    assert out["health"]["failed_choleskys"] == 0 and out["health"]["ranks_with_nonfinite_scores"] == 0
+
+
 def test_batched_minibootstrap_equals_the_sequential_one_bit_for_bit(tmp_path, monkeypatch):
     """opts['class_batch'] = k fits all classes of a Minibootstrap round with one batched preconditioner launch chain and
     runs their K_nM builds / CG loops on k streams.  Fed the same Nystroem indices (the wrapper's index rule replaced by a

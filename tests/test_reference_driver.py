@@ -94,25 +94,34 @@ def test_restated_call_sequence_leaves_what_the_driver_left_cpu(tmp_path):
         odx.set_backend(None)
 
 
-@pytest.mark.gpu
-def test_driver_call_sequence_on_the_gpu_matches_the_reference_run(tmp_path):
-    """The GPU route of the same driver (no --CPU: the `_incore` classes, caches as a GPU harvest leaves them) through libodx:
-    same files, same structure and shapes, the same centres drawn, every FALKON alpha within 5e-4 relative and every regressor
-    within 1e-5 of what the reference driver's run produced with the f64 oracle backend, mAP within 0.1.  (The 1e-4 bar on
-    alpha is stated — and tested, tests/test_gpu_kernels.py — on IDENTICAL inputs; here the rows each fit sees have already
-    passed through the drivers' f32 statistics and normalisation, computed by torch on the GPU in one run and on the CPU in the
-    other: their last bits differ, and the tiny problems of this fixture — 30 centres on 8-dimensional mask pixels — carry
-    that to 1.5e-4 in alpha.  RPN and detector classifiers come out within 1e-4 here too.)"""
+def _gpu_driver_run(tmp_path, host_stats):
     odx.set_backend(None)
     assert odx.get_backend().name == "hip-gfx950"
     out, cfg_path, want = _setup(tmp_path, "cuda")
     torch.manual_seed(df.SEED)
     os.environ["ODX_SAMPLES"], os.environ["ODX_MODEL"] = "tests.driver_fixture:samples", "tests.driver_fixture:model"
     try:
-        df.replay(out, cfg_path, cpu=False)
+        df.replay(out, cfg_path, cpu=False, host_stats=host_stats)
     finally:
         del os.environ["ODX_SAMPLES"], os.environ["ODX_MODEL"]
-    got = df.summarize(out)
+    return df.summarize(out), want
+
+
+def _alpha_gaps(got, want):
+    """{head: largest relative alpha gap over its classifiers} (norm and leading entries, relative to the reference's norm)."""
+    gaps = {}
+    for tag in ("rpn", "detector", "segmentation"):
+        worst = 0.0
+        for g, w in zip(got[tag]["classifiers"], want[tag]["classifiers"]):
+            if w is None:
+                continue
+            worst = max(worst, abs(g["alpha_norm"] - w["alpha_norm"]) / w["alpha_norm"],
+                        max(abs(a - b) for a, b in zip(g["alpha_head"], w["alpha_head"])) / w["alpha_norm"])
+        gaps[tag] = worst
+    return gaps
+
+
+def _check_structure_and_the_rest(got, want):
     assert got["files"] == want["files"]
     for tag in ("rpn", "detector", "segmentation"):
         assert len(got[tag]["classifiers"]) == len(want[tag]["classifiers"])
@@ -122,9 +131,6 @@ def test_driver_call_sequence_on_the_gpu_matches_the_reference_run(tmp_path):
                 continue
             assert (g["M"], g["D"], g["alpha_shape"]) == (w["M"], w["D"], w["alpha_shape"]), tag
             assert abs(g["centres_sum"] - w["centres_sum"]) <= 1e-4 * max(1.0, abs(w["centres_sum"])), tag     # the same centres were drawn
-            bar = 5e-4 if tag == "segmentation" else 1e-4
-            assert abs(g["alpha_norm"] - w["alpha_norm"]) <= bar * w["alpha_norm"], (tag, g["alpha_norm"], w["alpha_norm"])
-            assert max(abs(a - b) for a, b in zip(g["alpha_head"], w["alpha_head"])) <= bar * w["alpha_norm"], tag
         for g, w in zip(got[tag].get("regressors", []), want[tag].get("regressors", [])):
             assert (g is None) == (w is None), tag
             if w is not None:
@@ -135,4 +141,40 @@ def test_driver_call_sequence_on_the_gpu_matches_the_reference_run(tmp_path):
     assert set(gm) == set(wm)
     for k in wm:
         assert abs(gm[k] - wm[k]) <= 0.1, (k, gm[k], wm[k])
-    print("driver on the GPU:", gm, "reference run:", wm)
+    return gm, wm
+
+
+@pytest.mark.gpu
+def test_driver_call_sequence_on_the_gpu_matches_the_reference_run(tmp_path):
+    """The GPU route of the same driver (no --CPU: the `_incore` classes, caches as a GPU harvest leaves them) through libodx,
+    on IDENTICAL inputs: the three feature statistics are reduced on the host exactly as in the reference run the fixture
+    holds (tests/driver_fixture._stats_on_the_host; the normalisation that follows is elementwise f32, the same on both
+    devices), so every fit sees the rows the reference's fit saw.  Same files, same structure and shapes, the same centres
+    drawn, EVERY FALKON alpha — RPN, detector and segmentation heads — within the north star's 1e-4 relative, every regressor
+    within 1e-5, mAP within 0.1 (experiments/run_experiment_online_rpn_ood_oos.py:240-259)."""
+    got, want = _gpu_driver_run(tmp_path, host_stats=True)
+    gm, wm = _check_structure_and_the_rest(got, want)
+    gaps = _alpha_gaps(got, want)
+    print("driver on the GPU (host statistics):", gm, "reference run:", wm, "alpha gaps:", gaps)
+    for tag, gap in gaps.items():
+        assert gap <= 1e-4, (tag, gap)
+
+
+@pytest.mark.gpu
+def test_driver_on_the_gpu_with_device_reduced_statistics(tmp_path):
+    """The same run with the statistics reduced ON THE DEVICE, as a user's GPU run does (py_od_utils.py:59-95 with
+    cpu_tensor=False): torch's f32 mean / std / norm reductions sum in another order there, the normalised rows differ from
+    the reference run's in their last bits, and the fits start from DIFFERENT inputs.  RPN and detector heads still land
+    within 1e-4; the segmentation head of this fixture (30 centres on 8-dimensional mask pixels, lambda 1e-4: tiny and
+    ill-conditioned) carries the input difference to ~1.5e-4 — a FINDING about input sensitivity, recorded under a named
+    xfail, not a bar of the fit (that bar is the test above, on identical inputs)."""
+    got, want = _gpu_driver_run(tmp_path, host_stats=False)
+    _check_structure_and_the_rest(got, want)
+    gaps = _alpha_gaps(got, want)
+    print("driver on the GPU (device statistics): alpha gaps:", gaps)
+    assert gaps["rpn"] <= 1e-4 and gaps["detector"] <= 1e-4, gaps
+    if gaps["segmentation"] > 1e-4:
+        assert gaps["segmentation"] <= 5e-4, gaps          # an input-rounding effect, not a divergence
+        pytest.xfail("segmentation alpha %.2e > 1e-4 with device-reduced f32 statistics: the inputs of the two runs differ "
+                     "in their last bits (see test_driver_call_sequence_on_the_gpu_matches_the_reference_run for identical inputs)"
+                     % gaps["segmentation"])
