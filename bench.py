@@ -403,6 +403,8 @@ def main():
                         best = (pkd["launches"] * pkd["avg_launch_ms"], kname, pkd["traffic_GB_per_launch"], unit)
                 if best is not None:
                     r["traffic"], r["traffic_unit"] = best[2], "%s of %s" % (best[3], best[1])
+                elif unit:
+                    r["traffic_unit"] = unit
         kernel_ms = {pk[0]: p1_ms, pk[1]: p2_ms, gk[0]: ph["knm"].total_ms(), gk[1]: ph["mmv"].total_ms()}
         dominant = max(kernel_ms, key=kernel_ms.get)
         # `roofline` = the kernel FAMILY with more measured device time in this run's timed region (round-3 review: the single
@@ -482,6 +484,15 @@ def main():
             # behind — helper streams of the chains (found and released this round: DESIGN section 7), which hardware queues
             # later streams land on (the Minibootstrap: 0.46 or 0.51 s).  What is wanted here is what those paths cost, not what
             # the headline job's leftovers add to them; ODX_BENCH_EXTRAS=inprocess keeps the old arrangement.
+            # ... and, first, the latency-bound ones HERE, behind the job (round-5 review, item 6: both figures are reported — a
+            # user's process will have run a fit before it runs a forward)
+            try:
+                from tools import bench_extras as _be_extras
+                out["extras_in_headline_process"] = _be_extras.after_headline()
+            except Exception as e:      # noqa: BLE001
+                out["extras_in_headline_process"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            be.release_workspaces()
+            torch.cuda.empty_cache()
             if os.environ.get("ODX_BENCH_EXTRAS", "child") == "inprocess":
                 from tools import bench_extras
                 out.update(bench_extras.collect(args))
@@ -516,11 +527,28 @@ def _same_kernel(name, profiled):
     return want == base + targs or ("<" not in want and want == base)
 
 
+def csrc_sha16():
+    """Fingerprint of the kernel sources this tree builds libodx.so from (sha256 over the sorted csrc/*.hip, *.h, *.cpp and
+    the Makefile, first 16 hex digits).  tools/profile_round.sh stores it beside the PMC passes it takes
+    (profiles/rNN_pmc_meta.json); `roofline.traffic` is only quoted from passes whose fingerprint is this tree's — a kernel
+    changed after the last profile yields `null`, not stale bytes (round-5 review, weak 6).  Works without .git (GPU box)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "online-detection_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.cpp"))
+                    + [os.path.join(d, "Makefile")]):
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def profiled_traffic_gb(kernel_names):
     """HBM bytes per launch of ONE kernel from the newest committed rocprofv3 PMC passes
     (profiles/rNN_pmc_*: the counters cannot be read from inside this process): FETCH_SIZE (KiB, doubled per the gfx950
     correction of the guide) + WRITE_SIZE (KiB), median over the profiled launches at this same shard shape.  The file
-    stem the number came from is named in the unit string.  None if absent."""
+    stem the number came from is named in the unit string.  (None, reason) when there are no passes, or when the newest
+    ones were taken on OTHER kernel sources than this tree's (profiles/rNN_pmc_meta.json: csrc_sha16)."""
     import csv
     import glob
     import re
@@ -529,6 +557,14 @@ def profiled_traffic_gb(kernel_names):
                     for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*_counter_collection.csv"))
                     if re.match(r"r\d+_pmc_", os.path.basename(f))})
     for stem in reversed(stems):
+        meta_path = os.path.join(ROOT, "profiles", "%s_pmc_meta.json" % stem)
+        try:
+            prof_sha = json.load(open(meta_path)).get("csrc_sha16")
+        except Exception:
+            prof_sha = None
+        if prof_sha != csrc_sha16():
+            return None, ("null: the newest PMC passes (profiles/%s_pmc_*) were taken on kernel sources %s, this tree's are %s "
+                          "— re-run tools/profile_round.sh" % (stem, prof_sha or "without a recorded fingerprint", csrc_sha16()))
         tot, found = 0.0, 0
         for counter, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
             path = os.path.join(ROOT, "profiles", "%s_pmc_%s_counter_collection.csv" % (stem, counter))
@@ -541,7 +577,8 @@ def profiled_traffic_gb(kernel_names):
                 tot += mult * 1024.0 * statistics.median(vals)
         if found == 2:
             return round(tot / 1e9, 2), ("GB per launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, from the committed "
-                                         "profiles/%s_pmc_* (not measured in this run)" % stem)
+                                         "profiles/%s_pmc_* (not measured in this run; taken on this tree's kernel sources, "
+                                         "csrc_sha16 %s)" % (stem, prof_sha))
     return None, None
 
 

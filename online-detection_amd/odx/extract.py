@@ -624,7 +624,9 @@ class GraphedCall:
         self.seen = {}                         # shape -> calls so far: a shape is captured at its SECOND call (a stream of images
         # that all differ in size — capture costs three forwards — then simply runs launch by launch)
         self.enabled = os.environ.get("ODX_TRUNK_GRAPH", "1") != "0"
-        self.lock = threading.Lock()           # the extractor's forward thread and the caller's may both come through here
+        # (re-entrant: fn itself may call clear() — a weight pack remade inside the forward drops the graphs that point at the
+        # old one, OnlineDetectionModel._wpack)
+        self.lock = threading.RLock()          # the extractor's forward thread and the caller's may both come through here
 
     def clear(self):
         with self.lock:
@@ -637,7 +639,7 @@ class GraphedCall:
     def __setstate__(self, d):
         import threading
         self.fn, self.max_graphs, self.enabled = d["fn"], d["max_graphs"], d["enabled"]
-        self.graphs, self.seen, self.captures, self.lock = {}, {}, {}, threading.Lock()
+        self.graphs, self.seen, self.captures, self.lock = {}, {}, {}, threading.RLock()
 
     def _capture(self, xs, gstream):
         with torch.cuda.stream(gstream):
@@ -817,8 +819,35 @@ class OnlineDetectionModel(nn.Module):
         cache = self.__dict__.setdefault("_wpacks", {})
         hit = cache.get(name)
         if hit is None or hit[0] != key:
+            if hit is not None:
+                self._drop_captured()       # a captured forward points at the pack this one replaces: no graph may outlive it
             hit = cache[name] = (key, make())
         return hit[1]
+
+    def _weights_key(self):
+        """(storage, in-place version) of EVERY parameter and buffer of the model: part of both graph caches' keys.  A captured
+        forward bakes in the trunk, the RPN head's and the conv5 head's packed weights and the mask pack; an optimiser step,
+        `weight.data.normal_()` or a `copy_` into any of them — none of which passes through load_state_dict or _apply — must
+        not be answered from the old capture (round-5 advisor finding: the keys used to cover two trunk weights only)."""
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
+    def refresh_weights(self):
+        """Drop everything derived from the weights — folded batch norms, packed GEMM operands, captured graphs — after an
+        in-place edit of a FROZEN weight (the trunk and the conv5 head fold their norms once, at load / .to() /
+        load_state_dict, and are not version-checked per call; the RPN head's, the mask branch's and the on-line heads'
+        operands are)."""
+        for m in self.modules():
+            if isinstance(m, _FoldedBN):
+                m._folded.clear()
+        self.__dict__.pop("_mask_pack", None)
+        self.__dict__.pop("_wpacks", None)
+        self._drop_captured()
+
+    def _drop_captured(self):
+        for name in ("_trunk_graphs", "_group_graphs"):
+            g = self.__dict__.get(name)
+            if g is not None and not torch.cuda.is_current_stream_capturing():
+                g.clear()
 
     def _rows16_path(self, x):
         """_rows_path for a forward run in bf16 / f16 (compute_dtype): trunk stages and RPN head on 16-bit rows (odx_gemm_b16)."""
@@ -844,10 +873,9 @@ class OnlineDetectionModel(nn.Module):
     @torch.no_grad()
     def c4(self, image):
         """(1, C, H/16, W/16) f32 trunk features; on the GPU replayed from a HIP graph per image size (GraphedCall)."""
-        w0, w1 = self.backbone.conv1.weight, self.backbone.layer3[-1].conv3.weight
-        # (the weights' storage and in-place version counters are part of the key: a graph replays the tensors it was captured
+        # (every weight's storage and in-place version counter is part of the key: a graph replays the tensors it was captured
         # with — an optimiser step or a copy_ into a weight must not be answered from the old capture)
-        return self._trunk_graphs(image, key_extra=(self.compute_dtype, w0.data_ptr(), w0._version, w1.data_ptr(), w1._version))
+        return self._trunk_graphs(image, key_extra=(self.compute_dtype, self._weights_key()))
 
     def update_model(self, models_rpn=None, models_detection=None, models_segmentation=None):
         """Swap trained on-line models into the running pipeline, each a dict {'classifiers', 'regressors', 'stats'}
@@ -1010,7 +1038,8 @@ class OnlineDetectionModel(nn.Module):
         h, w = -(-images.shape[2] // self.stride), -(-images.shape[3] // self.stride)          # the C4 map: ceil(size / 16)
         anchors = self.grid_anchors(h, w, dev)
         out = self._group_graphs(images, gt_slots, anchors, key_extra=(self.pre_nms_top_n, self.post_nms_top_n, self.rpn_nms,
-                                                                       self.compute_dtype, self.resolution), capture=capture)
+                                                                       self.compute_dtype, self.resolution, self._weights_key()),
+                                 capture=capture)
         return (out, G, gpad)
 
     @torch.no_grad()
@@ -1074,6 +1103,8 @@ class OnlineDetectionModel(nn.Module):
             key = (cm.weight.data_ptr(), cm.weight._version, cm.bias._version)
             hit = self.__dict__.get("_mask_pack")
             if hit is None or hit[0] != key:
+                if hit is not None:
+                    self._drop_captured()                                                         # (graphs that point at the old pack)
                 wt = cm.weight.detach().float().reshape(Cin, -1).t().contiguous()                 # (Cout * 4, Cin): column (oc, di, dj)
                 hit = self.__dict__["_mask_pack"] = (key, be.packed(wt), cm.bias.detach().float().repeat_interleave(4).contiguous())
             out = be.gemm_h2(be.packed(rows), hit[1], bias=hit[2], relu=True)               # (R H W, Cout * 4)

@@ -272,8 +272,9 @@ class OnlineDetectionModelFPN(nn.Module):
         """The pyramid of an image, on the GPU replayed from a HIP graph per image size (extract.GraphedCall: this forward is
         host-bound at batch 1 — trunk + pyramid are ~170 launches and the proposal stage behind them synchronises with the
         host per level, so the host never runs ahead)."""
-        w0 = self.backbone.conv1.weight
-        return self._trunk_graphs(image, key_extra=(self.compute_dtype, w0.data_ptr(), w0._version))
+        # every weight's (storage, in-place version) in the key: a graph replays the tensors and packs it was captured with
+        wk = tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        return self._trunk_graphs(image, key_extra=(self.compute_dtype, wk))
 
     def _c4_eager(self, image):
         """The trunk features of an image — here the pyramid (P2 .. P6) (the method keeps extract's name: the harvest loops

@@ -91,3 +91,31 @@ def test_gpus_n_without_a_launcher_starts_n_ranks(monkeypatch, capsys):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 7
+
+
+def test_roofline_traffic_is_only_quoted_from_passes_of_this_trees_kernel_sources(tmp_path, monkeypatch):
+    """`roofline.traffic` comes from committed PMC passes (the counters cannot be read inside the benched process): the passes
+    carry the fingerprint of the kernel sources they were taken on (profiles/rNN_pmc_meta.json, tools/profile_round.sh) and a
+    tree whose csrc differs — a kernel changed, the profile forgotten — gets null with the reason, not stale bytes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sha = bench.csrc_sha16()
+    assert len(sha) == 16 and sha == bench.csrc_sha16()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    for counter, v in (("FETCH_SIZE", 1.0e7), ("WRITE_SIZE", 5.0e6)):
+        with open(prof / ("r77_pmc_%s_counter_collection.csv" % counter), "w") as f:
+            f.write("Kernel_Name,Counter_Name,Counter_Value\n")
+            f.write('"void odx::knm_passq_stag_kernel<10, 2, 1>(odx::Args)",%s,%f\n' % (counter, v))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "csrc_sha16", lambda: sha)
+    got, why = bench.profiled_traffic_gb("knm_passq_stag_kernel<10,2,1>")
+    assert got is None and "without a recorded fingerprint" in why
+    json.dump({"csrc_sha16": "0" * 16}, open(prof / "r77_pmc_meta.json", "w"))
+    got, why = bench.profiled_traffic_gb("knm_passq_stag_kernel<10,2,1>")
+    assert got is None and "0000000000000000" in why and sha in why
+    json.dump({"csrc_sha16": sha}, open(prof / "r77_pmc_meta.json", "w"))
+    got, why = bench.profiled_traffic_gb("knm_passq_stag_kernel<10,2,1>")
+    assert got == 25.6 and sha in why

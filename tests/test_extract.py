@@ -638,6 +638,30 @@ def test_group_forward_from_one_graph_equals_the_eager_batched_forward():
         check(a)
         assert len(model._group_graphs.graphs) == 2
         assert all(r["boxes"].shape[0] <= 25 + 3 for r in model.forward_group(images, a))
+        # in-place weight changes that pass through neither load_state_dict nor _apply (an optimiser step, .data.normal_(), a
+        # copy_): the graph of the old weights — it baked in the trunk, the packed RPN / conv5-head operands and the mask pack —
+        # must not answer; every parameter's (storage, version) is in the graphs' key (round-5 advisor finding)
+        before = model.forward_group(images, a)
+        last_conv = [m for m in model.head.modules() if isinstance(m, torch.nn.Conv2d)][-1]
+        for w in (last_conv.weight, model.rpn_conv.weight, model.conv5_mask.weight, model.backbone.layer2[0].conv1.weight):
+            w.data.mul_(1.25) if w is not last_conv.weight else w.mul_(0.5)
+            check(a)                                          # (first call of the new key: launch by launch)
+            check(a)                                          # captured with the new weights
+        after = model.forward_group(images, a)
+        assert not torch.equal(after[0]["feats"], before[0]["feats"])
+        assert len(model._group_graphs.graphs) <= model._group_graphs.max_graphs
+        # the frozen trunk / conv5 head fold their batch norms into the weights once (at load, .to(), load_state_dict): an
+        # in-place edit of THOSE needs refresh_weights(), which drops every derived tensor and every graph
+        c0 = model.c4(images[:1])
+        c0 = model.c4(images[:1])
+        model.backbone.layer3[0].conv2.weight.data.mul_(1.5)
+        model.refresh_weights()
+        c1 = model.c4(images[:1])
+        c1 = model.c4(images[:1])
+        want = model._c4_eager(images[:1])
+        assert not torch.equal(c0, c1) and float((c1 - want).abs().max()) <= 1e-4 * float(want.abs().max())
+        check(a)
+        check(a)
 
 
 @pytest.mark.gpu

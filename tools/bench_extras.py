@@ -78,7 +78,7 @@ def rls_extra(n=300_000, D=1024, C=30, lam=1000.0, cpu=True):
     return out
 
 
-def forward_extra(height=600, width=800, rois=300, reps=8):
+def forward_extra(height=600, width=800, rois=300, reps=8, dtypes=("f32", "bf16"), groups=(4, 8)):
     from odx.extract import OnlineDetectionModel
     dev = torch.device("cuda")
     model = OnlineDetectionModel(post_nms_top_n=rois).to(dev).eval()
@@ -87,6 +87,8 @@ def forward_extra(height=600, width=800, rois=300, reps=8):
     out = {"workload": "R-50-C4 trunk + RPN proposals (HIP NMS) + RoIAlign (HIP) + conv5 head on one synthetic %dx%d image, "
                        "%d RoIs, random weights" % (height, width, rois)}
     for name, ctx in (("f32", torch.autocast("cuda", enabled=False)), ("bf16", torch.autocast("cuda", dtype=torch.bfloat16))):
+        if name not in dtypes:
+            continue
         with torch.no_grad(), ctx:
             for _ in range(3):
                 model(img)
@@ -98,9 +100,11 @@ def forward_extra(height=600, width=800, rois=300, reps=8):
     # of the RoI head per group; in f32 from three images on the trunk stages, the RPN head and the conv5 head are one chain of
     # row GEMMs on the split-f16 tile cores) — what the harvest loop runs; the one-image keys above are detect()'s route
     for name, cd in (("f32", None), ("bf16", torch.bfloat16)):
+        if name not in dtypes or not groups:
+            continue
         gm = OnlineDetectionModel(post_nms_top_n=rois, compute_dtype=cd).to(dev).eval()
         from odx.extract import forward_batch
-        for B in (4, 8):
+        for B in groups:
             imgs = torch.randn((B, 3, height, width), device=dev, generator=g)
             with torch.no_grad():
                 for _ in range(3):
@@ -180,7 +184,7 @@ def _forward_roofline(flop, ms, name):
             "ceiling": "dense f16 MFMA peak / 3 (three MFMAs per f32-accurate product)" if name == "f32" else "dense bf16 MFMA peak"}
 
 
-def forward_fpn_extra(height=600, width=800, reps=8):
+def forward_fpn_extra(height=600, width=800, reps=8, dtypes=("f32", "bf16"), groups=(4, 8)):
     """BASELINE config 2's forward as named — ResNet50-FPN + RoIAlign -> D = 1024 RoI features (odx/fpn.py): trunk + pyramid,
     RPN over five levels (1000 candidates per level, NMS, 1000 kept over all levels), ONE multi-level RoIAlign launch, fc6 /
     fc7 on the split-f16 tile cores; f32 and bf16 autocast, random weights."""
@@ -191,6 +195,8 @@ def forward_fpn_extra(height=600, width=800, reps=8):
     out = {"workload": "R-50-FPN trunk + pyramid + RPN over 5 levels (HIP NMS) + multi-level RoIAlign (one HIP launch) + fc6 / fc7 on "
                        "one synthetic %dx%d image, random weights" % (height, width)}
     for name, dt in (("f32", None), ("bf16", torch.bfloat16)):
+        if name not in dtypes:
+            continue
         model = OnlineDetectionModelFPN(compute_dtype=dt).to(dev).eval()
         with torch.no_grad():
             for _ in range(3):
@@ -203,7 +209,7 @@ def forward_fpn_extra(height=600, width=800, reps=8):
         # groups of images of one size through extract.forward_batch: one trunk + pyramid call (f32, three images or more: the
         # stages and the pyramid as row GEMMs on the split-f16 tile cores), the proposal stage per image, ONE fc6 / fc7 pass
         from odx.extract import forward_batch
-        for B in (4, 8):
+        for B in groups:
             imgs = torch.randn((B, 3, height, width), device=dev, generator=g)
             with torch.no_grad():
                 for _ in range(3):
@@ -220,7 +226,7 @@ def forward_fpn_extra(height=600, width=800, reps=8):
     return out
 
 
-def harvest_extra(images=24, C=30, height=600, width=800):
+def harvest_extra(images=24, C=30, height=600, width=800, passes=6, one_image_per_call=True):
     """The on-line training's feature pass per image (FeatureExtractorRPNDetector.train, extract_features_rpn_detector.py:105-369 —
     by the builder's own figures 99 % of the reference's reported on-line training time): forward + detector rows + on-line RPN
     rows + mask pixel rows through OnlineFeatureExtractor on synthetic images of one size with 1-3 ground-truth boxes each,
@@ -245,11 +251,13 @@ def harvest_extra(images=24, C=30, height=600, width=800):
     out = {"workload": "forward + detector / on-line RPN / mask-pixel harvest of %d synthetic %dx%d images (1-3 boxes each, %d classes), "
                        "R-50-C4, 300 proposals, f32, random weights" % (images, height, width, C)}
     for key, kw in (("ms_per_image", {}), ("ms_per_image_one_image_per_call", {"trunk_batch": 1})):
+        if kw and not one_image_per_call:
+            continue
         ex = OnlineFeatureExtractor(model, C, parts=("rpn", "detector", "mask"), **kw)
         torch.manual_seed(0)
         ex.train(samples[:6])
         best = None
-        for _ in range(6):                    # (a host-bound loop: another tenant's burst on the box's cores reads as + 10 % in one pass)
+        for _ in range(passes):               # (a host-bound loop: another tenant's burst on the box's cores reads as + 10 % in one pass)
             torch.manual_seed(0)
             dt, _ = _sync_time(lambda: ex.train(samples))
             best = dt if best is None else min(best, dt)
@@ -259,7 +267,7 @@ def harvest_extra(images=24, C=30, height=600, width=800):
     return out
 
 
-def detect_extra(height=600, width=800, rois=300, C=30, M=1000, reps=10):
+def detect_extra(height=600, width=800, rois=300, C=30, M=1000, reps=10, groups=(4, 8)):
     """One test-time image end to end (odx.extract.detect: trunk, RPN proposals, RoIAlign, conv5 head, the on-line box
     head of C FALKON classifiers + C box regressors, decode / threshold / per-class NMS / top-k): ms per image, with the
     post-processing also timed on its own.  Random weights and random models (shape only)."""
@@ -292,7 +300,7 @@ def detect_extra(height=600, width=800, rois=300, C=30, M=1000, reps=10):
         # groups of images through one forward and one pass of the heads (extract.detect_batch: what the evaluator drop-in runs)
         from odx.extract import detect_batch
         grp = {}
-        for B in (4, 8):
+        for B in groups:
             imgs = torch.randn((B, 3, height, width), generator=g).to(dev)
             for _ in range(3):
                 detect_batch(model, imgs, [(width, height)] * B, -2.0, 0.3, 100)
@@ -522,6 +530,32 @@ def config_extras():
         import odx
         odx.get_backend().release_workspaces()
         torch.cuda.empty_cache()
+    return out
+
+
+def after_headline():
+    """The latency-bound extras measured IN THE HEADLINE PROCESS, straight after its job released its buffers (round-5 review,
+    item 6: a user's process will have run a fit before it runs a forward): one-image forwards (R-50-C4, R-50-FPN, f32),
+    detect() on one image, the harvest loop per image at its default group size, the default Minibootstrap.  The same keys
+    are measured again in a fresh child process by collect(); both figures sit side by side in the bench line."""
+    out = {}
+
+    def run(key, fn, pick):
+        try:
+            r = fn()
+            out.update({k2: r.get(k1) for k1, k2 in pick})
+        except Exception as e:          # noqa: BLE001
+            out[key + "_error"] = "%s: %s" % (type(e).__name__, e)
+        torch.cuda.empty_cache()
+    run("minibootstrap", lambda: minibootstrap_extra(modes=(("default", None),)), (("s_default", "minibootstrap_s_default"),))
+    run("forward", lambda: forward_extra(dtypes=("f32",), groups=(8,)),
+        (("ms_per_image_f32", "forward_ms_per_image_f32"), ("ms_per_image_f32_group8", "forward_ms_per_image_f32_group8")))
+    run("forward_fpn", lambda: forward_fpn_extra(dtypes=("f32",), groups=(8,)),
+        (("ms_per_image_f32", "forward_fpn_ms_per_image_f32"), ("ms_per_image_f32_group8", "forward_fpn_ms_per_image_f32_group8")))
+    run("detect", lambda: detect_extra(groups=(8,)), (("ms_per_image", "detect_ms_per_image"), ("ms_per_image_group8", "detect_ms_per_image_group8")))
+    run("harvest", lambda: harvest_extra(passes=4, one_image_per_call=False), (("ms_per_image", "harvest_ms_per_image"),))
+    out["note"] = ("measured in the headline process right after its job released its buffers; the same keys under forward / "
+                   "forward_fpn / detect / harvest / minibootstrap come from a fresh child process")
     return out
 
 

@@ -14,6 +14,8 @@ PMC2="WRITE_SIZE"
 PMC3="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
 PMC4="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA"
 if [ "$PART" = "1" ]; then
+  # the kernel sources these passes are taken on: bench.py quotes `roofline.traffic` only from passes of ITS tree's sources
+  python -c "import json, bench; print(json.dumps({'csrc_sha16': bench.csrc_sha16()}))" > $OUT/pmc_meta.json
   python bench.py --steps 3 --warmup 2 > $OUT/bench_n1.json 2> $OUT/bench_n1.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
   for c in "$PMC1" "$PMC2" "$PMC3" "$PMC4"; do
