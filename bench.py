@@ -72,6 +72,8 @@ def parse():
                     help="issue the look-ahead preconditioner behind the batch's CG instead of before its fit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the rls / forward / detect / minibootstrap extra keys (N = 1 only)")
+    ap.add_argument("--extras", choices=("child", "inprocess"), default="child", help="where the full set of extras runs: a fresh child "
+                    "process (default; the latency-bound ones are ALSO measured in this process, key extras_in_headline_process) or this one")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="0 = pick by host core count")
     ap.add_argument("--check", action="store_true", help="verify one class against the oracle on a row sample")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) in production; gloo only for the "
@@ -445,7 +447,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": (("f32-accurate K_nM (X Z' as a two-term f16 split on the f16 MFMA, f32 accumulate) stored as %s + f64 solver%s"
                                                  % ({"f32": "f32", "u24": "24-bit fixed point (step 2^-24)", "bf16": "bf16 (throughput only)"}[kfmt],
-                                                    "" if os.environ.get("ODX_PRECOND", "")[:1] == "f" or (M < 4096 and os.environ.get("ODX_PRECOND", "")[:1] != "s") else
+                                                    "" if odx.options.current().precond == "f64" or (M < 4096 and odx.options.current().precond != "split") else
                                                     " (preconditioner: K_MM, T and T^-1 in f64; the products of the A factor, which only preconditions, at f32 accuracy on the f16 MFMA)"))
                                                 if be.gauss == "h2" else "f32 K_nM (f32-input MFMA) + f64 solver"),
             "data": "synthetic",
@@ -453,7 +455,9 @@ def main():
                                    "rows sharded over %d GPU(s)" % (C, N, D, M, args.maxiter, args.emulate_world if emulated else world),
                        "N": N, "D": D, "M": M, "classes": C, "sigma": args.sigma, "lambda": args.lam,
                        "rows_per_gpu": n_loc, "preconditioners_per_batched_chain": G, "preconditioner_cus": args.precond_cus or "all",
-                       "lockstep_batch": job_b, "planned_GB_per_rank": plan_gb, "cg_exchange": args.cg_exchange},
+                       "lockstep_batch": job_b, "planned_GB_per_rank": plan_gb, "cg_exchange": args.cg_exchange,
+                       # the one options table (odx/options.py): what this run's kernels and schedules were selected by
+                       "options": odx.options.as_dict()},
             "roofline": roof,
             "roofline_hbm": roof_p,
             "roofline_mfma": roof_g,
@@ -483,7 +487,7 @@ def main():
             # read 10-60 % worse than the same calls in a fresh process, and by how much depends on what the job's streams left
             # behind — helper streams of the chains (found and released this round: DESIGN section 7), which hardware queues
             # later streams land on (the Minibootstrap: 0.46 or 0.51 s).  What is wanted here is what those paths cost, not what
-            # the headline job's leftovers add to them; ODX_BENCH_EXTRAS=inprocess keeps the old arrangement.
+            # the headline job's leftovers add to them; --extras inprocess keeps the old arrangement.
             # ... and, first, the latency-bound ones HERE, behind the job (round-5 review, item 6: both figures are reported — a
             # user's process will have run a fit before it runs a forward)
             try:
@@ -493,7 +497,7 @@ def main():
                 out["extras_in_headline_process"] = {"error": "%s: %s" % (type(e).__name__, e)}
             be.release_workspaces()
             torch.cuda.empty_cache()
-            if os.environ.get("ODX_BENCH_EXTRAS", "child") == "inprocess":
+            if args.extras == "inprocess":
                 from tools import bench_extras
                 out.update(bench_extras.collect(args))
             else:

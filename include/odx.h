@@ -35,11 +35,30 @@ const char* odx_last_error_string(void);
 int odx_version(void);
 /* number of compute units of the current device (grid sizing for persistent kernels) */
 int odx_device_cus(void);
+/* Process-wide options of the library — the ONLY switches there are: no entry point reads the environment.  The host side sets
+ * them once when it loads the library (odx/options.py; INTEGRATION.md has the table).  Defaults = the benched configuration.
+ *
+ *   name                      values                         default  meaning
+ *   "h2_tile"                 0 | 128 | 256                  0        tile core of the split-f16 Gaussian kernels / row GEMMs:
+ *                                                                     0 = 256 x 256 once a launch has >= 512 (GEMMs: 256) tiles
+ *   "precond"                 0 | 1 | 2                      0        A factor of the preconditioner on the split-f16 core:
+ *                                                                     0 = from 4096 centres on, 1 = never (all-f64 chain), 2 = always
+ *   "chain_helpers"           -1 | 0 | 1                     -1       internal helper streams of the factorisation chains:
+ *                                                                     -1 = from 4096 rows on, 0 = never, 1 = always
+ *   "rls_force_nt_gram"       0 | 1                          0        TEST HOOK: every RLS Gram by the transposed-copy + NT-GEMM
+ *                                                                     route (otherwise only D % 8 != 0 takes it)
+ *   "rls_force_inverse_solve" 0 | 1                          0        TEST HOOK: every RLS solve by the explicit inverse
+ *                                                                     (otherwise only D + 1 > 2048 takes it)
+ *
+ * odx_set_option: ODX_ERR_INVALID for an unknown name or a value outside the column above.  odx_option_default: the default. */
+int odx_set_option(const char* name, int value);
+int odx_get_option(const char* name, int* value);
+int odx_option_default(const char* name, int* value);
 /* Destroys the calling thread's internal helper streams of the factorisation chains (odx_falkon_precond_*, odx_potrf_f64 from 4096
  * rows on: look-ahead updates, the inverse beside T T'); they are made again on demand.  Does not wait: the runtime keeps a
  * destroyed stream until the work queued on it has completed.  Call it when a fit / a training step is queued: on this runtime
  * the helpers of a class-batched chain, idle but alive, slow every later small launch of the process (a one-image forward behind
- * the headline job: 4.7 -> 7.6 ms).  ODX_CHAIN_RELEASE_HELPERS=1 makes every chain do it by itself. */
+ * the headline job: 4.7 -> 7.6 ms). */
 int odx_release_helper_streams(void);
 /* CU-partitioned execution (diagnostic: tools/cu_split_probe.py measured it and the job does NOT use it).
  * odx_stream_create_cu_mask: a HIP stream whose kernels run only on the compute units whose
@@ -106,7 +125,7 @@ int odx_gauss_mmv_f32(const float* X, int64_t ldx, const float* xsq, int64_t n,
 int odx_split_f16(const float* X, int64_t ldx, int64_t n, int D, void* P, int64_t ldp, float* meta,
                   odx_stream_t stream);
 int odx_split_f16_premax(const float* X, int64_t ldx, int64_t n, int D, void* P, int64_t ldp, float* meta, odx_stream_t stream);
-/* odx_set_h2_tile pins the tile core (128 or 256; 0 = automatic, the default): a process-wide setting for tests and
+/* odx_set_h2_tile(t) = odx_set_option("h2_tile", t): pins the tile core (128 or 256; 0 = automatic, the default) for tests and
  * measurements.  odx_gauss_h2_tile: side of the square output tile odx_gauss_knm_h2 uses for an n x M block under the
  * current setting; 0 for an empty block. */
 int odx_set_h2_tile(int tile);
@@ -124,7 +143,7 @@ int odx_gauss_knm_h2_rhs(const void* PX, int64_t ldpx, const float* metax, const
                          double sigma, float* K, int64_t ldk, const double* w, double* ktw, void* workspace,
                          int64_t workspace_bytes, odx_stream_t stream);
 /* Two tile cores serve both calls: 256 x 256 outputs per workgroup (half the L2 traffic per product) once a launch
- * has >= 512 such tiles, 128 x 128 below that; the environment variable ODX_H2_TILE=128|256 pins one.
+ * has >= 512 such tiles, 128 x 128 below that; the option "h2_tile" (odx_set_option) pins one.
  * Scoring is tiled over (row block, group of 512 centre columns); the f64 partial sums of the groups pass through
  * `workspace` (odx_gauss_mmv_h2_workspace_bytes(n, max_range, T)) and are added in fixed order.  max_range must be
  * >= the longest per-column row range (ranges[2c+1] - ranges[2c]); pass the number of rows of V when unknown. */
@@ -194,7 +213,7 @@ int odx_knm_fwd_bwd2_q(const void* K, int64_t ldk, const void* Klo, int64_t ldlo
  * dtype is f32, config/defaults.py:466).  Each operand value is rounded ONCE to e4m3 (after a power-of-two scaling of the
  * whole matrix), the products run on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales — a third of the MFMA issue
  * slots of the f16-split kernels at a quarter of the operand bytes.  K entries come out ~1e-3 off, scores ~5e-3
- * (tools/precision_scoring_study.py): NOT a parity path, never the default; ODX_GAUSS=f8 selects it in the Python backend.
+ * (tools/precision_scoring_study.py): NOT a parity path, never the default; odx.options gauss="f8" selects it in the Python backend.
  * odx_split_f8: P8 row-major e4m3 bytes, row stride ldp8 bytes (ldp8 % 16 == 0, ldp8 >= roundup(D, 128)), features past D
  * zero; meta[0] = the scale, meta[1] = max |x| (as odx_split_f16); qsq (n floats, may be NULL) = the squared norms of the
  * ROUNDED rows, |e4m3(s x)|^2 / s^2 — what the f8 kernels take as xsq / zsq, so that d^2 is the squared distance of the
@@ -369,9 +388,9 @@ int odx_rls_predict_rows_batched_f64(const float* X, int64_t ldx, int D, const i
  *          the whitened targets in the same padded order.  G (C blocks g_stride apart, (D+1) x ldg lower) += Gram,
  *          XtY (C blocks xy_stride apart, 4 x ldxy) += Yt [X 1] — straight from the f32 rows when D % 8 == 0, ldx % 4 == 0
  *          and X is 16-byte aligned (one TN Gram launch on the f64 matrix cores + one sweep for X'Y); otherwise, or with
- *          ODX_RLS_GRAM=nt in the environment, through a transposed f64 copy of the rows and the NT GEMM.
+ *          the test hook "rls_force_nt_gram", through a transposed f64 copy of the rows and the NT GEMM.
  *   solve: per class the result of odx_rls_solve_f64 (to rounding: Cholesky, then block substitution with the factor — one
- *          workgroup per class — instead of the explicit inverse; ODX_RLS_SOLVE=inverse keeps that form); W: C blocks w_stride
+ *          workgroup per class — instead of the explicit inverse; the test hook "rls_force_inverse_solve" keeps that form); W: C blocks w_stride
  *          apart, 4 x ldw; info: C words.
  * Two calls so that a row-sharded caller can all-reduce G and XtY in between. */
 int64_t odx_rls_gram_batched_workspace_bytes(int64_t npad, int D);
@@ -379,7 +398,7 @@ int64_t odx_rls_gram_batched_workspace_bytes(int64_t npad, int D);
  * targets (train_region_refiner.py:58-68: mean, covariance, its eigen-decomposition, the whitening): odx_rls_gram_batched_f64
  * with Yt == NULL and XtY == NULL forms the Grams alone, odx_rls_xty_batched_f64 (same workspace size) then adds Yt [X 1] and
  * the bias row / column of G.  Both need the rows form (odx_rls_rows_form(X, ldx, D) != 0: D % 8 == 0, ldx % 4 == 0, X 16-byte
- * aligned, ODX_RLS_GRAM != nt) and return ODX_ERR_UNSUPPORTED without it — the single call with Yt always works. */
+ * aligned, "rls_force_nt_gram" unset) and return ODX_ERR_UNSUPPORTED without it — the single call with Yt always works. */
 int odx_rls_rows_form(const float* X, int64_t ldx, int D);
 int odx_rls_xty_batched_f64(const float* X, int64_t ldx, int D, const int64_t* idx_pad, int64_t npad,
                             const int64_t* seg_off, const int64_t* seg_len, int C, const double* Yt, int64_t ldy,

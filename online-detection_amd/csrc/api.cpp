@@ -15,6 +15,52 @@ void set_error(const char* fmt, ...) {
 
 extern "C" const char* odx_last_error_string(void) { return odx::g_error; }
 
+// ---------------------------------------------------------------- options
+// One table instead of environment variables read inside launch paths (round-5 review, item 7).  The defaults ARE the benched
+// configuration; tests/test_abi.py pins them.
+#include "odx_internal.h"
+namespace odx {
+struct OptSpec {
+  const char* name;
+  int def, lo, hi;      // default, inclusive range (h2_tile: the three legal values are checked separately)
+};
+static const OptSpec g_opt_spec[OPT_COUNT] = {
+    {"h2_tile", 0, 0, 256}, {"precond", 0, 0, 2}, {"chain_helpers", -1, -1, 1}, {"rls_force_nt_gram", 0, 0, 1},
+    {"rls_force_inverse_solve", 0, 0, 1}};
+static int g_opt[OPT_COUNT] = {0, 0, -1, 0, 0};
+int lib_option(int which) { return g_opt[which]; }
+static int opt_index(const char* name) {
+  if (name)
+    for (int i = 0; i < OPT_COUNT; ++i)
+      if (strcmp(name, g_opt_spec[i].name) == 0) return i;
+  return -1;
+}
+}  // namespace odx
+
+extern "C" int odx_set_option(const char* name, int value) {
+  const int i = odx::opt_index(name);
+  ODX_REQUIRE(i >= 0, "odx_set_option: unknown option '%s'", name ? name : "(null)");
+  const odx::OptSpec& sp = odx::g_opt_spec[i];
+  ODX_REQUIRE(value >= sp.lo && value <= sp.hi && (i != odx::OPT_H2_TILE || value == 0 || value == 128 || value == 256),
+              "odx_set_option: %s = %d out of range", name, value);
+  odx::g_opt[i] = value;
+  return ODX_OK;
+}
+
+extern "C" int odx_get_option(const char* name, int* value) {
+  const int i = odx::opt_index(name);
+  ODX_REQUIRE(i >= 0 && value, "odx_get_option: unknown option '%s'", name ? name : "(null)");
+  *value = odx::g_opt[i];
+  return ODX_OK;
+}
+
+extern "C" int odx_option_default(const char* name, int* value) {
+  const int i = odx::opt_index(name);
+  ODX_REQUIRE(i >= 0 && value, "odx_option_default: unknown option '%s'", name ? name : "(null)");
+  *value = odx::g_opt_spec[i].def;
+  return ODX_OK;
+}
+
 extern "C" int odx_version(void) { return 100; }
 
 extern "C" int odx_device_cus(void) {

@@ -583,23 +583,17 @@ static std::vector<uint32_t> g_side_mask;
 // callers (fit_batch's half chains, the classes of a Minibootstrap round): every extra stream then competes for the runtime's
 // few hardware queues (4 by default) with the streams of the other chains — measured on a Minibootstrap round: 0.48 s with
 // the small chains in order on their caller's stream, 0.52-0.57 s with helpers, depending on which streams collided.
-// ODX_CHAIN_HELPERS=1 / 0 in the environment forces them on / off (read at every call).
+// The option chain_helpers (odx_set_option: -1 automatic, 0 never, 1 always) overrides the rule.
 constexpr int64_t CHAIN_HELPER_MIN_M = 4096;
 
 static bool chain_helpers(int64_t M) {
-  const char* e = getenv("ODX_CHAIN_HELPERS");
-  if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+  const int o = lib_option(OPT_CHAIN_HELPERS);
+  if (o == 0 || o == 1) return o == 1;
   return M >= CHAIN_HELPER_MIN_M;
 }
 
-// ODX_CHAIN_RELEASE_HELPERS=1: every chain releases its helper streams when its last launch is queued (two stream creations per
-// chain: +7 % on a 0.2 s training step of six classes, nothing at the headline's size).  Default: they stay until the caller
-// releases them (odx_release_helper_streams: the Python host side does at the end of a fit / a training step).
-static bool chain_release_helpers() {
-  const char* e = getenv("ODX_CHAIN_RELEASE_HELPERS");
-  return e && e[0] == '1';
-}
-
+// The helper streams stay until the caller releases them (odx_release_helper_streams: the host side does at the end of a fit /
+// a training step; releasing inside every chain cost 7 % on a 0.2 s training step and is gone).
 struct SideEntry {
   int device;
   hipStream_t caller;
@@ -691,12 +685,12 @@ constexpr int POTRF_NBO = 512;
 // The GEMM-shaped work of the A factor (T T' / M, the rank-512 updates of its Cholesky) on the split-f16 tile core: A only
 // preconditions the system (the solution the CG converges to does not depend on it, and the reference's all-f32 falkon gives it
 // f32 accuracy at best), so its products are formed at f32 accuracy at ~6 x the f64 MFMA rate; T, whose products define the
-// regulariser, stays f64 throughout.  ODX_PRECOND = "f64": never; "split": always; default: from 4096 centres on (below that
-// the chain is latency-bound and nothing is gained).  Read at every call.
+// regulariser, stays f64 throughout.  Option precond (odx_set_option): 1 = never ("f64"), 2 = always ("split"), 0 = from 4096
+// centres on (below that the chain is latency-bound and nothing is gained).
 static bool precond_split(int64_t M) {
-  const char* e = getenv("ODX_PRECOND");
-  if (e && e[0] == 'f') return false;
-  if (e && e[0] == 's') return true;
+  const int o = lib_option(OPT_PRECOND);
+  if (o == 1) return false;
+  if (o == 2) return true;
   return M >= 4096;
 }
 // scratch of the split path per matrix, in doubles: 2 M roundup(M, 64) 4-byte units for the packed T and, later, the four
@@ -971,10 +965,6 @@ extern "C" int odx_potrf_f64(double* A, int64_t lda, int64_t M, int32_t* info, v
   }
   ODX_CHECK_HIP(hipMemsetAsync(info, 0, sizeof(int32_t), as_stream(stream)));
   const int rc = potrf_f64(A, lda, M, static_cast<double*>(workspace), info, as_stream(stream));
-  if (chain_helpers(M) && chain_release_helpers()) {
-    const int rr = release_side_streams(false);
-    return rc != ODX_OK ? rc : rr;
-  }
   return rc;
 }
 
@@ -1027,17 +1017,12 @@ static int falkon_precond_f64_impl(const float* Z, int64_t ldz, int64_t M, int D
                                    double eps, double* LTi, double* LTit, double* LAi, double* LAit, int64_t ld,
                                    int32_t* info, void* workspace, int64_t workspace_bytes, odx_stream_t stream);
 
-// (ODX_CHAIN_RELEASE_HELPERS=1: the helper streams of a chain are released when its last launch is queued — the joins are already
-// in the caller's stream, the runtime keeps the streams until their work is done.  Left alive, the idle helpers of a
-// class-batched chain slow every later small launch of the process: odx_release_helper_streams.)
+// (Left alive, the idle helper streams of a class-batched chain slow every later small launch of the process: the caller
+// releases them when its fit / training step is queued, odx_release_helper_streams.)
 extern "C" int odx_falkon_precond_f64(const float* Z, int64_t ldz, int64_t M, int D, double sigma, double lam,
                                       double eps, double* LTi, double* LTit, double* LAi, double* LAit, int64_t ld,
                                       int32_t* info, void* workspace, int64_t workspace_bytes, odx_stream_t stream) {
   const int rc = falkon_precond_f64_impl(Z, ldz, M, D, sigma, lam, eps, LTi, LTit, LAi, LAit, ld, info, workspace, workspace_bytes, stream);
-  if (chain_helpers(M) && chain_release_helpers()) {
-    const int rr = release_side_streams(false);
-    return rc != ODX_OK ? rc : rr;
-  }
   return rc;
 }
 
@@ -1149,10 +1134,6 @@ extern "C" int odx_falkon_precond_batched_f64(const float* const* Z, const int64
                                               int64_t ld, int64_t out_stride, int32_t* info, void* workspace,
                                               int64_t workspace_bytes, odx_stream_t stream) {
   const int rc = falkon_precond_batched_f64_impl(Z, ldz, M, B, Mmax, D, sigma, lam, eps, out, ld, out_stride, info, workspace, workspace_bytes, stream);
-  if (Mmax > 0 && chain_helpers(Mmax) && chain_release_helpers()) {
-    const int rr = release_side_streams(false);
-    return rc != ODX_OK ? rc : rr;
-  }
   return rc;
 }
 

@@ -198,7 +198,7 @@ struct H2Stage {
 // units) from the uniform tile base, so the loads take the scalar-base + vector-offset form.
 // PERM (the B operand of the plain products): LDS row 64 b + 16 t + i of the image holds operand row 64 b + 4 i + t, so that the
 // four accumulator blocks tn = 0..3 of a lane are four ADJACENT output columns 64 wc + 4 (lane & 15) + tn (as on the wide
-// core, w_row_offsets): the epilogue moves 16 bytes per lane instead of four scattered floats.
+// core, w_dma_offsets<true>): the epilogue moves 16 bytes per lane instead of four scattered floats.
 template <bool PERM = false>
 __device__ __forceinline__ void h2_row_offsets(uint32_t (&voff)[8], int64_t ld, int64_t row0, int64_t nrows) {
   const int tid = threadIdx.x;
@@ -531,51 +531,16 @@ __global__ __launch_bounds__(256) void mmv_reduce_kernel(const double* __restric
 // of 8 lanes writes the 8 slots of one row.
 constexpr int W_BM = 256, W_BN = 256, W_THREADS = 512;
 constexpr int W_KS = 32;                                  // features per stage (one granule)
-enum { STG_REG = 0, STG_DMA = 1 };                        // operand staging: through registers (w_mainloop) or by LDS-DMA (w_mainloop_dma)
 constexpr int W_ROW = 128;                                // bytes per LDS row
 constexpr int W_OPND_BYTES = W_BM * W_ROW;                // 32,768
 constexpr int W_STAGE_BYTES = 2 * W_OPND_BYTES;           // 65,536
 constexpr int W_LDS_BYTES = 2 * W_STAGE_BYTES;            // 131,072
 
-struct WStage {
-  u32x4 a[4], b[4];
-};
-
-// thread t: 16-byte chunk t & 7 of rows (t >> 3) + 64 p.  Rows past the operand's end are read as its last row.
 // PERM (the B operand of the K_nM builds): LDS row 64 w + 16 t + r of the image holds operand row 64 w + 4 r + t, so that
 // the four accumulator blocks tn = 0..3 of a lane are four ADJACENT output columns 64 wc + 4 (lane & 15) + tn and the
 // epilogue stores 16 bytes per lane (a whole 256-byte row segment per 16 lanes) instead of four scattered floats.  The
-// image's geometry — and with it the conflict-free fragment reads — is unchanged: only which operand row a thread fetches.
-template <bool PERM>
-__device__ __forceinline__ void w_row_offsets(uint32_t (&voff)[4], int64_t ld, int64_t row0, int64_t nrows) {
-  const int tid = threadIdx.x;
-  const int64_t l64 = nrows - 1 - row0;               // >= 0: the tile starts inside the operand
-  const int last = l64 < W_BM - 1 ? (int)l64 : W_BM - 1;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int ri = (tid >> 3) + 64 * p;
-    const int r = PERM ? ((ri & ~63) | ((ri & 15) << 2) | ((ri >> 4) & 3)) : ri;
-    voff[p] = (uint32_t)(r < last ? r : last) * (uint32_t)ld + (uint32_t)(tid & 7) * 4u;
-  }
-}
+// image's geometry — and with it the conflict-free fragment reads — is unchanged: only which operand row a lane fetches.
 
-__device__ __forceinline__ void w_load_operand(u32x4 (&r)[4], const uint32_t* __restrict__ tile, const uint32_t (&voff)[4]) {
-#pragma unroll
-  for (int p = 0; p < 4; ++p) r[p] = *reinterpret_cast<const u32x4*>(tile + voff[p]);
-}
-
-__device__ __forceinline__ void w_store_operand(const u32x4 (&r)[4], char* lds) {
-  const int tid = threadIdx.x;
-  const int row = tid >> 3;
-  char* d = lds + row * W_ROW + (((tid & 7) ^ ((row >> 1) & 7)) << 4);   // ((row + 64 p) >> 1) & 7 == (row >> 1) & 7
-#pragma unroll
-  for (int p = 0; p < 4; ++p) *reinterpret_cast<u32x4*>(d + 64 * p * W_ROW) = r[p];
-}
-
-// One stage in four parts of two row blocks (24 MFMAs) each.  Between the parts the wave puts a quarter of stage s + 1
-// (two of its eight 16-byte pieces) into the other LDS buffer and re-issues the loads of those two registers for stage
-// s + 2: the LDS stores (64 KiB per stage at ~79 B/clk = 830 cycles of the LDS port) and the load issue then run under the
-// MFMA work instead of in front of it, and every register has exactly one stage of MFMA time to be refilled.
 // CORE_H2: operands are two-term f16 splits, three v_mfma_f32_16x16x32_f16 per product block (lo.hi, hi.lo, hi.hi).
 // CORE_F8: operands are OCP e4m3 bytes (odx_split_f8): a stage's 128 bytes per row are 128 FEATURES, and the 16-byte
 // pieces a lane reads as "hi" and "lo" — chunks g and g + 4 of the row — are simply its 32 of them: ONE
@@ -591,128 +556,8 @@ __device__ __forceinline__ i32x8 f8_frag(const f16x8& lo16, const f16x8& hi16) {
   return i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
 }
 
-template <int CORE>
-__device__ __forceinline__ void w_compute_part(f32x4 (&acc)[8][4], const char* pa, const f16x8 (&bh)[4], const f16x8 (&bl)[4],
-                                               int hi, int lo, int tm0) {
-#pragma unroll
-  for (int tm = tm0; tm < tm0 + 2; ++tm) {
-    const f16x8 ah = *reinterpret_cast<const f16x8*>(pa + tm * 16 * W_ROW + hi);
-    const f16x8 al = *reinterpret_cast<const f16x8*>(pa + tm * 16 * W_ROW + lo);
-    if (CORE == CORE_F8) {
-      const i32x8 a8 = f8_frag(ah, al);
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn)
-        acc[tm][tn] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8, f8_frag(bh[tn], bl[tn]), acc[tm][tn], 0, 0, 0,
-                                                                        F8_SCALE_ONE, 0, F8_SCALE_ONE);
-    } else if (CORE == CORE_BF16) {
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh[tn]), acc[tm][tn], 0, 0, 0);
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bl[tn]), acc[tm][tn], 0, 0, 0);
-      }
-    } else if (CORE == CORE_F16) {
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[tn], acc[tm][tn], 0, 0, 0);
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bl[tn], acc[tm][tn], 0, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[tn], acc[tm][tn], 0, 0, 0);
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[tn], acc[tm][tn], 0, 0, 0);
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[tn], acc[tm][tn], 0, 0, 0);
-      }
-    }
-  }
-}
-
-struct WAddr {
-  uint32_t offa[4], offb[4];   // global: per-thread offsets of its four rows of each operand (4-byte units)
-  int sto;                     // LDS: this thread's 16-byte slot of rows (tid >> 3) + 64 p of an operand image
-  int fa, fb, hi, lo;          // LDS: fragment rows of this lane in the A / B image, hi / lo chunk inside a row
-};
-
-// STORE: stage s + 1 exists (its registers go to `nxt`); LOAD: stage s + 2 exists (re-issue the loads).  Compile-time
-// flags keep the loop body free of branches, so the compiler can count its vmcnt waits exactly.
-template <bool STORE, bool LOAD, int CORE>
-__device__ __forceinline__ void w_stage(f32x4 (&acc)[8][4], WStage& st, const char* cur, char* nxt,
-                                        const uint32_t* __restrict__ ta2, const uint32_t* __restrict__ tb2, const WAddr& ad) {
-  f16x8 bh[4], bl[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    bh[t] = *reinterpret_cast<const f16x8*>(cur + ad.fb + t * 16 * W_ROW + ad.hi);
-    bl[t] = *reinterpret_cast<const f16x8*>(cur + ad.fb + t * 16 * W_ROW + ad.lo);
-  }
-#pragma unroll
-  for (int part = 0; part < 4; ++part) {
-    w_compute_part<CORE>(acc, cur + ad.fa, bh, bl, ad.hi, ad.lo, 2 * part);
-    if (STORE) {
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int p = 2 * (part & 1) + q;
-        if (part < 2) {
-          *reinterpret_cast<u32x4*>(nxt + ad.sto + 64 * p * W_ROW) = st.a[p];
-          if (LOAD) st.a[p] = *reinterpret_cast<const u32x4*>(ta2 + ad.offa[p]);
-        } else {
-          *reinterpret_cast<u32x4*>(nxt + W_OPND_BYTES + ad.sto + 64 * p * W_ROW) = st.b[p];
-          if (LOAD) st.b[p] = *reinterpret_cast<const u32x4*>(tb2 + ad.offb[p]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  __syncthreads();
-}
-
-// acc += A[i0 .. i0 + 256, :] . B[j0 .. j0 + 256, :]' over `stages` >= 1 granules.  Ends on a barrier (LDS reusable at once).
-// PERMB: the rows of B are fetched in the permuted order of w_row_offsets<true> (accumulator block tn of lane l is then
-// output column 64 wc + 4 (l & 15) + tn instead of 64 wc + 16 tn + (l & 15)).
-template <bool PERMB = false, int CORE = CORE_H2>
-__device__ __forceinline__ void w_mainloop(f32x4 (&acc)[8][4], const uint32_t* __restrict__ A, int64_t lda, int64_t m,
-                                           const uint32_t* __restrict__ B, int64_t ldb, int64_t n, int64_t i0, int64_t j0,
-                                           int stages, char* lds) {
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 2, wc = wave & 3;
-  WAddr ad;
-  w_row_offsets<false>(ad.offa, lda, i0, m);
-  w_row_offsets<PERMB>(ad.offb, ldb, j0, n);
-  const uint32_t* ta = A + i0 * lda;
-  const uint32_t* tb = B + j0 * ldb;
-  const int srow = tid >> 3;
-  ad.sto = srow * W_ROW + (((tid & 7) ^ ((srow >> 1) & 7)) << 4);
-  const int r = lane & 15, g = lane >> 4;
-  ad.hi = ((g ^ ((r >> 1) & 7)) << 4);
-  ad.lo = ad.hi ^ 64;
-  ad.fa = (wr * 128 + r) * W_ROW;
-  ad.fb = W_OPND_BYTES + (wc * 64 + r) * W_ROW;
-
-  WStage st;
-  w_load_operand(st.a, ta, ad.offa);
-  w_load_operand(st.b, tb, ad.offb);
-  w_store_operand(st.a, lds);
-  w_store_operand(st.b, lds + W_OPND_BYTES);
-  if (stages > 1) {
-    w_load_operand(st.a, ta + W_KS, ad.offa);
-    w_load_operand(st.b, tb + W_KS, ad.offb);
-  }
-  __syncthreads();
-  int s = 0;
-  for (; s + 2 < stages; ++s) {
-    // nxt was last read during stage s - 1, before the barrier that ended it
-    w_stage<true, true, CORE>(acc, st, lds + (s & 1) * W_STAGE_BYTES, lds + ((s + 1) & 1) * W_STAGE_BYTES,
-                        ta + (int64_t)(s + 2) * W_KS, tb + (int64_t)(s + 2) * W_KS, ad);
-  }
-  if (s + 1 < stages) {
-    w_stage<true, false, CORE>(acc, st, lds + (s & 1) * W_STAGE_BYTES, lds + ((s + 1) & 1) * W_STAGE_BYTES, ta, tb, ad);
-    ++s;
-  }
-  w_stage<false, false, CORE>(acc, st, lds + (s & 1) * W_STAGE_BYTES, lds, ta, tb, ad);
-}
-
-// ---- the same stage pipeline with the operands staged by LDS-DMA (buffer_load_dwordx4 ... lds) instead of through registers.
+// ---- the stage pipeline: operands staged by LDS-DMA (buffer_load_dwordx4 ... lds).  (Round 3's register-staged loop — global ->
+// registers -> ds_write — measured 8-10 % slower in same-process A/B runs and is gone.)
 // A wave-instruction of the DMA fills 1 KiB of LDS — 8 rows of the image — as wave-uniform base + lane * 16: lane l lands in
 // slot l & 7 of image row 8 P + (l >> 3), so the XOR swizzle of the image is applied on the SOURCE side (the lane fetches chunk
 // (l & 7) ^ ((row >> 1) & 7) of its row: the same 128-byte line, its 16-byte pieces permuted).  Wave w moves pieces w, w + 8,
@@ -721,7 +566,7 @@ __device__ __forceinline__ void w_mainloop(f32x4 (&acc)[8][4], const uint32_t* _
 // fragments, read before the current part's MFMAs are issued, so that no MFMA waits for an LDS read inside a stage.
 // Stage s + 1 is fetched into the other buffer during stage s; every wave waits for its own DMAs (vmcnt(0)) before the
 // barrier that ends the stage — nothing else orders a ds_read behind an LDS-DMA.  Rows are addressed through one buffer
-// descriptor per operand (tile base, rows clamped to the operand's last row as in w_row_offsets), the stage on the scalar
+// descriptor per operand (tile base, rows clamped to the operand's last row), the stage on the scalar
 // offset: no vector address arithmetic in the loop.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -1209,12 +1054,12 @@ __device__ __forceinline__ void knm_tile_epilogue(const f32x4 (&acc)[8][4], cons
   }
 }
 
-// accumulator element (tm, tn, q) of a wave's 128 x 64 share (B rows permuted, w_mainloop<true>):
+// accumulator element (tm, tn, q) of a wave's 128 x 64 share (B rows permuted, w_mainloop_dma<true>):
 // row 16 tm + 4 (lane >> 4) + q, column 4 (lane & 15) + tn — a lane holds four adjacent columns of every one of its rows.
 // RHS: also leave wslab[row block][j] = sum over the tile's rows i of K_ij w_i (f64), K_ij being the value the block
 // STORES (the dequantised one for KF_U24 / KF_BF16): the column sums K' w of the right-hand side of the fit come out of
 // the build, and the first pass over the stored K_nM is not needed.
-template <bool RHS, int FMT, int CORE, int STG>
+template <bool RHS, int FMT, int CORE>
 __global__ __launch_bounds__(W_THREADS, 1) void gauss_knm_h2w256_kernel(
     const uint32_t* __restrict__ PX, int64_t ldpx, const float* __restrict__ metax, const float* __restrict__ xsq, int64_t n,
     const uint32_t* __restrict__ PZ, int64_t ldpz, const float* __restrict__ metaz, const float* __restrict__ zsq, int64_t M,
@@ -1237,8 +1082,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_knm_h2w256_kernel(
 
   f32x4 acc[8][4];
   w_zero(acc);
-  if (STG == STG_DMA) w_mainloop_dma<true, CORE>(acc, PX, ldpx, n, PZ, ldpz, M, i0, j0, stages, lds);      // its barriers also publish xg_s
-  else w_mainloop<true, CORE>(acc, PX, ldpx, n, PZ, ldpz, M, i0, j0, stages, lds);
+  w_mainloop_dma<true, CORE>(acc, PX, ldpx, n, PZ, ldpz, M, i0, j0, stages, lds);      // its barriers also publish xg_s
 
   const float m2g = -2.f / (metax[0] * metaz[0]) * gamma_log2e;    // the scales are powers of two: m2 is exact
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1422,7 +1266,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_h2s16_kernel(
                    amax, pk);
 }
 
-template <int STG, bool TAPS = false>
+template <bool TAPS = false>
 __global__ __launch_bounds__(W_THREADS, 1) void gemm_h2w256_kernel(
     const uint32_t* __restrict__ PA, int64_t ldpa, const float* __restrict__ metaa, int64_t m, const uint32_t* __restrict__ PB,
     int64_t ldpb, const float* __restrict__ metab, int64_t n, int stages, const float* __restrict__ bias,
@@ -1439,8 +1283,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void gemm_h2w256_kernel(
   w_zero(acc);
   // B rows in the permuted order of the K_nM builds: a lane holds four ADJACENT output columns 64 wc + 4 (lane & 15) + tn
   // of each of its rows, and stores them (loads bias / residual) 16 bytes at a time when the matrices allow it
-  if (STG == STG_DMA) w_mainloop_dma<true, CORE_H2, TAPS>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds, tapH, tapW, tapC * 4);
-  else w_mainloop<true>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds);
+  w_mainloop_dma<true, CORE_H2, TAPS>(acc, PA, ldpa, m, PB, ldpb, n, i0, j0, stages, lds, tapH, tapW, tapC * 4);
   const float inv = 1.f / (metaa[0] * metab[0]);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 2, wc = wave & 3;
@@ -1812,7 +1655,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void gemm_h2w256_f64_kernel(H2F64Para
 
 // Fused scoring on the 256 x 256 core: same decomposition as gauss_mmv_h2s16_kernel (row block x group of `tg` column
 // tiles, f64 partial row sums per group in the slab, mmv_reduce_kernel adds the groups), 256-row blocks, 256-column tiles.
-template <int CORE, int STG>
+template <int CORE>
 __global__ __launch_bounds__(W_THREADS, 1) void gauss_mmv_h2w256_kernel(
     const uint32_t* __restrict__ PX, int64_t ldpx, const float* __restrict__ metax, const float* __restrict__ xsq, int64_t n,
     const uint32_t* __restrict__ PZ, int64_t ldpz, const float* __restrict__ metaz, const float* __restrict__ zsq, int stages,
@@ -1844,8 +1687,7 @@ __global__ __launch_bounds__(W_THREADS, 1) void gauss_mmv_h2w256_kernel(
   for (int64_t j0 = s0; j0 < s1; j0 += W_BN) {
     f32x4 acc[8][4];
     w_zero(acc);
-    if (STG == STG_DMA) w_mainloop_dma<false, CORE>(acc, PX, ldpx, n, PZ + j0 * ldpz, ldpz, r1 - j0, i0, 0, stages, lds);
-    else w_mainloop<false, CORE>(acc, PX, ldpx, n, PZ + j0 * ldpz, ldpz, r1 - j0, i0, 0, stages, lds);
+    w_mainloop_dma<false, CORE>(acc, PX, ldpx, n, PZ + j0 * ldpz, ldpz, r1 - j0, i0, 0, stages, lds);
     float zs[4];
     double al[4];
 #pragma unroll
@@ -1912,25 +1754,13 @@ static int h2_enable_lds(const void* fn, int bytes = S16_LDS_BYTES) {   // > 64 
 }
 
 // Tile core for a launch of `tiles256` 256 x 256 tiles: the wide core once it fills the chip twice over, the 128 x 128
-// core (4 x as many, smaller workgroups) below that.  odx_set_h2_tile(128 | 256) pins one (tests, measurements); the
-// environment variable ODX_H2_TILE gives the initial setting.
-static int g_h2_tile = -1;
-
-// ODX_H2_STAGING=reg keeps the register-staged main loop of the 256 x 256 core (A/B runs in one process: the variable is read
-// at every launch); default: LDS-DMA
-static int w_staging() {
-  const char* e = getenv("ODX_H2_STAGING");
-  return (e && e[0] == 'r') ? STG_REG : STG_DMA;
-}
-
+// core (4 x as many, smaller workgroups) below that.  The option h2_tile (odx_set_option / odx_set_h2_tile: 128 | 256) pins one
+// (tests, measurements).  The wide core stages its operands by LDS-DMA (round 4: 0.925 / 0.900 of the register-staged loop's
+// times in same-process A/B runs; the register-staged instantiations are gone).
 static bool h2_use_w256(int64_t tiles256) {
-  if (g_h2_tile < 0) {
-    const char* e = getenv("ODX_H2_TILE");
-    const int v = e ? atoi(e) : 0;
-    g_h2_tile = (v == 128 || v == 256) ? v : 0;
-  }
-  if (g_h2_tile == 128) return false;
-  if (g_h2_tile == 256) return true;
+  const int t = lib_option(OPT_H2_TILE);
+  if (t == 128) return false;
+  if (t == 256) return true;
   return tiles256 >= 512;
 }
 
@@ -2004,10 +1834,10 @@ int gemm_h2_f64(const uint32_t* PA, int64_t ldpa, int64_t zsa, float sa, const u
 
 using namespace odx;
 
+extern "C" int odx_set_option(const char* name, int value);
 extern "C" int odx_set_h2_tile(int tile) {
   ODX_REQUIRE(tile == 0 || tile == 128 || tile == 256, "odx_set_h2_tile: tile must be 0 (automatic), 128 or 256");
-  g_h2_tile = tile;
-  return ODX_OK;
+  return odx_set_option("h2_tile", tile);
 }
 
 extern "C" int odx_split_f16(const float* X, int64_t ldx, int64_t n, int D, void* P, int64_t ldp, float* meta,
@@ -2058,15 +1888,9 @@ static int launch_knm_w256_t(unsigned wt, hipStream_t s, const uint32_t* PX, int
                              int64_t n, const uint32_t* PZ, int64_t ldpz, const float* metaz, const float* zsq, int64_t M,
                              int stages, float g2, void* K, int64_t ldk, unsigned char* Klo, int64_t ldlo, int wgr,
                              const double* w, double* wslab, int64_t wslab_ld) {
-  if (w_staging() == STG_DMA) {
-    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2w256_kernel<RHS, FMT, CORE, STG_DMA>), W_LDS_BYTES));
-    hipLaunchKernelGGL((gauss_knm_h2w256_kernel<RHS, FMT, CORE, STG_DMA>), dim3(wt), dim3(W_THREADS), W_LDS_BYTES, s, PX, ldpx, metax,
-                       xsq, n, PZ, ldpz, metaz, zsq, M, stages, g2, K, ldk, Klo, ldlo, wgr, w, wslab, wslab_ld);
-  } else {
-    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2w256_kernel<RHS, FMT, CORE, STG_REG>), W_LDS_BYTES));
-    hipLaunchKernelGGL((gauss_knm_h2w256_kernel<RHS, FMT, CORE, STG_REG>), dim3(wt), dim3(W_THREADS), W_LDS_BYTES, s, PX, ldpx, metax,
-                       xsq, n, PZ, ldpz, metaz, zsq, M, stages, g2, K, ldk, Klo, ldlo, wgr, w, wslab, wslab_ld);
-  }
+  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_knm_h2w256_kernel<RHS, FMT, CORE>), W_LDS_BYTES));
+  hipLaunchKernelGGL((gauss_knm_h2w256_kernel<RHS, FMT, CORE>), dim3(wt), dim3(W_THREADS), W_LDS_BYTES, s, PX, ldpx, metax,
+                     xsq, n, PZ, ldpz, metaz, zsq, M, stages, g2, K, ldk, Klo, ldlo, wgr, w, wslab, wslab_ld);
   return ODX_OK;
 }
 
@@ -2077,9 +1901,7 @@ static int launch_knm_w256(const void* PX, int64_t ldpx, const float* metax, con
                            void* K, int64_t ldk, void* Klo, int64_t ldlo, const double* w, double* wslab, int64_t wslab_ld,
                            odx_stream_t stream, int core = CORE_H2) {
   // band height of the tile order; 2 / 4 / 8 / 16 / 32 measured alone: 395 / 397 / 391 / 376 / 347 TF
-  // (ODX_H2_BAND overrides it for experiments: a taller band re-streams the centres from the Infinity Cache less often)
-  static const int wgr_env = [] { const char* e = getenv("ODX_H2_BAND"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 64) ? v : 0; }();
-  const int wgr = wgr_env ? wgr_env : 4;
+  const int wgr = 4;
   const int64_t wt = round_up(ceil_div(n, W_BM), wgr) * ceil_div(M, W_BN);
   ODX_REQUIRE(wt < (1ll << 31), "odx_gauss_knm_h2: grid too large");
   const float g2 = (float)(-0.5 / (sigma * sigma)) * LOG2E;
@@ -2174,17 +1996,10 @@ static int gemm_h2_launch(const void* PA, int64_t ldpa, const float* metaa, int6
   if (t256 >= 256 && n > GEMM_BN) {           // the 256 x 256 core once it fills the chip (one workgroup per CU), else 128 x 128 tiles
     const int64_t wt = round_up(ceil_div(m, W_BM), gr) * ceil_div(n, W_BN);
     ODX_REQUIRE(wt < (1ll << 31), "odx_gemm_h2_f32: grid too large");
-    if (w_staging() == STG_DMA) {
-      ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2w256_kernel<STG_DMA>), W_LDS_BYTES));
-      hipLaunchKernelGGL(gemm_h2w256_kernel<STG_DMA>, dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
-                         (const uint32_t*)PA, ldpa, metaa, m, (const uint32_t*)PB, ldpb, metab, n, (int)(dp / W_KS), bias, residual,
-                         ldr, relu, out, ldo, gr, amax, 0, 0, 0, pk);
-    } else {
-      ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2w256_kernel<STG_REG>), W_LDS_BYTES));
-      hipLaunchKernelGGL(gemm_h2w256_kernel<STG_REG>, dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
-                         (const uint32_t*)PA, ldpa, metaa, m, (const uint32_t*)PB, ldpb, metab, n, (int)(dp / W_KS), bias, residual,
-                         ldr, relu, out, ldo, gr, amax, 0, 0, 0, pk);
-    }
+    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2w256_kernel<false>), W_LDS_BYTES));
+    hipLaunchKernelGGL(gemm_h2w256_kernel<false>, dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
+                       (const uint32_t*)PA, ldpa, metaa, m, (const uint32_t*)PB, ldpb, metab, n, (int)(dp / W_KS), bias, residual,
+                       ldr, relu, out, ldo, gr, amax, 0, 0, 0, pk);
     ODX_CHECK_LAUNCH("odx_gemm_h2_f32(w256)");
     return ODX_OK;
   }
@@ -2359,7 +2174,7 @@ extern "C" int odx_taps3x3_packed(const void* PY, int64_t ldpy, int64_t R, int H
 // 1 when odx_gemm_h2_taps_f32 serves this layer: the 256 x 256 LDS-DMA core (it fills the chip: >= 256 tiles, more than 128
 // output columns), whole 32-channel stages per tap, 32-bit byte offsets over the packed rows.
 static bool h2_taps_wide(int64_t m, int64_t n, int C) {        // the layer goes to the 256 x 256 LDS-DMA core (gemm_h2_launch's rule)
-  return n > GEMM_BN && C % W_KS == 0 && w_staging() == STG_DMA && ceil_div(m, W_BM) * ceil_div(n, W_BN) >= 256;
+  return n > GEMM_BN && C % W_KS == 0 && ceil_div(m, W_BM) * ceil_div(n, W_BN) >= 256;
 }
 
 extern "C" int odx_gemm_h2_taps_supported(int64_t m, int64_t n, int C, int64_t ldpy) {
@@ -2404,8 +2219,8 @@ extern "C" int odx_gemm_h2_taps_f32(const void* PY, int64_t ldpy, const float* m
   }
   const int64_t wt = round_up(ceil_div(m, W_BM), gr) * ceil_div(n, W_BN);
   ODX_REQUIRE(wt < (1ll << 31), "odx_gemm_h2_taps_f32: grid too large");
-  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2w256_kernel<STG_DMA, true>), W_LDS_BYTES));
-  hipLaunchKernelGGL((gemm_h2w256_kernel<STG_DMA, true>), dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
+  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gemm_h2w256_kernel<true>), W_LDS_BYTES));
+  hipLaunchKernelGGL((gemm_h2w256_kernel<true>), dim3((unsigned)wt), dim3(W_THREADS), W_LDS_BYTES, as_stream(stream),
                      (const uint32_t*)PY, ldpy, metay, m, (const uint32_t*)PB, ldpb, metab, n, (int)(K / W_KS), bias, residual, ldr,
                      relu, out, ldo, gr, amax, H, W, C, pk);
   ODX_CHECK_LAUNCH("odx_gemm_h2_taps_f32");
@@ -2454,7 +2269,8 @@ static int launch_gemm_b16(const void* A, int64_t lda, int64_t m, const void* B,
                            const void* residual, int64_t ldr, int relu, void* out, int64_t ldo, hipStream_t s) {
   const int gr = 8;
   const int64_t t256 = ceil_div(m, W_BM) * ceil_div(n, W_BN);
-  const bool wide = g_h2_tile == 256 || (g_h2_tile != 128 && t256 >= 256 && n > GEMM_BN);     // (<= 128 columns: half a wide tile idle)
+  const int pin = lib_option(OPT_H2_TILE);
+  const bool wide = pin == 256 || (pin != 128 && t256 >= 256 && n > GEMM_BN);     // (<= 128 columns: half a wide tile idle)
   if (wide) {                  // the 256 x 256 core once it fills the chip (one workgroup per CU), else 128 x 128 tiles
     const int64_t wt = round_up(ceil_div(m, W_BM), gr) * ceil_div(n, W_BN);
     ODX_REQUIRE(wt < (1ll << 31), "odx_gemm_b16: grid too large");
@@ -2496,7 +2312,8 @@ extern "C" int odx_gemm_b16(const void* A, int64_t lda, int64_t m, const void* B
 // 16-bit NHWC rows Y (R H W rows of C channels, C % 64 == 0, row stride ldy elements, FOLLOWED BY ONE ALL-ZERO ROW) gathered
 // inside the product's operand loads — odx_taps3x3_16's matrix is never written.  B (n x 9 C) as for odx_gemm_b16.
 static bool b16_taps_wide(int64_t m, int64_t n, int C) {       // launch_gemm_b16's rule for the 256 x 256 core
-  return C % 64 == 0 && (g_h2_tile == 256 || (g_h2_tile != 128 && ceil_div(m, W_BM) * ceil_div(n, W_BN) >= 256 && n > GEMM_BN));
+  const int pin = lib_option(OPT_H2_TILE);
+  return C % 64 == 0 && (pin == 256 || (pin != 128 && ceil_div(m, W_BM) * ceil_div(n, W_BN) >= 256 && n > GEMM_BN));
 }
 
 extern "C" int odx_gemm_b16_taps_supported(int64_t m, int64_t n, int C, int64_t ldy) {
@@ -2785,17 +2602,10 @@ static int launch_mmv_w256(const void* PX, int64_t ldpx, const float* metax, con
   const int64_t Gw = ceil_div(ceil_div(max_range, W_BN), W_MMV_TG);      // <= mmv_groups(max_range): the slab is large enough
   const int64_t wgs = round_up(ceil_div(n, W_BM), 8) * Gw;
   ODX_REQUIRE(wgs < (1ll << 31), "odx_gauss_mmv: grid too large");
-  if (w_staging() == STG_DMA) {
-    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_mmv_h2w256_kernel<CORE, STG_DMA>), W_LDS_BYTES));
-    hipLaunchKernelGGL((gauss_mmv_h2w256_kernel<CORE, STG_DMA>), dim3((unsigned)wgs, (unsigned)C), dim3(W_THREADS), W_LDS_BYTES,
-                       as_stream(stream), (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq, stages,
-                       (float)(-0.5 / (sigma * sigma)) * LOG2E, V, ldv, ranges, W_MMV_TG, (int)Gw, slab, slab_ld);
-  } else {
-    ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_mmv_h2w256_kernel<CORE, STG_REG>), W_LDS_BYTES));
-    hipLaunchKernelGGL((gauss_mmv_h2w256_kernel<CORE, STG_REG>), dim3((unsigned)wgs, (unsigned)C), dim3(W_THREADS), W_LDS_BYTES,
-                       as_stream(stream), (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq, stages,
-                       (float)(-0.5 / (sigma * sigma)) * LOG2E, V, ldv, ranges, W_MMV_TG, (int)Gw, slab, slab_ld);
-  }
+  ODX_PROPAGATE(h2_enable_lds(reinterpret_cast<const void*>(gauss_mmv_h2w256_kernel<CORE>), W_LDS_BYTES));
+  hipLaunchKernelGGL((gauss_mmv_h2w256_kernel<CORE>), dim3((unsigned)wgs, (unsigned)C), dim3(W_THREADS), W_LDS_BYTES,
+                     as_stream(stream), (const uint32_t*)PX, ldpx, metax, xsq, n, (const uint32_t*)PZ, ldpz, metaz, zsq, stages,
+                     (float)(-0.5 / (sigma * sigma)) * LOG2E, V, ldv, ranges, W_MMV_TG, (int)Gw, slab, slab_ld);
   ODX_CHECK_LAUNCH("odx_gauss_mmv(w256)");
   hipLaunchKernelGGL(mmv_reduce_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)C), dim3(256), 0, as_stream(stream), slab,
                      slab_ld, (int)Gw, W_MMV_TG, W_BN, ranges, n, out, ldo);

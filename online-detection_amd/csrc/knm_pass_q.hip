@@ -456,40 +456,23 @@ struct QCfg {
 // copy of v in LDS: independent workgroups drift apart, so one multiplies while the other waits for memory — a single
 // 512-thread workgroup meets at its barrier every row block, its eight waves wait and compute together, and the decode's
 // extra vector work (a third more instructions per byte than the f32 kernel) then adds to the memory time instead of
-// hiding under it.  Measured at n = 5e5, M = 1e4, 24-bit format (tools/passq_bench.py):
+// hiding under it.  Measured at n = 5e5, M = 1e4, 24-bit format (round 3, per-configuration timings):
 // 512 x 5 x 6 rows 5.2 TB/s; two register sets alternating across the barrier 5.0-5.1; 8-column chunks (16-byte loads)
 // 4.9-5.2; descriptors per (row, chunk) 5.2; 2 x (256 x 10 x 2 rows) 5.73 TB/s.  f32 kernel: 5.96.
 static bool pick_qcfg(int64_t M, int nv, int fmt, QCfg* cfg) {
   const int64_t chunks = (M + 3) / 4;
   if (nv == 1) {
-    // experiments: ODX_PASSQ_CFG="nt ch r" forces a configuration (must cover the row and be one of those built below)
-    if (const char* e = getenv("ODX_PASSQ_CFG")) {
-      int nt = 0, ch = 0, r = 0;
-      // only tuples dispatch_passq() instantiates: an unlisted one would run another configuration's kernel on a grid and an
-      // LDS size computed for this one (out-of-bounds LDS reads); anything else in the variable is ignored
-      static const int built[][3] = {{0, 2, 8}, {0, 4, 4}, {0, 10, 2}, {256, 1, 16}, {256, 2, 8}, {256, 4, 8}, {256, 8, 3}, {256, 10, 2},
-                                     {512, 4, 8}, {512, 5, 6}, {512, 6, 4}, {1024, 5, 1}};
-      bool ok = false;
-      if (sscanf(e, "%d %d %d", &nt, &ch, &r) == 3)
-        for (const auto& b : built) ok = ok || (b[0] == nt && b[1] == ch && b[2] == r);
-      if (fmt == QF_BF16 && nt == 256 && ch == 10 && r == 3) ok = true;
-      if (ok && (int64_t)(nt ? nt : 256) * ch >= chunks) { *cfg = {nt, ch, r, (nt == 0) ? (ch == 10 ? 1 : 2) : (nt <= 256 ? 2 : 1)}; return true; }
-    }
     if (chunks <= 256) { *cfg = {256, 1, 16, 2}; return true; }
     // (the two-halves form, two workgroups per CU: 4.9 / 5.0 TB/s at M = 2000 / 3000 against 4.1 / 4.5 for the barrier form
     // below; at 8 chunks per thread it needs the CU to itself and loses to it — 5.1 against 5.3 TB/s at M = 6000)
-    const bool halves = !getenv("ODX_PASSQ_NO_STAGGER");
-    if (halves && chunks <= 512) { *cfg = {0, 2, 8, 2}; return true; }
-    if (halves && chunks <= 1024) { *cfg = {0, 4, 4, 2}; return true; }
-    if (chunks <= 512) { *cfg = {256, 2, 8, 2}; return true; }
-    if (chunks <= 1024) { *cfg = {256, 4, 8, 2}; return true; }
+    if (chunks <= 512) { *cfg = {0, 2, 8, 2}; return true; }
+    if (chunks <= 1024) { *cfg = {0, 4, 4, 2}; return true; }
     if (chunks <= 2048) { *cfg = {256, 8, 3, 2}; return true; }
     // (2 x (256 x 10 x 2 rows) is 10 % faster alone at M = 1e4 but needs the CU's whole LDS for its two copies of v: beside
     // the preconditioner stream of the headline job a CU holding one small workgroup of another kernel takes only ONE of
     // the two, the displaced workgroup of the persistent grid runs after the others, and the pass loses more than it won
-    // — 5.10 against 5.30 TB/s inside bench.py.  ODX_PASSQ_CFG="256 10 2" selects it.)
-    if (chunks <= 2560 && !getenv("ODX_PASSQ_NO_STAGGER")) { *cfg = {0, 10, 2, 1}; return true; }      // two free-running halves
-    if (chunks <= 2560) { *cfg = {512, 5, 6, 1}; return true; }
+    // — 5.10 against 5.30 TB/s inside bench.py.)
+    if (chunks <= 2560) { *cfg = {0, 10, 2, 1}; return true; }      // two free-running halves
     if (chunks <= 3072) { *cfg = {512, 6, 4, 1}; return true; }
     if (chunks <= 5110) { *cfg = {1024, 5, 1, 1}; return true; }      // v + its zero chunk + the reduction scratch in 160 KB of LDS
     return false;
@@ -552,17 +535,9 @@ static int dispatch_passq(const QCfg& cfg, int grid, size_t lds, hipStream_t s, 
       ODX_QH(10, 2);
 #undef ODX_QH
     }
+    // (exactly the configurations pick_qcfg hands out)
     if (cfg.nt == 256 && cfg.ch == 1) ODX_Q(256, 1, 16);
-    if (cfg.nt == 256 && cfg.ch == 2) ODX_Q(256, 2, 8);
-    if (cfg.nt == 256 && cfg.ch == 4) ODX_Q(256, 4, 8);
     if (cfg.nt == 256 && cfg.ch == 8) ODX_Q(256, 8, 3);
-    if (cfg.nt == 256 && cfg.ch == 10 && cfg.r == 2) ODX_Q(256, 10, 2);
-    if (cfg.nt == 256 && cfg.ch == 10) {
-      if constexpr (FMT == QF_BF16) ODX_Q(256, 10, 3);
-      else ODX_Q(256, 10, 2);
-    }
-    if (cfg.nt == 512 && cfg.ch == 4) ODX_Q(512, 4, 8);
-    if (cfg.nt == 512 && cfg.ch == 5) ODX_Q(512, 5, 6);
     if (cfg.nt == 512 && cfg.ch == 6) ODX_Q(512, 6, 4);
     ODX_Q(1024, 5, 1);
   } else {
@@ -594,7 +569,7 @@ static bool passq_batch_cfg(int B, const int64_t* M, int fmt, QCfg* out) {
   }
   // (the configurations launch_passq_batched instantiates)
   const bool built = (c0.nt == 0 && (c0.ch == 2 || c0.ch == 4 || c0.ch == 10)) ||
-                     (c0.nt == 256 && (c0.ch == 1 || c0.ch == 2 || c0.ch == 4 || c0.ch == 8)) || (c0.nt == 512 && (c0.ch == 5 || c0.ch == 6));
+                     (c0.nt == 256 && (c0.ch == 1 || c0.ch == 8)) || (c0.nt == 512 && c0.ch == 6);
   if (out) *out = c0;
   return B > 0 && built;
 }
@@ -642,10 +617,7 @@ static int launch_passq_batched(const QCfg& cfg, const PassBatchQ& pb, int gmax,
   if (cfg.nt == 0 && cfg.ch == 4) ODX_QBH(4, 4);
   if (cfg.nt == 0 && cfg.ch == 10) ODX_QBH(10, 2);
   if (cfg.nt == 256 && cfg.ch == 1) ODX_QB(256, 1, 16);
-  if (cfg.nt == 256 && cfg.ch == 2) ODX_QB(256, 2, 8);
-  if (cfg.nt == 256 && cfg.ch == 4) ODX_QB(256, 4, 8);
   if (cfg.nt == 256 && cfg.ch == 8) ODX_QB(256, 8, 3);
-  if (cfg.nt == 512 && cfg.ch == 5) ODX_QB(512, 5, 6);
   if (cfg.nt == 512 && cfg.ch == 6) ODX_QB(512, 6, 4);
 #undef ODX_QB
 #undef ODX_QBH

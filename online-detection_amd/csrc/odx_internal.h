@@ -3,6 +3,18 @@
 #include "odx_common.h"
 
 namespace odx {
+// The library's process-wide options (api.cpp: odx_set_option / odx_get_option; include/odx.h has the table).  Set once by the
+// host side when it loads the library (odx/options.py); no kernel or launch path reads the environment.
+enum LibOpt {
+  OPT_H2_TILE = 0,                 // 0 automatic | 128 | 256: the split-f16 tile core of the Gaussian kernels and row GEMMs
+  OPT_PRECOND,                     // 0 automatic (A factor on the split core from 4096 centres on) | 1 all-f64 chain | 2 split always
+  OPT_CHAIN_HELPERS,               // -1 automatic (helper streams from 4096 centres on) | 0 never | 1 always
+  OPT_RLS_FORCE_NT_GRAM,           // test hook: 1 = the transposed-copy + NT-GEMM Gram (the route of D % 8 != 0) for every D
+  OPT_RLS_FORCE_INVERSE_SOLVE,     // test hook: 1 = the explicit-inverse solve (the route of D + 1 > 16 x 128) for every D
+  OPT_COUNT
+};
+int lib_option(int which);
+
 
 constexpr int ODX_MAX_ZBATCH = 32;    // classes per batched launch (kernel-argument arrays are sized by it)
 

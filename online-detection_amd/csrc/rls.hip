@@ -129,14 +129,12 @@ __global__ __launch_bounds__(256) void rls_xty_kernel(const double* __restrict__
 // ---------------------------------------------------------------- the Grams of a class batch straight from the f32 rows
 // G_c (D x D, lower 128 x 64 tiles) += X_c' X_c for the rows listed in class c's padded segment of idx (-1 = no row), on the
 // f64 MFMA (v_mfma_f64_16x16x4_f64) WITHOUT the transposed f64 copy of the rows the NT GEMM needs (round 3: a 2.46 GB write
-// and read-back at config 3's size): a k-tile is 16 ROWS of X — 128 (A side) + 64 (B side) consecutive floats of each,
-// gathered by row id, converted to f64 on the way into LDS as [k][column] rows of 144 / 80 doubles (the four k-rows a 32-lane
-// group of ds_read_b64 touches lie 128 bytes apart modulo the 256-byte bank window: conflict-free), the next k-tile's floats
-// prefetched into registers under the MFMAs.  One workgroup owns a tile and walks all of the class's rows: the sum over k is
-// in one fixed order (bitwise reproducible; row shards add their Grams by all-reduce afterwards).
+// and read-back at config 3's size): a k-tile is a block of ROWS of X — 128 (A side) + 64 (B side) consecutive floats of each,
+// gathered by row id into LDS as [k][column] rows, the next k-tile's floats prefetched into registers under the MFMAs
+// (rls_gram_rows32_kernel below).  One workgroup owns a tile and walks all of the class's rows: the sum over k is in one fixed
+// order (bitwise reproducible; row shards add their Grams by all-reduce afterwards).
 typedef float f32x2r __attribute__((ext_vector_type(2)));
-constexpr int RG_BM = 128, RG_BN = 64, RG_BK = 16;
-constexpr int RG_LDA = RG_BM + 16, RG_LDB = RG_BN + 16;      // doubles per LDS row
+constexpr int RG_BM = 128, RG_BN = 64;
 
 // The tile (class c, tile row bi, tile column bj) of a workgroup of the Gram launches (grid: tiles x 1 x classes).
 __device__ __forceinline__ void rls_gram_tile_of(int D, bool heavy_first, int& c, int& bi, int& bj) {
@@ -171,170 +169,10 @@ __device__ __forceinline__ void rls_gram_tile_of(int D, bool heavy_first, int& c
   }
 }
 
-__global__ __launch_bounds__(256, 3) void rls_gram_rows_kernel(const float* __restrict__ X, int64_t ldx, int D,
-                                                               const int64_t* __restrict__ idx, RlsSegs sg, double* __restrict__ G,
-                                                               int64_t ldg, int64_t g_stride, const float* __restrict__ Yraw,
-                                                               int64_t ldyr, double* __restrict__ O5, int64_t ldo) {
-  __shared__ __attribute__((aligned(16))) double lds_a[RG_BK * RG_LDA];
-  __shared__ __attribute__((aligned(16))) double lds_b[RG_BK * RG_LDB];
-  __shared__ __attribute__((aligned(16))) double lds_y[RG_BK * 4];
-  int c, bi, bj;
-  rls_gram_tile_of(D, Yraw != nullptr, c, bi, bj);
-  const int i0 = bi * RG_BM, j0 = bj * RG_BN;
-  if (i0 >= D || j0 > i0 + RG_BM - 1) return;                  // lower tiles only
-  const int64_t off = sg.off[c], len = sg.len[c];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int krow = tid >> 4, seg = tid & 15;
-  // this thread's columns: pairs (2 seg, 2 seg + 1) of the four 32-column groups of the A side and the two of the B side —
-  // the 16 lanes of a k-row write 16 consecutive 16-byte pairs of an LDS row (conflict-free; eight consecutive columns per
-  // lane put lanes 0, 4, 8, 12 on the same banks: four-way conflicts on every store)
-  // D % 8 == 0 (the host's condition for this kernel): a pair is whole or absent; an absent one reads the row's first floats
-  // and is zeroed on the way into LDS, like a padded row (id -1 -> row 0).  No branch around a load: with one the compiler
-  // waits for every load at the join, i.e. in front of the MFMAs the loads are meant to hide under.
-  int cae[4], cbe[2];
-  bool aok[4], bok[2];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int col = i0 + q * 32 + seg * 2;
-    aok[q] = col < D;
-    cae[q] = aok[q] ? col : 0;
-  }
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int col = j0 + q * 32 + seg * 2;
-    bok[q] = col < D;
-    cbe[q] = bok[q] ? col : 0;
-  }
-  f64x4 acc[4][2];
-#pragma unroll
-  for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = f64x4{0.0, 0.0, 0.0, 0.0};
-  const int64_t nk = (len + RG_BK - 1) / RG_BK;
-  if (nk == 0) {
-    if (Yraw != nullptr && j0 == 0 && tid < 128 && i0 + tid < D)
-      for (int j = 0; j < 5; ++j) O5[((int64_t)c * 5 + j) * ldo + i0 + tid] = 0.0;
-    return;
-  }
-  // the row id of a k-tile is fetched one k-tile before its row is: the row's loads never wait for a dependent load
-  // (the segment is padded with -1 to a multiple of 16 rows; past the last k-tile the last one is read again and dropped)
-  auto row_of = [&](int64_t kt) -> int64_t { return idx[off + (kt < nk ? kt : nk - 1) * RG_BK + krow]; };
-  // Yraw != nullptr: the workgroups of the first tile column also form [Y 1]' X for their 128 columns — the RAW targets' products
-  // and the column sums, on the vector ALU under the MFMAs (O5[c][0..3] = Y' X, O5[c][4] = 1' X): with them the whitened targets'
-  // X' Yw = (X' Y - X' 1 mu') T needs no second sweep over the rows once the statistics are known (odx_rls_fold_whitened_f64)
-  const bool xty = Yraw != nullptr && j0 == 0;
-  f32x2r ra[4], rb[2];
-  f32x4r ry = {0.f, 0.f, 0.f, 0.f};
-  bool valid;
-  auto load = [&](int64_t row) {
-    valid = row >= 0;
-    const float* x = X + (valid ? row : 0) * ldx;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) ra[q] = *reinterpret_cast<const f32x2r*>(x + cae[q]);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) rb[q] = *reinterpret_cast<const f32x2r*>(x + cbe[q]);
-    if (xty && seg == 0) ry = *reinterpret_cast<const f32x4r*>(Yraw + (valid ? row : 0) * ldyr);
-  };
-  double ysum[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  const int ycol = tid & 127, yhalf = tid >> 7;               // the targets' products: column ycol of the A side, two k-rows of every step
-  int64_t row_next = row_of(1);
-  load(row_of(0));
-  const int r16 = lane & 15, kq = lane >> 4;
-  for (int64_t kt = 0; kt < nk; ++kt) {
-    __syncthreads();                                           // everyone finished reading the previous k-tile
-    double* da = lds_a + krow * RG_LDA + seg * 2;
-    double* db = lds_b + krow * RG_LDB + seg * 2;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float m = valid && aok[q] ? 1.f : 0.f;
-      *reinterpret_cast<f64x2*>(da + q * 32) = f64x2{(double)(m * ra[q][0]), (double)(m * ra[q][1])};
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const float m = valid && bok[q] ? 1.f : 0.f;
-      *reinterpret_cast<f64x2*>(db + q * 32) = f64x2{(double)(m * rb[q][0]), (double)(m * rb[q][1])};
-    }
-    if (xty && seg == 0) {                                     // (a padded row's A entries are zero: its targets only have to be finite)
-      *reinterpret_cast<f64x2*>(lds_y + krow * 4) = f64x2{(double)ry[0], (double)ry[1]};
-      *reinterpret_cast<f64x2*>(lds_y + krow * 4 + 2) = f64x2{(double)ry[2], (double)ry[3]};
-    }
-    __syncthreads();
-    load(row_next);
-    row_next = row_of(kt + 2);
-    __builtin_amdgcn_sched_barrier(0);                         // (the loads stay in front of the MFMAs they hide under)
-    // (the next step's operands are read from LDS BEFORE this step's eight matrix instructions are issued: written as read-then-
-    // multiply per step, every step began with an LDS round trip nothing else of the wave covered)
-    double a[2][4], b[2][2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a[0][t] = lds_a[kq * RG_LDA + wr * 64 + t * 16 + r16];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) b[0][t] = lds_b[kq * RG_LDB + wc * 32 + t * 16 + r16];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int cur = ks & 1, nxt = cur ^ 1;
-      if (ks < 3) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) a[nxt][t] = lds_a[((ks + 1) * 4 + kq) * RG_LDA + wr * 64 + t * 16 + r16];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) b[nxt][t] = lds_b[((ks + 1) * 4 + kq) * RG_LDB + wc * 32 + t * 16 + r16];
-        __builtin_amdgcn_sched_barrier(0);                     // (reads first: the scheduler sinks them below the multiplies otherwise)
-      }
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][tm], b[cur][tn], acc[tm][tn], 0, 0, 0);
-      if (xty) {
-        // two of this step's four k-rows per thread: ten vector FMAs issued while the matrix pipe works off the eight above
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const int kr = ks * 4 + yhalf * 2 + r;
-          const double av = lds_a[kr * RG_LDA + ycol];
-          const f64x2 y01 = *reinterpret_cast<const f64x2*>(lds_y + kr * 4), y23 = *reinterpret_cast<const f64x2*>(lds_y + kr * 4 + 2);
-          ysum[0] = fma(av, y01[0], ysum[0]);
-          ysum[1] = fma(av, y01[1], ysum[1]);
-          ysum[2] = fma(av, y23[0], ysum[2]);
-          ysum[3] = fma(av, y23[1], ysum[3]);
-          ysum[4] += av;
-        }
-      }
-    }
-  }
-  if (xty) {
-    // the two halves of the k-rows: the upper one through LDS, one fixed order of additions
-    __syncthreads();
-    if (yhalf == 1) {
-#pragma unroll
-      for (int j = 0; j < 5; ++j) lds_a[j * 128 + ycol] = ysum[j];
-    }
-    __syncthreads();
-    if (yhalf == 0 && i0 + ycol < D) {
-#pragma unroll
-      for (int j = 0; j < 5; ++j) O5[((int64_t)c * 5 + j) * ldo + i0 + ycol] = ysum[j] + lds_a[j * 128 + ycol];
-    }
-  }
-  // accumulator (tm, tn, reg): row 16 tm + (lane >> 4) + 4 reg, column 16 tn + (lane & 15) of the wave's 64 x 32 share
-  double* g = G + (int64_t)c * g_stride;
-#pragma unroll
-  for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int row = i0 + wr * 64 + tm * 16 + kq + 4 * reg;
-      if (row >= D) continue;
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        const int col = j0 + wc * 32 + tn * 16 + r16;
-        if (col < D) g[(int64_t)row * ldg + col] += acc[tm][tn][reg];
-      }
-    }
-}
-
-// The same Grams with a k-tile of 32 rows held in LDS as the rows' own FLOATS (converted to f64 on the way from LDS into the
-// matrix instructions' operands — six conversions per eight MFMAs, on the vector ALU beside them): the LDS footprint of the
-// 16-row f64 form, HALF the barriers per matrix instruction (two per 64 instead of two per 32: the waves of a workgroup sit on
-// four SIMDs whose other residents differ, and every barrier makes the fastest wait for the slowest), half the LDS bytes
-// written and read.  Same order of the sum over k per output: the lower triangle comes out bit for bit as from the 16-row form (the
-// conversion is exact either way; checked by hashing both); above the diagonal the half tiles leave their unused block unwritten.
+// The kernel: a k-tile of 32 rows held in LDS as the rows' own FLOATS (converted to f64 on the way from LDS into the matrix
+// instructions' operands — six conversions per eight MFMAs, on the vector ALU beside them), two barriers per 64 matrix
+// instructions.  (Round 4's form — 16-row k-tiles held as f64 in LDS — gave the same sums bit for bit and was 0.5-1.5 % slower
+// in same-box A/B runs; it is gone.)  Above the diagonal the half tiles leave their unused block unwritten.
 constexpr int RG32_BK = 32;
 constexpr int RG32_LDA = RG_BM + 16, RG32_LDB = RG_BN + 16;   // floats per LDS row: 16 banks further per k-row (the four k-rows a
                                                                // 64-lane ds_read_b32 touches fall on four different bank quarters)
@@ -777,7 +615,7 @@ __global__ __launch_bounds__(256) void rls_fold_bias_kernel(const double* __rest
   G[(int64_t)c * g_stride + (int64_t)(D1 - 1) * ldg + j] += o[4 * ldo + j];
 }
 
-// The whitened targets' products from the raw ones (rls_gram_rows_kernel's O5 = [Y 1]' X per class, columns 0 .. D - 1): with
+// The whitened targets' products from the raw ones (rls_gram_rows32_kernel's O5 = [Y 1]' X per class, columns 0 .. D - 1): with
 // Yw = (Y - 1 mu') T,   X' Yw = (X' Y - (X' 1) mu') T,   1' Yw = 0,   and the Gram's bias row [X 1]' 1 = (X' 1, n).
 // stats (C, 9, 4) f64 = [mu; T; T_inv] per class (the block the trainer keeps anyway), cnt (C) f64 = rows per class.
 __global__ __launch_bounds__(256) void rls_fold_whitened_kernel(const double* __restrict__ O5, int64_t ldo, int D1,
@@ -810,17 +648,11 @@ __global__ __launch_bounds__(256) void rls_fold_whitened_kernel(const double* __
   gb[d] += ones;
 }
 
-// The Grams come straight from the f32 rows (rls_gram_rows_kernel) when the rows allow 16-byte column groups; ODX_RLS_GRAM=nt
-// keeps round 3's form (a transposed f64 copy of all rows + the generic NT GEMM) for A/B runs.
-// ODX_RLS_GRAM_BK=16: the 16-row k-tile held as f64 in LDS (round 4's form, kept for A/B runs); default 32 rows held as floats
-static int rls_gram_bk() {
-  static const int bk = [] { const char* e = getenv("ODX_RLS_GRAM_BK"); return e && atoi(e) == 16 ? 16 : 32; }();
-  return bk;
-}
-
+// The Grams come straight from the f32 rows (rls_gram_rows32_kernel) when the rows allow 16-byte column groups; otherwise
+// (D % 8 != 0, unaligned rows) a transposed f64 copy of the rows + the generic NT GEMM.  The option rls_force_nt_gram (a test
+// hook, odx_set_option) sends every D down the second route so that both can be compared on the same rows.
 static bool rls_rows_form(const float* X, int64_t ldx, int D) {
-  const char* e = getenv("ODX_RLS_GRAM");
-  return !(e && e[0] == 'n') && D % 8 == 0 && ldx % 4 == 0 && aligned16(X);
+  return !lib_option(OPT_RLS_FORCE_NT_GRAM) && D % 8 == 0 && ldx % 4 == 0 && aligned16(X);
 }
 
 extern "C" int odx_rls_rows_form(const float* X, int64_t ldx, int D) { return rls_rows_form(X, ldx, D) ? 1 : 0; }
@@ -877,7 +709,7 @@ extern "C" int odx_rls_pad_index(const int64_t* run, int64_t total, const int64_
   return ODX_OK;
 }
 
-// The Grams of a class batch AND the raw targets' products [Y 1]' X in one sweep over the rows (rls_gram_rows_kernel, rows form
+// The Grams of a class batch AND the raw targets' products [Y 1]' X in one sweep over the rows (rls_gram_rows32_kernel, rows form
 // only): Yraw (n, >= 4) f32 holds the UN-whitened targets by row id, O5 (C, 5, ldo) f64 receives Y' X (rows 0 .. 3) and 1' X (row 4)
 // for columns 0 .. D - 1.  odx_rls_fold_whitened_f64 turns them into the whitened targets' X' Yw and the Gram's bias row once the
 // statistics are known — the sweep does not wait for them.
@@ -899,7 +731,7 @@ extern "C" int odx_rls_gram_raw_batched_f64(const float* X, int64_t ldx, int D, 
     sg.len[c] = seg_len[c];
   }
   const int tiles = (int)(8 * ceil_div(ceil_div(D, RG_BM), 8) * ceil_div(D, RG_BN));
-  hipLaunchKernelGGL(rls_gram_bk() == 16 ? rls_gram_rows_kernel : rls_gram_rows32_kernel, dim3((unsigned)tiles, 1, (unsigned)C), dim3(256), 0,
+  hipLaunchKernelGGL(rls_gram_rows32_kernel, dim3((unsigned)tiles, 1, (unsigned)C), dim3(256), 0,
                      as_stream(stream), X, ldx, D, idx_pad, sg, G, ldg, g_stride, Yraw, ldyr, O5, ldo);
   ODX_CHECK_LAUNCH("rls_gram_rows (raw targets)");
   return ODX_OK;
@@ -982,7 +814,7 @@ extern "C" int odx_rls_gram_batched_f64(const float* X, int64_t ldx, int D, cons
   }
   hipStream_t s = as_stream(stream);
   {
-    // default: the Grams and the skinny products straight from the f32 rows (rls_gram_rows_kernel, rls_xty_rows_kernel)
+    // default: the Grams and the skinny products straight from the f32 rows (rls_gram_rows32_kernel, rls_xty_rows_kernel)
     if (rls_rows_form(X, ldx, D)) {
       RlsSegs sg;
       for (int c = 0; c < ODX_MAX_ZBATCH; ++c) sg.off[c] = sg.len[c] = 0;
@@ -994,7 +826,7 @@ extern "C" int odx_rls_gram_batched_f64(const float* X, int64_t ldx, int D, cons
         sg.len[c] = seg_len[c];
       }
       const int tiles = (int)(8 * ceil_div(ceil_div(D, RG_BM), 8) * ceil_div(D, RG_BN));
-      hipLaunchKernelGGL(rls_gram_bk() == 16 ? rls_gram_rows_kernel : rls_gram_rows32_kernel, dim3((unsigned)tiles, 1, (unsigned)C), dim3(256), 0, s,
+      hipLaunchKernelGGL(rls_gram_rows32_kernel, dim3((unsigned)tiles, 1, (unsigned)C), dim3(256), 0, s,
                          X, ldx, D, idx_pad, sg, G, ldg, g_stride, (const float*)nullptr, (int64_t)0, (double*)nullptr, (int64_t)0);
       ODX_CHECK_LAUNCH("rls_gram_rows");
       if (gram_only) return ODX_OK;
@@ -1240,9 +1072,9 @@ extern "C" int odx_rls_solve_batched_f64(double* G, int64_t ldg, int64_t g_strid
   ZBatch zb;
   zb.count = C; zb.strideA = g_stride; zb.strideD = dsz; zb.strideO = lsz; zb.strideW = wtsz;
   ODX_PROPAGATE(potrf_f64(G, ldg, D1, Dinv, info, s, zb));
-  const char* sub = getenv("ODX_RLS_SOLVE");
-  if (!(sub && sub[0] == 'i') && ceil_div(D1, RS_NB) <= RS_MAXB) {
-    // block substitution with the factor (rls_substitute_kernel); ODX_RLS_SOLVE=inverse keeps the explicit inverse + products
+  if (!lib_option(OPT_RLS_FORCE_INVERSE_SOLVE) && ceil_div(D1, RS_NB) <= RS_MAXB) {
+    // block substitution with the factor (rls_substitute_kernel); wider systems (and the test hook rls_force_inverse_solve)
+    // take the explicit inverse + products below
     const int64_t npad = ceil_div(D1, RS_NB) * RS_NB;
     const size_t lds = (size_t)(npad * 4 + RS_NB * 4 + 8 * RS_NB * 4) * sizeof(double);
     ODX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rls_substitute_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -108,19 +108,18 @@ class HipBackend:
         self._capture_meta_pool = None
         # "h2": X Z' of the Gaussian kernels on the f16 matrix cores via the two-term split (f32 accuracy);
         # "f32": the all-f32 MFMA chain.  Both are HIP paths of libodx; there is no other.
-        self.gauss = os.environ.get("ODX_GAUSS", "h2")
         # ("f8": BASELINE config 5's e4m3 contraction — throughput only, K entries ~1e-3 off; never a default)
-        if self.gauss not in ("h2", "f32", "f8"):
-            raise ValueError("ODX_GAUSS must be 'h2', 'f32' or 'f8', got %r" % self.gauss)
+        from . import options as _options
+        opts = _options.load()                 # the one options table (odx/options.py): filled once, here
+        self.gauss = opts.gauss
         # Storage of the K_nM block the CG passes stream (include/odx.h): "f32" always f32; "u24" / "bf16" always that compact
         # format (f16-split kernels only); "auto" (default): 24-bit fixed point for the blocks whose passes are HBM-bound
         # (>= 2^27 entries and at least 1024 centres on the wide tile core: the headline, config 5's shards, configs 2 and
         # 4), f32 below — the fits of a Minibootstrap round (<= 22 000 x 2000) gain nothing.  The one-call / class-batched CG
         # loops stream either (odx_falkon_cg_batched_f64 / _q_f64).  tools/precision_storage_study.py: alpha against the f64 evaluation is the same
         # with u24 as with f32 storage; bf16 is BASELINE config 2's throughput-only storage (alpha off by 1e-2..6e-1).
-        self.knm_storage = os.environ.get("ODX_KNM", "auto")
-        if self.knm_storage not in ("auto", "f32", "u24", "bf16"):
-            raise ValueError("ODX_KNM must be 'auto', 'f32', 'u24' or 'bf16', got %r" % self.knm_storage)
+        self.knm_storage = opts.knm_storage
+        _options.apply()                       # h2_tile / precond / chain_helpers -> libodx (odx_set_option)
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -448,7 +447,8 @@ class HipBackend:
 
     def pin_gauss_tile(self, tile):
         """Pin the tile core of the f16-split Gaussian kernels (128 or 256); 0 = chosen per launch (default)."""
-        hip.check(self.lib.odx_set_h2_tile(int(tile)), "odx_set_h2_tile")
+        from . import options as _options
+        _options.set(h2_tile=int(tile))
 
     def reserve_cus_during_passes(self, cus):
         """Leave `cus` CUs free while the persistent CG pass kernel runs, for work queued on other streams."""

@@ -26,6 +26,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import backend as _backend
+from . import options as _options
 from .harvest import DetectorHarvester, MaskHarvester, RPNHarvester, project_masks_on_boxes, to_device
 from .heads import OnlineBoxPredictor, OnlineMaskPredictor, OnlineRPNHead  # noqa: F401
 
@@ -299,7 +300,7 @@ def _stem_rows(net, x):
         x = x.to(dt)                                     # (autocast's own cast of the image, made once here)
     conv, bn = net.conv1, net.bn1
     wb = net._fold("conv1", conv, bn, x)
-    if (_fused_epilogue(x, wb[0]) and hasattr(be, "stem_pool_rows") and os.environ.get("ODX_STEM", "fused") != "library"):
+    if _fused_epilogue(x, wb[0]) and hasattr(be, "stem_pool_rows"):
         y = F.conv2d(x, wb[0], None, conv.stride, conv.padding)
         if y.is_contiguous():
             return be.stem_pool_rows(y, wb[1])
@@ -610,7 +611,7 @@ class GraphedCall:
     copies, so nothing the caller holds is overwritten by the next replay.  Shapes are data here (aspect ratios differ between
     images): at most `max_graphs` are kept, least recently used first out.  Whoever changes the weights behind fn calls
     clear().  A capture that fails (an operation the runtime cannot capture) turns the wrapper into a plain call for good;
-    ODX_TRUNK_GRAPH=0 does the same from the environment."""
+    odx.options trunk_graph=False does the same for every wrapper made afterwards."""
 
     import threading as _threading
     _tls = _threading.local()                  # .forbid = True: no capture from this thread (a thread that shares the device with
@@ -623,7 +624,7 @@ class GraphedCall:
         self.captures = {}                     # key -> times captured (see __call__)
         self.seen = {}                         # shape -> calls so far: a shape is captured at its SECOND call (a stream of images
         # that all differ in size — capture costs three forwards — then simply runs launch by launch)
-        self.enabled = os.environ.get("ODX_TRUNK_GRAPH", "1") != "0"
+        self.enabled = bool(_options.load().trunk_graph)
         # (re-entrant: fn itself may call clear() — a weight pack remade inside the forward drops the graphs that point at the
         # old one, OnlineDetectionModel._wpack)
         self.lock = threading.RLock()          # the extractor's forward thread and the caller's may both come through here
@@ -757,9 +758,9 @@ class OnlineDetectionModel(nn.Module):
         self.online_mask = None         # odx.heads.OnlineMaskPredictor
         self.mask_dim = mask_dim
         # stride-16 positions (images x h x w) from which the f32 trunk and RPN head run as row GEMMs (_rows_path)
-        self.rows_min_positions = int(os.environ.get("ODX_ROWS_MIN_POSITIONS", 3600))
+        self.rows_min_positions = int(_options.load().rows_min_positions)
         self._trunk_graphs = GraphedCall(self._c4_eager)
-        # The whole group forward from ONE HIP graph (forward_group); ODX_GROUP_GRAPH=0 turns it off.  What it took on this
+        # The whole group forward from ONE HIP graph (forward_group); odx.options group_graph=False turns it off.  What it took on this
         # runtime (round 5): (i) with the proposal stage as tensor operations (a library top-k, gather, advanced indexing) the
         # graph's second or third replay ended in a GPU memory fault — tools/group_graph_bisect.py localised it to that stage,
         # which is three kernels of this library now (odx_rpn_topk_decode_f32, odx_nms_batched_first_f32, odx_nms_compact_f32);
@@ -771,7 +772,7 @@ class OnlineDetectionModel(nn.Module):
         # forwards on changing images and calling streams with another graph and other work in between, 40 harvest passes,
         # every result checked against the launch-by-launch forward: no difference) is what the default rests on.
         self._group_graphs = GraphedCall(self._group_static, max_graphs=4)
-        if os.environ.get("ODX_GROUP_GRAPH", "1") == "0":
+        if not _options.load().group_graph:
             self._group_graphs.enabled = False
         self.register_load_state_dict_post_hook(OnlineDetectionModel._drop_graphs)
 
@@ -801,9 +802,9 @@ class OnlineDetectionModel(nn.Module):
 
     def _rows_path(self, x):
         """The f32 forward on the GPU runs as row GEMMs on this library's tile cores from the stem's output on (trunk stages,
-        RPN head; the conv5 head always did): ODX_TRUNK=conv keeps the convolution library for the trunk and the RPN head."""
+        RPN head; the conv5 head always did): odx.options trunk="conv" keeps the convolution library for the trunk and the RPN head."""
         if not (x.is_cuda and self.compute_dtype is None and x.dtype == torch.float32 and not torch.is_grad_enabled()
-                and not torch.is_autocast_enabled("cuda") and os.environ.get("ODX_TRUNK", "rows") != "conv"):
+                and not torch.is_autocast_enabled("cuda") and _options.current().trunk != "conv"):
             return False
         # below two images of 600 x 800 the stage-3 / RPN products (1900 rows per image) leave most of the chip idle on
         # 128 x 128 tiles and the convolution library's kernels are faster (forward 3.85 against 4.34 ms at one image; 3.30
@@ -826,9 +827,10 @@ class OnlineDetectionModel(nn.Module):
 
     def _weights_key(self):
         """(storage, in-place version) of EVERY parameter and buffer of the model: part of both graph caches' keys.  A captured
-        forward bakes in the trunk, the RPN head's and the conv5 head's packed weights and the mask pack; an optimiser step,
-        `weight.data.normal_()` or a `copy_` into any of them — none of which passes through load_state_dict or _apply — must
-        not be answered from the old capture (round-5 advisor finding: the keys used to cover two trunk weights only)."""
+        forward bakes in the trunk, the RPN head's and the conv5 head's packed weights and the mask pack; an optimiser step or a
+        `mul_` / `copy_` into any of them under no_grad — none of which passes through load_state_dict or _apply — must not be
+        answered from the old capture (round-5 advisor finding: the keys used to cover two trunk weights only).  An edit
+        through `.data` moves no version counter and cannot be seen here or by any cache: call refresh_weights() after one."""
         return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
 
     def refresh_weights(self):
@@ -852,7 +854,7 @@ class OnlineDetectionModel(nn.Module):
     def _rows16_path(self, x):
         """_rows_path for a forward run in bf16 / f16 (compute_dtype): trunk stages and RPN head on 16-bit rows (odx_gemm_b16)."""
         if not (x.is_cuda and self.compute_dtype in (torch.bfloat16, torch.float16) and not torch.is_grad_enabled()
-                and os.environ.get("ODX_TRUNK", "rows") != "conv"):
+                and _options.current().trunk != "conv"):
             return False
         positions = x.shape[0] * x.shape[2] * x.shape[3] if x.shape[1] != 3 else x.shape[0] * (-(-x.shape[2] // self.stride)) * (-(-x.shape[3] // self.stride))
         if positions < self.rows_min_positions:

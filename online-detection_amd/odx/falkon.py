@@ -19,6 +19,7 @@ import types
 import torch
 
 from . import backend as _backend
+from . import options as _options
 from .solver import SolverOptions, falkon_fit
 
 
@@ -227,7 +228,7 @@ def fit_batch(estimators, Xs, Ys, streams=None):
                 if streams:
                     for s in streams:           # before the chain is queued: the builds below start beside it, not after it
                         s.wait_stream(cur)
-            if streams and len(chunk) >= 2 * _CHAIN_SPLIT_MIN:
+            if streams and len(chunk) >= 2 * int(_options.current().chain_split_min):
                 # two half chains side by side: a chain is a dependent sequence of short launches, a third of them one
                 # workgroup per class (the 128 x 128 diagonal factorisations), and a half's products fill what the other
                 # half's diagonal steps leave idle.  Both write their classes' slots of ONE factor block (the lock-step CG
@@ -453,7 +454,6 @@ class BatchFit:
         return self.est
 
 
-_CHAIN_SPLIT_MIN = int(os.environ.get('ODX_CHAIN_SPLIT_MIN', '4'))
 _chain_streams = {}
 
 

@@ -34,6 +34,12 @@ from .extract import (DELTA_CLAMP, FrozenBatchNorm2d, _FoldedBN, _nms_takes_max_
                       _stages_rows_form, cell_anchors, decode_deltas, grid_anchors)
 
 
+
+def _trunk_rows():
+    """odx.options trunk != "conv": the trunk stages, pyramid and RPN head as row GEMMs on the library's tile cores."""
+    from . import options as _options
+    return _options.current().trunk != "conv"
+
 class ResNet50Stages(_FoldedBN):
     """ResNet-50 stem + res2..res5, returning all four stage outputs (C2..C5: 256, 512, 1024, 2048 channels at width 64)."""
 
@@ -236,8 +242,8 @@ class OnlineDetectionModelFPN(nn.Module):
         self.online_mask = None
         self._packed = {}
         self._anchor_cache = {}
-        import os
-        self.rows_min_positions = int(os.environ.get("ODX_ROWS_MIN_POSITIONS", 3600))
+        from . import options as _options
+        self.rows_min_positions = int(_options.load().rows_min_positions)
         from .extract import GraphedCall
         self._trunk_graphs = GraphedCall(self._c4_eager)
         # load_state_dict copies the parameters in place and never goes through _apply: the packed fc weights are derived
@@ -299,7 +305,7 @@ class OnlineDetectionModelFPN(nn.Module):
         """_rows_path for compute_dtype = bf16 / f16: trunk and pyramid on 16-bit rows (odx_gemm_b16 / odx_gemm_b16_taps)."""
         import os
         if not (x.is_cuda and self.compute_dtype in (torch.bfloat16, torch.float16) and not torch.is_grad_enabled()
-                and os.environ.get("ODX_TRUNK", "rows") != "conv"):
+                and _trunk_rows()):
             return False
         if x.shape[0] * (-(-x.shape[2] // 16)) * (-(-x.shape[3] // 16)) < self.rows_min_positions:
             return False
@@ -307,10 +313,10 @@ class OnlineDetectionModelFPN(nn.Module):
 
     def _rows_path(self, x):
         """The f32 trunk and pyramid on the GPU as row GEMMs on the library's tile cores (as OnlineDetectionModel._rows_path: from
-        rows_min_positions stride-16 positions per call on; ODX_TRUNK=conv keeps the convolution library)."""
+        rows_min_positions stride-16 positions per call on; odx.options trunk="conv" keeps the convolution library)."""
         import os
         if not (x.is_cuda and self.compute_dtype is None and x.dtype == torch.float32 and not torch.is_grad_enabled()
-                and not torch.is_autocast_enabled("cuda") and os.environ.get("ODX_TRUNK", "rows") != "conv"):
+                and not torch.is_autocast_enabled("cuda") and _trunk_rows()):
             return False
         if x.shape[0] * (-(-x.shape[2] // 16)) * (-(-x.shape[3] // 16)) < self.rows_min_positions:
             return False
@@ -441,12 +447,12 @@ class OnlineDetectionModelFPN(nn.Module):
         score = torch.full((B, L, Rmax), -1.0, dtype=torch.float32, device=dev)           # (sigmoid scores are > 0: pads sort last)
         rows_head = (self.compute_dtype is None and trunk[0].dtype == torch.float32 and not torch.is_autocast_enabled("cuda")
                      and not torch.is_grad_enabled() and hasattr(be, "conv3x3_rows") and self.rpn_conv.in_channels % 8 == 0
-                     and __import__("os").environ.get("ODX_TRUNK", "rows") != "conv")
+                     and _trunk_rows())
         dt16 = self.compute_dtype if self.compute_dtype in (torch.bfloat16, torch.float16) else None
         rows16_head = (dt16 is not None and trunk[0].dtype == dt16 and not torch.is_grad_enabled() and hasattr(be, "conv3x3_rows16")
-                       and self.rpn_conv.in_channels % 8 == 0 and __import__("os").environ.get("ODX_TRUNK", "rows") != "conv")
+                       and self.rpn_conv.in_channels % 8 == 0 and _trunk_rows())
         side = cur = None
-        if (rows_head or rows16_head) and __import__("os").environ.get("ODX_RPN_SELECT_STREAM", "1") != "0" and not torch.cuda.is_current_stream_capturing():
+        if (rows_head or rows16_head) and not torch.cuda.is_current_stream_capturing():
             from . import streams as _streams
             own = _streams.distinct(1)
             if own:

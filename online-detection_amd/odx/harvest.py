@@ -30,6 +30,8 @@ import threading
 import numpy as np
 import torch
 
+from . import options as _options
+
 
 class _Staging:
     """One page-locked block per host thread, split in two halves that are filled in turn: a small host tensor is copied into the
@@ -70,7 +72,7 @@ _staging = threading.local()
 
 
 def to_device(host, device):
-    """A small host tensor (index lists, draws, labels) on `device`: a plain copy.  ODX_STAGED_UPLOADS=1: through a persistent
+    """A small host tensor (index lists, draws, labels) on `device`: a plain copy.  odx.options staged_uploads=True: through a persistent
     page-locked staging block and an asynchronous copy (_Staging) — in isolation the difference is large (a `.to(device)` of
     pageable memory waits, on the host, for whatever the GPU is running: 1.5 ms per copy beside a busy stream against 15-20 us
     staged, tools/h2d_probe.py; the harvesters make ~11 such copies per image beside the next group's forward), but the harvest
@@ -81,7 +83,7 @@ def to_device(host, device):
     device = torch.device(device)
     nbytes = host.numel() * host.element_size()
     if (device.type != "cuda" or host.is_cuda or nbytes == 0 or nbytes > _Staging.HALF // 4 or not host.is_contiguous()
-            or os.environ.get("ODX_STAGED_UPLOADS", "0") != "1"):
+            or not _options.current().staged_uploads):
         return host.to(device)
     st = getattr(_staging, "block", None)
     if st is None:

@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _LIB = None
-# (ODX_LIB_PATH: a development knob — experimental builds of the library side by side, tools/ab_gauss.py)
+# (ODX_LIB_PATH: a development knob — another build of the library)
 _LIB_PATH = os.environ.get("ODX_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libodx.so")
 
 ODX_OK = 0
@@ -33,6 +33,9 @@ SIGNATURES = {
     "odx_knm_pass_kernel_name": (ctypes.c_char_p, [_i64, _i32, _i32]),
     "odx_version": (_i32, []),
     "odx_device_cus": (_i32, []),
+    "odx_set_option": (_i32, [ctypes.c_char_p, _i32]),
+    "odx_get_option": (_i32, [ctypes.c_char_p, _vp]),
+    "odx_option_default": (_i32, [ctypes.c_char_p, _vp]),
     "odx_release_helper_streams": (_i32, []),
     "odx_stream_create_cu_mask": (_i32, [_vp, _i32, _vp]),
     "odx_stream_destroy": (_i32, [_vp]),

@@ -102,15 +102,18 @@ class OnlineRegionClassifierBase:
         self.return_caches = False
         self.class_streams = 0          # > 0: classes trained concurrently on that many streams (opts['class_streams'])
         self.class_batch = 0            # > 0: the classes of a round fitted by one batched call, on that many streams (opts['class_batch'])
-        # the experiment drivers call trainRegionClassifier() without options: ODX_CLASS_BATCH / ODX_CLASS_STREAMS /
-        # ODX_CLASS_SHARD in the environment select the same opt-ins without touching a driver (opts still win)
-        self.class_batch = int(os.environ.get("ODX_CLASS_BATCH", "0") or 0)
-        self.class_streams = int(os.environ.get("ODX_CLASS_STREAMS", "0") or 0)
+        # the experiment drivers call trainRegionClassifier() without options: odx.options class_batch / class_streams /
+        # class_shard / reference_order (environment: ODX_CLASS_BATCH, ...) select the same opt-ins without touching a driver
+        # (opts still win)
+        from . import options as _options
+        o = _options.load()
+        self.class_batch = int(o.class_batch)
+        self.class_streams = int(o.class_streams)
         # 'auto': the reference's order of draws with the classes advancing together when that can be predicted (GPU,
         # stock index rule); 'sequential': always the class-by-class loop (opts['reference_order'], ODX_REFERENCE_ORDER)
-        self.reference_order = os.environ.get("ODX_REFERENCE_ORDER", "auto")
+        self.reference_order = o.reference_order
         self.class_rng = False          # one RNG stream per class for the Nystroem draws (opts['class_rng']; implied by the three modes above/below)
-        self.class_shard = os.environ.get("ODX_CLASS_SHARD", "0") not in ("", "0")   # classes round-robin over the ranks of torch.distributed, models gathered at the end (opts['class_shard'])
+        self.class_shard = bool(o.class_shard)   # classes round-robin over the ranks of torch.distributed, models gathered at the end (opts['class_shard'])
 
     def loadRegionClassifier(self) -> None:
         pass

@@ -20,6 +20,8 @@ import torch
 
 from . import backend as _backend
 
+RAW_TARGETS = True        # f32 targets: [Y 1]' X out of the Gram sweep (test hook: False = the two-sweep form f64 targets take)
+
 
 def _device():
     return 'cuda' if torch.cuda.is_available() else 'cpu'
@@ -168,7 +170,7 @@ class RegionRefinerTrainer:
                 # With f32 targets the same sweep forms the RAW targets' products [Y 1]' X too (on the vector ALU under the Gram's
                 # matrix instructions): the whitening is linear, so X' Yw follows from them and the statistics in a launch of a few
                 # microseconds (rls_fold_whitened) — the 0.6-ms sweep for Yt [X 1] that used to land BEHIND the Grams (this
-                # stream's small kernels starve beside them) is gone.  ODX_RLS_RAW_TARGETS=0 keeps the two-sweep form.
+                # stream's small kernels starve beside them) is gone.  rls.RAW_TARGETS = False (a test hook) keeps the two-sweep form, which f64 targets always take.
                 begun = side = raw5 = None
                 if hasattr(be, "rls_gram_begin") and xdev.type == "cuda" and be.rls_rows_form(F):
                     from . import streams as _streams
@@ -178,7 +180,7 @@ class RegionRefinerTrainer:
                         # (zeroed on THIS stream: the fold / Yt [X 1] adds to its bias row later)
                         begun = pre_zero[:G_] if pre_zero is not None and g0 == 0 else be.rls_gram_zeros(F, G_)
                         use_raw = (hasattr(be, "rls_gram_raw_begin") and Yall.dtype == torch.float32 and Yall.dim() == 2
-                                   and Yall.shape[1] == 4 and os.environ.get("ODX_RLS_RAW_TARGETS", "1") != "0")
+                                   and Yall.shape[1] == 4 and RAW_TARGETS)
                         Yraw = Yall.contiguous() if use_raw else None
                         use_raw = use_raw and Yraw.data_ptr() % 16 == 0
                         side.wait_stream(cur)

@@ -25,25 +25,35 @@ def _collide(a, b, scratch):
     marker's completion against the start and the end of the busy kernel —, not from a host sleep: a stalled host (a loaded
     box, a profiler attached) cannot make a colliding stream look independent (advisor, round 4).  Two readings must agree;
     when they do not, the stream counts as colliding (the safe side: it is simply not picked)."""
-    if os.environ.get("ODX_STREAM_PROBE", "host") != "events":
+    from . import options as _options
+    if _options.current().stream_probe != "events":
         # round 4's reading, kept as the default: one look after a host sleep.  The event-timed reading below (two readings that
         # must agree: a stalled host cannot make a colliding stream look independent — advisor, round 4) is the more careful test,
         # but the probe's own launches are part of what decides which hardware queue a stream lands on, and the arrangement the
         # careful probe ends with costs the headline job 2 % (A/B on one box, two runs each: 6.89 / 6.92 s per step against
         # 6.72 / 6.78 — the preconditioner chains then run beside the HBM-bound passes instead of beside the builds).  It stays
-        # selectable (ODX_STREAM_PROBE=events); either way the choice changes how work overlaps, never what is computed.
+        # selectable (odx.options stream_probe="events"); either way the choice changes how work overlaps, never what is computed.
+        # A reading only counts if stream a was STILL busy when the marker was looked at (advisor, round 5: a host stalled past
+        # the busy kernel's end — a loaded box, a profiler — saw the marker done and called a colliding stream independent);
+        # three attempts, then the safe verdict (colliding: the stream is simply not picked).
         import time
-        torch.cuda.synchronize()
-        with torch.cuda.stream(a):
-            torch.cuda._sleep(2 * BUSY_CYCLES)
-        done = torch.cuda.Event()
-        with torch.cuda.stream(b):
-            scratch.add_(1)
-            done.record()
-        time.sleep(3e-4)
-        hit = not done.query()
-        torch.cuda.synchronize()
-        return hit
+        for _ in range(3):
+            torch.cuda.synchronize()
+            busy_end = torch.cuda.Event()
+            with torch.cuda.stream(a):
+                torch.cuda._sleep(2 * BUSY_CYCLES)
+                busy_end.record()
+            done = torch.cuda.Event()
+            with torch.cuda.stream(b):
+                scratch.add_(1)
+                done.record()
+            time.sleep(3e-4)
+            finished = done.query()
+            valid = not busy_end.query()          # a was busy throughout what the host just looked at
+            torch.cuda.synchronize()
+            if valid:
+                return not finished
+        return True
     verdicts = []
     for _ in range(2):
         torch.cuda.synchronize()

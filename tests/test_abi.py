@@ -84,3 +84,64 @@ def test_product_package_calls_no_vendor_solver_or_fused_gemm():
                 for ln, line in enumerate(open(os.path.join(dp, f)), 1):
                     code = line.split("#", 1)[0]
                     assert not banned.search(code), "%s:%d: %s" % (os.path.join(dp, f), ln, line.strip())
+
+
+# ---------------------------------------------------------------- the one options table (round-5 review, item 7)
+BENCHED = {"gauss": "h2", "knm_storage": "auto", "precond": "auto", "h2_tile": 0, "chain_helpers": -1, "chain_split_min": 4, "trunk": "rows",
+           "trunk_graph": True, "group_graph": True, "stream_probe": "host", "staged_uploads": False, "class_batch": 0,
+           "class_streams": 0, "reference_order": "auto", "class_shard": False}
+
+
+def test_option_defaults_are_the_benched_configuration():
+    """odx.options' defaults = what the committed bench line ran on (its `config.options`, from round 6 on), and the library's
+    own defaults (odx_option_default) agree with the table's: two boxes with an empty environment run the same kernels."""
+    import dataclasses
+    import glob
+    import json
+    from odx import options
+    d = dataclasses.asdict(options.Options())
+    for k, v in BENCHED.items():
+        assert d[k] == v, (k, d[k], v)
+    assert set(d) == set(BENCHED) | {"rows_min_positions"}
+    assert set(options.ENV.values()) == set(d)                       # every option has its (read-once) environment variable
+    lib = ctypes.CDLL(hip.lib_path())
+    for name, want in (("h2_tile", d["h2_tile"]), ("precond", {"auto": 0, "f64": 1, "split": 2}[d["precond"]]),
+                       ("chain_helpers", d["chain_helpers"]), ("rls_force_nt_gram", 0), ("rls_force_inverse_solve", 0)):
+        got = ctypes.c_int(-99)
+        assert lib.odx_option_default(name.encode(), ctypes.byref(got)) == 0 and got.value == want, (name, got.value)
+        assert lib.odx_get_option(name.encode(), ctypes.byref(got)) == 0 and got.value == want, (name, got.value)   # untouched: the default
+    assert lib.odx_set_option(b"no_such_option", 1) != 0 and lib.odx_set_option(b"h2_tile", 64) != 0
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1.json")))
+    cfg = json.loads(open(lines[-1]).read().strip().splitlines()[-1])["config"]
+    if "options" in cfg:                                             # (bench lines from round 6 on carry the table)
+        for k, v in cfg["options"].items():
+            assert d[k] == v, (k, d[k], v)
+
+
+def test_options_are_read_once_and_validated():
+    from odx import options
+    o = options.Options()
+    assert options._coerce("precond", "split") == "split" and options._coerce("trunk_graph", "0") is False
+    assert options._coerce("class_shard", "1") is True and options._coerce("h2_tile", "256") == 256
+    with pytest.raises(ValueError):
+        options._coerce("gauss", "fp4")
+    with pytest.raises(ValueError):
+        options._coerce("h2_tile", 64)
+    with pytest.raises(AttributeError):
+        options.set(no_such_option=1)
+    assert o.rows_min_positions >= 0
+
+
+def test_no_environment_reads_outside_the_options_table():
+    """No `getenv` in the library's sources; in the Python package `os.environ` appears only in options.py (the table),
+    providers.py (ODX_SAMPLES / ODX_MODEL: the unmodified-driver contract) and hip.py (ODX_LIB_PATH)."""
+    import glob
+    csrc = os.path.join(ROOT, "online-detection_amd", "csrc")
+    for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")) + glob.glob(os.path.join(csrc, "*.h")):
+        assert "getenv" not in open(f).read(), f
+    pkg = os.path.join(ROOT, "online-detection_amd", "odx")
+    allowed = {"options.py", "providers.py", "hip.py"}
+    for f in glob.glob(os.path.join(pkg, "*.py")):
+        if os.path.basename(f) not in allowed:
+            text = open(f).read()
+            assert "os.environ" not in text and "getenv" not in text, f

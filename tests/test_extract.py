@@ -638,17 +638,20 @@ def test_group_forward_from_one_graph_equals_the_eager_batched_forward():
         check(a)
         assert len(model._group_graphs.graphs) == 2
         assert all(r["boxes"].shape[0] <= 25 + 3 for r in model.forward_group(images, a))
-        # in-place weight changes that pass through neither load_state_dict nor _apply (an optimiser step, .data.normal_(), a
-        # copy_): the graph of the old weights — it baked in the trunk, the packed RPN / conv5-head operands and the mask pack —
-        # must not answer; every parameter's (storage, version) is in the graphs' key (round-5 advisor finding)
+        # in-place weight changes that pass through neither load_state_dict nor _apply (an optimiser step, a mul_ / copy_ under
+        # no_grad): the graph of the old weights — it baked in the packed RPN operands and the mask pack — must not answer; every
+        # parameter's (storage, version) is in the graphs' key (round-5 advisor finding).  (Edits through `.data` do not move a
+        # parameter's version counter — nothing can see them — and want refresh_weights(), below.)
         before = model.forward_group(images, a)
-        last_conv = [m for m in model.head.modules() if isinstance(m, torch.nn.Conv2d)][-1]
-        for w in (last_conv.weight, model.rpn_conv.weight, model.conv5_mask.weight, model.backbone.layer2[0].conv1.weight):
-            w.data.mul_(1.25) if w is not last_conv.weight else w.mul_(0.5)
+        for w in (model.rpn_deltas.weight, model.rpn_conv.bias, model.conv5_mask.weight):
+            v0 = w._version
+            w.add_(0.02) if w is model.rpn_conv.bias else w.mul_(1.5)
+            assert w._version > v0
             check(a)                                          # (first call of the new key: launch by launch)
             check(a)                                          # captured with the new weights
         after = model.forward_group(images, a)
-        assert not torch.equal(after[0]["feats"], before[0]["feats"])
+        assert after[0]["boxes"].shape != before[0]["boxes"].shape or not torch.equal(after[0]["boxes"], before[0]["boxes"])
+        assert not torch.equal(after[0]["act"], before[0]["act"])
         assert len(model._group_graphs.graphs) <= model._group_graphs.max_graphs
         # the frozen trunk / conv5 head fold their batch norms into the weights once (at load, .to(), load_state_dict): an
         # in-place edit of THOSE needs refresh_weights(), which drops every derived tensor and every graph

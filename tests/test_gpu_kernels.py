@@ -593,15 +593,27 @@ def test_precond_identities(be, M, D, sigma, lam):
 
 
 @pytest.fixture
-def split_precond(monkeypatch):
+def split_precond():
     """The preconditioner chain with the A factor's products on the split-f16 tile core (the default from 4096 centres on;
-    forced here so that oracle-sized problems run it; the library reads the variable at every call)."""
-    monkeypatch.setenv("ODX_PRECOND", "split")
+    forced here so that oracle-sized problems run it: odx.options precond = "split" -> the library's option)."""
+    import odx
+    with odx.options.override(precond="split"):
+        yield
+
+
+@pytest.fixture(autouse=True)
+def _options_back_to_what_they_were():
+    """A test that changes odx.options (precond / tile / storage) leaves them as it found them."""
+    import odx
+    before = odx.options.as_dict()
+    yield
+    if odx.options.as_dict() != before:
+        odx.options.set(**before)
 
 
 @pytest.mark.parametrize("M,D,sigma,lam", [(700, 64, 9.0, 1e-4), (1537, 256, 15.0, 1e-5), (2600, 128, 12.0, 1e-6)])
 def test_precond_split_path(be, split_precond, monkeypatch, M, D, sigma, lam):
-    """ODX_PRECOND=split: T (whose products define the regulariser) is formed exactly as in the all-f64 chain — its inverse
+    """odx.options precond = "split": T (whose products define the regulariser) is formed exactly as in the all-f64 chain — its inverse
     factors are the same bits —, while T T' / M and the rank-512 updates of chol(T T' / M + lam I) run on the split-f16 tile
     core: L_A^-1 then satisfies its defining identity at f32 accuracy and differs from the f64 chain's by a
     preconditioner-grade amount.  Ragged sizes: the packed operands are padded to 64 columns, the 256-row tiles masked."""
@@ -611,7 +623,8 @@ def test_precond_split_path(be, split_precond, monkeypatch, M, D, sigma, lam):
     Zf = be.features(torch.from_numpy(Z))
     Ps = be.precond(Zf, sigma, lam, 1e-5)
     be.check_precond(Ps)
-    monkeypatch.setenv("ODX_PRECOND", "f64")
+    import odx
+    odx.options.set(precond="f64")
     Pd = be.precond(Zf, sigma, lam, 1e-5)
     assert torch.equal(Ps.LTi[:, :M], Pd.LTi[:, :M]) and torch.equal(Ps.LTit[:, :M], Pd.LTit[:, :M])
     assert torch.equal(Ps.LAi[:, :M].t(), Ps.LAit[:, :M])                        # still exact transposes of each other
@@ -634,7 +647,8 @@ def test_batched_precond_equals_the_single_class_one_bit_for_bit(be, monkeypatch
     adds exact zeros there too)  odx_falkon_precond_batched_f64 advances the factorisations of several classes with one chain of launches; classes
     with fewer centres are bordered with an identity block.  The leading M_b x M_b blocks of its outputs must be the
     very bits the single-class call produces (same block boundaries, the border adds exact zeros only)."""
-    monkeypatch.setenv("ODX_PRECOND", chain)
+    import odx
+    odx.options.set(precond=chain)
     rng = np.random.default_rng(sum(Ms) + D)
     sigma, lam = 9.0, 1e-4
     Zfs = []
@@ -688,7 +702,7 @@ def test_falkon_fit_alpha_parity(be, gauss, n, M, D, sigma, lam):
 def test_falkon_fit_alpha_with_the_split_chain_forced(be, split_precond, n, M, D, sigma, lam, bar):
     """The A factor's products of the preconditioner on the split-f16 tile core, FORCED onto problems the default rule never
     gives it to (it applies from 4096 centres on, where tests/test_gpu_configs.py asserts the 1e-4 bar at M = 1e4 on the
-    headline's own data; ODX_PRECOND=f64 is the parity setting for anything else).  A only preconditions — the solution the
+    headline's own data; precond = "f64" is the parity setting for anything else).  A only preconditions — the solution the
     CG converges to does not depend on it — but 20 steps are not convergence (alpha_20 and alpha_40 differ by 1e-2 .. 1e-1 on
     these problems), so the iterate moves by about (how unconverged it is) x (cond(T T'/M + lam I) x 1e-7): 3e-7 .. 1.3e-5 on
     five of these problems and 2.2e-4 on the one with 300 centres in 1024 dimensions — why the rule is not 'always'."""

@@ -138,8 +138,8 @@ def test_batched_rls_equals_the_class_by_class_loop(hip_backend, D):
 
 
 def test_rls_grams_from_rows_equal_the_transposed_copy_form(hip_backend, monkeypatch):
-    """The two forms of the batched Gram step (ODX_RLS_GRAM=nt: transposed f64 copy + NT GEMM; default: straight from the f32
-    rows) sum the same f64 products in different orders, and so do the two forms of the solves (block substitution with the
+    """The two forms of the batched Gram step (the route of D % 8 != 0, forced here by the library's test hook
+    rls_force_nt_gram: transposed f64 copy + NT GEMM; default: straight from the f32 rows) sum the same f64 products in different orders, and so do the two forms of the solves (block substitution with the
     Cholesky factor; its explicit inverse): the regressors agree to rounding, for class sizes that are not multiples of the
     16-row k-tile and feature counts that leave ragged tiles (D + 1 = 457: four 128-blocks, the last one 73 rows)."""
     from odx.rls import RegionRefinerTrainer
@@ -153,13 +153,18 @@ def test_rls_grams_from_rows_equal_the_transposed_copy_form(hip_backend, monkeyp
     COXY = {"C": Cl[perm].view(-1, 1), "O": None, "X": X[perm], "Y": Y[perm]}
     cfg = {"CHOSEN_CLASSES": {i: "c%d" % i for i in range(C + 1)}, "REGION_REFINER": {"opts": {"lambda": 10.0}}}
     out = {}
-    for mode in ("nt", "rows", "rows+inverse"):
-        monkeypatch.setenv("ODX_RLS_GRAM", mode.split("+")[0])
-        # the solves: block substitution with the factor (default) / the explicit inverse and triangular products
-        monkeypatch.setenv("ODX_RLS_SOLVE", "inverse" if mode.endswith("inverse") else "")
-        tr = RegionRefinerTrainer(cfg, 10.0, False)
-        tr.COXY = COXY
-        out[mode] = quiet(tr._train_batched, hip_backend)
+    import odx
+    try:
+        for mode in ("nt", "rows", "rows+inverse"):
+            odx.options.library_hook("rls_force_nt_gram", 1 if mode == "nt" else 0)
+            # the solves: block substitution with the factor (default) / the explicit inverse and triangular products
+            odx.options.library_hook("rls_force_inverse_solve", 1 if mode.endswith("inverse") else 0)
+            tr = RegionRefinerTrainer(cfg, 10.0, False)
+            tr.COXY = COXY
+            out[mode] = quiet(tr._train_batched, hip_backend)
+    finally:
+        odx.options.library_hook("rls_force_nt_gram", 0)
+        odx.options.library_hook("rls_force_inverse_solve", 0)
     for c in range(C):
         for k in range(4):
             wb = out["rows"][c]["Beta"][str(k)]["weights"]
@@ -220,7 +225,7 @@ def test_rls_pad_index_equals_the_tensor_statements(hip_backend):
 def test_rls_raw_target_products_equal_the_second_sweep(hip_backend, monkeypatch):
     """The whitened targets' X' Yw from the RAW targets' products formed inside the Gram sweep, (X' Y - X' 1 mu') T
     (odx_rls_gram_raw_batched_f64 + odx_rls_fold_whitened_f64: the default with f32 targets), against the second sweep over the
-    rows with the whitened targets (ODX_RLS_RAW_TARGETS=0): the same f64 sums in another order.  Targets with means far above
+    rows with the whitened targets (odx.rls.RAW_TARGETS = False): the same f64 sums in another order.  Targets with means far above
     their spread (the subtraction cancels four digits), ragged class sizes, a ragged last tile; f64 targets keep the two-sweep
     form (nothing may be rounded to f32 on the way)."""
     from odx.rls import RegionRefinerTrainer
@@ -241,7 +246,7 @@ def test_rls_raw_target_products_equal_the_second_sweep(hip_backend, monkeypatch
     monkeypatch.setattr(hip_backend, "rls_gram_raw_begin", spy)
     out = {}
     for mode, ydt in (("raw", torch.float32), ("sweep", torch.float32), ("f64", torch.float64)):
-        monkeypatch.setenv("ODX_RLS_RAW_TARGETS", "0" if mode == "sweep" else "1")
+        monkeypatch.setattr("odx.rls.RAW_TARGETS", mode != "sweep")
         tr = RegionRefinerTrainer(cfg, 10.0, False)
         tr.COXY = {"C": Cl[perm].view(-1, 1), "O": None, "X": X[perm], "Y": Y[perm].to(ydt)}
         n0 = len(calls)

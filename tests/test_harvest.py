@@ -272,11 +272,12 @@ def test_rpn_positives_with_one_host_read_equal_the_box_by_box_walk(device):
 
 @pytest.mark.gpu
 def test_staged_uploads_deliver_the_same_tensors(monkeypatch):
-    """harvest.to_device through the page-locked staging block (ODX_STAGED_UPLOADS=1): every tensor arrives as a plain copy
+    """harvest.to_device through the page-locked staging block (odx.options staged_uploads = True): every tensor arrives as a plain copy
     would deliver it — dtypes, shapes, more bytes than both halves of the block hold (the halves are re-entered behind their
     fences), copies issued from two streams."""
     from odx import harvest
-    monkeypatch.setenv("ODX_STAGED_UPLOADS", "1")
+    import odx
+    monkeypatch.setattr(odx.options.current(), "staged_uploads", True)
     dev = torch.device("cuda")
     g = torch.Generator().manual_seed(0)
     side = torch.cuda.Stream()
