@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--precond-cus", type=int, default=0, help="confine the preconditioner chains (their stream and the library's "
                     "helper streams) to this many compute units, spread over the XCDs (0: the whole device; an experiment knob — "
                     "measured slower at 48..128 CUs: the confined chains starve behind the main stream's grids, DESIGN.md 7)")
+    ap.add_argument("--gauss-on-complement", action="store_true", help="with --precond-cus k: launch the K_nM builds and the scoring on a "
+                    "stream confined to the other (all - k) compute units — chain and Gaussian workgroups then never share a CU (an "
+                    "experiment: DESIGN.md has the sweep)")
     ap.add_argument("--reserve-cus", type=int, default=0, help="CUs the persistent pass kernel leaves to the side streams")
     ap.add_argument("--precond-behind-cg", dest="precond_after_fit", action="store_true",
                     help="issue the look-ahead preconditioner behind the batch's CG instead of before its fit")
@@ -278,7 +281,7 @@ def main():
     job = LockstepClassJob(be, X, N, M, lambda c: torch.where((row_ids % C) == c, 1.0, -1.0).to(torch.float64), cidx_dev,
                            args.sigma, args.lam, args.maxiter, opt, shard=shard, precond_batch=args.precond_batch,
                            precond_depth=args.precond_depth, precond_after_fit=args.precond_after_fit, precond_cus=args.precond_cus,
-                           batch=args.lockstep_batch, exchange=args.cg_exchange)
+                           batch=args.lockstep_batch, exchange=args.cg_exchange, gauss_on_complement=args.gauss_on_complement)
     G, ldk, scores = job.G, job.ldk, job.scores
     job_b, plan_gb = job.b, round(job.plan.total_bytes / 1e9, 1)
     kfmt = be.knm_format(n_loc, M)                 # storage of the K_nM shards ("u24" at the headline size, "f32" for small ones)
@@ -455,6 +458,7 @@ def main():
                                    "rows sharded over %d GPU(s)" % (C, N, D, M, args.maxiter, args.emulate_world if emulated else world),
                        "N": N, "D": D, "M": M, "classes": C, "sigma": args.sigma, "lambda": args.lam,
                        "rows_per_gpu": n_loc, "preconditioners_per_batched_chain": G, "preconditioner_cus": args.precond_cus or "all",
+                       "gaussians_on_the_complement": bool(args.gauss_on_complement and args.precond_cus),
                        "lockstep_batch": job_b, "planned_GB_per_rank": plan_gb, "cg_exchange": args.cg_exchange,
                        # the one options table (odx/options.py): what this run's kernels and schedules were selected by
                        "options": odx.options.as_dict()},

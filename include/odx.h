@@ -112,6 +112,14 @@ int odx_gauss_mmv_f32(const float* X, int64_t ldx, const float* xsq, int64_t n,
                       const double* V, int64_t ldv, const int32_t* ranges, int T,
                       float* out, int64_t ldo, odx_stream_t stream);
 
+/* The same block for SMALL problems by direct differences: K_ij = exp(-sum_d (x_id - z_jd)^2 / (2 sigma^2)), the differences
+ * formed directly and summed in f64 — the stored f32 entry is the exactly rounded one (no norm cancellation; one thread per
+ * entry, O(n M D) on the vector ALU).  The Python host side takes it for blocks of at most 2^24 multiply-adds (toy problems
+ * and fixtures, where tiny ill-conditioned fits feel the 1e-6 of the f32-accurate forms); same reference call site as
+ * odx_gauss_knm_f32.  No alignment requirement on X / Z. */
+int odx_gauss_knm_direct_f32(const float* X, int64_t ldx, int64_t n, const float* Z, int64_t ldz, int64_t M, int D,
+                             double sigma, float* K, int64_t ldk, odx_stream_t stream);
+
 /* ---------------------------------------------------------------- A3 / A5 on the f16 matrix cores
  * The same two operations (same reference call sites as odx_gauss_knm_f32 / odx_gauss_mmv_f32 above) with
  * the X Z' contraction on v_mfma_f32_16x16x32_f16 at f32 accuracy: every f32 value is split once into two

@@ -270,6 +270,33 @@ int gauss_kmm_f64(const double* Zd, int64_t ldz, int64_t M, int D, double sigma,
   return gauss_kmm_f64_batched(Zd, ldz, 0, zsq - Zd, vb, D, sigma, Kmm, ldk, 0, stream);
 }
 
+// ---------------------------------------------------------------- small blocks by direct differences
+// K_ij = exp(gamma sum_d (x_id - z_jd)^2) with the differences formed directly and summed in f64: no ||x||^2 + ||z||^2 - 2 x.z
+// cancellation, so the stored f32 entry is the exactly rounded one.  For blocks whose whole contraction is a few million
+// multiply-adds (toy problems, unit fixtures: the matrix cores have nothing to win there) the f32-accurate MFMA forms leave
+// 1e-6 relative in an entry — the norms' cancellation, which the reference's own f32 formula has four-fold —, and on tiny
+// ill-conditioned fits that is what stands between alpha and the 1e-4 bar (a 30-centre problem on 8-dimensional mask pixels:
+// 1.06e-4 with it, 3e-5 with exactly rounded entries).  One thread per entry.
+__global__ __launch_bounds__(256) void gauss_knm_direct_kernel(const float* __restrict__ X, int64_t ldx, int64_t n,
+                                                               const float* __restrict__ Z, int64_t ldz, int64_t M, int D, double gamma,
+                                                               float* __restrict__ K, int64_t ldk) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = e / ldk, j = e - i * ldk;
+  if (i >= n) return;
+  if (j >= M) {
+    K[i * ldk + j] = 0.f;                 // pad columns
+    return;
+  }
+  const float* x = X + i * ldx;
+  const float* z = Z + j * ldz;
+  double s = 0.0;
+  for (int d = 0; d < D; ++d) {
+    const double t = (double)x[d] - (double)z[d];
+    s = fma(t, t, s);
+  }
+  K[i * ldk + j] = (float)exp(gamma * s);
+}
+
 }  // namespace odx
 
 using namespace odx;
@@ -308,6 +335,19 @@ extern "C" int odx_gauss_knm_f32(const float* X, int64_t ldx, const float* xsq, 
   hipLaunchKernelGGL(gauss_knm_f32_kernel, dim3((unsigned)tiles), dim3(GEMM_THREADS), 0, as_stream(stream), X, ldx,
                      xsq, n, Z, ldz, zsq, M, D, (float)(-0.5 / (sigma * sigma)), K, ldk);
   ODX_CHECK_LAUNCH("odx_gauss_knm_f32");
+  return ODX_OK;
+}
+
+extern "C" int odx_gauss_knm_direct_f32(const float* X, int64_t ldx, int64_t n, const float* Z, int64_t ldz, int64_t M, int D,
+                                        double sigma, float* K, int64_t ldk, odx_stream_t stream) {
+  if (n <= 0 || M <= 0) return ODX_OK;
+  ODX_REQUIRE(X && Z && K && D > 0 && sigma > 0 && ldx >= D && ldz >= D, "odx_gauss_knm_direct_f32: bad argument");
+  ODX_REQUIRE(ldk % 4 == 0 && ldk >= round_up(M, 4) && aligned16(K), "odx_gauss_knm_direct_f32: K must be 16-byte aligned, ldk %% 4 == 0, ldk >= roundup(M, 4)");
+  const int64_t blocks = ceil_div(n * ldk, 256);
+  ODX_REQUIRE(blocks < (1ll << 31), "odx_gauss_knm_direct_f32: grid too large");
+  hipLaunchKernelGGL(gauss_knm_direct_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), X, ldx, n, Z, ldz, M, D,
+                     -0.5 / (sigma * sigma), K, ldk);
+  ODX_CHECK_LAUNCH("odx_gauss_knm_direct_f32");
   return ODX_OK;
 }
 

@@ -29,11 +29,12 @@ def _p(t):
 class Features:
     """Row-major f32 rows (n x D, leading dimension a multiple of 4) plus their squared norms and, once a
     Gaussian-kernel call has needed it, the packed two-term f16 split of the rows (P, meta: odx_split_f16)."""
-    __slots__ = ("X", "sq", "n", "D", "ld", "P", "meta", "own_pack", "P8", "meta8", "sq8")
+    __slots__ = ("X", "sq", "n", "D", "ld", "P", "meta", "own_pack", "P8", "meta8", "sq8", "zero_row")
 
     def __init__(self, X, sq, D, P=None, meta=None):
         self.X, self.sq, self.n, self.D, self.ld = X, sq, X.shape[0], D, X.stride(0) if X.shape[0] else X.shape[1]
         self.P, self.meta = P, meta
+        self.zero_row = False           # P is followed by one all-zero row in memory (what the tap-gathering products read outside the map)
         self.own_pack = P is None       # False: P was gathered from another matrix's split and carries ITS scale
         self.P8 = self.meta8 = self.sq8 = None     # e4m3 packing (odx_split_f8), made on demand by the throughput-only fp8 kernels
 
@@ -202,17 +203,20 @@ class HipBackend:
             hip.check(self.lib.odx_row_sqnorm_f32(_p(X), X.stride(0), n, D, _p(sq), self._stream()), "odx_row_sqnorm_f32")
         return Features(X, sq, D)
 
-    def masked_stream(self, cus):
+    def masked_stream(self, cus, complement=False):
         """A stream confined to `cus` compute units, spread evenly over the XCDs (logical CU i sits on XCC i % 8, so the
         first `cus` bits are cus / 8 per XCD); the library's internal helper streams created from now on get the same
-        mask.  Kept alive by the backend."""
+        mask.  complement: the stream gets the OTHER total - cus units instead (and the helper streams' mask is left alone) —
+        the MFMA-bound Gaussian kernels on the part of the chip the factorisation chains are not confined to.  Kept alive by
+        the backend."""
         total = int(self.lib.odx_device_cus())
-        cus = max(8, min(int(cus), total))
+        cus = max(8, min(int(cus), total - 8 if complement else total))
         words = (total + 31) // 32
         arr = (ctypes.c_uint32 * words)()
-        for b in range(cus):
+        for b in (range(cus, total) if complement else range(cus)):
             arr[b // 32] |= 1 << (b % 32)
-        hip.check(self.lib.odx_set_side_stream_cu_mask(arr, words), "odx_set_side_stream_cu_mask")
+        if not complement:
+            hip.check(self.lib.odx_set_side_stream_cu_mask(arr, words), "odx_set_side_stream_cu_mask")
         raw = ctypes.c_void_p()
         hip.check(self.lib.odx_stream_create_cu_mask(arr, words, ctypes.byref(raw)), "odx_stream_create_cu_mask")
         st = torch.cuda.ExternalStream(raw.value, device=self.device)
@@ -272,12 +276,19 @@ class HipBackend:
     def pack(self, F, zero_row=False):
         """Make sure F carries its packed f16 split (odx_split_f16); returns F.  zero_row: the packed rows are followed by
         one all-zero row in memory (what gemm_h2_taps reads for a position outside the map)."""
+        if F.P is not None and zero_row and not F.zero_row:
+            # a packing that exists but lacks the trailing zero row (advisor, round 5: it was silently handed on and the tap
+            # gather read past its end): packed again with the row when the split is this matrix's own, refused otherwise
+            if not F.own_pack:
+                raise ValueError("pack(zero_row=True): the packed rows were gathered from another matrix and have no zero row behind them")
+            F.P = None
         if F.P is None:
             ldp = (F.D + 63) // 64 * 64
             if zero_row:
                 buf = torch.empty((F.n + 1, ldp), dtype=torch.int32, device=self.device)
                 buf[F.n].zero_()
                 F.P = buf[:F.n]
+                F.zero_row = True
             else:
                 F.P = torch.empty((F.n, ldp), dtype=torch.int32, device=self.device)
             if F.meta is not None and F.n:            # features() already left max |x| in meta[1]
@@ -399,6 +410,11 @@ class HipBackend:
             return self._knm_store(F, Zf, sigma, fmt, None, out, None)[0]
         K = self._knm_block(n, M, "f32", out)
         ld = K.ld
+        if self.direct_small(n, M, F.D):
+            # a toy-sized block: every entry from direct differences summed in f64, exactly rounded (odx_gauss_knm_direct_f32)
+            hip.check(self.lib.odx_gauss_knm_direct_f32(_p(F.X), F.ld, n, _p(Zf.X), Zf.ld, M, F.D, float(sigma), _p(K.K), ld,
+                                                        self._stream()), "odx_gauss_knm_direct_f32")
+            return K
         if self.gauss == "h2":
             self.pack(F), self.pack(Zf)
             hip.check(self.lib.odx_gauss_knm_h2(_p(F.P), F.P.stride(0), _p(F.meta), _p(F.sq), n, _p(Zf.P), Zf.P.stride(0),
@@ -408,6 +424,16 @@ class HipBackend:
             hip.check(self.lib.odx_gauss_knm_f32(_p(F.X), F.ld, _p(F.sq), n, _p(Zf.X), Zf.ld, _p(Zf.sq), M, F.D,
                                                  float(sigma), _p(K.K), ld, self._stream()), "odx_gauss_knm_f32")
         return K
+
+    DIRECT_MAX_MACS = 1 << 24
+
+    def direct_small(self, n, M, D):
+        """Whether an (n, M) block over D features is built by direct differences (exactly rounded entries): the default
+        kernels (gauss "h2", tile core not pinned) and at most 2^24 multiply-adds — far below every problem of the reference's
+        regime (its smallest fits are 1e4 rows x 500 centres x 256 features = 1.3e9)."""
+        from . import options as _options
+        return (self.gauss == "h2" and _options.current().h2_tile == 0 and n > 0 and M > 0 and self.knm_storage in ("auto", "f32")
+                and int(n) * int(M) * int(D) <= self.DIRECT_MAX_MACS)
 
     def _knm_store(self, F, Zf, sigma, fmt, w, out, rhs_out):
         """Build on the wide tile core into storage format `fmt` (odx_gauss_knm_h2_store), with the fused right-hand side
@@ -440,7 +466,7 @@ class HipBackend:
         fmt = self.knm_format(n, M)
         if (fmt != "f32" or self.gauss == "f8") and n > 0:
             return self._knm_store(F, Zf, sigma, fmt, w, out, rhs_out)
-        if not (self.gauss == "h2" and n > 0 and self.lib.odx_gauss_h2_tile(n, M) == 256):
+        if not (self.gauss == "h2" and n > 0 and self.lib.odx_gauss_h2_tile(n, M) == 256) or self.direct_small(n, M, F.D):
             K = self.knm(F, Zf, sigma, out=out)
             return K, self.ktk(K, w=w, out=rhs_out)
         return self._knm_store(F, Zf, sigma, "f32", w, out, rhs_out)
@@ -1075,9 +1101,9 @@ class HipBackend:
         """X (rows, K) as the operand of gemm_b16: a bf16 / f16 row-major block whose rows are a multiple of 128 elements
         long, zero beyond K (Rows16).  A matrix that already is one (right dtype, contiguous, K % 128 == 0) is taken as it is.
         zero_row: the block is followed by one all-zero row in memory (conv3x3_rows16 gathers its taps in the product then)."""
-        if isinstance(X, Rows16) and (X.zero_row or not zero_row):
+        if isinstance(X, Rows16) and (X.zero_row or not zero_row) and (dtype is None or X.buf.dtype == dtype):
             return X
-        if isinstance(X, Rows16):
+        if isinstance(X, Rows16):            # (no zero row where one is wanted, or another 16-bit type than asked for: made again)
             X = X.dense
         dtype = dtype or (X.dtype if X.dtype in (torch.bfloat16, torch.float16) else torch.bfloat16)
         n, K = X.shape

@@ -1278,7 +1278,7 @@ class OnlineFeatureExtractor:
     `parts` selects what is harvested: any of "rpn", "detector", "mask"."""
 
     def __init__(self, model, num_classes, parts=("rpn", "detector"), det=None, rpn=None, mask=None, rank=0, world=1,
-                 pipeline=True, trunk_batch=4):
+                 pipeline=True, trunk_batch=8):
         self.model, self.C, self.parts, self.rank, self.world = model, num_classes, tuple(parts), rank, world
         self.pipeline = pipeline        # on a GPU: forward of the next image on a second thread / stream while this one is harvested
         # on a GPU: consecutive images of one size share ONE forward — trunk, proposal stage and RoI head each run once for the

@@ -412,9 +412,18 @@ class DetectorHarvester:
                 lens.append(k)
         if not plan:
             return torch.empty((0, self.D), dtype=x.dtype, device=x.device), lens
-        up = to_device(torch.stack(draws), x.device)                                           # one copy for all classes' draws
-        parts = [up[d] if kind == "host" else cand_order[:, col[i]][up[d]] for kind, i, d in plan]
-        return x[torch.cat(parts)].view(-1, self.D), lens
+        # one copy for all classes' draws (+ per draw the column of its class's candidate list, -1 for a class that is not in the
+        # image), and the rows of ALL classes from a handful of launches: sel[:, p] = the candidate order of draw p's class,
+        # gathered at the draws — what `cand_order[:, col[i]][up[d]]` class by class gave (two launches per class before)
+        colv = torch.tensor([col[i] if kind == "dev" else -1 for kind, i, _ in plan], dtype=torch.int64)
+        up = to_device(torch.cat((torch.stack(draws), colv[:, None]), dim=1), x.device)
+        dr, cv = up[:, :k], up[:, k]
+        if cand_order is None or not any(kind == "dev" for kind, _, _ in plan):
+            idx = dr.reshape(-1)
+        else:
+            sel = cand_order.index_select(1, cv.clamp_min(0))                                  # (R, draws)
+            idx = torch.where(cv[:, None] >= 0, torch.gather(sel, 0, dr.t()).t(), dr).reshape(-1)
+        return x[idx].view(-1, self.D), lens
 
     def _fill_batches(self, x, overlap, gt_labels_list, known=None):
         done = []

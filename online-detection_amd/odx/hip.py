@@ -46,6 +46,7 @@ SIGNATURES = {
     "odx_row_sqnorm_absmax_f32": (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "odx_split_f16_premax": (_i32, [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp]),
     "odx_gauss_knm_f32": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _f64, _vp, _i64, _vp]),
+    "odx_gauss_knm_direct_f32": (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _i32, _f64, _vp, _i64, _vp]),
     "odx_gauss_mmv_f32": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _f64, _vp, _i64, _vp, _i32, _vp, _i64, _vp]),
     "odx_split_f16": (_i32, [_vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp]),
     "odx_gauss_h2_tile": (_i32, [_i64, _i64]),

@@ -66,6 +66,27 @@ def _wait(ev):
         torch.cuda.current_stream().wait_event(ev)
 
 
+class _OnStream:
+    """`inner` (a phase timer or nothing) entered on `stream`, joined to the current stream on both sides: the launches of the
+    block run on `stream` in the order the current stream would have given them."""
+
+    def __init__(self, stream, inner):
+        self.stream, self.inner = stream, inner
+
+    def __enter__(self):
+        self.cur = torch.cuda.current_stream()
+        self.stream.wait_stream(self.cur)
+        self.ctx = torch.cuda.stream(self.stream)
+        self.ctx.__enter__()
+        return self.inner.__enter__()
+
+    def __exit__(self, *exc):
+        r = self.inner.__exit__(*exc)
+        self.ctx.__exit__(*exc)
+        self.cur.wait_stream(self.stream)
+        return r
+
+
 precond_groups = _plan.precond_groups       # (kept under its old name: tests and tools import it from here)
 
 
@@ -75,7 +96,7 @@ class LockstepClassJob:
 
     def __init__(self, be, X, n_total, M, labels, centre_idx, sigma, lam, maxiter=20, opt=None, shard=None,
                  precond_batch=0, precond_depth=2, precond_after_fit=False, classes=None, precond_cus=0, batch=0,
-                 hbm_bytes=None, exchange="lockstep"):
+                 hbm_bytes=None, exchange="lockstep", gauss_on_complement=False):
         """precond_batch: classes per rank and preconditioner chain (g; 0 = planned, 1 = one chain per class on `precond_depth`
         side streams); batch: classes per lock-step batch (b, a divisor of the world size; 0 = planned); hbm_bytes: the
         memory the plan may count on per rank (default: the device's, 288 GB without one).
@@ -83,6 +104,8 @@ class LockstepClassJob:
         directions and one reduce-scatter of the partials (what bench.py times); "allreduce" — the north star's literal form:
         classes one at a time, EVERY rank builds every class's preconditioner and runs every M-sized product, per CG iteration
         ONE all-reduce of the (M,) partial (solver.falkon_fit's replicated mode).  Same arithmetic per class either way."""
+        # gauss_on_complement (with precond_cus = k > 0; an experiment, round-5 review item 1a): the K_nM builds and the scoring run
+        # on a stream confined to the OTHER total - k compute units, so that chain and Gaussian workgroups never share a CU
         if exchange not in ("lockstep", "allreduce"):
             raise ValueError("LockstepClassJob: exchange must be 'lockstep' or 'allreduce', got %r" % (exchange,))
         self.exchange = exchange
@@ -121,6 +144,8 @@ class LockstepClassJob:
         self.sides = [_Side(dev, be, precond_cus, index=k) for k in range(self.nslot)] if self.G == 1 else []
         self.gside = _Side(dev, be, precond_cus) if (self.G > 1 or exchange == "allreduce") else None
         self._cplans = {}        # class -> the centre-assembly plan of gather_centres (world > 1)
+        self.gauss_stream = (be.masked_stream(precond_cus, complement=True)
+                             if gauss_on_complement and precond_cus > 0 and dev.type == "cuda" and hasattr(be, "masked_stream") else None)
         self.pbuf, self.pgroup = [], []
         self.trace = []          # (kind, payload) records of the schedule this rank executed (tests read it)
         if self.G > 1 and hasattr(be, "precond_batched") and hasattr(be, "lib") and dev.type == "cuda":
@@ -289,7 +314,11 @@ class LockstepClassJob:
         that receives class -> alpha (M,) f64 of every fitted class.  Returns (alpha, Zf) of the last class."""
         be, world, rank = self.be, self.world, self.rank
         classes = list(range(self.C)) if classes is None else list(classes)
-        ph = (lambda name: phases[name]) if phases is not None else (lambda name: contextlib.nullcontext())
+        base = (lambda name: phases[name]) if phases is not None else (lambda name: contextlib.nullcontext())
+        if self.gauss_stream is not None:
+            ph = lambda name: _OnStream(self.gauss_stream, base(name)) if name in ("knm", "mmv") else base(name)      # noqa: E731
+        else:
+            ph = base
         if self.exchange == "allreduce":
             return self._run_replicated(F, classes, ph, phases, infos, alphas_out)
         sched = _plan.lockstep_batches(classes, world, self.b)          # [(classes of the batch, their owner ranks)]
@@ -316,7 +345,7 @@ class LockstepClassJob:
             self.trace.append(("fit", tuple(batch)))
             alphas = solver.falkon_fit_lockstep(be, F, ys, Zs, self.sigma, self.lam, self.maxiter, self.opt, n_total=self.N,
                                                 shard=self.shard, knm_outs=self.kbufs[:len(batch)],
-                                                phase=(lambda name: phases[name]) if phases is not None else None,
+                                                phase=ph if (phases is not None or self.gauss_stream is not None) else None,
                                                 precond=P if mine else None,
                                                 precond_ready=(lambda: _wait(ev)) if mine else None, owners=owners)
             if self.G == 1 and self.after_fit and bi + self.depth < len(sched):

@@ -19,7 +19,7 @@ and load Detectron weights; datasets, weights and that package are outside this 
                                  over more than one rank), False otherwise
     cfg_options['shard']         the odx.dist.RowShard the caller's sharded trainers use (falkon_fit(shard=),
                                  RegionRefinerTrainer(shard=)): images are then split over its ranks by default
-    cfg_options['trunk_batch']   images of one size that share ONE forward (trunk, proposals, RoI head) in the harvest loop (default 4; 1 = one image
+    cfg_options['trunk_batch']   images of one size that share ONE forward (trunk, proposals, RoI head) in the harvest loop (default 8; 1 = one image
                                  per call).  With > 1 an image's features depend on its neighbour in the list in the
                                  last bits (the convolution library picks its algorithm per batch size) and so differ
                                  in rounding from the one-image detect() / forward() path used at test time: pass 1 for
@@ -149,7 +149,7 @@ class FeatureExtractor(FeatureExtractorAbstract):
                 'iterations': det_kw.get('iterations', 10), 'batch_size': det_kw.get('batch_size', 2000)})
             return t0, ex.test(cfg_options['samples'])
         ex = OnlineFeatureExtractor(model, num_classes, parts=parts, det=det_kw, rpn=self._kw(cfg, 'RPN'), mask=mask_kw,
-                                    rank=rank, world=world, trunk_batch=int(cfg_options.get('trunk_batch', 4)))
+                                    rank=rank, world=world, trunk_batch=int(cfg_options.get('trunk_batch', 8)))
         if save_features and not output_dir:
             raise ValueError('Output directory must be specified.')       # the reference prints this and quits
         out = ex.train(cfg_options['samples'], use_only_gt_positives, save_dir=output_dir if save_features else None)

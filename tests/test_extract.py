@@ -739,6 +739,51 @@ def _plain_roi_align(feat, boxes, scale, P):
 
 
 @pytest.mark.gpu
+def test_default_route_dispatch_straddles_the_threshold():
+    """The suite runs with rows_min_positions = 0 (tests/conftest.py: its small models would never reach the threshold), so the
+    product's DEFAULT dispatch is exercised here (advisor, round 5): a model with the default threshold (odx.options, not the
+    suite's environment) sends one 600 x 800 image (38 x 50 = 1900 stride-16 positions) to the convolution route and two (3800)
+    to the row-GEMM route, in f32 and in bf16 alike, and the two routes agree on the same images."""
+    from odx import options
+    from odx.extract import forward_batch
+    odx.set_backend(None)
+    default = options.Options().rows_min_positions
+    model = OnlineDetectionModel(width=16, pre_nms_top_n=300, post_nms_top_n=40, seed=3).eval()
+    model.rpn_logits.weight.data.normal_(0, 0.3)
+    model = model.cuda()
+    model.rows_min_positions = default
+    g = torch.Generator().manual_seed(2)
+    one, two = torch.randn(1, 3, 600, 800, generator=g).cuda(), torch.randn(2, 3, 600, 800, generator=g).cuda()
+    if default > 0:
+        assert 1900 < default <= 3800
+        assert not model._rows_path(one) and model._rows_path(two)
+        model.compute_dtype = torch.bfloat16
+        assert not model._rows16_path(one) and model._rows16_path(two)
+        model.compute_dtype = None
+    else:
+        assert model._rows_path(one) and model._rows_path(two)        # (threshold 0: one hand-written route at every size)
+    with torch.no_grad():
+        got = {}
+        for name, thr in (("default", default), ("rows", 0), ("conv", 1 << 40)):
+            model.rows_min_positions = thr
+            model._trunk_graphs.clear()
+            got[name] = (model._c4_eager(one).contiguous(), model._c4_eager(two).contiguous())
+        for k in range(2):
+            scale = float(got["conv"][k].abs().max())
+            assert float((got["rows"][k] - got["conv"][k]).abs().max()) <= 2e-4 * scale      # two routes, one network
+            assert float((got["default"][k] - got["conv"][k]).abs().max()) <= 2e-4 * scale
+        # near-tied RPN scores (logits within ~1e-3 of each other) on ONE route: the batched proposal stage keeps what the
+        # single-image stage keeps (across routes a tie may legitimately flip: their sums differ in the last bits)
+        model.rows_min_positions = 0
+        model.rpn_logits.weight.data.mul_(1e-3)
+        model.refresh_weights()
+        per, _, _, _ = forward_batch(model, two, [None, None])
+        for b in range(2):
+            boxes_b, _, _ = model(two[b:b + 1], None)
+            assert per[b][0].shape == boxes_b.shape and float((per[b][0] - boxes_b).abs().max()) < 1e-2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("batch,route", [(1, "rows"), (3, "rows"), (1, "conv"), (3, "conv")])
 def test_forward_gpu_equals_plain_torch_cpu(batch, route):
     """route: "rows" = trunk stages and RPN head as row GEMMs on the split-f16 tile cores (ResNet50C4.forward_rows, the map

@@ -1496,3 +1496,60 @@ def test_upsample_add_rows_equals_the_tensor_statements(be):
             want16 = (l16.dense.reshape(B, H, W, C) + t16.dense.reshape(B, Hp, Wp, C)[:, hi][:, :, wi]).reshape(B * H * W, C)
             be.upsample_add_rows16(l16, t16, B, H, W, Hp, Wp)
             assert torch.equal(l16.dense, want16), dt
+
+
+@pytest.mark.gpu
+def test_pack_honours_a_later_request_for_the_zero_row_and_rows16_a_dtype(be):
+    """HipBackend.pack(F, zero_row=True) on Features that already carry a packing WITHOUT the trailing zero row packs again with it
+    (the tap-gathering products read that row for positions outside the map; advisor, round 5: the request was silently ignored),
+    refuses a packing gathered from another matrix; rows16 converts an existing Rows16 of another 16-bit type."""
+    from odx.backend import Rows16
+    g = torch.Generator(device="cuda").manual_seed(2)
+    X = torch.randn((70, 96), generator=g, device="cuda")
+    F = be.pack(be.features(X))
+    assert F.P is not None and not F.zero_row
+    P0 = F.P.clone()
+    F = be.pack(F, zero_row=True)
+    assert F.zero_row and torch.equal(F.P, P0)
+    behind = torch.as_strided(F.P, (1, F.P.shape[1]), (F.P.stride(0), 1), F.P.storage_offset() + F.n * F.P.stride(0))
+    assert int(behind.abs().max()) == 0
+    Zf = be.rows(F, torch.arange(0, 70, 7, device="cuda"))          # gathered rows carry the source's scale, no zero row
+    if not Zf.own_pack and Zf.P is not None:
+        with pytest.raises(ValueError):
+            be.pack(Zf, zero_row=True)
+    A = be.rows16(torch.randn((5, 128), generator=g, device="cuda"), torch.bfloat16)
+    assert isinstance(A, Rows16) and be.rows16(A) is A and be.rows16(A, torch.bfloat16) is A
+    B = be.rows16(A, torch.float16)
+    assert B is not A and B.buf.dtype == torch.float16 and float((B.dense.float() - A.dense.float()).abs().max()) < 0.02
+
+
+def test_small_blocks_are_built_by_direct_differences(be):
+    """HipBackend.knm on a toy-sized block (<= 2^24 multiply-adds, default kernels, tile core not pinned): every entry from
+    direct differences summed in f64 (odx_gauss_knm_direct_f32) — the exactly rounded f32 of the f64 oracle's entry, pad
+    columns zero, ragged shapes, unaligned leading dimensions; a pinned tile core or a larger block keeps the matrix-core
+    form.  This is what lets tiny ill-conditioned fits (the reference driver fixture's 30-centre segmentation head) sit at
+    the storage floor instead of the f32 formula's cancellation error."""
+    from oracle import falkon_ref as fr
+    rng = np.random.default_rng(77)
+    old = (be.gauss, be.knm_storage)
+    be.gauss, be.knm_storage = "h2", "auto"
+    try:
+        for n, M, D, sigma in ((1, 1, 1, 3.0), (37, 30, 8, 5.0), (513, 129, 70, 12.0), (300, 500, 100, 25.0)):
+            assert be.direct_small(n, M, D)
+            X = (rng.standard_normal((n, D)) * (20.0 / np.sqrt(D))).astype(np.float32)
+            Z = (rng.standard_normal((M, D)) * (20.0 / np.sqrt(D))).astype(np.float32)
+            Z[: min(M, n) // 2] = X[: min(M, n) // 2] + 1e-3 * rng.standard_normal((min(M, n) // 2, D)).astype(np.float32)   # near-duplicates: d^2 ~ 1e-6 D
+            K = be.knm(be.features(torch.from_numpy(X)), be.features(torch.from_numpy(Z)), sigma)
+            ref = fr.gaussian_kernel(X.astype(np.float64), Z.astype(np.float64), sigma)
+            # the oracle forms d^2 from norms in f64 (absolute error ~1e-13 x 800 in d^2): compare with differences in f64
+            d2 = ((X.astype(np.float64)[:, None, :] - Z.astype(np.float64)[None, :, :]) ** 2).sum(2)
+            exact = np.exp(-d2 / (2 * sigma ** 2))
+            got = kdense(K).astype(np.float64)
+            assert np.abs(got - exact.astype(np.float32).astype(np.float64)).max() <= 6e-8 * 1.01      # one f32 ulp at most (exp's last bit)
+            assert np.abs(got - ref).max() < 1e-6
+        assert not be.direct_small(4000, 1000, 2048) and not be.direct_small(10_000, 500, 256)       # the reference's regime: matrix cores
+        be.pin_gauss_tile(128)
+        assert not be.direct_small(37, 30, 8)                                                     # a pinned tile core: the tests' MFMA variants
+    finally:
+        be.pin_gauss_tile(0)
+        be.gauss, be.knm_storage = old

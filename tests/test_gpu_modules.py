@@ -571,7 +571,8 @@ def test_batched_minibootstrap_equals_the_sequential_one_bit_for_bit(tmp_path, m
                        ("b3", {"class_batch": 3, "return_caches": True}), ("s3", {"class_streams": 3, "return_caches": True}),
                        ("b3g", {"class_batch": 3, "return_caches": True}), ("b3h", {"class_batch": 3, "return_caches": True})):
         monkeypatch.setattr(OnlineRegionClassifierBase, "GROUP_MIN_CLASSES", {"b3g": 1, "b3h": 99}.get(mode, 4))
-        monkeypatch.setattr(odx_falkon, "_CHAIN_SPLIT_MIN", 1 if mode == "b3h" else 4)
+        import odx
+        monkeypatch.setattr(odx.options.current(), "chain_split_min", 1 if mode == "b3h" else 4)
         pos, neg = data()
         w = wrap_mod.FALKONWrapper(cfg_path=path)
         w.compute_indices_selection = injected
