@@ -66,10 +66,10 @@ def parse():
                     "class's preconditioner and M-sized state, ONE all-reduce of the (M,) partial per CG iteration")
     ap.add_argument("--precond-cus", type=int, default=0, help="confine the preconditioner chains (their stream and the library's "
                     "helper streams) to this many compute units, spread over the XCDs (0: the whole device; an experiment knob — "
-                    "measured slower at 48..128 CUs: the confined chains starve behind the main stream's grids, DESIGN.md 7)")
+                    "measured slower at 48..128 CUs: the confined chains starve behind the main stream's grids, docs/HISTORY.md 7)")
     ap.add_argument("--gauss-on-complement", action="store_true", help="with --precond-cus k: launch the K_nM builds and the scoring on a "
                     "stream confined to the other (all - k) compute units — chain and Gaussian workgroups then never share a CU (an "
-                    "experiment: DESIGN.md has the sweep)")
+                    "experiment: DESIGN.md section 9 has the sweep)")
     ap.add_argument("--reserve-cus", type=int, default=0, help="CUs the persistent pass kernel leaves to the side streams")
     ap.add_argument("--precond-behind-cg", dest="precond_after_fit", action="store_true",
                     help="issue the look-ahead preconditioner behind the batch's CG instead of before its fit")

@@ -60,7 +60,7 @@ int odx_option_default(const char* name, int* value);
  * the helpers of a class-batched chain, idle but alive, slow every later small launch of the process (a one-image forward behind
  * the headline job: 4.7 -> 7.6 ms). */
 int odx_release_helper_streams(void);
-/* CU-partitioned execution (diagnostic: tools/cu_split_probe.py measured it and the job does NOT use it, DESIGN.md §7).
+/* CU-partitioned execution (diagnostic: tools/cu_split_probe.py measured it and the job does NOT use it, DESIGN.md §9).
  * odx_stream_create_cu_mask: a HIP stream whose kernels run only on the compute units whose
  * bit is set in `mask` (`words` 32-bit words, bit i = logical CU i; hipExtStreamCreateWithCUMask) — the HBM-bound CG passes
  * of one class and the MFMA-bound K_nM build / scoring of its neighbours then run beside each other on disjoint parts of

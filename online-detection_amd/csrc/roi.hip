@@ -458,7 +458,7 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const unsigned long long
 // k-th key in seven 8-bit passes over the image's logits (L2-resident: 28 500 floats at 600 x 800), the k keys at or above it
 // are compacted into LDS and sorted there (bitonic, <= 8192 entries), and each thread then decodes its ranks.  Replaces a
 // sigmoid, a top-k, a gather, an advanced-index gather and ~25 elementwise launches — and the library top-k whose replay from
-// a captured HIP graph faulted.  logits (B, A, H, W), deltas (B, 4 A, H, W), anchors (H W A, 4) in the
+// a captured HIP graph faulted (docs/HISTORY.md 7, round 5).  logits (B, A, H, W), deltas (B, 4 A, H, W), anchors (H W A, 4) in the
 // (location, anchor type) order of grid_anchors; flat candidate index i = (h W + w) A + a.
 constexpr int TOPK_NT = 1024, TOPK_MAX = 8192;
 

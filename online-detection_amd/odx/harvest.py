@@ -168,11 +168,20 @@ class _Growing:
 
 class _Slot:
     """One (class, batch) window of the negatives store of a _SlotGrid, with the interface of a _Growing buffer
-    (n, view, append)."""
+    (n, view, append).  Its fill count lives in the grid's host matrix `fill` (the vectorised planner works on whole rows of
+    it); `n` reads and writes that entry."""
 
     def __init__(self, grid, cls, b):
-        self.grid, self.cls, self.b, self.n = grid, cls, b, 0
+        self.grid, self.cls, self.b = grid, cls, b
         self.mark_every, self.marks = None, []
+
+    @property
+    def n(self):
+        return int(self.grid.fill[self.cls, self.b])
+
+    @n.setter
+    def n(self, v):
+        self.grid.fill[self.cls, self.b] = v
 
     def view(self):
         return self.grid.store[self.cls, self.b, : self.n]
@@ -185,32 +194,36 @@ class _Slot:
 
 class _SlotGrid:
     """Negatives of the fill mode: a batch never grows past batch_size rows, so every (class, batch) has a fixed home in
-    ONE (classes, batches, batch_size, D) tensor.  `plan` records, on the host, where the rows sampled for an image go
-    (the reference's bookkeeping, integer arithmetic only); `commit` moves all of them with one gather + one
+    ONE (classes, batches, batch_size, D) tensor.  `plan` / `plan_rows` record, on the host, where the rows sampled for an
+    image go (the reference's bookkeeping, integer arithmetic only); `commit` moves all of them with one gather + one
     index_copy_ — the reference (and round 1 here) appends them piece by piece, one small device copy per class and
     open batch: several hundred per image at 30 classes x 10 batches."""
 
     def __init__(self, D, iterations, batch_size, device):
         self.D, self.iterations, self.batch_size, self.device = D, iterations, batch_size, device
         self.store = torch.empty((0, iterations, batch_size, D), dtype=torch.float32, device=device)
+        self.fill = np.zeros((0, iterations), dtype=np.int64)          # rows in every (class, batch) window
         self.classes = 0
-        self.dst, self.src = [], []
+        self.dst, self.src, self.runs = [], [], []
+
+    def _grow(self, cap):
+        new = torch.empty((cap,) + tuple(self.store.shape[1:]), dtype=torch.float32, device=self.device)
+        new[: self.classes] = self.store[: self.classes]
+        self.store = new
+        fill = np.zeros((cap, self.iterations), dtype=np.int64)
+        fill[: self.fill.shape[0]] = self.fill
+        self.fill = fill
 
     def add_class(self):
         if self.classes == self.store.shape[0]:                       # grow (construction reserves the exact count)
-            cap = max(1, 2 * self.store.shape[0])
-            new = torch.empty((cap,) + tuple(self.store.shape[1:]), dtype=torch.float32, device=self.device)
-            new[: self.classes] = self.store[: self.classes]
-            self.store = new
+            self._grow(max(1, 2 * self.store.shape[0]))
         c = self.classes
         self.classes += 1
         return [_Slot(self, c, b) for b in range(self.iterations)]
 
     def reserve(self, classes):
         if classes > self.store.shape[0]:
-            new = torch.empty((classes,) + tuple(self.store.shape[1:]), dtype=torch.float32, device=self.device)
-            new[: self.classes] = self.store[: self.classes]
-            self.store = new
+            self._grow(classes)
 
     def plan(self, slot, src_start, k):
         if k > 0:
@@ -219,22 +232,69 @@ class _SlotGrid:
             self.src.append(src_start)
             slot.n += k
 
+    def plan_rows(self, cls, take, src):
+        """The plans of whole classes at once: take (len(cls), batches) rows into every window of the classes `cls` (host
+        arrays), read from src (same shape) on in the image's sampled rows; class-major, batch-minor — the order of the
+        box-by-box `plan` calls this replaces (fill_plan)."""
+        ci, bi = np.nonzero(take)
+        if ci.size:
+            c = np.asarray(cls, dtype=np.int64)[ci]
+            ks = take[ci, bi]
+            base = (c * self.iterations + bi) * self.batch_size + self.fill[c, bi]
+            self.runs.append((base, src[ci, bi], ks))
+            self.fill[c, bi] += ks
+
     def commit(self, rows):
         """rows: the sampled rows of the image, all classes back to back (the `src_start` frame of plan)."""
-        if not self.dst:
+        if self.dst:
+            r = np.asarray(self.dst, dtype=np.int64).reshape(-1, 2)
+            self.runs.append((r[:, 0], np.asarray(self.src, dtype=np.int64), r[:, 1]))
+            self.dst, self.src = [], []
+        if not self.runs:
             return
         # (several hundred (start, count) runs per image: expanded with a handful of array operations, not one arange per run)
-        runs = np.asarray(self.dst, dtype=np.int64).reshape(-1, 2)
-        ks = runs[:, 1]
+        base = np.concatenate([r[0] for r in self.runs])
+        start = np.concatenate([r[1] for r in self.runs])
+        ks = np.concatenate([r[2] for r in self.runs])
+        self.runs = []
         ramp = np.arange(int(ks.sum()), dtype=np.int64) - np.repeat(np.cumsum(ks) - ks, ks)
-        dst = np.repeat(runs[:, 0], ks) + ramp
-        src = np.repeat(np.asarray(self.src, dtype=np.int64), ks) + ramp
-        self.dst, self.src = [], []
+        dst = np.repeat(base, ks) + ramp
+        src = np.repeat(start, ks) + ramp
         idx = to_device(torch.from_numpy(np.stack((dst, src))), rows.device)      # one host -> device copy
         # the rows take the store's dtype / device here (f64 or f16 features, features of another device): index_copy_
         # itself accepts neither, and by now `plan` has already counted the rows
         picked = rows.index_select(0, idx[1]).to(device=self.store.device, dtype=self.store.dtype)
         self.store.view(-1, self.D).index_copy_(0, idx[0].to(self.store.device), picked)
+
+
+def fill_plan(fill, cb, per_batch, batch_size, k, n_rows, phantom):
+    """Where the reference's batch walk puts the rows sampled for one image, for ALL classes at once (host integer arrays).
+
+    The walk, per class (box_head_getProposals.py:226-290, rpn_getProposals.py:283-331): from the class's current batch on,
+    a full batch (fill >= batch_size) is skipped and counted (`current_batch += 1`), an open one receives
+    min(per_batch, its room, k - taken[, n - taken]) rows, and the walk ends when k rows are taken.  `phantom` (the detector's
+    form): a class with n < k rows still advances `taken` by the full amounts — its rows simply run out (neg[taken:end]
+    is empty past n) —; without it (the on-line RPN's form) the amounts are limited by n and the walk, never reaching k,
+    visits every batch.
+    fill (nc, B): rows in every batch of the nc classes; cb (nc,): their current batch; n_rows (nc,): rows sampled per class.
+    Returns take (nc, B): rows that really land in each batch; lo (nc, B): their offset inside the class's sampled rows;
+    skipped (nc,): full batches the walk passed."""
+    nc, B = fill.shape
+    bidx = np.arange(B, dtype=np.int64)[None, :]
+    active = bidx >= cb[:, None]
+    room = batch_size - fill
+    full = active & (room <= 0)
+    want = np.where(active & (room > 0), np.minimum(per_batch, room), 0)
+    limit = np.full(nc, k, dtype=np.int64) if phantom else np.minimum(k, n_rows)
+    cum = np.cumsum(want, axis=1)
+    before = cum - want
+    amount = np.clip(limit[:, None] - before, 0, want)                 # what the walk counts as taken in each batch
+    reaches = (np.minimum(cum, limit[:, None]) >= k) & (want > 0)      # the batch at which `taken == k` ends the walk
+    stop = np.where(reaches.any(axis=1), reaches.argmax(axis=1), B - 1)
+    skipped = (full & (bidx <= stop[:, None])).sum(axis=1)
+    lo = np.minimum(before, n_rows[:, None])
+    hi = np.minimum(before + amount, n_rows[:, None])
+    return hi - lo, lo, skipped
 
 
 def clamp_boxes_(b, img_size):
@@ -426,32 +486,25 @@ class DetectorHarvester:
         return x[idx].view(-1, self.D), lens
 
     def _fill_batches(self, x, overlap, gt_labels_list, known=None):
-        done = []
         classes = list(self.still_to_complete)
         feats_all, lens = self._sample_all(x, overlap, classes, gt_labels_list, known)
-        at = 0
-        per_batch = math.ceil(self.negatives_to_pick / self.iterations)
-        for i, n_i in zip(classes, lens):
-            # where the reference would append this class's rows (box_head_getProposals.py:226-290), as integer
-            # bookkeeping on the host; the rows themselves move once, for all classes, in _SlotGrid.commit
-            taken = 0
-            for b in range(self.current_batch[i], self.iterations):
-                cur = self._neg[i][b]
-                if cur.n >= self.batch_size:
-                    self.current_batch[i] += 1
+        if classes:
+            # where the reference would append every class's rows (box_head_getProposals.py:226-290), as integer bookkeeping on
+            # the host — all classes by one fill_plan (a Python walk over every (class, open batch) before: several hundred
+            # steps per image); the rows themselves move once, for all classes, in _SlotGrid.commit
+            cls = np.asarray(classes, dtype=np.int64)
+            n_rows = np.asarray(lens, dtype=np.int64)
+            cb = np.asarray([self.current_batch[i] for i in classes], dtype=np.int64)
+            per_batch = math.ceil(self.negatives_to_pick / self.iterations)
+            take, lo, skipped = fill_plan(self._grid.fill[cls], cb, per_batch, self.batch_size, self.negatives_to_pick, n_rows, phantom=True)
+            at = np.cumsum(n_rows) - n_rows
+            self._grid.plan_rows(cls, take, at[:, None] + lo)
+            for i, sk in zip(classes, skipped.tolist()):
+                if sk:
+                    self.current_batch[i] += sk
                     if self.current_batch[i] >= self.iterations:
-                        done.append(i)
-                    continue
-                end = int(taken + min(per_batch, self.batch_size - cur.n, self.negatives_to_pick - taken))
-                lo, hi = min(taken, n_i), min(end, n_i)          # a class without candidates has no rows: neg_i[taken:end] is empty
-                self._grid.plan(cur, at + lo, hi - lo)
-                taken = end
-                if taken == self.negatives_to_pick:
-                    break
-            at += n_i
+                        self.still_to_complete.remove(i)
         self._grid.commit(feats_all)
-        for i in done:
-            self.still_to_complete.remove(i)
 
     # ------------------------------------------------------------------ test time
     def add_test_image(self, x, proposals, gt_label_count, img_size):
@@ -641,35 +694,30 @@ class RPNHarvester:
         up = to_device(torch.cat(picks + [torch.tensor(rank_of, dtype=torch.int64)]), dev) if (picks or G) else None
         pick_idx, rank_dev = up[:n_neg], up[n_neg:]
         feats_all = self._gather(t, order[pick_idx]) if n_neg else torch.empty((0, self.D), dtype=t.dtype, device=dev)
-        done = []
-        at = 0
-        for i, n_i in zip(types, lens):
-            feat_i = feats_all[at:at + n_i]
-            at += n_i
-            if self.shuffle_negatives:
+        if self.shuffle_negatives:
+            at = 0
+            for i, n_i in zip(types, lens):
                 last = self._neg[i][-1]
-                last.append(feat_i)
+                last.append(feats_all[at:at + n_i])
+                at += n_i
                 if last.n >= self.batch_size:
                     self._neg[i].append(_Growing(self.D, self.device, cap=self.batch_size))
-                continue
-            per_batch = math.ceil(self.negatives_to_pick / self.iterations)
-            taken = 0
-            for b in range(self.current_batch[i], self.iterations):
-                cur = self._neg[i][b]
-                if cur.n >= self.batch_size:
-                    self.current_batch[i] += 1
-                    if self.current_batch[i] >= self.iterations:
-                        done.append(i)
-                    continue
-                end = int(taken + min(per_batch, self.batch_size - cur.n, self.negatives_to_pick - taken, n_i - taken))
-                self._grid.plan(cur, at - n_i + taken, end - taken)       # rows move once for all types (commit below)
-                taken = end
-                if taken == self.negatives_to_pick:
-                    break
-        if self._grid is not None:
+        else:
+            if types:
+                # the batch walk of every anchor type at once (fill_plan; rpn_getProposals.py:283-331: the amounts limited by the
+                # rows a type really has); the rows move once for all types (commit below)
+                tarr, n_rows = np.asarray(types, dtype=np.int64), np.asarray(lens, dtype=np.int64)
+                cb = np.asarray([self.current_batch[i] for i in types], dtype=np.int64)
+                per_batch = math.ceil(self.negatives_to_pick / self.iterations)
+                take, lo, skipped = fill_plan(self._grid.fill[tarr], cb, per_batch, self.batch_size, self.negatives_to_pick, n_rows, phantom=False)
+                at = np.cumsum(n_rows) - n_rows
+                self._grid.plan_rows(tarr, take, at[:, None] + lo)
+                for i, sk in zip(types, skipped.tolist()):
+                    if sk:
+                        self.current_batch[i] += sk
+                        if self.current_batch[i] >= self.iterations:
+                            self.still_to_complete.remove(i)
             self._grid.commit(feats_all)
-        for i in done:
-            self.still_to_complete.remove(i)
         # The reference walks the anchor types that have positives in ascending order and, per type, appends its rows
         # (rpn_getProposals.py:383-449): over-threshold anchors first (ascending anchor index), then the added best anchors box
         # by box.  Here: ONE stable sort by (type, group) gives that order for all types at once, one gather fetches every

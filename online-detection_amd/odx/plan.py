@@ -10,7 +10,7 @@ N M s_K bytes of K_nM per rank at EVERY world size, which BASELINE config 5 (N =
         of a batch are b of the ranks; consecutive batches rotate through the ranks, so that over a ROUND of world / b
         batches every rank owns exactly one class (the preconditioner work stays balanced);
     g   classes per rank and preconditioner chain = rounds per chain group (<= 6: past that the batched chain gains
-        nothing).
+        nothing, docs/HISTORY.md 7).
 
 Everything here is host arithmetic on quantities every rank agrees on (N, D, M, C, world, the budget), so all ranks derive
 the same schedule and issue the same collectives.  The reference has no counterpart (single process, one class at a time:

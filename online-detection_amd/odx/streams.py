@@ -4,7 +4,7 @@ A HIP stream is a software queue; the runtime multiplexes all streams of a proce
 `GPU_MAX_HW_QUEUES`), and work of two streams that landed on the same hardware queue runs in submission order: a
 latency-bound factorisation chain queues behind every kernel of a K_nM build that happens to share its queue.  Which streams
 share one depends on the order in which all streams of the process were first used — a Minibootstrap round measured 0.47 s or
-0.60 s on the same machine depending on how many streams the process had touched before.
+0.60 s on the same machine depending on how many streams the process had touched before (docs/HISTORY.md 7, round 4).
 
 `distinct(n)` picks side streams by MEASURING: a candidate is kept if a marker recorded on it completes while a busy kernel is
 still running on the current stream and on every stream kept so far.  At most (hardware queues - 1) streams can qualify; the

@@ -754,15 +754,15 @@ def test_default_route_dispatch_straddles_the_threshold():
     model.rows_min_positions = default
     g = torch.Generator().manual_seed(2)
     one, two = torch.randn(1, 3, 600, 800, generator=g).cuda(), torch.randn(2, 3, 600, 800, generator=g).cuda()
-    if default > 0:
-        assert 1900 < default <= 3800
-        assert not model._rows_path(one) and model._rows_path(two)
-        model.compute_dtype = torch.bfloat16
-        assert not model._rows16_path(one) and model._rows16_path(two)
-        model.compute_dtype = None
-    else:
-        assert model._rows_path(one) and model._rows_path(two)        # (threshold 0: one hand-written route at every size)
     with torch.no_grad():
+        if default > 0:
+            assert 1900 < default <= 3800
+            assert not model._rows_path(one) and model._rows_path(two)
+            model.compute_dtype = torch.bfloat16
+            assert not model._rows16_path(one) and model._rows16_path(two)
+            model.compute_dtype = None
+        else:
+            assert model._rows_path(one) and model._rows_path(two)        # (threshold 0: one hand-written route at every size)
         got = {}
         for name, thr in (("default", default), ("rows", 0), ("conv", 1 << 40)):
             model.rows_min_positions = thr

@@ -377,3 +377,49 @@ def test_labelling_kernels_equal_the_tensor_statements(G):
     fin = torch.isfinite(wantt[:, 2:])
     assert torch.equal(gott[:, :2], wantt[:, :2]) and torch.equal(torch.isfinite(gott[:, 2:]), fin)
     assert float((gott[:, 2:][fin] - wantt[:, 2:][fin]).abs().max()) <= 1e-6
+
+
+def _walk(fill, cb, per_batch, bs, k, n, phantom):
+    """The batch walk as the reference's loops state it, one class (box_head_getProposals.py:226-290 with phantom rows,
+    rpn_getProposals.py:283-331 without): returns (rows landed per batch, their source offsets, full batches passed)."""
+    B = len(fill)
+    take, lo, skipped, taken = [0] * B, [0] * B, 0, 0
+    for b in range(cb, B):
+        if fill[b] >= bs:
+            skipped += 1
+            continue
+        if phantom:
+            end = taken + min(per_batch, bs - fill[b], k - taken)
+            a, z = min(taken, n), min(end, n)
+        else:
+            end = taken + min(per_batch, bs - fill[b], k - taken, n - taken)
+            a, z = taken, end
+        take[b], lo[b] = z - a, a
+        taken = end
+        if taken == k:
+            break
+    return take, lo, skipped
+
+
+def test_fill_plan_equals_the_batch_walk_on_random_states():
+    """harvest.fill_plan (all classes of an image at once, array arithmetic) against the class-by-class batch walk it replaces,
+    on random fill states: full batches in the middle, classes at their last batch, fewer rows than asked for (phantom rows in
+    the detector's form, an exhausted walk in the on-line RPN's), per_batch 1 and larger than a batch's room."""
+    from odx.harvest import fill_plan
+    rng = np.random.default_rng(123)
+    for trial in range(400):
+        nc, B = int(rng.integers(1, 9)), int(rng.integers(1, 12))
+        bs = int(rng.integers(1, 40))
+        k = int(rng.integers(1, 60))
+        per_batch = -(-k // B) if rng.random() < 0.7 else int(rng.integers(1, k + 1))
+        fill = rng.integers(0, bs + 1, (nc, B))
+        fill[rng.random((nc, B)) < 0.3] = bs                                  # plenty of full batches
+        cb = rng.integers(0, B, nc)
+        n = np.where(rng.random(nc) < 0.3, rng.integers(0, k + 1, nc), k)       # some classes with fewer rows than k (0 included)
+        for phantom in (True, False):
+            take, lo, skipped = fill_plan(fill.astype(np.int64), cb.astype(np.int64), per_batch, bs, k, n.astype(np.int64), phantom)
+            for c in range(nc):
+                wt, wl, ws = _walk(fill[c].tolist(), int(cb[c]), per_batch, bs, k, int(n[c]), phantom)
+                assert take[c].tolist() == wt, (trial, phantom, c, take[c].tolist(), wt)
+                assert skipped[c] == ws, (trial, phantom, c)
+                assert all(lo[c][b] == wl[b] for b in range(B) if wt[b]), (trial, phantom, c)
