@@ -67,6 +67,11 @@ def parse():
     ap.add_argument("--precond-cus", type=int, default=0, help="confine the preconditioner chains (their stream and the library's "
                     "helper streams) to this many compute units, spread over the XCDs (0: the whole device; an experiment knob — "
                     "measured slower at 48..128 CUs: the confined chains starve behind the main stream's grids, docs/HISTORY.md 7)")
+    ap.add_argument("--precond-lookahead", type=int, default=1, help="chain groups in flight ahead of the group being fitted (one more "
+                    "factor block each)")
+    ap.add_argument("--precond-cus-full-only", action="store_true", help="with --precond-cus k: only the full-size chain groups are "
+                    "confined to k compute units (their f64 work then runs beside the HBM-bound passes); the ramp groups the first fits "
+                    "wait for keep the whole chip")
     ap.add_argument("--gauss-on-complement", action="store_true", help="with --precond-cus k: launch the K_nM builds and the scoring on a "
                     "stream confined to the other (all - k) compute units — chain and Gaussian workgroups then never share a CU (an "
                     "experiment: DESIGN.md section 9 has the sweep)")
@@ -281,7 +286,8 @@ def main():
     job = LockstepClassJob(be, X, N, M, lambda c: torch.where((row_ids % C) == c, 1.0, -1.0).to(torch.float64), cidx_dev,
                            args.sigma, args.lam, args.maxiter, opt, shard=shard, precond_batch=args.precond_batch,
                            precond_depth=args.precond_depth, precond_after_fit=args.precond_after_fit, precond_cus=args.precond_cus,
-                           batch=args.lockstep_batch, exchange=args.cg_exchange, gauss_on_complement=args.gauss_on_complement)
+                           batch=args.lockstep_batch, exchange=args.cg_exchange, gauss_on_complement=args.gauss_on_complement,
+                           precond_lookahead=args.precond_lookahead, precond_cus_full_only=args.precond_cus_full_only)
     G, ldk, scores = job.G, job.ldk, job.scores
     job_b, plan_gb = job.b, round(job.plan.total_bytes / 1e9, 1)
     kfmt = be.knm_format(n_loc, M)                 # storage of the K_nM shards ("u24" at the headline size, "f32" for small ones)
@@ -459,6 +465,7 @@ def main():
                        "N": N, "D": D, "M": M, "classes": C, "sigma": args.sigma, "lambda": args.lam,
                        "rows_per_gpu": n_loc, "preconditioners_per_batched_chain": G, "preconditioner_cus": args.precond_cus or "all",
                        "gaussians_on_the_complement": bool(args.gauss_on_complement and args.precond_cus),
+                       "preconditioner_lookahead_groups": args.precond_lookahead, "preconditioner_cus_full_groups_only": bool(args.precond_cus_full_only),
                        "lockstep_batch": job_b, "planned_GB_per_rank": plan_gb, "cg_exchange": args.cg_exchange,
                        # the one options table (odx/options.py): what this run's kernels and schedules were selected by
                        "options": odx.options.as_dict()},
@@ -475,10 +482,11 @@ def main():
                                "collectives_replaced_by_local_copies_warmup_included": {k: {"calls": v[0], "bytes": v[1]} for k, v in shard.calls.items()},
                                "note": "value = N / this rank's compute-only step time: what the %d-rank job would reach if every rank took "
                                        "this long and the collectives were free; unmeasured on hardware" % args.emulate_world}
-        if not args.no_cpu_baseline and world == 1 and not emulated:      # reported at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(args)
         if args.check:
             out["check"] = check_against_oracle(be, F, last, X, row_ids, args, C - 1)
+        want_cpu = not args.no_cpu_baseline and world == 1 and not emulated      # reported at N = 1 only
+        if want_cpu and (args.no_extras or world != 1 or emulated):
+            out["cpu_baseline"] = cpu_baseline(args)
         if not args.no_extras and world == 1 and not emulated:
             # the other halves of BASELINE configs 2 and 3 (RLS regressors, feature forward) and the reference-regime
             # minibootstrap: measured after and outside the timed headline region, with its buffers released first
@@ -501,6 +509,11 @@ def main():
                 out["extras_in_headline_process"] = {"error": "%s: %s" % (type(e).__name__, e)}
             be.release_workspaces()
             torch.cuda.empty_cache()
+            # (the CPU baseline BEHIND the in-process extras: its numpy run leaves a pool of host threads — one per core —
+            # spinning for a while, and that, not anything the headline job left on the GPU, is what made the latency-bound
+            # extras read 10-20 % slower in this process than in a fresh one: tools/after_headline_probe.py, round 6)
+            if want_cpu:
+                out["cpu_baseline"] = cpu_baseline(args)
             if args.extras == "inprocess":
                 from tools import bench_extras
                 out.update(bench_extras.collect(args))

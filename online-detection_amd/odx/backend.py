@@ -223,6 +223,20 @@ class HipBackend:
         self._masked_streams = getattr(self, "_masked_streams", []) + [(st, raw)]
         return st
 
+    def set_helper_cus(self, cus):
+        """The CU mask the library's internal helper streams are CREATED with from now on (first `cus` compute units; 0: the
+        whole device).  Streams that exist keep theirs (odx_set_side_stream_cu_mask)."""
+        cus = int(cus)
+        if cus <= 0:
+            hip.check(self.lib.odx_set_side_stream_cu_mask(None, 0), "odx_set_side_stream_cu_mask")
+            return
+        total = int(self.lib.odx_device_cus())
+        words = (total + 31) // 32
+        arr = (ctypes.c_uint32 * words)()
+        for b in range(max(8, min(cus, total))):
+            arr[b // 32] |= 1 << (b % 32)
+        hip.check(self.lib.odx_set_side_stream_cu_mask(arr, words), "odx_set_side_stream_cu_mask")
+
     def _meta_slot(self):
         """Two zeroed floats (scale, max |x| bits) for one matrix, cut from a pool that is zeroed once per 4096 matrices —
         a fill launch per matrix otherwise (a Minibootstrap round: ~250 of them).  A slot is handed out once; the slices

@@ -96,7 +96,7 @@ class LockstepClassJob:
 
     def __init__(self, be, X, n_total, M, labels, centre_idx, sigma, lam, maxiter=20, opt=None, shard=None,
                  precond_batch=0, precond_depth=2, precond_after_fit=False, classes=None, precond_cus=0, batch=0,
-                 hbm_bytes=None, exchange="lockstep", gauss_on_complement=False):
+                 hbm_bytes=None, exchange="lockstep", gauss_on_complement=False, precond_lookahead=1, precond_cus_full_only=False):
         """precond_batch: classes per rank and preconditioner chain (g; 0 = planned, 1 = one chain per class on `precond_depth`
         side streams); batch: classes per lock-step batch (b, a divisor of the world size; 0 = planned); hbm_bytes: the
         memory the plan may count on per rank (default: the device's, 288 GB without one).
@@ -105,7 +105,12 @@ class LockstepClassJob:
         classes one at a time, EVERY rank builds every class's preconditioner and runs every M-sized product, per CG iteration
         ONE all-reduce of the (M,) partial (solver.falkon_fit's replicated mode).  Same arithmetic per class either way."""
         # gauss_on_complement (with precond_cus = k > 0; an experiment, round-5 review item 1a): the K_nM builds and the scoring run
-        # on a stream confined to the OTHER total - k compute units, so that chain and Gaussian workgroups never share a CU
+        # on a stream confined to the OTHER total - k compute units, so that chain and Gaussian workgroups never share a CU.
+        # precond_lookahead = L: chain groups in flight ahead of the group being fitted (L + 1 factor blocks; 1 = round 2-5's
+        # schedule).  precond_cus = k > 0 confines the chains to k compute units; with precond_cus_full_only the ramp groups
+        # (fewer than g classes: the ones the first fits wait for) keep the whole chip and only the full-size groups — which have
+        # L groups' worth of fits to finish in — are confined: their f64 work then runs beside the HBM-bound passes, which lose
+        # little to it, instead of beside the MFMA-bound builds, which lose all of it.
         if exchange not in ("lockstep", "allreduce"):
             raise ValueError("LockstepClassJob: exchange must be 'lockstep' or 'allreduce', got %r" % (exchange,))
         self.exchange = exchange
@@ -129,7 +134,8 @@ class LockstepClassJob:
             self.N, D, self.M, self.C, self.world, batch=batch, chain=precond_batch,
             hbm_bytes=hbm_bytes if hbm_bytes is not None else (_plan.device_hbm_bytes(dev) if dev.type == "cuda" else _plan.HBM_BYTES_MI355X),
             knm_format=(be.knm_format if hasattr(be, "knm_format") else None),
-            knm_bytes=(be.knm_bytes if hasattr(be, "knm_bytes") else None), gauss=getattr(be, "gauss", "h2"))
+            knm_bytes=(be.knm_bytes if hasattr(be, "knm_bytes") else None), gauss=getattr(be, "gauss", "h2"),
+            lookahead=max(1, int(precond_lookahead)), chain_sides=2 if (precond_cus_full_only and precond_cus > 0) else 1)
         if not self.plan.feasible:
             raise MemoryError("LockstepClassJob: this job does not fit %d rank(s): %s" % (self.world, self.plan.summary()))
         self.b, self.G = self.plan.b, self.plan.g
@@ -142,7 +148,13 @@ class LockstepClassJob:
         self.ld_p = (self.M + 1) // 2 * 2
         self.nslot = self.depth + 1
         self.sides = [_Side(dev, be, precond_cus, index=k) for k in range(self.nslot)] if self.G == 1 else []
-        self.gside = _Side(dev, be, precond_cus) if (self.G > 1 or exchange == "allreduce") else None
+        self.lookahead = max(1, int(precond_lookahead))
+        self.precond_cus, self.full_only = int(precond_cus), bool(precond_cus_full_only and precond_cus > 0)
+        grouped = self.G > 1 or exchange == "allreduce"
+        # gside: the chains' side stream (confined when precond_cus > 0 and not full_only); cside: the confined stream of the
+        # full-size groups under full_only
+        self.gside = _Side(dev, be, 0 if self.full_only else precond_cus) if grouped else None
+        self.cside = _Side(dev, be, precond_cus, index=1) if (grouped and self.full_only) else None
         self._cplans = {}        # class -> the centre-assembly plan of gather_centres (world > 1)
         self.gauss_stream = (be.masked_stream(precond_cus, complement=True)
                              if gauss_on_complement and precond_cus > 0 and dev.type == "cuda" and hasattr(be, "masked_stream") else None)
@@ -152,10 +164,12 @@ class LockstepClassJob:
             # the two factor blocks and the chain's scratch at their final size now, not inside the first step that needs them
             # (a warm-up on a few classes runs smaller chains: the 22 GB scratch of a 6-class chain was first allocated in the
             # timed region)
-            while len(self.pgroup) < 2:
+            while len(self.pgroup) < self.lookahead + 1:
                 self.pgroup.append(torch.empty((self.G, 4, self.M, self.ld_p), dtype=torch.float64, device=dev))
-            with self.gside:
-                be._workspace("precond_group", be.lib.odx_falkon_precond_batched_workspace_bytes(self.M, D, self.G))
+            for side in (self.gside, self.cside):
+                if side is not None:
+                    with side:
+                        be._workspace("precond_group", be.lib.odx_falkon_precond_batched_workspace_bytes(self.M, D, self.G))
 
     def release(self):
         self.kbufs, self.pbuf, self.pgroup, self.scores = [], [], [], None
@@ -240,18 +254,24 @@ class LockstepClassJob:
         own = [(k, owners.index(self.rank)) for k, (_, owners) in enumerate(group) if self.rank in owners]
         Ps, ev = {}, None
         if own:
-            self.gside.after_current()    # the slot's last readers were issued, the centres exist
-            with self.gside:
+            confined = self.cside is not None and len(own) >= self.G        # (full_only: a full-size group)
+            side = self.cside if confined else self.gside
+            if self.precond_cus > 0 and hasattr(be, "set_helper_cus"):
+                # the library's helper streams of a chain are created — with the mask current at that moment — when a caller
+                # stream first needs them: confined for the confined stream's chains, the whole chip for the others
+                be.set_helper_cus(self.precond_cus if (confined or not self.full_only) else 0)
+            side.after_current()          # the slot's last readers were issued, the centres exist
+            with side:
                 with ph("precond"):
                     zf = [Zs_all[k][pos] for k, pos in own]
                     if hasattr(be, "precond_batched"):
-                        while len(self.pgroup) < 2:
+                        while len(self.pgroup) < self.lookahead + 1:
                             self.pgroup.append(torch.empty((self.G, 4, self.M, self.ld_p), dtype=torch.float64, device=dev))
                         plist = be.precond_batched(zf, self.sigma, self.lam, self.opt.pc_epsilon,
                                                    out=self.pgroup[slot][:len(own)], ws_key="precond_group")
                     else:                 # a backend without the batched chain (tests' oracle backend): one after the other
                         plist = [be.precond(z, self.sigma, self.lam, self.opt.pc_epsilon) for z in zf]
-                ev = self.gside.mark()
+                ev = side.mark()
             Ps = dict(zip((k for k, _ in own), plist))
             if infos is not None:
                 infos.extend(p.info for p in plist if hasattr(p, "info"))
@@ -329,14 +349,18 @@ class LockstepClassJob:
             groups = [[bi for r in grp for bi in range(r * self.R, min((r + 1) * self.R, len(sched)))]
                       for grp in precond_groups(n_rounds, self.G)]
             first_of = {grp[0]: gi for gi, grp in enumerate(groups)}
-            ready = dict(zip(groups[0], self._prepare_group([sched[bi] for bi in groups[0]], 0, ph, infos)))
+            L, nb = self.lookahead, self.lookahead + 1
+            ready = {}
+            for g0 in range(min(L, len(groups))):          # the first L groups are issued before the first fit
+                ready.update(zip(groups[g0], self._prepare_group([sched[bi] for bi in groups[g0]], g0 % nb, ph, infos)))
         else:
             ready = {bi: self._prepare(*sched[bi], bi % self.nslot, ph, infos) for bi in range(min(self.depth, len(sched)))}
         for bi, (batch, owners) in enumerate(sched):
             if self.G > 1:
                 gi = first_of.get(bi)
-                if gi is not None and gi + 1 < len(groups):          # one group ahead, on the side stream
-                    ready.update(zip(groups[gi + 1], self._prepare_group([sched[k] for k in groups[gi + 1]], (gi + 1) % 2, ph, infos)))
+                if gi is not None and gi + L < len(groups):          # L groups ahead, on the side stream(s); block (gi + L) % nb was
+                    # group gi - 1's: its fits are queued in front of this point
+                    ready.update(zip(groups[gi + L], self._prepare_group([sched[k] for k in groups[gi + L]], (gi + L) % nb, ph, infos)))
             elif not self.after_fit and bi + self.depth < len(sched):
                 ready[bi + self.depth] = self._prepare(*sched[bi + self.depth], (bi + self.depth) % self.nslot, ph, infos)
             Zs, P, ev = ready.pop(bi)

@@ -116,7 +116,7 @@ class JobPlan:
             self.world, self.b, self.g, self.knm_format, self.total_bytes / 1e9, self.budget_bytes / 1e9, gb)
 
 
-def _parts(N, D, M, C, world, b, g, fmt, gauss="h2", knm_bytes=None, rows_resident=True):
+def _parts(N, D, M, C, world, b, g, fmt, gauss="h2", knm_bytes=None, rows_resident=True, lookahead=1, chain_sides=1):
     n_loc = (int(N) + world - 1) // world
     kb = knm_bytes(n_loc, M) if knm_bytes is not None else knm_bytes_rule(n_loc, M, fmt)
     ldx = _round_up(D, 4)
@@ -127,11 +127,13 @@ def _parts(N, D, M, C, world, b, g, fmt, gauss="h2", knm_bytes=None, rows_reside
     parts["labels"] = 2 * b * n_loc * 8
     parts["scores"] = n_loc * C * 4
     parts["knm_shards"] = b * kb
-    parts["factors_two_groups"] = 2 * g * factor_bytes(M)
-    parts["chain_workspace"] = g * chain_workspace_bytes(M, D)
+    # (lookahead + 1 groups of factors: the one being fitted and the ones being built ahead of it; a chain workspace per side
+    # stream the chains run on)
+    parts["factors_two_groups"] = (lookahead + 1) * g * factor_bytes(M)
+    parts["chain_workspace"] = chain_sides * g * chain_workspace_bytes(M, D)
     # the centres (rows, packed split, norms) of every class of two chain groups: every rank builds the K_nM shard of
     # every class of a batch, so it holds all of a group's centres, not only those of the classes it owns
-    parts["centres_two_groups"] = 2 * g * world * M * (ldx * 4 + _round_up(D, 64) * 4 + 4)
+    parts["centres_two_groups"] = (lookahead + 1) * g * world * M * (ldx * 4 + _round_up(D, 64) * 4 + 4)
     parts["kernel_workspaces"] = (2 * n_loc * ((M + 511) // 512) * 8              # fused scoring: f64 partials per column group
                                   + ((n_loc + 255) // 256) * _round_up(M, 4) * 8   # right-hand side out of the build: one slab row per row block
                                   + 2 * 512 * _round_up(M, 4) * 8                  # pass slabs
@@ -141,7 +143,7 @@ def _parts(N, D, M, C, world, b, g, fmt, gauss="h2", knm_bytes=None, rows_reside
 
 
 def plan_lockstep(N, D, M, C, world, hbm_bytes=HBM_BYTES_MI355X, budget_fraction=BUDGET_FRACTION, storage="auto", gauss="h2",
-                  knm_format=None, knm_bytes=None, batch=0, chain=0, rows_resident=True):
+                  knm_format=None, knm_bytes=None, batch=0, chain=0, rows_resident=True, lookahead=1, chain_sides=1):
     """Choose (b, g) for C classes on N rows sharded over `world` ranks: the largest divisor b of `world` — then the largest
     g <= 6 — whose planned bytes per rank stay within budget_fraction x hbm_bytes.  `batch` / `chain` > 0 pin b / g (the plan
     then only reports whether they fit).  knm_format / knm_bytes: the backend's own rule and byte count (HipBackend), the
@@ -158,7 +160,7 @@ def plan_lockstep(N, D, M, C, world, hbm_bytes=HBM_BYTES_MI355X, budget_fraction
         n_rounds = max(1, ((C + b - 1) // b + world // b - 1) // (world // b))
         gs = [int(chain)] if chain else list(range(max(1, min(MAX_CHAIN_CLASSES, n_rounds)), 0, -1))
         for g in gs:
-            n_loc, parts = _parts(N, D, M, C, world, b, g, fmt, gauss, knm_bytes, rows_resident)
+            n_loc, parts = _parts(N, D, M, C, world, b, g, fmt, gauss, knm_bytes, rows_resident, lookahead, chain_sides)
             total = float(sum(parts.values()))
             last = JobPlan(world, b, g, n_loc, fmt, total <= budget, budget, total, parts)
             if last.feasible:

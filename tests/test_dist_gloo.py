@@ -234,7 +234,7 @@ def test_class_sharded_minibootstrap_equals_single_process(world, tmp_path):
             assert M == ref[c].M and sigma == 6.0
 
 
-def _job_worker(rank, world, port, N, D, M, C, ret, batch=0, chain=0, exchange="lockstep"):
+def _job_worker(rank, world, port, N, D, M, C, ret, batch=0, chain=0, exchange="lockstep", lookahead=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -251,7 +251,7 @@ def _job_worker(rank, world, port, N, D, M, C, ret, batch=0, chain=0, exchange="
         row_ids = torch.arange(lo, hi)
         job = LockstepClassJob(be, torch.from_numpy(X[lo:hi]), N, M, lambda c: torch.where((row_ids % C) == c, 1.0, -1.0).double(),
                                [torch.from_numpy(i) for i in cidx], 6.0, 1e-4, 20, shard=shard, batch=batch, precond_batch=chain,
-                               exchange=exchange)
+                               exchange=exchange, precond_lookahead=lookahead)
         F = be.features(job.X)
         alpha, _ = job.run(F)
         ret[rank] = {"scores": job.scores.numpy().copy(), "trace": list(job.trace), "G": job.G, "alpha_last": alpha.numpy().copy(),
@@ -310,6 +310,31 @@ def test_headline_control_flow_on_eight_ranks():
         want = fr.falkon_predict(Xd, Z, a, 6.0)[:, 0]
         assert np.abs(scores[:, c] - want).max() < 1e-6 * max(1.0, np.abs(want).max()), c
     assert (scores.argmax(1) == np.arange(N) % C).mean() > 0.9
+
+
+def test_chain_groups_several_ahead_of_the_fits():
+    """precond_lookahead = 3: the class-batched preconditioner chains of three groups are issued before the first fit and every
+    later group three groups ahead (four factor blocks in rotation) instead of one — what lets chains confined to a few compute
+    units keep pace with the fits (bench.py --precond-lookahead / --precond-cus-full-only).  Same fits: scores equal the
+    one-group-ahead schedule's bit for bit, and the recorded schedule shows the issue order."""
+    N, D, M, C, world = 1300, 16, 40, 26, 2
+    ret, ret1 = mp.Manager().dict(), mp.Manager().dict()
+    mp.spawn(_job_worker, args=(world, _free_port(), N, D, M, C, ret, 0, 0, "lockstep", 3), nprocs=world, join=True)
+    mp.spawn(_job_worker, args=(world, _free_port(), N, D, M, C, ret1), nprocs=world, join=True)
+    for r in range(world):
+        assert np.array_equal(ret[r]["scores"], ret1[r]["scores"])
+        kinds = [k for k, _ in ret[r]["trace"]]
+        # three groups before the loop and the fourth as the first group's fit is reached (one-group-ahead: precond, precond, fit)
+        assert kinds[:5] == ["precond", "precond", "precond", "precond", "fit"], kinds[:6]
+        assert [p for k, p in ret[r]["trace"] if k == "precond"] == [p for k, p in ret1[r]["trace"] if k == "precond"]   # same groups, same owners
+        assert [p for k, p in ret[r]["trace"] if k == "fit"] == [p for k, p in ret1[r]["trace"] if k == "fit"]
+        # every group is issued before the first fit of the group three behind it
+        t = ret[r]["trace"]
+        pos_pre = [i for i, (k, _) in enumerate(t) if k == "precond"]
+        first_fit_of_class = {c: i for i, (k, p) in reversed(list(enumerate(t))) if k == "fit" for c in p}
+        for gi, i in enumerate(pos_pre):
+            for c in t[i][1]:
+                assert i < first_fit_of_class[c]
 
 
 @pytest.mark.parametrize("world", [2, 3])
