@@ -147,7 +147,7 @@ class _Growing:
             nb[: self.n] = self.buf[: self.n]
             self.buf = nb
         if k:
-            self.buf[self.n:self.n + k] = rows.to(self.buf.device)
+            self.buf[self.n:self.n + k] = rows if rows.device == self.buf.device else rows.to(self.buf.device)
         at = self.n
         self.n += k
         if self.mark_every:
@@ -871,12 +871,19 @@ class MaskHarvester:
                 else:
                     p = torch.arange(cnt)
                 picks.setdefault((c, kind), []).append((i, p + start))
-        for (c, kind), lst in picks.items():
-            loc = torch.cat([p for _, p in lst])
-            obj = torch.cat([torch.full((len(p),), i, dtype=torch.int64) for i, p in lst])
-            idx = to_device(torch.stack((obj, loc)), dev)
-            sel = order[idx[0], idx[1]] + idx[0] * S2
-            (self._pos if kind == 0 else self._neg)[c].append(rows.index_select(0, sel), seg_lens=[len(p) for _, p in lst])
+        # ONE upload and ONE gather for all (class, kind) groups of the image (a cat + full + stack + upload + two gathers per
+        # group before): the picks are laid out group after group, every class buffer then receives its slice
+        groups = list(picks.items())
+        obj = np.concatenate([np.full(len(p), i, dtype=np.int64) for _, lst in groups for i, p in lst])
+        loc = torch.cat([p for _, lst in groups for _, p in lst])
+        idx = to_device(torch.stack((torch.from_numpy(obj), loc)), dev)
+        sel = order[idx[0], idx[1]] + idx[0] * S2
+        picked = rows.index_select(0, sel)
+        at = 0
+        for (c, kind), lst in groups:
+            k = sum(len(p) for _, p in lst)
+            (self._pos if kind == 0 else self._neg)[c].append(picked[at:at + k], seg_lens=[len(p) for _, p in lst])
+            at += k
 
     def finalize(self):
         """negatives, positives as tensors per class (extract_features_detector.py:273-278)."""
