@@ -121,6 +121,14 @@ class HipBackend:
         # with u24 as with f32 storage; bf16 is BASELINE config 2's throughput-only storage (alpha off by 1e-2..6e-1).
         self.knm_storage = opts.knm_storage
         _options.apply()                       # h2_tile / precond / chain_helpers -> libodx (odx_set_option)
+        # the process's side streams are picked NOW, while the process is fresh (odx/streams.py: which hardware queue a stream
+        # lands on depends on the streams the process has used before; picked behind a big job they landed worse — the
+        # Minibootstrap read 0.51 instead of 0.43 s, the harvest loop 4.5 instead of 3.6 ms per image; ~50 ms, once)
+        try:
+            from . import streams as _streams
+            _streams.of_default(3, self.device)
+        except Exception:          # noqa: BLE001 — a heuristic: never a reason not to start
+            pass
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):

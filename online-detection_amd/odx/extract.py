@@ -696,7 +696,13 @@ class GraphedCall:
                     return self.fn(*xs)               # more of them than are kept — a capture costs ~4 plain calls, stop paying it
                 self.captures[key] = self.captures.get(key, 0) + 1
                 cur = torch.cuda.current_stream()
-                gstream = torch.cuda.Stream()
+                # the graph's launch stream: the LAST of the process's measured side streams (odx/streams.py: on a hardware queue
+                # of its own, away from the chains' streams, which take the first ones) — a plain pool stream made here, behind
+                # whatever the process ran before, could share the caller's queue, and a group's forward then queues in front of
+                # the harvest's small kernels (4.5 instead of 3.6 ms per image behind the headline job)
+                from . import streams as _streams
+                own = _streams.of_default(3, x.device)
+                gstream = own[-1] if own and own[-1].cuda_stream != cur.cuda_stream else torch.cuda.Stream()
                 gstream.wait_stream(cur)
                 try:
                     entry = self._capture(xs, gstream)
@@ -1355,9 +1361,10 @@ class OnlineFeatureExtractor:
             and RoI head each once for the group; `graphed`: the group's group_begin, whose results are collected here); the
             per-image items come out in the group's order."""
             unp = [_unpack(smp) for smp in group]
-            images = torch.cat([u[0].to(dev) for u in unp], dim=0)
+            # (a graphed group's images were concatenated — and copied into the graph — by group_begin: not again here)
+            images = torch.cat([u[0].to(dev) for u in unp], dim=0) if graphed is None else None
             gts = [u[1].to(dev).float() for u in unp]
-            img_size = (images.shape[3], images.shape[2])
+            img_size = (unp[0][0].shape[3], unp[0][0].shape[2])
             items = [{"gt_boxes": gts[j], "gt_labels": list(unp[j][2]), "img_size": img_size} for j in range(len(group))]
             gts_host = None
             if hv_mask is not None and any(u[3] is not None and len(u[2]) for u in unp):
@@ -1522,7 +1529,9 @@ class OnlineFeatureExtractor:
             # threads — below, for networks without a graphed group forward — share the interpreter: with ~300 launches per
             # image to queue, the forward thread and the harvesting thread took turns and the loop was bound by their sum.)
             main = torch.cuda.current_stream()
-            fwd = torch.cuda.Stream()
+            from . import streams as _streams
+            own = _streams.of_default(3, dev)
+            fwd = own[-2] if len(own) >= 2 and own[-2].cuda_stream != main.cuda_stream else torch.cuda.Stream()
             fwd.wait_stream(main)
             # (the harvest's own kernels — hundreds of tiny launches with a host read every few of them — on a high-priority stream
             # of their own: measured, no gain: 5.4 against 5.2 ms per image)
@@ -1577,7 +1586,9 @@ class OnlineFeatureExtractor:
                             m.c4(ims)
                 torch.cuda.synchronize()
             main = torch.cuda.current_stream()
-            fwd = torch.cuda.Stream()
+            from . import streams as _streams
+            own = _streams.of_default(3, dev)
+            fwd = own[-2] if len(own) >= 2 and own[-2].cuda_stream != main.cuda_stream else torch.cuda.Stream()
             fwd.wait_stream(main)
             q = queue.Queue(maxsize=2 * max(1, int(self.trunk_batch)) + 2)      # two groups ahead: the next group's forward starts
             # while the current group's items are still being harvested

@@ -100,6 +100,18 @@ def distinct(n, device=None):
     return list(have[0][:n])
 
 
+def of_default(n, device=None):
+    """distinct(n) as seen from the device's DEFAULT stream, whatever stream the caller is on: the process-wide set of side
+    streams (HipBackend picks it when it is created, i.e. while the process is fresh — round 6: side streams first picked
+    BEHIND a big job landed on worse hardware queues, a Minibootstrap read 0.51 instead of 0.43 s and the harvest loop 4.5
+    instead of 3.6 ms per image; tools/after_headline_probe.py)."""
+    if not torch.cuda.is_available():
+        return []
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    with torch.cuda.stream(torch.cuda.default_stream(dev)):
+        return distinct(n, dev)
+
+
 def spread(streams, k):
     """k streams for round-robin use out of `streams` (repeated when there are fewer); [] when there are none."""
     return [streams[i % len(streams)] for i in range(k)] if streams else []

@@ -734,3 +734,28 @@ def test_default_mode_keeps_the_reference_order_of_draws(tmp_path, monkeypatch, 
         if a is not None:
             assert torch.equal(a.ny_points_, b.ny_points_) and torch.equal(a.alpha_, b.alpha_), c
             assert torch.equal(out["auto"][1][c]["neg"], out["loop"][1][c]["neg"]), c
+
+
+@pytest.mark.parametrize("n,D1", [(101, 37), (64, 2), (513, 130)])
+def test_rls_solve_on_a_general_design_matrix_odd_sizes(hip_backend, n, D1):
+    """RegionRefinerTrainer.solve on a matrix that is NOT f32 features + a column of ones (f64 rows that are not f32-exact, no
+    bias column): Gram, X'y, Cholesky + solves and predictions on the library's f64 kernels (odx_gemm_nt_f64, odx_rls_solve_f64)
+    — against the dense normal equations in numpy, at odd n and odd D1 (the f64 GEMM's even-stride padding; advisor, round 5),
+    with and without per-coordinate row subsets."""
+    from odx.rls import RegionRefinerTrainer
+    rng = np.random.default_rng(n * 1000 + D1)
+    X = rng.standard_normal((n, D1)) * 0.7 + 0.1 / 3.0                      # f64, not representable in f32
+    y = rng.standard_normal((n, 4)) * 0.3
+    lam = 0.5
+    tr = RegionRefinerTrainer({"CHOSEN_CLASSES": {}}, lam, False)
+    for indices in (None, [np.sort(rng.choice(n, size=max(D1, n // 2) if n > D1 else n, replace=False)) for _ in range(4)]):
+        out = quiet(tr.solve, torch.from_numpy(X).cuda(), torch.from_numpy(y).cuda(), lam,
+                    indices=None if indices is None else [torch.from_numpy(i) for i in indices])
+        for k in range(4):
+            I = np.arange(n) if indices is None else indices[k]
+            A = X[I].T @ X[I] + lam * np.eye(D1)
+            w = np.linalg.solve(A, X[I].T @ y[I, k])
+            got = out[str(k)]["weights"].double().cpu().numpy()
+            assert np.abs(got - w).max() < 2e-6 * max(1.0, np.abs(w).max()), (k, indices is None)        # (f32 hand-out of f64 weights)
+            loss = 0.5 * (X[I] @ w - y[I, k]) ** 2
+            assert np.abs(out[str(k)]["losses"].double().cpu().numpy() - loss).max() < 1e-5 * max(1.0, loss.max())

@@ -34,11 +34,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--classes", type=int, default=30)
     ap.add_argument("--timers", type=int, default=1, help="1: HIP-event timers around every kernel family, as bench.py hangs them")
+    ap.add_argument("--runs", type=int, default=1, help="times the job is run (bench.py: warm-up + steps); every run creates and "
+                    "releases the chains' helper streams")
+    ap.add_argument("--no-fresh", action="store_true", help="do not run the Minibootstrap in the fresh process first (bench.py does not)")
+    ap.add_argument("--prewarm-streams", type=int, default=0, help="pick this many measured-distinct side streams in the fresh process")
+    ap.add_argument("--keep-helpers", action="store_true", help="do not release the helper streams between the runs (only at the end)")
     args = ap.parse_args()
     be = odx.get_backend()
     dev = torch.device("cuda", 0)
-    mini("fresh process:")
-    mini("fresh process, again:")
+    if args.prewarm_streams:
+        print("side streams picked in the fresh process:", len(odx_streams.distinct(args.prewarm_streams)), flush=True)
+    if not args.no_fresh:
+        mini("fresh process:")
+        mini("fresh process, again:")
     N, D, M, C = 1_000_000, 1024, 10_000, args.classes
     X = bench.synth_rows(0, N, D, 30, 1237, dev)
     row_ids = torch.arange(0, N, device=dev)
@@ -47,10 +55,16 @@ def main():
     job = LockstepClassJob(be, X, N, M, lambda c: torch.where((row_ids % 30) == c, 1.0, -1.0).to(torch.float64), cidx, 15.0, 1e-5, 20,
                            SolverOptions(check_pivots=False))
     infos = []
-    t0 = time.perf_counter()
-    job.run(be.features(X), list(range(C)), phases=ph, infos=infos if ph is not None else None)
-    torch.cuda.synchronize()
-    print("headline job, %d classes: %.2f s" % (C, time.perf_counter() - t0), flush=True)
+    real_release = be.release_helper_streams
+    if args.keep_helpers:
+        be.release_helper_streams = lambda: None
+    for r in range(args.runs):
+        t0 = time.perf_counter()
+        job.run(be.features(X), list(range(C)), phases=ph, infos=infos if ph is not None else None)
+        torch.cuda.synchronize()
+        print("headline job, %d classes, run %d: %.2f s" % (C, r, time.perf_counter() - t0), flush=True)
+    be.release_helper_streams = real_release
+    be.release_helper_streams()
     job.release()
     job = X = row_ids = cidx = None
     be.release_workspaces()
