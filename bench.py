@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--precond-cus-full-only", action="store_true", help="with --precond-cus k: only the full-size chain groups are "
                     "confined to k compute units (their f64 work then runs beside the HBM-bound passes); the ramp groups the first fits "
                     "wait for keep the whole chip")
+    ap.add_argument("--main-priority", action="store_true", help="run the job's main stream (builds, passes, scoring, CG) on a HIGH-priority "
+                    "stream: the chains' kernels are then dispatched where the main stream has no workgroup waiting — beside the "
+                    "persistent passes, not beside the builds (an experiment; combine with --precond-lookahead 2)")
     ap.add_argument("--gauss-on-complement", action="store_true", help="with --precond-cus k: launch the K_nM builds and the scoring on a "
                     "stream confined to the other (all - k) compute units — chain and Gaussian workgroups then never share a CU (an "
                     "experiment: DESIGN.md section 9 has the sweep)")
@@ -292,8 +295,16 @@ def main():
     job_b, plan_gb = job.b, round(job.plan.total_bytes / 1e9, 1)
     kfmt = be.knm_format(n_loc, M)                 # storage of the K_nM shards ("u24" at the headline size, "f32" for small ones)
 
+    main_stream = torch.cuda.Stream(priority=-1) if args.main_priority else None
+
     def run_classes(classes, timed):
-        return job.run(F, classes, phases=ph if timed else None, infos=infos if timed else None)
+        if main_stream is None:
+            return job.run(F, classes, phases=ph if timed else None, infos=infos if timed else None)
+        main_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(main_stream):
+            r = job.run(F, classes, phases=ph if timed else None, infos=infos if timed else None)
+        torch.cuda.current_stream().wait_stream(main_stream)
+        return r
 
     def barrier():
         torch.cuda.synchronize()
@@ -465,7 +476,7 @@ def main():
                        "N": N, "D": D, "M": M, "classes": C, "sigma": args.sigma, "lambda": args.lam,
                        "rows_per_gpu": n_loc, "preconditioners_per_batched_chain": G, "preconditioner_cus": args.precond_cus or "all",
                        "gaussians_on_the_complement": bool(args.gauss_on_complement and args.precond_cus),
-                       "preconditioner_lookahead_groups": args.precond_lookahead, "preconditioner_cus_full_groups_only": bool(args.precond_cus_full_only),
+                       "main_stream_high_priority": bool(args.main_priority), "preconditioner_lookahead_groups": args.precond_lookahead, "preconditioner_cus_full_groups_only": bool(args.precond_cus_full_only),
                        "lockstep_batch": job_b, "planned_GB_per_rank": plan_gb, "cg_exchange": args.cg_exchange,
                        # the one options table (odx/options.py): what this run's kernels and schedules were selected by
                        "options": odx.options.as_dict()},

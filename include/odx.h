@@ -60,6 +60,13 @@ int odx_option_default(const char* name, int* value);
  * the helpers of a class-batched chain, idle but alive, slow every later small launch of the process (a one-image forward behind
  * the headline job: 4.7 -> 7.6 ms). */
 int odx_release_helper_streams(void);
+/* Two streams for the library to use as its helper streams (slot 0: the forked inverse, slot 1: the look-ahead updates) instead of
+ * creating its own; (NULL, NULL): it creates them again.  Why: the hardware queue a stream created inside the library lands on
+ * depends on how many streams the process has created before, and a helper that shares the main stream's queue serialises the
+ * chain's GEMMs behind every K_nM build; the Python host side measures which streams sit on queues of their own
+ * (odx/streams.py) and hands two of them in when it loads the library.  Handed-in streams are never destroyed by the library;
+ * chains confined by a CU mask (odx_set_side_stream_cu_mask) keep making masked helpers of their own. */
+int odx_set_helper_streams(odx_stream_t s0, odx_stream_t s1);
 /* CU-partitioned execution (diagnostic: tools/cu_split_probe.py measured it and the job does NOT use it).
  * odx_stream_create_cu_mask: a HIP stream whose kernels run only on the compute units whose
  * bit is set in `mask` (`words` 32-bit words, bit i = logical CU i; hipExtStreamCreateWithCUMask) — the HBM-bound CG passes

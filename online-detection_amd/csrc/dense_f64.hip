@@ -568,6 +568,7 @@ struct SideStream {
   hipStream_t stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
   int device = -1;
+  bool owned = true;           // made here (destroyed on release) — or handed in by the caller (odx_set_helper_streams)
 };
 
 // Internal helper streams, a pair per (host thread, device, calling stream): slot 0 forks the inverse of L_T inside the
@@ -577,6 +578,11 @@ struct SideStream {
 // CU mask the helper streams are created with (odx_set_side_stream_cu_mask: a factorisation chain confined to a part of
 // the chip takes its look-ahead and fork streams along); empty = the whole device.  Streams that exist keep their mask.
 static std::vector<uint32_t> g_side_mask;
+// Helper streams handed in by the host side (odx_set_helper_streams): which hardware queue a stream created HERE lands on depends
+// on how many streams the process has created before, and a look-ahead helper that shares the main stream's queue serialises
+// the chain's GEMMs behind every build (round 6: 6.83 instead of 6.68 s per headline step after three more streams had been
+// probed at start-up).  The host measures which streams sit on queues of their own (odx/streams.py) and gives two of them.
+static hipStream_t g_given_helper[2] = {nullptr, nullptr};
 
 // Helper streams pay where the chain is GEMM-bound (the headline's M = 1e4: the look-ahead update beside the next panel, the
 // inverse of L_T beside T T').  Below CHAIN_HELPER_MIN_M centres a chain is latency-bound and is run several at a time by its
@@ -611,7 +617,7 @@ static int release_side_streams(bool wait = true) {
       if (s.stream != nullptr) {
         // (without the wait: the runtime keeps a destroyed stream and its events until the work queued on them has completed)
         if (wait) ODX_CHECK_HIP(hipStreamSynchronize(s.stream));
-        ODX_CHECK_HIP(hipStreamDestroy(s.stream));
+        if (s.owned) ODX_CHECK_HIP(hipStreamDestroy(s.stream));
       }
       if (s.fork != nullptr) ODX_CHECK_HIP(hipEventDestroy(s.fork));
       if (s.join != nullptr) ODX_CHECK_HIP(hipEventDestroy(s.join));
@@ -652,7 +658,11 @@ static int side_stream(SideStream** out, int slot, hipStream_t caller, int64_t M
   }
   SideStream& s = e->ss[slot];
   if (s.stream == nullptr) {
-    if (!g_side_mask.empty()) {
+    s.owned = true;
+    if (g_given_helper[slot] != nullptr && g_side_mask.empty()) {
+      s.stream = g_given_helper[slot];
+      s.owned = false;
+    } else if (!g_side_mask.empty()) {
       ODX_CHECK_HIP(hipExtStreamCreateWithCUMask(&s.stream, (uint32_t)g_side_mask.size(), g_side_mask.data()));
     } else if (slot == 1) {
       // The look-ahead updates are bulk work that must not starve the latency-bound chain they overlap with: lowest
@@ -1238,6 +1248,12 @@ static int falkon_precond_batched_f64_impl(const float* const* Z, const int64_t*
 extern "C" int odx_set_side_stream_cu_mask(const uint32_t* mask, int words) {
   ODX_REQUIRE(words >= 0 && words <= 64 && (words == 0 || mask != nullptr), "odx_set_side_stream_cu_mask: bad argument");
   g_side_mask.assign(mask, mask + words);
+  return ODX_OK;
+}
+
+extern "C" int odx_set_helper_streams(odx_stream_t s0, odx_stream_t s1) {
+  g_given_helper[0] = reinterpret_cast<hipStream_t>(s0);
+  g_given_helper[1] = reinterpret_cast<hipStream_t>(s1);
   return ODX_OK;
 }
 

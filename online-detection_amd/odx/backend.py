@@ -124,9 +124,18 @@ class HipBackend:
         # the process's side streams are picked NOW, while the process is fresh (odx/streams.py: which hardware queue a stream
         # lands on depends on the streams the process has used before; picked behind a big job they landed worse — the
         # Minibootstrap read 0.51 instead of 0.43 s, the harvest loop 4.5 instead of 3.6 ms per image; ~50 ms, once)
+        # ... and two of them become the library's helper streams (odx_set_helper_streams: a helper the library creates by itself
+        # may land on the main stream's hardware queue, which serialises a chain's GEMMs behind every K_nM build)
+        self.helper_streams = []
         try:
             from . import streams as _streams
-            _streams.of_default(3, self.device)
+            own = _streams.of_default(3, self.device)
+            if len(own) >= 3:
+                self.helper_streams = own[1:3]
+                hip.check(self.lib.odx_set_helper_streams(ctypes.c_void_p(own[1].cuda_stream), ctypes.c_void_p(own[2].cuda_stream)),
+                          "odx_set_helper_streams")
+        except hip.OdxError:
+            raise
         except Exception:          # noqa: BLE001 — a heuristic: never a reason not to start
             pass
 

@@ -37,6 +37,7 @@ SIGNATURES = {
     "odx_get_option": (_i32, [ctypes.c_char_p, _vp]),
     "odx_option_default": (_i32, [ctypes.c_char_p, _vp]),
     "odx_release_helper_streams": (_i32, []),
+    "odx_set_helper_streams": (_i32, [_vp, _vp]),
     "odx_stream_create_cu_mask": (_i32, [_vp, _i32, _vp]),
     "odx_stream_destroy": (_i32, [_vp]),
     "odx_set_pass_cus": (_i32, [_i32]),
