@@ -458,7 +458,7 @@ print("RCCL-OK")
 
 
 @pytest.mark.parametrize("ranks,classes,rows,centres,storage,batch", [(2, 4, 80000, 4200, "u24", 0), (3, 4, 40000, 1024, "auto", 0),
-                                                                       (4, 7, 40000, 1024, "auto", 2)])
+                                                                       (4, 7, 40000, 1024, "auto", 2), (2, 4, 80000, 4200, "u24", -1)])
 def test_bench_starts_its_own_ranks_and_matches_the_oracle(ranks, classes, rows, centres, storage, batch):
     """`python bench.py --gpus 2` (the driver's form, no launcher around it): the parent starts the two ranks itself, the
     ranks shard the rows and run the lock-step fit with its per-iteration exchange (gloo here: both ranks share this
@@ -471,7 +471,10 @@ def test_bench_starts_its_own_ranks_and_matches_the_oracle(ranks, classes, rows,
     # preconditioner groups of different sizes per rank, identical collectives on all of them; 4 ranks, 7 classes, batches of 2)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "1",
                         "--single-device", "--dist-backend", "gloo", "--rows", str(rows), "--centres", str(centres), "--classes", str(classes),
-                        "--check", "--no-cpu-baseline", "--no-extras"] + (["--lockstep-batch", str(batch)] if batch else []),
+                        "--check", "--no-cpu-baseline", "--no-extras"] + (["--lockstep-batch", str(batch)] if batch > 0 else [])
+                       # batch = -1: the replicated one-all-reduce-per-iteration form (every rank builds every preconditioner,
+                       # folded two-vector iteration included) with the real kernels
+                       + (["--cg-exchange", "allreduce"] if batch < 0 else []),
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -485,7 +488,8 @@ def test_bench_starts_its_own_ranks_and_matches_the_oracle(ranks, classes, rows,
     assert out["check"]["alpha_rel_err_vs_oracle_fit"] < 1e-4
     # (4 ranks, lock-step batches of 2: the owners of consecutive batches rotate through the ranks — odx/plan.py — with the
     # real kernels and collectives under them)
-    assert out["config"]["lockstep_batch"] == (batch or ranks)
+    assert out["config"]["lockstep_batch"] == (1 if batch < 0 else (batch or ranks))
+    assert out["config"]["cg_exchange"] == ("allreduce" if batch < 0 else "lockstep")
     assert out["health"]["failed_choleskys"] == 0 and out["health"]["ranks_with_nonfinite_scores"] == 0
 
 
