@@ -1284,8 +1284,12 @@ class OnlineFeatureExtractor:
     `parts` selects what is harvested: any of "rpn", "detector", "mask"."""
 
     def __init__(self, model, num_classes, parts=("rpn", "detector"), det=None, rpn=None, mask=None, rank=0, world=1,
-                 pipeline=True, trunk_batch=8):
+                 pipeline=True, trunk_batch=8, num_images=None):
         self.model, self.C, self.parts, self.rank, self.world = model, num_classes, tuple(parts), rank, world
+        # num_images: the length of the WHOLE image stream when `train` is handed a part of it (the reference sizes its
+        # per-image quota of negatives from len(dataset), box_head_getProposals.py:67: ceil(BATCH_SIZE x ITERATIONS / images));
+        # default: the images train() is given
+        self.num_images = num_images
         self.pipeline = pipeline        # on a GPU: forward of the next image on a second thread / stream while this one is harvested
         # on a GPU: consecutive images of one size share ONE forward — trunk, proposal stage and RoI head each run once for the
         # group (forward_batch; 1 = one image per call).  With > 1 a harvested row depends, in its last bits, on the image's
@@ -1306,7 +1310,7 @@ class OnlineFeatureExtractor:
         samples = list(samples)[self.rank::self.world]
         m = self.model
         dev = next(m.parameters()).device
-        n = max(len(samples), 1)
+        n = max(len(samples) if self.num_images is None else int(self.num_images), 1)
         hv_det = DetectorHarvester(m.feat_dim, self.C, num_images=n, device=dev, **self.det_kw) if "detector" in self.parts else None
         hv_rpn = RPNHarvester(m.backbone.out_channels, m.cells.shape[0], num_images=n, device=dev, **self.rpn_kw) if "rpn" in self.parts else None
         hv_mask = MaskHarvester(m.mask_dim, self.C, device=dev, **self.mask_kw) if "mask" in self.parts else None
