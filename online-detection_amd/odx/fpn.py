@@ -351,6 +351,15 @@ class OnlineDetectionModelFPN(nn.Module):
         fused = hasattr(be, "rpn_topk_decode") and trunk[0].is_cuda and self.online_rpn is None
         sel_reg, sel_anc, sel_score, counts = [], [], [], []
         lvl_boxes = []
+        side = cur = None
+        if fused and not torch.cuda.is_current_stream_capturing():
+            # a level's selection kernel is ONE workgroup (a radix select + sort of the level's candidates: 50 .. 280 us on one of
+            # the chip's 256 CUs): on a side stream it runs under the NEXT level's head convolutions instead of between them — at
+            # one image per call the five selections were 0.53 of the forward's 4.8 ms (profiles/r06_summary.md)
+            from . import streams as _streams
+            own = _streams.distinct(1)
+            if own:
+                side, cur = own[0], torch.cuda.current_stream()
         for lvl, p in enumerate(trunk):
             p = p.contiguous()                   # (a level of the row-GEMM pyramid is a channels-last view: the library's route copies)
             with (contextlib.nullcontext() if p.dtype in (torch.bfloat16, torch.float16) else self._amp()):
@@ -364,7 +373,17 @@ class OnlineDetectionModelFPN(nn.Module):
             if fused and k <= 8192:
                 # a level's top-k, sorting, delta gather, decoding and clipping as ONE launch (odx_rpn_topk_decode_f32) instead of
                 # ~25 tensor operations: the five levels were 125 of this forward's launches
-                b, sc, _ = be.rpn_topk_decode(logits, deltas, self._anchors(lvl, H, W, logits.device), k, img_size, DELTA_CLAMP)
+                anchors = self._anchors(lvl, H, W, logits.device)
+                if side is not None:
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        b, sc, _ = be.rpn_topk_decode(logits, deltas, anchors, k, img_size, DELTA_CLAMP)
+                    for t_ in (logits, deltas):
+                        t_.record_stream(side)
+                    for t_ in (b, sc):
+                        t_.record_stream(cur)
+                else:
+                    b, sc, _ = be.rpn_topk_decode(logits, deltas, anchors, k, img_size, DELTA_CLAMP)
                 lvl_boxes.append(b[0])
                 sel_score.append(sc[0])
                 counts.append(k)
@@ -376,6 +395,8 @@ class OnlineDetectionModelFPN(nn.Module):
             sel_anc.append(self._anchors(lvl, H, W, reg.device)[idx])
             sel_score.append(score)
             counts.append(k)
+        if side is not None:
+            cur.wait_stream(side)
         if lvl_boxes and len(lvl_boxes) == len(counts):
             scores_cat, boxes_cat = torch.cat(sel_score), torch.cat(lvl_boxes)          # (already sigmoid, decoded, clipped)
         else:
