@@ -160,6 +160,12 @@ class LockstepClassJob:
                              if gauss_on_complement and precond_cus > 0 and dev.type == "cuda" and hasattr(be, "masked_stream") else None)
         self.pbuf, self.pgroup = [], []
         self.trace = []          # (kind, payload) records of the schedule this rank executed (tests read it)
+        if self.world > 1 and not getattr(self.shard, "emulated", False):
+            # who owns which centre row: host arithmetic on the job's inputs (like the memory plan), made for every class NOW —
+            # its one device-to-host read per class must not land inside a step
+            for idx in self.cidx[:self.C]:
+                if torch.is_tensor(idx):
+                    self._centre_plan(idx)
         if self.G > 1 and hasattr(be, "precond_batched") and hasattr(be, "lib") and dev.type == "cuda":
             # the two factor blocks and the chain's scratch at their final size now, not inside the first step that needs them
             # (a warm-up on a few classes runs smaller chains: the 22 GB scratch of a 6-class chain was first allocated in the

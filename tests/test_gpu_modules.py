@@ -449,6 +449,26 @@ assert torch.equal(sh.allreduce(Z.clone()), Z)
 v = torch.randn(M, dtype=torch.float64, device="cuda")
 assert torch.equal(sh.broadcast(v.clone(), src=0), v)
 assert sh.total(12345) == 12345
+# the centres' all-gather of equal-sized blocks (LockstepClassJob.gather_centres): (world, r, D) f32 from (r, D)
+blk = torch.randn((137, 1024), device="cuda")
+allb = torch.zeros((1, 137, 1024), device="cuda")
+sh.gather_blocks(blk, allb)
+assert torch.equal(allb[0], blk)
+# ... and through the job itself: gather_centres on a one-rank nccl group goes down the collective path
+import odx
+from odx.job import LockstepClassJob
+be = odx.get_backend()
+X = torch.randn((500, 64), device="cuda")
+idx = torch.tensor([499, 0, 0, 17, 250, 3], device="cuda")
+job = LockstepClassJob(be, X, 500, 6, lambda c: None, [idx], 6.0, 1e-4, 20, shard=sh)
+job.world = 1
+Zf = job.gather_centres(idx) if False else None          # (world == 1 short-cuts; exercise the plan + gather by hand)
+mine, cmax, slot, n_mine = job._centre_plan(idx)
+b2 = torch.zeros((cmax, 64), device="cuda")
+torch.index_select(X, 0, mine, out=b2[:n_mine])
+a2 = torch.empty((1, cmax, 64), device="cuda")
+sh.gather_blocks(b2, a2)
+assert torch.equal(a2.view(cmax, 64).index_select(0, slot), X[idx])
 torch.cuda.synchronize()
 dist.destroy_process_group()
 print("RCCL-OK")
